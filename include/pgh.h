@@ -1,0 +1,180 @@
+/*
+ * pgh.h -- C-ABI of the MI355X-native propagation engine for pygrank-style graph filters.
+ *
+ * This is the drop-in boundary underneath pygrank's backend-module interface
+ * (reference: pygrank/core/backend/specification.py:5-118, the 29 backend functions; loader
+ * pygrank/core/backend/__init__.py:40-84).  Every entry point below is what a Python (ctypes) backend
+ * module -- pygrank_amd/backend/hip.py, or a `pygrank/core/backend/hip.py` a maintainer adds upstream
+ *  -- binds.  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; pgh_last_error() gives the message
+ *     (the reference raises plain `Exception`, e.g. convergence.py:90 -- the Python side converts).
+ *   - vectors are dense f32 arrays resident in HBM, addressed through opaque handles; reductions
+ *     accumulate in f64 and return f64 scalars to the host (reference vectors are fp64 numpy arrays,
+ *     numpy.py:34-46; fp32 device precedent: pytorch.py:63-65,113-114).
+ *   - a graph handle stores CSR(M^T) (f32 values, int32 columns) because the propagation multiplies by
+ *     the transpose: conv(x, M) = x @ M = M^T x (numpy.py:64-65).
+ *   - all work is enqueued on one HIP stream per process (pgh_set_stream adopts an external one, e.g.
+ *     torch's current stream for the RCCL row-partitioned path).  Calls that return scalars synchronise.
+ */
+#ifndef PGH_H
+#define PGH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgh_vec_s*   pgh_vec_t;     /* dense f32 vector in HBM                                  */
+typedef struct pgh_mat_s*   pgh_mat_t;     /* dense row-major f32 [n, b] slab in HBM (multi-seed batch) */
+typedef struct pgh_graph_s* pgh_graph_t;   /* CSR(M^T) + merge-path tile table in HBM                  */
+typedef struct pgh_timer_s* pgh_timer_t;   /* pair of HIP events on the engine stream                  */
+
+/* ---------------------------------------------------------------- runtime ------------------------- */
+/* replaces backend_init(), specification.py:9-10 */
+int         pgh_init(int device_ordinal);
+int         pgh_shutdown(void);
+const char* pgh_last_error(void);
+/* "hip:gfx950" for the product library; the host test double under oracle/ reports "host-oracle". */
+const char* pgh_runtime_name(void);
+int         pgh_device_count(int* count);
+int         pgh_device_name(char* buf, int buflen);
+int         pgh_mem_info(int64_t* free_bytes, int64_t* total_bytes);
+int         pgh_set_stream(void* hip_stream);      /* NULL -> the engine's own stream */
+int         pgh_sync(void);
+
+int pgh_timer_create(pgh_timer_t* out);
+int pgh_timer_destroy(pgh_timer_t t);
+int pgh_timer_start(pgh_timer_t t);                /* hipEventRecord on the engine stream */
+int pgh_timer_stop(pgh_timer_t t);
+int pgh_timer_elapsed_ms(pgh_timer_t t, double* ms);   /* synchronises on the stop event */
+
+/* per-kernel HIP-event profiling of the propagation kernels (bench.py roofline leg) */
+enum { PGH_K_SPMV = 0, PGH_K_FIXUP = 1, PGH_K_RESIDUAL = 2, PGH_K_FINAL = 3, PGH_K_SPMM = 4, PGH_K_COUNT = 5 };
+int pgh_profile_enable(int on);
+int pgh_profile_reset(void);
+int pgh_profile_read(int kernel_id, int64_t* launches, double* total_ms);
+
+/* ---------------------------------------------------------------- vectors ------------------------- */
+/* to_array / repeat / copy / length, specification.py:70-95; numpy.py:34-46 */
+int     pgh_vec_alloc(int64_t n, pgh_vec_t* out);
+int     pgh_vec_wrap(void* device_ptr, int64_t n, pgh_vec_t* out);   /* non-owning view (torch buffer) */
+int     pgh_vec_free(pgh_vec_t v);
+int64_t pgh_vec_len(pgh_vec_t v);
+void*   pgh_vec_ptr(pgh_vec_t v);
+int     pgh_vec_h2d_f32(pgh_vec_t v, const float* host, int64_t n);
+int     pgh_vec_h2d_f64(pgh_vec_t v, const double* host, int64_t n);
+int     pgh_vec_d2h_f32(pgh_vec_t v, float* host, int64_t n);
+int     pgh_vec_d2h_f64(pgh_vec_t v, double* host, int64_t n);
+int     pgh_vec_fill(pgh_vec_t v, double value);                     /* repeat(), specification.py:86 */
+int     pgh_vec_copy(pgh_vec_t dst, pgh_vec_t src);                  /* copy(),   specification.py:66 */
+int     pgh_vec_get(pgh_vec_t v, int64_t i, double* out);            /* float(x[i]), signals.py:89-90 */
+int     pgh_vec_set(pgh_vec_t v, int64_t i, double value);           /* x[i] = v,    signals.py:92-96 */
+int     pgh_vec_scatter_set(pgh_vec_t v, const int64_t* idx, const double* val, int64_t count);
+
+/* elementwise operator protocol of the primitive type (signals.py:114-178) */
+enum { PGH_ADD = 0, PGH_SUB = 1, PGH_MUL = 2, PGH_DIV = 3, PGH_POW = 4, PGH_MAXOP = 5, PGH_MINOP = 6,
+       PGH_GT = 7, PGH_GE = 8, PGH_LT = 9, PGH_LE = 10, PGH_EQ = 11, PGH_NE = 12 };
+enum { PGH_ABS = 0, PGH_EXP = 1, PGH_LOG = 2, PGH_NEG = 3, PGH_SQRT = 4, PGH_SAFE_INV = 5 };
+int pgh_ewise_vv(int op, pgh_vec_t a, pgh_vec_t b, pgh_vec_t out);
+int pgh_ewise_vs(int op, pgh_vec_t a, double scalar, int scalar_on_left, pgh_vec_t out);
+int pgh_ewise_unary(int op, pgh_vec_t a, pgh_vec_t out);            /* abs/exp/log, specification.py:25-47 */
+int pgh_axpby(double a, pgh_vec_t x, double b, pgh_vec_t y, pgh_vec_t out);   /* out = a*x + b*y */
+/* filter_out(x, exclude) = x[exclude == 0], specification.py:113; out must hold len(x); count returned */
+int pgh_filter_out(pgh_vec_t x, pgh_vec_t exclude, pgh_vec_t out, int64_t* out_len);
+
+/* reductions: sum/min/max/mean/dot, specification.py:29-43,109; f64 accumulation */
+enum { PGH_SUM = 0, PGH_ABSSUM = 1, PGH_MAX = 2, PGH_MIN = 3 };
+int pgh_reduce(int kind, pgh_vec_t x, double* out);
+int pgh_dot(pgh_vec_t x, pgh_vec_t y, double* out);
+/* convergence residuals: Mabs / L1 / MaxDifference, measures/supervised.py:93-106,133-138 */
+enum { PGH_ERR_MABS = 0, PGH_ERR_L1 = 1, PGH_ERR_LINF = 2, PGH_ERR_ITERS = 3 };
+int pgh_residual(int kind, pgh_vec_t a, pgh_vec_t b, double* out);
+
+/* ---------------------------------------------------------------- dense [n, b] slabs -------------- */
+/* separate_cols / combine_cols, specification.py:17-22 (NodeRanking.propagate, signals.py:225-226) */
+int     pgh_mat_alloc(int64_t n, int32_t b, pgh_mat_t* out);
+int     pgh_mat_free(pgh_mat_t m);
+int     pgh_mat_shape(pgh_mat_t m, int64_t* n, int32_t* b);
+void*   pgh_mat_ptr(pgh_mat_t m);
+int     pgh_mat_h2d_f64(pgh_mat_t m, const double* host_row_major);
+int     pgh_mat_d2h_f64(pgh_mat_t m, double* host_row_major);
+int     pgh_mat_set_col(pgh_mat_t m, int32_t col, pgh_vec_t v);     /* combine_cols */
+int     pgh_mat_get_col(pgh_mat_t m, int32_t col, pgh_vec_t v);     /* separate_cols */
+
+/* ---------------------------------------------------------------- graph --------------------------- */
+/* scipy_sparse_to_backend(M), specification.py:70-71 (called at core/utils/preprocessing.py:144).
+ * Input: host CSR of the preprocessor's normalised matrix M (n_rows x n_cols, fp64 values, as scipy
+ * holds it).  The engine uploads it, computes degrees(M) (row sums, numpy.py:76-77), transposes on the
+ * device into CSR(M^T) and builds the merge-path tile table.  */
+enum { PGH_GRAPH_DEFAULT = 0 };
+int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                       const int32_t* indices, const double* data, int flags, pgh_graph_t* out);
+int pgh_graph_destroy(pgh_graph_t g);
+int pgh_graph_info(pgh_graph_t g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* device_bytes);
+/* degrees(M): row sums of the un-transposed M, specification.py:105; numpy.py:76-77 */
+int pgh_graph_degrees(pgh_graph_t g, pgh_vec_t out);
+/* download the stored CSR(M^T) (verification / CPU baseline hand-off) */
+int pgh_graph_download(pgh_graph_t g, int64_t* indptr_t, int32_t* indices_t, float* data_t);
+
+/* conv(signal, M) = M^T x, specification.py:97-98; numpy.py:64-65.  Pure: y is a different buffer. */
+int pgh_spmv(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y);
+
+/* ---------------------------------------------------------------- fused propagation steps --------- */
+/* PageRank._formula (adhoc.py:34-36): y = alpha * x_scale * (M^T x) + (1 - alpha) * p.
+ * x_scale carries the lazily applied L1 quotient of RecursiveGraphFilter._step
+ * (abstract_filters.py:133-134).  sum_y (nullable) receives sum(y) and synchronises. */
+int pgh_ppr_step(pgh_graph_t g, pgh_vec_t x, double x_scale, pgh_vec_t p, double alpha, pgh_vec_t y,
+                 double* sum_y);
+/* AbsorbingWalks._formula (adhoc.py:166-169): y = ((M^T x) * x_scale * deg + p * lam) / (lam + deg). */
+int pgh_absorb_step(pgh_graph_t g, pgh_vec_t x, double x_scale, pgh_vec_t p, pgh_vec_t deg, pgh_vec_t lam,
+                    pgh_vec_t y, double* sum_y);
+/* ClosedFormGraphFilter._step (abstract_filters.py:215-230,248-256), one polynomial term:
+ *   term_out = a * (M^T term) + b * term;  result += c * term_out;
+ *   delta = sum|result_new - result_old| (kind L1/MABS) or max|.| (LINF).
+ * (a, b) = (1, 0) Taylor; (2, -1) the reference's "chebyshev" recurrence for iteration > 2. */
+int pgh_poly_step(pgh_graph_t g, pgh_vec_t term, pgh_vec_t term_out, double a, double b, pgh_vec_t result,
+                  double c, int err_kind, double* delta);
+/* quotient + residual of one recursive step (abstract_filters.py:133-134 + convergence.py:96-101):
+ *   err = residual(kind, y * y_scale, x * x_scale) without materialising the scaled vectors. */
+int pgh_scaled_residual(int kind, pgh_vec_t y, double y_scale, pgh_vec_t x, double x_scale, double* err);
+
+/* ---------------------------------------------------------------- whole loops on the device ------- */
+/* GraphFilter.rank's hot loop (abstract_filters.py:58-62) with ConvergenceManager semantics
+ * (convergence.py:77-101) evaluated on the device: kernels of an iteration become no-ops once the
+ * convergence flag is set, so the host enqueues iterations in batches without a sync per iteration. */
+typedef struct {
+    double  alpha;          /* PageRank / AbsorbingWalks alpha                                   */
+    int32_t use_quotient;   /* RecursiveGraphFilter use_quotient (bool form)                      */
+    int32_t err_kind;       /* PGH_ERR_*; ITERS = stop at max_iters without raising               */
+    double  tol;            /* already max(tol, epsilon()) (convergence.py:101); tol=None -> 0    */
+    int32_t max_iters;
+    int32_t end_modulo;
+    double  out_scale;      /* preserve_norm factor applied to the final ranks (abstract_filters.py:63-64) */
+} pgh_loop_cfg;
+
+typedef struct {
+    int32_t iterations;     /* value of ConvergenceManager.iteration at loop exit                 */
+    int32_t converged;      /* 1 = tolerance met; 0 = max_iters reached (caller raises unless ITERS) */
+    int32_t spmv_count;     /* SpMV launches that contributed to the result                        */
+    int32_t reserved;
+    double  last_error;     /* residual of the last executed check                                */
+    double  loop_ms;        /* HIP-event time of the loop on the engine stream                    */
+} pgh_loop_result;
+
+/* ranks: in = starting vector (copy of p or warm_start), out = final ranks. */
+int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
+int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg,
+                   pgh_loop_result* res);
+/* closed-form run with host-computed coefficient schedule c_1..c_K (adhoc.py:83-84,113-116;
+ * low_pass.py:23-26): iteration it uses coeffs[it-1], 0 beyond K.  chebyshev != 0 selects the
+ * reference's recurrence (abstract_filters.py:216-224). */
+int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, int32_t chebyshev,
+                 pgh_vec_t result, const pgh_loop_cfg* cfg, pgh_loop_result* res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGH_H */

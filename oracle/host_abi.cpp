@@ -1,0 +1,580 @@
+// TEST INFRASTRUCTURE ONLY -- host restatement of the include/pgh.h C-ABI ("test double").
+//
+// Purpose: lets tests/ exercise the host-side Python of pygrank_amd (backend module, signals, filters,
+// convergence bookkeeping, the gloo row-partition path) in a container without a GPU, and gives the GPU
+// parity tests an independent f32-storage / f64-accumulate implementation of every entry point.  It is
+// never loaded by the product: pygrank_amd/_lib.py binds only csrc/libpgh_hip.so, and only
+// tests call _lib._install_test_double().  pgh_runtime_name() reports "host-oracle".
+//
+// Each function restates the reference semantics it stands for (citations: path:line under /root/reference):
+//   conv                      pygrank/core/backend/numpy.py:64-65        y = x @ M = M^T x
+//   degrees                   pygrank/core/backend/numpy.py:76-77        row sums of M
+//   PageRank step             pygrank/algorithms/filters/adhoc.py:34-36
+//   AbsorbingWalks step       pygrank/algorithms/filters/adhoc.py:166-169
+//   closed-form step          pygrank/algorithms/filters/abstract_filters.py:215-230,248-256
+//   L1 quotient               pygrank/algorithms/filters/abstract_filters.py:133-134
+//   stopping rule             pygrank/algorithms/convergence.py:77-101
+//   residuals                 pygrank/measures/supervised.py:93-106,133-138
+// Build: make -C oracle  (g++ -O2 -shared -fPIC) -> oracle/_build/libpgh_host_oracle.so
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "pgh.h"
+
+struct pgh_vec_s {
+    float* data;
+    int64_t n;
+    bool owns;
+};
+struct pgh_mat_s {
+    std::vector<float> data;
+    int64_t n;
+    int32_t b;
+};
+struct pgh_timer_s {
+    std::chrono::steady_clock::time_point a, b;
+};
+struct pgh_graph_s {
+    int64_t n_rows, n_cols, nnz;
+    std::vector<int64_t> rowptr;   // CSR of M^T
+    std::vector<int32_t> col;
+    std::vector<float> val;
+    std::vector<float> degrees;
+};
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+    g_err = m;
+    return 1;
+}
+#define CHECK(c, m) \
+    do {            \
+        if (!(c)) return fail(m); \
+    } while (0)
+
+extern "C" {
+
+int pgh_init(int) { return 0; }
+int pgh_shutdown(void) { return 0; }
+const char* pgh_last_error(void) { return g_err.c_str(); }
+const char* pgh_runtime_name(void) { return "host-oracle"; }
+int pgh_device_count(int* c) {
+    *c = 0;
+    return 0;
+}
+int pgh_device_name(char* buf, int len) {
+    snprintf(buf, len, "host-oracle (test double)");
+    return 0;
+}
+int pgh_mem_info(int64_t* f, int64_t* t) {
+    *f = *t = 0;
+    return 0;
+}
+int pgh_set_stream(void*) { return 0; }
+int pgh_sync(void) { return 0; }
+
+int pgh_timer_create(pgh_timer_t* out) {
+    *out = new pgh_timer_s();
+    return 0;
+}
+int pgh_timer_destroy(pgh_timer_t t) {
+    delete t;
+    return 0;
+}
+int pgh_timer_start(pgh_timer_t t) {
+    t->a = std::chrono::steady_clock::now();
+    return 0;
+}
+int pgh_timer_stop(pgh_timer_t t) {
+    t->b = std::chrono::steady_clock::now();
+    return 0;
+}
+int pgh_timer_elapsed_ms(pgh_timer_t t, double* ms) {
+    *ms = std::chrono::duration<double, std::milli>(t->b - t->a).count();
+    return 0;
+}
+int pgh_profile_enable(int) { return 0; }
+int pgh_profile_reset(void) { return 0; }
+int pgh_profile_read(int, int64_t* launches, double* ms) {
+    *launches = 0;
+    *ms = 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ vectors
+int pgh_vec_alloc(int64_t n, pgh_vec_t* out) {
+    CHECK(n >= 0, "pgh_vec_alloc: negative length");
+    pgh_vec_s* v = new pgh_vec_s();
+    v->data = new float[n > 0 ? n : 1]();
+    v->n = n;
+    v->owns = true;
+    *out = v;
+    return 0;
+}
+int pgh_vec_wrap(void* p, int64_t n, pgh_vec_t* out) {
+    pgh_vec_s* v = new pgh_vec_s();
+    v->data = (float*)p;
+    v->n = n;
+    v->owns = false;
+    *out = v;
+    return 0;
+}
+int pgh_vec_free(pgh_vec_t v) {
+    if (!v) return 0;
+    if (v->owns) delete[] v->data;
+    delete v;
+    return 0;
+}
+int64_t pgh_vec_len(pgh_vec_t v) { return v ? v->n : -1; }
+void* pgh_vec_ptr(pgh_vec_t v) { return v ? v->data : nullptr; }
+int pgh_vec_h2d_f32(pgh_vec_t v, const float* h, int64_t n) {
+    CHECK(v && n == v->n, "pgh_vec_h2d_f32: length mismatch");
+    std::copy(h, h + n, v->data);
+    return 0;
+}
+int pgh_vec_h2d_f64(pgh_vec_t v, const double* h, int64_t n) {
+    CHECK(v && n == v->n, "pgh_vec_h2d_f64: length mismatch");
+    for (int64_t i = 0; i < n; ++i) v->data[i] = (float)h[i];
+    return 0;
+}
+int pgh_vec_d2h_f32(pgh_vec_t v, float* h, int64_t n) {
+    CHECK(v && n == v->n, "pgh_vec_d2h_f32: length mismatch");
+    std::copy(v->data, v->data + n, h);
+    return 0;
+}
+int pgh_vec_d2h_f64(pgh_vec_t v, double* h, int64_t n) {
+    CHECK(v && n == v->n, "pgh_vec_d2h_f64: length mismatch");
+    for (int64_t i = 0; i < n; ++i) h[i] = (double)v->data[i];
+    return 0;
+}
+int pgh_vec_fill(pgh_vec_t v, double value) {
+    std::fill(v->data, v->data + v->n, (float)value);
+    return 0;
+}
+int pgh_vec_copy(pgh_vec_t d, pgh_vec_t s) {
+    CHECK(d && s && d->n == s->n, "pgh_vec_copy: length mismatch");
+    std::copy(s->data, s->data + s->n, d->data);
+    return 0;
+}
+int pgh_vec_get(pgh_vec_t v, int64_t i, double* out) {
+    CHECK(v && i >= 0 && i < v->n, "pgh_vec_get: index out of range");
+    *out = v->data[i];
+    return 0;
+}
+int pgh_vec_set(pgh_vec_t v, int64_t i, double value) {
+    CHECK(v && i >= 0 && i < v->n, "pgh_vec_set: index out of range");
+    v->data[i] = (float)value;
+    return 0;
+}
+int pgh_vec_scatter_set(pgh_vec_t v, const int64_t* idx, const double* val, int64_t count) {
+    for (int64_t k = 0; k < count; ++k) {
+        CHECK(idx[k] >= 0 && idx[k] < v->n, "pgh_vec_scatter_set: index out of range");
+        v->data[idx[k]] = (float)val[k];
+    }
+    return 0;
+}
+
+static float bin(int op, float a, float b) {
+    switch (op) {
+        case PGH_ADD: return a + b;
+        case PGH_SUB: return a - b;
+        case PGH_MUL: return a * b;
+        case PGH_DIV: return a / b;
+        case PGH_POW: return std::pow(a, b);
+        case PGH_MAXOP: return std::fmax(a, b);
+        case PGH_MINOP: return std::fmin(a, b);
+        case PGH_GT: return a > b;
+        case PGH_GE: return a >= b;
+        case PGH_LT: return a < b;
+        case PGH_LE: return a <= b;
+        case PGH_EQ: return a == b;
+        default: return a != b;
+    }
+}
+int pgh_ewise_vv(int op, pgh_vec_t a, pgh_vec_t b, pgh_vec_t out) {
+    CHECK(a && b && out && a->n == b->n && a->n == out->n, "pgh_ewise_vv: length mismatch");
+    CHECK(op >= 0 && op <= PGH_NE, "unknown binary operator");
+    for (int64_t i = 0; i < a->n; ++i) out->data[i] = bin(op, a->data[i], b->data[i]);
+    return 0;
+}
+int pgh_ewise_vs(int op, pgh_vec_t a, double s, int left, pgh_vec_t out) {
+    CHECK(a && out && a->n == out->n, "pgh_ewise_vs: length mismatch");
+    CHECK(op >= 0 && op <= PGH_NE, "unknown binary operator");
+    const float f = (float)s;
+    for (int64_t i = 0; i < a->n; ++i) out->data[i] = left ? bin(op, f, a->data[i]) : bin(op, a->data[i], f);
+    return 0;
+}
+int pgh_ewise_unary(int op, pgh_vec_t a, pgh_vec_t out) {
+    CHECK(a && out && a->n == out->n, "pgh_ewise_unary: length mismatch");
+    for (int64_t i = 0; i < a->n; ++i) {
+        const float x = a->data[i];
+        float r;
+        switch (op) {
+            case PGH_ABS: r = std::fabs(x); break;
+            case PGH_EXP: r = std::exp(x); break;
+            case PGH_LOG: r = std::log(x); break;
+            case PGH_NEG: r = -x; break;
+            case PGH_SQRT: r = std::sqrt(x); break;
+            case PGH_SAFE_INV: r = x != 0.f ? 1.f / x : 0.f; break;
+            default: return fail("unknown unary operator");
+        }
+        out->data[i] = r;
+    }
+    return 0;
+}
+int pgh_axpby(double a, pgh_vec_t x, double b, pgh_vec_t y, pgh_vec_t out) {
+    CHECK(x && y && out && x->n == y->n && x->n == out->n, "pgh_axpby: length mismatch");
+    for (int64_t i = 0; i < x->n; ++i) out->data[i] = (float)a * x->data[i] + (float)b * y->data[i];
+    return 0;
+}
+int pgh_filter_out(pgh_vec_t x, pgh_vec_t ex, pgh_vec_t out, int64_t* out_len) {
+    CHECK(x && ex && out && x->n == ex->n && out->n >= x->n, "pgh_filter_out: length mismatch");
+    int64_t k = 0;
+    for (int64_t i = 0; i < x->n; ++i)
+        if (ex->data[i] == 0.f) out->data[k++] = x->data[i];
+    *out_len = k;
+    return 0;
+}
+int pgh_reduce(int kind, pgh_vec_t x, double* out) {
+    CHECK(x && out, "pgh_reduce: null argument");
+    if (x->n == 0) {
+        CHECK(kind == PGH_SUM || kind == PGH_ABSSUM, "pgh_reduce: max/min of an empty vector");
+        *out = 0;
+        return 0;
+    }
+    double acc = kind == PGH_MAX ? -INFINITY : (kind == PGH_MIN ? INFINITY : 0.0);
+    for (int64_t i = 0; i < x->n; ++i) {
+        const double v = x->data[i];
+        if (kind == PGH_SUM) acc += v;
+        else if (kind == PGH_ABSSUM) acc += std::fabs(v);
+        else if (kind == PGH_MAX) acc = std::fmax(acc, v);
+        else if (kind == PGH_MIN) acc = std::fmin(acc, v);
+        else return fail("pgh_reduce: unknown kind");
+    }
+    *out = acc;
+    return 0;
+}
+int pgh_dot(pgh_vec_t x, pgh_vec_t y, double* out) {
+    CHECK(x && y && x->n == y->n, "pgh_dot: length mismatch");
+    double acc = 0;
+    for (int64_t i = 0; i < x->n; ++i) acc += (double)x->data[i] * (double)y->data[i];
+    *out = acc;
+    return 0;
+}
+static double scaled_res(int kind, const float* y, double ys, const float* x, double xs, int64_t n) {
+    double acc = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double d = std::fabs((double)y[i] * ys - (double)x[i] * xs);
+        acc = (kind == PGH_ERR_LINF) ? std::fmax(acc, d) : acc + d;
+    }
+    if (kind == PGH_ERR_MABS && n > 0) acc /= (double)n;
+    return acc;
+}
+int pgh_scaled_residual(int kind, pgh_vec_t y, double ys, pgh_vec_t x, double xs, double* err) {
+    CHECK(y && x && x->n == y->n, "pgh_scaled_residual: length mismatch");
+    CHECK(kind == PGH_ERR_MABS || kind == PGH_ERR_L1 || kind == PGH_ERR_LINF, "pgh_scaled_residual: unknown kind");
+    *err = scaled_res(kind, y->data, ys, x->data, xs, x->n);
+    return 0;
+}
+int pgh_residual(int kind, pgh_vec_t a, pgh_vec_t b, double* out) { return pgh_scaled_residual(kind, a, 1, b, 1, out); }
+
+// ------------------------------------------------------------------------------------------ slabs
+int pgh_mat_alloc(int64_t n, int32_t b, pgh_mat_t* out) {
+    CHECK(n >= 0 && b >= 1, "pgh_mat_alloc: bad shape");
+    pgh_mat_s* m = new pgh_mat_s();
+    m->n = n;
+    m->b = b;
+    m->data.assign((size_t)n * b, 0.f);
+    *out = m;
+    return 0;
+}
+int pgh_mat_free(pgh_mat_t m) {
+    delete m;
+    return 0;
+}
+int pgh_mat_shape(pgh_mat_t m, int64_t* n, int32_t* b) {
+    *n = m->n;
+    *b = m->b;
+    return 0;
+}
+void* pgh_mat_ptr(pgh_mat_t m) { return m ? m->data.data() : nullptr; }
+int pgh_mat_h2d_f64(pgh_mat_t m, const double* h) {
+    for (size_t i = 0; i < m->data.size(); ++i) m->data[i] = (float)h[i];
+    return 0;
+}
+int pgh_mat_d2h_f64(pgh_mat_t m, double* h) {
+    for (size_t i = 0; i < m->data.size(); ++i) h[i] = m->data[i];
+    return 0;
+}
+int pgh_mat_set_col(pgh_mat_t m, int32_t c, pgh_vec_t v) {
+    CHECK(m && v && v->n == m->n && c >= 0 && c < m->b, "pgh_mat_set_col: shape mismatch");
+    for (int64_t i = 0; i < m->n; ++i) m->data[i * m->b + c] = v->data[i];
+    return 0;
+}
+int pgh_mat_get_col(pgh_mat_t m, int32_t c, pgh_vec_t v) {
+    CHECK(m && v && v->n == m->n && c >= 0 && c < m->b, "pgh_mat_get_col: shape mismatch");
+    for (int64_t i = 0; i < m->n; ++i) v->data[i] = m->data[i * m->b + c];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ graph
+int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                       const double* data, int, pgh_graph_t* out) {
+    CHECK(indptr && indptr[0] == 0 && indptr[n_rows] == nnz, "pgh_graph_from_csr: indptr does not match nnz");
+    pgh_graph_s* g = new pgh_graph_s();
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = nnz;
+    g->degrees.assign(n_rows, 0.f);
+    g->rowptr.assign(n_cols + 1, 0);
+    g->col.resize(nnz);
+    g->val.resize(nnz);
+    for (int64_t r = 0; r < n_rows; ++r) {                      // numpy.py:76-77
+        double acc = 0;
+        for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k) acc += data[k];
+        g->degrees[r] = (float)acc;
+    }
+    for (int64_t k = 0; k < nnz; ++k) {
+        if (indices[k] < 0 || indices[k] >= n_cols) {
+            delete g;
+            return fail("pgh_graph_from_csr: column index out of range");
+        }
+        g->rowptr[indices[k] + 1]++;
+    }
+    for (int64_t c = 0; c < n_cols; ++c) g->rowptr[c + 1] += g->rowptr[c];
+    std::vector<int64_t> cursor(g->rowptr.begin(), g->rowptr.end() - 1);
+    for (int64_t r = 0; r < n_rows; ++r)                         // stable: rows ascending inside every M^T row
+        for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k) {
+            const int64_t pos = cursor[indices[k]]++;
+            g->col[pos] = (int32_t)r;
+            g->val[pos] = (float)data[k];
+        }
+    *out = g;
+    return 0;
+}
+int pgh_graph_destroy(pgh_graph_t g) {
+    delete g;
+    return 0;
+}
+int pgh_graph_info(pgh_graph_t g, int64_t* a, int64_t* b, int64_t* c, int64_t* d) {
+    if (a) *a = g->n_rows;
+    if (b) *b = g->n_cols;
+    if (c) *c = g->nnz;
+    if (d) *d = 0;
+    return 0;
+}
+int pgh_graph_degrees(pgh_graph_t g, pgh_vec_t out) {
+    CHECK(g && out && out->n == g->n_rows, "pgh_graph_degrees: length mismatch");
+    std::copy(g->degrees.begin(), g->degrees.end(), out->data);
+    return 0;
+}
+int pgh_graph_download(pgh_graph_t g, int64_t* ip, int32_t* idx, float* d) {
+    std::copy(g->rowptr.begin(), g->rowptr.end(), ip);
+    if (idx) std::copy(g->col.begin(), g->col.end(), idx);
+    if (d) std::copy(g->val.begin(), g->val.end(), d);
+    return 0;
+}
+
+// row sum of M^T x in f64 from f32 products (mirrors the kernel: f32 multiply, f64 accumulate, f32 store)
+static inline float row_dot(const pgh_graph_s* g, const float* x, int64_t row) {
+    double acc = 0;
+    for (int64_t k = g->rowptr[row]; k < g->rowptr[row + 1]; ++k) acc += (double)(g->val[k] * x[g->col[k]]);
+    return (float)acc;
+}
+static int check_gv(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y, const char* who) {
+    CHECK(g && x && y, std::string(who) + ": null argument");
+    CHECK(x->n == g->n_rows, std::string(who) + ": input length must equal the number of rows of M");
+    CHECK(y->n == g->n_cols, std::string(who) + ": output length must equal the number of columns of M");
+    CHECK(x->data != y->data, std::string(who) + ": conv must be pure (output aliases input)");
+    return 0;
+}
+int pgh_spmv(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y) {
+    if (check_gv(g, x, y, "pgh_spmv")) return 1;
+    for (int64_t r = 0; r < g->n_cols; ++r) y->data[r] = row_dot(g, x->data, r);
+    return 0;
+}
+
+static double ppr_step(const pgh_graph_s* g, const float* x, double xs, const float* p, double alpha, float* y) {
+    const float a = (float)(alpha * xs), b = (float)(1.0 - alpha);
+    double sum = 0;
+    for (int64_t r = 0; r < g->n_cols; ++r) {
+        const float v = a * row_dot(g, x, r) + b * p[r];        // adhoc.py:36
+        y[r] = v;
+        sum += v;
+    }
+    return sum;
+}
+static double absorb_step(const pgh_graph_s* g, const float* x, double xs, const float* p, const float* deg,
+                          const float* lam, float* y) {
+    const float a = (float)xs;
+    double sum = 0;
+    for (int64_t r = 0; r < g->n_cols; ++r) {
+        const float v = (a * row_dot(g, x, r) * deg[r] + p[r] * lam[r]) / (lam[r] + deg[r]);   // adhoc.py:167-168
+        y[r] = v;
+        sum += v;
+    }
+    return sum;
+}
+int pgh_ppr_step(pgh_graph_t g, pgh_vec_t x, double xs, pgh_vec_t p, double alpha, pgh_vec_t y, double* sum_y) {
+    if (check_gv(g, x, y, "pgh_ppr_step")) return 1;
+    CHECK(p && p->n == g->n_cols, "pgh_ppr_step: personalization length mismatch");
+    const double s = ppr_step(g, x->data, xs, p->data, alpha, y->data);
+    if (sum_y) *sum_y = s;
+    return 0;
+}
+int pgh_absorb_step(pgh_graph_t g, pgh_vec_t x, double xs, pgh_vec_t p, pgh_vec_t deg, pgh_vec_t lam, pgh_vec_t y,
+                    double* sum_y) {
+    if (check_gv(g, x, y, "pgh_absorb_step")) return 1;
+    CHECK(p && deg && lam && p->n == g->n_cols && deg->n == g->n_cols && lam->n == g->n_cols,
+          "pgh_absorb_step: vector length mismatch");
+    const double s = absorb_step(g, x->data, xs, p->data, deg->data, lam->data, y->data);
+    if (sum_y) *sum_y = s;
+    return 0;
+}
+static double poly_step(const pgh_graph_s* g, const float* term, float* term_out, double a, double b, float* result,
+                        double c, int linf) {
+    double delta = 0;
+    for (int64_t r = 0; r < g->n_cols; ++r) {
+        float t = (float)a * row_dot(g, term, r);
+        if (b != 0.0) t += (float)b * term[r];
+        term_out[r] = t;
+        const float r_old = result[r], r_new = r_old + (float)c * t;
+        result[r] = r_new;
+        const double d = std::fabs((double)r_new - (double)r_old);
+        delta = linf ? std::fmax(delta, d) : delta + d;
+    }
+    return delta;
+}
+int pgh_poly_step(pgh_graph_t g, pgh_vec_t term, pgh_vec_t term_out, double a, double b, pgh_vec_t result, double c,
+                  int err_kind, double* delta) {
+    if (check_gv(g, term, term_out, "pgh_poly_step")) return 1;
+    CHECK(result && result->n == g->n_cols, "pgh_poly_step: result length mismatch");
+    CHECK(b == 0.0 || term->n == g->n_cols, "pgh_poly_step: b != 0 needs a square matrix");
+    double d = poly_step(g, term->data, term_out->data, a, b, result->data, c, err_kind == PGH_ERR_LINF);
+    if (err_kind == PGH_ERR_MABS && g->n_cols > 0) d /= (double)g->n_cols;
+    if (delta) *delta = d;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ loops
+// Direct restatement of GraphFilter.rank's loop (abstract_filters.py:58-62) with ConvergenceManager
+// (convergence.py:77-101): has_converged runs BEFORE every step and increments `iteration` first.
+extern "C++" {
+struct Conv {
+    const pgh_loop_cfg* cfg;
+    int iteration = 0;
+    bool have_last = false;
+    bool converged = false;
+    double last_err = 0;
+    // returns true when the loop must stop; err_fn evaluates the residual between the last two iterates
+    template <class F>
+    bool has_converged(F err_fn) {
+        ++iteration;
+        if (iteration >= cfg->max_iters) return true;                      // caller raises unless ITERS
+        bool done = false;
+        if (have_last && cfg->err_kind != PGH_ERR_ITERS && iteration % cfg->end_modulo == 0) {
+            last_err = err_fn();
+            done = last_err <= cfg->tol;
+            converged = done;
+        }
+        have_last = true;
+        return done;
+    }
+};
+
+template <class StepFn>
+static int recursive_run(pgh_graph_t g, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res, StepFn step) {
+    CHECK(g->n_rows == g->n_cols, "recursive filters need a square matrix");
+    CHECK(ranks && ranks->n == g->n_cols, "ranks length mismatch");
+    CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
+    const int64_t n = g->n_cols;
+    std::vector<float> cur(ranks->data, ranks->data + n), prev(n), next(n);
+    double cur_scale = 1.0, prev_scale = 1.0;
+    Conv cm{cfg};
+    int steps = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!cm.has_converged([&] { return scaled_res(cfg->err_kind, cur.data(), cur_scale, prev.data(), prev_scale, n); })) {
+        const double s = step(cur.data(), cur_scale, next.data());
+        prev.swap(cur);
+        prev_scale = cur_scale;
+        cur.swap(next);
+        cur_scale = cfg->use_quotient ? (s != 0.0 ? 1.0 / s : 0.0) : 1.0;   // abstract_filters.py:133-134
+        ++steps;
+    }
+    const float f = (float)(cur_scale * cfg->out_scale);                     // abstract_filters.py:63-64
+    for (int64_t i = 0; i < n; ++i) ranks->data[i] = cur[i] * f;
+    memset(res, 0, sizeof(*res));
+    res->iterations = cm.iteration;
+    res->converged = cm.converged ? 1 : 0;
+    res->spmv_count = steps;
+    res->last_error = cm.last_err;
+    res->loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+}  // extern "C++"
+
+int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    CHECK(g && p && ranks && cfg && res, "pgh_ppr_run: null argument");
+    CHECK(p->n == g->n_cols, "pgh_ppr_run: personalization length mismatch");
+    return recursive_run(g, ranks, cfg, res, [&](const float* x, double xs, float* y) {
+        return ppr_step(g, x, xs, p->data, cfg->alpha, y);
+    });
+}
+int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg,
+                   pgh_loop_result* res) {
+    CHECK(g && p && lam && ranks && cfg && res, "pgh_absorb_run: null argument");
+    CHECK(p->n == g->n_cols && lam->n == g->n_cols, "pgh_absorb_run: vector length mismatch");
+    return recursive_run(g, ranks, cfg, res, [&](const float* x, double xs, float* y) {
+        return absorb_step(g, x, xs, p->data, g->degrees.data(), lam->data, y);
+    });
+}
+
+int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, int32_t chebyshev,
+                 pgh_vec_t result, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    CHECK(g && p && result && cfg && res, "pgh_poly_run: null argument");
+    const int64_t n = g->n_cols;
+    CHECK(g->n_rows == n && p->n == n && result->n == n, "pgh_poly_run: shape mismatch");
+    CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
+    auto coeff = [&](int it) { return (it >= 1 && it <= num_coeffs) ? coeffs[it - 1] : 0.0; };
+    // reference order (abstract_filters.py:248-256): accumulate the current term, THEN advance the power.
+    std::vector<float> resv(n, 0.f), prev_res(n, 0.f), term(p->data, p->data + n), prev_term, tmp(n);
+    Conv cm{cfg};
+    int spmv = 0;
+    const int linf = cfg->err_kind == PGH_ERR_LINF;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!cm.has_converged([&] { return scaled_res(cfg->err_kind, resv.data(), 1.0, prev_res.data(), 1.0, n); })) {
+        const int it = cm.iteration;
+        const double c = coeff(it);
+        prev_res = resv;
+        if (chebyshev) {                                                     // abstract_filters.py:216-224
+            if (it == 2) prev_term = term;
+            if (it > 2) {
+                for (int64_t i = 0; i < n; ++i) term[i] = 2.f * term[i] - prev_term[i];
+                prev_term = term;
+            }
+        }
+        for (int64_t i = 0; i < n; ++i) resv[i] = resv[i] + (float)c * term[i];
+        for (int64_t r = 0; r < n; ++r) tmp[r] = row_dot(g, term.data(), r);  // abstract_filters.py:256
+        term.swap(tmp);
+        ++spmv;
+        (void)linf;
+    }
+    const float f = (float)cfg->out_scale;
+    for (int64_t i = 0; i < n; ++i) result->data[i] = resv[i] * f;
+    memset(res, 0, sizeof(*res));
+    res->iterations = cm.iteration;
+    res->converged = cm.converged ? 1 : 0;
+    res->spmv_count = spmv;
+    res->last_error = cm.last_err;
+    res->loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+}  // extern "C"

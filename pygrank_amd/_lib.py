@@ -1,0 +1,181 @@
+"""ctypes binding of the C-ABI declared in include/pgh.h.
+
+The product binds exactly one library: ``pygrank_amd/csrc/libpgh_hip.so`` (hand-written HIP for gfx950).
+There is NO CPU fallback: if the library is missing, or no MI355X is visible when the engine is first
+used, an exception is raised.  ``_install_test_double`` exists only so that tests/ can exercise the host-side
+Python (signals, filters, convergence bookkeeping, the gloo row-partition path) against a host restatement
+of the same ABI that lives under oracle/ -- the product never calls it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpgh_hip.so")
+
+c_vec = C.c_void_p
+c_mat = C.c_void_p
+c_graph = C.c_void_p
+c_timer = C.c_void_p
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+
+
+class LoopCfg(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("use_quotient", C.c_int32), ("err_kind", C.c_int32), ("tol", C.c_double),
+                ("max_iters", C.c_int32), ("end_modulo", C.c_int32), ("out_scale", C.c_double)]
+
+
+class LoopResult(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("spmv_count", C.c_int32),
+                ("reserved", C.c_int32), ("last_error", C.c_double), ("loop_ms", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/pgh.h declares
+SIGNATURES = {
+    "pgh_init": (C.c_int, [C.c_int]),
+    "pgh_shutdown": (C.c_int, []),
+    "pgh_last_error": (C.c_char_p, []),
+    "pgh_runtime_name": (C.c_char_p, []),
+    "pgh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pgh_device_name": (C.c_int, [C.c_char_p, C.c_int]),
+    "pgh_mem_info": (C.c_int, [c_i64p, c_i64p]),
+    "pgh_set_stream": (C.c_int, [C.c_void_p]),
+    "pgh_sync": (C.c_int, []),
+    "pgh_timer_create": (C.c_int, [C.POINTER(c_timer)]),
+    "pgh_timer_destroy": (C.c_int, [c_timer]),
+    "pgh_timer_start": (C.c_int, [c_timer]),
+    "pgh_timer_stop": (C.c_int, [c_timer]),
+    "pgh_timer_elapsed_ms": (C.c_int, [c_timer, c_f64p]),
+    "pgh_profile_enable": (C.c_int, [C.c_int]),
+    "pgh_profile_reset": (C.c_int, []),
+    "pgh_profile_read": (C.c_int, [C.c_int, c_i64p, c_f64p]),
+    "pgh_vec_alloc": (C.c_int, [C.c_int64, C.POINTER(c_vec)]),
+    "pgh_vec_wrap": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(c_vec)]),
+    "pgh_vec_free": (C.c_int, [c_vec]),
+    "pgh_vec_len": (C.c_int64, [c_vec]),
+    "pgh_vec_ptr": (C.c_void_p, [c_vec]),
+    "pgh_vec_h2d_f32": (C.c_int, [c_vec, C.c_void_p, C.c_int64]),
+    "pgh_vec_h2d_f64": (C.c_int, [c_vec, C.c_void_p, C.c_int64]),
+    "pgh_vec_d2h_f32": (C.c_int, [c_vec, C.c_void_p, C.c_int64]),
+    "pgh_vec_d2h_f64": (C.c_int, [c_vec, C.c_void_p, C.c_int64]),
+    "pgh_vec_fill": (C.c_int, [c_vec, C.c_double]),
+    "pgh_vec_copy": (C.c_int, [c_vec, c_vec]),
+    "pgh_vec_get": (C.c_int, [c_vec, C.c_int64, c_f64p]),
+    "pgh_vec_set": (C.c_int, [c_vec, C.c_int64, C.c_double]),
+    "pgh_vec_scatter_set": (C.c_int, [c_vec, C.c_void_p, C.c_void_p, C.c_int64]),
+    "pgh_ewise_vv": (C.c_int, [C.c_int, c_vec, c_vec, c_vec]),
+    "pgh_ewise_vs": (C.c_int, [C.c_int, c_vec, C.c_double, C.c_int, c_vec]),
+    "pgh_ewise_unary": (C.c_int, [C.c_int, c_vec, c_vec]),
+    "pgh_axpby": (C.c_int, [C.c_double, c_vec, C.c_double, c_vec, c_vec]),
+    "pgh_filter_out": (C.c_int, [c_vec, c_vec, c_vec, c_i64p]),
+    "pgh_reduce": (C.c_int, [C.c_int, c_vec, c_f64p]),
+    "pgh_dot": (C.c_int, [c_vec, c_vec, c_f64p]),
+    "pgh_residual": (C.c_int, [C.c_int, c_vec, c_vec, c_f64p]),
+    "pgh_mat_alloc": (C.c_int, [C.c_int64, C.c_int32, C.POINTER(c_mat)]),
+    "pgh_mat_free": (C.c_int, [c_mat]),
+    "pgh_mat_shape": (C.c_int, [c_mat, c_i64p, c_i32p]),
+    "pgh_mat_ptr": (C.c_void_p, [c_mat]),
+    "pgh_mat_h2d_f64": (C.c_int, [c_mat, C.c_void_p]),
+    "pgh_mat_d2h_f64": (C.c_int, [c_mat, C.c_void_p]),
+    "pgh_mat_set_col": (C.c_int, [c_mat, C.c_int32, c_vec]),
+    "pgh_mat_get_col": (C.c_int, [c_mat, C.c_int32, c_vec]),
+    "pgh_graph_from_csr": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.POINTER(c_graph)]),
+    "pgh_graph_destroy": (C.c_int, [c_graph]),
+    "pgh_graph_info": (C.c_int, [c_graph, c_i64p, c_i64p, c_i64p, c_i64p]),
+    "pgh_graph_degrees": (C.c_int, [c_graph, c_vec]),
+    "pgh_graph_download": (C.c_int, [c_graph, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgh_spmv": (C.c_int, [c_graph, c_vec, c_vec]),
+    "pgh_ppr_step": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, C.c_double, c_vec, c_f64p]),
+    "pgh_absorb_step": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, c_vec, c_vec, c_vec, c_f64p]),
+    "pgh_poly_step": (C.c_int, [c_graph, c_vec, c_vec, C.c_double, C.c_double, c_vec, C.c_double, C.c_int, c_f64p]),
+    "pgh_scaled_residual": (C.c_int, [C.c_int, c_vec, C.c_double, c_vec, C.c_double, c_f64p]),
+    "pgh_ppr_run": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
+    "pgh_absorb_run": (C.c_int, [c_graph, c_vec, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
+    "pgh_poly_run": (C.c_int, [c_graph, c_vec, C.c_void_p, C.c_int32, C.c_int32, c_vec, C.POINTER(LoopCfg),
+                               C.POINTER(LoopResult)]),
+}
+
+# enum values of include/pgh.h
+ADD, SUB, MUL, DIV, POW, MAXOP, MINOP, GT, GE, LT, LE, EQ, NE = range(13)
+ABS, EXP, LOG, NEG, SQRT, SAFE_INV = range(6)
+SUM, ABSSUM, MAX, MIN = range(4)
+ERR_MABS, ERR_L1, ERR_LINF, ERR_ITERS = range(4)
+K_SPMV, K_FIXUP, K_RESIDUAL, K_FINAL, K_SPMM = range(5)
+
+_lib = None
+_is_test_double = False
+_initialised = False
+
+
+class EngineError(Exception):
+    """Raised for every non-zero status of the C-ABI (the reference raises plain Exception)."""
+
+
+def _bind(cdll):
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(cdll, name)      # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return cdll
+
+
+def load_library(path=None):
+    """dlopen + bind without touching the GPU (used by the build check and the symbol test)."""
+    path = LIB_PATH if path is None else path
+    if not os.path.exists(path):
+        raise EngineError(
+            f"MI355X engine library not found at {path}: build it with `make -C pygrank_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    return _bind(C.CDLL(path))
+
+
+def lib():
+    """The bound engine library; loads the HIP build on first use."""
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib
+
+
+def _install_test_double(cdll):
+    """TESTS ONLY: route the binding to a host restatement of the ABI (oracle/host_abi.c)."""
+    global _lib, _is_test_double, _initialised
+    _lib = _bind(cdll)
+    _is_test_double = True
+    _initialised = False
+
+
+def _remove_test_double():
+    global _lib, _is_test_double, _initialised
+    _lib = None
+    _is_test_double = False
+    _initialised = False
+
+
+def check(status):
+    if status != 0:
+        msg = lib().pgh_last_error()
+        raise EngineError(msg.decode("utf-8", "replace") if msg else f"engine call failed with status {status}")
+
+
+def ensure_init(device=None):
+    """backend_init(): selects the GPU (LOCAL_RANK when launched by torch.distributed.run) and fails loudly
+    when none is visible."""
+    global _initialised
+    if _initialised:
+        return
+    L = lib()
+    name = L.pgh_runtime_name().decode()
+    if not _is_test_double and not name.startswith("hip:"):
+        raise EngineError(f"refusing to run the product path on runtime '{name}'")
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    check(L.pgh_init(int(device)))
+    _initialised = True
+
+
+def runtime_name():
+    return lib().pgh_runtime_name().decode()

@@ -1,0 +1,150 @@
+// Internal definitions shared by the engine's translation units (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "pgh.h"
+
+namespace pgh {
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const std::string& msg);
+int  fail(const std::string& msg);
+
+#define PGH_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            return ::pgh::fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                               ":" + std::to_string(__LINE__) + ")");                              \
+        }                                                                                          \
+    } while (0)
+
+#define PGH_CHECK(cond, msg)                 \
+    do {                                     \
+        if (!(cond)) return ::pgh::fail(msg); \
+    } while (0)
+
+#define PGH_TRY(expr)            \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// ---------------------------------------------------------------- runtime state
+struct Runtime {
+    bool        initialised = false;
+    int         device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;        // the stream every kernel is launched on
+    int         num_cus = 256;
+    // scratch for reductions: device partials + pinned host mirror for scalar results
+    double*     d_partials = nullptr;    // [kMaxPartials * 2]
+    double*     d_scalars = nullptr;     // [kNumScalars]
+    double*     h_scalars = nullptr;     // pinned
+    // profiling
+    bool        profiling = false;
+    hipEvent_t  ev_a = nullptr, ev_b = nullptr;
+    int64_t     prof_count[PGH_K_COUNT] = {0};
+    double      prof_ms[PGH_K_COUNT] = {0};
+};
+Runtime& rt();
+int ensure_init();
+
+constexpr int kMaxPartials = 4096;   // upper bound on workgroups contributing block partials
+constexpr int kNumScalars = 64;
+
+// RAII-less helper: time one launch with events when profiling is on.
+struct ProfScope {
+    int id;
+    bool on;
+    explicit ProfScope(int kernel_id);
+    ~ProfScope();
+};
+
+}  // namespace pgh
+
+// ---------------------------------------------------------------- handle types
+struct pgh_vec_s {
+    float*  data = nullptr;
+    int64_t n = 0;
+    bool    owns = true;
+};
+
+struct pgh_mat_s {
+    float*  data = nullptr;
+    int64_t n = 0;
+    int32_t b = 0;
+};
+
+struct pgh_timer_s {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+struct pgh_graph_s {
+    int64_t n_rows = 0;      // rows of M   (= columns of the stored M^T)
+    int64_t n_cols = 0;      // columns of M (= rows of the stored M^T = length of conv output)
+    int64_t nnz = 0;
+    // CSR of M^T
+    int32_t* rowptr = nullptr;   // [n_cols + 1]
+    int32_t* col = nullptr;      // [nnz]  (row index of M)
+    float*   val = nullptr;      // [nnz]
+    float*   degrees = nullptr;  // [n_rows] row sums of M
+    // merge-path tile table: start coordinate (row, nnz) of every tile, plus the end sentinel
+    int32_t  items_per_tile = 0;
+    int32_t  num_tiles = 0;
+    int2*    tile_coord = nullptr;   // [num_tiles + 1]
+    int32_t* chain_first = nullptr;  // [num_tiles] first tile of the carry chain ending in tile t, or -1
+    // per-tile carries of rows that span tiles (f64)
+    double*  tail_carry = nullptr;   // [num_tiles]
+    double*  head_partial = nullptr; // [num_tiles]
+    int64_t  device_bytes = 0;
+};
+
+// ---------------------------------------------------------------- device helpers
+namespace pgh {
+
+__device__ __forceinline__ double wave_reduce_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// Block reduction for blockDim.x == 256 (4 wavefronts).  kind: 0 sum, 1 max, 2 min.  Result valid in thread 0.
+template <int KIND>
+__device__ __forceinline__ double block_reduce_256(double v, double* s_scratch /* >= 4 doubles */) {
+    if (KIND == 0) v = wave_reduce_sum(v);
+    if (KIND == 1) v = wave_reduce_max(v);
+    if (KIND == 2) v = wave_reduce_min(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_scratch[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = s_scratch[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            if (KIND == 0) r += s_scratch[w];
+            if (KIND == 1) r = fmax(r, s_scratch[w]);
+            if (KIND == 2) r = fmin(r, s_scratch[w]);
+        }
+        v = r;
+    }
+    return v;
+}
+
+}  // namespace pgh

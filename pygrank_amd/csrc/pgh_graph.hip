@@ -1,0 +1,307 @@
+// Graph upload: host CSR(M) -> device CSR(M^T) + degrees(M) + merge-path tile table.
+//
+// Reference counterpart: scipy_sparse_to_backend(M) (pygrank/core/backend/specification.py:70-71), called once
+// per (graph, preprocessor) at pygrank/core/utils/preprocessing.py:144; the fp32 device engines of the
+// reference also store the transpose (pytorch.py:63-65, torch_sparse.py:72-76).  degrees(M) = row sums of the
+// un-transposed matrix (numpy.py:76-77).
+//
+// The transposition is a device radix sort of (column << 32 | row) keys (rocPRIM via hipCUB -- a one-time
+// format conversion, not part of the per-iteration hot path), so the stored rows of M^T come out with their
+// column indices ascending and the result is deterministic.
+#include "pgh_common.h"
+
+#include <hipcub/hipcub.hpp>
+
+using namespace pgh;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kItemsPerTile = 256 * 7;     // must match kIPT in pgh_spmv.hip
+
+inline int blocks_for(int64_t n, int cap_mult = 16) {
+    int64_t b = (n + kBlock - 1) / kBlock;
+    const int64_t cap = (int64_t)rt().num_cus * cap_mult;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// row sums of M in f64 (one wavefront per row keeps hub rows parallel) -> f32 degrees
+__global__ void k_row_sums(const int64_t* __restrict__ indptr, const double* __restrict__ data, int64_t n_rows,
+                           float* __restrict__ deg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_rows; r += nwaves) {
+        const int64_t b = indptr[r], e = indptr[r + 1];
+        double acc = 0.0;
+        for (int64_t k = b + lane; k < e; k += 64) acc += data[k];
+        acc = wave_reduce_sum(acc);
+        if (lane == 0) deg[r] = (float)acc;
+    }
+}
+
+// expand CSR(M) into sort keys (col << 32 | row) and f32 values
+__global__ void k_make_keys(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                            const double* __restrict__ data, int64_t n_rows, uint64_t* __restrict__ keys,
+                            float* __restrict__ vals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_rows; r += nwaves) {
+        const int64_t b = indptr[r], e = indptr[r + 1];
+        for (int64_t k = b + lane; k < e; k += 64) {
+            keys[k] = ((uint64_t)(uint32_t)indices[k] << 32) | (uint64_t)(uint32_t)r;
+            vals[k] = (float)data[k];
+        }
+    }
+}
+
+// sorted keys -> col array of M^T (= row of M) and rowptr of M^T (boundaries of the high word)
+__global__ void k_split_keys(const uint64_t* __restrict__ keys, int64_t nnz, int64_t n_cols, int32_t* __restrict__ colT,
+                             int32_t* __restrict__ rowptrT) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += stride) {
+        const uint64_t key = keys[k];
+        const int64_t c = (int64_t)(key >> 32);
+        colT[k] = (int32_t)(key & 0xffffffffu);
+        const int64_t prev = (k == 0) ? -1 : (int64_t)(keys[k - 1] >> 32);
+        for (int64_t r = prev + 1; r <= c; ++r) rowptrT[r] = (int32_t)k;     // rows (prev, c] start at k
+        if (k == nnz - 1)
+            for (int64_t r = c + 1; r <= n_cols; ++r) rowptrT[r] = (int32_t)nnz;
+    }
+}
+
+__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// merge-path start coordinate of every tile: diagonal d = tile * items; the A list are the row-end
+// offsets rowptr[1..n], the B list the nnz indices (Merrill & Garland merge-based SpMV)
+__global__ void k_tile_coords(const int32_t* __restrict__ rowptr, int n, int nnz, int items, int num_tiles,
+                              int2* __restrict__ coord) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= num_tiles; t += gridDim.x * blockDim.x) {
+        const int64_t total = (int64_t)n + nnz;
+        int64_t d = (int64_t)t * items;
+        if (d > total) d = total;
+        int64_t lo = d - nnz > 0 ? d - nnz : 0;
+        int64_t hi = d < n ? d : n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)rowptr[mid + 1] <= d - mid - 1) lo = mid + 1; else hi = mid;
+        }
+        coord[t] = make_int2((int)lo, (int)(d - lo));
+    }
+}
+
+// chain_first[t]: tile t's first row began in an earlier tile and ends inside t -> index of the first tile
+// whose tail carry belongs to that row; -1 otherwise
+__global__ void k_chain_first(const int32_t* __restrict__ rowptr, const int2* __restrict__ coord, int n, int num_tiles,
+                              int32_t* __restrict__ chain_first) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < num_tiles; t += gridDim.x * blockDim.x) {
+        const int row0 = coord[t].x, z0 = coord[t].y;
+        int first = -1;
+        if (row0 < n && rowptr[row0] < z0 && coord[t + 1].x > row0) {
+            int s = t - 1;
+            while (s > 0 && coord[s].x == row0) --s;     // tile s-1 also ends inside row0 when tile s starts in it
+            // now coord[s].x != row0 (tile s started before row0 and ends in it) or s == 0
+            first = s;
+        }
+        chain_first[t] = first;
+    }
+}
+
+__global__ void k_flags_from_exclude(const float* __restrict__ ex, int64_t n, char* __restrict__ flags) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        flags[i] = ex[i] == 0.f ? 1 : 0;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t count) {
+        PGH_HIP(hipMalloc(&p, sizeof(T) * (count > 0 ? count : 1)));
+        return 0;
+    }
+};
+
+}  // namespace
+
+namespace pgh {
+
+// Builds tile table + carry buffers for a graph whose CSR(M^T) arrays are already on the device.
+int finish_graph(pgh_graph_s* g) {
+    Runtime& r = rt();
+    const int64_t nT = g->n_cols;
+    const int64_t total = nT + g->nnz;
+    PGH_CHECK(total / kItemsPerTile < (1 << 30), "graph too large for the int32 tile table");
+    g->items_per_tile = kItemsPerTile;
+    g->num_tiles = (int)((total + kItemsPerTile - 1) / kItemsPerTile);
+    const int nt = g->num_tiles;
+    PGH_HIP(hipMalloc(&g->tile_coord, sizeof(int2) * (size_t)(nt + 1)));
+    PGH_HIP(hipMalloc(&g->chain_first, sizeof(int32_t) * (size_t)(nt > 0 ? nt : 1)));
+    PGH_HIP(hipMalloc(&g->tail_carry, sizeof(double) * (size_t)(nt > 0 ? nt : 1)));
+    PGH_HIP(hipMalloc(&g->head_partial, sizeof(double) * (size_t)(nt > 0 ? nt : 1)));
+    PGH_HIP(hipMemsetAsync(g->tail_carry, 0, sizeof(double) * (size_t)(nt > 0 ? nt : 1), r.stream));
+    PGH_HIP(hipMemsetAsync(g->head_partial, 0, sizeof(double) * (size_t)(nt > 0 ? nt : 1), r.stream));
+    k_tile_coords<<<blocks_for(nt + 1), kBlock, 0, r.stream>>>(g->rowptr, (int)nT, (int)g->nnz, kItemsPerTile, nt, g->tile_coord);
+    if (nt > 0)
+        k_chain_first<<<blocks_for(nt), kBlock, 0, r.stream>>>(g->rowptr, g->tile_coord, (int)nT, nt, g->chain_first);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    g->device_bytes = (int64_t)sizeof(int32_t) * (nT + 1) + (int64_t)(sizeof(int32_t) + sizeof(float)) * g->nnz +
+                      (int64_t)sizeof(float) * g->n_rows + (int64_t)(sizeof(int2) + 4 + 16) * (nt + 1);
+    return 0;
+}
+
+}  // namespace pgh
+
+extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                                  const int32_t* indices, const double* data, int flags, pgh_graph_t* out) {
+    (void)flags;
+    PGH_TRY(ensure_init());
+    PGH_CHECK(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "pgh_graph_from_csr: negative size");
+    PGH_CHECK(n_rows < 2147483647LL && n_cols < 2147483647LL && nnz < 2147483647LL,
+              "pgh_graph_from_csr: int32 index space exceeded; row-partition the graph (SURVEY.md 8e)");
+    PGH_CHECK(indptr != nullptr && (nnz == 0 || (indices && data)), "pgh_graph_from_csr: null array");
+    PGH_CHECK(indptr[0] == 0 && indptr[n_rows] == nnz, "pgh_graph_from_csr: indptr does not match nnz");
+    Runtime& r = rt();
+    pgh_graph_s* g = new pgh_graph_s();
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = nnz;
+    int rc = [&]() -> int {
+        DevBuf<int64_t> d_indptr;
+        DevBuf<int32_t> d_indices;
+        DevBuf<double> d_data;
+        DevBuf<uint64_t> keys_a, keys_b;
+        DevBuf<float> vals_a;
+        PGH_TRY(d_indptr.alloc(n_rows + 1));
+        PGH_TRY(d_indices.alloc(nnz));
+        PGH_TRY(d_data.alloc(nnz));
+        PGH_HIP(hipMemcpyAsync(d_indptr.p, indptr, sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, r.stream));
+        if (nnz > 0) {
+            PGH_HIP(hipMemcpyAsync(d_indices.p, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, r.stream));
+            PGH_HIP(hipMemcpyAsync(d_data.p, data, sizeof(double) * nnz, hipMemcpyHostToDevice, r.stream));
+        }
+        PGH_HIP(hipMalloc(&g->degrees, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
+        PGH_HIP(hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_cols + 1)));
+        PGH_HIP(hipMalloc(&g->col, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+        PGH_HIP(hipMalloc(&g->val, sizeof(float) * (size_t)(nnz > 0 ? nnz : 1)));
+        if (n_rows > 0) k_row_sums<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_data.p, n_rows, g->degrees);
+        if (nnz > 0) {
+            PGH_TRY(keys_a.alloc(nnz));
+            PGH_TRY(keys_b.alloc(nnz));
+            PGH_TRY(vals_a.alloc(nnz));
+            k_make_keys<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, d_data.p, n_rows, keys_a.p, vals_a.p);
+            PGH_HIP(hipGetLastError());
+            int bits_row = 1, bits_col = 1;
+            while ((1LL << bits_row) < n_rows) ++bits_row;
+            while ((1LL << bits_col) < n_cols) ++bits_col;
+            const int end_bit = 32 + bits_col;
+            size_t temp_bytes = 0;
+            PGH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a.p, keys_b.p, vals_a.p, g->val, (int)nnz, 0,
+                                                       end_bit, r.stream));
+            DevBuf<char> temp;
+            PGH_TRY(temp.alloc(temp_bytes));
+            PGH_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.p, keys_b.p, vals_a.p, g->val, (int)nnz, 0,
+                                                       end_bit, r.stream));
+            k_split_keys<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_b.p, nnz, n_cols, g->col, g->rowptr);
+            PGH_HIP(hipGetLastError());
+            PGH_HIP(hipStreamSynchronize(r.stream));
+            (void)bits_row;
+        } else {
+            k_fill_i32<<<blocks_for(n_cols + 1), kBlock, 0, r.stream>>>(g->rowptr, n_cols + 1, 0);
+            PGH_HIP(hipGetLastError());
+            PGH_HIP(hipStreamSynchronize(r.stream));
+        }
+        return finish_graph(g);
+    }();
+    if (rc != 0) {
+        std::string keep = pgh_last_error();
+        pgh_graph_destroy(g);
+        return fail(keep);
+    }
+    *out = g;
+    return 0;
+}
+
+extern "C" int pgh_graph_destroy(pgh_graph_t g) {
+    if (!g) return 0;
+    if (rt().initialised) (void)hipStreamSynchronize(rt().stream);
+    (void)hipFree(g->rowptr);
+    (void)hipFree(g->col);
+    (void)hipFree(g->val);
+    (void)hipFree(g->degrees);
+    (void)hipFree(g->tile_coord);
+    (void)hipFree(g->chain_first);
+    (void)hipFree(g->tail_carry);
+    (void)hipFree(g->head_partial);
+    delete g;
+    return 0;
+}
+
+extern "C" int pgh_graph_info(pgh_graph_t g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* device_bytes) {
+    PGH_CHECK(g, "pgh_graph_info: null graph");
+    if (n_rows) *n_rows = g->n_rows;
+    if (n_cols) *n_cols = g->n_cols;
+    if (nnz) *nnz = g->nnz;
+    if (device_bytes) *device_bytes = g->device_bytes;
+    return 0;
+}
+
+extern "C" int pgh_graph_degrees(pgh_graph_t g, pgh_vec_t out) {
+    PGH_CHECK(g && out && out->n == g->n_rows, "pgh_graph_degrees: length mismatch");
+    if (g->n_rows == 0) return 0;
+    PGH_HIP(hipMemcpyAsync(out->data, g->degrees, sizeof(float) * g->n_rows, hipMemcpyDeviceToDevice, rt().stream));
+    return 0;
+}
+
+extern "C" int pgh_graph_download(pgh_graph_t g, int64_t* indptr_t, int32_t* indices_t, float* data_t) {
+    PGH_CHECK(g && indptr_t, "pgh_graph_download: null argument");
+    Runtime& r = rt();
+    std::string err;
+    int32_t* tmp = new int32_t[g->n_cols + 1];
+    hipError_t e = hipMemcpyAsync(tmp, g->rowptr, sizeof(int32_t) * (g->n_cols + 1), hipMemcpyDeviceToHost, r.stream);
+    if (e == hipSuccess && g->nnz > 0 && indices_t)
+        e = hipMemcpyAsync(indices_t, g->col, sizeof(int32_t) * g->nnz, hipMemcpyDeviceToHost, r.stream);
+    if (e == hipSuccess && g->nnz > 0 && data_t)
+        e = hipMemcpyAsync(data_t, g->val, sizeof(float) * g->nnz, hipMemcpyDeviceToHost, r.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r.stream);
+    if (e == hipSuccess)
+        for (int64_t i = 0; i <= g->n_cols; ++i) indptr_t[i] = tmp[i];
+    delete[] tmp;
+    if (e != hipSuccess) return fail(std::string("pgh_graph_download: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// filter_out(x, exclude) = x[exclude == 0] (specification.py:113): order-preserving stream compaction
+extern "C" int pgh_filter_out(pgh_vec_t x, pgh_vec_t exclude, pgh_vec_t out, int64_t* out_len) {
+    PGH_CHECK(x && exclude && out && out_len && x->n == exclude->n && out->n >= x->n, "pgh_filter_out: length mismatch");
+    PGH_CHECK(x->n < 2147483647LL, "pgh_filter_out: vector too long");
+    Runtime& r = rt();
+    const int64_t n = x->n;
+    if (n == 0) {
+        *out_len = 0;
+        return 0;
+    }
+    DevBuf<char> flags;
+    DevBuf<int> d_count;
+    PGH_TRY(flags.alloc(n));
+    PGH_TRY(d_count.alloc(1));
+    k_flags_from_exclude<<<blocks_for(n), kBlock, 0, r.stream>>>(exclude->data, n, flags.p);
+    size_t temp_bytes = 0;
+    PGH_HIP(hipcub::DeviceSelect::Flagged(nullptr, temp_bytes, x->data, flags.p, out->data, d_count.p, (int)n, r.stream));
+    DevBuf<char> temp;
+    PGH_TRY(temp.alloc(temp_bytes));
+    PGH_HIP(hipcub::DeviceSelect::Flagged(temp.p, temp_bytes, x->data, flags.p, out->data, d_count.p, (int)n, r.stream));
+    int count = 0;
+    PGH_HIP(hipMemcpyAsync(&count, d_count.p, sizeof(int), hipMemcpyDeviceToHost, r.stream));
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    *out_len = count;
+    return 0;
+}

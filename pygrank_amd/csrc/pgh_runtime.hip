@@ -1,0 +1,743 @@
+// Runtime, dense vectors, elementwise operator protocol and f64-accumulated reductions.
+//
+// Reference counterparts: the vector primitives of pygrank/core/backend/specification.py:5-118 as the
+// numpy engine implements them (pygrank/core/backend/numpy.py:1-86) and the residual measures of
+// pygrank/measures/supervised.py:93-106,133-138.  All of these are HBM-bound streaming kernels:
+// 16-byte loads per lane, 64-wide wavefront shuffles for reductions, f64 accumulators.
+#include "pgh_common.h"
+
+#include <mutex>
+#include <vector>
+
+namespace pgh {
+
+static thread_local std::string g_error;
+static Runtime g_rt;
+
+void set_error(const std::string& msg) { g_error = msg; }
+int fail(const std::string& msg) {
+    g_error = msg;
+    return 1;
+}
+Runtime& rt() { return g_rt; }
+
+int ensure_init() {
+    if (g_rt.initialised) return 0;
+    return pgh_init(0);
+}
+
+ProfScope::ProfScope(int kernel_id) : id(kernel_id), on(g_rt.profiling) {
+    if (on) (void)hipEventRecord(g_rt.ev_a, g_rt.stream);
+}
+ProfScope::~ProfScope() {
+    if (on) {
+        (void)hipEventRecord(g_rt.ev_b, g_rt.stream);
+        (void)hipEventSynchronize(g_rt.ev_b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, g_rt.ev_a, g_rt.ev_b);
+        g_rt.prof_count[id] += 1;
+        g_rt.prof_ms[id] += ms;
+    }
+}
+
+}  // namespace pgh
+
+using namespace pgh;
+
+// =================================================================================================
+// runtime
+// =================================================================================================
+extern "C" const char* pgh_last_error(void) { return g_error.c_str(); }
+extern "C" const char* pgh_runtime_name(void) { return "hip:gfx950"; }
+
+extern "C" int pgh_device_count(int* count) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = c;
+    return 0;
+}
+
+extern "C" int pgh_init(int device_ordinal) {
+    Runtime& r = rt();
+    if (r.initialised && r.device == device_ordinal) return 0;
+    PGH_CHECK(!r.initialised, "pgh_init: engine already initialised on another device; call pgh_shutdown first");
+    int count = 0;
+    PGH_TRY(pgh_device_count(&count));
+    PGH_CHECK(count > 0, "pgh_init: no HIP device visible (the MI355X engine has no CPU fallback)");
+    PGH_CHECK(device_ordinal >= 0 && device_ordinal < count, "pgh_init: device ordinal out of range");
+    PGH_HIP(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    PGH_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    r.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    PGH_HIP(hipStreamCreateWithFlags(&r.own_stream, hipStreamNonBlocking));
+    r.stream = r.own_stream;
+    PGH_HIP(hipMalloc(&r.d_partials, sizeof(double) * kMaxPartials * 2));
+    PGH_HIP(hipMalloc(&r.d_scalars, sizeof(double) * kNumScalars));
+    PGH_HIP(hipHostMalloc(&r.h_scalars, sizeof(double) * kNumScalars, hipHostMallocDefault));
+    PGH_HIP(hipEventCreate(&r.ev_a));
+    PGH_HIP(hipEventCreate(&r.ev_b));
+    r.device = device_ordinal;
+    r.initialised = true;
+    return 0;
+}
+
+extern "C" int pgh_shutdown(void) {
+    Runtime& r = rt();
+    if (!r.initialised) return 0;
+    (void)hipStreamSynchronize(r.stream);
+    (void)hipFree(r.d_partials);
+    (void)hipFree(r.d_scalars);
+    (void)hipHostFree(r.h_scalars);
+    (void)hipEventDestroy(r.ev_a);
+    (void)hipEventDestroy(r.ev_b);
+    (void)hipStreamDestroy(r.own_stream);
+    r = Runtime();
+    return 0;
+}
+
+extern "C" int pgh_device_name(char* buf, int buflen) {
+    PGH_TRY(ensure_init());
+    hipDeviceProp_t prop;
+    PGH_HIP(hipGetDeviceProperties(&prop, rt().device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+extern "C" int pgh_mem_info(int64_t* free_bytes, int64_t* total_bytes) {
+    PGH_TRY(ensure_init());
+    size_t f = 0, t = 0;
+    PGH_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f;
+    *total_bytes = (int64_t)t;
+    return 0;
+}
+
+extern "C" int pgh_set_stream(void* hip_stream) {
+    PGH_TRY(ensure_init());
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    rt().stream = hip_stream ? (hipStream_t)hip_stream : rt().own_stream;
+    return 0;
+}
+
+extern "C" int pgh_sync(void) {
+    PGH_TRY(ensure_init());
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    return 0;
+}
+
+extern "C" int pgh_timer_create(pgh_timer_t* out) {
+    PGH_TRY(ensure_init());
+    pgh_timer_s* t = new pgh_timer_s();
+    PGH_HIP(hipEventCreate(&t->start));
+    PGH_HIP(hipEventCreate(&t->stop));
+    *out = t;
+    return 0;
+}
+extern "C" int pgh_timer_destroy(pgh_timer_t t) {
+    if (!t) return 0;
+    (void)hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->stop);
+    delete t;
+    return 0;
+}
+extern "C" int pgh_timer_start(pgh_timer_t t) {
+    PGH_HIP(hipEventRecord(t->start, rt().stream));
+    return 0;
+}
+extern "C" int pgh_timer_stop(pgh_timer_t t) {
+    PGH_HIP(hipEventRecord(t->stop, rt().stream));
+    return 0;
+}
+extern "C" int pgh_timer_elapsed_ms(pgh_timer_t t, double* ms) {
+    PGH_HIP(hipEventSynchronize(t->stop));
+    float f = 0.f;
+    PGH_HIP(hipEventElapsedTime(&f, t->start, t->stop));
+    *ms = (double)f;
+    return 0;
+}
+
+extern "C" int pgh_profile_enable(int on) {
+    PGH_TRY(ensure_init());
+    rt().profiling = (on != 0);
+    return 0;
+}
+extern "C" int pgh_profile_reset(void) {
+    for (int i = 0; i < PGH_K_COUNT; ++i) {
+        rt().prof_count[i] = 0;
+        rt().prof_ms[i] = 0.0;
+    }
+    return 0;
+}
+extern "C" int pgh_profile_read(int kernel_id, int64_t* launches, double* total_ms) {
+    PGH_CHECK(kernel_id >= 0 && kernel_id < PGH_K_COUNT, "pgh_profile_read: bad kernel id");
+    *launches = rt().prof_count[kernel_id];
+    *total_ms = rt().prof_ms[kernel_id];
+    return 0;
+}
+
+// =================================================================================================
+// vectors
+// =================================================================================================
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(int64_t n, int per_thread = 4) {
+    int64_t blocks = (n + (int64_t)kBlock * per_thread - 1) / ((int64_t)kBlock * per_thread);
+    int64_t cap = (int64_t)rt().num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+__global__ void k_fill(float* __restrict__ x, int64_t n, float v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
+}
+
+__global__ void k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+__global__ void k_f32_to_f64(const float* __restrict__ in, double* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (double)in[i];
+}
+
+__global__ void k_scatter_set(float* __restrict__ x, const int64_t* __restrict__ idx, const double* __restrict__ val,
+                              int64_t count) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        x[idx[i]] = (float)val[i];
+}
+
+__device__ __forceinline__ float apply_bin(int op, float a, float b) {
+    switch (op) {
+        case PGH_ADD: return a + b;
+        case PGH_SUB: return a - b;
+        case PGH_MUL: return a * b;
+        case PGH_DIV: return a / b;
+        case PGH_POW: return powf(a, b);
+        case PGH_MAXOP: return fmaxf(a, b);
+        case PGH_MINOP: return fminf(a, b);
+        case PGH_GT: return a > b ? 1.f : 0.f;
+        case PGH_GE: return a >= b ? 1.f : 0.f;
+        case PGH_LT: return a < b ? 1.f : 0.f;
+        case PGH_LE: return a <= b ? 1.f : 0.f;
+        case PGH_EQ: return a == b ? 1.f : 0.f;
+        default: return a != b ? 1.f : 0.f;
+    }
+}
+
+__device__ __forceinline__ float apply_un(int op, float a) {
+    switch (op) {
+        case PGH_ABS: return fabsf(a);
+        case PGH_EXP: return expf(a);
+        case PGH_LOG: return logf(a);
+        case PGH_NEG: return -a;
+        case PGH_SQRT: return sqrtf(a);
+        default: return a != 0.f ? 1.f / a : 0.f;   // safe_inv, backend/__init__.py:20-23
+    }
+}
+
+// 16 B per lane on the aligned body, scalar tail.  OP is a template parameter so the switch folds.
+template <int OP>
+__global__ void k_ewise_vv(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           int64_t n, int vec_ok) {
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t body = vec_ok ? (n >> 2) : 0;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (int64_t i = tid; i < body; i += stride) {
+        float4 x = a4[i], y = b4[i], r;
+        r.x = apply_bin(OP, x.x, y.x);
+        r.y = apply_bin(OP, x.y, y.y);
+        r.z = apply_bin(OP, x.z, y.z);
+        r.w = apply_bin(OP, x.w, y.w);
+        o4[i] = r;
+    }
+    for (int64_t i = (body << 2) + tid; i < n; i += stride) out[i] = apply_bin(OP, a[i], b[i]);
+}
+
+template <int OP, int LEFT>
+__global__ void k_ewise_vs(const float* __restrict__ a, float s, float* __restrict__ out, int64_t n, int vec_ok) {
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t body = vec_ok ? (n >> 2) : 0;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (int64_t i = tid; i < body; i += stride) {
+        float4 x = a4[i], r;
+        r.x = LEFT ? apply_bin(OP, s, x.x) : apply_bin(OP, x.x, s);
+        r.y = LEFT ? apply_bin(OP, s, x.y) : apply_bin(OP, x.y, s);
+        r.z = LEFT ? apply_bin(OP, s, x.z) : apply_bin(OP, x.z, s);
+        r.w = LEFT ? apply_bin(OP, s, x.w) : apply_bin(OP, x.w, s);
+        o4[i] = r;
+    }
+    for (int64_t i = (body << 2) + tid; i < n; i += stride)
+        out[i] = LEFT ? apply_bin(OP, s, a[i]) : apply_bin(OP, a[i], s);
+}
+
+template <int OP>
+__global__ void k_ewise_un(const float* __restrict__ a, float* __restrict__ out, int64_t n, int vec_ok) {
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t body = vec_ok ? (n >> 2) : 0;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (int64_t i = tid; i < body; i += stride) {
+        float4 x = a4[i], r;
+        r.x = apply_un(OP, x.x);
+        r.y = apply_un(OP, x.y);
+        r.z = apply_un(OP, x.z);
+        r.w = apply_un(OP, x.w);
+        o4[i] = r;
+    }
+    for (int64_t i = (body << 2) + tid; i < n; i += stride) out[i] = apply_un(OP, a[i]);
+}
+
+__global__ void k_axpby(float a, const float* __restrict__ x, float b, const float* __restrict__ y,
+                        float* __restrict__ out, int64_t n, int vec_ok) {
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t body = vec_ok ? (n >> 2) : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (int64_t i = tid; i < body; i += stride) {
+        float4 u = x4[i], v = y4[i], r;
+        r.x = a * u.x + b * v.x;
+        r.y = a * u.y + b * v.y;
+        r.z = a * u.z + b * v.z;
+        r.w = a * u.w + b * v.w;
+        o4[i] = r;
+    }
+    for (int64_t i = (body << 2) + tid; i < n; i += stride) out[i] = a * x[i] + b * y[i];
+}
+
+inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int pgh_vec_alloc(int64_t n, pgh_vec_t* out) {
+    PGH_TRY(ensure_init());
+    PGH_CHECK(n >= 0, "pgh_vec_alloc: negative length");
+    pgh_vec_s* v = new pgh_vec_s();
+    v->n = n;
+    v->owns = true;
+    size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(float);
+    hipError_t e = hipMalloc(&v->data, bytes);
+    if (e != hipSuccess) {
+        delete v;
+        return fail(std::string("pgh_vec_alloc: hipMalloc failed: ") + hipGetErrorString(e));
+    }
+    *out = v;
+    return 0;
+}
+
+extern "C" int pgh_vec_wrap(void* device_ptr, int64_t n, pgh_vec_t* out) {
+    PGH_TRY(ensure_init());
+    PGH_CHECK(device_ptr != nullptr || n == 0, "pgh_vec_wrap: null pointer");
+    pgh_vec_s* v = new pgh_vec_s();
+    v->data = (float*)device_ptr;
+    v->n = n;
+    v->owns = false;
+    *out = v;
+    return 0;
+}
+
+extern "C" int pgh_vec_free(pgh_vec_t v) {
+    if (!v) return 0;
+    if (v->owns && v->data) {
+        // frees are stream-ordered by synchronising only when work may be in flight on this buffer
+        (void)hipStreamSynchronize(rt().stream);
+        (void)hipFree(v->data);
+    }
+    delete v;
+    return 0;
+}
+
+extern "C" int64_t pgh_vec_len(pgh_vec_t v) { return v ? v->n : -1; }
+extern "C" void* pgh_vec_ptr(pgh_vec_t v) { return v ? (void*)v->data : nullptr; }
+
+extern "C" int pgh_vec_h2d_f32(pgh_vec_t v, const float* host, int64_t n) {
+    PGH_CHECK(v && n == v->n, "pgh_vec_h2d_f32: length mismatch");
+    if (n == 0) return 0;
+    PGH_HIP(hipMemcpyAsync(v->data, host, sizeof(float) * n, hipMemcpyHostToDevice, rt().stream));
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    return 0;
+}
+
+extern "C" int pgh_vec_h2d_f64(pgh_vec_t v, const double* host, int64_t n) {
+    PGH_CHECK(v && n == v->n, "pgh_vec_h2d_f64: length mismatch");
+    if (n == 0) return 0;
+    double* staging = nullptr;
+    PGH_HIP(hipMalloc(&staging, sizeof(double) * n));
+    PGH_HIP(hipMemcpyAsync(staging, host, sizeof(double) * n, hipMemcpyHostToDevice, rt().stream));
+    k_f64_to_f32<<<grid_for(n), kBlock, 0, rt().stream>>>(staging, v->data, n);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    PGH_HIP(hipFree(staging));
+    return 0;
+}
+
+extern "C" int pgh_vec_d2h_f32(pgh_vec_t v, float* host, int64_t n) {
+    PGH_CHECK(v && n == v->n, "pgh_vec_d2h_f32: length mismatch");
+    if (n == 0) return 0;
+    PGH_HIP(hipMemcpyAsync(host, v->data, sizeof(float) * n, hipMemcpyDeviceToHost, rt().stream));
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    return 0;
+}
+
+extern "C" int pgh_vec_d2h_f64(pgh_vec_t v, double* host, int64_t n) {
+    PGH_CHECK(v && n == v->n, "pgh_vec_d2h_f64: length mismatch");
+    if (n == 0) return 0;
+    double* staging = nullptr;
+    PGH_HIP(hipMalloc(&staging, sizeof(double) * n));
+    k_f32_to_f64<<<grid_for(n), kBlock, 0, rt().stream>>>(v->data, staging, n);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipMemcpyAsync(host, staging, sizeof(double) * n, hipMemcpyDeviceToHost, rt().stream));
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    PGH_HIP(hipFree(staging));
+    return 0;
+}
+
+extern "C" int pgh_vec_fill(pgh_vec_t v, double value) {
+    PGH_CHECK(v, "pgh_vec_fill: null vector");
+    if (v->n == 0) return 0;
+    k_fill<<<grid_for(v->n), kBlock, 0, rt().stream>>>(v->data, v->n, (float)value);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pgh_vec_copy(pgh_vec_t dst, pgh_vec_t src) {
+    PGH_CHECK(dst && src && dst->n == src->n, "pgh_vec_copy: length mismatch");
+    if (dst->n == 0) return 0;
+    PGH_HIP(hipMemcpyAsync(dst->data, src->data, sizeof(float) * dst->n, hipMemcpyDeviceToDevice, rt().stream));
+    return 0;
+}
+
+extern "C" int pgh_vec_get(pgh_vec_t v, int64_t i, double* out) {
+    PGH_CHECK(v && i >= 0 && i < v->n, "pgh_vec_get: index out of range");
+    float f = 0.f;
+    PGH_HIP(hipMemcpyAsync(&f, v->data + i, sizeof(float), hipMemcpyDeviceToHost, rt().stream));
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    *out = (double)f;
+    return 0;
+}
+
+extern "C" int pgh_vec_set(pgh_vec_t v, int64_t i, double value) {
+    PGH_CHECK(v && i >= 0 && i < v->n, "pgh_vec_set: index out of range");
+    float f = (float)value;
+    PGH_HIP(hipMemcpyAsync(v->data + i, &f, sizeof(float), hipMemcpyHostToDevice, rt().stream));
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    return 0;
+}
+
+extern "C" int pgh_vec_scatter_set(pgh_vec_t v, const int64_t* idx, const double* val, int64_t count) {
+    PGH_CHECK(v, "pgh_vec_scatter_set: null vector");
+    if (count == 0) return 0;
+    for (int64_t k = 0; k < count; ++k) PGH_CHECK(idx[k] >= 0 && idx[k] < v->n, "pgh_vec_scatter_set: index out of range");
+    int64_t* d_idx = nullptr;
+    double* d_val = nullptr;
+    PGH_HIP(hipMalloc(&d_idx, sizeof(int64_t) * count));
+    PGH_HIP(hipMalloc(&d_val, sizeof(double) * count));
+    PGH_HIP(hipMemcpyAsync(d_idx, idx, sizeof(int64_t) * count, hipMemcpyHostToDevice, rt().stream));
+    PGH_HIP(hipMemcpyAsync(d_val, val, sizeof(double) * count, hipMemcpyHostToDevice, rt().stream));
+    k_scatter_set<<<grid_for(count, 1), kBlock, 0, rt().stream>>>(v->data, d_idx, d_val, count);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    PGH_HIP(hipFree(d_idx));
+    PGH_HIP(hipFree(d_val));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise dispatch
+// ------------------------------------------------------------------------------------------------
+#define PGH_DISPATCH_BIN(OPVAR, CALL)                      \
+    switch (OPVAR) {                                       \
+        case PGH_ADD: CALL(PGH_ADD); break;                \
+        case PGH_SUB: CALL(PGH_SUB); break;                \
+        case PGH_MUL: CALL(PGH_MUL); break;                \
+        case PGH_DIV: CALL(PGH_DIV); break;                \
+        case PGH_POW: CALL(PGH_POW); break;                \
+        case PGH_MAXOP: CALL(PGH_MAXOP); break;            \
+        case PGH_MINOP: CALL(PGH_MINOP); break;            \
+        case PGH_GT: CALL(PGH_GT); break;                  \
+        case PGH_GE: CALL(PGH_GE); break;                  \
+        case PGH_LT: CALL(PGH_LT); break;                  \
+        case PGH_LE: CALL(PGH_LE); break;                  \
+        case PGH_EQ: CALL(PGH_EQ); break;                  \
+        case PGH_NE: CALL(PGH_NE); break;                  \
+        default: return fail("unknown binary operator");   \
+    }
+
+extern "C" int pgh_ewise_vv(int op, pgh_vec_t a, pgh_vec_t b, pgh_vec_t out) {
+    PGH_CHECK(a && b && out && a->n == b->n && a->n == out->n, "pgh_ewise_vv: length mismatch");
+    const int64_t n = a->n;
+    if (n == 0) return 0;
+    const int vec_ok = aligned16(a->data) && aligned16(b->data) && aligned16(out->data);
+    const int grid = grid_for(n, 8);
+#define CALL(OP) k_ewise_vv<OP><<<grid, kBlock, 0, rt().stream>>>(a->data, b->data, out->data, n, vec_ok)
+    PGH_DISPATCH_BIN(op, CALL)
+#undef CALL
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pgh_ewise_vs(int op, pgh_vec_t a, double scalar, int scalar_on_left, pgh_vec_t out) {
+    PGH_CHECK(a && out && a->n == out->n, "pgh_ewise_vs: length mismatch");
+    const int64_t n = a->n;
+    if (n == 0) return 0;
+    const int vec_ok = aligned16(a->data) && aligned16(out->data);
+    const int grid = grid_for(n, 8);
+    const float s = (float)scalar;
+    if (scalar_on_left) {
+#define CALL(OP) k_ewise_vs<OP, 1><<<grid, kBlock, 0, rt().stream>>>(a->data, s, out->data, n, vec_ok)
+        PGH_DISPATCH_BIN(op, CALL)
+#undef CALL
+    } else {
+#define CALL(OP) k_ewise_vs<OP, 0><<<grid, kBlock, 0, rt().stream>>>(a->data, s, out->data, n, vec_ok)
+        PGH_DISPATCH_BIN(op, CALL)
+#undef CALL
+    }
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pgh_ewise_unary(int op, pgh_vec_t a, pgh_vec_t out) {
+    PGH_CHECK(a && out && a->n == out->n, "pgh_ewise_unary: length mismatch");
+    const int64_t n = a->n;
+    if (n == 0) return 0;
+    const int vec_ok = aligned16(a->data) && aligned16(out->data);
+    const int grid = grid_for(n, 8);
+    switch (op) {
+        case PGH_ABS: k_ewise_un<PGH_ABS><<<grid, kBlock, 0, rt().stream>>>(a->data, out->data, n, vec_ok); break;
+        case PGH_EXP: k_ewise_un<PGH_EXP><<<grid, kBlock, 0, rt().stream>>>(a->data, out->data, n, vec_ok); break;
+        case PGH_LOG: k_ewise_un<PGH_LOG><<<grid, kBlock, 0, rt().stream>>>(a->data, out->data, n, vec_ok); break;
+        case PGH_NEG: k_ewise_un<PGH_NEG><<<grid, kBlock, 0, rt().stream>>>(a->data, out->data, n, vec_ok); break;
+        case PGH_SQRT: k_ewise_un<PGH_SQRT><<<grid, kBlock, 0, rt().stream>>>(a->data, out->data, n, vec_ok); break;
+        case PGH_SAFE_INV: k_ewise_un<PGH_SAFE_INV><<<grid, kBlock, 0, rt().stream>>>(a->data, out->data, n, vec_ok); break;
+        default: return fail("unknown unary operator");
+    }
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pgh_axpby(double a, pgh_vec_t x, double b, pgh_vec_t y, pgh_vec_t out) {
+    PGH_CHECK(x && y && out && x->n == y->n && x->n == out->n, "pgh_axpby: length mismatch");
+    const int64_t n = x->n;
+    if (n == 0) return 0;
+    const int vec_ok = aligned16(x->data) && aligned16(y->data) && aligned16(out->data);
+    k_axpby<<<grid_for(n, 8), kBlock, 0, rt().stream>>>((float)a, x->data, (float)b, y->data, out->data, n, vec_ok);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+// =================================================================================================
+// reductions (f64 accumulation; wavefront shuffles -> LDS -> per-block partial -> single-block final)
+// =================================================================================================
+namespace {
+
+// MODE: 0 sum x, 1 sum |x|, 2 max x, 3 min x, 4 dot(x, y), 5 sum |a*sa - b*sb|, 6 max |a*sa - b*sb|
+template <int MODE>
+__global__ void k_reduce_partials(const float* __restrict__ a, const float* __restrict__ b, double sa, double sb,
+                                  int64_t n, int vec_ok, double* __restrict__ partials) {
+    __shared__ double s_scratch[4];
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    constexpr bool kMax = (MODE == 2 || MODE == 6);
+    constexpr bool kMin = (MODE == 3);
+    double acc = kMax ? -INFINITY : (kMin ? INFINITY : 0.0);
+    if (MODE == 6) acc = 0.0;
+    auto fold = [&](float u, float v) {
+        if (MODE == 0) acc += (double)u;
+        if (MODE == 1) acc += fabs((double)u);
+        if (MODE == 2) acc = fmax(acc, (double)u);
+        if (MODE == 3) acc = fmin(acc, (double)u);
+        if (MODE == 4) acc += (double)u * (double)v;
+        if (MODE == 5) acc += fabs((double)u * sa - (double)v * sb);
+        if (MODE == 6) acc = fmax(acc, fabs((double)u * sa - (double)v * sb));
+    };
+    constexpr bool kTwo = (MODE >= 4);
+    int64_t body = vec_ok ? (n >> 2) : 0;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    for (int64_t i = tid; i < body; i += stride) {
+        float4 u = a4[i];
+        float4 v = kTwo ? b4[i] : u;
+        fold(u.x, v.x);
+        fold(u.y, v.y);
+        fold(u.z, v.z);
+        fold(u.w, v.w);
+    }
+    for (int64_t i = (body << 2) + tid; i < n; i += stride) fold(a[i], kTwo ? b[i] : 0.f);
+    double r = block_reduce_256<kMax ? 1 : (kMin ? 2 : 0)>(acc, s_scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// KIND: 0 sum, 1 max, 2 min
+template <int KIND>
+__global__ void k_reduce_final(const double* __restrict__ partials, int count, double* __restrict__ out) {
+    __shared__ double s_scratch[4];
+    double acc = KIND == 0 ? 0.0 : (KIND == 1 ? -INFINITY : INFINITY);
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        double v = partials[i];
+        if (KIND == 0) acc += v;
+        if (KIND == 1) acc = fmax(acc, v);
+        if (KIND == 2) acc = fmin(acc, v);
+    }
+    double r = block_reduce_256<KIND>(acc, s_scratch);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+template <int MODE>
+int run_reduce(const float* a, const float* b, double sa, double sb, int64_t n, double* out) {
+    Runtime& r = rt();
+    int grid = grid_for(n, 16);
+    if (grid > kMaxPartials) grid = kMaxPartials;
+    const int vec_ok = aligned16(a) && (b == nullptr || aligned16(b));
+    k_reduce_partials<MODE><<<grid, kBlock, 0, r.stream>>>(a, b ? b : a, sa, sb, n, vec_ok, r.d_partials);
+    constexpr int KIND = (MODE == 2 || MODE == 6) ? 1 : (MODE == 3 ? 2 : 0);
+    k_reduce_final<KIND><<<1, kBlock, 0, r.stream>>>(r.d_partials, grid, r.d_scalars);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipMemcpyAsync(r.h_scalars, r.d_scalars, sizeof(double), hipMemcpyDeviceToHost, r.stream));
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    *out = r.h_scalars[0];
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pgh_reduce(int kind, pgh_vec_t x, double* out) {
+    PGH_CHECK(x && out, "pgh_reduce: null argument");
+    if (x->n == 0) {
+        PGH_CHECK(kind == PGH_SUM || kind == PGH_ABSSUM, "pgh_reduce: max/min of an empty vector");
+        *out = 0.0;
+        return 0;
+    }
+    switch (kind) {
+        case PGH_SUM: return run_reduce<0>(x->data, nullptr, 1, 1, x->n, out);
+        case PGH_ABSSUM: return run_reduce<1>(x->data, nullptr, 1, 1, x->n, out);
+        case PGH_MAX: return run_reduce<2>(x->data, nullptr, 1, 1, x->n, out);
+        case PGH_MIN: return run_reduce<3>(x->data, nullptr, 1, 1, x->n, out);
+        default: return fail("pgh_reduce: unknown kind");
+    }
+}
+
+extern "C" int pgh_dot(pgh_vec_t x, pgh_vec_t y, double* out) {
+    PGH_CHECK(x && y && out && x->n == y->n, "pgh_dot: length mismatch");
+    if (x->n == 0) {
+        *out = 0.0;
+        return 0;
+    }
+    return run_reduce<4>(x->data, y->data, 1, 1, x->n, out);
+}
+
+extern "C" int pgh_scaled_residual(int kind, pgh_vec_t y, double y_scale, pgh_vec_t x, double x_scale, double* err) {
+    PGH_CHECK(y && x && err && x->n == y->n, "pgh_scaled_residual: length mismatch");
+    if (x->n == 0) {
+        *err = 0.0;
+        return 0;
+    }
+    ProfScope prof(PGH_K_RESIDUAL);
+    if (kind == PGH_ERR_LINF) return run_reduce<6>(y->data, x->data, y_scale, x_scale, x->n, err);
+    PGH_CHECK(kind == PGH_ERR_MABS || kind == PGH_ERR_L1, "pgh_scaled_residual: unknown kind");
+    PGH_TRY((run_reduce<5>(y->data, x->data, y_scale, x_scale, x->n, err)));
+    if (kind == PGH_ERR_MABS) *err /= (double)x->n;      // measures/supervised.py:106
+    return 0;
+}
+
+extern "C" int pgh_residual(int kind, pgh_vec_t a, pgh_vec_t b, double* out) {
+    return pgh_scaled_residual(kind, a, 1.0, b, 1.0, out);
+}
+
+// =================================================================================================
+// dense [n, b] slabs
+// =================================================================================================
+namespace {
+__global__ void k_mat_set_col(float* __restrict__ m, int64_t n, int b, int col, const float* __restrict__ v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m[i * b + col] = v[i];
+}
+__global__ void k_mat_get_col(const float* __restrict__ m, int64_t n, int b, int col, float* __restrict__ v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        v[i] = m[i * b + col];
+}
+}  // namespace
+
+extern "C" int pgh_mat_alloc(int64_t n, int32_t b, pgh_mat_t* out) {
+    PGH_TRY(ensure_init());
+    PGH_CHECK(n >= 0 && b >= 1, "pgh_mat_alloc: bad shape");
+    pgh_mat_s* m = new pgh_mat_s();
+    m->n = n;
+    m->b = b;
+    size_t bytes = sizeof(float) * (size_t)(n > 0 ? n : 1) * (size_t)b;
+    hipError_t e = hipMalloc(&m->data, bytes);
+    if (e != hipSuccess) {
+        delete m;
+        return fail(std::string("pgh_mat_alloc: hipMalloc failed: ") + hipGetErrorString(e));
+    }
+    *out = m;
+    return 0;
+}
+extern "C" int pgh_mat_free(pgh_mat_t m) {
+    if (!m) return 0;
+    (void)hipStreamSynchronize(rt().stream);
+    (void)hipFree(m->data);
+    delete m;
+    return 0;
+}
+extern "C" int pgh_mat_shape(pgh_mat_t m, int64_t* n, int32_t* b) {
+    PGH_CHECK(m, "pgh_mat_shape: null");
+    *n = m->n;
+    *b = m->b;
+    return 0;
+}
+extern "C" void* pgh_mat_ptr(pgh_mat_t m) { return m ? (void*)m->data : nullptr; }
+
+extern "C" int pgh_mat_h2d_f64(pgh_mat_t m, const double* host) {
+    PGH_CHECK(m, "pgh_mat_h2d_f64: null");
+    const int64_t total = m->n * m->b;
+    if (total == 0) return 0;
+    double* staging = nullptr;
+    PGH_HIP(hipMalloc(&staging, sizeof(double) * total));
+    PGH_HIP(hipMemcpyAsync(staging, host, sizeof(double) * total, hipMemcpyHostToDevice, rt().stream));
+    k_f64_to_f32<<<grid_for(total), kBlock, 0, rt().stream>>>(staging, m->data, total);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    PGH_HIP(hipFree(staging));
+    return 0;
+}
+extern "C" int pgh_mat_d2h_f64(pgh_mat_t m, double* host) {
+    PGH_CHECK(m, "pgh_mat_d2h_f64: null");
+    const int64_t total = m->n * m->b;
+    if (total == 0) return 0;
+    double* staging = nullptr;
+    PGH_HIP(hipMalloc(&staging, sizeof(double) * total));
+    k_f32_to_f64<<<grid_for(total), kBlock, 0, rt().stream>>>(m->data, staging, total);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipMemcpyAsync(host, staging, sizeof(double) * total, hipMemcpyDeviceToHost, rt().stream));
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    PGH_HIP(hipFree(staging));
+    return 0;
+}
+extern "C" int pgh_mat_set_col(pgh_mat_t m, int32_t col, pgh_vec_t v) {
+    PGH_CHECK(m && v && v->n == m->n && col >= 0 && col < m->b, "pgh_mat_set_col: shape mismatch");
+    if (m->n == 0) return 0;
+    k_mat_set_col<<<grid_for(m->n, 1), kBlock, 0, rt().stream>>>(m->data, m->n, m->b, col, v->data);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int pgh_mat_get_col(pgh_mat_t m, int32_t col, pgh_vec_t v) {
+    PGH_CHECK(m && v && v->n == m->n && col >= 0 && col < m->b, "pgh_mat_get_col: shape mismatch");
+    if (m->n == 0) return 0;
+    k_mat_get_col<<<grid_for(m->n, 1), kBlock, 0, rt().stream>>>(m->data, m->n, m->b, col, v->data);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,794 @@
+// Merge-path CSR SpMV over CSR(M^T) with fused propagation epilogues -- the hot kernel of the engine.
+//
+// Reference counterpart: conv(signal, M) = signal @ M (pygrank/core/backend/numpy.py:64-65, scipy
+// csc_matvec scatter-add, 87 % of rank() wall time) and the per-iteration vector algebra
+// around it: PageRank._formula (pygrank/algorithms/filters/adhoc.py:34-36), AbsorbingWalks._formula
+// (adhoc.py:166-169), ClosedFormGraphFilter._recursion/_step (abstract_filters.py:215-230,248-256).
+//
+// Design (MI355X / gfx950, HBM-bound, no MFMA):
+//   * The (rows + nnz) merge path of CSR(M^T) is cut into equal tiles of 256 * IPT items at upload time
+//     (tile table in HBM), so hub rows of a power-law graph are split across workgroups and runs of
+//     empty rows cost the same as non-zeros: perfect load balance irrespective of the degree skew.
+//   * A 256-thread workgroup (4 wavefronts of 64) streams the tile's column indices and values with
+//     fully coalesced loads (each lane reads consecutive nnz), gathers x[col] (L2 / Infinity-Cache
+//     resident), and stages the products in LDS.
+//   * Every thread then walks IPT consecutive merge items in LDS (f64 accumulators), rows that cross
+//     thread boundaries are stitched with a 64-wide __shfl segmented scan + a 4-wavefront LDS hand-off,
+//     rows that cross tile boundaries leave f64 carries that a tiny fix-up kernel combines in a fixed
+//     order (deterministic, atomic-free).
+//   * The epilogue (alpha/(1-alpha) axpby, absorbing-walk quotient, polynomial accumulation) and the
+//     block-partial sum(y) / residual run in the same pass, so one propagation step reads the matrix once
+//     and every dense vector once: 8*nnz + 16*n bytes for the PageRank step.
+#include "pgh_common.h"
+
+using namespace pgh;
+
+namespace {
+
+constexpr int WG = 256;
+
+enum EpiMode { EPI_PLAIN = 0, EPI_AXPBY = 1, EPI_ABSORB = 2, EPI_POLY = 3 };
+
+struct EpiParams {
+    double       a;        // multiplies the row sum (alpha, or 1 / 2 for the polynomial recurrences)
+    double       b;        // multiplies v[row]  ((1 - alpha) for PageRank, 0 / -1 for polynomial terms)
+    const float* v;        // personalization p (PPR / ABSORB) or the current term (POLY with b != 0)
+    const float* deg;      // ABSORB: degrees(M)
+    const float* lam;      // ABSORB: absorption * (1 - alpha) / alpha
+    float*       y;        // output vector
+    float*       r;        // POLY: result accumulator (in place)
+    double       c;        // POLY: coefficient of the new term
+    int          err_linf; // POLY: delta is a max instead of a sum
+};
+
+// Device-resident loop state (ConvergenceManager on the device, convergence.py:77-101).
+struct LoopState {
+    double scale;       // lazily applied L1 quotient of the current iterate (abstract_filters.py:133-134)
+    double err;         // last residual
+    double sum;         // sum(y) of the last step
+    int    done;        // convergence flag: once set every later kernel of the loop is a no-op
+    int    steps;       // propagation steps executed so far
+    int    converged;   // 1 when the tolerance was met
+    int    pad;
+};
+
+struct GraphView {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float*   val;
+    const int2*    tile_coord;
+    const int32_t* chain_first;
+    double*        tail_carry;
+    double*        head_partial;
+    int            n;          // rows of M^T (= length of y)
+    int            num_tiles;
+};
+
+template <int MODE>
+__device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff, int row, float sum,
+                                                double& sum_y, double& delta) {
+    float y;
+    if (MODE == EPI_PLAIN) {
+        y = a_eff * sum;
+    } else if (MODE == EPI_AXPBY || MODE == EPI_POLY) {
+        y = a_eff * sum;
+        if (ep.v != nullptr) y += (float)ep.b * ep.v[row];
+    } else {   // EPI_ABSORB: ((M^T x) * deg + p * lam) / (lam + deg), adhoc.py:167-168
+        const float d = ep.deg[row], l = ep.lam[row];
+        y = (a_eff * sum * d + ep.v[row] * l) / (l + d);
+    }
+    ep.y[row] = y;
+    sum_y += (double)y;
+    if (MODE == EPI_POLY) {
+        const float r_old = ep.r[row];
+        const float r_new = r_old + (float)ep.c * y;
+        ep.r[row] = r_new;
+        const double d = fabs((double)r_new - (double)r_old);
+        delta = ep.err_linf ? fmax(delta, d) : delta + d;
+    }
+    return y;
+}
+
+// -------------------------------------------------------------------------------------------------
+// main kernel: persistent workgroups stride over the merge-path tiles
+// -------------------------------------------------------------------------------------------------
+template <int IPT, int MODE>
+__global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EpiParams ep, const float* __restrict__ x,
+                                                    const LoopState* __restrict__ state,
+                                                    double* __restrict__ partial_sum,
+                                                    double* __restrict__ partial_delta) {
+    constexpr int ITEMS = WG * IPT;
+    __shared__ float  s_prod[ITEMS];
+    __shared__ int    s_rend[ITEMS + 1];
+    __shared__ float  s_rsum[ITEMS];
+    __shared__ int    s_wkey[4];
+    __shared__ double s_wval[4];
+    __shared__ double s_red[4];
+
+    double scale = 1.0;
+    if (state != nullptr) {
+        if (state->done) return;
+        scale = state->scale;
+    }
+    const float a_eff = (float)(ep.a * scale);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double sum_y = 0.0, delta = 0.0;
+
+    for (int tile = blockIdx.x; tile < g.num_tiles; tile += gridDim.x) {
+        const int2 c0 = g.tile_coord[tile], c1 = g.tile_coord[tile + 1];
+        const int row0 = c0.x, z0 = c0.y;
+        const int tile_rows = c1.x - row0;          // rows whose end lies inside the tile
+        const int tile_nnz = c1.y - z0;
+        const int tile_items = tile_rows + tile_nnz;
+
+        // ---- stage row ends (one extra: the row still in progress at the end of the tile)
+        for (int r = tid; r <= tile_rows; r += WG) {
+            const int row = row0 + r;
+            s_rend[r] = (row < g.n) ? g.rowptr[row + 1] - z0 : 0x7fffffff;
+        }
+        // ---- stream col/val coalesced, gather x, stage products
+        int   cidx[IPT];
+        float vals[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int idx = k * WG + tid;
+            const bool ok = idx < tile_nnz;
+            cidx[k] = ok ? g.col[z0 + idx] : 0;
+            vals[k] = ok ? g.val[z0 + idx] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int idx = k * WG + tid;
+            if (idx < tile_nnz) s_prod[idx] = vals[k] * x[cidx[k]];
+        }
+        __syncthreads();
+
+        // ---- per-thread merge-path start coordinate inside the tile
+        const int d0 = min(tid * IPT, tile_items);
+        const int d1 = min(d0 + IPT, tile_items);
+        int lo = max(d0 - tile_nnz, 0), hi = min(d0, tile_rows);
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_rend[mid] <= d0 - mid - 1) lo = mid + 1; else hi = mid;
+        }
+        int i = lo, j = d0 - lo;
+        // ---- serial walk over IPT merge items (f64 accumulation)
+        double acc = 0.0, first_val = 0.0;
+        int first_emit = -1;
+        int rend = s_rend[i];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            if (d0 + k < d1) {
+                if (j < rend) {
+                    acc += (double)s_prod[j];
+                    ++j;
+                } else {
+                    if (first_emit < 0) {
+                        first_emit = i;
+                        first_val = acc;
+                    } else {
+                        s_rsum[i] = (float)acc;
+                    }
+                    acc = 0.0;
+                    ++i;
+                    rend = s_rend[i];
+                }
+            }
+        }
+        // ---- stitch rows that cross thread boundaries: segmented inclusive scan keyed by row
+        int key = i;
+        double val = acc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int k2 = __shfl_up(key, off, 64);
+            const double v2 = __shfl_up(val, off, 64);
+            if (lane >= off && k2 == key) val += v2;
+        }
+        if (lane == 63) {
+            s_wkey[wave] = key;
+            s_wval[wave] = val;
+        }
+        __syncthreads();
+        int pk = -1;
+        double pv = 0.0;
+        for (int w = 0; w < wave; ++w) {
+            const int wk = s_wkey[w];
+            const double wv = s_wval[w];
+            if (wk == pk) pv += wv; else { pk = wk; pv = wv; }
+        }
+        if (pk == key) val += pv;
+        // exclusive value = inclusive value of the previous thread
+        int ek = __shfl_up(key, 1, 64);
+        double ev = __shfl_up(val, 1, 64);
+        if (lane == 0) { ek = pk; ev = pv; }
+        if (first_emit >= 0) {
+            const double total = first_val + ((tid > 0 && ek == first_emit) ? ev : 0.0);
+            s_rsum[first_emit] = (float)total;
+            if (first_emit == 0) g.head_partial[tile] = total;   // consumed by the fix-up if row0 spans tiles
+        }
+        if (tid == WG - 1) g.tail_carry[tile] = val;             // nnz of the row still open at the tile end
+        __syncthreads();
+
+        // ---- epilogue over the rows that ended in this tile (row0 skipped when it began in an earlier tile)
+        const bool head_spans = (row0 < g.n) && (g.rowptr[row0] < z0);
+        for (int r = tid; r < tile_rows; r += WG) {
+            if (r == 0 && head_spans) continue;
+            apply_epilogue<MODE>(ep, a_eff, row0 + r, s_rsum[r], sum_y, delta);
+        }
+        __syncthreads();
+    }
+
+    const double bs = block_reduce_256<0>(sum_y, s_red);
+    if (tid == 0) partial_sum[blockIdx.x] = bs;
+    if (MODE == EPI_POLY) {
+        const double bd = ep.err_linf ? block_reduce_256<1>(delta, s_red) : block_reduce_256<0>(delta, s_red);
+        if (tid == 0) partial_delta[blockIdx.x] = bd;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// fix-up kernel: one thread per tile whose first row began in an earlier tile and ends here.
+// Sums the tail carries of the chain of tiles in ascending order and applies the epilogue once.
+// -------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_spmv_fixup(GraphView g, EpiParams ep, const LoopState* __restrict__ state,
+                                                    double* __restrict__ partial_sum,
+                                                    double* __restrict__ partial_delta) {
+    __shared__ double s_red[4];
+    double scale = 1.0;
+    if (state != nullptr) {
+        if (state->done) return;
+        scale = state->scale;
+    }
+    const float a_eff = (float)(ep.a * scale);
+    double sum_y = 0.0, delta = 0.0;
+    for (int t = blockIdx.x * WG + threadIdx.x; t < g.num_tiles; t += gridDim.x * WG) {
+        const int first = g.chain_first[t];
+        if (first < 0) continue;                      // row0 does not span tiles / does not end here
+        double total = 0.0;
+        for (int s = first; s < t; ++s) total += g.tail_carry[s];
+        total += g.head_partial[t];
+        apply_epilogue<MODE>(ep, a_eff, g.tile_coord[t].x, (float)total, sum_y, delta);
+    }
+    const double bs = block_reduce_256<0>(sum_y, s_red);
+    if (threadIdx.x == 0) partial_sum[blockIdx.x] = bs;
+    if (MODE == EPI_POLY) {
+        const double bd = ep.err_linf ? block_reduce_256<1>(delta, s_red) : block_reduce_256<0>(delta, s_red);
+        if (threadIdx.x == 0) partial_delta[blockIdx.x] = bd;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// scalar stages of a step
+// -------------------------------------------------------------------------------------------------
+// Every workgroup folds the partials in the same order, so all of them see a bitwise identical sum.
+__device__ __forceinline__ double fold_partials(const double* __restrict__ partials, int count, int linf,
+                                                double* s_red) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += WG) {
+        const double v = partials[i];
+        acc = linf ? fmax(acc, v) : acc + v;
+    }
+    double r = linf ? block_reduce_256<1>(acc, s_red) : block_reduce_256<0>(acc, s_red);
+    __shared__ double s_bcast;
+    __syncthreads();
+    if (threadIdx.x == 0) s_bcast = r;
+    __syncthreads();
+    return s_bcast;
+}
+
+// residual partials of one recursive step: sum / max of |y * inv - x * scale| (f64), measures/supervised.py:93-138
+__global__ __launch_bounds__(WG) void k_step_residual(const float* __restrict__ y, const float* __restrict__ x,
+                                                       int64_t n, int vec_ok, int use_quotient, int linf,
+                                                       const LoopState* __restrict__ state,
+                                                       const double* __restrict__ partial_sum, int num_partials,
+                                                       double* __restrict__ partial_res) {
+    __shared__ double s_red[4];
+    if (state->done) return;
+    const double S = fold_partials(partial_sum, num_partials, 0, s_red);
+    const double inv = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+    const double scale = state->scale;
+    const int64_t tid = blockIdx.x * (int64_t)WG + threadIdx.x, stride = (int64_t)gridDim.x * WG;
+    double acc = 0.0;
+    auto fold = [&](float u, float v) {
+        const double d = fabs((double)u * inv - (double)v * scale);
+        acc = linf ? fmax(acc, d) : acc + d;
+    };
+    const int64_t body = vec_ok ? (n >> 2) : 0;
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = tid; i < body; i += stride) {
+        const float4 u = y4[i], v = x4[i];
+        fold(u.x, v.x);
+        fold(u.y, v.y);
+        fold(u.z, v.z);
+        fold(u.w, v.w);
+    }
+    for (int64_t i = (body << 2) + tid; i < n; i += stride) fold(y[i], x[i]);
+    const double r = linf ? block_reduce_256<1>(acc, s_red) : block_reduce_256<0>(acc, s_red);
+    if (threadIdx.x == 0) partial_res[blockIdx.x] = r;
+}
+
+// single-workgroup stage that closes a step on the device: folds the partials, updates the loop state and
+// evaluates ConvergenceManager._has_converged (convergence.py:96-101) for the check that follows the step.
+//   check != 0  : this step is followed by a residual comparison (iteration % end_modulo == 0, not "iters")
+//   res_partials: residual partials (recursive filters) or delta partials (polynomial filters)
+__global__ __launch_bounds__(WG) void k_step_close(LoopState* __restrict__ state, const double* __restrict__ partial_sum,
+                                                    int num_sum, const double* __restrict__ res_partials, int num_res,
+                                                    int use_quotient, int check, int err_kind, double tol, int64_t n,
+                                                    double* __restrict__ scalars_out) {
+    __shared__ double s_red[4];
+    if (state->done) return;
+    const double S = fold_partials(partial_sum, num_sum, 0, s_red);
+    double err = 0.0;
+    if (check) {
+        err = fold_partials(res_partials, num_res, err_kind == PGH_ERR_LINF, s_red);
+        if (err_kind == PGH_ERR_MABS) err /= (double)n;
+    }
+    if (threadIdx.x == 0) {
+        state->sum = S;
+        if (use_quotient) state->scale = (S != 0.0 ? 1.0 / S : 0.0);
+        else state->scale = 1.0;
+        state->steps += 1;
+        if (check) {
+            state->err = err;
+            if (err <= tol) {
+                state->done = 1;
+                state->converged = 1;
+            }
+        }
+        if (scalars_out != nullptr) {
+            scalars_out[1] = S;
+            scalars_out[2] = err;
+        }
+    }
+}
+
+__global__ void k_state_init(LoopState* state, double scale) {
+    state->scale = scale;
+    state->err = 0.0;
+    state->sum = 0.0;
+    state->done = 0;
+    state->steps = 0;
+    state->converged = 0;
+    state->pad = 0;
+}
+
+__global__ void k_scale_copy(const float* __restrict__ in, float* __restrict__ out, int64_t n, double factor) {
+    const float f = (float)factor;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i] * f;
+}
+
+// -------------------------------------------------------------------------------------------------
+// host-side launch helpers
+// -------------------------------------------------------------------------------------------------
+constexpr int kIPT = 7;     // 1792 merge items per tile; 21.5 KB LDS per workgroup
+
+GraphView view_of(pgh_graph_t g) {
+    GraphView v;
+    v.rowptr = g->rowptr;
+    v.col = g->col;
+    v.val = g->val;
+    v.tile_coord = g->tile_coord;
+    v.chain_first = g->chain_first;
+    v.tail_carry = g->tail_carry;
+    v.head_partial = g->head_partial;
+    v.n = (int)g->n_cols;
+    v.num_tiles = g->num_tiles;
+    return v;
+}
+
+struct StepGrid {
+    int main_grid;
+    int fix_grid;
+    int total() const { return main_grid + fix_grid; }
+};
+
+StepGrid grids_for(pgh_graph_t g) {
+    StepGrid s;
+    const int cap = rt().num_cus * 8;
+    s.main_grid = g->num_tiles < cap ? (g->num_tiles > 0 ? g->num_tiles : 1) : cap;
+    int fix = (g->num_tiles + WG - 1) / WG;
+    if (fix < 1) fix = 1;
+    if (fix > 1024) fix = 1024;
+    s.fix_grid = fix;
+    return s;
+}
+
+// Enqueue one SpMV (+ fix-up) with epilogue MODE.  Block partials land in rt().d_partials:
+//   sums  : [0, total)            deltas: [kMaxPartials, kMaxPartials + total)
+template <int MODE>
+int launch_spmv(pgh_graph_t g, const EpiParams& ep, const float* x, const LoopState* state, StepGrid* grid_out) {
+    Runtime& r = rt();
+    PGH_CHECK(g->items_per_tile == WG * kIPT, "graph tile table was built for a different tile size");
+    const GraphView v = view_of(g);
+    const StepGrid sg = grids_for(g);
+    double* psum = r.d_partials;
+    double* pdel = r.d_partials + kMaxPartials;
+    {
+        ProfScope prof(PGH_K_SPMV);
+        k_spmv_merge<kIPT, MODE><<<sg.main_grid, WG, 0, r.stream>>>(v, ep, x, state, psum, pdel);
+    }
+    {
+        ProfScope prof(PGH_K_FIXUP);
+        k_spmv_fixup<MODE><<<sg.fix_grid, WG, 0, r.stream>>>(v, ep, state, psum + sg.main_grid, pdel + sg.main_grid);
+    }
+    PGH_HIP(hipGetLastError());
+    if (grid_out) *grid_out = sg;
+    return 0;
+}
+
+inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int residual_grid(int64_t n) {
+    int64_t blocks = (n + (int64_t)WG * 16 - 1) / ((int64_t)WG * 16);
+    const int64_t cap = (int64_t)rt().num_cus * 4;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// Lazily created device loop state + pinned mirror
+LoopState* g_state = nullptr;
+LoopState* g_state_host = nullptr;
+
+int ensure_state() {
+    if (g_state) return 0;
+    PGH_HIP(hipMalloc(&g_state, sizeof(LoopState)));
+    PGH_HIP(hipHostMalloc(&g_state_host, sizeof(LoopState), hipHostMallocDefault));
+    return 0;
+}
+
+int fetch_state() {
+    PGH_HIP(hipMemcpyAsync(g_state_host, g_state, sizeof(LoopState), hipMemcpyDeviceToHost, rt().stream));
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    return 0;
+}
+
+int fetch_scalars(int first, int count) {
+    Runtime& r = rt();
+    PGH_HIP(hipMemcpyAsync(r.h_scalars + first, r.d_scalars + first, sizeof(double) * count, hipMemcpyDeviceToHost, r.stream));
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    return 0;
+}
+
+// single-shot step: run SpMV+fix-up with MODE, fold sum(y) (and delta) to the host
+template <int MODE>
+int single_step(pgh_graph_t g, const EpiParams& ep, const float* x, double* sum_out, double* delta_out, int err_kind) {
+    PGH_TRY(ensure_state());
+    Runtime& r = rt();
+    StepGrid sg;
+    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
+    PGH_TRY((launch_spmv<MODE>(g, ep, x, nullptr, &sg)));
+    if (sum_out != nullptr || delta_out != nullptr) {
+        ProfScope prof(PGH_K_FINAL);
+        k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, sg.total(), r.d_partials + kMaxPartials, sg.total(),
+                                             0, MODE == EPI_POLY ? 1 : 0, err_kind, -1.0, g->n_cols, r.d_scalars);
+        PGH_HIP(hipGetLastError());
+        PGH_TRY(fetch_scalars(1, 2));
+        if (sum_out) *sum_out = r.h_scalars[1];
+        if (delta_out) *delta_out = r.h_scalars[2];
+    }
+    return 0;
+}
+
+int check_graph_vecs(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y, const char* who) {
+    PGH_CHECK(g && x && y, std::string(who) + ": null argument");
+    PGH_CHECK(x->n == g->n_rows, std::string(who) + ": input length must equal the number of rows of M");
+    PGH_CHECK(y->n == g->n_cols, std::string(who) + ": output length must equal the number of columns of M");
+    PGH_CHECK(x->data != y->data, std::string(who) + ": conv must be pure (output aliases input)");
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI: single steps
+// =================================================================================================
+extern "C" int pgh_spmv(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y) {
+    PGH_TRY(check_graph_vecs(g, x, y, "pgh_spmv"));
+    if (g->n_cols == 0) return 0;
+    EpiParams ep{};
+    ep.a = 1.0;
+    ep.y = y->data;
+    return single_step<EPI_PLAIN>(g, ep, x->data, nullptr, nullptr, PGH_ERR_L1);
+}
+
+extern "C" int pgh_ppr_step(pgh_graph_t g, pgh_vec_t x, double x_scale, pgh_vec_t p, double alpha, pgh_vec_t y,
+                            double* sum_y) {
+    PGH_TRY(check_graph_vecs(g, x, y, "pgh_ppr_step"));
+    PGH_CHECK(p && p->n == g->n_cols, "pgh_ppr_step: personalization length mismatch");
+    if (g->n_cols == 0) {
+        if (sum_y) *sum_y = 0.0;
+        return 0;
+    }
+    EpiParams ep{};
+    ep.a = alpha * x_scale;
+    ep.b = 1.0 - alpha;
+    ep.v = p->data;
+    ep.y = y->data;
+    return single_step<EPI_AXPBY>(g, ep, x->data, sum_y, nullptr, PGH_ERR_L1);
+}
+
+extern "C" int pgh_absorb_step(pgh_graph_t g, pgh_vec_t x, double x_scale, pgh_vec_t p, pgh_vec_t deg, pgh_vec_t lam,
+                               pgh_vec_t y, double* sum_y) {
+    PGH_TRY(check_graph_vecs(g, x, y, "pgh_absorb_step"));
+    PGH_CHECK(p && deg && lam && p->n == g->n_cols && deg->n == g->n_cols && lam->n == g->n_cols,
+              "pgh_absorb_step: vector length mismatch");
+    if (g->n_cols == 0) {
+        if (sum_y) *sum_y = 0.0;
+        return 0;
+    }
+    EpiParams ep{};
+    ep.a = x_scale;
+    ep.v = p->data;
+    ep.deg = deg->data;
+    ep.lam = lam->data;
+    ep.y = y->data;
+    return single_step<EPI_ABSORB>(g, ep, x->data, sum_y, nullptr, PGH_ERR_L1);
+}
+
+extern "C" int pgh_poly_step(pgh_graph_t g, pgh_vec_t term, pgh_vec_t term_out, double a, double b, pgh_vec_t result,
+                             double c, int err_kind, double* delta) {
+    PGH_TRY(check_graph_vecs(g, term, term_out, "pgh_poly_step"));
+    PGH_CHECK(result && result->n == g->n_cols, "pgh_poly_step: result length mismatch");
+    PGH_CHECK(b == 0.0 || term->n == g->n_cols, "pgh_poly_step: b != 0 needs a square matrix");
+    if (g->n_cols == 0) {
+        if (delta) *delta = 0.0;
+        return 0;
+    }
+    EpiParams ep{};
+    ep.a = a;
+    ep.b = b;
+    ep.v = (b != 0.0) ? term->data : nullptr;
+    ep.y = term_out->data;
+    ep.r = result->data;
+    ep.c = c;
+    ep.err_linf = (err_kind == PGH_ERR_LINF);
+    double d = 0.0;
+    PGH_TRY((single_step<EPI_POLY>(g, ep, term->data, nullptr, &d, err_kind == PGH_ERR_LINF ? PGH_ERR_LINF : PGH_ERR_L1)));
+    if (err_kind == PGH_ERR_MABS) d /= (double)g->n_cols;
+    if (delta) *delta = d;
+    return 0;
+}
+
+// =================================================================================================
+// C-ABI: whole loops on the device
+// =================================================================================================
+namespace {
+
+// iterations between host polls of the device loop state: short enough that post-convergence no-op
+// launches are negligible, long enough that the poll's sync does not show on small graphs
+int batch_for(pgh_graph_t g) {
+    const double est_us = (8.0 * (double)g->nnz + 16.0 * (double)g->n_cols) / 4.0e6;   // ~4 TB/s
+    if (est_us > 200.0) return 4;
+    if (est_us > 20.0) return 8;
+    return 16;
+}
+
+struct LoopTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    int start() {
+        PGH_HIP(hipEventCreate(&a));
+        PGH_HIP(hipEventCreate(&b));
+        PGH_HIP(hipEventRecord(a, rt().stream));
+        return 0;
+    }
+    int stop(double* ms) {
+        PGH_HIP(hipEventRecord(b, rt().stream));
+        PGH_HIP(hipEventSynchronize(b));
+        float f = 0.f;
+        PGH_HIP(hipEventElapsedTime(&f, a, b));
+        *ms = (double)f;
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        return 0;
+    }
+};
+
+// Recursive filters (PageRank / AbsorbingWalks): RecursiveGraphFilter._step + ConvergenceManager.
+template <int MODE>
+int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    PGH_TRY(ensure_state());
+    Runtime& r = rt();
+    const int64_t n = g->n_cols;
+    PGH_CHECK(g->n_rows == g->n_cols, "recursive filters need a square matrix");
+    PGH_CHECK(ranks && ranks->n == n, "ranks length mismatch");
+    PGH_CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
+    memset(res, 0, sizeof(*res));
+    // two work buffers; buf[0] starts as the incoming ranks
+    float* work = nullptr;
+    PGH_HIP(hipMalloc(&work, sizeof(float) * (size_t)(n > 0 ? n : 1)));
+    float* buf[2] = {ranks->data, work};
+    const int linf = (cfg->err_kind == PGH_ERR_LINF);
+    const int rgrid = residual_grid(n);
+    double* pres = r.d_partials + kMaxPartials;      // residual partials share the delta region
+    LoopTimer timer;
+    PGH_TRY(timer.start());
+    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
+    // ConvergenceManager.has_converged is evaluated before every step with iteration = step index
+    // (convergence.py:85): step k runs iff k < max_iters and the check at iteration k did not fire.
+    const int max_steps = cfg->max_iters - 1 > 0 ? cfg->max_iters - 1 : 0;
+    const int batch = batch_for(g);
+    int enq = 0;          // steps enqueued so far
+    bool done = false;
+    while (!done && enq < max_steps) {
+        const int upto = (enq + batch < max_steps) ? enq + batch : max_steps;
+        for (; enq < upto; ++enq) {
+            const int k = enq + 1;                        // this is step k; it produces x_k from x_{k-1}
+            const float* xin = buf[(k - 1) & 1];
+            float* yout = buf[k & 1];
+            ep.y = yout;
+            StepGrid sg;
+            PGH_TRY((launch_spmv<MODE>(g, ep, xin, g_state, &sg)));
+            // the check that follows step k happens at iteration k + 1 (skipped when that iteration hits max_iters)
+            const int it = k + 1;
+            const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
+            if (check) {
+                ProfScope prof(PGH_K_RESIDUAL);
+                const int vec_ok = aligned16(yout) && aligned16(xin);
+                k_step_residual<<<rgrid, WG, 0, r.stream>>>(yout, xin, n, vec_ok, cfg->use_quotient, linf, g_state,
+                                                            r.d_partials, sg.total(), pres);
+            }
+            {
+                ProfScope prof(PGH_K_FINAL);
+                k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, sg.total(), pres, rgrid, cfg->use_quotient,
+                                                     check, cfg->err_kind, cfg->tol, n, nullptr);
+            }
+        }
+        PGH_HIP(hipGetLastError());
+        PGH_TRY(fetch_state());
+        done = g_state_host->done != 0;
+    }
+    PGH_TRY(fetch_state());
+    const int steps = g_state_host->steps;
+    // result lives in buf[steps & 1]; apply the pending quotient and preserve_norm factor
+    const double factor = g_state_host->scale * cfg->out_scale;
+    const float* final_buf = buf[steps & 1];
+    if (n > 0 && (final_buf != ranks->data || factor != 1.0))
+        k_scale_copy<<<residual_grid(n), WG, 0, r.stream>>>(final_buf, ranks->data, n, factor);
+    PGH_HIP(hipGetLastError());
+    PGH_TRY(timer.stop(&res->loop_ms));
+    PGH_HIP(hipFree(work));
+    res->iterations = steps + 1;                 // ConvergenceManager.iteration at loop exit
+    res->converged = g_state_host->converged;
+    res->spmv_count = steps;
+    res->last_error = g_state_host->err;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    PGH_CHECK(g && p && ranks && cfg && res, "pgh_ppr_run: null argument");
+    PGH_CHECK(p->n == g->n_cols, "pgh_ppr_run: personalization length mismatch");
+    EpiParams ep{};
+    ep.a = cfg->alpha;
+    ep.b = 1.0 - cfg->alpha;
+    ep.v = p->data;
+    return recursive_run<EPI_AXPBY>(g, ep, ranks, cfg, res);
+}
+
+extern "C" int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg,
+                              pgh_loop_result* res) {
+    PGH_CHECK(g && p && lam && ranks && cfg && res, "pgh_absorb_run: null argument");
+    PGH_CHECK(p->n == g->n_cols && lam->n == g->n_cols, "pgh_absorb_run: vector length mismatch");
+    EpiParams ep{};
+    ep.a = 1.0;
+    ep.v = p->data;
+    ep.deg = g->degrees;
+    ep.lam = lam->data;
+    return recursive_run<EPI_ABSORB>(g, ep, ranks, cfg, res);
+}
+
+// Closed-form filters: result_k = result_{k-1} + c_k * term_k, term_{k+1} = a * M^T term_k + b * term_k.
+// The reference accumulates first and multiplies afterwards (abstract_filters.py:254-256), which costs one
+// trailing, unused SpMV per run; here step k computes term_{k+1} AND folds it into the result, so the
+// run needs (iterations - 2) SpMVs for the identical result.
+extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, int32_t chebyshev,
+                            pgh_vec_t result, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    PGH_CHECK(g && p && result && cfg && res && (coeffs || num_coeffs == 0), "pgh_poly_run: null argument");
+    PGH_TRY(ensure_state());
+    Runtime& r = rt();
+    const int64_t n = g->n_cols;
+    PGH_CHECK(g->n_rows == g->n_cols && p->n == n && result->n == n, "pgh_poly_run: shape mismatch");
+    PGH_CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
+    memset(res, 0, sizeof(*res));
+    auto coeff = [&](int it) -> double { return (it >= 1 && it <= num_coeffs) ? coeffs[it - 1] : 0.0; };
+    const int max_iters = cfg->max_iters;
+    LoopTimer timer;
+    PGH_TRY(timer.start());
+    // iteration 1: has_converged never compares; the step sets result_1 = c_1 * p (term_1 = p).
+    // Every reference run starts from result_0 = 0 (abstract_filters.py:212-213).
+    int it = 1;                       // ConvergenceManager.iteration
+    if (it >= max_iters) {            // convergence.py:86-89: stops before the first step
+        PGH_TRY(pgh_vec_fill(result, 0.0));
+        PGH_TRY(timer.stop(&res->loop_ms));
+        res->iterations = it;
+        res->converged = 0;
+        return 0;
+    }
+    const double c1 = coeff(1);
+    if (n > 0) k_scale_copy<<<residual_grid(n), WG, 0, r.stream>>>(p->data, result->data, n, c1);
+    // delta_1 = sum|result_1 - 0| = |c_1| * sum|p|; evaluated on the device like every other delta
+    float* tbuf[2] = {nullptr, nullptr};
+    PGH_HIP(hipMalloc(&tbuf[0], sizeof(float) * (size_t)(n > 0 ? n : 1)));
+    PGH_HIP(hipMalloc(&tbuf[1], sizeof(float) * (size_t)(n > 0 ? n : 1)));
+    const float* term = p->data;      // term_1
+    double err = 0.0;
+    {
+        pgh_vec_s zero_view;          // |result_1 - 0|
+        double e = 0.0;
+        pgh_vec_s rv = *result;
+        rv.owns = false;
+        // residual against an implicit zero vector: scaled residual with x_scale = 0
+        PGH_TRY(pgh_scaled_residual(cfg->err_kind == PGH_ERR_ITERS ? PGH_ERR_L1 : cfg->err_kind, &rv, 1.0, &rv, 0.0, &e));
+        err = e;
+        (void)zero_view;
+    }
+    int spmv = 0;
+    bool converged = false;
+    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
+    const int batch = batch_for(g);
+    // host-side mirror of the reference loop for iteration 2 (uses err of step 1), then device batches
+    it = 2;
+    bool stop = false;
+    if (it >= max_iters) {
+        stop = true;
+    } else if (cfg->err_kind != PGH_ERR_ITERS && it % cfg->end_modulo == 0 && err <= cfg->tol) {
+        stop = true;
+        converged = true;
+    }
+    if (!stop) {
+        // steps for iterations it = 2 .. max_iters-1; step at iteration `it` produces term_it and result_it
+        int next_it = 2;
+        bool done = false;
+        while (!done && next_it < max_iters) {
+            const int upto = (next_it + batch < max_iters) ? next_it + batch : max_iters;
+            for (; next_it < upto; ++next_it) {
+                const int k = next_it;            // iteration index of this step
+                EpiParams ep{};
+                const bool cheb = chebyshev && k > 2;      // abstract_filters.py:219-221
+                ep.a = cheb ? 2.0 : 1.0;
+                ep.b = cheb ? -1.0 : 0.0;
+                ep.v = cheb ? term : nullptr;
+                float* tout = tbuf[k & 1];
+                ep.y = tout;
+                ep.r = result->data;
+                ep.c = coeff(k);
+                ep.err_linf = (cfg->err_kind == PGH_ERR_LINF);
+                StepGrid sg;
+                PGH_TRY((launch_spmv<EPI_POLY>(g, ep, term, g_state, &sg)));
+                const int chk_it = k + 1;         // the comparison of result_k with result_{k-1}
+                const int check = (cfg->err_kind != PGH_ERR_ITERS) && (chk_it < max_iters) && (chk_it % cfg->end_modulo == 0);
+                {
+                    ProfScope prof(PGH_K_FINAL);
+                    k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, sg.total(), r.d_partials + kMaxPartials,
+                                                         sg.total(), 0, check, cfg->err_kind, cfg->tol, n, nullptr);
+                }
+                term = tout;
+            }
+            PGH_HIP(hipGetLastError());
+            PGH_TRY(fetch_state());
+            done = g_state_host->done != 0;
+        }
+        PGH_TRY(fetch_state());
+        spmv = g_state_host->steps;
+        converged = g_state_host->converged != 0;
+        err = g_state_host->steps > 0 ? g_state_host->err : err;
+        it = 2 + spmv;                 // iteration value at loop exit
+        if (!converged && it < max_iters) it = max_iters;
+    }
+    if (n > 0 && cfg->out_scale != 1.0)
+        k_scale_copy<<<residual_grid(n), WG, 0, r.stream>>>(result->data, result->data, n, cfg->out_scale);
+    PGH_HIP(hipGetLastError());
+    PGH_TRY(timer.stop(&res->loop_ms));
+    PGH_HIP(hipFree(tbuf[0]));
+    PGH_HIP(hipFree(tbuf[1]));
+    res->iterations = it;
+    res->converged = converged ? 1 : 0;
+    res->spmv_count = spmv;
+    res->last_error = err;
+    return 0;
+}

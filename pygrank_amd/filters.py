@@ -1,0 +1,444 @@
+"""Graph filters of the propagation path on the MI355X engine.
+
+Same classes, constructor arguments, operators and error behaviour as the reference:
+  GraphFilter / RecursiveGraphFilter / ClosedFormGraphFilter  pygrank/algorithms/filters/abstract_filters.py:11-270
+  PageRank, PageRankClosed, HeatKernel, AbsorbingWalks         pygrank/algorithms/filters/adhoc.py:9-174
+  GenericGraphFilter, ImpulseGraphFilter, LowPassRecursive...  pygrank/algorithms/filters/low_pass.py:5-91
+
+Two execution routes, both on the GPU:
+  * generic route -- the reference's ``_start / while not has_converged: _step / _end`` structure
+    (abstract_filters.py:58-62) expressed with backend primitives; used whenever an option needs per-step
+    Python (callable quotient, custom error measure, optimisation dict, graph dropout ...).
+  * fused route -- the whole loop runs inside the engine (pgh_ppr_run / pgh_absorb_run / pgh_poly_run,
+    include/pgh.h): one merge-path SpMV kernel per iteration with the filter's vector algebra in its
+    epilogue, the residual as a separate wavefront-reduced kernel, and ConvergenceManager's stopping rule
+    evaluated on the device so that the host does not synchronise every iteration.  Results and
+    ``convergence.iteration`` are those of the generic route.
+"""
+import ctypes as C
+
+import numpy as np
+
+from pygrank_amd import _lib as L
+from pygrank_amd import backend
+from pygrank_amd.convergence import ConvergenceManager
+from pygrank_amd.device import DeviceGraph, DeviceVector
+from pygrank_amd.postprocess import Postprocessor, Tautology
+from pygrank_amd.preprocessing import obj2id, preprocessor as default_preprocessor
+from pygrank_amd.signals import GraphSignal, NodeRanking, to_signal
+from pygrank_amd.utils import call, ensure_used_args
+
+
+def _device_graph(M):
+    array = getattr(M, "array", M)
+    return array if isinstance(array, DeviceGraph) else None
+
+
+class GraphFilter(NodeRanking):
+    """abstract_filters.py:11-106."""
+
+    def __init__(self, preprocessor=None, convergence=None, personalization_transform=None, preserve_norm=True,
+                 **kwargs):
+        self.preprocessor = call(default_preprocessor, kwargs) if preprocessor is None else preprocessor
+        self.convergence = call(ConvergenceManager, kwargs) if convergence is None else convergence
+        self.personalization_transform = Tautology() if personalization_transform is None else personalization_transform
+        self.preserve_norm = preserve_norm
+        ensure_used_args(kwargs, [default_preprocessor, ConvergenceManager])
+
+    def _prepare(self, personalization):
+        pass
+
+    def rank(self, graph=None, personalization=None, warm_start=None, graph_dropout=0, *args, **kwargs):
+        personalization = to_signal(graph, personalization)                       # abstract_filters.py:49
+        self._prepare(personalization)
+        personalization = self.personalization_transform(personalization)
+        norm = backend.sum(backend.abs(personalization.np))                       # :52
+        if norm == 0:
+            return personalization                                                # :53-54
+        personalization = to_signal(personalization, personalization.np / norm)   # :55
+        ranks = to_signal(personalization,
+                          backend.copy(personalization.np) if warm_start is None else warm_start)   # :56
+        M = self.preprocessor(self._prepare_graph(personalization.graph, personalization, *args, **kwargs))
+        self.convergence.start()
+        out_scale = norm if self.preserve_norm else 1.0
+        if graph_dropout == 0 and self._fused_loop(M, personalization, ranks, out_scale, *args, **kwargs):
+            return ranks
+        self._start(backend.graph_dropout(M, graph_dropout), personalization, ranks, *args, **kwargs)
+        while not self.convergence.has_converged(ranks.np):                       # :60 the hot loop
+            self._step(backend.graph_dropout(M, graph_dropout), personalization, ranks, *args, **kwargs)
+        self._end(backend.graph_dropout(M, graph_dropout), personalization, ranks, *args, **kwargs)
+        if self.preserve_norm:                                                    # :63-64
+            ranks.np = ranks.np * norm
+        return ranks
+
+    # ---- hooks
+    def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
+        """Runs the whole loop inside the engine when the configuration allows it; returns True when it did."""
+        return False
+
+    def _loop_cfg(self, alpha=0.0, use_quotient=False, out_scale=1.0):
+        cm = self.convergence
+        if type(cm) is not ConvergenceManager:
+            return None
+        kind = cm.device_error_kind()
+        if kind is None:
+            return None
+        return L.LoopCfg(alpha=float(alpha), use_quotient=1 if use_quotient else 0, err_kind=kind,
+                         tol=float(cm.effective_tolerance()), max_iters=int(cm.max_iters),
+                         end_modulo=int(cm.end_modulo), out_scale=float(out_scale))
+
+    def _prepare_graph(self, graph, *args, **kwargs):
+        return graph
+
+    def _start(self, M, personalization, ranks, *args, **kwargs):
+        pass
+
+    def _end(self, M, personalization, ranks, *args, **kwargs):
+        pass
+
+    def _step(self, M, personalization, ranks, *args, **kwargs):
+        raise Exception("Use a derived class of GraphFilter that implements the _step method")
+
+    def references(self):
+        return ["graph filter \\cite{ortega2018graph}"]
+
+    def cite(self):
+        ret = super().cite()
+        if isinstance(self.personalization_transform, Tautology) and self.personalization_transform.ranker is None:
+            return ret
+        return self.personalization_transform.cite() + "\n  passed to " + ret
+
+    def __add__(self, other):                                                     # abstract_filters.py:86-95
+        if isinstance(other, ConvergenceManager):
+            self.convergence = other
+        elif hasattr(other, "__name__") and other.__name__ == "preprocess":
+            self.preprocessor = other
+        elif isinstance(other, Postprocessor):
+            self.use_quotient = other
+        else:
+            raise Exception("Can only add convergence managers and preprocessors to graph filters")
+        return self
+
+    def __lshift__(self, ranker):                                                 # abstract_filters.py:97-101
+        if not isinstance(ranker, NodeRanking):
+            raise Exception("pygrank can only shift rankers into filters")
+        self.personalization_transform = ranker
+        return ranker
+
+
+# =====================================================================================================
+# recursive filters
+# =====================================================================================================
+class RecursiveGraphFilter(GraphFilter):
+    """abstract_filters.py:104-149: ranks = formula(G, ranks), optional L1 quotient per step."""
+
+    def __init__(self, use_quotient=True, converge_to_eigenvectors=False, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.use_quotient = use_quotient
+        self.converge_to_eigenvectors = converge_to_eigenvectors
+
+    def _step(self, M, personalization, ranks, *args, **kwargs):                  # abstract_filters.py:126-136
+        ranks.np = self._formula(M, personalization, ranks, *args, **kwargs)
+        if isinstance(ranks.np, GraphSignal):
+            ranks.np = ranks.np.np
+        if isinstance(self.use_quotient, Postprocessor):
+            ranks.np = self.use_quotient(ranks)
+        elif self.use_quotient:
+            ranks.np = backend.safe_div(ranks, backend.sum(ranks))
+        if self.converge_to_eigenvectors:
+            personalization.np = ranks.np
+
+    def _formula(self, M, personalization, ranks, *args, **kwargs):
+        raise Exception("Use a derived class of RecursiveGraphFilter that implements the _formula method")
+
+    def _plain_quotient(self):
+        return (self.use_quotient is None or isinstance(self.use_quotient, (bool, int))) \
+            and not self.converge_to_eigenvectors
+
+    def _run_recursive(self, entry, g, cfg, ranks, *vectors):
+        if cfg is None or g is None or g.shape[0] != g.shape[1]:
+            return False
+        x = ranks.np
+        if not isinstance(x, DeviceVector):
+            return False
+        res = L.LoopResult()
+        L.check(entry(g._h, *[v._h for v in vectors], x._h, C.byref(cfg), C.byref(res)))
+        ranks.np = x                       # updated in place by the engine; drops the host mirror
+        self.last_loop = dict(iterations=res.iterations, converged=bool(res.converged), spmv=res.spmv_count,
+                              last_error=res.last_error, loop_ms=res.loop_ms)
+        self.convergence.finish_device_loop(res.iterations, res.converged)
+        return True
+
+    def references(self):
+        refs = super().references()
+        if self.converge_to_eigenvectors:
+            refs += ["unbiased eigenvector convergence \\cite{krasanakis2018venuerank}"]
+        return refs
+
+
+class PageRank(RecursiveGraphFilter):
+    """adhoc.py:9-46: r <- alpha * M^T r + (1 - alpha) * p."""
+
+    def __init__(self, alpha=0.85, *args, **kwargs):
+        self.alpha = alpha
+        super().__init__(*args, **kwargs)
+
+    def _formula(self, M, personalization, ranks, *args, **kwargs):               # adhoc.py:34-36
+        return backend.conv(ranks, M) * self.alpha + personalization * (1 - self.alpha)
+
+    def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
+        if args or kwargs or not self._plain_quotient() or type(self)._formula is not PageRank._formula \
+                or type(self)._step is not RecursiveGraphFilter._step:
+            return False
+        cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), out_scale)
+        p = personalization.np
+        if not isinstance(p, DeviceVector):
+            return False
+        return self._run_recursive(L.lib().pgh_ppr_run, _device_graph(M), cfg, ranks, p)
+
+    def references(self):
+        refs = super().references()
+        refs[0] = "personalized PageRank \\cite{page1999pagerank}"
+        refs.insert(1, f"diffusion rate {self.alpha:.3f}")
+        return refs
+
+
+class AbsorbingWalks(RecursiveGraphFilter):
+    """adhoc.py:125-174: partially absorbing random walks."""
+
+    def __init__(self, alpha=1 - 1.E-6, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.alpha = alpha
+
+    def _start(self, M, personalization, ranks, absorption=None, **kwargs):       # adhoc.py:157-159
+        self.absorption = to_signal(personalization.graph, absorption) * ((1 - self.alpha) / self.alpha)
+        self.degrees = backend.degrees(M)
+
+    def _end(self, *args, **kwargs):
+        super()._end(*args, **kwargs)
+        del self.absorption
+        del self.degrees
+
+    def _formula(self, M, personalization, ranks, *args, **kwargs):               # adhoc.py:166-169
+        return (backend.conv(ranks, M) * self.degrees + personalization * self.absorption) / \
+            (self.absorption + self.degrees)
+
+    def _fused_loop(self, M, personalization, ranks, out_scale, *args, absorption=None, **kwargs):
+        if args or kwargs or not self._plain_quotient() or type(self)._formula is not AbsorbingWalks._formula \
+                or type(self)._step is not RecursiveGraphFilter._step:
+            return False
+        cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), out_scale)
+        p = personalization.np
+        if not isinstance(p, DeviceVector):
+            return False
+        lam = (to_signal(personalization.graph, absorption) * ((1 - self.alpha) / self.alpha)).np
+        return self._run_recursive(L.lib().pgh_absorb_run, _device_graph(M), cfg, ranks, p, lam)
+
+    def references(self):
+        refs = super().references()
+        refs[0] = "partially absorbing random walks \\cite{wu2012learning}"
+        return refs
+
+
+class LowPassRecursiveGraphFilter(GraphFilter):
+    """low_pass.py:61-91: recursive low-pass filter with per-iteration parameters."""
+
+    def __init__(self, params=None, *args, **kwargs):
+        if params is None:
+            params = [0.9] * 10
+        super().__init__(*args, **kwargs)
+        self.params = params
+
+    def _step(self, M, personalization, ranks, *args, **kwargs):
+        if self.convergence.iteration > len(self.params):
+            return 0
+        param = self.params[self.convergence.iteration - 1]
+        if param == 0:
+            return ranks
+        if param == 1:
+            ranks.np = backend.conv(ranks, M).np
+            return ranks
+        ranks.np = (backend.conv(ranks, M) * param + personalization * (1 - param)).np
+
+
+class ImpulseGraphFilter(GraphFilter):
+    """low_pass.py:29-58: filter defined by its impulse-response parameters."""
+
+    def __init__(self, params=None, *args, **kwargs):
+        if params is None:
+            params = [0.9] * 10
+        super().__init__(*args, **kwargs)
+        self.params = params
+
+    def _step(self, M, personalization, ranks, *args, **kwargs):
+        if self.convergence.iteration > len(self.params):
+            return 0
+        param = self.params[self.convergence.iteration - 1]
+        if param == 0:
+            return ranks
+        if param == 1:
+            ranks.np = backend.conv(ranks, M).np
+            return ranks
+        ranks.np = (backend.conv(ranks, M) * param + ranks * (1 - param)).np
+
+
+# =====================================================================================================
+# closed-form (polynomial) filters
+# =====================================================================================================
+class ClosedFormGraphFilter(GraphFilter):
+    """abstract_filters.py:152-270: sum_k c_k (M^T)^k p with Taylor or the reference's "chebyshev" recurrence."""
+
+    def __init__(self, krylov_dims=None, coefficient_type="taylor", optimization_dict=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if krylov_dims is not None:
+            raise NotImplementedError("the Krylov-space approximation (krylov_space.py) is outside the propagation "
+                                      "hot path of this build (SURVEY.md 2 row 16)")
+        self.krylov_dims = None
+        self.coefficient_type = coefficient_type.lower()
+        self.optimization_dict = optimization_dict
+        self._active_dict = None
+
+    def references(self):
+        refs = super().references()
+        if self.coefficient_type == "chebyshev":
+            refs.append("Chebyshev coefficients \\cite{yu2021chebyshev}")
+        if self.optimization_dict is not None:
+            refs.append("dictionary-based hashing \\cite{krasanakis2022pygrank}")
+        return refs
+
+    def _start(self, M, personalization, ranks, *args, **kwargs):                 # abstract_filters.py:196-213
+        self.coefficient = None
+        if self.coefficient_type == "chebyshev":
+            self.prev_term = 0
+        self.ranks_power = personalization.np
+        ranks.np = backend.repeat(0.0, backend.length(ranks.np))
+
+    def _recursion(self, result, next_term, next_coefficient):                    # abstract_filters.py:215-230
+        if self.coefficient_type == "chebyshev":
+            if self.convergence.iteration == 2:
+                self.prev_term = next_term
+            if self.convergence.iteration > 2:
+                next_term = 2 * next_term - self.prev_term
+                self.prev_term = next_term
+                if self.coefficient == 0:
+                    return result, next_term
+            return result + next_term * next_coefficient, next_term
+        elif self.coefficient_type == "taylor":
+            if self.coefficient == 0:
+                return result, next_term
+            return result + next_term * next_coefficient, next_term
+        raise Exception("Invalid coefficient type")
+
+    def _prepare(self, personalization):                                          # abstract_filters.py:232-239
+        if self.optimization_dict is not None:
+            pid = obj2id(personalization)
+            if pid not in self.optimization_dict:
+                self.optimization_dict[pid] = dict()
+            self._active_dict = self.optimization_dict[pid]
+        else:
+            self._active_dict = None
+
+    def _retrieve_power(self, ranks_power, M):                                    # abstract_filters.py:241-246
+        if self._active_dict is not None:
+            if self.convergence.iteration not in self._active_dict:
+                self._active_dict[self.convergence.iteration] = backend.conv(ranks_power, M)
+            return self._active_dict[self.convergence.iteration]
+        return backend.conv(ranks_power, M)
+
+    def _step(self, M, personalization, ranks, *args, **kwargs):                  # abstract_filters.py:248-256
+        self.coefficient = self._coefficient(self.coefficient)
+        ranks.np, self.ranks_power = self._recursion(ranks.np, self.ranks_power, self.coefficient)
+        self.ranks_power = self._retrieve_power(self.ranks_power, M)
+
+    def _end(self, M, personalization, ranks, *args, **kwargs):                   # abstract_filters.py:258-267
+        del self.ranks_power
+        if self.coefficient_type == "chebyshev":
+            del self.prev_term
+        del self.coefficient
+        self._active_dict = None
+
+    def _coefficient(self, previous_coefficient):
+        raise Exception("Use a derived class of ClosedFormGraphFilter that implements the _coefficient method")
+
+    def _coefficient_schedule(self, count):
+        """c_1 .. c_count exactly as ``_step`` would draw them (``_coefficient`` sees ``convergence.iteration``)."""
+        saved = self.convergence.iteration
+        coeffs, prev = [], None
+        try:
+            for it in range(1, count + 1):
+                self.convergence.iteration = it
+                prev = self._coefficient(prev)
+                coeffs.append(float(prev))
+        finally:
+            self.convergence.iteration = saved
+        return coeffs
+
+    def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
+        if args or kwargs or self.optimization_dict is not None or type(self)._step is not ClosedFormGraphFilter._step \
+                or type(self)._recursion is not ClosedFormGraphFilter._recursion:
+            return False
+        if self.coefficient_type not in ("taylor", "chebyshev"):
+            raise Exception("Invalid coefficient type")
+        cfg = self._loop_cfg(0.0, False, out_scale)
+        g = _device_graph(M)
+        p, x = personalization.np, ranks.np
+        if cfg is None or g is None or g.shape[0] != g.shape[1] or not isinstance(p, DeviceVector) \
+                or not isinstance(x, DeviceVector):
+            return False
+        coeffs = np.asarray(self._coefficient_schedule(max(int(self.convergence.max_iters) - 1, 0)), dtype=np.float64)
+        res = L.LoopResult()
+        L.check(L.lib().pgh_poly_run(g._h, p._h, coeffs.ctypes.data_as(C.c_void_p), len(coeffs),
+                                     1 if self.coefficient_type == "chebyshev" else 0, x._h, C.byref(cfg),
+                                     C.byref(res)))
+        ranks.np = x
+        self.last_loop = dict(iterations=res.iterations, converged=bool(res.converged), spmv=res.spmv_count,
+                              last_error=res.last_error, loop_ms=res.loop_ms)
+        self.convergence.finish_device_loop(res.iterations, res.converged)
+        return True
+
+
+class GenericGraphFilter(ClosedFormGraphFilter):
+    """low_pass.py:5-26: filter defined by its hop weights."""
+
+    def __init__(self, weights=None, **kwargs):
+        super().__init__(**kwargs)
+        self.weights = weights if weights is not None else [0.9] * 10
+
+    def _coefficient(self, _):
+        if self.convergence.iteration > len(self.weights):
+            return 0
+        return self.weights[self.convergence.iteration - 1]
+
+
+class HeatKernel(ClosedFormGraphFilter):
+    """adhoc.py:93-122."""
+
+    def __init__(self, t=3, *args, **kwargs):
+        self.t = t
+        super().__init__(*args, **kwargs)
+
+    def _coefficient(self, previous_coefficient):                                 # adhoc.py:113-116
+        return 1. if previous_coefficient is None else (previous_coefficient * self.t / (self.convergence.iteration + 1))
+
+    def references(self):
+        refs = super().references()
+        refs[0] = "HeatKernel \\cite{chung2007heat}"
+        refs.insert(1, f"emphasis on {self.t}-hop distances")
+        return refs
+
+
+class PageRankClosed(ClosedFormGraphFilter):
+    """adhoc.py:63-90."""
+
+    def __init__(self, alpha=0.85, *args, **kwargs):
+        self.alpha = alpha
+        super().__init__(*args, **kwargs)
+
+    def _coefficient(self, previous_coefficient):                                 # adhoc.py:83-84
+        return 1. if previous_coefficient is None else (previous_coefficient * self.alpha)
+
+    def references(self):
+        refs = super().references()
+        refs[0] = "polynomial personalized PageRank \\cite{page1999pagerank}"
+        refs.insert(1, f"diffusion rate {self.alpha:.3f}")
+        return refs

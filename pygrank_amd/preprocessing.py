@@ -1,0 +1,192 @@
+"""Graph -> normalised CSR -> HBM-resident backend graph, with the reference's caching semantics.
+
+Restates pygrank/core/utils/preprocessing.py (Adjacency :9-28, to_sparse_matrix :50-152, MethodHasher
+:181-230, preprocessor :233-287) and the graph entry points of pygrank/fastgraph (Graph.to_scipy_sparse_array
+fastgraph.py:73-78, AdjacencyWrapper wrapgraph.py:4-22).  As in the reference, normalisation runs on the host
+with scipy for every engine (preprocessing.py:99: ``with backend.Backend("numpy")``); the upload
+``backend.scipy_sparse_to_backend`` (preprocessing.py:144) is where the matrix moves to HBM and is transposed.
+"""
+import uuid
+
+import numpy as np
+import scipy.sparse as sp
+
+from pygrank_amd import backend
+from pygrank_amd.signals import _IdentityMap
+
+
+class Adjacency:
+    """preprocessing.py:9-28: wrapper that lets immutable matrix primitives carry pygrank metadata."""
+
+    def __init__(self, array):
+        self.array = array
+        if hasattr(array, "shape"):
+            self.shape = array.shape
+
+    def _np(self):
+        return self.array
+
+    def sum(self, axis=None):
+        return self.array.sum(axis)
+
+    def tocoo(self):
+        return self.array.tocoo()
+
+    def __len__(self):
+        return len(self.array)
+
+
+class AdjacencyWrapper:
+    """fastgraph/wrapgraph.py:4-22: O(1) wrap of a scipy matrix as a graph whose nodes are range(n)."""
+
+    def __init__(self, adj, directed=True):
+        if hasattr(adj, "array"):
+            adj = adj.array
+        self.adj = adj
+        self.num_nodes = adj.shape[0]
+        self.directed = directed
+
+    def is_directed(self):
+        return self.directed
+
+    def __iter__(self):
+        return iter(range(self.num_nodes))
+
+    def __len__(self):
+        return self.num_nodes
+
+    def to_scipy_sparse_array(self):
+        return self.adj
+
+
+def _row_sums(M):                                           # numpy.py:76-77
+    return np.asarray(M.sum(axis=1)).ravel()
+
+
+def _inv_nonzero(v, sqrt=False):
+    v = np.array(v, dtype=np.float64).ravel()
+    if sqrt:
+        v = np.sqrt(v)
+    nz = v != 0
+    v[nz] = 1.0 / v[nz]                                     # zero-degree rows stay zero (preprocessing.py:111)
+    return v
+
+
+def _scaling(v, shape):
+    return sp.spdiags(v, 0, *shape, format="csr").tocsr()
+
+
+def normalize_adjacency(M, normalization, reduction=None):
+    """The host normalisations of preprocessing.py:109-142 on a scipy CSR matrix."""
+    left_reduction = _row_sums if reduction is None else reduction
+
+    def right_reduction(x):
+        return left_reduction(x.T)
+
+    if normalization == "col":                              # preprocessing.py:109-113
+        return _scaling(_inv_nonzero(left_reduction(M)), M.shape) @ M
+    if normalization == "symmetric":                        # preprocessing.py:131-138
+        return _scaling(_inv_nonzero(left_reduction(M), True), M.shape) @ M @ \
+            _scaling(_inv_nonzero(right_reduction(M), True), M.shape)
+    if normalization == "both":                             # preprocessing.py:123-130
+        return _scaling(_inv_nonzero(left_reduction(M)), M.shape) @ M @ _scaling(_inv_nonzero(right_reduction(M)), M.shape)
+    if normalization == "laplacian":                        # preprocessing.py:114-122
+        M = _scaling(_inv_nonzero(left_reduction(M), True), M.shape) @ M @ \
+            _scaling(_inv_nonzero(right_reduction(M), True), M.shape)
+        return -M + sp.eye(M.shape[0]).tocsr()
+    if callable(normalization):                             # preprocessing.py:139-140
+        return normalization(M)
+    if normalization != "none":
+        raise Exception("Supported normalizations: none, col, symmetric, both, laplacian, auto")
+    return M
+
+
+def graph_to_scipy(G, weight="weight"):
+    """preprocessing.py:103: fastgraph-style graphs expose to_scipy_sparse_array, networkx graphs are converted."""
+    if hasattr(G, "to_scipy_sparse_array"):
+        return G.to_scipy_sparse_array()
+    import networkx as nx
+    return nx.to_scipy_sparse_array(G, weight=weight, dtype=float)
+
+
+def to_sparse_matrix(G, normalization="auto", weight="weight", renormalize=False, reduction=None,
+                     transform_adjacency=lambda x: x, cors=False):
+    """preprocessing.py:50-152.  Returns an ``Adjacency`` whose ``.array`` is the engine's backend graph."""
+    name = backend.backend_name()
+    if hasattr(G, "_pygrank_preprocessed"):                 # preprocessing.py:88-98 (already preprocessed input)
+        cache = G._pygrank_preprocessed
+        if name in cache:
+            return cache[name]
+        ret = Adjacency(backend.scipy_sparse_to_backend(cache["numpy"].array))
+        ret._pygrank_preprocessed = cache if cors else {name: ret}
+        ret._pygrank_preprocessed[name] = ret
+        ret._pygrank_node2id = G._pygrank_node2id
+        return ret
+    normalization = normalization.lower() if isinstance(normalization, str) else normalization
+    if normalization == "auto":                             # preprocessing.py:101-102
+        normalization = "col" if G.is_directed() else "symmetric"
+    M = sp.csr_array(graph_to_scipy(G, weight), dtype=np.float64)
+    renormalize = float(renormalize)
+    if renormalize != 0:                                    # preprocessing.py:107-108
+        M = M + sp.eye(M.shape[0]).tocsr() * renormalize
+    M = sp.csr_array(normalize_adjacency(M, normalization, reduction))
+    M = transform_adjacency(M)                              # preprocessing.py:143
+    ret = Adjacency(backend.scipy_sparse_to_backend(M))     # preprocessing.py:144-145: upload to HBM
+    if cors:                                                # preprocessing.py:146-148
+        ret._pygrank_preprocessed = {name: ret, "numpy": Adjacency(M)}
+    else:
+        ret._pygrank_preprocessed = {name: ret}
+    if isinstance(G, AdjacencyWrapper):
+        ret._pygrank_node2id = _IdentityMap(len(G))         # {v: i} over range(n) without n dict entries
+    else:
+        ret._pygrank_node2id = {v: i for i, v in enumerate(G)}   # preprocessing.py:151
+    return ret
+
+
+def obj2id(obj):                                            # preprocessing.py:165-170
+    if isinstance(obj, object) and not isinstance(obj, str):
+        if not hasattr(obj, "uuid"):
+            obj.uuid = uuid.uuid1()
+        return str(obj.uuid)
+    return str(hash(obj))
+
+
+def _idfier(*args, **kwargs):                               # preprocessing.py:173-178
+    return "[" + ",".join(obj2id(arg) for arg in args) + "]" + \
+        "{" + ",".join(v + ":" + obj2id(kwarg) for v, kwarg in kwargs.items()) + "}" + backend.backend_name()
+
+
+class MethodHasher:
+    """preprocessing.py:181-230: memoises a method on the identity of its arguments and the backend name."""
+
+    def __init__(self, method, assume_immutability=True):
+        self.assume_immutability = assume_immutability
+        self._method = method
+        self._stored = dict()
+
+    def clear_hashed(self):
+        self._stored = dict()
+
+    def __call__(self, *args, **kwargs):
+        if not self.assume_immutability:
+            return self._method(*args, **kwargs)
+        desc = _idfier(*args, **kwargs)
+        if desc not in self._stored:
+            self._stored[desc] = self._method(*args, **kwargs)
+        return self._stored[desc]
+
+
+def preprocessor(normalization="auto", assume_immutability=False, weight="weight", renormalize=False,
+                 reduction=None, transform_adjacency=lambda x: x, cors=False):
+    """preprocessing.py:233-287."""
+    if assume_immutability:
+        ret = MethodHasher(preprocessor(assume_immutability=False, normalization=normalization, weight=weight,
+                                        renormalize=renormalize, reduction=reduction, cors=cors,
+                                        transform_adjacency=transform_adjacency))
+        ret.__name__ = "preprocess"
+        return ret
+
+    def preprocess(G):
+        return to_sparse_matrix(G, normalization=normalization, weight=weight, renormalize=renormalize,
+                                reduction=reduction, cors=cors, transform_adjacency=transform_adjacency)
+    return preprocess

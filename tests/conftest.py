@@ -35,3 +35,41 @@ def graphs():
             cache[key] = cases.GRAPHS[key]()
         return cache[key]
     return get
+
+
+def _ensure_oracle_built():
+    import subprocess
+    build = os.path.join(ROOT, "oracle", "_build")
+    if not (os.path.exists(os.path.join(build, "libpgh_host_oracle.so"))
+            and os.path.exists(os.path.join(build, "liboracle_spmv.so"))):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    return build
+
+
+@pytest.fixture(scope="session")
+def oracle_build_dir():
+    return _ensure_oracle_built()
+
+
+@pytest.fixture()
+def host_engine(oracle_build_dir):
+    """Routes pygrank_amd's ctypes binding to the host test double (oracle/host_abi.cpp) for CPU tests of
+    the host-side Python.  The product never does this."""
+    import ctypes
+    import pygrank_amd as pg
+    from pygrank_amd import _lib
+    _lib._install_test_double(ctypes.CDLL(os.path.join(oracle_build_dir, "libpgh_host_oracle.so")))
+    pg.load_backend("hip")
+    yield pg
+    _lib._remove_test_double()
+
+
+@pytest.fixture(scope="session")
+def gpu_engine():
+    """The real engine: libpgh_hip.so on an MI355X (tests marked gpu)."""
+    import pygrank_amd as pg
+    from pygrank_amd import _lib
+    assert not _lib._is_test_double
+    pg.load_backend("hip")
+    assert _lib.runtime_name().startswith("hip:")
+    return pg

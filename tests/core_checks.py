@@ -1,0 +1,322 @@
+"""Engine-agnostic check bodies (take the loaded ``pygrank_amd`` module).  Each restates assertions of the
+reference's own tests; file:line given per check."""
+import networkx as nx
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ref_loops as orc
+
+
+def _graph9():
+    """Stand-in for the reference's downloaded 'graph9': 9 nodes A..I, undirected."""
+    G = nx.Graph()
+    G.add_edges_from([("A", "B"), ("A", "C"), ("B", "C"), ("C", "D"), ("D", "E"), ("E", "F"), ("F", "G"),
+                      ("G", "H"), ("H", "I"), ("D", "F"), ("B", "E")])
+    return G
+
+
+def check_primitive_conversion(pg):                          # tests/test_core.py:25-33
+    assert pg.obj2id("str") == str(hash("str"))
+    assert pg.sum(pg.to_array([1, 2, 3])) == 6
+    assert pg.sum(pg.dot(pg.exp(pg.log(pg.to_array([4, 5]))), pg.to_array([2, 2]))) == pytest.approx(18, rel=1e-6)
+    primitive = pg.to_array([1, 2, 3])
+    assert id(primitive) == id(pg.to_array(primitive, copy_array=False))
+    assert id(primitive) != id(pg.to_array(primitive, copy_array=True))
+
+
+def check_separate_and_combine(pg):                          # tests/test_core.py:36-44
+    table = pg.to_primitive([[1, 2, 3], [4, 5, 6]])
+    cols = pg.separate_cols(table)
+    assert len(cols) == 3
+    for col in cols:
+        assert pg.length(col) == 2
+    new_table = pg.combine_cols(cols)
+    assert pg.sum(pg.abs(table - new_table)) == 0
+
+
+def check_signal_init(pg):                                   # tests/test_core.py:74-83
+    with pytest.raises(Exception):
+        pg.GraphSignal([1, 2, 3], [1, 2])
+    signal = pg.GraphSignal(_graph9(), {"A": 1, "B": 2})
+    del signal["A"]
+    assert signal["A"] == 0
+    assert signal["B"] == 2
+
+
+def check_backend_load(pg):                                  # tests/test_core.py:91-101
+    assert pg.backend_name() == "hip"
+    with pytest.raises(Exception):
+        pg.load_backend("unknown")
+    with pytest.raises(Exception):
+        pg.load_backend("numpy")          # this build ships exactly one engine
+    assert pg.backend_name() == "hip"
+    with pg.Backend("hip") as backend:
+        assert backend.backend_name() == "hip"
+    assert pg.backend_name() == "hip"
+
+
+def check_signal_direct_operations(pg):                      # tests/test_core.py:122-155
+    graph = nx.DiGraph([(1, 2), (2, 3)])
+    signal = pg.to_signal(graph, [1., 2., 3.])
+    assert pg.sum(signal) == 6
+    assert pg.sum(signal + 1) == 9
+    assert pg.sum(1 + signal) == 9
+    assert pg.sum(signal ** 2) == 14
+    assert pg.sum(signal - pg.to_signal(graph, [1, 2, 2])) == 1
+    assert pg.sum(-1 + signal) == 3
+    assert pg.sum(signal / pg.to_signal(graph, [1., 2., 3.])) == 3
+    assert pg.sum(3 ** signal) == 3 + 9 + 27
+    signal **= 2
+    assert pg.sum(signal) == 14
+    signal.np = pg.to_signal(graph, [4, 4, 4])
+    assert pg.sum(signal) == 12
+    assert pg.sum(+signal) == 12
+    assert pg.sum(-signal) == -12
+    assert pg.sum(-signal / 2) == -6
+    assert pg.sum(2 / signal) == 1.5
+    signal += 1
+    assert pg.sum(signal) == 15
+    signal -= 1
+    assert pg.sum(signal) == 12
+    signal /= 2
+    assert pg.sum(signal) == 6
+    signal /= 2
+    assert pg.sum(signal) == 3
+    signal *= 4
+    assert pg.sum(signal) == 12
+    with pytest.raises(Exception):
+        signal + pg.to_signal(graph.copy(), [1., 2., 3.])
+
+
+def check_vector_protocol(pg):                               # SURVEY.md 8a row a4 operator protocol
+    x = pg.to_array([3., -1., 0., 2.])
+    y = pg.to_array([1., 1., 2., 2.])
+    assert np.allclose(np.asarray(x > y), [1, 0, 0, 0])
+    assert np.allclose(np.asarray(x != y), [1, 1, 1, 0])
+    assert np.allclose(np.asarray(x == y), [0, 0, 0, 1])
+    assert np.allclose(np.asarray(pg.filter_out(x, pg.to_array([0., 1., 0., 1.]))), [3., 0.])
+    assert np.allclose(np.asarray(x[x > 0]), [3., 2.])
+    assert float(x[1]) == -1.0
+    x[1] = 5.0
+    assert float(x[1]) == 5.0
+    assert pg.max(x) == 5 and pg.min(x) == 0 and pg.mean(x) == 2.5
+    assert pg.length(x) == 4 and pg.is_array(x) and pg.is_array([1]) and not pg.is_array(3.0)
+    assert np.allclose(np.asarray(pg.repeat(0.5, 3)), [0.5] * 3)
+    z = pg.self_normalize(pg.to_array([1., -1., 2.]))
+    assert np.allclose(np.asarray(z), [0.25, -0.25, 0.5])
+    assert np.allclose(np.asarray(pg.safe_inv(pg.to_array([2., 0., 4.]))), [0.5, 0., 0.25])
+    assert pg.epsilon() == float(np.finfo(np.float32).eps)
+    assert pg.sum(pg.abs(pg.to_array([]))) == 0
+    assert np.allclose(np.asarray(pg.to_array(np.ones((3, 1)))), [1, 1, 1])     # (n, 1) is flattened
+    assert pg.cast(x) is x and pg.graph_dropout("M", 0) == "M"
+
+
+def check_preprocessor_types(pg):                            # tests/test_preprocessor.py:6-15
+    graph = _graph9()
+    rng = np.random.default_rng(0)
+    signal = pg.to_signal(graph, {v: rng.random() for v in graph})
+    laplacian = pg.preprocessor(normalization="laplacian")(graph)
+    symmetric = pg.preprocessor(normalization="symmetric")(graph)
+    assert abs(pg.sum(pg.conv(signal, laplacian) + pg.conv(signal, symmetric) - signal)) <= 4 * pg.epsilon()
+
+
+def check_preprocessor_hashing(pg):                          # tests/test_preprocessor.py:18-46
+    with pytest.raises(Exception):
+        pg.preprocessor(normalization="unknown", assume_immutability=True)(_graph9())
+    pre = pg.preprocessor(normalization="col", assume_immutability=False)
+    graph = _graph9()
+    assert id(pre(graph)) != id(pre(graph))
+    pre = pg.MethodHasher(pg.preprocessor, assume_immutability=True)
+    graph = _graph9()
+    res1 = pre(graph)
+    pre.assume_immutability = False
+    assert id(res1) != id(pre(graph))
+    pre = pg.preprocessor(normalization="col", assume_immutability=True)
+    graph = _graph9()
+    res1 = pre(graph)
+    assert id(res1) == id(pre(graph))
+    pre.clear_hashed()
+    assert id(res1) != id(pre(graph))
+
+
+def check_upload_matches_reference_normalisation(pg):        # preprocessing.py:99-144 + numpy.py:76-77
+    rng = np.random.default_rng(3)
+    A = sp.random(60, 60, density=0.1, random_state=np.random.RandomState(5), format="csr")
+    A = sp.csr_array(A)
+    for normalization in ["col", "symmetric", "both", "laplacian", "none"]:
+        for renorm in [False, True]:
+            M = orc.normalize(A, normalization, True, float(renorm))
+            adj = pg.preprocessor(normalization=normalization, renormalize=renorm)(pg.AdjacencyWrapper(A, directed=True))
+            got = adj.array.download_transposed()
+            assert np.allclose(got.toarray(), M.T.toarray(), rtol=2e-7, atol=1e-12)
+            assert np.allclose(np.asarray(pg.degrees(adj)), orc.row_sums(M), rtol=2e-7, atol=1e-7)
+            x = rng.random(60)
+            assert np.allclose(np.asarray(pg.conv(pg.to_array(x), adj)), x @ M, rtol=2e-6, atol=1e-7)
+
+
+def check_zero_personalization(pg):                          # tests/test_filters.py:9-10
+    assert pg.sum(pg.PageRank()(_graph9(), {}).np) == 0
+
+
+def check_abstract_filter_types(pg):                         # tests/test_filters.py:13-20
+    graph = _graph9()
+    for cls in (pg.GraphFilter, pg.RecursiveGraphFilter, pg.ClosedFormGraphFilter):
+        with pytest.raises(Exception):
+            cls().rank(graph)
+
+
+def check_invalid_parameters(pg):                            # tests/test_filters.py:24-29, test_core.py:21-22
+    graph = _graph9()
+    with pytest.raises(Exception):
+        pg.HeatKernel(normalization="unknown").rank(graph)
+    with pytest.raises(Exception):
+        pg.HeatKernel(coefficient_type="unknown").rank(graph)
+    with pytest.raises(Exception):
+        pg.PageRank(krylov_dims=5)
+    with pytest.raises(Exception):
+        pg.PageRank().rank(list(graph))                      # tests/test_filters.py:53-56
+
+
+def check_convergence_string(pg):                            # tests/test_filters.py:32-38
+    ranker = pg.PageRank() >> pg.Normalize()
+    ranker(_graph9())
+    assert str(ranker.convergence.iteration) + " iterations" in str(ranker.convergence)
+
+
+def check_pagerank_vs_networkx(pg):                          # tests/test_filters.py:41-50
+    graph = _graph9().to_directed()
+    ranker = pg.Normalize("sum", pg.PageRank(normalization="col", tol=1e-9, max_iters=1000))
+    want = nx.pagerank(graph, tol=1e-12)
+    got = ranker(graph)
+    assert max(abs(got[v] - want[v]) for v in graph) < 5e-7   # fp32 engine: eps-level agreement in fp32
+
+
+def check_non_convergence(pg):                               # tests/test_filters.py:59-62
+    with pytest.raises(Exception):
+        pg.PageRank(max_iters=5).rank(_graph9())
+
+
+def check_custom_runs(pg):                                   # tests/test_filters.py:65-72
+    graph = _graph9()
+    tol = pg.epsilon()
+    ranks1 = pg.Normalize(pg.PageRank(0.85, tol=tol, max_iters=1000, use_quotient=False)).rank(graph, {"A": 1})
+    ranks2 = pg.Normalize(pg.GenericGraphFilter([0.85 ** i * len(graph) for i in range(80)], tol=tol)).rank(graph, {"A": 1})
+    ranks3 = pg.Normalize(pg.LowPassRecursiveGraphFilter([0.85 for _ in range(80)], tol=tol)).rank(graph, {"A": 1})
+    assert pg.Mabs(ranks1)(ranks2) < 1.E-6
+    assert pg.Mabs(ranks1)(ranks3) < 1.E-6
+
+
+def check_stream(pg):                                        # tests/test_filters.py:85-98
+    graph = _graph9()
+    ranks1 = pg.Normalize(pg.PageRank(0.85, tol=pg.epsilon(), max_iters=1000, use_quotient=False)).rank(graph, {"A": 1})
+    ranks2 = pg.to_signal(graph, {"A": 1}) >> pg.PageRank(0.85, tol=pg.epsilon(), max_iters=1000) + pg.Tautology() >> pg.Normalize()
+    assert pg.Mabs(ranks1)(ranks2) < 4 * pg.epsilon()
+    ranks1 = pg.GenericGraphFilter([0, 0, 1], max_iters=4, error_type="iters") | pg.to_signal(graph, {"A": 1})
+    ranks2 = pg.GenericGraphFilter([1, 1, 1], tol=None) & ~pg.GenericGraphFilter([1, 1], tol=None) | pg.to_signal(graph, {"A": 1})
+    assert pg.Mabs(ranks1)(ranks2) < 4 * pg.epsilon()
+
+
+def check_quotient(pg):                                      # tests/test_filters.py:118-135
+    graph = _graph9()
+    tol = max(1.E-9, pg.epsilon())
+    a = pg.PageRank(normalization="symmetric", tol=tol, use_quotient=True).rank(graph)
+    b = pg.PageRank(normalization="symmetric", tol=tol, use_quotient=pg.Normalize("sum")).rank(graph)
+    assert pg.Mabs(a)(b) < 4 * pg.epsilon()
+    c = pg.Normalize(pg.PageRank(normalization="symmetric", tol=tol, use_quotient=True)).rank(graph)
+    d = pg.PageRank(tol=tol) + pg.preprocessor(normalization="symmetric") + pg.Normalize("sum") >> pg.Normalize() \
+        | pg.to_signal(graph, {v: 1 for v in graph})
+    assert pg.Mabs(c)(d) < 4 * pg.epsilon()
+
+
+def check_automatic_graph_casting(pg):                       # tests/test_filters.py:138-148
+    graph = _graph9()
+    signal = pg.to_signal(graph, {"A": 1})
+    r1 = pg.PageRank(normalization="col").rank(signal, signal)
+    r2 = pg.PageRank(normalization="col").rank(personalization=signal)
+    assert pg.Mabs(r1)(r2) < pg.epsilon()
+    with pytest.raises(Exception):
+        pg.PageRank(normalization="col").rank(personalization={"A": 1})
+    with pytest.raises(Exception):
+        pg.PageRank(normalization="col").rank(graph.copy(), signal)
+
+
+def check_absorbing_vs_pagerank(pg):                         # tests/test_filters.py:151-157
+    graph = _graph9()
+    p = {"A": 1, "B": 1}
+    a = pg.PageRank(normalization="col").rank(graph, p)
+    b = pg.AbsorbingWalks(0.85, normalization="col", max_iters=1000).rank(graph, p)
+    assert pg.Mabs(a)(b) < 4 * pg.epsilon()
+
+
+def check_lowpass_vs_pagerank(pg):                           # tests/test_filters.py:160-166
+    graph = _graph9()
+    p = {"A": 1, "B": 1}
+    a = pg.PageRank(0.9, use_quotient=False, max_iters=11, error_type="iters").rank(graph, p)
+    b = pg.LowPassRecursiveGraphFilter().rank(graph, p)
+    assert pg.Mabs(a)(b) < 4 * pg.epsilon()
+
+
+def check_kernel_locality(pg):                               # tests/test_filters.py:169-177
+    graph = _graph9()
+    p = {"A": 1, "B": 1}
+    a = pg.Normalize("sum", pg.PageRank(max_iters=1000)).rank(graph, p)
+    b = pg.Normalize("sum", pg.HeatKernel(max_iters=1000)).rank(graph, p)
+    assert a["A"] < b["A"]
+    assert a["I"] > b["I"]
+
+
+def check_optimization_dict(pg):                             # tests/test_filters.py:180-197 (cache semantics)
+    graph = _graph9()
+    pre = pg.preprocessor(assume_immutability=True)
+    signal = pg.to_signal(graph, {"A": 1, "B": 1})
+    cache = dict()
+    a = pg.HeatKernel(t=3, preprocessor=pre, optimization_dict=cache, error_type="iters", max_iters=12).rank(signal)
+    assert len(cache) == 1 and len(next(iter(cache.values()))) == 11
+    b = pg.HeatKernel(t=3, preprocessor=pre, optimization_dict=cache, error_type="iters", max_iters=12).rank(signal)
+    c = pg.HeatKernel(t=3, preprocessor=pre, error_type="iters", max_iters=12).rank(signal)
+    assert pg.Mabs(a)(b) == 0
+    assert pg.Mabs(a)(c) < 4 * pg.epsilon()
+
+
+def check_generic_route_equals_fused_route(pg):
+    """The per-step backend-primitive route (reference structure) and the fused device loop agree."""
+    import cases
+    A, directed, p = cases.GRAPHS["rmat10_dir"]()
+    graph = pg.AdjacencyWrapper(A, directed=directed)
+    for make in (lambda **k: pg.PageRank(0.85, tol=1e-6, **k),
+                 lambda **k: pg.PageRank(0.85, use_quotient=False, error_type=pg.L1, tol=1e-6, max_iters=500, **k),
+                 lambda **k: pg.AbsorbingWalks(0.9, tol=1e-6, max_iters=500, **k),
+                 lambda **k: pg.HeatKernel(t=5, error_type="iters", max_iters=21, **k),
+                 lambda **k: pg.HeatKernel(t=5, coefficient_type="chebyshev", error_type="iters", max_iters=21, **k),
+                 lambda **k: pg.GenericGraphFilter([0.5, 0.3, 0, 0.2], tol=1e-7, **k)):
+        fused = make()
+        r_fused = fused.rank(graph, p.copy())
+        assert hasattr(fused, "last_loop")
+        generic = make()
+        generic._fused_loop = lambda *a, **k: False
+        r_generic = generic.rank(graph, p.copy())
+        assert generic.convergence.iteration == fused.convergence.iteration
+        got, want = np.asarray(r_fused.np), np.asarray(r_generic.np)
+        assert np.max(np.abs(got - want)) <= 2e-6 * np.max(np.abs(want))
+
+
+def check_warm_start_and_propagate(pg):                      # abstract_filters.py:47,56; signals.py:225-226
+    import cases
+    A, directed, p = cases.GRAPHS["rmat10_dir"]()
+    graph = pg.AdjacencyWrapper(A, directed=directed)
+    base = pg.PageRank(0.85, tol=1e-7, max_iters=500)
+    r = base.rank(graph, p.copy())
+    iters_cold = base.convergence.iteration
+    warm = pg.PageRank(0.85, tol=1e-7, max_iters=500)
+    r2 = warm.rank(graph, p.copy(), warm_start=np.asarray(r.np) / np.asarray(r.np).sum())
+    assert warm.convergence.iteration < iters_cold
+    assert np.max(np.abs(np.asarray(r2.np) - np.asarray(r.np))) < 1e-5 * np.asarray(r.np).max()
+    feats = np.stack([p, np.roll(p, 7)], axis=1)
+    out = pg.PageRank(0.85).propagate(graph, pg.to_primitive(feats))
+    cols = np.asarray(out)
+    assert cols.shape == (A.shape[0], 2)
+    assert np.allclose(cols[:, 0], np.asarray(pg.PageRank(0.85).rank(graph, p.copy()).np), rtol=1e-6, atol=1e-9)
+
+
+ALL = [v for k, v in sorted(globals().items()) if k.startswith("check_") and callable(v)]
