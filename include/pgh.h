@@ -174,6 +174,17 @@ int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, c
 int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, int32_t chebyshev,
                  pgh_vec_t result, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 
+/* ---------------------------------------------------------------- synthetic workload -------------- */
+/* Graph500-style RMAT generator + normalisation on the device (build-side addition, SURVEY.md 8d: the
+ * reference has no generator).  Produces exactly the edges of oracle/rmat_np.py (integer-exact hash), sums
+ * duplicate edges into weights and keeps self-loops (fastgraph.py:77-78 coo->csr semantics), then applies the
+ * preprocessor's normalisation on the GPU: 0 = "col" (preprocessing.py:109-113), 1 = "symmetric"
+ * (preprocessing.py:131-138), 2 = "none".  symmetrize != 0 builds A + A^T.  Only rows [row_begin, row_end) of
+ * M^T are kept (1-D row partition; row_end <= 0 means all): the graph then maps a full-length
+ * vector to the slice's outputs. */
+int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, double b, double c, uint64_t seed,
+                   int32_t normalization, int32_t symmetrize, int64_t row_begin, int64_t row_end, pgh_graph_t* out);
+
 #ifdef __cplusplus
 }
 #endif

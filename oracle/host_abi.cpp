@@ -577,4 +577,80 @@ int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------ synthetic
+// host restatement of pgh_graph_rmat (same splitmix64 hash and thresholds as oracle/rmat_np.py)
+static inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+int pgh_graph_rmat(int32_t scale, int32_t ef, double a, double b, double c, uint64_t seed, int32_t normalization,
+                   int32_t symmetrize, int64_t row_begin, int64_t row_end, pgh_graph_t* out) {
+    CHECK(scale >= 1 && scale <= 30 && ef >= 1, "pgh_graph_rmat: scale must be in [1, 30]");
+    CHECK(normalization >= 0 && normalization <= 2, "pgh_graph_rmat: normalization must be 0, 1 or 2");
+    const int64_t n = 1LL << scale, E = n * ef;
+    if (row_end <= 0) row_end = n;
+    CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= n, "pgh_graph_rmat: bad row range");
+    const uint32_t ta = (uint32_t)std::floor(a * 4294967296.0), tb = (uint32_t)std::floor((a + b) * 4294967296.0),
+                   tc = (uint32_t)std::floor((a + b + c) * 4294967296.0);
+    std::vector<double> outdeg(n, 0.0), indeg(row_end - row_begin, 0.0);
+    std::vector<uint64_t> keys;
+    for (int64_t e = 0; e < E; ++e) {
+        const uint64_t emix = (uint64_t)e * 0xD6E8FEB86659FD93ULL;
+        uint32_t s = 0, d = 0;
+        for (int pair = 0; pair < (scale + 1) / 2; ++pair) {
+            const uint64_t h = splitmix64(splitmix64(seed * 0x9E3779B97F4A7C15ULL + (uint64_t)(pair + 1)) ^ emix);
+            for (int half = 0; half < 2; ++half) {
+                const int level = 2 * pair + half;
+                if (level >= scale) break;
+                const uint32_t u = half == 0 ? (uint32_t)(h >> 32) : (uint32_t)(h & 0xffffffffu);
+                s |= (uint32_t)(u >= tb) << (scale - 1 - level);
+                d |= (uint32_t)(((u >= ta) && (u < tb)) || (u >= tc)) << (scale - 1 - level);
+            }
+        }
+        outdeg[s] += 1;
+        if (d >= row_begin && d < row_end) keys.push_back(((uint64_t)(d - row_begin) << 32) | s);
+        if (symmetrize) {
+            outdeg[d] += 1;
+            if (s >= row_begin && s < row_end) keys.push_back(((uint64_t)(s - row_begin) << 32) | d);
+        }
+    }
+    std::sort(keys.begin(), keys.end());
+    pgh_graph_s* g = new pgh_graph_s();
+    g->n_rows = n;
+    g->n_cols = row_end - row_begin;
+    std::vector<double> w;
+    std::vector<uint64_t> uk;
+    for (size_t k = 0; k < keys.size(); ++k) {
+        if (k > 0 && keys[k] == keys[k - 1]) w.back() += 1; else { uk.push_back(keys[k]); w.push_back(1); }
+    }
+    for (size_t k = 0; k < uk.size(); ++k) indeg[uk[k] >> 32] += w[k];
+    g->nnz = (int64_t)uk.size();
+    g->rowptr.assign(g->n_cols + 1, 0);
+    g->col.resize(uk.size());
+    g->val.resize(uk.size());
+    std::vector<double> deg(n, 0.0);
+    for (size_t k = 0; k < uk.size(); ++k) {
+        const int64_t row = (int64_t)(uk[k] >> 32);
+        const uint32_t src = (uint32_t)(uk[k] & 0xffffffffu);
+        double v;
+        if (normalization == 0) v = (outdeg[src] != 0 ? 1.0 / outdeg[src] : 0.0) * w[k];
+        else if (normalization == 1) {
+            const double l = std::sqrt(outdeg[src]), r = std::sqrt(indeg[row]);
+            v = ((l != 0 ? 1.0 / l : 0.0) * w[k]) * (r != 0 ? 1.0 / r : 0.0);
+        } else v = w[k];
+        g->col[k] = (int32_t)src;
+        g->val[k] = (float)v;
+        deg[src] += v;
+        g->rowptr[row + 1]++;
+    }
+    for (int64_t r = 0; r < g->n_cols; ++r) g->rowptr[r + 1] += g->rowptr[r];
+    g->degrees.resize(n);
+    for (int64_t i = 0; i < n; ++i) g->degrees[i] = (float)deg[i];
+    *out = g;
+    return 0;
+}
+
 }  // extern "C"

@@ -96,6 +96,8 @@ SIGNATURES = {
     "pgh_absorb_run": (C.c_int, [c_graph, c_vec, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_poly_run": (C.c_int, [c_graph, c_vec, C.c_void_p, C.c_int32, C.c_int32, c_vec, C.POINTER(LoopCfg),
                                C.POINTER(LoopResult)]),
+    "pgh_graph_rmat": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int32,
+                                 C.c_int32, C.c_int64, C.c_int64, C.POINTER(c_graph)]),
 }
 
 # enum values of include/pgh.h

@@ -55,6 +55,14 @@ struct Runtime {
 Runtime& rt();
 int ensure_init();
 
+// merge items (rows + nnz) per thread of a 256-thread workgroup; the tile table is built for 256 * PGH_IPT
+#ifndef PGH_IPT
+#define PGH_IPT 7
+#endif
+// diagnostic builds only (tools/probe_variants.py): 1 = gather from 4 KB, 2 = from 4 MB, 3 = no gather
+#ifndef PGH_PROBE_GATHER
+#define PGH_PROBE_GATHER 0
+#endif
 constexpr int kMaxPartials = 4096;   // upper bound on workgroups contributing block partials
 constexpr int kNumScalars = 64;
 

@@ -17,7 +17,7 @@ using namespace pgh;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kItemsPerTile = 256 * 7;     // must match kIPT in pgh_spmv.hip
+constexpr int kItemsPerTile = 256 * PGH_IPT;
 
 inline int blocks_for(int64_t n, int cap_mult = 16) {
     int64_t b = (n + kBlock - 1) / kBlock;

@@ -1,0 +1,280 @@
+// Synthetic power-law workload on the device: Graph500-style RMAT edges -> normalised CSR(M^T) in HBM.
+//
+// The reference has no generator ("the build writes its own"); this is the build-side input
+// path for BASELINE.json configs[1..4] (RMAT scale 23) and configs[4] (scale 27, row-partitioned).  It also
+// performs, on the GPU, the normalisation the reference's preprocessor does on the host:
+//   "col"        M = D^-1 A                      pygrank/core/utils/preprocessing.py:109-113
+//   "symmetric"  M = Dl^-1/2 A Dr^-1/2           pygrank/core/utils/preprocessing.py:131-138
+// with the same fp64 evaluation order ((1/deg) * w, then * right) before the single rounding to f32, zero-degree
+// rows left zero (preprocessing.py:111), duplicate edges summed into weights and self-loops kept
+// (coo -> csr semantics of pygrank/fastgraph/fastgraph.py:77-78).
+//
+// Edges are a pure function of (seed, edge index): splitmix64 hashes and 32-bit integer thresholds, bit-for-bit
+// the same as oracle/rmat_np.py, so host tests see exactly the graph the GPU builds.  Sorting / run-length
+// encoding use rocPRIM through hipCUB: one-time format construction, not the per-iteration hot path.
+#include "pgh_common.h"
+
+#include <hipcub/hipcub.hpp>
+
+using namespace pgh;
+
+namespace pgh {
+int finish_graph(pgh_graph_s* g);
+}
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct RmatParams {
+    int      scale;
+    int64_t  num_edges;       // generated (directed) edges
+    uint32_t ta, tb, tc;      // quadrant thresholds on a 32-bit uniform
+    uint64_t seed;
+    int      symmetrize;      // also emit (dst, src)
+    int64_t  row_begin, row_end;
+};
+
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ void rmat_edge(const RmatParams& P, uint64_t e, uint32_t& src, uint32_t& dst) {
+    const uint64_t emix = e * 0xD6E8FEB86659FD93ULL;
+    uint32_t s = 0, d = 0;
+    const int pairs = (P.scale + 1) / 2;
+    for (int pair = 0; pair < pairs; ++pair) {
+        const uint64_t key = splitmix64(P.seed * 0x9E3779B97F4A7C15ULL + (uint64_t)(pair + 1));
+        const uint64_t h = splitmix64(key ^ emix);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int level = 2 * pair + half;
+            if (level < P.scale) {
+                const uint32_t u = half == 0 ? (uint32_t)(h >> 32) : (uint32_t)(h & 0xffffffffu);
+                const uint32_t rbit = u >= P.tb;                                    // quadrants c, d
+                const uint32_t cbit = ((u >= P.ta) && (u < P.tb)) || (u >= P.tc);   // quadrants b, d
+                const int shift = P.scale - 1 - level;
+                s |= rbit << shift;
+                d |= cbit << shift;
+            }
+        }
+    }
+    src = s;
+    dst = d;
+}
+
+// pass 1: global out-degree weights (edge multiplicities per source) and number of edges kept by this row range
+__global__ void k_rmat_count(RmatParams P, unsigned int* __restrict__ outdeg, unsigned long long* __restrict__ kept) {
+    unsigned long long local = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < P.num_edges; e += stride) {
+        uint32_t s, d;
+        rmat_edge(P, (uint64_t)e, s, d);
+        atomicAdd(&outdeg[s], 1u);
+        if ((int64_t)d >= P.row_begin && (int64_t)d < P.row_end) ++local;
+        if (P.symmetrize) {
+            atomicAdd(&outdeg[d], 1u);
+            if ((int64_t)s >= P.row_begin && (int64_t)s < P.row_end) ++local;
+        }
+    }
+    // wavefront-aggregate before the global atomic
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(kept, local);
+}
+
+// pass 2: emit sort keys (local_row << 32 | src) for the kept edges
+__global__ void k_rmat_fill(RmatParams P, uint64_t* __restrict__ keys, unsigned long long* __restrict__ cursor, int dense) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < P.num_edges; e += stride) {
+        uint32_t s, d;
+        rmat_edge(P, (uint64_t)e, s, d);
+        if (dense) {                       // whole row range, no symmetrisation: edge e owns slot e (deterministic)
+            keys[e] = ((uint64_t)d << 32) | s;
+            continue;
+        }
+        if ((int64_t)d >= P.row_begin && (int64_t)d < P.row_end) {
+            const unsigned long long pos = atomicAdd(cursor, 1ULL);
+            keys[pos] = ((uint64_t)(d - (uint32_t)P.row_begin) << 32) | s;
+        }
+        if (P.symmetrize && (int64_t)s >= P.row_begin && (int64_t)s < P.row_end) {
+            const unsigned long long pos = atomicAdd(cursor, 1ULL);
+            keys[pos] = ((uint64_t)(s - (uint32_t)P.row_begin) << 32) | d;
+        }
+    }
+}
+
+// in-degree weights of the local rows from the run-length encoded keys
+__global__ void k_indeg(const uint64_t* __restrict__ ukeys, const int* __restrict__ counts, int64_t nnz,
+                        unsigned int* __restrict__ indeg) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += stride)
+        atomicAdd(&indeg[(uint32_t)(ukeys[k] >> 32)], (unsigned int)counts[k]);
+}
+
+// normalised values + column indices + row pointer + row sums of M (degrees)
+__global__ void k_rmat_values(const uint64_t* __restrict__ ukeys, const int* __restrict__ counts, int64_t nnz, int64_t n_local,
+                              int normalization, const unsigned int* __restrict__ outdeg,
+                              const unsigned int* __restrict__ indeg, int32_t* __restrict__ col, float* __restrict__ val,
+                              int32_t* __restrict__ rowptr, double* __restrict__ deg_acc) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += stride) {
+        const uint64_t key = ukeys[k];
+        const int64_t row = (int64_t)(key >> 32);            // local destination row
+        const uint32_t src = (uint32_t)(key & 0xffffffffu);
+        const double w = (double)counts[k];
+        double v;
+        if (normalization == 0) {                            // "col": (1 / rowsum(A)[src]) * w, preprocessing.py:110-113
+            const double s = (double)outdeg[src];
+            v = (s != 0.0 ? 1.0 / s : 0.0) * w;
+        } else if (normalization == 1) {                     // "symmetric": (l * w) * r, preprocessing.py:132-138
+            const double l = sqrt((double)outdeg[src]);
+            const double r = sqrt((double)indeg[row]);
+            v = ((l != 0.0 ? 1.0 / l : 0.0) * w) * (r != 0.0 ? 1.0 / r : 0.0);
+        } else {
+            v = w;
+        }
+        col[k] = (int32_t)src;
+        val[k] = (float)v;
+        atomicAdd(&deg_acc[src], v);                         // row sums of M (numpy.py:76-77); f64, rounded once below
+        const int64_t prev = (k == 0) ? -1 : (int64_t)(ukeys[k - 1] >> 32);
+        for (int64_t r = prev + 1; r <= row; ++r) rowptr[r] = (int32_t)k;
+        if (k == nnz - 1)
+            for (int64_t r = row + 1; r <= n_local; ++r) rowptr[r] = (int32_t)nnz;
+    }
+}
+
+__global__ void k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+
+__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+inline int blocks_for(int64_t n) {
+    int64_t b = (n + kBlock - 1) / kBlock;
+    const int64_t cap = (int64_t)rt().num_cus * 16;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t count, bool zero = false) {
+        PGH_HIP(hipMalloc(&p, sizeof(T) * (count > 0 ? count : 1)));
+        if (zero) PGH_HIP(hipMemsetAsync(p, 0, sizeof(T) * (count > 0 ? count : 1), rt().stream));
+        return 0;
+    }
+};
+
+}  // namespace
+
+extern "C" int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, double b, double c, uint64_t seed,
+                              int32_t normalization, int32_t symmetrize, int64_t row_begin, int64_t row_end,
+                              pgh_graph_t* out) {
+    PGH_TRY(ensure_init());
+    PGH_CHECK(scale >= 1 && scale <= 30 && edge_factor >= 1, "pgh_graph_rmat: scale must be in [1, 30]");
+    PGH_CHECK(normalization >= 0 && normalization <= 2, "pgh_graph_rmat: normalization must be 0 (col), 1 (symmetric) or 2 (none)");
+    const int64_t n = 1LL << scale;
+    if (row_end <= 0) row_end = n;
+    PGH_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= n, "pgh_graph_rmat: bad row range");
+    Runtime& r = rt();
+    RmatParams P;
+    P.scale = scale;
+    P.num_edges = n * (int64_t)edge_factor;
+    P.ta = (uint32_t)floor(a * 4294967296.0);
+    P.tb = (uint32_t)floor((a + b) * 4294967296.0);
+    P.tc = (uint32_t)floor((a + b + c) * 4294967296.0);
+    P.seed = seed;
+    P.symmetrize = symmetrize ? 1 : 0;
+    P.row_begin = row_begin;
+    P.row_end = row_end;
+    const int64_t n_local = row_end - row_begin;
+    const bool dense = (row_begin == 0 && row_end == n && !symmetrize);
+
+    pgh_graph_s* g = new pgh_graph_s();
+    g->n_rows = n;          // rows of M = sources = length of the gathered vector
+    g->n_cols = n_local;    // rows of the stored M^T slice = length of the output
+    int rc = [&]() -> int {
+        DevBuf<unsigned int> outdeg, indeg;
+        DevBuf<unsigned long long> counters;
+        DevBuf<uint64_t> keys_a, keys_b, ukeys;
+        DevBuf<int> counts, num_runs;
+        DevBuf<double> deg_acc;
+        PGH_TRY(outdeg.alloc(n, true));
+        PGH_TRY(indeg.alloc(n_local, true));
+        PGH_TRY(counters.alloc(2, true));
+        k_rmat_count<<<blocks_for(P.num_edges), kBlock, 0, r.stream>>>(P, outdeg.p, counters.p);
+        PGH_HIP(hipGetLastError());
+        unsigned long long kept = 0;
+        PGH_HIP(hipMemcpyAsync(&kept, counters.p, sizeof(kept), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        PGH_CHECK(kept < 2147483647ULL, "pgh_graph_rmat: more than 2^31 edges in one partition; use more partitions");
+        const int64_t K = (int64_t)kept;
+        int64_t nnz = 0;
+        PGH_HIP(hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_local + 1)));
+        PGH_HIP(hipMalloc(&g->degrees, sizeof(float) * (size_t)n));
+        PGH_TRY(deg_acc.alloc(n, true));
+        if (K > 0) {
+            PGH_TRY(keys_a.alloc(K));
+            PGH_TRY(keys_b.alloc(K));
+            k_rmat_fill<<<blocks_for(P.num_edges), kBlock, 0, r.stream>>>(P, keys_a.p, counters.p + 1, dense ? 1 : 0);
+            PGH_HIP(hipGetLastError());
+            int bits_row = 1;
+            while ((1LL << bits_row) < n_local) ++bits_row;
+            size_t temp_bytes = 0;
+            PGH_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_a.p, keys_b.p, (int)K, 0, 32 + bits_row, r.stream));
+            {
+                DevBuf<char> temp;
+                PGH_TRY(temp.alloc(temp_bytes));
+                PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)K, 0, 32 + bits_row, r.stream));
+                PGH_HIP(hipStreamSynchronize(r.stream));
+            }
+            // run-length encode duplicates into weights; keys_a is reused for the unique keys
+            PGH_TRY(counts.alloc(K));
+            PGH_TRY(num_runs.alloc(1));
+            temp_bytes = 0;
+            PGH_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, temp_bytes, keys_b.p, keys_a.p, counts.p, num_runs.p, (int)K, r.stream));
+            {
+                DevBuf<char> temp;
+                PGH_TRY(temp.alloc(temp_bytes));
+                PGH_HIP(hipcub::DeviceRunLengthEncode::Encode(temp.p, temp_bytes, keys_b.p, keys_a.p, counts.p, num_runs.p, (int)K, r.stream));
+                int runs = 0;
+                PGH_HIP(hipMemcpyAsync(&runs, num_runs.p, sizeof(int), hipMemcpyDeviceToHost, r.stream));
+                PGH_HIP(hipStreamSynchronize(r.stream));
+                nnz = runs;
+            }
+            PGH_HIP(hipMalloc(&g->col, sizeof(int32_t) * (size_t)nnz));
+            PGH_HIP(hipMalloc(&g->val, sizeof(float) * (size_t)nnz));
+            k_indeg<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_a.p, counts.p, nnz, indeg.p);
+            k_rmat_values<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_a.p, counts.p, nnz, n_local, normalization, outdeg.p,
+                                                                    indeg.p, g->col, g->val, g->rowptr, deg_acc.p);
+            PGH_HIP(hipGetLastError());
+        } else {
+            PGH_HIP(hipMalloc(&g->col, sizeof(int32_t)));
+            PGH_HIP(hipMalloc(&g->val, sizeof(float)));
+            k_fill_i32<<<blocks_for(n_local + 1), kBlock, 0, r.stream>>>(g->rowptr, n_local + 1, 0);
+        }
+        g->nnz = nnz;
+        k_f64_to_f32<<<blocks_for(n), kBlock, 0, r.stream>>>(deg_acc.p, g->degrees, n);
+        PGH_HIP(hipGetLastError());
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        return finish_graph(g);
+    }();
+    if (rc != 0) {
+        std::string keep = pgh_last_error();
+        pgh_graph_destroy(g);
+        return fail(keep);
+    }
+    *out = g;
+    return 0;
+}

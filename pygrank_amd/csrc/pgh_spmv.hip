@@ -139,7 +139,15 @@ __global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EpiParams ep, co
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
             const int idx = k * WG + tid;
+#if PGH_PROBE_GATHER == 1
+            if (idx < tile_nnz) s_prod[idx] = vals[k] * x[cidx[k] & 1023];
+#elif PGH_PROBE_GATHER == 2
+            if (idx < tile_nnz) s_prod[idx] = vals[k] * x[cidx[k] & 0xFFFFF];
+#elif PGH_PROBE_GATHER == 3
+            if (idx < tile_nnz) s_prod[idx] = vals[k] * (float)cidx[k];
+#else
             if (idx < tile_nnz) s_prod[idx] = vals[k] * x[cidx[k]];
+#endif
         }
         __syncthreads();
 
@@ -363,7 +371,7 @@ __global__ void k_scale_copy(const float* __restrict__ in, float* __restrict__ o
 // -------------------------------------------------------------------------------------------------
 // host-side launch helpers
 // -------------------------------------------------------------------------------------------------
-constexpr int kIPT = 7;     // 1792 merge items per tile; 21.5 KB LDS per workgroup
+constexpr int kIPT = PGH_IPT;   // 7 -> 1792 merge items per tile; 21.5 KB LDS per workgroup
 
 GraphView view_of(pgh_graph_t g) {
     GraphView v;

@@ -1,0 +1,224 @@
+"""Engine-agnostic kernel-level checks through the C-ABI wrappers (DeviceVector / DeviceGraph / fused steps).
+Run against the host test double on the CPU (validates the checks themselves) and against libpgh_hip.so on
+the MI355X (tests/test_gpu_parity.py).  Tolerances are written next to each assertion."""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from oracle import rmat_np
+
+F32 = np.float32
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def _vec(pg, a):
+    return pg.to_array(np.asarray(a, dtype=np.float64))
+
+
+def _np(v):
+    return np.asarray(v, dtype=np.float64)
+
+
+SIZES = [0, 1, 3, 64, 255, 256, 1000, 4099, 100003]
+
+
+def check_elementwise_and_reductions(pg):
+    rng = np.random.default_rng(0)
+    for n in SIZES:
+        a = (rng.random(n) * 4 - 2).astype(F32).astype(np.float64)
+        b = (rng.random(n) * 3 + 0.5).astype(F32).astype(np.float64)
+        da, db = _vec(pg, a), _vec(pg, b)
+        f = lambda x: np.asarray(x, dtype=F32)               # noqa: E731  (engine arithmetic is fp32)
+        # single-rounding ops are bit-exact against numpy fp32
+        for k, (got, want) in enumerate([(da + db, f(a) + f(b)), (da - db, f(a) - f(b)), (da * db, f(a) * f(b)),
+                                         (da * 2.5, f(a) * F32(2.5)), (3.0 - da, F32(3.0) - f(a)), (-da, -f(a)),
+                                         (abs(da), np.abs(f(a))), (da > db, (f(a) > f(b)).astype(F32))]):
+            assert np.array_equal(np.asarray(got, dtype=F32), want.astype(F32)), (n, k)
+        # division and the fused a*x + b*y (hipcc contracts it into an FMA) are held to 1 ulp
+        for k, (got, want) in enumerate([(da / db, a / b), (2.0 / db, 2.0 / b)]):
+            assert np.allclose(_np(got), want, rtol=1.5 * EPS32, atol=1e-30), (n, k)
+        want = float(F32(0.3)) * a + float(F32(0.7)) * b
+        assert np.all(np.abs(_np(da.axpby(0.3, db, 0.7)) - want) <= 2 * EPS32 * (0.3 * np.abs(a) + 0.7 * np.abs(b)) + 1e-30), n
+        assert np.allclose(_np(pg.exp(da)), np.exp(a), rtol=1e-6)
+        assert np.allclose(_np(pg.log(db)), np.log(b), rtol=1e-6, atol=1e-6)
+        assert np.allclose(_np(db ** 2), b ** 2, rtol=1e-6)
+        # f64-accumulated reductions of the f32 data: exact to 1e-12 relative
+        assert abs(pg.sum(da) - a.sum()) <= 1e-12 * max(1.0, np.abs(a).sum())
+        assert abs(pg.sum(pg.abs(da)) - np.abs(a).sum()) <= 1e-12 * max(1.0, np.abs(a).sum())
+        assert abs(pg.dot(da, db) - float(a @ b)) <= 1e-12 * max(1.0, float(np.abs(a) @ np.abs(b)))
+        if n:
+            assert pg.max(da) == a.max() and pg.min(da) == a.min()
+            assert abs(pg.Mabs(da)(db) - np.abs(a - b).sum() / n) <= 1e-12 * max(1.0, np.abs(a - b).sum())
+            assert abs(pg.L1(da)(db) - np.abs(a - b).sum()) <= 1e-12 * max(1.0, np.abs(a - b).sum())
+            assert pg.MaxDifference(da)(db) == np.abs(a - b).max()
+            keep = rng.random(n) < 0.5
+            got = pg.filter_out(da, _vec(pg, (~keep).astype(float)))
+            assert np.array_equal(_np(got), a[keep])
+            assert np.array_equal(_np(da.copy()), a) and float(da[n - 1]) == a[-1]
+
+
+def _random_matrix(rng, n_rows, n_cols, density, hubs=0, empty_frac=0.0):
+    A = sp.random(n_rows, n_cols, density=density, random_state=np.random.RandomState(int(rng.integers(1 << 30))),
+                  format="lil")
+    for _ in range(hubs):
+        A[:, int(rng.integers(0, n_cols))] = rng.random((n_rows, 1))      # hub column of M = hub row of M^T
+    A = sp.csr_array(A.tocsr())
+    if empty_frac:
+        keep = (rng.random(n_cols) >= empty_frac).astype(float)
+        A = sp.csr_array(A @ sp.diags(keep))
+        A.eliminate_zeros()
+    A.sort_indices()
+    return A
+
+
+def matrices():
+    rng = np.random.default_rng(1)
+    yield "empty5", sp.csr_array((5, 5))
+    yield "single", sp.csr_array(np.array([[2.0]]))
+    yield "dense40", sp.csr_array(rng.random((40, 40)))
+    yield "rect_30x70", _random_matrix(rng, 30, 70, 0.2)
+    yield "rect_70x30", _random_matrix(rng, 70, 30, 0.2)
+    yield "sparse_3000", _random_matrix(rng, 3000, 3000, 0.002, hubs=2, empty_frac=0.3)
+    yield "hubs_5000", _random_matrix(rng, 5000, 5000, 0.001, hubs=5, empty_frac=0.6)
+    yield "empty_tail", sp.csr_array(sp.vstack([_random_matrix(rng, 100, 20000, 0.05), sp.csr_array((19900, 20000))]).T)
+    yield "rmat14", rmat_np.rmat_csr(14, 8, seed=2)
+    yield "rmat16_ef16", rmat_np.rmat_csr(16, 16, seed=0)
+
+
+def check_upload_transpose_degrees_spmv(pg):
+    rng = np.random.default_rng(2)
+    for name, M in matrices():
+        g = pg.scipy_sparse_to_backend(M)
+        assert g.shape == M.shape
+        MT = g.download_transposed()
+        want = sp.csr_array(M.T.astype(F32))
+        want.sort_indices()
+        # bit-exact format conversion: same structure, values rounded once to f32, columns ascending per row
+        assert np.array_equal(MT.indptr, want.indptr), name
+        assert np.array_equal(MT.indices, want.indices), name
+        assert np.array_equal(MT.data, want.data), name
+        deg = np.asarray(M.sum(axis=1)).ravel()
+        assert np.allclose(_np(pg.degrees(g)), deg, rtol=EPS32, atol=0), name
+        x = rng.random(M.shape[0]).astype(F32).astype(np.float64)
+        y = _np(pg.conv(_vec(pg, x), g))
+        ref = x @ sp.csr_array(M.astype(F32).astype(np.float64))     # exact sum of the engine's f32 products, up to
+        scale = np.abs(x) @ np.abs(M)                                   # one f32 rounding per product and per row
+        assert np.all(np.abs(y - ref) <= 2.5 * EPS32 * scale + 1e-30), name
+
+
+def check_fused_steps(pg):
+    from pygrank_amd import _lib as L
+    from pygrank_amd.device import DeviceVector
+    rng = np.random.default_rng(3)
+    for name, M in matrices():
+        if M.shape[0] != M.shape[1]:
+            continue
+        n = M.shape[0]
+        g = pg.scipy_sparse_to_backend(M)
+        M32 = sp.csr_array(M.astype(F32).astype(np.float64))
+        x = rng.random(n).astype(F32).astype(np.float64)
+        p = rng.random(n).astype(F32).astype(np.float64)
+        dx, dp = _vec(pg, x), _vec(pg, p)
+        tol = lambda ref_abs: 4 * EPS32 * ref_abs + 1e-30           # noqa: E731
+        # ---- PageRank step (adhoc.py:36) with a pending quotient
+        y = DeviceVector.empty(n)
+        s = C.c_double()
+        L.check(L.lib().pgh_ppr_step(g._h, dx._h, 0.5, dp._h, 0.85, y._h, C.byref(s)))
+        ref = 0.85 * 0.5 * (x @ M32) + 0.15 * p
+        bound = 0.85 * 0.5 * (np.abs(x) @ np.abs(M32)) + 0.15 * np.abs(p)
+        assert np.all(np.abs(_np(y) - ref) <= tol(bound)), name
+        assert abs(s.value - _np(y).sum()) <= 1e-12 * max(1.0, np.abs(_np(y)).sum()), name
+        # ---- AbsorbingWalks step (adhoc.py:167-168)
+        deg = (rng.random(n) + 0.1).astype(F32).astype(np.float64)
+        lam = (rng.random(n) + 0.1).astype(F32).astype(np.float64)
+        ddeg, dlam = _vec(pg, deg), _vec(pg, lam)
+        L.check(L.lib().pgh_absorb_step(g._h, dx._h, 2.0, dp._h, ddeg._h, dlam._h, y._h, C.byref(s)))
+        ref = ((2.0 * (x @ M32)) * deg + p * lam) / (lam + deg)
+        bound = ((2.0 * (np.abs(x) @ np.abs(M32))) * deg + p * lam) / (lam + deg)
+        assert np.all(np.abs(_np(y) - ref) <= 2 * tol(bound)), name
+        assert abs(s.value - _np(y).sum()) <= 1e-12 * max(1.0, np.abs(_np(y)).sum()), name
+        # ---- polynomial step (abstract_filters.py:215-230): taylor and the chebyshev recurrence
+        for a, b in ((1.0, 0.0), (2.0, -1.0)):
+            res0 = rng.random(n).astype(F32).astype(np.float64)
+            dres, tout, d = _vec(pg, res0), DeviceVector.empty(n), C.c_double()
+            L.check(L.lib().pgh_poly_step(g._h, dx._h, tout._h, a, b, dres._h, 0.25, L.ERR_L1, C.byref(d)))
+            t_ref = a * (x @ M32) + b * x
+            t_bound = abs(a) * (np.abs(x) @ np.abs(M32)) + abs(b) * np.abs(x)
+            assert np.all(np.abs(_np(tout) - t_ref) <= tol(t_bound)), name
+            r_ref = res0 + 0.25 * _np(tout)
+            assert np.all(np.abs(_np(dres) - r_ref) <= 2 * EPS32 * np.abs(r_ref) + 1e-30), name
+            assert abs(d.value - np.abs(_np(dres) - res0).sum()) <= 1e-9 * max(1.0, np.abs(r_ref).sum()), name
+        # ---- scaled residual (abstract_filters.py:133-134 + supervised.py:93-138)
+        for kind, fn in ((L.ERR_L1, lambda v: v.sum()), (L.ERR_MABS, lambda v: v.sum() / n), (L.ERR_LINF, lambda v: v.max())):
+            e = C.c_double()
+            L.check(L.lib().pgh_scaled_residual(kind, dx._h, 0.7, dp._h, 1.3, C.byref(e)))
+            want = fn(np.abs(x * 0.7 - p * 1.3))
+            assert abs(e.value - want) <= 1e-12 * max(1.0, want), name
+
+
+def check_loop_is_deterministic(pg):
+    A = rmat_np.rmat_csr(14, 8, seed=2)
+    p = np.zeros(A.shape[0])
+    p[rmat_np.seed_nodes(A, 30, seed=1)] = 1.0
+    graph = pg.AdjacencyWrapper(A, directed=True)
+    pre = pg.preprocessor(assume_immutability=True)
+    runs = [np.asarray(pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=1e-6, max_iters=500).rank(graph, p.copy()).np,
+                       dtype=F32) for _ in range(3)]
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])   # atomic-free, fixed order
+
+
+def check_error_reporting(pg):
+    import pytest
+    from pygrank_amd import _lib as L
+    a, b = _vec(pg, [1, 2, 3]), _vec(pg, [1, 2])
+    with pytest.raises(L.EngineError):
+        a + b
+    g = pg.scipy_sparse_to_backend(sp.csr_array(np.eye(3)))
+    with pytest.raises(L.EngineError):
+        pg.conv(b, g)
+    with pytest.raises(L.EngineError):
+        a[7]
+
+
+def check_rmat_generator_matches_numpy(pg):
+    """Device RMAT generation + on-GPU normalisation == oracle/rmat_np.py + the reference's host normalisation
+    (preprocessing.py:109-113,131-138): structure bit-exact, values equal after the single rounding to f32."""
+    from oracle import ref_loops as orc
+    from pygrank_amd.synthetic import rmat_device_graph, rmat_graph
+    for scale, ef, seed in ((6, 4, 1), (11, 8, 0), (14, 16, 3)):
+        A = rmat_np.rmat_csr(scale, ef, seed=seed)
+        for normalization, sym in (("none", False), ("col", False), ("symmetric", False), ("symmetric", True), ("col", True)):
+            B = sp.csr_array(A + A.T) if sym else A
+            M = sp.csr_array(orc.normalize(B, normalization, True))
+            g = rmat_device_graph(scale, ef, seed=seed, normalization=normalization, symmetrize=sym)
+            assert g.shape == M.shape and g.nnz == M.nnz, (scale, normalization, sym)
+            MT = g.download_transposed()
+            want = sp.csr_array(M.T)
+            want.sort_indices()
+            assert np.array_equal(MT.indptr, want.indptr) and np.array_equal(MT.indices, want.indices)
+            assert np.allclose(MT.data, want.data, rtol=1.5 * EPS32, atol=0), (scale, normalization, sym)
+            if normalization == "none":
+                assert np.array_equal(MT.data, want.data.astype(F32))          # integer multiplicities: exact
+            assert np.allclose(_np(pg.degrees(g)), orc.row_sums(M), rtol=2 * EPS32, atol=1e-30)
+    # row slices (1-D partition of M^T) stack back to the full matrix
+    A = rmat_np.rmat_csr(11, 8, seed=0)
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    full = sp.csr_array(M.T)
+    bounds = [0, 300, 301, 1500, 2048]
+    parts = [rmat_device_graph(11, 8, seed=0, normalization="col", row_begin=b0, row_end=b1).download_transposed()
+             for b0, b1 in zip(bounds[:-1], bounds[1:])]
+    stacked = sp.vstack(parts).tocsr()
+    assert stacked.shape == full.shape and abs(stacked - full).max() <= 1.5 * EPS32
+    # the preprocessed graph object plugs into the filters like a preprocessor outcome
+    adj = rmat_graph(11, 8, seed=0)
+    p = np.zeros(A.shape[0])
+    p[rmat_np.seed_nodes(A, 20, seed=1)] = 1.0
+    ranker = pg.PageRank(0.85, error_type=pg.L1, tol=1e-6, max_iters=500)
+    got = np.asarray(ranker.rank(adj, p.copy()).np)
+    want, it = orc.pagerank(M, p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=500)
+    assert ranker.convergence.iteration == it
+    assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
+
+
+ALL = [v for k, v in sorted(globals().items()) if k.startswith("check_") and callable(v)]
