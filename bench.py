@@ -1,0 +1,156 @@
+"""bench.py -- headline benchmark of the propagation path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (SURVEY.md 8d / BASELINE.json configs[1]): personalized PageRank, alpha = 0.85, to tol = 1e-6 with the
+L1 residual (the "headline" stopping rule), on a synthetic RMAT graph (a, b, c, d) =
+(0.57, 0.19, 0.19, 0.05), seed 0, duplicates summed, "col" normalisation, fp32 values, one personalization
+vector of 100 seed nodes per step.  N = 1: scale 23, edge factor 16 (8.4 M nodes, ~131 M edges).
+N > 1: the CSR is 1-D row-partitioned across the ranks (nnz-balanced), every iteration all-gathers the rank
+vector over RCCL/xGMI; per-GPU work is held fixed (weak scaling): scale 23 + log2(N) at edge factor 16, and the
+BASELINE.json configs[4] graph (scale 27, edge factor 8, ~1.07 B edges) at N = 8.
+
+A "step" is one full PPR run (personalization resident in HBM -> converged ranks in HBM).  The timed region
+covers exactly K steps; value = nnz * (SpMV launches of all steps) / time  [edges*iterations/s, reported in
+GTEPS].  Extra objects on the JSON line: "roofline" (HIP-event time of the SpMV kernel vs the 8*nnz + 16*n
+algorithmic bytes of one PPR step) and "cpu_baseline" (the oracle's scipy loop -- exactly the reference's
+numpy-backend arithmetic -- on the same graph, one core), plus the in-run parity of GPU vs CPU ranks.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+RMAT = dict(a=0.57, b=0.19, c=0.19)
+ALPHA, TOL, MAX_ITERS, SEEDS = 0.85, 1e-6, 1000, 100
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+
+
+def seeds_for(step, candidates, count=SEEDS):
+    rng = np.random.default_rng(1 + step)           # RNG seed 1 (+ step for further draws)
+    return np.sort(rng.choice(candidates, size=min(count, len(candidates)), replace=False))
+
+
+def single_gpu(args):
+    import pygrank_amd as pg
+    from pygrank_amd import _lib as L
+    from pygrank_amd.synthetic import rmat_graph
+    pg.load_backend("hip")
+    lib = L.lib()
+    scale, ef = args.scale, args.ef
+    t0 = time.time()
+    adj = rmat_graph(scale, ef, seed=0, normalization="col", **RMAT)
+    L.check(lib.pgh_sync())
+    build_s = time.time() - t0
+    g = adj.array
+    n, nnz = g.shape[0], g.nnz
+    out_deg = np.asarray(pg.degrees(g))              # row sums of M: > 0 <=> out-degree > 0
+    candidates = np.flatnonzero(out_deg > 0)
+    total = args.warmup + args.steps
+    personalizations = []
+    for step in range(total):                        # inputs resident in HBM before the timed region
+        p = np.zeros(n)
+        p[seeds_for(step, candidates)] = 1.0
+        personalizations.append(pg.to_signal(adj, p))
+    ranker = pg.PageRank(alpha=ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS)
+
+    def run(step):
+        ranks = ranker.rank(adj, personalizations[step])
+        return ranks, ranker.last_loop
+
+    for step in range(args.warmup):
+        run(step)
+    L.check(lib.pgh_sync())
+    spmv_total, loop_ms_total, iters = 0, 0.0, []
+    t0 = time.perf_counter()
+    for step in range(args.warmup, total):
+        ranks, info = run(step)
+        spmv_total += info["spmv"]
+        loop_ms_total += info["loop_ms"]
+        iters.append(info["iterations"])
+    L.check(lib.pgh_sync())
+    elapsed = time.perf_counter() - t0
+    gteps = nnz * spmv_total / elapsed / 1e9
+
+    # ---- roofline leg: HIP events around every launch of the dominant kernel (one extra, untimed run)
+    L.check(lib.pgh_profile_reset())
+    L.check(lib.pgh_profile_enable(1))
+    run(total - 1)
+    L.check(lib.pgh_profile_enable(0))
+    prof = {}
+    for kid, name in ((L.K_SPMV, "spmv"), (L.K_FIXUP, "fixup"), (L.K_RESIDUAL, "residual"), (L.K_FINAL, "close")):
+        cnt, ms = C.c_int64(), C.c_double()
+        L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
+        prof[name] = dict(launches=cnt.value, avg_us=(ms.value / cnt.value * 1e3) if cnt.value else None)
+    alg_bytes = 8 * nnz + 16 * n                     # fused PPR step, per launch
+    spmv_s = prof["spmv"]["avg_us"] * 1e-6
+    achieved = alg_bytes / spmv_s / 1e9
+    roofline = dict(bound="hbm", kernel="k_spmv_merge (PPR epilogue)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(prof["spmv"]["avg_us"], 2),
+                    format="csr32+f32 (8 B/edge)", other_kernels_avg_us={k: v["avg_us"] for k, v in prof.items() if k != "spmv"})
+
+    # ---- CPU baseline + parity: the oracle's scipy loop (= reference numpy backend), same graph, same seeds
+    cpu = None
+    parity = None
+    if not args.no_cpu:
+        import scipy.sparse as sp
+        from oracle import ref_loops as orc
+        MT = g.download_transposed()
+        M = sp.csr_array(MT.T.astype(np.float64))     # fp32-rounded values of the same normalised matrix
+        p = np.asarray(personalizations[total - 1].np, dtype=np.float64)
+        t1 = time.perf_counter()
+        want, cpu_iters = orc.pagerank(M, p, alpha=ALPHA, error_type="l1", tol=TOL, max_iters=MAX_ITERS)
+        cpu_s = time.perf_counter() - t1
+        got = np.asarray(run(total - 1)[0].np, dtype=np.float64)
+        cpu = dict(value=round(nnz * (cpu_iters - 1) / cpu_s / 1e9, 4), unit="GTEPS", cores=1, kind="port",
+                   sample=f"1 full PPR run ({cpu_iters - 1} SpMV) on the same scale-{scale} graph, scipy x @ M fp64 "
+                          f"single thread, {cpu_s:.1f} s")
+        parity = dict(rel_linf=float(np.max(np.abs(got - want)) / np.max(np.abs(want))), gpu_iterations=int(iters[-1]),
+                      cpu_iterations=int(cpu_iters), bound=1e-6)
+    return dict(
+        metric="edges*iters/sec (GTEPS) for PPR alpha=0.85 to tol=1e-6", value=round(gteps, 2), unit="GTEPS", n_gpus=1,
+        steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True,
+        scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+        config=dict(workload=f"single-GPU PPR on RMAT scale-{scale} ef-{ef} (BASELINE.json configs[1])", n=n, nnz=nnz,
+                    alpha=ALPHA, tol=TOL, error_type="L1", seeds=SEEDS, iterations_per_step=iters,
+                    spmv_per_step=spmv_total / args.steps, device_loop_ms_per_step=round(loop_ms_total / args.steps, 4),
+                    graph_build_s=round(build_s, 2), parallelism="1 GPU"),
+        roofline=roofline, cpu_baseline=cpu, parity=parity)
+
+
+def multi_gpu(args):
+    from pygrank_amd.distributed import bench_row_partitioned
+    return bench_row_partitioned(args, RMAT, ALPHA, TOL, MAX_ITERS, SEEDS, HBM_PEAK_GBS)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=int, default=None, help="override the RMAT scale (default: 23 + log2(gpus))")
+    ap.add_argument("--ef", type=int, default=None)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        result = multi_gpu(args)
+    else:
+        args.scale = 23 if args.scale is None else args.scale
+        args.ef = 16 if args.ef is None else args.ef
+        result = single_gpu(args)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

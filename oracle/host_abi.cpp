@@ -100,11 +100,21 @@ int pgh_timer_elapsed_ms(pgh_timer_t t, double* ms) {
     *ms = std::chrono::duration<double, std::milli>(t->b - t->a).count();
     return 0;
 }
-int pgh_profile_enable(int) { return 0; }
-int pgh_profile_reset(void) { return 0; }
-int pgh_profile_read(int, int64_t* launches, double* ms) {
-    *launches = 0;
-    *ms = 0;
+static bool g_prof_on = false;
+static int64_t g_prof_count[PGH_K_COUNT] = {0};
+static double g_prof_ms[PGH_K_COUNT] = {0};
+int pgh_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+int pgh_profile_reset(void) {
+    for (int i = 0; i < PGH_K_COUNT; ++i) g_prof_count[i] = 0, g_prof_ms[i] = 0;
+    return 0;
+}
+int pgh_profile_read(int id, int64_t* launches, double* ms) {
+    CHECK(id >= 0 && id < PGH_K_COUNT, "pgh_profile_read: bad kernel id");
+    *launches = g_prof_count[id];
+    *ms = g_prof_ms[id];
     return 0;
 }
 
@@ -501,7 +511,12 @@ static int recursive_run(pgh_graph_t g, pgh_vec_t ranks, const pgh_loop_cfg* cfg
     int steps = 0;
     const auto t0 = std::chrono::steady_clock::now();
     while (!cm.has_converged([&] { return scaled_res(cfg->err_kind, cur.data(), cur_scale, prev.data(), prev_scale, n); })) {
+        const auto ts = std::chrono::steady_clock::now();
         const double s = step(cur.data(), cur_scale, next.data());
+        if (g_prof_on) {
+            g_prof_count[PGH_K_SPMV] += 1;
+            g_prof_ms[PGH_K_SPMV] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
+        }
         prev.swap(cur);
         prev_scale = cur_scale;
         cur.swap(next);

@@ -1,0 +1,22 @@
+"""bench.py contract on the CPU: the single-GPU leg runs end to end against the host test double at a tiny scale
+and emits the fields the driver and the judge read (metric/value/unit/..., roofline, cpu_baseline, parity)."""
+import argparse
+import json
+
+import bench
+
+
+def test_single_gpu_leg_fields(host_engine):
+    args = argparse.Namespace(gpus=1, steps=2, warmup=1, scale=10, ef=8, no_cpu=False)
+    out = bench.single_gpu(args)
+    line = json.loads(json.dumps(out))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["unit"] == "GTEPS" and line["n_gpus"] == 1 and line["dtype"] == "f32" and line["data"] == "synthetic"
+    assert line["vs_baseline"] is None and line["higher_is_better"] is True
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["peak"] == 8000.0
+    assert line["parity"]["rel_linf"] <= 1e-6
+    assert line["parity"]["gpu_iterations"] == line["parity"]["cpu_iterations"]
