@@ -1,0 +1,686 @@
+// Column-blocked segment-flag format (BSF) of CSR(M^T): builder and the two propagation kernels that stream it.
+//
+// Why (MI355X, measured -- profiles/r01): the row-major merge-path SpMV moves 4.7 GB per launch for 1.18 GB of
+// algorithmic bytes at RMAT scale 23; 3.5 GB of that is 128-byte line over-fetch for 4-byte x[col] gathers that miss
+// the 4 MB per-XCD L2.  The fix is a layout decision, made once at upload time:
+//   1. relabel: sources sorted by descending reference count and dealt round-robin to B column blocks, so every
+//      block's slice of the gather vector is one contiguous hot-first range;
+//   2. block b's entries are streamed only by workgroups whose dispatch slot maps to one XCD group
+//      (blockIdx % 8, a speed-only affinity), so that slice stays resident in that XCD's L2 while the matrix
+//      stream passes through with non-temporal loads;
+//   3. per block, entries are sorted by (row, col) and a row segment is marked by bit 31 of its first column
+//      index: the SpMV pass reads no row pointers and never touches empty rows;
+//   4. when M^T = diag(dst) * W * diag(src) with small integer W (the preprocessor's "col"/"symmetric"
+//      normalisations of an unweighted or multi-edge graph, preprocessing.py:109-138) the values disappear:
+//      multiplicities become repeated entries (4 B/edge), src moves into the gather vector, dst into the epilogue.
+// Block partial sums go to B dense f32 vectors; k_bsf_combine folds them with the filter's epilogue
+// (apply_epilogue: adhoc.py:34-36,166-169; abstract_filters.py:215-230) and writes the next gather vector.
+//
+// Reference counterpart of the arithmetic: conv(signal, M) = signal @ M (pygrank/core/backend/numpy.py:64-65).
+#include "pgh_kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cstdlib>
+#include <vector>
+
+using namespace pgh;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kIPT = PGH_IPT;
+constexpr int kTile = WG * kIPT;
+constexpr uint64_t kLow29 = (1ULL << 29) - 1;
+constexpr uint64_t kRowSentinel = kLow29;        // sorts after every real row of a block
+
+inline int blocks_for(int64_t n, int cap_mult = 16) {
+    int64_t b = (n + kBlock - 1) / kBlock;
+    const int64_t cap = (int64_t)rt().num_cus * cap_mult;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t count, bool zero = false) {
+        PGH_HIP(hipMalloc(&p, sizeof(T) * (count > 0 ? count : 1)));
+        if (zero) PGH_HIP(hipMemsetAsync(p, 0, sizeof(T) * (count > 0 ? count : 1), rt().stream));
+        return 0;
+    }
+    T* release() {
+        T* q = p;
+        p = nullptr;
+        return q;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------- builder kernels
+// reference count of every source (weights count as multiplicities when the format is value-free)
+__global__ void k_source_counts(const int32_t* __restrict__ col, const int32_t* __restrict__ mult, int64_t nnz,
+                                unsigned int* __restrict__ cnt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += stride)
+        atomicAdd(&cnt[col[k]], mult ? (unsigned int)mult[k] : 1u);
+}
+
+__global__ void k_iota(int32_t* p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (int32_t)i;
+}
+
+// rank r (descending count) -> new id = (r % B) * blk + r / B
+__global__ void k_make_perm(const int32_t* __restrict__ sorted_ids, int64_t n, int B, int blk, int32_t* __restrict__ perm,
+                            int32_t* __restrict__ iperm) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int old = sorted_ids[r];
+        const int nw = (int)(r % B) * blk + (int)(r / B);
+        iperm[old] = nw;
+        perm[nw] = old;
+    }
+}
+
+__global__ void k_fill_perm_pad(int32_t* __restrict__ perm, int64_t n_pad) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) perm[i] = -1;
+}
+
+// expand CSR(M^T) rows into sort keys (block << 58 | new_row << 29 | new_col); `offs` = first output slot of entry k
+__global__ void k_bsf_keys(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+                           const int32_t* __restrict__ mult, const int64_t* __restrict__ offs, int64_t n_out,
+                           const int32_t* __restrict__ iperm_rows, const int32_t* __restrict__ iperm_cols, int blk,
+                           uint64_t* __restrict__ keys, float* __restrict__ vals_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_out; r += nwaves) {
+        const uint64_t nr = (uint64_t)(iperm_rows ? iperm_rows[r] : (int32_t)r);
+        for (int64_t k = rowptr[r] + lane; k < rowptr[r + 1]; k += 64) {
+            const int c = iperm_cols ? iperm_cols[col[k]] : col[k];
+            const uint64_t key = ((uint64_t)(c / blk) << 58) | (nr << 29) | (uint64_t)c;
+            const int64_t o = offs ? offs[k] : k;
+            const int m = mult ? mult[k] : 1;
+            for (int q = 0; q < m; ++q) keys[o + q] = key;
+            if (vals_out) vals_out[o] = val[k];
+        }
+    }
+}
+
+__global__ void k_bsf_sentinels(uint64_t* __restrict__ keys, int64_t first, int B, int n_src_pad) {
+    const int b = threadIdx.x;
+    // the sentinel's segment is never closed, so its product is irrelevant: it gathers from the block's first slot
+    if (b < B) keys[first + b] = ((uint64_t)b << 58) | (kRowSentinel << 29) | (uint64_t)((int64_t)b * (n_src_pad / B));
+}
+
+// sorted keys -> colf (+flag), int flags for the segment scan
+__global__ void k_bsf_flags(const uint64_t* __restrict__ keys, int64_t E, uint32_t* __restrict__ colf, int* __restrict__ flags) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += stride) {
+        const uint64_t key = keys[e];
+        const int f = (e == 0) || ((key >> 29) != (keys[e - 1] >> 29));
+        colf[e] = (uint32_t)(key & kLow29) | ((uint32_t)f << 31);
+        flags[e] = f;
+    }
+}
+
+// segid = inclusive scan of flags; segment s = segid - 1 starts at the flagged entry
+__global__ void k_bsf_seg_rows(const uint64_t* __restrict__ keys, const int* __restrict__ segid, int64_t E,
+                               int32_t* __restrict__ seg_row) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += stride) {
+        const bool f = (e == 0) || (segid[e] != segid[e - 1]);
+        if (f) {
+            const uint64_t row = (keys[e] >> 29) & kLow29;
+            seg_row[segid[e] - 1] = row == kRowSentinel ? -1 : (int32_t)row;
+        }
+    }
+}
+
+// first entry of every block (lower bound of b << 58), E for b == B
+__global__ void k_bsf_block_starts(const uint64_t* __restrict__ keys, int64_t E, int B, int64_t* __restrict__ starts) {
+    const int b = threadIdx.x;
+    if (b > B) return;
+    const uint64_t target = (uint64_t)b << 58;
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    starts[b] = lo;
+}
+
+struct TileBuild {
+    int64_t block_start[9];
+    int     tile_begin[9];
+    int     B;
+};
+
+__global__ void k_bsf_tiles(TileBuild tb, const int* __restrict__ segid, int4* __restrict__ tile) {
+    const int total = tb.tile_begin[tb.B];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        int b = 0;
+        while (b + 1 < tb.B && t >= tb.tile_begin[b + 1]) ++b;
+        const int64_t start = tb.block_start[b] + (int64_t)(t - tb.tile_begin[b]) * kTile;
+        const int64_t end = min(start + (int64_t)kTile, tb.block_start[b + 1]);
+        const int seg_before = start > 0 ? segid[start - 1] : 0;       // segments started before this tile
+        const int flags_here = segid[end - 1] - seg_before;
+        int first = -1;
+        if (flags_here > 0) {
+            // chain: tiles first..t-1 carry pieces of the segment that is open when tile t starts
+            int s = t;
+            while (s > tb.tile_begin[b]) {
+                const int64_t ps = tb.block_start[b] + (int64_t)(s - 1 - tb.tile_begin[b]) * kTile;
+                const int64_t pe = ps + kTile;                           // previous tiles are always full
+                const int pflags = segid[pe - 1] - (ps > 0 ? segid[ps - 1] : 0);
+                --s;
+                if (pflags > 0) break;
+            }
+            first = s;
+        }
+        tile[t] = make_int4((int)start, (int)(end - start), seg_before - 1, first);
+    }
+}
+
+__global__ void k_permute_in(const float* __restrict__ src, const int32_t* __restrict__ perm, const float* __restrict__ scale,
+                             int64_t n_pad, int64_t n_valid, float hole, float* __restrict__ dst) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = perm ? perm[i] : (i < n_valid ? (int)i : -1);
+        float v = o >= 0 ? src[o] : hole;
+        if (scale) v *= scale[i];
+        dst[i] = v;
+    }
+}
+
+__global__ void k_permute_out(const float* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_pad, int64_t n_valid,
+                              float factor, float* __restrict__ dst) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = perm ? perm[i] : (i < n_valid ? (int)i : -1);
+        if (o >= 0) dst[o] = src[i] * factor;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- SpMV kernels
+struct BsfView {
+    const uint32_t* colf;
+    const float*    val;
+    const int32_t*  seg_row;
+    const int4*     tile;
+    double*         tail_carry;
+    double*         head_partial;
+    float*          part;
+    int64_t         part_stride;
+    int             num_blocks;
+    int             pad_index;
+    int             tile_begin[9];
+};
+
+// One tile = kTile consecutive entries of one column block.  Coalesced (non-temporal) stream of the column words,
+// gather from the block's L2-resident slice of xg, LDS transpose so that every thread owns IPT consecutive
+// entries, serial segmented sum in f64, __shfl_up segmented scan across the wavefront + LDS hand-off across the
+// 4 wavefronts, carries for segments that cross tiles.
+template <int IPT, bool HAS_VAL>
+__global__ __launch_bounds__(WG) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
+                                                     const LoopState* __restrict__ state) {
+    constexpr int T = WG * IPT;
+    constexpr int NW = 4 * IPT;                       // 64-bit flag words per tile
+    __shared__ float              s_prod[T];
+    __shared__ float              s_out[T];
+    __shared__ unsigned long long s_mask[NW + 1];
+    __shared__ int                s_wpre[NW + 1];
+    __shared__ int                s_wkey[4];
+    __shared__ double             s_wval[4];
+    if (state != nullptr && state->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
+    const int label = blockIdx.x & 7;
+    const int b = label % f.num_blocks;
+    const int per = 8 / f.num_blocks;
+    const int rank = (blockIdx.x >> 3) * per + label / f.num_blocks;
+    const int stride = (gridDim.x >> 3) * per;
+    float* __restrict__ part = f.part + (int64_t)b * f.part_stride;
+
+    for (int t = f.tile_begin[b] + rank; t < f.tile_begin[b + 1]; t += stride) {
+        const int4 ti = f.tile[t];
+        const int z0 = ti.x, count = ti.y, seg_base = ti.z;
+        uint32_t cf[IPT];
+        float    vv[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int idx = k * WG + tid;
+            const bool ok = idx < count;
+            cf[k] = ok ? __builtin_nontemporal_load(f.colf + z0 + idx) : (uint32_t)f.pad_index;
+            if (HAS_VAL) vv[k] = ok ? __builtin_nontemporal_load(f.val + z0 + idx) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int idx = k * WG + tid;
+#if PGH_PROBE_GATHER == 1
+            const float xv = xg[cf[k] & 1023u];
+#elif PGH_PROBE_GATHER == 2
+            const float xv = xg[cf[k] & 0xFFFFFu];
+#elif PGH_PROBE_GATHER == 3
+            const float xv = (float)(cf[k] & 0xffffu);
+#elif PGH_PROBE_GATHER == 4
+            const float xv = __hip_atomic_load(xg + (cf[k] & 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif PGH_PROBE_GATHER == 5
+            const float xv = __builtin_nontemporal_load(xg + (cf[k] & 0x7fffffffu));
+#else
+            const float xv = xg[cf[k] & 0x7fffffffu];
+#endif
+            s_prod[idx] = HAS_VAL ? vv[k] * xv : xv;
+            const unsigned long long m = __ballot((cf[k] >> 31) != 0);
+            if (lane == 0) s_mask[k * 4 + wave] = m;
+        }
+        if (tid == 0) s_mask[NW] = 0ULL;
+        __syncthreads();
+        if (wave == 0) {                               // exclusive prefix of the per-word flag counts
+            const int pc = lane < NW ? __popcll(s_mask[lane]) : 0;
+            int inc = pc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += v;
+            }
+            if (lane < NW) s_wpre[lane] = inc - pc;
+            if (lane == NW - 1) s_wpre[NW] = inc;
+        }
+        __syncthreads();
+        const int total_flags = s_wpre[NW];
+        // ---- this thread's IPT consecutive entries
+        const int p0 = tid * IPT;
+        const int w0 = p0 >> 6, off = p0 & 63;
+        const unsigned long long m0 = s_mask[w0], m1 = s_mask[w0 + 1];
+        unsigned int bits = (unsigned int)(m0 >> off);
+        if (off + IPT > 64) bits |= (unsigned int)(m1 << (64 - off));
+        bits &= (1u << IPT) - 1u;
+        const int before = s_wpre[w0] + __popcll(m0 & ((1ULL << off) - 1ULL));   // flags ahead of this chunk
+        double acc = 0.0, first_val = 0.0;
+        int q = 0, first_o = -2;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            if ((bits >> k) & 1u) {                   // entry k opens segment (before + q): close the open one
+                const int o = before + q;
+                if (first_o == -2) {
+                    first_o = o;
+                    first_val = acc;
+                } else {
+                    s_out[o - 1] = (float)acc;
+                }
+                acc = 0.0;
+                ++q;
+            }
+            acc += (double)s_prod[p0 + k];
+        }
+        // ---- stitch segments that cross thread boundaries (keys are non-decreasing across threads)
+        int key = before + q - 1;                     // local index of the segment open at the end of the chunk
+        double val = acc;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+            const int k2 = __shfl_up(key, o2, 64);
+            const double v2 = __shfl_up(val, o2, 64);
+            if (lane >= o2 && k2 == key) val += v2;
+        }
+        if (lane == 63) {
+            s_wkey[wave] = key;
+            s_wval[wave] = val;
+        }
+        __syncthreads();
+        int pk = -2;
+        double pv = 0.0;
+        for (int w = 0; w < wave; ++w) {
+            const int wk = s_wkey[w];
+            const double wv = s_wval[w];
+            if (wk == pk) pv += wv; else { pk = wk; pv = wv; }
+        }
+        if (pk == key) val += pv;
+        int ek = __shfl_up(key, 1, 64);
+        double ev = __shfl_up(val, 1, 64);
+        if (lane == 0) { ek = pk; ev = pv; }
+        if (first_o != -2) {
+            const int closes = first_o - 1;           // local index of the segment this thread's first flag closes
+            const double total = first_val + ((tid > 0 && ek == closes) ? ev : 0.0);
+            if (closes < 0) f.head_partial[t] = total;    // the segment that was open when the tile started
+            else s_out[closes] = (float)total;
+        }
+        if (tid == WG - 1) f.tail_carry[t] = val;     // piece of the segment still open at the end of the tile
+        __syncthreads();
+        // ---- segments that start and end inside the tile: local 0 .. total_flags - 2
+        const int32_t* __restrict__ rows = f.seg_row + seg_base + 1;
+        for (int j = tid; j < total_flags - 1; j += WG) {
+            const int row = rows[j];
+            if (row >= 0) part[row] = s_out[j];
+        }
+        __syncthreads();
+    }
+}
+
+// segments that cross tiles: fixed-order sum of the carries, one thread per closing tile
+__global__ __launch_bounds__(WG) void k_bsf_fixup(BsfView f, int num_tiles, const LoopState* __restrict__ state) {
+    if (state != nullptr && state->done) return;
+    for (int t = blockIdx.x * WG + threadIdx.x; t < num_tiles; t += gridDim.x * WG) {
+        const int4 ti = f.tile[t];
+        if (ti.w < 0 || ti.z < 0) continue;
+        const int row = f.seg_row[ti.z];
+        if (row < 0) continue;
+        double total = 0.0;
+        for (int s = ti.w; s < t; ++s) total += f.tail_carry[s];
+        total += f.head_partial[t];
+        int b = 0;
+        while (b + 1 < f.num_blocks && t >= f.tile_begin[b + 1]) ++b;
+        f.part[(int64_t)b * f.part_stride + row] = (float)total;
+    }
+}
+
+// fold the B block partials, apply the filter epilogue, write the next gather vector
+template <int MODE, int B>
+__global__ __launch_bounds__(WG) void k_bsf_combine(const float* __restrict__ part, int64_t part_stride, int64_t n_out,
+                                                     const float* __restrict__ dst_scale, EpiParams ep,
+                                                     const LoopState* __restrict__ state, double* __restrict__ partial_sum,
+                                                     double* __restrict__ partial_delta) {
+    __shared__ double s_red[4];
+    double scale = 1.0;
+    if (state != nullptr) {
+        if (state->done) return;
+        scale = state->scale;
+    }
+    const float a_eff = (float)(ep.a * scale);
+    double sum_y = 0.0, delta = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n_out; i += stride) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) s += (double)part[(int64_t)b * part_stride + i];
+        if (dst_scale != nullptr) s *= (double)dst_scale[i];
+        apply_epilogue<MODE>(ep, a_eff, (int)i, (float)s, sum_y, delta);
+    }
+    const double bs = block_reduce_256<0>(sum_y, s_red);
+    if (threadIdx.x == 0) partial_sum[blockIdx.x] = bs;
+    if (MODE == EPI_POLY) {
+        const double bd = ep.err_linf ? block_reduce_256<1>(delta, s_red) : block_reduce_256<0>(delta, s_red);
+        if (threadIdx.x == 0) partial_delta[blockIdx.x] = bd;
+    }
+}
+
+BsfView view_of(const BsfFormat& f) {
+    BsfView v;
+    v.colf = f.colf;
+    v.val = f.val;
+    v.seg_row = f.seg_row;
+    v.tile = f.tile;
+    v.tail_carry = f.tail_carry;
+    v.head_partial = f.head_partial;
+    v.part = f.part;
+    v.part_stride = f.n_out;
+    v.num_blocks = f.num_blocks;
+    v.pad_index = 0;   // lanes past the end of a block only feed the sentinel's never-closed segment
+    for (int i = 0; i < 9; ++i) v.tile_begin[i] = f.tile_begin[i];
+    return v;
+}
+
+int env_int(const char* name, int fallback) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : fallback;
+}
+
+}  // namespace
+
+namespace pgh {
+
+int bsf_combine_grid(int64_t n_out) {
+    int64_t blocks = (n_out + (int64_t)WG * 4 - 1) / ((int64_t)WG * 4);
+    const int64_t cap = (int64_t)rt().num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// Enqueue M^T-times-gather-vector in the blocked format followed by the MODE epilogue.
+// xg: gather vector in the graph's internal id space, already multiplied by src_scale when the format has one.
+// Block partials of sum(y) / delta land in rt().d_partials like the row-major path; *num_partials receives their count.
+template <int MODE>
+int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials) {
+    Runtime& r = rt();
+    BsfFormat& f = g->bsf;
+    const BsfView v = view_of(f);
+    const int main_grid = r.num_cus * 8;              // multiple of 8: XCD-affine block assignment
+    {
+        ProfScope prof(PGH_K_SPMV);
+        if (f.val) k_bsf_partial<kIPT, true><<<main_grid, WG, 0, r.stream>>>(v, xg, state);
+        else k_bsf_partial<kIPT, false><<<main_grid, WG, 0, r.stream>>>(v, xg, state);
+    }
+    {
+        ProfScope prof(PGH_K_FIXUP);
+        int fix_grid = (f.num_tiles + WG - 1) / WG;
+        if (fix_grid < 1) fix_grid = 1;
+        if (fix_grid > 1024) fix_grid = 1024;
+        k_bsf_fixup<<<fix_grid, WG, 0, r.stream>>>(v, f.num_tiles, state);
+    }
+    const int cgrid = bsf_combine_grid(f.n_out);
+    double* psum = r.d_partials;
+    double* pdel = r.d_partials + kMaxPartials;
+    {
+        ProfScope prof(PGH_K_COMBINE);
+        switch (f.num_blocks) {
+            case 1: k_bsf_combine<MODE, 1><<<cgrid, WG, 0, r.stream>>>(f.part, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            case 2: k_bsf_combine<MODE, 2><<<cgrid, WG, 0, r.stream>>>(f.part, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            case 4: k_bsf_combine<MODE, 4><<<cgrid, WG, 0, r.stream>>>(f.part, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            default: k_bsf_combine<MODE, 8><<<cgrid, WG, 0, r.stream>>>(f.part, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+        }
+    }
+    PGH_HIP(hipGetLastError());
+    if (num_partials) *num_partials = cgrid;
+    return 0;
+}
+
+template int bsf_launch<EPI_PLAIN>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*);
+template int bsf_launch<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*);
+template int bsf_launch<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*);
+template int bsf_launch<EPI_POLY>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*);
+
+// original-space source-side vector -> internal (relabelled, padded) space, optionally times src_scale
+int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale, float hole) {
+    BsfFormat& f = g->bsf;
+    k_permute_in<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(src, f.perm, prescale ? f.src_scale : nullptr, f.n_src_pad,
+                                                                    f.n_src, hole, dst);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+// output-side vector: original -> internal
+int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole) {
+    BsfFormat& f = g->bsf;
+    k_permute_in<<<blocks_for(f.n_out), kBlock, 0, rt().stream>>>(src, f.relabelled ? f.perm : nullptr, nullptr, f.n_out,
+                                                                 f.n_out_orig, hole, dst);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+// output-side vector: internal -> original
+int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor) {
+    BsfFormat& f = g->bsf;
+    k_permute_out<<<blocks_for(f.n_out), kBlock, 0, rt().stream>>>(src, f.relabelled ? f.perm : nullptr, f.n_out, f.n_out_orig,
+                                                                  (float)factor, dst);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+void bsf_destroy(BsfFormat& f) {
+    (void)hipFree(f.colf);
+    (void)hipFree(f.val);
+    (void)hipFree(f.seg_row);
+    (void)hipFree(f.tile);
+    (void)hipFree(f.tail_carry);
+    (void)hipFree(f.head_partial);
+    (void)hipFree(f.part);
+    (void)hipFree(f.perm);
+    (void)hipFree(f.src_scale);
+    (void)hipFree(f.dst_scale);
+    (void)hipFree(f.xg);
+    (void)hipFree(f.tmp_out);
+    f = BsfFormat();
+}
+
+// Build the blocked format from CSR(M^T) already on the device.
+//   val  != null : generic weighted matrix (8 B/edge)
+//   mult != null : value-free; M^T = diag(dst_old) * mult * diag(src_old) (either scale may be null = 1)
+// relabel: permute ids by descending source count (square graphs only).
+int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel) {
+    Runtime& r = rt();
+    BsfFormat& f = g->bsf;
+    const int64_t n_src = g->n_rows, n_out = g->n_cols, nnz = g->nnz;
+    PGH_CHECK(n_src < (1LL << 28) && n_out < (1LL << 28), "blocked format needs fewer than 2^28 rows/columns");
+    if (relabel && n_src != n_out) relabel = false;
+    // number of column blocks: keep a block's slice of the gather vector around 8 MB (hot-first, so its reused
+    // prefix fits a 4 MB L2); override with PGH_BLOCKS for experiments
+    int B = 1;
+    while (B < 8 && n_src * 4 > (int64_t)B * (8 << 20)) B <<= 1;
+    const int forced = env_int("PGH_BLOCKS", 0);
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) B = forced;
+    const int blk = (int)((n_src + B - 1) / B);
+    const int n_src_pad = B * blk;
+    f.num_blocks = B;
+    f.blk_size = blk;
+    f.n_src = (int)n_src;
+    f.n_src_pad = n_src_pad;
+    f.relabelled = relabel;
+    f.n_out_orig = (int)n_out;
+    f.n_out = relabel ? n_src_pad : (int)n_out;     // relabelled ids are spread over [0, B * blk): outputs live there too
+
+    DevBuf<int32_t> iperm;
+    if (relabel) {
+        DevBuf<unsigned int> cnt, cnt_sorted;
+        DevBuf<int32_t> ids, ids_sorted;
+        PGH_TRY(cnt.alloc(n_src, true));
+        PGH_TRY(cnt_sorted.alloc(n_src));
+        PGH_TRY(ids.alloc(n_src));
+        PGH_TRY(ids_sorted.alloc(n_src));
+        PGH_TRY(iperm.alloc(n_src));
+        PGH_HIP(hipMalloc(&f.perm, sizeof(int32_t) * (size_t)n_src_pad));
+        if (nnz > 0) k_source_counts<<<blocks_for(nnz), kBlock, 0, r.stream>>>(g->col, mult, nnz, cnt.p);
+        k_iota<<<blocks_for(n_src), kBlock, 0, r.stream>>>(ids.p, n_src);
+        size_t temp_bytes = 0;
+        PGH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, temp_bytes, cnt.p, cnt_sorted.p, ids.p, ids_sorted.p, (int)n_src, 0, 32, r.stream));
+        DevBuf<char> temp;
+        PGH_TRY(temp.alloc(temp_bytes));
+        PGH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(temp.p, temp_bytes, cnt.p, cnt_sorted.p, ids.p, ids_sorted.p, (int)n_src, 0, 32, r.stream));
+        k_fill_perm_pad<<<blocks_for(n_src_pad), kBlock, 0, r.stream>>>(f.perm, n_src_pad);
+        k_make_perm<<<blocks_for(n_src), kBlock, 0, r.stream>>>(ids_sorted.p, n_src, B, blk, f.perm, iperm.p);
+        PGH_HIP(hipGetLastError());
+        PGH_HIP(hipStreamSynchronize(r.stream));
+    }
+    // ---- entry expansion offsets (value-free: multiplicities become repeated entries)
+    DevBuf<int64_t> offs;
+    int64_t E = nnz;
+    if (mult && nnz > 0) {
+        PGH_TRY(offs.alloc(nnz));
+        size_t temp_bytes = 0;
+        PGH_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, mult, offs.p, (int)nnz, r.stream));
+        DevBuf<char> temp;
+        PGH_TRY(temp.alloc(temp_bytes));
+        PGH_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, temp_bytes, mult, offs.p, (int)nnz, r.stream));
+        int64_t last_off = 0;
+        int32_t last_m = 0;
+        PGH_HIP(hipMemcpyAsync(&last_off, offs.p + nnz - 1, sizeof(int64_t), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipMemcpyAsync(&last_m, mult + nnz - 1, sizeof(int32_t), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        E = last_off + last_m;
+    }
+    E += B;                                            // one sentinel per block
+    PGH_CHECK(E < 2147483647LL, "blocked format: more than 2^31 entries in one graph; partition it (SURVEY.md 8e)");
+    f.num_entries = E;
+    DevBuf<uint64_t> keys_a, keys_b;
+    DevBuf<float> vals_a;
+    DevBuf<int> flags, segid;
+    PGH_TRY(keys_a.alloc(E));
+    PGH_TRY(keys_b.alloc(E));
+    if (val) {
+        PGH_TRY(vals_a.alloc(E, true));
+        PGH_HIP(hipMalloc(&f.val, sizeof(float) * (size_t)E));
+    }
+    if (nnz > 0)
+        k_bsf_keys<<<blocks_for(n_out * 64), kBlock, 0, r.stream>>>(g->rowptr, g->col, val, mult, offs.p, n_out,
+                                                                    relabel ? iperm.p : nullptr, relabel ? iperm.p : nullptr, blk,
+                                                                    keys_a.p, val ? vals_a.p : nullptr);
+    k_bsf_sentinels<<<1, 64, 0, r.stream>>>(keys_a.p, E - B, B, n_src_pad);
+    PGH_HIP(hipGetLastError());
+    {
+        size_t temp_bytes = 0;
+        if (val) PGH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a.p, keys_b.p, vals_a.p, f.val, (int)E, 0, 61, r.stream));
+        else PGH_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_a.p, keys_b.p, (int)E, 0, 61, r.stream));
+        DevBuf<char> temp;
+        PGH_TRY(temp.alloc(temp_bytes));
+        if (val) PGH_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.p, keys_b.p, vals_a.p, f.val, (int)E, 0, 61, r.stream));
+        else PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)E, 0, 61, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+    }
+    PGH_HIP(hipMalloc(&f.colf, sizeof(uint32_t) * (size_t)E));
+    PGH_TRY(flags.alloc(E));
+    PGH_TRY(segid.alloc(E));
+    k_bsf_flags<<<blocks_for(E), kBlock, 0, r.stream>>>(keys_b.p, E, f.colf, flags.p);
+    {
+        size_t temp_bytes = 0;
+        PGH_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, temp_bytes, flags.p, segid.p, (int)E, r.stream));
+        DevBuf<char> temp;
+        PGH_TRY(temp.alloc(temp_bytes));
+        PGH_HIP(hipcub::DeviceScan::InclusiveSum(temp.p, temp_bytes, flags.p, segid.p, (int)E, r.stream));
+        int nseg = 0;
+        PGH_HIP(hipMemcpyAsync(&nseg, segid.p + E - 1, sizeof(int), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        f.num_segs = nseg;
+    }
+    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1)));
+    k_bsf_seg_rows<<<blocks_for(E), kBlock, 0, r.stream>>>(keys_b.p, segid.p, E, f.seg_row);
+    // ---- tiles
+    TileBuild tb;
+    tb.B = B;
+    {
+        DevBuf<int64_t> starts;
+        PGH_TRY(starts.alloc(9));
+        k_bsf_block_starts<<<1, 64, 0, r.stream>>>(keys_b.p, E, B, starts.p);
+        int64_t h[9] = {0};
+        PGH_HIP(hipMemcpyAsync(h, starts.p, sizeof(int64_t) * (B + 1), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        int tiles = 0;
+        for (int b = 0; b <= 8; ++b) {
+            tb.block_start[b] = b <= B ? h[b] : E;
+            tb.tile_begin[b] = tiles;
+            f.tile_begin[b] = tiles;
+            if (b < B) tiles += (int)((h[b + 1] - h[b] + kTile - 1) / kTile);
+        }
+        f.num_tiles = tiles;
+    }
+    PGH_HIP(hipMalloc(&f.tile, sizeof(int4) * (size_t)(f.num_tiles + 1)));
+    PGH_HIP(hipMalloc(&f.tail_carry, sizeof(double) * (size_t)(f.num_tiles + 1)));
+    PGH_HIP(hipMalloc(&f.head_partial, sizeof(double) * (size_t)(f.num_tiles + 1)));
+    PGH_HIP(hipMemsetAsync(f.tail_carry, 0, sizeof(double) * (size_t)(f.num_tiles + 1), r.stream));
+    PGH_HIP(hipMemsetAsync(f.head_partial, 0, sizeof(double) * (size_t)(f.num_tiles + 1), r.stream));
+    k_bsf_tiles<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(tb, segid.p, f.tile);
+    // ---- work buffers and scales
+    const size_t n_int = (size_t)(f.n_out > 0 ? f.n_out : 1);
+    PGH_HIP(hipMalloc(&f.part, sizeof(float) * (size_t)B * n_int));
+    PGH_HIP(hipMemsetAsync(f.part, 0, sizeof(float) * (size_t)B * n_int, r.stream));
+    PGH_HIP(hipMalloc(&f.xg, sizeof(float) * (size_t)(n_src_pad + 1)));
+    PGH_HIP(hipMemsetAsync(f.xg, 0, sizeof(float) * (size_t)(n_src_pad + 1), r.stream));
+    PGH_HIP(hipMalloc(&f.tmp_out, sizeof(float) * n_int));
+    if (src_old) {
+        PGH_HIP(hipMalloc(&f.src_scale, sizeof(float) * (size_t)(n_src_pad + 1)));
+        PGH_HIP(hipMemsetAsync(f.src_scale, 0, sizeof(float) * (size_t)(n_src_pad + 1), r.stream));
+        k_permute_in<<<blocks_for(n_src_pad), kBlock, 0, r.stream>>>(src_old, f.perm, nullptr, n_src_pad, n_src, 0.f, f.src_scale);
+    }
+    if (dst_old) {
+        PGH_HIP(hipMalloc(&f.dst_scale, sizeof(float) * n_int));
+        // rows use the same relabelling as sources on square graphs; rectangular slices are not relabelled
+        k_permute_in<<<blocks_for(f.n_out), kBlock, 0, r.stream>>>(dst_old, relabel ? f.perm : nullptr, nullptr, f.n_out, n_out, 0.f, f.dst_scale);
+    }
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    f.device_bytes = (int64_t)E * (val ? 8 : 4) + f.num_segs * 4 + (int64_t)f.num_tiles * 32 + (int64_t)B * f.n_out * 4 +
+                     (int64_t)n_src_pad * (4 + (src_old ? 4 : 0) + (relabel ? 4 : 0)) + (int64_t)n_out * (dst_old ? 8 : 4);
+    f.enabled = true;
+    return 0;
+}
+
+}  // namespace pgh

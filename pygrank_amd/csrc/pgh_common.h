@@ -93,6 +93,42 @@ struct pgh_timer_s {
     hipEvent_t start = nullptr, stop = nullptr;
 };
 
+// Column-blocked segment-flag format ("BSF") of CSR(M^T): the layout the propagation kernels stream.
+//   * sources are (optionally) relabelled by descending reference count and dealt round-robin to B column
+//     blocks, so each block's slice of the gather vector is a contiguous, hot-first range that stays resident
+//     in one XCD's 4 MB L2;
+//   * per block the entries are sorted by (row, col); a row segment starts at an entry whose bit 31 is set,
+//     so neither row pointers nor empty rows are read by the SpMV pass;
+//   * value-free when M^T = diag(dst_scale) * W * diag(src_scale) with small integer W: multiplicities are
+//     stored as repeated entries (4 B/edge), the scales move into the gather vector and the epilogue.
+struct BsfFormat {
+    bool      enabled = false;
+    int       num_blocks = 1;       // B in {1, 2, 4, 8}
+    int       blk_size = 0;         // sources per block
+    int       n_src = 0;            // length of the gather vector (rows of M)
+    int       n_src_pad = 0;        // B * blk_size; slot n_src_pad is a permanent zero
+    int       n_out = 0;            // outputs in the internal id space (= n_src_pad when relabelled)
+    int       n_out_orig = 0;       // outputs in the caller's id space (rows of M^T held by this graph)
+    bool      relabelled = false;
+    int64_t   num_entries = 0;      // incl. one sentinel per block
+    int64_t   num_segs = 0;
+    uint32_t* colf = nullptr;       // [num_entries] column (new id) | bit31 = first entry of a row segment
+    float*    val = nullptr;        // [num_entries] or null (value-free)
+    int32_t*  seg_row = nullptr;    // [num_segs] output row (new id) of every segment, -1 for sentinels
+    int       num_tiles = 0;
+    int4*     tile = nullptr;       // [num_tiles] {entry_start, entry_count, seg_base, chain_first}
+    int       tile_begin[9] = {0};  // tile range of every block
+    double*   tail_carry = nullptr; // [num_tiles]
+    double*   head_partial = nullptr;
+    float*    part = nullptr;       // [B][n_out] block partial sums (structurally empty pairs stay 0 forever)
+    int32_t*  perm = nullptr;       // [n_src] new id -> old id, or null (identity)
+    float*    src_scale = nullptr;  // [n_src_pad + 1] new space, or null
+    float*    dst_scale = nullptr;  // [n_out] new space, or null
+    float*    xg = nullptr;         // [n_src_pad + 1] gather-source work buffer (new space)
+    float*    tmp_out = nullptr;    // [n_out] work buffer (new space) for the single-step entry points
+    int64_t   device_bytes = 0;
+};
+
 struct pgh_graph_s {
     int64_t n_rows = 0;      // rows of M   (= columns of the stored M^T)
     int64_t n_cols = 0;      // columns of M (= rows of the stored M^T = length of conv output)
@@ -111,6 +147,7 @@ struct pgh_graph_s {
     double*  tail_carry = nullptr;   // [num_tiles]
     double*  head_partial = nullptr; // [num_tiles]
     int64_t  device_bytes = 0;
+    BsfFormat bsf;
 };
 
 // ---------------------------------------------------------------- device helpers

@@ -8,9 +8,11 @@
 // The transposition is a device radix sort of (column << 32 | row) keys (rocPRIM via hipCUB -- a one-time
 // format conversion, not part of the per-iteration hot path), so the stored rows of M^T come out with their
 // column indices ascending and the result is deterministic.
-#include "pgh_common.h"
+#include "pgh_kernels.h"
 
 #include <hipcub/hipcub.hpp>
+
+#include <cstdlib>
 
 using namespace pgh;
 
@@ -219,7 +221,14 @@ extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, c
             PGH_HIP(hipGetLastError());
             PGH_HIP(hipStreamSynchronize(r.stream));
         }
-        return finish_graph(g);
+        PGH_TRY(finish_graph(g));
+        // the layout the propagation kernels stream (PGH_FORMAT=csr keeps only the row-major merge-path route)
+        const char* fmt = getenv("PGH_FORMAT");
+        if (fmt == nullptr || std::string(fmt) != "csr") {
+            const char* rl = getenv("PGH_RELABEL");
+            PGH_TRY(bsf_build(g, g->val, nullptr, nullptr, nullptr, rl == nullptr || atoi(rl) != 0));
+        }
+        return 0;
     }();
     if (rc != 0) {
         std::string keep = pgh_last_error();
@@ -241,6 +250,7 @@ extern "C" int pgh_graph_destroy(pgh_graph_t g) {
     (void)hipFree(g->chain_first);
     (void)hipFree(g->tail_carry);
     (void)hipFree(g->head_partial);
+    bsf_destroy(g->bsf);
     delete g;
     return 0;
 }

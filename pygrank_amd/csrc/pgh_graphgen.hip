@@ -12,15 +12,14 @@
 // Edges are a pure function of (seed, edge index): splitmix64 hashes and 32-bit integer thresholds, bit-for-bit
 // the same as oracle/rmat_np.py, so host tests see exactly the graph the GPU builds.  Sorting / run-length
 // encoding use rocPRIM through hipCUB: one-time format construction, not the per-iteration hot path.
-#include "pgh_common.h"
+#include "pgh_kernels.h"
 
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 using namespace pgh;
 
-namespace pgh {
-int finish_graph(pgh_graph_s* g);
-}
 
 namespace {
 
@@ -146,6 +145,23 @@ __global__ void k_rmat_values(const uint64_t* __restrict__ ukeys, const int* __r
     }
 }
 
+// per-source / per-row scales of the value-free blocked format: M^T = diag(dst) * multiplicities * diag(src)
+__global__ void k_rmat_scales(const unsigned int* __restrict__ outdeg, const unsigned int* __restrict__ indeg, int64_t n,
+                              int64_t n_local, int normalization, float* __restrict__ src, float* __restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double d = (double)outdeg[i];
+        double s = 1.0;
+        if (normalization == 0) s = d != 0.0 ? 1.0 / d : 0.0;
+        if (normalization == 1) s = d != 0.0 ? 1.0 / sqrt(d) : 0.0;
+        src[i] = (float)s;
+        if (dst != nullptr && i < n_local) {
+            const double e = (double)indeg[i];
+            dst[i] = (float)(e != 0.0 ? 1.0 / sqrt(e) : 0.0);
+        }
+    }
+}
+
 __global__ void k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (float)in[i];
@@ -268,7 +284,26 @@ extern "C" int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, doub
         k_f64_to_f32<<<blocks_for(n), kBlock, 0, r.stream>>>(deg_acc.p, g->degrees, n);
         PGH_HIP(hipGetLastError());
         PGH_HIP(hipStreamSynchronize(r.stream));
-        return finish_graph(g);
+        PGH_TRY(finish_graph(g));
+        // blocked value-free layout: multiplicities as repeated entries, the normalisation as vector scales
+        const char* fmt = getenv("PGH_FORMAT");
+        if (nnz > 0 && (fmt == nullptr || std::string(fmt) != "csr")) {
+            const char* rl = getenv("PGH_RELABEL");
+            const bool valfree = getenv("PGH_VALUES") == nullptr || atoi(getenv("PGH_VALUES")) == 0;
+            if (valfree) {
+                DevBuf<float> src, dst;
+                PGH_TRY(src.alloc(n));
+                if (normalization == 1) PGH_TRY(dst.alloc(n_local));
+                k_rmat_scales<<<blocks_for(n), kBlock, 0, r.stream>>>(outdeg.p, indeg.p, n, n_local, normalization, src.p,
+                                                                      normalization == 1 ? dst.p : nullptr);
+                PGH_HIP(hipGetLastError());
+                PGH_TRY(bsf_build(g, nullptr, counts.p, normalization == 2 ? nullptr : src.p,
+                                  normalization == 1 ? dst.p : nullptr, rl == nullptr || atoi(rl) != 0));
+            } else {
+                PGH_TRY(bsf_build(g, g->val, nullptr, nullptr, nullptr, rl == nullptr || atoi(rl) != 0));
+            }
+        }
+        return 0;
     }();
     if (rc != 0) {
         std::string keep = pgh_last_error();

@@ -1,0 +1,86 @@
+// Shared device-side definitions of the propagation kernels (internal; not part of the C-ABI).
+#pragma once
+#include "pgh_common.h"
+
+namespace pgh {
+
+constexpr int WG = 256;
+
+enum EpiMode { EPI_PLAIN = 0, EPI_AXPBY = 1, EPI_ABSORB = 2, EPI_POLY = 3 };
+
+struct EpiParams {
+    double       a;        // multiplies the row sum (alpha, or 1 / 2 for the polynomial recurrences)
+    double       b;        // multiplies v[row]  ((1 - alpha) for PageRank, 0 / -1 for polynomial terms)
+    const float* v;        // personalization p (PPR / ABSORB) or the current term (POLY with b != 0)
+    const float* deg;      // ABSORB: degrees(M)
+    const float* lam;      // ABSORB: absorption * (1 - alpha) / alpha
+    float*       y;        // output vector
+    float*       r;        // POLY: result accumulator (in place)
+    double       c;        // POLY: coefficient of the new term
+    int          err_linf; // POLY: delta is a max instead of a sum
+    float*       xg_out;   // blocked format with a source scale: next gather source y * src_scale (else null)
+    const float* src_scale;
+};
+
+// Device-resident loop state (ConvergenceManager on the device, convergence.py:77-101).
+struct LoopState {
+    double scale;       // lazily applied L1 quotient of the current iterate (abstract_filters.py:133-134)
+    double err;         // last residual
+    double sum;         // sum(y) of the last step
+    int    done;        // convergence flag: once set every later kernel of the loop is a no-op
+    int    steps;       // propagation steps executed so far
+    int    converged;   // 1 when the tolerance was met
+    int    pad;
+};
+
+struct GraphView {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float*   val;
+    const int2*    tile_coord;
+    const int32_t* chain_first;
+    double*        tail_carry;
+    double*        head_partial;
+    int            n;          // rows of M^T (= length of y)
+    int            num_tiles;
+};
+
+template <int MODE>
+__device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff, int row, float sum,
+                                                double& sum_y, double& delta) {
+    float y;
+    if (MODE == EPI_PLAIN) {
+        y = a_eff * sum;
+    } else if (MODE == EPI_AXPBY || MODE == EPI_POLY) {
+        y = a_eff * sum;
+        if (ep.v != nullptr) y += (float)ep.b * ep.v[row];
+    } else {   // EPI_ABSORB: ((M^T x) * deg + p * lam) / (lam + deg), adhoc.py:167-168
+        const float d = ep.deg[row], l = ep.lam[row];
+        y = (a_eff * sum * d + ep.v[row] * l) / (l + d);
+    }
+    ep.y[row] = y;
+    if (ep.xg_out != nullptr) ep.xg_out[row] = y * ep.src_scale[row];
+    sum_y += (double)y;
+    if (MODE == EPI_POLY) {
+        const float r_old = ep.r[row];
+        const float r_new = r_old + (float)ep.c * y;
+        ep.r[row] = r_new;
+        const double d = fabs((double)r_new - (double)r_old);
+        delta = ep.err_linf ? fmax(delta, d) : delta + d;
+    }
+    return y;
+}
+
+
+
+// blocked-format entry points (pgh_bsf.hip)
+template <int MODE>
+int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials);
+int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale, float hole);
+int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
+int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);
+int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel);
+void bsf_destroy(BsfFormat& f);
+int finish_graph(pgh_graph_s* g);
+
+}  // namespace pgh

@@ -19,75 +19,11 @@
 //   * The epilogue (alpha/(1-alpha) axpby, absorbing-walk quotient, polynomial accumulation) and the
 //     block-partial sum(y) / residual run in the same pass, so one propagation step reads the matrix once
 //     and every dense vector once: 8*nnz + 16*n bytes for the PageRank step.
-#include "pgh_common.h"
+#include "pgh_kernels.h"
 
 using namespace pgh;
 
 namespace {
-
-constexpr int WG = 256;
-
-enum EpiMode { EPI_PLAIN = 0, EPI_AXPBY = 1, EPI_ABSORB = 2, EPI_POLY = 3 };
-
-struct EpiParams {
-    double       a;        // multiplies the row sum (alpha, or 1 / 2 for the polynomial recurrences)
-    double       b;        // multiplies v[row]  ((1 - alpha) for PageRank, 0 / -1 for polynomial terms)
-    const float* v;        // personalization p (PPR / ABSORB) or the current term (POLY with b != 0)
-    const float* deg;      // ABSORB: degrees(M)
-    const float* lam;      // ABSORB: absorption * (1 - alpha) / alpha
-    float*       y;        // output vector
-    float*       r;        // POLY: result accumulator (in place)
-    double       c;        // POLY: coefficient of the new term
-    int          err_linf; // POLY: delta is a max instead of a sum
-};
-
-// Device-resident loop state (ConvergenceManager on the device, convergence.py:77-101).
-struct LoopState {
-    double scale;       // lazily applied L1 quotient of the current iterate (abstract_filters.py:133-134)
-    double err;         // last residual
-    double sum;         // sum(y) of the last step
-    int    done;        // convergence flag: once set every later kernel of the loop is a no-op
-    int    steps;       // propagation steps executed so far
-    int    converged;   // 1 when the tolerance was met
-    int    pad;
-};
-
-struct GraphView {
-    const int32_t* rowptr;
-    const int32_t* col;
-    const float*   val;
-    const int2*    tile_coord;
-    const int32_t* chain_first;
-    double*        tail_carry;
-    double*        head_partial;
-    int            n;          // rows of M^T (= length of y)
-    int            num_tiles;
-};
-
-template <int MODE>
-__device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff, int row, float sum,
-                                                double& sum_y, double& delta) {
-    float y;
-    if (MODE == EPI_PLAIN) {
-        y = a_eff * sum;
-    } else if (MODE == EPI_AXPBY || MODE == EPI_POLY) {
-        y = a_eff * sum;
-        if (ep.v != nullptr) y += (float)ep.b * ep.v[row];
-    } else {   // EPI_ABSORB: ((M^T x) * deg + p * lam) / (lam + deg), adhoc.py:167-168
-        const float d = ep.deg[row], l = ep.lam[row];
-        y = (a_eff * sum * d + ep.v[row] * l) / (l + d);
-    }
-    ep.y[row] = y;
-    sum_y += (double)y;
-    if (MODE == EPI_POLY) {
-        const float r_old = ep.r[row];
-        const float r_new = r_old + (float)ep.c * y;
-        ep.r[row] = r_new;
-        const double d = fabs((double)r_new - (double)r_old);
-        delta = ep.err_linf ? fmax(delta, d) : delta + d;
-    }
-    return y;
-}
 
 // -------------------------------------------------------------------------------------------------
 // main kernel: persistent workgroups stride over the merge-path tiles
@@ -373,6 +309,23 @@ __global__ void k_scale_copy(const float* __restrict__ in, float* __restrict__ o
 // -------------------------------------------------------------------------------------------------
 constexpr int kIPT = PGH_IPT;   // 7 -> 1792 merge items per tile; 21.5 KB LDS per workgroup
 
+// epilogue of a step applied to plain row sums held in a dense vector (single-step entry points on the
+// blocked format: the sums come back in the caller's id space)
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_apply_epilogue(const float* __restrict__ sums, int64_t n, EpiParams ep, float a_eff,
+                                                        double* __restrict__ partial_sum, double* __restrict__ partial_delta) {
+    __shared__ double s_red[4];
+    double sum_y = 0.0, delta = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG)
+        apply_epilogue<MODE>(ep, a_eff, (int)i, sums[i], sum_y, delta);
+    const double bs = block_reduce_256<0>(sum_y, s_red);
+    if (threadIdx.x == 0) partial_sum[blockIdx.x] = bs;
+    if (MODE == EPI_POLY) {
+        const double bd = ep.err_linf ? block_reduce_256<1>(delta, s_red) : block_reduce_256<0>(delta, s_red);
+        if (threadIdx.x == 0) partial_delta[blockIdx.x] = bd;
+    }
+}
+
 GraphView view_of(pgh_graph_t g) {
     GraphView v;
     v.rowptr = g->rowptr;
@@ -404,10 +357,10 @@ StepGrid grids_for(pgh_graph_t g) {
     return s;
 }
 
-// Enqueue one SpMV (+ fix-up) with epilogue MODE.  Block partials land in rt().d_partials:
-//   sums  : [0, total)            deltas: [kMaxPartials, kMaxPartials + total)
+// Row-major merge-path route: one SpMV (+ fix-up) with epilogue MODE.  Block partials land in rt().d_partials:
+//   sums  : [0, count)            deltas: [kMaxPartials, kMaxPartials + count)
 template <int MODE>
-int launch_spmv(pgh_graph_t g, const EpiParams& ep, const float* x, const LoopState* state, StepGrid* grid_out) {
+int launch_merge(pgh_graph_t g, const EpiParams& ep, const float* x, const LoopState* state, int* num_partials) {
     Runtime& r = rt();
     PGH_CHECK(g->items_per_tile == WG * kIPT, "graph tile table was built for a different tile size");
     const GraphView v = view_of(g);
@@ -423,8 +376,15 @@ int launch_spmv(pgh_graph_t g, const EpiParams& ep, const float* x, const LoopSt
         k_spmv_fixup<MODE><<<sg.fix_grid, WG, 0, r.stream>>>(v, ep, state, psum + sg.main_grid, pdel + sg.main_grid);
     }
     PGH_HIP(hipGetLastError());
-    if (grid_out) *grid_out = sg;
+    if (num_partials) *num_partials = sg.total();
     return 0;
+}
+
+// One propagation step in the graph's internal id space, whichever format the graph carries.
+template <int MODE>
+int launch_step(pgh_graph_t g, const EpiParams& ep, const float* gather_src, const LoopState* state, int* num_partials) {
+    if (g->bsf.enabled) return bsf_launch<MODE>(g, ep, gather_src, state, num_partials);
+    return launch_merge<MODE>(g, ep, gather_src, state, num_partials);
 }
 
 inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -461,18 +421,48 @@ int fetch_scalars(int first, int count) {
     return 0;
 }
 
-// single-shot step: run SpMV+fix-up with MODE, fold sum(y) (and delta) to the host
+struct DevF32 {
+    float* p = nullptr;
+    ~DevF32() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(int64_t n) {
+        PGH_HIP(hipMalloc(&p, sizeof(float) * (size_t)(n > 0 ? n : 1)));
+        return 0;
+    }
+};
+
+// single-shot step in the CALLER's id space: ep holds caller-space pointers, x is the un-scaled gather vector
 template <int MODE>
-int single_step(pgh_graph_t g, const EpiParams& ep, const float* x, double* sum_out, double* delta_out, int err_kind) {
+int single_step(pgh_graph_t g, const EpiParams& ep_in, const float* x, double* sum_out, double* delta_out, int err_kind) {
     PGH_TRY(ensure_state());
     Runtime& r = rt();
-    StepGrid sg;
+    int count = 0;
     k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
-    PGH_TRY((launch_spmv<MODE>(g, ep, x, nullptr, &sg)));
+    if (!g->bsf.enabled) {
+        PGH_TRY((launch_merge<MODE>(g, ep_in, x, nullptr, &count)));
+    } else {
+        // plain row sums through the blocked format, returned to the caller's space, then the epilogue there
+        BsfFormat& f = g->bsf;
+        PGH_TRY(bsf_to_internal(g, x, f.xg, f.src_scale != nullptr, 0.f));
+        EpiParams plain{};
+        plain.a = 1.0;
+        plain.y = f.tmp_out;
+        PGH_TRY((bsf_launch<EPI_PLAIN>(g, plain, f.xg, nullptr, &count)));
+        DevF32 sums;
+        PGH_TRY(sums.alloc(g->n_cols));
+        PGH_TRY(bsf_to_original(g, f.tmp_out, sums.p, 1.0));
+        count = residual_grid(g->n_cols) * 4;
+        if (count > kMaxPartials) count = kMaxPartials;
+        k_apply_epilogue<MODE><<<count, WG, 0, r.stream>>>(sums.p, g->n_cols, ep_in, (float)ep_in.a, r.d_partials,
+                                                          r.d_partials + kMaxPartials);
+        PGH_HIP(hipGetLastError());
+        PGH_HIP(hipStreamSynchronize(r.stream));       // sums is freed on return
+    }
     if (sum_out != nullptr || delta_out != nullptr) {
         ProfScope prof(PGH_K_FINAL);
-        k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, sg.total(), r.d_partials + kMaxPartials, sg.total(),
-                                             0, MODE == EPI_POLY ? 1 : 0, err_kind, -1.0, g->n_cols, r.d_scalars);
+        k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, r.d_partials + kMaxPartials, count, 0,
+                                             MODE == EPI_POLY ? 1 : 0, err_kind, -1.0, g->n_cols, r.d_scalars);
         PGH_HIP(hipGetLastError());
         PGH_TRY(fetch_scalars(1, 2));
         if (sum_out) *sum_out = r.h_scalars[1];
@@ -577,6 +567,10 @@ int batch_for(pgh_graph_t g) {
 
 struct LoopTimer {
     hipEvent_t a = nullptr, b = nullptr;
+    ~LoopTimer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
     int start() {
         PGH_HIP(hipEventCreate(&a));
         PGH_HIP(hipEventCreate(&b));
@@ -589,8 +583,27 @@ struct LoopTimer {
         float f = 0.f;
         PGH_HIP(hipEventElapsedTime(&f, a, b));
         *ms = (double)f;
-        (void)hipEventDestroy(a);
-        (void)hipEventDestroy(b);
+        return 0;
+    }
+};
+
+// Vectors of a loop in the graph's internal id space.  Row-major graphs: internal == caller space (no copies).
+// Blocked graphs: relabelled + padded; `bring` copies a caller vector in, `take_back` writes the result out.
+struct InternalSpace {
+    pgh_graph_t g;
+    bool        blocked;
+    int64_t     n;        // caller-space length (square loops)
+    int64_t     n_int;    // internal length
+    explicit InternalSpace(pgh_graph_t graph) : g(graph), blocked(graph->bsf.enabled), n(graph->n_cols),
+                                                n_int(graph->bsf.enabled ? graph->bsf.n_out : graph->n_cols) {}
+    int bring(const float* src, DevF32& buf, const float** out, float hole = 0.f) {
+        if (!blocked) {
+            *out = src;
+            return 0;
+        }
+        PGH_TRY(buf.alloc(n_int));
+        PGH_TRY(bsf_out_to_internal(g, src, buf.p, hole));
+        *out = buf.p;
         return 0;
     }
 };
@@ -605,15 +618,33 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     PGH_CHECK(ranks && ranks->n == n, "ranks length mismatch");
     PGH_CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
     memset(res, 0, sizeof(*res));
-    // two work buffers; buf[0] starts as the incoming ranks
-    float* work = nullptr;
-    PGH_HIP(hipMalloc(&work, sizeof(float) * (size_t)(n > 0 ? n : 1)));
-    float* buf[2] = {ranks->data, work};
-    const int linf = (cfg->err_kind == PGH_ERR_LINF);
-    const int rgrid = residual_grid(n);
-    double* pres = r.d_partials + kMaxPartials;      // residual partials share the delta region
+    InternalSpace sp(g);
+    const int64_t n_int = sp.n_int;
     LoopTimer timer;
     PGH_TRY(timer.start());
+    // ---- bring the operands into the internal space
+    DevF32 v_buf, deg_buf, lam_buf, y0, y1;
+    PGH_TRY(sp.bring(ep.v, v_buf, &ep.v));
+    if (MODE == EPI_ABSORB) {
+        PGH_TRY(sp.bring(ep.deg, deg_buf, &ep.deg));
+        PGH_TRY(sp.bring(ep.lam, lam_buf, &ep.lam, 1.f));      // holes: (0 * 0 + 0 * 1) / (1 + 0) = 0
+    }
+    PGH_TRY(y1.alloc(n_int));
+    float* buf[2] = {ranks->data, y1.p};
+    if (sp.blocked) {
+        PGH_TRY(y0.alloc(n_int));
+        PGH_TRY(bsf_out_to_internal(g, ranks->data, y0.p, 0.f));
+        buf[0] = y0.p;
+    }
+    const bool scaled_gather = sp.blocked && g->bsf.src_scale != nullptr;
+    if (scaled_gather) {
+        PGH_TRY(bsf_to_internal(g, ranks->data, g->bsf.xg, true, 0.f));
+        ep.xg_out = g->bsf.xg;
+        ep.src_scale = g->bsf.src_scale;
+    }
+    const int linf = (cfg->err_kind == PGH_ERR_LINF);
+    const int rgrid = residual_grid(n_int);
+    double* pres = r.d_partials + kMaxPartials;      // residual partials share the delta region
     k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
     // ConvergenceManager.has_converged is evaluated before every step with iteration = step index
     // (convergence.py:85): step k runs iff k < max_iters and the check at iteration k did not fire.
@@ -628,20 +659,20 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             const float* xin = buf[(k - 1) & 1];
             float* yout = buf[k & 1];
             ep.y = yout;
-            StepGrid sg;
-            PGH_TRY((launch_spmv<MODE>(g, ep, xin, g_state, &sg)));
+            int count = 0;
+            PGH_TRY((launch_step<MODE>(g, ep, scaled_gather ? g->bsf.xg : xin, g_state, &count)));
             // the check that follows step k happens at iteration k + 1 (skipped when that iteration hits max_iters)
             const int it = k + 1;
             const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
             if (check) {
                 ProfScope prof(PGH_K_RESIDUAL);
                 const int vec_ok = aligned16(yout) && aligned16(xin);
-                k_step_residual<<<rgrid, WG, 0, r.stream>>>(yout, xin, n, vec_ok, cfg->use_quotient, linf, g_state,
-                                                            r.d_partials, sg.total(), pres);
+                k_step_residual<<<rgrid, WG, 0, r.stream>>>(yout, xin, n_int, vec_ok, cfg->use_quotient, linf, g_state,
+                                                            r.d_partials, count, pres);
             }
             {
                 ProfScope prof(PGH_K_FINAL);
-                k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, sg.total(), pres, rgrid, cfg->use_quotient,
+                k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, pres, rgrid, cfg->use_quotient,
                                                      check, cfg->err_kind, cfg->tol, n, nullptr);
             }
         }
@@ -654,11 +685,13 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     // result lives in buf[steps & 1]; apply the pending quotient and preserve_norm factor
     const double factor = g_state_host->scale * cfg->out_scale;
     const float* final_buf = buf[steps & 1];
-    if (n > 0 && (final_buf != ranks->data || factor != 1.0))
+    if (sp.blocked) {
+        PGH_TRY(bsf_to_original(g, final_buf, ranks->data, factor));
+    } else if (n > 0 && (final_buf != ranks->data || factor != 1.0)) {
         k_scale_copy<<<residual_grid(n), WG, 0, r.stream>>>(final_buf, ranks->data, n, factor);
+    }
     PGH_HIP(hipGetLastError());
     PGH_TRY(timer.stop(&res->loop_ms));
-    PGH_HIP(hipFree(work));
     res->iterations = steps + 1;                 // ConvergenceManager.iteration at loop exit
     res->converged = g_state_host->converged;
     res->spmv_count = steps;
@@ -717,23 +750,36 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
         res->converged = 0;
         return 0;
     }
+    InternalSpace sp(g);
+    const int64_t n_int = sp.n_int;
+    DevF32 p_buf, res_buf, t0, t1;
+    const float* p_int = nullptr;
+    PGH_TRY(sp.bring(p->data, p_buf, &p_int));
+    float* result_int = result->data;
+    if (sp.blocked) {
+        PGH_TRY(res_buf.alloc(n_int));
+        result_int = res_buf.p;
+    }
     const double c1 = coeff(1);
-    if (n > 0) k_scale_copy<<<residual_grid(n), WG, 0, r.stream>>>(p->data, result->data, n, c1);
-    // delta_1 = sum|result_1 - 0| = |c_1| * sum|p|; evaluated on the device like every other delta
-    float* tbuf[2] = {nullptr, nullptr};
-    PGH_HIP(hipMalloc(&tbuf[0], sizeof(float) * (size_t)(n > 0 ? n : 1)));
-    PGH_HIP(hipMalloc(&tbuf[1], sizeof(float) * (size_t)(n > 0 ? n : 1)));
-    const float* term = p->data;      // term_1
+    if (n_int > 0) k_scale_copy<<<residual_grid(n_int), WG, 0, r.stream>>>(p_int, result_int, n_int, c1);
+    PGH_TRY(t0.alloc(n_int));
+    PGH_TRY(t1.alloc(n_int));
+    float* tbuf[2] = {t0.p, t1.p};
+    const float* term = p_int;        // term_1
+    const bool scaled_gather = sp.blocked && g->bsf.src_scale != nullptr;
+    if (scaled_gather) PGH_TRY(bsf_to_internal(g, p->data, g->bsf.xg, true, 0.f));
+    // delta_1 = |result_1 - 0|, evaluated on the device like every other delta
     double err = 0.0;
     {
-        pgh_vec_s zero_view;          // |result_1 - 0|
-        double e = 0.0;
-        pgh_vec_s rv = *result;
+        pgh_vec_s rv;
+        rv.data = result_int;
+        rv.n = n_int;
         rv.owns = false;
-        // residual against an implicit zero vector: scaled residual with x_scale = 0
-        PGH_TRY(pgh_scaled_residual(cfg->err_kind == PGH_ERR_ITERS ? PGH_ERR_L1 : cfg->err_kind, &rv, 1.0, &rv, 0.0, &e));
+        double e = 0.0;
+        const int kind = cfg->err_kind == PGH_ERR_ITERS ? PGH_ERR_L1 : cfg->err_kind;
+        PGH_TRY(pgh_scaled_residual(kind == PGH_ERR_MABS ? PGH_ERR_L1 : kind, &rv, 1.0, &rv, 0.0, &e));
+        if (kind == PGH_ERR_MABS && n > 0) e /= (double)n;
         err = e;
-        (void)zero_view;
     }
     int spmv = 0;
     bool converged = false;
@@ -763,17 +809,21 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
                 ep.v = cheb ? term : nullptr;
                 float* tout = tbuf[k & 1];
                 ep.y = tout;
-                ep.r = result->data;
+                ep.r = result_int;
                 ep.c = coeff(k);
                 ep.err_linf = (cfg->err_kind == PGH_ERR_LINF);
-                StepGrid sg;
-                PGH_TRY((launch_spmv<EPI_POLY>(g, ep, term, g_state, &sg)));
+                if (scaled_gather) {
+                    ep.xg_out = g->bsf.xg;
+                    ep.src_scale = g->bsf.src_scale;
+                }
+                int count = 0;
+                PGH_TRY((launch_step<EPI_POLY>(g, ep, scaled_gather ? g->bsf.xg : term, g_state, &count)));
                 const int chk_it = k + 1;         // the comparison of result_k with result_{k-1}
                 const int check = (cfg->err_kind != PGH_ERR_ITERS) && (chk_it < max_iters) && (chk_it % cfg->end_modulo == 0);
                 {
                     ProfScope prof(PGH_K_FINAL);
-                    k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, sg.total(), r.d_partials + kMaxPartials,
-                                                         sg.total(), 0, check, cfg->err_kind, cfg->tol, n, nullptr);
+                    k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, r.d_partials + kMaxPartials,
+                                                         count, 0, check, cfg->err_kind, cfg->tol, n, nullptr);
                 }
                 term = tout;
             }
@@ -786,14 +836,14 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
         converged = g_state_host->converged != 0;
         err = g_state_host->steps > 0 ? g_state_host->err : err;
         it = 2 + spmv;                 // iteration value at loop exit
-        if (!converged && it < max_iters) it = max_iters;
     }
-    if (n > 0 && cfg->out_scale != 1.0)
+    if (sp.blocked) {
+        PGH_TRY(bsf_to_original(g, result_int, result->data, cfg->out_scale));
+    } else if (n > 0 && cfg->out_scale != 1.0) {
         k_scale_copy<<<residual_grid(n), WG, 0, r.stream>>>(result->data, result->data, n, cfg->out_scale);
+    }
     PGH_HIP(hipGetLastError());
     PGH_TRY(timer.stop(&res->loop_ms));
-    PGH_HIP(hipFree(tbuf[0]));
-    PGH_HIP(hipFree(tbuf[1]));
     res->iterations = it;
     res->converged = converged ? 1 : 0;
     res->spmv_count = spmv;
