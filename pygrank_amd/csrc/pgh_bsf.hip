@@ -29,8 +29,10 @@ using namespace pgh;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kIPT = PGH_IPT;
-constexpr int kTile = WG * kIPT;
+constexpr int kIPT = PGH_BSF_IPT;          // entries per lane of a wavefront tile
+constexpr int kTile = 64 * kIPT;            // one tile = one wavefront
+constexpr int kBsfThreads = 1024;           // one 16-wavefront workgroup per CU shares the hot cache
+constexpr int kBsfHot = PGH_BSF_HOT;        // f32 entries of the gather vector cached in LDS per workgroup
 constexpr uint64_t kLow29 = (1ULL << 29) - 1;
 constexpr uint64_t kRowSentinel = kLow29;        // sorts after every real row of a block
 
@@ -213,109 +215,124 @@ struct BsfView {
     float*          part;
     int64_t         part_stride;
     int             num_blocks;
-    int             pad_index;
+    int             blk_size;
     int             tile_begin[9];
 };
 
-// One tile = kTile consecutive entries of one column block.  Coalesced (non-temporal) stream of the column words,
-// gather from the block's L2-resident slice of xg, LDS transpose so that every thread owns IPT consecutive
-// entries, serial segmented sum in f64, __shfl_up segmented scan across the wavefront + LDS hand-off across the
-// 4 wavefronts, carries for segments that cross tiles.
+// One tile = 64 * IPT consecutive entries of one column block, owned by ONE wavefront: no workgroup barrier is
+// needed inside the tile loop, so the 16 wavefronts of a 1024-thread workgroup (one workgroup per CU) run
+// 16 independent load -> gather -> segmented-sum pipelines and hide each other's latency.
+//
+// What the workgroup shares is the HOT CACHE: the first kBsfHot entries of the block's (hot-first ordered)
+// slice of the gather vector, copied into LDS once per launch.  On a power-law graph they serve the bulk of
+// the gathers at LDS speed; only the cold remainder goes through the vector memory pipe, whose divergent-
+// address issue rate (not L2 hit rate) bounds this kernel (profiles/r01/bsf_v2_probe_scale23.log).
+//
+// Per tile: coalesced non-temporal stream of the column words (next tile prefetched into registers), gather,
+// products to the wavefront's private LDS strip, every lane then owns IPT consecutive entries, serial segmented
+// sum in f64, __shfl_up segmented scan across the 64 lanes, f64 carries for segments that cross tiles.
 template <int IPT, bool HAS_VAL>
-__global__ __launch_bounds__(WG) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
-                                                     const LoopState* __restrict__ state) {
-    constexpr int T = WG * IPT;
-    constexpr int NW = 4 * IPT;                       // 64-bit flag words per tile
-    __shared__ float              s_prod[T];
-    __shared__ float              s_out[T];
-    __shared__ unsigned long long s_mask[NW + 1];
-    __shared__ int                s_wpre[NW + 1];
-    __shared__ int                s_wkey[4];
-    __shared__ double             s_wval[4];
+__global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
+                                                              const LoopState* __restrict__ state) {
+    constexpr int T = 64 * IPT;
+    constexpr int WAVES = kBsfThreads / 64;
+    __shared__ float              s_hot[kBsfHot];
+    __shared__ float              s_strip[WAVES][T];
+    __shared__ unsigned long long s_mask[WAVES][IPT + 1];
     if (state != nullptr && state->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
     const int label = blockIdx.x & 7;
     const int b = label % f.num_blocks;
     const int per = 8 / f.num_blocks;
-    const int rank = (blockIdx.x >> 3) * per + label / f.num_blocks;
-    const int stride = (gridDim.x >> 3) * per;
+    const int rank = ((blockIdx.x >> 3) * per + label / f.num_blocks) * WAVES + wave;
+    const int stride = (gridDim.x >> 3) * per * WAVES;
     float* __restrict__ part = f.part + (int64_t)b * f.part_stride;
+    const int base = b * f.blk_size;
+    const int hot = min(kBsfHot, f.blk_size);
+    for (int i = tid; i < hot; i += kBsfThreads) s_hot[i] = xg[base + i];
+    __syncthreads();
+    float* __restrict__ strip = s_strip[wave];
+    unsigned long long* __restrict__ mask = s_mask[wave];
 
-    for (int t = f.tile_begin[b] + rank; t < f.tile_begin[b + 1]; t += stride) {
-        const int4 ti = f.tile[t];
-        const int z0 = ti.x, count = ti.y, seg_base = ti.z;
-        uint32_t cf[IPT];
-        float    vv[IPT];
+    int t = f.tile_begin[b] + rank;
+    const int t_end = f.tile_begin[b + 1];
+    uint32_t cf[IPT];
+    float    vv[IPT];
+    int4     ti = make_int4(0, 0, 0, 0);
+    auto fetch = [&](int tile) {
+        ti = f.tile[tile];
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
-            const int idx = k * WG + tid;
-            const bool ok = idx < count;
-            cf[k] = ok ? __builtin_nontemporal_load(f.colf + z0 + idx) : (uint32_t)f.pad_index;
-            if (HAS_VAL) vv[k] = ok ? __builtin_nontemporal_load(f.val + z0 + idx) : 0.f;
+            const int idx = k * 64 + lane;
+            const bool ok = idx < ti.y;
+            cf[k] = ok ? __builtin_nontemporal_load(f.colf + ti.x + idx) : (uint32_t)base;
+            if (HAS_VAL) vv[k] = ok ? __builtin_nontemporal_load(f.val + ti.x + idx) : 0.f;
         }
+    };
+    if (t < t_end) fetch(t);
+    for (; t < t_end; t += stride) {
+        const int seg_base = ti.z;
+        // ---- gather (hot entries from LDS, cold ones from the L2-resident slice) and stage the products
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
-            const int idx = k * WG + tid;
-#if PGH_PROBE_GATHER == 1
-            const float xv = xg[cf[k] & 1023u];
-#elif PGH_PROBE_GATHER == 2
-            const float xv = xg[cf[k] & 0xFFFFFu];
-#elif PGH_PROBE_GATHER == 3
-            const float xv = (float)(cf[k] & 0xffffu);
-#elif PGH_PROBE_GATHER == 4
-            const float xv = __hip_atomic_load(xg + (cf[k] & 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif PGH_PROBE_GATHER == 5
-            const float xv = __builtin_nontemporal_load(xg + (cf[k] & 0x7fffffffu));
+            const uint32_t c = cf[k] & 0x7fffffffu;
+            const uint32_t loc = c - (uint32_t)base;
+#if PGH_PROBE_GATHER == 3
+            const float xv = (float)(c & 0xffffu);
+#elif PGH_PROBE_GATHER == 6
+            const float xv = s_hot[loc % (uint32_t)hot];
 #else
-            const float xv = xg[cf[k] & 0x7fffffffu];
+            const float xv = loc < (uint32_t)hot ? s_hot[loc] : xg[c];
 #endif
-            s_prod[idx] = HAS_VAL ? vv[k] * xv : xv;
+            strip[k * 64 + lane] = HAS_VAL ? vv[k] * xv : xv;
             const unsigned long long m = __ballot((cf[k] >> 31) != 0);
-            if (lane == 0) s_mask[k * 4 + wave] = m;
+            if (lane == 0) mask[k] = m;
         }
-        if (tid == 0) s_mask[NW] = 0ULL;
-        __syncthreads();
-        if (wave == 0) {                               // exclusive prefix of the per-word flag counts
-            const int pc = lane < NW ? __popcll(s_mask[lane]) : 0;
-            int inc = pc;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += v;
-            }
-            if (lane < NW) s_wpre[lane] = inc - pc;
-            if (lane == NW - 1) s_wpre[NW] = inc;
-        }
-        __syncthreads();
-        const int total_flags = s_wpre[NW];
-        // ---- this thread's IPT consecutive entries
-        const int p0 = tid * IPT;
+        if (lane == 0) mask[IPT] = 0ULL;
+        const int this_tile = t;
+        if (t + stride < t_end) fetch(t + stride);          // prefetch the next tile's stream into registers
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- this lane's IPT consecutive entries
+        const int p0 = lane * IPT;
         const int w0 = p0 >> 6, off = p0 & 63;
-        const unsigned long long m0 = s_mask[w0], m1 = s_mask[w0 + 1];
+        const unsigned long long m0 = mask[w0], m1 = mask[w0 + 1];
         unsigned int bits = (unsigned int)(m0 >> off);
         if (off + IPT > 64) bits |= (unsigned int)(m1 << (64 - off));
         bits &= (1u << IPT) - 1u;
-        const int before = s_wpre[w0] + __popcll(m0 & ((1ULL << off) - 1ULL));   // flags ahead of this chunk
+        int before = __popcll(m0 & ((1ULL << off) - 1ULL));      // flags ahead of this chunk
+        int total_flags = 0;
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int pc = __popcll(mask[u]);
+            if (u < w0) before += pc;
+            total_flags += pc;
+        }
+        float v[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) v[k] = strip[p0 + k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                    // strip is reused for the segment sums below
         double acc = 0.0, first_val = 0.0;
         int q = 0, first_o = -2;
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
-            if ((bits >> k) & 1u) {                   // entry k opens segment (before + q): close the open one
+            if ((bits >> k) & 1u) {                         // entry k opens segment (before + q): close the open one
                 const int o = before + q;
                 if (first_o == -2) {
                     first_o = o;
                     first_val = acc;
                 } else {
-                    s_out[o - 1] = (float)acc;
+                    strip[o - 1] = (float)acc;
                 }
                 acc = 0.0;
                 ++q;
             }
-            acc += (double)s_prod[p0 + k];
+            acc += (double)v[k];
         }
-        // ---- stitch segments that cross thread boundaries (keys are non-decreasing across threads)
-        int key = before + q - 1;                     // local index of the segment open at the end of the chunk
+        // ---- stitch segments that cross lane boundaries (keys are non-decreasing across lanes)
+        const int key = before + q - 1;                     // local index of the segment open at the end of the chunk
         double val = acc;
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) {
@@ -323,37 +340,25 @@ __global__ __launch_bounds__(WG) void k_bsf_partial(BsfView f, const float* __re
             const double v2 = __shfl_up(val, o2, 64);
             if (lane >= o2 && k2 == key) val += v2;
         }
-        if (lane == 63) {
-            s_wkey[wave] = key;
-            s_wval[wave] = val;
-        }
-        __syncthreads();
-        int pk = -2;
-        double pv = 0.0;
-        for (int w = 0; w < wave; ++w) {
-            const int wk = s_wkey[w];
-            const double wv = s_wval[w];
-            if (wk == pk) pv += wv; else { pk = wk; pv = wv; }
-        }
-        if (pk == key) val += pv;
-        int ek = __shfl_up(key, 1, 64);
-        double ev = __shfl_up(val, 1, 64);
-        if (lane == 0) { ek = pk; ev = pv; }
+        const int ek = __shfl_up(key, 1, 64);
+        const double ev = __shfl_up(val, 1, 64);
         if (first_o != -2) {
-            const int closes = first_o - 1;           // local index of the segment this thread's first flag closes
-            const double total = first_val + ((tid > 0 && ek == closes) ? ev : 0.0);
-            if (closes < 0) f.head_partial[t] = total;    // the segment that was open when the tile started
-            else s_out[closes] = (float)total;
+            const int closes = first_o - 1;                 // local index of the segment this lane's first flag closes
+            const double total = first_val + ((lane > 0 && ek == closes) ? ev : 0.0);
+            if (closes < 0) f.head_partial[this_tile] = total;   // the segment that was open when the tile started
+            else strip[closes] = (float)total;
         }
-        if (tid == WG - 1) f.tail_carry[t] = val;     // piece of the segment still open at the end of the tile
-        __syncthreads();
+        if (lane == 63) f.tail_carry[this_tile] = val;      // piece of the segment still open at the end of the tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // ---- segments that start and end inside the tile: local 0 .. total_flags - 2
         const int32_t* __restrict__ rows = f.seg_row + seg_base + 1;
-        for (int j = tid; j < total_flags - 1; j += WG) {
+        for (int j = lane; j < total_flags - 1; j += 64) {
             const int row = rows[j];
-            if (row >= 0) part[row] = s_out[j];
+            if (row >= 0) part[row] = strip[j];
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -415,7 +420,7 @@ BsfView view_of(const BsfFormat& f) {
     v.part = f.part;
     v.part_stride = f.n_out;
     v.num_blocks = f.num_blocks;
-    v.pad_index = 0;   // lanes past the end of a block only feed the sentinel's never-closed segment
+    v.blk_size = f.blk_size;
     for (int i = 0; i < 9; ++i) v.tile_begin[i] = f.tile_begin[i];
     return v;
 }
@@ -445,11 +450,11 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
     Runtime& r = rt();
     BsfFormat& f = g->bsf;
     const BsfView v = view_of(f);
-    const int main_grid = r.num_cus * 8;              // multiple of 8: XCD-affine block assignment
+    const int main_grid = r.num_cus;                  // one workgroup per CU; a multiple of 8 (XCD-affine blocks)
     {
         ProfScope prof(PGH_K_SPMV);
-        if (f.val) k_bsf_partial<kIPT, true><<<main_grid, WG, 0, r.stream>>>(v, xg, state);
-        else k_bsf_partial<kIPT, false><<<main_grid, WG, 0, r.stream>>>(v, xg, state);
+        if (f.val) k_bsf_partial<kIPT, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+        else k_bsf_partial<kIPT, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
     }
     {
         ProfScope prof(PGH_K_FIXUP);
@@ -547,7 +552,9 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     f.n_src_pad = n_src_pad;
     f.relabelled = relabel;
     f.n_out_orig = (int)n_out;
-    f.n_out = relabel ? n_src_pad : (int)n_out;     // relabelled ids are spread over [0, B * blk): outputs live there too
+    // square graphs: outputs live in the padded internal id space [0, B * blk) (relabelled ids are spread over it,
+    // and an un-relabelled output vector doubles as the next gather vector, whose hot prefix is read per block)
+    f.n_out = (n_src == n_out) ? n_src_pad : (int)n_out;
 
     DevBuf<int32_t> iperm;
     if (relabel) {

@@ -59,6 +59,13 @@ int ensure_init();
 #ifndef PGH_IPT
 #define PGH_IPT 7
 #endif
+// blocked format: entries per lane of a wavefront tile, and the LDS hot cache (f32 entries) per workgroup
+#ifndef PGH_BSF_IPT
+#define PGH_BSF_IPT 8
+#endif
+#ifndef PGH_BSF_HOT
+#define PGH_BSF_HOT 30720
+#endif
 // diagnostic builds only (tools/probe_variants.py): 1 = gather from 4 KB, 2 = from 4 MB, 3 = no gather
 #ifndef PGH_PROBE_GATHER
 #define PGH_PROBE_GATHER 0
