@@ -128,6 +128,18 @@ __global__ void k_bsf_flags(const uint64_t* __restrict__ keys, int64_t E, uint32
     }
 }
 
+// diagnostics (PGH_DEBUG=1): entries whose column falls inside the per-workgroup hot cache
+__global__ void k_bsf_count_hot(const uint32_t* __restrict__ colf, int64_t E, int blk, int hot, unsigned long long* __restrict__ out) {
+    unsigned long long local = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += stride) {
+        const uint32_t c = colf[e] & 0x7fffffffu;
+        if ((int)(c % (uint32_t)blk) < hot) ++local;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+
 // segid = inclusive scan of flags; segment s = segid - 1 starts at the flagged entry
 __global__ void k_bsf_seg_rows(const uint64_t* __restrict__ keys, const int* __restrict__ segid, int64_t E,
                                int32_t* __restrict__ seg_row) {
@@ -152,6 +164,26 @@ __global__ void k_bsf_block_starts(const uint64_t* __restrict__ keys, int64_t E,
         if (keys[mid] < target) lo = mid + 1; else hi = mid;
     }
     starts[b] = lo;
+}
+
+struct PadLayout {
+    int64_t src_start[9];     // first sorted entry of every block (src_start[B] = E)
+    int64_t dst_start[9];     // first padded slot of every block (multiples of the tile size)
+    int     B;
+};
+
+// sorted keys -> tile-padded keys; pad slots repeat the block's sentinel key (same (block, row): no flag)
+__global__ void k_bsf_pad(PadLayout pl, const uint64_t* __restrict__ keys, const float* __restrict__ vals, int64_t EP, int blk,
+                          uint64_t* __restrict__ keys_out, float* __restrict__ vals_out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < EP; e += stride) {
+        int b = 0;
+        while (b + 1 < pl.B && e >= pl.dst_start[b + 1]) ++b;
+        const int64_t src = pl.src_start[b] + (e - pl.dst_start[b]);
+        const bool real = src < pl.src_start[b + 1];
+        keys_out[e] = real ? keys[src] : (((uint64_t)b << 58) | (kRowSentinel << 29) | (uint64_t)((int64_t)b * blk));
+        if (vals_out) vals_out[e] = real ? vals[src] : 0.f;
+    }
 }
 
 struct TileBuild {
@@ -216,29 +248,34 @@ struct BsfView {
     int64_t         part_stride;
     int             num_blocks;
     int             blk_size;
+    int             xg_bytes;
     int             tile_begin[9];
 };
 
 // One tile = 64 * IPT consecutive entries of one column block, owned by ONE wavefront: no workgroup barrier is
 // needed inside the tile loop, so the 16 wavefronts of a 1024-thread workgroup (one workgroup per CU) run
-// 16 independent load -> gather -> segmented-sum pipelines and hide each other's latency.
+// 16 independent pipelines and hide each other's latency.
 //
 // What the workgroup shares is the HOT CACHE: the first kBsfHot entries of the block's (hot-first ordered)
 // slice of the gather vector, copied into LDS once per launch.  On a power-law graph they serve the bulk of
 // the gathers at LDS speed; only the cold remainder goes through the vector memory pipe, whose divergent-
-// address issue rate (not L2 hit rate) bounds this kernel (profiles/r01/bsf_v2_probe_scale23.log).
+// address issue rate (not the L2 hit rate) bounds this kernel (profiles/r01/bsf_v2_probe_scale23.log).
 //
-// Per tile: coalesced non-temporal stream of the column words (next tile prefetched into registers), gather,
-// products to the wavefront's private LDS strip, every lane then owns IPT consecutive entries, serial segmented
-// sum in f64, __shfl_up segmented scan across the 64 lanes, f64 carries for segments that cross tiles.
+// Every lane owns IPT CONSECUTIVE entries and fetches them with 16-byte non-temporal loads (blocks are padded
+// to whole tiles at build time, so every load is aligned and in range): no LDS transpose, the segment flags
+// (bit 31 of the column words) are lane-local.  Three tiles are in flight per wavefront in registers:
+// column stream of tile t+2, gathers of tile t+1, arithmetic of tile t.  In-tile sums are f32 (a lane adds at
+// most IPT terms, the 64-lane stitch is a log-depth __shfl_up segmented scan); pieces of segments that cross
+// tiles are carried in f64 and combined in a fixed order by k_bsf_fixup (deterministic, atomic-free).
 template <int IPT, bool HAS_VAL>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
                                                               const LoopState* __restrict__ state) {
+    static_assert(IPT % 4 == 0, "lanes fetch their entries as 16-byte words");
     constexpr int T = 64 * IPT;
     constexpr int WAVES = kBsfThreads / 64;
-    __shared__ float              s_hot[kBsfHot];
-    __shared__ float              s_strip[WAVES][T];
-    __shared__ unsigned long long s_mask[WAVES][IPT + 1];
+    constexpr int Q = IPT / 4;
+    __shared__ float s_hot[kBsfHot];
+    __shared__ float s_strip[WAVES][T];
     if (state != nullptr && state->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
@@ -248,117 +285,165 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     const int rank = ((blockIdx.x >> 3) * per + label / f.num_blocks) * WAVES + wave;
     const int stride = (gridDim.x >> 3) * per * WAVES;
     float* __restrict__ part = f.part + (int64_t)b * f.part_stride;
-    const int base = b * f.blk_size;
-    const int hot = min(kBsfHot, f.blk_size);
-    for (int i = tid; i < hot; i += kBsfThreads) s_hot[i] = xg[base + i];
+    const uint32_t base = (uint32_t)(b * f.blk_size);
+    const uint32_t hot = (uint32_t)min(kBsfHot, f.blk_size);
+    for (uint32_t i = tid; i < hot; i += kBsfThreads) s_hot[i] = xg[base + i];
     __syncthreads();
     float* __restrict__ strip = s_strip[wave];
-    unsigned long long* __restrict__ mask = s_mask[wave];
-
-    int t = f.tile_begin[b] + rank;
     const int t_end = f.tile_begin[b + 1];
-    uint32_t cf[IPT];
-    float    vv[IPT];
-    int4     ti = make_int4(0, 0, 0, 0);
-    auto fetch = [&](int tile) {
-        ti = f.tile[tile];
+    const __amdgpu_buffer_rsrc_t xg_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg), 0, f.xg_bytes, 0x00020000);
+
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    struct Stream {
+        u32x4 c[Q];
+        u32x4 v[Q];
+    };
+    auto load_stream = [&](int tile, Stream& st) {
+        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(f.colf + (int64_t)tile * T + lane * IPT);
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            const int idx = k * 64 + lane;
-            const bool ok = idx < ti.y;
-            cf[k] = ok ? __builtin_nontemporal_load(f.colf + ti.x + idx) : (uint32_t)base;
-            if (HAS_VAL) vv[k] = ok ? __builtin_nontemporal_load(f.val + ti.x + idx) : 0.f;
+        for (int q = 0; q < Q; ++q) st.c[q] = __builtin_nontemporal_load(src + q);
+        if (HAS_VAL) {
+            const u32x4* __restrict__ vs = reinterpret_cast<const u32x4*>(f.val + (int64_t)tile * T + lane * IPT);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) st.v[q] = __builtin_nontemporal_load(vs + q);
         }
     };
-    if (t < t_end) fetch(t);
-    for (; t < t_end; t += stride) {
-        const int seg_base = ti.z;
-        // ---- gather (hot entries from LDS, cold ones from the L2-resident slice) and stage the products
+    // gather stage: issue the LDS read and the buffer load of every entry WITHOUT consuming them (the select happens
+    // one tile later, in the arithmetic stage), so both stay in flight across the loop back-edge
+    struct Gathered {
+        float h[IPT];        // hot-cache value (valid when the column is inside the cached prefix)
+        float c[IPT];        // buffer-load value (0 for hot lanes: their offset is pushed out of range)
+        int   row0, row1;    // output rows of the tile's first 128 closed segments (prefetched)
+        int   seg_base;
+    };
+    auto gather = [&](const Stream& st, int seg_base, Gathered& g) {
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
-            const uint32_t c = cf[k] & 0x7fffffffu;
-            const uint32_t loc = c - (uint32_t)base;
+            const uint32_t c = st.c[k >> 2][k & 3] & 0x7fffffffu;
+            const uint32_t loc = c - base;
 #if PGH_PROBE_GATHER == 3
-            const float xv = (float)(c & 0xffffu);
+            g.h[k] = (float)(c & 0xffffu);
+            g.c[k] = 0.f;
 #elif PGH_PROBE_GATHER == 6
-            const float xv = s_hot[loc % (uint32_t)hot];
+            g.h[k] = s_hot[loc % hot];
+            g.c[k] = 0.f;
+#elif PGH_PROBE_GATHER == 7      // every buffer load out of range: cost of issuing the (dropped) loads
+            g.h[k] = s_hot[loc % hot];
+            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, 0xfffffff0u, 0, 0));
+#elif PGH_PROBE_GATHER == 8      // cold lanes gather from a 4 KB window: divergent but L1-resident
+            g.h[k] = s_hot[loc < hot ? loc : 0u];
+            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, loc < hot ? 0xfffffff0u : (c & 1023u) << 2, 0, 0));
+#elif PGH_PROBE_GATHER == 9      // cold lanes gather from a 2 MB window: divergent, L2-resident
+            g.h[k] = s_hot[loc < hot ? loc : 0u];
+            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, loc < hot ? 0xfffffff0u : (c & 0x7ffffu) << 2, 0, 0));
 #else
-            const float xv = loc < (uint32_t)hot ? s_hot[loc] : xg[c];
+            g.h[k] = s_hot[loc < hot ? loc : 0u];
+            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, loc < hot ? 0xfffffff0u : c << 2, 0, 0));
 #endif
-            strip[k * 64 + lane] = HAS_VAL ? vv[k] * xv : xv;
-            const unsigned long long m = __ballot((cf[k] >> 31) != 0);
-            if (lane == 0) mask[k] = m;
         }
-        if (lane == 0) mask[IPT] = 0ULL;
-        const int this_tile = t;
-        if (t + stride < t_end) fetch(t + stride);          // prefetch the next tile's stream into registers
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- this lane's IPT consecutive entries
-        const int p0 = lane * IPT;
-        const int w0 = p0 >> 6, off = p0 & 63;
-        const unsigned long long m0 = mask[w0], m1 = mask[w0 + 1];
-        unsigned int bits = (unsigned int)(m0 >> off);
-        if (off + IPT > 64) bits |= (unsigned int)(m1 << (64 - off));
-        bits &= (1u << IPT) - 1u;
-        int before = __popcll(m0 & ((1ULL << off) - 1ULL));      // flags ahead of this chunk
-        int total_flags = 0;
+        g.seg_base = seg_base;
+        const int32_t* __restrict__ rows = f.seg_row + seg_base + 1;      // reads past the tile's segments are harmless
+        g.row0 = rows[lane];
+        g.row1 = rows[64 + lane];
+    };
+
+    int t = f.tile_begin[b] + rank;
+    if (t >= t_end) return;
+    // The pipeline issues its loads UNCONDITIONALLY (tile indices are clamped to the block's last tile; the clamped
+    // results are never consumed): a fixed number of vector-memory operations per iteration lets the compiler emit
+    // counted s_waitcnt vmcnt(N) instead of draining the queue, which is what keeps three tiles in flight.
+    const int t_last = t_end - 1;
+    Stream sa, sb, sc;
+    Gathered ga, gb;
+    load_stream(t, sa);
+    gather(sa, f.tile[t].z, ga);
+    load_stream(min(t + stride, t_last), sb);
+    int zb = f.tile[min(t + stride, t_last)].z;         // seg_base of the tile held in sb
+    for (; t < t_end; t += stride) {
+        // vmcnt retires in order: the gathers (needed at the top of the next iteration) are issued BEFORE the stream
+        // of tile t+2 (needed an iteration later), so waiting for the former leaves the latter in flight
+        gather(sb, zb, gb);                               // gathers + output rows one tile ahead
+        const int t2 = min(t + 2 * stride, t_last);
+        load_stream(t2, sc);                              // column stream + tile header two tiles ahead
+        const int zc = f.tile[t2].z;
+        // ---- arithmetic of tile t: lane-local flags, f32 segmented sum
+        unsigned int bits = 0;
+        float prod[IPT];
 #pragma unroll
-        for (int u = 0; u < IPT; ++u) {
-            const int pc = __popcll(mask[u]);
-            if (u < w0) before += pc;
-            total_flags += pc;
+        for (int k = 0; k < IPT; ++k) {
+            const uint32_t w = sa.c[k >> 2][k & 3];
+            bits |= (w >> 31) << k;
+#if PGH_PROBE_GATHER == 3 || PGH_PROBE_GATHER == 6 || PGH_PROBE_GATHER == 7
+            float xv = ga.h[k] + ga.c[k];
+#else
+            float xv = ((w & 0x7fffffffu) - base) < hot ? ga.h[k] : ga.c[k];
+#endif
+            if (HAS_VAL) xv *= __uint_as_float(sa.v[k >> 2][k & 3]);
+            prod[k] = xv;
         }
-        float v[IPT];
+        const int mine = __popc(bits);
+        int incl = mine;                                  // inclusive prefix of the per-lane flag counts
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) v[k] = strip[p0 + k];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();                    // strip is reused for the segment sums below
-        double acc = 0.0, first_val = 0.0;
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+            const int v2 = __shfl_up(incl, o2, 64);
+            if (lane >= o2) incl += v2;
+        }
+        const int before = incl - mine;
+        const int closed = __shfl(incl, 63, 64) - 1;      // segments that start and end inside the tile
+        float acc = 0.f, first_val = 0.f;
         int q = 0, first_o = -2;
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
-            if ((bits >> k) & 1u) {                         // entry k opens segment (before + q): close the open one
+            if ((bits >> k) & 1u) {                       // entry k opens segment (before + q): close the open one
                 const int o = before + q;
                 if (first_o == -2) {
                     first_o = o;
                     first_val = acc;
                 } else {
-                    strip[o - 1] = (float)acc;
+                    strip[o - 1] = acc;
                 }
-                acc = 0.0;
+                acc = 0.f;
                 ++q;
             }
-            acc += (double)v[k];
+            acc += prod[k];
         }
         // ---- stitch segments that cross lane boundaries (keys are non-decreasing across lanes)
-        const int key = before + q - 1;                     // local index of the segment open at the end of the chunk
-        double val = acc;
+        const int key = before + q - 1;                   // local index of the segment open at the end of the chunk
+        float val = acc;
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) {
             const int k2 = __shfl_up(key, o2, 64);
-            const double v2 = __shfl_up(val, o2, 64);
+            const float v2 = __shfl_up(val, o2, 64);
             if (lane >= o2 && k2 == key) val += v2;
         }
         const int ek = __shfl_up(key, 1, 64);
-        const double ev = __shfl_up(val, 1, 64);
+        const float ev = __shfl_up(val, 1, 64);
         if (first_o != -2) {
-            const int closes = first_o - 1;                 // local index of the segment this lane's first flag closes
-            const double total = first_val + ((lane > 0 && ek == closes) ? ev : 0.0);
-            if (closes < 0) f.head_partial[this_tile] = total;   // the segment that was open when the tile started
-            else strip[closes] = (float)total;
+            const int closes = first_o - 1;               // local index of the segment this lane's first flag closes
+            const float total = first_val + ((lane > 0 && ek == closes) ? ev : 0.f);
+            if (closes < 0) f.head_partial[t] = (double)total;   // the segment that was open when the tile started
+            else strip[closes] = total;
         }
-        if (lane == 63) f.tail_carry[this_tile] = val;      // piece of the segment still open at the end of the tile
+        if (lane == 63) f.tail_carry[t] = (double)val;    // piece of the segment still open at the end of the tile
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- segments that start and end inside the tile: local 0 .. total_flags - 2
-        const int32_t* __restrict__ rows = f.seg_row + seg_base + 1;
-        for (int j = lane; j < total_flags - 1; j += 64) {
-            const int row = rows[j];
-            if (row >= 0) part[row] = strip[j];
+        // ---- closed segments -> block partial vector (rows prefetched for the first 128; rare long tail below)
+        if (lane < closed && ga.row0 >= 0) part[ga.row0] = strip[lane];
+        if (64 + lane < closed && ga.row1 >= 0) part[ga.row1] = strip[64 + lane];
+        if (closed > 128) {
+            const int32_t* __restrict__ rows = f.seg_row + ga.seg_base + 1;
+            for (int j = 128 + lane; j < closed; j += 64) {
+                const int row = rows[j];
+                if (row >= 0) part[row] = strip[j];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // ---- rotate the register pipeline
+        sa = sb;
+        sb = sc;
+        zb = zc;
+        ga = gb;
     }
 }
 
@@ -421,6 +506,7 @@ BsfView view_of(const BsfFormat& f) {
     v.part_stride = f.n_out;
     v.num_blocks = f.num_blocks;
     v.blk_size = f.blk_size;
+    v.xg_bytes = f.n_src_pad * 4;
     for (int i = 0; i < 9; ++i) v.tile_begin[i] = f.tile_begin[i];
     return v;
 }
@@ -597,7 +683,6 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     }
     E += B;                                            // one sentinel per block
     PGH_CHECK(E < 2147483647LL, "blocked format: more than 2^31 entries in one graph; partition it (SURVEY.md 8e)");
-    f.num_entries = E;
     DevBuf<uint64_t> keys_a, keys_b;
     DevBuf<float> vals_a;
     DevBuf<int> flags, segid;
@@ -623,42 +708,66 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         else PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)E, 0, 61, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
-    PGH_HIP(hipMalloc(&f.colf, sizeof(uint32_t) * (size_t)E));
-    PGH_TRY(flags.alloc(E));
-    PGH_TRY(segid.alloc(E));
-    k_bsf_flags<<<blocks_for(E), kBlock, 0, r.stream>>>(keys_b.p, E, f.colf, flags.p);
-    {
-        size_t temp_bytes = 0;
-        PGH_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, temp_bytes, flags.p, segid.p, (int)E, r.stream));
-        DevBuf<char> temp;
-        PGH_TRY(temp.alloc(temp_bytes));
-        PGH_HIP(hipcub::DeviceScan::InclusiveSum(temp.p, temp_bytes, flags.p, segid.p, (int)E, r.stream));
-        int nseg = 0;
-        PGH_HIP(hipMemcpyAsync(&nseg, segid.p + E - 1, sizeof(int), hipMemcpyDeviceToHost, r.stream));
-        PGH_HIP(hipStreamSynchronize(r.stream));
-        f.num_segs = nseg;
-    }
-    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1)));
-    k_bsf_seg_rows<<<blocks_for(E), kBlock, 0, r.stream>>>(keys_b.p, segid.p, E, f.seg_row);
-    // ---- tiles
+    // ---- pad every block to whole tiles: every wavefront tile is full, 16-byte aligned and never straddles blocks.
+    //      Pad entries repeat the block's sentinel key: no flag, they only feed the sentinel's never-closed segment.
     TileBuild tb;
     tb.B = B;
+    int64_t h[9] = {0};
     {
         DevBuf<int64_t> starts;
         PGH_TRY(starts.alloc(9));
         k_bsf_block_starts<<<1, 64, 0, r.stream>>>(keys_b.p, E, B, starts.p);
-        int64_t h[9] = {0};
         PGH_HIP(hipMemcpyAsync(h, starts.p, sizeof(int64_t) * (B + 1), hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
         int tiles = 0;
         for (int b = 0; b <= 8; ++b) {
-            tb.block_start[b] = b <= B ? h[b] : E;
             tb.tile_begin[b] = tiles;
             f.tile_begin[b] = tiles;
+            tb.block_start[b] = (int64_t)tiles * kTile;
             if (b < B) tiles += (int)((h[b + 1] - h[b] + kTile - 1) / kTile);
         }
         f.num_tiles = tiles;
     }
+    const int64_t EP = (int64_t)f.num_tiles * kTile;
+    PGH_CHECK(EP < 2147483647LL, "blocked format: more than 2^31 padded entries in one graph; partition it (SURVEY.md 8e)");
+    f.num_entries = EP;
+    keys_a.~DevBuf<uint64_t>();
+    new (&keys_a) DevBuf<uint64_t>();
+    DevBuf<uint64_t> keys_p;
+    PGH_TRY(keys_p.alloc(EP));
+    float* val_sorted = f.val;
+    if (val) PGH_HIP(hipMalloc(&f.val, sizeof(float) * (size_t)EP));
+    {
+        PadLayout pl;
+        pl.B = B;
+        for (int b = 0; b <= 8; ++b) {
+            pl.src_start[b] = b <= B ? h[b] : E;
+            pl.dst_start[b] = tb.block_start[b];
+        }
+        k_bsf_pad<<<blocks_for(EP), kBlock, 0, r.stream>>>(pl, keys_b.p, val ? val_sorted : nullptr, EP, blk, keys_p.p, val ? f.val : nullptr);
+        PGH_HIP(hipGetLastError());
+        PGH_HIP(hipStreamSynchronize(r.stream));
+    }
+    if (val) (void)hipFree(val_sorted);
+    keys_b.~DevBuf<uint64_t>();
+    new (&keys_b) DevBuf<uint64_t>();
+    PGH_HIP(hipMalloc(&f.colf, sizeof(uint32_t) * (size_t)EP));
+    PGH_TRY(flags.alloc(EP));
+    PGH_TRY(segid.alloc(EP));
+    k_bsf_flags<<<blocks_for(EP), kBlock, 0, r.stream>>>(keys_p.p, EP, f.colf, flags.p);
+    {
+        size_t temp_bytes = 0;
+        PGH_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, temp_bytes, flags.p, segid.p, (int)EP, r.stream));
+        DevBuf<char> temp;
+        PGH_TRY(temp.alloc(temp_bytes));
+        PGH_HIP(hipcub::DeviceScan::InclusiveSum(temp.p, temp_bytes, flags.p, segid.p, (int)EP, r.stream));
+        int nseg = 0;
+        PGH_HIP(hipMemcpyAsync(&nseg, segid.p + EP - 1, sizeof(int), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        f.num_segs = nseg;
+    }
+    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1)));
+    k_bsf_seg_rows<<<blocks_for(EP), kBlock, 0, r.stream>>>(keys_p.p, segid.p, EP, f.seg_row);
     PGH_HIP(hipMalloc(&f.tile, sizeof(int4) * (size_t)(f.num_tiles + 1)));
     PGH_HIP(hipMalloc(&f.tail_carry, sizeof(double) * (size_t)(f.num_tiles + 1)));
     PGH_HIP(hipMalloc(&f.head_partial, sizeof(double) * (size_t)(f.num_tiles + 1)));
@@ -686,6 +795,17 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     PGH_HIP(hipStreamSynchronize(r.stream));
     f.device_bytes = (int64_t)E * (val ? 8 : 4) + f.num_segs * 4 + (int64_t)f.num_tiles * 32 + (int64_t)B * f.n_out * 4 +
                      (int64_t)n_src_pad * (4 + (src_old ? 4 : 0) + (relabel ? 4 : 0)) + (int64_t)n_out * (dst_old ? 8 : 4);
+    if (env_int("PGH_DEBUG", 0)) {
+        DevBuf<unsigned long long> cnt;
+        PGH_TRY(cnt.alloc(1, true));
+        k_bsf_count_hot<<<blocks_for(EP), kBlock, 0, r.stream>>>(f.colf, EP, blk, kBsfHot < blk ? kBsfHot : blk, cnt.p);
+        unsigned long long hcount = 0;
+        PGH_HIP(hipMemcpyAsync(&hcount, cnt.p, sizeof(hcount), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        fprintf(stderr, "[pgh] bsf: B=%d blk=%d entries=%lld (padded %lld) segs=%lld tiles=%d hot=%d covers %.1f%% of entries, value-free=%d relabel=%d\n",
+                B, blk, (long long)E, (long long)EP, (long long)f.num_segs, f.num_tiles, kBsfHot, 100.0 * (double)hcount / (double)EP,
+                val ? 0 : 1, relabel ? 1 : 0);
+    }
     f.enabled = true;
     return 0;
 }
