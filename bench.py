@@ -86,17 +86,24 @@ def single_gpu(args):
     run(total - 1)
     L.check(lib.pgh_profile_enable(0))
     prof = {}
-    for kid, name in ((L.K_SPMV, "spmv"), (L.K_FIXUP, "fixup"), (L.K_RESIDUAL, "residual"), (L.K_FINAL, "close")):
+    for kid, name in ((L.K_SPMV, "spmv"), (L.K_FIXUP, "fixup"), (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual"),
+                      (L.K_FINAL, "close")):
         cnt, ms = C.c_int64(), C.c_double()
         L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
         prof[name] = dict(launches=cnt.value, avg_us=(ms.value / cnt.value * 1e3) if cnt.value else None)
     alg_bytes = 8 * nnz + 16 * n                     # fused PPR step, per launch
-    spmv_s = prof["spmv"]["avg_us"] * 1e-6
-    achieved = alg_bytes / spmv_s / 1e9
-    roofline = dict(bound="hbm", kernel="k_spmv_merge (PPR epilogue)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                    algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(prof["spmv"]["avg_us"], 2),
-                    format="csr32+f32 (8 B/edge)", other_kernels_avg_us={k: v["avg_us"] for k, v in prof.items() if k != "spmv"})
+    # the fused PPR step (SpMV + axpby epilogue + sum(y)) is one launch on the row-major layout and three launches
+    # (block partials, cross-tile fix-up, combine + epilogue) on the blocked layout: its duration is their sum
+    step_kernels = [k for k in ("spmv", "fixup", "combine") if prof[k]["avg_us"]]
+    step_us = sum(prof[k]["avg_us"] for k in step_kernels)
+    achieved = alg_bytes / (step_us * 1e-6) / 1e9
+    blocked = prof["combine"]["avg_us"] is not None
+    roofline = dict(bound="hbm",
+                    kernel=("k_bsf_partial + k_bsf_fixup + k_bsf_combine<AXPBY>" if blocked else "k_spmv_merge<AXPBY> + k_spmv_fixup")
+                    + " (one fused PPR step)",
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                    traffic=None, algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(step_us, 2),
+                    format=g.format(), kernels_avg_us={k: (round(v["avg_us"], 2) if v["avg_us"] else None) for k, v in prof.items()})
 
     # ---- CPU baseline + parity: the oracle's scipy loop (= reference numpy backend), same graph, same seeds
     cpu = None

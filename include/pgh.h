@@ -115,6 +115,8 @@ int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
                        const int32_t* indices, const double* data, int flags, pgh_graph_t* out);
 int pgh_graph_destroy(pgh_graph_t g);
 int pgh_graph_info(pgh_graph_t g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* device_bytes);
+/* human-readable description of the layout the propagation kernels stream (bench.py reports it) */
+int pgh_graph_format(pgh_graph_t g, char* buf, int buflen);
 /* degrees(M): row sums of the un-transposed M, specification.py:105; numpy.py:76-77 */
 int pgh_graph_degrees(pgh_graph_t g, pgh_vec_t out);
 /* download the stored CSR(M^T) (verification / CPU baseline hand-off) */

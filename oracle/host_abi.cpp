@@ -380,6 +380,10 @@ int pgh_graph_info(pgh_graph_t g, int64_t* a, int64_t* b, int64_t* c, int64_t* d
     if (d) *d = 0;
     return 0;
 }
+int pgh_graph_format(pgh_graph_t, char* buf, int len) {
+    snprintf(buf, len, "host-oracle csr");
+    return 0;
+}
 int pgh_graph_degrees(pgh_graph_t g, pgh_vec_t out) {
     CHECK(g && out && out->n == g->n_rows, "pgh_graph_degrees: length mismatch");
     std::copy(g->degrees.begin(), g->degrees.end(), out->data);

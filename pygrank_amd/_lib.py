@@ -85,6 +85,7 @@ SIGNATURES = {
                                      C.POINTER(c_graph)]),
     "pgh_graph_destroy": (C.c_int, [c_graph]),
     "pgh_graph_info": (C.c_int, [c_graph, c_i64p, c_i64p, c_i64p, c_i64p]),
+    "pgh_graph_format": (C.c_int, [c_graph, C.c_char_p, C.c_int]),
     "pgh_graph_degrees": (C.c_int, [c_graph, c_vec]),
     "pgh_graph_download": (C.c_int, [c_graph, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgh_spmv": (C.c_int, [c_graph, c_vec, c_vec]),

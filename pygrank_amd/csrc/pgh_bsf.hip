@@ -274,8 +274,8 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     constexpr int T = 64 * IPT;
     constexpr int WAVES = kBsfThreads / 64;
     constexpr int Q = IPT / 4;
-    __shared__ float s_hot[kBsfHot];
-    __shared__ float s_strip[WAVES][T];
+    __shared__ float s_hot[kBsfHot + 1];                 // + one permanent zero: the slot cold lanes read
+    __shared__ float s_strip[WAVES][T + 64];             // + one scratch slot per lane for predicated-off writes
     if (state != nullptr && state->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
@@ -288,6 +288,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     const uint32_t base = (uint32_t)(b * f.blk_size);
     const uint32_t hot = (uint32_t)min(kBsfHot, f.blk_size);
     for (uint32_t i = tid; i < hot; i += kBsfThreads) s_hot[i] = xg[base + i];
+    if (tid == 0) s_hot[hot] = 0.f;
     __syncthreads();
     float* __restrict__ strip = s_strip[wave];
     const int t_end = f.tile_begin[b + 1];
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     struct Stream {
         u32x4 c[Q];
         u32x4 v[Q];
+        int   seg_base;
     };
     auto load_stream = [&](int tile, Stream& st) {
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(f.colf + (int64_t)tile * T + lane * IPT);
@@ -307,19 +309,27 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
 #pragma unroll
             for (int q = 0; q < Q; ++q) st.v[q] = __builtin_nontemporal_load(vs + q);
         }
+        st.seg_base = f.tile[tile].z;
     };
-    // gather stage: issue the LDS read and the buffer load of every entry WITHOUT consuming them (the select happens
-    // one tile later, in the arithmetic stage), so both stay in flight across the loop back-edge
+    // gather stage: issue the LDS read and the buffer load of every entry WITHOUT consuming them (they are summed one
+    // tile later, in the arithmetic stage), so both stay in flight across the loop back-edge.  Hot lanes push their
+    // buffer offset out of range (the load returns 0 without touching memory); cold lanes read the zero slot of the
+    // hot cache: value = h + c, no select.
     struct Gathered {
-        float h[IPT];        // hot-cache value (valid when the column is inside the cached prefix)
-        float c[IPT];        // buffer-load value (0 for hot lanes: their offset is pushed out of range)
-        int   row0, row1;    // output rows of the tile's first 128 closed segments (prefetched)
-        int   seg_base;
+        float        h[IPT];
+        float        c[IPT];
+        float        v[HAS_VAL ? IPT : 1];
+        unsigned int bits;           // segment-start flags of the lane's IPT entries
+        int          row0, row1;     // output rows of the tile's first 128 closed segments (prefetched)
+        int          seg_base;
     };
-    auto gather = [&](const Stream& st, int seg_base, Gathered& g) {
+    auto gather = [&](const Stream& st, Gathered& g) {
+        unsigned int bits = 0;
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
-            const uint32_t c = st.c[k >> 2][k & 3] & 0x7fffffffu;
+            const uint32_t w = st.c[k >> 2][k & 3];
+            bits |= (w >> 31) << k;
+            const uint32_t c = w & 0x7fffffffu;
             const uint32_t loc = c - base;
 #if PGH_PROBE_GATHER == 3
             g.h[k] = (float)(c & 0xffffu);
@@ -330,19 +340,15 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
 #elif PGH_PROBE_GATHER == 7      // every buffer load out of range: cost of issuing the (dropped) loads
             g.h[k] = s_hot[loc % hot];
             g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, 0xfffffff0u, 0, 0));
-#elif PGH_PROBE_GATHER == 8      // cold lanes gather from a 4 KB window: divergent but L1-resident
-            g.h[k] = s_hot[loc < hot ? loc : 0u];
-            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, loc < hot ? 0xfffffff0u : (c & 1023u) << 2, 0, 0));
-#elif PGH_PROBE_GATHER == 9      // cold lanes gather from a 2 MB window: divergent, L2-resident
-            g.h[k] = s_hot[loc < hot ? loc : 0u];
-            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, loc < hot ? 0xfffffff0u : (c & 0x7ffffu) << 2, 0, 0));
 #else
-            g.h[k] = s_hot[loc < hot ? loc : 0u];
+            g.h[k] = s_hot[min(loc, hot)];
             g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, loc < hot ? 0xfffffff0u : c << 2, 0, 0));
 #endif
+            if (HAS_VAL) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
         }
-        g.seg_base = seg_base;
-        const int32_t* __restrict__ rows = f.seg_row + seg_base + 1;      // reads past the tile's segments are harmless
+        g.bits = bits;
+        g.seg_base = st.seg_base;
+        const int32_t* __restrict__ rows = f.seg_row + st.seg_base + 1;   // reads past the tile's segments are harmless
         g.row0 = rows[lane];
         g.row1 = rows[64 + lane];
     };
@@ -351,36 +357,22 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     if (t >= t_end) return;
     // The pipeline issues its loads UNCONDITIONALLY (tile indices are clamped to the block's last tile; the clamped
     // results are never consumed): a fixed number of vector-memory operations per iteration lets the compiler emit
-    // counted s_waitcnt vmcnt(N) instead of draining the queue, which is what keeps three tiles in flight.
+    // counted s_waitcnt vmcnt(N) instead of draining the queue.  In flight per wavefront: the column stream of tiles
+    // t+2 and t+3, the gathers of tile t+1, the arithmetic of tile t.
     const int t_last = t_end - 1;
-    Stream sa, sb, sc;
-    Gathered ga, gb;
-    load_stream(t, sa);
-    gather(sa, f.tile[t].z, ga);
-    load_stream(min(t + stride, t_last), sb);
-    int zb = f.tile[min(t + stride, t_last)].z;         // seg_base of the tile held in sb
+    Stream s1, s2, s3;
+    Gathered g0, g1;
+    load_stream(t, s1);
+    gather(s1, g0);
+    load_stream(min(t + stride, t_last), s1);
+    load_stream(min(t + 2 * stride, t_last), s2);
     for (; t < t_end; t += stride) {
-        // vmcnt retires in order: the gathers (needed at the top of the next iteration) are issued BEFORE the stream
-        // of tile t+2 (needed an iteration later), so waiting for the former leaves the latter in flight
-        gather(sb, zb, gb);                               // gathers + output rows one tile ahead
-        const int t2 = min(t + 2 * stride, t_last);
-        load_stream(t2, sc);                              // column stream + tile header two tiles ahead
-        const int zc = f.tile[t2].z;
-        // ---- arithmetic of tile t: lane-local flags, f32 segmented sum
-        unsigned int bits = 0;
-        float prod[IPT];
-#pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            const uint32_t w = sa.c[k >> 2][k & 3];
-            bits |= (w >> 31) << k;
-#if PGH_PROBE_GATHER == 3 || PGH_PROBE_GATHER == 6 || PGH_PROBE_GATHER == 7
-            float xv = ga.h[k] + ga.c[k];
-#else
-            float xv = ((w & 0x7fffffffu) - base) < hot ? ga.h[k] : ga.c[k];
-#endif
-            if (HAS_VAL) xv *= __uint_as_float(sa.v[k >> 2][k & 3]);
-            prod[k] = xv;
-        }
+        // vmcnt retires in order: the gathers (consumed next iteration) go out BEFORE the stream of tile t+3 (consumed
+        // two iterations later), so waiting for the former leaves the latter in flight
+        gather(s1, g1);
+        load_stream(min(t + 3 * stride, t_last), s3);
+        // ---- arithmetic of tile t: lane-local flags, branch-free f32 segmented sum
+        const unsigned int bits = g0.bits;
         const int mine = __popc(bits);
         int incl = mine;                                  // inclusive prefix of the per-lane flag counts
 #pragma unroll
@@ -390,25 +382,26 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         }
         const int before = incl - mine;
         const int closed = __shfl(incl, 63, 64) - 1;      // segments that start and end inside the tile
+        // entry k with its flag set opens segment (before + #flags below k) and closes the previous one.  The lane's
+        // first flag closes a segment that may have begun in earlier lanes (finished after the scan below); every
+        // later flag closes a segment that lies inside the lane: its sum goes straight to the strip.  Writes of
+        // entries without a flag are steered to the lane's scratch slot instead of being branched around.
+        const int first_pos = bits ? __builtin_ctz(bits) : 32;
         float acc = 0.f, first_val = 0.f;
-        int q = 0, first_o = -2;
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
-            if ((bits >> k) & 1u) {                       // entry k opens segment (before + q): close the open one
-                const int o = before + q;
-                if (first_o == -2) {
-                    first_o = o;
-                    first_val = acc;
-                } else {
-                    strip[o - 1] = acc;
-                }
-                acc = 0.f;
-                ++q;
-            }
-            acc += prod[k];
+            const bool flag = (bits >> k) & 1u;
+            const bool is_first = (k == first_pos);
+            const int o = before + __popc(bits & ((1u << k) - 1u));
+            first_val = is_first ? acc : first_val;
+            strip[(flag && !is_first) ? o - 1 : T + lane] = acc;
+            acc = flag ? 0.f : acc;
+            float xv = g0.h[k] + g0.c[k];
+            if (HAS_VAL) xv *= g0.v[k];
+            acc += xv;
         }
         // ---- stitch segments that cross lane boundaries (keys are non-decreasing across lanes)
-        const int key = before + q - 1;                   // local index of the segment open at the end of the chunk
+        const int key = before + mine - 1;                // local index of the segment open at the end of the chunk
         float val = acc;
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) {
@@ -418,9 +411,9 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         }
         const int ek = __shfl_up(key, 1, 64);
         const float ev = __shfl_up(val, 1, 64);
-        if (first_o != -2) {
-            const int closes = first_o - 1;               // local index of the segment this lane's first flag closes
-            const float total = first_val + ((lane > 0 && ek == closes) ? ev : 0.f);
+        const int closes = before - 1;                    // local index of the segment this lane's first flag closes
+        const float total = first_val + ((lane > 0 && ek == closes) ? ev : 0.f);
+        if (bits != 0u) {
             if (closes < 0) f.head_partial[t] = (double)total;   // the segment that was open when the tile started
             else strip[closes] = total;
         }
@@ -428,10 +421,10 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- closed segments -> block partial vector (rows prefetched for the first 128; rare long tail below)
-        if (lane < closed && ga.row0 >= 0) part[ga.row0] = strip[lane];
-        if (64 + lane < closed && ga.row1 >= 0) part[ga.row1] = strip[64 + lane];
+        if (lane < closed && g0.row0 >= 0) part[g0.row0] = strip[lane];
+        if (64 + lane < closed && g0.row1 >= 0) part[g0.row1] = strip[64 + lane];
         if (closed > 128) {
-            const int32_t* __restrict__ rows = f.seg_row + ga.seg_base + 1;
+            const int32_t* __restrict__ rows = f.seg_row + g0.seg_base + 1;
             for (int j = 128 + lane; j < closed; j += 64) {
                 const int row = rows[j];
                 if (row >= 0) part[row] = strip[j];
@@ -440,10 +433,9 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- rotate the register pipeline
-        sa = sb;
-        sb = sc;
-        zb = zc;
-        ga = gb;
+        s1 = s2;
+        s2 = s3;
+        g0 = g1;
     }
 }
 

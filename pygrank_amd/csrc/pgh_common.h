@@ -64,7 +64,7 @@ int ensure_init();
 #define PGH_BSF_IPT 8
 #endif
 #ifndef PGH_BSF_HOT
-#define PGH_BSF_HOT 30720
+#define PGH_BSF_HOT 29696
 #endif
 // diagnostic builds only (tools/probe_variants.py): 1 = gather from 4 KB, 2 = from 4 MB, 3 = no gather
 #ifndef PGH_PROBE_GATHER

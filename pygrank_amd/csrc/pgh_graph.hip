@@ -264,6 +264,19 @@ extern "C" int pgh_graph_info(pgh_graph_t g, int64_t* n_rows, int64_t* n_cols, i
     return 0;
 }
 
+extern "C" int pgh_graph_format(pgh_graph_t g, char* buf, int buflen) {
+    PGH_CHECK(g && buf && buflen > 0, "pgh_graph_format: null argument");
+    if (g->bsf.enabled) {
+        const BsfFormat& f = g->bsf;
+        snprintf(buf, buflen, "bsf: %d column blocks x %d sources, %s, %s entries (%d B/edge), %lld entries, %d wavefront tiles, LDS hot cache %d",
+                 f.num_blocks, f.blk_size, f.relabelled ? "relabelled by source count" : "original ids",
+                 f.val ? "f32-valued" : "value-free", f.val ? 8 : 4, (long long)f.num_entries, f.num_tiles, PGH_BSF_HOT);
+    } else {
+        snprintf(buf, buflen, "csr32+f32 row-major merge-path (8 B/edge), %d tiles of %d items", g->num_tiles, g->items_per_tile);
+    }
+    return 0;
+}
+
 extern "C" int pgh_graph_degrees(pgh_graph_t g, pgh_vec_t out) {
     PGH_CHECK(g && out && out->n == g->n_rows, "pgh_graph_degrees: length mismatch");
     if (g->n_rows == 0) return 0;

@@ -344,6 +344,11 @@ class DeviceGraph:
         L.check(L.lib().pgh_graph_info(self._h, *[C.byref(v) for v in vals]))
         return dict(n_rows=vals[0].value, n_cols=vals[1].value, nnz=vals[2].value, device_bytes=vals[3].value)
 
+    def format(self):
+        buf = C.create_string_buffer(512)
+        L.check(L.lib().pgh_graph_format(self._h, buf, 512))
+        return buf.value.decode()
+
     def degrees(self):
         out = DeviceVector.empty(self.shape[0])
         L.check(L.lib().pgh_graph_degrees(self._h, out._h))
