@@ -135,6 +135,7 @@ def single_gpu(args):
 
 
 def multi_gpu(args):
+    os.environ["NCCL_DEBUG"] = os.environ.get("PGH_NCCL_DEBUG", "WARN")     # keep RCCL's banner off stdout: one JSON line only
     from pygrank_amd.distributed import bench_row_partitioned
     return bench_row_partitioned(args, RMAT, ALPHA, TOL, MAX_ITERS, SEEDS, HBM_PEAK_GBS)
 
@@ -147,14 +148,20 @@ def main():
     ap.add_argument("--scale", type=int, default=None, help="override the RMAT scale (default: 23 + log2(gpus))")
     ap.add_argument("--ef", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    ap.add_argument("--force-partitioned", action="store_true", help="run the row-partitioned path even with one rank")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_partitioned:
         result = multi_gpu(args)
     else:
         args.scale = 23 if args.scale is None else args.scale
         args.ef = 16 if args.ef is None else args.ef
         result = single_gpu(args)
+    if args.gpus > 1 or world > 1 or args.force_partitioned:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
     if result is not None:
         print(json.dumps(result), flush=True)
 

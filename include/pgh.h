@@ -177,6 +177,18 @@ int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, c
 int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, int32_t chebyshev,
                  pgh_vec_t result, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 
+/* ---------------------------------------------------------------- row-partitioned step ---- */
+/* The path shards with one exchange per iteration: every rank holds a contiguous slice of the rows of M^T in a
+ * globally relabelled id space and a full-length gather vector; after each step the slices are all-gathered
+ * (RCCL over xGMI; torch.distributed drives it on the engine stream, see pygrank_amd/distributed.py).
+ * pgh_ppr_step_dist = PageRank._formula (adhoc.py:34-36) on the slice; it also writes this rank's slice of the
+ * next gather vector (y * source scale), so the all-gather needs no extra pass.  No reference counterpart. */
+int pgh_ppr_step_dist(pgh_graph_t g, pgh_vec_t xg_full, double x_scale, pgh_vec_t p_local, double alpha,
+                      pgh_vec_t y_local, pgh_vec_t xg_local_out, double* sum_y);
+int pgh_dist_prescale(pgh_graph_t g, pgh_vec_t x_local, pgh_vec_t xg_local_out);
+/* new id -> original id of a relabelled (partitioned) graph, and the first row this graph holds */
+int pgh_graph_perm(pgh_graph_t g, int32_t* new_to_old, int64_t* row_begin);
+
 /* ---------------------------------------------------------------- synthetic workload -------------- */
 /* Graph500-style RMAT generator + normalisation on the device (build-side addition, SURVEY.md 8d: the
  * reference has no generator).  Produces exactly the edges of oracle/rmat_np.py (integer-exact hash), sums
@@ -187,6 +199,13 @@ int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
  * vector to the slice's outputs. */
 int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, double b, double c, uint64_t seed,
                    int32_t normalization, int32_t symmetrize, int64_t row_begin, int64_t row_end, pgh_graph_t* out);
+/* Row-partitioned variant: ids are relabelled by descending source count into max(part_count, auto) hot-first
+ * blocks (every rank derives the same permutation from the same edge stream); rank part_rank keeps the contiguous
+ * slice [part_rank * n / part_count, (part_rank + 1) * n / part_count) of the new ids, so slices are equal-sized
+ * (no padding in the all-gather) and statistically nnz-balanced.  Vectors of such a graph live in the new id space
+ * (pgh_graph_perm maps back). */
+int pgh_graph_rmat_part(int32_t scale, int32_t edge_factor, double a, double b, double c, uint64_t seed,
+                        int32_t normalization, int32_t symmetrize, int32_t part_rank, int32_t part_count, pgh_graph_t* out);
 
 #ifdef __cplusplus
 }

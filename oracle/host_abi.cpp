@@ -47,6 +47,8 @@ struct pgh_graph_s {
     std::vector<int32_t> col;
     std::vector<float> val;
     std::vector<float> degrees;
+    std::vector<int32_t> part_perm;   // new id -> old id for row-partitioned graphs
+    int64_t row_begin = 0;
 };
 
 static thread_local std::string g_err;
@@ -605,17 +607,15 @@ static inline uint64_t splitmix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-int pgh_graph_rmat(int32_t scale, int32_t ef, double a, double b, double c, uint64_t seed, int32_t normalization,
-                   int32_t symmetrize, int64_t row_begin, int64_t row_end, pgh_graph_t* out) {
+static int rmat_build(int32_t scale, int32_t ef, double a, double b, double c, uint64_t seed, int32_t normalization,
+                      int32_t symmetrize, int64_t row_begin, int64_t row_end, int32_t part_rank, int32_t part_count,
+                      pgh_graph_t* out) {
     CHECK(scale >= 1 && scale <= 30 && ef >= 1, "pgh_graph_rmat: scale must be in [1, 30]");
     CHECK(normalization >= 0 && normalization <= 2, "pgh_graph_rmat: normalization must be 0, 1 or 2");
     const int64_t n = 1LL << scale, E = n * ef;
-    if (row_end <= 0) row_end = n;
-    CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= n, "pgh_graph_rmat: bad row range");
     const uint32_t ta = (uint32_t)std::floor(a * 4294967296.0), tb = (uint32_t)std::floor((a + b) * 4294967296.0),
                    tc = (uint32_t)std::floor((a + b + c) * 4294967296.0);
-    std::vector<double> outdeg(n, 0.0), indeg(row_end - row_begin, 0.0);
-    std::vector<uint64_t> keys;
+    std::vector<uint32_t> src(E), dst(E);
     for (int64_t e = 0; e < E; ++e) {
         const uint64_t emix = (uint64_t)e * 0xD6E8FEB86659FD93ULL;
         uint32_t s = 0, d = 0;
@@ -629,6 +629,47 @@ int pgh_graph_rmat(int32_t scale, int32_t ef, double a, double b, double c, uint
                 d |= (uint32_t)(((u >= ta) && (u < tb)) || (u >= tc)) << (scale - 1 - level);
             }
         }
+        src[e] = s;
+        dst[e] = d;
+    }
+    pgh_graph_s* g = new pgh_graph_s();
+    if (part_count > 0) {
+        CHECK((part_count & (part_count - 1)) == 0 && part_count <= n && part_rank >= 0 && part_rank < part_count,
+              "pgh_graph_rmat_part: the number of partitions must be a power of two and the rank inside it");
+        // global relabelling by descending source count (stable), dealt round-robin to B hot-first blocks
+        std::vector<uint32_t> cnt(n, 0);
+        for (int64_t e = 0; e < E; ++e) {
+            cnt[src[e]]++;
+            if (symmetrize) cnt[dst[e]]++;
+        }
+        int B = 1;
+        while (B < 8 && n * 4 > (int64_t)B * (8 << 20)) B <<= 1;
+        if (B < part_count) B = part_count;
+        CHECK(B <= 8, "pgh_graph_rmat_part: at most 8 partitions per node");
+        const int64_t blk = n / B;
+        std::vector<int32_t> ids(n);
+        std::iota(ids.begin(), ids.end(), 0);
+        std::stable_sort(ids.begin(), ids.end(), [&](int32_t x, int32_t y) { return cnt[x] > cnt[y]; });
+        std::vector<int32_t> iperm(n);
+        g->part_perm.assign(n, -1);
+        for (int64_t r = 0; r < n; ++r) {
+            const int32_t nw = (int32_t)((r % B) * blk + r / B);
+            iperm[ids[r]] = nw;
+            g->part_perm[nw] = ids[r];
+        }
+        for (int64_t e = 0; e < E; ++e) {
+            src[e] = (uint32_t)iperm[src[e]];
+            dst[e] = (uint32_t)iperm[dst[e]];
+        }
+        row_begin = (int64_t)part_rank * (n / part_count);
+        row_end = row_begin + n / part_count;
+    }
+    if (row_end <= 0) row_end = n;
+    CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= n, "pgh_graph_rmat: bad row range");
+    std::vector<double> outdeg(n, 0.0), indeg(row_end - row_begin, 0.0);
+    std::vector<uint64_t> keys;
+    for (int64_t e = 0; e < E; ++e) {
+        const uint32_t s = src[e], d = dst[e];
         outdeg[s] += 1;
         if (d >= row_begin && d < row_end) keys.push_back(((uint64_t)(d - row_begin) << 32) | s);
         if (symmetrize) {
@@ -637,9 +678,9 @@ int pgh_graph_rmat(int32_t scale, int32_t ef, double a, double b, double c, uint
         }
     }
     std::sort(keys.begin(), keys.end());
-    pgh_graph_s* g = new pgh_graph_s();
     g->n_rows = n;
     g->n_cols = row_end - row_begin;
+    g->row_begin = row_begin;
     std::vector<double> w;
     std::vector<uint64_t> uk;
     for (size_t k = 0; k < keys.size(); ++k) {
@@ -653,22 +694,53 @@ int pgh_graph_rmat(int32_t scale, int32_t ef, double a, double b, double c, uint
     std::vector<double> deg(n, 0.0);
     for (size_t k = 0; k < uk.size(); ++k) {
         const int64_t row = (int64_t)(uk[k] >> 32);
-        const uint32_t src = (uint32_t)(uk[k] & 0xffffffffu);
+        const uint32_t s = (uint32_t)(uk[k] & 0xffffffffu);
         double v;
-        if (normalization == 0) v = (outdeg[src] != 0 ? 1.0 / outdeg[src] : 0.0) * w[k];
+        if (normalization == 0) v = (outdeg[s] != 0 ? 1.0 / outdeg[s] : 0.0) * w[k];
         else if (normalization == 1) {
-            const double l = std::sqrt(outdeg[src]), r = std::sqrt(indeg[row]);
+            const double l = std::sqrt(outdeg[s]), r = std::sqrt(indeg[row]);
             v = ((l != 0 ? 1.0 / l : 0.0) * w[k]) * (r != 0 ? 1.0 / r : 0.0);
         } else v = w[k];
-        g->col[k] = (int32_t)src;
+        g->col[k] = (int32_t)s;
         g->val[k] = (float)v;
-        deg[src] += v;
+        deg[s] += v;
         g->rowptr[row + 1]++;
     }
     for (int64_t r = 0; r < g->n_cols; ++r) g->rowptr[r + 1] += g->rowptr[r];
     g->degrees.resize(n);
     for (int64_t i = 0; i < n; ++i) g->degrees[i] = (float)deg[i];
     *out = g;
+    return 0;
+}
+
+int pgh_graph_rmat(int32_t scale, int32_t ef, double a, double b, double c, uint64_t seed, int32_t normalization,
+                   int32_t symmetrize, int64_t row_begin, int64_t row_end, pgh_graph_t* out) {
+    return rmat_build(scale, ef, a, b, c, seed, normalization, symmetrize, row_begin, row_end, 0, 0, out);
+}
+int pgh_graph_rmat_part(int32_t scale, int32_t ef, double a, double b, double c, uint64_t seed, int32_t normalization,
+                        int32_t symmetrize, int32_t part_rank, int32_t part_count, pgh_graph_t* out) {
+    CHECK(part_count >= 1, "pgh_graph_rmat_part: part_count must be >= 1");
+    return rmat_build(scale, ef, a, b, c, seed, normalization, symmetrize, 0, 0, part_rank, part_count, out);
+}
+int pgh_graph_perm(pgh_graph_t g, int32_t* new_to_old, int64_t* row_begin) {
+    if (row_begin) *row_begin = g->row_begin;
+    for (int64_t i = 0; i < g->n_rows; ++i) new_to_old[i] = g->part_perm.empty() ? (int32_t)i : g->part_perm[i];
+    return 0;
+}
+// the double keeps the normalisation inside the values, so its gather vector is the iterate itself
+int pgh_ppr_step_dist(pgh_graph_t g, pgh_vec_t xg_full, double xs, pgh_vec_t p, double alpha, pgh_vec_t y, pgh_vec_t xg_local,
+                      double* sum_y) {
+    CHECK(g && xg_full && p && y && xg_local, "pgh_ppr_step_dist: null argument");
+    CHECK(xg_full->n >= g->n_rows && p->n == g->n_cols && y->n == g->n_cols && xg_local->n == g->n_cols,
+          "pgh_ppr_step_dist: vector length mismatch");
+    const double s = ppr_step(g, xg_full->data, xs, p->data, alpha, y->data);
+    std::copy(y->data, y->data + y->n, xg_local->data);
+    if (sum_y) *sum_y = s;
+    return 0;
+}
+int pgh_dist_prescale(pgh_graph_t g, pgh_vec_t x, pgh_vec_t out) {
+    CHECK(g && x && out && x->n == g->n_cols && out->n == g->n_cols, "pgh_dist_prescale: length mismatch");
+    std::copy(x->data, x->data + x->n, out->data);
     return 0;
 }
 

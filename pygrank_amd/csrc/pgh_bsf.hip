@@ -606,22 +606,51 @@ void bsf_destroy(BsfFormat& f) {
     f = BsfFormat();
 }
 
+// Relabelling shared by the single-GPU layout and the row-partitioned generator: ids sorted by descending reference
+// count (stable: ties keep ascending id), rank r -> new id (r % B) * blk + r / B, i.e. dealt round-robin to B
+// contiguous hot-first blocks.  perm[new] = old (pad slots -1, perm has B * blk entries), iperm[old] = new.
+int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t* perm, int32_t* iperm) {
+    Runtime& r = rt();
+    DevBuf<unsigned int> cnt_sorted;
+    DevBuf<int32_t> ids, ids_sorted;
+    PGH_TRY(cnt_sorted.alloc(n));
+    PGH_TRY(ids.alloc(n));
+    PGH_TRY(ids_sorted.alloc(n));
+    k_iota<<<blocks_for(n), kBlock, 0, r.stream>>>(ids.p, n);
+    size_t temp_bytes = 0;
+    PGH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, temp_bytes, cnt, cnt_sorted.p, ids.p, ids_sorted.p, (int)n, 0, 32, r.stream));
+    DevBuf<char> temp;
+    PGH_TRY(temp.alloc(temp_bytes));
+    PGH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(temp.p, temp_bytes, cnt, cnt_sorted.p, ids.p, ids_sorted.p, (int)n, 0, 32, r.stream));
+    k_fill_perm_pad<<<blocks_for((int64_t)B * blk), kBlock, 0, r.stream>>>(perm, (int64_t)B * blk);
+    k_make_perm<<<blocks_for(n), kBlock, 0, r.stream>>>(ids_sorted.p, n, B, blk, perm, iperm);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    return 0;
+}
+
+// number of column blocks: keep a block's slice of the gather vector around 8 MB (hot-first, so its reused prefix
+// fits a 4 MB L2); override with PGH_BLOCKS for experiments
+int bsf_auto_blocks(int64_t n_src) {
+    int B = 1;
+    while (B < 8 && n_src * 4 > (int64_t)B * (8 << 20)) B <<= 1;
+    const int forced = env_int("PGH_BLOCKS", 0);
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) B = forced;
+    return B;
+}
+
 // Build the blocked format from CSR(M^T) already on the device.
 //   val  != null : generic weighted matrix (8 B/edge)
 //   mult != null : value-free; M^T = diag(dst_old) * mult * diag(src_old) (either scale may be null = 1)
 // relabel: permute ids by descending source count (square graphs only).
-int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel) {
+int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel,
+              int force_blocks) {
     Runtime& r = rt();
     BsfFormat& f = g->bsf;
     const int64_t n_src = g->n_rows, n_out = g->n_cols, nnz = g->nnz;
     PGH_CHECK(n_src < (1LL << 28) && n_out < (1LL << 28), "blocked format needs fewer than 2^28 rows/columns");
     if (relabel && n_src != n_out) relabel = false;
-    // number of column blocks: keep a block's slice of the gather vector around 8 MB (hot-first, so its reused
-    // prefix fits a 4 MB L2); override with PGH_BLOCKS for experiments
-    int B = 1;
-    while (B < 8 && n_src * 4 > (int64_t)B * (8 << 20)) B <<= 1;
-    const int forced = env_int("PGH_BLOCKS", 0);
-    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) B = forced;
+    const int B = force_blocks > 0 ? force_blocks : bsf_auto_blocks(n_src);
     const int blk = (int)((n_src + B - 1) / B);
     const int n_src_pad = B * blk;
     f.num_blocks = B;
@@ -636,25 +665,12 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
 
     DevBuf<int32_t> iperm;
     if (relabel) {
-        DevBuf<unsigned int> cnt, cnt_sorted;
-        DevBuf<int32_t> ids, ids_sorted;
+        DevBuf<unsigned int> cnt;
         PGH_TRY(cnt.alloc(n_src, true));
-        PGH_TRY(cnt_sorted.alloc(n_src));
-        PGH_TRY(ids.alloc(n_src));
-        PGH_TRY(ids_sorted.alloc(n_src));
         PGH_TRY(iperm.alloc(n_src));
         PGH_HIP(hipMalloc(&f.perm, sizeof(int32_t) * (size_t)n_src_pad));
         if (nnz > 0) k_source_counts<<<blocks_for(nnz), kBlock, 0, r.stream>>>(g->col, mult, nnz, cnt.p);
-        k_iota<<<blocks_for(n_src), kBlock, 0, r.stream>>>(ids.p, n_src);
-        size_t temp_bytes = 0;
-        PGH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, temp_bytes, cnt.p, cnt_sorted.p, ids.p, ids_sorted.p, (int)n_src, 0, 32, r.stream));
-        DevBuf<char> temp;
-        PGH_TRY(temp.alloc(temp_bytes));
-        PGH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(temp.p, temp_bytes, cnt.p, cnt_sorted.p, ids.p, ids_sorted.p, (int)n_src, 0, 32, r.stream));
-        k_fill_perm_pad<<<blocks_for(n_src_pad), kBlock, 0, r.stream>>>(f.perm, n_src_pad);
-        k_make_perm<<<blocks_for(n_src), kBlock, 0, r.stream>>>(ids_sorted.p, n_src, B, blk, f.perm, iperm.p);
-        PGH_HIP(hipGetLastError());
-        PGH_HIP(hipStreamSynchronize(r.stream));
+        PGH_TRY(build_count_perm(cnt.p, n_src, B, blk, f.perm, iperm.p));
     }
     // ---- entry expansion offsets (value-free: multiplicities become repeated entries)
     DevBuf<int64_t> offs;

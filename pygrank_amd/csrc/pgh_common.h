@@ -155,6 +155,9 @@ struct pgh_graph_s {
     double*  head_partial = nullptr; // [num_tiles]
     int64_t  device_bytes = 0;
     BsfFormat bsf;
+    // row-partitioned graphs: ids are globally relabelled, this graph holds rows [row_begin, row_begin + n_cols)
+    int32_t* part_perm = nullptr;    // [n_rows] new id -> original id (same on every rank), or null
+    int64_t  row_begin = 0;
 };
 
 // ---------------------------------------------------------------- device helpers

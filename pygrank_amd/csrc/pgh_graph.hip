@@ -251,6 +251,7 @@ extern "C" int pgh_graph_destroy(pgh_graph_t g) {
     (void)hipFree(g->tail_carry);
     (void)hipFree(g->head_partial);
     bsf_destroy(g->bsf);
+    (void)hipFree(g->part_perm);
     delete g;
     return 0;
 }
@@ -261,6 +262,18 @@ extern "C" int pgh_graph_info(pgh_graph_t g, int64_t* n_rows, int64_t* n_cols, i
     if (n_cols) *n_cols = g->n_cols;
     if (nnz) *nnz = g->nnz;
     if (device_bytes) *device_bytes = g->device_bytes;
+    return 0;
+}
+
+extern "C" int pgh_graph_perm(pgh_graph_t g, int32_t* new_to_old, int64_t* row_begin) {
+    PGH_CHECK(g && new_to_old, "pgh_graph_perm: null argument");
+    if (row_begin) *row_begin = g->row_begin;
+    if (g->part_perm != nullptr) {
+        PGH_HIP(hipMemcpyAsync(new_to_old, g->part_perm, sizeof(int32_t) * g->n_rows, hipMemcpyDeviceToHost, rt().stream));
+        PGH_HIP(hipStreamSynchronize(rt().stream));
+    } else {
+        for (int64_t i = 0; i < g->n_rows; ++i) new_to_old[i] = (int32_t)i;
+    }
     return 0;
 }
 

@@ -32,6 +32,7 @@ struct RmatParams {
     uint64_t seed;
     int      symmetrize;      // also emit (dst, src)
     int64_t  row_begin, row_end;
+    const int32_t* iperm;   // row-partitioned mode: old id -> globally relabelled id (null otherwise)
 };
 
 __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
@@ -72,6 +73,10 @@ __global__ void k_rmat_count(RmatParams P, unsigned int* __restrict__ outdeg, un
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < P.num_edges; e += stride) {
         uint32_t s, d;
         rmat_edge(P, (uint64_t)e, s, d);
+        if (P.iperm != nullptr) {
+            s = (uint32_t)P.iperm[s];
+            d = (uint32_t)P.iperm[d];
+        }
         atomicAdd(&outdeg[s], 1u);
         if ((int64_t)d >= P.row_begin && (int64_t)d < P.row_end) ++local;
         if (P.symmetrize) {
@@ -90,6 +95,10 @@ __global__ void k_rmat_fill(RmatParams P, uint64_t* __restrict__ keys, unsigned 
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < P.num_edges; e += stride) {
         uint32_t s, d;
         rmat_edge(P, (uint64_t)e, s, d);
+        if (P.iperm != nullptr) {
+            s = (uint32_t)P.iperm[s];
+            d = (uint32_t)P.iperm[d];
+        }
         if (dense) {                       // whole row range, no symmetrisation: edge e owns slot e (deterministic)
             keys[e] = ((uint64_t)d << 32) | s;
             continue;
@@ -194,14 +203,33 @@ struct DevBuf {
 
 }  // namespace
 
-extern "C" int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, double b, double c, uint64_t seed,
-                              int32_t normalization, int32_t symmetrize, int64_t row_begin, int64_t row_end,
-                              pgh_graph_t* out) {
+namespace {
+__global__ void k_gather_u32(const unsigned int* __restrict__ src, const int32_t* __restrict__ perm, int64_t n, unsigned int* __restrict__ dst) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[perm[i]];
+}
+}  // namespace
+
+// part_count == 0: ids as generated, rows [row_begin, row_end).  part_count > 0: ids globally relabelled by
+// descending source count into B = max(part_count, auto) hot-first blocks (identical on every rank), this rank keeps
+// the contiguous slice of new ids [part_rank * n / part_count, (part_rank + 1) * n / part_count).
+static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, double c, uint64_t seed, int32_t normalization,
+                      int32_t symmetrize, int64_t row_begin, int64_t row_end, int32_t part_rank, int32_t part_count,
+                      pgh_graph_t* out) {
     PGH_TRY(ensure_init());
     PGH_CHECK(scale >= 1 && scale <= 30 && edge_factor >= 1, "pgh_graph_rmat: scale must be in [1, 30]");
     PGH_CHECK(normalization >= 0 && normalization <= 2, "pgh_graph_rmat: normalization must be 0 (col), 1 (symmetric) or 2 (none)");
     const int64_t n = 1LL << scale;
     if (row_end <= 0) row_end = n;
+    int part_blocks = 0;
+    if (part_count > 0) {
+        PGH_CHECK((part_count & (part_count - 1)) == 0 && part_count <= n && part_rank >= 0 && part_rank < part_count,
+                  "pgh_graph_rmat_part: the number of partitions must be a power of two and the rank inside it");
+        part_blocks = bsf_auto_blocks(n);
+        if (part_blocks < part_count) part_blocks = part_count;
+        PGH_CHECK(part_blocks <= 8, "pgh_graph_rmat_part: at most 8 partitions per node");
+        row_begin = (int64_t)part_rank * (n / part_count);
+        row_end = row_begin + n / part_count;
+    }
     PGH_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= n, "pgh_graph_rmat: bad row range");
     Runtime& r = rt();
     RmatParams P;
@@ -214,12 +242,14 @@ extern "C" int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, doub
     P.symmetrize = symmetrize ? 1 : 0;
     P.row_begin = row_begin;
     P.row_end = row_end;
+    P.iperm = nullptr;
     const int64_t n_local = row_end - row_begin;
-    const bool dense = (row_begin == 0 && row_end == n && !symmetrize);
+    const bool dense = (row_begin == 0 && row_end == n && !symmetrize && part_count == 0);
 
     pgh_graph_s* g = new pgh_graph_s();
     g->n_rows = n;          // rows of M = sources = length of the gathered vector
     g->n_cols = n_local;    // rows of the stored M^T slice = length of the output
+    g->row_begin = row_begin;
     int rc = [&]() -> int {
         DevBuf<unsigned int> outdeg, indeg;
         DevBuf<unsigned long long> counters;
@@ -229,6 +259,21 @@ extern "C" int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, doub
         PGH_TRY(outdeg.alloc(n, true));
         PGH_TRY(indeg.alloc(n_local, true));
         PGH_TRY(counters.alloc(2, true));
+        DevBuf<int32_t> iperm;
+        if (part_count > 0) {
+            // pass 0: global source counts in the generated ids -> the relabelling every rank derives identically
+            DevBuf<unsigned int> outdeg_old;
+            PGH_TRY(outdeg_old.alloc(n, true));
+            RmatParams P0 = P;
+            P0.row_begin = P0.row_end = 0;
+            k_rmat_count<<<blocks_for(P.num_edges), kBlock, 0, r.stream>>>(P0, outdeg_old.p, counters.p);
+            PGH_HIP(hipGetLastError());
+            PGH_TRY(iperm.alloc(n));
+            PGH_HIP(hipMalloc(&g->part_perm, sizeof(int32_t) * (size_t)n));
+            PGH_TRY(build_count_perm(outdeg_old.p, n, part_blocks, (int)(n / part_blocks), g->part_perm, iperm.p));
+            PGH_HIP(hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * 2, r.stream));
+            P.iperm = iperm.p;
+        }
         k_rmat_count<<<blocks_for(P.num_edges), kBlock, 0, r.stream>>>(P, outdeg.p, counters.p);
         PGH_HIP(hipGetLastError());
         unsigned long long kept = 0;
@@ -298,9 +343,10 @@ extern "C" int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, doub
                                                                       normalization == 1 ? dst.p : nullptr);
                 PGH_HIP(hipGetLastError());
                 PGH_TRY(bsf_build(g, nullptr, counts.p, normalization == 2 ? nullptr : src.p,
-                                  normalization == 1 ? dst.p : nullptr, rl == nullptr || atoi(rl) != 0));
+                                  normalization == 1 ? dst.p : nullptr, part_count == 0 && (rl == nullptr || atoi(rl) != 0),
+                                  part_blocks));
             } else {
-                PGH_TRY(bsf_build(g, g->val, nullptr, nullptr, nullptr, rl == nullptr || atoi(rl) != 0));
+                PGH_TRY(bsf_build(g, g->val, nullptr, nullptr, nullptr, part_count == 0 && (rl == nullptr || atoi(rl) != 0), part_blocks));
             }
         }
         return 0;
@@ -312,4 +358,17 @@ extern "C" int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, doub
     }
     *out = g;
     return 0;
+}
+
+extern "C" int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, double b, double c, uint64_t seed,
+                              int32_t normalization, int32_t symmetrize, int64_t row_begin, int64_t row_end,
+                              pgh_graph_t* out) {
+    return rmat_build(scale, edge_factor, a, b, c, seed, normalization, symmetrize, row_begin, row_end, 0, 0, out);
+}
+
+extern "C" int pgh_graph_rmat_part(int32_t scale, int32_t edge_factor, double a, double b, double c, uint64_t seed,
+                                   int32_t normalization, int32_t symmetrize, int32_t part_rank, int32_t part_count,
+                                   pgh_graph_t* out) {
+    PGH_CHECK(part_count >= 1, "pgh_graph_rmat_part: part_count must be >= 1");
+    return rmat_build(scale, edge_factor, a, b, c, seed, normalization, symmetrize, 0, 0, part_rank, part_count, out);
 }

@@ -79,7 +79,10 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
 int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale, float hole);
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);
-int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel);
+int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel,
+              int force_blocks = 0);
+int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t* perm, int32_t* iperm);
+int bsf_auto_blocks(int64_t n_src);
 void bsf_destroy(BsfFormat& f);
 int finish_graph(pgh_graph_s* g);
 

@@ -21,6 +21,8 @@
 //     and every dense vector once: 8*nnz + 16*n bytes for the PageRank step.
 #include "pgh_kernels.h"
 
+#include <vector>
+
 using namespace pgh;
 
 namespace {
@@ -421,15 +423,48 @@ int fetch_scalars(int first, int count) {
     return 0;
 }
 
+// Work vectors of the loops come from a small size-keyed pool: hipMalloc / hipFree synchronise the device and cost
+// 100+ us each, which would otherwise dominate a 5 ms PageRank run (SURVEY.md 7 "Python overhead per iteration").
+struct WorkPool {
+    struct Slot {
+        float*  p;
+        int64_t n;
+        bool    busy;
+    };
+    std::vector<Slot> slots;
+    int acquire(int64_t n, float** out) {
+        for (Slot& s : slots)
+            if (!s.busy && s.n == n) {
+                s.busy = true;
+                *out = s.p;
+                return 0;
+            }
+        if (slots.size() >= 24) {                     // bounded: drop idle buffers of other sizes
+            std::vector<Slot> keep;
+            for (Slot& s : slots) {
+                if (s.busy) keep.push_back(s); else (void)hipFree(s.p);
+            }
+            slots.swap(keep);
+        }
+        float* p = nullptr;
+        PGH_HIP(hipMalloc(&p, sizeof(float) * (size_t)(n > 0 ? n : 1)));
+        slots.push_back({p, n, true});
+        *out = p;
+        return 0;
+    }
+    void release(float* p) {
+        for (Slot& s : slots)
+            if (s.p == p) s.busy = false;
+    }
+};
+WorkPool g_pool;
+
 struct DevF32 {
     float* p = nullptr;
     ~DevF32() {
-        if (p) (void)hipFree(p);
+        if (p) g_pool.release(p);                     // stream-ordered reuse: every user enqueues on the engine stream
     }
-    int alloc(int64_t n) {
-        PGH_HIP(hipMalloc(&p, sizeof(float) * (size_t)(n > 0 ? n : 1)));
-        return 0;
-    }
+    int alloc(int64_t n) { return g_pool.acquire(n, &p); }
 };
 
 // single-shot step in the CALLER's id space: ep holds caller-space pointers, x is the un-scaled gather vector
@@ -549,6 +584,57 @@ extern "C" int pgh_poly_step(pgh_graph_t g, pgh_vec_t term, pgh_vec_t term_out, 
     if (err_kind == PGH_ERR_MABS) d /= (double)g->n_cols;
     if (delta) *delta = d;
     return 0;
+}
+
+// Row-partitioned PageRank step: this rank holds rows [row_begin, row_begin + n_local) of M^T in the
+// globally relabelled id space.  xg_full is the all-gathered gather vector (x * src_scale of every rank's slice);
+// the step writes y_local and this rank's slice of the next gather vector, so the all-gather moves xg directly.
+extern "C" int pgh_ppr_step_dist(pgh_graph_t g, pgh_vec_t xg_full, double x_scale, pgh_vec_t p_local, double alpha,
+                                 pgh_vec_t y_local, pgh_vec_t xg_local_out, double* sum_y) {
+    PGH_CHECK(g && xg_full && p_local && y_local && xg_local_out, "pgh_ppr_step_dist: null argument");
+    PGH_CHECK(g->bsf.enabled, "pgh_ppr_step_dist: the graph has no blocked layout");
+    BsfFormat& f = g->bsf;
+    PGH_CHECK(xg_full->n >= f.n_src_pad, "pgh_ppr_step_dist: gather vector shorter than the source space");
+    PGH_CHECK(p_local->n == g->n_cols && y_local->n == g->n_cols && xg_local_out->n == g->n_cols,
+              "pgh_ppr_step_dist: local vector length mismatch");
+    PGH_TRY(ensure_state());
+    Runtime& r = rt();
+    EpiParams ep{};
+    ep.a = alpha * x_scale;
+    ep.b = 1.0 - alpha;
+    ep.v = p_local->data;
+    ep.y = y_local->data;
+    if (f.src_scale != nullptr) {
+        ep.xg_out = xg_local_out->data;
+        ep.src_scale = f.src_scale + g->row_begin;
+    }
+    int count = 0;
+    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
+    PGH_TRY((bsf_launch<EPI_AXPBY>(g, ep, xg_full->data, nullptr, &count)));
+    if (f.src_scale == nullptr) PGH_TRY(pgh_vec_copy(xg_local_out, y_local));
+    if (sum_y != nullptr) {
+        ProfScope prof(PGH_K_FINAL);
+        k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, r.d_partials + kMaxPartials, count, 0, 0, PGH_ERR_L1,
+                                             -1.0, g->n_cols, r.d_scalars);
+        PGH_HIP(hipGetLastError());
+        PGH_TRY(fetch_scalars(1, 2));
+        *sum_y = r.h_scalars[1];
+    }
+    return 0;
+}
+
+// gather vector slice of a local vector: out = x_local * src_scale[row_begin ...] (the first iterate of a partitioned run)
+extern "C" int pgh_dist_prescale(pgh_graph_t g, pgh_vec_t x_local, pgh_vec_t xg_local_out) {
+    PGH_CHECK(g && x_local && xg_local_out && x_local->n == g->n_cols && xg_local_out->n == g->n_cols,
+              "pgh_dist_prescale: length mismatch");
+    if (g->bsf.enabled && g->bsf.src_scale != nullptr) {
+        pgh_vec_s sv;
+        sv.data = g->bsf.src_scale + g->row_begin;
+        sv.n = g->n_cols;
+        sv.owns = false;
+        return pgh_ewise_vv(PGH_MUL, x_local, &sv, xg_local_out);
+    }
+    return pgh_vec_copy(xg_local_out, x_local);
 }
 
 // =================================================================================================

@@ -1,0 +1,52 @@
+"""Worker of tests/test_distributed_cpu.py: one process per rank (gloo), engine = host test double.
+Runs DistributedPageRank on a row-partitioned RMAT graph and writes this rank's slice to a .npz."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir, scale, ef = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    import torch.distributed as dist
+    import pygrank_amd as pg
+    from pygrank_amd import _lib
+    from pygrank_amd.device import DeviceVector
+    from pygrank_amd.distributed import DistributedPageRank, rmat_partitioned
+    on_gpu = os.environ.get("PGH_TEST_ENGINE") == "hip"
+    if on_gpu:                                   # tests/test_gpu_parity.py: the real engine + RCCL (world size 1 on the 1-GPU box)
+        import torch
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    else:
+        _lib._install_test_double(ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libpgh_host_oracle.so")))
+    pg.load_backend("hip")
+    dist.init_process_group(backend="nccl" if on_gpu else "gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    graph = rmat_partitioned(scale, ef, rank, world, seed=0)
+    perm = graph.perm
+    # personalization defined on ORIGINAL ids (same on every rank), mapped into this rank's slice of new ids
+    rng = np.random.default_rng(1)
+    p_old = np.zeros(graph.n)
+    p_old[rng.choice(graph.n, 20, replace=False)] = rng.random(20) + 0.5
+    lo = graph.row_begin
+    p_local = p_old[perm[lo:lo + graph.n_local]]
+    results = {}
+    for name, kw in (("l1", dict(error_type="l1", tol=1e-6, max_iters=500)),
+                     ("mabs", dict(error_type="mabs", tol=1e-7, max_iters=500)),
+                     ("iters", dict(error_type="iters", max_iters=21)),
+                     ("noquot", dict(error_type="linf", tol=1e-7, max_iters=500, use_quotient=False))):
+        ranker = DistributedPageRank(alpha=0.85, **kw)
+        out = ranker.rank(graph, DeviceVector.from_host(p_local))
+        results[name + "_ranks"] = np.asarray(out)
+        results[name + "_iters"] = ranker.iteration
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), perm=perm, lo=lo, n_local=graph.n_local, nnz=graph.graph.nnz, **results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

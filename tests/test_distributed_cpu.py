@@ -1,0 +1,50 @@
+"""N > 1 path on the CPU: world_size 2 and 4 gloo runs of the row-partitioned PageRank (pygrank_amd/distributed.py)
+against the host test double, compared with the single-process oracle on the same graph (ranks un-permuted).
+Covers the global relabelling, equal-sized slices, the all-gather of the gather vector and the scalar all-reduces."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ref_loops as orc, rmat_np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_partitioned_pagerank_gloo(tmp_path, oracle_build_dir, world):
+    scale, ef = 10, 8
+    port = 29500 + world + (os.getpid() % 500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(scale), str(ef)]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    n = 1 << scale
+    perm = parts[0]["perm"]
+    assert sorted(perm.tolist()) == list(range(n))                     # a permutation, identical on every rank
+    for part in parts[1:]:
+        assert np.array_equal(part["perm"], perm)
+    assert [int(part["n_local"]) for part in parts] == [n // world] * world     # equal slices: unpadded all-gather
+    A = rmat_np.rmat_csr(scale, ef, seed=0)
+    assert sum(int(part["nnz"]) for part in parts) == A.nnz
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    rng = np.random.default_rng(1)
+    p_old = np.zeros(n)
+    p_old[rng.choice(n, 20, replace=False)] = rng.random(20) + 0.5
+    cases = {"l1": dict(error_type="l1", tol=1e-6, max_iters=500), "mabs": dict(error_type="mabs", tol=1e-7, max_iters=500),
+             "iters": dict(error_type="iters", max_iters=21),
+             "noquot": dict(error_type="linf", tol=1e-7, max_iters=500, use_quotient=False)}
+    for name, kw in cases.items():
+        want, want_iters = orc.pagerank(M, p_old, alpha=0.85, eps=EPS32, **kw)
+        got = np.zeros(n)
+        for part in parts:
+            lo, m = int(part["lo"]), int(part["n_local"])
+            got[perm[lo:lo + m]] = part[name + "_ranks"]
+            assert int(part[name + "_iters"]) == want_iters, name
+        assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), name

@@ -138,3 +138,40 @@ def test_full_size_properties_rmat20(gpu_engine):
     again = pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=1e-5, max_iters=1000)
     again.rank(graph, p.copy(), warm_start=np.asarray(ranks.np) / np.asarray(ranks.np).sum())
     assert again.convergence.iteration == 2
+
+
+def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path):
+    """The N > 1 code path (relabelled slice generation, pgh_ppr_step_dist, RCCL all-gather / all-reduce on the engine
+    stream) with world size 1 on the single GPU of this box, against the oracle; world sizes 2 and 4 are covered on the
+    CPU by tests/test_distributed_cpu.py, 8 GPUs by the driver's scaling run."""
+    import os
+    import subprocess
+    import sys
+    import scipy.sparse as sp
+    from oracle import ref_loops as orc, rmat_np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scale, ef = 14, 8
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(root, "tests", "dist_worker.py"), str(tmp_path), str(scale), str(ef)]
+    env = dict(os.environ, PYTHONPATH=root, PGH_TEST_ENGINE="hip", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    part = np.load(os.path.join(tmp_path, "rank0.npz"))
+    n = 1 << scale
+    perm = part["perm"]
+    assert sorted(perm.tolist()) == list(range(n))
+    A = rmat_np.rmat_csr(scale, ef, seed=0)
+    assert int(part["nnz"]) == A.nnz
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    rng = np.random.default_rng(1)
+    p_old = np.zeros(n)
+    p_old[rng.choice(n, 20, replace=False)] = rng.random(20) + 0.5
+    cases_ = {"l1": dict(error_type="l1", tol=1e-6, max_iters=500), "mabs": dict(error_type="mabs", tol=1e-7, max_iters=500),
+              "iters": dict(error_type="iters", max_iters=21),
+              "noquot": dict(error_type="linf", tol=1e-7, max_iters=500, use_quotient=False)}
+    for name, kw in cases_.items():
+        want, want_iters = orc.pagerank(M, p_old, alpha=0.85, eps=EPS32, **kw)
+        got = np.zeros(n)
+        got[perm] = part[name + "_ranks"]
+        assert int(part[name + "_iters"]) == want_iters, name
+        assert rel_linf(got, want) <= 1e-6, name
