@@ -177,6 +177,16 @@ int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, c
 int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, int32_t chebyshev,
                  pgh_vec_t result, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 
+/* ---------------------------------------------------------------- multi-seed batch (SpMM) --------- */
+/* Y = M^T X for a row-major [n, b] slab (b <= 64): the b conv() calls of NodeRanking.propagate
+ * (signals.py:225-226) / tuner probes / sweeps in ONE pass over the adjacency. */
+int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y);
+/* b independent PageRank runs (same alpha and ConvergenceManager settings; personalizations = columns of p, already
+ * L1-normalised; ranks in/out like pgh_ppr_run).  Column j keeps its own quotient, residual and stopping iteration:
+ * results[j] is what pgh_ppr_run would report for seed j.  out_scales (nullable): per-column preserve_norm factor. */
+int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales,
+                      pgh_loop_result* per_column_results);
+
 /* ---------------------------------------------------------------- row-partitioned step ---- */
 /* The path shards with one exchange per iteration: every rank holds a contiguous slice of the rows of M^T in a
  * globally relabelled id space and a full-length gather vector; after each step the slices are all-gathered

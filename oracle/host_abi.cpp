@@ -607,6 +607,42 @@ static inline uint64_t splitmix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
+// multi-seed entry points: column-by-column restatement (NodeRanking.propagate, signals.py:225-226)
+int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
+    CHECK(g && x && y && x->n == g->n_rows && y->n == g->n_cols && x->b == y->b, "pgh_spmm: shape mismatch");
+    CHECK(x->b >= 1 && x->b <= 64, "pgh_spmm: the batch width must be in [1, 64]");
+    std::vector<float> col(g->n_rows);
+    for (int32_t j = 0; j < x->b; ++j) {
+        for (int64_t i = 0; i < g->n_rows; ++i) col[i] = x->data[i * x->b + j];
+        for (int64_t r = 0; r < g->n_cols; ++r) y->data[r * y->b + j] = row_dot(g, col.data(), r);
+    }
+    return 0;
+}
+int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales,
+                      pgh_loop_result* results) {
+    CHECK(g && p && ranks && cfg && results && p->n == g->n_cols && ranks->n == g->n_cols && p->b == ranks->b,
+          "pgh_ppr_run_batch: shape mismatch");
+    CHECK(p->b >= 1 && p->b <= 64, "pgh_ppr_run_batch: the batch width must be in [1, 64]");
+    const int64_t n = g->n_cols;
+    for (int32_t j = 0; j < p->b; ++j) {
+        pgh_vec_t vp, vr;
+        pgh_vec_alloc(n, &vp);
+        pgh_vec_alloc(n, &vr);
+        for (int64_t i = 0; i < n; ++i) {
+            vp->data[i] = p->data[i * p->b + j];
+            vr->data[i] = ranks->data[i * p->b + j];
+        }
+        pgh_loop_cfg c = *cfg;
+        if (out_scales) c.out_scale = out_scales[j];
+        const int rc = pgh_ppr_run(g, vp, vr, &c, &results[j]);
+        for (int64_t i = 0; i < n; ++i) ranks->data[i * p->b + j] = vr->data[i];
+        pgh_vec_free(vp);
+        pgh_vec_free(vr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static int rmat_build(int32_t scale, int32_t ef, double a, double b, double c, uint64_t seed, int32_t normalization,
                       int32_t symmetrize, int64_t row_begin, int64_t row_end, int32_t part_rank, int32_t part_count,
                       pgh_graph_t* out) {

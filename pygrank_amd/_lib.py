@@ -97,6 +97,8 @@ SIGNATURES = {
     "pgh_absorb_run": (C.c_int, [c_graph, c_vec, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_poly_run": (C.c_int, [c_graph, c_vec, C.c_void_p, C.c_int32, C.c_int32, c_vec, C.POINTER(LoopCfg),
                                C.POINTER(LoopResult)]),
+    "pgh_spmm": (C.c_int, [c_graph, c_mat, c_mat]),
+    "pgh_ppr_run_batch": (C.c_int, [c_graph, c_mat, c_mat, C.POINTER(LoopCfg), C.c_void_p, C.POINTER(LoopResult)]),
     "pgh_ppr_step_dist": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, C.c_double, c_vec, c_vec, c_f64p]),
     "pgh_dist_prescale": (C.c_int, [c_graph, c_vec, c_vec]),
     "pgh_graph_perm": (C.c_int, [c_graph, C.c_void_p, c_i64p]),

@@ -151,7 +151,7 @@ def self_normalize(obj):                  # specification.py:93; numpy.py:57-61
 
 
 def conv(signal, M):                      # specification.py:97; numpy.py:64-65: signal @ M = M^T signal
-    return M.conv(_vec(signal))
+    return M.conv(_vec(signal))             # an [n, b] slab is propagated in one multi-seed pass
 
 
 def length(x):                            # specification.py:101

@@ -644,9 +644,10 @@ int bsf_auto_blocks(int64_t n_src) {
 //   mult != null : value-free; M^T = diag(dst_old) * mult * diag(src_old) (either scale may be null = 1)
 // relabel: permute ids by descending source count (square graphs only).
 int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel,
-              int force_blocks) {
+              int force_blocks, BsfFormat* target) {
     Runtime& r = rt();
-    BsfFormat& f = g->bsf;
+    BsfFormat& f = target ? *target : g->bsf;
+    const bool batch_layout = target != nullptr && target != &g->bsf;   // multi-seed layout: no single-vector work buffers
     const int64_t n_src = g->n_rows, n_out = g->n_cols, nnz = g->nnz;
     PGH_CHECK(n_src < (1LL << 28) && n_out < (1LL << 28), "blocked format needs fewer than 2^28 rows/columns");
     if (relabel && n_src != n_out) relabel = false;
@@ -784,11 +785,13 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     k_bsf_tiles<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(tb, segid.p, f.tile);
     // ---- work buffers and scales
     const size_t n_int = (size_t)(f.n_out > 0 ? f.n_out : 1);
-    PGH_HIP(hipMalloc(&f.part, sizeof(float) * (size_t)B * n_int));
-    PGH_HIP(hipMemsetAsync(f.part, 0, sizeof(float) * (size_t)B * n_int, r.stream));
-    PGH_HIP(hipMalloc(&f.xg, sizeof(float) * (size_t)(n_src_pad + 1)));
-    PGH_HIP(hipMemsetAsync(f.xg, 0, sizeof(float) * (size_t)(n_src_pad + 1), r.stream));
-    PGH_HIP(hipMalloc(&f.tmp_out, sizeof(float) * n_int));
+    if (!batch_layout) {
+        PGH_HIP(hipMalloc(&f.part, sizeof(float) * (size_t)B * n_int));
+        PGH_HIP(hipMemsetAsync(f.part, 0, sizeof(float) * (size_t)B * n_int, r.stream));
+        PGH_HIP(hipMalloc(&f.xg, sizeof(float) * (size_t)(n_src_pad + 1)));
+        PGH_HIP(hipMemsetAsync(f.xg, 0, sizeof(float) * (size_t)(n_src_pad + 1), r.stream));
+        PGH_HIP(hipMalloc(&f.tmp_out, sizeof(float) * n_int));
+    }
     if (src_old) {
         PGH_HIP(hipMalloc(&f.src_scale, sizeof(float) * (size_t)(n_src_pad + 1)));
         PGH_HIP(hipMemsetAsync(f.src_scale, 0, sizeof(float) * (size_t)(n_src_pad + 1), r.stream));

@@ -155,6 +155,11 @@ struct pgh_graph_s {
     double*  head_partial = nullptr; // [num_tiles]
     int64_t  device_bytes = 0;
     BsfFormat bsf;
+    // multi-seed (SpMM) layout: one column block, built on first use from the factors kept below
+    BsfFormat bsf_mm;
+    int32_t*  keep_mult = nullptr;   // [nnz] edge multiplicities of the value-free factorisation (generator graphs)
+    float*    keep_src = nullptr;    // [n_rows] source scale, caller id space
+    float*    keep_dst = nullptr;    // [n_cols] output scale
     // row-partitioned graphs: ids are globally relabelled, this graph holds rows [row_begin, row_begin + n_cols)
     int32_t* part_perm = nullptr;    // [n_rows] new id -> original id (same on every rank), or null
     int64_t  row_begin = 0;

@@ -251,6 +251,10 @@ extern "C" int pgh_graph_destroy(pgh_graph_t g) {
     (void)hipFree(g->tail_carry);
     (void)hipFree(g->head_partial);
     bsf_destroy(g->bsf);
+    bsf_destroy(g->bsf_mm);
+    (void)hipFree(g->keep_mult);
+    (void)hipFree(g->keep_src);
+    (void)hipFree(g->keep_dst);
     (void)hipFree(g->part_perm);
     delete g;
     return 0;

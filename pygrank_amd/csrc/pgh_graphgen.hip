@@ -199,6 +199,11 @@ struct DevBuf {
         if (zero) PGH_HIP(hipMemsetAsync(p, 0, sizeof(T) * (count > 0 ? count : 1), rt().stream));
         return 0;
     }
+    T* release() {
+        T* q = p;
+        p = nullptr;
+        return q;
+    }
 };
 
 }  // namespace
@@ -345,6 +350,10 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
                 PGH_TRY(bsf_build(g, nullptr, counts.p, normalization == 2 ? nullptr : src.p,
                                   normalization == 1 ? dst.p : nullptr, part_count == 0 && (rl == nullptr || atoi(rl) != 0),
                                   part_blocks));
+                // keep the factorisation for the multi-seed layout, which is built on first use (pgh_spmm.hip)
+                g->keep_mult = (int32_t*)counts.release();
+                if (normalization != 2) g->keep_src = src.release();
+                if (normalization == 1) g->keep_dst = dst.release();
             } else {
                 PGH_TRY(bsf_build(g, g->val, nullptr, nullptr, nullptr, part_count == 0 && (rl == nullptr || atoi(rl) != 0), part_blocks));
             }

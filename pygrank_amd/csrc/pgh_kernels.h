@@ -80,7 +80,7 @@ int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale,
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);
 int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel,
-              int force_blocks = 0);
+              int force_blocks = 0, BsfFormat* target = nullptr);
 int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t* perm, int32_t* iperm);
 int bsf_auto_blocks(int64_t n_src);
 void bsf_destroy(BsfFormat& f);

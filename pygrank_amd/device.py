@@ -364,7 +364,13 @@ class DeviceGraph:
         return sp.csr_array((data, indices, indptr), shape=(self.shape[1], self.shape[0]))
 
     def conv(self, x):
-        """M^T x (numpy.py:64-65); pure."""
+        """M^T x (numpy.py:64-65); pure.  A DeviceMatrix [n, b] is propagated as one multi-seed pass (b <= 64)."""
+        if isinstance(x, DeviceMatrix):
+            if x.b > 64:
+                return DeviceMatrix.from_columns([self.conv(c) for c in x.columns()])
+            y = DeviceMatrix.empty(self.shape[1], x.b)
+            L.check(L.lib().pgh_spmm(self._h, x._h, y._h))
+            return y
         y = DeviceVector.empty(self.shape[1])
         L.check(L.lib().pgh_spmv(self._h, x._h, y._h))
         return y

@@ -196,6 +196,41 @@ class PageRank(RecursiveGraphFilter):
             return False
         return self._run_recursive(L.lib().pgh_ppr_run, _device_graph(M), cfg, ranks, p)
 
+    def propagate(self, graph, features, *args, **kwargs):
+        """signals.py:225-226 semantics (one rank() per feature column), run as multi-seed batches of up to 64 columns
+        through pgh_ppr_run_batch: the adjacency is streamed once per iteration for the whole batch and every column
+        keeps its own quotient, residual and stopping iteration."""
+        from pygrank_amd.device import DeviceMatrix
+        cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), 1.0)
+        batched = (not args and not kwargs and cfg is not None and self._plain_quotient()
+                   and type(self)._formula is PageRank._formula and type(self)._step is RecursiveGraphFilter._step
+                   and isinstance(self.personalization_transform, Tautology) and self.personalization_transform.ranker is None)
+        cols = backend.separate_cols(features)
+        M = self.preprocessor(graph) if batched else None
+        g = _device_graph(M) if batched else None
+        if g is None or g.shape[0] != g.shape[1]:
+            return super().propagate(graph, features, *args, **kwargs)
+        self.last_batches = []
+        out_cols = []
+        for start in range(0, len(cols), 64):
+            chunk = cols[start:start + 64]
+            norms = [c.abssum() for c in chunk]                                   # abstract_filters.py:52-55 per column
+            normalized = [c / nrm if nrm != 0 else c for c, nrm in zip(chunk, norms)]
+            P = DeviceMatrix.from_columns(normalized)
+            R = DeviceMatrix.from_columns(normalized)                              # ranks start as a copy of p (:56)
+            results = (L.LoopResult * len(chunk))()
+            scales = (C.c_double * len(chunk))(*[(nrm if self.preserve_norm else 1.0) for nrm in norms])
+            self.convergence.start()
+            L.check(L.lib().pgh_ppr_run_batch(g._h, P._h, R._h, C.byref(cfg), scales, results))
+            info = [dict(iterations=r.iterations, converged=bool(r.converged), spmv=r.spmv_count, loop_ms=r.loop_ms)
+                    for r in results]
+            self.last_batches.append(info)
+            for j, (r, nrm) in enumerate(zip(results, norms)):
+                if nrm != 0:
+                    self.convergence.finish_device_loop(r.iterations, r.converged)   # raises like the per-column run would
+            out_cols.extend(R.columns())
+        return backend.combine_cols(out_cols)
+
     def references(self):
         refs = super().references()
         refs[0] = "personalized PageRank \\cite{page1999pagerank}"

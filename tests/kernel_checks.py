@@ -221,4 +221,45 @@ def check_rmat_generator_matches_numpy(pg):
     assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
 
 
+def check_multi_seed_spmm_and_batched_pagerank(pg):
+    """One pass over the adjacency for a slab of seeds == the per-column single-vector results (signals.py:225-226)."""
+    from oracle import ref_loops as orc
+    rng = np.random.default_rng(9)
+    for name, M in matrices():
+        if M.shape[0] != M.shape[1] or M.shape[0] < 2:
+            continue
+        n = M.shape[0]
+        g = pg.scipy_sparse_to_backend(M)
+        M32 = sp.csr_array(M.astype(F32).astype(np.float64))
+        for b in (1, 3, 64):
+            X = rng.random((n, b)).astype(F32).astype(np.float64)
+            Y = np.asarray(pg.conv(pg.to_primitive(X), g))
+            ref = (X.T @ M32).T
+            scale = (np.abs(X).T @ np.abs(M32)).T
+            assert Y.shape == (n, b), name
+            assert np.all(np.abs(Y - ref) <= 4 * EPS32 * scale + 1e-30), (name, b)
+    # batched PageRank: every column stops at its own iteration and equals the single-vector run / the oracle
+    A = rmat_np.rmat_csr(12, 8, seed=5)
+    n = A.shape[0]
+    Mn = sp.csr_array(orc.normalize(A, "col", True))
+    graph = pg.AdjacencyWrapper(A, directed=True)
+    pre = pg.preprocessor(assume_immutability=True)
+    feats = np.zeros((n, 5))
+    for j in range(5):
+        feats[rmat_np.seed_nodes(A, [1, 2000, 40, 5, 300][j], seed=j + 1), j] = 1.0 + j
+    feats[:, 3] = 0.0                                               # a zero personalization column stays zero
+    ranker = pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=1e-6, max_iters=500)
+    out = np.asarray(ranker.propagate(graph, pg.to_primitive(feats)))
+    assert out.shape == (n, 5) and hasattr(ranker, "last_batches")
+    iters = [c["iterations"] for c in ranker.last_batches[0]]
+    for j in range(5):
+        if j == 3:
+            assert np.all(out[:, j] == 0)
+            continue
+        want, it = orc.pagerank(Mn, feats[:, j], alpha=0.85, error_type="l1", tol=1e-6, max_iters=500)
+        assert iters[j] == it, (j, iters[j], it)
+        assert np.max(np.abs(out[:, j] - want)) <= 1e-6 * np.max(np.abs(want)), j
+    assert len(set(i for k, i in enumerate(iters) if k != 3)) > 1, iters   # the columns really stop at different iterations
+
+
 ALL = [v for k, v in sorted(globals().items()) if k.startswith("check_") and callable(v)]
