@@ -113,6 +113,14 @@ int     pgh_mat_get_col(pgh_mat_t m, int32_t col, pgh_vec_t v);     /* separate_
 enum { PGH_GRAPH_DEFAULT = 0 };
 int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
                        const int32_t* indices, const double* data, int flags, pgh_graph_t* out);
+/* Factored upload: M = diag(left) * W * diag(right) with W the (weighted / multi-edge) adjacency in CSR.  This is what
+ * the preprocessor's "col" (left = 1 / rowsum, right = null, preprocessing.py:109-113), "symmetric" (left = rowsum^-1/2,
+ * right = colsum^-1/2, :131-138) and "both" (:123-130) normalisations produce; the values of M are evaluated on the
+ * device in the reference's order ((left * w) * right, fp64, one rounding to f32).  When every weight of W is a small
+ * positive integer the engine stores the value-free blocked layout (4 B/edge).  Same results as pgh_graph_from_csr(M). */
+int pgh_graph_from_factored_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                                const int32_t* indices, const double* weights, const double* left, const double* right,
+                                int flags, pgh_graph_t* out);
 int pgh_graph_destroy(pgh_graph_t g);
 int pgh_graph_info(pgh_graph_t g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* device_bytes);
 /* human-readable description of the layout the propagation kernels stream (bench.py reports it) */

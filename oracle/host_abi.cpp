@@ -371,6 +371,14 @@ int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
     *out = g;
     return 0;
 }
+int pgh_graph_from_factored_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                                const double* w, const double* left, const double* right, int flags, pgh_graph_t* out) {
+    std::vector<double> data(nnz);
+    for (int64_t r = 0; r < n_rows; ++r)
+        for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k)
+            data[k] = ((left ? left[r] : 1.0) * w[k]) * (right ? right[indices[k]] : 1.0);      // preprocessing.py:113,138
+    return pgh_graph_from_csr(n_rows, n_cols, nnz, indptr, indices, data.data(), flags, out);
+}
 int pgh_graph_destroy(pgh_graph_t g) {
     delete g;
     return 0;

@@ -83,6 +83,8 @@ SIGNATURES = {
     "pgh_mat_get_col": (C.c_int, [c_mat, C.c_int32, c_vec]),
     "pgh_graph_from_csr": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(c_graph)]),
+    "pgh_graph_from_factored_csr": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int, C.POINTER(c_graph)]),
     "pgh_graph_destroy": (C.c_int, [c_graph]),
     "pgh_graph_info": (C.c_int, [c_graph, c_i64p, c_i64p, c_i64p, c_i64p]),
     "pgh_graph_format": (C.c_int, [c_graph, C.c_char_p, C.c_int]),

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
             g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, 0xfffffff0u, 0, 0));
 #else
             g.h[k] = s_hot[min(loc, hot)];
-            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, loc < hot ? 0xfffffff0u : c << 2, 0, 0));
+            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, loc < hot ? 0xfffffff0u : c << 2, 0, PGH_COLD_AUX));
 #endif
             if (HAS_VAL) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
         }

@@ -66,6 +66,10 @@ int ensure_init();
 #ifndef PGH_BSF_HOT
 #define PGH_BSF_HOT 29696
 #endif
+// cache-policy bits of the cold gather (buffer_load aux: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef PGH_COLD_AUX
+#define PGH_COLD_AUX 0
+#endif
 // diagnostic builds only (tools/probe_variants.py): 1 = gather from 4 KB, 2 = from 4 MB, 3 = no gather
 #ifndef PGH_PROBE_GATHER
 #define PGH_PROBE_GATHER 0

@@ -129,6 +129,11 @@ struct DevBuf {
         PGH_HIP(hipMalloc(&p, sizeof(T) * (count > 0 ? count : 1)));
         return 0;
     }
+    T* release() {
+        T* q = p;
+        p = nullptr;
+        return q;
+    }
 };
 
 }  // namespace
@@ -162,9 +167,68 @@ int finish_graph(pgh_graph_s* g) {
 
 }  // namespace pgh
 
-extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
-                                  const int32_t* indices, const double* data, int flags, pgh_graph_t* out) {
-    (void)flags;
+namespace {
+
+// factored upload: data[k] <- (left[row] * w[k]) * right[col] in fp64 (the reference's evaluation order,
+// preprocessing.py:113,138); all_int records whether every weight is a small positive integer
+__global__ void k_apply_factors(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, double* __restrict__ data,
+                                const double* __restrict__ left, const double* __restrict__ right, int64_t n_rows,
+                                int32_t* __restrict__ mult, unsigned long long* __restrict__ stats /* [0]=non-integer count, [1]=sum w */) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long bad = 0, sum = 0;
+    for (int64_t r = wave; r < n_rows; r += nwaves) {
+        const double l = left ? left[r] : 1.0;
+        for (int64_t k = indptr[r] + lane; k < indptr[r + 1]; k += 64) {
+            const double w = data[k];
+            const double rw = right ? right[indices[k]] : 1.0;
+            const double m = rint(w);
+            if (!(w == m && m >= 1.0 && m <= 32768.0)) ++bad; else sum += (unsigned long long)m;
+            mult[k] = (int32_t)(m >= 1.0 && m <= 32768.0 ? m : 1.0);
+            data[k] = (l * w) * rw;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        bad += __shfl_down(bad, off, 64);
+        sum += __shfl_down(sum, off, 64);
+    }
+    if (lane == 0) {
+        if (bad) atomicAdd(&stats[0], bad);
+        if (sum) atomicAdd(&stats[1], sum);
+    }
+}
+
+// expand CSR(M) into sort keys (col << 32 | row) with the entry index as payload
+__global__ void k_make_keys_idx(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t n_rows,
+                                uint64_t* __restrict__ keys, int32_t* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_rows; r += nwaves)
+        for (int64_t k = indptr[r] + lane; k < indptr[r + 1]; k += 64) {
+            keys[k] = ((uint64_t)(uint32_t)indices[k] << 32) | (uint64_t)(uint32_t)r;
+            idx[k] = (int32_t)k;
+        }
+}
+
+__global__ void k_gather_vals(const int32_t* __restrict__ idx, const double* __restrict__ data, const int32_t* __restrict__ mult,
+                              int64_t nnz, float* __restrict__ val_t, int32_t* __restrict__ mult_t) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += stride) {
+        const int32_t src = idx[k];
+        val_t[k] = (float)data[src];
+        if (mult_t) mult_t[k] = mult[src];
+    }
+}
+
+__global__ void k_f64_to_f32_g(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+
+// Shared implementation of the two uploads.  factored: data holds the weights W and M = diag(left) W diag(right).
+int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                        const double* data, bool factored, const double* left, const double* right, pgh_graph_t* out) {
     PGH_TRY(ensure_init());
     PGH_CHECK(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "pgh_graph_from_csr: negative size");
     PGH_CHECK(n_rows < 2147483647LL && n_cols < 2147483647LL && nnz < 2147483647LL,
@@ -178,10 +242,10 @@ extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, c
     g->nnz = nnz;
     int rc = [&]() -> int {
         DevBuf<int64_t> d_indptr;
-        DevBuf<int32_t> d_indices;
-        DevBuf<double> d_data;
+        DevBuf<int32_t> d_indices, d_mult, idx_a, idx_b, mult_t;
+        DevBuf<double> d_data, d_left, d_right;
         DevBuf<uint64_t> keys_a, keys_b;
-        DevBuf<float> vals_a;
+        DevBuf<unsigned long long> stats;
         PGH_TRY(d_indptr.alloc(n_rows + 1));
         PGH_TRY(d_indices.alloc(nnz));
         PGH_TRY(d_data.alloc(nnz));
@@ -189,6 +253,30 @@ extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, c
         if (nnz > 0) {
             PGH_HIP(hipMemcpyAsync(d_indices.p, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, r.stream));
             PGH_HIP(hipMemcpyAsync(d_data.p, data, sizeof(double) * nnz, hipMemcpyHostToDevice, r.stream));
+        }
+        bool value_free = false;
+        if (factored) {
+            PGH_TRY(d_mult.alloc(nnz));
+            PGH_TRY(stats.alloc(2));
+            PGH_HIP(hipMemsetAsync(stats.p, 0, sizeof(unsigned long long) * 2, r.stream));
+            if (left) {
+                PGH_TRY(d_left.alloc(n_rows));
+                PGH_HIP(hipMemcpyAsync(d_left.p, left, sizeof(double) * n_rows, hipMemcpyHostToDevice, r.stream));
+            }
+            if (right) {
+                PGH_TRY(d_right.alloc(n_cols));
+                PGH_HIP(hipMemcpyAsync(d_right.p, right, sizeof(double) * n_cols, hipMemcpyHostToDevice, r.stream));
+            }
+            if (n_rows > 0 && nnz > 0)
+                k_apply_factors<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, d_data.p, left ? d_left.p : nullptr,
+                                                                                 right ? d_right.p : nullptr, n_rows, d_mult.p, stats.p);
+            unsigned long long h[2] = {0, 0};
+            PGH_HIP(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipStreamSynchronize(r.stream));
+            // value-free when every weight is a small positive integer and expanding the multiplicities costs < 25 % entries
+            value_free = nnz > 0 && h[0] == 0 && (double)h[1] <= 1.25 * (double)nnz + 1024.0;
+            const char* vf = getenv("PGH_VALUES");
+            if (vf != nullptr && atoi(vf) != 0) value_free = false;
         }
         PGH_HIP(hipMalloc(&g->degrees, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
         PGH_HIP(hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_cols + 1)));
@@ -198,24 +286,24 @@ extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, c
         if (nnz > 0) {
             PGH_TRY(keys_a.alloc(nnz));
             PGH_TRY(keys_b.alloc(nnz));
-            PGH_TRY(vals_a.alloc(nnz));
-            k_make_keys<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, d_data.p, n_rows, keys_a.p, vals_a.p);
+            PGH_TRY(idx_a.alloc(nnz));
+            PGH_TRY(idx_b.alloc(nnz));
+            k_make_keys_idx<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, n_rows, keys_a.p, idx_a.p);
             PGH_HIP(hipGetLastError());
-            int bits_row = 1, bits_col = 1;
-            while ((1LL << bits_row) < n_rows) ++bits_row;
+            int bits_col = 1;
             while ((1LL << bits_col) < n_cols) ++bits_col;
             const int end_bit = 32 + bits_col;
             size_t temp_bytes = 0;
-            PGH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a.p, keys_b.p, vals_a.p, g->val, (int)nnz, 0,
-                                                       end_bit, r.stream));
+            PGH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (int)nnz, 0, end_bit, r.stream));
             DevBuf<char> temp;
             PGH_TRY(temp.alloc(temp_bytes));
-            PGH_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.p, keys_b.p, vals_a.p, g->val, (int)nnz, 0,
-                                                       end_bit, r.stream));
+            PGH_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (int)nnz, 0, end_bit, r.stream));
+            if (value_free) PGH_TRY(mult_t.alloc(nnz));
+            k_gather_vals<<<blocks_for(nnz), kBlock, 0, r.stream>>>(idx_b.p, d_data.p, value_free ? d_mult.p : nullptr, nnz, g->val,
+                                                                    value_free ? mult_t.p : nullptr);
             k_split_keys<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_b.p, nnz, n_cols, g->col, g->rowptr);
             PGH_HIP(hipGetLastError());
             PGH_HIP(hipStreamSynchronize(r.stream));
-            (void)bits_row;
         } else {
             k_fill_i32<<<blocks_for(n_cols + 1), kBlock, 0, r.stream>>>(g->rowptr, n_cols + 1, 0);
             PGH_HIP(hipGetLastError());
@@ -226,7 +314,22 @@ extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, c
         const char* fmt = getenv("PGH_FORMAT");
         if (fmt == nullptr || std::string(fmt) != "csr") {
             const char* rl = getenv("PGH_RELABEL");
-            PGH_TRY(bsf_build(g, g->val, nullptr, nullptr, nullptr, rl == nullptr || atoi(rl) != 0));
+            const bool relabel = rl == nullptr || atoi(rl) != 0;
+            if (value_free) {
+                // M^T = diag(right) * W^T * diag(left): the source scale is `left` (rows of M), the output scale `right`
+                if (left) {
+                    PGH_HIP(hipMalloc(&g->keep_src, sizeof(float) * (size_t)n_rows));
+                    k_f64_to_f32_g<<<blocks_for(n_rows), kBlock, 0, r.stream>>>(d_left.p, g->keep_src, n_rows);
+                }
+                if (right) {
+                    PGH_HIP(hipMalloc(&g->keep_dst, sizeof(float) * (size_t)n_cols));
+                    k_f64_to_f32_g<<<blocks_for(n_cols), kBlock, 0, r.stream>>>(d_right.p, g->keep_dst, n_cols);
+                }
+                g->keep_mult = mult_t.release();
+                PGH_TRY(bsf_build(g, nullptr, g->keep_mult, g->keep_src, g->keep_dst, relabel));
+            } else {
+                PGH_TRY(bsf_build(g, g->val, nullptr, nullptr, nullptr, relabel));
+            }
         }
         return 0;
     }();
@@ -237,6 +340,21 @@ extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, c
     }
     *out = g;
     return 0;
+}
+
+}  // namespace
+
+extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                                  const int32_t* indices, const double* data, int flags, pgh_graph_t* out) {
+    (void)flags;
+    return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, data, false, nullptr, nullptr, out);
+}
+
+extern "C" int pgh_graph_from_factored_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                                           const int32_t* indices, const double* weights, const double* left,
+                                           const double* right, int flags, pgh_graph_t* out) {
+    (void)flags;
+    return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, weights, true, left, right, out);
 }
 
 extern "C" int pgh_graph_destroy(pgh_graph_t g) {

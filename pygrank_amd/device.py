@@ -319,6 +319,11 @@ class DeviceGraph:
     def from_scipy(M):
         import scipy.sparse as sp
         L.ensure_init()
+        factors = getattr(M, "_pgh_factors", None)
+        if factors is not None:
+            W, left, right = factors
+            if W.format == "csr" and W.nnz == M.nnz and np.array_equal(W.indptr, M.indptr) and np.array_equal(W.indices, M.indices):
+                return DeviceGraph.from_factored(W, left, right)
         M = sp.csr_array(M) if not sp.issparse(M) or M.format != "csr" else M
         indptr = np.ascontiguousarray(M.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(M.indices, dtype=np.int32)
@@ -327,6 +332,25 @@ class DeviceGraph:
         L.check(L.lib().pgh_graph_from_csr(M.shape[0], M.shape[1], len(data), _ptr(indptr), _ptr(indices), _ptr(data),
                                            0, C.byref(h)))
         return DeviceGraph(h, M.shape, len(data))
+
+    @staticmethod
+    def from_factored(W, left=None, right=None):
+        """M = diag(left) W diag(right) evaluated on the device (include/pgh.h pgh_graph_from_factored_csr)."""
+        import scipy.sparse as sp
+        L.ensure_init()
+        W = sp.csr_array(W) if not sp.issparse(W) or W.format != "csr" else W
+        indptr = np.ascontiguousarray(W.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(W.indices, dtype=np.int32)
+        data = np.ascontiguousarray(W.data, dtype=np.float64)
+        left = None if left is None else np.ascontiguousarray(left, dtype=np.float64)
+        right = None if right is None else np.ascontiguousarray(right, dtype=np.float64)
+        if (left is not None and len(left) != W.shape[0]) or (right is not None and len(right) != W.shape[1]):
+            raise L.EngineError("from_factored: scale vector length does not match the matrix")
+        h = L.c_graph()
+        L.check(L.lib().pgh_graph_from_factored_csr(W.shape[0], W.shape[1], len(data), _ptr(indptr), _ptr(indices), _ptr(data),
+                                                    None if left is None else _ptr(left), None if right is None else _ptr(right),
+                                                    0, C.byref(h)))
+        return DeviceGraph(h, W.shape, len(data))
 
     def __del__(self):
         try:

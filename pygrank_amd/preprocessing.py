@@ -76,6 +76,19 @@ def _scaling(v, shape):
     return sp.spdiags(v, 0, *shape, format="csr").tocsr()
 
 
+def _with_factors(N, W, left, right):
+    """Remember N = diag(left) W diag(right): the upload (DeviceGraph.from_scipy) hands the factors to the engine, which
+    stores the 4 B/edge value-free layout when W holds small integer weights (include/pgh.h pgh_graph_from_factored_csr)."""
+    N = sp.csr_array(N)
+    if N.nnz == W.nnz and N.shape == W.shape:               # no entry vanished: same structure
+        N.sort_indices()                                    # (scipy's product emits each row in reverse order)
+        if not W.has_sorted_indices:
+            W = W.copy()
+            W.sort_indices()
+        N._pgh_factors = (W, left, right)
+    return N
+
+
 def normalize_adjacency(M, normalization, reduction=None):
     """The host normalisations of preprocessing.py:109-142 on a scipy CSR matrix."""
     left_reduction = _row_sums if reduction is None else reduction
@@ -84,12 +97,14 @@ def normalize_adjacency(M, normalization, reduction=None):
         return left_reduction(x.T)
 
     if normalization == "col":                              # preprocessing.py:109-113
-        return _scaling(_inv_nonzero(left_reduction(M)), M.shape) @ M
+        left = _inv_nonzero(left_reduction(M))
+        return _with_factors(_scaling(left, M.shape) @ M, M, left, None)
     if normalization == "symmetric":                        # preprocessing.py:131-138
-        return _scaling(_inv_nonzero(left_reduction(M), True), M.shape) @ M @ \
-            _scaling(_inv_nonzero(right_reduction(M), True), M.shape)
+        left, right = _inv_nonzero(left_reduction(M), True), _inv_nonzero(right_reduction(M), True)
+        return _with_factors(_scaling(left, M.shape) @ M @ _scaling(right, M.shape), M, left, right)
     if normalization == "both":                             # preprocessing.py:123-130
-        return _scaling(_inv_nonzero(left_reduction(M)), M.shape) @ M @ _scaling(_inv_nonzero(right_reduction(M)), M.shape)
+        left, right = _inv_nonzero(left_reduction(M)), _inv_nonzero(right_reduction(M))
+        return _with_factors(_scaling(left, M.shape) @ M @ _scaling(right, M.shape), M, left, right)
     if normalization == "laplacian":                        # preprocessing.py:114-122
         M = _scaling(_inv_nonzero(left_reduction(M), True), M.shape) @ M @ \
             _scaling(_inv_nonzero(right_reduction(M), True), M.shape)
@@ -129,7 +144,8 @@ def to_sparse_matrix(G, normalization="auto", weight="weight", renormalize=False
     renormalize = float(renormalize)
     if renormalize != 0:                                    # preprocessing.py:107-108
         M = M + sp.eye(M.shape[0]).tocsr() * renormalize
-    M = sp.csr_array(normalize_adjacency(M, normalization, reduction))
+    M = normalize_adjacency(M, normalization, reduction)
+    M = M if isinstance(M, sp.csr_array) else sp.csr_array(M)
     M = transform_adjacency(M)                              # preprocessing.py:143
     ret = Adjacency(backend.scipy_sparse_to_backend(M))     # preprocessing.py:144-145: upload to HBM
     if cors:                                                # preprocessing.py:146-148

@@ -262,4 +262,66 @@ def check_multi_seed_spmm_and_batched_pagerank(pg):
     assert len(set(i for k, i in enumerate(iters) if k != 3)) > 1, iters   # the columns really stop at different iterations
 
 
+def check_factored_upload_matches_valued_upload(pg):
+    """pgh_graph_from_factored_csr(W, left, right) stores the same matrix as pgh_graph_from_csr(diag(left) W diag(right)):
+    bit-identical f32 values / degrees, and the same propagation results whether the engine picked the value-free
+    layout (integer multi-edge weights) or the valued one (real weights)."""
+    from pygrank_amd.device import DeviceGraph
+    from pygrank_amd.preprocessing import normalize_adjacency
+    rng = np.random.default_rng(11)
+    cases = []
+    A = rmat_np.rmat_csr(13, 8, seed=3)                             # integer multiplicities, dangling + empty rows
+    cases.append(("rmat13_int", A))
+    cases.append(("rmat13_sym", sp.csr_array(A + A.T)))
+    B = _random_matrix(rng, 2000, 2000, 0.004, hubs=3, empty_frac=0.2)
+    cases.append(("real_weights", B))
+    C = sp.csr_array(_random_matrix(rng, 300, 500, 0.05))
+    C.data[:] = 1.0
+    cases.append(("rect_unit", C))
+    big = sp.csr_array(A.copy())
+    big.data[::7] = 40000.0                                         # multiplicity too large to expand: valued layout
+    cases.append(("heavy_int", big))
+    for name, W in cases:
+        for norm in ("col", "symmetric", "both", "none"):
+            if norm != "none" and W.shape[0] != W.shape[1]:
+                continue                                            # the reference's normalisations are square-only
+            N = normalize_adjacency(W, norm)
+            if norm == "none":
+                gf = DeviceGraph.from_factored(W)
+            else:
+                assert hasattr(N, "_pgh_factors"), (name, norm)
+                gf = pg.scipy_sparse_to_backend(N)                  # routed through the factors
+                if name.startswith("rmat13"):
+                    assert "value-free" in gf.format() or "host" in gf.format(), gf.format()
+            plain = sp.csr_array((N.data.copy(), N.indices.copy(), N.indptr.copy()), shape=N.shape)
+            gv = pg.scipy_sparse_to_backend(plain)                  # valued upload of the host-evaluated product
+            a, b = gf.download_transposed(), gv.download_transposed()
+            assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices), (name, norm)
+            assert np.array_equal(a.data, b.data), (name, norm, float(np.max(np.abs(a.data - b.data))))
+            assert np.allclose(_np(pg.degrees(gf)), _np(pg.degrees(gv)), rtol=EPS32, atol=0), (name, norm)
+            x = rng.random(W.shape[0]).astype(F32).astype(np.float64)
+            yf, yv = _np(pg.conv(_vec(pg, x), gf)), _np(pg.conv(_vec(pg, x), gv))
+            scale = np.abs(x) @ np.abs(sp.csr_array(N))
+            assert np.all(np.abs(yf - yv) <= 6 * EPS32 * scale + 1e-30), (name, norm)
+    # rectangular with explicit scales on both sides
+    left, right = rng.random(C.shape[0]) + 0.5, rng.random(C.shape[1]) + 0.5
+    gf = DeviceGraph.from_factored(C, left, right)
+    N = sp.csr_array(sp.diags(left) @ C @ sp.diags(right))
+    gv = pg.scipy_sparse_to_backend(N)
+    assert np.array_equal(gf.download_transposed().data, gv.download_transposed().data)
+    x = rng.random(C.shape[0]).astype(F32).astype(np.float64)
+    yf, yv = _np(pg.conv(_vec(pg, x), gf)), _np(pg.conv(_vec(pg, x), gv))
+    assert yf.shape == (C.shape[1],) and np.all(np.abs(yf - yv) <= 6 * EPS32 * (np.abs(x) @ np.abs(N)) + 1e-30)
+    # end to end through the preprocessor: PageRank on the multigraph equals the oracle
+    from oracle import ref_loops as orc
+    graph = pg.AdjacencyWrapper(A, directed=True)
+    p = np.zeros(A.shape[0])
+    p[rmat_np.seed_nodes(A, 50, seed=4)] = 1.0
+    ranker = pg.PageRank(0.85, error_type=pg.L1, tol=1e-6, max_iters=500)
+    got = np.asarray(ranker.rank(graph, p).np)
+    want, it = orc.pagerank(sp.csr_array(orc.normalize(A, "col", True)), p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=500)
+    assert ranker.last_loop["iterations"] == it
+    assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
+
+
 ALL = [v for k, v in sorted(globals().items()) if k.startswith("check_") and callable(v)]
