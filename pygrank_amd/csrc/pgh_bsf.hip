@@ -228,6 +228,21 @@ __global__ void k_permute_in(const float* __restrict__ src, const int32_t* __res
     }
 }
 
+// personalization and start vector of a recursive loop in one pass over the permutation (square, relabelled graphs):
+// v_int = v[perm], y0 = ranks[perm], xg = ranks[perm] * src_scale
+__global__ void k_permute_in_pair(const float* __restrict__ v, const float* __restrict__ ranks, const int32_t* __restrict__ perm,
+                                  const float* __restrict__ scale, int64_t n_pad, float* __restrict__ v_int, float* __restrict__ y0,
+                                  float* __restrict__ xg) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = perm[i];
+        const float a = o >= 0 ? v[o] : 0.f;
+        const float b = o >= 0 ? ranks[o] : 0.f;
+        v_int[i] = a;
+        y0[i] = b;
+        if (xg) xg[i] = scale ? b * scale[i] : b;
+    }
+}
+
 __global__ void k_permute_out(const float* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_pad, int64_t n_valid,
                               float factor, float* __restrict__ dst) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
@@ -568,6 +583,19 @@ int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale,
     BsfFormat& f = g->bsf;
     k_permute_in<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(src, f.perm, prescale ? f.src_scale : nullptr, f.n_src_pad,
                                                                     f.n_src, hole, dst);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+// recursive loops on square relabelled graphs: both loop operands (and the scaled gather vector) in one launch
+bool bsf_can_bring_pair(const pgh_graph_s* g) {
+    const BsfFormat& f = g->bsf;
+    return f.enabled && f.relabelled && f.perm != nullptr && f.n_out == f.n_src_pad;
+}
+int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg) {
+    BsfFormat& f = g->bsf;
+    k_permute_in_pair<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(v, ranks, f.perm, f.src_scale, f.n_src_pad, v_int, y0,
+                                                                          want_xg ? f.xg : nullptr);
     PGH_HIP(hipGetLastError());
     return 0;
 }

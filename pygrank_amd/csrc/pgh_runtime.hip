@@ -5,6 +5,8 @@
 // pygrank/measures/supervised.py:93-106,133-138.  All of these are HBM-bound streaming kernels:
 // 16-byte loads per lane, 64-wide wavefront shuffles for reductions, f64 accumulators.
 #include "pgh_common.h"
+#include <unordered_map>
+#include <map>
 
 #include <mutex>
 #include <vector>
@@ -85,10 +87,83 @@ extern "C" int pgh_init(int device_ordinal) {
     return 0;
 }
 
+namespace {
+struct DevicePool {
+    std::multimap<size_t, void*> idle;          // size -> block
+    std::unordered_map<void*, size_t> live;     // block -> size
+    size_t idle_bytes = 0;
+    size_t cap_bytes = 0;
+};
+DevicePool g_dev_pool;
+}  // namespace
+
+namespace pgh {
+void pool_trim() {
+    DevicePool& P = g_dev_pool;
+    if (P.idle.empty()) return;
+    (void)hipStreamSynchronize(rt().stream);
+    for (auto& kv : P.idle) (void)hipFree(kv.second);
+    P.idle.clear();
+    P.idle_bytes = 0;
+}
+
+int pool_alloc(size_t bytes, void** out) {
+    DevicePool& P = g_dev_pool;
+    if (bytes == 0) bytes = 4;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = P.idle.find(bytes);
+    if (it != P.idle.end()) {
+        *out = it->second;
+        P.idle_bytes -= bytes;
+        P.idle.erase(it);
+        P.live[*out] = bytes;
+        return 0;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pool_trim();
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) return fail(std::string("device allocation of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+    P.live[p] = bytes;
+    *out = p;
+    return 0;
+}
+
+void pool_free(void* p) {
+    if (p == nullptr) return;
+    DevicePool& P = g_dev_pool;
+    auto it = P.live.find(p);
+    if (it == P.live.end()) {                  // not ours (should not happen): plain free
+        (void)hipStreamSynchronize(rt().stream);
+        (void)hipFree(p);
+        return;
+    }
+    const size_t bytes = it->second;
+    P.live.erase(it);
+    if (P.cap_bytes == 0) {
+        const char* e = getenv("PGH_POOL_MB");
+        P.cap_bytes = (size_t)(e ? atoll(e) : 16384) << 20;
+        if (P.cap_bytes == 0) P.cap_bytes = 1;
+    }
+    if (P.idle_bytes + bytes > P.cap_bytes) pool_trim();
+    if (bytes > P.cap_bytes) {
+        (void)hipStreamSynchronize(rt().stream);
+        (void)hipFree(p);
+        return;
+    }
+    P.idle.emplace(bytes, p);
+    P.idle_bytes += bytes;
+}
+}  // namespace pgh
+
 extern "C" int pgh_shutdown(void) {
     Runtime& r = rt();
     if (!r.initialised) return 0;
     (void)hipStreamSynchronize(r.stream);
+    pool_trim();
     (void)hipFree(r.d_partials);
     (void)hipFree(r.d_scalars);
     (void)hipHostFree(r.h_scalars);
@@ -330,10 +405,9 @@ extern "C" int pgh_vec_alloc(int64_t n, pgh_vec_t* out) {
     v->n = n;
     v->owns = true;
     size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(float);
-    hipError_t e = hipMalloc(&v->data, bytes);
-    if (e != hipSuccess) {
+    if (pool_alloc(bytes, (void**)&v->data) != 0) {
         delete v;
-        return fail(std::string("pgh_vec_alloc: hipMalloc failed: ") + hipGetErrorString(e));
+        return -1;
     }
     *out = v;
     return 0;
@@ -352,11 +426,7 @@ extern "C" int pgh_vec_wrap(void* device_ptr, int64_t n, pgh_vec_t* out) {
 
 extern "C" int pgh_vec_free(pgh_vec_t v) {
     if (!v) return 0;
-    if (v->owns && v->data) {
-        // frees are stream-ordered by synchronising only when work may be in flight on this buffer
-        (void)hipStreamSynchronize(rt().stream);
-        (void)hipFree(v->data);
-    }
+    if (v->owns && v->data) pool_free(v->data);      // stream-ordered reuse, no device synchronisation
     delete v;
     return 0;
 }
@@ -376,12 +446,12 @@ extern "C" int pgh_vec_h2d_f64(pgh_vec_t v, const double* host, int64_t n) {
     PGH_CHECK(v && n == v->n, "pgh_vec_h2d_f64: length mismatch");
     if (n == 0) return 0;
     double* staging = nullptr;
-    PGH_HIP(hipMalloc(&staging, sizeof(double) * n));
+    PGH_TRY(pool_alloc(sizeof(double) * n, (void**)&staging));
     PGH_HIP(hipMemcpyAsync(staging, host, sizeof(double) * n, hipMemcpyHostToDevice, rt().stream));
     k_f64_to_f32<<<grid_for(n), kBlock, 0, rt().stream>>>(staging, v->data, n);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(rt().stream));
-    PGH_HIP(hipFree(staging));
+    pool_free(staging);
     return 0;
 }
 
@@ -397,12 +467,12 @@ extern "C" int pgh_vec_d2h_f64(pgh_vec_t v, double* host, int64_t n) {
     PGH_CHECK(v && n == v->n, "pgh_vec_d2h_f64: length mismatch");
     if (n == 0) return 0;
     double* staging = nullptr;
-    PGH_HIP(hipMalloc(&staging, sizeof(double) * n));
+    PGH_TRY(pool_alloc(sizeof(double) * n, (void**)&staging));
     k_f32_to_f64<<<grid_for(n), kBlock, 0, rt().stream>>>(v->data, staging, n);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipMemcpyAsync(host, staging, sizeof(double) * n, hipMemcpyDeviceToHost, rt().stream));
     PGH_HIP(hipStreamSynchronize(rt().stream));
-    PGH_HIP(hipFree(staging));
+    pool_free(staging);
     return 0;
 }
 
@@ -678,18 +748,16 @@ extern "C" int pgh_mat_alloc(int64_t n, int32_t b, pgh_mat_t* out) {
     m->n = n;
     m->b = b;
     size_t bytes = sizeof(float) * (size_t)(n > 0 ? n : 1) * (size_t)b;
-    hipError_t e = hipMalloc(&m->data, bytes);
-    if (e != hipSuccess) {
+    if (pool_alloc(bytes, (void**)&m->data) != 0) {
         delete m;
-        return fail(std::string("pgh_mat_alloc: hipMalloc failed: ") + hipGetErrorString(e));
+        return -1;
     }
     *out = m;
     return 0;
 }
 extern "C" int pgh_mat_free(pgh_mat_t m) {
     if (!m) return 0;
-    (void)hipStreamSynchronize(rt().stream);
-    (void)hipFree(m->data);
+    pool_free(m->data);
     delete m;
     return 0;
 }
@@ -706,12 +774,12 @@ extern "C" int pgh_mat_h2d_f64(pgh_mat_t m, const double* host) {
     const int64_t total = m->n * m->b;
     if (total == 0) return 0;
     double* staging = nullptr;
-    PGH_HIP(hipMalloc(&staging, sizeof(double) * total));
+    PGH_TRY(pool_alloc(sizeof(double) * total, (void**)&staging));
     PGH_HIP(hipMemcpyAsync(staging, host, sizeof(double) * total, hipMemcpyHostToDevice, rt().stream));
     k_f64_to_f32<<<grid_for(total), kBlock, 0, rt().stream>>>(staging, m->data, total);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(rt().stream));
-    PGH_HIP(hipFree(staging));
+    pool_free(staging);
     return 0;
 }
 extern "C" int pgh_mat_d2h_f64(pgh_mat_t m, double* host) {
@@ -719,12 +787,12 @@ extern "C" int pgh_mat_d2h_f64(pgh_mat_t m, double* host) {
     const int64_t total = m->n * m->b;
     if (total == 0) return 0;
     double* staging = nullptr;
-    PGH_HIP(hipMalloc(&staging, sizeof(double) * total));
+    PGH_TRY(pool_alloc(sizeof(double) * total, (void**)&staging));
     k_f32_to_f64<<<grid_for(total), kBlock, 0, rt().stream>>>(m->data, staging, total);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipMemcpyAsync(host, staging, sizeof(double) * total, hipMemcpyDeviceToHost, rt().stream));
     PGH_HIP(hipStreamSynchronize(rt().stream));
-    PGH_HIP(hipFree(staging));
+    pool_free(staging);
     return 0;
 }
 extern "C" int pgh_mat_set_col(pgh_mat_t m, int32_t col, pgh_vec_t v) {

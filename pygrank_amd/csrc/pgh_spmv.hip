@@ -20,6 +20,7 @@
 //     block-partial sum(y) / residual run in the same pass, so one propagation step reads the matrix once
 //     and every dense vector once: 8*nnz + 16*n bytes for the PageRank step.
 #include "pgh_kernels.h"
+#include <chrono>
 
 #include <vector>
 
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(WG) void k_step_residual(const float* __restrict__ 
 __global__ __launch_bounds__(WG) void k_step_close(LoopState* __restrict__ state, const double* __restrict__ partial_sum,
                                                     int num_sum, const double* __restrict__ res_partials, int num_res,
                                                     int use_quotient, int check, int err_kind, double tol, int64_t n,
-                                                    double* __restrict__ scalars_out) {
+                                                    double* __restrict__ scalars_out, int* __restrict__ progress = nullptr) {
     __shared__ double s_red[4];
     if (state->done) return;
     const double S = fold_partials(partial_sum, num_sum, 0, s_red);
@@ -286,6 +287,10 @@ __global__ __launch_bounds__(WG) void k_step_close(LoopState* __restrict__ state
         if (scalars_out != nullptr) {
             scalars_out[1] = S;
             scalars_out[2] = err;
+        }
+        if (progress != nullptr) {      // host-visible progress word (pinned, mapped): lets the host run ahead without syncs
+            __hip_atomic_store(progress + 1, state->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(progress, state->steps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -403,10 +408,26 @@ int residual_grid(int64_t n) {
 LoopState* g_state = nullptr;
 LoopState* g_state_host = nullptr;
 
+// Host-visible progress of the device loop: {steps executed, done flag}, written by k_step_close into pinned mapped
+// memory.  The host keeps a window of iterations enqueued ahead of the last step it has seen complete, so the stream
+// never drains between iterations and at most `window` no-op iterations trail the converged one.
+volatile int* g_progress_host = nullptr;
+int* g_progress_dev = nullptr;
+
 int ensure_state() {
     if (g_state) return 0;
     PGH_HIP(hipMalloc(&g_state, sizeof(LoopState)));
     PGH_HIP(hipHostMalloc(&g_state_host, sizeof(LoopState), hipHostMallocDefault));
+    void* hp = nullptr;
+    PGH_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    g_progress_host = (volatile int*)hp;
+    g_progress_host[0] = 0;
+    g_progress_host[1] = 0;
+    void* dp = nullptr;
+    PGH_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+    g_progress_dev = (int*)dp;
+    const char* e = getenv("PGH_POLL");
+    if (e != nullptr && atoi(e) == 0) g_progress_dev = nullptr;      // PGH_POLL=0: batch + sync polling (A/B measurements)
     return 0;
 }
 
@@ -416,6 +437,41 @@ int fetch_state() {
     return 0;
 }
 
+// Call with the previous loop complete (every run ends with fetch_state()).
+void progress_reset() {
+    g_progress_host[0] = 0;
+    g_progress_host[1] = 0;
+}
+
+// Blocks until fewer than `window` enqueued steps are outstanding or the loop has finished.  Falls back to a real
+// synchronisation if the progress word does not move for 100 ms (never observed; keeps a lost update from hanging).
+int progress_wait(int enqueued, int window, bool* done) {
+    using clk = std::chrono::steady_clock;
+    clk::time_point t0 = clk::now();
+    int last = g_progress_host[0];
+    int spins = 0;
+    for (;;) {
+        const int d = g_progress_host[1];
+        const int s = g_progress_host[0];
+        if (d) {
+            *done = true;
+            return 0;
+        }
+        if (enqueued - s < window) return 0;
+        if (s != last) {
+            last = s;
+            t0 = clk::now();
+        }
+        if ((++spins & 1023) == 0 && std::chrono::duration<double>(clk::now() - t0).count() > 0.1) {
+            PGH_TRY(fetch_state());
+            *done = g_state_host->done != 0;
+            g_progress_host[0] = g_state_host->steps;
+            return 0;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 int fetch_scalars(int first, int count) {
     Runtime& r = rt();
     PGH_HIP(hipMemcpyAsync(r.h_scalars + first, r.d_scalars + first, sizeof(double) * count, hipMemcpyDeviceToHost, r.stream));
@@ -423,39 +479,10 @@ int fetch_scalars(int first, int count) {
     return 0;
 }
 
-// Work vectors of the loops come from a small size-keyed pool: hipMalloc / hipFree synchronise the device and cost
-// 100+ us each, which would otherwise dominate a 5 ms PageRank run (SURVEY.md 7 "Python overhead per iteration").
+// Work vectors of the loops come from the runtime's stream-ordered pool (pgh_common.h pool_alloc).
 struct WorkPool {
-    struct Slot {
-        float*  p;
-        int64_t n;
-        bool    busy;
-    };
-    std::vector<Slot> slots;
-    int acquire(int64_t n, float** out) {
-        for (Slot& s : slots)
-            if (!s.busy && s.n == n) {
-                s.busy = true;
-                *out = s.p;
-                return 0;
-            }
-        if (slots.size() >= 24) {                     // bounded: drop idle buffers of other sizes
-            std::vector<Slot> keep;
-            for (Slot& s : slots) {
-                if (s.busy) keep.push_back(s); else (void)hipFree(s.p);
-            }
-            slots.swap(keep);
-        }
-        float* p = nullptr;
-        PGH_HIP(hipMalloc(&p, sizeof(float) * (size_t)(n > 0 ? n : 1)));
-        slots.push_back({p, n, true});
-        *out = p;
-        return 0;
-    }
-    void release(float* p) {
-        for (Slot& s : slots)
-            if (s.p == p) s.busy = false;
-    }
+    int acquire(int64_t n, float** out) { return pool_alloc(sizeof(float) * (size_t)(n > 0 ? n : 1), (void**)out); }
+    void release(float* p) { pool_free(p); }
 };
 WorkPool g_pool;
 
@@ -651,6 +678,14 @@ int batch_for(pgh_graph_t g) {
     return 16;
 }
 
+// steps kept in flight ahead of the last one seen complete (progress_wait)
+int window_for(pgh_graph_t g) {
+    const double est_us = (8.0 * (double)g->nnz + 16.0 * (double)g->n_cols) / 4.0e6;
+    if (est_us > 200.0) return 2;
+    if (est_us > 20.0) return 4;
+    return 8;
+}
+
 struct LoopTimer {
     hipEvent_t a = nullptr, b = nullptr;
     ~LoopTimer() {
@@ -710,21 +745,31 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     PGH_TRY(timer.start());
     // ---- bring the operands into the internal space
     DevF32 v_buf, deg_buf, lam_buf, y0, y1;
-    PGH_TRY(sp.bring(ep.v, v_buf, &ep.v));
+    const bool scaled_gather = sp.blocked && g->bsf.src_scale != nullptr;
+    const bool pair = sp.blocked && bsf_can_bring_pair(g);
+    float* buf[2] = {ranks->data, nullptr};
+    if (pair) {          // personalization, start vector and scaled gather vector in one pass over the permutation
+        PGH_TRY(v_buf.alloc(n_int));
+        PGH_TRY(y0.alloc(n_int));
+        PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, y0.p, scaled_gather));
+        ep.v = v_buf.p;
+        buf[0] = y0.p;
+    } else {
+        PGH_TRY(sp.bring(ep.v, v_buf, &ep.v));
+    }
     if (MODE == EPI_ABSORB) {
         PGH_TRY(sp.bring(ep.deg, deg_buf, &ep.deg));
         PGH_TRY(sp.bring(ep.lam, lam_buf, &ep.lam, 1.f));      // holes: (0 * 0 + 0 * 1) / (1 + 0) = 0
     }
     PGH_TRY(y1.alloc(n_int));
-    float* buf[2] = {ranks->data, y1.p};
-    if (sp.blocked) {
+    buf[1] = y1.p;
+    if (sp.blocked && !pair) {
         PGH_TRY(y0.alloc(n_int));
         PGH_TRY(bsf_out_to_internal(g, ranks->data, y0.p, 0.f));
         buf[0] = y0.p;
+        if (scaled_gather) PGH_TRY(bsf_to_internal(g, ranks->data, g->bsf.xg, true, 0.f));
     }
-    const bool scaled_gather = sp.blocked && g->bsf.src_scale != nullptr;
     if (scaled_gather) {
-        PGH_TRY(bsf_to_internal(g, ranks->data, g->bsf.xg, true, 0.f));
         ep.xg_out = g->bsf.xg;
         ep.src_scale = g->bsf.src_scale;
     }
@@ -735,10 +780,17 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     // ConvergenceManager.has_converged is evaluated before every step with iteration = step index
     // (convergence.py:85): step k runs iff k < max_iters and the check at iteration k did not fire.
     const int max_steps = cfg->max_iters - 1 > 0 ? cfg->max_iters - 1 : 0;
-    const int batch = batch_for(g);
+    const bool poll = g_progress_dev != nullptr;
+    const int batch = poll ? 1 : batch_for(g);
+    const int window = window_for(g);
+    if (poll) progress_reset();
     int enq = 0;          // steps enqueued so far
     bool done = false;
     while (!done && enq < max_steps) {
+        if (poll) {
+            PGH_TRY(progress_wait(enq, window, &done));
+            if (done) break;
+        }
         const int upto = (enq + batch < max_steps) ? enq + batch : max_steps;
         for (; enq < upto; ++enq) {
             const int k = enq + 1;                        // this is step k; it produces x_k from x_{k-1}
@@ -759,12 +811,14 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             {
                 ProfScope prof(PGH_K_FINAL);
                 k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, pres, rgrid, cfg->use_quotient,
-                                                     check, cfg->err_kind, cfg->tol, n, nullptr);
+                                                     check, cfg->err_kind, cfg->tol, n, nullptr, g_progress_dev);
             }
         }
         PGH_HIP(hipGetLastError());
-        PGH_TRY(fetch_state());
-        done = g_state_host->done != 0;
+        if (!poll) {
+            PGH_TRY(fetch_state());
+            done = g_state_host->done != 0;
+        }
     }
     PGH_TRY(fetch_state());
     const int steps = g_state_host->steps;
@@ -870,7 +924,10 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
     int spmv = 0;
     bool converged = false;
     k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
-    const int batch = batch_for(g);
+    const bool poll = g_progress_dev != nullptr;
+    const int batch = poll ? 1 : batch_for(g);
+    const int window = window_for(g);
+    if (poll) progress_reset();
     // host-side mirror of the reference loop for iteration 2 (uses err of step 1), then device batches
     it = 2;
     bool stop = false;
@@ -885,6 +942,10 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
         int next_it = 2;
         bool done = false;
         while (!done && next_it < max_iters) {
+            if (poll) {
+                PGH_TRY(progress_wait(next_it - 2, window, &done));
+                if (done) break;
+            }
             const int upto = (next_it + batch < max_iters) ? next_it + batch : max_iters;
             for (; next_it < upto; ++next_it) {
                 const int k = next_it;            // iteration index of this step
@@ -909,13 +970,15 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
                 {
                     ProfScope prof(PGH_K_FINAL);
                     k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, r.d_partials + kMaxPartials,
-                                                         count, 0, check, cfg->err_kind, cfg->tol, n, nullptr);
+                                                         count, 0, check, cfg->err_kind, cfg->tol, n, nullptr, g_progress_dev);
                 }
                 term = tout;
             }
             PGH_HIP(hipGetLastError());
-            PGH_TRY(fetch_state());
-            done = g_state_host->done != 0;
+            if (!poll) {
+                PGH_TRY(fetch_state());
+                done = g_state_host->done != 0;
+            }
         }
         PGH_TRY(fetch_state());
         spmv = g_state_host->steps;

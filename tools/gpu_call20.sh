@@ -1,0 +1,10 @@
+#!/bin/bash
+export PYTHONPATH=$GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 300 python tools/probe_latency.py 14 2>&1 | grep latency
+timeout 300 python tools/probe_latency.py 20 2>&1 | grep latency
+for i in 1 2; do
+timeout 300 python bench.py --no-cpu --steps 20 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'], d['config']['device_loop_ms_per_step'], d['roofline']['kernels_avg_us'])"
+done
