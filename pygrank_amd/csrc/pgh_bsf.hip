@@ -128,6 +128,45 @@ __global__ void k_bsf_flags(const uint64_t* __restrict__ keys, int64_t E, uint32
     }
 }
 
+// final pass of the build: digest the entry stream for k_bsf_partial.  Thread = (tile, lane): its 8 column words become
+// block-local byte offsets, their bit-31 flags become one byte.
+struct PackLayout {
+    int tile_begin[9];
+    int num_blocks;
+};
+__global__ void k_bsf_pack(uint32_t* __restrict__ colf, uint32_t* __restrict__ val, PackLayout pl, int num_tiles, int blk,
+                           uint8_t* __restrict__ flags8) {
+    // one WAVEFRONT per tile (blockDim is a multiple of 64): every lane reads its 8 logical words before any lane
+    // writes, so the in-place transposition below is safe
+    const int64_t total = (int64_t)num_tiles * 64;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tile = (int)(i >> 6), lane = (int)(i & 63);
+        int b = 0;
+        while (b + 1 < pl.num_blocks && tile >= pl.tile_begin[b + 1]) ++b;
+        const uint32_t base = (uint32_t)b * (uint32_t)blk;
+        uint32_t* w = colf + i * 8;
+        uint32_t x[8], v[8];
+        unsigned int bits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            x[k] = w[k];
+            if (val) v[k] = val[i * 8 + k];
+            bits |= (x[k] >> 31) << k;
+            x[k] = ((x[k] & 0x7fffffffu) - base) << 2;
+        }
+        flags8[i] = (uint8_t)bits;
+        // physical order inside the tile: [q = k / 4][lane][k % 4], so that the q-th 16-byte load of the 64 lanes
+        // covers one contiguous KB (PGH_TILE_TRANSPOSE = 0 keeps the logical order: lane-contiguous 32 bytes)
+        const int64_t t0 = (int64_t)tile * 512;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t dst = PGH_TILE_TRANSPOSE ? t0 + (k >> 2) * 256 + lane * 4 + (k & 3) : t0 + lane * 8 + k;
+            colf[dst] = x[k];
+            if (val) val[dst] = v[k];
+        }
+    }
+}
+
 // diagnostics (PGH_DEBUG=1): entries whose column falls inside the per-workgroup hot cache
 __global__ void k_bsf_count_hot(const uint32_t* __restrict__ colf, int64_t E, int blk, int hot, unsigned long long* __restrict__ out) {
     unsigned long long local = 0;
@@ -253,7 +292,8 @@ __global__ void k_permute_out(const float* __restrict__ src, const int32_t* __re
 
 // ------------------------------------------------------------------------------------------------- SpMV kernels
 struct BsfView {
-    const uint32_t* colf;
+    const uint32_t* colf;      // packed: byte offset of the source inside its block
+    const uint8_t*  flags8;    // [num_tiles * 64] segment-start flags of each lane's 8 entries
     const float*    val;
     const int32_t*  seg_row;
     const int4*     tile;
@@ -267,6 +307,47 @@ struct BsfView {
     int             tile_begin[9];
 };
 
+// ---- wavefront scans on the DPP crossbar (no LDS traffic): Hillis-Steele inside the 16-lane rows, then the two
+// row broadcasts (lane 15 -> next row on rows 1/3, lane 31 -> rows 2/3) that complete a 64-lane inclusive scan
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+    v += dpp_i32<0x111, 0xf>(0, v);      // row_shr:1
+    v += dpp_i32<0x112, 0xf>(0, v);      // row_shr:2
+    v += dpp_i32<0x114, 0xf>(0, v);      // row_shr:4
+    v += dpp_i32<0x118, 0xf>(0, v);      // row_shr:8
+    v += dpp_i32<0x142, 0xa>(0, v);      // row_bcast:15 -> rows 1, 3
+    v += dpp_i32<0x143, 0xc>(0, v);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// inclusive segmented sum with head flags: keep = 0 on lanes whose value starts a new segment, 1 on lanes that continue
+// the previous lane's segment.  Per step: val += keep * val[l - d]; keep *= keep[l - d]  (lanes without a source read
+// 0 / 1), i.e. two DPP operand fetches, one fma and one multiply.
+__device__ __forceinline__ float wave_segmented_sum(float keep, float val) {
+#define PGH_SEG_STEP(CTRL, MASK)                                   \
+    {                                                              \
+        const float v2 = dpp_f32<CTRL, MASK>(0.f, val);            \
+        const float k2 = dpp_f32<CTRL, MASK>(1.f, keep);           \
+        val = __builtin_fmaf(v2, keep, val);                       \
+        keep *= k2;                                                \
+    }
+    PGH_SEG_STEP(0x111, 0xf)
+    PGH_SEG_STEP(0x112, 0xf)
+    PGH_SEG_STEP(0x114, 0xf)
+    PGH_SEG_STEP(0x118, 0xf)
+    PGH_SEG_STEP(0x142, 0xa)
+    PGH_SEG_STEP(0x143, 0xc)
+#undef PGH_SEG_STEP
+    return val;
+}
+
 // One tile = 64 * IPT consecutive entries of one column block, owned by ONE wavefront: no workgroup barrier is
 // needed inside the tile loop, so the 16 wavefronts of a 1024-thread workgroup (one workgroup per CU) run
 // 16 independent pipelines and hide each other's latency.
@@ -274,25 +355,33 @@ struct BsfView {
 // What the workgroup shares is the HOT CACHE: the first kBsfHot entries of the block's (hot-first ordered)
 // slice of the gather vector, copied into LDS once per launch.  On a power-law graph they serve the bulk of
 // the gathers at LDS speed; only the cold remainder goes through the vector memory pipe, whose divergent-
-// address issue rate (not the L2 hit rate) bounds this kernel (profiles/r01/bsf_v2_probe_scale23.log).
+// address miss rate (not the L2 hit rate) bounds this kernel (profiles/r01/bsf_v2_probe_scale23.log).
 //
-// Every lane owns IPT CONSECUTIVE entries and fetches them with 16-byte non-temporal loads (blocks are padded
-// to whole tiles at build time, so every load is aligned and in range): no LDS transpose, the segment flags
-// (bit 31 of the column words) are lane-local.  Three tiles are in flight per wavefront in registers:
-// column stream of tile t+2, gathers of tile t+1, arithmetic of tile t.  In-tile sums are f32 (a lane adds at
-// most IPT terms, the 64-lane stitch is a log-depth __shfl_up segmented scan); pieces of segments that cross
+// Every lane owns IPT = 8 CONSECUTIVE entries and fetches them with 16-byte non-temporal loads (blocks are padded
+// to whole tiles at build time, so every load is aligned and in range).  The stream is pre-digested at build time
+// (k_bsf_pack) so that the per-entry instruction count is minimal: a column word is the BYTE offset of the source
+// inside its block (LDS address = min(word, 4 * hot); cold buffer offset = word - 4 * hot, which wraps out of range
+// for hot lanes so their load returns 0 without touching memory), and the segment-start flags of a lane's entries
+// come as one byte per lane.  Per entry the arithmetic stage issues 6 vector ALU instructions and one LDS write
+// (PGH_ENTRY below).  Software pipeline per wavefront, two register sets used ping-pong (loop unrolled twice, no
+// register moves): column stream of tile t+2, gathers of tile t+1, arithmetic of tile t.  In-tile sums are f32 (a
+// lane adds at most IPT terms, the 64-lane stitch is a log-depth DPP segmented scan); pieces of segments that cross
 // tiles are carried in f64 and combined in a fixed order by k_bsf_fixup (deterministic, atomic-free).
 template <int IPT, bool HAS_VAL>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
                                                               const LoopState* __restrict__ state) {
-    static_assert(IPT % 4 == 0, "lanes fetch their entries as 16-byte words");
+    static_assert(IPT == 8, "one flag byte per lane; lanes fetch their entries as 16-byte words");
     constexpr int T = 64 * IPT;
     constexpr int WAVES = kBsfThreads / 64;
     constexpr int Q = IPT / 4;
-    __shared__ float s_hot[kBsfHot + 1];                 // + one permanent zero: the slot cold lanes read
-    __shared__ float s_strip[WAVES][T + 64];             // + one scratch slot per lane for predicated-off writes
+    constexpr int STRIP = T + 1 + 64;
+    // LDS: [0, 4 * (kBsfHot + 1)) hot cache + one permanent zero (the slot cold lanes read); then per wavefront a strip:
+    // slot 0 = piece of the segment open at the tile start, slot 1 + j = closed segment j, slot T + 1 + lane = scratch
+    // for predicated-off writes.  One array, so that every LDS address below is an offset from LDS address 0.
+    __shared__ float s_lds[kBsfHot + 1 + WAVES * STRIP];
     if (state != nullptr && state->done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
     const int label = blockIdx.x & 7;
     const int b = label % f.num_blocks;
@@ -302,34 +391,54 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     float* __restrict__ part = f.part + (int64_t)b * f.part_stride;
     const uint32_t base = (uint32_t)(b * f.blk_size);
     const uint32_t hot = (uint32_t)min(kBsfHot, f.blk_size);
-    for (uint32_t i = tid; i < hot; i += kBsfThreads) s_hot[i] = xg[base + i];
-    if (tid == 0) s_hot[hot] = 0.f;
+    const uint32_t hot4 = hot << 2;
+    for (uint32_t i = tid; i < hot; i += kBsfThreads) s_lds[i] = xg[base + i];
+    if (tid == 0) s_lds[hot] = 0.f;
     __syncthreads();
-    float* __restrict__ strip = s_strip[wave];
+    char* __restrict__ lds = reinterpret_cast<char*>(s_lds);
+    const int strip4 = (kBsfHot + 1 + wave * STRIP) << 2;        // byte offset of this wavefront's strip
+    const float* __restrict__ seg = s_lds + (kBsfHot + 1) + wave * STRIP;
     const int t_end = f.tile_begin[b + 1];
-    const __amdgpu_buffer_rsrc_t xg_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg), 0, f.xg_bytes, 0x00020000);
+    // the block's cold slice [hot, blk_size) as a buffer: offsets outside it (every hot lane) read 0
+    const __amdgpu_buffer_rsrc_t cold_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg + base + hot), 0, (int)(((uint32_t)f.blk_size - hot) << 2), 0x00020000);
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     struct Stream {
-        u32x4 c[Q];
-        u32x4 v[Q];
-        int   seg_base;
+        u32x4        c[Q];
+        u32x4        v[Q];
+        int          rel;            // tile index relative to the block's first tile (scalar)
+        int          seg_base;
     };
-    auto load_stream = [&](int tile, Stream& st) {
-        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(f.colf + (int64_t)tile * T + lane * IPT);
+    // The stream is read through buffer descriptors rebased to the block's first tile: the lane part of an address is a
+    // constant VGPR, the tile part a scalar offset (tile indices are wavefront-uniform), so the loop needs no vector
+    // address arithmetic and no address temporaries (a temporary that reuses the destination of an outstanding load
+    // forces a full s_waitcnt vmcnt(0)).  Offsets are 32-bit: a block holds < 2^30 entries (bsf_build checks).
+    const int tb = f.tile_begin[b];
+    const int64_t blk_tiles = (int64_t)(t_end - tb);
+    const auto clamp32 = [](int64_t bytes) { return (int)(bytes > 0xffffffffLL ? 0xffffffffLL : bytes); };
+    const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(f.colf + (int64_t)tb * T), 0, clamp32(blk_tiles * T * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(HAS_VAL ? f.val + (int64_t)tb * T : nullptr), 0, HAS_VAL ? clamp32(blk_tiles * T * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t flag_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(f.flags8 + (int64_t)tb * 64), 0, clamp32(blk_tiles * 64), 0x00020000);
+    const int lane32 = PGH_TILE_TRANSPOSE ? lane * 16 : lane * (IPT * 4);
+    constexpr int kQStep = PGH_TILE_TRANSPOSE ? 1024 : 16;
+    constexpr int kNT = PGH_STREAM_AUX;                    // buffer aux: 2 = non-temporal (streamed once per launch)
+    auto load_stream = [&](int tile, Stream& st) __attribute__((always_inline)) {
+        const int rel = tile - tb;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) st.c[q] = __builtin_nontemporal_load(src + q);
+        for (int q = 0; q < Q; ++q) st.c[q] = __builtin_amdgcn_raw_buffer_load_b128(col_rsrc, lane32 + kQStep * q, rel * (T * 4), kNT);
         if (HAS_VAL) {
-            const u32x4* __restrict__ vs = reinterpret_cast<const u32x4*>(f.val + (int64_t)tile * T + lane * IPT);
 #pragma unroll
-            for (int q = 0; q < Q; ++q) st.v[q] = __builtin_nontemporal_load(vs + q);
+            for (int q = 0; q < Q; ++q) st.v[q] = __builtin_amdgcn_raw_buffer_load_b128(val_rsrc, lane32 + kQStep * q, rel * (T * 4), kNT);
         }
+        st.rel = rel;
         st.seg_base = f.tile[tile].z;
     };
     // gather stage: issue the LDS read and the buffer load of every entry WITHOUT consuming them (they are summed one
-    // tile later, in the arithmetic stage), so both stay in flight across the loop back-edge.  Hot lanes push their
-    // buffer offset out of range (the load returns 0 without touching memory); cold lanes read the zero slot of the
-    // hot cache: value = h + c, no select.
+    // tile later, in the arithmetic stage), so both stay in flight across the loop back-edge.  value = h + c, no select.
     struct Gathered {
         float        h[IPT];
         float        c[IPT];
@@ -338,120 +447,123 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         int          row0, row1;     // output rows of the tile's first 128 closed segments (prefetched)
         int          seg_base;
     };
-    auto gather = [&](const Stream& st, Gathered& g) {
-        unsigned int bits = 0;
+    auto gather = [&](const Stream& st, Gathered& g) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
             const uint32_t w = st.c[k >> 2][k & 3];
-            bits |= (w >> 31) << k;
-            const uint32_t c = w & 0x7fffffffu;
-            const uint32_t loc = c - base;
-#if PGH_PROBE_GATHER == 3
-            g.h[k] = (float)(c & 0xffffu);
+#if PGH_PROBE_GATHER == 6        // everything from the hot cache: the kernel without vector-memory gathers
+            g.h[k] = *reinterpret_cast<const float*>(lds + (w % hot4 & ~3u));
             g.c[k] = 0.f;
-#elif PGH_PROBE_GATHER == 6
-            g.h[k] = s_hot[loc % hot];
+#elif PGH_PROBE_GATHER == 8      // no gathers at all: the stream, the arithmetic and the output stage
+            g.h[k] = __uint_as_float(w & 0xffffu);
             g.c[k] = 0.f;
-#elif PGH_PROBE_GATHER == 7      // every buffer load out of range: cost of issuing the (dropped) loads
-            g.h[k] = s_hot[loc % hot];
-            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, 0xfffffff0u, 0, 0));
 #else
-            g.h[k] = s_hot[min(loc, hot)];
-            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xg_rsrc, loc < hot ? 0xfffffff0u : c << 2, 0, PGH_COLD_AUX));
+            g.h[k] = *reinterpret_cast<const float*>(lds + min(w, hot4));
+            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cold_rsrc, w - hot4, 0, PGH_COLD_AUX));
 #endif
             if (HAS_VAL) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
         }
-        g.bits = bits;
+        g.bits = __builtin_amdgcn_raw_buffer_load_b8(flag_rsrc, lane, st.rel * 64, 0);
         g.seg_base = st.seg_base;
+#if PGH_PROBE_SKIP & 1           // diagnostic: no output stage
+        g.row0 = g.row1 = -1;
+#else
         const int32_t* __restrict__ rows = f.seg_row + st.seg_base + 1;   // reads past the tile's segments are harmless
         g.row0 = rows[lane];
         g.row1 = rows[64 + lane];
+#endif
+    };
+    const int scr4 = strip4 + ((T + 1 + lane) << 2);
+    // arithmetic of one tile: lane-local flags, branch-free f32 segmented sum
+    auto reduce = [&](const Gathered& g0, int t) __attribute__((always_inline)) {
+        const int bits = (int)g0.bits;
+        const int mine = __popc(g0.bits);
+        const int incl = wave_inclusive_sum(mine);        // flags in lanes <= this one
+        const int before = incl - mine;
+        const int closed = __builtin_amdgcn_readlane(incl, 63) - 1;      // segments that start and end inside the tile
+        // The j-th flag of the tile (j = before + #flags below entry k) opens segment j and closes segment j - 1: the
+        // running sum goes to slot j (slot 0 = the segment that was open when the tile started).  A lane's first flag
+        // closes a segment that may have begun in earlier lanes; their contribution is added after the stitch below.
+        // Writes of entries without a flag are steered to the lane's scratch slot instead of being branched around.
+        const int slot0 = strip4 + (before << 2);
+        int o4 = slot0;
+        int accb = 0;
+        // per entry: m = flag ? -1 : 0; address = flag ? o4 : scratch; store acc; o4 += 4 * flag; acc = flag ? 0 : acc
+#define PGH_ENTRY(K)                                                                                   \
+        {                                                                                              \
+            int m, a;                                                                                  \
+            asm("v_bfe_i32 %0, %1, " #K ", 1" : "=v"(m) : "v"(bits));                                  \
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(a) : "v"(m), "v"(o4), "v"(scr4));                    \
+            if (!(PGH_PROBE_SKIP & 2) || K == 7) *reinterpret_cast<int*>(lds + a) = accb;              \
+            asm("v_mad_i32_i24 %0, %1, -4, %2" : "=v"(o4) : "v"(m), "v"(o4));                          \
+            asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(accb) : "v"(m), "v"(accb));                           \
+            float xv = g0.h[K] + g0.c[K];                                                              \
+            if (HAS_VAL) xv *= g0.v[K];                                                                \
+            accb = __builtin_bit_cast(int, __builtin_bit_cast(float, accb) + xv);                      \
+        }
+        PGH_ENTRY(0) PGH_ENTRY(1) PGH_ENTRY(2) PGH_ENTRY(3) PGH_ENTRY(4) PGH_ENTRY(5) PGH_ENTRY(6) PGH_ENTRY(7)
+#undef PGH_ENTRY
+        // ---- stitch segments that cross lane boundaries: the sum after a lane's last flag continues into the next
+        // lane unless that lane starts with ... any flag of its own (head flag = lane has a flag)
+        const float acc = __builtin_bit_cast(float, accb);
+        const float val = wave_segmented_sum(mine ? 0.f : 1.f, acc);
+        const float ev = dpp_f32<0x138, 0xf>(0.f, val);   // wave_shr:1: what the earlier lanes hold of the segment this
+        if (bits != 0) {                                  // lane's first flag closes (lane l-1 ends in segment before-1)
+            float* slot = reinterpret_cast<float*>(lds + slot0);
+            *slot += ev;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#if !(PGH_PROBE_SKIP & 4)
+        if (lane == 0 && closed >= 0) f.head_partial[t] = (double)seg[0];   // the segment that was open at the tile start
+        if (lane == 63) f.tail_carry[t] = (double)val;    // piece of the segment still open at the end of the tile
+#else
+        if (val == 123.456f) f.tail_carry[t] = 0.0;
+#endif
+        // ---- closed segments -> block partial vector (rows prefetched for the first 128; rare long tail below)
+        if (lane < closed && g0.row0 >= 0) part[g0.row0] = seg[1 + lane];
+        if (64 + lane < closed && g0.row1 >= 0) part[g0.row1] = seg[65 + lane];
+        if (closed > 128) {
+            const int32_t* __restrict__ rows = f.seg_row + g0.seg_base + 1;
+            for (int j = 128 + lane; j < closed; j += 64) {
+                const int row = rows[j];
+                if (row >= 0) part[row] = seg[1 + j];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
 
     int t = f.tile_begin[b] + rank;
     if (t >= t_end) return;
     // The pipeline issues its loads UNCONDITIONALLY (tile indices are clamped to the block's last tile; the clamped
     // results are never consumed): a fixed number of vector-memory operations per iteration lets the compiler emit
-    // counted s_waitcnt vmcnt(N) instead of draining the queue.  In flight per wavefront: the column stream of tiles
-    // t+2 and t+3, the gathers of tile t+1, the arithmetic of tile t.
+    // counted s_waitcnt vmcnt(N) instead of draining the queue.  In flight per wavefront at iteration i: the column
+    // streams of tiles i+2 and i+3 (what bounds the kernel without gathers is bytes in flight x latency, so the stream
+    // runs two tiles ahead), the gathers of tile i+1, the arithmetic of tile i.  Three stream register sets and two
+    // gather sets rotate without moves: the loop is unrolled six times.
     const int t_last = t_end - 1;
-    Stream s1, s2, s3;
+    Stream s0, s1, s2;
     Gathered g0, g1;
-    load_stream(t, s1);
-    gather(s1, g0);
+    load_stream(t, s0);
+    gather(s0, g0);
     load_stream(min(t + stride, t_last), s1);
     load_stream(min(t + 2 * stride, t_last), s2);
-    for (; t < t_end; t += stride) {
-        // vmcnt retires in order: the gathers (consumed next iteration) go out BEFORE the stream of tile t+3 (consumed
-        // two iterations later), so waiting for the former leaves the latter in flight
-        gather(s1, g1);
-        load_stream(min(t + 3 * stride, t_last), s3);
-        // ---- arithmetic of tile t: lane-local flags, branch-free f32 segmented sum
-        const unsigned int bits = g0.bits;
-        const int mine = __popc(bits);
-        int incl = mine;                                  // inclusive prefix of the per-lane flag counts
-#pragma unroll
-        for (int o2 = 1; o2 < 64; o2 <<= 1) {
-            const int v2 = __shfl_up(incl, o2, 64);
-            if (lane >= o2) incl += v2;
-        }
-        const int before = incl - mine;
-        const int closed = __shfl(incl, 63, 64) - 1;      // segments that start and end inside the tile
-        // entry k with its flag set opens segment (before + #flags below k) and closes the previous one.  The lane's
-        // first flag closes a segment that may have begun in earlier lanes (finished after the scan below); every
-        // later flag closes a segment that lies inside the lane: its sum goes straight to the strip.  Writes of
-        // entries without a flag are steered to the lane's scratch slot instead of being branched around.
-        const int first_pos = bits ? __builtin_ctz(bits) : 32;
-        float acc = 0.f, first_val = 0.f;
-#pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            const bool flag = (bits >> k) & 1u;
-            const bool is_first = (k == first_pos);
-            const int o = before + __popc(bits & ((1u << k) - 1u));
-            first_val = is_first ? acc : first_val;
-            strip[(flag && !is_first) ? o - 1 : T + lane] = acc;
-            acc = flag ? 0.f : acc;
-            float xv = g0.h[k] + g0.c[k];
-            if (HAS_VAL) xv *= g0.v[k];
-            acc += xv;
-        }
-        // ---- stitch segments that cross lane boundaries (keys are non-decreasing across lanes)
-        const int key = before + mine - 1;                // local index of the segment open at the end of the chunk
-        float val = acc;
-#pragma unroll
-        for (int o2 = 1; o2 < 64; o2 <<= 1) {
-            const int k2 = __shfl_up(key, o2, 64);
-            const float v2 = __shfl_up(val, o2, 64);
-            if (lane >= o2 && k2 == key) val += v2;
-        }
-        const int ek = __shfl_up(key, 1, 64);
-        const float ev = __shfl_up(val, 1, 64);
-        const int closes = before - 1;                    // local index of the segment this lane's first flag closes
-        const float total = first_val + ((lane > 0 && ek == closes) ? ev : 0.f);
-        if (bits != 0u) {
-            if (closes < 0) f.head_partial[t] = (double)total;   // the segment that was open when the tile started
-            else strip[closes] = total;
-        }
-        if (lane == 63) f.tail_carry[t] = (double)val;    // piece of the segment still open at the end of the tile
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- closed segments -> block partial vector (rows prefetched for the first 128; rare long tail below)
-        if (lane < closed && g0.row0 >= 0) part[g0.row0] = strip[lane];
-        if (64 + lane < closed && g0.row1 >= 0) part[g0.row1] = strip[64 + lane];
-        if (closed > 128) {
-            const int32_t* __restrict__ rows = f.seg_row + g0.seg_base + 1;
-            for (int j = 128 + lane; j < closed; j += 64) {
-                const int row = rows[j];
-                if (row >= 0) part[row] = strip[j];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- rotate the register pipeline
-        s1 = s2;
-        s2 = s3;
-        g0 = g1;
+#define PGH_STEP(SL, SG, GN, GC)                             \
+    load_stream(min(t + 3 * stride, t_last), SL);            \
+    gather(SG, GN);                                          \
+    reduce(GC, t);                                           \
+    t += stride;                                             \
+    if (t >= t_end) break;
+    for (;;) {
+        PGH_STEP(s0, s1, g1, g0)
+        PGH_STEP(s1, s2, g0, g1)
+        PGH_STEP(s2, s0, g1, g0)
+        PGH_STEP(s0, s1, g0, g1)
+        PGH_STEP(s1, s2, g1, g0)
+        PGH_STEP(s2, s0, g0, g1)
     }
+#undef PGH_STEP
 }
 
 // segments that cross tiles: fixed-order sum of the carries, one thread per closing tile
@@ -504,6 +616,7 @@ __global__ __launch_bounds__(WG) void k_bsf_combine(const float* __restrict__ pa
 BsfView view_of(const BsfFormat& f) {
     BsfView v;
     v.colf = f.colf;
+    v.flags8 = f.flags8;
     v.val = f.val;
     v.seg_row = f.seg_row;
     v.tile = f.tile;
@@ -620,6 +733,7 @@ int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor)
 
 void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.colf);
+    (void)hipFree(f.flags8);
     (void)hipFree(f.val);
     (void)hipFree(f.seg_row);
     (void)hipFree(f.tile);
@@ -844,6 +958,17 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         fprintf(stderr, "[pgh] bsf: B=%d blk=%d entries=%lld (padded %lld) segs=%lld tiles=%d hot=%d covers %.1f%% of entries, value-free=%d relabel=%d\n",
                 B, blk, (long long)E, (long long)EP, (long long)f.num_segs, f.num_tiles, kBsfHot, 100.0 * (double)hcount / (double)EP,
                 val ? 0 : 1, relabel ? 1 : 0);
+    }
+    if (!batch_layout) {
+        static_assert(kIPT == 8, "k_bsf_pack digests 8 entries per lane");
+        PGH_HIP(hipMalloc(&f.flags8, (size_t)f.num_tiles * 64 + 64));
+        PackLayout pl;
+        pl.num_blocks = B;
+        for (int b = 0; b <= 8; ++b) pl.tile_begin[b] = f.tile_begin[b];
+        k_bsf_pack<<<blocks_for((int64_t)f.num_tiles * 64), kBlock, 0, r.stream>>>(f.colf, reinterpret_cast<uint32_t*>(f.val), pl, f.num_tiles, blk, f.flags8);
+        PGH_HIP(hipGetLastError());
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        f.device_bytes += (int64_t)f.num_tiles * 64;
     }
     f.enabled = true;
     return 0;

@@ -82,6 +82,17 @@ void pool_trim();
 #ifndef PGH_PROBE_GATHER
 #define PGH_PROBE_GATHER 0
 #endif
+// physical order of a tile's entries (k_bsf_pack) and cache policy of the stream loads
+#ifndef PGH_TILE_TRANSPOSE
+#define PGH_TILE_TRANSPOSE 1
+#endif
+#ifndef PGH_STREAM_AUX
+#define PGH_STREAM_AUX 2
+#endif
+// diagnostic builds only: bit 0 = no output stage, bit 1 = no strip writes, bit 2 = no carry stores
+#ifndef PGH_PROBE_SKIP
+#define PGH_PROBE_SKIP 0
+#endif
 constexpr int kMaxPartials = 4096;   // upper bound on workgroups contributing block partials
 constexpr int kNumScalars = 64;
 
@@ -131,7 +142,9 @@ struct BsfFormat {
     bool      relabelled = false;
     int64_t   num_entries = 0;      // incl. one sentinel per block
     int64_t   num_segs = 0;
-    uint32_t* colf = nullptr;       // [num_entries] column (new id) | bit31 = first entry of a row segment
+    uint32_t* colf = nullptr;       // [num_entries] SpMV layout: byte offset of the source inside its block (k_bsf_pack);
+                                    // multi-seed layout: column (new id) | bit31 = first entry of a row segment
+    uint8_t*  flags8 = nullptr;     // [num_tiles * 64] SpMV layout: segment-start flags of each lane's 8 entries
     float*    val = nullptr;        // [num_entries] or null (value-free)
     int32_t*  seg_row = nullptr;    // [num_segs] output row (new id) of every segment, -1 for sentinels
     int       num_tiles = 0;
