@@ -134,8 +134,30 @@ def single_gpu(args):
         roofline=roofline, cpu_baseline=cpu, parity=parity)
 
 
+_REAL_STDOUT = None
+
+
+def _stdout_to_stderr():
+    """RCCL prints its version banner and warnings on fd 1.  The contract is ONE JSON line on stdout, so during the
+    multi-GPU run fd 1 points at stderr; the JSON goes to the saved descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
 def multi_gpu(args):
-    os.environ["NCCL_DEBUG"] = os.environ.get("PGH_NCCL_DEBUG", "WARN")     # keep RCCL's banner off stdout: one JSON line only
+    os.environ["NCCL_DEBUG"] = os.environ.get("PGH_NCCL_DEBUG", "WARN")
+    _stdout_to_stderr()
     from pygrank_amd.distributed import bench_row_partitioned
     return bench_row_partitioned(args, RMAT, ALPHA, TOL, MAX_ITERS, SEEDS, HBM_PEAK_GBS)
 
@@ -163,7 +185,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
     if result is not None:
-        print(json.dumps(result), flush=True)
+        _emit(json.dumps(result))
 
 
 if __name__ == "__main__":

@@ -48,3 +48,24 @@ def test_row_partitioned_pagerank_gloo(tmp_path, oracle_build_dir, world):
             got[perm[lo:lo + m]] = part[name + "_ranks"]
             assert int(part[name + "_iters"]) == want_iters, name
         assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), name
+
+
+def test_bench_two_ranks_prints_one_json_line(oracle_build_dir):
+    """The driver's N > 1 launch of bench.py (torch.distributed.run, one rank per GPU): rank 0 prints exactly one JSON
+    line on stdout (RCCL/gloo chatter goes to stderr), the value is the whole-job rate."""
+    import json
+    port = 29900 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "bench_dist_worker.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--scale", "11", "--ef", "8"]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["value"] >= 0 and out["ms_per_step"] > 0 and out["unit"] == "GTEPS" and out["vs_baseline"] is None
+    assert out["config"]["nnz"] == rmat_np.rmat_csr(11, 8, seed=0).nnz
+    assert len(out["config"]["iterations_per_step"]) == 2
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(out["roofline"])
