@@ -652,7 +652,8 @@ int bsf_combine_grid(int64_t n_out) {
 // xg: gather vector in the graph's internal id space, already multiplied by src_scale when the format has one.
 // Block partials of sum(y) / delta land in rt().d_partials like the row-major path; *num_partials receives their count.
 template <int MODE>
-int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials) {
+int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials,
+               hipEvent_t before_combine) {
     Runtime& r = rt();
     BsfFormat& f = g->bsf;
     const BsfView v = view_of(f);
@@ -672,6 +673,9 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
     const int cgrid = bsf_combine_grid(f.n_out);
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
+    // the epilogue is the first consumer of the previous step's scalars (quotient, done flag): the partial sums above
+    // may run while the previous step's residual / close kernels are still in flight on the side stream
+    if (before_combine != nullptr) PGH_HIP(hipStreamWaitEvent(r.stream, before_combine, 0));
     {
         ProfScope prof(PGH_K_COMBINE);
         switch (f.num_blocks) {
@@ -686,10 +690,10 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
     return 0;
 }
 
-template int bsf_launch<EPI_PLAIN>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*);
-template int bsf_launch<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*);
-template int bsf_launch<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*);
-template int bsf_launch<EPI_POLY>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*);
+template int bsf_launch<EPI_PLAIN>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);
+template int bsf_launch<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);
+template int bsf_launch<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);
+template int bsf_launch<EPI_POLY>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);
 
 // original-space source-side vector -> internal (relabelled, padded) space, optionally times src_scale
 int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale, float hole) {

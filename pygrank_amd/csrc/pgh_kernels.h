@@ -75,7 +75,8 @@ __device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff
 
 // blocked-format entry points (pgh_bsf.hip)
 template <int MODE>
-int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials);
+int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials,
+               hipEvent_t before_combine = nullptr);
 int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale, float hole);
 bool bsf_can_bring_pair(const pgh_graph_s* g);
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg);

@@ -389,8 +389,9 @@ int launch_merge(pgh_graph_t g, const EpiParams& ep, const float* x, const LoopS
 
 // One propagation step in the graph's internal id space, whichever format the graph carries.
 template <int MODE>
-int launch_step(pgh_graph_t g, const EpiParams& ep, const float* gather_src, const LoopState* state, int* num_partials) {
-    if (g->bsf.enabled) return bsf_launch<MODE>(g, ep, gather_src, state, num_partials);
+int launch_step(pgh_graph_t g, const EpiParams& ep, const float* gather_src, const LoopState* state, int* num_partials,
+                hipEvent_t before_combine = nullptr) {
+    if (g->bsf.enabled) return bsf_launch<MODE>(g, ep, gather_src, state, num_partials, before_combine);
     return launch_merge<MODE>(g, ep, gather_src, state, num_partials);
 }
 
@@ -413,6 +414,11 @@ LoopState* g_state_host = nullptr;
 // never drains between iterations and at most `window` no-op iterations trail the converged one.
 volatile int* g_progress_host = nullptr;
 int* g_progress_dev = nullptr;
+// Side stream of the recursive loops: the residual and close kernels of step k run there, concurrently with the block
+// partial sums of step k + 1 on the engine stream (which do not depend on step k's scalars); the epilogue of step k + 1
+// waits for them (ev_closed), they wait for the epilogue of step k (ev_combined).
+hipStream_t g_side_stream = nullptr;
+hipEvent_t g_ev_combined = nullptr, g_ev_closed = nullptr;
 
 int ensure_state() {
     if (g_state) return 0;
@@ -428,6 +434,14 @@ int ensure_state() {
     g_progress_dev = (int*)dp;
     const char* e = getenv("PGH_POLL");
     if (e != nullptr && atoi(e) == 0) g_progress_dev = nullptr;      // PGH_POLL=0: batch + sync polling (A/B measurements)
+    // measured on MI355X (profiles/r01/overlap_ab.log): 252 GTEPS with the side stream vs 268 without -- the 1024-thread
+    // partial-sum workgroups own every CU and the second queue only perturbs their dispatch -- so it is opt-in
+    const char* o = getenv("PGH_OVERLAP");
+    if (o != nullptr && atoi(o) != 0) {
+        PGH_HIP(hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking));
+        PGH_HIP(hipEventCreateWithFlags(&g_ev_combined, hipEventDisableTiming));
+        PGH_HIP(hipEventCreateWithFlags(&g_ev_closed, hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -784,6 +798,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     const int batch = poll ? 1 : batch_for(g);
     const int window = window_for(g);
     if (poll) progress_reset();
+    const bool overlap = g_side_stream != nullptr && sp.blocked;     // the row-major kernel applies its epilogue in place
     int enq = 0;          // steps enqueued so far
     bool done = false;
     while (!done && enq < max_steps) {
@@ -798,10 +813,17 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             float* yout = buf[k & 1];
             ep.y = yout;
             int count = 0;
-            PGH_TRY((launch_step<MODE>(g, ep, scaled_gather ? g->bsf.xg : xin, g_state, &count)));
+            PGH_TRY((launch_step<MODE>(g, ep, scaled_gather ? g->bsf.xg : xin, g_state, &count,
+                                       (overlap && enq > 0) ? g_ev_closed : nullptr)));
             // the check that follows step k happens at iteration k + 1 (skipped when that iteration hits max_iters)
             const int it = k + 1;
             const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
+            hipStream_t main_stream = r.stream;
+            if (overlap) {
+                PGH_HIP(hipEventRecord(g_ev_combined, main_stream));
+                PGH_HIP(hipStreamWaitEvent(g_side_stream, g_ev_combined, 0));
+                r.stream = g_side_stream;            // ProfScope and the launches below follow rt().stream
+            }
             if (check) {
                 ProfScope prof(PGH_K_RESIDUAL);
                 const int vec_ok = aligned16(yout) && aligned16(xin);
@@ -813,13 +835,19 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
                 k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, pres, rgrid, cfg->use_quotient,
                                                      check, cfg->err_kind, cfg->tol, n, nullptr, g_progress_dev);
             }
+            if (overlap) {
+                r.stream = main_stream;
+                PGH_HIP(hipEventRecord(g_ev_closed, g_side_stream));
+            }
         }
         PGH_HIP(hipGetLastError());
         if (!poll) {
+            if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
             PGH_TRY(fetch_state());
             done = g_state_host->done != 0;
         }
     }
+    if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
     PGH_TRY(fetch_state());
     const int steps = g_state_host->steps;
     // result lives in buf[steps & 1]; apply the pending quotient and preserve_norm factor
