@@ -32,11 +32,28 @@ if ROOT not in sys.path:
 RMAT = dict(a=0.57, b=0.19, c=0.19)
 ALPHA, TOL, MAX_ITERS, SEEDS = 0.85, 1e-6, 1000, 100
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+# HBM traffic of the step kernels: rocprofv3 --pmc passes of this same command (tools/gpu_bench_call.sh), summarised by
+# tools/summarize_pmc.py with the guide's gfx950 corrections; counters cannot be read from inside the timed process
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_n1_v7_pmc.json")
 
 
 def seeds_for(step, candidates, count=SEEDS):
     rng = np.random.default_rng(1 + step)           # RNG seed 1 (+ step for further draws)
     return np.sort(rng.choice(candidates, size=min(count, len(candidates)), replace=False))
+
+
+def measured_traffic(scale, ef, blocked):
+    """Per-launch HBM bytes (read + written) of the fused step's kernels from the committed PMC summary, or None when
+    the summary does not describe this workload."""
+    if not blocked or (scale, ef) != (23, 16) or not os.path.exists(PMC_SUMMARY):
+        return None, None
+    with open(PMC_SUMMARY) as f:
+        pmc = json.load(f)
+    total = 0.0
+    for name, row in pmc.items():
+        if name.startswith(("k_bsf_partial", "k_bsf_fixup", "k_bsf_combine")):
+            total += row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
+    return (int(total), os.path.relpath(PMC_SUMMARY, ROOT)) if total > 0 else (None, None)
 
 
 def single_gpu(args):
@@ -98,12 +115,13 @@ def single_gpu(args):
     step_us = sum(prof[k]["avg_us"] for k in step_kernels)
     achieved = alg_bytes / (step_us * 1e-6) / 1e9
     blocked = prof["combine"]["avg_us"] is not None
+    traffic, traffic_source = measured_traffic(scale, ef, blocked)
     roofline = dict(bound="hbm",
                     kernel=("k_bsf_partial + k_bsf_fixup + k_bsf_combine<AXPBY>" if blocked else "k_spmv_merge<AXPBY> + k_spmv_fixup")
                     + " (one fused PPR step)",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=None, algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(step_us, 2),
-                    format=g.format(), kernels_avg_us={k: (round(v["avg_us"], 2) if v["avg_us"] else None) for k, v in prof.items()})
+                    traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=alg_bytes,
+                    avg_launch_us=round(step_us, 2), format=g.format(), kernels_avg_us={k: (round(v["avg_us"], 2) if v["avg_us"] else None) for k, v in prof.items()})
 
     # ---- CPU baseline + parity: the oracle's scipy loop (= reference numpy backend), same graph, same seeds
     cpu = None
