@@ -204,6 +204,32 @@ int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loo
 int pgh_ppr_step_dist(pgh_graph_t g, pgh_vec_t xg_full, double x_scale, pgh_vec_t p_local, double alpha,
                       pgh_vec_t y_local, pgh_vec_t xg_local_out, double* sum_y);
 int pgh_dist_prescale(pgh_graph_t g, pgh_vec_t x_local, pgh_vec_t xg_local_out);
+
+/* Layout of the gather vector.  The source id space is cut into num_blocks column blocks of blk_size slots, hottest
+ * sources first; live[b] = 1 + the highest slot of block b that an entry of THIS graph references (sources nobody
+ * points at sort last: on RMAT graphs that is half of the id space or more).  A partitioned run exchanges only the
+ * first L = max over ranks and blocks of live[] slots of every block and tells the engine where each block's slice
+ * starts inside the (shorter) gather vector it passes to the steps below.  Defaults: bases[b] = b * blk_size. */
+int pgh_graph_gather_layout(pgh_graph_t g, int32_t* num_blocks, int64_t* blk_size, int32_t* live /* [8] */);
+int pgh_graph_set_gather_bases(pgh_graph_t g, const int64_t* bases /* [num_blocks] */);
+
+/* Device-driven partitioned loop: the scalars of the iteration stay in DEVICE memory, the collectives (RCCL
+ * all-reduce, issued by the caller on the engine stream) act on them in place, and no call below synchronises with
+ * the host.  `state` = 64 bytes of device memory owned by the caller, viewed as 8 doubles:
+ *   d[0] scale (lazily applied L1 quotient of the current iterate)   d[1] err   d[2] sum
+ *   d[3] = {int32 done, int32 steps}   d[4] = {int32 converged, int32 pad}   d[5] scale of the previous iterate
+ *   d[6] residual as evaluated by the stopping rule   d[7] reserved
+ * One iteration:  pgh_dist_partial -> pgh_dist_combine (d[2] = this rank's sum(y)) -> all_reduce(d[2], SUM) ->
+ * pgh_dist_close_sum -> all-gather of the gather slices -> pgh_dist_residual (d[1] = this rank's residual) ->
+ * all_reduce(d[1], SUM | MAX) -> pgh_dist_close_err (ConvergenceManager._has_converged, convergence.py:96-101).
+ * Once `done` is set every call is a no-op on the device, so the partial sums of the next iteration can be enqueued
+ * before the host has seen the flag. */
+int pgh_dist_state_init(double* state);
+int pgh_dist_partial(pgh_graph_t g, pgh_vec_t xg_full, const double* state);
+int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, pgh_vec_t y_local, pgh_vec_t xg_local_out, double* state);
+int pgh_dist_close_sum(double* state, int32_t use_quotient);
+int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old, double* state);
+int pgh_dist_close_err(double* state, int32_t kind, double tol, int64_t n_global);
 /* new id -> original id of a relabelled (partitioned) graph, and the first row this graph holds */
 int pgh_graph_perm(pgh_graph_t g, int32_t* new_to_old, int64_t* row_begin);
 

@@ -49,6 +49,12 @@ struct pgh_graph_s {
     std::vector<float> degrees;
     std::vector<int32_t> part_perm;   // new id -> old id for row-partitioned graphs
     int64_t row_begin = 0;
+    // gather-vector layout of partitioned graphs (pgh_graph_gather_layout / pgh_graph_set_gather_bases)
+    int32_t gather_blocks = 1;
+    int64_t gather_blk = 0;
+    int64_t gather_base[8] = {0};
+    const float* pending_xg = nullptr;
+    std::vector<float> dense_x;       // gather vector expanded to the full id space
 };
 
 static thread_local std::string g_err;
@@ -707,6 +713,9 @@ static int rmat_build(int32_t scale, int32_t ef, double a, double b, double c, u
         }
         row_begin = (int64_t)part_rank * (n / part_count);
         row_end = row_begin + n / part_count;
+        g->gather_blocks = B;
+        g->gather_blk = blk;
+        for (int b = 0; b < 8; ++b) g->gather_base[b] = (int64_t)b * blk;
     }
     if (row_end <= 0) row_end = n;
     CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= n, "pgh_graph_rmat: bad row range");
@@ -771,13 +780,100 @@ int pgh_graph_perm(pgh_graph_t g, int32_t* new_to_old, int64_t* row_begin) {
     for (int64_t i = 0; i < g->n_rows; ++i) new_to_old[i] = g->part_perm.empty() ? (int32_t)i : g->part_perm[i];
     return 0;
 }
+// gather vector in the caller's (possibly trimmed) layout -> dense vector over the whole id space
+static const float* expand_gather(pgh_graph_s* g, const float* xg, int64_t xg_len) {
+    if (g->gather_blk <= 0) return xg;
+    bool identity = true;
+    for (int b = 0; b < g->gather_blocks; ++b) identity = identity && g->gather_base[b] == (int64_t)b * g->gather_blk;
+    if (identity) return xg;
+    g->dense_x.assign((size_t)g->n_rows, 0.f);
+    for (int b = 0; b < g->gather_blocks; ++b)
+        for (int64_t i = 0; i < g->gather_blk && g->gather_base[b] + i < xg_len; ++i)
+            g->dense_x[(size_t)(b * g->gather_blk + i)] = xg[g->gather_base[b] + i];
+    return g->dense_x.data();
+}
+int pgh_graph_gather_layout(pgh_graph_t g, int32_t* num_blocks, int64_t* blk_size, int32_t* live) {
+    CHECK(g && g->gather_blk > 0, "pgh_graph_gather_layout: not a partitioned graph");
+    if (num_blocks) *num_blocks = g->gather_blocks;
+    if (blk_size) *blk_size = g->gather_blk;
+    if (live) {
+        for (int b = 0; b < 8; ++b) live[b] = 0;
+        for (int64_t k = 0; k < g->nnz; ++k) {
+            const int64_t c = g->col[k];
+            const int b = (int)(c / g->gather_blk);
+            const int32_t top = (int32_t)(c % g->gather_blk) + 1;
+            if (top > live[b]) live[b] = top;
+        }
+        for (int b = 0; b < g->gather_blocks; ++b)
+            if (live[b] < 1) live[b] = 1;
+    }
+    return 0;
+}
+int pgh_graph_set_gather_bases(pgh_graph_t g, const int64_t* bases) {
+    CHECK(g && bases && g->gather_blk > 0, "pgh_graph_set_gather_bases: not a partitioned graph");
+    for (int b = 0; b < g->gather_blocks; ++b) g->gather_base[b] = bases[b];
+    return 0;
+}
+// device-driven partitioned loop: same state layout as the engine (include/pgh.h)
+struct DistState {
+    double scale, err, sum;
+    int32_t done, steps, converged, pad;
+    double prev_scale, evaluated, reserved;
+};
+static_assert(sizeof(DistState) == 64, "pgh_dist state is 8 doubles");
+int pgh_dist_state_init(double* state) {
+    DistState* st = reinterpret_cast<DistState*>(state);
+    *st = DistState{};
+    st->scale = st->prev_scale = 1.0;
+    return 0;
+}
+int pgh_dist_partial(pgh_graph_t g, pgh_vec_t xg_full, const double* state) {
+    CHECK(g && xg_full && state, "pgh_dist_partial: null argument");
+    if (reinterpret_cast<const DistState*>(state)->done) return 0;
+    g->pending_xg = expand_gather(g, xg_full->data, xg_full->n);
+    return 0;
+}
+static double ppr_step(const pgh_graph_s* g, const float* x, double xs, const float* p, double alpha, float* y);
+int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p, double alpha, pgh_vec_t y, pgh_vec_t xg_local, double* state) {
+    CHECK(g && p && y && xg_local && state, "pgh_dist_combine: null argument");
+    CHECK(p->n == g->n_cols && y->n == g->n_cols && xg_local->n == g->n_cols, "pgh_dist_combine: local vector length mismatch");
+    DistState* st = reinterpret_cast<DistState*>(state);
+    if (st->done) return 0;
+    CHECK(g->pending_xg != nullptr, "pgh_dist_combine: no pgh_dist_partial before it");
+    st->sum = ppr_step(g, g->pending_xg, st->scale, p->data, alpha, y->data);
+    std::copy(y->data, y->data + y->n, xg_local->data);
+    return 0;
+}
+int pgh_dist_close_sum(double* state, int32_t use_quotient) {
+    DistState* st = reinterpret_cast<DistState*>(state);
+    if (st->done) return 0;
+    st->prev_scale = st->scale;
+    st->scale = use_quotient ? (st->sum != 0.0 ? 1.0 / st->sum : 0.0) : 1.0;
+    st->steps += 1;
+    return 0;
+}
+int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old, double* state) {
+    CHECK(y_new && y_old && state && y_new->n == y_old->n, "pgh_dist_residual: bad arguments");
+    DistState* st = reinterpret_cast<DistState*>(state);
+    if (st->done) return 0;
+    st->err = scaled_res(kind == PGH_ERR_LINF ? PGH_ERR_LINF : PGH_ERR_L1, y_new->data, st->scale, y_old->data, st->prev_scale, y_new->n);
+    return 0;
+}
+int pgh_dist_close_err(double* state, int32_t kind, double tol, int64_t n_global) {
+    DistState* st = reinterpret_cast<DistState*>(state);
+    if (st->done) return 0;
+    double e = st->err;
+    if (kind == PGH_ERR_MABS) e /= (double)n_global;
+    st->evaluated = e;
+    if (e <= tol) st->done = st->converged = 1;
+    return 0;
+}
 // the double keeps the normalisation inside the values, so its gather vector is the iterate itself
 int pgh_ppr_step_dist(pgh_graph_t g, pgh_vec_t xg_full, double xs, pgh_vec_t p, double alpha, pgh_vec_t y, pgh_vec_t xg_local,
                       double* sum_y) {
     CHECK(g && xg_full && p && y && xg_local, "pgh_ppr_step_dist: null argument");
-    CHECK(xg_full->n >= g->n_rows && p->n == g->n_cols && y->n == g->n_cols && xg_local->n == g->n_cols,
-          "pgh_ppr_step_dist: vector length mismatch");
-    const double s = ppr_step(g, xg_full->data, xs, p->data, alpha, y->data);
+    CHECK(p->n == g->n_cols && y->n == g->n_cols && xg_local->n == g->n_cols, "pgh_ppr_step_dist: vector length mismatch");
+    const double s = ppr_step(g, expand_gather(g, xg_full->data, xg_full->n), xs, p->data, alpha, y->data);
     std::copy(y->data, y->data + y->n, xg_local->data);
     if (sum_y) *sum_y = s;
     return 0;

@@ -102,6 +102,14 @@ SIGNATURES = {
     "pgh_spmm": (C.c_int, [c_graph, c_mat, c_mat]),
     "pgh_ppr_run_batch": (C.c_int, [c_graph, c_mat, c_mat, C.POINTER(LoopCfg), C.c_void_p, C.POINTER(LoopResult)]),
     "pgh_ppr_step_dist": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, C.c_double, c_vec, c_vec, c_f64p]),
+    "pgh_graph_gather_layout": (C.c_int, [c_graph, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_void_p]),
+    "pgh_graph_set_gather_bases": (C.c_int, [c_graph, C.c_void_p]),
+    "pgh_dist_state_init": (C.c_int, [C.c_void_p]),
+    "pgh_dist_partial": (C.c_int, [c_graph, c_vec, C.c_void_p]),
+    "pgh_dist_combine": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, c_vec, C.c_void_p]),
+    "pgh_dist_close_sum": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pgh_dist_residual": (C.c_int, [C.c_int32, c_vec, c_vec, C.c_void_p]),
+    "pgh_dist_close_err": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int64]),
     "pgh_dist_prescale": (C.c_int, [c_graph, c_vec, c_vec]),
     "pgh_graph_perm": (C.c_int, [c_graph, C.c_void_p, c_i64p]),
     "pgh_graph_rmat_part": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int32,

@@ -135,7 +135,7 @@ struct PackLayout {
     int num_blocks;
 };
 __global__ void k_bsf_pack(uint32_t* __restrict__ colf, uint32_t* __restrict__ val, PackLayout pl, int num_tiles, int blk,
-                           uint8_t* __restrict__ flags8) {
+                           uint8_t* __restrict__ flags8, int32_t* __restrict__ live) {
     // one WAVEFRONT per tile (blockDim is a multiple of 64): every lane reads its 8 logical words before any lane
     // writes, so the in-place transposition below is safe
     const int64_t total = (int64_t)num_tiles * 64;
@@ -147,14 +147,22 @@ __global__ void k_bsf_pack(uint32_t* __restrict__ colf, uint32_t* __restrict__ v
         uint32_t* w = colf + i * 8;
         uint32_t x[8], v[8];
         unsigned int bits = 0;
+        uint32_t top = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             x[k] = w[k];
             if (val) v[k] = val[i * 8 + k];
             bits |= (x[k] >> 31) << k;
-            x[k] = ((x[k] & 0x7fffffffu) - base) << 2;
+            const uint32_t loc = (x[k] & 0x7fffffffu) - base;
+            top = loc > top ? loc : top;           // sentinels and pads point at slot 0
+            x[k] = loc << 2;
         }
         flags8[i] = (uint8_t)bits;
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_down(top, off, 64);
+            top = o > top ? o : top;
+        }
+        if (lane == 0) atomicMax(&live[b], (int32_t)top + 1);
         // physical order inside the tile: [q = k / 4][lane][k % 4], so that the q-th 16-byte load of the 64 lanes
         // covers one contiguous KB (PGH_TILE_TRANSPOSE = 0 keeps the logical order: lane-contiguous 32 bytes)
         const int64_t t0 = (int64_t)tile * 512;
@@ -258,12 +266,14 @@ __global__ void k_bsf_tiles(TileBuild tb, const int* __restrict__ segid, int4* _
 }
 
 __global__ void k_permute_in(const float* __restrict__ src, const int32_t* __restrict__ perm, const float* __restrict__ scale,
-                             int64_t n_pad, int64_t n_valid, float hole, float* __restrict__ dst) {
+                             int64_t n_pad, int64_t n_valid, float hole, float* __restrict__ dst, int xg_blk = 0, int xg_live = 0) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = xg_slot((int)i, xg_blk, xg_live);
+        if (slot < 0) continue;
         const int o = perm ? perm[i] : (i < n_valid ? (int)i : -1);
         float v = o >= 0 ? src[o] : hole;
         if (scale) v *= scale[i];
-        dst[i] = v;
+        dst[slot] = v;
     }
 }
 
@@ -271,14 +281,17 @@ __global__ void k_permute_in(const float* __restrict__ src, const int32_t* __res
 // v_int = v[perm], y0 = ranks[perm], xg = ranks[perm] * src_scale
 __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __restrict__ ranks, const int32_t* __restrict__ perm,
                                   const float* __restrict__ scale, int64_t n_pad, float* __restrict__ v_int, float* __restrict__ y0,
-                                  float* __restrict__ xg) {
+                                  float* __restrict__ xg, int xg_blk, int xg_live) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
         const int o = perm[i];
         const float a = o >= 0 ? v[o] : 0.f;
         const float b = o >= 0 ? ranks[o] : 0.f;
         v_int[i] = a;
         y0[i] = b;
-        if (xg) xg[i] = scale ? b * scale[i] : b;
+        if (xg) {
+            const int slot = xg_slot((int)i, xg_blk, xg_live);
+            if (slot >= 0) xg[slot] = scale ? b * scale[i] : b;
+        }
     }
 }
 
@@ -303,7 +316,7 @@ struct BsfView {
     int64_t         part_stride;
     int             num_blocks;
     int             blk_size;
-    int             xg_bytes;
+    int64_t         xg_base[8];
     int             tile_begin[9];
 };
 
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     const int rank = ((blockIdx.x >> 3) * per + label / f.num_blocks) * WAVES + wave;
     const int stride = (gridDim.x >> 3) * per * WAVES;
     float* __restrict__ part = f.part + (int64_t)b * f.part_stride;
-    const uint32_t base = (uint32_t)(b * f.blk_size);
+    const int64_t base = f.xg_base[b];
     const uint32_t hot = (uint32_t)min(kBsfHot, f.blk_size);
     const uint32_t hot4 = hot << 2;
     for (uint32_t i = tid; i < hot; i += kBsfThreads) s_lds[i] = xg[base + i];
@@ -626,7 +639,7 @@ BsfView view_of(const BsfFormat& f) {
     v.part_stride = f.n_out;
     v.num_blocks = f.num_blocks;
     v.blk_size = f.blk_size;
-    v.xg_bytes = f.n_src_pad * 4;
+    for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base[i];
     for (int i = 0; i < 9; ++i) v.tile_begin[i] = f.tile_begin[i];
     return v;
 }
@@ -651,9 +664,7 @@ int bsf_combine_grid(int64_t n_out) {
 // Enqueue M^T-times-gather-vector in the blocked format followed by the MODE epilogue.
 // xg: gather vector in the graph's internal id space, already multiplied by src_scale when the format has one.
 // Block partials of sum(y) / delta land in rt().d_partials like the row-major path; *num_partials receives their count.
-template <int MODE>
-int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials,
-               hipEvent_t before_combine) {
+int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state) {
     Runtime& r = rt();
     BsfFormat& f = g->bsf;
     const BsfView v = view_of(f);
@@ -670,12 +681,17 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
         if (fix_grid > 1024) fix_grid = 1024;
         k_bsf_fixup<<<fix_grid, WG, 0, r.stream>>>(v, f.num_tiles, state);
     }
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int MODE>
+int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* state, int* num_partials) {
+    Runtime& r = rt();
+    BsfFormat& f = g->bsf;
     const int cgrid = bsf_combine_grid(f.n_out);
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
-    // the epilogue is the first consumer of the previous step's scalars (quotient, done flag): the partial sums above
-    // may run while the previous step's residual / close kernels are still in flight on the side stream
-    if (before_combine != nullptr) PGH_HIP(hipStreamWaitEvent(r.stream, before_combine, 0));
     {
         ProfScope prof(PGH_K_COMBINE);
         switch (f.num_blocks) {
@@ -690,6 +706,17 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
     return 0;
 }
 
+template <int MODE>
+int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials,
+               hipEvent_t before_combine) {
+    PGH_TRY(bsf_launch_partial(g, xg, state));
+    // the epilogue is the first consumer of the previous step's scalars (quotient, done flag): the partial sums above
+    // may run while the previous step's residual / close kernels are still in flight on the side stream
+    if (before_combine != nullptr) PGH_HIP(hipStreamWaitEvent(rt().stream, before_combine, 0));
+    return bsf_launch_combine<MODE>(g, ep, state, num_partials);
+}
+
+template int bsf_launch_combine<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const LoopState*, int*);
 template int bsf_launch<EPI_PLAIN>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);
 template int bsf_launch<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);
 template int bsf_launch<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);
@@ -698,8 +725,9 @@ template int bsf_launch<EPI_POLY>(pgh_graph_s*, const EpiParams&, const float*, 
 // original-space source-side vector -> internal (relabelled, padded) space, optionally times src_scale
 int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale, float hole) {
     BsfFormat& f = g->bsf;
+    const bool own = (dst == f.xg);          // the engine's own gather vector may be stored trimmed
     k_permute_in<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(src, f.perm, prescale ? f.src_scale : nullptr, f.n_src_pad,
-                                                                    f.n_src, hole, dst);
+                                                                    f.n_src, hole, dst, f.blk_size, own ? f.xg_live : 0);
     PGH_HIP(hipGetLastError());
     return 0;
 }
@@ -712,7 +740,7 @@ bool bsf_can_bring_pair(const pgh_graph_s* g) {
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg) {
     BsfFormat& f = g->bsf;
     k_permute_in_pair<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(v, ranks, f.perm, f.src_scale, f.n_src_pad, v_int, y0,
-                                                                          want_xg ? f.xg : nullptr);
+                                                                          want_xg ? f.xg : nullptr, f.blk_size, f.xg_live);
     PGH_HIP(hipGetLastError());
     return 0;
 }
@@ -738,6 +766,7 @@ int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor)
 void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.colf);
     (void)hipFree(f.flags8);
+    (void)hipFree(f.live_dev);
     (void)hipFree(f.val);
     (void)hipFree(f.seg_row);
     (void)hipFree(f.tile);
@@ -969,9 +998,25 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PackLayout pl;
         pl.num_blocks = B;
         for (int b = 0; b <= 8; ++b) pl.tile_begin[b] = f.tile_begin[b];
-        k_bsf_pack<<<blocks_for((int64_t)f.num_tiles * 64), kBlock, 0, r.stream>>>(f.colf, reinterpret_cast<uint32_t*>(f.val), pl, f.num_tiles, blk, f.flags8);
+        PGH_HIP(hipMalloc(&f.live_dev, sizeof(int32_t) * 8));
+        PGH_HIP(hipMemsetAsync(f.live_dev, 0, sizeof(int32_t) * 8, r.stream));
+        k_bsf_pack<<<blocks_for((int64_t)f.num_tiles * 64), kBlock, 0, r.stream>>>(f.colf, reinterpret_cast<uint32_t*>(f.val), pl, f.num_tiles, blk, f.flags8,
+                                                                                 f.live_dev);
         PGH_HIP(hipGetLastError());
+        PGH_HIP(hipMemcpyAsync(f.live, f.live_dev, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
+        for (int b = 0; b < 8; ++b) f.xg_base[b] = (int64_t)b * blk;
+        // The engine's own gather vector (graphs with a source scale: xg = y * src_scale, written by the epilogue) keeps
+        // only the referenced prefix of every block.  Partitioned graphs get their layout from the caller instead.
+        if (src_old != nullptr && g->part_perm == nullptr && env_int("PGH_TRIM", 1)) {
+            int top = 1;
+            for (int b = 0; b < B; ++b) top = f.live[b] > top ? f.live[b] : top;
+            top = (top + 63) / 64 * 64;
+            if (top < blk) {
+                f.xg_live = top;
+                for (int b = 0; b < 8; ++b) f.xg_base[b] = (int64_t)b * top;
+            }
+        }
         f.device_bytes += (int64_t)f.num_tiles * 64;
     }
     f.enabled = true;

@@ -156,6 +156,13 @@ struct BsfFormat {
     int32_t*  perm = nullptr;       // [n_src] new id -> old id, or null (identity)
     float*    src_scale = nullptr;  // [n_src_pad + 1] new space, or null
     float*    dst_scale = nullptr;  // [n_out] new space, or null
+    int32_t*  live_dev = nullptr;   // [8] device copy target of `live`
+    int       live[8] = {0};        // per block: 1 + the highest source slot any entry references (hot-first order puts
+                                    // never-referenced sources last: they need not be exchanged or stored)
+    int64_t   xg_base[8] = {0};     // first element of every block's slice inside the gather vector (default b * blk_size;
+                                    // a partitioned run lays the slices out as the trimmed all-gather delivers them)
+    int       xg_live = 0;          // > 0: the engine's own gather vector `xg` stores only the first xg_live slots of every
+                                    // block (xg_base[b] = b * xg_live): a smaller cold region for the same gathers
     float*    xg = nullptr;         // [n_src_pad + 1] gather-source work buffer (new space)
     float*    tmp_out = nullptr;    // [n_out] work buffer (new space) for the single-step entry points
     int64_t   device_bytes = 0;

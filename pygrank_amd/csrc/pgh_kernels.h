@@ -20,7 +20,20 @@ struct EpiParams {
     int          err_linf; // POLY: delta is a max instead of a sum
     float*       xg_out;   // blocked format with a source scale: next gather source y * src_scale (else null)
     const float* src_scale;
+    int          xg_blk;   // trimmed gather vector (BsfFormat::xg_live): slots per block in the id space ...
+    int          xg_live;  // ... and slots per block actually stored (0 = stored in full, slot = row)
 };
+
+// position of internal id `row` inside a gather vector that keeps only the first `live` slots of every block of `blk`
+// ids (never-referenced sources sort last inside a block and are not stored); -1 = not stored
+__device__ __forceinline__ int xg_slot(int row, int blk, int live) {
+    if (live == 0) return row;
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) b += (row >= k * blk) ? 1 : 0;
+    const int loc = row - b * blk;
+    return loc < live ? b * live + loc : -1;
+}
 
 // Device-resident loop state (ConvergenceManager on the device, convergence.py:77-101).
 struct LoopState {
@@ -59,7 +72,10 @@ __device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff
         y = (a_eff * sum * d + ep.v[row] * l) / (l + d);
     }
     ep.y[row] = y;
-    if (ep.xg_out != nullptr) ep.xg_out[row] = y * ep.src_scale[row];
+    if (ep.xg_out != nullptr) {
+        const int slot = xg_slot(row, ep.xg_blk, ep.xg_live);
+        if (slot >= 0) ep.xg_out[slot] = y * ep.src_scale[row];
+    }
     sum_y += (double)y;
     if (MODE == EPI_POLY) {
         const float r_old = ep.r[row];
@@ -74,6 +90,9 @@ __device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff
 
 
 // blocked-format entry points (pgh_bsf.hip)
+int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state);
+template <int MODE>
+int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* state, int* num_partials);
 template <int MODE>
 int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials,
                hipEvent_t before_combine = nullptr);

@@ -232,9 +232,15 @@ __global__ __launch_bounds__(WG) void k_step_residual(const float* __restrict__ 
                                                        double* __restrict__ partial_res) {
     __shared__ double s_red[4];
     if (state->done) return;
-    const double S = fold_partials(partial_sum, num_partials, 0, s_red);
-    const double inv = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
-    const double scale = state->scale;
+    double inv, scale;
+    if (partial_sum != nullptr) {
+        const double S = fold_partials(partial_sum, num_partials, 0, s_red);
+        inv = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+        scale = state->scale;
+    } else {               // partitioned loop: both quotients are already in the state (pgh_dist_close_sum)
+        inv = state->scale;
+        scale = reinterpret_cast<const double*>(state)[5];
+    }
     const int64_t tid = blockIdx.x * (int64_t)WG + threadIdx.x, stride = (int64_t)gridDim.x * WG;
     double acc = 0.0;
     auto fold = [&](float u, float v) {
@@ -630,12 +636,27 @@ extern "C" int pgh_poly_step(pgh_graph_t g, pgh_vec_t term, pgh_vec_t term_out, 
 // Row-partitioned PageRank step: this rank holds rows [row_begin, row_begin + n_local) of M^T in the
 // globally relabelled id space.  xg_full is the all-gathered gather vector (x * src_scale of every rank's slice);
 // the step writes y_local and this rank's slice of the next gather vector, so the all-gather moves xg directly.
+namespace {
+int check_dist_graph(pgh_graph_t g, pgh_vec_t xg_full, const char* who) {
+    PGH_CHECK(g && g->bsf.enabled, std::string(who) + ": the graph has no blocked layout");
+    const BsfFormat& f = g->bsf;
+    if (xg_full != nullptr) {
+        const int64_t hot = (int64_t)PGH_BSF_HOT < f.blk_size ? (int64_t)PGH_BSF_HOT : f.blk_size;
+        for (int b = 0; b < f.num_blocks; ++b) {
+            const int64_t need = f.xg_base[b] + (f.live[b] > hot ? f.live[b] : hot);
+            PGH_CHECK(xg_full->n >= need, std::string(who) + ": gather vector shorter than the layout set by pgh_graph_set_gather_bases");
+        }
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" int pgh_ppr_step_dist(pgh_graph_t g, pgh_vec_t xg_full, double x_scale, pgh_vec_t p_local, double alpha,
                                  pgh_vec_t y_local, pgh_vec_t xg_local_out, double* sum_y) {
     PGH_CHECK(g && xg_full && p_local && y_local && xg_local_out, "pgh_ppr_step_dist: null argument");
     PGH_CHECK(g->bsf.enabled, "pgh_ppr_step_dist: the graph has no blocked layout");
     BsfFormat& f = g->bsf;
-    PGH_CHECK(xg_full->n >= f.n_src_pad, "pgh_ppr_step_dist: gather vector shorter than the source space");
+    PGH_TRY(check_dist_graph(g, xg_full, "pgh_ppr_step_dist"));
     PGH_CHECK(p_local->n == g->n_cols && y_local->n == g->n_cols && xg_local_out->n == g->n_cols,
               "pgh_ppr_step_dist: local vector length mismatch");
     PGH_TRY(ensure_state());
@@ -676,6 +697,150 @@ extern "C" int pgh_dist_prescale(pgh_graph_t g, pgh_vec_t x_local, pgh_vec_t xg_
         return pgh_ewise_vv(PGH_MUL, x_local, &sv, xg_local_out);
     }
     return pgh_vec_copy(xg_local_out, x_local);
+}
+
+// ---- device-driven partitioned loop (include/pgh.h): scalars in caller-owned device memory laid out as a LoopState
+// followed by {prev_scale, evaluated residual, reserved}
+namespace {
+static_assert(sizeof(LoopState) == 40, "pgh_dist state layout: 5 doubles of LoopState + 3 extras");
+
+__global__ void k_dist_state_init(double* d) {
+    LoopState* st = reinterpret_cast<LoopState*>(d);
+    st->scale = 1.0;
+    st->err = 0.0;
+    st->sum = 0.0;
+    st->done = 0;
+    st->steps = 0;
+    st->converged = 0;
+    st->pad = 0;
+    d[5] = 1.0;
+    d[6] = 0.0;
+    d[7] = 0.0;
+}
+
+// folds block partials (sum or max) into one field of the state
+__global__ __launch_bounds__(WG) void k_dist_fold(double* __restrict__ d, const double* __restrict__ partials, int count,
+                                                   int linf, int field) {
+    __shared__ double s_red[4];
+    if (reinterpret_cast<const LoopState*>(d)->done) return;
+    const double v = fold_partials(partials, count, linf, s_red);
+    if (threadIdx.x == 0) d[field] = v;
+}
+
+// after the all-reduce of sum(y): RecursiveGraphFilter._step's L1 quotient (abstract_filters.py:133-134), kept lazy
+__global__ void k_dist_close_sum(double* d, int use_quotient) {
+    LoopState* st = reinterpret_cast<LoopState*>(d);
+    if (st->done) return;
+    d[5] = st->scale;
+    const double S = st->sum;
+    st->scale = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+    st->steps += 1;
+}
+
+// after the all-reduce of the residual: ConvergenceManager._has_converged (convergence.py:96-101)
+__global__ void k_dist_close_err(double* d, int kind, double tol, double n_global) {
+    LoopState* st = reinterpret_cast<LoopState*>(d);
+    if (st->done) return;
+    double e = st->err;
+    if (kind == PGH_ERR_MABS) e /= n_global;
+    d[6] = e;
+    if (e <= tol) {
+        st->done = 1;
+        st->converged = 1;
+    }
+}
+
+}  // namespace
+
+extern "C" int pgh_graph_gather_layout(pgh_graph_t g, int32_t* num_blocks, int64_t* blk_size, int32_t* live) {
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_graph_gather_layout"));
+    const BsfFormat& f = g->bsf;
+    if (num_blocks) *num_blocks = f.num_blocks;
+    if (blk_size) *blk_size = f.blk_size;
+    if (live)
+        for (int b = 0; b < 8; ++b) live[b] = b < f.num_blocks ? f.live[b] : 0;
+    return 0;
+}
+
+extern "C" int pgh_graph_set_gather_bases(pgh_graph_t g, const int64_t* bases) {
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_graph_set_gather_bases"));
+    PGH_CHECK(bases != nullptr, "pgh_graph_set_gather_bases: null argument");
+    BsfFormat& f = g->bsf;
+    for (int b = 0; b < f.num_blocks; ++b) {
+        PGH_CHECK(bases[b] >= 0 && bases[b] < (1LL << 31), "pgh_graph_set_gather_bases: base out of range");
+        f.xg_base[b] = bases[b];
+    }
+    return 0;
+}
+
+extern "C" int pgh_dist_state_init(double* state) {
+    PGH_TRY(ensure_init());
+    PGH_CHECK(state != nullptr, "pgh_dist_state_init: null state");
+    k_dist_state_init<<<1, 1, 0, rt().stream>>>(state);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pgh_dist_partial(pgh_graph_t g, pgh_vec_t xg_full, const double* state) {
+    PGH_CHECK(xg_full && state, "pgh_dist_partial: null argument");
+    PGH_TRY(check_dist_graph(g, xg_full, "pgh_dist_partial"));
+    return bsf_launch_partial(g, xg_full->data, reinterpret_cast<const LoopState*>(state));
+}
+
+extern "C" int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, pgh_vec_t y_local, pgh_vec_t xg_local_out,
+                                double* state) {
+    PGH_CHECK(p_local && y_local && xg_local_out && state, "pgh_dist_combine: null argument");
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_dist_combine"));
+    PGH_CHECK(p_local->n == g->n_cols && y_local->n == g->n_cols && xg_local_out->n == g->n_cols,
+              "pgh_dist_combine: local vector length mismatch");
+    BsfFormat& f = g->bsf;
+    Runtime& r = rt();
+    EpiParams ep{};
+    ep.a = alpha;                                  // the kernel multiplies by state->scale
+    ep.b = 1.0 - alpha;
+    ep.v = p_local->data;
+    ep.y = y_local->data;
+    if (f.src_scale != nullptr) {
+        ep.xg_out = xg_local_out->data;
+        ep.src_scale = f.src_scale + g->row_begin;
+    }
+    int count = 0;
+    PGH_TRY((bsf_launch_combine<EPI_AXPBY>(g, ep, reinterpret_cast<const LoopState*>(state), &count)));
+    if (f.src_scale == nullptr) PGH_TRY(pgh_vec_copy(xg_local_out, y_local));
+    k_dist_fold<<<1, WG, 0, r.stream>>>(state, r.d_partials, count, 0, 2);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pgh_dist_close_sum(double* state, int32_t use_quotient) {
+    PGH_CHECK(state != nullptr, "pgh_dist_close_sum: null state");
+    k_dist_close_sum<<<1, 1, 0, rt().stream>>>(state, use_quotient);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old, double* state) {
+    PGH_CHECK(y_new && y_old && state && y_new->n == y_old->n, "pgh_dist_residual: bad arguments");
+    Runtime& r = rt();
+    const int linf = (kind == PGH_ERR_LINF);
+    const int rgrid = residual_grid(y_new->n);
+    double* pres = r.d_partials + kMaxPartials;
+    {
+        ProfScope prof(PGH_K_RESIDUAL);
+        const int vec_ok = aligned16(y_new->data) && aligned16(y_old->data);
+        k_step_residual<<<rgrid, WG, 0, r.stream>>>(y_new->data, y_old->data, y_new->n, vec_ok, 1, linf,
+                                                    reinterpret_cast<const LoopState*>(state), nullptr, 0, pres);
+    }
+    k_dist_fold<<<1, WG, 0, r.stream>>>(state, pres, rgrid, linf, 1);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pgh_dist_close_err(double* state, int32_t kind, double tol, int64_t n_global) {
+    PGH_CHECK(state != nullptr, "pgh_dist_close_err: null state");
+    k_dist_close_err<<<1, 1, 0, rt().stream>>>(state, kind, tol, (double)n_global);
+    PGH_HIP(hipGetLastError());
+    return 0;
 }
 
 // =================================================================================================
@@ -786,6 +951,8 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     if (scaled_gather) {
         ep.xg_out = g->bsf.xg;
         ep.src_scale = g->bsf.src_scale;
+        ep.xg_blk = g->bsf.blk_size;
+        ep.xg_live = g->bsf.xg_live;
     }
     const int linf = (cfg->err_kind == PGH_ERR_LINF);
     const int rgrid = residual_grid(n_int);
@@ -990,6 +1157,8 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
                 if (scaled_gather) {
                     ep.xg_out = g->bsf.xg;
                     ep.src_scale = g->bsf.src_scale;
+                    ep.xg_blk = g->bsf.blk_size;
+                    ep.xg_live = g->bsf.xg_live;
                 }
                 int count = 0;
                 PGH_TRY((launch_step<EPI_POLY>(g, ep, scaled_gather ? g->bsf.xg : term, g_state, &count)));

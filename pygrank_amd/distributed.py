@@ -54,23 +54,66 @@ def rmat_partitioned(scale, edge_factor, rank, world, a=0.57, b=0.19, c=0.19, se
     return PartitionedGraph(DeviceGraph(h, (vals[0].value, vals[1].value), vals[2].value), rank, world)
 
 
-class _Buffers:
-    """torch tensors (device memory for RCCL, host memory for gloo) viewed as engine vectors."""
+_HOT_PAD = 32768          # the engine's LDS hot cache reads up to this many leading slots of a block's slice
 
-    def __init__(self, n, n_local, device):
+
+class _Buffers:
+    """torch tensors (device memory for RCCL, host memory for gloo) viewed as engine vectors.
+
+    Gather-vector layout.  The engine cuts the source id space into `nb` hot-first column blocks of `blk` slots; rank r
+    owns blocks r*bpr .. r*bpr + bpr - 1 (bpr = nb / world).  Only the first L slots of a block can be referenced by
+    anybody (pgh_graph_gather_layout; L = max over ranks), so the exchange is bpr all-gathers of L floats per rank and
+    the gather vector is stored as [j][rank][L]: block r*bpr + j starts at (j * world + r) * L."""
+
+    def __init__(self, pgraph, device, dist):
         import torch
         self.torch = torch
-        self.xg_full = torch.zeros(n, dtype=torch.float32, device=device)
+        lib = L.lib()
+        g = pgraph.graph
+        n_local, world = pgraph.n_local, pgraph.world
+        nb, blk = C.c_int32(), C.c_int64()
+        live = np.zeros(8, dtype=np.int32)
+        L.check(lib.pgh_graph_gather_layout(g._h, C.byref(nb), C.byref(blk), live.ctypes.data_as(C.c_void_p)))
+        self.nb, self.blk = nb.value, blk.value
+        assert self.nb % world == 0 and self.blk * self.nb == pgraph.n
+        self.bpr = self.nb // world
+        top = torch.tensor([int(live.max())], dtype=torch.int64, device=device)
+        dist.all_reduce(top, op=dist.ReduceOp.MAX)
+        self.live = min(self.blk, (int(top.item()) + 63) // 64 * 64)
+        bases = np.zeros(8, dtype=np.int64)
+        for b in range(self.nb):
+            r, j = divmod(b, self.bpr)
+            bases[b] = (j * world + r) * self.live
+        L.check(lib.pgh_graph_set_gather_bases(g._h, bases.ctypes.data_as(C.c_void_p)))
+        n_xg = self.nb * self.live + _HOT_PAD
+        self.xg_full = torch.zeros(n_xg, dtype=torch.float32, device=device)
         self.xg_local = torch.zeros(n_local, dtype=torch.float32, device=device)
         self.y = [torch.zeros(n_local, dtype=torch.float32, device=device) for _ in range(2)]
         self.scalar = torch.zeros(1, dtype=torch.float64, device=device)
-        self.v_xg_full = DeviceVector.wrap(self.xg_full.data_ptr(), n, keepalive=self.xg_full)
+        self.state = torch.zeros(8, dtype=torch.float64, device=device)          # pgh_dist_* state (include/pgh.h)
+        self.state_host = torch.zeros(8, dtype=torch.float64)
+        if device.type == "cuda":
+            self.state_host = self.state_host.pin_memory()
+        self.v_xg_full = DeviceVector.wrap(self.xg_full.data_ptr(), n_xg, keepalive=self.xg_full)
         self.v_xg_local = DeviceVector.wrap(self.xg_local.data_ptr(), n_local, keepalive=self.xg_local)
         self.v_y = [DeviceVector.wrap(t.data_ptr(), n_local, keepalive=t) for t in self.y]
+        self.exchange_bytes = 4 * self.live * self.bpr * (world - 1)            # received per rank and iteration
+
+    def all_gather(self, dist):
+        """xg_local (this rank's slice of the next gather vector) -> every rank's xg_full, live prefixes only."""
+        per = self.live * (self.nb // self.bpr)                                  # world * L floats per all-gather
+        for j in range(self.bpr):
+            dist.all_gather_into_tensor(self.xg_full[j * per:(j + 1) * per], self.xg_local[j * self.blk:j * self.blk + self.live])
 
 
 class DistributedPageRank:
-    """PageRank(alpha) with ConvergenceManager(tol, error_type, max_iters, end_modulo) on a PartitionedGraph."""
+    """PageRank(alpha) with ConvergenceManager(tol, error_type, max_iters, end_modulo) on a PartitionedGraph.
+
+    The loop is device-driven: the iteration's scalars (sum(y), residual, quotient, done flag) live in an 8-double
+    device tensor, the RCCL all-reduces act on its elements in place, and every engine call turns into a no-op once the
+    stopping rule has fired.  The host only looks at the flag after a step that was followed by a residual check, and
+    by then it has already enqueued the next step's partial sums (which do not depend on the scalars), so the device
+    never waits for the host."""
 
     _KINDS = {"mabs": L.ERR_MABS, "l1": L.ERR_L1, "linf": L.ERR_LINF, "iters": L.ERR_ITERS}
 
@@ -94,8 +137,9 @@ class DistributedPageRank:
         lib = L.lib()
         g = pgraph.graph
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        if self._buffers is None or self._buffers.xg_full.numel() != pgraph.n:
-            self._buffers = _Buffers(pgraph.n, pgraph.n_local, device)
+        if self._buffers is None or self._buffers_for is not pgraph:
+            self._buffers = _Buffers(pgraph, device, dist)
+            self._buffers_for = pgraph
         bufs = self._buffers
         kind = self._KINDS[self.error_type]
         tol = 0.0 if self.tol is None else max(self.tol, self.epsilon)          # convergence.py:101
@@ -109,6 +153,19 @@ class DistributedPageRank:
         else:
             import contextlib
             stream_ctx = contextlib.nullcontext()
+        state = C.c_void_p(bufs.state.data_ptr())
+        sum_view, err_view = bufs.state[2:3], bufs.state[1:2]
+        err_op = dist.ReduceOp.MAX if kind == L.ERR_LINF else dist.ReduceOp.SUM
+        local_kind = L.ERR_LINF if kind == L.ERR_LINF else L.ERR_L1
+
+        def read_state():
+            """(done, steps, converged, scale) once everything enqueued before this call has run."""
+            bufs.state_host.copy_(bufs.state, non_blocking=True)
+            if device.type == "cuda":
+                self._stream.synchronize()
+            ints = bufs.state_host.view(torch.int32)
+            return int(ints[6]), int(ints[7]), int(ints[8]), float(bufs.state_host[0])
+
         with stream_ctx:
             # ---- prologue of GraphFilter.rank (abstract_filters.py:52-56): global L1 norm, x0 = p / norm
             norm = self._all_reduce(bufs, dist, p_local.abssum(), dist.ReduceOp.SUM)
@@ -116,39 +173,59 @@ class DistributedPageRank:
                 self.iteration = 0
                 return p_local
             p = p_local / norm
-            cur, scale, prev_scale = 0, 1.0, 1.0
+            cur = 0
             L.check(lib.pgh_vec_copy(bufs.v_y[cur]._h, p._h))
             L.check(lib.pgh_dist_prescale(g._h, bufs.v_y[cur]._h, bufs.v_xg_local._h))
-            dist.all_gather_into_tensor(bufs.xg_full, bufs.xg_local)
+            bufs.all_gather(dist)
+            L.check(lib.pgh_dist_state_init(state))
             t0 = time.perf_counter()
             it, spmv, converged = 1, 0, False       # `it` = ConvergenceManager.iteration of the pending has_converged call
-            err, s_local = C.c_double(), C.c_double()
+            pending_flag = None                     # event recorded after the last residual check
+            partial_enqueued = False
             while it < self.max_iters:                                             # convergence.py:86
                 nxt = 1 - cur
-                L.check(lib.pgh_ppr_step_dist(g._h, bufs.v_xg_full._h, scale, p._h, self.alpha, bufs.v_y[nxt]._h,
-                                              bufs.v_xg_local._h, C.byref(s_local)))
-                total = self._all_reduce(bufs, dist, s_local.value, dist.ReduceOp.SUM)
-                dist.all_gather_into_tensor(bufs.xg_full, bufs.xg_local)           # next gather vector over xGMI ...
-                prev_scale, scale = scale, ((1.0 / total if total != 0 else 0.0) if self.use_quotient else 1.0)
+                if not partial_enqueued:
+                    L.check(lib.pgh_dist_partial(g._h, bufs.v_xg_full._h, state))
+                partial_enqueued = False
+                if pending_flag is not None:
+                    # the check that followed the previous step: its flag is on its way while the partial sums run
+                    if device.type == "cuda":
+                        pending_flag.synchronize()
+                    pending_flag = None
+                    if int(bufs.state_host.view(torch.int32)[6]):
+                        converged = True            # the partial sums just enqueued were no-ops (done was already set)
+                        break
+                L.check(lib.pgh_dist_combine(g._h, p._h, self.alpha, bufs.v_y[nxt]._h, bufs.v_xg_local._h, state))
+                dist.all_reduce(sum_view)
+                L.check(lib.pgh_dist_close_sum(state, 1 if self.use_quotient else 0))
+                bufs.all_gather(dist)                                              # next gather vector over xGMI
                 cur = nxt
                 spmv += 1
                 it += 1
                 if it >= self.max_iters:
                     break
-                if kind != L.ERR_ITERS and it % self.end_modulo == 0:              # ... overlapped with the residual
-                    local_kind = L.ERR_LINF if kind == L.ERR_LINF else L.ERR_L1
-                    L.check(lib.pgh_scaled_residual(local_kind, bufs.v_y[cur]._h, scale, bufs.v_y[1 - cur]._h, prev_scale,
-                                                    C.byref(err)))
-                    e = self._all_reduce(bufs, dist, err.value, dist.ReduceOp.MAX if kind == L.ERR_LINF else dist.ReduceOp.SUM)
-                    if kind == L.ERR_MABS:
-                        e /= pgraph.n
-                    if e <= tol:
-                        converged = True
-                        break
-            if device.type == "cuda":
-                self._stream.synchronize()
+                if kind != L.ERR_ITERS and it % self.end_modulo == 0:
+                    L.check(lib.pgh_dist_residual(local_kind, bufs.v_y[cur]._h, bufs.v_y[1 - cur]._h, state))
+                    dist.all_reduce(err_view, op=err_op)
+                    L.check(lib.pgh_dist_close_err(state, kind, tol, pgraph.n))
+                    bufs.state_host.copy_(bufs.state, non_blocking=True)
+                    if device.type == "cuda":
+                        pending_flag = torch.cuda.Event()
+                        pending_flag.record(self._stream)
+                        # speculate: the next partial sums only need the all-gather above
+                        L.check(lib.pgh_dist_partial(g._h, bufs.v_xg_full._h, state))
+                        partial_enqueued = True
+                    else:
+                        pending_flag = True
+            if pending_flag is not None and not converged:
+                if device.type == "cuda":
+                    pending_flag.synchronize()
+                converged = bool(int(bufs.state_host.view(torch.int32)[6]))
+            done, steps, conv, scale = read_state()
             self.elapsed = time.perf_counter() - t0
+            assert steps == spmv, (steps, spmv)
             self.iteration, self.spmv, self.converged = it, spmv, converged
+            self.last_error = float(bufs.state_host[6])
             if not converged and self.error_type != "iters" and it >= self.max_iters:
                 raise Exception("Could not converge within " + str(self.max_iters) + " iterations")
             factor = scale * (norm if self.preserve_norm else 1.0)                 # abstract_filters.py:63-64
@@ -240,7 +317,8 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
                     n=n, nnz=nnz_total, alpha=alpha, tol=tol, error_type="L1", seeds=num_seeds, iterations_per_step=iters,
                     spmv_per_step=spmv_total / args.steps, graph_build_s=round(build_s, 2),
                     parallelism=f"1-D row partition x{world}, all-gather of the gather vector + 2 scalar all-reduces per iteration",
-                    exchange_bytes_per_iteration_per_gpu=4 * n_local * (world - 1)),
+                    exchange_bytes_per_iteration_per_gpu=ranker._buffers.exchange_bytes,
+                    gather_vector_slots=ranker._buffers.nb * ranker._buffers.live, column_blocks=ranker._buffers.nb),
         roofline=dict(bound="hbm", kernel="k_bsf_partial + k_bsf_fixup + k_bsf_combine<AXPBY> (one fused PPR step, rank 0 slice)",
                       achieved=round(achieved, 1) if achieved else None, peak=hbm_peak, unit="GB/s",
                       frac=round(achieved / hbm_peak, 4) if achieved else None, traffic=None,
