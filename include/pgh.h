@@ -164,6 +164,13 @@ typedef struct {
     int32_t max_iters;
     int32_t end_modulo;
     double  out_scale;      /* preserve_norm factor applied to the final ranks (abstract_filters.py:63-64) */
+    /* GraphFilter.rank's prologue folded into the loop's first pass over the operands (recursive runs only):
+     * the personalization the loop uses is p / in_norm (abstract_filters.py:55; 0 means 1), and with start_from_p != 0
+     * the starting vector is that same p / in_norm (abstract_filters.py:56 without warm_start) -- `ranks` is then
+     * output only. */
+    double  in_norm;
+    int32_t start_from_p;
+    int32_t reserved;
 } pgh_loop_cfg;
 
 typedef struct {

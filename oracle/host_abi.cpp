@@ -520,12 +520,14 @@ struct Conv {
 };
 
 template <class StepFn>
-static int recursive_run(pgh_graph_t g, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res, StepFn step) {
+static int recursive_run(pgh_graph_t g, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res, const float* start,
+                         StepFn step) {
     CHECK(g->n_rows == g->n_cols, "recursive filters need a square matrix");
     CHECK(ranks && ranks->n == g->n_cols, "ranks length mismatch");
     CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
     const int64_t n = g->n_cols;
     std::vector<float> cur(ranks->data, ranks->data + n), prev(n), next(n);
+    if (cfg->start_from_p) cur.assign(start, start + n);                    // abstract_filters.py:56 (no warm start)
     double cur_scale = 1.0, prev_scale = 1.0;
     Conv cm{cfg};
     int steps = 0;
@@ -555,19 +557,30 @@ static int recursive_run(pgh_graph_t g, pgh_vec_t ranks, const pgh_loop_cfg* cfg
 }
 }  // extern "C++"
 
+// personalization / in_norm in f32 (abstract_filters.py:55)
+static std::vector<float> normalised(pgh_vec_t p, const pgh_loop_cfg* cfg) {
+    std::vector<float> out(p->data, p->data + p->n);
+    if (cfg->in_norm != 0.0 && cfg->in_norm != 1.0) {
+        const float d = (float)cfg->in_norm;
+        for (float& v : out) v = v / d;
+    }
+    return out;
+}
 int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
     CHECK(g && p && ranks && cfg && res, "pgh_ppr_run: null argument");
     CHECK(p->n == g->n_cols, "pgh_ppr_run: personalization length mismatch");
-    return recursive_run(g, ranks, cfg, res, [&](const float* x, double xs, float* y) {
-        return ppr_step(g, x, xs, p->data, cfg->alpha, y);
+    const std::vector<float> pn = normalised(p, cfg);
+    return recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
+        return ppr_step(g, x, xs, pn.data(), cfg->alpha, y);
     });
 }
 int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg,
                    pgh_loop_result* res) {
     CHECK(g && p && lam && ranks && cfg && res, "pgh_absorb_run: null argument");
     CHECK(p->n == g->n_cols && lam->n == g->n_cols, "pgh_absorb_run: vector length mismatch");
-    return recursive_run(g, ranks, cfg, res, [&](const float* x, double xs, float* y) {
-        return absorb_step(g, x, xs, p->data, g->degrees.data(), lam->data, y);
+    const std::vector<float> pn = normalised(p, cfg);
+    return recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
+        return absorb_step(g, x, xs, pn.data(), g->degrees.data(), lam->data, y);
     });
 }
 

@@ -24,7 +24,8 @@ c_f64p = C.POINTER(C.c_double)
 
 class LoopCfg(C.Structure):
     _fields_ = [("alpha", C.c_double), ("use_quotient", C.c_int32), ("err_kind", C.c_int32), ("tol", C.c_double),
-                ("max_iters", C.c_int32), ("end_modulo", C.c_int32), ("out_scale", C.c_double)]
+                ("max_iters", C.c_int32), ("end_modulo", C.c_int32), ("out_scale", C.c_double),
+                ("in_norm", C.c_double), ("start_from_p", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LoopResult(C.Structure):

@@ -281,11 +281,12 @@ __global__ void k_permute_in(const float* __restrict__ src, const int32_t* __res
 // v_int = v[perm], y0 = ranks[perm], xg = ranks[perm] * src_scale
 __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __restrict__ ranks, const int32_t* __restrict__ perm,
                                   const float* __restrict__ scale, int64_t n_pad, float* __restrict__ v_int, float* __restrict__ y0,
-                                  float* __restrict__ xg, int xg_blk, int xg_live) {
+                                  float* __restrict__ xg, int xg_blk, int xg_live, float in_norm, int start_from_v) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
         const int o = perm[i];
-        const float a = o >= 0 ? v[o] : 0.f;
-        const float b = o >= 0 ? ranks[o] : 0.f;
+        float a = o >= 0 ? v[o] : 0.f;
+        if (in_norm != 1.f) a = a / in_norm;              // the same f32 division as the backend's `p / norm`
+        const float b = start_from_v ? a : (o >= 0 ? ranks[o] : 0.f);
         v_int[i] = a;
         y0[i] = b;
         if (xg) {
@@ -737,10 +738,12 @@ bool bsf_can_bring_pair(const pgh_graph_s* g) {
     const BsfFormat& f = g->bsf;
     return f.enabled && f.relabelled && f.perm != nullptr && f.n_out == f.n_src_pad;
 }
-int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg) {
+int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
+                   bool start_from_v) {
     BsfFormat& f = g->bsf;
     k_permute_in_pair<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(v, ranks, f.perm, f.src_scale, f.n_src_pad, v_int, y0,
-                                                                          want_xg ? f.xg : nullptr, f.blk_size, f.xg_live);
+                                                                          want_xg ? f.xg : nullptr, f.blk_size, f.xg_live, in_norm,
+                                                                          start_from_v ? 1 : 0);
     PGH_HIP(hipGetLastError());
     return 0;
 }

@@ -98,7 +98,8 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
                hipEvent_t before_combine = nullptr);
 int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale, float hole);
 bool bsf_can_bring_pair(const pgh_graph_s* g);
-int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg);
+int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
+                   bool start_from_v);
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);
 int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel,

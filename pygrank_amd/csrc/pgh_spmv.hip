@@ -923,14 +923,33 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     LoopTimer timer;
     PGH_TRY(timer.start());
     // ---- bring the operands into the internal space
-    DevF32 v_buf, deg_buf, lam_buf, y0, y1;
+    DevF32 v_buf, deg_buf, lam_buf, y0, y1, pn_buf;
     const bool scaled_gather = sp.blocked && g->bsf.src_scale != nullptr;
     const bool pair = sp.blocked && bsf_can_bring_pair(g);
+    // GraphFilter.rank's prologue (abstract_filters.py:55-56) folded into the loop: p / in_norm, start vector = that
+    const float in_norm = (cfg->in_norm != 0.0) ? (float)cfg->in_norm : 1.f;
+    const bool from_p = cfg->start_from_p != 0;
+    if (!pair && (in_norm != 1.f || from_p)) {       // layouts without the fused permutation: materialise the prologue
+        pgh_vec_s pv, tv;
+        pv.data = const_cast<float*>(ep.v);
+        pv.n = n;
+        pv.owns = false;
+        if (in_norm != 1.f) {
+            PGH_TRY(pn_buf.alloc(n));
+            tv.data = pn_buf.p;
+            tv.n = n;
+            tv.owns = false;
+            PGH_TRY(pgh_ewise_vs(PGH_DIV, &pv, (double)in_norm, 0, &tv));
+            ep.v = pn_buf.p;
+            pv.data = pn_buf.p;
+        }
+        if (from_p) PGH_TRY(pgh_vec_copy(ranks, &pv));
+    }
     float* buf[2] = {ranks->data, nullptr};
     if (pair) {          // personalization, start vector and scaled gather vector in one pass over the permutation
         PGH_TRY(v_buf.alloc(n_int));
         PGH_TRY(y0.alloc(n_int));
-        PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, y0.p, scaled_gather));
+        PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, y0.p, scaled_gather, in_norm, from_p));
         ep.v = v_buf.p;
         buf[0] = y0.p;
     } else {

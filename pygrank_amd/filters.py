@@ -52,9 +52,15 @@ class GraphFilter(NodeRanking):
         personalization = to_signal(graph, personalization)                       # abstract_filters.py:49
         self._prepare(personalization)
         personalization = self.personalization_transform(personalization)
-        norm = backend.sum(backend.abs(personalization.np))                       # :52
+        raw = personalization.np
+        norm = raw.abssum() if isinstance(raw, DeviceVector) else backend.sum(backend.abs(raw))   # :52
         if norm == 0:
             return personalization                                                # :53-54
+        if warm_start is None and graph_dropout == 0:
+            # :55-56 folded into the engine's first pass over the operands (pgh_loop_cfg.in_norm / start_from_p)
+            ranks = self._fused_rank(personalization, norm, *args, **kwargs)
+            if ranks is not None:
+                return ranks
         personalization = to_signal(personalization, personalization.np / norm)   # :55
         ranks = to_signal(personalization,
                           backend.copy(personalization.np) if warm_start is None else warm_start)   # :56
@@ -72,6 +78,11 @@ class GraphFilter(NodeRanking):
         return ranks
 
     # ---- hooks
+    def _fused_rank(self, personalization, norm, *args, **kwargs):
+        """Whole rank() after the norm check inside the engine, starting from the UN-normalised personalization; returns
+        the ranks signal or None when this filter / configuration has no such route."""
+        return None
+
     def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
         """Runs the whole loop inside the engine when the configuration allows it; returns True when it did."""
         return False
@@ -195,6 +206,23 @@ class PageRank(RecursiveGraphFilter):
         if not isinstance(p, DeviceVector):
             return False
         return self._run_recursive(L.lib().pgh_ppr_run, _device_graph(M), cfg, ranks, p)
+
+    def _fused_rank(self, personalization, norm, *args, **kwargs):
+        if args or kwargs or not self._plain_quotient() or type(self)._formula is not PageRank._formula \
+                or type(self)._step is not RecursiveGraphFilter._step or type(self)._prepare_graph is not GraphFilter._prepare_graph:
+            return None
+        p = personalization.np
+        cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), norm if self.preserve_norm else 1.0)
+        if cfg is None or not isinstance(p, DeviceVector):
+            return None
+        M = self.preprocessor(personalization.graph)
+        g = _device_graph(M)
+        if g is None or g.shape[0] != g.shape[1] or g.shape[0] != len(p):
+            return None
+        cfg.in_norm, cfg.start_from_p = float(norm), 1
+        self.convergence.start()
+        ranks = to_signal(personalization, DeviceVector.empty(len(p)))
+        return ranks if self._run_recursive(L.lib().pgh_ppr_run, g, cfg, ranks, p) else None
 
     def propagate(self, graph, features, *args, **kwargs):
         """signals.py:225-226 semantics (one rank() per feature column), run as multi-seed batches of up to 64 columns

@@ -324,4 +324,53 @@ def check_factored_upload_matches_valued_upload(pg):
     assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
 
 
+def check_trimmed_gather_layout(pg):
+    """pgh_graph_gather_layout / pgh_graph_set_gather_bases: a partitioned step gives bit-identical results whether the
+    gather vector is stored in full (block b at b * blk) or trimmed to the referenced prefix of every block."""
+    import ctypes as C
+    from pygrank_amd import _lib as L
+    from pygrank_amd.device import DeviceVector
+    from pygrank_amd.distributed import rmat_partitioned
+    lib = L.lib()
+    rng = np.random.default_rng(13)
+    for scale, ef in ((12, 4), (15, 8)):
+        part = rmat_partitioned(scale, ef, 0, 1)
+        g, n = part.graph, part.n
+        nb, blk = C.c_int32(), C.c_int64()
+        live = np.zeros(8, dtype=np.int32)
+        L.check(lib.pgh_graph_gather_layout(g._h, C.byref(nb), C.byref(blk), live.ctypes.data_as(C.c_void_p)))
+        nb, blk = nb.value, blk.value
+        assert nb * blk == n and np.all(live[:nb] >= 1) and np.all(live[:nb] <= blk) and np.all(live[nb:] == 0)
+        assert live[:nb].max() < blk          # RMAT: a large share of the sources is never referenced
+        x = rng.random(n).astype(F32)
+        p = rng.random(n).astype(F32)
+        xg_local, dx = DeviceVector.empty(n), DeviceVector.from_host(x.astype(np.float64))
+        dp = DeviceVector.from_host(p.astype(np.float64))
+        L.check(lib.pgh_dist_prescale(g._h, dx._h, xg_local._h))
+        xg = np.asarray(xg_local).astype(F32)
+
+        def step(layout_bases, gather):
+            bases = np.zeros(8, dtype=np.int64)
+            bases[:nb] = layout_bases
+            L.check(lib.pgh_graph_set_gather_bases(g._h, bases.ctypes.data_as(C.c_void_p)))
+            y, xo, s = DeviceVector.empty(n), DeviceVector.empty(n), C.c_double()
+            dg = DeviceVector.from_host(gather.astype(np.float64))
+            L.check(lib.pgh_ppr_step_dist(g._h, dg._h, 0.7, dp._h, 0.85, y._h, xo._h, C.byref(s)))
+            return np.asarray(y).astype(F32), np.asarray(xo).astype(F32), s.value
+
+        full = step(np.arange(nb) * blk, xg)
+        top = int((live[:nb].max() + 63) // 64 * 64)
+        compact = np.zeros(nb * top + 32768, dtype=F32)
+        for b in range(nb):
+            compact[b * top:b * top + min(top, blk)] = xg[b * blk:b * blk + min(top, blk)]
+        trimmed = step(np.arange(nb) * top, compact)
+        assert np.array_equal(full[0], trimmed[0]) and np.array_equal(full[1], trimmed[1]) and full[2] == trimmed[2]
+        # a gather vector shorter than the layout is refused
+        short = DeviceVector.from_host(np.zeros(top, dtype=np.float64))
+        y, xo = DeviceVector.empty(n), DeviceVector.empty(n)
+        rc = lib.pgh_ppr_step_dist(g._h, short._h, 1.0, dp._h, 0.85, y._h, xo._h, None)
+        if not L._is_test_double:
+            assert rc != 0 and b"gather vector" in lib.pgh_last_error()
+
+
 ALL = [v for k, v in sorted(globals().items()) if k.startswith("check_") and callable(v)]
