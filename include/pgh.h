@@ -104,6 +104,13 @@ int     pgh_mat_h2d_f64(pgh_mat_t m, const double* host_row_major);
 int     pgh_mat_d2h_f64(pgh_mat_t m, double* host_row_major);
 int     pgh_mat_set_col(pgh_mat_t m, int32_t col, pgh_vec_t v);     /* combine_cols */
 int     pgh_mat_get_col(pgh_mat_t m, int32_t col, pgh_vec_t v);     /* separate_cols */
+/* whole-slab forms of GraphFilter.rank's prologue for a batch of columns (abstract_filters.py:52-55 per column):
+ * out[j] = sum_i |m[i, j]| (host doubles), and out[i, j] = m[i, j] / (float)divisors[j] (a zero divisor copies). */
+int     pgh_mat_col_abssum(pgh_mat_t m, double* out_host /* [b] */);
+int     pgh_mat_div_cols(pgh_mat_t m, const double* divisors_host /* [b] */, pgh_mat_t out);
+/* out[:, 0:count] = m[:, first:first+count]  /  m[:, first:first+src.b] = src  (batches wider than 64 columns) */
+int     pgh_mat_get_cols(pgh_mat_t m, int32_t first, pgh_mat_t out);
+int     pgh_mat_set_cols(pgh_mat_t m, int32_t first, pgh_mat_t src);
 
 /* ---------------------------------------------------------------- graph --------------------------- */
 /* scipy_sparse_to_backend(M), specification.py:70-71 (called at core/utils/preprocessing.py:144).
@@ -197,7 +204,8 @@ int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
  * (signals.py:225-226) / tuner probes / sweeps in ONE pass over the adjacency. */
 int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y);
 /* b independent PageRank runs (same alpha and ConvergenceManager settings; personalizations = columns of p, already
- * L1-normalised; ranks in/out like pgh_ppr_run).  Column j keeps its own quotient, residual and stopping iteration:
+ * L1-normalised; ranks in/out like pgh_ppr_run, output only with cfg->start_from_p).  Column j keeps its own quotient,
+ * residual and stopping iteration:
  * results[j] is what pgh_ppr_run would report for seed j.  out_scales (nullable): per-column preserve_norm factor. */
 int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales,
                       pgh_loop_result* per_column_results);

@@ -342,6 +342,35 @@ int pgh_mat_get_col(pgh_mat_t m, int32_t c, pgh_vec_t v) {
     return 0;
 }
 
+int pgh_mat_col_abssum(pgh_mat_t m, double* out) {
+    CHECK(m && out, "pgh_mat_col_abssum: null argument");
+    for (int j = 0; j < m->b; ++j) out[j] = 0.0;
+    for (int64_t i = 0; i < m->n; ++i)
+        for (int j = 0; j < m->b; ++j) out[j] += std::fabs((double)m->data[i * m->b + j]);
+    return 0;
+}
+int pgh_mat_div_cols(pgh_mat_t m, const double* div, pgh_mat_t out) {
+    CHECK(m && out && div && m->n == out->n && m->b == out->b, "pgh_mat_div_cols: shape mismatch");
+    for (int64_t i = 0; i < m->n; ++i)
+        for (int j = 0; j < m->b; ++j) {
+            const float d = (float)div[j];
+            out->data[i * m->b + j] = d != 0.f ? m->data[i * m->b + j] / d : m->data[i * m->b + j];
+        }
+    return 0;
+}
+int pgh_mat_get_cols(pgh_mat_t m, int32_t first, pgh_mat_t out) {
+    CHECK(m && out && m->n == out->n && first >= 0 && first + out->b <= m->b, "pgh_mat_get_cols: shape mismatch");
+    for (int64_t i = 0; i < m->n; ++i)
+        for (int j = 0; j < out->b; ++j) out->data[i * out->b + j] = m->data[i * m->b + first + j];
+    return 0;
+}
+int pgh_mat_set_cols(pgh_mat_t m, int32_t first, pgh_mat_t src) {
+    CHECK(m && src && m->n == src->n && first >= 0 && first + src->b <= m->b, "pgh_mat_set_cols: shape mismatch");
+    for (int64_t i = 0; i < m->n; ++i)
+        for (int j = 0; j < src->b; ++j) m->data[i * m->b + first + j] = src->data[i * src->b + j];
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ graph
 int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
                        const double* data, int, pgh_graph_t* out) {

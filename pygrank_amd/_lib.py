@@ -81,6 +81,10 @@ SIGNATURES = {
     "pgh_mat_h2d_f64": (C.c_int, [c_mat, C.c_void_p]),
     "pgh_mat_d2h_f64": (C.c_int, [c_mat, C.c_void_p]),
     "pgh_mat_set_col": (C.c_int, [c_mat, C.c_int32, c_vec]),
+    "pgh_mat_col_abssum": (C.c_int, [c_mat, C.c_void_p]),
+    "pgh_mat_div_cols": (C.c_int, [c_mat, C.c_void_p, c_mat]),
+    "pgh_mat_get_cols": (C.c_int, [c_mat, C.c_int32, c_mat]),
+    "pgh_mat_set_cols": (C.c_int, [c_mat, C.c_int32, c_mat]),
     "pgh_mat_get_col": (C.c_int, [c_mat, C.c_int32, c_vec]),
     "pgh_graph_from_csr": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(c_graph)]),

@@ -58,7 +58,8 @@ int ensure_init();
 // Stream-ordered caching allocator for vectors, slabs and loop work buffers.  hipMalloc / hipFree synchronise the
 // device and cost 100+ us each; a PageRank run allocates ~10 n-vectors.  A released block is reused by the next
 // request of the same size; every user enqueues on the engine stream, so reuse is ordered after the last use.
-// Idle blocks are capped (PGH_POOL_MB, default 16384) and dropped on allocation failure.
+// Idle blocks are capped (PGH_POOL_MB, default a quarter of the device memory; largest evicted first) and dropped on
+// allocation failure.
 int  pool_alloc(size_t bytes, void** out);
 void pool_free(void* p);
 void pool_trim();

@@ -143,16 +143,30 @@ void pool_free(void* p) {
     }
     const size_t bytes = it->second;
     P.live.erase(it);
-    if (P.cap_bytes == 0) {
+    if (P.cap_bytes == 0) {                    // idle blocks kept: PGH_POOL_MB, default a quarter of the device memory
         const char* e = getenv("PGH_POOL_MB");
-        P.cap_bytes = (size_t)(e ? atoll(e) : 16384) << 20;
+        if (e != nullptr) {
+            P.cap_bytes = (size_t)atoll(e) << 20;
+        } else {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
+            P.cap_bytes = total_b / 4;
+        }
         if (P.cap_bytes == 0) P.cap_bytes = 1;
     }
-    if (P.idle_bytes + bytes > P.cap_bytes) pool_trim();
     if (bytes > P.cap_bytes) {
         (void)hipStreamSynchronize(rt().stream);
         (void)hipFree(p);
         return;
+    }
+    if (P.idle_bytes + bytes > P.cap_bytes) {  // evict the largest idle blocks until the new one fits
+        (void)hipStreamSynchronize(rt().stream);
+        while (!P.idle.empty() && P.idle_bytes + bytes > P.cap_bytes) {
+            auto last = std::prev(P.idle.end());
+            (void)hipFree(last->second);
+            P.idle_bytes -= last->first;
+            P.idle.erase(last);
+        }
     }
     P.idle.emplace(bytes, p);
     P.idle_bytes += bytes;
@@ -795,6 +809,104 @@ extern "C" int pgh_mat_d2h_f64(pgh_mat_t m, double* host) {
     pool_free(staging);
     return 0;
 }
+namespace {
+// per-column sum of |.| of a row-major slab: every thread keeps ONE column (the grid stride is a multiple of b), f64;
+// the threads of a workgroup that share a column are folded through LDS in thread order (deterministic)
+__global__ __launch_bounds__(kBlock) void k_mat_col_abssum(const float* __restrict__ m, int64_t n, int b, double* __restrict__ partial /* [grid][b] */) {
+    __shared__ double s_acc[kBlock];
+    const int64_t total = n * b;
+    const int64_t stride = ((int64_t)gridDim.x * kBlock + b - 1) / b * b;
+    const int64_t block_first = blockIdx.x * (int64_t)kBlock;
+    double acc = 0.0;
+    for (int64_t i = block_first + threadIdx.x; i < total; i += stride) acc += fabs((double)m[i]);
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    for (int j = threadIdx.x; j < b; j += kBlock) {
+        double t = 0.0;
+        int first = (int)((j - block_first % b + b) % b);          // first thread of this workgroup that owns column j
+        for (int k = first; k < kBlock; k += b) t += s_acc[k];
+        partial[(int64_t)blockIdx.x * b + j] = t;
+    }
+}
+__global__ void k_mat_fold_cols(const double* __restrict__ partial, int count, int b, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= b) return;
+    double acc = 0.0;
+    for (int i = 0; i < count; ++i) acc += partial[(int64_t)i * b + j];     // fixed order
+    out[j] = acc;
+}
+__global__ void k_mat_div_cols(const float* __restrict__ m, int64_t total, int b, const float* __restrict__ div, float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = div[i % b];
+        out[i] = d != 0.f ? m[i] / d : m[i];
+    }
+}
+// dst[:, dst_first + j] = src[:, src_first + j] for j < count
+__global__ void k_mat_copy_cols(const float* __restrict__ src, int ld_src, int src_first, float* __restrict__ dst, int ld_dst, int dst_first,
+                                int count, int64_t n) {
+    const int64_t total = n * count;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / count;
+        const int j = (int)(i - r * count);
+        dst[r * ld_dst + dst_first + j] = src[r * ld_src + src_first + j];
+    }
+}
+}  // namespace
+
+extern "C" int pgh_mat_col_abssum(pgh_mat_t m, double* out_host) {
+    PGH_CHECK(m && out_host, "pgh_mat_col_abssum: null argument");
+    PGH_CHECK(m->b <= 1024, "pgh_mat_col_abssum: at most 1024 columns");
+    Runtime& r = rt();
+    for (int j = 0; j < m->b; ++j) out_host[j] = 0.0;
+    if (m->n == 0) return 0;
+    int grid = r.num_cus * 4;
+    double* partial = nullptr;
+    double* folded = nullptr;
+    PGH_TRY(pool_alloc(sizeof(double) * (size_t)grid * m->b, (void**)&partial));
+    PGH_TRY(pool_alloc(sizeof(double) * (size_t)m->b, (void**)&folded));
+    k_mat_col_abssum<<<grid, kBlock, 0, r.stream>>>(m->data, m->n, m->b, partial);
+    k_mat_fold_cols<<<(m->b + 63) / 64, 64, 0, r.stream>>>(partial, grid, m->b, folded);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipMemcpyAsync(out_host, folded, sizeof(double) * m->b, hipMemcpyDeviceToHost, r.stream));
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    pool_free(partial);
+    pool_free(folded);
+    return 0;
+}
+
+extern "C" int pgh_mat_div_cols(pgh_mat_t m, const double* divisors_host, pgh_mat_t out) {
+    PGH_CHECK(m && out && divisors_host && m->n == out->n && m->b == out->b, "pgh_mat_div_cols: shape mismatch");
+    if (m->n == 0) return 0;
+    Runtime& r = rt();
+    std::vector<float> h(m->b);
+    for (int j = 0; j < m->b; ++j) h[j] = (float)divisors_host[j];
+    float* d = nullptr;
+    PGH_TRY(pool_alloc(sizeof(float) * (size_t)m->b, (void**)&d));
+    PGH_HIP(hipMemcpyAsync(d, h.data(), sizeof(float) * m->b, hipMemcpyHostToDevice, r.stream));
+    PGH_HIP(hipStreamSynchronize(r.stream));                       // h goes out of scope
+    const int64_t total = m->n * m->b;
+    k_mat_div_cols<<<grid_for(total, 4), kBlock, 0, r.stream>>>(m->data, total, m->b, d, out->data);
+    PGH_HIP(hipGetLastError());
+    pool_free(d);
+    return 0;
+}
+
+extern "C" int pgh_mat_get_cols(pgh_mat_t m, int32_t first, pgh_mat_t out) {
+    PGH_CHECK(m && out && m->n == out->n && first >= 0 && first + out->b <= m->b, "pgh_mat_get_cols: shape mismatch");
+    if (m->n == 0) return 0;
+    k_mat_copy_cols<<<grid_for(m->n * out->b, 4), kBlock, 0, rt().stream>>>(m->data, m->b, first, out->data, out->b, 0, out->b, m->n);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pgh_mat_set_cols(pgh_mat_t m, int32_t first, pgh_mat_t src) {
+    PGH_CHECK(m && src && m->n == src->n && first >= 0 && first + src->b <= m->b, "pgh_mat_set_cols: shape mismatch");
+    if (m->n == 0) return 0;
+    k_mat_copy_cols<<<grid_for(m->n * src->b, 4), kBlock, 0, rt().stream>>>(src->data, src->b, 0, m->data, m->b, first, src->b, m->n);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int pgh_mat_set_col(pgh_mat_t m, int32_t col, pgh_vec_t v) {
     PGH_CHECK(m && v && v->n == m->n && col >= 0 && col < m->b, "pgh_mat_set_col: shape mismatch");
     if (m->n == 0) return 0;

@@ -154,15 +154,24 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
     }
 }
 
-// per-column fold of the block partials (one wavefront: lane = column); MODE 0: sums -> state.sum, 1: residuals -> state.err
-__global__ void k_mm_fold(const double* __restrict__ partials, int count, int linf, double* __restrict__ out) {
-    const int lane = threadIdx.x;
+// per-column fold of the block partials: lane = column, the WG / 64 wavefronts take interleaved rows of the partial table
+// and are combined in wavefront order (fixed summation order)
+__global__ __launch_bounds__(WG) void k_mm_fold(const double* __restrict__ partials, int count, int linf, double* __restrict__ out) {
+    __shared__ double s_red[WG / 64][kLanes];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double acc = 0.0;
-    for (int i = 0; i < count; ++i) {
+    for (int i = w; i < count; i += WG / 64) {
         const double v = partials[(int64_t)i * kLanes + lane];
         acc = linf ? fmax(acc, v) : acc + v;
     }
-    out[lane] = acc;
+    s_red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+        double t = s_red[0][lane];
+#pragma unroll
+        for (int k = 1; k < WG / 64; ++k) t = linf ? fmax(t, s_red[k][lane]) : t + s_red[k][lane];
+        out[lane] = t;
+    }
 }
 
 __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y, const float* __restrict__ y_old, int64_t n, int ld, int b,
@@ -265,15 +274,12 @@ inline int blocks_for(int64_t n, int cap_mult = 16) {
     return (int)blocks;
 }
 
-struct DevBytes {
+struct DevBytes {          // slab work buffers from the runtime's stream-ordered pool (eight 2 GB slabs per 64-seed batch)
     void* p = nullptr;
     ~DevBytes() {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p);
     }
-    int alloc(size_t bytes) {
-        PGH_HIP(hipMalloc(&p, bytes > 0 ? bytes : 1));
-        return 0;
-    }
+    int alloc(size_t bytes) { return pool_alloc(bytes > 0 ? bytes : 1, &p); }
     template <typename T>
     T* as() { return static_cast<T*>(p); }
 };
@@ -396,8 +402,9 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     PGH_HIP(hipMemsetAsync(sums.p, 0, slab, r.stream));
     k_mm_state_init<<<1, kLanes, 0, r.stream>>>(state, b);
     k_mm_permute_in<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(p->data, f.perm, nullptr, n_int, n, ld, pint.as<float>());
-    k_mm_permute_in<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(ranks->data, f.perm, nullptr, n_int, n, ld, y0.as<float>());
-    k_mm_permute_in<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(ranks->data, f.perm, f.src_scale, n_int, n, ld, xg.as<float>());
+    const float* start = cfg->start_from_p ? p->data : ranks->data;          // abstract_filters.py:56 without warm_start
+    k_mm_permute_in<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(start, f.perm, nullptr, n_int, n, ld, y0.as<float>());
+    k_mm_permute_in<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(start, f.perm, f.src_scale, n_int, n, ld, xg.as<float>());
     float* buf[2] = {y0.as<float>(), y1.as<float>()};
     const int linf = cfg->err_kind == PGH_ERR_LINF;
     const int max_steps = cfg->max_iters - 1 > 0 ? cfg->max_iters - 1 : 0;
@@ -425,13 +432,13 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
                 ProfScope prof(PGH_K_COMBINE);
                 k_mm_combine<<<cgrid, WG, 0, r.stream>>>(c, n_int, ld, b, state, partial.as<double>());
             }
-            k_mm_fold<<<1, kLanes, 0, r.stream>>>(partial.as<double>(), cgrid, 0, reinterpret_cast<double*>(state) + 2 * kLanes);   // -> state.sum
+            k_mm_fold<<<1, WG, 0, r.stream>>>(partial.as<double>(), cgrid, 0, reinterpret_cast<double*>(state) + 2 * kLanes);   // -> state.sum
             const int it = k + 1;
             const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
             if (check) {
                 ProfScope prof(PGH_K_RESIDUAL);
                 k_mm_residual<<<cgrid, WG, 0, r.stream>>>(yout, yin, n_int, ld, b, cfg->use_quotient, linf, state, partial.as<double>());
-                k_mm_fold<<<1, kLanes, 0, r.stream>>>(partial.as<double>(), cgrid, linf, reinterpret_cast<double*>(state) + kLanes);     // -> state.err
+                k_mm_fold<<<1, WG, 0, r.stream>>>(partial.as<double>(), cgrid, linf, reinterpret_cast<double*>(state) + kLanes);     // -> state.err
             }
             k_mm_close<<<1, kLanes, 0, r.stream>>>(state, cfg->use_quotient, check, cfg->err_kind, cfg->tol, n);
         }

@@ -296,6 +296,27 @@ class DeviceMatrix:
     def columns(self):
         return [self.column(j) for j in range(self.b)]
 
+    # ---- whole-slab operations (one kernel each; the per-column forms above cost one strided pass per column)
+    def col_abssum(self):
+        out = np.zeros(self.b, dtype=np.float64)
+        L.check(L.lib().pgh_mat_col_abssum(self._h, _ptr(out)))
+        return out
+
+    def div_cols(self, divisors):
+        """out[:, j] = self[:, j] / divisors[j]; a zero divisor copies the column."""
+        d = np.ascontiguousarray(divisors, dtype=np.float64)
+        out = DeviceMatrix.empty(self.n, self.b)
+        L.check(L.lib().pgh_mat_div_cols(self._h, _ptr(d), out._h))
+        return out
+
+    def get_cols(self, first, count):
+        out = DeviceMatrix.empty(self.n, count)
+        L.check(L.lib().pgh_mat_get_cols(self._h, int(first), out._h))
+        return out
+
+    def set_cols(self, first, src):
+        L.check(L.lib().pgh_mat_set_cols(self._h, int(first), src._h))
+
     def __sub__(self, other):
         return DeviceMatrix.from_columns([a - b for a, b in zip(self.columns(), other.columns())])
 

@@ -233,31 +233,35 @@ class PageRank(RecursiveGraphFilter):
         batched = (not args and not kwargs and cfg is not None and self._plain_quotient()
                    and type(self)._formula is PageRank._formula and type(self)._step is RecursiveGraphFilter._step
                    and isinstance(self.personalization_transform, Tautology) and self.personalization_transform.ranker is None)
-        cols = backend.separate_cols(features)
         M = self.preprocessor(graph) if batched else None
         g = _device_graph(M) if batched else None
         if g is None or g.shape[0] != g.shape[1]:
             return super().propagate(graph, features, *args, **kwargs)
+        F = features if isinstance(features, DeviceMatrix) else backend.to_primitive(features)
+        if not isinstance(F, DeviceMatrix):
+            F = DeviceMatrix.from_columns([F])
         self.last_batches = []
-        out_cols = []
-        for start in range(0, len(cols), 64):
-            chunk = cols[start:start + 64]
-            norms = [c.abssum() for c in chunk]                                   # abstract_filters.py:52-55 per column
-            normalized = [c / nrm if nrm != 0 else c for c, nrm in zip(chunk, norms)]
-            P = DeviceMatrix.from_columns(normalized)
-            R = DeviceMatrix.from_columns(normalized)                              # ranks start as a copy of p (:56)
-            results = (L.LoopResult * len(chunk))()
-            scales = (C.c_double * len(chunk))(*[(nrm if self.preserve_norm else 1.0) for nrm in norms])
+        out = DeviceMatrix.empty(F.n, F.b) if F.b > 64 else None
+        for start in range(0, F.b, 64):
+            chunk = F if F.b <= 64 else F.get_cols(start, min(64, F.b - start))
+            norms = chunk.col_abssum()                                            # abstract_filters.py:52-55 per column
+            P = chunk.div_cols(norms)                                             # zero columns stay zero (:53-54)
+            R = DeviceMatrix.empty(chunk.n, chunk.b)
+            results = (L.LoopResult * chunk.b)()
+            scales = (C.c_double * chunk.b)(*[(float(nrm) if self.preserve_norm else 1.0) for nrm in norms])
+            cfg.start_from_p = 1                                                  # ranks start as a copy of p (:56)
             self.convergence.start()
             L.check(L.lib().pgh_ppr_run_batch(g._h, P._h, R._h, C.byref(cfg), scales, results))
             info = [dict(iterations=r.iterations, converged=bool(r.converged), spmv=r.spmv_count, loop_ms=r.loop_ms)
                     for r in results]
             self.last_batches.append(info)
-            for j, (r, nrm) in enumerate(zip(results, norms)):
+            for r, nrm in zip(results, norms):
                 if nrm != 0:
                     self.convergence.finish_device_loop(r.iterations, r.converged)   # raises like the per-column run would
-            out_cols.extend(R.columns())
-        return backend.combine_cols(out_cols)
+            if out is None:
+                return R
+            out.set_cols(start, R)
+        return out
 
     def references(self):
         refs = super().references()

@@ -324,6 +324,46 @@ def check_factored_upload_matches_valued_upload(pg):
     assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
 
 
+def check_slab_ops_and_wide_propagate(pg):
+    """Whole-slab prologue kernels (pgh_mat_col_abssum / div_cols / get_cols / set_cols) against numpy, and propagate
+    over more than 64 feature columns (two batches) against per-column rank()."""
+    from pygrank_amd.device import DeviceMatrix
+    rng = np.random.default_rng(21)
+    for n, b in ((1, 1), (1000, 3), (4097, 64), (513, 70)):
+        X = (rng.random((n, b)) - 0.3).astype(F32).astype(np.float64)
+        X[:, b // 2] = 0.0
+        D = DeviceMatrix.from_host(X)
+        sums = D.col_abssum()
+        assert np.allclose(sums, np.abs(X).sum(axis=0), rtol=1e-12, atol=0), (n, b)
+        assert np.array_equal(D.col_abssum(), sums)                   # deterministic
+        Q = np.asarray(D.div_cols(sums))
+        want = X.copy()
+        nz = sums != 0
+        want[:, nz] = (X[:, nz].astype(F32) / sums[nz].astype(F32)).astype(np.float64)
+        assert np.allclose(Q, want, rtol=2 * EPS32, atol=0), (n, b)
+        if b > 2:
+            part = D.get_cols(1, b - 2)
+            assert np.array_equal(np.asarray(part), X[:, 1:b - 1])
+            Z = DeviceMatrix.from_host(np.zeros((n, b)))
+            Z.set_cols(1, part)
+            back = np.asarray(Z)
+            assert np.array_equal(back[:, 1:b - 1], X[:, 1:b - 1]) and np.all(back[:, 0] == 0) and np.all(back[:, -1] == 0)
+    A = rmat_np.rmat_csr(10, 8, seed=7)
+    n = A.shape[0]
+    graph = pg.AdjacencyWrapper(A, directed=True)
+    pre = pg.preprocessor(assume_immutability=True)
+    feats = np.zeros((n, 70))
+    for j in range(70):
+        feats[rmat_np.seed_nodes(A, 3 + j, seed=j + 1), j] = 1.0 + 0.1 * j
+    feats[:, 66] = 0.0
+    ranker = pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=1e-6, max_iters=500)
+    out = np.asarray(ranker.propagate(graph, pg.to_primitive(feats)))
+    assert out.shape == (n, 70) and len(ranker.last_batches) == 2 and len(ranker.last_batches[1]) == 6
+    for j in (0, 17, 63, 64, 66, 69):
+        single = np.asarray(ranker.rank(graph, feats[:, j]).np)
+        assert np.max(np.abs(out[:, j] - single)) <= 2e-6 * max(np.max(np.abs(single)), 1e-30), j
+
+
 def check_trimmed_gather_layout(pg):
     """pgh_graph_gather_layout / pgh_graph_set_gather_bases: a partitioned step gives bit-identical results whether the
     gather vector is stored in full (block b at b * blk) or trimmed to the referenced prefix of every block."""
