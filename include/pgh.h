@@ -128,6 +128,15 @@ int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
 int pgh_graph_from_factored_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
                                 const int32_t* indices, const double* weights, const double* left, const double* right,
                                 int flags, pgh_graph_t* out);
+/* The preprocessor's normalisation evaluated on the device: W is the raw (weighted / multi-edge)
+ * adjacency as graph_to_scipy delivers it (preprocessing.py:103; weights == NULL means all ones: 4 B/edge over PCIe),
+ * the engine forms the degree reductions (row sums; column sums for "symmetric" / "both"), their (square-root)
+ * inverses with zero degrees left zero (preprocessing.py:109-138) and M = diag(left) W diag(right) in fp64, in the
+ * reference's evaluation order.  Bit-identical to the host route for integer weights (the sums are exact); for real
+ * weights the row sums are accumulated in a different order than scipy's, i.e. values agree to 1 ulp of f32. */
+enum { PGH_NORM_COL = 0, PGH_NORM_SYMMETRIC = 1, PGH_NORM_NONE = 2, PGH_NORM_BOTH = 3 };
+int pgh_graph_from_adjacency(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                             const double* weights, int32_t normalization, int flags, pgh_graph_t* out);
 int pgh_graph_destroy(pgh_graph_t g);
 int pgh_graph_info(pgh_graph_t g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* device_bytes);
 /* human-readable description of the layout the propagation kernels stream (bench.py reports it) */

@@ -414,6 +414,33 @@ int pgh_graph_from_factored_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, con
             data[k] = ((left ? left[r] : 1.0) * w[k]) * (right ? right[indices[k]] : 1.0);      // preprocessing.py:113,138
     return pgh_graph_from_csr(n_rows, n_cols, nnz, indptr, indices, data.data(), flags, out);
 }
+int pgh_graph_from_adjacency(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                             const double* w, int32_t normalization, int flags, pgh_graph_t* out) {
+    CHECK(normalization >= 0 && normalization <= 3, "pgh_graph_from_adjacency: unknown normalization");
+    CHECK(normalization == PGH_NORM_NONE || normalization == PGH_NORM_COL || n_rows == n_cols,
+          "pgh_graph_from_adjacency: symmetric / both normalisation needs a square adjacency");
+    // preprocessing.py:109-138: degree reductions, (square-root) inverses with zero degrees left zero
+    std::vector<double> weights(nnz, 1.0), left(n_rows, 0.0), right(n_cols, 0.0);
+    if (w) weights.assign(w, w + nnz);
+    for (int64_t r = 0; r < n_rows; ++r)
+        for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k) {
+            left[r] += weights[k];
+            right[indices[k]] += weights[k];
+        }
+    const bool sq = normalization == PGH_NORM_SYMMETRIC;
+    auto inv = [&](std::vector<double>& v) {
+        for (double& x : v) {
+            if (sq) x = std::sqrt(x);
+            if (x != 0.0) x = 1.0 / x;
+        }
+    };
+    inv(left);
+    inv(right);
+    const bool use_left = normalization != PGH_NORM_NONE;
+    const bool use_right = normalization == PGH_NORM_SYMMETRIC || normalization == PGH_NORM_BOTH;
+    return pgh_graph_from_factored_csr(n_rows, n_cols, nnz, indptr, indices, weights.data(), use_left ? left.data() : nullptr,
+                                       use_right ? right.data() : nullptr, flags, out);
+}
 int pgh_graph_destroy(pgh_graph_t g) {
     delete g;
     return 0;

@@ -22,6 +22,9 @@ c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)
 
 
+NORM_COL, NORM_SYMMETRIC, NORM_NONE, NORM_BOTH = 0, 1, 2, 3      # include/pgh.h PGH_NORM_*
+
+
 class LoopCfg(C.Structure):
     _fields_ = [("alpha", C.c_double), ("use_quotient", C.c_int32), ("err_kind", C.c_int32), ("tol", C.c_double),
                 ("max_iters", C.c_int32), ("end_modulo", C.c_int32), ("out_scale", C.c_double),
@@ -90,6 +93,8 @@ SIGNATURES = {
                                      C.POINTER(c_graph)]),
     "pgh_graph_from_factored_csr": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int, C.POINTER(c_graph)]),
+    "pgh_graph_from_adjacency": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int,
+                                           C.POINTER(c_graph)]),
     "pgh_graph_destroy": (C.c_int, [c_graph]),
     "pgh_graph_info": (C.c_int, [c_graph, c_i64p, c_i64p, c_i64p, c_i64p]),
     "pgh_graph_format": (C.c_int, [c_graph, C.c_char_p, C.c_int]),

@@ -226,14 +226,47 @@ __global__ void k_f64_to_f32_g(const double* __restrict__ in, float* __restrict_
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
 }
 
-// Shared implementation of the two uploads.  factored: data holds the weights W and M = diag(left) W diag(right).
+// f64 row sums of a CSR matrix, one wavefront per row, fixed summation order.  idx != null: values are data[idx[k]]
+// (the transposed structure after the key sort: sums over the COLUMNS of the uploaded matrix)
+template <typename PtrT>
+__global__ void k_row_sums_f64(const PtrT* __restrict__ ptr, const int32_t* __restrict__ idx, const double* __restrict__ data,
+                               int64_t n_rows, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_rows; r += nwaves) {
+        double acc = 0.0;
+        for (int64_t k = (int64_t)ptr[r] + lane; k < (int64_t)ptr[r + 1]; k += 64) acc += idx ? data[idx[k]] : data[k];
+        acc = wave_reduce_sum(acc);
+        if (lane == 0) out[r] = acc;
+    }
+}
+
+// preprocessing.py:111 / numpy semantics of the reference's scaling vectors: v -> sqrt(v) (symmetric), then 1 / v where v != 0
+__global__ void k_inv_nonzero(double* __restrict__ v, int64_t n, int take_sqrt) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double x = v[i];
+        if (take_sqrt) x = sqrt(x);
+        v[i] = x != 0.0 ? 1.0 / x : x;
+    }
+}
+
+__global__ void k_fill_f64(double* p, int64_t n, double v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// Shared implementation of the uploads.
+//   factored == false: data holds the values of M.
+//   factored == true : data holds the weights W (null = all ones) and M = diag(left) W diag(right); the scale vectors
+//                      come from the host (left / right) or are evaluated here from W (device_norm = PGH_NORM_*).
 int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
-                        const double* data, bool factored, const double* left, const double* right, pgh_graph_t* out) {
+                        const double* data, bool factored, const double* left, const double* right, int device_norm,
+                        pgh_graph_t* out) {
     PGH_TRY(ensure_init());
     PGH_CHECK(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "pgh_graph_from_csr: negative size");
     PGH_CHECK(n_rows < 2147483647LL && n_cols < 2147483647LL && nnz < 2147483647LL,
               "pgh_graph_from_csr: int32 index space exceeded; row-partition the graph (SURVEY.md 8e)");
-    PGH_CHECK(indptr != nullptr && (nnz == 0 || (indices && data)), "pgh_graph_from_csr: null array");
+    PGH_CHECK(indptr != nullptr && (nnz == 0 || (indices && (data || device_norm >= 0))), "pgh_graph_from_csr: null array");
     PGH_CHECK(indptr[0] == 0 && indptr[n_rows] == nnz, "pgh_graph_from_csr: indptr does not match nnz");
     Runtime& r = rt();
     pgh_graph_s* g = new pgh_graph_s();
@@ -252,37 +285,14 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
         PGH_HIP(hipMemcpyAsync(d_indptr.p, indptr, sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, r.stream));
         if (nnz > 0) {
             PGH_HIP(hipMemcpyAsync(d_indices.p, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, r.stream));
-            PGH_HIP(hipMemcpyAsync(d_data.p, data, sizeof(double) * nnz, hipMemcpyHostToDevice, r.stream));
-        }
-        bool value_free = false;
-        if (factored) {
-            PGH_TRY(d_mult.alloc(nnz));
-            PGH_TRY(stats.alloc(2));
-            PGH_HIP(hipMemsetAsync(stats.p, 0, sizeof(unsigned long long) * 2, r.stream));
-            if (left) {
-                PGH_TRY(d_left.alloc(n_rows));
-                PGH_HIP(hipMemcpyAsync(d_left.p, left, sizeof(double) * n_rows, hipMemcpyHostToDevice, r.stream));
-            }
-            if (right) {
-                PGH_TRY(d_right.alloc(n_cols));
-                PGH_HIP(hipMemcpyAsync(d_right.p, right, sizeof(double) * n_cols, hipMemcpyHostToDevice, r.stream));
-            }
-            if (n_rows > 0 && nnz > 0)
-                k_apply_factors<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, d_data.p, left ? d_left.p : nullptr,
-                                                                                 right ? d_right.p : nullptr, n_rows, d_mult.p, stats.p);
-            unsigned long long h[2] = {0, 0};
-            PGH_HIP(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, r.stream));
-            PGH_HIP(hipStreamSynchronize(r.stream));
-            // value-free when every weight is a small positive integer and expanding the multiplicities costs < 25 % entries
-            value_free = nnz > 0 && h[0] == 0 && (double)h[1] <= 1.25 * (double)nnz + 1024.0;
-            const char* vf = getenv("PGH_VALUES");
-            if (vf != nullptr && atoi(vf) != 0) value_free = false;
+            if (data != nullptr) PGH_HIP(hipMemcpyAsync(d_data.p, data, sizeof(double) * nnz, hipMemcpyHostToDevice, r.stream));
+            else k_fill_f64<<<blocks_for(nnz), kBlock, 0, r.stream>>>(d_data.p, nnz, 1.0);
         }
         PGH_HIP(hipMalloc(&g->degrees, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
         PGH_HIP(hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_cols + 1)));
         PGH_HIP(hipMalloc(&g->col, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
         PGH_HIP(hipMalloc(&g->val, sizeof(float) * (size_t)(nnz > 0 ? nnz : 1)));
-        if (n_rows > 0) k_row_sums<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_data.p, n_rows, g->degrees);
+        // ---- structure first: sort (col, row) keys with the entry index as payload -> rows of M^T, ascending columns
         if (nnz > 0) {
             PGH_TRY(keys_a.alloc(nnz));
             PGH_TRY(keys_b.alloc(nnz));
@@ -298,17 +308,70 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
             DevBuf<char> temp;
             PGH_TRY(temp.alloc(temp_bytes));
             PGH_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (int)nnz, 0, end_bit, r.stream));
-            if (value_free) PGH_TRY(mult_t.alloc(nnz));
-            k_gather_vals<<<blocks_for(nnz), kBlock, 0, r.stream>>>(idx_b.p, d_data.p, value_free ? d_mult.p : nullptr, nnz, g->val,
-                                                                    value_free ? mult_t.p : nullptr);
             k_split_keys<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_b.p, nnz, n_cols, g->col, g->rowptr);
             PGH_HIP(hipGetLastError());
-            PGH_HIP(hipStreamSynchronize(r.stream));
         } else {
             k_fill_i32<<<blocks_for(n_cols + 1), kBlock, 0, r.stream>>>(g->rowptr, n_cols + 1, 0);
             PGH_HIP(hipGetLastError());
-            PGH_HIP(hipStreamSynchronize(r.stream));
         }
+        // ---- scale vectors
+        bool have_left = left != nullptr, have_right = right != nullptr;
+        if (factored && device_norm >= 0) {
+            // to_sparse_matrix's normalisations evaluated in HBM (preprocessing.py:109-138): left from the row sums of W,
+            // right from its column sums (rows of the transposed structure); zero-degree rows / columns stay zero
+            have_left = device_norm == PGH_NORM_COL || device_norm == PGH_NORM_SYMMETRIC || device_norm == PGH_NORM_BOTH;
+            have_right = device_norm == PGH_NORM_SYMMETRIC || device_norm == PGH_NORM_BOTH;
+            const int take_sqrt = device_norm == PGH_NORM_SYMMETRIC;
+            if (have_left) {
+                PGH_TRY(d_left.alloc(n_rows));
+                if (n_rows > 0) {
+                    k_row_sums_f64<int64_t><<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, nullptr, d_data.p, n_rows, d_left.p);
+                    k_inv_nonzero<<<blocks_for(n_rows), kBlock, 0, r.stream>>>(d_left.p, n_rows, take_sqrt);
+                }
+            }
+            if (have_right) {
+                PGH_TRY(d_right.alloc(n_cols));
+                if (n_cols > 0) {
+                    k_row_sums_f64<int32_t><<<blocks_for(n_cols * 64), kBlock, 0, r.stream>>>(g->rowptr, idx_b.p, d_data.p, n_cols, d_right.p);
+                    k_inv_nonzero<<<blocks_for(n_cols), kBlock, 0, r.stream>>>(d_right.p, n_cols, take_sqrt);
+                }
+            }
+            PGH_HIP(hipGetLastError());
+        } else if (factored) {
+            if (have_left) {
+                PGH_TRY(d_left.alloc(n_rows));
+                PGH_HIP(hipMemcpyAsync(d_left.p, left, sizeof(double) * n_rows, hipMemcpyHostToDevice, r.stream));
+            }
+            if (have_right) {
+                PGH_TRY(d_right.alloc(n_cols));
+                PGH_HIP(hipMemcpyAsync(d_right.p, right, sizeof(double) * n_cols, hipMemcpyHostToDevice, r.stream));
+            }
+        }
+        // ---- values: data[k] <- (left[row] * w[k]) * right[col] in place (original order), integer-weight census
+        bool value_free = false;
+        if (factored) {
+            PGH_TRY(d_mult.alloc(nnz));
+            PGH_TRY(stats.alloc(2));
+            PGH_HIP(hipMemsetAsync(stats.p, 0, sizeof(unsigned long long) * 2, r.stream));
+            if (n_rows > 0 && nnz > 0)
+                k_apply_factors<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, d_data.p, have_left ? d_left.p : nullptr,
+                                                                                 have_right ? d_right.p : nullptr, n_rows, d_mult.p, stats.p);
+            unsigned long long h[2] = {0, 0};
+            PGH_HIP(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipStreamSynchronize(r.stream));
+            // value-free when every weight is a small positive integer and expanding the multiplicities costs < 25 % entries
+            value_free = nnz > 0 && h[0] == 0 && (double)h[1] <= 1.25 * (double)nnz + 1024.0;
+            const char* vf = getenv("PGH_VALUES");
+            if (vf != nullptr && atoi(vf) != 0) value_free = false;
+        }
+        if (n_rows > 0) k_row_sums<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_data.p, n_rows, g->degrees);
+        if (nnz > 0) {
+            if (value_free) PGH_TRY(mult_t.alloc(nnz));
+            k_gather_vals<<<blocks_for(nnz), kBlock, 0, r.stream>>>(idx_b.p, d_data.p, value_free ? d_mult.p : nullptr, nnz, g->val,
+                                                                    value_free ? mult_t.p : nullptr);
+            PGH_HIP(hipGetLastError());
+        }
+        PGH_HIP(hipStreamSynchronize(r.stream));
         PGH_TRY(finish_graph(g));
         // the layout the propagation kernels stream (PGH_FORMAT=csr keeps only the row-major merge-path route)
         const char* fmt = getenv("PGH_FORMAT");
@@ -317,12 +380,12 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
             const bool relabel = rl == nullptr || atoi(rl) != 0;
             if (value_free) {
                 // M^T = diag(right) * W^T * diag(left): the source scale is `left` (rows of M), the output scale `right`
-                if (left) {
-                    PGH_HIP(hipMalloc(&g->keep_src, sizeof(float) * (size_t)n_rows));
+                if (have_left) {
+                    PGH_HIP(hipMalloc(&g->keep_src, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
                     k_f64_to_f32_g<<<blocks_for(n_rows), kBlock, 0, r.stream>>>(d_left.p, g->keep_src, n_rows);
                 }
-                if (right) {
-                    PGH_HIP(hipMalloc(&g->keep_dst, sizeof(float) * (size_t)n_cols));
+                if (have_right) {
+                    PGH_HIP(hipMalloc(&g->keep_dst, sizeof(float) * (size_t)(n_cols > 0 ? n_cols : 1)));
                     k_f64_to_f32_g<<<blocks_for(n_cols), kBlock, 0, r.stream>>>(d_right.p, g->keep_dst, n_cols);
                 }
                 g->keep_mult = mult_t.release();
@@ -347,14 +410,26 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
 extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
                                   const int32_t* indices, const double* data, int flags, pgh_graph_t* out) {
     (void)flags;
-    return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, data, false, nullptr, nullptr, out);
+    return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, data, false, nullptr, nullptr, -1, out);
 }
 
 extern "C" int pgh_graph_from_factored_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
                                            const int32_t* indices, const double* weights, const double* left,
                                            const double* right, int flags, pgh_graph_t* out) {
     (void)flags;
-    return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, weights, true, left, right, out);
+    PGH_CHECK(weights != nullptr || nnz == 0, "pgh_graph_from_factored_csr: null weights");
+    return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, weights, true, left, right, -1, out);
+}
+
+extern "C" int pgh_graph_from_adjacency(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                                        const int32_t* indices, const double* weights, int32_t normalization, int flags,
+                                        pgh_graph_t* out) {
+    (void)flags;
+    PGH_CHECK(normalization == PGH_NORM_COL || normalization == PGH_NORM_SYMMETRIC || normalization == PGH_NORM_NONE ||
+                  normalization == PGH_NORM_BOTH, "pgh_graph_from_adjacency: unknown normalization");
+    PGH_CHECK(normalization == PGH_NORM_NONE || normalization == PGH_NORM_COL || n_rows == n_cols,
+              "pgh_graph_from_adjacency: symmetric / both normalisation needs a square adjacency");
+    return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, weights, true, nullptr, nullptr, normalization, out);
 }
 
 extern "C" int pgh_graph_destroy(pgh_graph_t g) {

@@ -355,6 +355,23 @@ class DeviceGraph:
         return DeviceGraph(h, M.shape, len(data))
 
     @staticmethod
+    def from_adjacency(W, normalization):
+        """The preprocessor's "col" / "symmetric" / "both" / "none" normalisation of the raw adjacency W evaluated on the
+        device (include/pgh.h pgh_graph_from_adjacency); unit weights travel as structure only."""
+        import scipy.sparse as sp
+        L.ensure_init()
+        kind = {"col": L.NORM_COL, "symmetric": L.NORM_SYMMETRIC, "none": L.NORM_NONE, "both": L.NORM_BOTH}[normalization]
+        W = sp.csr_array(W) if not sp.issparse(W) or W.format != "csr" else W
+        indptr = np.ascontiguousarray(W.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(W.indices, dtype=np.int32)
+        data = np.ascontiguousarray(W.data, dtype=np.float64)
+        unit = len(data) > 0 and bool(np.all(data == 1.0))
+        h = L.c_graph()
+        L.check(L.lib().pgh_graph_from_adjacency(W.shape[0], W.shape[1], len(data), _ptr(indptr), _ptr(indices),
+                                                 None if unit else _ptr(data), kind, 0, C.byref(h)))
+        return DeviceGraph(h, W.shape, len(data))
+
+    @staticmethod
     def from_factored(W, left=None, right=None):
         """M = diag(left) W diag(right) evaluated on the device (include/pgh.h pgh_graph_from_factored_csr)."""
         import scipy.sparse as sp

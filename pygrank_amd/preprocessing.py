@@ -124,8 +124,12 @@ def graph_to_scipy(G, weight="weight"):
     return nx.to_scipy_sparse_array(G, weight=weight, dtype=float)
 
 
+def _identity(x):
+    return x
+
+
 def to_sparse_matrix(G, normalization="auto", weight="weight", renormalize=False, reduction=None,
-                     transform_adjacency=lambda x: x, cors=False):
+                     transform_adjacency=_identity, cors=False):
     """preprocessing.py:50-152.  Returns an ``Adjacency`` whose ``.array`` is the engine's backend graph."""
     name = backend.backend_name()
     if hasattr(G, "_pygrank_preprocessed"):                 # preprocessing.py:88-98 (already preprocessed input)
@@ -142,12 +146,20 @@ def to_sparse_matrix(G, normalization="auto", weight="weight", renormalize=False
         normalization = "col" if G.is_directed() else "symmetric"
     M = sp.csr_array(graph_to_scipy(G, weight), dtype=np.float64)
     renormalize = float(renormalize)
-    if renormalize != 0:                                    # preprocessing.py:107-108
-        M = M + sp.eye(M.shape[0]).tocsr() * renormalize
-    M = normalize_adjacency(M, normalization, reduction)
-    M = M if isinstance(M, sp.csr_array) else sp.csr_array(M)
-    M = transform_adjacency(M)                              # preprocessing.py:143
-    ret = Adjacency(backend.scipy_sparse_to_backend(M))     # preprocessing.py:144-145: upload to HBM
+    on_device = (name == "hip" and normalization in ("col", "symmetric", "both", "none") and renormalize == 0
+                 and reduction is None and transform_adjacency is _identity and not cors
+                 and (normalization in ("col", "none") or M.shape[0] == M.shape[1]))
+    if on_device:
+        # degree reductions, scaling and transposition in HBM; the host only hands over the raw adjacency
+        from pygrank_amd.device import DeviceGraph
+        ret = Adjacency(DeviceGraph.from_adjacency(M, normalization))
+    else:
+        if renormalize != 0:                                # preprocessing.py:107-108
+            M = M + sp.eye(M.shape[0]).tocsr() * renormalize
+        M = normalize_adjacency(M, normalization, reduction)
+        M = M if isinstance(M, sp.csr_array) else sp.csr_array(M)
+        M = transform_adjacency(M)                          # preprocessing.py:143
+        ret = Adjacency(backend.scipy_sparse_to_backend(M)) # preprocessing.py:144-145: upload to HBM
     if cors:                                                # preprocessing.py:146-148
         ret._pygrank_preprocessed = {name: ret, "numpy": Adjacency(M)}
     else:
@@ -193,7 +205,7 @@ class MethodHasher:
 
 
 def preprocessor(normalization="auto", assume_immutability=False, weight="weight", renormalize=False,
-                 reduction=None, transform_adjacency=lambda x: x, cors=False):
+                 reduction=None, transform_adjacency=_identity, cors=False):
     """preprocessing.py:233-287."""
     if assume_immutability:
         ret = MethodHasher(preprocessor(assume_immutability=False, normalization=normalization, weight=weight,

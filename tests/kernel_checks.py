@@ -324,6 +324,46 @@ def check_factored_upload_matches_valued_upload(pg):
     assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
 
 
+def check_device_preprocessor_matches_host(pg):
+    """pgh_graph_from_adjacency (normalisation evaluated in HBM) == the reference's host normalisation
+    followed by an upload: identical structure; identical f32 values for integer weights (the degree sums are exact),
+    within 1 ulp of f32 for real weights (scipy sums a row in a different order)."""
+    from pygrank_amd.device import DeviceGraph
+    from pygrank_amd.preprocessing import normalize_adjacency, to_sparse_matrix
+    rng = np.random.default_rng(17)
+    A = rmat_np.rmat_csr(13, 8, seed=3)
+    unit = sp.csr_array(A.copy())
+    unit.data[:] = 1.0
+    real = _random_matrix(rng, 1500, 1500, 0.006, hubs=3, empty_frac=0.2)
+    rect = sp.csr_array(_random_matrix(rng, 200, 700, 0.03))
+    for name, W, exact in (("rmat13_int", A, True), ("rmat13_sym", sp.csr_array(A + A.T), True), ("unit", unit, True),
+                           ("real", real, False), ("rect", rect, False), ("empty", sp.csr_array((6, 6)), True)):
+        for norm in ("col", "symmetric", "both", "none"):
+            if W.shape[0] != W.shape[1] and norm != "none":
+                continue                                            # the reference's normalisations are square-only
+            gd = DeviceGraph.from_adjacency(W, norm)
+            N = normalize_adjacency(W, norm)
+            plain = sp.csr_array((N.data.copy(), N.indices.copy(), N.indptr.copy()), shape=N.shape)
+            gh = pg.scipy_sparse_to_backend(plain)
+            a, b = gd.download_transposed(), gh.download_transposed()
+            assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices), (name, norm)
+            if exact:
+                assert np.array_equal(a.data, b.data), (name, norm)
+            else:
+                assert np.allclose(a.data, b.data, rtol=1.01 * EPS32, atol=0), (name, norm)
+            assert np.allclose(_np(pg.degrees(gd)), _np(pg.degrees(gh)), rtol=2 * EPS32, atol=1e-30), (name, norm)
+            if W.nnz and name.startswith(("rmat13", "unit")) and "host" not in gd.format():
+                assert "value-free" in gd.format(), (name, norm, gd.format())
+    # the preprocessor takes the device route for the standard normalisations and the host route otherwise
+    graph = pg.AdjacencyWrapper(A, directed=True)
+    for kw in (dict(normalization="col"), dict(normalization="symmetric"), dict(normalization="col", renormalize=True),
+               dict(normalization="laplacian")):
+        dev = to_sparse_matrix(graph, **kw).array.download_transposed()
+        host = to_sparse_matrix(graph, transform_adjacency=lambda m: m, **kw).array.download_transposed()
+        assert np.array_equal(dev.indptr, host.indptr) and np.array_equal(dev.indices, host.indices), kw
+        assert np.array_equal(dev.data, host.data), kw
+
+
 def check_slab_ops_and_wide_propagate(pg):
     """Whole-slab prologue kernels (pgh_mat_col_abssum / div_cols / get_cols / set_cols) against numpy, and propagate
     over more than 64 feature columns (two batches) against per-column rank()."""
