@@ -244,11 +244,14 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    # PGH_DIST_BACKEND=gloo with several ranks on ONE GPU: a functional test of the multi-rank device path (streams,
+    # events, in-place collectives on device scalars) on boxes with a single GPU; never a measurement
+    device_index = local_rank % torch.cuda.device_count() if use_cuda else 0
     if use_cuda:
-        torch.cuda.set_device(local_rank)
-    L.ensure_init(local_rank if use_cuda else 0)
+        torch.cuda.set_device(device_index)
+    L.ensure_init(device_index)
     if not dist.is_initialized():
-        dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend=os.environ.get("PGH_DIST_BACKEND", "nccl" if use_cuda else "gloo"))
     if args.scale is None:                      # weak scaling: fixed edges per GPU; configs[4] at 8 GPUs
         scale, ef = (27, 8) if world == 8 else (23 + int(math.log2(world)), 16)
     else:

@@ -18,13 +18,15 @@ def main():
     from pygrank_amd.device import DeviceVector
     from pygrank_amd.distributed import DistributedPageRank, rmat_partitioned
     on_gpu = os.environ.get("PGH_TEST_ENGINE") == "hip"
-    if on_gpu:                                   # tests/test_gpu_parity.py: the real engine + RCCL (world size 1 on the 1-GPU box)
-        import torch
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if on_gpu:            # tests/test_gpu_parity.py: the real engine; RCCL with one rank, or (PGH_DIST_BACKEND=gloo)
+        import torch      # several ranks sharing the single GPU of the box: the multi-rank DEVICE path, functionally
+        device = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        torch.cuda.set_device(device)
+        _lib.ensure_init(device)
     else:
         _lib._install_test_double(ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libpgh_host_oracle.so")))
     pg.load_backend("hip")
-    dist.init_process_group(backend="nccl" if on_gpu else "gloo")
+    dist.init_process_group(backend=os.environ.get("PGH_DIST_BACKEND", "nccl" if on_gpu else "gloo"))
     rank, world = dist.get_rank(), dist.get_world_size()
     graph = rmat_partitioned(scale, ef, rank, world, seed=0)
     perm = graph.perm

@@ -140,10 +140,13 @@ def test_full_size_properties_rmat20(gpu_engine):
     assert again.convergence.iteration == 2
 
 
-def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path):
-    """The N > 1 code path (relabelled slice generation, pgh_ppr_step_dist, RCCL all-gather / all-reduce on the engine
-    stream) with world size 1 on the single GPU of this box, against the oracle; world sizes 2 and 4 are covered on the
-    CPU by tests/test_distributed_cpu.py, 8 GPUs by the driver's scaling run."""
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")], ids=["rccl_x1", "gloo_x2", "gloo_x4"])
+def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend):
+    """The N > 1 code path on the real engine: relabelled slice generation, the device-driven pgh_dist_* loop, in-place
+    collectives on device scalars, the trimmed all-gather -- against the oracle.  World size 1 runs over RCCL; world sizes
+    2 and 4 share the single GPU of this box and exchange through gloo (functional coverage of the multi-rank device
+    path: RCCL refuses two ranks on one GPU).  The same logic runs on the CPU in tests/test_distributed_cpu.py; 8 GPUs
+    over RCCL/xGMI are the driver's scaling run."""
     import os
     import subprocess
     import sys
@@ -151,17 +154,17 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path):
     from oracle import ref_loops as orc, rmat_np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     scale, ef = 14, 8
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", os.path.join(root, "tests", "dist_worker.py"), str(tmp_path), str(scale), str(ef)]
-    env = dict(os.environ, PYTHONPATH=root, PGH_TEST_ENGINE="hip", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29611 + world), os.path.join(root, "tests", "dist_worker.py"), str(tmp_path), str(scale), str(ef)]
+    env = dict(os.environ, PYTHONPATH=root, PGH_TEST_ENGINE="hip", PGH_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    part = np.load(os.path.join(tmp_path, "rank0.npz"))
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     n = 1 << scale
-    perm = part["perm"]
+    perm = parts[0]["perm"]
     assert sorted(perm.tolist()) == list(range(n))
     A = rmat_np.rmat_csr(scale, ef, seed=0)
-    assert int(part["nnz"]) == A.nnz
+    assert sum(int(part["nnz"]) for part in parts) == A.nnz
     M = sp.csr_array(orc.normalize(A, "col", True))
     rng = np.random.default_rng(1)
     p_old = np.zeros(n)
@@ -172,6 +175,8 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path):
     for name, kw in cases_.items():
         want, want_iters = orc.pagerank(M, p_old, alpha=0.85, eps=EPS32, **kw)
         got = np.zeros(n)
-        got[perm] = part[name + "_ranks"]
-        assert int(part[name + "_iters"]) == want_iters, name
+        for part in parts:
+            lo, m = int(part["lo"]), int(part["n_local"])
+            got[perm[lo:lo + m]] = part[name + "_ranks"]
+            assert int(part[name + "_iters"]) == want_iters, name
         assert rel_linf(got, want) <= 1e-6, name
