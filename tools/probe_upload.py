@@ -4,7 +4,23 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pygrank_amd as pg
 from pygrank_amd import _lib as L
-from oracle import rmat_np
+
+
+
+def host_rmat(scale, ef, a=0.57, b=0.19, c=0.19, seed=0):
+    """A host-side RMAT multigraph (numpy RNG; duplicates summed into integer weights) as scipy CSR: the kind of input
+    a pygrank user hands to the preprocessor."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    n, m = 1 << scale, (1 << scale) * ef
+    src = np.zeros(m, dtype=np.int64)
+    dst = np.zeros(m, dtype=np.int64)
+    for _ in range(scale):
+        r = rng.random(m)
+        src = (src << 1) | (r >= a + b)
+        dst = (dst << 1) | (((r >= a) & (r < a + b)) | (r >= a + b + c))
+    return sp.csr_array(sp.coo_array((np.ones(m), (src, dst)), shape=(n, n)))
+
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=21)
@@ -13,7 +29,7 @@ ap.add_argument("--runs", type=int, default=10)
 args = ap.parse_args()
 pg.load_backend("hip")
 t0 = time.time()
-A = rmat_np.rmat_csr(args.scale, args.ef, seed=0)
+A = host_rmat(args.scale, args.ef)
 t_gen = time.time() - t0
 for values in ("0", "1"):
     os.environ["PGH_VALUES"] = values
@@ -26,7 +42,7 @@ for values in ("0", "1"):
     g = adj.array
     n, nnz = g.shape[0], g.nnz
     p = np.zeros(n)
-    p[rmat_np.seed_nodes(A, 100, seed=1)] = 1.0
+    p[np.random.default_rng(1).choice(np.flatnonzero(np.diff(A.indptr) > 0), 100, replace=False)] = 1.0
     sig = pg.to_signal(adj, p)
     ranker = pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=1e-6, max_iters=1000)
     ranker.rank(adj, sig)
