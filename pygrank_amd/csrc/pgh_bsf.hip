@@ -306,6 +306,7 @@ __global__ void k_permute_out(const float* __restrict__ src, const int32_t* __re
 
 // ------------------------------------------------------------------------------------------------- SpMV kernels
 struct BsfView {
+    const int64_t*  fix_dst;   // [num_tiles] index into `part` that receives tile t's fix-up, or -1
     const uint32_t* colf;      // packed: byte offset of the source inside its block
     const uint8_t*  flags8;    // [num_tiles * 64] segment-start flags of each lane's 8 entries
     const float*    val;
@@ -580,20 +581,55 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
 #undef PGH_STEP
 }
 
-// segments that cross tiles: fixed-order sum of the carries, one thread per closing tile
+// build time: where the fix-up of tile t goes (index into the partial vectors, -1 = nothing to fix), so that the
+// per-iteration kernel below needs no dependent loads
+__global__ void k_bsf_fixlist(const int4* __restrict__ tile, const int32_t* __restrict__ seg_row, BsfView f, int num_tiles,
+                              int64_t* __restrict__ fix_dst) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < num_tiles; t += gridDim.x * blockDim.x) {
+        const int4 ti = tile[t];
+        int64_t dst = -1;
+        if (ti.w >= 0 && ti.z >= 0) {
+            const int row = seg_row[ti.z];
+            if (row >= 0) {
+                int b = 0;
+                while (b + 1 < f.num_blocks && t >= f.tile_begin[b + 1]) ++b;
+                dst = (int64_t)b * f.part_stride + row;
+            }
+        }
+        fix_dst[t] = dst;
+    }
+}
+
+// segments that cross tiles: fixed-order sum of the carries, one thread per closing tile; a hub row spans hundreds of
+// tiles, so chains of 32+ tiles are summed by the whole wavefront (strided lanes + fixed reduction tree) instead of
+// leaving one thread with a serial chain of dependent loads that would set the kernel's duration
 __global__ __launch_bounds__(WG) void k_bsf_fixup(BsfView f, int num_tiles, const LoopState* __restrict__ state) {
     if (state != nullptr && state->done) return;
-    for (int t = blockIdx.x * WG + threadIdx.x; t < num_tiles; t += gridDim.x * WG) {
-        const int4 ti = f.tile[t];
-        if (ti.w < 0 || ti.z < 0) continue;
-        const int row = f.seg_row[ti.z];
-        if (row < 0) continue;
-        double total = 0.0;
-        for (int s = ti.w; s < t; ++s) total += f.tail_carry[s];
-        total += f.head_partial[t];
-        int b = 0;
-        while (b + 1 < f.num_blocks && t >= f.tile_begin[b + 1]) ++b;
-        f.part[(int64_t)b * f.part_stride + row] = (float)total;
+    const int lane = threadIdx.x & 63;
+    const int rounds = (num_tiles + gridDim.x * WG - 1) / (gridDim.x * WG);
+    for (int r = 0; r < rounds; ++r) {                    // wavefront-uniform trip count: the cooperative part uses shuffles
+        const int t = (r * gridDim.x + blockIdx.x) * WG + threadIdx.x;
+        const int64_t dst = t < num_tiles ? f.fix_dst[t] : -1;
+        const int first = dst >= 0 ? f.tile[t].w : 0;
+        const int len = dst >= 0 ? t - first : 0;
+        const bool is_long = len >= 32;
+        if (dst >= 0 && !is_long) {
+            double total = 0.0;
+            for (int s = first; s < t; ++s) total += f.tail_carry[s];
+            total += f.head_partial[t];
+            f.part[dst] = (float)total;
+        }
+        unsigned long long todo = __ballot(is_long);
+        while (todo != 0ULL) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1ULL;
+            const int c_first = __shfl(first, src, 64), c_t = __shfl(t, src, 64);
+            double part_sum = 0.0;
+            for (int s = c_first + lane; s < c_t; s += 64) part_sum += f.tail_carry[s];
+            part_sum = wave_reduce_sum(part_sum);
+            const double total = __shfl(part_sum, 0, 64) + f.head_partial[c_t];
+            if (lane == src) f.part[dst] = (float)total;
+        }
     }
 }
 
@@ -629,6 +665,7 @@ __global__ __launch_bounds__(WG) void k_bsf_combine(const float* __restrict__ pa
 
 BsfView view_of(const BsfFormat& f) {
     BsfView v;
+    v.fix_dst = f.fix_dst;
     v.colf = f.colf;
     v.flags8 = f.flags8;
     v.val = f.val;
@@ -769,6 +806,7 @@ int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor)
 void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.colf);
     (void)hipFree(f.flags8);
+    (void)hipFree(f.fix_dst);
     (void)hipFree(f.live_dev);
     (void)hipFree(f.val);
     (void)hipFree(f.seg_row);
@@ -1009,6 +1047,10 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipMemcpyAsync(f.live, f.live_dev, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
         for (int b = 0; b < 8; ++b) f.xg_base[b] = (int64_t)b * blk;
+        PGH_HIP(hipMalloc(&f.fix_dst, sizeof(int64_t) * (size_t)(f.num_tiles + 1)));
+        k_bsf_fixlist<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.tile, f.seg_row, view_of(f), f.num_tiles, f.fix_dst);
+        PGH_HIP(hipGetLastError());
+        PGH_HIP(hipStreamSynchronize(r.stream));
         // The engine's own gather vector (graphs with a source scale: xg = y * src_scale, written by the epilogue) keeps
         // only the referenced prefix of every block.  Partitioned graphs get their layout from the caller instead.
         if (src_old != nullptr && g->part_perm == nullptr && env_int("PGH_TRIM", 1)) {
