@@ -34,7 +34,7 @@ ALPHA, TOL, MAX_ITERS, SEEDS = 0.85, 1e-6, 1000, 100
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 # HBM traffic of the step kernels: rocprofv3 --pmc passes of this same command (tools/gpu_bench_call.sh), summarised by
 # tools/summarize_pmc.py with the guide's gfx950 corrections; counters cannot be read from inside the timed process
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_n1_v7_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_n1_final_pmc.json")
 
 
 def seeds_for(step, candidates, count=SEEDS):
