@@ -123,6 +123,26 @@ def single_gpu(args):
                     traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=alg_bytes,
                     avg_launch_us=round(step_us, 2), format=g.format(), kernels_avg_us={k: (round(v["avg_us"], 2) if v["avg_us"] else None) for k, v in prof.items()})
 
+    # ---- the other filters of the path on the same resident graph (8 nnz + 20 n per polynomial term,
+    # 8 nnz + 24 n per absorbing step); reported beside the headline, not part of `value`
+    secondary = {}
+    if not args.no_secondary:
+        for label, other, per_step in (("heat_kernel_t5_31_iterations", pg.HeatKernel(5, error_type="iters", max_iters=31), 8 * nnz + 20 * n),
+                                       ("absorbing_walks_a085_l1_1e-6", pg.AbsorbingWalks(ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS),
+                                        8 * nnz + 24 * n)):
+            other.rank(adj, personalizations[0])
+            L.check(lib.pgh_sync())
+            t1 = time.perf_counter()
+            count, loop = 0, 0.0
+            for step in range(3):
+                other.rank(adj, personalizations[step % total])
+                count += other.last_loop["spmv"]
+                loop += other.last_loop["loop_ms"]
+            L.check(lib.pgh_sync())
+            dt = time.perf_counter() - t1
+            secondary[label] = dict(gteps=round(nnz * count / dt / 1e9, 2), device_step_us=round(loop / count * 1e3, 1),
+                                    nominal_gbs=round(per_step / (loop / count * 1e-3) / 1e9, 1), spmv_per_run=count // 3)
+
     # ---- CPU baseline + parity: the oracle's scipy loop (= reference numpy backend), same graph, same seeds
     cpu = None
     parity = None
@@ -149,7 +169,7 @@ def single_gpu(args):
                     alpha=ALPHA, tol=TOL, error_type="L1", seeds=SEEDS, iterations_per_step=iters,
                     spmv_per_step=spmv_total / args.steps, device_loop_ms_per_step=round(loop_ms_total / args.steps, 4),
                     graph_build_s=round(build_s, 2), parallelism="1 GPU"),
-        roofline=roofline, cpu_baseline=cpu, parity=parity)
+        roofline=roofline, cpu_baseline=cpu, parity=parity, secondary=secondary)
 
 
 _REAL_STDOUT = None
@@ -188,6 +208,7 @@ def main():
     ap.add_argument("--scale", type=int, default=None, help="override the RMAT scale (default: 23 + log2(gpus))")
     ap.add_argument("--ef", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the HeatKernel / AbsorbingWalks side measurements")
     ap.add_argument("--force-partitioned", action="store_true", help="run the row-partitioned path even with one rank")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -7,7 +7,7 @@ import bench
 
 
 def test_single_gpu_leg_fields(host_engine):
-    args = argparse.Namespace(gpus=1, steps=2, warmup=1, scale=10, ef=8, no_cpu=False)
+    args = argparse.Namespace(gpus=1, steps=2, warmup=1, scale=10, ef=8, no_cpu=False, no_secondary=False)
     out = bench.single_gpu(args)
     line = json.loads(json.dumps(out))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -20,3 +20,5 @@ def test_single_gpu_leg_fields(host_engine):
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["peak"] == 8000.0
     assert line["parity"]["rel_linf"] <= 1e-6
     assert line["parity"]["gpu_iterations"] == line["parity"]["cpu_iterations"]
+    assert set(line["secondary"]) == {"heat_kernel_t5_31_iterations", "absorbing_walks_a085_l1_1e-6"}
+    assert line["secondary"]["heat_kernel_t5_31_iterations"]["spmv_per_run"] in (29, 30)
