@@ -51,7 +51,7 @@ def measured_traffic(scale, ef, blocked):
         pmc = json.load(f)
     total = 0.0
     for name, row in pmc.items():
-        if name.startswith(("k_bsf_partial", "k_bsf_fixup", "k_bsf_combine")):
+        if name.startswith(("k_bsf_partial", "k_bsf_fixup", "k_bsf_combine", "k_pb_gather", "k_pb_accumulate")):
             total += row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
     return (int(total), os.path.relpath(PMC_SUMMARY, ROOT)) if total > 0 else (None, None)
 
@@ -103,21 +103,22 @@ def single_gpu(args):
     run(total - 1)
     L.check(lib.pgh_profile_enable(0))
     prof = {}
-    for kid, name in ((L.K_SPMV, "spmv"), (L.K_FIXUP, "fixup"), (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual"),
-                      (L.K_FINAL, "close")):
+    for kid, name in ((L.K_SPMV, "spmv"), (L.K_PB_GATHER, "pb_gather"), (L.K_PB_ACCUM, "pb_accumulate"), (L.K_FIXUP, "fixup"),
+                      (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual"), (L.K_FINAL, "close")):
         cnt, ms = C.c_int64(), C.c_double()
         L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
         prof[name] = dict(launches=cnt.value, avg_us=(ms.value / cnt.value * 1e3) if cnt.value else None)
     alg_bytes = 8 * nnz + 16 * n                     # fused PPR step, per launch
     # the fused PPR step (SpMV + axpby epilogue + sum(y)) is one launch on the row-major layout and three launches
     # (block partials, cross-tile fix-up, combine + epilogue) on the blocked layout: its duration is their sum
-    step_kernels = [k for k in ("spmv", "fixup", "combine") if prof[k]["avg_us"]]
+    step_kernels = [k for k in ("spmv", "pb_gather", "pb_accumulate", "fixup", "combine") if prof[k]["avg_us"]]
     step_us = sum(prof[k]["avg_us"] for k in step_kernels)
     achieved = alg_bytes / (step_us * 1e-6) / 1e9
     blocked = prof["combine"]["avg_us"] is not None
     traffic, traffic_source = measured_traffic(scale, ef, blocked)
     roofline = dict(bound="hbm",
-                    kernel=("k_bsf_partial + k_bsf_fixup + k_bsf_combine<AXPBY>" if blocked else "k_spmv_merge<AXPBY> + k_spmv_fixup")
+                    kernel=(("k_bsf_partial + k_pb_gather + k_pb_accumulate + k_bsf_fixup + k_bsf_combine<AXPBY>" if prof["pb_gather"]["avg_us"]
+                             else "k_bsf_partial + k_bsf_fixup + k_bsf_combine<AXPBY>") if blocked else "k_spmv_merge<AXPBY> + k_spmv_fixup")
                     + " (one fused PPR step)",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=alg_bytes,

@@ -53,7 +53,8 @@ int pgh_timer_elapsed_ms(pgh_timer_t t, double* ms);   /* synchronises on the st
 
 /* per-kernel HIP-event profiling of the propagation kernels (bench.py roofline leg) */
 enum { PGH_K_SPMV = 0, PGH_K_FIXUP = 1, PGH_K_RESIDUAL = 2, PGH_K_FINAL = 3, PGH_K_SPMM = 4, PGH_K_COMBINE = 5,
-       PGH_K_COUNT = 6 };
+       PGH_K_PB_GATHER = 6, PGH_K_PB_ACCUM = 7,     /* propagation-blocking passes of the cold tail (pgh_pb.hip) */
+       PGH_K_COUNT = 8 };
 int pgh_profile_enable(int on);
 int pgh_profile_reset(void);
 int pgh_profile_read(int kernel_id, int64_t* launches, double* total_ms);

@@ -133,7 +133,7 @@ ADD, SUB, MUL, DIV, POW, MAXOP, MINOP, GT, GE, LT, LE, EQ, NE = range(13)
 ABS, EXP, LOG, NEG, SQRT, SAFE_INV = range(6)
 SUM, ABSSUM, MAX, MIN = range(4)
 ERR_MABS, ERR_L1, ERR_LINF, ERR_ITERS = range(4)
-K_SPMV, K_FIXUP, K_RESIDUAL, K_FINAL, K_SPMM, K_COMBINE = range(6)
+K_SPMV, K_FIXUP, K_RESIDUAL, K_FINAL, K_SPMM, K_COMBINE, K_PB_GATHER, K_PB_ACCUM = range(8)
 
 _lib = None
 _is_test_double = False

@@ -175,6 +175,24 @@ __global__ void k_bsf_pack(uint32_t* __restrict__ colf, uint32_t* __restrict__ v
     }
 }
 
+// 1 + highest referenced slot of every block, over all entries of the sorted stream (sentinels point at slot 0)
+__global__ void k_bsf_live(const uint64_t* __restrict__ keys, int64_t E, int blk, int32_t* __restrict__ live) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[e];
+        const int b = (int)(key >> 58);
+        const int loc = (int)((int64_t)(key & kLow29) - (int64_t)b * blk);
+        if (loc + 1 > live[b]) atomicMax(&live[b], loc + 1);
+    }
+}
+
+__global__ void k_bsf_is_hot(const uint64_t* __restrict__ keys, int64_t E, int blk, int hot, unsigned char* __restrict__ flag) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[e];
+        const int b = (int)(key >> 58);
+        flag[e] = ((int64_t)(key & kLow29) - (int64_t)b * blk) < hot ? 1 : 0;
+    }
+}
+
 // diagnostics (PGH_DEBUG=1): entries whose column falls inside the per-workgroup hot cache
 __global__ void k_bsf_count_hot(const uint32_t* __restrict__ colf, int64_t E, int blk, int hot, unsigned long long* __restrict__ out) {
     unsigned long long local = 0;
@@ -382,7 +400,7 @@ __device__ __forceinline__ float wave_segmented_sum(float keep, float val) {
 // register moves): column stream of tile t+2, gathers of tile t+1, arithmetic of tile t.  In-tile sums are f32 (a
 // lane adds at most IPT terms, the 64-lane stitch is a log-depth DPP segmented scan); pieces of segments that cross
 // tiles are carried in f64 and combined in a fixed order by k_bsf_fixup (deterministic, atomic-free).
-template <int IPT, bool HAS_VAL>
+template <int IPT, bool HAS_VAL, bool COLD>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
                                                               const LoopState* __restrict__ state) {
     static_assert(IPT == 8, "one flag byte per lane; lanes fetch their entries as 16-byte words");
@@ -474,7 +492,8 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
             g.c[k] = 0.f;
 #else
             g.h[k] = *reinterpret_cast<const float*>(lds + min(w, hot4));
-            g.c[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cold_rsrc, w - hot4, 0, PGH_COLD_AUX));
+            // COLD = false: the stream holds hot entries only (the cold ones live in the propagation-blocking image)
+            g.c[k] = COLD ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cold_rsrc, w - hot4, 0, PGH_COLD_AUX)) : 0.f;
 #endif
             if (HAS_VAL) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
         }
@@ -635,7 +654,8 @@ __global__ __launch_bounds__(WG) void k_bsf_fixup(BsfView f, int num_tiles, cons
 
 // fold the B block partials, apply the filter epilogue, write the next gather vector
 template <int MODE, int B>
-__global__ __launch_bounds__(WG) void k_bsf_combine(const float* __restrict__ part, int64_t part_stride, int64_t n_out,
+__global__ __launch_bounds__(WG) void k_bsf_combine(const float* __restrict__ part, const float* __restrict__ cold,
+                                                     int64_t part_stride, int64_t n_out,
                                                      const float* __restrict__ dst_scale, EpiParams ep,
                                                      const LoopState* __restrict__ state, double* __restrict__ partial_sum,
                                                      double* __restrict__ partial_delta) {
@@ -652,6 +672,7 @@ __global__ __launch_bounds__(WG) void k_bsf_combine(const float* __restrict__ pa
         double s = 0.0;
 #pragma unroll
         for (int b = 0; b < B; ++b) s += (double)part[(int64_t)b * part_stride + i];
+        if (cold != nullptr) s += (double)cold[i];
         if (dst_scale != nullptr) s *= (double)dst_scale[i];
         apply_epilogue<MODE>(ep, a_eff, (int)i, (float)s, sum_y, delta);
     }
@@ -709,9 +730,15 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state) 
     const int main_grid = r.num_cus;                  // one workgroup per CU; a multiple of 8 (XCD-affine blocks)
     {
         ProfScope prof(PGH_K_SPMV);
-        if (f.val) k_bsf_partial<kIPT, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
-        else k_bsf_partial<kIPT, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+        if (f.pb.enabled) {
+            if (f.val) k_bsf_partial<kIPT, true, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+            else k_bsf_partial<kIPT, false, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+        } else {
+            if (f.val) k_bsf_partial<kIPT, true, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+            else k_bsf_partial<kIPT, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+        }
     }
+    PGH_TRY(pb_launch(g, xg, state));              // cold entries: two streaming passes -> f.pb.out
     {
         ProfScope prof(PGH_K_FIXUP);
         int fix_grid = (f.num_tiles + WG - 1) / WG;
@@ -730,13 +757,14 @@ int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* sta
     const int cgrid = bsf_combine_grid(f.n_out);
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
+    const float* cold = f.pb.enabled ? f.pb.out : nullptr;
     {
         ProfScope prof(PGH_K_COMBINE);
         switch (f.num_blocks) {
-            case 1: k_bsf_combine<MODE, 1><<<cgrid, WG, 0, r.stream>>>(f.part, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
-            case 2: k_bsf_combine<MODE, 2><<<cgrid, WG, 0, r.stream>>>(f.part, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
-            case 4: k_bsf_combine<MODE, 4><<<cgrid, WG, 0, r.stream>>>(f.part, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
-            default: k_bsf_combine<MODE, 8><<<cgrid, WG, 0, r.stream>>>(f.part, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            case 1: k_bsf_combine<MODE, 1><<<cgrid, WG, 0, r.stream>>>(f.part, cold, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            case 2: k_bsf_combine<MODE, 2><<<cgrid, WG, 0, r.stream>>>(f.part, cold, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            case 4: k_bsf_combine<MODE, 4><<<cgrid, WG, 0, r.stream>>>(f.part, cold, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            default: k_bsf_combine<MODE, 8><<<cgrid, WG, 0, r.stream>>>(f.part, cold, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
         }
     }
     PGH_HIP(hipGetLastError());
@@ -804,6 +832,7 @@ int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor)
 }
 
 void bsf_destroy(BsfFormat& f) {
+    pb_destroy(f.pb);
     (void)hipFree(f.colf);
     (void)hipFree(f.flags8);
     (void)hipFree(f.fix_dst);
@@ -933,6 +962,42 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         else PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)E, 0, 61, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
+    // ---- referenced prefix of every block (over ALL entries), then the cold tail moves to its own image (pgh_pb.hip)
+    int live_all[8] = {0};
+    {
+        DevBuf<int32_t> d_live;
+        PGH_TRY(d_live.alloc(8, true));
+        k_bsf_live<<<blocks_for(E), kBlock, 0, r.stream>>>(keys_b.p, E, blk, d_live.p);
+        PGH_HIP(hipMemcpyAsync(live_all, d_live.p, sizeof(live_all), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+    }
+    const int hot_slots = kBsfHot < blk ? kBsfHot : blk;
+    if (!batch_layout && g->part_perm == nullptr && hot_slots < blk && E > B) {
+        DevBuf<unsigned char> is_hot;
+        DevBuf<int64_t> num_hot;
+        PGH_TRY(is_hot.alloc(E));
+        PGH_TRY(num_hot.alloc(1));
+        k_bsf_is_hot<<<blocks_for(E), kBlock, 0, r.stream>>>(keys_b.p, E, blk, hot_slots, is_hot.p);
+        size_t temp_bytes = 0;
+        PGH_HIP(hipcub::DevicePartition::Flagged(nullptr, temp_bytes, keys_b.p, is_hot.p, keys_a.p, num_hot.p, (int)E, r.stream));
+        DevBuf<char> temp;
+        PGH_TRY(temp.alloc(temp_bytes));
+        // hot entries first, in stream order; the cold ones behind them (reversed; their image sorts them again)
+        PGH_HIP(hipcub::DevicePartition::Flagged(temp.p, temp_bytes, keys_b.p, is_hot.p, keys_a.p, num_hot.p, (int)E, r.stream));
+        int64_t E_hot = 0;
+        PGH_HIP(hipMemcpyAsync(&E_hot, num_hot.p, sizeof(int64_t), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        if (pb_wanted(f, E - E_hot, E, live_all, hot_slots)) {
+            if (val) {
+                PGH_HIP(hipcub::DevicePartition::Flagged(temp.p, temp_bytes, f.val, is_hot.p, vals_a.p, num_hot.p, (int)E, r.stream));
+                PGH_HIP(hipStreamSynchronize(r.stream));
+            }
+            PGH_TRY(pb_build(f, keys_a.p + E_hot, val ? vals_a.p + E_hot : nullptr, E - E_hot, live_all, hot_slots));
+            std::swap(keys_a.p, keys_b.p);                 // keys_b: the hot entries, still sorted by (block, row, col)
+            if (val) std::swap(f.val, vals_a.p);
+            E = E_hot;
+        }
+    }
     // ---- pad every block to whole tiles: every wavefront tile is full, 16-byte aligned and never straddles blocks.
     //      Pad entries repeat the block's sentinel key: no flag, they only feed the sentinel's never-closed segment.
     TileBuild tb;
@@ -1046,6 +1111,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipGetLastError());
         PGH_HIP(hipMemcpyAsync(f.live, f.live_dev, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
+        for (int b = 0; b < 8; ++b) f.live[b] = live_all[b] > f.live[b] ? live_all[b] : f.live[b];   // the cold image's sources count too
         for (int b = 0; b < 8; ++b) f.xg_base[b] = (int64_t)b * blk;
         PGH_HIP(hipMalloc(&f.fix_dst, sizeof(int64_t) * (size_t)(f.num_tiles + 1)));
         k_bsf_fixlist<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.tile, f.seg_row, view_of(f), f.num_tiles, f.fix_dst);

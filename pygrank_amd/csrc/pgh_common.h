@@ -132,8 +132,39 @@ struct pgh_timer_s {
 //     so neither row pointers nor empty rows are read by the SpMV pass;
 //   * value-free when M^T = diag(dst_scale) * W * diag(src_scale) with small integer W: multiplicities are
 //     stored as repeated entries (4 B/edge), the scales move into the gather vector and the epilogue.
+// Propagation-blocking image of the COLD entries of the blocked stream (sources outside the LDS hot cache), see
+// pgh_pb.hip: two streaming passes replace their random 4-byte gathers.
+struct PbFormat {
+    bool      enabled = false;
+    int64_t   num_entries = 0;      // cold entries (multiplicities expanded)
+    int       chunk = 0;            // sources per chunk (phase A keeps one chunk of the gather vector in LDS)
+    int       num_chunks = 0;
+    int       rows_per_bin = 0;     // output rows per wavefront bin (phase B keeps their f64 sums in LDS)
+    int       num_bins = 0;
+    int       hot = 0;              // sources of every block that stay in the hot cache (not part of this image)
+    int64_t   cold_prefix[9] = {0}; // first cold id of every block (cold ids number the referenced cold sources, block-major)
+    uint16_t* sloc = nullptr;       // [num_entries] source index inside its chunk, order (chunk, bin, row, source)
+    uint16_t* dloc = nullptr;       // [num_entries] output row inside its bin
+    float*    val = nullptr;        // [num_entries] or null (value-free)
+    uint32_t* run_start = nullptr;  // [num_bins][num_chunks] first entry of run (bin, chunk)
+    uint32_t* run_len = nullptr;    // [num_bins][num_chunks]
+    int       num_tasks = 0;
+    int4*     task = nullptr;       // phase A work list {chunk, entry_begin, entry_end, 0}
+    // phase B work list: a unit = a slice [first, last) of one bin's entries (its runs concatenated in chunk order), capped
+    // so that hub rows do not serialise a bin; a bin cut into several units is summed from per-unit f64 partials
+    int       num_units = 0;
+    int4*     unit = nullptr;       // {bin, first, last, extra slot or -1 (the only unit of its bin: writes `out` directly)}
+    int       num_merges = 0;
+    int4*     merge = nullptr;      // {bin, first extra slot, slot count, 0}
+    double*   extra = nullptr;      // [extra slots][rows_per_bin]
+    float*    tmp = nullptr;        // [num_entries] gathered (and weighted) source values, same order
+    float*    out = nullptr;        // [n_out] cold part of every row sum (structurally empty rows stay 0)
+    int64_t   device_bytes = 0;
+};
+
 struct BsfFormat {
     bool      enabled = false;
+    PbFormat  pb;
     int       num_blocks = 1;       // B in {1, 2, 4, 8}
     int       blk_size = 0;         // sources per block
     int       n_src = 0;            // length of the gather vector (rows of M)

@@ -478,9 +478,12 @@ extern "C" int pgh_graph_format(pgh_graph_t g, char* buf, int buflen) {
     PGH_CHECK(g && buf && buflen > 0, "pgh_graph_format: null argument");
     if (g->bsf.enabled) {
         const BsfFormat& f = g->bsf;
-        snprintf(buf, buflen, "bsf: %d column blocks x %d sources, %s, %s entries (%d B/edge), %lld entries, %d wavefront tiles, LDS hot cache %d",
-                 f.num_blocks, f.blk_size, f.relabelled ? "relabelled by source count" : "original ids",
-                 f.val ? "f32-valued" : "value-free", f.val ? 8 : 4, (long long)f.num_entries, f.num_tiles, PGH_BSF_HOT);
+        int used = snprintf(buf, buflen, "bsf: %d column blocks x %d sources, %s, %s entries (%d B/edge), %lld entries, %d wavefront tiles, LDS hot cache %d",
+                            f.num_blocks, f.blk_size, f.relabelled ? "relabelled by source count" : "original ids",
+                            f.val ? "f32-valued" : "value-free", f.val ? 8 : 4, (long long)f.num_entries, f.num_tiles, PGH_BSF_HOT);
+        if (f.pb.enabled && used > 0 && used < buflen)
+            snprintf(buf + used, buflen - used, "; cold tail: propagation-blocking image, %lld entries in %d chunks x %d bins",
+                     (long long)f.pb.num_entries, f.pb.num_chunks, f.pb.num_bins);
     } else {
         snprintf(buf, buflen, "csr32+f32 row-major merge-path (8 B/edge), %d tiles of %d items", g->num_tiles, g->items_per_tile);
     }

@@ -90,6 +90,11 @@ __device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff
 
 
 // blocked-format entry points (pgh_bsf.hip)
+// pgh_pb.hip: propagation-blocking image of the cold entries
+bool pb_wanted(const BsfFormat& f, int64_t cold_entries, int64_t all_entries, const int* live, int hot);
+int pb_build(BsfFormat& f, const uint64_t* cold_keys, const float* cold_vals, int64_t count, const int* live, int hot);
+int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state);
+void pb_destroy(PbFormat& p);
 int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state);
 template <int MODE>
 int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* state, int* num_partials);

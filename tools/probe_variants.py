@@ -43,7 +43,7 @@ def main():
                 out.append(f"loop/iter={per*1e3:7.1f}us GTEPS={nnz/per/1e6:6.1f} alg={bytes_iter/per/1e6:5.0f}GB/s")
             else:
                 parts = []
-                for kid, name in ((0, "spmv"), (1, "fixup"), (5, "combine"), (2, "resid"), (3, "final")):
+                for kid, name in ((0, "spmv"), (6, "pbA"), (7, "pbB"), (1, "fixup"), (5, "combine"), (2, "resid"), (3, "final")):
                     cnt, ms = C.c_int64(), C.c_double()
                     lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms))
                     if cnt.value:
