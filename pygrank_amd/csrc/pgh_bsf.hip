@@ -730,7 +730,7 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state) 
     const int main_grid = r.num_cus;                  // one workgroup per CU; a multiple of 8 (XCD-affine blocks)
     {
         ProfScope prof(PGH_K_SPMV);
-        if (f.pb.enabled) {
+        if (f.pb.enabled && !f.pb.k1_cold) {
             if (f.val) k_bsf_partial<kIPT, true, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
             else k_bsf_partial<kIPT, false, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
         } else {
@@ -978,22 +978,27 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_TRY(is_hot.alloc(E));
         PGH_TRY(num_hot.alloc(1));
         k_bsf_is_hot<<<blocks_for(E), kBlock, 0, r.stream>>>(keys_b.p, E, blk, hot_slots, is_hot.p);
-        size_t temp_bytes = 0;
-        PGH_HIP(hipcub::DevicePartition::Flagged(nullptr, temp_bytes, keys_b.p, is_hot.p, keys_a.p, num_hot.p, (int)E, r.stream));
-        DevBuf<char> temp;
-        PGH_TRY(temp.alloc(temp_bytes));
-        // hot entries first, in stream order; the cold ones behind them (reversed; their image sorts them again)
-        PGH_HIP(hipcub::DevicePartition::Flagged(temp.p, temp_bytes, keys_b.p, is_hot.p, keys_a.p, num_hot.p, (int)E, r.stream));
-        int64_t E_hot = 0;
-        PGH_HIP(hipMemcpyAsync(&E_hot, num_hot.p, sizeof(int64_t), hipMemcpyDeviceToHost, r.stream));
-        PGH_HIP(hipStreamSynchronize(r.stream));
-        if (pb_wanted(f, E - E_hot, E, live_all, hot_slots)) {
+        PbPlan plan;
+        bool use_pb = false;
+        PGH_TRY(pb_plan(f, keys_b.p, E, live_all, hot_slots, is_hot.p, &plan, &use_pb));   // may keep heavy rows in the stream
+        if (use_pb) {
+            size_t temp_bytes = 0;
+            PGH_HIP(hipcub::DevicePartition::Flagged(nullptr, temp_bytes, keys_b.p, is_hot.p, keys_a.p, num_hot.p, (int)E, r.stream));
+            DevBuf<char> temp;
+            PGH_TRY(temp.alloc(temp_bytes));
+            // stream entries first, in order; the image's entries behind them (reversed; the image sorts them again)
+            PGH_HIP(hipcub::DevicePartition::Flagged(temp.p, temp_bytes, keys_b.p, is_hot.p, keys_a.p, num_hot.p, (int)E, r.stream));
+            int64_t E_hot = 0;
+            PGH_HIP(hipMemcpyAsync(&E_hot, num_hot.p, sizeof(int64_t), hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipStreamSynchronize(r.stream));
             if (val) {
                 PGH_HIP(hipcub::DevicePartition::Flagged(temp.p, temp_bytes, f.val, is_hot.p, vals_a.p, num_hot.p, (int)E, r.stream));
                 PGH_HIP(hipStreamSynchronize(r.stream));
             }
-            PGH_TRY(pb_build(f, keys_a.p + E_hot, val ? vals_a.p + E_hot : nullptr, E - E_hot, live_all, hot_slots));
-            std::swap(keys_a.p, keys_b.p);                 // keys_b: the hot entries, still sorted by (block, row, col)
+            const int rc_pb = pb_build(f, &plan, keys_a.p + E_hot, val ? vals_a.p + E_hot : nullptr, E - E_hot, live_all, hot_slots);
+            pb_plan_release(&plan);
+            PGH_TRY(rc_pb);
+            std::swap(keys_a.p, keys_b.p);                 // keys_b: the stream's entries, still sorted by (block, row, col)
             if (val) std::swap(f.val, vals_a.p);
             E = E_hot;
         }

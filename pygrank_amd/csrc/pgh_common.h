@@ -136,28 +136,26 @@ struct pgh_timer_s {
 // pgh_pb.hip: two streaming passes replace their random 4-byte gathers.
 struct PbFormat {
     bool      enabled = false;
-    int64_t   num_entries = 0;      // cold entries (multiplicities expanded)
+    bool      k1_cold = false;      // rows too heavy for a bin keep their cold entries in the blocked stream
+    int64_t   num_entries = 0;      // cold entries in the image (multiplicities expanded)
     int       chunk = 0;            // sources per chunk (phase A keeps one chunk of the gather vector in LDS)
     int       num_chunks = 0;
-    int       rows_per_bin = 0;     // output rows per wavefront bin (phase B keeps their f64 sums in LDS)
-    int       num_bins = 0;
+    int       num_bins = 0;         // bins = runs of consecutive output rows with <= kPbBinEntries cold entries
     int       hot = 0;              // sources of every block that stay in the hot cache (not part of this image)
     int64_t   cold_prefix[9] = {0}; // first cold id of every block (cold ids number the referenced cold sources, block-major)
-    uint16_t* sloc = nullptr;       // [num_entries] source index inside its chunk, order (chunk, bin, row, source)
-    uint16_t* dloc = nullptr;       // [num_entries] output row inside its bin
+    // phase A order: (chunk, bin, row, source)
+    uint16_t* sloc = nullptr;       // [num_entries] source index inside its chunk
     float*    val = nullptr;        // [num_entries] or null (value-free)
-    uint32_t* run_start = nullptr;  // [num_bins][num_chunks] first entry of run (bin, chunk)
-    uint32_t* run_len = nullptr;    // [num_bins][num_chunks]
     int       num_tasks = 0;
-    int4*     task = nullptr;       // phase A work list {chunk, entry_begin, entry_end, 0}
-    // phase B work list: a unit = a slice [first, last) of one bin's entries (its runs concatenated in chunk order), capped
-    // so that hub rows do not serialise a bin; a bin cut into several units is summed from per-unit f64 partials
-    int       num_units = 0;
-    int4*     unit = nullptr;       // {bin, first, last, extra slot or -1 (the only unit of its bin: writes `out` directly)}
-    int       num_merges = 0;
-    int4*     merge = nullptr;      // {bin, first extra slot, slot count, 0}
-    double*   extra = nullptr;      // [extra slots][rows_per_bin]
-    float*    tmp = nullptr;        // [num_entries] gathered (and weighted) source values, same order
+    int4*     task = nullptr;       // phase A pieces {chunk, entry_begin, entry_end, 0}: consecutive ranges of the entry stream
+    int*      task_range = nullptr; // [num_tasks + 1] pieces of every phase A workgroup (equal shares of the stream)
+    float*    tmp = nullptr;        // [num_entries] gathered (and weighted) source values, phase A order
+    // phase B: per bin the runs (one per chunk) that hold its entries in tmp, and its entries in row-major order
+    uint32_t* run_start = nullptr;  // [num_bins][num_chunks] first entry of run (bin, chunk) in tmp
+    uint32_t* run_len = nullptr;    // [num_bins][num_chunks]
+    int4*     bin = nullptr;        // [num_bins] {first output row, rows, first row-major entry, entries}
+    uint16_t* perm = nullptr;       // [num_entries] row-major order: position of the entry inside its bin's staged region
+    uint16_t* drow = nullptr;       // [num_entries] row-major order: output row inside the bin
     float*    out = nullptr;        // [n_out] cold part of every row sum (structurally empty rows stay 0)
     int64_t   device_bytes = 0;
 };

@@ -91,8 +91,17 @@ __device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff
 
 // blocked-format entry points (pgh_bsf.hip)
 // pgh_pb.hip: propagation-blocking image of the cold entries
-bool pb_wanted(const BsfFormat& f, int64_t cold_entries, int64_t all_entries, const int* live, int hot);
-int pb_build(BsfFormat& f, const uint64_t* cold_keys, const float* cold_vals, int64_t count, const int* live, int hot);
+struct PbPlan {
+    int4*    bin = nullptr;        // device: {first row, rows, first row-major entry, entries}
+    int32_t* row_bin = nullptr;    // device: bin of every output row, -1 = too heavy for a bin
+    int      num_bins = 0, num_chunks = 0;
+    int64_t  entries = 0;          // cold entries that go into the image
+    int64_t  padded_entries = 0;   // row-major slots (every bin's range padded to a multiple of 8)
+    bool     heavy_rows = false;   // some rows keep their cold entries in the blocked stream
+};
+int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int hot, unsigned char* is_hot, PbPlan* plan, bool* use);
+int pb_build(BsfFormat& f, PbPlan* plan, const uint64_t* cold_keys, const float* cold_vals, int64_t count, const int* live, int hot);
+void pb_plan_release(PbPlan* plan);
 int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state);
 void pb_destroy(PbFormat& p);
 int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state);
