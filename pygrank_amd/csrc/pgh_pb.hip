@@ -183,25 +183,35 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
     int loaded = -1;
     for (int piece = piece_begin; piece < piece_end; ++piece) {
         const int4 task = f.task[piece];
-        if (task.x != loaded) {
+#ifndef PGH_PROBE_PB
+#define PGH_PROBE_PB 0
+#endif
+        if (task.x != loaded && !(PGH_PROBE_PB & 1)) {
             __syncthreads();
+            // cold ids [first_id, first_id + chunk) -> positions in the gather vector, block by block: the block loop is
+            // unrolled so that the layout tables are read with constant indices (scalar loads), and a thread keeps 8
+            // independent loads in flight
             const int64_t first_id = (int64_t)task.x * f.chunk;
-            static_assert(kPbChunk % (kPbThreads * 8) == 0, "the chunk fill keeps 8 loads per thread in flight");
-            for (int i0 = threadIdx.x; i0 < f.chunk; i0 += kPbThreads * 8) {
-                float v[8];
+            const int64_t last_id = min(first_id + f.chunk, f.num_cold);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int64_t id = first_id + i0 + u * kPbThreads;
-                    v[u] = 0.f;
-                    if (id < f.num_cold) {
-                        int b = 0;
+            for (int b = 0; b < 8; ++b) {
+                if (b >= f.num_blocks) continue;
+                const int64_t lo = max(first_id, f.cold_prefix[b]), hi = min(last_id, f.cold_prefix[b + 1]);
+                if (lo >= hi) continue;                     // wavefront-uniform
+                const float* __restrict__ src = xg + f.xg_base[b] + f.hot - f.cold_prefix[b];      // src[id] = value of cold id
+                for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kPbThreads * 8) {
+                    float v[8];
 #pragma unroll
-                        for (int k = 1; k < 8; ++k) b += (k < f.num_blocks && id >= f.cold_prefix[k]) ? 1 : 0;
-                        v[u] = xg[f.xg_base[b] + f.hot + (id - f.cold_prefix[b])];
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t id = i0 + (int64_t)u * kPbThreads;
+                        v[u] = src[min(id, hi - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t id = i0 + (int64_t)u * kPbThreads;
+                        if (id < hi) s_x[id - first_id] = v[u];
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) s_x[i0 + u * kPbThreads] = v[u];
             }
             __syncthreads();
             loaded = task.x;
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
         for (int64_t e = body_end + threadIdx.x; e < end; e += kPbThreads) f.tmp[e] = HAS_VAL ? s_x[f.sloc[e]] * f.val[e] : s_x[f.sloc[e]];
         // four 16-byte index loads per lane in flight: one load per round trip would leave the CU latency-bound
         constexpr int P = 4;
+        if (PGH_PROBE_PB & 2) continue;
         for (int64_t e0 = body_begin + (int64_t)threadIdx.x * 8; e0 < body_end; e0 += (int64_t)kPbThreads * 8 * P) {
             u16x8 s8[P];
             f32x4 w0[P], w1[P];
@@ -243,6 +254,10 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
                 if (HAS_VAL) {
                     lo *= w0[q];
                     hi *= w1[q];
+                }
+                if (PGH_PROBE_PB & 4) {
+                    if (lo.x + hi.w == 123.456f) f.tmp[e] = lo.y;
+                    continue;
                 }
                 *reinterpret_cast<f32x4*>(f.tmp + e) = lo;
                 *reinterpret_cast<f32x4*>(f.tmp + e + 4) = hi;
