@@ -321,10 +321,11 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
     const uint32_t* __restrict__ starts = f.run_start + (int64_t)blockIdx.x * f.num_chunks;
     const uint32_t* __restrict__ lens = f.run_len + (int64_t)blockIdx.x * f.num_chunks;
     for (int i = tid; i < bin.y; i += kPbThreads) s_row[i] = 0.f;
+    if (PGH_PROBE_PB & 8) s_val[tid] = 1.f;
     // ---- stage the runs (each contiguous in tmp) one behind the other: staged offset = exclusive prefix of the lengths
     {
         int base = 0;
-        for (int c0 = 0; c0 < f.num_chunks; c0 += 64) {
+        for (int c0 = 0; c0 < f.num_chunks && !(PGH_PROBE_PB & 8); c0 += 64) {
             const int cc = c0 + lane;
             const int len = cc < f.num_chunks ? (int)lens[cc] : 0;
             const uint32_t start = cc < f.num_chunks ? starts[cc] : 0u;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
     constexpr int T = 512;
     const int tiles = (bin.w + T - 1) / T;
     const int per_wave = (tiles + kPbWaves - 1) / kPbWaves;
-    const int t_begin = min(wave * per_wave, tiles), t_end = min(t_begin + per_wave, tiles);
+    const int t_begin = min(wave * per_wave, tiles), t_end = (PGH_PROBE_PB & 16) ? 0 : min(t_begin + per_wave, tiles);
     const uint16_t* __restrict__ perm = f.perm + bin.z;
     const uint16_t* __restrict__ drow = f.drow + bin.z;
     double carry = 0.0;                                     // sum so far of the segment open at the start of the tile
