@@ -322,31 +322,55 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
     const uint32_t* __restrict__ lens = f.run_len + (int64_t)blockIdx.x * f.num_chunks;
     for (int i = tid; i < bin.y; i += kPbThreads) s_row[i] = 0.f;
     if (PGH_PROBE_PB & 8) s_val[tid] = 1.f;
-    // ---- stage the runs (each contiguous in tmp) one behind the other: staged offset = exclusive prefix of the lengths
-    {
+    // ---- this wavefront's part of the row-major walk: the index loads of its first tile do not depend on the staging,
+    //      so they are issued now and land while the runs are being staged
+    constexpr int T = 512;
+    const int tiles = (bin.w + T - 1) / T;
+    const int per_wave = (tiles + kPbWaves - 1) / kPbWaves;
+    const int t_begin = min(wave * per_wave, tiles), t_end = (PGH_PROBE_PB & 16) ? 0 : min(t_begin + per_wave, tiles);
+    const uint16_t* __restrict__ perm = f.perm + bin.z;
+    const uint16_t* __restrict__ drow = f.drow + bin.z;
+    u16x8 pk_next = {0, 0, 0, 0, 0, 0, 0, 0}, dk_next = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t_begin < t_end) {
+        const int e0 = t_begin * T + lane * 8;
+        if (bin.w - e0 > 0) {
+            pk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(perm + e0));
+            dk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + e0));
+        }
+    }
+    // ---- stage the runs (each contiguous in tmp) one behind the other: staged offset = exclusive prefix of the lengths.
+    //      Descriptors of two 64-run groups are fetched together, then every wavefront fetches the first 64 entries of
+    //      its (up to 8) runs together: two round trips for the typical bin instead of four.
+    if (!(PGH_PROBE_PB & 8)) {
         int base = 0;
-        for (int c0 = 0; c0 < f.num_chunks && !(PGH_PROBE_PB & 8); c0 += 64) {
-            const int cc = c0 + lane;
-            const int len = cc < f.num_chunks ? (int)lens[cc] : 0;
-            const uint32_t start = cc < f.num_chunks ? starts[cc] : 0u;
-            const int incl = pb_wave_inclusive_sum(len);
-            const int off = base + incl - len;
-            base += __shfl(incl, 63, 64);
-            // runs c0 + wave, c0 + wave + 16, ... of this group belong to this wavefront: their first 64 entries are
-            // fetched together (independent loads in flight), longer runs finish in a loop
-            float first[4];
-            int rlen[4], roff[4];
-            uint32_t rstart[4];
+        for (int c0 = 0; c0 < f.num_chunks; c0 += 128) {
+            int len[2], incl[2], off[2];
+            uint32_t start[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = wave + j * kPbWaves;
-                rlen[j] = (c0 + r < f.num_chunks) ? __shfl(len, r, 64) : 0;
-                rstart[j] = __shfl(start, r, 64);
-                roff[j] = __shfl(off, r, 64);
+            for (int h = 0; h < 2; ++h) {
+                const int cc = c0 + h * 64 + lane;
+                len[h] = cc < f.num_chunks ? (int)lens[cc] : 0;
+                start[h] = cc < f.num_chunks ? starts[cc] : 0u;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                incl[h] = pb_wave_inclusive_sum(len[h]);
+                off[h] = base + incl[h] - len[h];
+                base += __shfl(incl[h], 63, 64);
+            }
+            float first[8];
+            int rlen[8], roff[8];
+            uint32_t rstart[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int h = j >> 2, r = wave + (j & 3) * kPbWaves;           // run c0 + h * 64 + r belongs to this wavefront
+                rlen[j] = (c0 + h * 64 + r < f.num_chunks) ? __shfl(len[h], r, 64) : 0;
+                rstart[j] = __shfl(start[h], r, 64);
+                roff[j] = __shfl(off[h], r, 64);
                 first[j] = lane < rlen[j] ? __builtin_nontemporal_load(f.tmp + rstart[j] + lane) : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 if (lane < rlen[j]) s_val[roff[j] + lane] = first[j];
                 for (int i = 64 + lane; i < rlen[j]; i += 64) s_val[roff[j] + i] = __builtin_nontemporal_load(f.tmp + rstart[j] + i);
             }
@@ -354,14 +378,8 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
     }
     __syncthreads();
     // ---- row-major walk of this wavefront's part
-    constexpr int T = 512;
-    const int tiles = (bin.w + T - 1) / T;
-    const int per_wave = (tiles + kPbWaves - 1) / kPbWaves;
-    const int t_begin = min(wave * per_wave, tiles), t_end = (PGH_PROBE_PB & 16) ? 0 : min(t_begin + per_wave, tiles);
-    const uint16_t* __restrict__ perm = f.perm + bin.z;
-    const uint16_t* __restrict__ drow = f.drow + bin.z;
     double carry = 0.0;                                     // sum so far of the segment open at the start of the tile
-    int open_row = t_begin < t_end ? (int)drow[t_begin * T] : -1;
+    int open_row = t_begin < t_end ? __shfl((int)dk_next[0], 0, 64) : -1;   // row of the part's first entry
     bool have_head = false;                                 // a row change has been seen in this part
     double head = 0.0;
     int head_row = -1;
@@ -369,10 +387,15 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
         const int e0 = t * T + lane * 8;
         const int left = bin.w - e0;                        // this lane's valid entries: min(max(left, 0), 8)
         int my_last = open_row;
-        u16x8 pk = {0, 0, 0, 0, 0, 0, 0, 0}, dk = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (left > 0) {                                     // the bin's range starts at a multiple of 8 slots and is padded
-            pk = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(perm + e0));
-            dk = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + e0));
+        const u16x8 pk = pk_next, dk = dk_next;             // fetched one tile ahead
+        if (t + 1 < t_end) {                                // the bin's range starts at a multiple of 8 slots and is padded
+            const int n0 = e0 + T;
+            pk_next = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            dk_next = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (bin.w - n0 > 0) {
+                pk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(perm + n0));
+                dk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + n0));
+            }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
