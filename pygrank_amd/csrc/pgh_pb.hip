@@ -319,11 +319,11 @@ struct PbPrefetch {
     int4     bin;              // {first row, rows, first row-major slot, entries}; entries < 0: no such bin
     int      len[2];           // run descriptors of chunks lane and 64 + lane
     uint32_t start[2];
-    float    first[8];         // first 64 entries of this wavefront's runs (chunks wave + 16 j and 64 + wave + 16 j)
     u16x8    pk, dk;           // indices of the first tile of this wavefront's part
 };
 
-__global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
+__global__ __launch_bounds__(kPbThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
     __shared__ float s_val[kPbBinEntries];                 // the bin's entries, staged: runs in chunk order
     __shared__ float s_row[kPbBinRows];                    // row sums of the bin
     __shared__ double s_head[kPbWaves], s_tail[kPbWaves];
@@ -351,15 +351,8 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
             n.start[h] = ok ? starts[cc] : 0u;
         }
     };
-    // stage 2: first 64 entries of this wavefront's runs among the first 128, and the indices of its first tile
+    // stage 2: the indices of this wavefront's first tile
     auto fetch_data = [&](PbPrefetch& n) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int h = j >> 2, r = wave + (j & 3) * kPbWaves;
-            const int rlen = __shfl(n.len[h], r, 64);
-            const uint32_t rstart = __shfl(n.start[h], r, 64);
-            n.first[j] = (lane < rlen && !(PGH_PROBE_PB & 8)) ? __builtin_nontemporal_load(f.tmp + rstart + lane) : 0.f;
-        }
         n.pk = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
         n.dk = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
         if (n.bin.w > 0) {
@@ -390,14 +383,22 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
                     off[h] = base + incl[h] - cur.len[h];
                     base += __shfl(incl[h], 63, 64);
                 }
+                // the first 64 entries of this wavefront's (up to 8) runs: independent loads, all in flight together
+                float first[8];
+                int rlen[8], roff[8];
+                uint32_t rstart[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int h = j >> 2, r = wave + (j & 3) * kPbWaves;
-                    const int rlen = __shfl(cur.len[h], r, 64);
-                    const uint32_t rstart = __shfl(cur.start[h], r, 64);
-                    const int roff = __shfl(off[h], r, 64);
-                    if (lane < rlen) s_val[roff + lane] = cur.first[j];
-                    for (int i = 64 + lane; i < rlen; i += 64) s_val[roff + i] = __builtin_nontemporal_load(f.tmp + rstart + i);
+                    rlen[j] = __shfl(cur.len[h], r, 64);
+                    rstart[j] = __shfl(cur.start[h], r, 64);
+                    roff[j] = __shfl(off[h], r, 64);
+                    first[j] = lane < rlen[j] ? __builtin_nontemporal_load(f.tmp + rstart[j] + lane) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (lane < rlen[j]) s_val[roff[j] + lane] = first[j];
+                    for (int i = 64 + lane; i < rlen[j]; i += 64) s_val[roff[j] + i] = __builtin_nontemporal_load(f.tmp + rstart[j] + i);
                 }
             }
             // graphs with more than 128 chunks: the remaining runs, 64 descriptors at a time (not prefetched)
