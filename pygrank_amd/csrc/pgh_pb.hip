@@ -31,7 +31,8 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in phase A
-constexpr int kPbBinEntries = 16384;     // entries per bin: 64 KB of LDS in phase B (two workgroups per CU)
+constexpr int kPbBinEntries = 15360;     // entries per bin: 60 KB of LDS in phase B (two workgroups per CU)
+constexpr int kPbMaxChunks = 1024;       // run table of a bin in LDS (8 KB)
 constexpr int kPbBinRows = 2048;         // rows per bin (8 KB of f32 row sums in LDS)
 constexpr int kPbThreads = 1024;
 constexpr int kPbWaves = kPbThreads / 64;
@@ -304,239 +305,201 @@ __device__ __forceinline__ float pb_segmented_sum(float keep, float val) {
     return val;
 }
 
-// Workgroups loop over bins (bin = blockIdx.x, + gridDim.x, ...).  For every bin: the bin's runs (one per chunk, each
-// contiguous in tmp) are staged in LDS one behind the other; then wavefront w walks the w-th contiguous part of the
-// bin's row-major entry list in tiles of 512 (8 consecutive entries per lane).  A row is one segment of that list.
-// Inside a part: the segment that contains the part's first entry is its HEAD piece, the one that contains its last
-// entry its TAIL piece (a part without a row change is a single piece); every other segment is complete and goes
-// straight to the bin's row array in LDS.  The pieces are handed over in f64 and stitched in part order by one thread
-// after the barrier: fixed order, no atomics.
-//
-// Everything that comes from global memory is fetched ONE BIN AHEAD into registers (run descriptors while the current
-// bin is walked, the runs' first 64 entries and the first tile's indices while it is written out): a bin would otherwise
-// be a chain of four dependent round trips with nothing to overlap them.
-struct PbPrefetch {
-    int4     bin;              // {first row, rows, first row-major slot, entries}; entries < 0: no such bin
-    int      len[2];           // run descriptors of chunks lane and 64 + lane
-    uint32_t start[2];
-    u16x8    pk, dk;           // indices of the first tile of this wavefront's part
-};
-
-__global__ __launch_bounds__(kPbThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
+// One workgroup per bin.  Wavefront w walks the w-th contiguous part of the bin's row-major entry list in tiles of 512
+// (8 consecutive entries per lane).  A row is one segment of that list.  Inside a part: the segment that contains the
+// part's first entry is its HEAD piece, the one that contains its last entry its TAIL piece (a part without a row change
+// is a single piece); every other segment is complete and goes straight to the bin's row array in LDS.  The pieces are
+// handed over in f64 and stitched in part order by one thread after the barrier: fixed order, no atomics.
+__global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
     __shared__ float s_val[kPbBinEntries];                 // the bin's entries, staged: runs in chunk order
     __shared__ float s_row[kPbBinRows];                    // row sums of the bin
     __shared__ double s_head[kPbWaves], s_tail[kPbWaves];
     __shared__ int s_head_row[kPbWaves], s_tail_row[kPbWaves], s_pieces[kPbWaves];   // pieces: 0 none, 1 single, 2 head + tail
+    __shared__ int s_pref[kPbMaxChunks + 1];               // staged offset of every run
+    __shared__ uint32_t s_start[kPbMaxChunks];             // its first entry in tmp
+    __shared__ int s_group[kPbWaves], s_group_base[kPbWaves];
     if (state != nullptr && state->done) return;
+    const int4 bin = f.bin[blockIdx.x];                    // {first row, rows, first row-major slot, entries}
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t* __restrict__ starts = f.run_start + (int64_t)blockIdx.x * f.num_chunks;
+    const uint32_t* __restrict__ lens = f.run_len + (int64_t)blockIdx.x * f.num_chunks;
+    for (int i = tid; i < bin.y; i += kPbThreads) s_row[i] = 0.f;
+    if (PGH_PROBE_PB & 8) s_val[tid] = 1.f;
+    // ---- this wavefront's part of the row-major walk: the index loads of its first tile do not depend on the staging,
+    //      so they are issued now and land while the runs are being staged
     constexpr int T = 512;
-    auto part_of = [&](const int4& bin, int& t_begin, int& t_end) {
-        const int tiles = (bin.w + T - 1) / T;
-        const int per_wave = (tiles + kPbWaves - 1) / kPbWaves;
-        t_begin = min(wave * per_wave, tiles);
-        t_end = (PGH_PROBE_PB & 16) ? 0 : min(t_begin + per_wave, tiles);
-    };
-    // stage 1 of the prefetch: the bin and its first 128 run descriptors
-    auto fetch_desc = [&](int b, PbPrefetch& n) {
-        n.bin = b < f.num_bins ? f.bin[b] : make_int4(0, 0, 0, -1);
-        const uint32_t* __restrict__ starts = f.run_start + (int64_t)min(b, f.num_bins - 1) * f.num_chunks;
-        const uint32_t* __restrict__ lens = f.run_len + (int64_t)min(b, f.num_bins - 1) * f.num_chunks;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int cc = h * 64 + lane;
-            const bool ok = b < f.num_bins && cc < f.num_chunks;
-            n.len[h] = ok ? (int)lens[cc] : 0;
-            n.start[h] = ok ? starts[cc] : 0u;
+    const int tiles = (bin.w + T - 1) / T;
+    const int per_wave = (tiles + kPbWaves - 1) / kPbWaves;
+    const int t_begin = min(wave * per_wave, tiles), t_end = (PGH_PROBE_PB & 16) ? 0 : min(t_begin + per_wave, tiles);
+    const uint16_t* __restrict__ perm = f.perm + bin.z;
+    const uint16_t* __restrict__ drow = f.drow + bin.z;
+    u16x8 pk_next = {0, 0, 0, 0, 0, 0, 0, 0}, dk_next = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t_begin < t_end) {
+        const int e0 = t_begin * T + lane * 8;
+        if (bin.w - e0 > 0) {
+            pk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(perm + e0));
+            dk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + e0));
         }
-    };
-    // stage 2: the indices of this wavefront's first tile
-    auto fetch_data = [&](PbPrefetch& n) {
-        n.pk = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        n.dk = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (n.bin.w > 0) {
-            int t_begin, t_end;
-            part_of(n.bin, t_begin, t_end);
-            const int e0 = t_begin * T + lane * 8;
-            if (t_begin < t_end && n.bin.w - e0 > 0) {
-                n.pk = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(f.perm + n.bin.z + e0));
-                n.dk = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(f.drow + n.bin.z + e0));
-            }
-        }
-    };
-    PbPrefetch cur, nxt;
-    fetch_desc(blockIdx.x, cur);
-    fetch_data(cur);
-    for (int b = blockIdx.x; b < f.num_bins; b += gridDim.x) {
-        const int4 bin = cur.bin;
-        fetch_desc(b + gridDim.x, nxt);                    // lands while this bin is staged and walked
-        for (int i = tid; i < bin.y; i += kPbThreads) s_row[i] = 0.f;
-        // ---- stage the runs: staged offset = exclusive prefix of the run lengths
-        if (!(PGH_PROBE_PB & 8)) {
-            int base = 0;
-            {
-                int incl[2], off[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    incl[h] = pb_wave_inclusive_sum(cur.len[h]);
-                    off[h] = base + incl[h] - cur.len[h];
-                    base += __shfl(incl[h], 63, 64);
-                }
-                // the first 64 entries of this wavefront's (up to 8) runs: independent loads, all in flight together
-                float first[8];
-                int rlen[8], roff[8];
-                uint32_t rstart[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int h = j >> 2, r = wave + (j & 3) * kPbWaves;
-                    rlen[j] = __shfl(cur.len[h], r, 64);
-                    rstart[j] = __shfl(cur.start[h], r, 64);
-                    roff[j] = __shfl(off[h], r, 64);
-                    first[j] = lane < rlen[j] ? __builtin_nontemporal_load(f.tmp + rstart[j] + lane) : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (lane < rlen[j]) s_val[roff[j] + lane] = first[j];
-                    for (int i = 64 + lane; i < rlen[j]; i += 64) s_val[roff[j] + i] = __builtin_nontemporal_load(f.tmp + rstart[j] + i);
-                }
-            }
-            // graphs with more than 128 chunks: the remaining runs, 64 descriptors at a time (not prefetched)
-            const uint32_t* __restrict__ starts = f.run_start + (int64_t)b * f.num_chunks;
-            const uint32_t* __restrict__ lens = f.run_len + (int64_t)b * f.num_chunks;
-            for (int c0 = 128; c0 < f.num_chunks; c0 += 64) {
-                const int cc = c0 + lane;
-                const int len = cc < f.num_chunks ? (int)lens[cc] : 0;
-                const uint32_t start = cc < f.num_chunks ? starts[cc] : 0u;
-                const int incl = pb_wave_inclusive_sum(len);
-                const int off = base + incl - len;
-                base += __shfl(incl, 63, 64);
-                for (int r = wave; r < 64 && c0 + r < f.num_chunks; r += kPbWaves) {
-                    const int rlen = __shfl(len, r, 64);
-                    const uint32_t rstart = __shfl(start, r, 64);
-                    const int roff = __shfl(off, r, 64);
-                    for (int i = lane; i < rlen; i += 64) s_val[roff + i] = __builtin_nontemporal_load(f.tmp + rstart + i);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- row-major walk of this wavefront's part
-        int t_begin, t_end;
-        part_of(bin, t_begin, t_end);
-        const uint16_t* __restrict__ perm = f.perm + bin.z;
-        const uint16_t* __restrict__ drow = f.drow + bin.z;
-        u16x8 pk_next = cur.pk, dk_next = cur.dk;
-        double carry = 0.0;                                 // sum so far of the segment open at the start of the tile
-        int open_row = t_begin < t_end ? __shfl((int)dk_next[0], 0, 64) : -1;   // row of the part's first entry
-        bool have_head = false;                             // a row change has been seen in this part
-        double head = 0.0;
-        int head_row = -1;
-        for (int t = t_begin; t < t_end; ++t) {
-            const int e0 = t * T + lane * 8;
-            const int left = bin.w - e0;                    // this lane's valid entries: min(max(left, 0), 8)
-            const u16x8 pk = pk_next, dk = dk_next;         // fetched one tile ahead
-            if (t + 1 < t_end) {                            // the bin's range starts at a multiple of 8 slots and is padded
-                const int n0 = e0 + T;
-                pk_next = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                dk_next = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (bin.w - n0 > 0) {
-                    pk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(perm + n0));
-                    dk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + n0));
-                }
-            }
-            int my_last = open_row;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < left) my_last = (int)dk[k];
-            // previous entry's row for the lane's first entry: last row of the previous lane, `open_row` for lane 0
-            int prev = pb_dpp_i32<0x138, 0xf>(-1, my_last);  // wave_shr:1
-            if (lane == 0) prev = open_row;
-            float acc = 0.f, first_val = 0.f;
-            int first_row = -1, cur_row = prev;
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool valid = k < left;
-                const int r = (int)dk[k];
-                if (valid && r != cur_row) {                // the row changes: the segment of `cur_row` ends here
-                    if (!any) {
-                        first_val = acc;                    // may have started in earlier lanes / tiles: finished below
-                        first_row = cur_row;
-                        any = true;
-                    } else {
-                        s_row[cur_row] = acc;               // a row entirely inside this lane
-                    }
-                    acc = 0.f;
-                    cur_row = r;
-                }
-                if (valid) acc += s_val[pk[k]];
-            }
-            // the lane's tail (acc) continues into the following lanes until one of them sees a row change
-            const float run = pb_segmented_sum(any ? 0.f : 1.f, acc);     // tails chained over lanes without a change
-            const float before = pb_dpp_f32<0x138, 0xf>(0.f, run);         // what the lanes before hold of my first row
-            const unsigned long long changes = __ballot(any);
-            const bool first_in_tile = any && (changes & ((1ULL << lane) - 1ULL)) == 0ULL;
-            if (any) {
-                const double total = (double)first_val + (lane > 0 ? (double)before : 0.0) + (first_in_tile ? carry : 0.0);
-                if (first_in_tile && !have_head) {
-                    head = total;                           // the segment that contains the part's first entry
-                    head_row = first_row;
-                } else {
-                    s_row[first_row] = (float)total;
-                }
-            }
-            const float tile_tail = __shfl(run, 63, 64);
-            const int last_lane = min(63, max(0, (bin.w - t * T + 7) / 8 - 1));
-            const int tile_last_row = __shfl(left > 0 ? cur_row : open_row, last_lane, 64);
-            if (changes != 0ULL) {
-                if (!have_head) {
-                    const int closer = __builtin_ctzll(changes);
-                    head = __shfl(head, closer, 64);
-                    head_row = __shfl(head_row, closer, 64);
-                    have_head = true;
-                }
-                carry = (double)tile_tail;
-                open_row = tile_last_row;
-            } else {
-                carry += (double)tile_tail;
-            }
-        }
-        if (lane == 0) {
-            const int pieces = t_begin >= t_end ? 0 : (have_head ? 2 : 1);
-            s_pieces[wave] = pieces;
-            s_head[wave] = pieces == 2 ? head : carry;
-            s_head_row[wave] = pieces == 2 ? head_row : open_row;
-            s_tail[wave] = carry;
-            s_tail_row[wave] = open_row;
-        }
-        fetch_data(nxt);                                    // the next bin's runs and indices: land during stitch + write-out
-        __syncthreads();
-        // ---- stitch the pieces in part order (one thread)
-        if (tid == 0) {
-            double open = 0.0;
-            int row = -1;
-            for (int w = 0; w < kPbWaves; ++w) {
-                if (s_pieces[w] == 0) continue;
-                if (s_head_row[w] == row) {                 // head (or single) piece continues the open segment
-                    open += s_head[w];
-                } else {
-                    if (row >= 0) s_row[row] = (float)open;
-                    open = s_head[w];
-                    row = s_head_row[w];
-                }
-                if (s_pieces[w] == 2) {                     // the head segment ended inside the part; the tail one is open now
-                    if (row >= 0) s_row[row] = (float)open;
-                    open = s_tail[w];
-                    row = s_tail_row[w];
-                }
-            }
-            if (row >= 0) s_row[row] = (float)open;
-        }
-        __syncthreads();
-        for (int i = tid; i < bin.y; i += kPbThreads) f.out[bin.x + i] = s_row[i];
-        __syncthreads();                                    // s_row / s_val are rewritten by the next bin
-        cur = nxt;
     }
+    // ---- stage the runs (each contiguous in tmp) one behind the other.  The run table goes to LDS (first entry in tmp,
+    //      exclusive prefix of the lengths = staged offset); then the staged region is filled FLAT: every thread owns 16
+    //      consecutive staged slots, finds their run by binary search and walks forward -- sixteen independent loads per
+    //      thread, i.e. one round trip for the whole bin however its entries split into runs.
+    if (!(PGH_PROBE_PB & 8)) {
+        int base = 0;
+        for (int c0 = 0; c0 < f.num_chunks; c0 += 64 * kPbWaves) {          // wavefront w takes descriptors c0 + 64 w ..
+            const int cc = c0 + wave * 64 + lane;
+            const int len = cc < f.num_chunks ? (int)lens[cc] : 0;
+            const uint32_t start = cc < f.num_chunks ? starts[cc] : 0u;
+            const int incl = pb_wave_inclusive_sum(len);
+            if (cc < f.num_chunks) {
+                s_pref[cc] = incl - len;                                    // prefix inside the wavefront's group of 64
+                s_start[cc] = start;
+            }
+            if (lane == 63) s_group[wave] = incl;                           // total of the group
+            (void)base;
+        }
+        __syncthreads();
+        // groups of 64 runs -> bin-wide exclusive prefix (num_chunks <= kPbMaxChunks = 64 * kPbWaves: one pass)
+        if (tid < kPbWaves) {
+            int acc = 0;
+            for (int w = 0; w < tid; ++w) acc += s_group[w];
+            s_group_base[tid] = acc;
+        }
+        __syncthreads();
+        for (int c = tid; c < f.num_chunks; c += kPbThreads) s_pref[c] += s_group_base[c >> 6];
+        if (tid == 0) s_pref[f.num_chunks] = bin.w;
+        __syncthreads();
+        constexpr int S = kPbBinEntries / kPbThreads;                       // staged slots per thread
+        const int p0 = tid * S;
+        if (p0 < bin.w) {
+            int lo = 0, hi = f.num_chunks;                                  // last run with pref <= p0
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pref[mid] <= p0) lo = mid; else hi = mid;
+            }
+            int run = lo;
+            float v[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const int pos = p0 + k;
+                while (run + 1 < f.num_chunks && s_pref[run + 1] <= pos) ++run;
+                v[k] = pos < bin.w ? __builtin_nontemporal_load(f.tmp + s_start[run] + (pos - s_pref[run])) : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < S; ++k) s_val[p0 + k] = v[k];
+        }
+    }
+    __syncthreads();
+    // ---- row-major walk of this wavefront's part
+    double carry = 0.0;                                     // sum so far of the segment open at the start of the tile
+    int open_row = t_begin < t_end ? __shfl((int)dk_next[0], 0, 64) : -1;   // row of the part's first entry
+    bool have_head = false;                                 // a row change has been seen in this part
+    double head = 0.0;
+    int head_row = -1;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int e0 = t * T + lane * 8;
+        const int left = bin.w - e0;                        // this lane's valid entries: min(max(left, 0), 8)
+        int my_last = open_row;
+        const u16x8 pk = pk_next, dk = dk_next;             // fetched one tile ahead
+        if (t + 1 < t_end) {                                // the bin's range starts at a multiple of 8 slots and is padded
+            const int n0 = e0 + T;
+            pk_next = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            dk_next = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (bin.w - n0 > 0) {
+                pk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(perm + n0));
+                dk_next = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + n0));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < left) my_last = (int)dk[k];
+        // previous entry's row for the lane's first entry: last row of the previous lane, `open_row` for lane 0
+        int prev = pb_dpp_i32<0x138, 0xf>(-1, my_last);    // wave_shr:1
+        if (lane == 0) prev = open_row;
+        float acc = 0.f, first_val = 0.f;
+        int first_row = -1, cur = prev;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool valid = k < left;
+            const int r = (int)dk[k];
+            if (valid && r != cur) {                        // the row changes: the segment of `cur` ends here
+                if (!any) {
+                    first_val = acc;                        // may have started in earlier lanes / tiles: finished below
+                    first_row = cur;
+                    any = true;
+                } else {
+                    s_row[cur] = acc;                       // a row entirely inside this lane
+                }
+                acc = 0.f;
+                cur = r;
+            }
+            if (valid) acc += s_val[pk[k]];
+        }
+        // the lane's tail (acc) continues into the following lanes until one of them sees a row change
+        const float run = pb_segmented_sum(any ? 0.f : 1.f, acc);       // tails chained over lanes without a change
+        const float before = pb_dpp_f32<0x138, 0xf>(0.f, run);           // what the lanes before hold of my first row
+        const unsigned long long changes = __ballot(any);
+        const bool first_in_tile = any && (changes & ((1ULL << lane) - 1ULL)) == 0ULL;
+        if (any) {
+            const double total = (double)first_val + (lane > 0 ? (double)before : 0.0) + (first_in_tile ? carry : 0.0);
+            if (first_in_tile && !have_head) {
+                head = total;                               // the segment that contains the part's first entry
+                head_row = first_row;
+            } else {
+                s_row[first_row] = (float)total;
+            }
+        }
+        const float tile_tail = __shfl(run, 63, 64);
+        const int last_lane = min(63, max(0, (bin.w - t * T + 7) / 8 - 1));
+        const int tile_last_row = __shfl(left > 0 ? cur : open_row, last_lane, 64);
+        if (changes != 0ULL) {
+            if (!have_head) {
+                const int closer = __builtin_ctzll(changes);
+                head = __shfl(head, closer, 64);
+                head_row = __shfl(head_row, closer, 64);
+                have_head = true;
+            }
+            carry = (double)tile_tail;
+            open_row = tile_last_row;
+        } else {
+            carry += (double)tile_tail;
+        }
+    }
+    if (lane == 0) {
+        const int pieces = t_begin >= t_end ? 0 : (have_head ? 2 : 1);
+        s_pieces[wave] = pieces;
+        s_head[wave] = pieces == 2 ? head : carry;
+        s_head_row[wave] = pieces == 2 ? head_row : open_row;
+        s_tail[wave] = carry;
+        s_tail_row[wave] = open_row;
+    }
+    __syncthreads();
+    // ---- stitch the pieces in part order (one thread)
+    if (tid == 0) {
+        double open = 0.0;
+        int row = -1;
+        for (int w = 0; w < kPbWaves; ++w) {
+            if (s_pieces[w] == 0) continue;
+            if (s_head_row[w] == row) {                     // head (or single) piece continues the open segment
+                open += s_head[w];
+            } else {
+                if (row >= 0) s_row[row] = (float)open;
+                open = s_head[w];
+                row = s_head_row[w];
+            }
+            if (s_pieces[w] == 2) {                         // the head segment ended inside the part; the tail one is open now
+                if (row >= 0) s_row[row] = (float)open;
+                open = s_tail[w];
+                row = s_tail_row[w];
+            }
+        }
+        if (row >= 0) s_row[row] = (float)open;
+    }
+    __syncthreads();
+    for (int i = tid; i < bin.y; i += kPbThreads) f.out[bin.x + i] = s_row[i];
 }
 
 PbView pb_view(const BsfFormat& f) {
@@ -577,7 +540,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     int64_t cold_sources = 0;
     for (int b = 0; b < f.num_blocks; ++b) cold_sources += live[b] > hot ? live[b] - hot : 0;
     const int64_t chunks = (cold_sources + kPbChunk - 1) / kPbChunk;
-    if (chunks < 1 || chunks >= (1 << 13) || f.n_out >= (1 << 28)) return 0;
+    if (chunks < 1 || chunks > kPbMaxChunks || f.n_out >= (1 << 28)) return 0;
     PbBuf<uint32_t> d_counts;
     PGH_TRY(d_counts.alloc(f.n_out, true));
     k_pb_row_counts<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, is_hot, E, d_counts.p);
@@ -823,8 +786,7 @@ int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state) {
     }
     {
         ProfScope prof(PGH_K_PB_ACCUM);
-        const int grid = std::min(f.pb.num_bins, 2 * r.num_cus);       // two resident workgroups per CU, each loops over bins
-        if (grid > 0) k_pb_accumulate<<<grid, kPbThreads, 0, r.stream>>>(v, state);
+        if (f.pb.num_bins > 0) k_pb_accumulate<<<f.pb.num_bins, kPbThreads, 0, r.stream>>>(v, state);
     }
     PGH_HIP(hipGetLastError());
     return 0;
