@@ -371,24 +371,31 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
         for (int c = tid; c < f.num_chunks; c += kPbThreads) s_pref[c] += s_group_base[c >> 6];
         if (tid == 0) s_pref[f.num_chunks] = bin.w;
         __syncthreads();
-        constexpr int S = kPbBinEntries / kPbThreads;                       // staged slots per thread
-        const int p0 = tid * S;
-        if (p0 < bin.w) {
-            int lo = 0, hi = f.num_chunks;                                  // last run with pref <= p0
+        // wavefront w fills staged slots [w * S, (w + 1) * S) in steps of 64 consecutive slots (coalesced reads of tmp:
+        // neighbouring slots are neighbouring entries of a run); a lane finds its run by binary search at the first
+        // step and walks forward from there (a step advances by about one run)
+        constexpr int S = kPbBinEntries / kPbWaves;                         // staged slots per wavefront
+        constexpr int STEPS = S / 64;
+        static_assert(S % 64 == 0, "whole steps");
+        const int w0 = wave * S;
+        if (w0 < bin.w) {
+            int lo = 0, hi = f.num_chunks;                                  // last run with pref <= w0 + lane
+            const int p_first = min(w0 + lane, bin.w - 1);
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (s_pref[mid] <= p0) lo = mid; else hi = mid;
+                if (s_pref[mid] <= p_first) lo = mid; else hi = mid;
             }
             int run = lo;
-            float v[S];
+            float v[STEPS];
 #pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const int pos = p0 + k;
-                while (run + 1 < f.num_chunks && s_pref[run + 1] <= pos) ++run;
-                v[k] = pos < bin.w ? __builtin_nontemporal_load(f.tmp + s_start[run] + (pos - s_pref[run])) : 0.f;
+            for (int k = 0; k < STEPS; ++k) {
+                const int pos = w0 + k * 64 + lane;
+                const int q = min(pos, bin.w - 1);
+                while (s_pref[run + 1] <= q) ++run;                         // s_pref[num_chunks] = bin.w > q: terminates
+                v[k] = pos < bin.w ? __builtin_nontemporal_load(f.tmp + s_start[run] + (q - s_pref[run])) : 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < S; ++k) s_val[p0 + k] = v[k];
+            for (int k = 0; k < STEPS; ++k) s_val[w0 + k * 64 + lane] = v[k];
         }
     }
     __syncthreads();
