@@ -19,6 +19,11 @@
 // ~14 sequential bytes per cold entry instead of one line fill.  Runs must stay long enough to be worth a copy, which
 // limits the image to graphs where cold_entries / (chunks * bins) >= ~24 (scale <= 24 on RMAT); beyond that the cold
 // entries stay in k_bsf_partial.
+//
+// STATUS: experimental, opt-in with PGH_PB=1 (PGH_PB_FORCE=1 lifts the size heuristics for tests).  Results are identical
+// to the default path to 1e-7; at scale 23 the three kernels take 136 + 68 + 181 us against 372 us for k_bsf_partial
+// with the cold gathers left in: phase B is bound by DRAM-inefficient reads of ~250-byte runs (LDS capacity fixes the
+// chunk and bin sizes, hence the run length).  profiles/r01/pb_experiment_scale23.log.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -541,8 +546,10 @@ PbView pb_view(const BsfFormat& f) {
 // re-flagged as staying.  plan->bin / plan->row_bin are device arrays (pb_build takes the former, pb_plan_release frees).
 int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int hot, unsigned char* is_hot, PbPlan* plan, bool* use) {
     *use = false;
+    // Opt-in (PGH_PB=1): measured on MI355X at scale 23 the image is correct but not yet faster than leaving the cold
+    // gathers in k_bsf_partial (136 + 68 + 181 us against 372 us) -- see the analysis there.
     const char* env = getenv("PGH_PB");
-    if (env != nullptr && atoi(env) == 0) return 0;
+    if (env == nullptr || atoi(env) == 0) return 0;
     Runtime& r = rt();
     int64_t cold_sources = 0;
     for (int b = 0; b < f.num_blocks; ++b) cold_sources += live[b] > hot ? live[b] - hot : 0;

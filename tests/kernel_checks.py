@@ -364,6 +364,56 @@ def check_device_preprocessor_matches_host(pg):
         assert np.array_equal(dev.data, host.data), kw
 
 
+def check_propagation_blocking_image(pg):
+    """The opt-in propagation-blocking image of the cold tail (PGH_PB=1, csrc/pgh_pb.hip): same products and same
+    PageRank as the default layout, for value-free and valued graphs, deterministic.  (No-op on the test double.)"""
+    import os
+    from pygrank_amd import _lib as L
+    if L._is_test_double:
+        return
+    from pygrank_amd.device import DeviceGraph
+    rng = np.random.default_rng(23)
+    A = rmat_np.rmat_csr(17, 16, seed=1)                        # 131 K nodes: four times the LDS hot cache
+    Wreal = sp.csr_array(A.copy())
+    Wreal.data = Wreal.data * (0.5 + rng.random(Wreal.nnz))
+    saved = {k: os.environ.get(k) for k in ("PGH_PB", "PGH_PB_FORCE")}
+    try:
+        for name, W in (("int", A), ("real", Wreal)):
+            os.environ.pop("PGH_PB", None)
+            os.environ.pop("PGH_PB_FORCE", None)
+            g0 = DeviceGraph.from_adjacency(W, "col")
+            os.environ["PGH_PB"], os.environ["PGH_PB_FORCE"] = "1", "1"
+            g1 = DeviceGraph.from_adjacency(W, "col")
+            assert "propagation-blocking" in g1.format() and "propagation-blocking" not in g0.format(), (g0.format(), g1.format())
+            x = rng.random(W.shape[0]).astype(F32).astype(np.float64)
+            y0, y1 = _np(pg.conv(_vec(pg, x), g0)), _np(pg.conv(_vec(pg, x), g1))
+            N = sp.csr_array(g0.download_transposed().T)
+            scale = np.abs(x) @ np.abs(N)
+            assert np.all(np.abs(y0 - y1) <= 8 * EPS32 * scale + 1e-30), name
+            assert np.array_equal(_np(pg.conv(_vec(pg, x), g1)), y1), name          # deterministic
+            p = np.zeros(W.shape[0])
+            p[rmat_np.seed_nodes(A, 50, seed=4)] = 1.0
+            runs = []
+            for g in (g0, g1):
+                ranker = pg.PageRank(0.85, error_type=pg.L1, tol=1e-6, max_iters=500)
+                from pygrank_amd.preprocessing import Adjacency
+                from pygrank_amd.signals import _IdentityMap
+                adj = Adjacency(g)
+                adj._pygrank_preprocessed = {"hip": adj}
+                adj._pygrank_node2id = _IdentityMap(g.shape[0])
+                adj.is_directed = lambda: True
+                r = ranker.rank(adj, p.copy())
+                runs.append((np.asarray(r.np), ranker.last_loop["iterations"]))
+            assert runs[0][1] == runs[1][1], name
+            assert np.max(np.abs(runs[0][0] - runs[1][0])) <= 1e-6 * np.max(np.abs(runs[0][0])), name
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def check_slab_ops_and_wide_propagate(pg):
     """Whole-slab prologue kernels (pgh_mat_col_abssum / div_cols / get_cols / set_cols) against numpy, and propagate
     over more than 64 feature columns (two batches) against per-column rank()."""
