@@ -832,6 +832,7 @@ int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor)
 }
 
 void bsf_destroy(BsfFormat& f) {
+    for (int sl = 1; sl < kPbMaxSlices; ++sl) pb_destroy(f.pb_more[sl - 1]);
     pb_destroy(f.pb);
     (void)hipFree(f.colf);
     (void)hipFree(f.flags8);
@@ -995,7 +996,22 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
                 PGH_HIP(hipcub::DevicePartition::Flagged(temp.p, temp_bytes, f.val, is_hot.p, vals_a.p, num_hot.p, (int)E, r.stream));
                 PGH_HIP(hipStreamSynchronize(r.stream));
             }
-            const int rc_pb = pb_build(f, &plan, keys_a.p + E_hot, val ? vals_a.p + E_hot : nullptr, E - E_hot, live_all, hot_slots);
+            int rc_pb = 0;
+            {
+                // the image is built slice by slice: the slice's entries are compacted out of the cold keys first
+                DevBuf<uint64_t> slice_keys;
+                DevBuf<float> slice_vals;
+                const int64_t cold_count = E - E_hot;
+                rc_pb = slice_keys.alloc(cold_count);
+                if (rc_pb == 0 && val) rc_pb = slice_vals.alloc(cold_count);
+                for (int sl = 0; rc_pb == 0 && sl < plan.slices; ++sl) {
+                    int64_t got = 0;
+                    rc_pb = pb_select_slice(&plan, sl, keys_a.p + E_hot, val ? vals_a.p + E_hot : nullptr, cold_count, slice_keys.p,
+                                            val ? slice_vals.p : nullptr, &got);
+                    if (rc_pb == 0) rc_pb = pb_build(f, &plan, sl, slice_keys.p, val ? slice_vals.p : nullptr, got, live_all, hot_slots);
+                }
+                if (rc_pb == 0) f.pb_slices = plan.slices;
+            }
             pb_plan_release(&plan);
             PGH_TRY(rc_pb);
             std::swap(keys_a.p, keys_b.p);                 // keys_b: the stream's entries, still sorted by (block, row, col)

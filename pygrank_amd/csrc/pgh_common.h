@@ -157,12 +157,16 @@ struct PbFormat {
     uint16_t* perm = nullptr;       // [num_entries] row-major order: position of the entry inside its bin's staged region
     uint16_t* drow = nullptr;       // [num_entries] row-major order: output row inside the bin
     float*    out = nullptr;        // [n_out] cold part of every row sum (structurally empty rows stay 0)
+    bool      owns_out = true;      // slices of one image share the output vector of the first
     int64_t   device_bytes = 0;
 };
+constexpr int kPbMaxSlices = 8;
 
 struct BsfFormat {
     bool      enabled = false;
-    PbFormat  pb;
+    PbFormat  pb;                   // first slice of the cold image (bins of the lowest rows); flags for the whole image
+    PbFormat  pb_more[kPbMaxSlices - 1];   // further slices: each is run (phase A, then phase B) before the next, so that the
+    int       pb_slices = 0;        // values handed from A to B are still in the L2 / Infinity Cache when B reads them
     int       num_blocks = 1;       // B in {1, 2, 4, 8}
     int       blk_size = 0;         // sources per block
     int       n_src = 0;            // length of the gather vector (rows of M)

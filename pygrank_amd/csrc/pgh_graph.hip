@@ -482,8 +482,8 @@ extern "C" int pgh_graph_format(pgh_graph_t g, char* buf, int buflen) {
                             f.num_blocks, f.blk_size, f.relabelled ? "relabelled by source count" : "original ids",
                             f.val ? "f32-valued" : "value-free", f.val ? 8 : 4, (long long)f.num_entries, f.num_tiles, PGH_BSF_HOT);
         if (f.pb.enabled && used > 0 && used < buflen)
-            snprintf(buf + used, buflen - used, "; cold tail: propagation-blocking image, %lld entries in %d chunks x %d bins%s",
-                     (long long)f.pb.num_entries, f.pb.num_chunks, f.pb.num_bins, f.pb.k1_cold ? " (heavy rows stay in the stream)" : "");
+            snprintf(buf + used, buflen - used, "; cold tail: propagation-blocking image in %d slices, first: %lld entries in %d chunks x %d bins%s",
+                     f.pb_slices, (long long)f.pb.num_entries, f.pb.num_chunks, f.pb.num_bins, f.pb.k1_cold ? " (heavy rows stay in the stream)" : "");
     } else {
         snprintf(buf, buflen, "csr32+f32 row-major merge-path (8 B/edge), %d tiles of %d items", g->num_tiles, g->items_per_tile);
     }

@@ -97,10 +97,17 @@ struct PbPlan {
     int      num_bins = 0, num_chunks = 0;
     int64_t  entries = 0;          // cold entries that go into the image
     int64_t  padded_entries = 0;   // row-major slots (every bin's range padded to a multiple of 8)
+    int      slices = 1;           // the bins are cut into `slices` consecutive groups of about equal entry counts
+    int      slice_first[kPbMaxSlices + 1] = {0};   // first bin of every slice
+    int64_t  slice_entries[kPbMaxSlices] = {0};
+    int4*    host_bins = nullptr;  // host copy of `bin` (new[]), owned by the plan
     bool     heavy_rows = false;   // some rows keep their cold entries in the blocked stream
 };
 int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int hot, unsigned char* is_hot, PbPlan* plan, bool* use);
-int pb_build(BsfFormat& f, PbPlan* plan, const uint64_t* cold_keys, const float* cold_vals, int64_t count, const int* live, int hot);
+int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, const float* cold_vals, int64_t count, const int* live, int hot);
+// compacts the entries of one slice (stream keys whose row belongs to bins [slice_first[s], slice_first[s + 1])) out of the cold keys
+int pb_select_slice(const PbPlan* plan, int slice, const uint64_t* cold_keys, const float* cold_vals, int64_t count, uint64_t* keys_out,
+                    float* vals_out, int64_t* selected);
 void pb_plan_release(PbPlan* plan);
 int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state);
 void pb_destroy(PbFormat& p);

@@ -92,7 +92,7 @@ struct PbLayout {
 
 // stream key -> phase A key (chunk << 45 | bin << 27 | row_in_bin << 15 | source_in_chunk)
 __global__ void k_pb_keys(const uint64_t* __restrict__ keys, int64_t count, PbLayout L, const int32_t* __restrict__ row_bin,
-                          const int4* __restrict__ bin, uint64_t* __restrict__ out) {
+                          int first_bin, const int4* __restrict__ bin /* of this slice */, uint64_t* __restrict__ out) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t key = keys[i];
         const int b = (int)(key >> 58);
@@ -100,7 +100,7 @@ __global__ void k_pb_keys(const uint64_t* __restrict__ keys, int64_t count, PbLa
         const int64_t loc = (int64_t)(key & kLow29) - (int64_t)b * L.blk;
         const int64_t cold_id = L.cold_prefix[b] + (loc - L.hot);
         const uint64_t c = (uint64_t)(cold_id / L.chunk), sl = (uint64_t)(cold_id % L.chunk);
-        const uint64_t w = (uint64_t)row_bin[row];
+        const uint64_t w = (uint64_t)(row_bin[row] - first_bin);
         const uint64_t dl = (uint64_t)(row - bin[w].x);
         out[i] = (c << 45) | (w << 27) | (dl << 15) | sl;
     }
@@ -514,8 +514,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
     for (int i = tid; i < bin.y; i += kPbThreads) f.out[bin.x + i] = s_row[i];
 }
 
-PbView pb_view(const BsfFormat& f) {
-    const PbFormat& p = f.pb;
+PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     PbView v;
     v.sloc = p.sloc;
     v.val = p.val;
@@ -627,24 +626,56 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     plan->num_bins = (int)num_bins;
     plan->num_chunks = (int)chunks;
     plan->entries = in_image;
+    // slices: consecutive bins, about equal entry counts, each small enough for its values to stay cached between the phases
+    {
+        const char* sl = getenv("PGH_PB_SLICES");
+        int want = sl != nullptr ? atoi(sl) : (int)((in_image * 4 + (24LL << 20) - 1) / (24LL << 20));     // ~24 MB of values each
+        want = std::max(1, std::min(want, kPbMaxSlices));
+        plan->slices = want;
+        plan->host_bins = new int4[bins.size()];
+        std::copy(bins.begin(), bins.end(), plan->host_bins);
+        int64_t acc = 0;
+        int s_at = 0;
+        plan->slice_first[0] = 0;
+        for (int w = 0; w < (int)num_bins; ++w) {
+            if (s_at + 1 < want && acc >= (in_image * (s_at + 1)) / want) plan->slice_first[++s_at] = w;
+            acc += bins[w].w;
+        }
+        while (s_at < want) plan->slice_first[++s_at] = (int)num_bins;
+        for (int g = 0; g < want; ++g) {
+            plan->slice_entries[g] = 0;
+            for (int w = plan->slice_first[g]; w < plan->slice_first[g + 1]; ++w) plan->slice_entries[g] += bins[w].w;
+        }
+    }
     plan->heavy_rows = heavy_rows && in_image < cold;
     *use = true;
     return 0;
 }
 
 // cold_keys: the entries of the image as stream keys (block << 58 | row << 29 | col), any order; cold_vals: values or null.
-int pb_build(BsfFormat& f, PbPlan* plan, const uint64_t* cold_keys, const float* cold_vals, int64_t count, const int* live, int hot) {
+int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, const float* cold_vals, int64_t count, const int* live,
+             int hot) {
     Runtime& r = rt();
-    PbFormat& p = f.pb;
+    PbFormat& p = slice == 0 ? f.pb : f.pb_more[slice - 1];
     p = PbFormat();
-    PGH_CHECK(count == plan->entries, "propagation blocking: entry count does not match the plan");
+    PGH_CHECK(count == plan->slice_entries[slice], "propagation blocking: entry count does not match the plan");
     p.num_entries = count;
     p.chunk = kPbChunk;
     p.hot = hot;
     p.k1_cold = plan->heavy_rows;
-    p.num_bins = plan->num_bins;
-    p.bin = plan->bin;
-    plan->bin = nullptr;
+    const int first_bin = plan->slice_first[slice];
+    p.num_bins = plan->slice_first[slice + 1] - first_bin;
+    int64_t padded_slots = 0;
+    {   // this slice's bins, row-major slots re-laid from 0
+        std::vector<int4> mine(plan->host_bins + first_bin, plan->host_bins + first_bin + p.num_bins);
+        for (int4& b : mine) {
+            b.z = (int)padded_slots;
+            padded_slots += ((int64_t)b.w + 7) & ~(int64_t)7;
+        }
+        PGH_HIP(hipMalloc(&p.bin, sizeof(int4) * (size_t)(p.num_bins > 0 ? p.num_bins : 1)));
+        PGH_HIP(hipMemcpyAsync(p.bin, mine.data(), sizeof(int4) * mine.size(), hipMemcpyHostToDevice, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+    }
     p.cold_prefix[0] = 0;
     for (int b = 0; b < 8; ++b) p.cold_prefix[b + 1] = p.cold_prefix[b] + (b < f.num_blocks && live[b] > hot ? live[b] - hot : 0);
     p.num_chunks = plan->num_chunks;
@@ -656,7 +687,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, const uint64_t* cold_keys, const float*
     PbBuf<uint64_t> keys_a, keys_b, keys_c;
     PGH_TRY(keys_a.alloc(count));
     PGH_TRY(keys_b.alloc(count));
-    k_pb_keys<<<pb_blocks_for(count), kBlock, 0, r.stream>>>(cold_keys, count, L, plan->row_bin, p.bin, keys_a.p);
+    k_pb_keys<<<pb_blocks_for(count), kBlock, 0, r.stream>>>(cold_keys, count, L, plan->row_bin, first_bin, p.bin, keys_a.p);
     PGH_HIP(hipGetLastError());
     PbBuf<char> temp;
     size_t temp_bytes = 0, need = 0;
@@ -715,7 +746,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, const uint64_t* cold_keys, const float*
         PGH_HIP(hipMemcpyAsync(bin_rank0.p, rank0.data(), sizeof(uint32_t) * p.num_bins, hipMemcpyHostToDevice, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
-    const int64_t padded = plan->padded_entries;
+    const int64_t padded = padded_slots;
     PGH_HIP(hipMalloc(&p.perm, sizeof(uint16_t) * (size_t)(padded + 8)));
     PGH_HIP(hipMalloc(&p.drow, sizeof(uint16_t) * (size_t)(padded + 8)));
     PGH_HIP(hipMemsetAsync(p.perm, 0, sizeof(uint16_t) * (size_t)(padded + 8), r.stream));
@@ -771,8 +802,13 @@ int pb_build(BsfFormat& f, PbPlan* plan, const uint64_t* cold_keys, const float*
     if (!tasks.empty()) PGH_HIP(hipMemcpyAsync(p.task, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMemcpyAsync(p.task_range, ranges.data(), sizeof(int) * (shares + 1), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMalloc(&p.tmp, sizeof(float) * (size_t)(count + 8)));
-    PGH_HIP(hipMalloc(&p.out, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1)));
-    PGH_HIP(hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1), r.stream));
+    if (slice == 0) {
+        PGH_HIP(hipMalloc(&p.out, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1)));
+        PGH_HIP(hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1), r.stream));
+    } else {
+        p.out = f.pb.out;                                  // disjoint rows of the same vector
+        p.owns_out = false;
+    }
     PGH_HIP(hipStreamSynchronize(r.stream));
     p.device_bytes = count * (4 + 2 + (cold_vals ? 4 : 0)) + padded * 4 + cells * 8 + (int64_t)f.n_out * 4;
     p.enabled = true;
@@ -782,25 +818,64 @@ int pb_build(BsfFormat& f, PbPlan* plan, const uint64_t* cold_keys, const float*
 void pb_plan_release(PbPlan* plan) {
     (void)hipFree(plan->bin);
     (void)hipFree(plan->row_bin);
+    delete[] plan->host_bins;
     plan->bin = nullptr;
     plan->row_bin = nullptr;
+    plan->host_bins = nullptr;
+}
+
+namespace {
+struct InSlice {
+    const int32_t* row_bin;
+    int lo, hi;
+    __device__ bool operator()(const uint64_t& key) const {
+        const int w = row_bin[(key >> 29) & kLow29];
+        return w >= lo && w < hi;
+    }
+};
+__global__ void k_pb_slice_flags(const uint64_t* __restrict__ keys, int64_t count, InSlice pred, unsigned char* __restrict__ flag) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) flag[i] = pred(keys[i]) ? 1 : 0;
+}
+}  // namespace
+
+int pb_select_slice(const PbPlan* plan, int slice, const uint64_t* cold_keys, const float* cold_vals, int64_t count, uint64_t* keys_out,
+                    float* vals_out, int64_t* selected) {
+    Runtime& r = rt();
+    PbBuf<unsigned char> flag;
+    PbBuf<int64_t> num;
+    PGH_TRY(flag.alloc(count));
+    PGH_TRY(num.alloc(1));
+    const InSlice pred{plan->row_bin, plan->slice_first[slice], plan->slice_first[slice + 1]};
+    k_pb_slice_flags<<<pb_blocks_for(count), kBlock, 0, r.stream>>>(cold_keys, count, pred, flag.p);
+    size_t temp_bytes = 0;
+    PGH_HIP(hipcub::DeviceSelect::Flagged(nullptr, temp_bytes, cold_keys, flag.p, keys_out, num.p, (int)count, r.stream));
+    PbBuf<char> temp;
+    PGH_TRY(temp.alloc(temp_bytes));
+    PGH_HIP(hipcub::DeviceSelect::Flagged(temp.p, temp_bytes, cold_keys, flag.p, keys_out, num.p, (int)count, r.stream));
+    if (cold_vals != nullptr) PGH_HIP(hipcub::DeviceSelect::Flagged(temp.p, temp_bytes, cold_vals, flag.p, vals_out, num.p, (int)count, r.stream));
+    PGH_HIP(hipMemcpyAsync(selected, num.p, sizeof(int64_t), hipMemcpyDeviceToHost, r.stream));
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    return 0;
 }
 
 int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state) {
     const BsfFormat& f = g->bsf;
     if (!f.pb.enabled) return 0;
     Runtime& r = rt();
-    const PbView v = pb_view(f);
+    for (int slice = 0; slice < f.pb_slices; ++slice) {
+    const PbFormat& p = slice == 0 ? f.pb : f.pb_more[slice - 1];
+    const PbView v = pb_view(f, p);
     {
         ProfScope prof(PGH_K_PB_GATHER);
-        if (f.pb.num_tasks > 0) {
-            if (f.pb.val) k_pb_gather<true><<<f.pb.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state);
-            else k_pb_gather<false><<<f.pb.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state);
+        if (p.num_tasks > 0) {
+            if (p.val) k_pb_gather<true><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state);
+            else k_pb_gather<false><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state);
         }
     }
     {
         ProfScope prof(PGH_K_PB_ACCUM);
-        if (f.pb.num_bins > 0) k_pb_accumulate<<<f.pb.num_bins, kPbThreads, 0, r.stream>>>(v, state);
+        if (p.num_bins > 0) k_pb_accumulate<<<p.num_bins, kPbThreads, 0, r.stream>>>(v, state);
+    }
     }
     PGH_HIP(hipGetLastError());
     return 0;
@@ -817,7 +892,7 @@ void pb_destroy(PbFormat& p) {
     (void)hipFree(p.bin);
     (void)hipFree(p.perm);
     (void)hipFree(p.drow);
-    (void)hipFree(p.out);
+    if (p.owns_out) (void)hipFree(p.out);
     p = PbFormat();
 }
 
