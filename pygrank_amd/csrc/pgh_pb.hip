@@ -629,7 +629,8 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     // slices: consecutive bins, about equal entry counts, each small enough for its values to stay cached between the phases
     {
         const char* sl = getenv("PGH_PB_SLICES");
-        int want = sl != nullptr ? atoi(sl) : (int)((in_image * 4 + (24LL << 20) - 1) / (24LL << 20));     // ~24 MB of values each
+        int want = sl != nullptr ? atoi(sl) : 1;            // measured: 4 / 8 slices lose more to launches and partial rounds than
+                                                            // the cached hand-over wins (pb_experiment_scale23.log)
         want = std::max(1, std::min(want, kPbMaxSlices));
         plan->slices = want;
         plan->host_bins = new int4[bins.size()];
