@@ -20,6 +20,9 @@ using namespace pgh;
 
 namespace {
 
+#ifndef PGH_MM_UNROLL
+#define PGH_MM_UNROLL 8
+#endif
 constexpr int kLanes = 64;
 constexpr int kTileMM = 64 * PGH_BSF_IPT;        // same tile table as the single-vector layout
 
@@ -59,15 +62,16 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
         int cur = ti.z;                       // segment open when the tile starts
         bool opened = false;                  // a flag has been seen in this tile (wave-uniform)
         double acc = 0.0;                     // f64: a lane adds up to 512 terms serially (the single-vector kernel adds 8)
-        for (int e0 = 0; e0 < kTileMM; e0 += 8) {
-            uint32_t w[8];
-            float x[8];
+        constexpr int U = PGH_MM_UNROLL;                  // row gathers in flight per wavefront
+        for (int e0 = 0; e0 < kTileMM; e0 += U) {
+            uint32_t w[U];
+            float x[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = cw[e0 + j];                         // wave-uniform: scalar loads
+            for (int j = 0; j < U; ++j) w[j] = cw[e0 + j];                         // wave-uniform: scalar loads
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = live ? xg[(int64_t)(w[j] & 0x7fffffffu) * ld + lane] : 0.f;
+            for (int j = 0; j < U; ++j) x[j] = live ? xg[(int64_t)(w[j] & 0x7fffffffu) * ld + lane] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < U; ++j) {
                 if (w[j] >> 31) {                                                   // wave-uniform branch: a row segment starts
                     if (!opened) {
                         f.head[(int64_t)t * kLanes + lane] = (float)acc;            // piece of the segment open at tile start
