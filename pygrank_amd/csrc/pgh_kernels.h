@@ -92,15 +92,13 @@ __device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff
 // blocked-format entry points (pgh_bsf.hip)
 // pgh_pb.hip: propagation-blocking image of the cold entries
 struct PbPlan {
-    int4*    bin = nullptr;        // device: {first row, rows, first row-major entry, entries}
     int32_t* row_bin = nullptr;    // device: bin of every output row, -1 = too heavy for a bin
     int      num_bins = 0, num_chunks = 0;
     int64_t  entries = 0;          // cold entries that go into the image
-    int64_t  padded_entries = 0;   // row-major slots (every bin's range padded to a multiple of 8)
     int      slices = 1;           // the bins are cut into `slices` consecutive groups of about equal entry counts
     int      slice_first[kPbMaxSlices + 1] = {0};   // first bin of every slice
     int64_t  slice_entries[kPbMaxSlices] = {0};
-    int4*    host_bins = nullptr;  // host copy of `bin` (new[]), owned by the plan
+    int4*    host_bins = nullptr;  // {first row, rows, -, entries} of every bin (new[]), owned by the plan
     bool     heavy_rows = false;   // some rows keep their cold entries in the blocked stream
 };
 int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int hot, unsigned char* is_hot, PbPlan* plan, bool* use);

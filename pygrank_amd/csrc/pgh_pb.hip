@@ -31,6 +31,12 @@
 
 #include "pgh_kernels.h"
 
+// diagnostic builds only (tools/build_variants.sh): 1 no chunk fill, 2 fills only, 4 no stores (phase A); 8 no staging,
+// 16 no walk (phase B)
+#ifndef PGH_PROBE_PB
+#define PGH_PROBE_PB 0
+#endif
+
 namespace pgh {
 namespace {
 
@@ -189,9 +195,6 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
     int loaded = -1;
     for (int piece = piece_begin; piece < piece_end; ++piece) {
         const int4 task = f.task[piece];
-#ifndef PGH_PROBE_PB
-#define PGH_PROBE_PB 0
-#endif
         if (task.x != loaded && !(PGH_PROBE_PB & 1)) {
             __syncthreads();
             // cold ids [first_id, first_id + chunk) -> positions in the gather vector, block by block: the block loop is
@@ -352,7 +355,6 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
     //      consecutive staged slots, finds their run by binary search and walks forward -- sixteen independent loads per
     //      thread, i.e. one round trip for the whole bin however its entries split into runs.
     if (!(PGH_PROBE_PB & 8)) {
-        int base = 0;
         for (int c0 = 0; c0 < f.num_chunks; c0 += 64 * kPbWaves) {          // wavefront w takes descriptors c0 + 64 w ..
             const int cc = c0 + wave * 64 + lane;
             const int len = cc < f.num_chunks ? (int)lens[cc] : 0;
@@ -363,7 +365,6 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
                 s_start[cc] = start;
             }
             if (lane == 63) s_group[wave] = incl;                           // total of the group
-            (void)base;
         }
         __syncthreads();
         // groups of 64 runs -> bin-wide exclusive prefix (num_chunks <= kPbMaxChunks = 64 * kPbWaves: one pass)
@@ -542,7 +543,7 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
 
 // Decides whether the cold tail gets its own image and, if so, lays out the bins.  keys: the sorted stream
 // (block << 58 | row << 29 | col), is_hot: 1 = stays in the stream; on success entries of rows too heavy for a bin are
-// re-flagged as staying.  plan->bin / plan->row_bin are device arrays (pb_build takes the former, pb_plan_release frees).
+// re-flagged as staying.  plan->row_bin is a device array and plan->host_bins a host array, both freed by pb_plan_release.
 int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int hot, unsigned char* is_hot, PbPlan* plan, bool* use) {
     *use = false;
     // Opt-in (PGH_PB=1): measured on MI355X at scale 23 the image is correct but not yet faster than leaving the cold
@@ -604,21 +605,11 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     }
     const int64_t num_bins = (int64_t)bins.size();
     if (num_bins < 1 || num_bins >= (1 << 18) || in_image >= 2147483647LL) return 0;
-    {   // row-major slot ranges, every bin's start a multiple of 8 (lanes fetch 8 entries per 16-byte load)
-        int64_t at = 0;
-        for (int4& b : bins) {
-            b.z = (int)at;
-            at += ((int64_t)b.w + 7) & ~(int64_t)7;
-        }
-        plan->padded_entries = at;
-    }
     const double run = (double)in_image / ((double)chunks * (double)num_bins);
     const char* force = getenv("PGH_PB_FORCE");
     const bool forced = force != nullptr && atoi(force) != 0;
     if (!forced && (in_image < (1 << 22) || in_image * 20 < E || run < 24.0)) return 0;
-    PGH_HIP(hipMalloc(&plan->bin, sizeof(int4) * (size_t)num_bins));
     PGH_HIP(hipMalloc(&plan->row_bin, sizeof(int32_t) * (size_t)f.n_out));
-    PGH_HIP(hipMemcpyAsync(plan->bin, bins.data(), sizeof(int4) * bins.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMemcpyAsync(plan->row_bin, row_bin.data(), sizeof(int32_t) * f.n_out, hipMemcpyHostToDevice, r.stream));
     k_pb_keep_heavy<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, E, plan->row_bin, is_hot);
     PGH_HIP(hipGetLastError());
@@ -817,10 +808,8 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
 }
 
 void pb_plan_release(PbPlan* plan) {
-    (void)hipFree(plan->bin);
     (void)hipFree(plan->row_bin);
     delete[] plan->host_bins;
-    plan->bin = nullptr;
     plan->row_bin = nullptr;
     plan->host_bins = nullptr;
 }

@@ -393,11 +393,11 @@ def check_propagation_blocking_image(pg):
             assert np.array_equal(_np(pg.conv(_vec(pg, x), g1)), y1), name          # deterministic
             p = np.zeros(W.shape[0])
             p[rmat_np.seed_nodes(A, 50, seed=4)] = 1.0
+            from pygrank_amd.preprocessing import Adjacency
+            from pygrank_amd.signals import _IdentityMap
             runs = []
             for g in (g0, g1):
                 ranker = pg.PageRank(0.85, error_type=pg.L1, tol=1e-6, max_iters=500)
-                from pygrank_amd.preprocessing import Adjacency
-                from pygrank_amd.signals import _IdentityMap
                 adj = Adjacency(g)
                 adj._pygrank_preprocessed = {"hip": adj}
                 adj._pygrank_node2id = _IdentityMap(g.shape[0])
