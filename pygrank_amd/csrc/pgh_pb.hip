@@ -42,11 +42,18 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in phase A
-constexpr int kPbBinEntries = 15360;     // entries per bin: 60 KB of LDS in phase B (two workgroups per CU)
-constexpr int kPbMaxChunks = 1024;       // run table of a bin in LDS (8 KB)
-constexpr int kPbBinRows = 2048;         // rows per bin (8 KB of f32 row sums in LDS)
+#ifndef PGH_PB_BIN
+#define PGH_PB_BIN 15360
+#endif
+#ifndef PGH_PB_BTHREADS
+#define PGH_PB_BTHREADS 1024
+#endif
+constexpr int kPbBinEntries = PGH_PB_BIN;        // entries per bin staged in LDS by phase B
+constexpr int kPbBThreads = PGH_PB_BTHREADS;     // phase B workgroup
+constexpr int kPbBWaves = kPbBThreads / 64;
+constexpr int kPbMaxChunks = 64 * kPbBWaves;     // run table of a bin in LDS: one descriptor pass
+constexpr int kPbBinRows = kPbBinEntries >= 8192 ? 2048 : 1024;   // rows per bin (f32 row sums in LDS)
 constexpr int kPbThreads = 1024;
-constexpr int kPbWaves = kPbThreads / 64;
 constexpr uint64_t kLow29 = (1ULL << 29) - 1;
 
 template <typename T>
@@ -318,27 +325,27 @@ __device__ __forceinline__ float pb_segmented_sum(float keep, float val) {
 // part's first entry is its HEAD piece, the one that contains its last entry its TAIL piece (a part without a row change
 // is a single piece); every other segment is complete and goes straight to the bin's row array in LDS.  The pieces are
 // handed over in f64 and stitched in part order by one thread after the barrier: fixed order, no atomics.
-__global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
+__global__ __launch_bounds__(kPbBThreads) void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
     __shared__ float s_val[kPbBinEntries];                 // the bin's entries, staged: runs in chunk order
     __shared__ float s_row[kPbBinRows];                    // row sums of the bin
-    __shared__ double s_head[kPbWaves], s_tail[kPbWaves];
-    __shared__ int s_head_row[kPbWaves], s_tail_row[kPbWaves], s_pieces[kPbWaves];   // pieces: 0 none, 1 single, 2 head + tail
+    __shared__ double s_head[kPbBWaves], s_tail[kPbBWaves];
+    __shared__ int s_head_row[kPbBWaves], s_tail_row[kPbBWaves], s_pieces[kPbBWaves];   // pieces: 0 none, 1 single, 2 head + tail
     __shared__ int s_pref[kPbMaxChunks + 1];               // staged offset of every run
     __shared__ uint32_t s_start[kPbMaxChunks];             // its first entry in tmp
-    __shared__ int s_group[kPbWaves], s_group_base[kPbWaves];
+    __shared__ int s_group[kPbBWaves], s_group_base[kPbBWaves];
     if (state != nullptr && state->done) return;
     const int4 bin = f.bin[blockIdx.x];                    // {first row, rows, first row-major slot, entries}
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t* __restrict__ starts = f.run_start + (int64_t)blockIdx.x * f.num_chunks;
     const uint32_t* __restrict__ lens = f.run_len + (int64_t)blockIdx.x * f.num_chunks;
-    for (int i = tid; i < bin.y; i += kPbThreads) s_row[i] = 0.f;
+    for (int i = tid; i < bin.y; i += kPbBThreads) s_row[i] = 0.f;
     if (PGH_PROBE_PB & 8) s_val[tid] = 1.f;
     // ---- this wavefront's part of the row-major walk: the index loads of its first tile do not depend on the staging,
     //      so they are issued now and land while the runs are being staged
     constexpr int T = 512;
     const int tiles = (bin.w + T - 1) / T;
-    const int per_wave = (tiles + kPbWaves - 1) / kPbWaves;
+    const int per_wave = (tiles + kPbBWaves - 1) / kPbBWaves;
     const int t_begin = min(wave * per_wave, tiles), t_end = (PGH_PROBE_PB & 16) ? 0 : min(t_begin + per_wave, tiles);
     const uint16_t* __restrict__ perm = f.perm + bin.z;
     const uint16_t* __restrict__ drow = f.drow + bin.z;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
     //      consecutive staged slots, finds their run by binary search and walks forward -- sixteen independent loads per
     //      thread, i.e. one round trip for the whole bin however its entries split into runs.
     if (!(PGH_PROBE_PB & 8)) {
-        for (int c0 = 0; c0 < f.num_chunks; c0 += 64 * kPbWaves) {          // wavefront w takes descriptors c0 + 64 w ..
+        for (int c0 = 0; c0 < f.num_chunks; c0 += 64 * kPbBWaves) {          // wavefront w takes descriptors c0 + 64 w ..
             const int cc = c0 + wave * 64 + lane;
             const int len = cc < f.num_chunks ? (int)lens[cc] : 0;
             const uint32_t start = cc < f.num_chunks ? starts[cc] : 0u;
@@ -367,20 +374,20 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
             if (lane == 63) s_group[wave] = incl;                           // total of the group
         }
         __syncthreads();
-        // groups of 64 runs -> bin-wide exclusive prefix (num_chunks <= kPbMaxChunks = 64 * kPbWaves: one pass)
-        if (tid < kPbWaves) {
+        // groups of 64 runs -> bin-wide exclusive prefix (num_chunks <= kPbMaxChunks = 64 * kPbBWaves: one pass)
+        if (tid < kPbBWaves) {
             int acc = 0;
             for (int w = 0; w < tid; ++w) acc += s_group[w];
             s_group_base[tid] = acc;
         }
         __syncthreads();
-        for (int c = tid; c < f.num_chunks; c += kPbThreads) s_pref[c] += s_group_base[c >> 6];
+        for (int c = tid; c < f.num_chunks; c += kPbBThreads) s_pref[c] += s_group_base[c >> 6];
         if (tid == 0) s_pref[f.num_chunks] = bin.w;
         __syncthreads();
         // wavefront w fills staged slots [w * S, (w + 1) * S) in steps of 64 consecutive slots (coalesced reads of tmp:
         // neighbouring slots are neighbouring entries of a run); a lane finds its run by binary search at the first
         // step and walks forward from there (a step advances by about one run)
-        constexpr int S = kPbBinEntries / kPbWaves;                         // staged slots per wavefront
+        constexpr int S = kPbBinEntries / kPbBWaves;                         // staged slots per wavefront
         constexpr int STEPS = S / 64;
         static_assert(S % 64 == 0, "whole steps");
         const int w0 = wave * S;
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
     if (tid == 0) {
         double open = 0.0;
         int row = -1;
-        for (int w = 0; w < kPbWaves; ++w) {
+        for (int w = 0; w < kPbBWaves; ++w) {
             if (s_pieces[w] == 0) continue;
             if (s_head_row[w] == row) {                     // head (or single) piece continues the open segment
                 open += s_head[w];
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_accumulate(PbView f, const Lo
         if (row >= 0) s_row[row] = (float)open;
     }
     __syncthreads();
-    for (int i = tid; i < bin.y; i += kPbThreads) f.out[bin.x + i] = s_row[i];
+    for (int i = tid; i < bin.y; i += kPbBThreads) f.out[bin.x + i] = s_row[i];
 }
 
 PbView pb_view(const BsfFormat& f, const PbFormat& p) {
@@ -864,7 +871,7 @@ int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state) {
     }
     {
         ProfScope prof(PGH_K_PB_ACCUM);
-        if (p.num_bins > 0) k_pb_accumulate<<<p.num_bins, kPbThreads, 0, r.stream>>>(v, state);
+        if (p.num_bins > 0) k_pb_accumulate<<<p.num_bins, kPbBThreads, 0, r.stream>>>(v, state);
     }
     }
     PGH_HIP(hipGetLastError());
