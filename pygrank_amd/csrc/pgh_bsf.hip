@@ -1077,7 +1077,10 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipStreamSynchronize(r.stream));
         f.num_segs = nseg;
     }
-    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1)));
+    // + 192: k_bsf_partial prefetches the rows of 128 segments per tile unconditionally (reads past a tile's own segments
+    // are never used, but they must stay inside the allocation: found by tools/stress_gpu.py as a rare memory fault)
+    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1 + 192)));
+    PGH_HIP(hipMemsetAsync(f.seg_row, 0xff, sizeof(int32_t) * (size_t)(f.num_segs + 1 + 192), r.stream));
     k_bsf_seg_rows<<<blocks_for(EP), kBlock, 0, r.stream>>>(keys_p.p, segid.p, EP, f.seg_row);
     PGH_HIP(hipMalloc(&f.tile, sizeof(int4) * (size_t)(f.num_tiles + 1)));
     PGH_HIP(hipMalloc(&f.tail_carry, sizeof(double) * (size_t)(f.num_tiles + 1)));
