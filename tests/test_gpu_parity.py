@@ -180,3 +180,18 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend):
             got[perm[lo:lo + m]] = part[name + "_ranks"]
             assert int(part[name + "_iters"]) == want_iters, name
         assert rel_linf(got, want) <= 1e-6, name
+
+
+def test_randomised_stress(gpu_engine):
+    """tools/stress_gpu.py for 20 s: random graph shapes (empty / tiny / hub rows / power-law / uniform / banded, integer and
+    real weights) x layout switches (1-8 column blocks, relabelling, trimmed gather vector, propagation-blocking image)
+    against scipy in fp64.  Kernels are serialised so that an out-of-allocation access faults where it happens (that is how
+    the unconditional row prefetch of k_bsf_partial was caught)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, AMD_SERIALIZE_KERNEL="3", HIP_LAUNCH_BLOCKING="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_gpu.py"), "--seconds", "20", "--seed", "7"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0 and "stress ok" in res.stdout, res.stdout[-1500:] + res.stderr[-2500:]
