@@ -1,0 +1,138 @@
+"""Randomised parity of the whole filters on the GPU (run by tests/test_gpu_parity.py as a subprocess with serialised
+kernels): random graphs x layout switches x {PageRank, AbsorbingWalks, HeatKernel taylor / chebyshev, propagate} against
+the oracle (oracle/ref_loops.py) run on the engine's stored f32 matrix.  Usage: python tests/stress_filters.py --seconds 20"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import pygrank_amd as pg  # noqa: E402
+from oracle import ref_loops as orc  # noqa: E402
+from pygrank_amd.device import DeviceGraph  # noqa: E402
+from pygrank_amd.preprocessing import Adjacency  # noqa: E402
+from pygrank_amd.signals import _IdentityMap  # noqa: E402
+from stress_gpu import random_graph  # noqa: E402
+
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=20)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    pg.load_backend("hip")
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    done = 0
+    while time.time() < t_end:
+        A = random_graph(rng)
+        n = A.shape[0]
+        if n < 2 or A.nnz == 0 or n > 80000:
+            continue
+        for key, val in (("PGH_BLOCKS", str(int(rng.choice([1, 2, 4, 8])))), ("PGH_RELABEL", str(int(rng.integers(0, 2)))),
+                         ("PGH_PB", str(int(rng.random() < 0.3))), ("PGH_PB_FORCE", "1"), ("PGH_TRIM", str(int(rng.integers(0, 2))))):
+            os.environ[key] = val
+        norm = str(rng.choice(["col", "symmetric"]))
+        g = DeviceGraph.from_adjacency(A, norm)
+        M = sp.csr_array(g.download_transposed().T.astype(np.float64))        # the engine's matrix (f32 values), un-transposed
+        adj = Adjacency(g)
+        adj._pygrank_preprocessed = {"hip": adj}
+        adj._pygrank_node2id = _IdentityMap(n)
+        adj.is_directed = lambda: True
+        p = np.zeros(n)
+        p[rng.integers(0, n, min(n, 7))] = 0.5 + rng.random(min(n, 7))
+        desc = f"#{done} n={n} nnz={A.nnz} norm={norm} " + " ".join(f"{k}={os.environ[k]}" for k in ("PGH_BLOCKS", "PGH_RELABEL", "PGH_PB", "PGH_TRIM"))
+        which = int(rng.integers(0, 5))
+        if which == 0:
+            kw = dict(alpha=float(rng.choice([0.5, 0.85, 0.99])), use_quotient=bool(rng.integers(0, 2)))
+            err = str(rng.choice(["l1", "mabs", "linf"]))
+            tol = float(rng.choice([1e-5, 1e-6]))
+            ranker = pg.PageRank(kw["alpha"], use_quotient=kw["use_quotient"], error_type={"l1": pg.L1, "mabs": pg.Mabs, "linf": pg.MaxDifference}[err],
+                                 tol=tol, max_iters=300)
+            try:
+                want, it = orc.pagerank(M, p, error_type=err, tol=tol, max_iters=300, eps=EPS32, **kw)
+            except Exception:                                      # does not converge in 300 iterations: the engine must say so too
+                try:
+                    ranker.rank(adj, p.copy())
+                except Exception:
+                    done += 1
+                    continue
+                print("MISSING non-convergence exception", desc, flush=True)
+                sys.exit(1)
+        elif which == 1:
+            ranker = pg.AbsorbingWalks(0.85, error_type=pg.L1, tol=1e-6, max_iters=300)
+            try:
+                want, it = orc.absorbing_walks(M, p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=300, eps=EPS32)
+            except Exception:
+                try:
+                    ranker.rank(adj, p.copy())
+                except Exception:
+                    done += 1
+                    continue
+                print("MISSING non-convergence exception", desc, flush=True)
+                sys.exit(1)
+        elif which in (2, 3):
+            ctype = "taylor" if which == 2 else "chebyshev"
+            want, it = orc.heat_kernel(M, p, t=3, coefficient_type=ctype, error_type="iters", max_iters=20, eps=EPS32)
+            ranker = pg.HeatKernel(3, coefficient_type=ctype, error_type="iters", max_iters=20)
+        else:
+            b = int(rng.choice([1, 3, 17]))
+            feats = np.zeros((n, b))
+            for j in range(b):
+                feats[rng.integers(0, n, 3), j] = 1.0 + j
+            ranker = pg.PageRank(0.85, error_type=pg.L1, tol=1e-6, max_iters=300)
+            oracle_runs, oracle_fails = [], False
+            for j in range(b):
+                try:
+                    oracle_runs.append(orc.pagerank(M, feats[:, j], alpha=0.85, error_type="l1", tol=1e-6, max_iters=300, eps=EPS32))
+                except Exception:
+                    oracle_fails = True
+                    oracle_runs.append(None)
+            try:
+                out = np.asarray(ranker.propagate(adj, pg.to_primitive(feats)))
+            except Exception as exc:
+                if oracle_fails:                                   # a column that does not converge raises in both
+                    done += 1
+                    continue
+                print("EXCEPTION propagate", desc, exc, flush=True)
+                sys.exit(1)
+            if oracle_fails:
+                print("MISSING non-convergence exception in propagate", desc, flush=True)
+                sys.exit(1)
+            for j in range(b):
+                want, it = oracle_runs[j]
+                its = ranker.last_batches[0][j]["iterations"]
+                rel = np.max(np.abs(out[:, j] - want)) / max(np.max(np.abs(want)), 1e-30)
+                # a residual within f32 rounding of the tolerance may stop one iteration apart: the iterates then differ by ~tol
+                if abs(its - it) > 1 or rel > (2e-6 if its == it else 6e-6):
+                    print("MISMATCH propagate", desc, "column", j, rel, "iterations", its, it, flush=True)
+                    sys.exit(1)
+            done += 1
+            continue
+        try:
+            got = np.asarray(ranker.rank(adj, p.copy()).np)
+        except Exception as exc:                                   # non-convergence must agree with the oracle too
+            print("EXCEPTION", desc, type(ranker).__name__, exc, flush=True)
+            sys.exit(1)
+        rel = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-30)
+        its = ranker.convergence.iteration
+        tolerance_based = which in (0, 1)
+        tol = tol if which == 0 else 1e-6
+        # a residual within f32 rounding of the tolerance may stop one iteration apart: the iterates then differ by ~tol
+        bound = 4e-6 if which == 3 else (2e-6 if its == it else max(2e-6, 6 * tol))   # chebyshev: parity_common.py
+        if rel > bound or (tolerance_based and abs(its - it) > 1) or (not tolerance_based and its != it):
+            print("MISMATCH", type(ranker).__name__, desc, "rel", rel, "iterations", its, it, flush=True)
+            sys.exit(1)
+        done += 1
+    print(f"filters stress ok: {done} runs in {args.seconds:.0f} s (seed {args.seed})", flush=True)
+
+
+if __name__ == "__main__":
+    main()

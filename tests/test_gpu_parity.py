@@ -195,3 +195,17 @@ def test_randomised_stress(gpu_engine):
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_gpu.py"), "--seconds", "20", "--seed", "7"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0 and "stress ok" in res.stdout, res.stdout[-1500:] + res.stderr[-2500:]
+
+
+def test_randomised_filters(gpu_engine):
+    """tests/stress_filters.py for 20 s: random graphs x layout switches x {PageRank (3 residuals, with / without quotient),
+    AbsorbingWalks, HeatKernel taylor / chebyshev, propagate} against the oracle on the engine's stored matrix, including
+    agreement on non-convergence; kernels serialised."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, AMD_SERIALIZE_KERNEL="3", HIP_LAUNCH_BLOCKING="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_filters.py"), "--seconds", "20", "--seed", "11"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0 and "filters stress ok" in res.stdout, res.stdout[-1500:] + res.stderr[-2500:]
