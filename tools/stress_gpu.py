@@ -73,6 +73,7 @@ def main():
         if os.environ.get("PGH_STRESS_VERBOSE"):
             print(desc, flush=True)
         if args.only >= 0 and done != args.only:                    # same draws as a full run, no GPU work
+            rng.integers(0, 3)
             rng.random(n)
             if n >= 2 and A.nnz > 0 and norm in ("col", "symmetric"):
                 rng.integers(0, n, min(n, 5))
@@ -83,7 +84,15 @@ def main():
             continue
         if args.only >= 0:
             sp.save_npz(os.path.join(ROOT, "gpurun_out", f"stress_graph_{done}.npz"), sp.csr_matrix(A))
-        g = DeviceGraph.from_adjacency(A, norm)
+        route = int(rng.integers(0, 3))          # device-side normalisation / factored upload / plain valued upload
+        if route == 0:
+            g = DeviceGraph.from_adjacency(A, norm)
+        else:
+            from pygrank_amd.preprocessing import normalize_adjacency
+            N = normalize_adjacency(A, norm)
+            if route == 2:
+                N = sp.csr_array((N.data.copy(), N.indices.copy(), N.indptr.copy()), shape=N.shape)   # drops the factors
+            g = pg.scipy_sparse_to_backend(N)
         MT = g.download_transposed().astype(np.float64)            # the stored f32 values, exactly
         x = rng.random(n).astype(np.float32).astype(np.float64)
         y = np.asarray(pg.conv(DeviceVector.from_host(x), g))
