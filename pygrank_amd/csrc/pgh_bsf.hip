@@ -1118,6 +1118,9 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         unsigned long long hcount = 0;
         PGH_HIP(hipMemcpyAsync(&hcount, cnt.p, sizeof(hcount), hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
+        fprintf(stderr, "[pgh] bsf: tiles per block:");
+        for (int b = 0; b < B; ++b) fprintf(stderr, " %d", f.tile_begin[b + 1] - f.tile_begin[b]);
+        fprintf(stderr, "\n");
         fprintf(stderr, "[pgh] bsf: B=%d blk=%d entries=%lld (padded %lld) segs=%lld tiles=%d hot=%d covers %.1f%% of entries, value-free=%d relabel=%d\n",
                 B, blk, (long long)E, (long long)EP, (long long)f.num_segs, f.num_tiles, kBsfHot, 100.0 * (double)hcount / (double)EP,
                 val ? 0 : 1, relabel ? 1 : 0);
