@@ -209,3 +209,23 @@ def test_randomised_filters(gpu_engine):
     res = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_filters.py"), "--seconds", "20", "--seed", "11"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0 and "filters stress ok" in res.stdout, res.stdout[-1500:] + res.stderr[-2500:]
+
+
+def test_bench_two_ranks_on_one_gpu(gpu_engine):
+    """The driver's N > 1 launch of bench.py on the real engine: two ranks sharing this box's GPU (gloo transport, see
+    test_row_partitioned_path_on_one_gpu), one JSON line on stdout from rank 0, whole-job value."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "16"]
+    env = dict(os.environ, PYTHONPATH=root, PGH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["unit"] == "GTEPS"
+    assert out["config"]["exchange_bytes_per_iteration_per_gpu"] > 0 and len(out["config"]["iterations_per_step"]) == 2
