@@ -9,7 +9,8 @@
 //      (blockIdx % 8, a speed-only affinity), so that slice stays resident in that XCD's L2 while the matrix
 //      stream passes through with non-temporal loads;
 //   3. per block, entries are sorted by (row, col) and a row segment is marked by bit 31 of its first column
-//      index: the SpMV pass reads no row pointers and never touches empty rows;
+//      index: the SpMV pass reads no row pointers and never touches empty rows (k_bsf_pack then digests the stream for
+//      the kernel: block-local byte offsets, one flag byte per lane, tiles transposed for coalesced 16-byte loads);
 //   4. when M^T = diag(dst) * W * diag(src) with small integer W (the preprocessor's "col"/"symmetric"
 //      normalisations of an unweighted or multi-edge graph, preprocessing.py:109-138) the values disappear:
 //      multiplicities become repeated entries (4 B/edge), src moves into the gather vector, dst into the epilogue.
