@@ -417,10 +417,14 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
-    const int label = blockIdx.x & 7;
+#ifndef PGH_XCD_AFFINE
+#define PGH_XCD_AFFINE 1
+#endif
+    const int label = PGH_XCD_AFFINE ? (blockIdx.x & 7) : (int)((blockIdx.x * 8u) / gridDim.x);
+    const int slot = PGH_XCD_AFFINE ? (blockIdx.x >> 3) : (int)(blockIdx.x % (gridDim.x >> 3));
     const int b = label % f.num_blocks;
     const int per = 8 / f.num_blocks;
-    const int rank = ((blockIdx.x >> 3) * per + label / f.num_blocks) * WAVES + wave;
+    const int rank = (slot * per + label / f.num_blocks) * WAVES + wave;
     const int stride = (gridDim.x >> 3) * per * WAVES;
     float* __restrict__ part = f.part + (int64_t)b * f.part_stride;
     const int64_t base = f.xg_base[b];
