@@ -140,22 +140,20 @@ struct PbFormat {
     int64_t   num_entries = 0;      // cold entries in the image (multiplicities expanded)
     int       chunk = 0;            // sources per chunk (phase A keeps one chunk of the gather vector in LDS)
     int       num_chunks = 0;
-    int       num_bins = 0;         // bins = runs of consecutive output rows with <= kPbBinEntries cold entries
+    int       num_bins = 0;         // bins = runs of consecutive output rows (bounded rows and cold entries)
     int       hot = 0;              // sources of every block that stay in the hot cache (not part of this image)
     int64_t   cold_prefix[9] = {0}; // first cold id of every block (cold ids number the referenced cold sources, block-major)
-    // phase A order: (chunk, bin, row, source)
-    uint16_t* sloc = nullptr;       // [num_entries] source index inside its chunk
-    float*    val = nullptr;        // [num_entries] or null (value-free)
+    // A order: [chunk][bin] runs, each padded to whole groups of 8 entries
+    uint16_t* sloc = nullptr;       // [padded] source index inside its chunk
+    float*    val = nullptr;        // [padded] or null (value-free)
+    uint32_t* dstg = nullptr;       // [padded / 8] group of B order that receives this group's values
     int       num_tasks = 0;
     int4*     task = nullptr;       // phase A pieces {chunk, entry_begin, entry_end, 0}: consecutive ranges of the entry stream
     int*      task_range = nullptr; // [num_tasks + 1] pieces of every phase A workgroup (equal shares of the stream)
-    float*    tmp = nullptr;        // [num_entries] gathered (and weighted) source values, phase A order
-    // phase B: per bin the runs (one per chunk) that hold its entries in tmp, and its entries in row-major order
-    uint32_t* run_start = nullptr;  // [num_bins][num_chunks] first entry of run (bin, chunk) in tmp
-    uint32_t* run_len = nullptr;    // [num_bins][num_chunks]
-    int4*     bin = nullptr;        // [num_bins] {first output row, rows, first row-major entry, entries}
-    uint16_t* perm = nullptr;       // [num_entries] row-major order: position of the entry inside its bin's staged region
-    uint16_t* drow = nullptr;       // [num_entries] row-major order: output row inside the bin
+    // B order: [bin][chunk] runs (the same runs): a bin is one contiguous range
+    float*    tmp = nullptr;        // [padded] gathered (and weighted) source values, written by phase A
+    int4*     bin = nullptr;        // [num_bins] {first output row, rows, first group, groups}
+    uint16_t* drow = nullptr;       // [padded] output row inside the bin (0xffff = pad entry)
     float*    out = nullptr;        // [n_out] cold part of every row sum (structurally empty rows stay 0)
     bool      owns_out = true;      // slices of one image share the output vector of the first
     int64_t   device_bytes = 0;
