@@ -152,7 +152,8 @@ struct PbFormat {
     int*      task_range = nullptr; // [num_tasks + 1] pieces of every phase A workgroup (equal shares of the stream)
     // B order: [bin][chunk] runs (the same runs): a bin is one contiguous range
     float*    tmp = nullptr;        // [padded] gathered (and weighted) source values, written by phase A
-    int4*     bin = nullptr;        // [num_bins] {first output row, rows, first group, groups}
+    int4*     bin = nullptr;        // [num_bins] {first output row, rows | log2ceil(largest row's entries) << 16, first group, groups}
+    uint32_t* amax = nullptr;       // [2] max |value| phase A wrote (bit pattern); phase B's exit tickets
     uint16_t* drow = nullptr;       // [padded] output row inside the bin (0xffff = pad entry)
     float*    out = nullptr;        // [n_out] cold part of every row sum (structurally empty rows stay 0)
     bool      owns_out = true;      // slices of one image share the output vector of the first

@@ -16,9 +16,14 @@
 //                             + 4 B target group read, 8 LDS gathers, 32 B written to the group's place in B order.
 //                             Writes land in runs of cells: ~2-3 KB each on the bench graph.
 //   phase B  k_pb_accumulate  one workgroup per bin: the bin's part of the B-order stream is ONE contiguous range: 32 B
-//                             of values + 16 B of 2-byte row indices per group, f32 atomic adds into the bin's LDS row
-//                             sums, rows written once, coalesced.  The order of the additions inside a row is not fixed:
-//                             results differ from run to run in the last bits (the blocked stream is deterministic).
+//                             of values + 16 B of 2-byte row indices per group.  The row sums of the bin live in LDS
+//                             as 64-BIT FIXED-POINT numbers and every entry is one integer LDS atomic add (f32 LDS
+//                             atomics run ~12x slower on gfx950: 386 us against 95 us for this kernel).  Integer sums
+//                             do not depend on the order of the additions: the result is deterministic.  The scale is
+//                             a power of two chosen per bin from max |value| of this launch (found by phase A) and the
+//                             bin's largest row, so that no row sum can overflow: an entry keeps
+//                             min(51, 62 - log2(rows' max entries)) bits below the launch's largest value -- f32-exact
+//                             for every value above ~1e-8 of it, absolute error below 2^-51 of it otherwise.
 //
 // ~12.5 sequential bytes per cold entry instead of one L2 request.
 //
@@ -44,12 +49,12 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in phase A
 #ifndef PGH_PB_ROWS
-#define PGH_PB_ROWS 16384
+#define PGH_PB_ROWS 8192
 #endif
 #ifndef PGH_PB_BTHREADS
 #define PGH_PB_BTHREADS 512
 #endif
-constexpr int kPbBinRows = PGH_PB_ROWS;          // rows per bin: f32 row sums in LDS during phase B (<= 32768: 15-bit keys)
+constexpr int kPbBinRows = PGH_PB_ROWS;          // rows per bin: 64-bit row sums in LDS during phase B (<= 32768: 15-bit keys)
 constexpr int kPbBinEntries = 6 * kPbBinRows;    // entries per bin (balance: the heavy rows come first)
 constexpr int kPbHeavyRow = 16384;               // a row with more cold entries keeps them in the blocked stream
 constexpr int kPbBThreads = PGH_PB_BTHREADS;     // phase B workgroup
@@ -171,6 +176,7 @@ struct PbView {
     const int4*     bin;
     const uint16_t* drow;
     float*          out;
+    uint32_t*       amax;              // [0] bit pattern of max |value| written by phase A, [1] phase B's exit tickets
     int64_t         cold_prefix[9];
     int64_t         xg_base[8];
     int             num_blocks, hot, chunk, num_chunks, num_bins;
@@ -184,7 +190,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool HAS_VAL>
 __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float* __restrict__ xg, const LoopState* __restrict__ state) {
     __shared__ float s_x[kPbChunk];
+    __shared__ uint32_t s_amax;
     if (state != nullptr && state->done) return;
+    if (threadIdx.x == 0) s_amax = 0u;
+    uint32_t amax = 0u;                 // bit pattern of max |value| this thread wrote (NaN > inf > finite as integers)
     // this workgroup's share of the entry stream: consecutive pieces, each inside one chunk; the LDS image of the chunk
     // is refilled only when the chunk changes
     const int piece_begin = f.task_range[blockIdx.x], piece_end = f.task_range[blockIdx.x + 1];
@@ -263,34 +272,55 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
                     if (lo.x + hi.w == 123.456f) f.tmp[e] = lo.y;
                     continue;
                 }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    amax = max(amax, max(__float_as_uint(lo[k]) & 0x7fffffffu, __float_as_uint(hi[k]) & 0x7fffffffu));
                 float* __restrict__ dst = f.tmp + (int64_t)to[q] * 8;
                 *reinterpret_cast<f32x4*>(dst) = lo;
                 *reinterpret_cast<f32x4*>(dst + 4) = hi;
             }
         }
     }
+    // max |value| of this launch: wavefront -> workgroup -> one global atomic
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, d, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && amax != 0u) atomicMax(&s_amax, amax);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_amax != 0u) atomicMax(f.amax, s_amax);
 }
 
 // ---- phase B
 // One workgroup per bin; the bin's entries are one contiguous range of whole 8-entry groups in B order.  Pad entries
-// carry row 0xffff.
+// carry row 0xffff.  Row sums: 64-bit fixed point in LDS, integer atomics (see the head of this file).
 __global__ __launch_bounds__(kPbBThreads) void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
-    __shared__ float s_row[kPbBinRows];
+    __shared__ unsigned long long s_row[kPbBinRows];
     if (state != nullptr && state->done) return;
-    const int4 bin = f.bin[blockIdx.x];                    // {first row, rows, first group, groups}
+    const int4 bin = f.bin[blockIdx.x];                    // {first row, rows | log2ceil(largest row) << 16, first group, groups}
+    const int rows = bin.y & 0xffff, count_bits = bin.y >> 16;
     const int tid = threadIdx.x;
-    for (int i = tid; i < bin.y; i += kPbBThreads) s_row[i] = 0.f;
+    const uint32_t amax = __builtin_nontemporal_load(f.amax);
+    const bool finite = amax < 0x7f800000u;                // inf / NaN among the values: the sums are not representable
+    // |value| <= amax < 2^e; an entry gets E = min(51, 62 - count_bits) bits: |value * S| < 2^E with S = 2^(E - e), and a
+    // row of <= 2^count_bits entries stays below 2^62
+    const int e = (int)(amax >> 23) - 126;                 // amax < 2^e (denormals: e = -126, still an upper bound)
+    const int E = min(51, 62 - count_bits);
+    const double S = __longlong_as_double((long long)(1023 + E - e) << 52);
+    const double inv_S = __longlong_as_double((long long)(1023 - E + e) << 52);
+    constexpr double kMagic = 6755399441055744.0;          // 1.5 * 2^52: fma(v, S, magic) holds round(v * S) in its low bits
+    for (int i = tid; i < rows; i += kPbBThreads) s_row[i] = 0ULL;
     __syncthreads();
+    const int groups = finite ? bin.w : 0;
     const float* __restrict__ tmp = f.tmp + (int64_t)bin.z * 8;
     const uint16_t* __restrict__ drow = f.drow + (int64_t)bin.z * 8;
     constexpr int P = 4;                                    // groups per thread in flight: twelve 16-byte loads
-    for (int g0 = tid; g0 < bin.w; g0 += kPbBThreads * P) {
+    for (int g0 = tid; g0 < groups; g0 += kPbBThreads * P) {
         u16x8 r8[P];
         f32x4 lo[P], hi[P];
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             const int g = g0 + q * kPbBThreads;
-            const bool ok = g < bin.w && !(PGH_PROBE_PB & 8);
+            const bool ok = g < groups && !(PGH_PROBE_PB & 8);
             r8[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + (int64_t)g * 8))
                        : u16x8{0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff};
             lo[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + (int64_t)g * 8)) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -300,7 +330,7 @@ __global__ __launch_bounds__(kPbBThreads) void k_pb_accumulate(PbView f, const L
             float z = 0.f;
 #pragma unroll
             for (int q = 0; q < P; ++q) z += lo[q].x + hi[q].w + (float)r8[q][3];
-            if (z == 123.456f) s_row[0] = z;
+            if (z == 123.456f) s_row[0] = 1ULL;
             continue;
         }
 #pragma unroll
@@ -309,12 +339,20 @@ __global__ __launch_bounds__(kPbBThreads) void k_pb_accumulate(PbView f, const L
             for (int k = 0; k < 8; ++k) {
                 const int r = (int)r8[q][k];
                 const float v = k < 4 ? lo[q][k] : hi[q][k - 4];
-                if (r < bin.y) atomicAdd(&s_row[r], v);
+                const long long fixed = __double_as_longlong(__builtin_fma((double)v, S, kMagic)) - __double_as_longlong(kMagic);
+                if (r < rows) atomicAdd(&s_row[r], (unsigned long long)fixed);
             }
         }
     }
     __syncthreads();
-    for (int i = tid; i < bin.y; i += kPbBThreads) f.out[bin.x + i] = s_row[i];
+    for (int i = tid; i < rows; i += kPbBThreads)
+        f.out[bin.x + i] = finite ? (float)((double)(long long)s_row[i] * inv_S) : __uint_as_float(0x7fc00000u);
+    // the last workgroup to leave re-arms the words for the next launch (every workgroup has read amax long before its
+    // ticket; the next phase A starts after this kernel)
+    if (tid == 0 && atomicAdd(f.amax + 1, 1u) == gridDim.x - 1) {
+        f.amax[0] = 0u;
+        f.amax[1] = 0u;
+    }
 }
 
 PbView pb_view(const BsfFormat& f, const PbFormat& p) {
@@ -328,6 +366,7 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.bin = p.bin;
     v.drow = p.drow;
     v.out = p.out;
+    v.amax = p.amax;
     for (int i = 0; i < 9; ++i) v.cold_prefix[i] = p.cold_prefix[i];
     for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base[i];
     v.num_blocks = f.num_blocks;
@@ -365,12 +404,13 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     std::vector<int32_t> row_bin(f.n_out);
     int64_t cold = 0, in_image = 0;
     int row0 = 0, rows = 0;
-    int64_t fill = 0;
+    int64_t fill = 0, largest = 0;     // cold entries of the open bin, and of its largest row
     bool heavy_rows = false;
     auto close_bin = [&]() {
-        if (rows > 0) bins.push_back(make_int4(row0, rows, 0, (int)fill));
+        if (rows > 0) bins.push_back(make_int4(row0, rows, (int)largest, (int)fill));
         rows = 0;
         fill = 0;
+        largest = 0;
     };
     for (int i = 0; i < f.n_out; ++i) {
         const int64_t c = counts[i];
@@ -386,6 +426,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         row_bin[i] = (int32_t)bins.size();
         ++rows;
         fill += c;
+        largest = std::max<int64_t>(largest, c);
         in_image += c;
     }
     close_bin();
@@ -521,6 +562,9 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     const int64_t padded = chunk_start[p.num_chunks];
     PGH_CHECK(padded == (int64_t)bin_start[p.num_bins] && padded < 2147483647LL, "propagation blocking: layout totals disagree");
     for (int w = 0; w < p.num_bins; ++w) {
+        int count_bits = 0;                                // 2^count_bits >= entries of the bin's largest row
+        while ((1 << count_bits) < mine[w].z) ++count_bits;
+        mine[w].y |= count_bits << 16;
         mine[w].z = (int)(bin_start[w] >> 3);
         mine[w].w = (int)((bin_start[w + 1] - bin_start[w]) >> 3);
     }
@@ -584,6 +628,8 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     if (!tasks.empty()) PGH_HIP(hipMemcpyAsync(p.task, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMemcpyAsync(p.task_range, ranges.data(), sizeof(int) * (shares + 1), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMalloc(&p.tmp, sizeof(float) * (size_t)(padded + 8)));
+    PGH_HIP(hipMalloc(&p.amax, sizeof(uint32_t) * 2));
+    PGH_HIP(hipMemsetAsync(p.amax, 0, sizeof(uint32_t) * 2, r.stream));
     if (slice == 0) {
         PGH_HIP(hipMalloc(&p.out, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1)));
         PGH_HIP(hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1), r.stream));
@@ -668,6 +714,7 @@ void pb_destroy(PbFormat& p) {
     (void)hipFree(p.task_range);
     (void)hipFree(p.tmp);
     (void)hipFree(p.dstg);
+    (void)hipFree(p.amax);
     (void)hipFree(p.bin);
     (void)hipFree(p.drow);
     if (p.owns_out) (void)hipFree(p.out);
