@@ -27,7 +27,9 @@
 //
 // ~12.5 sequential bytes per cold entry instead of one L2 request.
 //
-// STATUS: experimental, opt-in with PGH_PB=1 (PGH_PB_FORCE=1 lifts the size heuristics for tests).
+// Used whenever the image holds >= ~20 M cold entries (pb_plan; PGH_PB=0 switches it off, PGH_PB_FORCE=1 lifts the size
+// heuristics for tests); not yet for row-partitioned graphs and the multi-seed layout.  Bench graph (RMAT scale 23):
+// k_bsf_partial 137 us + phase A 80 us + phase B 80 us against 375 us with the cold gathers left in the stream.
 // profiles/r01/pb_experiment_scale23.log holds the history (v1/v2: bins of <= 15 K ENTRIES staged in LDS and walked
 // row-major, deterministic, but 6463 bins x 114 chunks made the runs 250 bytes long and phase B DRAM-inefficient).
 #include <hipcub/hipcub.hpp>
@@ -49,7 +51,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in phase A
 #ifndef PGH_PB_ROWS
-#define PGH_PB_ROWS 8192
+#define PGH_PB_ROWS 4096
 #endif
 #ifndef PGH_PB_BTHREADS
 #define PGH_PB_BTHREADS 512
@@ -385,9 +387,9 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
 // re-flagged as staying.  plan->row_bin is a device array and plan->host_bins a host array, both freed by pb_plan_release.
 int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int hot, unsigned char* is_hot, PbPlan* plan, bool* use) {
     *use = false;
-    // Opt-in (PGH_PB=1), see the STATUS note at the top of this file.
+    // PGH_PB=0 switches the image off; PGH_PB_FORCE=1 lifts the size heuristics below (tests).
     const char* env = getenv("PGH_PB");
-    if (env == nullptr || atoi(env) == 0) return 0;
+    if (env != nullptr && atoi(env) == 0) return 0;
     Runtime& r = rt();
     int64_t cold_sources = 0;
     for (int b = 0; b < f.num_blocks; ++b) cold_sources += live[b] > hot ? live[b] - hot : 0;
@@ -448,7 +450,11 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     const double run = (double)in_image / ((double)chunks * (double)num_bins);
     const char* force = getenv("PGH_PB_FORCE");
     const bool forced = force != nullptr && atoi(force) != 0;
-    if (!forced && (in_image < (1 << 22) || in_image * 20 < E || run < 24.0)) return 0;
+    // Worth it when the saved L2 requests (~4.2 ps per cold entry on MI355X) outweigh ~12.5 streamed bytes per entry
+    // (~2.9 ps) plus two launches, the chunk fills and a fifth vector in the combine (~28 us): from ~20 M cold entries.
+    // Measured (profiles/r01/pb_skew_scales.log): RMAT a=.57 scale 21 (11 M cold) -15 %, scale 22 (23 M) +-0, scale 23
+    // +11 %, scale 24 +13 %; uniform graphs x2.0 .. x2.4 at every scale.
+    if (!forced && (in_image < 20 * (1LL << 20) || in_image * 20 < E || run < 24.0)) return 0;
     PGH_HIP(hipMalloc(&plan->row_bin, sizeof(int32_t) * (size_t)f.n_out));
     PGH_HIP(hipMemcpyAsync(plan->row_bin, row_bin.data(), sizeof(int32_t) * f.n_out, hipMemcpyHostToDevice, r.stream));
     k_pb_keep_heavy<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, E, plan->row_bin, is_hot);

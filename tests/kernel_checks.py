@@ -365,8 +365,10 @@ def check_device_preprocessor_matches_host(pg):
 
 
 def check_propagation_blocking_image(pg):
-    """The opt-in propagation-blocking image of the cold tail (PGH_PB=1, csrc/pgh_pb.hip): same products and same
-    PageRank as the default layout, for value-free and valued graphs, deterministic.  (No-op on the test double.)"""
+    """The propagation-blocking image of the cold tail (csrc/pgh_pb.hip; forced here, large graphs get it by default):
+    same products and same PageRank as with the cold gathers left in the stream, for value-free and valued graphs,
+    deterministic, and exact to f32 rounding over 30 decades of input magnitudes (its row sums are 64-bit fixed point).
+    (No-op on the test double.)"""
     import os
     from pygrank_amd import _lib as L
     if L._is_test_double:
@@ -379,7 +381,7 @@ def check_propagation_blocking_image(pg):
     saved = {k: os.environ.get(k) for k in ("PGH_PB", "PGH_PB_FORCE")}
     try:
         for name, W in (("int", A), ("real", Wreal)):
-            os.environ.pop("PGH_PB", None)
+            os.environ["PGH_PB"] = "0"
             os.environ.pop("PGH_PB_FORCE", None)
             g0 = DeviceGraph.from_adjacency(W, "col")
             os.environ["PGH_PB"], os.environ["PGH_PB_FORCE"] = "1", "1"
@@ -391,6 +393,13 @@ def check_propagation_blocking_image(pg):
             scale = np.abs(x) @ np.abs(N)
             assert np.all(np.abs(y0 - y1) <= 8 * EPS32 * scale + 1e-30), name
             assert np.array_equal(_np(pg.conv(_vec(pg, x), g1)), y1), name          # deterministic
+            # signed values over 30 decades: every row stays within f32 rounding of the exact sum, plus the fixed-point
+            # quantum of the launch (<= 2^-48 of the largest |value| per entry)
+            xw = (rng.choice([-1.0, 1.0], W.shape[0]) * 10.0 ** rng.uniform(-30, 0, W.shape[0])).astype(F32).astype(np.float64)
+            yw = _np(pg.conv(_vec(pg, xw), g1))
+            exact = xw @ N
+            bound = 8 * EPS32 * (np.abs(xw) @ np.abs(N)) + 1e-11 * np.max(np.abs(xw)) * np.max(np.abs(N.data))
+            assert np.all(np.abs(yw - exact) <= bound), (name, float(np.max(np.abs(yw - exact) / bound)))
             p = np.zeros(W.shape[0])
             p[rmat_np.seed_nodes(A, 50, seed=4)] = 1.0
             from pygrank_amd.preprocessing import Adjacency
