@@ -12,4 +12,4 @@ for pass in "A:FETCH_SIZE" "B:WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $O/pmc_${TAG}_$name -- python3 $R/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu > $O/pmc_${TAG}_$name.log 2>&1
   echo "pmc $name rc=$?"
 done
-cd $R; python tools/summarize_pmc.py $O/pmc_${TAG}_summary.json $O/pmc_${TAG}_A $O/pmc_${TAG}_B | grep -E "bsf_partial|bsf_combine|bsf_fixup|residual"
+cd $R; python tools/summarize_pmc.py $O/pmc_${TAG}_summary.json $O/pmc_${TAG}_A $O/pmc_${TAG}_B | grep -E "bsf_partial|bsf_combine|bsf_fixup|k_pb_|residual"
