@@ -978,7 +978,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
     const int hot_slots = kBsfHot < blk ? kBsfHot : blk;
-    if (!batch_layout && g->part_perm == nullptr && hot_slots < blk && E > B) {
+    if (!batch_layout && hot_slots < blk && E > B) {
         DevBuf<unsigned char> is_hot;
         DevBuf<int64_t> num_hot;
         PGH_TRY(is_hot.alloc(E));

@@ -141,6 +141,7 @@ struct PbFormat {
     int       chunk = 0;            // sources per chunk (phase A keeps one chunk of the gather vector in LDS)
     int       num_chunks = 0;
     int       num_bins = 0;         // bins = runs of consecutive output rows (bounded rows and cold entries)
+    int       bin_rows = 0;         // rows per bin at most (selects the phase B kernel shape)
     int       hot = 0;              // sources of every block that stay in the hot cache (not part of this image)
     int64_t   cold_prefix[9] = {0}; // first cold id of every block (cold ids number the referenced cold sources, block-major)
     // A order: [chunk][bin] runs, each padded to whole groups of 8 entries

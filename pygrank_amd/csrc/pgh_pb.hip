@@ -5,9 +5,9 @@
 // section 4).  This image removes them: the cold entries are taken out of the stream and processed by two streaming
 // passes whose random accesses all land in LDS.
 //
-//   bins     runs of consecutive output rows: <= kPbBinRows rows (their f32 sums live in LDS during phase B) and
-//            <= kPbBinEntries cold entries (balance); a row with more than kPbHeavyRow cold entries keeps them in the
-//            blocked stream
+//   bins     runs of consecutive output rows: <= 4096 rows (their sums live in LDS during phase B; 16384 when the graph
+//            has so many chunks that the runs below would get short) and <= 6 cold entries per row on average (balance);
+//            a row with more than kPbHeavyRow cold entries keeps them in the blocked stream
 //   cells    (source chunk, bin) pairs; the entries of a cell form a RUN, padded to a multiple of 8 entries.  The same
 //            runs are laid out twice: A order = [chunk][bin] (what phase A reads), B order = [bin][chunk] (what phase B
 //            reads); an 8-entry group of one order maps to one 8-entry group of the other.
@@ -56,10 +56,13 @@ constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in 
 #ifndef PGH_PB_BTHREADS
 #define PGH_PB_BTHREADS 512
 #endif
-constexpr int kPbBinRows = PGH_PB_ROWS;          // rows per bin: 64-bit row sums in LDS during phase B (<= 32768: 15-bit keys)
-constexpr int kPbBinEntries = 6 * kPbBinRows;    // entries per bin (balance: the heavy rows come first)
+// rows per bin = 64-bit row sums in LDS during phase B (<= 32768: 15-bit keys).  Two shapes: the small one (32 KB, four
+// workgroups per CU) is the faster kernel; the large one (128 KB, one workgroup per CU) keeps the (chunk, bin) runs
+// long enough on graphs with many chunks (row-partitioned slices gather from the whole source space).
+constexpr int kPbBinRows = PGH_PB_ROWS, kPbBThreads = PGH_PB_BTHREADS;
+constexpr int kPbBinRowsLarge = 16384, kPbBThreadsLarge = 1024;
+constexpr int kPbBinFill = 6;                    // entries per bin <= kPbBinFill * rows (balance: the heavy rows come first)
 constexpr int kPbHeavyRow = 16384;               // a row with more cold entries keeps them in the blocked stream
-constexpr int kPbBThreads = PGH_PB_BTHREADS;     // phase B workgroup
 constexpr int kPbMaxChunks = 8192;               // 13-bit chunk field of the sort key
 constexpr int kPbMaxBins = 32767;                // 15-bit bin field
 constexpr int kPbThreads = 1024;
@@ -295,8 +298,10 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
 // ---- phase B
 // One workgroup per bin; the bin's entries are one contiguous range of whole 8-entry groups in B order.  Pad entries
 // carry row 0xffff.  Row sums: 64-bit fixed point in LDS, integer atomics (see the head of this file).
-__global__ __launch_bounds__(kPbBThreads) void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
-    __shared__ unsigned long long s_row[kPbBinRows];
+template <int ROWS, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
+    constexpr int kPbBThreads = THREADS;
+    __shared__ unsigned long long s_row[ROWS];
     if (state != nullptr && state->done) return;
     const int4 bin = f.bin[blockIdx.x];                    // {first row, rows | log2ceil(largest row) << 16, first group, groups}
     const int rows = bin.y & 0xffff, count_bits = bin.y >> 16;
@@ -401,50 +406,53 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     std::vector<uint32_t> counts(f.n_out);
     PGH_HIP(hipMemcpyAsync(counts.data(), d_counts.p, sizeof(uint32_t) * f.n_out, hipMemcpyDeviceToHost, r.stream));
     PGH_HIP(hipStreamSynchronize(r.stream));
-    // greedy bins: consecutive rows, <= kPbBinEntries entries, <= kPbBinRows rows; rows above kPbHeavyRow get none
+    // greedy bins: consecutive rows, <= bin_rows rows, <= kPbBinFill * bin_rows entries; rows above kPbHeavyRow get none;
+    // bins without entries are dropped (their rows never receive a cold contribution: `out` stays 0 there)
     std::vector<int4> bins;
     std::vector<int32_t> row_bin(f.n_out);
     int64_t cold = 0, in_image = 0;
-    int row0 = 0, rows = 0;
-    int64_t fill = 0, largest = 0;     // cold entries of the open bin, and of its largest row
     bool heavy_rows = false;
-    auto close_bin = [&]() {
-        if (rows > 0) bins.push_back(make_int4(row0, rows, (int)largest, (int)fill));
-        rows = 0;
-        fill = 0;
-        largest = 0;
-    };
-    for (int i = 0; i < f.n_out; ++i) {
-        const int64_t c = counts[i];
-        cold += c;
-        if (c > kPbHeavyRow) {               // its cold entries stay in the blocked stream
-            close_bin();
-            row_bin[i] = -1;
-            heavy_rows = true;
-            continue;
-        }
-        if (rows > 0 && (fill + c > kPbBinEntries || rows >= kPbBinRows)) close_bin();
-        if (rows == 0) row0 = i;
-        row_bin[i] = (int32_t)bins.size();
-        ++rows;
-        fill += c;
-        largest = std::max<int64_t>(largest, c);
-        in_image += c;
-    }
-    close_bin();
-    // drop bins without entries: their rows never receive a cold contribution (`out` stays 0 there)
-    {
-        std::vector<int4> kept;
-        std::vector<int32_t> remap(bins.size(), 0);
-        for (size_t w = 0; w < bins.size(); ++w)
-            if (bins[w].w > 0) {
-                remap[w] = (int32_t)kept.size();
-                kept.push_back(bins[w]);
+    auto lay_out = [&](int bin_rows) {
+        bins.clear();
+        cold = in_image = 0;
+        heavy_rows = false;
+        const int64_t bin_entries = (int64_t)kPbBinFill * bin_rows;
+        int row0 = 0, rows = 0;
+        int64_t fill = 0, largest = 0;     // cold entries of the open bin, and of its largest row
+        auto close_bin = [&]() {
+            if (rows > 0 && fill > 0) bins.push_back(make_int4(row0, rows, (int)largest, (int)fill));
+            rows = 0;
+            fill = 0;
+            largest = 0;
+        };
+        for (int i = 0; i < f.n_out; ++i) {
+            const int64_t c = counts[i];
+            cold += c;
+            if (c > kPbHeavyRow) {               // its cold entries stay in the blocked stream
+                close_bin();
+                row_bin[i] = -1;
+                heavy_rows = true;
+                continue;
             }
-        for (int i = 0; i < f.n_out; ++i)
-            if (row_bin[i] >= 0) row_bin[i] = remap[row_bin[i]];      // rows of dropped bins have no entries: never looked up
-        bins.swap(kept);
+            if (rows > 0 && (fill + c > bin_entries || rows >= bin_rows)) close_bin();
+            if (rows == 0) row0 = i;
+            row_bin[i] = (int32_t)bins.size();   // of a bin that ends up empty: never looked up (no entries)
+            ++rows;
+            fill += c;
+            largest = std::max<int64_t>(largest, c);
+            in_image += c;
+        }
+        close_bin();
+    };
+    int bin_rows = kPbBinRows;
+    lay_out(bin_rows);
+    // measured on row-partitioned slices (profiles/r01/partition_slices_pb.log): at 31 entries per run the small shape is
+    // still the faster one (450 vs 462 us per step), at 14 it would not pay at all
+    if ((double)in_image / ((double)chunks * (double)std::max<size_t>(bins.size(), 1)) < 24.0 && kPbBinRowsLarge > bin_rows) {
+        bin_rows = kPbBinRowsLarge;              // short runs: fewer, larger bins
+        lay_out(bin_rows);
     }
+    plan->bin_rows = bin_rows;
     const int64_t num_bins = (int64_t)bins.size();
     if (num_bins < 1 || num_bins > kPbMaxBins || in_image + 8 * chunks * num_bins >= 2147483647LL) return 0;
     const double run = (double)in_image / ((double)chunks * (double)num_bins);
@@ -454,7 +462,9 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     // (~2.9 ps) plus two launches, the chunk fills and a fifth vector in the combine (~28 us): from ~20 M cold entries.
     // Measured (profiles/r01/pb_skew_scales.log): RMAT a=.57 scale 21 (11 M cold) -15 %, scale 22 (23 M) +-0, scale 23
     // +11 %, scale 24 +13 %; uniform graphs x2.0 .. x2.4 at every scale.
-    if (!forced && (in_image < 20 * (1LL << 20) || in_image * 20 < E || run < 24.0)) return 0;
+    // Runs are padded to whole groups of 8 (3.5 pad entries on average): below ~10 entries per run the padding eats the
+    // gain.
+    if (!forced && (in_image < 20 * (1LL << 20) || in_image * 20 < E || run < 10.0)) return 0;
     PGH_HIP(hipMalloc(&plan->row_bin, sizeof(int32_t) * (size_t)f.n_out));
     PGH_HIP(hipMemcpyAsync(plan->row_bin, row_bin.data(), sizeof(int32_t) * f.n_out, hipMemcpyHostToDevice, r.stream));
     k_pb_keep_heavy<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, E, plan->row_bin, is_hot);
@@ -501,6 +511,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     p.chunk = kPbChunk;
     p.hot = hot;
     p.k1_cold = plan->heavy_rows;
+    p.bin_rows = plan->bin_rows;
     const int first_bin = plan->slice_first[slice];
     p.num_bins = plan->slice_first[slice + 1] - first_bin;
     // this slice's bins (the group ranges are filled in below)
@@ -706,7 +717,10 @@ int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state) {
     }
     {
         ProfScope prof(PGH_K_PB_ACCUM);
-        if (p.num_bins > 0) k_pb_accumulate<<<p.num_bins, kPbBThreads, 0, r.stream>>>(v, state);
+        if (p.num_bins > 0) {
+            if (p.bin_rows > kPbBinRows) k_pb_accumulate<kPbBinRowsLarge, kPbBThreadsLarge><<<p.num_bins, kPbBThreadsLarge, 0, r.stream>>>(v, state);
+            else k_pb_accumulate<kPbBinRows, kPbBThreads><<<p.num_bins, kPbBThreads, 0, r.stream>>>(v, state);
+        }
     }
     }
     PGH_HIP(hipGetLastError());

@@ -303,11 +303,14 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
     ranker.rank(pg, personalizations[total - 1])
     L.check(lib.pgh_profile_enable(0))
     prof = {}
-    for kid, name in ((L.K_SPMV, "spmv"), (L.K_FIXUP, "fixup"), (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual")):
+    for kid, name in ((L.K_SPMV, "spmv"), (L.K_PB_GATHER, "pb_gather"), (L.K_PB_ACCUM, "pb_accumulate"), (L.K_FIXUP, "fixup"),
+                      (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual")):
         cnt, ms = C.c_int64(), C.c_double()
         L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
         prof[name] = (ms.value / cnt.value * 1e3) if cnt.value else None
-    step_us = sum(v for k, v in prof.items() if k in ("spmv", "fixup", "combine") and v)
+    step_us = sum(v for k, v in prof.items() if k in ("spmv", "pb_gather", "pb_accumulate", "fixup", "combine") and v)
+    step_kernels = ("k_bsf_partial + k_pb_gather + k_pb_accumulate + k_bsf_fixup + k_bsf_combine<AXPBY>" if prof["pb_gather"]
+                    else "k_bsf_partial + k_bsf_fixup + k_bsf_combine<AXPBY>")
     alg_bytes = 8 * pg.graph.nnz + 4 * n + 16 * n_local
     achieved = alg_bytes / (step_us * 1e-6) / 1e9 if step_us else None
     if rank != 0:
@@ -322,7 +325,7 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
                     parallelism=f"1-D row partition x{world}, all-gather of the gather vector + 2 scalar all-reduces per iteration",
                     exchange_bytes_per_iteration_per_gpu=ranker._buffers.exchange_bytes,
                     gather_vector_slots=ranker._buffers.nb * ranker._buffers.live, column_blocks=ranker._buffers.nb),
-        roofline=dict(bound="hbm", kernel="k_bsf_partial + k_bsf_fixup + k_bsf_combine<AXPBY> (one fused PPR step, rank 0 slice)",
+        roofline=dict(bound="hbm", kernel=step_kernels + " (one fused PPR step, rank 0 slice)",
                       achieved=round(achieved, 1) if achieved else None, peak=hbm_peak, unit="GB/s",
                       frac=round(achieved / hbm_peak, 4) if achieved else None, traffic=None,
                       algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(step_us, 2), format=pg.graph.format(),

@@ -1,0 +1,56 @@
+"""Step-kernel times of ONE rank's slice of a row-partitioned graph, alone on the GPU (no exchange): what a rank of the
+N-GPU bench computes per iteration.  Usage: python tools/probe_partition.py [--worlds 2 4 8]   (PGH_PB=0 for the A/B)"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pygrank_amd as pg  # noqa: E402
+from pygrank_amd import _lib as L  # noqa: E402
+from pygrank_amd.device import DeviceVector  # noqa: E402
+from pygrank_amd.distributed import _HOT_PAD, rmat_partitioned  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--worlds", type=int, nargs="+", default=[2, 4, 8])
+ap.add_argument("--steps", type=int, default=10)
+args = ap.parse_args()
+pg.load_backend("hip")
+lib = L.lib()
+for world in args.worlds:
+    scale, ef = (27, 8) if world == 8 else (23 + int(np.log2(world)), 16)      # bench.py's weak-scaling workloads
+    part = rmat_partitioned(scale, ef, 0, world, seed=0)
+    g = part.graph
+    nb, blk = C.c_int32(), C.c_int64()
+    live = np.zeros(8, dtype=np.int32)
+    L.check(lib.pgh_graph_gather_layout(g._h, C.byref(nb), C.byref(blk), live.ctypes.data_as(C.c_void_p)))
+    top = min(blk.value, (int(live.max()) + 63) // 64 * 64)
+    bpr = nb.value // world
+    bases = np.zeros(8, dtype=np.int64)
+    for b in range(nb.value):
+        r, j = divmod(b, bpr)
+        bases[b] = (j * world + r) * top
+    L.check(lib.pgh_graph_set_gather_bases(g._h, bases.ctypes.data_as(C.c_void_p)))
+    rng = np.random.default_rng(0)
+    xg = DeviceVector.from_host(rng.random(nb.value * top + _HOT_PAD).astype(np.float32))
+    p = DeviceVector.from_host(rng.random(part.n_local).astype(np.float32))
+    y = DeviceVector.from_host(np.zeros(part.n_local, dtype=np.float32))
+    out = DeviceVector.from_host(np.zeros(part.n_local, dtype=np.float32))
+    for it in range(args.steps + 2):
+        if it == 2:
+            L.check(lib.pgh_profile_reset())
+            L.check(lib.pgh_profile_enable(1))
+        L.check(lib.pgh_ppr_step_dist(g._h, xg._h, 1.0, p._h, 0.85, y._h, out._h, None))
+    L.check(lib.pgh_profile_enable(0))
+    prof = {}
+    for kid, name in ((L.K_SPMV, "spmv"), (L.K_PB_GATHER, "pbA"), (L.K_PB_ACCUM, "pbB"), (L.K_FIXUP, "fixup"), (L.K_COMBINE, "combine")):
+        cnt, ms = C.c_int64(), C.c_double()
+        L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
+        prof[name] = ms.value / cnt.value * 1e3 if cnt.value else 0.0
+    step = sum(prof.values())
+    print(f"world={world} scale={scale} ef={ef} slice nnz={g.nnz} n_local={part.n_local} step={step:7.1f} us "
+          f"({g.nnz / step / 1e3:6.1f} GTEPS per rank) " + " ".join(f"{k}={v:.1f}" for k, v in prof.items()) + f" | {g.format()}", flush=True)
+    del xg, p, y, out, part, g
