@@ -881,10 +881,14 @@ int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t
 }
 
 // number of column blocks: keep a block's slice of the gather vector around 8 MB (hot-first, so its reused prefix
-// fits a 4 MB L2); override with PGH_BLOCKS for experiments
+// fits a 4 MB L2), at most 4: every block is one more partial vector written and read per step, and with the cold
+// entries in their own image (pgh_pb.hip) the hot-cache coverage of blocks 5..8 no longer pays for that (measured at
+// scale 24 / 25 / 26: 757 / 1634 / 3711 us per step with 4 blocks against 839 / 1666 / 3827 with 8,
+// profiles/r01/pb_large_graphs.log).  Override with PGH_BLOCKS for experiments.
 int bsf_auto_blocks(int64_t n_src) {
     int B = 1;
-    while (B < 8 && n_src * 4 > (int64_t)B * (8 << 20)) B <<= 1;
+    const int most = env_int("PGH_PB", 1) == 0 ? 8 : 4;
+    while (B < most && n_src * 4 > (int64_t)B * (8 << 20)) B <<= 1;
     const int forced = env_int("PGH_BLOCKS", 0);
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) B = forced;
     return B;

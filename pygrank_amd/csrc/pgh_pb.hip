@@ -445,10 +445,11 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         close_bin();
     };
     int bin_rows = kPbBinRows;
+    if (const char* shape = getenv("PGH_PB_BINROWS")) bin_rows = atoi(shape) > kPbBinRows ? kPbBinRowsLarge : kPbBinRows;   // diagnostic
     lay_out(bin_rows);
-    // measured on row-partitioned slices (profiles/r01/partition_slices_pb.log): at 31 entries per run the small shape is
-    // still the faster one (450 vs 462 us per step), at 14 it would not pay at all
-    if ((double)in_image / ((double)chunks * (double)std::max<size_t>(bins.size(), 1)) < 24.0 && kPbBinRowsLarge > bin_rows) {
+    // measured (profiles/r01/partition_slices_pb.log, pb_large_graphs.log): at 55 entries per run the small shape is 3 %
+    // faster (scale 24), at 31 it is 3 % faster on a partitioned slice but 7 % slower at scale 25, at 14 it does not pay
+    if ((double)in_image / ((double)chunks * (double)std::max<size_t>(bins.size(), 1)) < 40.0 && kPbBinRowsLarge > bin_rows && getenv("PGH_PB_BINROWS") == nullptr) {
         bin_rows = kPbBinRowsLarge;              // short runs: fewer, larger bins
         lay_out(bin_rows);
     }
