@@ -93,7 +93,7 @@ __device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff
 // pgh_pb.hip: propagation-blocking image of the cold entries
 struct PbPlan {
     int32_t* row_bin = nullptr;    // device: bin of every output row, -1 = too heavy for a bin
-    int      num_bins = 0, num_chunks = 0, bin_rows = 0;
+    int      num_bins = 0, num_chunks = 0, bin_rows = 0, heavy_row = 0;
     int64_t  entries = 0;          // cold entries that go into the image
     int      slices = 1;           // the bins are cut into `slices` consecutive groups of about equal entry counts
     int      slice_first[kPbMaxSlices + 1] = {0};   // first bin of every slice

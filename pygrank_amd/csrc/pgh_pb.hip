@@ -7,7 +7,8 @@
 //
 //   bins     runs of consecutive output rows: <= 4096 rows (their sums live in LDS during phase B; 16384 when the graph
 //            has so many chunks that the runs below would get short) and <= 6 cold entries per row on average (balance);
-//            a row with more than kPbHeavyRow cold entries keeps them in the blocked stream
+//            a row with more than 16 K cold entries is a "hub" bin by itself (summed in f64 registers instead of LDS
+//            atomics on one word); beyond 256 K they stay in the blocked stream
 //   cells    (source chunk, bin) pairs; the entries of a cell form a RUN, padded to a multiple of 8 entries.  The same
 //            runs are laid out twice: A order = [chunk][bin] (what phase A reads), B order = [bin][chunk] (what phase B
 //            reads); an 8-entry group of one order maps to one 8-entry group of the other.
@@ -62,7 +63,9 @@ constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in 
 constexpr int kPbBinRows = PGH_PB_ROWS, kPbBThreads = PGH_PB_BTHREADS;
 constexpr int kPbBinRowsLarge = 16384, kPbBThreadsLarge = 1024;
 constexpr int kPbBinFill = 6;                    // entries per bin <= kPbBinFill * rows (balance: the heavy rows come first)
-constexpr int kPbHeavyRow = 16384;               // a row with more cold entries keeps them in the blocked stream
+constexpr int kPbHeavyRow = 16384;               // a row with more cold entries gets a (hub) bin of its own ...
+constexpr int kPbHubMax = 262144;                // ... up to this many; beyond, they stay in the blocked stream
+// (PGH_PB_HEAVY / PGH_PB_HUBMAX override the two for tests: small graphs have no such rows)               // a row with more cold entries keeps them in the blocked stream
 constexpr int kPbMaxChunks = 8192;               // 13-bit chunk field of the sort key
 constexpr int kPbMaxBins = 32767;                // 15-bit bin field
 constexpr int kPbThreads = 1024;
@@ -303,8 +306,12 @@ __global__ __launch_bounds__(THREADS) void k_pb_accumulate(PbView f, const LoopS
     constexpr int kPbBThreads = THREADS;
     __shared__ unsigned long long s_row[ROWS];
     if (state != nullptr && state->done) return;
-    const int4 bin = f.bin[blockIdx.x];                    // {first row, rows | log2ceil(largest row) << 16, first group, groups}
-    const int rows = bin.y & 0xffff, count_bits = bin.y >> 16;
+    const int4 bin = f.bin[blockIdx.x];                    // {first row, rows | log2ceil(largest row) << 16 | hub << 30, first group, groups}
+    const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0xff;
+    // a hub bin is ONE row with more than kPbHeavyRow cold entries: thousands of atomics on one LDS word would serialise,
+    // so its values are summed in f64 registers and reduced in a fixed order (no fixed point needed, deterministic)
+    const bool hub = ((bin.y >> 30) & 1) != 0;
+    double hub_sum = 0.0;
     const int tid = threadIdx.x;
     const uint32_t amax = __builtin_nontemporal_load(f.amax);
     const bool finite = amax < 0x7f800000u;                // inf / NaN among the values: the sums are not representable
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(THREADS) void k_pb_accumulate(PbView f, const LoopS
     constexpr double kMagic = 6755399441055744.0;          // 1.5 * 2^52: fma(v, S, magic) holds round(v * S) in its low bits
     for (int i = tid; i < rows; i += kPbBThreads) s_row[i] = 0ULL;
     __syncthreads();
-    const int groups = finite ? bin.w : 0;
+    const int groups = finite || hub ? bin.w : 0;
     const float* __restrict__ tmp = f.tmp + (int64_t)bin.z * 8;
     const uint16_t* __restrict__ drow = f.drow + (int64_t)bin.z * 8;
     constexpr int P = 4;                                    // groups per thread in flight: twelve 16-byte loads
@@ -347,13 +354,29 @@ __global__ __launch_bounds__(THREADS) void k_pb_accumulate(PbView f, const LoopS
                 const int r = (int)r8[q][k];
                 const float v = k < 4 ? lo[q][k] : hi[q][k - 4];
                 const long long fixed = __double_as_longlong(__builtin_fma((double)v, S, kMagic)) - __double_as_longlong(kMagic);
-                if (r < rows) atomicAdd(&s_row[r], (unsigned long long)fixed);
+                if (hub) {
+                    if (r == 0) hub_sum += (double)v;
+                } else if (r < rows) {
+                    atomicAdd(&s_row[r], (unsigned long long)fixed);
+                }
             }
         }
     }
-    __syncthreads();
-    for (int i = tid; i < rows; i += kPbBThreads)
-        f.out[bin.x + i] = finite ? (float)((double)(long long)s_row[i] * inv_S) : __uint_as_float(0x7fc00000u);
+    if (hub) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) hub_sum += __shfl_xor(hub_sum, d, 64);
+        if ((tid & 63) == 0) s_row[tid >> 6] = (unsigned long long)__double_as_longlong(hub_sum);
+        __syncthreads();
+        if (tid == 0) {
+            double total = 0.0;
+            for (int w = 0; w < kPbBThreads / 64; ++w) total += __longlong_as_double((long long)s_row[w]);
+            f.out[bin.x] = (float)total;
+        }
+    } else {
+        __syncthreads();
+        for (int i = tid; i < rows; i += kPbBThreads)
+            f.out[bin.x + i] = finite ? (float)((double)(long long)s_row[i] * inv_S) : __uint_as_float(0x7fc00000u);
+    }
     // the last workgroup to leave re-arms the words for the next launch (every workgroup has read amax long before its
     // ticket; the next phase A starts after this kernel)
     if (tid == 0 && atomicAdd(f.amax + 1, 1u) == gridDim.x - 1) {
@@ -406,12 +429,17 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     std::vector<uint32_t> counts(f.n_out);
     PGH_HIP(hipMemcpyAsync(counts.data(), d_counts.p, sizeof(uint32_t) * f.n_out, hipMemcpyDeviceToHost, r.stream));
     PGH_HIP(hipStreamSynchronize(r.stream));
-    // greedy bins: consecutive rows, <= bin_rows rows, <= kPbBinFill * bin_rows entries; rows above kPbHeavyRow get none;
+    // greedy bins: consecutive rows, <= bin_rows rows, <= kPbBinFill * bin_rows entries; a row above kPbHeavyRow entries
+    // is a hub bin by itself (above kPbHubMax it gets none: its cold entries stay in the stream);
     // bins without entries are dropped (their rows never receive a cold contribution: `out` stays 0 there)
     std::vector<int4> bins;
     std::vector<int32_t> row_bin(f.n_out);
     int64_t cold = 0, in_image = 0;
     bool heavy_rows = false;
+    int heavy_row = kPbHeavyRow, hub_max = kPbHubMax;
+    if (const char* v = getenv("PGH_PB_HEAVY")) heavy_row = std::max(1, std::min(atoi(v), kPbHeavyRow));
+    if (const char* v = getenv("PGH_PB_HUBMAX")) hub_max = std::max(heavy_row, atoi(v));
+    plan->heavy_row = heavy_row;
     auto lay_out = [&](int bin_rows) {
         bins.clear();
         cold = in_image = 0;
@@ -428,10 +456,17 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         for (int i = 0; i < f.n_out; ++i) {
             const int64_t c = counts[i];
             cold += c;
-            if (c > kPbHeavyRow) {               // its cold entries stay in the blocked stream
+            if (c > hub_max) {                   // more than one workgroup should stream: its cold entries stay in the blocked stream
                 close_bin();
                 row_bin[i] = -1;
                 heavy_rows = true;
+                continue;
+            }
+            if (c > heavy_row) {                 // a hub bin of its own
+                close_bin();
+                row_bin[i] = (int32_t)bins.size();
+                bins.push_back(make_int4(i, 1, (int)c, (int)c));
+                in_image += c;
                 continue;
             }
             if (rows > 0 && (fill + c > bin_entries || rows >= bin_rows)) close_bin();
@@ -583,6 +618,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         int count_bits = 0;                                // 2^count_bits >= entries of the bin's largest row
         while ((1 << count_bits) < mine[w].z) ++count_bits;
         mine[w].y |= count_bits << 16;
+        if (mine[w].z > plan->heavy_row) mine[w].y |= 1 << 30;    // hub bin
         mine[w].z = (int)(bin_start[w] >> 3);
         mine[w].w = (int)((bin_start[w + 1] - bin_start[w]) >> 3);
     }

@@ -815,10 +815,13 @@ namespace {
 __global__ __launch_bounds__(kBlock) void k_mat_col_abssum(const float* __restrict__ m, int64_t n, int b, double* __restrict__ partial /* [grid][b] */) {
     __shared__ double s_acc[kBlock];
     const int64_t total = n * b;
-    const int64_t stride = ((int64_t)gridDim.x * kBlock + b - 1) / b * b;
+    // stride = the largest multiple of b the launch covers: the threads beyond it idle (rounding UP instead would leave
+    // the elements [threads, stride) of every period to nobody)
+    const int64_t stride = ((int64_t)gridDim.x * kBlock) / b * b;
     const int64_t block_first = blockIdx.x * (int64_t)kBlock;
     double acc = 0.0;
-    for (int64_t i = block_first + threadIdx.x; i < total; i += stride) acc += fabs((double)m[i]);
+    if (block_first + threadIdx.x < stride)
+        for (int64_t i = block_first + threadIdx.x; i < total; i += stride) acc += fabs((double)m[i]);
     s_acc[threadIdx.x] = acc;
     __syncthreads();
     for (int j = threadIdx.x; j < b; j += kBlock) {

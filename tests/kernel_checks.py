@@ -378,7 +378,8 @@ def check_propagation_blocking_image(pg):
     A = rmat_np.rmat_csr(17, 16, seed=1)                        # 131 K nodes: four times the LDS hot cache
     Wreal = sp.csr_array(A.copy())
     Wreal.data = Wreal.data * (0.5 + rng.random(Wreal.nnz))
-    saved = {k: os.environ.get(k) for k in ("PGH_PB", "PGH_PB_FORCE")}
+    saved = {k: os.environ.get(k) for k in ("PGH_PB", "PGH_PB_FORCE", "PGH_PB_HEAVY", "PGH_PB_HUBMAX")}
+    os.environ["PGH_PB_HEAVY"], os.environ["PGH_PB_HUBMAX"] = "256", "2000"       # hub bins and rows left in the stream, both
     try:
         for name, W in (("int", A), ("real", Wreal)):
             os.environ["PGH_PB"] = "0"
@@ -428,7 +429,7 @@ def check_slab_ops_and_wide_propagate(pg):
     over more than 64 feature columns (two batches) against per-column rank()."""
     from pygrank_amd.device import DeviceMatrix
     rng = np.random.default_rng(21)
-    for n, b in ((1, 1), (1000, 3), (4097, 64), (513, 70)):
+    for n, b in ((1, 1), (1000, 3), (4097, 64), (513, 70), (70001, 17), (300007, 3)):   # the last two: several grid periods, b not a divisor
         X = (rng.random((n, b)) - 0.3).astype(F32).astype(np.float64)
         X[:, b // 2] = 0.0
         D = DeviceMatrix.from_host(X)

@@ -37,7 +37,8 @@ def main():
         if n < 2 or A.nnz == 0 or n > 80000:
             continue
         for key, val in (("PGH_BLOCKS", str(int(rng.choice([1, 2, 4, 8])))), ("PGH_RELABEL", str(int(rng.integers(0, 2)))),
-                         ("PGH_PB", str(int(rng.random() < 0.3))), ("PGH_PB_FORCE", "1"), ("PGH_TRIM", str(int(rng.integers(0, 2))))):
+                         ("PGH_PB", str(int(rng.random() < 0.3))), ("PGH_PB_FORCE", "1"), ("PGH_TRIM", str(int(rng.integers(0, 2)))),
+                         ("PGH_PB_HEAVY", str(int(rng.choice([16384, 8, 64])))), ("PGH_PB_HUBMAX", str(int(rng.choice([262144, 150, 4000]))))):
             os.environ[key] = val
         norm = str(rng.choice(["col", "symmetric"]))
         g = DeviceGraph.from_adjacency(A, norm)
@@ -56,6 +57,7 @@ def main():
             tol = float(rng.choice([1e-5, 1e-6]))
             ranker = pg.PageRank(kw["alpha"], use_quotient=kw["use_quotient"], error_type={"l1": pg.L1, "mabs": pg.Mabs, "linf": pg.MaxDifference}[err],
                                  tol=tol, max_iters=300)
+            same_steps = lambda k: orc.pagerank(M, p, error_type="iters", max_iters=k, eps=EPS32, **kw)[0]   # noqa: E731
             try:
                 want, it = orc.pagerank(M, p, error_type=err, tol=tol, max_iters=300, eps=EPS32, **kw)
             except Exception:                                      # does not converge in 300 iterations: the engine must say so too
@@ -68,6 +70,7 @@ def main():
                 sys.exit(1)
         elif which == 1:
             ranker = pg.AbsorbingWalks(0.85, error_type=pg.L1, tol=1e-6, max_iters=300)
+            same_steps = lambda k: orc.absorbing_walks(M, p, alpha=0.85, error_type="iters", max_iters=k, eps=EPS32)[0]   # noqa: E731
             try:
                 want, it = orc.absorbing_walks(M, p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=300, eps=EPS32)
             except Exception:
@@ -110,9 +113,15 @@ def main():
                 want, it = oracle_runs[j]
                 its = ranker.last_batches[0][j]["iterations"]
                 rel = np.max(np.abs(out[:, j] - want)) / max(np.max(np.abs(want)), 1e-30)
-                # a residual within f32 rounding of the tolerance may stop one iteration apart: the iterates then differ by ~tol
-                if abs(its - it) > max(1, it // 50) or rel > (2e-6 if its == it else 6e-6):
+                # a residual within f32 rounding of the tolerance may stop an iteration apart: the iterates then differ by ~tol.
+                # The columns are not normalised (magnitudes up to 17): the f32 rounding noise of a column's residual
+                # scales with it and reaches tens of percent of tol = 1e-6, i.e. up to two steps of the 0.85 contraction.
+                if abs(its - it) > max(2, it // 25) or rel > (2e-6 if its == it else 6e-6):
                     print("MISMATCH propagate", desc, "column", j, rel, "iterations", its, it, flush=True)
+                    if os.environ.get("PGH_STRESS_DUMP"):          # replay material for a scratch script
+                        sp.save_npz(os.path.join(os.environ["PGH_STRESS_DUMP"], "case_graph.npz"), sp.csr_matrix(A))
+                        np.savez(os.path.join(os.environ["PGH_STRESS_DUMP"], "case_data.npz"), feats=feats, out=out, norm=norm,
+                                 env=np.array([f"{k}={v}" for k, v in os.environ.items() if k.startswith("PGH_")]))
                     sys.exit(1)
             done += 1
             continue
@@ -121,13 +130,15 @@ def main():
         except Exception as exc:                                   # non-convergence must agree with the oracle too
             print("EXCEPTION", desc, type(ranker).__name__, exc, flush=True)
             sys.exit(1)
-        rel = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-30)
         its = ranker.convergence.iteration
         tolerance_based = which in (0, 1)
-        tol = tol if which == 0 else 1e-6
-        # a residual within f32 rounding of the tolerance may stop one iteration apart: the iterates then differ by ~tol
-        bound = 4e-6 if which == 3 else (2e-6 if its == it else max(2e-6, 6 * tol))   # chebyshev: parity_common.py
         slack = max(1, it // 50)            # slowly converging runs sit near the tolerance for several iterations
+        # a residual within f32 rounding of the tolerance may stop an iteration apart: the result is then compared with the
+        # oracle stopped after the engine's number of steps
+        if tolerance_based and its != it and abs(its - it) <= slack:
+            want = same_steps(its)
+        rel = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-30)
+        bound = 4e-6 if which == 3 else 2e-6                        # chebyshev: parity_common.py
         if rel > bound or (tolerance_based and abs(its - it) > slack) or (not tolerance_based and its != it):
             print("MISMATCH", type(ranker).__name__, desc, "rel", rel, "iterations", its, it, flush=True)
             sys.exit(1)
