@@ -176,6 +176,23 @@ __global__ void k_bsf_pack(uint32_t* __restrict__ colf, uint32_t* __restrict__ v
     }
 }
 
+// Hot-only streams (every cold entry lives in the propagation-blocking image): a source is one of the <= 29 696 slots of
+// the block's LDS hot cache, so its byte offset / 2 fits 16 bits.  [tile][lane][8] halfwords: one 16-byte load per lane.
+// Sentinels and pads (slot 0 of the block: any value, they never close a segment) keep pointing at a valid slot.
+__global__ void k_bsf_narrow(const uint32_t* __restrict__ colf, int num_tiles, uint32_t hot4, uint16_t* __restrict__ colf16) {
+    const int64_t total = (int64_t)num_tiles * 64;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t0 = (i >> 6) * 512;
+        const int lane = (int)(i & 63);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t src = PGH_TILE_TRANSPOSE ? t0 + (k >> 2) * 256 + lane * 4 + (k & 3) : t0 + lane * 8 + k;
+            const uint32_t w = colf[src];
+            colf16[t0 + lane * 8 + k] = (uint16_t)((w < hot4 ? w : hot4) >> 1);
+        }
+    }
+}
+
 // 1 + highest referenced slot of every block, over all entries of the sorted stream (sentinels point at slot 0)
 __global__ void k_bsf_live(const uint64_t* __restrict__ keys, int64_t E, int blk, int32_t* __restrict__ live) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
@@ -327,6 +344,7 @@ __global__ void k_permute_out(const float* __restrict__ src, const int32_t* __re
 struct BsfView {
     const int64_t*  fix_dst;   // [num_tiles] index into `part` that receives tile t's fix-up, or -1
     const uint32_t* colf;      // packed: byte offset of the source inside its block
+    const uint16_t* colf16;    // hot-only streams: byte offset / 2, [tile][lane][8] (colf is null then)
     const uint8_t*  flags8;    // [num_tiles * 64] segment-start flags of each lane's 8 entries
     const float*    val;
     const int32_t*  seg_row;
@@ -401,10 +419,11 @@ __device__ __forceinline__ float wave_segmented_sum(float keep, float val) {
 // register moves): column stream of tile t+2, gathers of tile t+1, arithmetic of tile t.  In-tile sums are f32 (a
 // lane adds at most IPT terms, the 64-lane stitch is a log-depth DPP segmented scan); pieces of segments that cross
 // tiles are carried in f64 and combined in a fixed order by k_bsf_fixup (deterministic, atomic-free).
-template <int IPT, bool HAS_VAL, bool COLD>
+template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
                                                               const LoopState* __restrict__ state) {
     static_assert(IPT == 8, "one flag byte per lane; lanes fetch their entries as 16-byte words");
+    static_assert(!(W16 && COLD), "the 16-bit stream addresses the hot cache only");
     constexpr int T = 64 * IPT;
     constexpr int WAVES = kBsfThreads / 64;
     constexpr int Q = IPT / 4;
@@ -455,8 +474,9 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     const int tb = f.tile_begin[b];
     const int64_t blk_tiles = (int64_t)(t_end - tb);
     const auto clamp32 = [](int64_t bytes) { return (int)(bytes > 0xffffffffLL ? 0xffffffffLL : bytes); };
-    const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(f.colf + (int64_t)tb * T), 0, clamp32(blk_tiles * T * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t col_rsrc =
+        W16 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(f.colf16 + (int64_t)tb * T), 0, clamp32(blk_tiles * T * 2), 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(f.colf + (int64_t)tb * T), 0, clamp32(blk_tiles * T * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(HAS_VAL ? f.val + (int64_t)tb * T : nullptr), 0, HAS_VAL ? clamp32(blk_tiles * T * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t flag_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -466,8 +486,12 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     constexpr int kNT = PGH_STREAM_AUX;                    // buffer aux: 2 = non-temporal (streamed once per launch)
     auto load_stream = [&](int tile, Stream& st) __attribute__((always_inline)) {
         const int rel = tile - tb;
+        if (W16) {
+            st.c[0] = __builtin_amdgcn_raw_buffer_load_b128(col_rsrc, lane * 16, rel * (T * 2), kNT);
+        } else {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) st.c[q] = __builtin_amdgcn_raw_buffer_load_b128(col_rsrc, lane32 + kQStep * q, rel * (T * 4), kNT);
+            for (int q = 0; q < Q; ++q) st.c[q] = __builtin_amdgcn_raw_buffer_load_b128(col_rsrc, lane32 + kQStep * q, rel * (T * 4), kNT);
+        }
         if (HAS_VAL) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) st.v[q] = __builtin_amdgcn_raw_buffer_load_b128(val_rsrc, lane32 + kQStep * q, rel * (T * 4), kNT);
@@ -488,6 +512,14 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     auto gather = [&](const Stream& st, Gathered& g) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
+            if (W16) {                    // halfword k of the lane's 16 bytes = byte offset / 2 into the hot cache
+                const uint32_t pair = st.c[0][k >> 1];
+                const uint32_t off = (k & 1) ? (pair >> 16) << 1 : (pair & 0xffffu) << 1;
+                g.h[k] = *reinterpret_cast<const float*>(lds + off);
+                g.c[k] = 0.f;
+                if (HAS_VAL) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
+                continue;
+            }
             const uint32_t w = st.c[k >> 2][k & 3];
 #if PGH_PROBE_GATHER == 6        // everything from the hot cache: the kernel without vector-memory gathers
             g.h[k] = *reinterpret_cast<const float*>(lds + (w % hot4 & ~3u));
@@ -693,6 +725,7 @@ BsfView view_of(const BsfFormat& f) {
     BsfView v;
     v.fix_dst = f.fix_dst;
     v.colf = f.colf;
+    v.colf16 = f.colf16;
     v.flags8 = f.flags8;
     v.val = f.val;
     v.seg_row = f.seg_row;
@@ -735,7 +768,10 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state) 
     const int main_grid = r.num_cus;                  // one workgroup per CU; a multiple of 8 (XCD-affine blocks)
     {
         ProfScope prof(PGH_K_SPMV);
-        if (f.pb.enabled && !f.pb.k1_cold) {
+        if (f.colf16 != nullptr) {
+            if (f.val) k_bsf_partial<kIPT, true, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+            else k_bsf_partial<kIPT, false, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+        } else if (f.pb.enabled && !f.pb.k1_cold) {
             if (f.val) k_bsf_partial<kIPT, true, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
             else k_bsf_partial<kIPT, false, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
         } else {
@@ -840,6 +876,7 @@ void bsf_destroy(BsfFormat& f) {
     for (int sl = 1; sl < kPbMaxSlices; ++sl) pb_destroy(f.pb_more[sl - 1]);
     pb_destroy(f.pb);
     (void)hipFree(f.colf);
+    (void)hipFree(f.colf16);
     (void)hipFree(f.flags8);
     (void)hipFree(f.fix_dst);
     (void)hipFree(f.live_dev);
@@ -1153,6 +1190,16 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         k_bsf_fixlist<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.tile, f.seg_row, view_of(f), f.num_tiles, f.fix_dst);
         PGH_HIP(hipGetLastError());
         PGH_HIP(hipStreamSynchronize(r.stream));
+        if (f.pb.enabled && !f.pb.k1_cold && env_int("PGH_STREAM16", 1)) {       // hot-only stream: 2 bytes per entry
+            const uint32_t hot4 = (uint32_t)(kBsfHot < blk ? kBsfHot : blk) << 2;
+            PGH_HIP(hipMalloc(&f.colf16, sizeof(uint16_t) * (size_t)f.num_tiles * 512 + 64));
+            k_bsf_narrow<<<blocks_for((int64_t)f.num_tiles * 64), kBlock, 0, r.stream>>>(f.colf, f.num_tiles, hot4, f.colf16);
+            PGH_HIP(hipGetLastError());
+            PGH_HIP(hipStreamSynchronize(r.stream));
+            (void)hipFree(f.colf);
+            f.colf = nullptr;
+            f.device_bytes -= (int64_t)f.num_tiles * 512 * 2;
+        }
         // The engine's own gather vector (graphs with a source scale: xg = y * src_scale, written by the epilogue) keeps
         // only the referenced prefix of every block.  Partitioned graphs get their layout from the caller instead.
         if (src_old != nullptr && g->part_perm == nullptr && env_int("PGH_TRIM", 1)) {

@@ -178,6 +178,8 @@ struct BsfFormat {
     int64_t   num_segs = 0;
     uint32_t* colf = nullptr;       // [num_entries] SpMV layout: byte offset of the source inside its block (k_bsf_pack);
                                     // multi-seed layout: column (new id) | bit31 = first entry of a row segment
+    uint16_t* colf16 = nullptr;     // hot-only SpMV streams (all cold entries in `pb`): byte offset / 2 into the LDS hot cache,
+                                    // [tile][lane][8]; colf is freed then
     int64_t*  fix_dst = nullptr;    // [num_tiles] SpMV layout: where tile t's cross-tile fix-up lands in `part` (-1 = none)
     uint8_t*  flags8 = nullptr;     // [num_tiles * 64] SpMV layout: segment-start flags of each lane's 8 entries
     float*    val = nullptr;        // [num_entries] or null (value-free)

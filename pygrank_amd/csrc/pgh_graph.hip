@@ -480,7 +480,7 @@ extern "C" int pgh_graph_format(pgh_graph_t g, char* buf, int buflen) {
         const BsfFormat& f = g->bsf;
         int used = snprintf(buf, buflen, "bsf: %d column blocks x %d sources, %s, %s entries (%d B/edge), %lld entries, %d wavefront tiles, LDS hot cache %d",
                             f.num_blocks, f.blk_size, f.relabelled ? "relabelled by source count" : "original ids",
-                            f.val ? "f32-valued" : "value-free", f.val ? 8 : 4, (long long)f.num_entries, f.num_tiles, PGH_BSF_HOT);
+                            f.val ? "f32-valued" : "value-free", (f.val ? 4 : 0) + (f.colf16 ? 2 : 4), (long long)f.num_entries, f.num_tiles, PGH_BSF_HOT);
         if (f.pb.enabled && used > 0 && used < buflen)
             snprintf(buf + used, buflen - used, "; cold tail: propagation-blocking image in %d slices, first: %lld entries in %d chunks x %d bins%s",
                      f.pb_slices, (long long)f.pb.num_entries, f.pb.num_chunks, f.pb.num_bins, f.pb.k1_cold ? " (heavy rows stay in the stream)" : "");
