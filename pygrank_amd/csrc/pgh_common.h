@@ -154,6 +154,9 @@ struct PbFormat {
     // B order: [bin][chunk] runs (the same runs): a bin is one contiguous range
     float*    tmp = nullptr;        // [padded] gathered (and weighted) source values, written by phase A
     int4*     bin = nullptr;        // [num_bins] {first output row, rows | log2ceil(largest row's entries) << 16, first group, groups}
+    int       num_split = 0;        // hub rows spread over several bins ("pieces")
+    int4*     split = nullptr;      // [num_split] {row, first bin, pieces, -}
+    double*   hub_part = nullptr;   // [num_bins] piece sums, folded into `out` by k_pb_hub_fold
     uint32_t* amax = nullptr;       // [2] max |value| phase A wrote (bit pattern); phase B's exit tickets
     uint16_t* drow = nullptr;       // [padded] output row inside the bin (0xffff = pad entry)
     float*    out = nullptr;        // [n_out] cold part of every row sum (structurally empty rows stay 0)

@@ -98,6 +98,8 @@ struct PbPlan {
     int      slices = 1;           // the bins are cut into `slices` consecutive groups of about equal entry counts
     int      slice_first[kPbMaxSlices + 1] = {0};   // first bin of every slice
     int64_t  slice_entries[kPbMaxSlices] = {0};
+    int      num_split = 0;
+    int4*    host_split = nullptr; // {row, first bin, pieces, -} of the hub rows with several bins (new[]), owned by the plan
     int4*    host_bins = nullptr;  // {first row, rows, -, entries} of every bin (new[]), owned by the plan
     bool     heavy_rows = false;   // some rows keep their cold entries in the blocked stream
 };

@@ -7,8 +7,8 @@
 //
 //   bins     runs of consecutive output rows: <= 4096 rows (their sums live in LDS during phase B; 16384 when the graph
 //            has so many chunks that the runs below would get short) and <= 6 cold entries per row on average (balance);
-//            a row with more than 16 K cold entries is a "hub" bin by itself (summed in f64 registers instead of LDS
-//            atomics on one word); beyond 256 K they stay in the blocked stream
+//            a row with more than 16 K cold entries gets "hub" bins of its own, one per 64 K entries (summed in f64
+//            registers instead of LDS atomics on one word; the pieces of a split row are folded in a fixed order)
 //   cells    (source chunk, bin) pairs; the entries of a cell form a RUN, padded to a multiple of 8 entries.  The same
 //            runs are laid out twice: A order = [chunk][bin] (what phase A reads), B order = [bin][chunk] (what phase B
 //            reads); an 8-entry group of one order maps to one 8-entry group of the other.
@@ -63,9 +63,10 @@ constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in 
 constexpr int kPbBinRows = PGH_PB_ROWS, kPbBThreads = PGH_PB_BTHREADS;
 constexpr int kPbBinRowsLarge = 16384, kPbBThreadsLarge = 1024;
 constexpr int kPbBinFill = 6;                    // entries per bin <= kPbBinFill * rows (balance: the heavy rows come first)
-constexpr int kPbHeavyRow = 16384;               // a row with more cold entries gets a (hub) bin of its own ...
-constexpr int kPbHubMax = 262144;                // ... up to this many; beyond, they stay in the blocked stream
-// (PGH_PB_HEAVY / PGH_PB_HUBMAX override the two for tests: small graphs have no such rows)               // a row with more cold entries keeps them in the blocked stream
+constexpr int kPbHeavyRow = 16384;               // a row with more cold entries gets (hub) bins of its own:
+constexpr int kPbHubMax = 65536;                 // one per this many entries ("pieces", entries dealt by source chunk),
+constexpr int kPbMaxPieces = 1024;               // at most this many; beyond, its cold entries stay in the blocked stream
+// (PGH_PB_HEAVY / PGH_PB_HUBMAX override the first two for tests: small graphs have no such rows)               // a row with more cold entries keeps them in the blocked stream
 constexpr int kPbMaxChunks = 8192;               // 13-bit chunk field of the sort key
 constexpr int kPbMaxBins = 32767;                // 15-bit bin field
 constexpr int kPbThreads = 1024;
@@ -128,7 +129,9 @@ __global__ void k_pb_keys(const uint64_t* __restrict__ keys, int64_t count, PbLa
         const int64_t loc = (int64_t)(key & kLow29) - (int64_t)b * L.blk;
         const int64_t cold_id = L.cold_prefix[b] + (loc - L.hot);
         const uint64_t c = (uint64_t)(cold_id / L.chunk), sl = (uint64_t)(cold_id % L.chunk);
-        const uint64_t w = (uint64_t)(row_bin[row] - first_bin);
+        uint64_t w = (uint64_t)(row_bin[row] - first_bin);
+        const uint64_t pieces = (uint64_t)(((unsigned)bin[w].y >> 22) & 0x3ffu) + 1u;      // a split hub row: piece by source chunk
+        if (pieces > 1) w += c % pieces;
         const uint64_t dl = (uint64_t)(row - bin[w].x);
         out[i] = (c << 45) | (w << 30) | (dl << 15) | sl;
     }
@@ -184,6 +187,7 @@ struct PbView {
     const int4*     bin;
     const uint16_t* drow;
     float*          out;
+    double*         hub_part;          // [num_bins] sums of the pieces of split hub rows
     uint32_t*       amax;              // [0] bit pattern of max |value| written by phase A, [1] phase B's exit tickets
     int64_t         cold_prefix[9];
     int64_t         xg_base[8];
@@ -326,11 +330,12 @@ __global__ __launch_bounds__(THREADS) void k_pb_accumulate(PbView f, const LoopS
     constexpr int kPbBThreads = THREADS;
     __shared__ unsigned long long s_row[ROWS];
     if (state != nullptr && state->done) return;
-    const int4 bin = f.bin[blockIdx.x];                    // {first row, rows | log2ceil(largest row) << 16 | hub << 30, first group, groups}
-    const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0xff;
+    const int4 bin = f.bin[blockIdx.x];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
+    const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0x1f;
     // a hub bin is ONE row with more than kPbHeavyRow cold entries: thousands of atomics on one LDS word would serialise,
     // so its values are summed in f64 registers and reduced in a fixed order (no fixed point needed, deterministic)
-    const bool hub = ((bin.y >> 30) & 1) != 0;
+    const bool hub = ((bin.y >> 21) & 1) != 0;
+    const bool piece = ((unsigned)bin.y >> 22) != 0u;     // one of several bins of a split row: k_pb_hub_fold adds them up
     double hub_sum = 0.0;
     const int tid = threadIdx.x;
     const uint32_t amax = __builtin_nontemporal_load(f.amax);
@@ -390,7 +395,8 @@ __global__ __launch_bounds__(THREADS) void k_pb_accumulate(PbView f, const LoopS
         if (tid == 0) {
             double total = 0.0;
             for (int w = 0; w < kPbBThreads / 64; ++w) total += __longlong_as_double((long long)s_row[w]);
-            f.out[bin.x] = (float)total;
+            if (piece) f.hub_part[blockIdx.x] = total;
+            else f.out[bin.x] = (float)total;
         }
     } else {
         __syncthreads();
@@ -405,6 +411,18 @@ __global__ __launch_bounds__(THREADS) void k_pb_accumulate(PbView f, const LoopS
     }
 }
 
+// split hub rows: pieces (consecutive bins) -> the row's cold sum, fixed order
+__global__ void k_pb_hub_fold(const int4* __restrict__ split /* {row, first bin, pieces, -} */, int count, const double* __restrict__ hub_part,
+                              float* __restrict__ out, const LoopState* __restrict__ state) {
+    if (state != nullptr && state->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int4 sr = split[i];
+    double total = 0.0;
+    for (int k = 0; k < sr.z; ++k) total += hub_part[sr.y + k];
+    out[sr.x] = (float)total;
+}
+
 PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     PbView v;
     v.sloc = p.sloc;
@@ -417,6 +435,7 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.drow = p.drow;
     v.out = p.out;
     v.amax = p.amax;
+    v.hub_part = p.hub_part;
     for (int i = 0; i < 9; ++i) v.cold_prefix[i] = p.cold_prefix[i];
     for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base[i];
     v.num_blocks = f.num_blocks;
@@ -458,17 +477,19 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     bool heavy_rows = false;
     int heavy_row = kPbHeavyRow, hub_max = kPbHubMax;
     if (const char* v = getenv("PGH_PB_HEAVY")) heavy_row = std::max(1, std::min(atoi(v), kPbHeavyRow));
-    if (const char* v = getenv("PGH_PB_HUBMAX")) hub_max = std::max(heavy_row, atoi(v));
+    if (const char* v = getenv("PGH_PB_HUBMAX")) hub_max = std::max(8, atoi(v));
     plan->heavy_row = heavy_row;
+    std::vector<int4> split;               // {row, first bin, pieces, -} of every row with more than one hub bin
     auto lay_out = [&](int bin_rows) {
         bins.clear();
+        split.clear();
         cold = in_image = 0;
         heavy_rows = false;
         const int64_t bin_entries = (int64_t)kPbBinFill * bin_rows;
         int row0 = 0, rows = 0;
         int64_t fill = 0, largest = 0;     // cold entries of the open bin, and of its largest row
         auto close_bin = [&]() {
-            if (rows > 0 && fill > 0) bins.push_back(make_int4(row0, rows, (int)largest, (int)fill));
+            if (rows > 0 && fill > 0) bins.push_back(make_int4(row0, rows, (int)largest, (int)fill));   // .y: rows (pieces - 1 = 0)
             rows = 0;
             fill = 0;
             largest = 0;
@@ -476,16 +497,19 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         for (int i = 0; i < f.n_out; ++i) {
             const int64_t c = counts[i];
             cold += c;
-            if (c > hub_max) {                   // more than one workgroup should stream: its cold entries stay in the blocked stream
+            if (c > heavy_row) {                 // hub bins of its own
+                const int64_t pieces = (c + hub_max - 1) / hub_max;
                 close_bin();
-                row_bin[i] = -1;
-                heavy_rows = true;
-                continue;
-            }
-            if (c > heavy_row) {                 // a hub bin of its own
-                close_bin();
+                if (pieces > kPbMaxPieces || pieces > chunks) {       // its cold entries stay in the blocked stream
+                    row_bin[i] = -1;
+                    heavy_rows = true;
+                    continue;
+                }
                 row_bin[i] = (int32_t)bins.size();
-                bins.push_back(make_int4(i, 1, (int)c, (int)c));
+                if (pieces > 1) split.push_back(make_int4(i, (int)bins.size(), (int)pieces, 0));
+                for (int64_t k = 0; k < pieces; ++k)   // entries are dealt by source chunk: the fills are nominal (their sum is exact)
+                    bins.push_back(make_int4(i, 1 | (int)((pieces - 1) << 22), (int)std::min<int64_t>(c, 1 << 30),
+                                             (int)(c / pieces + (k == 0 ? c % pieces : 0))));
                 in_image += c;
                 continue;
             }
@@ -535,6 +559,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         int want = sl != nullptr ? atoi(sl) : 1;            // measured: 4 / 8 slices lose more to launches and partial rounds than
                                                             // the cached hand-over wins (pb_experiment_scale23.log)
         want = std::max(1, std::min(want, kPbMaxSlices));
+        if (!split.empty()) want = 1;          // the pieces of a row must not straddle slices
         plan->slices = want;
         plan->host_bins = new int4[bins.size()];
         std::copy(bins.begin(), bins.end(), plan->host_bins);
@@ -552,6 +577,11 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         }
     }
     plan->heavy_rows = heavy_rows && in_image < cold;
+    plan->num_split = (int)split.size();
+    if (!split.empty()) {
+        plan->host_split = new int4[split.size()];
+        std::copy(split.begin(), split.end(), plan->host_split);
+    }
     *use = true;
     return 0;
 }
@@ -638,7 +668,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         int count_bits = 0;                                // 2^count_bits >= entries of the bin's largest row
         while ((1 << count_bits) < mine[w].z) ++count_bits;
         mine[w].y |= count_bits << 16;
-        if (mine[w].z > plan->heavy_row) mine[w].y |= 1 << 30;    // hub bin
+        if (mine[w].z > plan->heavy_row) mine[w].y |= 1 << 21;    // hub bin
         mine[w].z = (int)(bin_start[w] >> 3);
         mine[w].w = (int)((bin_start[w + 1] - bin_start[w]) >> 3);
     }
@@ -702,6 +732,13 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     if (!tasks.empty()) PGH_HIP(hipMemcpyAsync(p.task, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMemcpyAsync(p.task_range, ranges.data(), sizeof(int) * (shares + 1), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMalloc(&p.tmp, sizeof(float) * (size_t)(padded + 8)));
+    if (plan->num_split > 0) {
+        p.num_split = plan->num_split;
+        PGH_HIP(hipMalloc(&p.split, sizeof(int4) * (size_t)p.num_split));
+        PGH_HIP(hipMemcpyAsync(p.split, plan->host_split, sizeof(int4) * (size_t)p.num_split, hipMemcpyHostToDevice, r.stream));
+        PGH_HIP(hipMalloc(&p.hub_part, sizeof(double) * (size_t)p.num_bins));
+        PGH_HIP(hipMemsetAsync(p.hub_part, 0, sizeof(double) * (size_t)p.num_bins, r.stream));
+    }
     PGH_HIP(hipMalloc(&p.amax, sizeof(uint32_t) * 2));
     PGH_HIP(hipMemsetAsync(p.amax, 0, sizeof(uint32_t) * 2, r.stream));
     if (slice == 0) {
@@ -720,6 +757,8 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
 void pb_plan_release(PbPlan* plan) {
     (void)hipFree(plan->row_bin);
     delete[] plan->host_bins;
+    delete[] plan->host_split;
+    plan->host_split = nullptr;
     plan->row_bin = nullptr;
     plan->host_bins = nullptr;
 }
@@ -777,6 +816,7 @@ int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state) {
         if (p.num_bins > 0) {
             if (p.bin_rows > kPbBinRows) k_pb_accumulate<kPbBinRowsLarge, kPbBThreadsLarge><<<p.num_bins, kPbBThreadsLarge, 0, r.stream>>>(v, state);
             else k_pb_accumulate<kPbBinRows, kPbBThreads><<<p.num_bins, kPbBThreads, 0, r.stream>>>(v, state);
+            if (p.num_split > 0) k_pb_hub_fold<<<(p.num_split + 63) / 64, 64, 0, r.stream>>>(p.split, p.num_split, p.hub_part, p.out, state);
         }
     }
     }
@@ -792,6 +832,8 @@ void pb_destroy(PbFormat& p) {
     (void)hipFree(p.tmp);
     (void)hipFree(p.dstg);
     (void)hipFree(p.amax);
+    (void)hipFree(p.split);
+    (void)hipFree(p.hub_part);
     (void)hipFree(p.bin);
     (void)hipFree(p.drow);
     if (p.owns_out) (void)hipFree(p.out);
