@@ -52,7 +52,7 @@ def measured_traffic(scale, ef, blocked):
     total = 0.0
     for name, row in pmc.items():
         # the PPR step's launches: the AXPBY combine is MODE 1 (the PMC run also holds the secondary filters' <2,.> / <3,.>)
-        if name.startswith(("k_bsf_partial", "k_bsf_fixup", "k_bsf_combine<1,", "k_pb_gather", "k_pb_accumulate")):
+        if name.startswith(("k_bsf_partial", "k_bsf_fixup", "k_bsf_combine<1,", "k_pb_gather", "k_pb_accumulate", "k_pb_hub_fold")):
             total += row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
     return (int(total), os.path.relpath(PMC_SUMMARY, ROOT)) if total > 0 else (None, None)
 
