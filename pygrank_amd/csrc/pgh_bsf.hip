@@ -318,25 +318,72 @@ __global__ void k_permute_in(const float* __restrict__ src, const int32_t* __res
 __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __restrict__ ranks, const int32_t* __restrict__ perm,
                                   const float* __restrict__ scale, int64_t n_pad, float* __restrict__ v_int, float* __restrict__ y0,
                                   float* __restrict__ xg, int xg_blk, int xg_live, float in_norm, int start_from_v) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
-        const int o = perm[i];
-        float a = o >= 0 ? v[o] : 0.f;
-        if (in_norm != 1.f) a = a / in_norm;              // the same f32 division as the backend's `p / norm`
-        const float b = start_from_v ? a : (o >= 0 ? ranks[o] : 0.f);
-        v_int[i] = a;
-        y0[i] = b;
-        if (xg) {
-            const int slot = xg_slot((int)i, xg_blk, xg_live);
-            if (slot >= 0) xg[slot] = scale ? b * scale[i] : b;
+    // four independent (index -> gather) chains per thread and round: one chain per round leaves the loop latency-bound
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < n_pad; i0 += stride * U) {
+        int o[U];
+        float a[U], b[U], sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            o[u] = i < n_pad ? perm[i] : -1;
+            sc[u] = scale && i < n_pad ? scale[i] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = o[u] >= 0 ? v[o[u]] : 0.f;
+            b[u] = !start_from_v && o[u] >= 0 ? ranks[o[u]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n_pad) continue;
+            if (in_norm != 1.f) a[u] = a[u] / in_norm;    // the same f32 division as the backend's `p / norm`
+            if (start_from_v) b[u] = a[u];
+            v_int[i] = a[u];
+            y0[i] = b[u];
+            if (xg) {
+                const int slot = xg_slot((int)i, xg_blk, xg_live);
+                if (slot >= 0) xg[slot] = scale ? b[u] * sc[u] : b[u];
+            }
         }
     }
 }
 
+// dst[old] = src[iperm[old]] * factor
+__global__ void k_permute_out_gather(const float* __restrict__ src, const int32_t* __restrict__ iperm, int64_t n, float factor,
+                                     float* __restrict__ dst) {
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
+        int at[U];
+        float x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) at[u] = i0 + u * stride < n ? iperm[i0 + u * stride] : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = src[at[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * stride < n) dst[i0 + u * stride] = x[u] * factor;
+    }
+}
 __global__ void k_permute_out(const float* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_pad, int64_t n_valid,
                               float factor, float* __restrict__ dst) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
-        const int o = perm ? perm[i] : (i < n_valid ? (int)i : -1);
-        if (o >= 0) dst[o] = src[i] * factor;
+    constexpr int U = 4;                                   // independent loads per thread and round (see k_permute_in_pair)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < n_pad; i0 += stride * U) {
+        int o[U];
+        float x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            o[u] = i < n_pad ? (perm ? perm[i] : (i < n_valid ? (int)i : -1)) : -1;
+            x[u] = i < n_pad ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (o[u] >= 0) dst[o[u]] = x[u] * factor;
     }
 }
 
@@ -866,6 +913,11 @@ int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole
 // output-side vector: internal -> original
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor) {
     BsfFormat& f = g->bsf;
+    if (f.relabelled && f.iperm != nullptr) {          // gather through the inverse map: coalesced stores (the scatter form
+        k_permute_out_gather<<<blocks_for(f.n_out_orig), kBlock, 0, rt().stream>>>(src, f.iperm, f.n_out_orig, (float)factor, dst);   // writes 4 bytes per line)
+        PGH_HIP(hipGetLastError());
+        return 0;
+    }
     k_permute_out<<<blocks_for(f.n_out), kBlock, 0, rt().stream>>>(src, f.relabelled ? f.perm : nullptr, f.n_out, f.n_out_orig,
                                                                   (float)factor, dst);
     PGH_HIP(hipGetLastError());
@@ -877,6 +929,7 @@ void bsf_destroy(BsfFormat& f) {
     pb_destroy(f.pb);
     (void)hipFree(f.colf);
     (void)hipFree(f.colf16);
+    (void)hipFree(f.iperm);
     (void)hipFree(f.flags8);
     (void)hipFree(f.fix_dst);
     (void)hipFree(f.live_dev);
@@ -1157,6 +1210,10 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     PGH_HIP(hipStreamSynchronize(r.stream));
     f.device_bytes = (int64_t)E * (val ? 8 : 4) + f.num_segs * 4 + (int64_t)f.num_tiles * 32 + (int64_t)B * f.n_out * 4 +
                      (int64_t)n_src_pad * (4 + (src_old ? 4 : 0) + (relabel ? 4 : 0)) + (int64_t)n_out * (dst_old ? 8 : 4);
+    if (relabel && !batch_layout) {                    // old id -> new id: results are brought back by a gather
+        f.iperm = iperm.release();
+        f.device_bytes += (int64_t)n_src * 4;
+    }
     if (env_int("PGH_DEBUG", 0)) {
         DevBuf<unsigned long long> cnt;
         PGH_TRY(cnt.alloc(1, true));

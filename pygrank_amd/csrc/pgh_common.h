@@ -194,6 +194,7 @@ struct BsfFormat {
     double*   head_partial = nullptr;
     float*    part = nullptr;       // [B][n_out] block partial sums (structurally empty pairs stay 0 forever)
     int32_t*  perm = nullptr;       // [n_src] new id -> old id, or null (identity)
+    int32_t*  iperm = nullptr;      // [n_src] old id -> new id (square relabelled graphs: results leave by a gather)
     float*    src_scale = nullptr;  // [n_src_pad + 1] new space, or null
     float*    dst_scale = nullptr;  // [n_out] new space, or null
     int32_t*  live_dev = nullptr;   // [8] device copy target of `live`

@@ -112,11 +112,13 @@ def main():
             for j in range(b):
                 want, it = oracle_runs[j]
                 its = ranker.last_batches[0][j]["iterations"]
+                if its != it and abs(its - it) <= max(2, it // 25):   # stopped a step apart: compare at the engine's step count
+                    want = orc.pagerank(M, feats[:, j], alpha=0.85, error_type="iters", max_iters=its, eps=EPS32)[0]
                 rel = np.max(np.abs(out[:, j] - want)) / max(np.max(np.abs(want)), 1e-30)
                 # a residual within f32 rounding of the tolerance may stop an iteration apart: the iterates then differ by ~tol.
                 # The columns are not normalised (magnitudes up to 17): the f32 rounding noise of a column's residual
                 # scales with it and reaches tens of percent of tol = 1e-6, i.e. up to two steps of the 0.85 contraction.
-                if abs(its - it) > max(2, it // 25) or rel > (2e-6 if its == it else 6e-6):
+                if abs(its - it) > max(2, it // 25) or rel > 2e-6:
                     print("MISMATCH propagate", desc, "column", j, rel, "iterations", its, it, flush=True)
                     if os.environ.get("PGH_STRESS_DUMP"):          # replay material for a scratch script
                         sp.save_npz(os.path.join(os.environ["PGH_STRESS_DUMP"], "case_graph.npz"), sp.csr_matrix(A))
