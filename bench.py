@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--force-partitioned", action="store_true", help="run the row-partitioned path even with one rank")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.force_partitioned and args.gpus == 1 and "RANK" not in os.environ:      # plain `python bench.py --force-partitioned`
+        for key, val in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29655")):
+            os.environ.setdefault(key, val)
     if args.gpus > 1 or world > 1 or args.force_partitioned:
         result = multi_gpu(args)
     else:
