@@ -110,8 +110,9 @@ def single_gpu(args):
         L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
         prof[name] = dict(launches=cnt.value, avg_us=(ms.value / cnt.value * 1e3) if cnt.value else None)
     alg_bytes = 8 * nnz + 16 * n                     # fused PPR step, per launch
-    # the fused PPR step (SpMV + axpby epilogue + sum(y)) is one launch on the row-major layout and three launches
-    # (block partials, cross-tile fix-up, combine + epilogue) on the blocked layout: its duration is their sum
+    # the fused PPR step (SpMV + axpby epilogue + sum(y)) is one launch on the row-major layout; on the blocked layout it
+    # is block partials, the cold image's two phases (when the graph has one), cross-tile fix-up, combine + epilogue:
+    # its duration is their sum
     step_kernels = [k for k in ("spmv", "pb_gather", "pb_accumulate", "fixup", "combine") if prof[k]["avg_us"]]
     step_us = sum(prof[k]["avg_us"] for k in step_kernels)
     achieved = alg_bytes / (step_us * 1e-6) / 1e9

@@ -13,7 +13,10 @@
 //      the kernel: block-local byte offsets, one flag byte per lane, tiles transposed for coalesced 16-byte loads);
 //   4. when M^T = diag(dst) * W * diag(src) with small integer W (the preprocessor's "col"/"symmetric"
 //      normalisations of an unweighted or multi-edge graph, preprocessing.py:109-138) the values disappear:
-//      multiplicities become repeated entries (4 B/edge), src moves into the gather vector, dst into the epilogue.
+//      multiplicities become repeated entries (4 B/edge), src moves into the gather vector, dst into the epilogue;
+//   5. entries whose source is outside a block's LDS hot cache ("cold") move to the propagation-blocking image of
+//      pgh_pb.hip when there are enough of them; the stream then holds hot entries only and is narrowed to 16-bit
+//      words (2 B/edge, k_bsf_narrow).
 // Block partial sums go to B dense f32 vectors; k_bsf_combine folds them with the filter's epilogue
 // (apply_epilogue: adhoc.py:34-36,166-169; abstract_filters.py:215-230) and writes the next gather vector.
 //

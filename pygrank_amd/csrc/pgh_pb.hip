@@ -29,8 +29,9 @@
 // ~12.5 sequential bytes per cold entry instead of one L2 request.
 //
 // Used whenever the image holds >= ~20 M cold entries (pb_plan; PGH_PB=0 switches it off, PGH_PB_FORCE=1 lifts the size
-// heuristics for tests); not yet for row-partitioned graphs and the multi-seed layout.  Bench graph (RMAT scale 23):
-// k_bsf_partial 137 us + phase A 80 us + phase B 80 us against 375 us with the cold gathers left in the stream.
+// heuristics for tests); row-partitioned slices included, the multi-seed layout not yet.  Bench graph (RMAT scale 23):
+// k_bsf_partial 83 us (hot entries only, 16-bit stream) + phase A 81 us + phase B 84 us against 375 us with the cold
+// gathers left in the stream.
 // profiles/r01/pb_experiment_scale23.log holds the history (v1/v2: bins of <= 15 K ENTRIES staged in LDS and walked
 // row-major, deterministic, but 6463 bins x 114 chunks made the runs 250 bytes long and phase B DRAM-inefficient).
 #include <hipcub/hipcub.hpp>
