@@ -140,14 +140,14 @@ def test_full_size_properties_rmat20(gpu_engine):
     assert again.convergence.iteration == 2
 
 
-@pytest.mark.parametrize("world,backend,scale", [(1, "nccl", 14), (2, "gloo", 14), (4, "gloo", 14), (2, "gloo", 17)],
+@pytest.mark.parametrize("world,backend,scale", [(1, "nccl", 14), (2, "gloo", 14), (4, "gloo", 14), (2, "gloo", 18)],
                          ids=["rccl_x1", "gloo_x2", "gloo_x4", "gloo_x2_cold_image"])
 def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, scale):
     """The N > 1 code path on the real engine: relabelled slice generation, the device-driven pgh_dist_* loop, in-place
     collectives on device scalars, the trimmed all-gather -- against the oracle.  World size 1 runs over RCCL; world sizes
     2 and 4 share the single GPU of this box and exchange through gloo (functional coverage of the multi-rank device
     path: RCCL refuses two ranks on one GPU).  The same logic runs on the CPU in tests/test_distributed_cpu.py; 8 GPUs
-    over RCCL/xGMI are the driver's scaling run.  The scale-17 case has sources outside the LDS hot cache and forces the
+    over RCCL/xGMI are the driver's scaling run.  The scale-18 case has sources outside the LDS hot cache and forces the
     propagation-blocking image of the cold entries onto every rank's slice."""
     import os
     import subprocess
@@ -159,8 +159,8 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(29611 + world), os.path.join(root, "tests", "dist_worker.py"), str(tmp_path), str(scale), str(ef)]
     env = dict(os.environ, PYTHONPATH=root, PGH_TEST_ENGINE="hip", PGH_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if scale > 14:
-        env.update(PGH_PB="1", PGH_PB_FORCE="1", PGH_DEBUG="1")
+    if scale > 14:                       # four column blocks over two ranks: two all-gathers per exchange, like bench.py --gpus 2
+        env.update(PGH_PB="1", PGH_PB_FORCE="1", PGH_DEBUG="1", PGH_BLOCKS="4", PGH_PB_HEAVY="64", PGH_PB_HUBMAX="500")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     if scale > 14:
