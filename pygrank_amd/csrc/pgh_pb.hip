@@ -28,7 +28,7 @@
 //
 // ~12.5 sequential bytes per cold entry instead of one L2 request.
 //
-// Used whenever the image holds >= ~20 M cold entries (pb_plan; PGH_PB=0 switches it off, PGH_PB_FORCE=1 lifts the size
+// Used whenever the image holds >= ~10 M cold entries (pb_plan; PGH_PB=0 switches it off, PGH_PB_FORCE=1 lifts the size
 // heuristics for tests); row-partitioned slices included, the multi-seed layout not yet.  Bench graph (RMAT scale 23):
 // k_bsf_partial 83 us (hot entries only, 16-bit stream) + phase A 81 us + phase B 84 us against 375 us with the cold
 // gathers left in the stream.
@@ -540,12 +540,15 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     const char* force = getenv("PGH_PB_FORCE");
     const bool forced = force != nullptr && atoi(force) != 0;
     // Worth it when the saved L2 requests (~4.2 ps per cold entry on MI355X) outweigh ~12.5 streamed bytes per entry
-    // (~2.9 ps) plus two launches, the chunk fills and a fifth vector in the combine (~28 us): from ~20 M cold entries.
-    // Measured (profiles/r01/pb_skew_scales.log): RMAT a=.57 scale 21 (11 M cold) -15 %, scale 22 (23 M) +-0, scale 23
-    // +11 %, scale 24 +13 %; uniform graphs x2.0 .. x2.4 at every scale.
+    // (~2.9 ps) plus two launches, the chunk fills and a fifth vector in the combine, minus what k_bsf_partial gains from
+    // a hot-only 16-bit stream: from ~10 M cold entries.  Measured (profiles/r01/pb_skew_scales.log): RMAT a=.57
+    // scale 20 (5 M cold) -36 %, scale 21 (11 M) +7 %, scale 22 +12 %, scale 23 +31 %; flat degree distributions: scale 20
+    // (10-17 M cold) -2 .. +11 %, scale 21 and up x1.5 .. x2.4.
     // Runs are padded to whole groups of 8 (3.5 pad entries on average): below ~10 entries per run the padding eats the
     // gain.
-    if (!forced && (in_image < 20 * (1LL << 20) || in_image * 20 < E || run < 10.0)) return 0;
+    // Valued graphs stream 4 more bytes per cold entry in phase A: 13 M cold entries measure -3 % (scale 21 upload).
+    const int64_t least = (f.val != nullptr ? 16 : 10) * (1LL << 20);
+    if (!forced && (in_image < least || in_image * 20 < E || run < 10.0)) return 0;
     PGH_HIP(hipMalloc(&plan->row_bin, sizeof(int32_t) * (size_t)f.n_out));
     PGH_HIP(hipMemcpyAsync(plan->row_bin, row_bin.data(), sizeof(int32_t) * f.n_out, hipMemcpyHostToDevice, r.stream));
     k_pb_keep_heavy<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, E, plan->row_bin, is_hot);
