@@ -134,7 +134,9 @@ def main():
             sys.exit(1)
         its = ranker.convergence.iteration
         tolerance_based = which in (0, 1)
-        slack = max(1, it // 50)            # slowly converging runs sit near the tolerance for several iterations
+        # slowly converging runs (alpha = 0.99: the residual shrinks ~1 % per step) sit within f32 rounding of the tolerance
+        # for several iterations; the RESULT is still held to 2e-6 against the oracle stopped at the engine's step count
+        slack = max(1, it // 25)
         # a residual within f32 rounding of the tolerance may stop an iteration apart: the result is then compared with the
         # oracle stopped after the engine's number of steps
         if tolerance_based and its != it and abs(its - it) <= slack:
