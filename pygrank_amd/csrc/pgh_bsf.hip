@@ -469,6 +469,10 @@ __device__ __forceinline__ float wave_segmented_sum(float keep, float val) {
 // register moves): column stream of tile t+2, gathers of tile t+1, arithmetic of tile t.  In-tile sums are f32 (a
 // lane adds at most IPT terms, the 64-lane stitch is a log-depth DPP segmented scan); pieces of segments that cross
 // tiles are carried in f64 and combined in a fixed order by k_bsf_fixup (deterministic, atomic-free).
+#ifndef PGH_ROWS_PF
+#define PGH_ROWS_PF 2          // groups of 64 segment rows fetched ahead per tile (3 / 4 / 6 measured: 79-82 us against 82-87 at
+                               // scale 23, nothing on partition slices: within noise, the default stays)
+#endif
 template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
                                                               const LoopState* __restrict__ state) {
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         float        c[IPT];
         float        v[HAS_VAL ? IPT : 1];
         unsigned int bits;           // segment-start flags of the lane's IPT entries
-        int          row0, row1;     // output rows of the tile's first 128 closed segments (prefetched)
+        int          row[PGH_ROWS_PF];   // output rows of the tile's first 64 * PGH_ROWS_PF closed segments (prefetched)
         int          seg_base;
     };
     auto gather = [&](const Stream& st, Gathered& g) __attribute__((always_inline)) {
@@ -587,11 +591,12 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         g.bits = __builtin_amdgcn_raw_buffer_load_b8(flag_rsrc, lane, st.rel * 64, 0);
         g.seg_base = st.seg_base;
 #if PGH_PROBE_SKIP & 1           // diagnostic: no output stage
-        g.row0 = g.row1 = -1;
+#pragma unroll
+        for (int k = 0; k < PGH_ROWS_PF; ++k) g.row[k] = -1;
 #else
         const int32_t* __restrict__ rows = f.seg_row + st.seg_base + 1;   // reads past the tile's segments are harmless
-        g.row0 = rows[lane];
-        g.row1 = rows[64 + lane];
+#pragma unroll
+        for (int k = 0; k < PGH_ROWS_PF; ++k) g.row[k] = rows[64 * k + lane];
 #endif
     };
     const int scr4 = strip4 + ((T + 1 + lane) << 2);
@@ -642,11 +647,12 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         if (val == 123.456f) f.tail_carry[t] = 0.0;
 #endif
         // ---- closed segments -> block partial vector (rows prefetched for the first 128; rare long tail below)
-        if (lane < closed && g0.row0 >= 0) part[g0.row0] = seg[1 + lane];
-        if (64 + lane < closed && g0.row1 >= 0) part[g0.row1] = seg[65 + lane];
-        if (closed > 128) {
+#pragma unroll
+        for (int k = 0; k < PGH_ROWS_PF; ++k)
+            if (64 * k + lane < closed && g0.row[k] >= 0) part[g0.row[k]] = seg[1 + 64 * k + lane];
+        if (closed > 64 * PGH_ROWS_PF) {
             const int32_t* __restrict__ rows = f.seg_row + g0.seg_base + 1;
-            for (int j = 128 + lane; j < closed; j += 64) {
+            for (int j = 64 * PGH_ROWS_PF + lane; j < closed; j += 64) {
                 const int row = rows[j];
                 if (row >= 0) part[row] = seg[1 + j];
             }
@@ -1181,8 +1187,8 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     }
     // + 192: k_bsf_partial prefetches the rows of 128 segments per tile unconditionally (reads past a tile's own segments
     // are never used, but they must stay inside the allocation: found by tools/stress_gpu.py as a rare memory fault)
-    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1 + 192)));
-    PGH_HIP(hipMemsetAsync(f.seg_row, 0xff, sizeof(int32_t) * (size_t)(f.num_segs + 1 + 192), r.stream));
+    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1 + 64 * PGH_ROWS_PF + 64)));
+    PGH_HIP(hipMemsetAsync(f.seg_row, 0xff, sizeof(int32_t) * (size_t)(f.num_segs + 1 + 64 * PGH_ROWS_PF + 64), r.stream));
     k_bsf_seg_rows<<<blocks_for(EP), kBlock, 0, r.stream>>>(keys_p.p, segid.p, EP, f.seg_row);
     PGH_HIP(hipMalloc(&f.tile, sizeof(int4) * (size_t)(f.num_tiles + 1)));
     PGH_HIP(hipMalloc(&f.tail_carry, sizeof(double) * (size_t)(f.num_tiles + 1)));

@@ -17,7 +17,10 @@ from pygrank_amd.distributed import _HOT_PAD, rmat_partitioned  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--worlds", type=int, nargs="+", default=[2, 4, 8])
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--lib", default=None, help="a diagnostic build of the engine (tools/build_variants.sh) instead of the in-tree one")
 args = ap.parse_args()
+if args.lib:
+    L._lib = L.load_library(os.path.abspath(args.lib))
 pg.load_backend("hip")
 lib = L.lib()
 for world in args.worlds:
