@@ -226,16 +226,31 @@ __global__ void k_bsf_count_hot(const uint32_t* __restrict__ colf, int64_t E, in
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
 }
 
-// segid = inclusive scan of flags; segment s = segid - 1 starts at the flagged entry
+// segid = inclusive scan of flags; segment s = segid - 1 starts at the flagged entry.  With `meta` (SpMV layout) the
+// segment also enters the row -> segment map of its block: bit (row % 64) of word row / 64, base = the word's lowest
+// segment index (a block's segments are sorted by row, so the segments of one word are consecutive).
 __global__ void k_bsf_seg_rows(const uint64_t* __restrict__ keys, const int* __restrict__ segid, int64_t E,
-                               int32_t* __restrict__ seg_row) {
+                               int32_t* __restrict__ seg_row, SegMeta* __restrict__ meta, int64_t meta_words) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += stride) {
         const bool f = (e == 0) || (segid[e] != segid[e - 1]);
         if (f) {
             const uint64_t row = (keys[e] >> 29) & kLow29;
-            seg_row[segid[e] - 1] = row == kRowSentinel ? -1 : (int32_t)row;
+            const int seg = segid[e] - 1;
+            seg_row[seg] = row == kRowSentinel ? -1 : (int32_t)row;
+            if (meta != nullptr && row != kRowSentinel) {
+                SegMeta* m = meta + (int64_t)(keys[e] >> 58) * meta_words + (int64_t)(row >> 6);
+                atomicOr(&m->mask, 1ULL << (row & 63));
+                atomicMin(&m->base, seg);
+            }
         }
+    }
+}
+__global__ void k_bsf_meta_init(SegMeta* __restrict__ meta, int64_t count) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        meta[i].mask = 0ULL;
+        meta[i].base = 0x7fffffff;
+        meta[i].pad = 0;
     }
 }
 
@@ -392,17 +407,15 @@ __global__ void k_permute_out(const float* __restrict__ src, const int32_t* __re
 
 // ------------------------------------------------------------------------------------------------- SpMV kernels
 struct BsfView {
-    const int64_t*  fix_dst;   // [num_tiles] index into `part` that receives tile t's fix-up, or -1
+    const int32_t*  fix_seg;   // [num_tiles] segment (index into `psum`) that receives tile t's fix-up, or -1
     const uint32_t* colf;      // packed: byte offset of the source inside its block
     const uint16_t* colf16;    // hot-only streams: byte offset / 2, [tile][lane][8] (colf is null then)
     const uint8_t*  flags8;    // [num_tiles * 64] segment-start flags of each lane's 8 entries
     const float*    val;
-    const int32_t*  seg_row;
     const int4*     tile;
     double*         tail_carry;
     double*         head_partial;
-    float*          part;
-    int64_t         part_stride;
+    float*          psum;      // [num_segs] compact block partial sums: segment s of the stream -> psum[s]
     int             num_blocks;
     int             blk_size;
     int64_t         xg_base[8];
@@ -469,10 +482,10 @@ __device__ __forceinline__ float wave_segmented_sum(float keep, float val) {
 // register moves): column stream of tile t+2, gathers of tile t+1, arithmetic of tile t.  In-tile sums are f32 (a
 // lane adds at most IPT terms, the 64-lane stitch is a log-depth DPP segmented scan); pieces of segments that cross
 // tiles are carried in f64 and combined in a fixed order by k_bsf_fixup (deterministic, atomic-free).
-#ifndef PGH_ROWS_PF
-#define PGH_ROWS_PF 2          // groups of 64 segment rows fetched ahead per tile (3 / 4 / 6 measured: 79-82 us against 82-87 at
-                               // scale 23, nothing on partition slices: within noise, the default stays)
-#endif
+// Output: the sum of the j-th segment closed inside tile t goes to psum[seg_base(t) + 1 + j] -- consecutive lanes write
+// consecutive floats, no row indices are read (round 1 wrote part[block][row] through a prefetched row list: 74 MB of
+// row indices per launch at scale 23 and scattered 4-byte stores; the flag byte and the row list were fetched only one
+// tile ahead, which left every wavefront waiting on them -- SQ_WAIT_ANY 62 %, profiles/r02/r01_kernels_sq_counters.json).
 template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
                                                               const LoopState* __restrict__ state) {
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     const int per = 8 / f.num_blocks;
     const int rank = (slot * per + label / f.num_blocks) * WAVES + wave;
     const int stride = (gridDim.x >> 3) * per * WAVES;
-    float* __restrict__ part = f.part + (int64_t)b * f.part_stride;
+    float* __restrict__ psum = f.psum;
     const int64_t base = f.xg_base[b];
     const uint32_t hot = (uint32_t)min(kBsfHot, f.blk_size);
     const uint32_t hot4 = hot << 2;
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     struct Stream {
         u32x4        c[Q];
         u32x4        v[Q];
-        int          rel;            // tile index relative to the block's first tile (scalar)
+        unsigned int bits;           // segment-start flags of the lane's IPT entries
         int          seg_base;
     };
     // The stream is read through buffer descriptors rebased to the block's first tile: the lane part of an address is a
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
 #pragma unroll
             for (int q = 0; q < Q; ++q) st.v[q] = __builtin_amdgcn_raw_buffer_load_b128(val_rsrc, lane32 + kQStep * q, rel * (T * 4), kNT);
         }
-        st.rel = rel;
+        st.bits = __builtin_amdgcn_raw_buffer_load_b8(flag_rsrc, lane, rel * 64, 0);
         st.seg_base = f.tile[tile].z;
     };
     // gather stage: issue the LDS read and the buffer load of every entry WITHOUT consuming them (they are summed one
@@ -559,8 +572,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         float        h[IPT];
         float        c[IPT];
         float        v[HAS_VAL ? IPT : 1];
-        unsigned int bits;           // segment-start flags of the lane's IPT entries
-        int          row[PGH_ROWS_PF];   // output rows of the tile's first 64 * PGH_ROWS_PF closed segments (prefetched)
+        unsigned int bits;
         int          seg_base;
     };
     auto gather = [&](const Stream& st, Gathered& g) __attribute__((always_inline)) {
@@ -588,16 +600,8 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
 #endif
             if (HAS_VAL) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
         }
-        g.bits = __builtin_amdgcn_raw_buffer_load_b8(flag_rsrc, lane, st.rel * 64, 0);
+        g.bits = st.bits;            // fetched with the stream, three tiles ahead: as old as the column words used above
         g.seg_base = st.seg_base;
-#if PGH_PROBE_SKIP & 1           // diagnostic: no output stage
-#pragma unroll
-        for (int k = 0; k < PGH_ROWS_PF; ++k) g.row[k] = -1;
-#else
-        const int32_t* __restrict__ rows = f.seg_row + st.seg_base + 1;   // reads past the tile's segments are harmless
-#pragma unroll
-        for (int k = 0; k < PGH_ROWS_PF; ++k) g.row[k] = rows[64 * k + lane];
-#endif
     };
     const int scr4 = strip4 + ((T + 1 + lane) << 2);
     // arithmetic of one tile: lane-local flags, branch-free f32 segmented sum
@@ -646,17 +650,14 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
 #else
         if (val == 123.456f) f.tail_carry[t] = 0.0;
 #endif
-        // ---- closed segments -> block partial vector (rows prefetched for the first 128; rare long tail below)
+        // ---- closed segments -> their slots of the compact partial-sum array: segment seg_base + 1 + j <- strip slot 1 + j
+        // (a fixed number of predicated stores: no loop of unknown length between the counted waits)
+#if !(PGH_PROBE_SKIP & 1)
+        float* __restrict__ dst = psum + (g0.seg_base + 1);
 #pragma unroll
-        for (int k = 0; k < PGH_ROWS_PF; ++k)
-            if (64 * k + lane < closed && g0.row[k] >= 0) part[g0.row[k]] = seg[1 + 64 * k + lane];
-        if (closed > 64 * PGH_ROWS_PF) {
-            const int32_t* __restrict__ rows = f.seg_row + g0.seg_base + 1;
-            for (int j = 64 * PGH_ROWS_PF + lane; j < closed; j += 64) {
-                const int row = rows[j];
-                if (row >= 0) part[row] = seg[1 + j];
-            }
-        }
+        for (int k = 0; k < IPT; ++k)
+            if (64 * k + lane < closed) dst[64 * k + lane] = seg[1 + 64 * k + lane];
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
@@ -695,60 +696,24 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
 
 // build time: where the fix-up of tile t goes (index into the partial vectors, -1 = nothing to fix), so that the
 // per-iteration kernel below needs no dependent loads
-__global__ void k_bsf_fixlist(const int4* __restrict__ tile, const int32_t* __restrict__ seg_row, BsfView f, int num_tiles,
-                              int64_t* __restrict__ fix_dst) {
+__global__ void k_bsf_fixlist(const int4* __restrict__ tile, const int32_t* __restrict__ seg_row, int num_tiles,
+                              int32_t* __restrict__ fix_seg) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < num_tiles; t += gridDim.x * blockDim.x) {
         const int4 ti = tile[t];
-        int64_t dst = -1;
-        if (ti.w >= 0 && ti.z >= 0) {
-            const int row = seg_row[ti.z];
-            if (row >= 0) {
-                int b = 0;
-                while (b + 1 < f.num_blocks && t >= f.tile_begin[b + 1]) ++b;
-                dst = (int64_t)b * f.part_stride + row;
-            }
-        }
-        fix_dst[t] = dst;
+        // ti.z = the segment open when the tile starts; it closes here when the tile holds a flag (ti.w >= 0)
+        fix_seg[t] = (ti.w >= 0 && ti.z >= 0 && seg_row[ti.z] >= 0) ? ti.z : -1;
     }
 }
 
-// segments that cross tiles: fixed-order sum of the carries, one thread per closing tile; a hub row spans hundreds of
-// tiles, so chains of 32+ tiles are summed by the whole wavefront (strided lanes + fixed reduction tree) instead of
-// leaving one thread with a serial chain of dependent loads that would set the kernel's duration
-__global__ __launch_bounds__(WG) void k_bsf_fixup(BsfView f, int num_tiles, const LoopState* __restrict__ state) {
+// segments that cross tiles (bsf_fixup_tiles, pgh_kernels.h) as a launch of their own: graphs without a cold image
+__global__ __launch_bounds__(WG) void k_bsf_fixup(FixView f, const LoopState* __restrict__ state) {
     if (state != nullptr && state->done) return;
-    const int lane = threadIdx.x & 63;
-    const int rounds = (num_tiles + gridDim.x * WG - 1) / (gridDim.x * WG);
-    for (int r = 0; r < rounds; ++r) {                    // wavefront-uniform trip count: the cooperative part uses shuffles
-        const int t = (r * gridDim.x + blockIdx.x) * WG + threadIdx.x;
-        const int64_t dst = t < num_tiles ? f.fix_dst[t] : -1;
-        const int first = dst >= 0 ? f.tile[t].w : 0;
-        const int len = dst >= 0 ? t - first : 0;
-        const bool is_long = len >= 32;
-        if (dst >= 0 && !is_long) {
-            double total = 0.0;
-            for (int s = first; s < t; ++s) total += f.tail_carry[s];
-            total += f.head_partial[t];
-            f.part[dst] = (float)total;
-        }
-        unsigned long long todo = __ballot(is_long);
-        while (todo != 0ULL) {
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1ULL;
-            const int c_first = __shfl(first, src, 64), c_t = __shfl(t, src, 64);
-            double part_sum = 0.0;
-            for (int s = c_first + lane; s < c_t; s += 64) part_sum += f.tail_carry[s];
-            part_sum = wave_reduce_sum(part_sum);
-            const double total = __shfl(part_sum, 0, 64) + f.head_partial[c_t];
-            if (lane == src) f.part[dst] = (float)total;
-        }
-    }
+    bsf_fixup_tiles(f, blockIdx.x * WG, gridDim.x * WG);
 }
 
 // fold the B block partials, apply the filter epilogue, write the next gather vector
 template <int MODE, int B>
-__global__ __launch_bounds__(WG) void k_bsf_combine(const float* __restrict__ part, const float* __restrict__ cold,
-                                                     int64_t part_stride, int64_t n_out,
+__global__ __launch_bounds__(WG) void k_bsf_combine(RowSums rs, int64_t n_out,
                                                      const float* __restrict__ dst_scale, EpiParams ep,
                                                      const LoopState* __restrict__ state, double* __restrict__ partial_sum,
                                                      double* __restrict__ partial_delta) {
@@ -762,10 +727,7 @@ __global__ __launch_bounds__(WG) void k_bsf_combine(const float* __restrict__ pa
     double sum_y = 0.0, delta = 0.0;
     const int64_t stride = (int64_t)gridDim.x * WG;
     for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n_out; i += stride) {
-        double s = 0.0;
-#pragma unroll
-        for (int b = 0; b < B; ++b) s += (double)part[(int64_t)b * part_stride + i];
-        if (cold != nullptr) s += (double)cold[i];
+        double s = block_row_sum<B>(rs, i);
         if (dst_scale != nullptr) s *= (double)dst_scale[i];
         apply_epilogue<MODE>(ep, a_eff, (int)i, (float)s, sum_y, delta);
     }
@@ -779,17 +741,15 @@ __global__ __launch_bounds__(WG) void k_bsf_combine(const float* __restrict__ pa
 
 BsfView view_of(const BsfFormat& f) {
     BsfView v;
-    v.fix_dst = f.fix_dst;
+    v.fix_seg = f.fix_seg;
     v.colf = f.colf;
     v.colf16 = f.colf16;
     v.flags8 = f.flags8;
     v.val = f.val;
-    v.seg_row = f.seg_row;
     v.tile = f.tile;
     v.tail_carry = f.tail_carry;
     v.head_partial = f.head_partial;
-    v.part = f.part;
-    v.part_stride = f.n_out;
+    v.psum = f.psum;
     v.num_blocks = f.num_blocks;
     v.blk_size = f.blk_size;
     for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base[i];
@@ -835,33 +795,54 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state) 
             else k_bsf_partial<kIPT, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
         }
     }
-    PGH_TRY(pb_launch(g, xg, state));              // cold entries: two streaming passes -> f.pb.out
-    {
+    FixView fix;
+    fix.fix_seg = f.fix_seg;
+    fix.tile = f.tile;
+    fix.tail_carry = f.tail_carry;
+    fix.head_partial = f.head_partial;
+    fix.psum = f.psum;
+    fix.num_tiles = f.num_tiles;
+    if (f.pb.enabled && f.pb.num_tasks > 0) {
+        // cold entries, phase A: gathered values -> bin order; its workgroups close the cross-tile segments first
+        PGH_TRY(pb_launch_gather(g, xg, state, fix));
+    } else {
         ProfScope prof(PGH_K_FIXUP);
         int fix_grid = (f.num_tiles + WG - 1) / WG;
         if (fix_grid < 1) fix_grid = 1;
         if (fix_grid > 1024) fix_grid = 1024;
-        k_bsf_fixup<<<fix_grid, WG, 0, r.stream>>>(v, f.num_tiles, state);
+        k_bsf_fixup<<<fix_grid, WG, 0, r.stream>>>(fix, state);
     }
     PGH_HIP(hipGetLastError());
     return 0;
+}
+
+RowSums row_sums_of(const BsfFormat& f) {
+    RowSums rs;
+    rs.meta = f.meta;
+    rs.psum = f.psum;
+    rs.words = f.meta_words;
+    rs.num_blocks = f.num_blocks;
+    rs.zero_at = (unsigned int)f.num_segs;            // past the last segment: zeroed at build time, never written
+    return rs;
 }
 
 template <int MODE>
 int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* state, int* num_partials) {
     Runtime& r = rt();
     BsfFormat& f = g->bsf;
+    const RowSums rs = row_sums_of(f);
+    // graphs with a cold image: phase B and the epilogue are one launch (pgh_pb.hip)
+    if (f.pb.enabled) return pb_launch_finish<MODE>(g, rs, ep, state, num_partials);
     const int cgrid = bsf_combine_grid(f.n_out);
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
-    const float* cold = f.pb.enabled ? f.pb.out : nullptr;
     {
         ProfScope prof(PGH_K_COMBINE);
         switch (f.num_blocks) {
-            case 1: k_bsf_combine<MODE, 1><<<cgrid, WG, 0, r.stream>>>(f.part, cold, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
-            case 2: k_bsf_combine<MODE, 2><<<cgrid, WG, 0, r.stream>>>(f.part, cold, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
-            case 4: k_bsf_combine<MODE, 4><<<cgrid, WG, 0, r.stream>>>(f.part, cold, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
-            default: k_bsf_combine<MODE, 8><<<cgrid, WG, 0, r.stream>>>(f.part, cold, f.n_out, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            case 1: k_bsf_combine<MODE, 1><<<cgrid, WG, 0, r.stream>>>(rs, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            case 2: k_bsf_combine<MODE, 2><<<cgrid, WG, 0, r.stream>>>(rs, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            case 4: k_bsf_combine<MODE, 4><<<cgrid, WG, 0, r.stream>>>(rs, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
+            default: k_bsf_combine<MODE, 8><<<cgrid, WG, 0, r.stream>>>(rs, f.n_out, f.dst_scale, ep, state, psum, pdel); break;
         }
     }
     PGH_HIP(hipGetLastError());
@@ -940,7 +921,9 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.colf16);
     (void)hipFree(f.iperm);
     (void)hipFree(f.flags8);
-    (void)hipFree(f.fix_dst);
+    (void)hipFree(f.fix_seg);
+    (void)hipFree(f.psum);
+    (void)hipFree(f.meta);
     (void)hipFree(f.live_dev);
     (void)hipFree(f.val);
     (void)hipFree(f.seg_row);
@@ -1187,9 +1170,14 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     }
     // + 192: k_bsf_partial prefetches the rows of 128 segments per tile unconditionally (reads past a tile's own segments
     // are never used, but they must stay inside the allocation: found by tools/stress_gpu.py as a rare memory fault)
-    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1 + 64 * PGH_ROWS_PF + 64)));
-    PGH_HIP(hipMemsetAsync(f.seg_row, 0xff, sizeof(int32_t) * (size_t)(f.num_segs + 1 + 64 * PGH_ROWS_PF + 64), r.stream));
-    k_bsf_seg_rows<<<blocks_for(EP), kBlock, 0, r.stream>>>(keys_p.p, segid.p, EP, f.seg_row);
+    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1)));
+    PGH_HIP(hipMemsetAsync(f.seg_row, 0xff, sizeof(int32_t) * (size_t)(f.num_segs + 1), r.stream));
+    if (!batch_layout) {                               // SpMV layout: the row -> segment map of the compact partial sums
+        f.meta_words = ((int64_t)(f.n_out > 0 ? f.n_out : 1) + 63) / 64;
+        PGH_HIP(hipMalloc(&f.meta, sizeof(SegMeta) * (size_t)(f.meta_words * B)));
+        k_bsf_meta_init<<<blocks_for(f.meta_words * B), kBlock, 0, r.stream>>>(f.meta, f.meta_words * B);
+    }
+    k_bsf_seg_rows<<<blocks_for(EP), kBlock, 0, r.stream>>>(keys_p.p, segid.p, EP, f.seg_row, f.meta, f.meta_words);
     PGH_HIP(hipMalloc(&f.tile, sizeof(int4) * (size_t)(f.num_tiles + 1)));
     PGH_HIP(hipMalloc(&f.tail_carry, sizeof(double) * (size_t)(f.num_tiles + 1)));
     PGH_HIP(hipMalloc(&f.head_partial, sizeof(double) * (size_t)(f.num_tiles + 1)));
@@ -1199,8 +1187,9 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     // ---- work buffers and scales
     const size_t n_int = (size_t)(f.n_out > 0 ? f.n_out : 1);
     if (!batch_layout) {
-        PGH_HIP(hipMalloc(&f.part, sizeof(float) * (size_t)B * n_int));
-        PGH_HIP(hipMemsetAsync(f.part, 0, sizeof(float) * (size_t)B * n_int, r.stream));
+        // + one tile of slack: the predicated stores of k_bsf_partial address up to 512 slots past a tile's first segment
+        PGH_HIP(hipMalloc(&f.psum, sizeof(float) * (size_t)(f.num_segs + kTile + 64)));
+        PGH_HIP(hipMemsetAsync(f.psum, 0, sizeof(float) * (size_t)(f.num_segs + kTile + 64), r.stream));
         PGH_HIP(hipMalloc(&f.xg, sizeof(float) * (size_t)(n_src_pad + 1)));
         PGH_HIP(hipMemsetAsync(f.xg, 0, sizeof(float) * (size_t)(n_src_pad + 1), r.stream));
         PGH_HIP(hipMalloc(&f.tmp_out, sizeof(float) * n_int));
@@ -1217,7 +1206,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     }
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(r.stream));
-    f.device_bytes = (int64_t)E * (val ? 8 : 4) + f.num_segs * 4 + (int64_t)f.num_tiles * 32 + (int64_t)B * f.n_out * 4 +
+    f.device_bytes = (int64_t)E * (val ? 8 : 4) + f.num_segs * 4 + (int64_t)f.num_tiles * 32 + f.meta_words * B * (int64_t)sizeof(SegMeta) +
                      (int64_t)n_src_pad * (4 + (src_old ? 4 : 0) + (relabel ? 4 : 0)) + (int64_t)n_out * (dst_old ? 8 : 4);
     if (relabel && !batch_layout) {                    // old id -> new id: results are brought back by a gather
         f.iperm = iperm.release();
@@ -1252,10 +1241,12 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipStreamSynchronize(r.stream));
         for (int b = 0; b < 8; ++b) f.live[b] = live_all[b] > f.live[b] ? live_all[b] : f.live[b];   // the cold image's sources count too
         for (int b = 0; b < 8; ++b) f.xg_base[b] = (int64_t)b * blk;
-        PGH_HIP(hipMalloc(&f.fix_dst, sizeof(int64_t) * (size_t)(f.num_tiles + 1)));
-        k_bsf_fixlist<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.tile, f.seg_row, view_of(f), f.num_tiles, f.fix_dst);
+        PGH_HIP(hipMalloc(&f.fix_seg, sizeof(int32_t) * (size_t)(f.num_tiles + 1)));
+        k_bsf_fixlist<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.tile, f.seg_row, f.num_tiles, f.fix_seg);
         PGH_HIP(hipGetLastError());
         PGH_HIP(hipStreamSynchronize(r.stream));
+        (void)hipFree(f.seg_row);                       // build-time only in this layout
+        f.seg_row = nullptr;
         if (f.pb.enabled && !f.pb.k1_cold && env_int("PGH_STREAM16", 1)) {       // hot-only stream: 2 bytes per entry
             const uint32_t hot4 = (uint32_t)(kBsfHot < blk ? kBsfHot : blk) << 2;
             PGH_HIP(hipMalloc(&f.colf16, sizeof(uint16_t) * (size_t)f.num_tiles * 512 + 64));

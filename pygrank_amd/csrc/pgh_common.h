@@ -159,11 +159,23 @@ struct PbFormat {
     double*   hub_part = nullptr;   // [num_bins] piece sums, folded into `out` by k_pb_hub_fold
     uint32_t* amax = nullptr;       // [2] max |value| phase A wrote (bit pattern); phase B's exit tickets
     uint16_t* drow = nullptr;       // [padded] output row inside the bin (0xffff = pad entry)
-    float*    out = nullptr;        // [n_out] cold part of every row sum (structurally empty rows stay 0)
-    bool      owns_out = true;      // slices of one image share the output vector of the first
+    // work list of the finishing pass (k_pb_finish: phase B + the filter's epilogue in one launch): every output row
+    // belongs to exactly one item.  item_a = the bin (as `bin`; rows = 0 for stretches without cold entries),
+    // item_b = {first row of the epilogue range, rows, split index or -1, first bin of the split row}
+    int       num_items = 0;
+    int4*     item_a = nullptr;
+    int4*     item_b = nullptr;
+    uint32_t* hub_ticket = nullptr; // [num_split] arrival counters of the pieces of split hub rows (re-armed by the last arriver)
     int64_t   device_bytes = 0;
 };
 constexpr int kPbMaxSlices = 8;
+
+// one word of the row -> segment map of the blocked SpMV layout (see BsfFormat::psum)
+struct SegMeta {
+    unsigned long long mask;
+    int32_t            base;
+    int32_t            pad;
+};
 
 struct BsfFormat {
     bool      enabled = false;
@@ -183,16 +195,23 @@ struct BsfFormat {
                                     // multi-seed layout: column (new id) | bit31 = first entry of a row segment
     uint16_t* colf16 = nullptr;     // hot-only SpMV streams (all cold entries in `pb`): byte offset / 2 into the LDS hot cache,
                                     // [tile][lane][8]; colf is freed then
-    int64_t*  fix_dst = nullptr;    // [num_tiles] SpMV layout: where tile t's cross-tile fix-up lands in `part` (-1 = none)
+    int32_t*  fix_seg = nullptr;    // [num_tiles] SpMV layout: segment (index into `psum`) that receives tile t's cross-tile fix-up, -1 = none
     uint8_t*  flags8 = nullptr;     // [num_tiles * 64] SpMV layout: segment-start flags of each lane's 8 entries
     float*    val = nullptr;        // [num_entries] or null (value-free)
-    int32_t*  seg_row = nullptr;    // [num_segs] output row (new id) of every segment, -1 for sentinels
+    int32_t*  seg_row = nullptr;    // [num_segs] output row (new id) of every segment, -1 for sentinels (multi-seed layout; the
+                                    // SpMV layout needs it at build time only)
     int       num_tiles = 0;
     int4*     tile = nullptr;       // [num_tiles] {entry_start, entry_count, seg_base, chain_first}
     int       tile_begin[9] = {0};  // tile range of every block
     double*   tail_carry = nullptr; // [num_tiles]
     double*   head_partial = nullptr;
-    float*    part = nullptr;       // [B][n_out] block partial sums (structurally empty pairs stay 0 forever)
+    float*    part = nullptr;       // multi-seed layout only: per-tile head sums
+    // SpMV layout: block partial sums are stored COMPACTLY, one float per (block, row) segment in stream order (psum),
+    // written sequentially by k_bsf_partial; the epilogue finds the segments of a row through one SegMeta word per
+    // (block, 64 rows): bit r of mask = row 64 w + r has a segment in the block, base = index of the word's first segment
+    float*    psum = nullptr;       // [num_segs + pad]
+    SegMeta*  meta = nullptr;       // [B][meta_words]
+    int64_t   meta_words = 0;       // ceil(n_out / 64)
     int32_t*  perm = nullptr;       // [n_src] new id -> old id, or null (identity)
     int32_t*  iperm = nullptr;      // [n_src] old id -> new id (square relabelled graphs: results leave by a gather)
     float*    src_scale = nullptr;  // [n_src_pad + 1] new space, or null

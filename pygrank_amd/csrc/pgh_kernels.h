@@ -58,36 +58,166 @@ struct GraphView {
     int            num_tiles;
 };
 
+// The epilogue of a step in two halves, so that a kernel can issue the operand loads of several rows before the first
+// dependent use (one row after the other leaves a thread with a chain of exposed memory latencies).
+struct EpiOps {
+    float v, deg, lam, src, r_old;
+    int   slot;           // position of the row in the (trimmed) next gather vector, -1 = not stored
+};
+// element `byte_off / sizeof(T)` of an array: a uniform base plus a 32-bit unsigned byte offset is one scalar register
+// pair and ONE address register, shared by every array that is indexed by the same row (a 64-bit address per load costs
+// two registers each and was what pushed the fused kernels into scratch)
+template <typename T>
+__device__ __forceinline__ T ld_off(const T* base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st_off(T* base, uint32_t byte_off, T value) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = value;
+}
 template <int MODE>
-__device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff, int row, float sum,
-                                                double& sum_y, double& delta) {
+__device__ __forceinline__ EpiOps epi_load(const EpiParams& ep, int row) {
+    EpiOps o;
+    o.v = 0.f, o.deg = 0.f, o.lam = 0.f, o.src = 0.f, o.r_old = 0.f, o.slot = -1;
+    const uint32_t at = (uint32_t)row << 2;
+    if (MODE == EPI_AXPBY || MODE == EPI_POLY) {
+        if (ep.v != nullptr) o.v = ld_off(ep.v, at);
+    } else if (MODE == EPI_ABSORB) {
+        o.v = ld_off(ep.v, at);
+        o.deg = ld_off(ep.deg, at);
+        o.lam = ld_off(ep.lam, at);
+    }
+    if (ep.xg_out != nullptr) {
+        o.slot = xg_slot(row, ep.xg_blk, ep.xg_live);
+        o.src = ld_off(ep.src_scale, at);     // unconditional: a load under a divergent branch serialises the loads around it
+    }
+    if (MODE == EPI_POLY) o.r_old = ld_off(const_cast<const float*>(ep.r), at);
+    return o;
+}
+template <int MODE>
+__device__ __forceinline__ float epi_apply(const EpiParams& ep, const EpiOps& o, float a_eff, int row, float sum,
+                                           double& sum_y, double& delta) {
     float y;
     if (MODE == EPI_PLAIN) {
         y = a_eff * sum;
     } else if (MODE == EPI_AXPBY || MODE == EPI_POLY) {
         y = a_eff * sum;
-        if (ep.v != nullptr) y += (float)ep.b * ep.v[row];
+        if (ep.v != nullptr) y += (float)ep.b * o.v;
     } else {   // EPI_ABSORB: ((M^T x) * deg + p * lam) / (lam + deg), adhoc.py:167-168
-        const float d = ep.deg[row], l = ep.lam[row];
-        y = (a_eff * sum * d + ep.v[row] * l) / (l + d);
+        y = (a_eff * sum * o.deg + o.v * o.lam) / (o.lam + o.deg);
     }
-    ep.y[row] = y;
-    if (ep.xg_out != nullptr) {
-        const int slot = xg_slot(row, ep.xg_blk, ep.xg_live);
-        if (slot >= 0) ep.xg_out[slot] = y * ep.src_scale[row];
-    }
+    const uint32_t at = (uint32_t)row << 2;
+    st_off(ep.y, at, y);
+    if (o.slot >= 0) st_off(ep.xg_out, (uint32_t)o.slot << 2, y * o.src);
     sum_y += (double)y;
     if (MODE == EPI_POLY) {
-        const float r_old = ep.r[row];
-        const float r_new = r_old + (float)ep.c * y;
-        ep.r[row] = r_new;
-        const double d = fabs((double)r_new - (double)r_old);
+        const float r_new = o.r_old + (float)ep.c * y;
+        st_off(ep.r, at, r_new);
+        const double d = fabs((double)r_new - (double)o.r_old);
         delta = ep.err_linf ? fmax(delta, d) : delta + d;
     }
     return y;
 }
+template <int MODE>
+__device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff, int row, float sum,
+                                                double& sum_y, double& delta) {
+    return epi_apply<MODE>(ep, epi_load<MODE>(ep, row), a_eff, row, sum, sum_y, delta);
+}
 
+// Row sum of the blocked SpMV layout: the row's segment of every column block, found through the block's SegMeta
+// word (BsfFormat::psum / meta), added in block order in f64.
+struct RowSums {
+    const SegMeta* meta;
+    const float*   psum;
+    int64_t        words;       // SegMeta words per block
+    int            num_blocks;
+    unsigned int   zero_at;     // a slot of psum that always holds 0 (branch-free lookups of rows without a segment)
+};
+template <int B>
+__device__ __forceinline__ double block_row_sum(const RowSums& rs, int64_t row) {
+    const int64_t w = row >> 6;
+    const unsigned long long bit = 1ULL << (row & 63);
+    // all map words first, then all segment sums: two exposed latencies per row instead of two per block
+    SegMeta m[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+        if (b < rs.num_blocks) m[b] = rs.meta[(int64_t)b * rs.words + w];
+    float v[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        v[b] = 0.f;
+        if (b < rs.num_blocks && (m[b].mask & bit)) v[b] = rs.psum[m[b].base + __popcll(m[b].mask & (bit - 1ULL))];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+        if (b < rs.num_blocks) s += (double)v[b];
+    return s;
+}
+// the same lookup in two steps for kernels that keep several rows in flight
+template <int B>
+struct RowLookup {
+    SegMeta m[B];
+};
+template <int B>
+__device__ __forceinline__ void row_lookup_meta(const RowSums& rs, int64_t row, RowLookup<B>& q) {
+    const int64_t w = row >> 6;
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+        if (b < rs.num_blocks) q.m[b] = rs.meta[(int64_t)b * rs.words + w];
+}
+template <int B>
+__device__ __forceinline__ void row_lookup_vals(const RowSums& rs, int64_t row, const RowLookup<B>& q, float (&v)[B]) {
+    const unsigned long long bit = 1ULL << (row & 63);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        v[b] = 0.f;
+        if (b < rs.num_blocks && (q.m[b].mask & bit)) v[b] = rs.psum[q.m[b].base + __popcll(q.m[b].mask & (bit - 1ULL))];
+    }
+}
 
+// Cross-tile fix-up of the blocked SpMV layout: a row segment that spans tiles is closed by adding the carries of the
+// tiles it crosses in a fixed order (deterministic, atomic-free).  One thread per closing tile; a hub row spans
+// hundreds of tiles, so chains of 32+ tiles are summed by the whole wavefront (strided lanes + fixed reduction tree)
+// instead of leaving one thread with a serial chain of dependent loads.  Runs as its own launch (k_bsf_fixup) or at
+// the start of the cold image's phase A (k_pb_gather), which needs nothing from it.
+struct FixView {
+    const int32_t* fix_seg;    // [num_tiles] segment (index into psum) that receives tile t's fix-up, or -1
+    const int4*    tile;       // .w = first tile of the carry chain that ends in tile t
+    const double*  tail_carry;
+    const double*  head_partial;
+    float*         psum;
+    int            num_tiles;
+};
+// `first`, `stride`: this workgroup's threads take tiles first + threadIdx.x, then += stride (whole wavefronts: the
+// cooperative part uses shuffles, so the trip count is wavefront-uniform)
+__device__ __forceinline__ void bsf_fixup_tiles(const FixView& f, int first_tile, int stride) {
+    const int lane = threadIdx.x & 63;
+    for (int t0 = first_tile; t0 < f.num_tiles; t0 += stride) {
+        const int t = t0 + (int)threadIdx.x;
+        const int dst = t < f.num_tiles ? f.fix_seg[t] : -1;
+        const int first = dst >= 0 ? f.tile[t].w : 0;
+        const int len = dst >= 0 ? t - first : 0;
+        const bool is_long = len >= 32;
+        if (dst >= 0 && !is_long) {
+            double total = 0.0;
+            for (int s = first; s < t; ++s) total += f.tail_carry[s];
+            total += f.head_partial[t];
+            f.psum[dst] = (float)total;
+        }
+        unsigned long long todo = __ballot(is_long);
+        while (todo != 0ULL) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1ULL;
+            const int c_first = __shfl(first, src, 64), c_t = __shfl(t, src, 64);
+            double part_sum = 0.0;
+            for (int s = c_first + lane; s < c_t; s += 64) part_sum += f.tail_carry[s];
+            part_sum = wave_reduce_sum(part_sum);
+            const double total = __shfl(part_sum, 0, 64) + f.head_partial[c_t];
+            if (lane == src) f.psum[dst] = (float)total;
+        }
+    }
+}
 
 // blocked-format entry points (pgh_bsf.hip)
 // pgh_pb.hip: propagation-blocking image of the cold entries
@@ -109,7 +239,9 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
 int pb_select_slice(const PbPlan* plan, int slice, const uint64_t* cold_keys, const float* cold_vals, int64_t count, uint64_t* keys_out,
                     float* vals_out, int64_t* selected);
 void pb_plan_release(PbPlan* plan);
-int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state);
+int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, const FixView& fix);
+template <int MODE>
+int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, const LoopState* state, int* num_partials);
 void pb_destroy(PbFormat& p);
 int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state);
 template <int MODE>

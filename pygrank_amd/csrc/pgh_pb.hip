@@ -16,7 +16,9 @@
 //                             goes to LDS (128 KB, coalesced), then per group of 8 entries: 16 B of 2-byte source indices
 //                             + 4 B target group read, 8 LDS gathers, 32 B written to the group's place in B order.
 //                             Writes land in runs of cells: ~2-3 KB each on the bench graph.
-//   phase B  k_pb_accumulate  one workgroup per bin: the bin's part of the B-order stream is ONE contiguous range: 32 B
+//   phase B  k_pb_finish      one workgroup per bin AND the filter's epilogue for the bin's rows in the same launch (round 1
+//                             ran k_pb_accumulate -> dense cold vector -> k_bsf_combine: a 2 x 4 n byte round trip and a
+//                             launch): the bin's part of the B-order stream is ONE contiguous range: 32 B
 //                             of values + 16 B of 2-byte row indices per group.  The row sums of the bin live in LDS
 //                             as 64-BIT FIXED-POINT numbers and every entry is one integer LDS atomic add (f32 LDS
 //                             atomics run ~12x slower on gfx950: 386 us against 95 us for this kernel).  Integer sums
@@ -56,7 +58,18 @@ constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in 
 #define PGH_PB_ROWS 4096
 #endif
 #ifndef PGH_PB_BTHREADS
-#define PGH_PB_BTHREADS 512
+#define PGH_PB_BTHREADS 256
+#endif
+// k_pb_finish build parameters (tools/build_variants.sh): groups per thread and stream round, rows per thread and epilogue
+// round, whether the next item's first stream round is issued before the current item's epilogue
+#ifndef PGH_FIN_P
+#define PGH_FIN_P 4
+#endif
+#ifndef PGH_FIN_G
+#define PGH_FIN_G 4
+#endif
+#ifndef PGH_FIN_PREFETCH
+#define PGH_FIN_PREFETCH 0
 #endif
 // rows per bin = 64-bit row sums in LDS during phase B (<= 32768: 15-bit keys).  Two shapes: the small one (32 KB, four
 // workgroups per CU) is the faster kernel; the large one (128 KB, one workgroup per CU) keeps the (chunk, bin) runs
@@ -185,9 +198,11 @@ struct PbView {
     const int4*     task;
     const int*      task_range;
     float*          tmp;
-    const int4*     bin;
+    const int4*     item_a;            // work list of k_pb_finish (PbFormat::item_a / item_b)
+    const int4*     item_b;
+    int             num_items;
+    uint32_t*       hub_ticket;
     const uint16_t* drow;
-    float*          out;
     double*         hub_part;          // [num_bins] sums of the pieces of split hub rows
     uint32_t*       amax;              // [0] bit pattern of max |value| written by phase A, [1] phase B's exit tickets
     int64_t         cold_prefix[9];
@@ -201,11 +216,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- phase A
 template <bool HAS_VAL>
-__global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float* __restrict__ xg, const LoopState* __restrict__ state) {
+__global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float* __restrict__ xg, const LoopState* __restrict__ state,
+                                                          FixView fix) {
     __shared__ float s_x[kPbChunk];
     __shared__ uint32_t s_amax;
     if (state != nullptr && state->done) return;
     if (threadIdx.x == 0) s_amax = 0u;
+    // the cross-tile fix-ups of the blocked stream ride along (one launch and one dependent boundary fewer per step):
+    // they touch nothing this kernel reads, and the next kernel (k_pb_finish) is the first to read their results
+    bsf_fixup_tiles(fix, blockIdx.x * kPbThreads, gridDim.x * kPbThreads);
     uint32_t amax = 0u;                 // bit pattern of max |value| this thread wrote (NaN > inf > finite as integers)
     // this workgroup's share of the entry stream: consecutive pieces, each inside one chunk; the LDS image of the chunk
     // is refilled only when the chunk changes
@@ -323,86 +342,262 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
     if (threadIdx.x == 0 && s_amax != 0u) atomicMax(f.amax, s_amax);
 }
 
-// ---- phase B
-// One workgroup per bin; the bin's entries are one contiguous range of whole 8-entry groups in B order.  Pad entries
-// carry row 0xffff.  Row sums: 64-bit fixed point in LDS, integer atomics (see the head of this file).
-template <int ROWS, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_pb_accumulate(PbView f, const LoopState* __restrict__ state) {
-    constexpr int kPbBThreads = THREADS;
+// ---- phase B + epilogue
+// Work items (PbFormat::item_a / item_b) tile the output rows: a regular bin (<= ROWS consecutive rows whose cold sums
+// live in LDS), a stretch of rows without cold entries (epilogue only), or one piece of a hub row.  A persistent grid
+// walks the list with a fixed stride, so the per-workgroup partial sums of sum(y) / delta are deterministic.
+//
+// Regular bin: the bin's entries are one contiguous range of whole 8-entry groups in B order (pad entries carry row
+// 0xffff).  Row sums: 64-bit fixed point in LDS, integer atomics (see the head of this file).  Then, for every row of
+// the bin: row sum = sum over the column blocks of the row's segment in psum (block_row_sum) + the cold sum, times the
+// output scale, and the filter's epilogue (apply_epilogue) -- what k_bsf_combine does for graphs without a cold image.
+//
+// Hub row (more than kPbHeavyRow cold entries): thousands of atomics on one LDS word would serialise, so its values are
+// summed in f64 registers and reduced in a fixed order.  A row split into pieces: every piece publishes its sum with a
+// device-scope atomic and takes a ticket; the last arriver adds the pieces in index order (deterministic whatever the
+// arrival order) and runs the row's epilogue.
+template <int MODE, int NB, int ROWS, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void k_pb_finish(PbView f, RowSums rs, const float* __restrict__ dst_scale, EpiParams ep,
+                                                        const LoopState* __restrict__ state, double* __restrict__ partial_sum,
+                                                        double* __restrict__ partial_delta) {
+    constexpr int WAVES = THREADS / 64;
+    constexpr int WORDS = ROWS / 64 + 1;                   // map words an item can touch per block (unaligned first row)
+    // groups per thread and stream round in flight (three 16-byte loads each), rows per thread and epilogue round.  Both
+    // shapes keep 16 wavefronts per CU (128 registers): 4 workgroups of 256 threads (32 KB of row sums each) or one of
+    // 1024; what covers the latencies an item exposes (stream, atomics, epilogue rounds) is the depth of each round plus
+    // the other workgroups of the CU.
+    constexpr int P = THREADS > 512 ? 2 : PGH_FIN_P;
+    constexpr int G = (THREADS > 512 || NB > 4) ? 2 : PGH_FIN_G;
     __shared__ unsigned long long s_row[ROWS];
-    if (state != nullptr && state->done) return;
-    const int4 bin = f.bin[blockIdx.x];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
-    const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0x1f;
-    // a hub bin is ONE row with more than kPbHeavyRow cold entries: thousands of atomics on one LDS word would serialise,
-    // so its values are summed in f64 registers and reduced in a fixed order (no fixed point needed, deterministic)
-    const bool hub = ((bin.y >> 21) & 1) != 0;
-    const bool piece = ((unsigned)bin.y >> 22) != 0u;     // one of several bins of a split row: k_pb_hub_fold adds them up
-    double hub_sum = 0.0;
+    __shared__ unsigned long long s_mask[NB * WORDS];      // the item's slice of the row -> segment map (BsfFormat::meta)
+    __shared__ int s_base[NB * WORDS];
+    __shared__ double s_red[WAVES];
+    __shared__ float s_hub;
+    __shared__ int s_last;
+    double scale = 1.0;
+    if (state != nullptr) {
+        if (state->done) return;
+        scale = state->scale;
+    }
+    const float a_eff = (float)(ep.a * scale);
     const int tid = threadIdx.x;
     const uint32_t amax = __builtin_nontemporal_load(f.amax);
     const bool finite = amax < 0x7f800000u;                // inf / NaN among the values: the sums are not representable
     // |value| <= amax < 2^e; an entry gets E = min(51, 62 - count_bits) bits: |value * S| < 2^E with S = 2^(E - e), and a
     // row of <= 2^count_bits entries stays below 2^62
     const int e = (int)(amax >> 23) - 126;                 // amax < 2^e (denormals: e = -126, still an upper bound)
-    const int E = min(51, 62 - count_bits);
-    const double S = __longlong_as_double((long long)(1023 + E - e) << 52);
-    const double inv_S = __longlong_as_double((long long)(1023 - E + e) << 52);
     constexpr double kMagic = 6755399441055744.0;          // 1.5 * 2^52: fma(v, S, magic) holds round(v * S) in its low bits
-    for (int i = tid; i < rows; i += kPbBThreads) s_row[i] = 0ULL;
-    __syncthreads();
-    const int groups = finite || hub ? bin.w : 0;
-    const float* __restrict__ tmp = f.tmp + (int64_t)bin.z * 8;
-    const uint16_t* __restrict__ drow = f.drow + (int64_t)bin.z * 8;
-    constexpr int P = 4;                                    // groups per thread in flight: twelve 16-byte loads
-    for (int g0 = tid; g0 < groups; g0 += kPbBThreads * P) {
+    double sum_y = 0.0, delta = 0.0;
+
+    struct Round {
         u16x8 r8[P];
         f32x4 lo[P], hi[P];
+    };
+    // groups tid + (round * P + q) * THREADS of the bin `bin` (pad rows 0xffff beyond the bin's range)
+    auto fetch = [&](const int4& bin, int round, Round& R) __attribute__((always_inline)) {
+        const bool hub = ((bin.y >> 21) & 1) != 0;
+        const int groups = finite || hub ? bin.w : 0;
+        const float* __restrict__ tmp = f.tmp + (int64_t)bin.z * 8;
+        const uint16_t* __restrict__ drow = f.drow + (int64_t)bin.z * 8;
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            const int g = g0 + q * kPbBThreads;
+            const int g = tid + (round * P + q) * THREADS;
             const bool ok = g < groups && !(PGH_PROBE_PB & 8);
-            r8[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + (int64_t)g * 8))
-                       : u16x8{0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff};
-            lo[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + (int64_t)g * 8)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            hi[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + (int64_t)g * 8 + 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.r8[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + (int64_t)g * 8))
+                         : u16x8{0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff};
+            R.lo[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + (int64_t)g * 8)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.hi[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + (int64_t)g * 8 + 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (PGH_PROBE_PB & 16) {
-            float z = 0.f;
+    };
+
+    int item = blockIdx.x;
+    int4 bin = make_int4(0, 0, 0, 0), epi = make_int4(0, 0, -1, 0);
+    Round R;
+    if (item < f.num_items) {
+        bin = f.item_a[item];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
+        epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1, first item of the split row}
+        fetch(bin, 0, R);
+    }
+    while (item < f.num_items) {
+        const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0x1f;
+        const bool hub = ((bin.y >> 21) & 1) != 0;
+        const int pieces = (int)((unsigned)bin.y >> 22) + 1;
+        const int E = min(51, 62 - count_bits);
+        const double S = __longlong_as_double((long long)(1023 + E - e) << 52);
+        const double inv_S = __longlong_as_double((long long)(1023 - E + e) << 52);
+        // ---- the item's slice of the row -> segment map: issued now, parked in LDS after the stream (below)
+        const int64_t word0 = (int64_t)epi.x >> 6;
+        const int words = hub ? 0 : (int)((((int64_t)epi.x + epi.y - 1) >> 6) - word0 + 1);
+        constexpr int MPT = (NB * WORDS + THREADS - 1) / THREADS;
+        SegMeta mreg[MPT];
 #pragma unroll
-            for (int q = 0; q < P; ++q) z += lo[q].x + hi[q].w + (float)r8[q][3];
-            if (z == 123.456f) s_row[0] = 1ULL;
-            continue;
+        for (int u = 0; u < MPT; ++u) {
+            const int j = tid + u * THREADS;
+            const int b = j / WORDS, w = j - b * WORDS;
+            mreg[u].mask = 0ULL;
+            mreg[u].base = 0;
+            if (b < rs.num_blocks && w < words) mreg[u] = rs.meta[(int64_t)b * rs.words + word0 + w];
+        }
+        double hub_sum = 0.0;
+        if (!hub)
+            for (int i = tid; i < rows; i += THREADS) s_row[i] = 0ULL;
+        __syncthreads();
+        const int groups = finite || hub ? bin.w : 0;
+        const int nrounds = (groups + THREADS * P - 1) / (THREADS * P);
+        for (int round = 0; round < nrounds; ++round) {
+            if (PGH_PROBE_PB & 16) {
+                float z = 0.f;
+#pragma unroll
+                for (int q = 0; q < P; ++q) z += R.lo[q].x + R.hi[q].w + (float)R.r8[q][3];
+                if (z == 123.456f) s_row[0] = 1ULL;
+            } else {
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = (int)R.r8[q][k];
+                        const float v = k < 4 ? R.lo[q][k] : R.hi[q][k - 4];
+                        const long long fixed = __double_as_longlong(__builtin_fma((double)v, S, kMagic)) - __double_as_longlong(kMagic);
+                        if (hub) {
+                            if (r == 0) hub_sum += (double)v;
+                        } else if (r < rows) {
+                            atomicAdd(&s_row[r], (unsigned long long)fixed);
+                        }
+                    }
+                }
+            }
+            if (round + 1 < nrounds) fetch(bin, round + 1, R);
+        }
+        // ---- the next item's first stream round goes out before this item's epilogue
+        const int next = item + gridDim.x;
+        int4 next_bin = make_int4(0, 0, 0, 0), next_epi = make_int4(0, 0, -1, 0);
+        if (next < f.num_items) {
+            next_bin = f.item_a[next];
+            next_epi = f.item_b[next];
+            if (PGH_FIN_PREFETCH) fetch(next_bin, 0, R);
         }
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
+        for (int u = 0; u < MPT; ++u) {
+            const int j = tid + u * THREADS;
+            if (j < NB * WORDS) {
+                s_mask[j] = mreg[u].mask;
+                s_base[j] = mreg[u].base;
+            }
+        }
+        if (hub) {
+            // one row: fixed-order reduction of the threads' f64 sums; of a split row only the last arriver continues
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = (int)r8[q][k];
-                const float v = k < 4 ? lo[q][k] : hi[q][k - 4];
-                const long long fixed = __double_as_longlong(__builtin_fma((double)v, S, kMagic)) - __double_as_longlong(kMagic);
-                if (hub) {
-                    if (r == 0) hub_sum += (double)v;
-                } else if (r < rows) {
-                    atomicAdd(&s_row[r], (unsigned long long)fixed);
+            for (int d = 32; d >= 1; d >>= 1) hub_sum += __shfl_xor(hub_sum, d, 64);
+            if ((tid & 63) == 0) s_red[tid >> 6] = hub_sum;
+            __syncthreads();
+            if (tid == 0) {
+                double total = 0.0;
+                for (int w = 0; w < WAVES; ++w) total += s_red[w];
+                int last = 1;
+                if (pieces > 1) {
+                    // publish the piece (device-scope exchange: performed at the memory side), then take a ticket
+                    unsigned long long* slot = reinterpret_cast<unsigned long long*>(f.hub_part) + item;
+                    (void)atomicExch(slot, (unsigned long long)__double_as_longlong(total));
+                    __threadfence();
+                    last = atomicAdd(f.hub_ticket + epi.z, 1u) == (unsigned)(pieces - 1) ? 1 : 0;
+                }
+                s_hub = (float)total;
+                s_last = last;
+            }
+            __syncthreads();
+            if (pieces > 1 && s_last) {
+                // the pieces of the row are the items epi.w .. epi.w + pieces - 1: read them coherently (atomic add of 0),
+                // add them in index order
+                __threadfence();
+                unsigned long long* part = reinterpret_cast<unsigned long long*>(f.hub_part) + epi.w;
+                double* s_piece = reinterpret_cast<double*>(s_row);
+                for (int k = tid; k < pieces; k += THREADS) s_piece[k] = __longlong_as_double((long long)atomicAdd(part + k, 0ULL));
+                __syncthreads();
+                if (tid == 0) {
+                    double total = 0.0;
+                    for (int k = 0; k < pieces; ++k) total += s_piece[k];
+                    s_hub = (float)total;
+                    (void)atomicExch(f.hub_ticket + epi.z, 0u);       // re-arm for the next launch
+                }
+                __syncthreads();
+            }
+            if (s_last && tid == 0) {                      // the row's epilogue (one row: the direct lookup)
+                const int64_t row = epi.x;
+                double sum = block_row_sum<NB>(rs, row) + (double)s_hub;
+                if (dst_scale != nullptr) sum *= (double)dst_scale[row];
+                apply_epilogue<MODE>(ep, a_eff, (int)row, (float)sum, sum_y, delta);
+            }
+        } else {
+            __syncthreads();
+            // G rows per thread in flight: the operand loads and segment-sum gathers of the G rows are all issued before
+            // the first dependent use; the map words come from LDS.  Branch-free: rows past the range repeat its last
+            // row, rows without a segment in a block read slot 0, and the results are discarded afterwards (a load
+            // under a divergent branch gets its own wait and serialises everything around it).
+            const int last_i = epi.y - 1;
+            const char* __restrict__ psum_b = reinterpret_cast<const char*>(rs.psum);
+            for (int base = 0; base < epi.y; base += THREADS * G) {
+                EpiOps ops[G];
+                float dsc[G];
+                float vals[G][NB];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int i = min(base + tid + u * THREADS, last_i);
+                    const int row = epi.x + i;
+                    const int w = (int)(((int64_t)row >> 6) - word0);
+                    const unsigned long long bit = 1ULL << (row & 63);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const unsigned long long mask = s_mask[b * WORDS + w];
+                        const unsigned int at = (unsigned int)(s_base[b * WORDS + w] + __popcll(mask & (bit - 1ULL)));
+                        // 32-bit byte offsets from a uniform base: one address register per load
+                        vals[u][b] = *reinterpret_cast<const float*>(psum_b + (((mask & bit) != 0ULL ? at : rs.zero_at) << 2));
+                    }
+                    ops[u] = epi_load<MODE>(ep, row);
+                    dsc[u] = dst_scale != nullptr ? ld_off(dst_scale, (uint32_t)row << 2) : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int i = base + tid + u * THREADS;
+                    if (i > last_i) continue;
+                    const int row = epi.x + i;
+                    float cold = 0.f;
+                    if (i < rows) cold = finite ? (float)((double)(long long)s_row[i] * inv_S) : __uint_as_float(0x7fc00000u);
+                    double sum = 0.0;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) sum += (double)vals[u][b];      // blocks past num_blocks read the zero slot
+                    sum += (double)cold;
+                    if (dst_scale != nullptr) sum *= (double)dsc[u];
+                    epi_apply<MODE>(ep, ops[u], a_eff, row, (float)sum, sum_y, delta);
                 }
             }
         }
+        __syncthreads();                                   // s_row / s_mask / s_hub are reused by the next item
+        if (!PGH_FIN_PREFETCH && next < f.num_items) fetch(next_bin, 0, R);
+        item = next;
+        bin = next_bin;
+        epi = next_epi;
     }
-    if (hub) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) hub_sum += __shfl_xor(hub_sum, d, 64);
-        if ((tid & 63) == 0) s_row[tid >> 6] = (unsigned long long)__double_as_longlong(hub_sum);
+    // ---- this workgroup's partials of sum(y) (and delta): wavefront shuffle, then a fixed-order sum over the wavefronts
+    {
+        double v = wave_reduce_sum(sum_y);
+        if ((tid & 63) == 0) s_red[tid >> 6] = v;
         __syncthreads();
         if (tid == 0) {
             double total = 0.0;
-            for (int w = 0; w < kPbBThreads / 64; ++w) total += __longlong_as_double((long long)s_row[w]);
-            if (piece) f.hub_part[blockIdx.x] = total;
-            else f.out[bin.x] = (float)total;
+            for (int w = 0; w < WAVES; ++w) total += s_red[w];
+            partial_sum[blockIdx.x] = total;
         }
-    } else {
-        __syncthreads();
-        for (int i = tid; i < rows; i += kPbBThreads)
-            f.out[bin.x + i] = finite ? (float)((double)(long long)s_row[i] * inv_S) : __uint_as_float(0x7fc00000u);
+        if (MODE == EPI_POLY) {
+            __syncthreads();
+            v = ep.err_linf ? wave_reduce_max(delta) : wave_reduce_sum(delta);
+            if ((tid & 63) == 0) s_red[tid >> 6] = v;
+            __syncthreads();
+            if (tid == 0) {
+                double total = 0.0;
+                for (int w = 0; w < WAVES; ++w) total = ep.err_linf ? fmax(total, s_red[w]) : total + s_red[w];
+                partial_delta[blockIdx.x] = total;
+            }
+        }
     }
     // the last workgroup to leave re-arms the words for the next launch (every workgroup has read amax long before its
     // ticket; the next phase A starts after this kernel)
@@ -410,18 +605,6 @@ __global__ __launch_bounds__(THREADS) void k_pb_accumulate(PbView f, const LoopS
         f.amax[0] = 0u;
         f.amax[1] = 0u;
     }
-}
-
-// split hub rows: pieces (consecutive bins) -> the row's cold sum, fixed order
-__global__ void k_pb_hub_fold(const int4* __restrict__ split /* {row, first bin, pieces, -} */, int count, const double* __restrict__ hub_part,
-                              float* __restrict__ out, const LoopState* __restrict__ state) {
-    if (state != nullptr && state->done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const int4 sr = split[i];
-    double total = 0.0;
-    for (int k = 0; k < sr.z; ++k) total += hub_part[sr.y + k];
-    out[sr.x] = (float)total;
 }
 
 PbView pb_view(const BsfFormat& f, const PbFormat& p) {
@@ -432,9 +615,11 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.task = p.task;
     v.task_range = p.task_range;
     v.tmp = p.tmp;
-    v.bin = p.bin;
+    v.item_a = p.item_a;
+    v.item_b = p.item_b;
+    v.num_items = p.num_items;
+    v.hub_ticket = p.hub_ticket;
     v.drow = p.drow;
-    v.out = p.out;
     v.amax = p.amax;
     v.hub_part = p.hub_part;
     for (int i = 0; i < 9; ++i) v.cold_prefix[i] = p.cold_prefix[i];
@@ -562,7 +747,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         const char* sl = getenv("PGH_PB_SLICES");
         int want = sl != nullptr ? atoi(sl) : 1;            // measured: 4 / 8 slices lose more to launches and partial rounds than
                                                             // the cached hand-over wins (pb_experiment_scale23.log)
-        want = std::max(1, std::min(want, kPbMaxSlices));
+        want = 1;                              // k_pb_finish walks ONE work list that tiles all output rows
         if (!split.empty()) want = 1;          // the pieces of a row must not straddle slices
         plan->slices = want;
         plan->host_bins = new int4[bins.size()];
@@ -736,24 +921,63 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     if (!tasks.empty()) PGH_HIP(hipMemcpyAsync(p.task, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMemcpyAsync(p.task_range, ranges.data(), sizeof(int) * (shares + 1), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMalloc(&p.tmp, sizeof(float) * (size_t)(padded + 8)));
-    if (plan->num_split > 0) {
-        p.num_split = plan->num_split;
-        PGH_HIP(hipMalloc(&p.split, sizeof(int4) * (size_t)p.num_split));
-        PGH_HIP(hipMemcpyAsync(p.split, plan->host_split, sizeof(int4) * (size_t)p.num_split, hipMemcpyHostToDevice, r.stream));
-        PGH_HIP(hipMalloc(&p.hub_part, sizeof(double) * (size_t)p.num_bins));
-        PGH_HIP(hipMemsetAsync(p.hub_part, 0, sizeof(double) * (size_t)p.num_bins, r.stream));
-    }
     PGH_HIP(hipMalloc(&p.amax, sizeof(uint32_t) * 2));
     PGH_HIP(hipMemsetAsync(p.amax, 0, sizeof(uint32_t) * 2, r.stream));
-    if (slice == 0) {
-        PGH_HIP(hipMalloc(&p.out, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1)));
-        PGH_HIP(hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1), r.stream));
-    } else {
-        p.out = f.pb.out;                                  // disjoint rows of the same vector
-        p.owns_out = false;
+    // ---- work list of k_pb_finish: the bins in row order (`mine` is sorted by first row; the pieces of a split hub row are
+    // consecutive), the row stretches between them cut into epilogue-only items, hub items first (they are the longest).
+    {
+        std::vector<int4> hub_a, hub_b, reg_a, reg_b;
+        const int stretch = p.bin_rows;                    // rows per epilogue-only item
+        auto cover = [&](int64_t lo, int64_t hi) {         // rows [lo, hi) have no cold entries in the image
+            for (int64_t at = lo; at < hi; at += stretch) {
+                reg_a.push_back(make_int4((int)at, 0, 0, 0));
+                reg_b.push_back(make_int4((int)at, (int)std::min<int64_t>(stretch, hi - at), -1, 0));
+            }
+        };
+        int64_t cursor = 0;
+        int split_at = 0;
+        for (int w = 0; w < p.num_bins;) {
+            const int4 b = mine[w];
+            const int row0 = b.x, rows = b.y & 0xffff;
+            const bool hub = ((b.y >> 21) & 1) != 0;
+            const int pieces = (int)((unsigned)b.y >> 22) + 1;
+            if (row0 > cursor) cover(cursor, row0);
+            if (hub) {
+                const int first_item = (int)hub_a.size();
+                for (int k = 0; k < pieces; ++k) {
+                    hub_a.push_back(mine[w + k]);
+                    hub_b.push_back(make_int4(row0, 1, pieces > 1 ? split_at : -1, first_item));
+                }
+                if (pieces > 1) ++split_at;
+                w += pieces;
+                cursor = (int64_t)row0 + 1;
+            } else {
+                reg_a.push_back(b);
+                reg_b.push_back(make_int4(row0, rows, -1, 0));
+                ++w;
+                cursor = (int64_t)row0 + rows;
+            }
+        }
+        if (cursor < f.n_out) cover(cursor, f.n_out);
+        PGH_CHECK(split_at == plan->num_split, "propagation blocking: split rows of the work list do not match the plan");
+        p.num_split = split_at;
+        p.num_items = (int)(hub_a.size() + reg_a.size());
+        std::vector<int4> all_a(hub_a), all_b(hub_b);
+        all_a.insert(all_a.end(), reg_a.begin(), reg_a.end());
+        all_b.insert(all_b.end(), reg_b.begin(), reg_b.end());
+        PGH_HIP(hipMalloc(&p.item_a, sizeof(int4) * (size_t)(p.num_items + 1)));
+        PGH_HIP(hipMalloc(&p.item_b, sizeof(int4) * (size_t)(p.num_items + 1)));
+        PGH_HIP(hipMemcpyAsync(p.item_a, all_a.data(), sizeof(int4) * all_a.size(), hipMemcpyHostToDevice, r.stream));
+        PGH_HIP(hipMemcpyAsync(p.item_b, all_b.data(), sizeof(int4) * all_b.size(), hipMemcpyHostToDevice, r.stream));
+        if (p.num_split > 0) {                             // piece sums are indexed by (hub) item, tickets by split row
+            PGH_HIP(hipMalloc(&p.hub_part, sizeof(double) * hub_a.size()));
+            PGH_HIP(hipMemsetAsync(p.hub_part, 0, sizeof(double) * hub_a.size(), r.stream));
+            PGH_HIP(hipMalloc(&p.hub_ticket, sizeof(uint32_t) * (size_t)p.num_split));
+            PGH_HIP(hipMemsetAsync(p.hub_ticket, 0, sizeof(uint32_t) * (size_t)p.num_split, r.stream));
+        }
+        PGH_HIP(hipStreamSynchronize(r.stream));           // the host vectors go out of scope
     }
-    PGH_HIP(hipStreamSynchronize(r.stream));
-    p.device_bytes = padded * (4 + 2 + 2 + (cold_vals ? 4 : 0)) + padded / 2 + (int64_t)f.n_out * 4;
+    p.device_bytes = padded * (4 + 2 + 2 + (cold_vals ? 4 : 0)) + padded / 2 + (int64_t)p.num_items * 32;
     p.enabled = true;
     return 0;
 }
@@ -801,32 +1025,55 @@ int pb_select_slice(const PbPlan* plan, int slice, const uint64_t* cold_keys, co
     return 0;
 }
 
-int pb_launch(pgh_graph_s* g, const float* xg, const LoopState* state) {
+// phase A of the cold image (after the block partial sums of the same step; independent of them)
+int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, const FixView& fix) {
     const BsfFormat& f = g->bsf;
     if (!f.pb.enabled) return 0;
     Runtime& r = rt();
-    for (int slice = 0; slice < f.pb_slices; ++slice) {
-    const PbFormat& p = slice == 0 ? f.pb : f.pb_more[slice - 1];
+    const PbFormat& p = f.pb;
     const PbView v = pb_view(f, p);
     {
         ProfScope prof(PGH_K_PB_GATHER);
         if (p.num_tasks > 0) {
-            if (p.val) k_pb_gather<true><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state);
-            else k_pb_gather<false><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state);
+            if (p.val) k_pb_gather<true><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
+            else k_pb_gather<false><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
         }
-    }
-    {
-        ProfScope prof(PGH_K_PB_ACCUM);
-        if (p.num_bins > 0) {
-            if (p.bin_rows > kPbBinRows) k_pb_accumulate<kPbBinRowsLarge, kPbBThreadsLarge><<<p.num_bins, kPbBThreadsLarge, 0, r.stream>>>(v, state);
-            else k_pb_accumulate<kPbBinRows, kPbBThreads><<<p.num_bins, kPbBThreads, 0, r.stream>>>(v, state);
-            if (p.num_split > 0) k_pb_hub_fold<<<(p.num_split + 63) / 64, 64, 0, r.stream>>>(p.split, p.num_split, p.hub_part, p.out, state);
-        }
-    }
     }
     PGH_HIP(hipGetLastError());
     return 0;
 }
+
+// phase B + the MODE epilogue for every output row; block partials of sum(y) / delta land in rt().d_partials
+template <int MODE>
+int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, const LoopState* state, int* num_partials) {
+    const BsfFormat& f = g->bsf;
+    const PbFormat& p = f.pb;
+    Runtime& r = rt();
+    const PbView v = pb_view(f, p);
+    double* psum = r.d_partials;
+    double* pdel = r.d_partials + kMaxPartials;
+    const bool large = p.bin_rows > kPbBinRows;
+    // persistent grid: as many workgroups as the CUs hold at once (LDS: 32 KB x 4 or 128 KB x 1 per CU)
+    int grid = r.num_cus * (large ? 1 : (kPbBThreads > 256 ? 2 : 4));
+    if (grid > p.num_items) grid = p.num_items;
+    if (grid > kMaxPartials) grid = kMaxPartials;
+    if (grid < 1) grid = 1;
+    {
+        ProfScope prof(PGH_K_PB_ACCUM);
+        const bool wide = f.num_blocks > 4;               // 8 column blocks: 8-way row partitions
+        if (large && wide) k_pb_finish<MODE, 8, kPbBinRowsLarge, kPbBThreadsLarge><<<grid, kPbBThreadsLarge, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel);
+        else if (large) k_pb_finish<MODE, 4, kPbBinRowsLarge, kPbBThreadsLarge><<<grid, kPbBThreadsLarge, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel);
+        else if (wide) k_pb_finish<MODE, 8, kPbBinRows, kPbBThreads><<<grid, kPbBThreads, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel);
+        else k_pb_finish<MODE, 4, kPbBinRows, kPbBThreads><<<grid, kPbBThreads, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel);
+    }
+    PGH_HIP(hipGetLastError());
+    if (num_partials) *num_partials = grid;
+    return 0;
+}
+template int pb_launch_finish<EPI_PLAIN>(pgh_graph_s*, const RowSums&, const EpiParams&, const LoopState*, int*);
+template int pb_launch_finish<EPI_AXPBY>(pgh_graph_s*, const RowSums&, const EpiParams&, const LoopState*, int*);
+template int pb_launch_finish<EPI_ABSORB>(pgh_graph_s*, const RowSums&, const EpiParams&, const LoopState*, int*);
+template int pb_launch_finish<EPI_POLY>(pgh_graph_s*, const RowSums&, const EpiParams&, const LoopState*, int*);
 
 void pb_destroy(PbFormat& p) {
     (void)hipFree(p.sloc);
@@ -838,9 +1085,11 @@ void pb_destroy(PbFormat& p) {
     (void)hipFree(p.amax);
     (void)hipFree(p.split);
     (void)hipFree(p.hub_part);
+    (void)hipFree(p.hub_ticket);
+    (void)hipFree(p.item_a);
+    (void)hipFree(p.item_b);
     (void)hipFree(p.bin);
     (void)hipFree(p.drow);
-    if (p.owns_out) (void)hipFree(p.out);
     p = PbFormat();
 }
 
