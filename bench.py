@@ -12,14 +12,23 @@ BASELINE.json configs[4] graph (scale 27, edge factor 8, ~1.07 B edges) at N = 8
 
 A "step" is one full PPR run (personalization resident in HBM -> converged ranks in HBM).  The timed region
 covers exactly K steps; value = nnz * (SpMV launches of all steps) / time  [edges*iterations/s, reported in
-GTEPS].  Extra objects on the JSON line: "roofline" (HIP-event time of the SpMV kernel vs the 8*nnz + 16*n
-algorithmic bytes of one PPR step) and "cpu_baseline" (the oracle's scipy loop -- exactly the reference's
-numpy-backend arithmetic -- on the same graph, one core), plus the in-run parity of GPU vs CPU ranks.
+GTEPS].  Extra objects on the JSON line: "roofline" (HIP-event time of EVERY launch of one PPR iteration -- block
+partial sums, the cold image's phase A, phase B + epilogue, residual, close -- vs the 8*nnz + 16*n algorithmic
+bytes of one iteration) and "cpu_baseline" (the oracle's scipy loop -- exactly the reference's numpy-backend
+arithmetic -- on the same graph, one core; the all-core OpenMP pull kernel beside it), plus the in-run parity of
+GPU vs CPU ranks.
+
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself: the parent (which never
+touches the GPU) runs `python -m torch.distributed.run --nproc-per-node N <this script> ...` as a child process, relays
+rank 0's JSON line and exits with the child's status.
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,7 +43,18 @@ ALPHA, TOL, MAX_ITERS, SEEDS = 0.85, 1e-6, 1000, 100
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 # HBM traffic of the step kernels: rocprofv3 --pmc passes of this same command (tools/gpu_bench_call.sh), summarised by
 # tools/summarize_pmc.py with the guide's gfx950 corrections; counters cannot be read from inside the timed process
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_n1_final_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "bench_n1_pmc.json")
+# the launches of one PPR iteration, in stream order (HIP-event ids of include/pgh.h)
+STEP_KERNELS = ("spmv", "fixup", "pb_gather", "pb_finish", "combine", "residual", "close")
+
+
+def csrc_sha16():
+    """Hash of the kernel sources: ties the committed PMC summary to the code that produced it."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "pygrank_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pygrank_amd", "csrc", "*.h"))):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def seeds_for(step, candidates, count=SEEDS):
@@ -43,18 +63,73 @@ def seeds_for(step, candidates, count=SEEDS):
 
 
 def measured_traffic(scale, ef, blocked):
-    """Per-launch HBM bytes (read + written) of the fused step's kernels from the committed PMC summary, or None when
-    the summary does not describe this workload."""
+    """Per-iteration HBM bytes (read + written) of the PPR iteration's kernels from the committed PMC summary of this same
+    command (counters cannot be read from inside the timed process), or None when the summary does not describe this
+    workload or was collected with different kernel sources (it carries the hash of pygrank_amd/csrc it was made from)."""
     if not blocked or (scale, ef) != (23, 16) or not os.path.exists(PMC_SUMMARY):
         return None, None
     with open(PMC_SUMMARY) as f:
         pmc = json.load(f)
+    if pmc.get("_meta", {}).get("csrc_sha16") != csrc_sha16():
+        return None, "stale: " + os.path.relpath(PMC_SUMMARY, ROOT) + " was collected from other kernel sources"
     total = 0.0
     for name, row in pmc.items():
-        # the PPR step's launches: the AXPBY combine is MODE 1 (the PMC run also holds the secondary filters' <2,.> / <3,.>)
-        if name.startswith(("k_bsf_partial", "k_bsf_fixup", "k_bsf_combine<1,", "k_pb_gather", "k_pb_accumulate", "k_pb_hub_fold")):
+        # the PPR iteration's launches: the AXPBY epilogue is MODE 1 (the PMC run also holds the secondary filters' <2,.> / <3,.>)
+        if name.startswith(("k_bsf_partial", "k_bsf_fixup", "k_bsf_combine<1,", "k_pb_gather", "k_pb_finish<1,", "k_step_residual", "k_step_close")):
             total += row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
     return (int(total), os.path.relpath(PMC_SUMMARY, ROOT)) if total > 0 else (None, None)
+
+
+def stream_ceiling_gbs(lib, L):
+    """What a plain streaming copy reaches on this box right now (read + written bytes per second, engine's pgh_vec_copy on
+    256 MB vectors): the practical HBM ceiling beside the 8 TB/s datasheet peak."""
+    m = 1 << 26
+    va, vb = L.c_vec(), L.c_vec()
+    L.check(lib.pgh_vec_alloc(m, C.byref(va)))
+    L.check(lib.pgh_vec_alloc(m, C.byref(vb)))
+    L.check(lib.pgh_vec_fill(va, 1.0))
+    t = L.c_timer()
+    L.check(lib.pgh_timer_create(C.byref(t)))
+    best = 0.0
+    for _ in range(3):
+        L.check(lib.pgh_vec_copy(vb, va))
+    for _ in range(3):
+        L.check(lib.pgh_timer_start(t))
+        for _ in range(4):
+            L.check(lib.pgh_vec_copy(vb, va))
+        L.check(lib.pgh_timer_stop(t))
+        ms = C.c_double()
+        L.check(lib.pgh_timer_elapsed_ms(t, C.byref(ms)))
+        best = max(best, 4 * 2 * 4.0 * m / (ms.value * 1e-3) / 1e9)
+    L.check(lib.pgh_timer_destroy(t))
+    L.check(lib.pgh_vec_free(va))
+    L.check(lib.pgh_vec_free(vb))
+    return round(best, 1)
+
+
+def allcore_cpu_gteps(MT, nnz, repeats=3):
+    """The oracle's OpenMP pull kernel over CSR(M^T) (oracle/spmv_oracle.c) on every host core: the "best-effort CPU" line
+    of SURVEY.md 8d beside the reference's single-threaded scipy path."""
+    import numpy as np
+    so = os.path.join(ROOT, "oracle", "_build", "liboracle_spmv.so")
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    n = MT.shape[0]
+    indptr = np.ascontiguousarray(MT.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(MT.indices, dtype=np.int32)
+    data = np.ascontiguousarray(MT.data, dtype=np.float64)
+    x = np.full(MT.shape[1], 1.0 / max(MT.shape[1], 1))
+    y = np.empty(n)
+    args = (C.c_int64(n), indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p),
+            x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+    lib.oracle_pull_spmv_omp(*args)
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        lib.oracle_pull_spmv_omp(*args)
+    dt = (time.perf_counter() - t0) / repeats
+    return dict(value=round(nnz / dt / 1e9, 3), unit="GTEPS", cores=os.cpu_count(), kind="port",
+                sample=f"{repeats} SpMV of the same graph, OpenMP pull kernel over CSR(M^T), fp64")
 
 
 def single_gpu(args):
@@ -104,47 +179,65 @@ def single_gpu(args):
     run(total - 1)
     L.check(lib.pgh_profile_enable(0))
     prof = {}
-    for kid, name in ((L.K_SPMV, "spmv"), (L.K_PB_GATHER, "pb_gather"), (L.K_PB_ACCUM, "pb_accumulate"), (L.K_FIXUP, "fixup"),
+    for kid, name in ((L.K_SPMV, "spmv"), (L.K_FIXUP, "fixup"), (L.K_PB_GATHER, "pb_gather"), (L.K_PB_ACCUM, "pb_finish"),
                       (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual"), (L.K_FINAL, "close")):
         cnt, ms = C.c_int64(), C.c_double()
         L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
         prof[name] = dict(launches=cnt.value, avg_us=(ms.value / cnt.value * 1e3) if cnt.value else None)
-    alg_bytes = 8 * nnz + 16 * n                     # fused PPR step, per launch
-    # the fused PPR step (SpMV + axpby epilogue + sum(y)) is one launch on the row-major layout; on the blocked layout it
-    # is block partials, the cold image's two phases (when the graph has one), cross-tile fix-up, combine + epilogue:
-    # its duration is their sum
-    step_kernels = [k for k in ("spmv", "pb_gather", "pb_accumulate", "fixup", "combine") if prof[k]["avg_us"]]
+    alg_bytes = 8 * nnz + 16 * n                     # PPR step + quotient + residual, per iteration
+    # One PPR iteration = every launch between two iterates: block partial sums, (cross-tile fix-up,) the cold image's
+    # phase A, phase B + epilogue (or the combine of graphs without a cold image), residual, close.  Its duration is the sum
+    # of their HIP-event times.
+    step_kernels = [k for k in STEP_KERNELS if prof[k]["avg_us"]]
     step_us = sum(prof[k]["avg_us"] for k in step_kernels)
     achieved = alg_bytes / (step_us * 1e-6) / 1e9
-    blocked = prof["combine"]["avg_us"] is not None
+    blocked = g.format().startswith("bsf")
     traffic, traffic_source = measured_traffic(scale, ef, blocked)
-    roofline = dict(bound="hbm",
-                    kernel=(("k_bsf_partial + k_pb_gather + k_pb_accumulate + k_bsf_fixup + k_bsf_combine<AXPBY>" if prof["pb_gather"]["avg_us"]
-                             else "k_bsf_partial + k_bsf_fixup + k_bsf_combine<AXPBY>") if blocked else "k_spmv_merge<AXPBY> + k_spmv_fixup")
-                    + " (one fused PPR step)",
+    ceiling = stream_ceiling_gbs(lib, L)
+    names = dict(spmv="k_bsf_partial" if blocked else "k_spmv_merge<AXPBY>", fixup="k_bsf_fixup" if blocked else "k_spmv_fixup",
+                 pb_gather="k_pb_gather", pb_finish="k_pb_finish<AXPBY>", combine="k_bsf_combine<AXPBY>", residual="k_step_residual",
+                 close="k_step_close")
+    roofline = dict(bound="hbm", kernel=" + ".join(names[k] for k in step_kernels) + " (one PPR iteration: step + quotient + residual)",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=alg_bytes,
-                    avg_launch_us=round(step_us, 2), format=g.format(), kernels_avg_us={k: (round(v["avg_us"], 2) if v["avg_us"] else None) for k, v in prof.items()})
+                    avg_launch_us=round(step_us, 2), measured_copy_gbs=ceiling,
+                    frac_of_measured_copy=round(achieved / ceiling, 4) if ceiling else None, format=g.format(),
+                    kernels_avg_us={k: (round(v["avg_us"], 2) if v["avg_us"] else None) for k, v in prof.items()})
 
     # ---- the other filters of the path on the same resident graph (8 nnz + 20 n per polynomial term,
     # 8 nnz + 24 n per absorbing step); reported beside the headline, not part of `value`
     secondary = {}
     if not args.no_secondary:
-        for label, other, per_step in (("heat_kernel_t5_31_iterations", pg.HeatKernel(5, error_type="iters", max_iters=31), 8 * nnz + 20 * n),
-                                       ("absorbing_walks_a085_l1_1e-6", pg.AbsorbingWalks(ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS),
-                                        8 * nnz + 24 * n)):
-            other.rank(adj, personalizations[0])
+        def side(label, other, graph, per_step, edges, runs=3, signals=None):
+            signals = personalizations if signals is None else signals
+            other.rank(graph, signals[0])
             L.check(lib.pgh_sync())
             t1 = time.perf_counter()
             count, loop = 0, 0.0
-            for step in range(3):
-                other.rank(adj, personalizations[step % total])
+            for step in range(runs):
+                other.rank(graph, signals[step % len(signals)])
                 count += other.last_loop["spmv"]
                 loop += other.last_loop["loop_ms"]
             L.check(lib.pgh_sync())
             dt = time.perf_counter() - t1
-            secondary[label] = dict(gteps=round(nnz * count / dt / 1e9, 2), device_step_us=round(loop / count * 1e3, 1),
-                                    nominal_gbs=round(per_step / (loop / count * 1e-3) / 1e9, 1), spmv_per_run=count // 3)
+            secondary[label] = dict(gteps=round(edges * count / dt / 1e9, 2), device_step_us=round(loop / count * 1e3, 1),
+                                    nominal_gbs=round(per_step / (loop / count * 1e-3) / 1e9, 1), spmv_per_run=count // runs,
+                                    iterations=int(other.convergence.iteration))
+        # the three stopping rules (the headline above is (ii)), both polynomial recurrences, the absorbing
+        # walk, and the symmetrised graph; 8 nnz + 20 n per polynomial term, 8 nnz + 24 n per absorbing step
+        side("ppr_mabs_default_tol1e-6", pg.PageRank(alpha=ALPHA, tol=TOL, max_iters=MAX_ITERS), adj, alg_bytes, nnz)
+        side("ppr_50_iterations", pg.PageRank(alpha=ALPHA, error_type="iters", max_iters=51), adj, alg_bytes, nnz)
+        side("heat_kernel_t5_31_iterations", pg.HeatKernel(5, error_type="iters", max_iters=31), adj, 8 * nnz + 20 * n, nnz)
+        side("heat_kernel_t5_31_iterations_chebyshev", pg.HeatKernel(5, coefficient_type="chebyshev", error_type="iters", max_iters=31),
+             adj, 8 * nnz + 20 * n, nnz)
+        side("absorbing_walks_a085_l1_1e-6", pg.AbsorbingWalks(ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS), adj,
+             8 * nnz + 24 * n, nnz)
+        if not args.no_symmetric:
+            sym = rmat_graph(scale, ef, seed=0, symmetrize=True, **RMAT)          # A + A^T, "symmetric" normalisation
+            nnz_s = sym.array.nnz
+            side("ppr_l1_1e-6_symmetrised_graph", pg.PageRank(alpha=ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS), sym,
+                 8 * nnz_s + 16 * n, nnz_s, signals=[pg.to_signal(sym, sig.np) for sig in personalizations[:3]])
+            del sym
 
     # ---- CPU baseline + parity: the oracle's scipy loop (= reference numpy backend), same graph, same seeds
     cpu = None
@@ -161,7 +254,8 @@ def single_gpu(args):
         got = np.asarray(run(total - 1)[0].np, dtype=np.float64)
         cpu = dict(value=round(nnz * (cpu_iters - 1) / cpu_s / 1e9, 4), unit="GTEPS", cores=1, kind="port",
                    sample=f"1 full PPR run ({cpu_iters - 1} SpMV) on the same scale-{scale} graph, scipy x @ M fp64 "
-                          f"single thread, {cpu_s:.1f} s")
+                          f"single thread, {cpu_s:.1f} s",
+                   all_cores=allcore_cpu_gteps(MT, nnz))
         parity = dict(rel_linf=float(np.max(np.abs(got - want)) / np.max(np.abs(want))), gpu_iterations=int(iters[-1]),
                       cpu_iterations=int(cpu_iters), bound=1e-6)
     return dict(
@@ -203,6 +297,33 @@ def multi_gpu(args):
     return bench_row_partitioned(args, RMAT, ALPHA, TOL, MAX_ITERS, SEEDS, HBM_PEAK_GBS)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process tree (torch.distributed.run, one
+    rank per GPU) and relay rank 0's JSON line.  This parent has not touched the GPU (no HIP call, no torch.cuda query) and
+    never replaces itself with another program."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    entry = os.path.abspath(getattr(sys.modules["__main__"], "__file__", __file__))     # tests enter through a wrapper
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), entry] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PYTHONPATH"] = ROOT + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{"):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 or line is not None else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,10 +332,14 @@ def main():
     ap.add_argument("--scale", type=int, default=None, help="override the RMAT scale (default: 23 + log2(gpus))")
     ap.add_argument("--ef", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the HeatKernel / AbsorbingWalks side measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements (other stopping rules / filters)")
+    ap.add_argument("--no-symmetric", action="store_true", help="skip the symmetrised-graph side measurement")
+    ap.add_argument("--no-same-graph", action="store_true", help="N > 1: skip the single-GPU run of the same graph on rank 0")
     ap.add_argument("--force-partitioned", action="store_true", help="run the row-partitioned path even with one rank")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:       # no launcher around us: become the launcher's parent
+        sys.exit(spawn_ranks(args))
     if args.force_partitioned and args.gpus == 1 and "RANK" not in os.environ:      # plain `python bench.py --force-partitioned`
         for key, val in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29655")):
             os.environ.setdefault(key, val)

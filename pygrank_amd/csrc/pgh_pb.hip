@@ -44,7 +44,7 @@
 #include "pgh_kernels.h"
 
 // diagnostic builds only (tools/build_variants.sh): 1 no chunk fill, 2 fills only, 4 no stores (phase A); 8 no loads,
-// 16 no atomics (phase B)
+// 16 no atomics (phase B), 32 no epilogue
 #ifndef PGH_PROBE_PB
 #define PGH_PROBE_PB 0
 #endif
@@ -245,15 +245,17 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
                 const int64_t lo = max(first_id, f.cold_prefix[b]), hi = min(last_id, f.cold_prefix[b + 1]);
                 if (lo >= hi) continue;                     // wavefront-uniform
                 const float* __restrict__ src = xg + f.xg_base[b] + f.hot - f.cold_prefix[b];      // src[id] = value of cold id
-                for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kPbThreads * 8) {
-                    float v[8];
+                // rounds of 8 loads per thread (the whole chunk in one round of 32 was measured: 7 us SLOWER per launch)
+                constexpr int FU = 8;
+                for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kPbThreads * FU) {
+                    float v[FU];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < FU; ++u) {
                         const int64_t id = i0 + (int64_t)u * kPbThreads;
                         v[u] = src[min(id, hi - 1)];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < FU; ++u) {
                         const int64_t id = i0 + (int64_t)u * kPbThreads;
                         if (id < hi) s_x[id - first_id] = v[u];
                     }
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     amax = max(amax, max(__float_as_uint(lo[k]) & 0x7fffffffu, __float_as_uint(hi[k]) & 0x7fffffffu));
-                float* __restrict__ dst = f.tmp + (int64_t)r.to[q] * 8;
+                float* __restrict__ dst = (PGH_PROBE_PB & 64) ? f.tmp + e : f.tmp + (int64_t)r.to[q] * 8;   // 64: diagnostic, sequential stores
                 *reinterpret_cast<f32x4*>(dst) = lo;
                 *reinterpret_cast<f32x4*>(dst + 4) = hi;
             }
@@ -361,13 +363,13 @@ __global__ __launch_bounds__(THREADS, 4) void k_pb_finish(PbView f, RowSums rs, 
                                                         const LoopState* __restrict__ state, double* __restrict__ partial_sum,
                                                         double* __restrict__ partial_delta) {
     constexpr int WAVES = THREADS / 64;
-    constexpr int WORDS = ROWS / 64 + 1;                   // map words an item can touch per block (unaligned first row)
     // groups per thread and stream round in flight (three 16-byte loads each), rows per thread and epilogue round.  Both
     // shapes keep 16 wavefronts per CU (128 registers): 4 workgroups of 256 threads (32 KB of row sums each) or one of
     // 1024; what covers the latencies an item exposes (stream, atomics, epilogue rounds) is the depth of each round plus
     // the other workgroups of the CU.
     constexpr int P = THREADS > 512 ? 2 : PGH_FIN_P;
     constexpr int G = (THREADS > 512 || NB > 4) ? 2 : PGH_FIN_G;
+    constexpr int WORDS = ROWS / 64 + 1;                   // map words an item can touch per block (unaligned first row)
     __shared__ unsigned long long s_row[ROWS];
     __shared__ unsigned long long s_mask[NB * WORDS];      // the item's slice of the row -> segment map (BsfFormat::meta)
     __shared__ int s_base[NB * WORDS];
@@ -426,8 +428,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_pb_finish(PbView f, RowSums rs, 
         const double S = __longlong_as_double((long long)(1023 + E - e) << 52);
         const double inv_S = __longlong_as_double((long long)(1023 - E + e) << 52);
         // ---- the item's slice of the row -> segment map: issued now, parked in LDS after the stream (below)
-        const int64_t word0 = (int64_t)epi.x >> 6;
-        const int words = hub ? 0 : (int)((((int64_t)epi.x + epi.y - 1) >> 6) - word0 + 1);
+        const int word0 = epi.x >> 6;
+        const int words = hub ? 0 : ((epi.x + epi.y - 1) >> 6) - word0 + 1;
         constexpr int MPT = (NB * WORDS + THREADS - 1) / THREADS;
         SegMeta mreg[MPT];
 #pragma unroll
@@ -529,49 +531,59 @@ __global__ __launch_bounds__(THREADS, 4) void k_pb_finish(PbView f, RowSums rs, 
             }
         } else {
             __syncthreads();
-            // G rows per thread in flight: the operand loads and segment-sum gathers of the G rows are all issued before
-            // the first dependent use; the map words come from LDS.  Branch-free: rows past the range repeat its last
-            // row, rows without a segment in a block read slot 0, and the results are discarded afterwards (a load
-            // under a divergent branch gets its own wait and serialises everything around it).
-            const int last_i = epi.y - 1;
+            // The epilogue walks the item's rows in ALIGNED groups of 64 (lane = row % 64), G groups per wavefront in
+            // flight.  The map word of a (block, group) is then wavefront-uniform: one broadcast read of the LDS copy,
+            // the lane's bit is a shift, its rank among the group's segments is v_mbcnt -- a handful of vector
+            // instructions per block instead of 64-bit masks per lane (scalar loads of the words straight from
+            // memory were tried: 260 us, every s_load a drained wait).  Branch-free loads: lanes outside the
+            // item repeat a row of it, rows without a segment in a block read the zero slot, results are dropped later
+            // (a load under a divergent branch gets its own wait and serialises everything around it).
+            const int lane = tid & 63;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int row_lo = epi.x, row_hi = epi.x + epi.y - 1;
+            const int g_hi = (PGH_PROBE_PB & 32) ? -1 : (row_hi >> 6);          // diagnostic: no epilogue
             const char* __restrict__ psum_b = reinterpret_cast<const char*>(rs.psum);
-            for (int base = 0; base < epi.y; base += THREADS * G) {
+            for (int g0 = (row_lo >> 6) + wave; g0 <= g_hi; g0 += WAVES * G) {
                 EpiOps ops[G];
                 float dsc[G];
                 float vals[G][NB];
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
-                    const int i = min(base + tid + u * THREADS, last_i);
-                    const int row = epi.x + i;
-                    const int w = (int)(((int64_t)row >> 6) - word0);
-                    const unsigned long long bit = 1ULL << (row & 63);
+                    const int g = min(g0 + u * WAVES, g_hi);                 // wavefront-uniform
+                    const int row = min(max((g << 6) + lane, row_lo), row_hi);
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
-                        const unsigned long long mask = s_mask[b * WORDS + w];
-                        const unsigned int at = (unsigned int)(s_base[b * WORDS + w] + __popcll(mask & (bit - 1ULL)));
-                        // 32-bit byte offsets from a uniform base: one address register per load
-                        vals[u][b] = *reinterpret_cast<const float*>(psum_b + (((mask & bit) != 0ULL ? at : rs.zero_at) << 2));
+                        // blocks past num_blocks hold empty words (mask 0): the zero slot
+                        const unsigned long long mask = s_mask[b * WORDS + (g - word0)];
+                        const unsigned int first = (unsigned int)s_base[b * WORDS + (g - word0)];
+                        const unsigned int lo = (unsigned int)mask, hi = (unsigned int)(mask >> 32);
+                        const unsigned int rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                        // by LANE, also for lanes whose row lies outside the item: row 64 g + lane exists in the map
+                        const bool has = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) != 0u;
+                        const unsigned int at = has ? first + rank : rs.zero_at;
+                        vals[u][b] = *reinterpret_cast<const float*>(psum_b + (at << 2));
                     }
                     ops[u] = epi_load<MODE>(ep, row);
                     dsc[u] = dst_scale != nullptr ? ld_off(dst_scale, (uint32_t)row << 2) : 1.f;
                 }
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
-                    const int i = base + tid + u * THREADS;
-                    if (i > last_i) continue;
-                    const int row = epi.x + i;
+                    const int g = g0 + u * WAVES;
+                    const int row = (g << 6) + lane;
+                    if (g > g_hi || row < row_lo || row > row_hi) continue;
+                    const int i = row - row_lo;
                     float cold = 0.f;
                     if (i < rows) cold = finite ? (float)((double)(long long)s_row[i] * inv_S) : __uint_as_float(0x7fc00000u);
                     double sum = 0.0;
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) sum += (double)vals[u][b];      // blocks past num_blocks read the zero slot
+                    for (int b = 0; b < NB; ++b) sum += (double)vals[u][b];      // blocks past num_blocks contribute 0
                     sum += (double)cold;
                     if (dst_scale != nullptr) sum *= (double)dsc[u];
                     epi_apply<MODE>(ep, ops[u], a_eff, row, (float)sum, sum_y, delta);
                 }
             }
         }
-        __syncthreads();                                   // s_row / s_mask / s_hub are reused by the next item
+        __syncthreads();                                   // s_row / s_hub are reused by the next item
         if (!PGH_FIN_PREFETCH && next < f.num_items) fetch(next_bin, 0, R);
         item = next;
         bin = next_bin;

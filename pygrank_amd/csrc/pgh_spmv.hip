@@ -248,20 +248,43 @@ __global__ __launch_bounds__(WG) void k_step_residual(const float* __restrict__ 
         acc = linf ? fmax(acc, d) : acc + d;
     };
     const int64_t body = vec_ok ? (n >> 2) : 0;
-    const float4* y4 = reinterpret_cast<const float4*>(y);
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (int64_t i = tid; i < body; i += stride) {
-        const float4 u = y4[i], v = x4[i];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    // four 16-byte pairs per thread in flight (one pair per round left the kernel latency-bound: 3.7 TB/s)
+    constexpr int U = 4;
+    int64_t i = tid;
+    for (; i + (U - 1) * stride < body; i += U * stride) {
+        f32x4 u[U], v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            u[k] = __builtin_nontemporal_load(y4 + i + k * stride);
+            v[k] = __builtin_nontemporal_load(x4 + i + k * stride);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            fold(u[k].x, v[k].x);
+            fold(u[k].y, v[k].y);
+            fold(u[k].z, v[k].z);
+            fold(u[k].w, v[k].w);
+        }
+    }
+    for (; i < body; i += stride) {
+        const f32x4 u = y4[i], v = x4[i];
         fold(u.x, v.x);
         fold(u.y, v.y);
         fold(u.z, v.z);
         fold(u.w, v.w);
     }
-    for (int64_t i = (body << 2) + tid; i < n; i += stride) fold(y[i], x[i]);
+    for (int64_t j = (body << 2) + tid; j < n; j += stride) fold(y[j], x[j]);
     const double r = linf ? block_reduce_256<1>(acc, s_red) : block_reduce_256<0>(acc, s_red);
     if (threadIdx.x == 0) partial_res[blockIdx.x] = r;
 }
 
+// (Tried in round 2: residual and close in ONE launch -- every workgroup publishes its partial with a device-scope
+// atomic, draws a ticket, the last one folds and closes.  28 us against 17 + 8 for the two launches: the two dependent
+// atomic round trips at the end of every workgroup cost more than the launch they save.  Round 1's __threadfence()
+// variant measured 113 us.)
 // single-workgroup stage that closes a step on the device: folds the partials, updates the loop state and
 // evaluates ConvergenceManager._has_converged (convergence.py:96-101) for the check that follows the step.
 //   check != 0  : this step is followed by a residual comparison (iteration % end_modulo == 0, not "iters")

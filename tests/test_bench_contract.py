@@ -7,7 +7,7 @@ import bench
 
 
 def test_single_gpu_leg_fields(host_engine):
-    args = argparse.Namespace(gpus=1, steps=2, warmup=1, scale=10, ef=8, no_cpu=False, no_secondary=False)
+    args = argparse.Namespace(gpus=1, steps=2, warmup=1, scale=10, ef=8, no_cpu=False, no_secondary=False, no_symmetric=False)
     out = bench.single_gpu(args)
     line = json.loads(json.dumps(out))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -20,5 +20,10 @@ def test_single_gpu_leg_fields(host_engine):
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["peak"] == 8000.0
     assert line["parity"]["rel_linf"] <= 1e-6
     assert line["parity"]["gpu_iterations"] == line["parity"]["cpu_iterations"]
-    assert set(line["secondary"]) == {"heat_kernel_t5_31_iterations", "absorbing_walks_a085_l1_1e-6"}
+    assert set(line["secondary"]) == {"ppr_mabs_default_tol1e-6", "ppr_50_iterations", "heat_kernel_t5_31_iterations",
+                                      "heat_kernel_t5_31_iterations_chebyshev", "absorbing_walks_a085_l1_1e-6",
+                                      "ppr_l1_1e-6_symmetrised_graph"}
+    assert line["secondary"]["ppr_50_iterations"]["spmv_per_run"] == 50
+    assert line["roofline"]["frac_of_measured_copy"] is not None and "residual" in line["roofline"]["kernel"]
+    assert line["cpu_baseline"]["all_cores"]["cores"] >= 1
     assert line["secondary"]["heat_kernel_t5_31_iterations"]["spmv_per_run"] in (29, 30)

@@ -69,3 +69,27 @@ def test_bench_two_ranks_prints_one_json_line(oracle_build_dir):
     assert out["config"]["nnz"] == rmat_np.rmat_csr(11, 8, seed=0).nnz
     assert len(out["config"]["iterations_per_step"]) == 2
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(out["roofline"])
+
+
+def test_bench_launcherless_spawns_its_ranks(oracle_build_dir):
+    """`python bench.py --gpus 2` with NO launcher (the way the driver starts the N = 1 run): the parent process spawns the
+    ranks as children, relays rank 0's single JSON line and exits with their status.  The N > 1 line carries parity (the
+    partitioned path vs the oracle), a CPU baseline, the nnz balance of the partition and the same-graph single-GPU leg."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_dist_worker.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--scale", "11", "--ef", "8"]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["parity"]["rel_linf"] <= 1e-6 and out["parity"]["gpu_iterations"] == out["parity"]["cpu_iterations"]
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] == 1
+    assert out["config"]["nnz_per_rank_max_over_mean"] <= 1.10       # scale 11: 2 K rows, statistical balance
+    same = out["same_graph_1gpu"]
+    assert same["rel_linf_partitioned_vs_1gpu"] <= 1e-6 and same["iterations_1gpu"] == same["iterations_partitioned"]
+    assert same["speedup_vs_1gpu_same_graph"] > 0

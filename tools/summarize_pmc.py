@@ -7,10 +7,22 @@ TCC_MISS * 128 B == its 8*n algorithmic bytes); WRITE_SIZE * 1024 is exact for s
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha16():
+    """Hash of the kernel sources the counters were collected from (bench.py drops `traffic` when it does not match)."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "pygrank_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pygrank_amd", "csrc", "*.h"))):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
@@ -41,8 +53,10 @@ def main():
             row["l2_hit_rate"] = row["TCC_HIT_sum"] / (row["TCC_HIT_sum"] + row["TCC_MISS_sum"])
             row["l2_miss_bytes_128B"] = row["TCC_MISS_sum"] * 128
         out[k] = row
+    shown = dict(out)
+    out["_meta"] = {"csrc_sha16": csrc_sha16()}
     json.dump(out, open(out_path, "w"), indent=1)
-    for k, row in out.items():
+    for k, row in shown.items():
         print(k, {c: (round(v, 1) if isinstance(v, float) else v) for c, v in row.items()})
 
 

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(sys.argv[1])):
         continue
     rows[m.group(1) + (m.group(2) or "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("kernel,launches,avg_all_us,working_launches,avg_working_us,min_us,max_us")
-keep = ("k_bsf_partial", "k_pb_gather", "k_pb_accumulate", "k_pb_hub_fold", "k_bsf_fixup", "k_bsf_combine", "k_step_", "k_permute", "k_spmm", "k_mm_")
+keep = ("k_bsf_partial", "k_pb_gather", "k_pb_finish", "k_bsf_fixup", "k_bsf_combine", "k_step_", "k_permute", "k_spmm", "k_mm_")
 for name, d in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
     if not name.startswith(keep):
         continue
