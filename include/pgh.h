@@ -203,6 +203,11 @@ typedef struct {
 int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg,
                    pgh_loop_result* res);
+/* SymmetricAbsorbingRandomWalks (adhoc.py:317-369): ranks <- conv(ranks / a, M) * deg / (a + deg) + p * a / (a + deg) with
+ * deg = degrees(M) and a = (1 + sqrt(1 + 4 deg)) / 2 (adhoc.py:348-353,362-364), then the L1 quotient of
+ * RecursiveGraphFilter._step; ranks in/out like pgh_ppr_run.  Graphs with the blocked layout (every uploaded / generated
+ * graph unless PGH_FORMAT=csr). */
+int pgh_sarw_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 /* closed-form run with host-computed coefficient schedule c_1..c_K (adhoc.py:83-84,113-116;
  * low_pass.py:23-26): iteration it uses coeffs[it-1], 0 beyond K.  chebyshev != 0 selects the
  * reference's recurrence (abstract_filters.py:216-224). */

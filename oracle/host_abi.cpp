@@ -640,6 +640,33 @@ int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, c
     });
 }
 
+// SymmetricAbsorbingRandomWalks (adhoc.py:348-364) written the way the reference writes it: precomputed skews, pre-scaled iterate
+int pgh_sarw_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    CHECK(g && p && ranks && cfg && res, "pgh_sarw_run: null argument");
+    CHECK(p->n == g->n_cols && g->n_rows == g->n_cols, "pgh_sarw_run: shape mismatch");
+    const int64_t n = g->n_cols;
+    const std::vector<float> pn = normalised(p, cfg);
+    std::vector<float> left(n), post(n), skew(n), xs_buf(n);
+    for (int64_t i = 0; i < n; ++i) {
+        const double deg = (double)g->degrees[i];
+        const double a = (1.0 + std::sqrt(1.0 + 4.0 * deg)) / 2.0;
+        left[i] = (float)(1.0 / a);
+        post[i] = (float)(deg / (a + deg));
+        skew[i] = (float)(a / (a + deg));
+    }
+    return recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
+        for (int64_t i = 0; i < n; ++i) xs_buf[i] = x[i] * left[i];
+        const float s = (float)xs;
+        double sum = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            const float v = s * row_dot(g, xs_buf.data(), r) * post[r] + pn[r] * skew[r];
+            y[r] = v;
+            sum += v;
+        }
+        return sum;
+    });
+}
+
 int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, int32_t chebyshev,
                  pgh_vec_t result, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
     CHECK(g && p && result && cfg && res, "pgh_poly_run: null argument");
@@ -647,6 +674,49 @@ int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
     CHECK(g->n_rows == n && p->n == n && result->n == n, "pgh_poly_run: shape mismatch");
     CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
     auto coeff = [&](int it) { return (it >= 1 && it <= num_coeffs) ? coeffs[it - 1] : 0.0; };
+    if (chebyshev) {
+        // The engine evaluates the reference's "chebyshev" recurrence in f64 (it amplifies rounding noise: an f32 evaluation
+        // cannot hold 1e-6); so does the double: f64 vectors, f64 row sums over the f32 matrix values.
+        std::vector<double> resv(n, 0.0), prev_res(n, 0.0), term(n), prev_term, tmp(n);
+        for (int64_t i = 0; i < n; ++i) term[i] = (double)p->data[i];
+        Conv cm{cfg};
+        int spmv = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        auto resid = [&] {
+            double acc = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                const double d = std::fabs(resv[i] - prev_res[i]);
+                acc = cfg->err_kind == PGH_ERR_LINF ? std::max(acc, d) : acc + d;
+            }
+            return cfg->err_kind == PGH_ERR_MABS && n > 0 ? acc / (double)n : acc;
+        };
+        while (!cm.has_converged(resid)) {
+            const int it = cm.iteration;
+            const double c = coeff(it);
+            prev_res = resv;
+            if (it == 2) prev_term = term;                                   // abstract_filters.py:216-224
+            if (it > 2) {
+                for (int64_t i = 0; i < n; ++i) term[i] = 2.0 * term[i] - prev_term[i];
+                prev_term = term;
+            }
+            for (int64_t i = 0; i < n; ++i) resv[i] = resv[i] + c * term[i];
+            for (int64_t r = 0; r < n; ++r) {
+                double acc = 0;
+                for (int64_t k = g->rowptr[r]; k < g->rowptr[r + 1]; ++k) acc += (double)g->val[k] * term[g->col[k]];
+                tmp[r] = acc;
+            }
+            term.swap(tmp);
+            ++spmv;
+        }
+        for (int64_t i = 0; i < n; ++i) result->data[i] = (float)(resv[i] * cfg->out_scale);
+        memset(res, 0, sizeof(*res));
+        res->iterations = cm.iteration;
+        res->converged = cm.converged ? 1 : 0;
+        res->spmv_count = spmv;
+        res->last_error = cm.last_err;
+        res->loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    }
     // reference order (abstract_filters.py:248-256): accumulate the current term, THEN advance the power.
     std::vector<float> resv(n, 0.f), prev_res(n, 0.f), term(p->data, p->data + n), prev_term, tmp(n);
     Conv cm{cfg};

@@ -27,7 +27,7 @@ from pygrank_amd.convergence import ConvergenceManager
 from pygrank_amd.postprocess import Normalize, Postprocessor, Tautology
 from pygrank_amd.filters import (AbsorbingWalks, ClosedFormGraphFilter, GenericGraphFilter, GraphFilter, HeatKernel,
                                  ImpulseGraphFilter, LowPassRecursiveGraphFilter, PageRank, PageRankClosed,
-                                 RecursiveGraphFilter)
+                                 RecursiveGraphFilter, SymmetricAbsorbingRandomWalks)
 from pygrank_amd.device import DeviceGraph, DeviceMatrix, DeviceVector
 
 __version__ = "0.1.0"

@@ -1,10 +1,8 @@
 """ctypes binding of the C-ABI declared in include/pgh.h.
 
 The product binds exactly one library: ``pygrank_amd/csrc/libpgh_hip.so`` (hand-written HIP for gfx950).
-There is NO CPU fallback: if the library is missing, or no MI355X is visible when the engine is first
-used, an exception is raised.  ``_install_test_double`` exists only so that tests/ can exercise the host-side
-Python (signals, filters, convergence bookkeeping, the gloo row-partition path) against a host restatement
-of the same ABI that lives under oracle/ -- the product never calls it.
+There is NO CPU fallback: if the library is missing, if it reports a runtime other than ``hip:*``, or if no MI355X is
+visible when the engine is first used, an exception is raised.
 """
 import ctypes as C
 import os
@@ -107,6 +105,7 @@ SIGNATURES = {
     "pgh_scaled_residual": (C.c_int, [C.c_int, c_vec, C.c_double, c_vec, C.c_double, c_f64p]),
     "pgh_ppr_run": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_absorb_run": (C.c_int, [c_graph, c_vec, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
+    "pgh_sarw_run": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_poly_run": (C.c_int, [c_graph, c_vec, C.c_void_p, C.c_int32, C.c_int32, c_vec, C.POINTER(LoopCfg),
                                C.POINTER(LoopResult)]),
     "pgh_spmm": (C.c_int, [c_graph, c_mat, c_mat]),
@@ -136,8 +135,8 @@ ERR_MABS, ERR_L1, ERR_LINF, ERR_ITERS = range(4)
 K_SPMV, K_FIXUP, K_RESIDUAL, K_FINAL, K_SPMM, K_COMBINE, K_PB_GATHER, K_PB_ACCUM = range(8)
 
 _lib = None
-_is_test_double = False
 _initialised = False
+ACCEPTED_RUNTIMES = ("hip:",)      # pgh_runtime_name() prefixes ensure_init() agrees to drive
 
 
 class EngineError(Exception):
@@ -170,21 +169,6 @@ def lib():
     return _lib
 
 
-def _install_test_double(cdll):
-    """TESTS ONLY: route the binding to a host restatement of the ABI (oracle/host_abi.c)."""
-    global _lib, _is_test_double, _initialised
-    _lib = _bind(cdll)
-    _is_test_double = True
-    _initialised = False
-
-
-def _remove_test_double():
-    global _lib, _is_test_double, _initialised
-    _lib = None
-    _is_test_double = False
-    _initialised = False
-
-
 def check(status):
     if status != 0:
         msg = lib().pgh_last_error()
@@ -199,7 +183,7 @@ def ensure_init(device=None):
         return
     L = lib()
     name = L.pgh_runtime_name().decode()
-    if not _is_test_double and not name.startswith("hip:"):
+    if not name.startswith(ACCEPTED_RUNTIMES):
         raise EngineError(f"refusing to run the product path on runtime '{name}'")
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))

@@ -891,6 +891,22 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
     return 0;
 }
 
+// gather vector of a square graph from an internal-space vector and an internal-space scale: xg = y * scale (stored in
+// the engine's own, possibly trimmed, layout)
+__global__ void k_make_gather(const float* __restrict__ y, const float* __restrict__ scale, int64_t n_pad, float* __restrict__ xg,
+                              int xg_blk, int xg_live) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = xg_slot((int)i, xg_blk, xg_live);
+        if (slot >= 0) xg[slot] = y[i] * scale[i];
+    }
+}
+int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int) {
+    BsfFormat& f = g->bsf;
+    k_make_gather<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(y_int, scale_int, f.n_src_pad, f.xg, f.blk_size, f.xg_live);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
 // output-side vector: original -> internal
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole) {
     BsfFormat& f = g->bsf;

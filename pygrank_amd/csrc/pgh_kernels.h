@@ -254,6 +254,7 @@ bool bsf_can_bring_pair(const pgh_graph_s* g);
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
                    bool start_from_v);
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
+int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int);
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);
 int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel,
               int force_blocks = 0, BsfFormat* target = nullptr);

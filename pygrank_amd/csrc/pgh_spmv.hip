@@ -31,15 +31,57 @@ namespace {
 // -------------------------------------------------------------------------------------------------
 // main kernel: persistent workgroups stride over the merge-path tiles
 // -------------------------------------------------------------------------------------------------
-template <int IPT, int MODE>
-__global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EpiParams ep, const float* __restrict__ x,
+// Epilogue policies of the row-major kernel: the f32 filter epilogues (apply_epilogue<MODE>), and the f64 polynomial step
+// of the reference's "chebyshev" recurrence (below).
+template <int MODE>
+struct EpiF32 {
+    EpiParams ep;
+    float     a_eff;
+    static constexpr bool kDelta = MODE == EPI_POLY;
+    __device__ __forceinline__ bool linf() const { return ep.err_linf != 0; }
+    __device__ __forceinline__ void prepare(double scale) { a_eff = (float)(ep.a * scale); }
+    __device__ __forceinline__ void apply(int row, float sum, double& sum_y, double& delta) const {
+        apply_epilogue<MODE>(ep, a_eff, row, sum, sum_y, delta);
+    }
+};
+// ClosedFormGraphFilter._recursion with coefficient_type "chebyshev" (abstract_filters.py:216-224) entirely in f64:
+//   term_out = a * (M^T term) + b * term;  result += c * term_out
+// S_k = (2 M^T - I) S_{k-1} amplifies whatever rounding noise enters a step -- by 20x on tests/golden rmat12/heat_cheb, by
+// up to ~1e4 along eigenvectors of M with eigenvalue near -1 (undirected graphs) -- so an f32 evaluation of it cannot hold
+// 1e-6 against the reference's fp64 result (this engine's f32 path, the reference's own pytorch backend and a numpy f32
+// restatement land between 4e-7 and 1.4e-6 on that case depending on rounding luck).  The chebyshev runs therefore go
+// through this f64 route over CSR(M^T): f64 gather vector, f64 row sums, f64 term / result vectors.
+struct EpiPoly64 {
+    double        a, b, c;
+    const double* term;
+    double*       term_out;
+    double*       r;
+    int           err_linf;
+    static constexpr bool kDelta = true;
+    __device__ __forceinline__ bool linf() const { return err_linf != 0; }
+    __device__ __forceinline__ void prepare(double) {}
+    __device__ __forceinline__ void apply(int row, double sum, double& sum_y, double& delta) const {
+        double y = a * sum;
+        if (b != 0.0) y += b * term[row];
+        term_out[row] = y;
+        sum_y += y;
+        const double r_old = r[row];
+        const double r_new = r_old + c * y;
+        r[row] = r_new;
+        const double d = fabs(r_new - r_old);
+        delta = err_linf ? fmax(delta, d) : delta + d;
+    }
+};
+
+template <int IPT, typename XT, typename EPI>
+__global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EPI epi, const XT* __restrict__ x,
                                                     const LoopState* __restrict__ state,
                                                     double* __restrict__ partial_sum,
                                                     double* __restrict__ partial_delta) {
     constexpr int ITEMS = WG * IPT;
-    __shared__ float  s_prod[ITEMS];
+    __shared__ XT     s_prod[ITEMS];
     __shared__ int    s_rend[ITEMS + 1];
-    __shared__ float  s_rsum[ITEMS];
+    __shared__ XT     s_rsum[ITEMS];
     __shared__ int    s_wkey[4];
     __shared__ double s_wval[4];
     __shared__ double s_red[4];
@@ -49,7 +91,7 @@ __global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EpiParams ep, co
         if (state->done) return;
         scale = state->scale;
     }
-    const float a_eff = (float)(ep.a * scale);
+    epi.prepare(scale);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double sum_y = 0.0, delta = 0.0;
 
@@ -78,15 +120,7 @@ __global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EpiParams ep, co
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
             const int idx = k * WG + tid;
-#if PGH_PROBE_GATHER == 1
-            if (idx < tile_nnz) s_prod[idx] = vals[k] * x[cidx[k] & 1023];
-#elif PGH_PROBE_GATHER == 2
-            if (idx < tile_nnz) s_prod[idx] = vals[k] * x[cidx[k] & 0xFFFFF];
-#elif PGH_PROBE_GATHER == 3
-            if (idx < tile_nnz) s_prod[idx] = vals[k] * (float)cidx[k];
-#else
-            if (idx < tile_nnz) s_prod[idx] = vals[k] * x[cidx[k]];
-#endif
+            if (idx < tile_nnz) s_prod[idx] = (XT)vals[k] * x[cidx[k]];
         }
         __syncthreads();
 
@@ -114,7 +148,7 @@ __global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EpiParams ep, co
                         first_emit = i;
                         first_val = acc;
                     } else {
-                        s_rsum[i] = (float)acc;
+                        s_rsum[i] = (XT)acc;
                     }
                     acc = 0.0;
                     ++i;
@@ -150,7 +184,7 @@ __global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EpiParams ep, co
         if (lane == 0) { ek = pk; ev = pv; }
         if (first_emit >= 0) {
             const double total = first_val + ((tid > 0 && ek == first_emit) ? ev : 0.0);
-            s_rsum[first_emit] = (float)total;
+            s_rsum[first_emit] = (XT)total;
             if (first_emit == 0) g.head_partial[tile] = total;   // consumed by the fix-up if row0 spans tiles
         }
         if (tid == WG - 1) g.tail_carry[tile] = val;             // nnz of the row still open at the tile end
@@ -160,15 +194,15 @@ __global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EpiParams ep, co
         const bool head_spans = (row0 < g.n) && (g.rowptr[row0] < z0);
         for (int r = tid; r < tile_rows; r += WG) {
             if (r == 0 && head_spans) continue;
-            apply_epilogue<MODE>(ep, a_eff, row0 + r, s_rsum[r], sum_y, delta);
+            epi.apply(row0 + r, s_rsum[r], sum_y, delta);
         }
         __syncthreads();
     }
 
     const double bs = block_reduce_256<0>(sum_y, s_red);
     if (tid == 0) partial_sum[blockIdx.x] = bs;
-    if (MODE == EPI_POLY) {
-        const double bd = ep.err_linf ? block_reduce_256<1>(delta, s_red) : block_reduce_256<0>(delta, s_red);
+    if (EPI::kDelta) {
+        const double bd = epi.linf() ? block_reduce_256<1>(delta, s_red) : block_reduce_256<0>(delta, s_red);
         if (tid == 0) partial_delta[blockIdx.x] = bd;
     }
 }
@@ -177,8 +211,8 @@ __global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EpiParams ep, co
 // fix-up kernel: one thread per tile whose first row began in an earlier tile and ends here.
 // Sums the tail carries of the chain of tiles in ascending order and applies the epilogue once.
 // -------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(WG) void k_spmv_fixup(GraphView g, EpiParams ep, const LoopState* __restrict__ state,
+template <typename XT, typename EPI>
+__global__ __launch_bounds__(WG) void k_spmv_fixup(GraphView g, EPI epi, const LoopState* __restrict__ state,
                                                     double* __restrict__ partial_sum,
                                                     double* __restrict__ partial_delta) {
     __shared__ double s_red[4];
@@ -187,7 +221,7 @@ __global__ __launch_bounds__(WG) void k_spmv_fixup(GraphView g, EpiParams ep, co
         if (state->done) return;
         scale = state->scale;
     }
-    const float a_eff = (float)(ep.a * scale);
+    epi.prepare(scale);
     double sum_y = 0.0, delta = 0.0;
     for (int t = blockIdx.x * WG + threadIdx.x; t < g.num_tiles; t += gridDim.x * WG) {
         const int first = g.chain_first[t];
@@ -195,12 +229,12 @@ __global__ __launch_bounds__(WG) void k_spmv_fixup(GraphView g, EpiParams ep, co
         double total = 0.0;
         for (int s = first; s < t; ++s) total += g.tail_carry[s];
         total += g.head_partial[t];
-        apply_epilogue<MODE>(ep, a_eff, g.tile_coord[t].x, (float)total, sum_y, delta);
+        epi.apply(g.tile_coord[t].x, (XT)total, sum_y, delta);
     }
     const double bs = block_reduce_256<0>(sum_y, s_red);
     if (threadIdx.x == 0) partial_sum[blockIdx.x] = bs;
-    if (MODE == EPI_POLY) {
-        const double bd = ep.err_linf ? block_reduce_256<1>(delta, s_red) : block_reduce_256<0>(delta, s_red);
+    if (EPI::kDelta) {
+        const double bd = epi.linf() ? block_reduce_256<1>(delta, s_red) : block_reduce_256<0>(delta, s_red);
         if (threadIdx.x == 0) partial_delta[blockIdx.x] = bd;
     }
 }
@@ -403,13 +437,16 @@ int launch_merge(pgh_graph_t g, const EpiParams& ep, const float* x, const LoopS
     const StepGrid sg = grids_for(g);
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
+    EpiF32<MODE> epi;
+    epi.ep = ep;
+    epi.a_eff = 0.f;
     {
         ProfScope prof(PGH_K_SPMV);
-        k_spmv_merge<kIPT, MODE><<<sg.main_grid, WG, 0, r.stream>>>(v, ep, x, state, psum, pdel);
+        k_spmv_merge<kIPT, float, EpiF32<MODE>><<<sg.main_grid, WG, 0, r.stream>>>(v, epi, x, state, psum, pdel);
     }
     {
         ProfScope prof(PGH_K_FIXUP);
-        k_spmv_fixup<MODE><<<sg.fix_grid, WG, 0, r.stream>>>(v, ep, state, psum + sg.main_grid, pdel + sg.main_grid);
+        k_spmv_fixup<float, EpiF32<MODE>><<<sg.fix_grid, WG, 0, r.stream>>>(v, epi, state, psum + sg.main_grid, pdel + sg.main_grid);
     }
     PGH_HIP(hipGetLastError());
     if (num_partials) *num_partials = sg.total();
@@ -933,7 +970,10 @@ struct InternalSpace {
 
 // Recursive filters (PageRank / AbsorbingWalks): RecursiveGraphFilter._step + ConvergenceManager.
 template <int MODE>
-int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+// pre_scale (nullable, caller id space): the step multiplies by M^T (x * pre_scale) instead of M^T x -- folded into the
+// gather vector the epilogue writes, like the source scale of the value-free layout (SymmetricAbsorbingRandomWalks).
+int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res,
+                  const float* pre_scale = nullptr) {
     PGH_TRY(ensure_state());
     Runtime& r = rt();
     const int64_t n = g->n_cols;
@@ -996,6 +1036,19 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         ep.xg_blk = g->bsf.blk_size;
         ep.xg_live = g->bsf.xg_live;
     }
+    DevF32 gs_buf;
+    bool use_xg = scaled_gather;
+    if (pre_scale != nullptr) {
+        PGH_CHECK(sp.blocked && g->bsf.n_out == g->bsf.n_src_pad, "a pre-scaled step needs the blocked layout of a square graph");
+        PGH_TRY(gs_buf.alloc(n_int + 1));
+        PGH_TRY(bsf_to_internal(g, pre_scale, gs_buf.p, g->bsf.src_scale != nullptr, 0.f));     // pre_scale[perm] * source scale
+        PGH_TRY(bsf_make_gather(g, buf[0], gs_buf.p));
+        ep.xg_out = g->bsf.xg;
+        ep.src_scale = gs_buf.p;
+        ep.xg_blk = g->bsf.blk_size;
+        ep.xg_live = g->bsf.xg_live;
+        use_xg = true;
+    }
     const int linf = (cfg->err_kind == PGH_ERR_LINF);
     const int rgrid = residual_grid(n_int);
     double* pres = r.d_partials + kMaxPartials;      // residual partials share the delta region
@@ -1022,7 +1075,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             float* yout = buf[k & 1];
             ep.y = yout;
             int count = 0;
-            PGH_TRY((launch_step<MODE>(g, ep, scaled_gather ? g->bsf.xg : xin, g_state, &count,
+            PGH_TRY((launch_step<MODE>(g, ep, use_xg ? g->bsf.xg : xin, g_state, &count,
                                        (overlap && enq > 0) ? g_ev_closed : nullptr)));
             // the check that follows step k happens at iteration k + 1 (skipped when that iteration hits max_iters)
             const int it = k + 1;
@@ -1100,6 +1153,184 @@ extern "C" int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec
     return recursive_run<EPI_ABSORB>(g, ep, ranks, cfg, res);
 }
 
+namespace {
+
+__global__ void k_f32_to_f64(const float* __restrict__ in, double* __restrict__ out, int64_t n, double factor) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (double)in[i] * factor;
+}
+__global__ void k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n, double factor) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)(in[i] * factor);
+}
+
+struct DevF64 {
+    double* p = nullptr;
+    ~DevF64() {
+        if (p) pool_free(p);
+    }
+    int alloc(int64_t n) { return pool_alloc(sizeof(double) * (size_t)(n > 0 ? n : 1), (void**)&p); }
+};
+
+// The reference's "chebyshev" recurrence in f64 over the row-major CSR(M^T) (see EpiPoly64 for why).  Same loop structure,
+// stopping rule and iteration accounting as the f32 route of pgh_poly_run below.
+int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, pgh_vec_t result, const pgh_loop_cfg* cfg,
+                 pgh_loop_result* res) {
+    Runtime& r = rt();
+    const int64_t n = g->n_cols;
+    auto coeff = [&](int it) -> double { return (it >= 1 && it <= num_coeffs) ? coeffs[it - 1] : 0.0; };
+    const int max_iters = cfg->max_iters;
+    LoopTimer timer;
+    PGH_TRY(timer.start());
+    int it = 1;
+    if (it >= max_iters) {
+        PGH_TRY(pgh_vec_fill(result, 0.0));
+        PGH_TRY(timer.stop(&res->loop_ms));
+        res->iterations = it;
+        res->converged = 0;
+        return 0;
+    }
+    PGH_CHECK(g->items_per_tile == WG * kIPT, "graph tile table was built for a different tile size");
+    DevF64 p64, res64, t0, t1;
+    PGH_TRY(p64.alloc(n));
+    PGH_TRY(res64.alloc(n));
+    PGH_TRY(t0.alloc(n));
+    PGH_TRY(t1.alloc(n));
+    const int cgrid = residual_grid(n);
+    const double c1 = coeff(1);
+    if (n > 0) {
+        k_f32_to_f64<<<cgrid, WG, 0, r.stream>>>(p->data, p64.p, n, 1.0);
+        k_f32_to_f64<<<cgrid, WG, 0, r.stream>>>(p->data, res64.p, n, c1);      // result_1 = c_1 * p (result_0 = 0)
+    }
+    // delta_1 = |result_1 - 0| (decides only whether the loop stops at iteration 2)
+    double err = 0.0;
+    {
+        DevF32 first;
+        PGH_TRY(first.alloc(n));
+        if (n > 0) k_scale_copy<<<cgrid, WG, 0, r.stream>>>(p->data, first.p, n, c1);
+        pgh_vec_s rv;
+        rv.data = first.p;
+        rv.n = n;
+        rv.owns = false;
+        const int kind = cfg->err_kind == PGH_ERR_ITERS ? PGH_ERR_L1 : cfg->err_kind;
+        PGH_TRY(pgh_scaled_residual(kind == PGH_ERR_MABS ? PGH_ERR_L1 : kind, &rv, 1.0, &rv, 0.0, &err));
+        if (kind == PGH_ERR_MABS && n > 0) err /= (double)n;
+    }
+    double* tbuf[2] = {t0.p, t1.p};
+    const double* term = p64.p;
+    int spmv = 0;
+    bool converged = false;
+    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
+    const bool poll = g_progress_dev != nullptr;
+    const int batch = poll ? 1 : batch_for(g);
+    const int window = window_for(g);
+    if (poll) progress_reset();
+    it = 2;
+    bool stop = false;
+    if (it >= max_iters) {
+        stop = true;
+    } else if (cfg->err_kind != PGH_ERR_ITERS && it % cfg->end_modulo == 0 && err <= cfg->tol) {
+        stop = true;
+        converged = true;
+    }
+    if (!stop) {
+        const GraphView v = view_of(g);
+        const StepGrid sg = grids_for(g);
+        double* psum = r.d_partials;
+        double* pdel = r.d_partials + kMaxPartials;
+        int next_it = 2;
+        bool done = false;
+        while (!done && next_it < max_iters) {
+            if (poll) {
+                PGH_TRY(progress_wait(next_it - 2, window, &done));
+                if (done) break;
+            }
+            const int upto = (next_it + batch < max_iters) ? next_it + batch : max_iters;
+            for (; next_it < upto; ++next_it) {
+                const int k = next_it;
+                const bool cheb = k > 2;                   // abstract_filters.py:219-221
+                EpiPoly64 epi;
+                epi.a = cheb ? 2.0 : 1.0;
+                epi.b = cheb ? -1.0 : 0.0;
+                epi.c = coeff(k);
+                epi.term = term;
+                epi.term_out = tbuf[k & 1];
+                epi.r = res64.p;
+                epi.err_linf = (cfg->err_kind == PGH_ERR_LINF);
+                {
+                    ProfScope prof(PGH_K_SPMV);
+                    k_spmv_merge<kIPT, double, EpiPoly64><<<sg.main_grid, WG, 0, r.stream>>>(v, epi, term, g_state, psum, pdel);
+                }
+                {
+                    ProfScope prof(PGH_K_FIXUP);
+                    k_spmv_fixup<double, EpiPoly64><<<sg.fix_grid, WG, 0, r.stream>>>(v, epi, g_state, psum + sg.main_grid, pdel + sg.main_grid);
+                }
+                const int chk_it = k + 1;
+                const int check = (cfg->err_kind != PGH_ERR_ITERS) && (chk_it < max_iters) && (chk_it % cfg->end_modulo == 0);
+                {
+                    ProfScope prof(PGH_K_FINAL);
+                    k_step_close<<<1, WG, 0, r.stream>>>(g_state, psum, sg.total(), pdel, sg.total(), 0, check, cfg->err_kind, cfg->tol, n,
+                                                         nullptr, g_progress_dev);
+                }
+                term = tbuf[k & 1];
+            }
+            PGH_HIP(hipGetLastError());
+            if (!poll) {
+                PGH_TRY(fetch_state());
+                done = g_state_host->done != 0;
+            }
+        }
+        PGH_TRY(fetch_state());
+        spmv = g_state_host->steps;
+        converged = g_state_host->converged != 0;
+        err = g_state_host->steps > 0 ? g_state_host->err : err;
+        it = 2 + spmv;
+    }
+    if (n > 0) k_f64_to_f32<<<cgrid, WG, 0, r.stream>>>(res64.p, result->data, n, cfg->out_scale);
+    PGH_HIP(hipGetLastError());
+    PGH_TRY(timer.stop(&res->loop_ms));
+    res->iterations = it;
+    res->converged = converged ? 1 : 0;
+    res->spmv_count = spmv;
+    res->last_error = err;
+    return 0;
+}
+
+}  // namespace
+
+// SymmetricAbsorbingRandomWalks (adhoc.py:317-369).  With deg = degrees(M) and absorption a = (1 + sqrt(1 + 4 deg)) / 2
+// (adhoc.py:349-350) the formula  conv(r / a, M) * deg / (a + deg) + p * a / (a + deg)  (adhoc.py:351-353,362-364) is the
+// absorbing-walk epilogue ((M^T x) deg + p lam) / (lam + deg) with lam = a, applied to the pre-scaled iterate x = r / a.
+namespace {
+__global__ void k_sarw_vectors(const float* __restrict__ deg, int64_t n, float* __restrict__ lam, float* __restrict__ left) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a = (1.0 + sqrt(1.0 + 4.0 * (double)deg[i])) * 0.5;
+        lam[i] = (float)a;
+        left[i] = (float)(1.0 / a);
+    }
+}
+}  // namespace
+
+extern "C" int pgh_sarw_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    PGH_CHECK(g && p && ranks && cfg && res, "pgh_sarw_run: null argument");
+    PGH_CHECK(p->n == g->n_cols && g->n_rows == g->n_cols, "pgh_sarw_run: shape mismatch");
+    PGH_CHECK(g->bsf.enabled, "pgh_sarw_run: the graph has no blocked layout");
+    const int64_t n = g->n_cols;
+    DevF32 lam, left;
+    PGH_TRY(lam.alloc(n));
+    PGH_TRY(left.alloc(n));
+    if (n > 0) k_sarw_vectors<<<residual_grid(n), WG, 0, rt().stream>>>(g->degrees, n, lam.p, left.p);
+    PGH_HIP(hipGetLastError());
+    EpiParams ep{};
+    ep.a = 1.0;
+    ep.v = p->data;
+    ep.deg = g->degrees;
+    ep.lam = lam.p;
+    const int rc = recursive_run<EPI_ABSORB>(g, ep, ranks, cfg, res, left.p);
+    PGH_HIP(hipStreamSynchronize(rt().stream));        // lam / left go back to the pool on return
+    return rc;
+}
+
 // Closed-form filters: result_k = result_{k-1} + c_k * term_k, term_{k+1} = a * M^T term_k + b * term_k.
 // The reference accumulates first and multiplies afterwards (abstract_filters.py:254-256), which costs one
 // trailing, unused SpMV per run; here step k computes term_{k+1} AND folds it into the result, so the
@@ -1113,6 +1344,10 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
     PGH_CHECK(g->n_rows == g->n_cols && p->n == n && result->n == n, "pgh_poly_run: shape mismatch");
     PGH_CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
     memset(res, 0, sizeof(*res));
+    // the reference's "chebyshev" recurrence amplifies rounding noise: f64 route (PGH_CHEB_F32=1 keeps it on the f32
+    // kernels for measurements)
+    if (chebyshev && !(getenv("PGH_CHEB_F32") != nullptr && atoi(getenv("PGH_CHEB_F32")) != 0))
+        return poly_run_f64(g, p, coeffs, num_coeffs, result, cfg, res);
     auto coeff = [&](int it) -> double { return (it >= 1 && it <= num_coeffs) ? coeffs[it - 1] : 0.0; };
     const int max_iters = cfg->max_iters;
     LoopTimer timer;

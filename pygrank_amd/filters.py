@@ -110,15 +110,6 @@ class GraphFilter(NodeRanking):
     def _step(self, M, personalization, ranks, *args, **kwargs):
         raise Exception("Use a derived class of GraphFilter that implements the _step method")
 
-    def references(self):
-        return ["graph filter \\cite{ortega2018graph}"]
-
-    def cite(self):
-        ret = super().cite()
-        if isinstance(self.personalization_transform, Tautology) and self.personalization_transform.ranker is None:
-            return ret
-        return self.personalization_transform.cite() + "\n  passed to " + ret
-
     def __add__(self, other):                                                     # abstract_filters.py:86-95
         if isinstance(other, ConvergenceManager):
             self.convergence = other
@@ -179,12 +170,6 @@ class RecursiveGraphFilter(GraphFilter):
                               last_error=res.last_error, loop_ms=res.loop_ms)
         self.convergence.finish_device_loop(res.iterations, res.converged)
         return True
-
-    def references(self):
-        refs = super().references()
-        if self.converge_to_eigenvectors:
-            refs += ["unbiased eigenvector convergence \\cite{krasanakis2018venuerank}"]
-        return refs
 
 
 class PageRank(RecursiveGraphFilter):
@@ -263,12 +248,6 @@ class PageRank(RecursiveGraphFilter):
             out.set_cols(start, R)
         return out
 
-    def references(self):
-        refs = super().references()
-        refs[0] = "personalized PageRank \\cite{page1999pagerank}"
-        refs.insert(1, f"diffusion rate {self.alpha:.3f}")
-        return refs
-
 
 class AbsorbingWalks(RecursiveGraphFilter):
     """adhoc.py:125-174: partially absorbing random walks."""
@@ -301,10 +280,39 @@ class AbsorbingWalks(RecursiveGraphFilter):
         lam = (to_signal(personalization.graph, absorption) * ((1 - self.alpha) / self.alpha)).np
         return self._run_recursive(L.lib().pgh_absorb_run, _device_graph(M), cfg, ranks, p, lam)
 
-    def references(self):
-        refs = super().references()
-        refs[0] = "partially absorbing random walks \\cite{wu2012learning}"
-        return refs
+
+class SymmetricAbsorbingRandomWalks(RecursiveGraphFilter):
+    """adhoc.py:317-369: symmetric partially absorbing random walks.  With d = degrees(M) and the per-node absorption
+    a = (1 + sqrt(1 + 4 d)) / 2 a step is ``conv(ranks / a, M) * d / (a + d) + personalization * a / (a + d)``
+    (``alpha`` is accepted for signature compatibility and, as in the reference, does not enter the formula)."""
+
+    def __init__(self, alpha=0.5, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.alpha = alpha
+
+    def _start(self, M, personalization, ranks, **kwargs):                        # adhoc.py:348-353
+        d = backend.degrees(M)
+        a = ((d * 4 + 1) ** 0.5 + 1) / 2
+        self._walk = dict(pre=1. / a, post=d / (a + d), skew=a / (a + d))
+
+    def _end(self, *args, **kwargs):
+        super()._end(*args, **kwargs)
+        self._walk = None
+
+    def _formula(self, M, personalization, ranks, *args, **kwargs):               # adhoc.py:362-364
+        w = self._walk
+        return backend.conv(ranks * w["pre"], M) * w["post"] + personalization * w["skew"]
+
+    def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
+        if args or kwargs or not self._plain_quotient() or type(self)._formula is not SymmetricAbsorbingRandomWalks._formula \
+                or type(self)._step is not RecursiveGraphFilter._step or type(self)._start is not SymmetricAbsorbingRandomWalks._start:
+            return False
+        cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), out_scale)
+        p = personalization.np
+        g = _device_graph(M)
+        if not isinstance(p, DeviceVector) or g is None or "row-major" in g.format():     # PGH_FORMAT=csr: generic route
+            return False
+        return self._run_recursive(L.lib().pgh_sarw_run, g, cfg, ranks, p)
 
 
 class LowPassRecursiveGraphFilter(GraphFilter):
@@ -364,14 +372,6 @@ class ClosedFormGraphFilter(GraphFilter):
         self.coefficient_type = coefficient_type.lower()
         self.optimization_dict = optimization_dict
         self._active_dict = None
-
-    def references(self):
-        refs = super().references()
-        if self.coefficient_type == "chebyshev":
-            refs.append("Chebyshev coefficients \\cite{yu2021chebyshev}")
-        if self.optimization_dict is not None:
-            refs.append("dictionary-based hashing \\cite{krasanakis2022pygrank}")
-        return refs
 
     def _start(self, M, personalization, ranks, *args, **kwargs):                 # abstract_filters.py:196-213
         self.coefficient = None
@@ -487,12 +487,6 @@ class HeatKernel(ClosedFormGraphFilter):
     def _coefficient(self, previous_coefficient):                                 # adhoc.py:113-116
         return 1. if previous_coefficient is None else (previous_coefficient * self.t / (self.convergence.iteration + 1))
 
-    def references(self):
-        refs = super().references()
-        refs[0] = "HeatKernel \\cite{chung2007heat}"
-        refs.insert(1, f"emphasis on {self.t}-hop distances")
-        return refs
-
 
 class PageRankClosed(ClosedFormGraphFilter):
     """adhoc.py:63-90."""
@@ -504,8 +498,4 @@ class PageRankClosed(ClosedFormGraphFilter):
     def _coefficient(self, previous_coefficient):                                 # adhoc.py:83-84
         return 1. if previous_coefficient is None else (previous_coefficient * self.alpha)
 
-    def references(self):
-        refs = super().references()
-        refs[0] = "polynomial personalized PageRank \\cite{page1999pagerank}"
-        refs.insert(1, f"diffusion rate {self.alpha:.3f}")
-        return refs
+

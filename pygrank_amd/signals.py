@@ -195,27 +195,11 @@ class NodeRanking:
     def propagate(self, graph, features, *args, **kwargs):   # signals.py:225-226
         return backend.combine_cols([self.rank(graph, col, *args, **kwargs)._np for col in backend.separate_cols(features)])
 
-    def references(self):
-        return ["unknown node ranking algorithm"]
-
-    def cite(self):
-        refs = self.references()
-        ret = refs[0]
-        if len(refs) > 1:
-            ret += " with " + ", ".join(refs[1:-1])
-            if len(refs) > 2:
-                ret += " and "
-            ret += refs[-1]
-        return ret
-
     def __and__(self, other):
         return _Sum(self, other)
 
     def __invert__(self):
         return _Negation(self)
-
-    def __str__(self):
-        return self.cite()
 
 
 class _Negation(NodeRanking):                              # signals.py:252-264
@@ -225,9 +209,6 @@ class _Negation(NodeRanking):                              # signals.py:252-264
     def rank(self, graph=None, personalization=None, *args, **kwargs):
         return -self.ranker.rank(graph, personalization, *args, **kwargs)
 
-    def cite(self):
-        return "negative of " + self.ranker.cite()
-
 
 class _Sum(NodeRanking):                                   # signals.py:267-278
     def __init__(self, ranker1, ranker2):
@@ -236,9 +217,6 @@ class _Sum(NodeRanking):                                   # signals.py:267-278
     def rank(self, graph=None, personalization=None, *args, **kwargs):
         return self.ranker1.rank(graph, personalization, *args, **kwargs) + \
             self.ranker2(graph, personalization, *args, **kwargs)
-
-    def cite(self):
-        return "Add " + self.ranker1.cite() + "\nand " + self.ranker2.cite()
 
 
 def to_signal(graph, obj):

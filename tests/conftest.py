@@ -55,13 +55,12 @@ def oracle_build_dir():
 def host_engine(oracle_build_dir):
     """Routes pygrank_amd's ctypes binding to the host test double (oracle/host_abi.cpp) for CPU tests of
     the host-side Python.  The product never does this."""
-    import ctypes
     import pygrank_amd as pg
-    from pygrank_amd import _lib
-    _lib._install_test_double(ctypes.CDLL(os.path.join(oracle_build_dir, "libpgh_host_oracle.so")))
+    import host_double
+    host_double.install(os.path.join(oracle_build_dir, "libpgh_host_oracle.so"))
     pg.load_backend("hip")
     yield pg
-    _lib._remove_test_double()
+    host_double.remove()
 
 
 @pytest.fixture(scope="session")
@@ -69,7 +68,6 @@ def gpu_engine():
     """The real engine: libpgh_hip.so on an MI355X (tests marked gpu)."""
     import pygrank_amd as pg
     from pygrank_amd import _lib
-    assert not _lib._is_test_double
     pg.load_backend("hip")
     assert _lib.runtime_name().startswith("hip:")
     return pg

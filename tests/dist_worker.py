@@ -24,7 +24,9 @@ def main():
         torch.cuda.set_device(device)
         _lib.ensure_init(device)
     else:
-        _lib._install_test_double(ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libpgh_host_oracle.so")))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import host_double
+        host_double.install()
     pg.load_backend("hip")
     dist.init_process_group(backend=os.environ.get("PGH_DIST_BACKEND", "nccl" if on_gpu else "gloo"))
     rank, world = dist.get_rank(), dist.get_world_size()

@@ -108,6 +108,11 @@ CASES = [
     ("rmat12/heat_taylor", "rmat12_sym", "heat", dict(**_HK)),
     ("rmat12/heat_cheb", "rmat12_sym", "heat", dict(coefficient_type="chebyshev", **_HK)),
     ("rmat12/absorbing_085", "rmat12_sym", "absorbing", dict(alpha=0.85, tol=1e-9, max_iters=1000)),
+    # ---- SymmetricAbsorbingRandomWalks (adhoc.py:317-369) ----
+    ("er10k/sarw_default", "er10k", "sarw", dict(max_iters=1000)),
+    ("rmat10/sarw_l1", "rmat10_dir", "sarw", dict(error_type="l1", tol=1e-7, max_iters=1000)),
+    ("rmat12/sarw_tol1e-9", "rmat12_sym", "sarw", dict(tol=1e-9, max_iters=1000)),
+    ("w300/sarw_noquot", "weighted300", "sarw", dict(use_quotient=False, tol=1e-10, max_iters=1000)),
     # ---- weighted digraph, non-uniform personalization (norm preserved) ----
     ("w300/pagerank_default", "weighted300", "pagerank", dict(alpha=0.85)),
     ("w300/pagerank_tol1e-10", "weighted300", "pagerank", dict(alpha=0.85, tol=1e-10, max_iters=1000)),

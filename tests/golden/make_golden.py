@@ -30,6 +30,7 @@ ALGO = {
     "pagerank_closed": pg.PageRankClosed,
     "absorbing": pg.AbsorbingWalks,
     "lowpass": pg.LowPassRecursiveGraphFilter,
+    "sarw": pg.SymmetricAbsorbingRandomWalks,
 }
 
 

@@ -66,15 +66,16 @@ def test_product_path_fails_loudly_without_gpu(built_lib):
 
 
 def test_product_refuses_foreign_runtime(oracle_build_dir):
-    """_lib.ensure_init only accepts the hip runtime unless a test explicitly installed the double."""
+    """_lib.ensure_init only drives a library whose runtime name starts with "hip:" (tests widen ACCEPTED_RUNTIMES from the
+    outside, tests/host_double.py; the product has no such switch)."""
     import ctypes
     from pygrank_amd import _lib
-    saved = (_lib._lib, _lib._is_test_double, _lib._initialised)
+    saved = (_lib._lib, _lib._initialised, _lib.ACCEPTED_RUNTIMES)
     try:
         _lib._lib = _lib._bind(ctypes.CDLL(os.path.join(oracle_build_dir, "libpgh_host_oracle.so")))
-        _lib._is_test_double = False
         _lib._initialised = False
+        _lib.ACCEPTED_RUNTIMES = ("hip:",)
         with pytest.raises(_lib.EngineError):
             _lib.ensure_init()
     finally:
-        _lib._lib, _lib._is_test_double, _lib._initialised = saved
+        _lib._lib, _lib._initialised, _lib.ACCEPTED_RUNTIMES = saved

@@ -19,7 +19,6 @@ pytestmark = pytest.mark.gpu
 def test_engine_is_the_hip_library(gpu_engine):
     from pygrank_amd import _lib
     assert _lib.runtime_name() == "hip:gfx950"
-    assert not _lib._is_test_double
     import ctypes
     buf = ctypes.create_string_buffer(256)
     _lib.check(_lib.lib().pgh_device_name(buf, 256))

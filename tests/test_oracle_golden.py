@@ -30,6 +30,8 @@ def run_oracle(A, directed, p, algo, kwargs):
         return orc.absorbing_walks(M, p, **kwargs)
     if algo == "lowpass":
         return orc.low_pass_recursive(M, p, kwargs.pop("params"), **kwargs)
+    if algo == "sarw":
+        return orc.symmetric_absorbing_walks(M, p, **kwargs)
     raise KeyError(algo)
 
 
