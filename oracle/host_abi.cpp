@@ -375,6 +375,8 @@ int pgh_mat_set_cols(pgh_mat_t m, int32_t first, pgh_mat_t src) {
 int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
                        const double* data, int, pgh_graph_t* out) {
     CHECK(indptr && indptr[0] == 0 && indptr[n_rows] == nnz, "pgh_graph_from_csr: indptr does not match nnz");
+    for (int64_t r = 0; r < n_rows; ++r)
+        CHECK(indptr[r] <= indptr[r + 1] && indptr[r] >= 0 && indptr[r + 1] <= nnz, "pgh_graph_from_csr: indptr is not non-decreasing within [0, nnz]");
     pgh_graph_s* g = new pgh_graph_s();
     g->n_rows = n_rows;
     g->n_cols = n_cols;

@@ -255,6 +255,24 @@ __global__ void k_fill_f64(double* p, int64_t n, double v) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// scipy raises on a CSR whose row pointers decrease or whose column indices leave [0, n_cols); an unchecked one would
+// make k_split_keys write past rowptr and the radix sort drop key bits.  bit 0: indptr not monotone within [0, nnz],
+// bit 1: a column index out of range.
+__global__ void k_validate_csr(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t n_rows, int64_t n_cols,
+                               int64_t nnz, unsigned int* __restrict__ bad) {
+    unsigned int mine = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows; i += stride) {
+        const int64_t a = indptr[i], b = indptr[i + 1];
+        if (a > b || a < 0 || b > nnz) mine |= 1u;
+    }
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += stride) {
+        const int32_t c = indices[k];
+        if (c < 0 || (int64_t)c >= n_cols) mine |= 2u;
+    }
+    if (mine) atomicOr(bad, mine);
+}
+
 // Shared implementation of the uploads.
 //   factored == false: data holds the values of M.
 //   factored == true : data holds the weights W (null = all ones) and M = diag(left) W diag(right); the scale vectors
@@ -287,6 +305,17 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
             PGH_HIP(hipMemcpyAsync(d_indices.p, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, r.stream));
             if (data != nullptr) PGH_HIP(hipMemcpyAsync(d_data.p, data, sizeof(double) * nnz, hipMemcpyHostToDevice, r.stream));
             else k_fill_f64<<<blocks_for(nnz), kBlock, 0, r.stream>>>(d_data.p, nnz, 1.0);
+        }
+        {
+            DevBuf<unsigned int> bad;
+            PGH_TRY(bad.alloc(1));
+            PGH_HIP(hipMemsetAsync(bad.p, 0, sizeof(unsigned int), r.stream));
+            k_validate_csr<<<blocks_for(nnz > n_rows ? nnz : n_rows), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, n_rows, n_cols, nnz, bad.p);
+            unsigned int h_bad = 0;
+            PGH_HIP(hipMemcpyAsync(&h_bad, bad.p, sizeof(unsigned int), hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipStreamSynchronize(r.stream));
+            PGH_CHECK((h_bad & 1u) == 0, "pgh_graph_from_csr: indptr is not non-decreasing within [0, nnz]");
+            PGH_CHECK((h_bad & 2u) == 0, "pgh_graph_from_csr: a column index lies outside [0, n_cols)");
         }
         PGH_HIP(hipMalloc(&g->degrees, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
         PGH_HIP(hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_cols + 1)));

@@ -1081,6 +1081,11 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             const int it = k + 1;
             const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
             hipStream_t main_stream = r.stream;
+            struct StreamGuard {                     // whatever happens below, the engine's stream is put back
+                Runtime& rt_;
+                hipStream_t saved;
+                ~StreamGuard() { rt_.stream = saved; }
+            } guard{r, main_stream};
             if (overlap) {
                 PGH_HIP(hipEventRecord(g_ev_combined, main_stream));
                 PGH_HIP(hipStreamWaitEvent(g_side_stream, g_ev_combined, 0));

@@ -166,72 +166,83 @@ class DistributedPageRank:
             ints = bufs.state_host.view(torch.int32)
             return int(ints[6]), int(ints[7]), int(ints[8]), float(bufs.state_host[0])
 
-        with stream_ctx:
-            # ---- prologue of GraphFilter.rank (abstract_filters.py:52-56): global L1 norm, x0 = p / norm
-            norm = self._all_reduce(bufs, dist, p_local.abssum(), dist.ReduceOp.SUM)
-            if norm == 0:
-                self.iteration = 0
-                return p_local
-            p = p_local / norm
-            cur = 0
-            L.check(lib.pgh_vec_copy(bufs.v_y[cur]._h, p._h))
-            L.check(lib.pgh_dist_prescale(g._h, bufs.v_y[cur]._h, bufs.v_xg_local._h))
-            bufs.all_gather(dist)
-            L.check(lib.pgh_dist_state_init(state))
-            t0 = time.perf_counter()
-            it, spmv, converged = 1, 0, False       # `it` = ConvergenceManager.iteration of the pending has_converged call
-            pending_flag = None                     # event recorded after the last residual check
+        try:
+            with stream_ctx:
+                return self._rank_on_stream(pgraph, p_local, bufs, dist, lib, g, device, kind, tol, state, sum_view, err_view,
+                                            err_op, local_kind, read_state, torch)
+        finally:
+            if device.type == "cuda":
+                # every later single-GPU call of this process goes back to the engine's own stream
+                L.check(lib.pgh_sync())
+                L.check(lib.pgh_set_stream(None))
+
+    def _rank_on_stream(self, pgraph, p_local, bufs, dist, lib, g, device, kind, tol, state, sum_view, err_view, err_op,
+                        local_kind, read_state, torch):
+        # ---- prologue of GraphFilter.rank (abstract_filters.py:52-56): global L1 norm, x0 = p / norm
+        norm = self._all_reduce(bufs, dist, p_local.abssum(), dist.ReduceOp.SUM)
+        if norm == 0:
+            self.iteration = 0
+            return p_local
+        p = p_local / norm
+        cur = 0
+        L.check(lib.pgh_vec_copy(bufs.v_y[cur]._h, p._h))
+        L.check(lib.pgh_dist_prescale(g._h, bufs.v_y[cur]._h, bufs.v_xg_local._h))
+        bufs.all_gather(dist)
+        L.check(lib.pgh_dist_state_init(state))
+        t0 = time.perf_counter()
+        it, spmv, converged = 1, 0, False       # `it` = ConvergenceManager.iteration of the pending has_converged call
+        pending_flag = None                     # event recorded after the last residual check
+        partial_enqueued = False
+        while it < self.max_iters:                                             # convergence.py:86
+            nxt = 1 - cur
+            if not partial_enqueued:
+                L.check(lib.pgh_dist_partial(g._h, bufs.v_xg_full._h, state))
             partial_enqueued = False
-            while it < self.max_iters:                                             # convergence.py:86
-                nxt = 1 - cur
-                if not partial_enqueued:
-                    L.check(lib.pgh_dist_partial(g._h, bufs.v_xg_full._h, state))
-                partial_enqueued = False
-                if pending_flag is not None:
-                    # the check that followed the previous step: its flag is on its way while the partial sums run
-                    if device.type == "cuda":
-                        pending_flag.synchronize()
-                    pending_flag = None
-                    if int(bufs.state_host.view(torch.int32)[6]):
-                        converged = True            # the partial sums just enqueued were no-ops (done was already set)
-                        break
-                L.check(lib.pgh_dist_combine(g._h, p._h, self.alpha, bufs.v_y[nxt]._h, bufs.v_xg_local._h, state))
-                dist.all_reduce(sum_view)
-                L.check(lib.pgh_dist_close_sum(state, 1 if self.use_quotient else 0))
-                bufs.all_gather(dist)                                              # next gather vector over xGMI
-                cur = nxt
-                spmv += 1
-                it += 1
-                if it >= self.max_iters:
-                    break
-                if kind != L.ERR_ITERS and it % self.end_modulo == 0:
-                    L.check(lib.pgh_dist_residual(local_kind, bufs.v_y[cur]._h, bufs.v_y[1 - cur]._h, state))
-                    dist.all_reduce(err_view, op=err_op)
-                    L.check(lib.pgh_dist_close_err(state, kind, tol, pgraph.n))
-                    bufs.state_host.copy_(bufs.state, non_blocking=True)
-                    if device.type == "cuda":
-                        pending_flag = torch.cuda.Event()
-                        pending_flag.record(self._stream)
-                        # speculate: the next partial sums only need the all-gather above
-                        L.check(lib.pgh_dist_partial(g._h, bufs.v_xg_full._h, state))
-                        partial_enqueued = True
-                    else:
-                        pending_flag = True
-            if pending_flag is not None and not converged:
+            if pending_flag is not None:
+                # the check that followed the previous step: its flag is on its way while the partial sums run
                 if device.type == "cuda":
                     pending_flag.synchronize()
-                converged = bool(int(bufs.state_host.view(torch.int32)[6]))
-            done, steps, conv, scale = read_state()
-            self.elapsed = time.perf_counter() - t0
-            assert steps == spmv, (steps, spmv)
-            self.iteration, self.spmv, self.converged = it, spmv, converged
-            self.last_error = float(bufs.state_host[6])
-            if not converged and self.error_type != "iters" and it >= self.max_iters:
-                raise Exception("Could not converge within " + str(self.max_iters) + " iterations")
-            factor = scale * (norm if self.preserve_norm else 1.0)                 # abstract_filters.py:63-64
-            out = bufs.v_y[cur] * factor
-            L.check(lib.pgh_sync())
-            return out
+                pending_flag = None
+                if int(bufs.state_host.view(torch.int32)[6]):
+                    converged = True            # the partial sums just enqueued were no-ops (done was already set)
+                    break
+            L.check(lib.pgh_dist_combine(g._h, p._h, self.alpha, bufs.v_y[nxt]._h, bufs.v_xg_local._h, state))
+            dist.all_reduce(sum_view)
+            L.check(lib.pgh_dist_close_sum(state, 1 if self.use_quotient else 0))
+            bufs.all_gather(dist)                                              # next gather vector over xGMI
+            cur = nxt
+            spmv += 1
+            it += 1
+            if it >= self.max_iters:
+                break
+            if kind != L.ERR_ITERS and it % self.end_modulo == 0:
+                L.check(lib.pgh_dist_residual(local_kind, bufs.v_y[cur]._h, bufs.v_y[1 - cur]._h, state))
+                dist.all_reduce(err_view, op=err_op)
+                L.check(lib.pgh_dist_close_err(state, kind, tol, pgraph.n))
+                bufs.state_host.copy_(bufs.state, non_blocking=True)
+                if device.type == "cuda":
+                    pending_flag = torch.cuda.Event()
+                    pending_flag.record(self._stream)
+                    # speculate: the next partial sums only need the all-gather above
+                    L.check(lib.pgh_dist_partial(g._h, bufs.v_xg_full._h, state))
+                    partial_enqueued = True
+                else:
+                    pending_flag = True
+        if pending_flag is not None and not converged:
+            if device.type == "cuda":
+                pending_flag.synchronize()
+            converged = bool(int(bufs.state_host.view(torch.int32)[6]))
+        done, steps, conv, scale = read_state()
+        self.elapsed = time.perf_counter() - t0
+        assert steps == spmv, (steps, spmv)
+        self.iteration, self.spmv, self.converged = it, spmv, converged
+        self.last_error = float(bufs.state_host[6])
+        if not converged and self.error_type != "iters" and it >= self.max_iters:
+            raise Exception("Could not converge within " + str(self.max_iters) + " iterations")
+        factor = scale * (norm if self.preserve_norm else 1.0)                 # abstract_filters.py:63-64
+        out = bufs.v_y[cur] * factor
+        L.check(lib.pgh_sync())
+        return out
 
 
 # ----------------------------------------------------------------------------------------------------------------

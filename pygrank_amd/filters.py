@@ -64,6 +64,10 @@ class GraphFilter(NodeRanking):
         personalization = to_signal(personalization, personalization.np / norm)   # :55
         ranks = to_signal(personalization,
                           backend.copy(personalization.np) if warm_start is None else warm_start)   # :56
+        if warm_start is not None:
+            # the reference never writes into the caller's warm_start (every step builds a fresh array); the device loops
+            # update their iterate in place, so they get a copy
+            ranks = to_signal(personalization, backend.copy(ranks.np))
         M = self.preprocessor(self._prepare_graph(personalization.graph, personalization, *args, **kwargs))
         self.convergence.start()
         out_scale = norm if self.preserve_norm else 1.0

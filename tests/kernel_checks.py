@@ -107,6 +107,31 @@ def check_upload_transpose_degrees_spmv(pg):
         assert np.all(np.abs(y - ref) <= 2.5 * EPS32 * scale + 1e-30), name
 
 
+def check_upload_rejects_invalid_csr(pg):
+    """scipy (what the reference hands its matrices to) refuses a CSR whose column indices leave [0, n_cols) or whose row
+    pointers decrease; so does the engine, instead of writing outside its row-pointer array."""
+    import ctypes as C
+    from pygrank_amd import _lib as L
+    L.ensure_init()
+    lib = L.lib()
+
+    def upload(indptr, indices, data, n_rows, n_cols):
+        ip, ix, dt = np.asarray(indptr, np.int64), np.asarray(indices, np.int32), np.asarray(data, np.float64)
+        h = L.c_graph()
+        rc = lib.pgh_graph_from_csr(n_rows, n_cols, len(ix), ip.ctypes.data_as(C.c_void_p), ix.ctypes.data_as(C.c_void_p),
+                                    dt.ctypes.data_as(C.c_void_p), 0, C.byref(h))
+        if rc == 0:
+            lib.pgh_graph_destroy(h)
+        return rc, lib.pgh_last_error()
+    assert upload([0, 2, 3], [0, 1, 2], [1., 1., 1.], 2, 3)[0] == 0
+    rc, msg = upload([0, 2, 3], [0, 3, 2], [1., 1., 1.], 2, 3)          # index == n_cols
+    assert rc != 0 and b"column index" in msg
+    rc, msg = upload([0, 2, 3], [0, -1, 2], [1., 1., 1.], 2, 3)         # negative index
+    assert rc != 0 and b"column index" in msg
+    rc, msg = upload([0, 3, 2, 3], [0, 1, 2], [1., 1., 1.], 3, 3)       # decreasing row pointers
+    assert rc != 0 and b"indptr" in msg
+
+
 def check_fused_steps(pg):
     from pygrank_amd import _lib as L
     from pygrank_amd.device import DeviceVector
