@@ -108,6 +108,7 @@ CASES = [
     ("rmat12/heat_taylor", "rmat12_sym", "heat", dict(**_HK)),
     ("rmat12/heat_cheb", "rmat12_sym", "heat", dict(coefficient_type="chebyshev", **_HK)),
     ("rmat12/absorbing_085", "rmat12_sym", "absorbing", dict(alpha=0.85, tol=1e-9, max_iters=1000)),
+    ("rmat12/pagerank_eigenvectors", "rmat12_sym", "pagerank", dict(alpha=0.85, converge_to_eigenvectors=True, tol=1e-9, max_iters=2000)),
     # ---- SymmetricAbsorbingRandomWalks (adhoc.py:317-369) ----
     ("er10k/sarw_default", "er10k", "sarw", dict(max_iters=1000)),
     ("rmat10/sarw_l1", "rmat10_dir", "sarw", dict(error_type="l1", tol=1e-7, max_iters=1000)),

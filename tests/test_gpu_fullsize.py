@@ -1,0 +1,99 @@
+"""The BASELINE.json configurations at their FULL size on the real engine ("configs not exercised at their
+size"): RMAT scale 23, edge factor 16 (8.4 M nodes, 131 M edges), the production layout the default heuristics choose
+(4 column blocks, 16-bit hot-only stream, propagation-blocking image of the cold tail).
+
+  configs[1]  PPR alpha = 0.85, L1 <= 1e-6     vs the oracle's scipy loop on the engine's own matrix (about 5 s of host time)
+  configs[3]  HeatKernel t = 5, 31 iterations  taylor and chebyshev vs the oracle (about 15 s each), linearity of the filter
+  configs[2]  64 personalizations at once      sampled columns equal single-seed runs, mass conservation, per-column stops
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCALE, EF = 23, 16
+
+
+@pytest.fixture(scope="module")
+def big(gpu_engine):
+    import scipy.sparse as sp
+    from pygrank_amd.synthetic import rmat_graph
+    pg = gpu_engine
+    adj = rmat_graph(SCALE, EF, seed=0, normalization="col", a=0.57, b=0.19, c=0.19)
+    g = adj.array
+    fmt = g.format()
+    assert "propagation-blocking image" in fmt and "(2 B/edge)" in fmt and "4 column blocks" in fmt, fmt
+    MT = g.download_transposed()
+    M = sp.csr_array(MT.T.astype(np.float64))          # the engine's own (f32-rounded) matrix: the oracle runs on it
+    deg = np.asarray(pg.degrees(g))
+    cand = np.flatnonzero(deg > 0)
+
+    def seeds(k):
+        rng = np.random.default_rng(1 + k)
+        p = np.zeros(g.shape[0])
+        p[np.sort(rng.choice(cand, 100, replace=False))] = 1.0
+        return p
+    return dict(pg=pg, adj=adj, g=g, M=M, seeds=seeds, n=g.shape[0], nnz=g.nnz)
+
+
+def _rel(got, want):
+    return float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+
+
+def test_cfg2_ppr_scale23_vs_oracle(big):
+    from oracle import ref_loops as orc
+    pg = big["pg"]
+    p = big["seeds"](0)
+    ranker = pg.PageRank(alpha=0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+    got = np.asarray(ranker.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, want_iters = orc.pagerank(big["M"], p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
+    assert ranker.convergence.iteration == want_iters
+    assert _rel(got, want) <= 1e-6
+    assert abs(got.sum() - p.sum()) <= 1e-5 * p.sum()          # preserve_norm: the L1 norm of the input comes back
+    # the reference's default stopping rule (Mabs, tol 1e-6) at this size: the oracle agrees on the iteration count
+    dflt = pg.PageRank(alpha=0.85)
+    got_d = np.asarray(dflt.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want_d, iters_d = orc.pagerank(big["M"], p, alpha=0.85)
+    assert dflt.convergence.iteration == iters_d and _rel(got_d, want_d) <= 1e-6
+
+
+@pytest.mark.parametrize("coefficient_type", ["taylor", "chebyshev"])
+def test_cfg4_heat_kernel_scale23_vs_oracle(big, coefficient_type):
+    from oracle import ref_loops as orc
+    pg = big["pg"]
+    p, q = big["seeds"](1), big["seeds"](2)
+    hk = pg.HeatKernel(5, coefficient_type=coefficient_type, error_type="iters", max_iters=31)
+    got = np.asarray(hk.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    assert hk.convergence.iteration == 31 and hk.last_loop["spmv"] == 29
+    want, iters = orc.heat_kernel(big["M"], p, t=5, coefficient_type=coefficient_type, error_type="iters", max_iters=31)
+    assert iters == 31
+    assert _rel(got, want) <= 1e-6
+    # linearity of a polynomial filter (size-independent property): H(p + 2 q) = H(p) + 2 H(q); preserve_norm rescales every
+    # run by its own input norm, so the identity holds for the returned vectors as they are
+    hq = np.asarray(hk.rank(big["adj"], q.copy()).np, dtype=np.float64)
+    hpq = np.asarray(hk.rank(big["adj"], p + 2.0 * q).np, dtype=np.float64)
+    assert _rel(hpq, got + 2.0 * hq) <= (2e-6 if coefficient_type == "taylor" else 1e-6)
+
+
+def test_cfg3_batch64_scale23(big):
+    pg = big["pg"]
+    n = big["n"]
+    b = 64
+    feats = np.zeros((n, b))
+    for j in range(b):
+        feats[:, j] = big["seeds"](10 + j)
+    F = pg.to_primitive(feats)
+    ranker = pg.PageRank(0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+    out = np.asarray(ranker.propagate(big["adj"], F), dtype=np.float64)
+    info = ranker.last_batches[0]
+    assert out.shape == (n, b) and len(info) == b
+    # mass conservation per column (L1 quotient + preserve_norm): every column sums to its 100 seeds
+    assert np.all(np.abs(out.sum(axis=0) - 100.0) <= 1e-3)
+    assert all(c["converged"] for c in info) and len({c["iterations"] for c in info}) >= 1
+    # sampled columns equal the single-seed device loop: same stopping iteration, <= 1e-6 (both are f32 evaluations of the
+    # same loop; the multi-seed kernel adds a row's entries in a different order)
+    for j in (0, 17, 42, 63):
+        single = pg.PageRank(0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+        ref = np.asarray(single.rank(big["adj"], feats[:, j].copy()).np, dtype=np.float64)
+        assert info[j]["iterations"] == single.convergence.iteration, j
+        assert _rel(out[:, j], ref) <= 1e-6, j
