@@ -281,6 +281,16 @@ int pgh_graph_rmat(int32_t scale, int32_t edge_factor, double a, double b, doubl
 int pgh_graph_rmat_part(int32_t scale, int32_t edge_factor, double a, double b, double c, uint64_t seed,
                         int32_t normalization, int32_t symmetrize, int32_t part_rank, int32_t part_count, pgh_graph_t* out);
 
+/* Row-partitioned upload of a CALLER's graph (the counterpart of pgh_graph_rmat_part for matrices that enter through
+ * scipy_sparse_to_backend, specification.py:70-71): every rank relabels the ids with the same permutation (new id ->
+ * original id in `perm`, -1 for padding ids; pygrank_amd/distributed.py partition_scipy derives it from the source counts,
+ * hot-first, dealt round-robin to num_blocks column blocks) and passes the columns [row_begin, row_begin + n_cols_local) of
+ * the relabelled, normalised M -- its rows of M^T -- as host CSR (n_rows x n_cols_local, fp64 values).  n_rows is the padded
+ * id space (a multiple of num_blocks); slices of all ranks are equal-sized.  Vectors of such a graph live in the new id
+ * space (pgh_graph_perm maps back); it is driven through pgh_dist_* like the generated partitions. */
+int pgh_graph_from_csr_part(int64_t n_rows, int64_t n_cols_local, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                            const double* data, int64_t row_begin, int32_t num_blocks, const int32_t* perm, pgh_graph_t* out);
+
 #ifdef __cplusplus
 }
 #endif

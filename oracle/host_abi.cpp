@@ -916,6 +916,19 @@ int pgh_graph_rmat_part(int32_t scale, int32_t ef, double a, double b, double c,
     CHECK(part_count >= 1, "pgh_graph_rmat_part: part_count must be >= 1");
     return rmat_build(scale, ef, a, b, c, seed, normalization, symmetrize, 0, 0, part_rank, part_count, out);
 }
+int pgh_graph_from_csr_part(int64_t n_rows, int64_t n_cols_local, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                            const double* data, int64_t row_begin, int32_t num_blocks, const int32_t* perm, pgh_graph_t* out) {
+    CHECK(perm && num_blocks >= 1 && num_blocks <= 8 && n_rows % num_blocks == 0, "pgh_graph_from_csr_part: bad layout");
+    CHECK(row_begin >= 0 && row_begin + n_cols_local <= n_rows, "pgh_graph_from_csr_part: slice outside the id space");
+    if (pgh_graph_from_csr(n_rows, n_cols_local, nnz, indptr, indices, data, 0, out)) return 1;
+    pgh_graph_s* g = *out;
+    g->row_begin = row_begin;
+    g->part_perm.assign(perm, perm + n_rows);
+    g->gather_blocks = num_blocks;
+    g->gather_blk = n_rows / num_blocks;
+    for (int b = 0; b < 8; ++b) g->gather_base[b] = (int64_t)b * g->gather_blk;
+    return 0;
+}
 int pgh_graph_perm(pgh_graph_t g, int32_t* new_to_old, int64_t* row_begin) {
     if (row_begin) *row_begin = g->row_begin;
     for (int64_t i = 0; i < g->n_rows; ++i) new_to_old[i] = g->part_perm.empty() ? (int32_t)i : g->part_perm[i];

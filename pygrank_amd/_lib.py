@@ -89,6 +89,8 @@ SIGNATURES = {
     "pgh_mat_get_col": (C.c_int, [c_mat, C.c_int32, c_vec]),
     "pgh_graph_from_csr": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(c_graph)]),
+    "pgh_graph_from_csr_part": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                          C.c_void_p, C.POINTER(c_graph)]),
     "pgh_graph_from_factored_csr": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int, C.POINTER(c_graph)]),
     "pgh_graph_from_adjacency": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int,

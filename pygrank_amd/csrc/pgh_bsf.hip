@@ -671,25 +671,50 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     // runs two tiles ahead), the gathers of tile i+1, the arithmetic of tile i.  Three stream register sets and two
     // gather sets rotate without moves: the loop is unrolled six times.
     const int t_last = t_end - 1;
-    Stream s0, s1, s2;
+    // stream register sets (tiles in flight ahead of the gather stage); build parameter for measurements
+#ifndef PGH_STREAM_SETS
+#define PGH_STREAM_SETS 3
+#endif
+    constexpr int NS = PGH_STREAM_SETS;
+    static_assert(NS == 3 || NS == 4 || NS == 6, "the unrolled rotation below is written for 3, 4 or 6 stream sets");
+    Stream s0, s1, s2, s3, s4, s5;
     Gathered g0, g1;
     load_stream(t, s0);
     gather(s0, g0);
     load_stream(min(t + stride, t_last), s1);
     load_stream(min(t + 2 * stride, t_last), s2);
+    if (NS >= 4) load_stream(min(t + 3 * stride, t_last), s3);
+    if (NS >= 6) {
+        load_stream(min(t + 4 * stride, t_last), s4);
+        load_stream(min(t + 5 * stride, t_last), s5);
+    }
 #define PGH_STEP(SL, SG, GN, GC)                             \
-    load_stream(min(t + 3 * stride, t_last), SL);            \
+    load_stream(min(t + NS * stride, t_last), SL);           \
     gather(SG, GN);                                          \
     reduce(GC, t);                                           \
     t += stride;                                             \
     if (t >= t_end) break;
     for (;;) {
-        PGH_STEP(s0, s1, g1, g0)
-        PGH_STEP(s1, s2, g0, g1)
-        PGH_STEP(s2, s0, g1, g0)
-        PGH_STEP(s0, s1, g0, g1)
-        PGH_STEP(s1, s2, g1, g0)
-        PGH_STEP(s2, s0, g0, g1)
+        if (NS == 3) {
+            PGH_STEP(s0, s1, g1, g0)
+            PGH_STEP(s1, s2, g0, g1)
+            PGH_STEP(s2, s0, g1, g0)
+            PGH_STEP(s0, s1, g0, g1)
+            PGH_STEP(s1, s2, g1, g0)
+            PGH_STEP(s2, s0, g0, g1)
+        } else if (NS == 4) {
+            PGH_STEP(s0, s1, g1, g0)
+            PGH_STEP(s1, s2, g0, g1)
+            PGH_STEP(s2, s3, g1, g0)
+            PGH_STEP(s3, s0, g0, g1)
+        } else {
+            PGH_STEP(s0, s1, g1, g0)
+            PGH_STEP(s1, s2, g0, g1)
+            PGH_STEP(s2, s3, g1, g0)
+            PGH_STEP(s3, s4, g0, g1)
+            PGH_STEP(s4, s5, g1, g0)
+            PGH_STEP(s5, s0, g0, g1)
+        }
     }
 #undef PGH_STEP
 }

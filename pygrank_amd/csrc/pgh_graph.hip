@@ -277,9 +277,17 @@ __global__ void k_validate_csr(const int64_t* __restrict__ indptr, const int32_t
 //   factored == false: data holds the values of M.
 //   factored == true : data holds the weights W (null = all ones) and M = diag(left) W diag(right); the scale vectors
 //                      come from the host (left / right) or are evaluated here from W (device_norm = PGH_NORM_*).
+// part (nullable): the matrix is a slice of a globally relabelled graph -- columns [row_begin, row_begin + n_cols) of M in
+// the new id space, i.e. this rank's rows of M^T; the blocked layout then keeps the caller's ids (no relabelling) and
+// uses the column-block count every rank agreed on.
+struct PartSpec {
+    int64_t        row_begin;
+    int32_t        num_blocks;
+    const int32_t* perm;        // host, [n_rows] new id -> original id (-1 = padding)
+};
 int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
                         const double* data, bool factored, const double* left, const double* right, int device_norm,
-                        pgh_graph_t* out) {
+                        pgh_graph_t* out, const PartSpec* part = nullptr) {
     PGH_TRY(ensure_init());
     PGH_CHECK(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "pgh_graph_from_csr: negative size");
     PGH_CHECK(n_rows < 2147483647LL && n_cols < 2147483647LL && nnz < 2147483647LL,
@@ -406,7 +414,14 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
         const char* fmt = getenv("PGH_FORMAT");
         if (fmt == nullptr || std::string(fmt) != "csr") {
             const char* rl = getenv("PGH_RELABEL");
-            const bool relabel = rl == nullptr || atoi(rl) != 0;
+            const bool relabel = part == nullptr && (rl == nullptr || atoi(rl) != 0);
+            const int force_blocks = part != nullptr ? part->num_blocks : 0;
+            if (part != nullptr) {
+                g->row_begin = part->row_begin;
+                PGH_HIP(hipMalloc(&g->part_perm, sizeof(int32_t) * (size_t)(n_rows > 0 ? n_rows : 1)));
+                PGH_HIP(hipMemcpyAsync(g->part_perm, part->perm, sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice, r.stream));
+                PGH_HIP(hipStreamSynchronize(r.stream));
+            }
             if (value_free) {
                 // M^T = diag(right) * W^T * diag(left): the source scale is `left` (rows of M), the output scale `right`
                 if (have_left) {
@@ -418,9 +433,9 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
                     k_f64_to_f32_g<<<blocks_for(n_cols), kBlock, 0, r.stream>>>(d_right.p, g->keep_dst, n_cols);
                 }
                 g->keep_mult = mult_t.release();
-                PGH_TRY(bsf_build(g, nullptr, g->keep_mult, g->keep_src, g->keep_dst, relabel));
+                PGH_TRY(bsf_build(g, nullptr, g->keep_mult, g->keep_src, g->keep_dst, relabel, force_blocks));
             } else {
-                PGH_TRY(bsf_build(g, g->val, nullptr, nullptr, nullptr, relabel));
+                PGH_TRY(bsf_build(g, g->val, nullptr, nullptr, nullptr, relabel, force_blocks));
             }
         }
         return 0;
@@ -440,6 +455,20 @@ extern "C" int pgh_graph_from_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, c
                                   const int32_t* indices, const double* data, int flags, pgh_graph_t* out) {
     (void)flags;
     return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, data, false, nullptr, nullptr, -1, out);
+}
+
+// Row-partitioned upload of a caller's graph (the synthetic counterpart is pgh_graph_rmat_part).
+extern "C" int pgh_graph_from_csr_part(int64_t n_rows, int64_t n_cols_local, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                                       const double* data, int64_t row_begin, int32_t num_blocks, const int32_t* perm,
+                                       pgh_graph_t* out) {
+    PGH_CHECK(perm != nullptr, "pgh_graph_from_csr_part: null permutation");
+    PGH_CHECK(num_blocks == 1 || num_blocks == 2 || num_blocks == 4 || num_blocks == 8, "pgh_graph_from_csr_part: 1, 2, 4 or 8 column blocks");
+    PGH_CHECK(n_rows % num_blocks == 0, "pgh_graph_from_csr_part: the (padded) id space must be a multiple of the column-block count");
+    PGH_CHECK(row_begin >= 0 && row_begin + n_cols_local <= n_rows, "pgh_graph_from_csr_part: slice outside the id space");
+    const char* fmt = getenv("PGH_FORMAT");
+    PGH_CHECK(fmt == nullptr || std::string(fmt) != "csr", "pgh_graph_from_csr_part: partitioned graphs need the blocked layout");
+    PartSpec part{row_begin, num_blocks, perm};
+    return graph_from_csr_impl(n_rows, n_cols_local, nnz, indptr, indices, data, false, nullptr, nullptr, -1, out, &part);
 }
 
 extern "C" int pgh_graph_from_factored_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,

@@ -63,7 +63,10 @@ constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in 
 // k_pb_finish build parameters (tools/build_variants.sh): groups per thread and stream round, rows per thread and epilogue
 // round, whether the next item's first stream round is issued before the current item's epilogue
 #ifndef PGH_FIN_P
-#define PGH_FIN_P 4
+#define PGH_FIN_P 2           // measured at scale 23 (profiles/r02/finish_pg_sweep.log): P x G = 4x4 108-113 us, 4x2 114, 2x4 104, 2x8 108, 6x4 118
+#endif
+#ifndef PGH_FIN_WPE
+#define PGH_FIN_WPE 4         // wavefronts per SIMD the small shape is compiled for (register budget 512 / WPE)
 #endif
 #ifndef PGH_FIN_G
 #define PGH_FIN_G 4
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
 // device-scope atomic and takes a ticket; the last arriver adds the pieces in index order (deterministic whatever the
 // arrival order) and runs the row's epilogue.
 template <int MODE, int NB, int ROWS, int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void k_pb_finish(PbView f, RowSums rs, const float* __restrict__ dst_scale, EpiParams ep,
+__global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb_finish(PbView f, RowSums rs, const float* __restrict__ dst_scale, EpiParams ep,
                                                         const LoopState* __restrict__ state, double* __restrict__ partial_sum,
                                                         double* __restrict__ partial_delta) {
     constexpr int WAVES = THREADS / 64;
@@ -1066,7 +1069,9 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
     double* pdel = r.d_partials + kMaxPartials;
     const bool large = p.bin_rows > kPbBinRows;
     // persistent grid: as many workgroups as the CUs hold at once (LDS: 32 KB x 4 or 128 KB x 1 per CU)
-    int grid = r.num_cus * (large ? 1 : (kPbBThreads > 256 ? 2 : 4));
+    // workgroups a CU holds at once: 4 by LDS (32 KB of row sums each), PGH_FIN_WPE wavefronts per SIMD by registers
+    const int by_regs = PGH_FIN_WPE * 4 / (kPbBThreads / 64);
+    int grid = r.num_cus * (large ? 1 : (by_regs < 4 ? (by_regs < 1 ? 1 : by_regs) : 4));
     if (grid > p.num_items) grid = p.num_items;
     if (grid > kMaxPartials) grid = kMaxPartials;
     if (grid < 1) grid = 1;

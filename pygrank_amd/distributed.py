@@ -33,6 +33,20 @@ class PartitionedGraph:
         self.row_begin = rank * self.n_local
         self._perm = None
 
+    def local_slice(self, vec_original):
+        """This rank's slice (new id order) of a vector given in ORIGINAL ids; padding ids get 0."""
+        perm = self.perm[self.row_begin:self.row_begin + self.n_local]
+        out = np.zeros(self.n_local)
+        ok = perm >= 0
+        out[ok] = np.asarray(vec_original, dtype=np.float64)[perm[ok]]
+        return out
+
+    def scatter_slice(self, slice_new, into_original):
+        """Writes this rank's slice (new id order) into a vector indexed by ORIGINAL ids."""
+        perm = self.perm[self.row_begin:self.row_begin + self.n_local]
+        ok = perm >= 0
+        into_original[perm[ok]] = np.asarray(slice_new)[ok]
+
     @property
     def perm(self):
         """new id -> original id (identical on every rank)."""
@@ -52,6 +66,54 @@ def rmat_partitioned(scale, edge_factor, rank, world, a=0.57, b=0.19, c=0.19, se
     vals = [C.c_int64() for _ in range(4)]
     L.check(L.lib().pgh_graph_info(h, *[C.byref(v) for v in vals]))
     return PartitionedGraph(DeviceGraph(h, (vals[0].value, vals[1].value), vals[2].value), rank, world)
+
+
+def _auto_blocks(n):
+    """Column blocks the engine's layout would choose for n sources (bsf_auto_blocks, csrc/pgh_bsf.hip)."""
+    blocks = 1
+    while blocks < 4 and n * 4 > blocks * (8 << 20):
+        blocks <<= 1
+    return blocks
+
+
+def partition_scipy(M, rank, world):
+    """Row-partitioned upload of a caller's matrix: M = the preprocessor's normalised scipy CSR (n x n, what
+    scipy_sparse_to_backend receives, preprocessing.py:144).  Every rank calls this with the SAME matrix and derives the same
+    relabelling: sources sorted by descending entry count (stable), dealt round-robin to B = max(world, auto) hot-first column
+    blocks, the id space padded to a multiple of 64 B; rank r then uploads only the columns of its slice of the new ids
+    (its rows of M^T).  Padding ids have no entries: with a zero personalization there they stay zero."""
+    import scipy.sparse as sp
+    L.ensure_init()
+    assert world in (1, 2, 4, 8) and 0 <= rank < world, "1, 2, 4 or 8 ranks"
+    M = sp.csr_array(M)
+    n = M.shape[0]
+    assert M.shape[0] == M.shape[1], "square matrices only"
+    blocks = max(world, _auto_blocks(n))
+    unit = 64 * blocks
+    n_pad = (n + unit - 1) // unit * unit
+    blk = n_pad // blocks
+    order = np.argsort(-np.diff(M.indptr), kind="stable")               # rank by descending source count
+    r = np.arange(n, dtype=np.int64)
+    new_of_rank = (r % blocks) * blk + r // blocks
+    perm = np.full(n_pad, -1, dtype=np.int32)
+    perm[new_of_rank] = order
+    iperm = np.empty(n, dtype=np.int64)
+    iperm[order] = new_of_rank
+    n_local = n_pad // world
+    lo = rank * n_local
+    coo = M.tocoo()
+    cols = iperm[coo.col]
+    keep = (cols >= lo) & (cols < lo + n_local)
+    local = sp.csr_array((coo.data[keep], (iperm[coo.row][keep], cols[keep] - lo)), shape=(n_pad, n_local))
+    local.sort_indices()
+    indptr = np.ascontiguousarray(local.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(local.indices, dtype=np.int32)
+    data = np.ascontiguousarray(local.data, dtype=np.float64)
+    h = L.c_graph()
+    L.check(L.lib().pgh_graph_from_csr_part(n_pad, n_local, local.nnz, indptr.ctypes.data_as(C.c_void_p),
+                                            indices.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p), lo, blocks,
+                                            perm.ctypes.data_as(C.c_void_p), C.byref(h)))
+    return PartitionedGraph(DeviceGraph(h, (n_pad, n_local), local.nnz), rank, world)
 
 
 _HOT_PAD = 32768          # the engine's LDS hot cache reads up to this many leading slots of a block's slice

@@ -93,3 +93,27 @@ def test_bench_launcherless_spawns_its_ranks(oracle_build_dir):
     same = out["same_graph_1gpu"]
     assert same["rel_linf_partitioned_vs_1gpu"] <= 1e-6 and same["iterations_1gpu"] == same["iterations_partitioned"]
     assert same["speedup_vs_1gpu_same_graph"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_partitioned_upload_of_a_scipy_graph(tmp_path, oracle_build_dir, world):
+    """pgh_graph_from_csr_part / distributed.partition_scipy: a caller's (weighted, non-power-of-two) scipy graph is relabelled
+    identically on every rank, each rank uploads its rows of M^T only, and the partitioned PageRank equals the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker_csr
+    port = 29700 + world + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_csr.py"), str(tmp_path)]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    A, p = dist_worker_csr.make_graph()
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    assert sum(int(part["nnz"]) for part in parts) == M.nnz            # every entry lives on exactly one rank
+    assert len({int(part["n_local"]) for part in parts}) == 1 and int(parts[0]["n_pad"]) >= A.shape[0]
+    for name, kw in (("l1", dict(error_type="l1", tol=1e-6, max_iters=500)), ("mabs", dict(error_type="mabs", tol=1e-7, max_iters=500))):
+        want, want_iters = orc.pagerank(M, p, alpha=0.85, eps=EPS32, **kw)
+        got = sum(part[name + "_ranks"] for part in parts)             # slices are disjoint
+        assert all(int(part[name + "_iters"]) == want_iters for part in parts), name
+        assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), name

@@ -236,3 +236,31 @@ def test_bench_two_ranks_on_one_gpu(gpu_engine):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["unit"] == "GTEPS"
     assert out["config"]["exchange_bytes_per_iteration_per_gpu"] > 0 and len(out["config"]["iterations_per_step"]) == 2
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")], ids=["rccl_x1", "gloo_x2"])
+def test_partitioned_upload_of_a_scipy_graph_on_gpu(gpu_engine, tmp_path, world, backend):
+    """pgh_graph_from_csr_part on the real engine (a caller's weighted scipy graph, relabelled and sliced per rank) driven
+    through the device partitioned loop, against the oracle.  Same worker as tests/test_distributed_cpu.py."""
+    import os
+    import subprocess
+    import sys
+    import scipy.sparse as sp
+    from oracle import ref_loops as orc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import dist_worker_csr
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29650 + world), os.path.join(root, "tests", "dist_worker_csr.py"), str(tmp_path)]
+    env = dict(os.environ, PYTHONPATH=root, PGH_TEST_ENGINE="hip", PGH_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    A, p = dist_worker_csr.make_graph()
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    assert sum(int(part["nnz"]) for part in parts) == M.nnz
+    for name, kw in (("l1", dict(error_type="l1", tol=1e-6, max_iters=500)), ("mabs", dict(error_type="mabs", tol=1e-7, max_iters=500))):
+        want, want_iters = orc.pagerank(M, p, alpha=0.85, eps=EPS32, **kw)
+        got = sum(part[name + "_ranks"] for part in parts)
+        assert all(int(part[name + "_iters"]) == want_iters for part in parts), name
+        assert rel_linf(got, want) <= 1e-6, name
