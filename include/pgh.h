@@ -256,6 +256,13 @@ int pgh_graph_set_gather_bases(pgh_graph_t g, const int64_t* bases /* [num_block
  * before the host has seen the flag. */
 int pgh_dist_state_init(double* state);
 int pgh_dist_partial(pgh_graph_t g, pgh_vec_t xg_full, const double* state);
+/* pgh_dist_partial in two stages, so that the exchange of the gather vector can overlap the step: stage 1 = the block partial
+ * sums, stage 2 = the cold image's phase A and the cross-tile fix-ups (stage 0 = both = pgh_dist_partial).  When
+ * pgh_graph_hot_prefix reports hot_slots > 0, stage 1 reads only the first hot_slots slots of every block of the gather
+ * vector (the LDS hot cache): a caller that all-gathers those first can start stage 1 while the rest is still in flight.
+ * hot_slots == 0: stage 1 needs the whole gather vector. */
+int pgh_dist_partial_stage(pgh_graph_t g, pgh_vec_t xg_full, const double* state, int32_t stage);
+int pgh_graph_hot_prefix(pgh_graph_t g, int32_t* hot_slots);
 int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, pgh_vec_t y_local, pgh_vec_t xg_local_out, double* state);
 int pgh_dist_close_sum(double* state, int32_t use_quotient);
 int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old, double* state);

@@ -987,6 +987,18 @@ int pgh_dist_partial(pgh_graph_t g, pgh_vec_t xg_full, const double* state) {
     g->pending_xg = expand_gather(g, xg_full->data, xg_full->n);
     return 0;
 }
+// the double has no hot cache: stage 1 does nothing, stage 2 (and 0) expand the gather vector; hot_slots = 0 tells the
+// caller that the whole vector must be there before stage 1
+int pgh_dist_partial_stage(pgh_graph_t g, pgh_vec_t xg_full, const double* state, int32_t stage) {
+    CHECK(g && xg_full && state && stage >= 0 && stage <= 2, "pgh_dist_partial_stage: bad argument");
+    if (stage == 1) return 0;
+    return pgh_dist_partial(g, xg_full, state);
+}
+int pgh_graph_hot_prefix(pgh_graph_t g, int32_t* hot_slots) {
+    CHECK(g && hot_slots && g->gather_blk > 0, "pgh_graph_hot_prefix: not a partitioned graph");
+    *hot_slots = 0;
+    return 0;
+}
 static double ppr_step(const pgh_graph_s* g, const float* x, double xs, const float* p, double alpha, float* y);
 int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p, double alpha, pgh_vec_t y, pgh_vec_t xg_local, double* state) {
     CHECK(g && p && y && xg_local && state, "pgh_dist_combine: null argument");

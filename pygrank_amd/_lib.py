@@ -117,6 +117,8 @@ SIGNATURES = {
     "pgh_graph_set_gather_bases": (C.c_int, [c_graph, C.c_void_p]),
     "pgh_dist_state_init": (C.c_int, [C.c_void_p]),
     "pgh_dist_partial": (C.c_int, [c_graph, c_vec, C.c_void_p]),
+    "pgh_dist_partial_stage": (C.c_int, [c_graph, c_vec, C.c_void_p, C.c_int32]),
+    "pgh_graph_hot_prefix": (C.c_int, [c_graph, C.POINTER(C.c_int32)]),
     "pgh_dist_combine": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, c_vec, C.c_void_p]),
     "pgh_dist_close_sum": (C.c_int, [C.c_void_p, C.c_int32]),
     "pgh_dist_residual": (C.c_int, [C.c_int32, c_vec, c_vec, C.c_void_p]),

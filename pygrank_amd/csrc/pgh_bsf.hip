@@ -802,12 +802,15 @@ int bsf_combine_grid(int64_t n_out) {
 // Enqueue M^T-times-gather-vector in the blocked format followed by the MODE epilogue.
 // xg: gather vector in the graph's internal id space, already multiplied by src_scale when the format has one.
 // Block partials of sum(y) / delta land in rt().d_partials like the row-major path; *num_partials receives their count.
-int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state) {
+// stages: 1 = block partial sums only (hot-only streams read just the first `hot` slots of every block of the gather
+// vector), 2 = the cold image's phase A + the cross-tile fix-ups, 0 = both.  A partitioned run overlaps the exchange of the
+// cold part of the gather vector with stage 1.
+int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, int stage) {
     Runtime& r = rt();
     BsfFormat& f = g->bsf;
     const BsfView v = view_of(f);
     const int main_grid = r.num_cus;                  // one workgroup per CU; a multiple of 8 (XCD-affine blocks)
-    {
+    if (stage != 2) {
         ProfScope prof(PGH_K_SPMV);
         if (f.colf16 != nullptr) {
             if (f.val) k_bsf_partial<kIPT, true, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
@@ -819,6 +822,10 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state) 
             if (f.val) k_bsf_partial<kIPT, true, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
             else k_bsf_partial<kIPT, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
         }
+    }
+    if (stage == 1) {
+        PGH_HIP(hipGetLastError());
+        return 0;
     }
     FixView fix;
     fix.fix_seg = f.fix_seg;
@@ -878,7 +885,7 @@ int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* sta
 template <int MODE>
 int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials,
                hipEvent_t before_combine) {
-    PGH_TRY(bsf_launch_partial(g, xg, state));
+    PGH_TRY(bsf_launch_partial(g, xg, state, 0));
     // the epilogue is the first consumer of the previous step's scalars (quotient, done flag): the partial sums above
     // may run while the previous step's residual / close kernels are still in flight on the side stream
     if (before_combine != nullptr) PGH_HIP(hipStreamWaitEvent(rt().stream, before_combine, 0));

@@ -243,7 +243,7 @@ int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, co
 template <int MODE>
 int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, const LoopState* state, int* num_partials);
 void pb_destroy(PbFormat& p);
-int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state);
+int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, int stage = 0);
 template <int MODE>
 int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* state, int* num_partials);
 template <int MODE>

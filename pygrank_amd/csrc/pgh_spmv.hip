@@ -847,6 +847,22 @@ extern "C" int pgh_dist_partial(pgh_graph_t g, pgh_vec_t xg_full, const double* 
     return bsf_launch_partial(g, xg_full->data, reinterpret_cast<const LoopState*>(state));
 }
 
+extern "C" int pgh_dist_partial_stage(pgh_graph_t g, pgh_vec_t xg_full, const double* state, int32_t stage) {
+    PGH_CHECK(xg_full && state && stage >= 0 && stage <= 2, "pgh_dist_partial_stage: bad argument");
+    PGH_TRY(check_dist_graph(g, xg_full, "pgh_dist_partial_stage"));
+    return bsf_launch_partial(g, xg_full->data, reinterpret_cast<const LoopState*>(state), stage);
+}
+
+extern "C" int pgh_graph_hot_prefix(pgh_graph_t g, int32_t* hot_slots) {
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_graph_hot_prefix"));
+    PGH_CHECK(hot_slots != nullptr, "pgh_graph_hot_prefix: null argument");
+    const BsfFormat& f = g->bsf;
+    const int hot = PGH_BSF_HOT < f.blk_size ? PGH_BSF_HOT : f.blk_size;
+    // hot-only stream (every cold entry lives in the propagation-blocking image): stage 1 touches slots [0, hot) only
+    *hot_slots = f.colf16 != nullptr ? hot : 0;
+    return 0;
+}
+
 extern "C" int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, pgh_vec_t y_local, pgh_vec_t xg_local_out,
                                 double* state) {
     PGH_CHECK(p_local && y_local && xg_local_out && state, "pgh_dist_combine: null argument");

@@ -160,12 +160,41 @@ class _Buffers:
         self.v_xg_local = DeviceVector.wrap(self.xg_local.data_ptr(), n_local, keepalive=self.xg_local)
         self.v_y = [DeviceVector.wrap(t.data_ptr(), n_local, keepalive=t) for t in self.y]
         self.exchange_bytes = 4 * self.live * self.bpr * (world - 1)            # received per rank and iteration
+        self.world = world
+        # Hot / cold split of the exchange: when the slice's stream is hot-only (every cold entry lives in the
+        # propagation-blocking image) the block partial sums read just the first `hot` slots of every block, so those
+        # are exchanged first (a few hundred KB) and the bulk of the gather vector travels while they run.
+        hs = C.c_int32()
+        L.check(lib.pgh_graph_hot_prefix(g._h, C.byref(hs)))
+        agree = torch.tensor([hs.value], dtype=torch.int64, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)                             # every rank must split the same way
+        hot = int(agree.item())
+        self.hot = (min(hot, self.live) + 63) // 64 * 64 if 0 < hot < self.live else 0
+        # the big exchange and the scalar reductions use communicators of their own so that neither queues behind the other
+        self.pg_exchange = dist.new_group(backend=dist.get_backend()) if world > 1 else None
 
-    def all_gather(self, dist):
-        """xg_local (this rank's slice of the next gather vector) -> every rank's xg_full, live prefixes only."""
-        per = self.live * (self.nb // self.bpr)                                  # world * L floats per all-gather
+    def _pieces(self, j, lo, hi):
+        """views of slots [lo, hi) of the blocks j, bpr + j, ... (one per rank) inside xg_full, and of this rank's slice"""
+        L_ = self.live
+        outs = [self.xg_full[(j * self.world + r) * L_ + lo:(j * self.world + r) * L_ + hi] for r in range(self.world)]
+        return outs, self.xg_local[j * self.blk + lo:j * self.blk + hi]
+
+    def all_gather(self, dist, part="all"):
+        """xg_local (this rank's slice of the next gather vector) -> every rank's xg_full, live prefixes only.
+        part: "all", or "hot" / "cold" = slots [0, hot) / [hot, live) of every block."""
+        group = self.pg_exchange
+        if part == "all" or self.hot == 0:
+            if part == "hot":
+                return
+            per = self.live * self.world                                         # world * L floats per all-gather
+            for j in range(self.bpr):
+                dist.all_gather_into_tensor(self.xg_full[j * per:(j + 1) * per], self.xg_local[j * self.blk:j * self.blk + self.live],
+                                            group=group)
+            return
+        lo, hi = (0, self.hot) if part == "hot" else (self.hot, self.live)
         for j in range(self.bpr):
-            dist.all_gather_into_tensor(self.xg_full[j * per:(j + 1) * per], self.xg_local[j * self.blk:j * self.blk + self.live])
+            outs, mine = self._pieces(j, lo, hi)
+            dist.all_gather(outs, mine, group=group)
 
 
 class DistributedPageRank:
@@ -240,6 +269,14 @@ class DistributedPageRank:
 
     def _rank_on_stream(self, pgraph, p_local, bufs, dist, lib, g, device, kind, tol, state, sum_view, err_view, err_op,
                         local_kind, read_state, torch):
+        """Three queues per rank (CUDA; the CPU/gloo path runs the same calls in order):
+          C  the engine's stream: block partial sums -> phase A -> phase B + epilogue of every step;
+          X  the exchange: after the epilogue of step k the hot prefixes of the gather slices are all-gathered, then the
+             rest; step k + 1's block partial sums wait for the first, its phase A for the second;
+          S  the scalars: all-reduce of sum(y), lazy L1 quotient, residual, its all-reduce, stopping rule -- behind the
+             epilogue of step k, ahead of the epilogue of step k + 1, beside everything in between.
+        The host reads the done flag of step k only after it has enqueued the first two stages of step k + 1."""
+        cuda = device.type == "cuda"
         # ---- prologue of GraphFilter.rank (abstract_filters.py:52-56): global L1 norm, x0 = p / norm
         norm = self._all_reduce(bufs, dist, p_local.abssum(), dist.ReduceOp.SUM)
         if norm == 0:
@@ -249,50 +286,92 @@ class DistributedPageRank:
         cur = 0
         L.check(lib.pgh_vec_copy(bufs.v_y[cur]._h, p._h))
         L.check(lib.pgh_dist_prescale(g._h, bufs.v_y[cur]._h, bufs.v_xg_local._h))
-        bufs.all_gather(dist)
+        bufs.all_gather(dist, "all")
         L.check(lib.pgh_dist_state_init(state))
+        if cuda:
+            if getattr(self, "_side", None) is None:
+                self._side = (torch.cuda.Stream(), torch.cuda.Stream())
+            main, (xs, ss) = self._stream, self._side
+            ev_fin, ev_hot, ev_cold, ev_err = (torch.cuda.Event() for _ in range(4))
+            for ev in (ev_hot, ev_cold, ev_err):
+                ev.record(main)                   # the initial exchange and state are in place once `main` gets here
+
+        def on(stream):
+            return torch.cuda.stream(stream) if cuda else _NullCtx()
+
+        def stages():
+            if cuda:
+                main.wait_event(ev_hot)
+            L.check(lib.pgh_dist_partial_stage(g._h, bufs.v_xg_full._h, state, 1))
+            if cuda:
+                main.wait_event(ev_cold)
+            L.check(lib.pgh_dist_partial_stage(g._h, bufs.v_xg_full._h, state, 2))
+
         t0 = time.perf_counter()
         it, spmv, converged = 1, 0, False       # `it` = ConvergenceManager.iteration of the pending has_converged call
-        pending_flag = None                     # event recorded after the last residual check
-        partial_enqueued = False
+        pending = False                         # a residual check whose outcome the host has not looked at yet
+        staged = False
         while it < self.max_iters:                                             # convergence.py:86
             nxt = 1 - cur
-            if not partial_enqueued:
-                L.check(lib.pgh_dist_partial(g._h, bufs.v_xg_full._h, state))
-            partial_enqueued = False
-            if pending_flag is not None:
-                # the check that followed the previous step: its flag is on its way while the partial sums run
-                if device.type == "cuda":
-                    pending_flag.synchronize()
-                pending_flag = None
+            if not staged:
+                stages()
+            staged = False
+            if pending:
+                # the check that followed the previous step: its flag travels while the stages above run
+                if cuda:
+                    ev_err.synchronize()
+                pending = False
                 if int(bufs.state_host.view(torch.int32)[6]):
-                    converged = True            # the partial sums just enqueued were no-ops (done was already set)
+                    converged = True            # whatever the stages above computed is never folded into an iterate
                     break
+            if cuda:
+                main.wait_event(ev_err)         # quotient and done flag of the previous step; its residual has read y[nxt]
             L.check(lib.pgh_dist_combine(g._h, p._h, self.alpha, bufs.v_y[nxt]._h, bufs.v_xg_local._h, state))
-            dist.all_reduce(sum_view)
-            L.check(lib.pgh_dist_close_sum(state, 1 if self.use_quotient else 0))
-            bufs.all_gather(dist)                                              # next gather vector over xGMI
+            if cuda:
+                ev_fin.record(main)
+            with on(xs if cuda else None):                                        # ---- X: the next gather vector over xGMI
+                if cuda:
+                    xs.wait_event(ev_fin)
+                bufs.all_gather(dist, "hot")
+                if cuda:
+                    ev_hot.record(xs)
+                bufs.all_gather(dist, "cold")
+                if cuda:
+                    ev_cold.record(xs)
             cur = nxt
             spmv += 1
             it += 1
+            check = it < self.max_iters and kind != L.ERR_ITERS and it % self.end_modulo == 0
+            with on(ss if cuda else None):                                        # ---- S: the scalars of the step
+                if cuda:
+                    ss.wait_event(ev_fin)
+                    L.check(lib.pgh_set_stream(C.c_void_p(ss.cuda_stream)))
+                try:
+                    dist.all_reduce(sum_view)
+                    L.check(lib.pgh_dist_close_sum(state, 1 if self.use_quotient else 0))
+                    if check:
+                        L.check(lib.pgh_dist_residual(local_kind, bufs.v_y[cur]._h, bufs.v_y[1 - cur]._h, state))
+                        dist.all_reduce(err_view, op=err_op)
+                        L.check(lib.pgh_dist_close_err(state, kind, tol, pgraph.n))
+                        bufs.state_host.copy_(bufs.state, non_blocking=True)
+                finally:
+                    if cuda:
+                        L.check(lib.pgh_set_stream(C.c_void_p(main.cuda_stream)))
+                if cuda:
+                    ev_err.record(ss)
             if it >= self.max_iters:
                 break
-            if kind != L.ERR_ITERS and it % self.end_modulo == 0:
-                L.check(lib.pgh_dist_residual(local_kind, bufs.v_y[cur]._h, bufs.v_y[1 - cur]._h, state))
-                dist.all_reduce(err_view, op=err_op)
-                L.check(lib.pgh_dist_close_err(state, kind, tol, pgraph.n))
-                bufs.state_host.copy_(bufs.state, non_blocking=True)
-                if device.type == "cuda":
-                    pending_flag = torch.cuda.Event()
-                    pending_flag.record(self._stream)
-                    # speculate: the next partial sums only need the all-gather above
-                    L.check(lib.pgh_dist_partial(g._h, bufs.v_xg_full._h, state))
-                    partial_enqueued = True
-                else:
-                    pending_flag = True
-        if pending_flag is not None and not converged:
-            if device.type == "cuda":
-                pending_flag.synchronize()
+            if check:
+                pending = True
+                if cuda:
+                    stages()                    # speculate: the next step's first two stages need the exchange only
+                    staged = True
+        if cuda:
+            main.wait_event(ev_err)
+            main.wait_event(ev_cold)
+        if pending and not converged:
+            if cuda:
+                ev_err.synchronize()
             converged = bool(int(bufs.state_host.view(torch.int32)[6]))
         done, steps, conv, scale = read_state()
         self.elapsed = time.perf_counter() - t0
@@ -305,6 +384,14 @@ class DistributedPageRank:
         out = bufs.v_y[cur] * factor
         L.check(lib.pgh_sync())
         return out
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -33,6 +33,8 @@ def test_row_partitioned_pagerank_gloo(tmp_path, oracle_build_dir, world):
     assert [int(part["n_local"]) for part in parts] == [n // world] * world     # equal slices: unpadded all-gather
     A = rmat_np.rmat_csr(scale, ef, seed=0)
     assert sum(int(part["nnz"]) for part in parts) == A.nnz
+    nnz_per_rank = [int(part["nnz"]) for part in parts]
+    assert max(nnz_per_rank) <= 1.05 * np.mean(nnz_per_rank), nnz_per_rank      # hot-first round-robin deal: balanced work
     M = sp.csr_array(orc.normalize(A, "col", True))
     rng = np.random.default_rng(1)
     p_old = np.zeros(n)
@@ -117,3 +119,13 @@ def test_partitioned_upload_of_a_scipy_graph(tmp_path, oracle_build_dir, world):
         got = sum(part[name + "_ranks"] for part in parts)             # slices are disjoint
         assert all(int(part[name + "_iters"]) == want_iters for part in parts), name
         assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), name
+
+
+def test_partition_balance_eight_ways(host_engine):
+    """nnz per rank of the 8-way partition (configs[4] shape at a CPU-sized scale): max / mean <= 1.05.  The slices are equal in
+    rows by construction; the entries follow because ids are dealt round-robin in descending order of their source counts."""
+    from pygrank_amd.distributed import rmat_partitioned
+    for world in (2, 4, 8):
+        nnz = [rmat_partitioned(16, 16, r, world).graph.nnz for r in range(world)]
+        assert max(nnz) <= 1.05 * np.mean(nnz), (world, nnz)
+        assert sum(nnz) == rmat_np.rmat_csr(16, 16, seed=0).nnz
