@@ -87,6 +87,12 @@ int pgh_axpby(double a, pgh_vec_t x, double b, pgh_vec_t y, pgh_vec_t out);   /*
 /* filter_out(x, exclude) = x[exclude == 0], specification.py:113; out must hold len(x); count returned */
 int pgh_filter_out(pgh_vec_t x, pgh_vec_t exclude, pgh_vec_t out, int64_t* out_len);
 
+/* Ordinals / Top (algorithms/postprocess/postprocess.py:163-195,246-290): out[i] = 1 + the number of entries
+ * that sort before x[i] in descending order of value (ties: lower index first, as python's stable sorted(reverse=True));
+ * value of the k-th largest entry (k >= 1).  One device radix sort each. */
+int pgh_vec_ordinals(pgh_vec_t x, pgh_vec_t out);
+int pgh_vec_kth_largest(pgh_vec_t x, int64_t k, double* value);
+
 /* reductions: sum/min/max/mean/dot, specification.py:29-43,109; f64 accumulation */
 enum { PGH_SUM = 0, PGH_ABSSUM = 1, PGH_MAX = 2, PGH_MIN = 3 };
 int pgh_reduce(int kind, pgh_vec_t x, double* out);
@@ -109,6 +115,10 @@ int     pgh_mat_get_col(pgh_mat_t m, int32_t col, pgh_vec_t v);     /* separate_
  * out[j] = sum_i |m[i, j]| (host doubles), and out[i, j] = m[i, j] / (float)divisors[j] (a zero divisor copies). */
 int     pgh_mat_col_abssum(pgh_mat_t m, double* out_host /* [b] */);
 int     pgh_mat_div_cols(pgh_mat_t m, const double* divisors_host /* [b] */, pgh_mat_t out);
+/* out[i] = sum_{j < count} m[i, j] * coeffs[j] (f64 accumulation): a closed-form filter evaluated from the stored powers
+ * {(M^T)^k p} of its personalization -- the device form of the optimisation dict (abstract_filters.py:232-246), so that a
+ * tuner probe (autotune/parameterized.py:135-145) costs one pass over an [n, K] slab instead of K SpMVs. */
+int     pgh_mat_gemv(pgh_mat_t m, const double* coeffs_host, int32_t count, pgh_vec_t out);
 /* out[:, 0:count] = m[:, first:first+count]  /  m[:, first:first+src.b] = src  (batches wider than 64 columns) */
 int     pgh_mat_get_cols(pgh_mat_t m, int32_t first, pgh_mat_t out);
 int     pgh_mat_set_cols(pgh_mat_t m, int32_t first, pgh_mat_t src);
@@ -149,6 +159,11 @@ int pgh_graph_download(pgh_graph_t g, int64_t* indptr_t, int32_t* indices_t, flo
 
 /* conv(signal, M) = M^T x, specification.py:97-98; numpy.py:64-65.  Pure: y is a different buffer. */
 int pgh_spmv(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y);
+
+/* conv(signal, graph_dropout(M, rate)) (specification.py:13; pytorch.py:34-38, torch dropout on the edge values): entry e of
+ * CSR(M^T) (the order of pgh_graph_download) survives when the high 32 bits of splitmix64(seed ^ e * 0xD6E8FEB86659FD93) are
+ * >= floor(rate * 2^32) and is scaled by 1 / (1 - rate).  The mask is never materialised. */
+int pgh_spmv_dropout(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y, double rate, uint64_t seed);
 
 /* ---------------------------------------------------------------- fused propagation steps --------- */
 /* PageRank._formula (adhoc.py:34-36): y = alpha * x_scale * (M^T x) + (1 - alpha) * p.

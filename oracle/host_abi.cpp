@@ -358,6 +358,32 @@ int pgh_mat_div_cols(pgh_mat_t m, const double* div, pgh_mat_t out) {
         }
     return 0;
 }
+static std::vector<int64_t> order_desc(pgh_vec_t x) {
+    std::vector<int64_t> idx(x->n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return x->data[a] > x->data[b]; });
+    return idx;
+}
+int pgh_vec_ordinals(pgh_vec_t x, pgh_vec_t out) {
+    CHECK(x && out && x->n == out->n && x->data != out->data, "pgh_vec_ordinals: bad arguments");
+    const std::vector<int64_t> idx = order_desc(x);
+    for (int64_t k = 0; k < x->n; ++k) out->data[idx[k]] = (float)(k + 1);
+    return 0;
+}
+int pgh_vec_kth_largest(pgh_vec_t x, int64_t k, double* value) {
+    CHECK(x && value && k >= 1 && k <= x->n, "pgh_vec_kth_largest: k outside [1, n]");
+    *value = x->data[order_desc(x)[k - 1]];
+    return 0;
+}
+int pgh_mat_gemv(pgh_mat_t m, const double* c, int32_t count, pgh_vec_t out) {
+    CHECK(m && out && (c || count == 0) && count >= 0 && count <= m->b && out->n == m->n, "pgh_mat_gemv: shape mismatch");
+    for (int64_t i = 0; i < m->n; ++i) {
+        double acc = 0;
+        for (int32_t j = 0; j < count; ++j) acc += (double)m->data[i * m->b + j] * c[j];
+        out->data[i] = (float)acc;
+    }
+    return 0;
+}
 int pgh_mat_get_cols(pgh_mat_t m, int32_t first, pgh_mat_t out) {
     CHECK(m && out && m->n == out->n && first >= 0 && first + out->b <= m->b, "pgh_mat_get_cols: shape mismatch");
     for (int64_t i = 0; i < m->n; ++i)
@@ -486,6 +512,26 @@ static int check_gv(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y, const char* who) {
 int pgh_spmv(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y) {
     if (check_gv(g, x, y, "pgh_spmv")) return 1;
     for (int64_t r = 0; r < g->n_cols; ++r) y->data[r] = row_dot(g, x->data, r);
+    return 0;
+}
+
+int pgh_spmv_dropout(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y, double rate, uint64_t seed) {
+    if (check_gv(g, x, y, "pgh_spmv_dropout")) return 1;
+    CHECK(rate >= 0.0 && rate < 1.0, "pgh_spmv_dropout: rate must lie in [0, 1)");
+    const uint32_t threshold = (uint32_t)std::floor(rate * 4294967296.0);
+    const float keep = (float)(1.0 / (1.0 - rate));
+    for (int64_t r = 0; r < g->n_cols; ++r) {
+        double acc = 0;
+        for (int64_t k = g->rowptr[r]; k < g->rowptr[r + 1]; ++k) {
+            uint64_t z = (seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ULL)) + 0x9E3779B97F4A7C15ULL;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z = z ^ (z >> 31);
+            const float f = (uint32_t)(z >> 32) >= threshold ? keep : 0.f;
+            acc += (double)((g->val[k] * f) * x->data[g->col[k]]);
+        }
+        y->data[r] = (float)acc;
+    }
     return 0;
 }
 

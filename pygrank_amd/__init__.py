@@ -22,9 +22,10 @@ from pygrank_amd.signals import GraphSignal, NodeRanking, to_signal
 from pygrank_amd.preprocessing import (Adjacency, AdjacencyWrapper, MethodHasher, obj2id, preprocessor,
                                        to_sparse_matrix)
 from pygrank_amd.utils import call, ensure_used_args, remove_used_args
-from pygrank_amd.measures import L1, Mabs, MaxDifference, Supervised
+from pygrank_amd.measures import (L1, L2, MSQ, MSQRT, Cos, Dot, Euclidean, Mabs, MaxDifference, RMabs, Supervised)
 from pygrank_amd.convergence import ConvergenceManager
-from pygrank_amd.postprocess import Normalize, Postprocessor, Tautology
+from pygrank_amd.postprocess import (LinearSweep, Normalize, Ordinals, Postprocessor, Sweep, Tautology, Threshold, Top,
+                                     Transformer)
 from pygrank_amd.filters import (AbsorbingWalks, ClosedFormGraphFilter, GenericGraphFilter, GraphFilter, HeatKernel,
                                  ImpulseGraphFilter, LowPassRecursiveGraphFilter, PageRank, PageRankClosed,
                                  RecursiveGraphFilter, SymmetricAbsorbingRandomWalks)

@@ -72,6 +72,8 @@ SIGNATURES = {
     "pgh_ewise_unary": (C.c_int, [C.c_int, c_vec, c_vec]),
     "pgh_axpby": (C.c_int, [C.c_double, c_vec, C.c_double, c_vec, c_vec]),
     "pgh_filter_out": (C.c_int, [c_vec, c_vec, c_vec, c_i64p]),
+    "pgh_vec_ordinals": (C.c_int, [c_vec, c_vec]),
+    "pgh_vec_kth_largest": (C.c_int, [c_vec, C.c_int64, c_f64p]),
     "pgh_reduce": (C.c_int, [C.c_int, c_vec, c_f64p]),
     "pgh_dot": (C.c_int, [c_vec, c_vec, c_f64p]),
     "pgh_residual": (C.c_int, [C.c_int, c_vec, c_vec, c_f64p]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     "pgh_mat_set_col": (C.c_int, [c_mat, C.c_int32, c_vec]),
     "pgh_mat_col_abssum": (C.c_int, [c_mat, C.c_void_p]),
     "pgh_mat_div_cols": (C.c_int, [c_mat, C.c_void_p, c_mat]),
+    "pgh_mat_gemv": (C.c_int, [c_mat, C.c_void_p, C.c_int32, c_vec]),
     "pgh_mat_get_cols": (C.c_int, [c_mat, C.c_int32, c_mat]),
     "pgh_mat_set_cols": (C.c_int, [c_mat, C.c_int32, c_mat]),
     "pgh_mat_get_col": (C.c_int, [c_mat, C.c_int32, c_vec]),
@@ -101,6 +104,7 @@ SIGNATURES = {
     "pgh_graph_degrees": (C.c_int, [c_graph, c_vec]),
     "pgh_graph_download": (C.c_int, [c_graph, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgh_spmv": (C.c_int, [c_graph, c_vec, c_vec]),
+    "pgh_spmv_dropout": (C.c_int, [c_graph, c_vec, c_vec, C.c_double, C.c_uint64]),
     "pgh_ppr_step": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, C.c_double, c_vec, c_f64p]),
     "pgh_absorb_step": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, c_vec, c_vec, c_vec, c_f64p]),
     "pgh_poly_step": (C.c_int, [c_graph, c_vec, c_vec, C.c_double, C.c_double, c_vec, C.c_double, C.c_int, c_f64p]),

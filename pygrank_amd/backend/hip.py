@@ -10,7 +10,7 @@ helpers ``eye``/``diag`` which the numpy and matvec engines of the reference als
 import numpy as _np
 
 from pygrank_amd import _lib as _L
-from pygrank_amd.device import DeviceGraph, DeviceMatrix, DeviceVector
+from pygrank_amd.device import DroppedGraph, DeviceGraph, DeviceMatrix, DeviceVector
 
 
 def backend_name():                       # specification.py:5-6
@@ -21,10 +21,23 @@ def backend_init():                       # specification.py:9-10; fails loudly 
     _L.ensure_init()
 
 
+_dropout_calls = [0x5EED]                  # seed of the next dropout mask; set_dropout_seed() makes runs reproducible
+
+
+def set_dropout_seed(seed):
+    _dropout_calls[0] = int(seed)
+
+
 def graph_dropout(M, dropout):            # specification.py:13; identity and O(1) for dropout == 0 (called 2 + #steps times)
     if dropout == 0:
         return M
-    raise NotImplementedError("graph_dropout > 0 is outside the propagation hot path (SURVEY.md 8f.4)")
+    # pytorch.py:34-38: a new Bernoulli mask on the edge values at every call.  Here the mask is a hash of (seed, entry)
+    # evaluated inside the SpMV (pgh_spmv_dropout): a dropped graph is a view, nothing is copied.
+    base = getattr(M, "array", M)
+    if isinstance(base, DroppedGraph):
+        base = base.base
+    _dropout_calls[0] += 1
+    return DroppedGraph(base, float(dropout), _dropout_calls[0])
 
 
 def separate_cols(x):                     # specification.py:17

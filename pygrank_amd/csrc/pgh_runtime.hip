@@ -5,6 +5,8 @@
 // pygrank/measures/supervised.py:93-106,133-138.  All of these are HBM-bound streaming kernels:
 // 16-byte loads per lane, 64-wide wavefront shuffles for reductions, f64 accumulators.
 #include "pgh_common.h"
+
+#include <hipcub/hipcub.hpp>
 #include <unordered_map>
 #include <map>
 
@@ -874,6 +876,111 @@ extern "C" int pgh_mat_col_abssum(pgh_mat_t m, double* out_host) {
     PGH_HIP(hipStreamSynchronize(r.stream));
     pool_free(partial);
     pool_free(folded);
+    return 0;
+}
+
+// out[i] = sum_j m[i, j] * c[j] over the first `count` columns (f64 accumulation, one rounding to f32): a polynomial filter
+// evaluated from the stored powers {(M^T)^k p} of its personalization.  A wavefront takes 64 consecutive
+// rows; its lanes read the rows' leading `count` floats (the rows are contiguous, so a wavefront covers one contiguous
+// range of the slab); the coefficients sit in LDS.
+namespace {
+__global__ __launch_bounds__(kBlock) void k_mat_gemv(const float* __restrict__ m, int64_t n, int b, const double* __restrict__ coeffs, int count,
+                                                      float* __restrict__ out) {
+    __shared__ double s_c[1024];
+    for (int j = threadIdx.x; j < count; j += kBlock) s_c[j] = coeffs[j];
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float* __restrict__ row = m + i * b;
+        double acc = 0.0;
+        int j = 0;
+        for (; j + 4 <= count; j += 4) {                   // four independent loads per round
+            const float a0 = row[j], a1 = row[j + 1], a2 = row[j + 2], a3 = row[j + 3];
+            acc += (double)a0 * s_c[j];
+            acc += (double)a1 * s_c[j + 1];
+            acc += (double)a2 * s_c[j + 2];
+            acc += (double)a3 * s_c[j + 3];
+        }
+        for (; j < count; ++j) acc += (double)row[j] * s_c[j];
+        out[i] = (float)acc;
+    }
+}
+}  // namespace
+
+extern "C" int pgh_mat_gemv(pgh_mat_t m, const double* coeffs_host, int32_t count, pgh_vec_t out) {
+    PGH_CHECK(m && out && (coeffs_host || count == 0), "pgh_mat_gemv: null argument");
+    PGH_CHECK(count >= 0 && count <= m->b && count <= 1024 && out->n == m->n, "pgh_mat_gemv: shape mismatch");
+    if (m->n == 0) return 0;
+    Runtime& r = rt();
+    double* d = nullptr;
+    PGH_TRY(pool_alloc(sizeof(double) * (size_t)(count > 0 ? count : 1), (void**)&d));
+    if (count > 0) {
+        PGH_HIP(hipMemcpyAsync(d, coeffs_host, sizeof(double) * count, hipMemcpyHostToDevice, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));           // the caller's array may go away
+    }
+    k_mat_gemv<<<grid_for(m->n, 8), kBlock, 0, r.stream>>>(m->data, m->n, m->b, d, count, out->data);
+    PGH_HIP(hipGetLastError());
+    pool_free(d);
+    return 0;
+}
+
+// Ordinals / Top (postprocess.py:163-195, 246-290): positions of the entries in descending order of value, ties in ascending
+// index order (python's sorted(..., reverse=True) is stable).  One device radix sort of (value, index) pairs.
+namespace {
+__global__ void k_iota_i32(int32_t* p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (int32_t)i;
+}
+__global__ void k_scatter_ordinals(const int32_t* __restrict__ order, int64_t n, float* __restrict__ out) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+        out[order[k]] = (float)(k + 1);
+}
+int sort_descending(pgh_vec_t x, float** keys_out, int32_t** order_out) {
+    Runtime& r = rt();
+    const int64_t n = x->n;
+    PGH_CHECK(n < 2147483647LL, "sort: vector too long");
+    float* keys = nullptr;
+    int32_t *idx = nullptr, *order = nullptr;
+    PGH_TRY(pool_alloc(sizeof(float) * (size_t)(n > 0 ? n : 1), (void**)&keys));
+    PGH_TRY(pool_alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1), (void**)&idx));
+    PGH_TRY(pool_alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1), (void**)&order));
+    if (n > 0) {
+        k_iota_i32<<<grid_for(n), kBlock, 0, r.stream>>>(idx, n);
+        size_t temp_bytes = 0;
+        PGH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, temp_bytes, x->data, keys, idx, order, (int)n, 0, 32, r.stream));
+        void* temp = nullptr;
+        PGH_TRY(pool_alloc(temp_bytes > 0 ? temp_bytes : 1, &temp));
+        PGH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, x->data, keys, idx, order, (int)n, 0, 32, r.stream));
+        pool_free(temp);
+    }
+    pool_free(idx);
+    *keys_out = keys;
+    *order_out = order;
+    return 0;
+}
+}  // namespace
+
+extern "C" int pgh_vec_ordinals(pgh_vec_t x, pgh_vec_t out) {
+    PGH_CHECK(x && out && x->n == out->n && x->data != out->data, "pgh_vec_ordinals: bad arguments");
+    float* keys = nullptr;
+    int32_t* order = nullptr;
+    PGH_TRY(sort_descending(x, &keys, &order));
+    if (x->n > 0) k_scatter_ordinals<<<grid_for(x->n), kBlock, 0, rt().stream>>>(order, x->n, out->data);
+    PGH_HIP(hipGetLastError());
+    pool_free(keys);
+    pool_free(order);
+    return 0;
+}
+
+extern "C" int pgh_vec_kth_largest(pgh_vec_t x, int64_t k, double* value) {
+    PGH_CHECK(x && value && k >= 1 && k <= x->n, "pgh_vec_kth_largest: k outside [1, n]");
+    float* keys = nullptr;
+    int32_t* order = nullptr;
+    PGH_TRY(sort_descending(x, &keys, &order));
+    float v = 0.f;
+    PGH_HIP(hipMemcpyAsync(&v, keys + (k - 1), sizeof(float), hipMemcpyDeviceToHost, rt().stream));
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    pool_free(keys);
+    pool_free(order);
+    *value = (double)v;
     return 0;
 }
 

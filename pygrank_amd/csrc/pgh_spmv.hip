@@ -73,11 +73,34 @@ struct EpiPoly64 {
     }
 };
 
-template <int IPT, typename XT, typename EPI>
+// graph_dropout(M, rate) (pytorch.py:34-38: torch.nn.functional.dropout on the edge values): an entry survives with
+// probability 1 - rate and is then scaled by 1 / (1 - rate); the mask is a pure function of (seed, entry index in
+// CSR(M^T) order), so a dropped graph is a (graph, rate, seed) triple and costs no memory.  Host twin: tests/kernel_checks.py.
+__device__ __forceinline__ float dropout_factor(uint64_t seed, uint64_t entry, uint32_t threshold, float keep_scale) {
+    uint64_t z = (seed ^ (entry * 0xD6E8FEB86659FD93ULL)) + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32) >= threshold ? keep_scale : 0.f;
+}
+struct NoDropout {
+    static constexpr bool kOn = false;
+    uint64_t seed;
+    uint32_t threshold;
+    float    keep_scale;
+};
+struct EdgeDropout {
+    static constexpr bool kOn = true;
+    uint64_t seed;
+    uint32_t threshold;      // floor(rate * 2^32): an entry is dropped when the high word of its hash is below it
+    float    keep_scale;     // 1 / (1 - rate)
+};
+
+template <int IPT, typename XT, typename EPI, typename DROP = NoDropout>
 __global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EPI epi, const XT* __restrict__ x,
                                                     const LoopState* __restrict__ state,
                                                     double* __restrict__ partial_sum,
-                                                    double* __restrict__ partial_delta) {
+                                                    double* __restrict__ partial_delta, DROP drop = DROP()) {
     constexpr int ITEMS = WG * IPT;
     __shared__ XT     s_prod[ITEMS];
     __shared__ int    s_rend[ITEMS + 1];
@@ -116,6 +139,7 @@ __global__ __launch_bounds__(WG) void k_spmv_merge(GraphView g, EPI epi, const X
             const bool ok = idx < tile_nnz;
             cidx[k] = ok ? g.col[z0 + idx] : 0;
             vals[k] = ok ? g.val[z0 + idx] : 0.f;
+            if (DROP::kOn) vals[k] *= dropout_factor(drop.seed, (uint64_t)(z0 + idx), drop.threshold, drop.keep_scale);
         }
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
@@ -633,6 +657,38 @@ extern "C" int pgh_spmv(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y) {
     ep.a = 1.0;
     ep.y = y->data;
     return single_step<EPI_PLAIN>(g, ep, x->data, nullptr, nullptr, PGH_ERR_L1);
+}
+
+// conv(signal, graph_dropout(M, rate)): the row-major kernel over CSR(M^T) with the dropout mask applied to the values as
+// they stream (pytorch.py:34-38).  rate in [0, 1); a fresh seed per call reproduces the reference's
+// "new mask at every graph_dropout call" (abstract_filters.py:59-62).
+extern "C" int pgh_spmv_dropout(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y, double rate, uint64_t seed) {
+    PGH_TRY(check_graph_vecs(g, x, y, "pgh_spmv_dropout"));
+    PGH_CHECK(rate >= 0.0 && rate < 1.0, "pgh_spmv_dropout: rate must lie in [0, 1)");
+    if (g->n_cols == 0) return 0;
+    PGH_CHECK(g->items_per_tile == WG * kIPT, "graph tile table was built for a different tile size");
+    Runtime& r = rt();
+    const GraphView v = view_of(g);
+    const StepGrid sg = grids_for(g);
+    EpiF32<EPI_PLAIN> epi;
+    epi.ep = EpiParams{};
+    epi.ep.a = 1.0;
+    epi.ep.y = y->data;
+    epi.a_eff = 1.f;
+    EdgeDropout drop;
+    drop.seed = seed;
+    drop.threshold = (uint32_t)floor(rate * 4294967296.0);
+    drop.keep_scale = (float)(1.0 / (1.0 - rate));
+    {
+        ProfScope prof(PGH_K_SPMV);
+        k_spmv_merge<kIPT, float, EpiF32<EPI_PLAIN>, EdgeDropout><<<sg.main_grid, WG, 0, r.stream>>>(v, epi, x->data, nullptr, r.d_partials,
+                                                                                                   r.d_partials + kMaxPartials, drop);
+    }
+    // rows that cross tiles: the carries already hold masked products
+    k_spmv_fixup<float, EpiF32<EPI_PLAIN>><<<sg.fix_grid, WG, 0, r.stream>>>(v, epi, nullptr, r.d_partials + sg.main_grid,
+                                                                            r.d_partials + kMaxPartials + sg.main_grid);
+    PGH_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" int pgh_ppr_step(pgh_graph_t g, pgh_vec_t x, double x_scale, pgh_vec_t p, double alpha, pgh_vec_t y,

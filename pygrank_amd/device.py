@@ -180,6 +180,17 @@ class DeviceVector:
     def mean(self):
         return self.sum() / self._n
 
+    def ordinals(self):
+        """1 for the largest entry, 2 for the next ... (ties: lower index first); one device radix sort."""
+        out = DeviceVector.empty(self._n)
+        L.check(L.lib().pgh_vec_ordinals(self._h, out._h))
+        return out
+
+    def kth_largest(self, k):
+        out = C.c_double()
+        L.check(L.lib().pgh_vec_kth_largest(self._h, int(k), C.byref(out)))
+        return out.value
+
     def dot(self, other):
         out = C.c_double()
         L.check(L.lib().pgh_dot(self._h, other._h, C.byref(out)))
@@ -308,6 +319,16 @@ class DeviceMatrix:
         out = DeviceMatrix.empty(self.n, self.b)
         L.check(L.lib().pgh_mat_div_cols(self._h, _ptr(d), out._h))
         return out
+
+    def gemv(self, coeffs):
+        """sum_j self[:, j] * coeffs[j] over the leading len(coeffs) columns (pgh_mat_gemv, f64 accumulation)."""
+        c = np.ascontiguousarray(coeffs, dtype=np.float64)
+        out = DeviceVector.empty(self.n)
+        L.check(L.lib().pgh_mat_gemv(self._h, _ptr(c), len(c), out._h))
+        return out
+
+    def set_column(self, j, vec):
+        L.check(L.lib().pgh_mat_set_col(self._h, int(j), vec._h))
 
     def get_cols(self, first, count):
         out = DeviceMatrix.empty(self.n, count)
@@ -439,3 +460,28 @@ class DeviceGraph:
 
     def tocoo(self):
         return self.download_transposed().T.tocoo()
+
+
+class DroppedGraph:
+    """graph_dropout(M, rate) with rate > 0 (pygrank/core/backend/pytorch.py:34-38): the same graph with every entry kept
+    with probability 1 - rate and scaled by 1 / (1 - rate).  The mask is a pure function of (seed, entry index) that the
+    SpMV kernel evaluates on the fly (include/pgh.h pgh_spmv_dropout)."""
+
+    def __init__(self, base, rate, seed):
+        if not 0 <= rate < 1:
+            raise L.EngineError("graph_dropout: the rate must lie in [0, 1)")
+        self.base, self.rate, self.seed = base, rate, seed
+        self.shape = base.shape
+
+    def conv(self, x):
+        if isinstance(x, DeviceMatrix):
+            return DeviceMatrix.from_columns([self.conv(c) for c in x.columns()])
+        y = DeviceVector.empty(self.shape[1])
+        L.check(L.lib().pgh_spmv_dropout(self.base._h, x._h, y._h, self.rate, self.seed))
+        return y
+
+    def degrees(self):
+        raise L.EngineError("degrees() of a dropped graph is not available (take them from the graph itself)")
+
+    def format(self):
+        return f"dropout {self.rate} (seed {self.seed}) over " + self.base.format()

@@ -364,6 +364,39 @@ class ImpulseGraphFilter(GraphFilter):
 # =====================================================================================================
 # closed-form (polynomial) filters
 # =====================================================================================================
+class _PowerSlab:
+    """The device form of the optimisation dict (abstract_filters.py:232-246): the powers
+    {(M^T)^k p, k = 0, 1, ...} of ONE personalization as the columns of an [n, 64] slab in HBM, extended on demand (one
+    conv per new column), with the L1 and L-inf norm of every column on the host.  A filter evaluated from it costs one
+    pass over the slab (pgh_mat_gemv) instead of one SpMV per term -- what a tuner that probes hundreds of coefficient
+    vectors on the same personalization (autotune/parameterized.py:135-145) needs."""
+    WIDTH = 64
+
+    def __init__(self, graph, p):
+        from pygrank_amd.device import DeviceMatrix
+        self.graph = graph
+        self.mat = DeviceMatrix.empty(len(p), self.WIDTH)
+        self.count = 0
+        self.l1, self.linf = [], []
+        self._last = None
+        self._push(p)
+
+    def _push(self, col):
+        self.mat.set_column(self.count, col)
+        self.l1.append(float(col.abssum()))
+        self.linf.append(float(backend.max(backend.abs(col))) if len(col) else 0.0)
+        self._last = col
+        self.count += 1
+
+    def ensure(self, columns):
+        """Makes the first `columns` powers available; False when they do not fit the slab."""
+        if columns > self.WIDTH:
+            return False
+        while self.count < columns:
+            self._push(self.graph.conv(self._last))
+        return True
+
+
 class ClosedFormGraphFilter(GraphFilter):
     """abstract_filters.py:152-270: sum_k c_k (M^T)^k p with Taylor or the reference's "chebyshev" recurrence."""
 
@@ -444,10 +477,50 @@ class ClosedFormGraphFilter(GraphFilter):
             self.convergence.iteration = saved
         return coeffs
 
+    def _fused_from_powers(self, M, personalization, ranks, out_scale):
+        """optimization_dict route: the filter as ONE pass over the stored powers of this personalization.  The stopping
+        iteration follows ConvergenceManager (convergence.py:77-101) on the exact change of every step, |c_k| * ||term_k||
+        (the reference compares result_k with result_{k-1} = result_k - c_k term_k)."""
+        cm = self.convergence
+        g = _device_graph(M)
+        p = personalization.np
+        if type(cm) is not ConvergenceManager or cm.device_error_kind() is None or g is None or g.shape[0] != g.shape[1] \
+                or not isinstance(p, DeviceVector) or self.coefficient_type != "taylor" or self._active_dict is None:
+            return False
+        slab = self._active_dict.get("powers")
+        if not isinstance(slab, _PowerSlab) or slab.graph is not g:
+            slab = _PowerSlab(g, p)
+            self._active_dict["powers"] = slab
+        kind, tol, n = cm.device_error_kind(), cm.effective_tolerance(), max(len(p), 1)
+        coeffs, prev, it, converged, delta = [], None, 0, False, None
+        while True:
+            it += 1
+            if it >= cm.max_iters:
+                break
+            if delta is not None and kind != L.ERR_ITERS and it % cm.end_modulo == 0 and delta <= tol:
+                converged = True
+                break
+            cm.iteration = it                           # _coefficient reads convergence.iteration
+            prev = self._coefficient(prev)
+            if not slab.ensure(it):
+                return False                            # more terms than the slab holds: the step-by-step route
+            c = float(prev)
+            coeffs.append(c)
+            norm = slab.linf[it - 1] if kind == L.ERR_LINF else slab.l1[it - 1]
+            delta = abs(c) * norm / (n if kind == L.ERR_MABS else 1)
+        ranks.np = slab.mat.gemv(np.asarray(coeffs, dtype=np.float64) * float(out_scale)) if coeffs \
+            else backend.repeat(0.0, len(p))
+        self.last_loop = dict(iterations=it, converged=converged, spmv=0, last_error=delta, loop_ms=0.0, terms=len(coeffs))
+        cm.finish_device_loop(it, converged)
+        return True
+
     def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
-        if args or kwargs or self.optimization_dict is not None or type(self)._step is not ClosedFormGraphFilter._step \
+        if args or kwargs or type(self)._step is not ClosedFormGraphFilter._step \
                 or type(self)._recursion is not ClosedFormGraphFilter._recursion:
             return False
+        if self.optimization_dict is not None:
+            return type(self)._retrieve_power is ClosedFormGraphFilter._retrieve_power \
+                and self._fused_from_powers(M, personalization, ranks, out_scale)
         if self.coefficient_type not in ("taylor", "chebyshev"):
             raise Exception("Invalid coefficient type")
         cfg = self._loop_cfg(0.0, False, out_scale)

@@ -1,4 +1,5 @@
-"""Residual measures used as convergence criteria: Mabs (default), L1, MaxDifference.
+"""Residual measures used as convergence criteria -- Mabs (default), L1, MaxDifference -- and the residual-style supervised
+measures on vectors already in HBM (RMabs, MSQ, MSQRT, L2, Euclidean, Cos, Dot; supervised.py:109-154,208-222).
 
 Restates pygrank/measures/supervised.py:18-47 (Supervised.to_numpy), :93-98 (MaxDifference), :101-106 (Mabs),
 :133-138 (L1).  When both operands are HBM vectors the residual is ONE fused HIP reduction
@@ -65,3 +66,60 @@ class Mabs(Supervised):                                      # supervised.py:101
 
 class L1(Supervised):                                        # supervised.py:133-138
     _KIND = L.ERR_L1
+
+
+class _Pairwise(Supervised):
+    """Measures that are a handful of device reductions over the two score vectors."""
+
+    def _pair(self, scores):
+        known, scores = self.to_numpy(scores)
+        if not (isinstance(known, DeviceVector) and isinstance(scores, DeviceVector)):
+            raise Exception("residual measures expect backend vectors")
+        return known, scores
+
+    def _squared_distance(self, scores):
+        known, scores = self._pair(scores)
+        d = known - scores
+        return d.dot(d), len(scores)
+
+
+class RMabs(_Pairwise):                                      # supervised.py:109-114
+    def evaluate(self, scores):
+        known, scores = self._pair(scores)
+        out = C.c_double()
+        L.check(L.lib().pgh_residual(L.ERR_L1, known._h, scores._h, C.byref(out)))
+        return out.value / known.abssum()
+
+
+class MSQ(_Pairwise):                                        # supervised.py:117-122
+    def evaluate(self, scores):
+        total, n = self._squared_distance(scores)
+        return total / n
+
+
+class MSQRT(_Pairwise):                                      # supervised.py:125-130
+    def evaluate(self, scores):
+        total, n = self._squared_distance(scores)
+        return (total / n) ** 0.5
+
+
+class L2(_Pairwise):                                         # supervised.py:141-146 (the squared distance, as the reference)
+    def evaluate(self, scores):
+        return self._squared_distance(scores)[0]
+
+
+class Euclidean(_Pairwise):                                  # supervised.py:149-154
+    def evaluate(self, scores):
+        return self._squared_distance(scores)[0] ** 0.5
+
+
+class Cos(_Pairwise):                                        # supervised.py:208-214
+    def evaluate(self, scores):
+        known, scores = self._pair(scores)
+        return backend.safe_div(known.dot(scores), (known.dot(known) * scores.dot(scores)) ** 0.5)
+
+
+class Dot(_Pairwise):                                        # supervised.py:217-222
+    def evaluate(self, scores):
+        known, scores = self._pair(scores)
+        return known.dot(scores)

@@ -1,11 +1,14 @@
-"""The two postprocessors the propagation path itself needs.
+"""Postprocessors that act on rank vectors already resident in HBM.
 
 ``Tautology`` is the default ``personalization_transform`` of every filter (abstract_filters.py:37) and ``Normalize`` is
 the callable form of ``use_quotient`` (abstract_filters.py:131-132; the reference's filter tests compare outcomes after
-``Normalize``, tests/test_filters.py:41-82).  Behaviour follows pygrank/algorithms/postprocess/postprocess.py:7-80,106-160;
-the normalisation constants are device reductions (pgh_reduce / pgh_dot) and the rescale is one elementwise kernel.  The
-rest of the postprocessor family re-invokes the hot path."""
+``Normalize``, tests/test_filters.py:41-82).  ``Ordinals`` / ``Top`` / ``Threshold`` / ``Transformer`` / ``Sweep`` /
+``LinearSweep`` are SURVEY.md 8f-3: elementwise kernels, device reductions and one device radix sort instead of the
+reference's per-node Python dictionaries.  Behaviour follows pygrank/algorithms/postprocess/postprocess.py:7-80,106-290,
+353-450.  The remaining postprocessors (oversampling, fairness, subgraph extraction) re-invoke the hot path and stay out of
+scope."""
 from pygrank_amd import backend
+from pygrank_amd.device import DeviceVector
 from pygrank_amd.signals import NodeRanking, to_signal
 from pygrank_amd.utils import call, ensure_used_args, remove_used_args
 
@@ -84,3 +87,119 @@ class Normalize(Postprocessor):
         if high == low:
             return ranks                                           # constant (or zero) signals stay as they are
         return (x - low) / (high - low)
+
+
+def _device(ranks):
+    x = ranks.np
+    return x if isinstance(x, DeviceVector) else backend.to_array(x)
+
+
+def _swap(first, second):
+    """The reference's constructors accept (ranker, value) in either order (postprocess.py:124-131,246-252)."""
+    if first is not None and not _is_ranker(first):
+        first, second = (second if _is_ranker(second) else None), first
+    return (first if first is not None else Tautology()), second
+
+
+class Ordinals(Postprocessor):
+    """1 for the highest rank, 2 for the second highest, ... (postprocess.py:163-195); ties keep node order."""
+
+    def __init__(self, ranker=None):
+        super().__init__(Tautology() if ranker is None else ranker)
+
+    def _transform(self, ranks, **kwargs):
+        ensure_used_args(kwargs)
+        return _device(ranks).ordinals()
+
+
+class Transformer(Postprocessor):
+    """Element-by-element expression, backend.exp by default (postprocess.py:198-243)."""
+
+    def __init__(self, ranker=None, expr=None):
+        ranker, expr = _swap(ranker, expr)
+        super().__init__(ranker)
+        self.expr = backend.exp if expr is None else expr
+
+    def _transform(self, ranks, **kwargs):
+        ensure_used_args(kwargs)
+        return self.expr(ranks.np)
+
+
+class Top(Postprocessor):
+    """1 for the top-scored nodes, 0 for the rest; ``fraction_of_training`` >= 1 counts nodes, < 1 is a share of the graph
+    (postprocess.py:246-290: every node that ties with the last kept one is kept too)."""
+
+    def __init__(self, ranker=None, fraction_of_training=1):
+        ranker, fraction = _swap(ranker, fraction_of_training)
+        super().__init__(ranker)
+        self.fraction_of_training = 1 if fraction is None else fraction
+
+    def _transform(self, ranks, **kwargs):
+        ensure_used_args(kwargs)
+        x = _device(ranks)
+        keep = self.fraction_of_training
+        keep = int(keep * len(x)) if keep < 1 else int(keep)
+        threshold = x.kth_largest(keep) if 1 <= keep <= len(x) else 0     # the reference's loop leaves 0 otherwise
+        return (x >= threshold) * 1.0
+
+
+class Threshold(Postprocessor):
+    """1 above a threshold, 0 elsewhere (postprocess.py:293-350); "gap" = the score after the largest relative drop."""
+
+    def __init__(self, ranker=None, threshold=0, inclusive=False):
+        ranker, threshold = _swap(ranker, threshold)
+        super().__init__(ranker)
+        self.threshold = 0 if threshold is None else threshold
+        self.inclusive = inclusive
+
+    def _transform(self, ranks, **kwargs):
+        ensure_used_args(kwargs)
+        x = _device(ranks)
+        threshold = self.threshold
+        if threshold == "gap":
+            import numpy as np
+            v = np.sort(np.asarray(x, dtype=np.float64))[::-1]
+            threshold = 0
+            prev, rest = v[:-1], v[1:]
+            ok = prev > 0
+            if ok.any():
+                drop = np.where(ok, (prev - rest) / np.where(ok, prev, 1.0), -1.0)
+                if drop.max() > 0:
+                    threshold = float(rest[int(np.argmax(drop))])     # first largest drop, as the reference's strict ">"
+        return ((x >= threshold) if self.inclusive else (x > threshold)) * 1.0
+
+
+class _UniformBaseline(Postprocessor):
+    """Sweep family: personalized ranks set against the same ranker's non-personalized outcome, computed once per graph."""
+
+    def __init__(self, ranker=None, uniform_ranker=None):
+        super().__init__(ranker)
+        self.uniform_ranker = ranker if uniform_ranker is None else uniform_ranker
+        self._baseline = {}
+
+    def _uniforms(self, ranks):
+        key = id(ranks.graph)
+        if key not in self._baseline:
+            self._baseline[key] = (ranks.graph, _device(self.uniform_ranker.rank(ranks.graph)))   # keeps the graph alive: ids are not reused
+        return self._baseline[key][1]
+
+    def __lshift__(self, ranker):
+        super().__lshift__(ranker)
+        self.uniform_ranker = ranker
+        return ranker
+
+
+class Sweep(_UniformBaseline):
+    """ranks / (1e-12 + uniform ranks) (postprocess.py:353-404)."""
+
+    def _transform(self, ranks, **kwargs):
+        ensure_used_args(kwargs)
+        return _device(ranks) / (self._uniforms(ranks) + 1.E-12)
+
+
+class LinearSweep(_UniformBaseline):
+    """ranks - uniform ranks (postprocess.py:407-450)."""
+
+    def _transform(self, ranks, **kwargs):
+        ensure_used_args(kwargs)
+        return _device(ranks) - self._uniforms(ranks)

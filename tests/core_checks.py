@@ -272,11 +272,92 @@ def check_optimization_dict(pg):                             # tests/test_filter
     signal = pg.to_signal(graph, {"A": 1, "B": 1})
     cache = dict()
     a = pg.HeatKernel(t=3, preprocessor=pre, optimization_dict=cache, error_type="iters", max_iters=12).rank(signal)
-    assert len(cache) == 1 and len(next(iter(cache.values()))) == 11
+    inner = next(iter(cache.values()))
+    # the reference keeps 11 cached convolutions (one per iteration); the engine keeps the 11 powers it needs as the
+    # columns of one device slab (filters._PowerSlab)
+    assert len(cache) == 1 and (len(inner) == 11 or inner["powers"].count == 11)
     b = pg.HeatKernel(t=3, preprocessor=pre, optimization_dict=cache, error_type="iters", max_iters=12).rank(signal)
     c = pg.HeatKernel(t=3, preprocessor=pre, error_type="iters", max_iters=12).rank(signal)
     assert pg.Mabs(a)(b) == 0
     assert pg.Mabs(a)(c) < 4 * pg.epsilon()
+
+
+def check_power_slab_serves_tuner_probes(pg):
+    """with an optimisation dict the powers {(M^T)^k p} of a personalization live in ONE device slab and every
+    further filter on that personalization (a tuner probing weight vectors, autotune/parameterized.py:135-145) is one pass
+    over it -- same results and iteration counts as the step-by-step loops, no further convolutions."""
+    import cases
+    A, directed, p = cases.GRAPHS["rmat10_dir"]()
+    graph = pg.AdjacencyWrapper(A, directed=directed)
+    pre = pg.preprocessor(assume_immutability=True)
+    signal = pg.to_signal(graph, p.copy())
+    cache = dict()
+    rng = np.random.default_rng(4)
+    probes = [list(rng.random(12)) for _ in range(5)] + [[0.5, 0.3, 0, 0.2], [1.0]]
+    columns = None
+    for weights in probes:
+        cached = pg.GenericGraphFilter(weights, preprocessor=pre, optimization_dict=cache, tol=1e-8, max_iters=100)
+        got = np.asarray(cached.rank(signal).np, dtype=np.float64)
+        plain = pg.GenericGraphFilter(weights, preprocessor=pre, tol=1e-8, max_iters=100)
+        want = np.asarray(plain.rank(signal).np, dtype=np.float64)
+        assert cached.convergence.iteration == plain.convergence.iteration, weights
+        assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), weights
+        assert cached.last_loop["spmv"] == 0 and cached.last_loop["terms"] == cached.convergence.iteration - 1
+        slab = next(iter(cache.values()))["powers"]
+        columns = max(columns or 0, slab.count)
+        assert slab.count == columns                      # the slab only ever grows to the longest probe
+    assert len(cache) == 1 and columns <= 14
+    # HeatKernel to a tolerance through the same slab machinery, and the non-convergence exception
+    hk = pg.HeatKernel(3, preprocessor=pre, optimization_dict=dict(), tol=1e-7, max_iters=60)
+    ref = pg.HeatKernel(3, preprocessor=pre, tol=1e-7, max_iters=60)
+    a, b = np.asarray(hk.rank(signal).np, dtype=np.float64), np.asarray(ref.rank(signal).np, dtype=np.float64)
+    assert hk.convergence.iteration == ref.convergence.iteration and np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(b))
+    try:
+        pg.HeatKernel(3, preprocessor=pre, optimization_dict=dict(), tol=1e-12, max_iters=5).rank(signal)
+        raise AssertionError("expected a non-convergence exception")
+    except Exception as exc:
+        assert "converge" in str(exc)
+
+
+def check_device_postprocessors_and_measures(pg):
+    """SURVEY.md 8f-3 against outcomes of the reference itself (tests/golden/golden_post.npz, written by make_golden.py):
+    Ordinals / Top / Threshold are exact on the reference's own ranks (integer / 0-1 outputs of one device sort and
+    elementwise kernels); Sweep / LinearSweep / Transformer / Normalize and the residual-style measures to fp32 rounding."""
+    import os
+    import cases
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_post.npz"))
+    A, directed, p = cases.GRAPHS["rmat10_dir"]()
+    graph = pg.AdjacencyWrapper(A, directed=directed)
+    ref_ranks = pg.to_signal(graph, gold["ranks"])
+    f32 = gold["ranks"].astype(np.float32).astype(np.float64)
+    distinct = len(np.unique(f32)) == len(np.unique(gold["ranks"]))       # no ties created by the fp32 storage
+
+    def out(algo):
+        return np.asarray(algo.transform(ref_ranks).np, dtype=np.float64)
+    if distinct:
+        assert np.array_equal(out(pg.Ordinals()), gold["post|ordinals"])
+    else:                                                                  # ties may swap neighbours: same multiset of ranks
+        assert np.array_equal(np.sort(out(pg.Ordinals())), np.sort(gold["post|ordinals"]))
+    assert np.array_equal(out(pg.Top(5)), gold["post|top5"])
+    assert np.array_equal(out(pg.Top(0.5)), gold["post|top_half"])
+    assert np.array_equal(out(pg.Threshold(0.02)), gold["post|threshold"])
+    assert np.array_equal(out(pg.Threshold(0.02, inclusive=True)), gold["post|threshold_inclusive"])
+    assert np.array_equal(out(pg.Threshold("gap")), gold["post|threshold_gap"])
+    for key, algo in (("transformer_exp", pg.Transformer()), ("normalize_range", pg.Normalize("range")), ("normalize_l2", pg.Normalize("L2"))):
+        got = out(algo)
+        assert np.max(np.abs(got - gold["post|" + key])) <= 4e-7 * np.max(np.abs(gold["post|" + key])), key
+    # the sweeps run the whole pipeline (two PageRank runs on the engine)
+    base = lambda: pg.PageRank(0.85, error_type="iters", max_iters=41)       # noqa: E731  (a stopping rule fp32 and fp64 engines share)
+    for key, algo in (("sweep", pg.Sweep(base())), ("linear_sweep", pg.LinearSweep(base()))):
+        got = np.asarray(algo.rank(graph, p.copy()).np, dtype=np.float64)
+        want = gold["post|" + key]
+        assert np.max(np.abs(got - want)) <= 2e-6 * np.max(np.abs(want)), (key, np.max(np.abs(got - want)) / np.max(np.abs(want)))
+    u, v = gold["measure|u"], gold["measure|v"]
+    du, dv = pg.to_array(u), pg.to_array(v)
+    for key, m in (("rmabs", pg.RMabs), ("msq", pg.MSQ), ("msqrt", pg.MSQRT), ("l2", pg.L2), ("euclidean", pg.Euclidean),
+                   ("cos", pg.Cos), ("dot", pg.Dot)):
+        got, want = float(m(du)(dv)), float(gold["measure|" + key])
+        assert abs(got - want) <= 1e-6 * abs(want), (key, got, want)
 
 
 def check_generic_route_equals_fused_route(pg):

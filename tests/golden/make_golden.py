@@ -76,6 +76,29 @@ def main():
     out["residual|linf"] = np.float64(pg.MaxDifference(u)(v))
     np.savez_compressed(os.path.join(HERE, "golden.npz"), **out)
 
+    # postprocessors and residual-style measures: reference outcomes on a fixed PageRank run
+    post = {}
+    A, directed, p = graph_cache["rmat10_dir"]
+    graph = pg.AdjacencyWrapper(A, directed=True)
+    base = lambda: pg.PageRank(0.85, error_type="iters", max_iters=41)       # noqa: E731  (a stopping rule fp32 and fp64 engines share)
+    ranks = base().rank(graph, p.copy())
+    post["ranks"] = np.asarray(ranks.np, dtype=np.float64)
+    for key, algo in (("ordinals", pg.Ordinals(base())), ("top5", pg.Top(base(), 5)), ("top_half", pg.Top(base(), 0.5)),
+                      ("threshold", pg.Threshold(base(), 0.02)), ("threshold_inclusive", pg.Threshold(base(), 0.02, inclusive=True)),
+                      ("threshold_gap", pg.Threshold(base(), "gap")),
+                      ("sweep", pg.Sweep(base())), ("linear_sweep", pg.LinearSweep(base())),
+                      ("transformer_exp", pg.Transformer(base())), ("normalize_range", pg.Normalize(base(), "range")),
+                      ("normalize_l2", pg.Normalize(base(), "L2"))):
+        out = algo.rank(graph, p.copy())
+        post["post|" + key] = np.asarray([out[v] for v in range(A.shape[0])], dtype=np.float64)
+    rng2 = np.random.default_rng(13)
+    u, v = rng2.random(A.shape[0]), rng2.random(A.shape[0])
+    post["measure|u"], post["measure|v"] = u, v
+    for key, m in (("rmabs", pg.RMabs), ("msq", pg.MSQ), ("msqrt", pg.MSQRT), ("l2", pg.L2), ("euclidean", pg.Euclidean),
+                   ("cos", pg.Cos), ("dot", pg.Dot)):
+        post["measure|" + key] = np.float64(m(u)(v))
+    np.savez_compressed(os.path.join(HERE, "golden_post.npz"), **post)
+
     # normalised CSR fixtures (preprocessing.py:99-142) + degrees (numpy.py:76-77)
     norm = {}
     for gkey in ["rmat10_dir", "weighted300"]:

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import scipy.sparse as sp
 
-from oracle import rmat_np
+from oracle import ref_loops as orc, rmat_np
 
 F32 = np.float32
 EPS32 = float(np.finfo(np.float32).eps)
@@ -130,6 +130,53 @@ def check_upload_rejects_invalid_csr(pg):
     assert rc != 0 and b"column index" in msg
     rc, msg = upload([0, 3, 2, 3], [0, 1, 2], [1., 1., 1.], 3, 3)       # decreasing row pointers
     assert rc != 0 and b"indptr" in msg
+
+
+def check_graph_dropout(pg):
+    """graph_dropout(M, rate) with rate > 0 (specification.py:13; pytorch.py:34-38): the mask is a hash of
+    (seed, entry of CSR(M^T)), so the product can be checked EXACTLY against scipy on the masked matrix rebuilt with the
+    numpy twin of the hash (oracle/rmat_np.splitmix64); plus the statistics of a dropout mask and the filter-level hooks."""
+    A = rmat_np.rmat_csr(11, 8, seed=2)
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    g = pg.scipy_sparse_to_backend(M)
+    MT = g.download_transposed()                                   # entry order of the mask
+    rng = np.random.default_rng(8)
+    x = rng.random(M.shape[0]).astype(F32).astype(np.float64)
+    assert pg.graph_dropout(g, 0) is g                             # identity and O(1)
+    for rate in (0.1, 0.5, 0.9):
+        pg.backend.hip.set_dropout_seed(41)
+        dropped = pg.graph_dropout(g, rate)
+        e = np.arange(MT.nnz, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            h = rmat_np.splitmix64(np.uint64(dropped.seed) ^ (e * np.uint64(0xD6E8FEB86659FD93)))
+        keep = (h >> np.uint64(32)).astype(np.int64) >= int(np.floor(rate * 4294967296.0))
+        assert abs(keep.mean() - (1 - rate)) < 0.02                # Bernoulli(1 - rate) survivors
+        masked = sp.csr_array(((MT.data * np.float32(1.0 / (1.0 - rate))).astype(F32).astype(np.float64) * keep, MT.indices, MT.indptr), shape=MT.shape)
+        got = _np(pg.conv(_vec(pg, x), dropped))
+        ref = masked @ x
+        scale = np.abs(masked) @ np.abs(x)
+        assert np.all(np.abs(got - ref) <= 2.5 * EPS32 * scale + 1e-30), rate
+        again = pg.graph_dropout(g, rate)                          # a new mask at every call (abstract_filters.py:59-62)
+        assert again.seed != dropped.seed and not np.array_equal(_np(pg.conv(_vec(pg, x), again)), got)
+    # E[dropout] = identity: the mean over masks approaches the plain product
+    plain = _np(pg.conv(_vec(pg, x), g))
+    acc = np.zeros_like(plain)
+    for _ in range(200):
+        acc += _np(pg.conv(_vec(pg, x), pg.graph_dropout(g, 0.5)))
+    assert np.abs(acc / 200 - plain).sum() <= 0.12 * np.abs(plain).sum()
+    # filter level: rank(..., graph_dropout=) takes the per-step route; deterministic under a fixed seed
+    graph = pg.AdjacencyWrapper(A, directed=True)
+    p = np.zeros(A.shape[0])
+    p[:20] = 1.0
+    outs = []
+    for _ in range(2):
+        pg.backend.hip.set_dropout_seed(7)
+        ranker = pg.PageRank(0.85, error_type="iters", max_iters=12)
+        outs.append(np.asarray(ranker.rank(graph, p.copy(), graph_dropout=0.3).np))
+        assert not hasattr(ranker, "last_loop") and ranker.convergence.iteration == 12
+    assert np.array_equal(outs[0], outs[1]) and abs(outs[0].sum() - 20.0) < 1e-3
+    base = np.asarray(pg.PageRank(0.85, error_type="iters", max_iters=12).rank(graph, p.copy()).np)
+    assert not np.allclose(outs[0], base) and np.corrcoef(outs[0], base)[0, 1] > 0.9
 
 
 def check_fused_steps(pg):
