@@ -486,6 +486,8 @@ __device__ __forceinline__ float wave_segmented_sum(float keep, float val) {
 // consecutive floats, no row indices are read (round 1 wrote part[block][row] through a prefetched row list: 74 MB of
 // row indices per launch at scale 23 and scattered 4-byte stores; the flag byte and the row list were fetched only one
 // tile ahead, which left every wavefront waiting on them -- SQ_WAIT_ANY 62 %, profiles/r02/r01_kernels_sq_counters.json).
+PGH_STAMP_DECL(g_times_partial)
+
 template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
                                                               const LoopState* __restrict__ state) {
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     // for predicated-off writes.  One array, so that every LDS address below is an offset from LDS address 0.
     __shared__ float s_lds[kBsfHot + 1 + WAVES * STRIP];
     if (state != nullptr && state->done) return;
+    PGH_STAMP_BEGIN(g_times_partial)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
@@ -717,6 +720,11 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         }
     }
 #undef PGH_STEP
+#if PGH_PROBE_TIMES
+    // wavefronts leave one by one: the workgroup's end = the latest of them (the clock only grows, so the maximum over
+    // launches is the last launch's)
+    if (lane == 0 && blockIdx.x < 4096) atomicMax(&g_times_partial[2 * blockIdx.x + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // build time: where the fix-up of tile t goes (index into the partial vectors, -1 = nothing to fix), so that the
@@ -822,6 +830,9 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, 
             if (f.val) k_bsf_partial<kIPT, true, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
             else k_bsf_partial<kIPT, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
         }
+    }
+    if (stage != 2) {
+        PGH_STAMP_DUMP(g_times_partial, main_grid, "k_bsf_partial")
     }
     if (stage == 1) {
         PGH_HIP(hipGetLastError());

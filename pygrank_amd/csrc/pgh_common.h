@@ -166,6 +166,12 @@ struct PbFormat {
     int4*     item_a = nullptr;
     int4*     item_b = nullptr;
     uint32_t* hub_ticket = nullptr; // [num_split] arrival counters of the pieces of split hub rows (re-armed by the last arriver)
+    // static schedule of k_pb_finish: workgroup w walks sched[sched_begin[w] .. sched_begin[w + 1]) -- item indices dealt by
+    // estimated cost (longest first onto the least loaded workgroup), so that the persistent workgroups finish together
+    int       sched_groups = 0;
+    int*      sched = nullptr;      // [num_items]
+    int*      sched_begin = nullptr;// [sched_groups + 1]
+    uint32_t* work_counter = nullptr; // dynamic hand-out of the schedule (one device word), or null = static deal
     int64_t   device_bytes = 0;
 };
 constexpr int kPbMaxSlices = 8;

@@ -2,6 +2,10 @@
 #pragma once
 #include "pgh_common.h"
 
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
 namespace pgh {
 
 constexpr int WG = 256;
@@ -218,6 +222,45 @@ __device__ __forceinline__ void bsf_fixup_tiles(const FixView& f, int first_tile
         }
     }
 }
+
+// diagnostic builds only (-DPGH_PROBE_TIMES=1): every workgroup stamps its start and end (100 MHz wall clock) so that the host
+// can print how evenly a launch's workgroups finish (tools/probe_variants.py with PGH_DUMP_TIMES=1)
+#ifndef PGH_PROBE_TIMES
+#define PGH_PROBE_TIMES 0
+#endif
+#if PGH_PROBE_TIMES
+#define PGH_STAMP_DECL(NAME) __device__ unsigned long long NAME[2 * 4096];
+#define PGH_STAMP_BEGIN(NAME) \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) NAME[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#define PGH_STAMP_END(NAME)                                                                              \
+    __syncthreads();                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) NAME[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#define PGH_STAMP_DUMP(NAME, GRID, LABEL)                                                                               \
+    if (getenv("PGH_DUMP_TIMES") != nullptr) {                                                                          \
+        static int dumped = 0;                                                                                          \
+        if (dumped++ == 8) {                                                                                            \
+            std::vector<unsigned long long> h(2 * 4096);                                                                \
+            (void)hipStreamSynchronize(rt().stream);                                                                    \
+            (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(NAME), sizeof(unsigned long long) * 2 * 4096);               \
+            const int n_ = (GRID) < 4096 ? (GRID) : 4096;                                                               \
+            unsigned long long t0 = ~0ULL;                                                                              \
+            for (int i = 0; i < n_; ++i) t0 = h[2 * i] < t0 ? h[2 * i] : t0;                                            \
+            std::vector<double> st(n_), en(n_);                                                                         \
+            for (int i = 0; i < n_; ++i) st[i] = (h[2 * i] - t0) * 0.01, en[i] = (h[2 * i + 1] - t0) * 0.01;            \
+            std::sort(st.begin(), st.end());                                                                            \
+            std::sort(en.begin(), en.end());                                                                            \
+            double mean = 0;                                                                                            \
+            for (double v : en) mean += v / n_;                                                                         \
+            fprintf(stderr, "[pgh times] %s: %d workgroups, start max %.1f us; end min %.1f p10 %.1f median %.1f mean %.1f p90 %.1f max %.1f us\n", \
+                    LABEL, n_, st[n_ - 1], en[0], en[n_ / 10], en[n_ / 2], mean, en[n_ * 9 / 10], en[n_ - 1]);          \
+        }                                                                                                               \
+    }
+#else
+#define PGH_STAMP_DECL(NAME)
+#define PGH_STAMP_BEGIN(NAME)
+#define PGH_STAMP_END(NAME)
+#define PGH_STAMP_DUMP(NAME, GRID, LABEL)
+#endif
 
 // blocked-format entry points (pgh_bsf.hip)
 // pgh_pb.hip: propagation-blocking image of the cold entries

@@ -65,6 +65,9 @@ constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in 
 #ifndef PGH_FIN_P
 #define PGH_FIN_P 2           // measured at scale 23 (profiles/r02/finish_pg_sweep.log): P x G = 4x4 108-113 us, 4x2 114, 2x4 104, 2x8 108, 6x4 118
 #endif
+#ifndef PGH_FIN_STAGGER
+#define PGH_FIN_STAGGER 0
+#endif
 #ifndef PGH_FIN_WPE
 #define PGH_FIN_WPE 4         // wavefronts per SIMD the small shape is compiled for (register budget 512 / WPE)
 #endif
@@ -204,6 +207,9 @@ struct PbView {
     const int4*     item_a;            // work list of k_pb_finish (PbFormat::item_a / item_b)
     const int4*     item_b;
     int             num_items;
+    const int*      sched;             // item order (PbFormat::sched); static deal: slices sched_begin[w] .. sched_begin[w + 1]
+    const int*      sched_begin;
+    uint32_t*       work_counter;      // dynamic hand-out: next position in `sched` (null = static deal)
     uint32_t*       hub_ticket;
     const uint16_t* drow;
     double*         hub_part;          // [num_bins] sums of the pieces of split hub rows
@@ -217,6 +223,9 @@ struct PbView {
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+PGH_STAMP_DECL(g_times_gather)
+PGH_STAMP_DECL(g_times_finish)
+
 // ---- phase A
 template <bool HAS_VAL>
 __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float* __restrict__ xg, const LoopState* __restrict__ state,
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
     __shared__ float s_x[kPbChunk];
     __shared__ uint32_t s_amax;
     if (state != nullptr && state->done) return;
+    PGH_STAMP_BEGIN(g_times_gather)
     if (threadIdx.x == 0) s_amax = 0u;
     // the cross-tile fix-ups of the blocked stream ride along (one launch and one dependent boundary fewer per step):
     // they touch nothing this kernel reads, and the next kernel (k_pb_finish) is the first to read their results
@@ -345,6 +355,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
     if ((threadIdx.x & 63) == 0 && amax != 0u) atomicMax(&s_amax, amax);
     __syncthreads();
     if (threadIdx.x == 0 && s_amax != 0u) atomicMax(f.amax, s_amax);
+    PGH_STAMP_END(g_times_gather)
 }
 
 // ---- phase B + epilogue
@@ -415,15 +426,64 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         }
     };
 
-    int item = blockIdx.x;
+    PGH_STAMP_BEGIN(g_times_finish)
+#if PGH_FIN_STAGGER > 0
+    // co-resident workgroups (the persistent grid is a multiple of the CU count: blockIdx / 256 = which of a CU's slots) start
+    // their item loops a fraction of an item apart, so that their traffic-free phases do not coincide
+    for (int k = 0; k < (int)(blockIdx.x >> 8) * PGH_FIN_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+#endif
+    // partials of sum(y) (and delta) accumulated since the last flush -> slot `where`: wavefront shuffle, then a fixed-order
+    // sum over the wavefronts; the accumulators start over
+    auto flush = [&](int where) __attribute__((always_inline)) {
+        double v = wave_reduce_sum(sum_y);
+        if ((tid & 63) == 0) s_red[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double total = 0.0;
+            for (int w = 0; w < WAVES; ++w) total += s_red[w];
+            partial_sum[where] = total;
+        }
+        if (MODE == EPI_POLY) {
+            __syncthreads();
+            v = ep.err_linf ? wave_reduce_max(delta) : wave_reduce_sum(delta);
+            if ((tid & 63) == 0) s_red[tid >> 6] = v;
+            __syncthreads();
+            if (tid == 0) {
+                double total = 0.0;
+                for (int w = 0; w < WAVES; ++w) total = ep.err_linf ? fmax(total, s_red[w]) : total + s_red[w];
+                partial_delta[where] = total;
+            }
+        }
+        __syncthreads();
+        sum_y = 0.0;
+        delta = 0.0;
+    };
+    // Items are handed out dynamically, most expensive first (f.sched = item indices by descending estimated cost; a
+    // device counter, re-armed by the last workgroup of the launch): the persistent workgroups finish within one small item
+    // of each other (a static deal left 18 us of a 97 us launch to imbalance, profiles/r02/wg_end_times.log).  Results do not
+    // depend on who processes what: sum(y) / delta partials are kept PER ITEM and folded in item order by the consumers.
+    __shared__ int s_next;
+    const bool dynamic = f.work_counter != nullptr;
+    int at = 0, at_end = 0;
+    if (dynamic) {
+        if (tid == 0) s_next = (int)atomicAdd(f.work_counter, 1u);
+        __syncthreads();
+        at = s_next;
+        at_end = f.num_items;
+    } else {
+        at = f.sched_begin[blockIdx.x];
+        at_end = f.sched_begin[blockIdx.x + 1];
+    }
+    int slot = at;                          // index of the current item in the schedule = its partial-sum slot
+    int item = at < at_end ? f.sched[at] : -1;
     int4 bin = make_int4(0, 0, 0, 0), epi = make_int4(0, 0, -1, 0);
     Round R;
-    if (item < f.num_items) {
+    if (item >= 0) {
         bin = f.item_a[item];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
         epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1, first item of the split row}
         fetch(bin, 0, R);
     }
-    while (item < f.num_items) {
+    while (item >= 0) {
         const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0x1f;
         const bool hub = ((bin.y >> 21) & 1) != 0;
         const int pieces = (int)((unsigned)bin.y >> 22) + 1;
@@ -474,9 +534,16 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             if (round + 1 < nrounds) fetch(bin, round + 1, R);
         }
         // ---- the next item's first stream round goes out before this item's epilogue
-        const int next = item + gridDim.x;
+        if (dynamic) {                      // the next item's index is fetched now, long before it is needed
+            if (tid == 0) s_next = (int)atomicAdd(f.work_counter, 1u);
+            __syncthreads();
+            at = s_next;
+        } else {
+            ++at;
+        }
+        const int next = at < at_end ? f.sched[at] : -1;
         int4 next_bin = make_int4(0, 0, 0, 0), next_epi = make_int4(0, 0, -1, 0);
-        if (next < f.num_items) {
+        if (next >= 0) {
             next_bin = f.item_a[next];
             next_epi = f.item_b[next];
             if (PGH_FIN_PREFETCH) fetch(next_bin, 0, R);
@@ -587,39 +654,22 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             }
         }
         __syncthreads();                                   // s_row / s_hub are reused by the next item
-        if (!PGH_FIN_PREFETCH && next < f.num_items) fetch(next_bin, 0, R);
+        if (dynamic) flush(slot);                          // per-item partials: the fold does not depend on the hand-out
+        slot = at;
+        if (!PGH_FIN_PREFETCH && next >= 0) fetch(next_bin, 0, R);
         item = next;
         bin = next_bin;
         epi = next_epi;
     }
-    // ---- this workgroup's partials of sum(y) (and delta): wavefront shuffle, then a fixed-order sum over the wavefronts
-    {
-        double v = wave_reduce_sum(sum_y);
-        if ((tid & 63) == 0) s_red[tid >> 6] = v;
-        __syncthreads();
-        if (tid == 0) {
-            double total = 0.0;
-            for (int w = 0; w < WAVES; ++w) total += s_red[w];
-            partial_sum[blockIdx.x] = total;
-        }
-        if (MODE == EPI_POLY) {
-            __syncthreads();
-            v = ep.err_linf ? wave_reduce_max(delta) : wave_reduce_sum(delta);
-            if ((tid & 63) == 0) s_red[tid >> 6] = v;
-            __syncthreads();
-            if (tid == 0) {
-                double total = 0.0;
-                for (int w = 0; w < WAVES; ++w) total = ep.err_linf ? fmax(total, s_red[w]) : total + s_red[w];
-                partial_delta[blockIdx.x] = total;
-            }
-        }
-    }
+    if (!dynamic) flush(blockIdx.x);                       // static deal: one partial per workgroup
     // the last workgroup to leave re-arms the words for the next launch (every workgroup has read amax long before its
     // ticket; the next phase A starts after this kernel)
     if (tid == 0 && atomicAdd(f.amax + 1, 1u) == gridDim.x - 1) {
         f.amax[0] = 0u;
         f.amax[1] = 0u;
+        if (dynamic) *f.work_counter = 0u;
     }
+    PGH_STAMP_END(g_times_finish)
 }
 
 PbView pb_view(const BsfFormat& f, const PbFormat& p) {
@@ -633,6 +683,9 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.item_a = p.item_a;
     v.item_b = p.item_b;
     v.num_items = p.num_items;
+    v.sched = p.sched;
+    v.sched_begin = p.sched_begin;
+    v.work_counter = p.work_counter;
     v.hub_ticket = p.hub_ticket;
     v.drow = p.drow;
     v.amax = p.amax;
@@ -942,7 +995,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     // consecutive), the row stretches between them cut into epilogue-only items, hub items first (they are the longest).
     {
         std::vector<int4> hub_a, hub_b, reg_a, reg_b;
-        const int stretch = p.bin_rows;                    // rows per epilogue-only item
+        const int stretch = p.bin_rows > 1024 ? 1024 : p.bin_rows;   // rows per epilogue-only item: small, they level the schedule
         auto cover = [&](int64_t lo, int64_t hi) {         // rows [lo, hi) have no cold entries in the image
             for (int64_t at = lo; at < hi; at += stretch) {
                 reg_a.push_back(make_int4((int)at, 0, 0, 0));
@@ -989,6 +1042,98 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             PGH_HIP(hipMemsetAsync(p.hub_part, 0, sizeof(double) * hub_a.size(), r.stream));
             PGH_HIP(hipMalloc(&p.hub_ticket, sizeof(uint32_t) * (size_t)p.num_split));
             PGH_HIP(hipMemsetAsync(p.hub_ticket, 0, sizeof(uint32_t) * (size_t)p.num_split, r.stream));
+        }
+        // ---- static schedule: persistent grid = what the CUs hold at once; items dealt longest-first onto the least
+        // loaded workgroup.  Cost model fitted at scale 23 (profiles/r02/finish_decompose_scale23.log: stream + atomics
+        // 0.72 ns per padded entry, epilogue 3.6 ns per row, 3.1 us per bin / 1.5 us per stretch without a stream).
+        {
+            const bool large = p.bin_rows > kPbBinRows;
+            const int by_regs = PGH_FIN_WPE * 4 / (kPbBThreads / 64);
+            int groups = r.num_cus * (large ? 1 : (by_regs < 4 ? (by_regs < 1 ? 1 : by_regs) : 4));
+            if (groups > p.num_items) groups = p.num_items;
+            if (groups > kMaxPartials) groups = kMaxPartials;
+            if (groups < 1) groups = 1;
+            std::vector<double> cost(p.num_items);
+            for (int i = 0; i < p.num_items; ++i)
+                cost[i] = 0.72 * 8.0 * (double)all_a[i].w + 3.6 * (double)all_b[i].y + (all_a[i].w > 0 ? 3100.0 : 1500.0);
+            std::vector<int> order(p.num_items);
+            for (int i = 0; i < p.num_items; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
+            // dynamic hand-out (per-item partial sums must fit the partial buffers): the schedule is the cost order itself
+            // (measured at scale 23, profiles/r02/wg_end_times.log: the dynamic hand-out costs ~6 us per item in atomics and
+            // per-item reductions -- 135 us against 105 for the static deals; it stays available as PGH_FIN_DYNAMIC=1)
+            const bool dynamic = p.num_items <= kMaxPartials && getenv("PGH_FIN_DYNAMIC") != nullptr && atoi(getenv("PGH_FIN_DYNAMIC")) != 0;
+            const char* deal_env = getenv("PGH_FIN_DEAL");
+            // 0 round-robin in row order (default; the cost-model deals 1 = snake by cost and 2 = longest-first measured
+            // 115-120 us against 105: what an item costs depends on how its entries collide in the LDS atomics, which the
+            // model does not see), 3 = one item per workgroup, handed out by the hardware dispatcher
+            const int deal = deal_env != nullptr ? atoi(deal_env) : 0;
+            if (deal == 3 && p.num_items <= kMaxPartials) groups = p.num_items;
+            std::vector<int> flat, begin(1, 0);
+            std::vector<std::pair<double, int>> heap;
+            if (dynamic) {
+                // hub pieces first (their last arriver folds the row), then by descending cost
+                std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+                    const bool hx = ((all_a[x].y >> 21) & 1) != 0, hy = ((all_a[y].y >> 21) & 1) != 0;
+                    return hx != hy ? hx : false;
+                });
+                flat = order;
+                for (int w = 0; w < groups; ++w) begin.push_back(0);
+                PGH_HIP(hipMalloc(&p.work_counter, sizeof(uint32_t)));
+                PGH_HIP(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), r.stream));
+            } else if (deal == 0 || deal == 1) {
+                // 0: item i -> workgroup i % groups in row order (neighbouring workgroups touch neighbouring rows);
+                // 1: by descending cost, dealt back and forth (snake) so that every workgroup gets one item of every cost tier
+                std::vector<std::vector<int>> lists(groups);
+                for (int i = 0; i < p.num_items; ++i) {
+                    const int it = deal == 0 ? i : order[i];
+                    const int tier = i / groups, pos = i % groups;
+                    lists[(deal == 1 && (tier & 1)) ? groups - 1 - pos : pos].push_back(it);
+                }
+                flat.reserve(p.num_items);
+                for (int w = 0; w < groups; ++w) {
+                    std::sort(lists[w].begin(), lists[w].end());
+                    flat.insert(flat.end(), lists[w].begin(), lists[w].end());
+                    begin.push_back((int)flat.size());
+                }
+            } else {
+                std::vector<std::vector<int>> lists(groups);
+                heap.reserve(groups);
+                for (int w = 0; w < groups; ++w) heap.emplace_back(0.0, w);
+                auto cmp = [](const std::pair<double, int>& x, const std::pair<double, int>& y) {
+                    return x.first > y.first || (x.first == y.first && x.second > y.second);
+                };
+                std::make_heap(heap.begin(), heap.end(), cmp);
+                for (int i : order) {
+                    std::pop_heap(heap.begin(), heap.end(), cmp);
+                    std::pair<double, int>& top = heap.back();
+                    lists[top.second].push_back(i);
+                    top.first += cost[i];
+                    std::push_heap(heap.begin(), heap.end(), cmp);
+                }
+                flat.reserve(p.num_items);
+                for (int w = 0; w < groups; ++w) {
+                    std::sort(lists[w].begin(), lists[w].end());        // hub items (lowest indices) first, then by row
+                    flat.insert(flat.end(), lists[w].begin(), lists[w].end());
+                    begin.push_back((int)flat.size());
+                }
+            }
+            p.sched_groups = groups;
+            PGH_HIP(hipMalloc(&p.sched, sizeof(int) * (size_t)(flat.size() + 1)));
+            PGH_HIP(hipMalloc(&p.sched_begin, sizeof(int) * (size_t)(groups + 1)));
+            PGH_HIP(hipMemcpyAsync(p.sched, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice, r.stream));
+            PGH_HIP(hipMemcpyAsync(p.sched_begin, begin.data(), sizeof(int) * begin.size(), hipMemcpyHostToDevice, r.stream));
+            PGH_HIP(hipStreamSynchronize(r.stream));
+            if (getenv("PGH_DEBUG") != nullptr && atoi(getenv("PGH_DEBUG")) != 0) {
+                double lo = 1e300, hi = 0, total = 0;
+                for (int w = 0; w + 1 < (int)begin.size(); ++w) {
+                    double load = 0;
+                    for (int k = begin[w]; k < begin[w + 1]; ++k) load += cost[flat[k]];
+                    lo = std::min(lo, load), hi = std::max(hi, load), total += load;
+                }
+                fprintf(stderr, "[pgh] pb finish schedule: %d items over %d workgroups, estimated load min %.1f mean %.1f max %.1f us\n",
+                        p.num_items, groups, lo * 1e-3, total / groups * 1e-3, hi * 1e-3);
+            }
         }
         PGH_HIP(hipStreamSynchronize(r.stream));           // the host vectors go out of scope
     }
@@ -1054,6 +1199,7 @@ int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, co
             else k_pb_gather<false><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
         }
     }
+    PGH_STAMP_DUMP(g_times_gather, p.num_tasks, "k_pb_gather")
     PGH_HIP(hipGetLastError());
     return 0;
 }
@@ -1068,13 +1214,7 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
     const bool large = p.bin_rows > kPbBinRows;
-    // persistent grid: as many workgroups as the CUs hold at once (LDS: 32 KB x 4 or 128 KB x 1 per CU)
-    // workgroups a CU holds at once: 4 by LDS (32 KB of row sums each), PGH_FIN_WPE wavefronts per SIMD by registers
-    const int by_regs = PGH_FIN_WPE * 4 / (kPbBThreads / 64);
-    int grid = r.num_cus * (large ? 1 : (by_regs < 4 ? (by_regs < 1 ? 1 : by_regs) : 4));
-    if (grid > p.num_items) grid = p.num_items;
-    if (grid > kMaxPartials) grid = kMaxPartials;
-    if (grid < 1) grid = 1;
+    const int grid = p.sched_groups;                   // persistent: as many workgroups as the CUs hold at once
     {
         ProfScope prof(PGH_K_PB_ACCUM);
         const bool wide = f.num_blocks > 4;               // 8 column blocks: 8-way row partitions
@@ -1084,7 +1224,8 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
         else k_pb_finish<MODE, 4, kPbBinRows, kPbBThreads><<<grid, kPbBThreads, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel);
     }
     PGH_HIP(hipGetLastError());
-    if (num_partials) *num_partials = grid;
+    PGH_STAMP_DUMP(g_times_finish, grid, "k_pb_finish")
+    if (num_partials) *num_partials = p.work_counter != nullptr ? p.num_items : grid;      // per item / per workgroup
     return 0;
 }
 template int pb_launch_finish<EPI_PLAIN>(pgh_graph_s*, const RowSums&, const EpiParams&, const LoopState*, int*);
@@ -1105,6 +1246,9 @@ void pb_destroy(PbFormat& p) {
     (void)hipFree(p.hub_ticket);
     (void)hipFree(p.item_a);
     (void)hipFree(p.item_b);
+    (void)hipFree(p.sched);
+    (void)hipFree(p.sched_begin);
+    (void)hipFree(p.work_counter);
     (void)hipFree(p.bin);
     (void)hipFree(p.drow);
     p = PbFormat();
