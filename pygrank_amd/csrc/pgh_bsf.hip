@@ -990,6 +990,7 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.tail_carry);
     (void)hipFree(f.head_partial);
     (void)hipFree(f.part);
+    (void)hipFree(f.mm_close);
     (void)hipFree(f.perm);
     (void)hipFree(f.src_scale);
     (void)hipFree(f.dst_scale);

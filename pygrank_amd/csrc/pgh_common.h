@@ -212,6 +212,7 @@ struct BsfFormat {
     double*   tail_carry = nullptr; // [num_tiles]
     double*   head_partial = nullptr;
     float*    part = nullptr;       // multi-seed layout only: per-tile head sums
+    int32_t*  mm_close = nullptr;   // multi-seed layout only: closing row of every entry (k_mm_close_rows, pgh_spmm.hip)
     // SpMV layout: block partial sums are stored COMPACTLY, one float per (block, row) segment in stream order (psum),
     // written sequentially by k_bsf_partial; the epilogue finds the segments of a row through one SegMeta word per
     // (block, 64 rows): bit r of mask = row 64 w + r has a segment in the block, base = index of the word's first segment

@@ -24,6 +24,7 @@ namespace {
 #define PGH_MM_UNROLL 8
 #endif
 constexpr int kLanes = 64;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTileMM = 64 * PGH_BSF_IPT;        // same tile table as the single-vector layout
 
 struct BatchState {
@@ -41,52 +42,123 @@ struct MMView {
     const uint32_t* colf;
     const float*    val;
     const int32_t*  seg_row;
+    const int32_t*  close;       // [num_entries] closing row of every entry (k_mm_close_rows)
     const int4*     tile;
     float*          head;        // [num_tiles][64]
     float*          tail;        // [num_tiles][64]
     int             num_tiles;
 };
 
+// closing row of every entry of the multi-seed stream (built once, ensure_mm_layout): -1 = the entry's segment goes on,
+// -2 = it ends the piece of the segment that was open when the tile started (-> head carry), otherwise the output row
+// of the segment that ends here.  A segment still open at the end of a tile leaves a tail carry.  With this word the
+// kernel needs no running segment counter and no dependent seg_row lookups.
+__global__ __launch_bounds__(WG) void k_mm_close_rows(const uint32_t* __restrict__ colf, const int4* __restrict__ tile,
+                                                       const int32_t* __restrict__ seg_row, int num_tiles, int32_t* __restrict__ close) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    const int stride = gridDim.x * (WG / 64);
+    for (int t = wave; t < num_tiles; t += stride) {
+        const int4 ti = tile[t];
+        const int64_t base = ti.x;
+        int before = 0;                                   // flags of the tile seen so far
+        for (int c = 0; c < kTileMM / 64; ++c) {
+            const int e = c * 64 + lane;
+            const bool flag = (colf[base + e] >> 31) != 0;
+            const unsigned long long mask = __ballot(flag);
+            const int k = before + __popcll(mask & (~0ULL >> (63 - lane)));       // flags at positions <= e
+            const bool next_flag = e + 1 < kTileMM && (colf[base + e + 1] >> 31) != 0;
+            int out = -1;
+            if (next_flag) {
+                if (k == 0) out = -2;
+                else {
+                    const int row = seg_row[ti.z + k];
+                    out = row >= 0 ? row : -1;
+                }
+            }
+            close[base + e] = out;
+            before += __popcll(mask);
+        }
+    }
+}
+
+// One wavefront = four groups of 16 lanes; a group walks its own 512-entry tile and a lane holds 4 of the <= 64 batch
+// columns, so ONE 16-byte load instruction of the wavefront fetches four 256-byte rows of the gather slab (the first
+// version fetched one row per instruction with lane = column and kept 8 of them in flight between dependent scalar
+// loads: 7.5 ms per pass at scale 23 whatever the batch width -- latency, not bandwidth).  The stream words of 16
+// entries are loaded by the group's 16 lanes and handed round with ds_bpermute; rows are gathered 8 entries ahead of
+// the sums that consume them (two register sets), stream words 16 entries ahead of the gathers.
+//
+// What bounds it now (profiles/r02/spmm_v2_*): of the 34.4 GB of rows gathered per pass at scale 23 / b = 64, 27.2 GB miss
+// the L2 and cross the fabric at 6.2 TB/s -- the ceiling the same box gives any L2-missing read stream, whether the
+// Infinity Cache or HBM serves it (tools/bw_probe: 5.3-6.2 TB/s re-reading 64-256 MB, 9 TB/s only below 32 MB).  An LRU
+// L2 of 4 MB keeps a row only if it comes back within ~10 K gathers: 19 % of the gathers.  Loading the rows of all but
+// the hottest sources with the streaming policy (nt) so that they would not evict the hot ones was measured and does
+// not change the hit rate (8.9-9.5 ms per step against 8.7).
 template <bool HAS_VAL>
 __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __restrict__ xg, int ld, int b, float* __restrict__ sums,
                                                     const BatchState* __restrict__ state) {
     if (state != nullptr && state->all_done) return;
     const int lane = threadIdx.x & 63;
+    const int l = lane & 15;
+    const int c4 = 4 * l;                                  // first of this lane's four columns
+    const int pull = (lane & 48) << 2;                     // ds_bpermute byte index of lane 0 of this group
+    const bool live = c4 < b;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (WG / 64) + (threadIdx.x >> 6)));
-    const int stride = gridDim.x * (WG / 64);
-    const bool live = lane < b;
-    for (int t = wave; t < f.num_tiles; t += stride) {
-        const int4 ti = f.tile[t];
-        const uint32_t* __restrict__ cw = f.colf + ti.x;
-        const float* __restrict__ vw = HAS_VAL ? f.val + ti.x : nullptr;
-        int cur = ti.z;                       // segment open when the tile starts
-        bool opened = false;                  // a flag has been seen in this tile (wave-uniform)
-        double acc = 0.0;                     // f64: a lane adds up to 512 terms serially (the single-vector kernel adds 8)
-        constexpr int U = PGH_MM_UNROLL;                  // row gathers in flight per wavefront
-        for (int e0 = 0; e0 < kTileMM; e0 += U) {
-            uint32_t w[U];
-            float x[U];
+    const int stride = gridDim.x * (WG / 64) * 4;
+    for (int t0 = wave * 4; t0 < f.num_tiles; t0 += stride) {
+        const int t = t0 + (lane >> 4);
+        const bool has = t < f.num_tiles;
+        const int64_t base = (int64_t)(has ? t : f.num_tiles - 1) * kTileMM;      // tiles are full and consecutive
+        uint32_t w0, w1, w2;
+        int c0, c1, c2;
+        float v0 = 1.f, v1 = 1.f, v2 = 1.f;
+        auto words = [&](int e16, uint32_t& w, int& c, float& v) __attribute__((always_inline)) {
+            const int64_t at = base + e16 + l;
+            w = __builtin_nontemporal_load(f.colf + at);
+            c = has ? __builtin_nontemporal_load(f.close + at) : -1;
+            if (HAS_VAL) v = __builtin_nontemporal_load(f.val + at);
+        };
+        auto gather = [&](uint32_t w, int half, f32x4 (&x)[8]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < U; ++j) w[j] = cw[e0 + j];                         // wave-uniform: scalar loads
-#pragma unroll
-            for (int j = 0; j < U; ++j) x[j] = live ? xg[(int64_t)(w[j] & 0x7fffffffu) * ld + lane] : 0.f;
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                if (w[j] >> 31) {                                                   // wave-uniform branch: a row segment starts
-                    if (!opened) {
-                        f.head[(int64_t)t * kLanes + lane] = (float)acc;            // piece of the segment open at tile start
-                        opened = true;
-                    } else {
-                        const int row = f.seg_row[cur];
-                        if (row >= 0 && live) sums[(int64_t)row * ld + lane] = (float)acc;
-                    }
-                    acc = 0.0;
-                    ++cur;
-                }
-                acc += (double)(HAS_VAL ? vw[e0 + j] * x[j] : x[j]);
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute(pull + 4 * (8 * half + j), (int)w) & 0x7fffffffu;
+                x[j] = live ? *reinterpret_cast<const f32x4*>(xg + (int64_t)src * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        };
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // f64: a lane adds up to 512 terms serially
+        auto consume = [&](int c, float v, int half, const f32x4 (&x)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ends = __builtin_amdgcn_ds_bpermute(pull + 4 * (8 * half + j), c);
+                f32x4 xv = x[j];
+                if (HAS_VAL) xv *= __int_as_float(__builtin_amdgcn_ds_bpermute(pull + 4 * (8 * half + j), __float_as_int(v)));
+                a0 += (double)xv.x;
+                a1 += (double)xv.y;
+                a2 += (double)xv.z;
+                a3 += (double)xv.w;
+                if (ends != -1) {                          // uniform inside a group
+                    const f32x4 s = {(float)a0, (float)a1, (float)a2, (float)a3};
+                    if (ends == -2) *reinterpret_cast<f32x4*>(f.head + (int64_t)t * kLanes + c4) = s;
+                    else if (live) __builtin_nontemporal_store(s, reinterpret_cast<f32x4*>(sums + (int64_t)ends * ld + c4));
+                    a0 = a1 = a2 = a3 = 0.0;
+                }
+            }
+        };
+        f32x4 xa[8], xb[8];
+        words(0, w0, c0, v0);
+        words(16, w1, c1, v1);
+        gather(w0, 0, xa);
+        for (int mr = 0; mr < kTileMM / 16; ++mr) {
+            gather(w0, 1, xb);
+            consume(c0, v0, 0, xa);
+            words(min(16 * (mr + 2), kTileMM - 16), w2, c2, v2);
+            if (mr + 1 < kTileMM / 16) gather(w1, 0, xa);
+            consume(c0, v0, 1, xb);
+            w0 = w1, c0 = c1, v0 = v1;
+            w1 = w2, c1 = c2, v1 = v2;
         }
-        f.tail[(int64_t)t * kLanes + lane] = (float)acc;                            // piece of the segment still open
+        if (has) *reinterpret_cast<f32x4*>(f.tail + (int64_t)t * kLanes + c4) = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
     }
 }
 
@@ -120,35 +192,79 @@ struct CombineParams {
     int          plain;      // 1: y = dst * sum
 };
 
+// (16 lanes x float4 per row, four rows per wavefront and pass, two passes in flight: the first version walked one row
+// per wavefront with lane = column and took 2.3 ms for its 8.4 GB at scale 23 / b = 64)
 __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, int ld, int b, const BatchState* __restrict__ state,
                                                     double* __restrict__ partial_sum /* [grid][64] */) {
     __shared__ double s_red[WG / 64][kLanes];
     if (state != nullptr && state->all_done) return;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
-    const int64_t wave = blockIdx.x * (int64_t)(WG / 64) + wave_in_wg;
-    const int64_t stride = (int64_t)gridDim.x * (WG / 64);
-    const bool live = lane < b;
-    const bool frozen = state != nullptr && live && state->done[lane] != 0;
-    const float a = c.plain ? 1.f : (float)(c.alpha * (state != nullptr && live ? state->scale[lane] : 1.0));
-    const float bc = (float)(1.0 - c.alpha);
-    double colsum = 0.0;
-    for (int64_t r = wave; r < n; r += stride) {
-        if (!live) continue;
-        const int64_t at = r * ld + lane;
-        float y;
-        if (frozen) {
-            y = c.y_old[at];
-        } else {
-            float s = c.sums[at];
-            if (c.dst_scale != nullptr) s *= c.dst_scale[r];
-            y = a * s;
-            if (!c.plain) y += bc * c.p[at];
+    const int l = lane & 15, c4 = 4 * l;
+    const bool live = c4 < b;
+    f32x4 a, frozen = {0.f, 0.f, 0.f, 0.f};                // per column: alpha * quotient; 1 = the column has stopped
+    bool any_frozen = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool col = c4 + k < b;
+        a[k] = c.plain ? 1.f : (float)(c.alpha * (state != nullptr && col ? state->scale[c4 + k] : 1.0));
+        if (state != nullptr && col && state->done[c4 + k] != 0) {
+            frozen[k] = 1.f;
+            any_frozen = true;
         }
-        c.y[at] = y;
-        if (c.xg_out != nullptr) c.xg_out[at] = c.src_scale != nullptr ? y * c.src_scale[r] : y;
-        colsum += (double)y;
     }
-    s_red[wave_in_wg][lane] = colsum;
+    any_frozen = __any(any_frozen);
+    const float bc = (float)(1.0 - c.alpha);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * 4 + (lane >> 4);
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * 4;
+    constexpr int U = 2;
+    for (int64_t r0 = first; r0 < n; r0 += stride * U) {
+        f32x4 sum[U], pv[U], yo[U];
+        float d[U], sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u * stride;
+            const bool ok = live && r < n;
+            const int64_t at = (ok ? r : 0) * ld + c4;
+            sum[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.sums + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            pv[u] = (ok && !c.plain) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.p + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            yo[u] = (ok && any_frozen) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.y_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[u] = (ok && c.dst_scale != nullptr) ? c.dst_scale[r] : 1.f;
+            sc[u] = (ok && c.xg_out != nullptr && c.src_scale != nullptr) ? c.src_scale[r] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u * stride;
+            if (!live || r >= n) continue;
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = sum[u][k];
+                if (c.dst_scale != nullptr) s *= d[u];
+                float v = a[k] * s;
+                if (!c.plain) v += bc * pv[u][k];
+                y[k] = frozen[k] != 0.f ? yo[u][k] : v;
+            }
+            const int64_t at = r * ld + c4;
+            *reinterpret_cast<f32x4*>(c.y + at) = y;
+            if (c.xg_out != nullptr) *reinterpret_cast<f32x4*>(c.xg_out + at) = c.src_scale != nullptr ? y * sc[u] : y;
+            s0 += (double)y.x;
+            s1 += (double)y.y;
+            s2 += (double)y.z;
+            s3 += (double)y.w;
+        }
+    }
+    // the four 16-lane groups hold the same columns: fold them in group order, then the wavefronts in wavefront order
+    s0 += __shfl_down(s0, 32, 64) + (__shfl_down(s0, 16, 64) + __shfl_down(s0, 48, 64));
+    s1 += __shfl_down(s1, 32, 64) + (__shfl_down(s1, 16, 64) + __shfl_down(s1, 48, 64));
+    s2 += __shfl_down(s2, 32, 64) + (__shfl_down(s2, 16, 64) + __shfl_down(s2, 48, 64));
+    s3 += __shfl_down(s3, 32, 64) + (__shfl_down(s3, 16, 64) + __shfl_down(s3, 48, 64));
+    if (lane < 16) {
+        s_red[wave_in_wg][c4 + 0] = s0;
+        s_red[wave_in_wg][c4 + 1] = s1;
+        s_red[wave_in_wg][c4 + 2] = s2;
+        s_red[wave_in_wg][c4 + 3] = s3;
+    }
     __syncthreads();
     if (wave_in_wg == 0) {
         double t = 0.0;
@@ -184,20 +300,49 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
     __shared__ double s_red[WG / 64][kLanes];
     if (state->all_done) return;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
-    const int64_t wave = blockIdx.x * (int64_t)(WG / 64) + wave_in_wg;
-    const int64_t stride = (int64_t)gridDim.x * (WG / 64);
-    const bool live = lane < b;
-    const double S = live ? state->sum[lane] : 1.0;
-    const double inv = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
-    const double scale = live ? state->scale[lane] : 1.0;
-    double acc = 0.0;
-    if (live && !state->done[lane]) {
-        for (int64_t r = wave; r < n; r += stride) {
-            const double d = fabs((double)y[r * ld + lane] * inv - (double)y_old[r * ld + lane] * scale);
-            acc = linf ? fmax(acc, d) : acc + d;
+    const int l = lane & 15, c4 = 4 * l;
+    double inv[4], scale[4], acc[4] = {0.0, 0.0, 0.0, 0.0};
+    bool want[4], any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool col = c4 + k < b;
+        const double S = col ? state->sum[c4 + k] : 1.0;
+        inv[k] = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+        scale[k] = col ? state->scale[c4 + k] : 1.0;
+        want[k] = col && !state->done[c4 + k];
+        any = any || want[k];
+    }
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * 4 + (lane >> 4);
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * 4;
+    constexpr int U = 4;
+    if (any) {
+        for (int64_t r0 = first; r0 < n; r0 += stride * U) {
+            f32x4 a[U], o[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = r0 + u * stride;
+                const int64_t at = (r < n ? r : 0) * ld + c4;
+                a[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + at));
+                o[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y_old + at));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r0 + u * stride >= n) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double d = fabs((double)a[u][k] * inv[k] - (double)o[u][k] * scale[k]);
+                    acc[k] = linf ? fmax(acc[k], d) : acc[k] + d;
+                }
+            }
         }
     }
-    s_red[wave_in_wg][lane] = acc;
+    // fold the four 16-lane groups (same columns) in group order, then the wavefronts in wavefront order
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double g1 = __shfl_down(acc[k], 16, 64), g2 = __shfl_down(acc[k], 32, 64), g3 = __shfl_down(acc[k], 48, 64);
+        const double t = linf ? fmax(fmax(acc[k], g1), fmax(g2, g3)) : (acc[k] + g1) + (g2 + g3);
+        if (lane < 16) s_red[wave_in_wg][c4 + k] = want[k] ? t : 0.0;
+    }
     __syncthreads();
     if (wave_in_wg == 0) {
         double t = 0.0;
@@ -245,28 +390,76 @@ __global__ void k_mm_state_init(BatchState* state, int b) {
     }
 }
 
-// caller-space slab -> internal (relabelled) slab, optional per-row scale; holes zero
-__global__ void k_mm_permute_in(const float* __restrict__ src, const int32_t* __restrict__ perm, const float* __restrict__ row_scale,
-                                int64_t n_int, int64_t n_valid, int ld, float* __restrict__ dst) {
-    const int64_t total = n_int * ld;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / ld;
-        const int col = (int)(i - r * ld);
+// caller-space slab(s) -> internal (relabelled) slabs, holes zero: the personalization, the start iterate and the first gather
+// slab (start * row_scale) leave in ONE pass over the permutation (three separate passes took 1.6 ms each at scale 23 /
+// b = 64).  A 16-lane group moves one row; the internal slabs round the row length up to whole float4s (columns b .. ld - 1
+// are zero), the caller's rows are b floats long.
+struct PermuteIn {
+    const float* src_a;      // -> out_a (personalization) or null
+    const float* src_b;      // -> out_b, and scaled -> out_bs (start iterate); may equal src_a
+    float*       out_a;
+    float*       out_b;
+    float*       out_bs;     // out_b * row_scale, or null
+    const float* row_scale;  // [n_int] or null
+};
+
+__global__ __launch_bounds__(WG) void k_mm_permute_in(PermuteIn q, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, int b, int ld) {
+    const int lane = threadIdx.x & 63, l = lane & 15, c4 = 4 * l;
+    if (c4 >= ld) return;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * 4;
+    const bool vec = (b & 3) == 0;
+    for (int64_t r = first; r < n_int; r += stride) {
         const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
-        float v = o >= 0 ? src[o * ld + col] : 0.f;
-        if (row_scale) v *= row_scale[r];
-        dst[i] = v;
+        auto fetch = [&](const float* src) __attribute__((always_inline)) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (o >= 0) {
+                if (vec) v = *reinterpret_cast<const f32x4*>(src + o * b + c4);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c4 + k < b) v[k] = src[o * b + c4 + k];
+                }
+            }
+            return v;
+        };
+        const int64_t at = r * ld + c4;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f};
+        if (q.src_a != nullptr) {
+            va = fetch(q.src_a);
+            *reinterpret_cast<f32x4*>(q.out_a + at) = va;
+        }
+        if (q.src_b != nullptr) {
+            const f32x4 vb = q.src_b == q.src_a ? va : fetch(q.src_b);
+            if (q.out_b != nullptr) *reinterpret_cast<f32x4*>(q.out_b + at) = vb;
+            if (q.out_bs != nullptr) *reinterpret_cast<f32x4*>(q.out_bs + at) = q.row_scale != nullptr ? vb * q.row_scale[r] : vb;
+        }
     }
 }
 
-__global__ void k_mm_permute_out(const float* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, int ld,
-                                 const double* __restrict__ col_factor, float* __restrict__ dst) {
-    const int64_t total = n_int * ld;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / ld;
-        const int col = (int)(i - r * ld);
+__global__ __launch_bounds__(WG) void k_mm_permute_out(const float* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid,
+                                                        int b, int ld, const double* __restrict__ col_factor, float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, l = lane & 15, c4 = 4 * l;
+    if (c4 >= b) return;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * 4;
+    const bool vec = (b & 3) == 0;
+    f32x4 factor = {1.f, 1.f, 1.f, 1.f};
+    if (col_factor != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c4 + k < b) factor[k] = (float)col_factor[c4 + k];
+    }
+    for (int64_t r = first; r < n_int; r += stride) {
         const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
-        if (o >= 0) dst[o * ld + col] = src[i] * (col_factor ? (float)col_factor[col] : 1.f);
+        if (o < 0) continue;
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + r * ld + c4)) * factor;
+        if (vec) *reinterpret_cast<f32x4*>(dst + o * b + c4) = v;
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c4 + k < b) dst[o * b + c4 + k] = v[k];
+        }
     }
 }
 
@@ -299,6 +492,11 @@ int ensure_mm_layout(pgh_graph_s* g) {
     PGH_HIP(hipMalloc(&f.xg, sizeof(float) * (size_t)(f.num_tiles + 1) * kLanes));
     PGH_HIP(hipMemsetAsync(f.part, 0, sizeof(float) * (size_t)(f.num_tiles + 1) * kLanes, rt().stream));
     PGH_HIP(hipMemsetAsync(f.xg, 0, sizeof(float) * (size_t)(f.num_tiles + 1) * kLanes, rt().stream));
+    PGH_HIP(hipMalloc(&f.mm_close, sizeof(int32_t) * (size_t)f.num_entries));
+    k_mm_close_rows<<<blocks_for((int64_t)f.num_tiles * 64, 64), WG, 0, rt().stream>>>(f.colf, f.tile, f.seg_row, f.num_tiles, f.mm_close);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    f.device_bytes += (int64_t)f.num_entries * 4;
     return 0;
 }
 
@@ -307,6 +505,7 @@ MMView mm_view(const BsfFormat& f) {
     v.colf = f.colf;
     v.val = f.val;
     v.seg_row = f.seg_row;
+    v.close = f.mm_close;
     v.tile = f.tile;
     v.head = f.part;
     v.tail = f.xg;
@@ -319,7 +518,16 @@ int mm_partial(pgh_graph_s* g, const float* xg, int ld, int b, float* sums, cons
     Runtime& r = rt();
     const BsfFormat& f = g->bsf_mm;
     const MMView v = mm_view(f);
-    const int grid = r.num_cus * 8;
+    // persistent grid: as many workgroups as the registers let a CU hold (PGH_MM_WGS overrides: diagnostic)
+    static int per_cu_val = 0, per_cu_plain = 0;
+    int& per_cu = f.val ? per_cu_val : per_cu_plain;
+    if (per_cu == 0) {
+        if (getenv("PGH_MM_WGS") != nullptr) per_cu = atoi(getenv("PGH_MM_WGS"));
+        else if (f.val) PGH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mm_partial<true>, WG, 0));
+        else PGH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mm_partial<false>, WG, 0));
+        if (per_cu < 1) per_cu = 1;
+    }
+    const int grid = r.num_cus * per_cu;
     {
         ProfScope prof(PGH_K_SPMM);
         if (f.val) k_mm_partial<true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state);
@@ -349,7 +557,7 @@ extern "C" int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
     PGH_TRY(ensure_mm_layout(g));
     Runtime& r = rt();
     const BsfFormat& f = g->bsf_mm;
-    const int ld = x->b, b = x->b;
+    const int b = x->b, ld = (b + 3) & ~3;
     const int64_t n_int = f.n_out;
     DevBytes xg, sums, yint, partial;
     PGH_TRY(xg.alloc(sizeof(float) * (size_t)n_int * ld));
@@ -357,7 +565,13 @@ extern "C" int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
     PGH_TRY(yint.alloc(sizeof(float) * (size_t)n_int * ld));
     PGH_TRY(partial.alloc(sizeof(double) * (size_t)combine_grid() * kLanes));
     PGH_HIP(hipMemsetAsync(sums.p, 0, sizeof(float) * (size_t)n_int * ld, r.stream));
-    k_mm_permute_in<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(x->data, f.perm, f.src_scale, n_int, g->n_rows, ld, xg.as<float>());
+    {
+        PermuteIn q{};
+        q.src_b = x->data;
+        q.out_bs = xg.as<float>();
+        q.row_scale = f.src_scale;
+        k_mm_permute_in<<<blocks_for(n_int * 16), WG, 0, r.stream>>>(q, f.perm, n_int, g->n_rows, b, ld);
+    }
     PGH_TRY(mm_partial(g, xg.as<float>(), ld, b, sums.as<float>(), nullptr));
     CombineParams c{};
     c.sums = sums.as<float>();
@@ -368,7 +582,7 @@ extern "C" int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
         ProfScope prof(PGH_K_COMBINE);
         k_mm_combine<<<combine_grid(), WG, 0, r.stream>>>(c, n_int, ld, b, nullptr, partial.as<double>());
     }
-    k_mm_permute_out<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(yint.as<float>(), f.perm, n_int, g->n_cols, ld, nullptr, y->data);
+    k_mm_permute_out<<<blocks_for(n_int * 16), WG, 0, r.stream>>>(yint.as<float>(), f.perm, n_int, g->n_cols, b, ld, nullptr, y->data);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(r.stream));
     return 0;
@@ -385,7 +599,7 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     PGH_TRY(ensure_mm_layout(g));
     Runtime& r = rt();
     const BsfFormat& f = g->bsf_mm;
-    const int ld = p->b, b = p->b;
+    const int b = p->b, ld = (b + 3) & ~3;
     const int64_t n = g->n_cols, n_int = f.n_out;
     const size_t slab = sizeof(float) * (size_t)n_int * ld;
     DevBytes pint, xg, sums, y0, y1, partial, state_mem, factors;
@@ -405,10 +619,16 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     PGH_HIP(hipEventRecord(ev_a, r.stream));
     PGH_HIP(hipMemsetAsync(sums.p, 0, slab, r.stream));
     k_mm_state_init<<<1, kLanes, 0, r.stream>>>(state, b);
-    k_mm_permute_in<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(p->data, f.perm, nullptr, n_int, n, ld, pint.as<float>());
-    const float* start = cfg->start_from_p ? p->data : ranks->data;          // abstract_filters.py:56 without warm_start
-    k_mm_permute_in<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(start, f.perm, nullptr, n_int, n, ld, y0.as<float>());
-    k_mm_permute_in<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(start, f.perm, f.src_scale, n_int, n, ld, xg.as<float>());
+    {
+        PermuteIn q{};
+        q.src_a = p->data;
+        q.src_b = cfg->start_from_p ? p->data : ranks->data;                  // abstract_filters.py:56 without warm_start
+        q.out_a = pint.as<float>();
+        q.out_b = y0.as<float>();
+        q.out_bs = xg.as<float>();
+        q.row_scale = f.src_scale;
+        k_mm_permute_in<<<blocks_for(n_int * 16), WG, 0, r.stream>>>(q, f.perm, n_int, n, b, ld);
+    }
     float* buf[2] = {y0.as<float>(), y1.as<float>()};
     const int linf = cfg->err_kind == PGH_ERR_LINF;
     const int max_steps = cfg->max_iters - 1 > 0 ? cfg->max_iters - 1 : 0;
@@ -459,7 +679,7 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     PGH_HIP(hipMemcpyAsync(factors.p, h_factors, sizeof(h_factors), hipMemcpyHostToDevice, r.stream));
     int executed = 0;                                    // steps that ran before every column had stopped
     for (int j = 0; j < b; ++j) executed = host_state.steps[j] > executed ? host_state.steps[j] : executed;
-    k_mm_permute_out<<<blocks_for(n_int * ld), WG, 0, r.stream>>>(buf[executed & 1], f.perm, n_int, n, ld, factors.as<double>(), ranks->data);
+    k_mm_permute_out<<<blocks_for(n_int * 16), WG, 0, r.stream>>>(buf[executed & 1], f.perm, n_int, n, b, ld, factors.as<double>(), ranks->data);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipEventRecord(ev_b, r.stream));
     PGH_HIP(hipEventSynchronize(ev_b));
