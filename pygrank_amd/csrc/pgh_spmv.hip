@@ -946,7 +946,10 @@ extern "C" int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, 
 
 extern "C" int pgh_dist_close_sum(double* state, int32_t use_quotient) {
     PGH_CHECK(state != nullptr, "pgh_dist_close_sum: null state");
-    k_dist_close_sum<<<1, 1, 0, rt().stream>>>(state, use_quotient);
+    {
+        ProfScope prof(PGH_K_FINAL);
+        k_dist_close_sum<<<1, 1, 0, rt().stream>>>(state, use_quotient);
+    }
     PGH_HIP(hipGetLastError());
     return 0;
 }
@@ -963,14 +966,20 @@ extern "C" int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old,
         k_step_residual<<<rgrid, WG, 0, r.stream>>>(y_new->data, y_old->data, y_new->n, vec_ok, 1, linf,
                                                     reinterpret_cast<const LoopState*>(state), nullptr, 0, pres);
     }
-    k_dist_fold<<<1, WG, 0, r.stream>>>(state, pres, rgrid, linf, 1);
+    {
+        ProfScope prof(PGH_K_FINAL);
+        k_dist_fold<<<1, WG, 0, r.stream>>>(state, pres, rgrid, linf, 1);
+    }
     PGH_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int pgh_dist_close_err(double* state, int32_t kind, double tol, int64_t n_global) {
     PGH_CHECK(state != nullptr, "pgh_dist_close_err: null state");
-    k_dist_close_err<<<1, 1, 0, rt().stream>>>(state, kind, tol, (double)n_global);
+    {
+        ProfScope prof(PGH_K_FINAL);
+        k_dist_close_err<<<1, 1, 0, rt().stream>>>(state, kind, tol, (double)n_global);
+    }
     PGH_HIP(hipGetLastError());
     return 0;
 }

@@ -466,14 +466,18 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
     ranker.rank(pg, personalizations[total - 1])
     L.check(lib.pgh_profile_enable(0))
     prof = {}
-    for kid, name in ((L.K_SPMV, "spmv"), (L.K_PB_GATHER, "pb_gather"), (L.K_PB_ACCUM, "pb_accumulate"), (L.K_FIXUP, "fixup"),
-                      (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual")):
+    for kid, name in ((L.K_SPMV, "spmv"), (L.K_PB_GATHER, "pb_gather"), (L.K_PB_ACCUM, "pb_finish"), (L.K_FIXUP, "fixup"),
+                      (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual"), (L.K_FINAL, "close")):
         cnt, ms = C.c_int64(), C.c_double()
         L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
-        prof[name] = (ms.value / cnt.value * 1e3) if cnt.value else None
-    step_us = sum(v for k, v in prof.items() if k in ("spmv", "pb_gather", "pb_accumulate", "fixup", "combine") and v)
-    step_kernels = ("k_bsf_partial + k_pb_gather + k_pb_accumulate + k_bsf_fixup + k_bsf_combine<AXPBY>" if prof["pb_gather"]
-                    else "k_bsf_partial + k_bsf_fixup + k_bsf_combine<AXPBY>")
+        if name == "spmv":
+            steps_profiled = max(cnt.value, 1)
+        prof[name] = (ms.value / steps_profiled * 1e3) if cnt.value else None     # us per iteration (a kind may launch twice)
+    # every launch of one iteration counts (as in the single-GPU line): step + residual + the scalar folds / closes
+    step_us = sum(v for v in prof.values() if v)
+    names = dict(spmv="k_bsf_partial", pb_gather="k_pb_gather", pb_finish="k_pb_finish<AXPBY>", fixup="k_bsf_fixup",
+                 combine="k_bsf_combine<AXPBY>", residual="k_step_residual", close="k_dist_close_sum + k_dist_fold + k_dist_close_err")
+    step_kernels = " + ".join(names[k] for k, v in prof.items() if v)
     alg_bytes = 8 * pg.graph.nnz + 4 * n + 16 * n_local
     achieved = alg_bytes / (step_us * 1e-6) / 1e9 if step_us else None
     # ---- parity + CPU baseline of the N-rank line: the same partitioned code path on a graph the oracle finishes in
