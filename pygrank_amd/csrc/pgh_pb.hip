@@ -225,6 +225,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 PGH_STAMP_DECL(g_times_gather)
 PGH_STAMP_DECL(g_times_finish)
+#if PGH_PROBE_TIMES
+__device__ unsigned int g_item_ticks[1 << 15];      // per work item of k_pb_finish: duration in 10 ns ticks
+__device__ unsigned int g_item_begin[1 << 15];      // ... and its start relative to the workgroup's start
+#endif
 
 // ---- phase A
 template <bool HAS_VAL>
@@ -458,10 +462,13 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         sum_y = 0.0;
         delta = 0.0;
     };
-    // Items are handed out dynamically, most expensive first (f.sched = item indices by descending estimated cost; a
-    // device counter, re-armed by the last workgroup of the launch): the persistent workgroups finish within one small item
-    // of each other (a static deal left 18 us of a 97 us launch to imbalance, profiles/r02/wg_end_times.log).  Results do not
-    // depend on who processes what: sum(y) / delta partials are kept PER ITEM and folded in item order by the consumers.
+    // Item schedule: static slices of f.sched per workgroup (default: round-robin in row order, one partial per workgroup),
+    // or -- diagnostic, PGH_FIN_DYNAMIC=1 -- a device counter hands the items out and sum(y) / delta partials are kept PER
+    // ITEM so that the fold does not depend on who processed what (measured slower: 135 vs 106 us).
+    // Per-item times (PGH_PROBE_TIMES build, profiles/r02/finish_item_times.csv): 10.6 us + 0.34 us per 1000 entries + 2.4 us
+    // per 1000 rows, i.e. half of an average item is a fixed cost.  Second register sets for the stream rounds and for the
+    // epilogue rounds (loads of round i + 1 in flight during round i) were built and measured: 107-115 us against 107 --
+    // the fixed cost is not one workgroup's exposed latency but the four workgroups of a CU taking turns.
     __shared__ int s_next;
     const bool dynamic = f.work_counter != nullptr;
     int at = 0, at_end = 0;
@@ -483,7 +490,13 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1, first item of the split row}
         fetch(bin, 0, R);
     }
+#if PGH_PROBE_TIMES
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     while (item >= 0) {
+#if PGH_PROBE_TIMES
+        const unsigned long long item_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0x1f;
         const bool hub = ((bin.y >> 21) & 1) != 0;
         const int pieces = (int)((unsigned)bin.y >> 22) + 1;
@@ -654,6 +667,12 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             }
         }
         __syncthreads();                                   // s_row / s_hub are reused by the next item
+#if PGH_PROBE_TIMES
+        if (tid == 0 && item < (1 << 15)) {
+            g_item_ticks[item] = (unsigned int)(__builtin_amdgcn_s_memrealtime() - item_t0);
+            g_item_begin[item] = (unsigned int)(item_t0 - wg_t0);
+        }
+#endif
         if (dynamic) flush(slot);                          // per-item partials: the fold does not depend on the hand-out
         slot = at;
         if (!PGH_FIN_PREFETCH && next >= 0) fetch(next_bin, 0, R);
@@ -1225,6 +1244,29 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
     }
     PGH_HIP(hipGetLastError());
     PGH_STAMP_DUMP(g_times_finish, grid, "k_pb_finish")
+#if PGH_PROBE_TIMES
+    if (getenv("PGH_DUMP_ITEMS") != nullptr) {             // per-item durations of the 10th launch, with the item descriptors
+        static int dumped = 0;
+        if (dumped++ == 9) {
+            (void)hipStreamSynchronize(r.stream);
+            const int n_ = p.num_items < (1 << 15) ? p.num_items : (1 << 15);
+            std::vector<unsigned int> ticks(1 << 15), begin(1 << 15);
+            std::vector<int4> ia(p.num_items), ib(p.num_items);
+            (void)hipMemcpyFromSymbol(ticks.data(), HIP_SYMBOL(g_item_ticks), sizeof(unsigned int) * (1 << 15));
+            (void)hipMemcpyFromSymbol(begin.data(), HIP_SYMBOL(g_item_begin), sizeof(unsigned int) * (1 << 15));
+            (void)hipMemcpy(ia.data(), p.item_a, sizeof(int4) * p.num_items, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(ib.data(), p.item_b, sizeof(int4) * p.num_items, hipMemcpyDeviceToHost);
+            FILE* out = fopen(getenv("PGH_DUMP_ITEMS"), "w");
+            if (out != nullptr) {
+                fprintf(out, "item,rows,count_bits,hub,pieces,groups,epi_rows,begin_us,us\n");
+                for (int i = 0; i < n_; ++i)
+                    fprintf(out, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.2f\n", i, ia[i].y & 0xffff, (ia[i].y >> 16) & 0x1f, (ia[i].y >> 21) & 1,
+                            (int)((unsigned)ia[i].y >> 22) + 1, ia[i].w, ib[i].y, begin[i] * 0.01, ticks[i] * 0.01);
+                fclose(out);
+            }
+        }
+    }
+#endif
     if (num_partials) *num_partials = p.work_counter != nullptr ? p.num_items : grid;      // per item / per workgroup
     return 0;
 }
