@@ -183,13 +183,15 @@ def single_gpu(args):
                       (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual"), (L.K_FINAL, "close")):
         cnt, ms = C.c_int64(), C.c_double()
         L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
-        prof[name] = dict(launches=cnt.value, avg_us=(ms.value / cnt.value * 1e3) if cnt.value else None)
+        prof[name] = dict(launches=cnt.value, avg_us=(ms.value / cnt.value * 1e3) if cnt.value else None, total_us=ms.value * 1e3)
     alg_bytes = 8 * nnz + 16 * n                     # PPR step + quotient + residual, per iteration
     # One PPR iteration = every launch between two iterates: block partial sums, (cross-tile fix-up,) the cold image's
     # phase A, phase B + epilogue (or the combine of graphs without a cold image), residual, close.  Its duration is the sum
-    # of their HIP-event times.
+    # of their HIP-event times per iteration = per launch of the step's first kernel (the close of a step rides in the first
+    # kernel of the next one on the blocked layout: k_step_close then runs once per run, not once per iteration).
     step_kernels = [k for k in STEP_KERNELS if prof[k]["avg_us"]]
-    step_us = sum(prof[k]["avg_us"] for k in step_kernels)
+    iterations = max(prof["spmv"]["launches"], 1)
+    step_us = sum(prof[k]["total_us"] for k in step_kernels) / iterations
     achieved = alg_bytes / (step_us * 1e-6) / 1e9
     blocked = g.format().startswith("bsf")
     traffic, traffic_source = measured_traffic(scale, ef, blocked)
@@ -202,7 +204,8 @@ def single_gpu(args):
                     traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=alg_bytes,
                     avg_launch_us=round(step_us, 2), measured_copy_gbs=ceiling,
                     frac_of_measured_copy=round(achieved / ceiling, 4) if ceiling else None, format=g.format(),
-                    kernels_avg_us={k: (round(v["avg_us"], 2) if v["avg_us"] else None) for k, v in prof.items()})
+                    kernels_avg_us={k: (round(v["avg_us"], 2) if v["avg_us"] else None) for k, v in prof.items()},
+                    launches_per_iteration={k: round(v["launches"] / iterations, 3) for k, v in prof.items() if v["launches"]})
 
     # ---- the other filters of the path on the same resident graph (8 nnz + 20 n per polynomial term,
     # 8 nnz + 24 n per absorbing step); reported beside the headline, not part of `value`

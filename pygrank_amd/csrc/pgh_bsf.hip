@@ -490,7 +490,7 @@ PGH_STAMP_DECL(g_times_partial)
 
 template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
-                                                              const LoopState* __restrict__ state) {
+                                                              const LoopState* __restrict__ state, PendingClose pc) {
     static_assert(IPT == 8, "one flag byte per lane; lanes fetch their entries as 16-byte words");
     static_assert(!(W16 && COLD), "the 16-bit stream addresses the hot cache only");
     constexpr int T = 64 * IPT;
@@ -502,6 +502,8 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     // for predicated-off writes.  One array, so that every LDS address below is an offset from LDS address 0.
     __shared__ float s_lds[kBsfHot + 1 + WAVES * STRIP];
     if (state != nullptr && state->done) return;
+    // the previous step's close, if the loop driver left it to this kernel (the LDS it uses is not yet in use)
+    if (pc.active && run_pending_close(pc, reinterpret_cast<double*>(s_lds))) return;
     PGH_STAMP_BEGIN(g_times_partial)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -818,17 +820,21 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, 
     BsfFormat& f = g->bsf;
     const BsfView v = view_of(f);
     const int main_grid = r.num_cus;                  // one workgroup per CU; a multiple of 8 (XCD-affine blocks)
+    // the previous step's close rides in this launch when the loop driver deferred it (PendingClose, pgh_kernels.h)
+    PendingClose pc = pending_close_slot();
+    if (stage == 2 || state == nullptr || pc.state != state) pc.active = 0;
+    else pending_close_slot().active = 0;             // consumed
     if (stage != 2) {
         ProfScope prof(PGH_K_SPMV);
         if (f.colf16 != nullptr) {
-            if (f.val) k_bsf_partial<kIPT, true, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
-            else k_bsf_partial<kIPT, false, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+            if (f.val) k_bsf_partial<kIPT, true, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc);
+            else k_bsf_partial<kIPT, false, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc);
         } else if (f.pb.enabled && !f.pb.k1_cold) {
-            if (f.val) k_bsf_partial<kIPT, true, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
-            else k_bsf_partial<kIPT, false, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+            if (f.val) k_bsf_partial<kIPT, true, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc);
+            else k_bsf_partial<kIPT, false, false><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc);
         } else {
-            if (f.val) k_bsf_partial<kIPT, true, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
-            else k_bsf_partial<kIPT, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state);
+            if (f.val) k_bsf_partial<kIPT, true, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc);
+            else k_bsf_partial<kIPT, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc);
         }
     }
     if (stage != 2) {

@@ -50,6 +50,22 @@ struct LoopState {
     int    pad;
 };
 
+// The close of a step (k_step_close: fold the partials, update the loop state, evaluate the stopping rule) can be
+// DEFERRED into the first kernel of the next step: every workgroup of that kernel folds the same partials in the same
+// order (so they all reach the same verdict, and the same bits as k_step_close), workgroup 0 writes the state.  One
+// launch and one dependent boundary fewer per iteration (k_step_close: 5.4 us + the gap around it).
+struct PendingClose {
+    LoopState*    state;
+    const double* partial_sum;
+    const double* res_partials;   // residual partials (recursive filters)
+    int*          progress;       // host-visible {steps, done} or null
+    double        tol;
+    long long     n;
+    int           num_sum, num_res;
+    int           use_quotient, check, err_kind;
+    int           active;
+};
+
 struct GraphView {
     const int32_t* rowptr;
     const int32_t* col;
@@ -261,6 +277,62 @@ __device__ __forceinline__ void bsf_fixup_tiles(const FixView& f, int first_tile
 #define PGH_STAMP_END(NAME)
 #define PGH_STAMP_DUMP(NAME, GRID, LABEL)
 #endif
+
+// fold of <= kMaxPartials partials by the first 256 threads of a workgroup of any size >= 256, in the order k_step_close /
+// fold_partials use (thread t adds partials t, t + 256, ...; wavefront shuffles; wavefronts 0..3 in order): every thread
+// returns the result.  s4: LDS scratch of 4 doubles.
+__device__ __forceinline__ double fold_partials_wide(const double* __restrict__ partials, int count, int linf, double* s4) {
+    double acc = 0.0;
+    if (threadIdx.x < 256) {
+        for (int i = threadIdx.x; i < count; i += 256) {
+            const double v = partials[i];
+            acc = linf ? fmax(acc, v) : acc + v;
+        }
+        acc = linf ? wave_reduce_max(acc) : wave_reduce_sum(acc);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256 && (threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double r = s4[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) r = linf ? fmax(r, s4[w]) : r + s4[w];
+    return r;
+}
+
+// the deferred close (see PendingClose); returns true when the loop has ended, i.e. the calling kernel must do nothing
+__device__ __forceinline__ bool run_pending_close(const PendingClose& pc, double* s4) {
+    const double S = fold_partials_wide(pc.partial_sum, pc.num_sum, 0, s4);
+    double err = 0.0;
+    if (pc.check) {
+        __syncthreads();
+        err = fold_partials_wide(pc.res_partials, pc.num_res, pc.err_kind == PGH_ERR_LINF, s4);
+        if (pc.err_kind == PGH_ERR_MABS) err /= (double)pc.n;
+    }
+    const bool done = pc.check && err <= pc.tol;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        LoopState* state = pc.state;
+        state->sum = S;
+        state->scale = pc.use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+        const int steps = state->steps + 1;
+        state->steps = steps;
+        if (pc.check) {
+            state->err = err;
+            if (done) {
+                state->done = 1;
+                state->converged = 1;
+            }
+        }
+        if (pc.progress != nullptr) {
+            __hip_atomic_store(pc.progress + 1, done ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pc.progress, steps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
+    return done;
+}
+
+// slot the loop driver fills (pgh_spmv.hip) and the next blocked-format launch consumes (pgh_bsf.hip)
+PendingClose& pending_close_slot();
 
 // blocked-format entry points (pgh_bsf.hip)
 // pgh_pb.hip: propagation-blocking image of the cold entries

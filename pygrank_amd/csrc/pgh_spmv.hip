@@ -510,6 +510,21 @@ int* g_progress_dev = nullptr;
 hipStream_t g_side_stream = nullptr;
 hipEvent_t g_ev_combined = nullptr, g_ev_closed = nullptr;
 
+// the deferred close of the last enqueued step (PendingClose): launched as its own kernel when no blocked-format launch
+// follows to carry it
+PendingClose g_pending_close = {};
+
+int flush_pending_close() {
+    PendingClose& pc = pending_close_slot();
+    if (!pc.active) return 0;
+    pc.active = 0;
+    ProfScope prof(PGH_K_FINAL);
+    k_step_close<<<1, WG, 0, rt().stream>>>(pc.state, pc.partial_sum, pc.num_sum, pc.res_partials, pc.num_res, pc.use_quotient, pc.check,
+                                            pc.err_kind, pc.tol, (int64_t)pc.n, nullptr, pc.progress);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
 int ensure_state() {
     if (g_state) return 0;
     PGH_HIP(hipMalloc(&g_state, sizeof(LoopState)));
@@ -984,6 +999,10 @@ extern "C" int pgh_dist_close_err(double* state, int32_t kind, double tol, int64
     return 0;
 }
 
+namespace pgh {
+PendingClose& pending_close_slot() { return g_pending_close; }
+}  // namespace pgh
+
 // =================================================================================================
 // C-ABI: whole loops on the device
 // =================================================================================================
@@ -1142,6 +1161,11 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     const int window = window_for(g);
     if (poll) progress_reset();
     const bool overlap = g_side_stream != nullptr && sp.blocked;     // the row-major kernel applies its epilogue in place
+    // blocked layout: the close of step k rides in the first kernel of step k + 1 (PendingClose); PGH_DEFER_CLOSE=0 keeps
+    // the separate launch
+    static const bool defer_env = getenv("PGH_DEFER_CLOSE") == nullptr || atoi(getenv("PGH_DEFER_CLOSE")) != 0;
+    const bool defer = defer_env && sp.blocked && !overlap;
+    pending_close_slot().active = 0;
     int enq = 0;          // steps enqueued so far
     bool done = false;
     while (!done && enq < max_steps) {
@@ -1178,7 +1202,21 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
                 k_step_residual<<<rgrid, WG, 0, r.stream>>>(yout, xin, n_int, vec_ok, cfg->use_quotient, linf, g_state,
                                                             r.d_partials, count, pres);
             }
-            {
+            if (defer) {
+                PendingClose& pc = pending_close_slot();
+                pc.state = g_state;
+                pc.partial_sum = r.d_partials;
+                pc.res_partials = pres;
+                pc.progress = g_progress_dev;
+                pc.tol = cfg->tol;
+                pc.n = (long long)n;
+                pc.num_sum = count;
+                pc.num_res = rgrid;
+                pc.use_quotient = cfg->use_quotient;
+                pc.check = check;
+                pc.err_kind = cfg->err_kind;
+                pc.active = 1;
+            } else {
                 ProfScope prof(PGH_K_FINAL);
                 k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, pres, rgrid, cfg->use_quotient,
                                                      check, cfg->err_kind, cfg->tol, n, nullptr, g_progress_dev);
@@ -1189,6 +1227,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             }
         }
         PGH_HIP(hipGetLastError());
+        if (!poll || enq >= max_steps) PGH_TRY(flush_pending_close());
         if (!poll) {
             if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
             PGH_TRY(fetch_state());
@@ -1196,6 +1235,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         }
     }
     if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
+    PGH_TRY(flush_pending_close());                  // a no-op once the loop has ended on the device
     PGH_TRY(fetch_state());
     const int steps = g_state_host->steps;
     // result lives in buf[steps & 1]; apply the pending quotient and preserve_norm factor
