@@ -171,7 +171,8 @@ struct PbFormat {
     int       sched_groups = 0;
     int*      sched = nullptr;      // [num_items]
     int*      sched_begin = nullptr;// [sched_groups + 1]
-    uint32_t* work_counter = nullptr; // dynamic hand-out of the schedule (one device word), or null = static deal
+    uint32_t* work_counter = nullptr; // hand-out of the schedule's tail (one device word), or null without a tail
+    int       tail_begin = 0, tail_count = 0;   // sched[tail_begin .. +tail_count): items handed out on the device
     int64_t   device_bytes = 0;
 };
 constexpr int kPbMaxSlices = 8;

@@ -209,7 +209,8 @@ struct PbView {
     int             num_items;
     const int*      sched;             // item order (PbFormat::sched); static deal: slices sched_begin[w] .. sched_begin[w + 1]
     const int*      sched_begin;
-    uint32_t*       work_counter;      // dynamic hand-out: next position in `sched` (null = static deal)
+    uint32_t*       work_counter;      // hand-out of the schedule's tail: next position (null without a tail)
+    int             tail_begin, tail_count;   // sched[tail_begin .. tail_begin + tail_count): handed out dynamically
     uint32_t*       hub_ticket;
     const uint16_t* drow;
     double*         hub_part;          // [num_bins] sums of the pieces of split hub rows
@@ -462,27 +463,39 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         sum_y = 0.0;
         delta = 0.0;
     };
-    // Item schedule: static slices of f.sched per workgroup (default: round-robin in row order, one partial per workgroup),
-    // or -- diagnostic, PGH_FIN_DYNAMIC=1 -- a device counter hands the items out and sum(y) / delta partials are kept PER
-    // ITEM so that the fold does not depend on who processed what (measured slower: 135 vs 106 us).
-    // Per-item times (PGH_PROBE_TIMES build, profiles/r02/finish_item_times.csv): 10.6 us + 0.34 us per 1000 entries + 2.4 us
-    // per 1000 rows, i.e. half of an average item is a fixed cost.  Second register sets for the stream rounds and for the
-    // epilogue rounds (loads of round i + 1 in flight during round i) were built and measured: 107-115 us against 107 --
-    // the fixed cost is not one workgroup's exposed latency but the four workgroups of a CU taking turns.
+    // Item schedule.  HEAD: static slices of f.sched per workgroup (round-robin in row order), their sum(y) / delta go to
+    // the workgroup's partial.  TAIL: the last items of the list (the coldest rows: small items) are handed out by a device
+    // counter to whoever has finished its slice; each tail item has a partial slot of its own, so the fold (workgroup
+    // partials in workgroup order, then tail partials in item order) does not depend on who processed what.
+    // Why: per-item times (PGH_PROBE_TIMES build, profiles/r02/finish_item_times.csv) are 10.6 us + 0.34 us per 1000
+    // entries + 2.4 us per 1000 rows with a residual of +-4 us that no property of the item explains (it follows the
+    // workgroup's place and time on the chip), so sums over a static slice spread by +-8 us and the slowest of 1024
+    // workgroups ended at 98 us with the mean at 79.  Static deals by modelled cost (snake, longest-first) measured
+    // 115-120 us against 106, a fully dynamic hand-out 135 us (every item pays the counter's round trip and a reduction),
+    // one item per workgroup 117 us, second register sets for the stream / epilogue rounds 107-115 us.
     __shared__ int s_next;
-    const bool dynamic = f.work_counter != nullptr;
-    int at = 0, at_end = 0;
-    if (dynamic) {
+    const int tail_count = f.tail_count;
+    int at = f.sched_begin[blockIdx.x];
+    const int at_end = f.sched_begin[blockIdx.x + 1];
+    int slot = blockIdx.x, item = -1;       // partial-sum slot of the item in hand
+    bool in_tail = at >= at_end;
+    auto take_tail = [&]() __attribute__((always_inline)) {        // -> item index or -1; all threads call it together
+        if (tail_count == 0) return -1;
+        __syncthreads();
         if (tid == 0) s_next = (int)atomicAdd(f.work_counter, 1u);
         __syncthreads();
-        at = s_next;
-        at_end = f.num_items;
-    } else {
-        at = f.sched_begin[blockIdx.x];
-        at_end = f.sched_begin[blockIdx.x + 1];
+        const int k = s_next;
+        if (k >= tail_count) return -1;
+        slot = gridDim.x + k;
+        return f.sched[f.tail_begin + k];
+    };
+    bool flushed_head = false;
+    if (!in_tail) item = f.sched[at];
+    else {
+        flush(blockIdx.x);                  // no static items: the workgroup's partial is zero
+        flushed_head = true;
+        item = take_tail();
     }
-    int slot = at;                          // index of the current item in the schedule = its partial-sum slot
-    int item = at < at_end ? f.sched[at] : -1;
     int4 bin = make_int4(0, 0, 0, 0), epi = make_int4(0, 0, -1, 0);
     Round R;
     if (item >= 0) {
@@ -546,15 +559,14 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             }
             if (round + 1 < nrounds) fetch(bin, round + 1, R);
         }
-        // ---- the next item's first stream round goes out before this item's epilogue
-        if (dynamic) {                      // the next item's index is fetched now, long before it is needed
-            if (tid == 0) s_next = (int)atomicAdd(f.work_counter, 1u);
-            __syncthreads();
-            at = s_next;
-        } else {
-            ++at;
+        // ---- the next item's descriptors are fetched before this item's epilogue
+        const int cur_slot = slot;
+        int next = -1;
+        if (!in_tail && ++at < at_end) next = f.sched[at];
+        else {
+            in_tail = true;
+            next = take_tail();
         }
-        const int next = at < at_end ? f.sched[at] : -1;
         int4 next_bin = make_int4(0, 0, 0, 0), next_epi = make_int4(0, 0, -1, 0);
         if (next >= 0) {
             next_bin = f.item_a[next];
@@ -673,20 +685,24 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             g_item_begin[item] = (unsigned int)(item_t0 - wg_t0);
         }
 #endif
-        if (dynamic) flush(slot);                          // per-item partials: the fold does not depend on the hand-out
-        slot = at;
+        // the head's partial leaves when the slice is done, a tail item's partial after the item
+        if (cur_slot != blockIdx.x) flush(cur_slot);
+        else if (in_tail) {
+            flush(blockIdx.x);
+            flushed_head = true;
+        }
         if (!PGH_FIN_PREFETCH && next >= 0) fetch(next_bin, 0, R);
         item = next;
         bin = next_bin;
         epi = next_epi;
     }
-    if (!dynamic) flush(blockIdx.x);                       // static deal: one partial per workgroup
+    if (!flushed_head) flush(blockIdx.x);
     // the last workgroup to leave re-arms the words for the next launch (every workgroup has read amax long before its
     // ticket; the next phase A starts after this kernel)
     if (tid == 0 && atomicAdd(f.amax + 1, 1u) == gridDim.x - 1) {
         f.amax[0] = 0u;
         f.amax[1] = 0u;
-        if (dynamic) *f.work_counter = 0u;
+        if (tail_count > 0) *f.work_counter = 0u;
     }
     PGH_STAMP_END(g_times_finish)
 }
@@ -705,6 +721,8 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.sched = p.sched;
     v.sched_begin = p.sched_begin;
     v.work_counter = p.work_counter;
+    v.tail_begin = p.tail_begin;
+    v.tail_count = p.tail_count;
     v.hub_ticket = p.hub_ticket;
     v.drow = p.drow;
     v.amax = p.amax;
@@ -1062,9 +1080,9 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             PGH_HIP(hipMalloc(&p.hub_ticket, sizeof(uint32_t) * (size_t)p.num_split));
             PGH_HIP(hipMemsetAsync(p.hub_ticket, 0, sizeof(uint32_t) * (size_t)p.num_split, r.stream));
         }
-        // ---- static schedule: persistent grid = what the CUs hold at once; items dealt longest-first onto the least
-        // loaded workgroup.  Cost model fitted at scale 23 (profiles/r02/finish_decompose_scale23.log: stream + atomics
-        // 0.72 ns per padded entry, epilogue 3.6 ns per row, 3.1 us per bin / 1.5 us per stretch without a stream).
+        // ---- schedule: persistent grid = what the CUs hold at once.  The head of the item list is dealt round-robin in row
+        // order (item i -> workgroup i % groups: neighbouring workgroups touch neighbouring rows), the tail -- PGH_FIN_TAIL
+        // percent of the items, never a hub piece -- is handed out on the device (k_pb_finish).
         {
             const bool large = p.bin_rows > kPbBinRows;
             const int by_regs = PGH_FIN_WPE * 4 / (kPbBThreads / 64);
@@ -1072,70 +1090,30 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             if (groups > p.num_items) groups = p.num_items;
             if (groups > kMaxPartials) groups = kMaxPartials;
             if (groups < 1) groups = 1;
+            const char* tail_env = getenv("PGH_FIN_TAIL");
+            // measured at scale 23 (profiles/r02/finish_tail_sweep.log): 0 % 105.7 us, 8 % 100.7, 16 % 103.3, 24 % 103.6, 32 % 105.7,
+            // 48 % 110.1; workgroup end times with 16 %: max 97 us instead of 105 (finish_tail_times.log)
+            const int tail_pct = tail_env != nullptr ? atoi(tail_env) : 12;
+            int tail = (int)((int64_t)p.num_items * (tail_pct < 0 ? 0 : (tail_pct > 90 ? 90 : tail_pct)) / 100);
+            if (tail > p.num_items - (int)hub_a.size()) tail = p.num_items - (int)hub_a.size();
+            if (tail > kMaxPartials - groups) tail = kMaxPartials - groups;
+            if (tail < 0) tail = 0;
+            const int head = p.num_items - tail;
             std::vector<double> cost(p.num_items);
-            for (int i = 0; i < p.num_items; ++i)
-                cost[i] = 0.72 * 8.0 * (double)all_a[i].w + 3.6 * (double)all_b[i].y + (all_a[i].w > 0 ? 3100.0 : 1500.0);
-            std::vector<int> order(p.num_items);
-            for (int i = 0; i < p.num_items; ++i) order[i] = i;
-            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
-            // dynamic hand-out (per-item partial sums must fit the partial buffers): the schedule is the cost order itself
-            // (measured at scale 23, profiles/r02/wg_end_times.log: the dynamic hand-out costs ~6 us per item in atomics and
-            // per-item reductions -- 135 us against 105 for the static deals; it stays available as PGH_FIN_DYNAMIC=1)
-            const bool dynamic = p.num_items <= kMaxPartials && getenv("PGH_FIN_DYNAMIC") != nullptr && atoi(getenv("PGH_FIN_DYNAMIC")) != 0;
-            const char* deal_env = getenv("PGH_FIN_DEAL");
-            // 0 round-robin in row order (default; the cost-model deals 1 = snake by cost and 2 = longest-first measured
-            // 115-120 us against 105: what an item costs depends on how its entries collide in the LDS atomics, which the
-            // model does not see), 3 = one item per workgroup, handed out by the hardware dispatcher
-            const int deal = deal_env != nullptr ? atoi(deal_env) : 0;
-            if (deal == 3 && p.num_items <= kMaxPartials) groups = p.num_items;
+            for (int i = 0; i < p.num_items; ++i)            // PGH_DEBUG only: 10.6 us + 0.34 ns per entry + 2.4 ns per row
+                cost[i] = 0.34 * 8.0 * (double)all_a[i].w + 2.4 * (double)all_b[i].y + 10600.0;
             std::vector<int> flat, begin(1, 0);
-            std::vector<std::pair<double, int>> heap;
-            if (dynamic) {
-                // hub pieces first (their last arriver folds the row), then by descending cost
-                std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-                    const bool hx = ((all_a[x].y >> 21) & 1) != 0, hy = ((all_a[y].y >> 21) & 1) != 0;
-                    return hx != hy ? hx : false;
-                });
-                flat = order;
-                for (int w = 0; w < groups; ++w) begin.push_back(0);
+            flat.reserve(p.num_items);
+            for (int w = 0; w < groups; ++w) {
+                for (int i = w; i < head; i += groups) flat.push_back(i);
+                begin.push_back((int)flat.size());
+            }
+            for (int i = head; i < p.num_items; ++i) flat.push_back(i);
+            p.tail_begin = head;
+            p.tail_count = tail;
+            if (tail > 0) {
                 PGH_HIP(hipMalloc(&p.work_counter, sizeof(uint32_t)));
                 PGH_HIP(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), r.stream));
-            } else if (deal == 0 || deal == 1) {
-                // 0: item i -> workgroup i % groups in row order (neighbouring workgroups touch neighbouring rows);
-                // 1: by descending cost, dealt back and forth (snake) so that every workgroup gets one item of every cost tier
-                std::vector<std::vector<int>> lists(groups);
-                for (int i = 0; i < p.num_items; ++i) {
-                    const int it = deal == 0 ? i : order[i];
-                    const int tier = i / groups, pos = i % groups;
-                    lists[(deal == 1 && (tier & 1)) ? groups - 1 - pos : pos].push_back(it);
-                }
-                flat.reserve(p.num_items);
-                for (int w = 0; w < groups; ++w) {
-                    std::sort(lists[w].begin(), lists[w].end());
-                    flat.insert(flat.end(), lists[w].begin(), lists[w].end());
-                    begin.push_back((int)flat.size());
-                }
-            } else {
-                std::vector<std::vector<int>> lists(groups);
-                heap.reserve(groups);
-                for (int w = 0; w < groups; ++w) heap.emplace_back(0.0, w);
-                auto cmp = [](const std::pair<double, int>& x, const std::pair<double, int>& y) {
-                    return x.first > y.first || (x.first == y.first && x.second > y.second);
-                };
-                std::make_heap(heap.begin(), heap.end(), cmp);
-                for (int i : order) {
-                    std::pop_heap(heap.begin(), heap.end(), cmp);
-                    std::pair<double, int>& top = heap.back();
-                    lists[top.second].push_back(i);
-                    top.first += cost[i];
-                    std::push_heap(heap.begin(), heap.end(), cmp);
-                }
-                flat.reserve(p.num_items);
-                for (int w = 0; w < groups; ++w) {
-                    std::sort(lists[w].begin(), lists[w].end());        // hub items (lowest indices) first, then by row
-                    flat.insert(flat.end(), lists[w].begin(), lists[w].end());
-                    begin.push_back((int)flat.size());
-                }
             }
             p.sched_groups = groups;
             PGH_HIP(hipMalloc(&p.sched, sizeof(int) * (size_t)(flat.size() + 1)));
@@ -1267,7 +1245,7 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
         }
     }
 #endif
-    if (num_partials) *num_partials = p.work_counter != nullptr ? p.num_items : grid;      // per item / per workgroup
+    if (num_partials) *num_partials = grid + p.tail_count;            // one per workgroup, then one per tail item
     return 0;
 }
 template int pb_launch_finish<EPI_PLAIN>(pgh_graph_s*, const RowSums&, const EpiParams&, const LoopState*, int*);
