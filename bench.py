@@ -176,7 +176,7 @@ def single_gpu(args):
     # ---- roofline leg: HIP events around every launch of the dominant kernel (one extra, untimed run)
     L.check(lib.pgh_profile_reset())
     L.check(lib.pgh_profile_enable(1))
-    run(total - 1)
+    _, prof_info = run(total - 1)
     L.check(lib.pgh_profile_enable(0))
     prof = {}
     for kid, name in ((L.K_SPMV, "spmv"), (L.K_FIXUP, "fixup"), (L.K_PB_GATHER, "pb_gather"), (L.K_PB_ACCUM, "pb_finish"),
@@ -187,10 +187,11 @@ def single_gpu(args):
     alg_bytes = 8 * nnz + 16 * n                     # PPR step + quotient + residual, per iteration
     # One PPR iteration = every launch between two iterates: block partial sums, (cross-tile fix-up,) the cold image's
     # phase A, phase B + epilogue (or the combine of graphs without a cold image), residual, close.  Its duration is the sum
-    # of their HIP-event times per iteration = per launch of the step's first kernel (the close of a step rides in the first
-    # kernel of the next one on the blocked layout: k_step_close then runs once per run, not once per iteration).
+    # of their HIP-event times per iteration that did work = per SpMV of the profiled run: the <= 2 no-op iterations the
+    # run-ahead loop leaves behind after convergence are charged to the working ones, and the close of a step rides in the
+    # first kernel of the next one on the blocked layout (k_step_close then runs once per run, not once per iteration).
     step_kernels = [k for k in STEP_KERNELS if prof[k]["avg_us"]]
-    iterations = max(prof["spmv"]["launches"], 1)
+    iterations = max(int(prof_info["spmv"]), 1)
     step_us = sum(prof[k]["total_us"] for k in step_kernels) / iterations
     achieved = alg_bytes / (step_us * 1e-6) / 1e9
     blocked = g.format().startswith("bsf")
