@@ -987,26 +987,42 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     std::vector<int4> tasks;
     std::vector<int> ranges(1, 0);
     {
-        const int64_t fill_cost = 24576;                   // a 128 KB fill ~ this many entries of streaming
-        const int64_t target = (int64_t)(1.16 * (double)(padded + (int64_t)p.num_chunks * fill_cost) / (double)r.num_cus) + 8;
-        int64_t left = target;
-        for (int c = 0; c < p.num_chunks; ++c) {
-            int64_t lo = chunk_start[c];
-            const int64_t hi = chunk_start[c + 1];
-            while (lo < hi) {
-                if (left < fill_cost + 4096 && (int)tasks.size() > ranges.back()) {
-                    ranges.push_back((int)tasks.size());   // next share
-                    left = target;
+        const int64_t fill_cost = getenv("PGH_PB_FILLCOST") != nullptr ? atoll(getenv("PGH_PB_FILLCOST")) : 24576;   // a 128 KB fill ~ this many entries of streaming
+        // every share that starts inside a chunk pays one more fill, so the total grows with the number of shares: the
+        // smallest per-share budget that needs no more shares than there are CUs is searched for (a fixed 1.16 x mean left 9
+        // of 256 CUs without a share at scale 23)
+        auto build = [&](int64_t target) {
+            tasks.clear();
+            ranges.assign(1, 0);
+            int64_t left = target;
+            for (int c = 0; c < p.num_chunks; ++c) {
+                int64_t lo = chunk_start[c];
+                const int64_t hi = chunk_start[c + 1];
+                while (lo < hi) {
+                    if (left < fill_cost + 4096 && (int)tasks.size() > ranges.back()) {
+                        ranges.push_back((int)tasks.size());   // next share
+                        left = target;
+                    }
+                    int64_t take = std::min<int64_t>(hi - lo, std::max<int64_t>(left - fill_cost, 4096));
+                    if (lo + take < hi) take = std::max<int64_t>(8, take & ~(int64_t)7);
+                    take = std::min<int64_t>(take, hi - lo);
+                    tasks.push_back(make_int4(c, (int)lo, (int)(lo + take), 0));
+                    lo += take;
+                    left -= fill_cost + take;
                 }
-                int64_t take = std::min<int64_t>(hi - lo, std::max<int64_t>(left - fill_cost, 4096));
-                if (lo + take < hi) take = std::max<int64_t>(8, take & ~(int64_t)7);
-                take = std::min<int64_t>(take, hi - lo);
-                tasks.push_back(make_int4(c, (int)lo, (int)(lo + take), 0));
-                lo += take;
-                left -= fill_cost + take;
             }
+            ranges.push_back((int)tasks.size());
+            return (int)ranges.size() - 1;
+        };
+        const double mean = (double)(padded + (int64_t)p.num_chunks * fill_cost) / (double)r.num_cus;
+        double lo_m = 1.0, hi_m = 1.5;
+        while (build((int64_t)(hi_m * mean) + 8) > r.num_cus) hi_m *= 1.25;
+        for (int it = 0; it < 24; ++it) {
+            const double mid = 0.5 * (lo_m + hi_m);
+            if (build((int64_t)(mid * mean) + 8) > r.num_cus) lo_m = mid;
+            else hi_m = mid;
         }
-        ranges.push_back((int)tasks.size());
+        (void)build((int64_t)(hi_m * mean) + 8);
     }
     const int shares = (int)ranges.size() - 1;
     p.num_tasks = shares;

@@ -57,6 +57,22 @@ def test_cfg2_ppr_scale23_vs_oracle(big):
     assert dflt.convergence.iteration == iters_d and _rel(got_d, want_d) <= 1e-6
 
 
+def test_cfg2_full_size_runs_are_bit_identical(big):
+    """The finish kernel hands the tail of its work list out through a device counter and the close of a step rides in the
+    next step's first kernel: who processes what differs from run to run, the results must not (per-item partial slots,
+    fixed fold order, integer accumulation of the cold sums)."""
+    pg = big["pg"]
+    p = big["seeds"](3)
+    runs = []
+    for _ in range(3):
+        ranker = pg.PageRank(alpha=0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+        out = np.asarray(ranker.rank(big["adj"], p.copy()).np)
+        runs.append((out.copy(), ranker.convergence.iteration, ranker.last_loop["last_error"]))
+    for out, iters, err in runs[1:]:
+        assert iters == runs[0][1] and err == runs[0][2]
+        assert np.array_equal(out, runs[0][0])
+
+
 @pytest.mark.parametrize("coefficient_type", ["taylor", "chebyshev"])
 def test_cfg4_heat_kernel_scale23_vs_oracle(big, coefficient_type):
     from oracle import ref_loops as orc
