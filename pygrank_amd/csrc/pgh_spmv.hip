@@ -1019,10 +1019,15 @@ int batch_for(pgh_graph_t g) {
 
 // steps kept in flight ahead of the last one seen complete (progress_wait)
 int window_for(pgh_graph_t g) {
+    static const int forced = getenv("PGH_WINDOW") != nullptr ? atoi(getenv("PGH_WINDOW")) : 0;      // diagnostic
+    if (forced > 0) return forced;
+    // (the close of a step rides in the next step's first kernel, so the step counter the host sees trails by one launch
+    // and a window of w keeps w - 1 whole iterations queued behind the running one.  Small graphs, profiles/r02/
+    // small_window_sweep.log: window 8 left up to 8 no-op iterations behind the converged one -- 238 / 274 / 325 us per run at
+    // scale 10 / 14 / 18 against 211 / 245 / 296 us with 3)
     const double est_us = (8.0 * (double)g->nnz + 16.0 * (double)g->n_cols) / 4.0e6;
     if (est_us > 200.0) return 2;
-    if (est_us > 20.0) return 4;
-    return 8;
+    return 3;
 }
 
 struct LoopTimer {
