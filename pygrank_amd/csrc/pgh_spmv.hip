@@ -1171,6 +1171,66 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     static const bool defer_env = getenv("PGH_DEFER_CLOSE") == nullptr || atoi(getenv("PGH_DEFER_CLOSE")) != 0;
     const bool defer = defer_env && sp.blocked && !overlap;
     pending_close_slot().active = 0;
+    int count_seen = 0;   // partials per step (the same for every step of a run)
+    // the close of step k as the record the next blocked-format launch executes (PendingClose)
+    auto stash_close = [&](PendingClose& pc, int k) {
+        const int it = k + 1;
+        pc.state = g_state;
+        pc.partial_sum = r.d_partials;
+        pc.res_partials = pres;
+        pc.progress = g_progress_dev;
+        pc.tol = cfg->tol;
+        pc.n = (long long)n;
+        pc.num_sum = count_seen;
+        pc.num_res = rgrid;
+        pc.use_quotient = cfg->use_quotient;
+        pc.check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
+        pc.err_kind = cfg->err_kind;
+        pc.active = 1;
+    };
+    // every launch of step k (it produces x_k from x_{k-1})
+    auto enqueue_step = [&](int k) -> int {
+        const float* xin = buf[(k - 1) & 1];
+        float* yout = buf[k & 1];
+        EpiParams epk = ep;
+        epk.y = yout;
+        int count = 0;
+        PGH_TRY((launch_step<MODE>(g, epk, use_xg ? g->bsf.xg : xin, g_state, &count,
+                                   (overlap && k > 1) ? g_ev_closed : nullptr)));
+        count_seen = count;
+        // the check that follows step k happens at iteration k + 1 (skipped when that iteration hits max_iters)
+        const int it = k + 1;
+        const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
+        hipStream_t main_stream = r.stream;
+        struct StreamGuard {                     // whatever happens below, the engine's stream is put back
+            Runtime& rt_;
+            hipStream_t saved;
+            ~StreamGuard() { rt_.stream = saved; }
+        } guard{r, main_stream};
+        if (overlap) {
+            PGH_HIP(hipEventRecord(g_ev_combined, main_stream));
+            PGH_HIP(hipStreamWaitEvent(g_side_stream, g_ev_combined, 0));
+            r.stream = g_side_stream;            // ProfScope and the launches below follow rt().stream
+        }
+        if (check) {
+            ProfScope prof(PGH_K_RESIDUAL);
+            const int vec_ok = aligned16(yout) && aligned16(xin);
+            k_step_residual<<<rgrid, WG, 0, r.stream>>>(yout, xin, n_int, vec_ok, cfg->use_quotient, linf, g_state,
+                                                        r.d_partials, count, pres);
+        }
+        if (defer) {
+            stash_close(pending_close_slot(), k);
+        } else {
+            ProfScope prof(PGH_K_FINAL);
+            k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, pres, rgrid, cfg->use_quotient,
+                                                 check, cfg->err_kind, cfg->tol, n, nullptr, g_progress_dev);
+        }
+        if (overlap) {
+            r.stream = main_stream;
+            PGH_HIP(hipEventRecord(g_ev_closed, g_side_stream));
+        }
+        return 0;
+    };
     int enq = 0;          // steps enqueued so far
     bool done = false;
     while (!done && enq < max_steps) {
@@ -1178,59 +1238,13 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             PGH_TRY(progress_wait(enq, window, &done));
             if (done) break;
         }
+        // (hipGraphs were measured for this loop, tools/graph_probe.hip + profiles/r02/loop_graph_*.log: dependent tiny kernels
+        // cost 2.7 us each in a stream and 1.7 us INSIDE one graph, but between two graph launches the gap is 2.7 us again,
+        // hipGraphLaunch takes 8 us of host time and an instantiate 140-300 us.  A graph short enough not to run far past the
+        // converged step -- two steps, eight kernels -- gains nothing (2.72 us per kernel), and the loop built on such pairs
+        // measured 520 instead of 286 us per run at scale 10 and 469.6 instead of 474.6 GTEPS at scale 23.)
         const int upto = (enq + batch < max_steps) ? enq + batch : max_steps;
-        for (; enq < upto; ++enq) {
-            const int k = enq + 1;                        // this is step k; it produces x_k from x_{k-1}
-            const float* xin = buf[(k - 1) & 1];
-            float* yout = buf[k & 1];
-            ep.y = yout;
-            int count = 0;
-            PGH_TRY((launch_step<MODE>(g, ep, use_xg ? g->bsf.xg : xin, g_state, &count,
-                                       (overlap && enq > 0) ? g_ev_closed : nullptr)));
-            // the check that follows step k happens at iteration k + 1 (skipped when that iteration hits max_iters)
-            const int it = k + 1;
-            const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
-            hipStream_t main_stream = r.stream;
-            struct StreamGuard {                     // whatever happens below, the engine's stream is put back
-                Runtime& rt_;
-                hipStream_t saved;
-                ~StreamGuard() { rt_.stream = saved; }
-            } guard{r, main_stream};
-            if (overlap) {
-                PGH_HIP(hipEventRecord(g_ev_combined, main_stream));
-                PGH_HIP(hipStreamWaitEvent(g_side_stream, g_ev_combined, 0));
-                r.stream = g_side_stream;            // ProfScope and the launches below follow rt().stream
-            }
-            if (check) {
-                ProfScope prof(PGH_K_RESIDUAL);
-                const int vec_ok = aligned16(yout) && aligned16(xin);
-                k_step_residual<<<rgrid, WG, 0, r.stream>>>(yout, xin, n_int, vec_ok, cfg->use_quotient, linf, g_state,
-                                                            r.d_partials, count, pres);
-            }
-            if (defer) {
-                PendingClose& pc = pending_close_slot();
-                pc.state = g_state;
-                pc.partial_sum = r.d_partials;
-                pc.res_partials = pres;
-                pc.progress = g_progress_dev;
-                pc.tol = cfg->tol;
-                pc.n = (long long)n;
-                pc.num_sum = count;
-                pc.num_res = rgrid;
-                pc.use_quotient = cfg->use_quotient;
-                pc.check = check;
-                pc.err_kind = cfg->err_kind;
-                pc.active = 1;
-            } else {
-                ProfScope prof(PGH_K_FINAL);
-                k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, pres, rgrid, cfg->use_quotient,
-                                                     check, cfg->err_kind, cfg->tol, n, nullptr, g_progress_dev);
-            }
-            if (overlap) {
-                r.stream = main_stream;
-                PGH_HIP(hipEventRecord(g_ev_closed, g_side_stream));
-            }
-        }
+        for (; enq < upto; ++enq) PGH_TRY(enqueue_step(enq + 1));
         PGH_HIP(hipGetLastError());
         if (!poll || enq >= max_steps) PGH_TRY(flush_pending_close());
         if (!poll) {
