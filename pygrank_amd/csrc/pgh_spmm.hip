@@ -95,44 +95,57 @@ __global__ __launch_bounds__(WG) void k_mm_close_rows(const uint32_t* __restrict
 // L2 of 4 MB keeps a row only if it comes back within ~10 K gathers: 19 % of the gathers.  Loading the rows of all but
 // the hottest sources with the streaming policy (nt) so that they would not evict the hot ones was measured and does
 // not change the hit rate (8.9-9.5 ms per step against 8.7).
-template <bool HAS_VAL>
+// Narrow batches: a row of <= 32 (<= 16) columns needs 8 (4) lanes, so the wavefront is cut into 8 (16) groups and one load
+// instruction fetches 8 (16) rows; a lane then holds 2 (4) of the 16 stream words of its group's round.
+template <bool HAS_VAL, int LPR>
 __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __restrict__ xg, int ld, int b, float* __restrict__ sums,
                                                     const BatchState* __restrict__ state) {
     if (state != nullptr && state->all_done) return;
+    constexpr int G = 64 / LPR;                            // groups (tiles in flight) per wavefront
+    constexpr int W = 16 / LPR;                            // stream words of a 16-entry round per lane
     const int lane = threadIdx.x & 63;
-    const int l = lane & 15;
+    const int l = lane & (LPR - 1);
     const int c4 = 4 * l;                                  // first of this lane's four columns
-    const int pull = (lane & 48) << 2;                     // ds_bpermute byte index of lane 0 of this group
+    const int pull = (lane & ~(LPR - 1)) << 2;             // ds_bpermute byte index of lane 0 of this group
     const bool live = c4 < b;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (WG / 64) + (threadIdx.x >> 6)));
-    const int stride = gridDim.x * (WG / 64) * 4;
-    for (int t0 = wave * 4; t0 < f.num_tiles; t0 += stride) {
-        const int t = t0 + (lane >> 4);
+    const int stride = gridDim.x * (WG / 64) * G;
+    struct Words {
+        uint32_t w[W];
+        int      c[W];
+        float    v[W];
+    };
+    for (int t0 = wave * G; t0 < f.num_tiles; t0 += stride) {
+        const int t = t0 + lane / LPR;
         const bool has = t < f.num_tiles;
         const int64_t base = (int64_t)(has ? t : f.num_tiles - 1) * kTileMM;      // tiles are full and consecutive
-        uint32_t w0, w1, w2;
-        int c0, c1, c2;
-        float v0 = 1.f, v1 = 1.f, v2 = 1.f;
-        auto words = [&](int e16, uint32_t& w, int& c, float& v) __attribute__((always_inline)) {
-            const int64_t at = base + e16 + l;
-            w = __builtin_nontemporal_load(f.colf + at);
-            c = has ? __builtin_nontemporal_load(f.close + at) : -1;
-            if (HAS_VAL) v = __builtin_nontemporal_load(f.val + at);
+        Words w0, w1, w2;
+        auto words = [&](int e16, Words& q) __attribute__((always_inline)) {
+            const int64_t at = base + e16 + l * W;
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                q.w[k] = __builtin_nontemporal_load(f.colf + at + k);
+                q.c[k] = has ? __builtin_nontemporal_load(f.close + at + k) : -1;
+                q.v[k] = HAS_VAL ? __builtin_nontemporal_load(f.val + at + k) : 1.f;
+            }
         };
-        auto gather = [&](uint32_t w, int half, f32x4 (&x)[8]) __attribute__((always_inline)) {
+        // entry j of the round lives in word j % W of lane j / W of the group
+        auto gather = [&](const Words& q, int half, f32x4 (&x)[8]) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute(pull + 4 * (8 * half + j), (int)w) & 0x7fffffffu;
+                const int e = 8 * half + j;
+                const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute(pull + 4 * (e / W), (int)q.w[e % W]) & 0x7fffffffu;
                 x[j] = live ? *reinterpret_cast<const f32x4*>(xg + (int64_t)src * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // f64: a lane adds up to 512 terms serially
-        auto consume = [&](int c, float v, int half, const f32x4 (&x)[8]) __attribute__((always_inline)) {
+        auto consume = [&](const Words& q, int half, const f32x4 (&x)[8]) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int ends = __builtin_amdgcn_ds_bpermute(pull + 4 * (8 * half + j), c);
+                const int e = 8 * half + j;
+                const int ends = __builtin_amdgcn_ds_bpermute(pull + 4 * (e / W), q.c[e % W]);
                 f32x4 xv = x[j];
-                if (HAS_VAL) xv *= __int_as_float(__builtin_amdgcn_ds_bpermute(pull + 4 * (8 * half + j), __float_as_int(v)));
+                if (HAS_VAL) xv *= __int_as_float(__builtin_amdgcn_ds_bpermute(pull + 4 * (e / W), __float_as_int(q.v[e % W])));
                 a0 += (double)xv.x;
                 a1 += (double)xv.y;
                 a2 += (double)xv.z;
@@ -146,17 +159,17 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
             }
         };
         f32x4 xa[8], xb[8];
-        words(0, w0, c0, v0);
-        words(16, w1, c1, v1);
+        words(0, w0);
+        words(16, w1);
         gather(w0, 0, xa);
         for (int mr = 0; mr < kTileMM / 16; ++mr) {
             gather(w0, 1, xb);
-            consume(c0, v0, 0, xa);
-            words(min(16 * (mr + 2), kTileMM - 16), w2, c2, v2);
+            consume(w0, 0, xa);
+            words(min(16 * (mr + 2), kTileMM - 16), w2);
             if (mr + 1 < kTileMM / 16) gather(w1, 0, xa);
-            consume(c0, v0, 1, xb);
-            w0 = w1, c0 = c1, v0 = v1;
-            w1 = w2, c1 = c2, v1 = v2;
+            consume(w0, 1, xb);
+            w0 = w1;
+            w1 = w2;
         }
         if (has) *reinterpret_cast<f32x4*>(f.tail + (int64_t)t * kLanes + c4) = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
     }
@@ -180,6 +193,10 @@ __global__ __launch_bounds__(WG) void k_mm_fixup(MMView f, int ld, int b, float*
     }
 }
 
+// lanes that move one row of the [n, ld] slabs as float4s: 16 for up to 64 columns, 8 for up to 32, 4 for up to 16 (the
+// other kernels of the batch use the same shape as k_mm_partial); a wavefront moves 64 / lanes rows per pass
+__host__ __device__ inline int lanes_per_row(int ld) { return ld <= 16 ? 4 : (ld <= 32 ? 8 : 16); }
+
 struct CombineParams {
     const float* sums;       // [n, ld] plain row sums (structural zeros never written)
     const float* dst_scale;  // [n] or null
@@ -199,7 +216,8 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
     __shared__ double s_red[WG / 64][kLanes];
     if (state != nullptr && state->all_done) return;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
-    const int l = lane & 15, c4 = 4 * l;
+    const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
+    const int l = lane & (lpr - 1), c4 = 4 * l;
     const bool live = c4 < b;
     f32x4 a, frozen = {0.f, 0.f, 0.f, 0.f};                // per column: alpha * quotient; 1 = the column has stopped
     bool any_frozen = false;
@@ -215,8 +233,8 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
     any_frozen = __any(any_frozen);
     const float bc = (float)(1.0 - c.alpha);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * 4 + (lane >> 4);
-    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * 4;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * rows_per_wave + lane / lpr;
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
     constexpr int U = 2;
     for (int64_t r0 = first; r0 < n; r0 += stride * U) {
         f32x4 sum[U], pv[U], yo[U];
@@ -254,12 +272,20 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
             s3 += (double)y.w;
         }
     }
-    // the four 16-lane groups hold the same columns: fold them in group order, then the wavefronts in wavefront order
-    s0 += __shfl_down(s0, 32, 64) + (__shfl_down(s0, 16, 64) + __shfl_down(s0, 48, 64));
-    s1 += __shfl_down(s1, 32, 64) + (__shfl_down(s1, 16, 64) + __shfl_down(s1, 48, 64));
-    s2 += __shfl_down(s2, 32, 64) + (__shfl_down(s2, 16, 64) + __shfl_down(s2, 48, 64));
-    s3 += __shfl_down(s3, 32, 64) + (__shfl_down(s3, 16, 64) + __shfl_down(s3, 48, 64));
-    if (lane < 16) {
+    // the lane groups hold the same columns: fold them in group order, then the wavefronts in wavefront order
+    {
+        double t0 = s0, t1 = s1, t2 = s2, t3 = s3;
+        for (int off = lpr; off < 64; off += lpr) {
+            t0 += __shfl_down(s0, off, 64);
+            t1 += __shfl_down(s1, off, 64);
+            t2 += __shfl_down(s2, off, 64);
+            t3 += __shfl_down(s3, off, 64);
+        }
+        s0 = t0, s1 = t1, s2 = t2, s3 = t3;
+    }
+    for (int j = threadIdx.x; j < (WG / 64) * kLanes; j += WG) (&s_red[0][0])[j] = 0.0;      // columns beyond 4 * lanes
+    __syncthreads();
+    if (lane < lpr) {
         s_red[wave_in_wg][c4 + 0] = s0;
         s_red[wave_in_wg][c4 + 1] = s1;
         s_red[wave_in_wg][c4 + 2] = s2;
@@ -300,7 +326,8 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
     __shared__ double s_red[WG / 64][kLanes];
     if (state->all_done) return;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
-    const int l = lane & 15, c4 = 4 * l;
+    const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
+    const int l = lane & (lpr - 1), c4 = 4 * l;
     double inv[4], scale[4], acc[4] = {0.0, 0.0, 0.0, 0.0};
     bool want[4], any = false;
 #pragma unroll
@@ -312,8 +339,8 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
         want[k] = col && !state->done[c4 + k];
         any = any || want[k];
     }
-    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * 4 + (lane >> 4);
-    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * 4;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * rows_per_wave + lane / lpr;
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
     constexpr int U = 4;
     if (any) {
         for (int64_t r0 = first; r0 < n; r0 += stride * U) {
@@ -336,12 +363,17 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
             }
         }
     }
-    // fold the four 16-lane groups (same columns) in group order, then the wavefronts in wavefront order
+    // fold the lane groups (same columns) in group order, then the wavefronts in wavefront order
+    for (int j = threadIdx.x; j < (WG / 64) * kLanes; j += WG) (&s_red[0][0])[j] = 0.0;      // columns beyond 4 * lanes
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const double g1 = __shfl_down(acc[k], 16, 64), g2 = __shfl_down(acc[k], 32, 64), g3 = __shfl_down(acc[k], 48, 64);
-        const double t = linf ? fmax(fmax(acc[k], g1), fmax(g2, g3)) : (acc[k] + g1) + (g2 + g3);
-        if (lane < 16) s_red[wave_in_wg][c4 + k] = want[k] ? t : 0.0;
+        double t = acc[k];
+        for (int off = lpr; off < 64; off += lpr) {
+            const double o = __shfl_down(acc[k], off, 64);
+            t = linf ? fmax(t, o) : t + o;
+        }
+        if (lane < lpr) s_red[wave_in_wg][c4 + k] = want[k] ? t : 0.0;
     }
     __syncthreads();
     if (wave_in_wg == 0) {
@@ -404,10 +436,11 @@ struct PermuteIn {
 };
 
 __global__ __launch_bounds__(WG) void k_mm_permute_in(PermuteIn q, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, int b, int ld) {
-    const int lane = threadIdx.x & 63, l = lane & 15, c4 = 4 * l;
+    const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
+    const int lane = threadIdx.x & 63, l = lane & (lpr - 1), c4 = 4 * l;
     if (c4 >= ld) return;
-    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * 4;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + (threadIdx.x >> 6)) * rows_per_wave + lane / lpr;
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
     const bool vec = (b & 3) == 0;
     for (int64_t r = first; r < n_int; r += stride) {
         const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
@@ -439,10 +472,11 @@ __global__ __launch_bounds__(WG) void k_mm_permute_in(PermuteIn q, const int32_t
 
 __global__ __launch_bounds__(WG) void k_mm_permute_out(const float* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid,
                                                         int b, int ld, const double* __restrict__ col_factor, float* __restrict__ dst) {
-    const int lane = threadIdx.x & 63, l = lane & 15, c4 = 4 * l;
+    const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
+    const int lane = threadIdx.x & 63, l = lane & (lpr - 1), c4 = 4 * l;
     if (c4 >= b) return;
-    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * 4;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + (threadIdx.x >> 6)) * rows_per_wave + lane / lpr;
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
     const bool vec = (b & 3) == 0;
     f32x4 factor = {1.f, 1.f, 1.f, 1.f};
     if (col_factor != nullptr) {
@@ -519,19 +553,28 @@ int mm_partial(pgh_graph_s* g, const float* xg, int ld, int b, float* sums, cons
     const BsfFormat& f = g->bsf_mm;
     const MMView v = mm_view(f);
     // persistent grid: as many workgroups as the registers let a CU hold (PGH_MM_WGS overrides: diagnostic)
-    static int per_cu_val = 0, per_cu_plain = 0;
-    int& per_cu = f.val ? per_cu_val : per_cu_plain;
+    const int lpr = lanes_per_row(ld);
+    const int which = (f.val ? 3 : 0) + (lpr == 16 ? 0 : (lpr == 8 ? 1 : 2));
+    const void* kernels[6] = {(const void*)k_mm_partial<false, 16>, (const void*)k_mm_partial<false, 8>, (const void*)k_mm_partial<false, 4>,
+                              (const void*)k_mm_partial<true, 16>,  (const void*)k_mm_partial<true, 8>,  (const void*)k_mm_partial<true, 4>};
+    static int per_cu_of[6] = {0, 0, 0, 0, 0, 0};
+    int& per_cu = per_cu_of[which];
     if (per_cu == 0) {
         if (getenv("PGH_MM_WGS") != nullptr) per_cu = atoi(getenv("PGH_MM_WGS"));
-        else if (f.val) PGH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mm_partial<true>, WG, 0));
-        else PGH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mm_partial<false>, WG, 0));
+        else PGH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernels[which], WG, 0));
         if (per_cu < 1) per_cu = 1;
     }
     const int grid = r.num_cus * per_cu;
     {
         ProfScope prof(PGH_K_SPMM);
-        if (f.val) k_mm_partial<true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state);
-        else k_mm_partial<false><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state);
+        switch (which) {
+            case 0: k_mm_partial<false, 16><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
+            case 1: k_mm_partial<false, 8><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
+            case 2: k_mm_partial<false, 4><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
+            case 3: k_mm_partial<true, 16><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
+            case 4: k_mm_partial<true, 8><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
+            default: k_mm_partial<true, 4><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
+        }
     }
     {
         ProfScope prof(PGH_K_FIXUP);
@@ -570,7 +613,7 @@ extern "C" int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
         q.src_b = x->data;
         q.out_bs = xg.as<float>();
         q.row_scale = f.src_scale;
-        k_mm_permute_in<<<blocks_for(n_int * 16), WG, 0, r.stream>>>(q, f.perm, n_int, g->n_rows, b, ld);
+        k_mm_permute_in<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(q, f.perm, n_int, g->n_rows, b, ld);
     }
     PGH_TRY(mm_partial(g, xg.as<float>(), ld, b, sums.as<float>(), nullptr));
     CombineParams c{};
@@ -582,7 +625,7 @@ extern "C" int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
         ProfScope prof(PGH_K_COMBINE);
         k_mm_combine<<<combine_grid(), WG, 0, r.stream>>>(c, n_int, ld, b, nullptr, partial.as<double>());
     }
-    k_mm_permute_out<<<blocks_for(n_int * 16), WG, 0, r.stream>>>(yint.as<float>(), f.perm, n_int, g->n_cols, b, ld, nullptr, y->data);
+    k_mm_permute_out<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(yint.as<float>(), f.perm, n_int, g->n_cols, b, ld, nullptr, y->data);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(r.stream));
     return 0;
@@ -627,7 +670,7 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
         q.out_b = y0.as<float>();
         q.out_bs = xg.as<float>();
         q.row_scale = f.src_scale;
-        k_mm_permute_in<<<blocks_for(n_int * 16), WG, 0, r.stream>>>(q, f.perm, n_int, n, b, ld);
+        k_mm_permute_in<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(q, f.perm, n_int, n, b, ld);
     }
     float* buf[2] = {y0.as<float>(), y1.as<float>()};
     const int linf = cfg->err_kind == PGH_ERR_LINF;
@@ -679,7 +722,7 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     PGH_HIP(hipMemcpyAsync(factors.p, h_factors, sizeof(h_factors), hipMemcpyHostToDevice, r.stream));
     int executed = 0;                                    // steps that ran before every column had stopped
     for (int j = 0; j < b; ++j) executed = host_state.steps[j] > executed ? host_state.steps[j] : executed;
-    k_mm_permute_out<<<blocks_for(n_int * 16), WG, 0, r.stream>>>(buf[executed & 1], f.perm, n_int, n, b, ld, factors.as<double>(), ranks->data);
+    k_mm_permute_out<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(buf[executed & 1], f.perm, n_int, n, b, ld, factors.as<double>(), ranks->data);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipEventRecord(ev_b, r.stream));
     PGH_HIP(hipEventSynchronize(ev_b));
