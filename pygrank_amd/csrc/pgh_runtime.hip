@@ -207,10 +207,15 @@ void pool_free(void* p) {
 }
 }  // namespace pgh
 
+namespace {
+void staged_release();      // pinned chunks of the device -> host copies (below)
+}
+
 extern "C" int pgh_shutdown(void) {
     Runtime& r = rt();
     if (!r.initialised) return 0;
     (void)hipStreamSynchronize(r.stream);
+    staged_release();
     pool_trim();
     (void)hipFree(r.d_partials);
     (void)hipFree(r.d_scalars);
@@ -506,12 +511,51 @@ extern "C" int pgh_vec_h2d_f64(pgh_vec_t v, const double* host, int64_t n) {
     return 0;
 }
 
+// Device -> pageable host memory through two pinned chunks: the copy of chunk i + 1 is in flight while chunk i is moved into
+// the caller's array (a plain hipMemcpy into pageable memory ran at ~2 GB/s: 17 ms for the 4 M doubles of a scale-22 result).
+namespace {
+constexpr size_t kStageBytes = 8u << 20;
+void* g_stage[2] = {nullptr, nullptr};
+hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
+
+void staged_release() {
+    for (int k = 0; k < 2; ++k) {
+        if (g_stage[k] != nullptr) (void)hipHostFree(g_stage[k]);
+        if (g_stage_ev[k] != nullptr) (void)hipEventDestroy(g_stage_ev[k]);
+        g_stage[k] = nullptr;
+        g_stage_ev[k] = nullptr;
+    }
+}
+
+int staged_d2h(void* host, const void* dev, size_t bytes) {
+    Runtime& r = rt();
+    if (g_stage[0] == nullptr) {
+        for (int k = 0; k < 2; ++k) {
+            PGH_HIP(hipHostMalloc(&g_stage[k], kStageBytes, hipHostMallocDefault));
+            PGH_HIP(hipEventCreateWithFlags(&g_stage_ev[k], hipEventDisableTiming));
+        }
+    }
+    const size_t chunks = (bytes + kStageBytes - 1) / kStageBytes;
+    for (size_t c = 0; c <= chunks; ++c) {
+        if (c < chunks) {
+            const size_t off = c * kStageBytes, len = bytes - off < kStageBytes ? bytes - off : kStageBytes;
+            PGH_HIP(hipMemcpyAsync(g_stage[c & 1], static_cast<const char*>(dev) + off, len, hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipEventRecord(g_stage_ev[c & 1], r.stream));
+        }
+        if (c > 0) {
+            const size_t p = c - 1, off = p * kStageBytes, len = bytes - off < kStageBytes ? bytes - off : kStageBytes;
+            PGH_HIP(hipEventSynchronize(g_stage_ev[p & 1]));
+            memcpy(static_cast<char*>(host) + off, g_stage[p & 1], len);
+        }
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" int pgh_vec_d2h_f32(pgh_vec_t v, float* host, int64_t n) {
     PGH_CHECK(v && n == v->n, "pgh_vec_d2h_f32: length mismatch");
     if (n == 0) return 0;
-    PGH_HIP(hipMemcpyAsync(host, v->data, sizeof(float) * n, hipMemcpyDeviceToHost, rt().stream));
-    PGH_HIP(hipStreamSynchronize(rt().stream));
-    return 0;
+    return staged_d2h(host, v->data, sizeof(float) * (size_t)n);
 }
 
 extern "C" int pgh_vec_d2h_f64(pgh_vec_t v, double* host, int64_t n) {
@@ -521,10 +565,10 @@ extern "C" int pgh_vec_d2h_f64(pgh_vec_t v, double* host, int64_t n) {
     PGH_TRY(pool_alloc(sizeof(double) * n, (void**)&staging));
     k_f32_to_f64<<<grid_for(n), kBlock, 0, rt().stream>>>(v->data, staging, n);
     PGH_HIP(hipGetLastError());
-    PGH_HIP(hipMemcpyAsync(host, staging, sizeof(double) * n, hipMemcpyDeviceToHost, rt().stream));
+    const int rc = staged_d2h(host, staging, sizeof(double) * (size_t)n);
     PGH_HIP(hipStreamSynchronize(rt().stream));
     pool_free(staging);
-    return 0;
+    return rc;
 }
 
 extern "C" int pgh_vec_fill(pgh_vec_t v, double value) {
@@ -841,10 +885,10 @@ extern "C" int pgh_mat_d2h_f64(pgh_mat_t m, double* host) {
     PGH_TRY(pool_alloc(sizeof(double) * total, (void**)&staging));
     k_f32_to_f64<<<grid_for(total), kBlock, 0, rt().stream>>>(m->data, staging, total);
     PGH_HIP(hipGetLastError());
-    PGH_HIP(hipMemcpyAsync(host, staging, sizeof(double) * total, hipMemcpyDeviceToHost, rt().stream));
+    const int rc = staged_d2h(host, staging, sizeof(double) * (size_t)total);
     PGH_HIP(hipStreamSynchronize(rt().stream));
     pool_free(staging);
-    return 0;
+    return rc;
 }
 namespace {
 // per-column sum of |.| of a row-major slab: every thread keeps ONE column (the grid stride is a multiple of b), f64;
