@@ -303,7 +303,7 @@ def check_multi_seed_spmm_and_batched_pagerank(pg):
         n = M.shape[0]
         g = pg.scipy_sparse_to_backend(M)
         M32 = sp.csr_array(M.astype(F32).astype(np.float64))
-        for b in (1, 3, 64):
+        for b in (1, 3, 16, 17, 24, 32, 33, 61, 64):     # the lane shapes of the multi-seed kernels: 4 / 8 / 16 lanes per row
             X = rng.random((n, b)).astype(F32).astype(np.float64)
             Y = np.asarray(pg.conv(pg.to_primitive(X), g))
             ref = (X.T @ M32).T
@@ -332,6 +332,11 @@ def check_multi_seed_spmm_and_batched_pagerank(pg):
         assert iters[j] == it, (j, iters[j], it)
         assert np.max(np.abs(out[:, j] - want)) <= 1e-6 * np.max(np.abs(want)), j
     assert len(set(i for k, i in enumerate(iters) if k != 3)) > 1, iters   # the columns really stop at different iterations
+    # the same seeds four times over (20 columns: 8 lanes per row instead of 4): same stopping iterations, same columns
+    wide = np.asarray(ranker.propagate(graph, pg.to_primitive(np.tile(feats, (1, 4)))))
+    assert [c["iterations"] for c in ranker.last_batches[0]] == iters * 4
+    for j in range(20):
+        assert np.max(np.abs(wide[:, j] - out[:, j % 5])) <= 1e-6 * max(np.max(np.abs(out[:, j % 5])), 1e-30), j
 
 
 def check_factored_upload_matches_valued_upload(pg):
