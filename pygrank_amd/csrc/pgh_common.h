@@ -156,7 +156,7 @@ struct PbFormat {
     int4*     bin = nullptr;        // [num_bins] {first output row, rows | log2ceil(largest row's entries) << 16, first group, groups}
     int       num_split = 0;        // hub rows spread over several bins ("pieces")
     int4*     split = nullptr;      // [num_split] {row, first bin, pieces, -}
-    double*   hub_part = nullptr;   // [num_bins] piece sums, folded into `out` by k_pb_hub_fold
+    double*   hub_part = nullptr;   // [hub items] piece sums of split hub rows (the last piece to arrive adds them in index order)
     uint32_t* amax = nullptr;       // [2] max |value| phase A wrote (bit pattern); phase B's exit tickets
     uint16_t* drow = nullptr;       // [padded] output row inside the bin (0xffff = pad entry)
     // work list of the finishing pass (k_pb_finish: phase B + the filter's epilogue in one launch): every output row

@@ -16,7 +16,7 @@
 //                             goes to LDS (128 KB, coalesced), then per group of 8 entries: 16 B of 2-byte source indices
 //                             + 4 B target group read, 8 LDS gathers, 32 B written to the group's place in B order.
 //                             Writes land in runs of cells: ~2-3 KB each on the bench graph.
-//   phase B  k_pb_finish      one workgroup per bin AND the filter's epilogue for the bin's rows in the same launch (round 1
+//   phase B  k_pb_finish      one work item per bin AND the filter's epilogue for the bin's rows in the same launch (round 1
 //                             ran k_pb_accumulate -> dense cold vector -> k_bsf_combine: a 2 x 4 n byte round trip and a
 //                             launch): the bin's part of the B-order stream is ONE contiguous range: 32 B
 //                             of values + 16 B of 2-byte row indices per group.  The row sums of the bin live in LDS
@@ -32,8 +32,8 @@
 //
 // Used whenever the image holds >= ~10 M cold entries (pb_plan; PGH_PB=0 switches it off, PGH_PB_FORCE=1 lifts the size
 // heuristics for tests); row-partitioned slices included, the multi-seed layout not yet.  Bench graph (RMAT scale 23):
-// k_bsf_partial 83 us (hot entries only, 16-bit stream) + phase A 81 us + phase B 84 us against 375 us with the cold
-// gathers left in the stream.
+// round 1: k_bsf_partial 83 us (hot entries only, 16-bit stream) + phase A 81 us + phase B 84 us (+ fix-up 11 + combine 49)
+// against 375 us with the cold gathers left in the stream; round 2: 62 + 75 + 96 us, phase B including the epilogue.
 // profiles/r01/pb_experiment_scale23.log holds the history (v1/v2: bins of <= 15 K ENTRIES staged in LDS and walked
 // row-major, deterministic, but 6463 bins x 114 chunks made the runs 250 bytes long and phase B DRAM-inefficient).
 #include <hipcub/hipcub.hpp>
