@@ -236,6 +236,33 @@ def single_gpu(args):
              adj, 8 * nnz + 20 * n, nnz)
         side("absorbing_walks_a085_l1_1e-6", pg.AbsorbingWalks(ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS), adj,
              8 * nnz + 24 * n, nnz)
+        # configs[2]: 64 personalizations at once (NodeRanking.propagate -> pgh_ppr_run_batch); edge-vector products per second,
+        # nominal bytes 8 nnz + 4 n + 12 n b per batch step
+        try:
+            from pygrank_amd.device import DeviceMatrix
+            width = 64
+            feats = DeviceMatrix.empty(n, width)
+            for j in range(width):
+                col = np.zeros(n)
+                col[seeds_for(100 + j, candidates)] = 1.0
+                feats.set_column(j, pg.to_signal(adj, col).np)
+            batch_ranker = pg.PageRank(alpha=ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS)
+            batch_ranker.propagate(adj, feats)
+            L.check(lib.pgh_sync())
+            t1 = time.perf_counter()
+            batch_ranker.propagate(adj, feats)
+            L.check(lib.pgh_sync())
+            dt = time.perf_counter() - t1
+            info = batch_ranker.last_batches[0]
+            products = sum(c["spmv"] for c in info)
+            steps = max(c["spmv"] for c in info)
+            secondary["ppr_l1_1e-6_batch_of_64_seeds"] = dict(
+                edge_vector_products_per_s_G=round(nnz * products / dt / 1e9, 1), device_step_us=round(info[0]["loop_ms"] / steps * 1e3, 1),
+                nominal_gbs=round((8 * nnz + 4 * n + 12 * n * width) / (info[0]["loop_ms"] / steps * 1e-3) / 1e9, 1),
+                batch_steps=steps, width=width)
+            del feats
+        except Exception as exc:                     # a side measurement never takes the headline down
+            secondary["ppr_l1_1e-6_batch_of_64_seeds"] = dict(error=str(exc))
         if not args.no_symmetric:
             sym = rmat_graph(scale, ef, seed=0, symmetrize=True, **RMAT)          # A + A^T, "symmetric" normalisation
             nnz_s = sym.array.nnz
