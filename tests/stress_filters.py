@@ -86,7 +86,7 @@ def main():
             want, it = orc.heat_kernel(M, p, t=3, coefficient_type=ctype, error_type="iters", max_iters=20, eps=EPS32)
             ranker = pg.HeatKernel(3, coefficient_type=ctype, error_type="iters", max_iters=20)
         else:
-            b = int(rng.choice([1, 3, 17]))
+            b = int(rng.choice([1, 3, 12, 17, 33]))            # 4 / 8 / 16 lanes per row in the multi-seed kernels
             feats = np.zeros((n, b))
             for j in range(b):
                 feats[rng.integers(0, n, 3), j] = 1.0 + j
