@@ -263,7 +263,9 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
                 const int64_t lo = max(first_id, f.cold_prefix[b]), hi = min(last_id, f.cold_prefix[b + 1]);
                 if (lo >= hi) continue;                     // wavefront-uniform
                 const float* __restrict__ src = xg + f.xg_base[b] + f.hot - f.cold_prefix[b];      // src[id] = value of cold id
-                // rounds of 8 loads per thread (the whole chunk in one round of 32 was measured: 7 us SLOWER per launch)
+                // rounds of 8 loads per thread (the whole chunk in one round of 32 was measured: 7 us SLOWER per launch; 16-byte
+                // loads from the first aligned element on -- one round of 8 per chunk -- no different: 77.6 vs 78.0 us, the fills
+                // of one share hide behind the streams of the others)
                 constexpr int FU = 8;
                 for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kPbThreads * FU) {
                     float v[FU];

@@ -290,6 +290,24 @@ __global__ __launch_bounds__(WG) void k_step_residual(const float* __restrict__ 
                                                        double* __restrict__ partial_res) {
     __shared__ double s_red[4];
     if (state->done) return;
+    const int64_t tid = blockIdx.x * (int64_t)WG + threadIdx.x, stride = (int64_t)gridDim.x * WG;
+    const int64_t body = vec_ok ? (n >> 2) : 0;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    // four 16-byte pairs per thread in flight (one pair per round left the kernel latency-bound: 3.7 TB/s); the first round is
+    // issued BEFORE the fold of the sum(y) partials below, whose two barriers would otherwise stand in front of every load
+    constexpr int U = 4;
+    int64_t i = tid;
+    f32x4 u[U], v[U];
+    const bool first_round = i + (U - 1) * stride < body;
+    if (first_round) {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            u[k] = __builtin_nontemporal_load(y4 + i + k * stride);
+            v[k] = __builtin_nontemporal_load(x4 + i + k * stride);
+        }
+    }
     double inv, scale;
     if (partial_sum != nullptr) {
         const double S = fold_partials(partial_sum, num_partials, 0, s_red);
@@ -299,32 +317,27 @@ __global__ __launch_bounds__(WG) void k_step_residual(const float* __restrict__ 
         inv = state->scale;
         scale = reinterpret_cast<const double*>(state)[5];
     }
-    const int64_t tid = blockIdx.x * (int64_t)WG + threadIdx.x, stride = (int64_t)gridDim.x * WG;
     double acc = 0.0;
-    auto fold = [&](float u, float v) {
-        const double d = fabs((double)u * inv - (double)v * scale);
+    auto fold = [&](float a, float b) {
+        const double d = fabs((double)a * inv - (double)b * scale);
         acc = linf ? fmax(acc, d) : acc + d;
     };
-    const int64_t body = vec_ok ? (n >> 2) : 0;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    // four 16-byte pairs per thread in flight (one pair per round left the kernel latency-bound: 3.7 TB/s)
-    constexpr int U = 4;
-    int64_t i = tid;
-    for (; i + (U - 1) * stride < body; i += U * stride) {
-        f32x4 u[U], v[U];
+    if (first_round) {
+        for (;;) {
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            u[k] = __builtin_nontemporal_load(y4 + i + k * stride);
-            v[k] = __builtin_nontemporal_load(x4 + i + k * stride);
-        }
+            for (int k = 0; k < U; ++k) {
+                fold(u[k].x, v[k].x);
+                fold(u[k].y, v[k].y);
+                fold(u[k].z, v[k].z);
+                fold(u[k].w, v[k].w);
+            }
+            i += U * stride;
+            if (!(i + (U - 1) * stride < body)) break;
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            fold(u[k].x, v[k].x);
-            fold(u[k].y, v[k].y);
-            fold(u[k].z, v[k].z);
-            fold(u[k].w, v[k].w);
+            for (int k = 0; k < U; ++k) {
+                u[k] = __builtin_nontemporal_load(y4 + i + k * stride);
+                v[k] = __builtin_nontemporal_load(x4 + i + k * stride);
+            }
         }
     }
     for (; i < body; i += stride) {
