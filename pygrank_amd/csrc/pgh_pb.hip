@@ -82,7 +82,9 @@ constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in 
 // long enough on graphs with many chunks (row-partitioned slices gather from the whole source space).
 constexpr int kPbBinRows = PGH_PB_ROWS, kPbBThreads = PGH_PB_BTHREADS;
 constexpr int kPbBinRowsLarge = 16384, kPbBThreadsLarge = 1024;
-constexpr int kPbBinFill = 6;                    // entries per bin <= kPbBinFill * rows (balance: the heavy rows come first)
+constexpr int kPbBinFill = 6;                    // entries per bin <= kPbBinFill * rows (balance: the heavy rows come first);
+                                                 // PGH_PB_BINFILL sweep at scale 23 (profiles/r02/binfill_sweep.log), k_pb_finish:
+                                                 // 4 -> 108.9 us, 6 -> 101.6, 8 -> 108.2, 12 -> 107.7, 16 -> 133.9
 constexpr int kPbHeavyRow = 16384;               // a row with more cold entries gets (hub) bins of its own:
 constexpr int kPbHubMax = 65536;                 // one per this many entries ("pieces", entries dealt by source chunk),
 constexpr int kPbMaxPieces = 1024;               // at most this many; beyond, its cold entries stay in the blocked stream
@@ -778,7 +780,8 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         split.clear();
         cold = in_image = 0;
         heavy_rows = false;
-        const int64_t bin_entries = (int64_t)kPbBinFill * bin_rows;
+        static const int bin_fill = getenv("PGH_PB_BINFILL") != nullptr ? std::max(1, atoi(getenv("PGH_PB_BINFILL"))) : kPbBinFill;
+        const int64_t bin_entries = (int64_t)bin_fill * bin_rows;
         int row0 = 0, rows = 0;
         int64_t fill = 0, largest = 0;     // cold entries of the open bin, and of its largest row
         auto close_bin = [&]() {
