@@ -113,3 +113,9 @@ def test_cfg3_batch64_scale23(big):
         ref = np.asarray(single.rank(big["adj"], feats[:, j].copy()).np, dtype=np.float64)
         assert info[j]["iterations"] == single.convergence.iteration, j
         assert _rel(out[:, j], ref) <= 1e-6, j
+    # ... and the oracle's loop on the engine's own matrix (two columns: about 5 s of host time each)
+    from oracle import ref_loops as orc
+    for j in (5, 60):
+        want, want_iters = orc.pagerank(big["M"], feats[:, j], alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
+        assert info[j]["iterations"] == want_iters, j
+        assert _rel(out[:, j], want) <= 1e-6, j
