@@ -202,6 +202,8 @@ struct CombineParams {
     const float* dst_scale;  // [n] or null
     const float* src_scale;  // [n] or null
     const float* p;          // [n, ld] personalization (AXPBY) or null (PLAIN)
+    const uint8_t* p_row_nz; // [n] or null: rows of p that hold a non-zero.  Seed-set personalizations are all zeros but for a
+                             // few rows, and a zero row adds nothing (fma(1 - alpha, 0, v) = v): its 4 ld bytes are not read
     const float* y_old;      // [n, ld] previous iterate (frozen columns copy it) or null
     float*       y;          // [n, ld]
     float*       xg_out;     // [n, ld] next gather slab (y * src_scale) or null
@@ -245,7 +247,8 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
             const bool ok = live && r < n;
             const int64_t at = (ok ? r : 0) * ld + c4;
             sum[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.sums + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            pv[u] = (ok && !c.plain) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.p + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool with_p = ok && !c.plain && (c.p_row_nz == nullptr || c.p_row_nz[r] != 0);
+            pv[u] = with_p ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.p + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
             yo[u] = (ok && any_frozen) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.y_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
             d[u] = (ok && c.dst_scale != nullptr) ? c.dst_scale[r] : 1.f;
             sc[u] = (ok && c.xg_out != nullptr && c.src_scale != nullptr) ? c.src_scale[r] : 1.f;
@@ -433,6 +436,7 @@ struct PermuteIn {
     float*       out_b;
     float*       out_bs;     // out_b * row_scale, or null
     const float* row_scale;  // [n_int] or null
+    uint8_t*     a_row_nz;   // [n_int] or null: 1 = row r of out_a holds a non-zero (k_mm_combine skips the zero rows of p)
 };
 
 __global__ __launch_bounds__(WG) void k_mm_permute_in(PermuteIn q, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, int b, int ld) {
@@ -461,6 +465,11 @@ __global__ __launch_bounds__(WG) void k_mm_permute_in(PermuteIn q, const int32_t
         if (q.src_a != nullptr) {
             va = fetch(q.src_a);
             *reinterpret_cast<f32x4*>(q.out_a + at) = va;
+            if (q.a_row_nz != nullptr) {
+                const bool nz = va.x != 0.f || va.y != 0.f || va.z != 0.f || va.w != 0.f;
+                const unsigned long long any = __ballot(nz) >> (lane & ~(lpr - 1));       // this row's lanes from bit 0 on
+                if (l == 0) q.a_row_nz[r] = (any & ((1ULL << lpr) - 1ULL)) != 0ULL ? 1 : 0;
+            }
         }
         if (q.src_b != nullptr) {
             const f32x4 vb = q.src_b == q.src_a ? va : fetch(q.src_b);
@@ -645,7 +654,8 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     const int b = p->b, ld = (b + 3) & ~3;
     const int64_t n = g->n_cols, n_int = f.n_out;
     const size_t slab = sizeof(float) * (size_t)n_int * ld;
-    DevBytes pint, xg, sums, y0, y1, partial, state_mem, factors;
+    DevBytes pint, xg, sums, y0, y1, partial, state_mem, factors, p_rows;
+    PGH_TRY(p_rows.alloc((size_t)n_int));
     PGH_TRY(pint.alloc(slab));
     PGH_TRY(xg.alloc(slab));
     PGH_TRY(sums.alloc(slab));
@@ -667,6 +677,7 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
         q.src_a = p->data;
         q.src_b = cfg->start_from_p ? p->data : ranks->data;                  // abstract_filters.py:56 without warm_start
         q.out_a = pint.as<float>();
+        q.a_row_nz = p_rows.as<uint8_t>();
         q.out_b = y0.as<float>();
         q.out_bs = xg.as<float>();
         q.row_scale = f.src_scale;
@@ -691,6 +702,7 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
             c.dst_scale = f.dst_scale;
             c.src_scale = f.src_scale;
             c.p = pint.as<float>();
+            c.p_row_nz = p_rows.as<uint8_t>();
             c.y_old = yin;
             c.y = yout;
             c.xg_out = xg.as<float>();
