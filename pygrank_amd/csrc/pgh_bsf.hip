@@ -1008,6 +1008,7 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.head_partial);
     (void)hipFree(f.part);
     (void)hipFree(f.mm_close);
+    (void)hipFree(f.mm_row_has);
     (void)hipFree(f.perm);
     (void)hipFree(f.src_scale);
     (void)hipFree(f.dst_scale);

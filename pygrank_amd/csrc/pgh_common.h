@@ -214,6 +214,7 @@ struct BsfFormat {
     double*   head_partial = nullptr;
     float*    part = nullptr;       // multi-seed layout only: per-tile head sums
     int32_t*  mm_close = nullptr;   // multi-seed layout only: closing row of every entry (k_mm_close_rows, pgh_spmm.hip)
+    uint8_t*  mm_row_has = nullptr; // multi-seed layout only: 1 = the row of M^T holds entries (k_mm_mark_rows)
     // SpMV layout: block partial sums are stored COMPACTLY, one float per (block, row) segment in stream order (psum),
     // written sequentially by k_bsf_partial; the epilogue finds the segments of a row through one SegMeta word per
     // (block, 64 rows): bit r of mask = row 64 w + r has a segment in the block, base = index of the word's first segment

@@ -82,6 +82,24 @@ __global__ __launch_bounds__(WG) void k_mm_close_rows(const uint32_t* __restrict
     }
 }
 
+// rows of M^T that hold at least one entry (static per graph): every closing row of the stream + the rows completed by the
+// cross-tile fix-ups.  A row WITHOUT entries whose personalization row is zero stays zero in every iterate of every
+// column: the batch loop neither reads nor writes it (k_mm_combine, k_mm_residual) -- 55 % of the rows of the RMAT bench graph.
+__global__ __launch_bounds__(WG) void k_mm_mark_rows(const int32_t* __restrict__ close, int64_t num_entries, const int4* __restrict__ tile,
+                                                      const int32_t* __restrict__ seg_row, int num_tiles, uint8_t* __restrict__ has) {
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    for (int64_t e = blockIdx.x * (int64_t)WG + threadIdx.x; e < num_entries; e += stride) {
+        const int c = close[e];
+        if (c >= 0) has[c] = 1;
+    }
+    for (int64_t t = blockIdx.x * (int64_t)WG + threadIdx.x; t < num_tiles; t += stride) {
+        const int4 ti = tile[t];
+        if (ti.w < 0 || ti.z < 0) continue;
+        const int row = seg_row[ti.z];
+        if (row >= 0) has[row] = 1;
+    }
+}
+
 // One wavefront = four groups of 16 lanes; a group walks its own 512-entry tile and a lane holds 4 of the <= 64 batch
 // columns, so ONE 16-byte load instruction of the wavefront fetches four 256-byte rows of the gather slab (the first
 // version fetched one row per instruction with lane = column and kept 8 of them in flight between dependent scalar
@@ -202,8 +220,10 @@ struct CombineParams {
     const float* dst_scale;  // [n] or null
     const float* src_scale;  // [n] or null
     const float* p;          // [n, ld] personalization (AXPBY) or null (PLAIN)
-    const uint8_t* p_row_nz; // [n] or null: rows of p that hold a non-zero.  Seed-set personalizations are all zeros but for a
-                             // few rows, and a zero row adds nothing (fma(1 - alpha, 0, v) = v): its 4 ld bytes are not read
+    const uint8_t* p_row_nz; // [n] or null: row flags (PermuteIn::a_row_nz).  bit 0 clear: the row of p is all zeros and adds
+                             // nothing (fma(1 - alpha, 0, v) = v): not read.  bit 1 clear: the row has no entries, its sum is 0:
+                             // not read.  Both clear: the row is zero in every iterate -- neither read nor written (y, xg and
+                             // the other iterate buffer hold zeros there from the start of the run)
     const float* y_old;      // [n, ld] previous iterate (frozen columns copy it) or null
     float*       y;          // [n, ld]
     float*       xg_out;     // [n, ld] next gather slab (y * src_scale) or null
@@ -241,13 +261,16 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
     for (int64_t r0 = first; r0 < n; r0 += stride * U) {
         f32x4 sum[U], pv[U], yo[U];
         float d[U], sc[U];
+        int fl[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t r = r0 + u * stride;
-            const bool ok = live && r < n;
+            const bool in_range = live && r < n;
+            fl[u] = in_range ? (c.p_row_nz != nullptr ? (int)c.p_row_nz[r] : 3) : 0;
+            const bool ok = in_range && fl[u] != 0;
             const int64_t at = (ok ? r : 0) * ld + c4;
-            sum[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.sums + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const bool with_p = ok && !c.plain && (c.p_row_nz == nullptr || c.p_row_nz[r] != 0);
+            sum[u] = (ok && (fl[u] & 2)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.sums + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool with_p = ok && !c.plain && (fl[u] & 1);
             pv[u] = with_p ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.p + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
             yo[u] = (ok && any_frozen) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.y_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
             d[u] = (ok && c.dst_scale != nullptr) ? c.dst_scale[r] : 1.f;
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t r = r0 + u * stride;
-            if (!live || r >= n) continue;
+            if (!live || r >= n || fl[u] == 0) continue;
             f32x4 y;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(WG) void k_mm_fold(const double* __restrict__ parti
 
 __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y, const float* __restrict__ y_old, int64_t n, int ld, int b,
                                                      int use_quotient, int linf, const BatchState* __restrict__ state,
-                                                     double* __restrict__ partial_res) {
+                                                     double* __restrict__ partial_res, const uint8_t* __restrict__ row_flags) {
     __shared__ double s_red[WG / 64][kLanes];
     if (state->all_done) return;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
@@ -348,16 +371,19 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
     if (any) {
         for (int64_t r0 = first; r0 < n; r0 += stride * U) {
             f32x4 a[U], o[U];
+            bool use[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t r = r0 + u * stride;
-                const int64_t at = (r < n ? r : 0) * ld + c4;
-                a[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + at));
-                o[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y_old + at));
+                // rows that are zero in every iterate (row flags 0: no entries, no personalization) add |0 - 0|: not read
+                use[u] = r < n && (row_flags == nullptr || row_flags[r] != 0);
+                const int64_t at = (use[u] ? r : 0) * ld + c4;
+                a[u] = use[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                o[u] = use[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (r0 + u * stride >= n) continue;
+                if (!use[u]) continue;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double d = fabs((double)a[u][k] * inv[k] - (double)o[u][k] * scale[k]);
@@ -436,7 +462,9 @@ struct PermuteIn {
     float*       out_b;
     float*       out_bs;     // out_b * row_scale, or null
     const float* row_scale;  // [n_int] or null
-    uint8_t*     a_row_nz;   // [n_int] or null: 1 = row r of out_a holds a non-zero (k_mm_combine skips the zero rows of p)
+    uint8_t*     a_row_nz;   // [n_int] or null: row flags for k_mm_combine / k_mm_residual: bit 0 = row r of out_a holds a
+                             // non-zero, bit 1 = row r of M^T holds entries (row_has); 0 = the row is zero in every iterate
+    const uint8_t* row_has;  // [n_int] static marks (k_mm_mark_rows) or null
 };
 
 __global__ __launch_bounds__(WG) void k_mm_permute_in(PermuteIn q, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, int b, int ld) {
@@ -468,7 +496,8 @@ __global__ __launch_bounds__(WG) void k_mm_permute_in(PermuteIn q, const int32_t
             if (q.a_row_nz != nullptr) {
                 const bool nz = va.x != 0.f || va.y != 0.f || va.z != 0.f || va.w != 0.f;
                 const unsigned long long any = __ballot(nz) >> (lane & ~(lpr - 1));       // this row's lanes from bit 0 on
-                if (l == 0) q.a_row_nz[r] = (any & ((1ULL << lpr) - 1ULL)) != 0ULL ? 1 : 0;
+                if (l == 0)
+                    q.a_row_nz[r] = (uint8_t)(((any & ((1ULL << lpr) - 1ULL)) != 0ULL ? 1 : 0) | ((q.row_has == nullptr || q.row_has[r] != 0) ? 2 : 0));
             }
         }
         if (q.src_b != nullptr) {
@@ -540,6 +569,12 @@ int ensure_mm_layout(pgh_graph_s* g) {
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(rt().stream));
     f.device_bytes += (int64_t)f.num_entries * 4;
+    PGH_HIP(hipMalloc(&f.mm_row_has, (size_t)(f.n_out > 0 ? f.n_out : 1)));
+    PGH_HIP(hipMemsetAsync(f.mm_row_has, 0, (size_t)(f.n_out > 0 ? f.n_out : 1), rt().stream));
+    k_mm_mark_rows<<<blocks_for(f.num_entries), WG, 0, rt().stream>>>(f.mm_close, f.num_entries, f.tile, f.seg_row, f.num_tiles, f.mm_row_has);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    f.device_bytes += f.n_out;
     return 0;
 }
 
@@ -656,6 +691,9 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     const size_t slab = sizeof(float) * (size_t)n_int * ld;
     DevBytes pint, xg, sums, y0, y1, partial, state_mem, factors, p_rows;
     PGH_TRY(p_rows.alloc((size_t)n_int));
+    // rows without entries and without personalization are zero in every iterate when the loop starts from p (they are then
+    // zero in the start iterate too): the second iterate buffer gets its zeros here, after that nobody touches those rows
+    const bool skip_dead = cfg->start_from_p != 0 && f.mm_row_has != nullptr;
     PGH_TRY(pint.alloc(slab));
     PGH_TRY(xg.alloc(slab));
     PGH_TRY(sums.alloc(slab));
@@ -670,7 +708,8 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     PGH_HIP(hipEventCreate(&ev_a));
     PGH_HIP(hipEventCreate(&ev_b));
     PGH_HIP(hipEventRecord(ev_a, r.stream));
-    PGH_HIP(hipMemsetAsync(sums.p, 0, slab, r.stream));
+    if (skip_dead) PGH_HIP(hipMemsetAsync(y1.p, 0, slab, r.stream));    // rows nobody will ever write (sums of rows without entries are not read)
+    else PGH_HIP(hipMemsetAsync(sums.p, 0, slab, r.stream));            // structural zeros of the rows without entries
     k_mm_state_init<<<1, kLanes, 0, r.stream>>>(state, b);
     {
         PermuteIn q{};
@@ -678,6 +717,7 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
         q.src_b = cfg->start_from_p ? p->data : ranks->data;                  // abstract_filters.py:56 without warm_start
         q.out_a = pint.as<float>();
         q.a_row_nz = p_rows.as<uint8_t>();
+        q.row_has = skip_dead ? f.mm_row_has : nullptr;          // null: every row counts as holding entries
         q.out_b = y0.as<float>();
         q.out_bs = xg.as<float>();
         q.row_scale = f.src_scale;
@@ -716,7 +756,8 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
             const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
             if (check) {
                 ProfScope prof(PGH_K_RESIDUAL);
-                k_mm_residual<<<cgrid, WG, 0, r.stream>>>(yout, yin, n_int, ld, b, cfg->use_quotient, linf, state, partial.as<double>());
+                k_mm_residual<<<cgrid, WG, 0, r.stream>>>(yout, yin, n_int, ld, b, cfg->use_quotient, linf, state, partial.as<double>(),
+                                                          skip_dead ? p_rows.as<uint8_t>() : nullptr);
                 k_mm_fold<<<1, WG, 0, r.stream>>>(partial.as<double>(), cgrid, linf, reinterpret_cast<double*>(state) + kLanes);     // -> state.err
             }
             k_mm_close<<<1, kLanes, 0, r.stream>>>(state, cfg->use_quotient, check, cfg->err_kind, cfg->tol, n);
