@@ -508,8 +508,10 @@ __global__ __launch_bounds__(WG) void k_mm_permute_in(PermuteIn q, const int32_t
     }
 }
 
+// (row_flags: rows whose flag is 0 are zero and the caller has cleared dst: they are neither read nor written)
 __global__ __launch_bounds__(WG) void k_mm_permute_out(const float* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid,
-                                                        int b, int ld, const double* __restrict__ col_factor, float* __restrict__ dst) {
+                                                        int b, int ld, const double* __restrict__ col_factor, float* __restrict__ dst,
+                                                        const uint8_t* __restrict__ row_flags = nullptr) {
     const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
     const int lane = threadIdx.x & 63, l = lane & (lpr - 1), c4 = 4 * l;
     if (c4 >= b) return;
@@ -523,6 +525,7 @@ __global__ __launch_bounds__(WG) void k_mm_permute_out(const float* __restrict__
             if (c4 + k < b) factor[k] = (float)col_factor[c4 + k];
     }
     for (int64_t r = first; r < n_int; r += stride) {
+        if (row_flags != nullptr && row_flags[r] == 0) continue;
         const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
         if (o < 0) continue;
         const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + r * ld + c4)) * factor;
@@ -775,7 +778,9 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     PGH_HIP(hipMemcpyAsync(factors.p, h_factors, sizeof(h_factors), hipMemcpyHostToDevice, r.stream));
     int executed = 0;                                    // steps that ran before every column had stopped
     for (int j = 0; j < b; ++j) executed = host_state.steps[j] > executed ? host_state.steps[j] : executed;
-    k_mm_permute_out<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(buf[executed & 1], f.perm, n_int, n, b, ld, factors.as<double>(), ranks->data);
+    if (skip_dead) PGH_HIP(hipMemsetAsync(ranks->data, 0, sizeof(float) * (size_t)n * b, r.stream));      // the rows that stayed zero
+    k_mm_permute_out<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(buf[executed & 1], f.perm, n_int, n, b, ld, factors.as<double>(), ranks->data,
+                                                                                   skip_dead ? p_rows.as<uint8_t>() : nullptr);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipEventRecord(ev_b, r.stream));
     PGH_HIP(hipEventSynchronize(ev_b));
