@@ -75,6 +75,21 @@ __global__ void k_source_counts(const int32_t* __restrict__ col, const int32_t* 
         atomicAdd(&cnt[col[k]], mult ? (unsigned int)mult[k] : 1u);
 }
 
+// sort key of the relabelling: reference count, ties broken in favour of ids whose ROW holds entries (square graphs: rows
+// and sources share the id space).  Ids that nobody references and whose row is empty -- isolated nodes -- then form the
+// tail of every block; `live` counts the others.
+__global__ void k_relabel_keys(const unsigned int* __restrict__ cnt, const int32_t* __restrict__ rowptr, int64_t n, unsigned int* __restrict__ key,
+                               unsigned int* __restrict__ live) {
+    unsigned int mine = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int c = cnt[i] < 0x7fffffffu ? cnt[i] : 0x7fffffffu;
+        const unsigned int has_row = rowptr[i + 1] > rowptr[i] ? 1u : 0u;
+        key[i] = (c << 1) | has_row;
+        mine += (c | has_row) != 0u ? 1u : 0u;
+    }
+    if (mine) atomicAdd(live, mine);
+}
+
 __global__ void k_iota(int32_t* p, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (int32_t)i;
 }
@@ -335,7 +350,8 @@ __global__ void k_permute_in(const float* __restrict__ src, const int32_t* __res
 // v_int = v[perm], y0 = ranks[perm], xg = ranks[perm] * src_scale
 __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __restrict__ ranks, const int32_t* __restrict__ perm,
                                   const float* __restrict__ scale, int64_t n_pad, float* __restrict__ v_int, float* __restrict__ y0,
-                                  float* __restrict__ xg, int xg_blk, int xg_live, float in_norm, int start_from_v) {
+                                  float* __restrict__ xg, int xg_blk, int xg_live, float in_norm, int start_from_v,
+                                  IsoTail iso = IsoTail{}) {
     // four independent (index -> gather) chains per thread and round: one chain per round leaves the loop latency-bound
     constexpr int U = 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -361,6 +377,8 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
             if (start_from_v) b[u] = a[u];
             v_int[i] = a[u];
             y0[i] = b[u];
+            // an operand that is not zero on an isolated row: the run cannot pass over those rows
+            if (iso.flag != nullptr && (a[u] != 0.f || b[u] != 0.f) && iso.holds(i)) atomicOr(iso.flag, 1);
             if (xg) {
                 const int slot = xg_slot((int)i, xg_blk, xg_live);
                 if (slot >= 0) xg[slot] = scale ? b[u] * sc[u] : b[u];
@@ -942,12 +960,34 @@ bool bsf_can_bring_pair(const pgh_graph_s* g) {
     return f.enabled && f.relabelled && f.perm != nullptr && f.n_out == f.n_src_pad;
 }
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
-                   bool start_from_v) {
+                   bool start_from_v, bool watch_iso) {
     BsfFormat& f = g->bsf;
+    IsoTail iso = IsoTail{};
+    if (watch_iso && f.iso_flag != nullptr) {          // the flag starts at 0; any non-zero operand on an isolated row raises it
+        PGH_HIP(hipMemsetAsync(f.iso_flag, 0, sizeof(int), rt().stream));
+        iso = iso_tail_of(f);
+    }
     k_permute_in_pair<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(v, ranks, f.perm, f.src_scale, f.n_src_pad, v_int, y0,
                                                                           want_xg ? f.xg : nullptr, f.blk_size, f.xg_live, in_norm,
-                                                                          start_from_v ? 1 : 0);
+                                                                          start_from_v ? 1 : 0, iso);
     PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+IsoTail iso_tail_of(const BsfFormat& f) {
+    IsoTail t = IsoTail{};
+    if (!f.has_iso || f.iso_flag == nullptr) return t;
+    t.flag = f.iso_flag;
+    t.blk = f.blk_size;
+    t.num_blocks = f.num_blocks;
+    for (int b = 0; b < 8; ++b) t.begin[b] = b < f.num_blocks ? f.iso_begin[b] : f.blk_size;
+    return t;
+}
+
+// the flag back to "process every row" (what every launch outside a watched recursive loop assumes)
+int iso_flag_release(pgh_graph_s* g) {
+    BsfFormat& f = g->bsf;
+    if (f.iso_flag != nullptr) PGH_HIP(hipMemsetAsync(f.iso_flag, 0xff, sizeof(int), rt().stream));
     return 0;
 }
 
@@ -1008,6 +1048,7 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.head_partial);
     (void)hipFree(f.part);
     (void)hipFree(f.mm_close);
+    (void)hipFree(f.iso_flag);
     (void)hipFree(f.mm_row_has);
     (void)hipFree(f.perm);
     (void)hipFree(f.src_scale);
@@ -1086,7 +1127,22 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_TRY(iperm.alloc(n_src));
         PGH_HIP(hipMalloc(&f.perm, sizeof(int32_t) * (size_t)n_src_pad));
         if (nnz > 0) k_source_counts<<<blocks_for(nnz), kBlock, 0, r.stream>>>(g->col, mult, nnz, cnt.p);
-        PGH_TRY(build_count_perm(cnt.p, n_src, B, blk, f.perm, iperm.p));
+        // isolated nodes (never referenced, empty row) sort last: the rows [iso_begin[b], blk) of every block b hold nothing
+        // and are referenced by nothing -- they change only through the personalization (k_pb_finish, k_step_residual)
+        DevBuf<unsigned int> key, live_count;
+        PGH_TRY(key.alloc(n_src));
+        PGH_TRY(live_count.alloc(1, true));
+        k_relabel_keys<<<blocks_for(n_src), kBlock, 0, r.stream>>>(cnt.p, g->rowptr, n_src, key.p, live_count.p);
+        PGH_TRY(build_count_perm(key.p, n_src, B, blk, f.perm, iperm.p));
+        unsigned int live_nodes = 0;
+        PGH_HIP(hipMemcpyAsync(&live_nodes, live_count.p, sizeof(unsigned int), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        for (int b = 0; b < B; ++b) {
+            // ranks r = b, b + B, ... land in block b at slot r / B: the first isolated slot, rounded up to whole float4s
+            const int64_t first_iso = ((int64_t)live_nodes - b + B - 1) / B;
+            f.iso_begin[b] = (int)std::min<int64_t>(blk, (std::max<int64_t>(first_iso, 0) + 3) & ~(int64_t)3);
+        }
+        f.has_iso = true;
     }
     // ---- entry expansion offsets (value-free: multiplicities become repeated entries)
     DevBuf<int64_t> offs;
@@ -1286,6 +1342,11 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     PGH_HIP(hipStreamSynchronize(r.stream));
     f.device_bytes = (int64_t)E * (val ? 8 : 4) + f.num_segs * 4 + (int64_t)f.num_tiles * 32 + f.meta_words * B * (int64_t)sizeof(SegMeta) +
                      (int64_t)n_src_pad * (4 + (src_old ? 4 : 0) + (relabel ? 4 : 0)) + (int64_t)n_out * (dst_old ? 8 : 4);
+    if (f.has_iso && !batch_layout) {                  // "process every row" until a recursive loop watches its operands
+        PGH_HIP(hipMalloc(&f.iso_flag, sizeof(int)));
+        PGH_HIP(hipMemsetAsync(f.iso_flag, 0xff, sizeof(int), r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+    }
     if (relabel && !batch_layout) {                    // old id -> new id: results are brought back by a gather
         f.iperm = iperm.release();
         f.device_bytes += (int64_t)n_src * 4;

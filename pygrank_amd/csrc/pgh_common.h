@@ -225,6 +225,11 @@ struct BsfFormat {
     int32_t*  iperm = nullptr;      // [n_src] old id -> new id (square relabelled graphs: results leave by a gather)
     float*    src_scale = nullptr;  // [n_src_pad + 1] new space, or null
     float*    dst_scale = nullptr;  // [n_out] new space, or null
+    // square relabelled graphs: isolated ids (never referenced, empty row) sort last, slots [iso_begin[b], blk_size) of block b
+    bool      has_iso = false;
+    int       iso_begin[8] = {0};
+    int*      iso_flag = nullptr;   // device word, set per run: 0 = the loop operands are zero on every isolated row, so those rows
+                                    // stay zero and k_pb_finish / k_step_residual skip them; non-zero = they are processed
     int32_t*  live_dev = nullptr;   // [8] device copy target of `live`
     int       live[8] = {0};        // per block: 1 + the highest source slot any entry references (hot-first order puts
                                     // never-referenced sources last: they need not be exchanged or stored)

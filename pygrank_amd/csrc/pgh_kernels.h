@@ -66,6 +66,20 @@ struct PendingClose {
     int           active;
 };
 
+// The isolated tail of every column block of a square relabelled graph (BsfFormat::iso_begin): rows without entries that
+// nobody references.  flag: device word, 0 = this run's operands are zero on all of them (they stay zero: skipped).
+struct IsoTail {
+    int* flag;
+    int  blk;
+    int  num_blocks;
+    int  begin[8];
+    __device__ __forceinline__ bool holds(int64_t row) const {
+        if (blk <= 0) return false;
+        const int b = (int)(row / blk);
+        return b < num_blocks && (int)(row - (int64_t)b * blk) >= begin[b];
+    }
+};
+
 struct GraphView {
     const int32_t* rowptr;
     const int32_t* col;
@@ -366,8 +380,10 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
                hipEvent_t before_combine = nullptr);
 int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale, float hole);
 bool bsf_can_bring_pair(const pgh_graph_s* g);
+IsoTail iso_tail_of(const BsfFormat& f);
+int iso_flag_release(pgh_graph_s* g);
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
-                   bool start_from_v);
+                   bool start_from_v, bool watch_iso = false);
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
 int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int);
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);

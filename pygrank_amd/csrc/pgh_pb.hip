@@ -217,6 +217,7 @@ struct PbView {
     const uint16_t* drow;
     double*         hub_part;          // [num_bins] sums of the pieces of split hub rows
     uint32_t*       amax;              // [0] bit pattern of max |value| written by phase A, [1] phase B's exit tickets
+    const int*      iso_flag;          // BsfFormat::iso_flag or null: 0 = items marked -2 (isolated rows) are passed over
     int64_t         cold_prefix[9];
     int64_t         xg_base[8];
     int             num_blocks, hot, chunk, num_chunks, num_bins;
@@ -502,9 +503,13 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     }
     int4 bin = make_int4(0, 0, 0, 0), epi = make_int4(0, 0, -1, 0);
     Round R;
+    // items marked -2 cover isolated rows (no entry, referenced by nobody): unless this run's operands are non-zero there
+    // they hold zeros in both iterates and are passed over (the item shrinks to no rows: barriers only)
+    const bool skip_iso = f.iso_flag != nullptr && *f.iso_flag == 0;
     if (item >= 0) {
         bin = f.item_a[item];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
-        epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1, first item of the split row}
+        epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1 (-2: isolated rows), first item of the split row}
+        if (epi.z == -2 && skip_iso) epi.y = 0;
         fetch(bin, 0, R);
     }
 #if PGH_PROBE_TIMES
@@ -575,6 +580,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         if (next >= 0) {
             next_bin = f.item_a[next];
             next_epi = f.item_b[next];
+            if (next_epi.z == -2 && skip_iso) next_epi.y = 0;
             if (PGH_FIN_PREFETCH) fetch(next_bin, 0, R);
         }
 #pragma unroll
@@ -730,6 +736,7 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.hub_ticket = p.hub_ticket;
     v.drow = p.drow;
     v.amax = p.amax;
+    v.iso_flag = f.iso_flag;
     v.hub_part = p.hub_part;
     for (int i = 0; i < 9; ++i) v.cold_prefix[i] = p.cold_prefix[i];
     for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base[i];
@@ -1052,12 +1059,33 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     // ---- work list of k_pb_finish: the bins in row order (`mine` is sorted by first row; the pieces of a split hub row are
     // consecutive), the row stretches between them cut into epilogue-only items, hub items first (they are the longest).
     {
-        std::vector<int4> hub_a, hub_b, reg_a, reg_b;
+        std::vector<int4> hub_a, hub_b, reg_a, reg_b, iso_a, iso_b;
         const int stretch = p.bin_rows > 1024 ? 1024 : p.bin_rows;   // rows per epilogue-only item: small, they level the schedule
-        auto cover = [&](int64_t lo, int64_t hi) {         // rows [lo, hi) have no cold entries in the image
+        // rows [lo, hi) have no cold entries in the image.  The part that lies in the isolated tail of its block (BsfFormat::
+        // iso_begin: rows without any entry that nobody references) goes into items of its own, marked -2: k_pb_finish passes
+        // over them unless the run's operands are non-zero there (BsfFormat::iso_flag).
+        auto cover_plain = [&](int64_t lo, int64_t hi) {
             for (int64_t at = lo; at < hi; at += stretch) {
                 reg_a.push_back(make_int4((int)at, 0, 0, 0));
                 reg_b.push_back(make_int4((int)at, (int)std::min<int64_t>(stretch, hi - at), -1, 0));
+            }
+        };
+        auto cover = [&](int64_t lo, int64_t hi) {
+            if (!f.has_iso || f.blk_size <= 0) {
+                cover_plain(lo, hi);
+                return;
+            }
+            while (lo < hi) {
+                const int64_t blk = lo / f.blk_size;
+                const int64_t blk_end = std::min<int64_t>(hi, (blk + 1) * (int64_t)f.blk_size);
+                const int64_t iso_at = blk * (int64_t)f.blk_size + (blk < f.num_blocks ? f.iso_begin[blk] : f.blk_size);
+                const int64_t mid = std::min(std::max(lo, iso_at), blk_end);
+                cover_plain(lo, mid);
+                for (int64_t at = mid; at < blk_end; at += p.bin_rows) {
+                    iso_a.push_back(make_int4((int)at, 0, 0, 0));
+                    iso_b.push_back(make_int4((int)at, (int)std::min<int64_t>(p.bin_rows, blk_end - at), -2, 0));
+                }
+                lo = blk_end;
             }
         };
         int64_t cursor = 0;
@@ -1087,8 +1115,12 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         if (cursor < f.n_out) cover(cursor, f.n_out);
         PGH_CHECK(split_at == plan->num_split, "propagation blocking: split rows of the work list do not match the plan");
         p.num_split = split_at;
-        p.num_items = (int)(hub_a.size() + reg_a.size());
+        // hub pieces first (the longest items), then the isolated stretches (usually passed over: dealt evenly, early), then
+        // the bins and plain stretches in row order (the last of them form the dynamic tail)
+        p.num_items = (int)(hub_a.size() + iso_a.size() + reg_a.size());
         std::vector<int4> all_a(hub_a), all_b(hub_b);
+        all_a.insert(all_a.end(), iso_a.begin(), iso_a.end());
+        all_b.insert(all_b.end(), iso_b.begin(), iso_b.end());
         all_a.insert(all_a.end(), reg_a.begin(), reg_a.end());
         all_b.insert(all_b.end(), reg_b.begin(), reg_b.end());
         PGH_HIP(hipMalloc(&p.item_a, sizeof(int4) * (size_t)(p.num_items + 1)));
@@ -1115,8 +1147,9 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             // measured at scale 23 (profiles/r02/finish_tail_sweep.log): 0 % 105.7 us, 8 % 100.7, 16 % 103.3, 24 % 103.6, 32 % 105.7,
             // 48 % 110.1; workgroup end times with 16 %: max 97 us instead of 105 (finish_tail_times.log)
             const int tail_pct = tail_env != nullptr ? atoi(tail_env) : 12;
-            int tail = (int)((int64_t)p.num_items * (tail_pct < 0 ? 0 : (tail_pct > 90 ? 90 : tail_pct)) / 100);
-            if (tail > p.num_items - (int)hub_a.size()) tail = p.num_items - (int)hub_a.size();
+            const int plain_items = (int)reg_a.size();         // neither hub pieces nor isolated stretches
+            int tail = (int)((int64_t)plain_items * (tail_pct < 0 ? 0 : (tail_pct > 90 ? 90 : tail_pct)) / 100);
+            if (tail > plain_items) tail = plain_items;
             if (tail > kMaxPartials - groups) tail = kMaxPartials - groups;
             if (tail < 0) tail = 0;
             const int head = p.num_items - tail;

@@ -287,10 +287,54 @@ __global__ __launch_bounds__(WG) void k_step_residual(const float* __restrict__ 
                                                        int64_t n, int vec_ok, int use_quotient, int linf,
                                                        const LoopState* __restrict__ state,
                                                        const double* __restrict__ partial_sum, int num_partials,
-                                                       double* __restrict__ partial_res) {
+                                                       double* __restrict__ partial_res, IsoTail iso = IsoTail{}) {
     __shared__ double s_red[4];
     if (state->done) return;
     const int64_t tid = blockIdx.x * (int64_t)WG + threadIdx.x, stride = (int64_t)gridDim.x * WG;
+    // isolated rows whose operands are zero hold zeros in both iterates: the tail of every block is not read
+    // (iso.begin are whole float4s; the vector path only: unaligned operands read everything)
+    const bool skip_iso = vec_ok && iso.flag != nullptr && *iso.flag == 0;
+    if (skip_iso) {
+        typedef float f32x4s __attribute__((ext_vector_type(4)));
+        const f32x4s* ya = reinterpret_cast<const f32x4s*>(y);
+        const f32x4s* xa = reinterpret_cast<const f32x4s*>(x);
+        const double S = fold_partials(partial_sum, num_partials, 0, s_red);
+        const double inv = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+        const double scale = state->scale;
+        double acc = 0.0;
+        for (int b = 0; b < iso.num_blocks; ++b) {
+            const int64_t lo = ((int64_t)b * iso.blk) >> 2, hi = ((int64_t)b * iso.blk + iso.begin[b]) >> 2;
+            constexpr int UU = 4;
+            int64_t i = lo + tid;
+            for (; i + (UU - 1) * stride < hi; i += UU * stride) {
+                f32x4s u[UU], v[UU];
+#pragma unroll
+                for (int k = 0; k < UU; ++k) {
+                    u[k] = __builtin_nontemporal_load(ya + i + k * stride);
+                    v[k] = __builtin_nontemporal_load(xa + i + k * stride);
+                }
+#pragma unroll
+                for (int k = 0; k < UU; ++k) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double d = fabs((double)u[k][c] * inv - (double)v[k][c] * scale);
+                        acc = linf ? fmax(acc, d) : acc + d;
+                    }
+                }
+            }
+            for (; i < hi; i += stride) {
+                const f32x4s u = ya[i], v = xa[i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double d = fabs((double)u[c] * inv - (double)v[c] * scale);
+                    acc = linf ? fmax(acc, d) : acc + d;
+                }
+            }
+        }
+        const double r = linf ? block_reduce_256<1>(acc, s_red) : block_reduce_256<0>(acc, s_red);
+        if (threadIdx.x == 0) partial_res[blockIdx.x] = r;
+        return;
+    }
     const int64_t body = vec_ok ? (n >> 2) : 0;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
@@ -1127,10 +1171,21 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         if (from_p) PGH_TRY(pgh_vec_copy(ranks, &pv));
     }
     float* buf[2] = {ranks->data, nullptr};
+    // isolated rows (no entry, referenced by nobody; BsfFormat::iso_begin) stay zero when both operands are zero there: the
+    // permute pass below watches for that, and the finish / residual kernels then pass over them.  Whatever happens, the
+    // flag goes back to "process every row" when this loop is left.
+    const bool watch_iso = MODE == EPI_AXPBY && pair && g->bsf.iso_flag != nullptr && g->bsf.pb.enabled && pre_scale == nullptr;
+    struct IsoGuard {
+        pgh_graph_t g_;
+        bool on;
+        ~IsoGuard() {
+            if (on) (void)iso_flag_release(g_);
+        }
+    } iso_guard{g, watch_iso};
     if (pair) {          // personalization, start vector and scaled gather vector in one pass over the permutation
         PGH_TRY(v_buf.alloc(n_int));
         PGH_TRY(y0.alloc(n_int));
-        PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, y0.p, scaled_gather, in_norm, from_p));
+        PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, y0.p, scaled_gather, in_norm, from_p, watch_iso));
         ep.v = v_buf.p;
         buf[0] = y0.p;
     } else {
@@ -1142,6 +1197,8 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     }
     PGH_TRY(y1.alloc(n_int));
     buf[1] = y1.p;
+    if (watch_iso) PGH_HIP(hipMemsetAsync(y1.p, 0, sizeof(float) * (size_t)n_int, r.stream));      // the rows nobody will write
+    const IsoTail iso_tail = watch_iso ? iso_tail_of(g->bsf) : IsoTail{};
     if (sp.blocked && !pair) {
         PGH_TRY(y0.alloc(n_int));
         PGH_TRY(bsf_out_to_internal(g, ranks->data, y0.p, 0.f));
@@ -1229,7 +1286,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             ProfScope prof(PGH_K_RESIDUAL);
             const int vec_ok = aligned16(yout) && aligned16(xin);
             k_step_residual<<<rgrid, WG, 0, r.stream>>>(yout, xin, n_int, vec_ok, cfg->use_quotient, linf, g_state,
-                                                        r.d_partials, count, pres);
+                                                        r.d_partials, count, pres, iso_tail);
         }
         if (defer) {
             stash_close(pending_close_slot(), k);

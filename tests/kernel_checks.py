@@ -324,17 +324,31 @@ def check_multi_seed_spmm_and_batched_pagerank(pg):
     out = np.asarray(ranker.propagate(graph, pg.to_primitive(feats)))
     assert out.shape == (n, 5) and hasattr(ranker, "last_batches")
     iters = [c["iterations"] for c in ranker.last_batches[0]]
+    borderline = set()                       # columns whose residual sits within f32 rounding of the tolerance at the stop
     for j in range(5):
         if j == 3:
             assert np.all(out[:, j] == 0)
             continue
         want, it = orc.pagerank(Mn, feats[:, j], alpha=0.85, error_type="l1", tol=1e-6, max_iters=500)
-        assert iters[j] == it, (j, iters[j], it)
+        if iters[j] != it:
+            # An iteration apart is accepted ONLY when the oracle's own residual at the engine's stopping check lies within
+            # 2 % of the tolerance: the f32 rounding of a column that sits on one heavy seed node moves its L1 residual by
+            # ~1e-8 (column 0: 1.0030e-6 at iteration 13 against tol = 1e-6).  The result is then held to the oracle stopped
+            # at the engine's count.
+            assert abs(iters[j] - it) == 1, (j, iters[j], it)
+            stop = iters[j]
+            at_stop = orc.pagerank(Mn, feats[:, j], alpha=0.85, error_type="iters", max_iters=stop)[0]
+            before = orc.pagerank(Mn, feats[:, j], alpha=0.85, error_type="iters", max_iters=stop - 1)[0]
+            residual = np.abs(at_stop - before).sum() / np.abs(feats[:, j]).sum()
+            assert abs(residual - 1e-6) <= 2e-8, (j, iters[j], it, residual)
+            want = at_stop
+            borderline.add(j)
         assert np.max(np.abs(out[:, j] - want)) <= 1e-6 * np.max(np.abs(want)), j
     assert len(set(i for k, i in enumerate(iters) if k != 3)) > 1, iters   # the columns really stop at different iterations
     # the same seeds four times over (20 columns: 8 lanes per row instead of 4): same stopping iterations, same columns
     wide = np.asarray(ranker.propagate(graph, pg.to_primitive(np.tile(feats, (1, 4)))))
-    assert [c["iterations"] for c in ranker.last_batches[0]] == iters * 4
+    wide_iters = [c["iterations"] for c in ranker.last_batches[0]]
+    assert all(abs(wide_iters[j] - iters[j % 5]) <= (1 if j % 5 in borderline else 0) for j in range(20)), (wide_iters, iters)
     for j in range(20):
         assert np.max(np.abs(wide[:, j] - out[:, j % 5])) <= 1e-6 * max(np.max(np.abs(out[:, j % 5])), 1e-30), j
 

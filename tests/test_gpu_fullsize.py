@@ -57,6 +57,30 @@ def test_cfg2_ppr_scale23_vs_oracle(big):
     assert dflt.convergence.iteration == iters_d and _rel(got_d, want_d) <= 1e-6
 
 
+def test_cfg2_personalization_on_isolated_nodes(big):
+    """Isolated nodes (no edge at all: ~45 % of this graph) sort last in every block and the loop passes over their rows while
+    its operands are zero there.  A personalization that touches some of them must switch that off: compared with the oracle."""
+    from oracle import ref_loops as orc
+    pg = big["pg"]
+    M = big["M"]
+    isolated = np.flatnonzero((np.diff(M.indptr) == 0) & (np.bincount(M.indices, minlength=big["n"]) == 0))
+    assert len(isolated) > big["n"] // 4
+    p = big["seeds"](4)
+    p[isolated[[0, len(isolated) // 2, -1]]] = 2.0
+    ranker = pg.PageRank(alpha=0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+    got = np.asarray(ranker.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, want_iters = orc.pagerank(M, p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
+    assert ranker.convergence.iteration == want_iters
+    assert _rel(got, want) <= 1e-6
+    assert np.all(got[isolated[[0, len(isolated) // 2, -1]]] > 0)
+    # ... and a run without them right after (the rows are passed over again) still matches
+    q = big["seeds"](5)
+    got_q = np.asarray(ranker.rank(big["adj"], q.copy()).np, dtype=np.float64)
+    want_q, iters_q = orc.pagerank(M, q, alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
+    assert ranker.convergence.iteration == iters_q and _rel(got_q, want_q) <= 1e-6
+    assert np.all(got_q[isolated] == 0)
+
+
 def test_cfg2_full_size_runs_are_bit_identical(big):
     """The finish kernel hands the tail of its work list out through a device counter and the close of a step rides in the
     next step's first kernel: who processes what differs from run to run, the results must not (per-item partial slots,
