@@ -388,17 +388,19 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
 }
 
 // dst[old] = src[iperm[old]] * factor
+// (isolated rows that the loop passed over hold zeros: not gathered)
 __global__ void k_permute_out_gather(const float* __restrict__ src, const int32_t* __restrict__ iperm, int64_t n, float factor,
-                                     float* __restrict__ dst) {
+                                     float* __restrict__ dst, IsoTail iso = IsoTail{}) {
     constexpr int U = 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool skip_iso = iso.flag != nullptr && *iso.flag == 0;
     for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
         int at[U];
         float x[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) at[u] = i0 + u * stride < n ? iperm[i0 + u * stride] : 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = src[at[u]];
+        for (int u = 0; u < U; ++u) x[u] = (skip_iso && iso.holds(at[u])) ? 0.f : src[at[u]];
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (i0 + u * stride < n) dst[i0 + u * stride] = x[u] * factor;
@@ -1020,7 +1022,8 @@ int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor) {
     BsfFormat& f = g->bsf;
     if (f.relabelled && f.iperm != nullptr) {          // gather through the inverse map: coalesced stores (the scatter form
-        k_permute_out_gather<<<blocks_for(f.n_out_orig), kBlock, 0, rt().stream>>>(src, f.iperm, f.n_out_orig, (float)factor, dst);   // writes 4 bytes per line)
+        k_permute_out_gather<<<blocks_for(f.n_out_orig), kBlock, 0, rt().stream>>>(src, f.iperm, f.n_out_orig, (float)factor, dst,   // writes 4 bytes per line)
+                                                                                    iso_tail_of(f));
         PGH_HIP(hipGetLastError());
         return 0;
     }
