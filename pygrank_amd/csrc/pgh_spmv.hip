@@ -439,6 +439,20 @@ __global__ __launch_bounds__(WG) void k_step_close(LoopState* __restrict__ state
     }
 }
 
+// raises the isolated-row flag when v is not zero on an isolated row (loops whose operands do not pass through
+// k_permute_in_pair)
+// (on_zero: raise it for a ZERO instead -- the absorbing epilogue divides by lambda + deg, and deg is 0 on those rows)
+__global__ __launch_bounds__(WG) void k_iso_watch(const float* __restrict__ v, int64_t n, IsoTail iso, int on_zero = 0) {
+    if (iso.flag == nullptr) return;
+    bool hit = false;
+    const int64_t tid = blockIdx.x * (int64_t)WG + threadIdx.x, stride = (int64_t)gridDim.x * WG;
+    for (int b = 0; b < iso.num_blocks; ++b) {
+        const int64_t lo = (int64_t)b * iso.blk + iso.begin[b], hi = min((int64_t)(b + 1) * iso.blk, n);
+        for (int64_t i = lo + tid; i < hi; i += stride) hit = hit || (on_zero ? !(v[i] != 0.f) : v[i] != 0.f);
+    }
+    if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(iso.flag, 1);
+}
+
 __global__ void k_state_init(LoopState* state, double scale) {
     state->scale = scale;
     state->err = 0.0;
@@ -1174,7 +1188,10 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     // isolated rows (no entry, referenced by nobody; BsfFormat::iso_begin) stay zero when both operands are zero there: the
     // permute pass below watches for that, and the finish / residual kernels then pass over them.  Whatever happens, the
     // flag goes back to "process every row" when this loop is left.
-    const bool watch_iso = MODE == EPI_AXPBY && pair && g->bsf.iso_flag != nullptr && g->bsf.pb.enabled && pre_scale == nullptr;
+    // (absorbing walks: the row of an isolated node is p * lambda / (lambda + 0): zero with p unless lambda is 0 there, which
+    // k_iso_watch looks for below)
+    const bool watch_iso = (MODE == EPI_AXPBY || MODE == EPI_ABSORB) && pair && g->bsf.iso_flag != nullptr && g->bsf.pb.enabled &&
+                           pre_scale == nullptr;
     struct IsoGuard {
         pgh_graph_t g_;
         bool on;
@@ -1194,6 +1211,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     if (MODE == EPI_ABSORB) {
         PGH_TRY(sp.bring(ep.deg, deg_buf, &ep.deg));
         PGH_TRY(sp.bring(ep.lam, lam_buf, &ep.lam, 1.f));      // holes: (0 * 0 + 0 * 1) / (1 + 0) = 0
+        if (watch_iso) k_iso_watch<<<residual_grid(n_int), WG, 0, r.stream>>>(ep.lam, n_int, iso_tail_of(g->bsf), 1);
     }
     PGH_TRY(y1.alloc(n_int));
     buf[1] = y1.p;
@@ -1593,6 +1611,22 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
     PGH_TRY(t1.alloc(n_int));
     float* tbuf[2] = {t0.p, t1.p};
     const float* term = p_int;        // term_1
+    // isolated rows (BsfFormat::iso_begin): every term after the first is a * 0 + b * previous term there, i.e. zero when the
+    // personalization is zero on them -- the finish kernel then passes over their items (the accumulator keeps c_1 * p = 0)
+    const bool watch_iso = sp.blocked && g->bsf.iso_flag != nullptr && g->bsf.pb.enabled && n_int > 0;
+    struct IsoGuard {
+        pgh_graph_t g_;
+        bool on;
+        ~IsoGuard() {
+            if (on) (void)iso_flag_release(g_);
+        }
+    } iso_guard{g, watch_iso};
+    if (watch_iso) {
+        PGH_HIP(hipMemsetAsync(g->bsf.iso_flag, 0, sizeof(int), r.stream));
+        k_iso_watch<<<residual_grid(n_int), WG, 0, r.stream>>>(p_int, n_int, iso_tail_of(g->bsf));
+        PGH_HIP(hipMemsetAsync(t0.p, 0, sizeof(float) * (size_t)n_int, r.stream));
+        PGH_HIP(hipMemsetAsync(t1.p, 0, sizeof(float) * (size_t)n_int, r.stream));
+    }
     const bool scaled_gather = sp.blocked && g->bsf.src_scale != nullptr;
     if (scaled_gather) PGH_TRY(bsf_to_internal(g, p->data, g->bsf.xg, true, 0.f));
     // delta_1 = |result_1 - 0|, evaluated on the device like every other delta
