@@ -280,6 +280,11 @@ int pgh_dist_partial_stage(pgh_graph_t g, pgh_vec_t xg_full, const double* state
 int pgh_graph_hot_prefix(pgh_graph_t g, int32_t* hot_slots);
 int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, pgh_vec_t y_local, pgh_vec_t xg_local_out, double* state);
 int pgh_dist_close_sum(double* state, int32_t use_quotient);
+/* Isolated rows of a rank's slice (ids without any edge sort last in every block of a generated partition).  Between these two
+ * calls the loop passes over them as long as p_local and the start iterate are zero there (checked on the device by the first
+ * call); the second call restores "every row is processed".  Without them every row is always processed. */
+int pgh_dist_watch_isolated(pgh_graph_t g, pgh_vec_t p_local, pgh_vec_t y_start);
+int pgh_dist_release_isolated(pgh_graph_t g);
 int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old, double* state);
 int pgh_dist_close_err(double* state, int32_t kind, double tol, int64_t n_global);
 /* new id -> original id of a relabelled (partitioned) graph, and the first row this graph holds */

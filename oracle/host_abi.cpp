@@ -1056,6 +1056,12 @@ int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p, double alpha, pgh_vec_t y, pgh_
     std::copy(y->data, y->data + y->n, xg_local->data);
     return 0;
 }
+// the host restatement processes every row in every step: nothing to watch
+int pgh_dist_watch_isolated(pgh_graph_t g, pgh_vec_t p_local, pgh_vec_t y_start) {
+    CHECK(g && p_local && y_start, "pgh_dist_watch_isolated: null argument");
+    return 0;
+}
+int pgh_dist_release_isolated(pgh_graph_t) { return 0; }
 int pgh_dist_close_sum(double* state, int32_t use_quotient) {
     DistState* st = reinterpret_cast<DistState*>(state);
     if (st->done) return 0;

@@ -981,8 +981,8 @@ IsoTail iso_tail_of(const BsfFormat& f) {
     if (!f.has_iso || f.iso_flag == nullptr) return t;
     t.flag = f.iso_flag;
     t.blk = f.blk_size;
-    t.num_blocks = f.num_blocks;
-    for (int b = 0; b < 8; ++b) t.begin[b] = b < f.num_blocks ? f.iso_begin[b] : f.blk_size;
+    t.num_blocks = f.iso_row_blocks;
+    for (int b = 0; b < 8; ++b) t.begin[b] = b < f.iso_row_blocks ? f.iso_begin[b] : f.blk_size;
     return t;
 }
 
@@ -1136,7 +1136,8 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_TRY(key.alloc(n_src));
         PGH_TRY(live_count.alloc(1, true));
         k_relabel_keys<<<blocks_for(n_src), kBlock, 0, r.stream>>>(cnt.p, g->rowptr, n_src, key.p, live_count.p);
-        PGH_TRY(build_count_perm(key.p, n_src, B, blk, f.perm, iperm.p));
+        const bool iso_on = env_int("PGH_ISO", 1) != 0;          // 0: the round-1 order (ties by id), no isolated tail (diagnostic)
+        PGH_TRY(build_count_perm(iso_on ? key.p : cnt.p, n_src, B, blk, f.perm, iperm.p));
         unsigned int live_nodes = 0;
         PGH_HIP(hipMemcpyAsync(&live_nodes, live_count.p, sizeof(unsigned int), hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
@@ -1145,7 +1146,22 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
             const int64_t first_iso = ((int64_t)live_nodes - b + B - 1) / B;
             f.iso_begin[b] = (int)std::min<int64_t>(blk, (std::max<int64_t>(first_iso, 0) + 3) & ~(int64_t)3);
         }
-        f.has_iso = true;
+        f.has_iso = iso_on;
+        f.iso_row_blocks = B;
+    } else if (g->part_perm != nullptr && g->part_live_nodes >= 0 && n_out > 0 && n_out % blk == 0 && g->row_begin % blk == 0 &&
+               (target == nullptr || target == &g->bsf)) {
+        // a rank's slice of a generated partition: its rows are the global blocks row_begin / blk .. (the generator broke the
+        // relabelling's ties the same way: pgh_graphgen.hip), so the tail of every one of its row blocks is isolated ids too
+        const int first_block = (int)(g->row_begin / blk), row_blocks = (int)(n_out / blk);
+        if (row_blocks >= 1 && row_blocks <= 8 && first_block + row_blocks <= B) {
+            for (int j = 0; j < 8; ++j) f.iso_begin[j] = blk;
+            for (int j = 0; j < row_blocks; ++j) {
+                const int64_t first_iso = (g->part_live_nodes - (first_block + j) + B - 1) / B;
+                f.iso_begin[j] = (int)std::min<int64_t>(blk, (std::max<int64_t>(first_iso, 0) + 3) & ~(int64_t)3);
+            }
+            f.has_iso = true;
+            f.iso_row_blocks = row_blocks;
+        }
     }
     // ---- entry expansion offsets (value-free: multiplicities become repeated entries)
     DevBuf<int64_t> offs;

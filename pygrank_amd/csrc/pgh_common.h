@@ -228,6 +228,7 @@ struct BsfFormat {
     // square relabelled graphs: isolated ids (never referenced, empty row) sort last, slots [iso_begin[b], blk_size) of block b
     bool      has_iso = false;
     int       iso_begin[8] = {0};
+    int       iso_row_blocks = 0;   // row blocks the thresholds cover: num_blocks (square graphs) or the blocks of a rank's slice
     int*      iso_flag = nullptr;   // device word, set per run: 0 = the loop operands are zero on every isolated row, so those rows
                                     // stay zero and k_pb_finish / k_step_residual skip them; non-zero = they are processed
     int32_t*  live_dev = nullptr;   // [8] device copy target of `live`
@@ -268,6 +269,7 @@ struct pgh_graph_s {
     float*    keep_dst = nullptr;    // [n_cols] output scale
     // row-partitioned graphs: ids are globally relabelled, this graph holds rows [row_begin, row_begin + n_cols)
     int32_t* part_perm = nullptr;    // [n_rows] new id -> original id (same on every rank), or null
+    int64_t  part_live_nodes = -1;   // generated partitions: ids with any edge (they sort first; -1 = unknown)
     int64_t  row_begin = 0;
 };
 

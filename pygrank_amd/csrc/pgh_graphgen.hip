@@ -67,7 +67,9 @@ __device__ __forceinline__ void rmat_edge(const RmatParams& P, uint64_t e, uint3
 }
 
 // pass 1: global out-degree weights (edge multiplicities per source) and number of edges kept by this row range
-__global__ void k_rmat_count(RmatParams P, unsigned int* __restrict__ outdeg, unsigned long long* __restrict__ kept) {
+// (has_in != null: marks the ids that receive an edge -- the relabelling of a partitioned graph breaks ties with it)
+__global__ void k_rmat_count(RmatParams P, unsigned int* __restrict__ outdeg, unsigned long long* __restrict__ kept,
+                             unsigned int* __restrict__ has_in = nullptr) {
     unsigned long long local = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < P.num_edges; e += stride) {
@@ -78,6 +80,10 @@ __global__ void k_rmat_count(RmatParams P, unsigned int* __restrict__ outdeg, un
             d = (uint32_t)P.iperm[d];
         }
         atomicAdd(&outdeg[s], 1u);
+        if (has_in != nullptr) {
+            has_in[d] = 1u;
+            if (P.symmetrize) has_in[s] = 1u;
+        }
         if ((int64_t)d >= P.row_begin && (int64_t)d < P.row_end) ++local;
         if (P.symmetrize) {
             atomicAdd(&outdeg[d], 1u);
@@ -87,6 +93,17 @@ __global__ void k_rmat_count(RmatParams P, unsigned int* __restrict__ outdeg, un
     // wavefront-aggregate before the global atomic
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(kept, local);
+}
+
+// relabelling keys of a partitioned graph, in place: count -> (count << 1) | receives an edge; live = ids with any edge
+__global__ void k_part_keys(unsigned int* __restrict__ cnt, const unsigned int* __restrict__ has_in, int64_t n, unsigned int* __restrict__ live) {
+    unsigned int mine = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int c = cnt[i] < 0x7fffffffu ? cnt[i] : 0x7fffffffu, h = has_in[i] != 0u ? 1u : 0u;
+        cnt[i] = (c << 1) | h;
+        mine += (c | h) != 0u ? 1u : 0u;
+    }
+    if (mine) atomicAdd(live, mine);
 }
 
 // pass 2: emit sort keys (local_row << 32 | src) for the kept edges
@@ -267,15 +284,24 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
         DevBuf<int32_t> iperm;
         if (part_count > 0) {
             // pass 0: global source counts in the generated ids -> the relabelling every rank derives identically
-            DevBuf<unsigned int> outdeg_old;
+            // (ties broken in favour of ids that receive an edge: the isolated ids -- no edge at all -- then form the tail of
+            // every block, i.e. of every rank's slice; BsfFormat::iso_begin)
+            DevBuf<unsigned int> outdeg_old, has_in, live_count;
             PGH_TRY(outdeg_old.alloc(n, true));
+            PGH_TRY(has_in.alloc(n, true));
+            PGH_TRY(live_count.alloc(1, true));
             RmatParams P0 = P;
             P0.row_begin = P0.row_end = 0;
-            k_rmat_count<<<blocks_for(P.num_edges), kBlock, 0, r.stream>>>(P0, outdeg_old.p, counters.p);
+            k_rmat_count<<<blocks_for(P.num_edges), kBlock, 0, r.stream>>>(P0, outdeg_old.p, counters.p, has_in.p);
+            k_part_keys<<<blocks_for(n), kBlock, 0, r.stream>>>(outdeg_old.p, has_in.p, n, live_count.p);     // in place -> sort keys
             PGH_HIP(hipGetLastError());
             PGH_TRY(iperm.alloc(n));
             PGH_HIP(hipMalloc(&g->part_perm, sizeof(int32_t) * (size_t)n));
             PGH_TRY(build_count_perm(outdeg_old.p, n, part_blocks, (int)(n / part_blocks), g->part_perm, iperm.p));
+            unsigned int live_nodes = 0;
+            PGH_HIP(hipMemcpyAsync(&live_nodes, live_count.p, sizeof(unsigned int), hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipStreamSynchronize(r.stream));
+            g->part_live_nodes = (int64_t)live_nodes;
             PGH_HIP(hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * 2, r.stream));
             P.iperm = iperm.p;
         }

@@ -509,7 +509,6 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     if (item >= 0) {
         bin = f.item_a[item];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
         epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1 (-2: isolated rows), first item of the split row}
-        if (epi.z == -2 && skip_iso) epi.y = 0;
         fetch(bin, 0, R);
     }
 #if PGH_PROBE_TIMES
@@ -519,6 +518,23 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
 #if PGH_PROBE_TIMES
         const unsigned long long item_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
+        if (epi.z == -2) {
+            // isolated rows: no entry, no segment in any block.  Passed over while the run's operands are zero there; otherwise
+            // the epilogue of an empty row sum, streamed (no row map, no partial sums), and the item is empty from here on.
+            if (!skip_iso) {
+                constexpr int UI = 2;                          // rows per thread in flight (4 spill in the polynomial variant)
+                const int row_end = epi.x + epi.y;
+                for (int row0 = epi.x + tid; row0 < row_end; row0 += THREADS * UI) {
+                    EpiOps ops[UI];
+#pragma unroll
+                    for (int u = 0; u < UI; ++u) ops[u] = epi_load<MODE>(ep, min(row0 + u * THREADS, row_end - 1));
+#pragma unroll
+                    for (int u = 0; u < UI; ++u)
+                        if (row0 + u * THREADS < row_end) epi_apply<MODE>(ep, ops[u], a_eff, row0 + u * THREADS, 0.f, sum_y, delta);
+                }
+            }
+            epi.y = 0;
+        }
         const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0x1f;
         const bool hub = ((bin.y >> 21) & 1) != 0;
         const int pieces = (int)((unsigned)bin.y >> 22) + 1;
@@ -580,7 +596,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         if (next >= 0) {
             next_bin = f.item_a[next];
             next_epi = f.item_b[next];
-            if (next_epi.z == -2 && skip_iso) next_epi.y = 0;
+
             if (PGH_FIN_PREFETCH) fetch(next_bin, 0, R);
         }
 #pragma unroll
@@ -1078,12 +1094,13 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             while (lo < hi) {
                 const int64_t blk = lo / f.blk_size;
                 const int64_t blk_end = std::min<int64_t>(hi, (blk + 1) * (int64_t)f.blk_size);
-                const int64_t iso_at = blk * (int64_t)f.blk_size + (blk < f.num_blocks ? f.iso_begin[blk] : f.blk_size);
+                const int64_t iso_at = blk * (int64_t)f.blk_size + (blk < f.iso_row_blocks ? f.iso_begin[blk] : f.blk_size);
                 const int64_t mid = std::min(std::max(lo, iso_at), blk_end);
                 cover_plain(lo, mid);
-                for (int64_t at = mid; at < blk_end; at += p.bin_rows) {
+                constexpr int64_t kIsoRows = 8192;            // streamed by the kernel: not bound by the LDS row map
+                for (int64_t at = mid; at < blk_end; at += kIsoRows) {
                     iso_a.push_back(make_int4((int)at, 0, 0, 0));
-                    iso_b.push_back(make_int4((int)at, (int)std::min<int64_t>(p.bin_rows, blk_end - at), -2, 0));
+                    iso_b.push_back(make_int4((int)at, (int)std::min<int64_t>(kIsoRows, blk_end - at), -2, 0));
                 }
                 lo = blk_end;
             }

@@ -298,9 +298,15 @@ __global__ __launch_bounds__(WG) void k_step_residual(const float* __restrict__ 
         typedef float f32x4s __attribute__((ext_vector_type(4)));
         const f32x4s* ya = reinterpret_cast<const f32x4s*>(y);
         const f32x4s* xa = reinterpret_cast<const f32x4s*>(x);
-        const double S = fold_partials(partial_sum, num_partials, 0, s_red);
-        const double inv = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
-        const double scale = state->scale;
+        double inv, scale;
+        if (partial_sum != nullptr) {
+            const double S = fold_partials(partial_sum, num_partials, 0, s_red);
+            inv = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+            scale = state->scale;
+        } else {           // partitioned loop: both quotients are already in the state (pgh_dist_close_sum)
+            inv = state->scale;
+            scale = reinterpret_cast<const double*>(state)[5];
+        }
         double acc = 0.0;
         for (int b = 0; b < iso.num_blocks; ++b) {
             const int64_t lo = ((int64_t)b * iso.blk) >> 2, hi = ((int64_t)b * iso.blk + iso.begin[b]) >> 2;
@@ -438,6 +444,8 @@ __global__ __launch_bounds__(WG) void k_step_close(LoopState* __restrict__ state
         }
     }
 }
+
+pgh_graph_s* g_dist_iso_graph = nullptr;     // the slice a partitioned run watches (pgh_dist_watch_isolated)
 
 // raises the isolated-row flag when v is not zero on an isolated row (loops whose operands do not pass through
 // k_permute_in_pair)
@@ -1030,6 +1038,30 @@ extern "C" int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, 
     return 0;
 }
 
+// Isolated rows of a rank's slice (ids without any edge sort last in every block of a generated partition): while the loop's
+// operands are zero on them they stay zero, and the finish kernel / the residual pass over them.  The caller brackets a run
+// with these two calls; in between the flag is 0 unless p or the start iterate touch such a row.
+extern "C" int pgh_dist_watch_isolated(pgh_graph_t g, pgh_vec_t p_local, pgh_vec_t y_start) {
+    PGH_CHECK(g && p_local && y_start, "pgh_dist_watch_isolated: null argument");
+    g_dist_iso_graph = nullptr;
+    if (!g->bsf.enabled || g->bsf.iso_flag == nullptr || !g->bsf.pb.enabled) return 0;
+    PGH_CHECK(p_local->n == g->n_cols && y_start->n == g->n_cols, "pgh_dist_watch_isolated: vectors must have the slice's length");
+    Runtime& r = rt();
+    const IsoTail iso = iso_tail_of(g->bsf);
+    PGH_HIP(hipMemsetAsync(g->bsf.iso_flag, 0, sizeof(int), r.stream));
+    k_iso_watch<<<residual_grid(g->n_cols), WG, 0, r.stream>>>(p_local->data, g->n_cols, iso);
+    k_iso_watch<<<residual_grid(g->n_cols), WG, 0, r.stream>>>(y_start->data, g->n_cols, iso);
+    PGH_HIP(hipGetLastError());
+    g_dist_iso_graph = g;
+    return 0;
+}
+
+extern "C" int pgh_dist_release_isolated(pgh_graph_t g) {
+    g_dist_iso_graph = nullptr;
+    if (g == nullptr) return 0;
+    return iso_flag_release(g);
+}
+
 extern "C" int pgh_dist_close_sum(double* state, int32_t use_quotient) {
     PGH_CHECK(state != nullptr, "pgh_dist_close_sum: null state");
     {
@@ -1049,8 +1081,9 @@ extern "C" int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old,
     {
         ProfScope prof(PGH_K_RESIDUAL);
         const int vec_ok = aligned16(y_new->data) && aligned16(y_old->data);
+        const IsoTail iso = (g_dist_iso_graph != nullptr && g_dist_iso_graph->n_cols == y_new->n) ? iso_tail_of(g_dist_iso_graph->bsf) : IsoTail{};
         k_step_residual<<<rgrid, WG, 0, r.stream>>>(y_new->data, y_old->data, y_new->n, vec_ok, 1, linf,
-                                                    reinterpret_cast<const LoopState*>(state), nullptr, 0, pres);
+                                                    reinterpret_cast<const LoopState*>(state), nullptr, 0, pres, iso);
     }
     {
         ProfScope prof(PGH_K_FINAL);

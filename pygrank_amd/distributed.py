@@ -262,6 +262,7 @@ class DistributedPageRank:
                 return self._rank_on_stream(pgraph, p_local, bufs, dist, lib, g, device, kind, tol, state, sum_view, err_view,
                                             err_op, local_kind, read_state, torch)
         finally:
+            L.check(lib.pgh_dist_release_isolated(g._h))
             if device.type == "cuda":
                 # every later single-GPU call of this process goes back to the engine's own stream
                 L.check(lib.pgh_sync())
@@ -284,7 +285,9 @@ class DistributedPageRank:
             return p_local
         p = p_local / norm
         cur = 0
+        bufs.y[1 - cur].zero_()                  # the rows a run passes over (isolated ids) must hold zeros in both iterates
         L.check(lib.pgh_vec_copy(bufs.v_y[cur]._h, p._h))
+        L.check(lib.pgh_dist_watch_isolated(g._h, p._h, bufs.v_y[cur]._h))
         L.check(lib.pgh_dist_prescale(g._h, bufs.v_y[cur]._h, bufs.v_xg_local._h))
         bufs.all_gather(dist, "all")
         L.check(lib.pgh_dist_state_init(state))

@@ -17,6 +17,8 @@ from pygrank_amd.distributed import _HOT_PAD, rmat_partitioned  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--worlds", type=int, nargs="+", default=[2, 4, 8])
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--seeds", action="store_true", help="a seed-set personalization (100 hot rows) and the isolated rows watched, as the "
+                                                       "partitioned PageRank loop does, instead of a dense random p")
 ap.add_argument("--lib", default=None, help="a diagnostic build of the engine (tools/build_variants.sh) instead of the in-tree one")
 args = ap.parse_args()
 if args.lib:
@@ -39,8 +41,15 @@ for world in args.worlds:
     L.check(lib.pgh_graph_set_gather_bases(g._h, bases.ctypes.data_as(C.c_void_p)))
     rng = np.random.default_rng(0)
     xg = DeviceVector.from_host(rng.random(nb.value * top + _HOT_PAD).astype(np.float32))
-    p = DeviceVector.from_host(rng.random(part.n_local).astype(np.float32))
+    if args.seeds:
+        p_host = np.zeros(part.n_local, dtype=np.float32)
+        p_host[:100] = 1.0
+    else:
+        p_host = rng.random(part.n_local).astype(np.float32)
+    p = DeviceVector.from_host(p_host)
     y = DeviceVector.from_host(np.zeros(part.n_local, dtype=np.float32))
+    if args.seeds:
+        L.check(lib.pgh_dist_watch_isolated(g._h, p._h, p._h))
     out = DeviceVector.from_host(np.zeros(part.n_local, dtype=np.float32))
     for it in range(args.steps + 2):
         if it == 2:
@@ -48,6 +57,8 @@ for world in args.worlds:
             L.check(lib.pgh_profile_enable(1))
         L.check(lib.pgh_ppr_step_dist(g._h, xg._h, 1.0, p._h, 0.85, y._h, out._h, None))
     L.check(lib.pgh_profile_enable(0))
+    if args.seeds:
+        L.check(lib.pgh_dist_release_isolated(g._h))
     prof = {}
     for kid, name in ((L.K_SPMV, "spmv"), (L.K_PB_GATHER, "pbA"), (L.K_PB_ACCUM, "pbB"), (L.K_FIXUP, "fixup"), (L.K_COMBINE, "combine")):
         cnt, ms = C.c_int64(), C.c_double()
