@@ -522,7 +522,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             // isolated rows: no entry, no segment in any block.  Passed over while the run's operands are zero there; otherwise
             // the epilogue of an empty row sum, streamed (no row map, no partial sums), and the item is empty from here on.
             if (!skip_iso) {
-                constexpr int UI = 2;                          // rows per thread in flight (4 spill in the polynomial variant)
+                constexpr int UI = 4;                          // rows per thread in flight
                 const int row_end = epi.x + epi.y;
                 for (int row0 = epi.x + tid; row0 < row_end; row0 += THREADS * UI) {
                     EpiOps ops[UI];
