@@ -1043,6 +1043,9 @@ IsoTail iso_tail_of(const BsfFormat& f) {
     if (!f.has_iso || f.iso_flag == nullptr) return t;
     t.flag = f.iso_flag;
     t.blk = f.blk_size;
+    t.shift = -1;
+    if (f.blk_size > 0 && (f.blk_size & (f.blk_size - 1)) == 0)
+        for (t.shift = 0; (1 << t.shift) < f.blk_size; ++t.shift) {}
     t.num_blocks = f.iso_row_blocks;
     for (int b = 0; b < 8; ++b) t.begin[b] = b < f.iso_row_blocks ? f.iso_begin[b] : f.blk_size;
     return t;

@@ -71,12 +71,14 @@ struct PendingClose {
 struct IsoTail {
     int* flag;
     int  blk;
+    int  shift;          // log2(blk) when the block size is a power of two (it usually is), else -1
     int  num_blocks;
     int  begin[8];
     __device__ __forceinline__ bool holds(int64_t row) const {
         if (blk <= 0) return false;
-        const int b = (int)(row / blk);
-        return b < num_blocks && (int)(row - (int64_t)b * blk) >= begin[b];
+        const unsigned int r32 = (unsigned int)row;            // ids are below 2^31
+        const int b = shift >= 0 ? (int)(r32 >> shift) : (int)(r32 / (unsigned int)blk);
+        return b < num_blocks && (int)(r32 - (unsigned int)b * (unsigned int)blk) >= begin[b];
     }
 };
 
