@@ -1017,7 +1017,8 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
         iso = iso_tail_of(f);
     }
     const int* seed_count = nullptr;
-    if (f.iperm != nullptr && env_int("PGH_SEED_LIST", 1) != 0) {
+    // (small graphs: the gather pass takes a few microseconds, two more launches would cost more)
+    if (f.iperm != nullptr && f.n_src_pad >= (1 << 21) && env_int("PGH_SEED_LIST", 1) != 0) {
         if (f.seed_list == nullptr) {
             PGH_HIP(hipMalloc(&f.seed_list, sizeof(int32_t) * (size_t)kSeedListCap));
             PGH_HIP(hipMalloc(&f.seed_count, sizeof(int)));
