@@ -438,7 +438,7 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
 // (isolated rows that the loop passed over hold zeros: not gathered)
 __global__ void k_permute_out_gather(const float* __restrict__ src, const int32_t* __restrict__ iperm, int64_t n, float factor,
                                      float* __restrict__ dst, IsoTail iso = IsoTail{}) {
-    constexpr int U = 4;
+    constexpr int U = 8;                                   // index -> gather chains in flight per thread
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool skip_iso = iso.flag != nullptr && *iso.flag == 0;
     for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
