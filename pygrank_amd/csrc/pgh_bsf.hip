@@ -22,6 +22,7 @@
 //
 // Reference counterpart of the arithmetic: conv(signal, M) = signal @ M (pygrank/core/backend/numpy.py:64-65).
 #include "pgh_kernels.h"
+#include "pgh_pb_gather.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -555,35 +556,34 @@ __device__ __forceinline__ float wave_segmented_sum(float keep, float val) {
 // tile ahead, which left every wavefront waiting on them -- SQ_WAIT_ANY 62 %, profiles/r02/r01_kernels_sq_counters.json).
 PGH_STAMP_DECL(g_times_partial)
 
+// LDS floats of the partial-sum body: [0, kBsfHot + 1) hot cache + one permanent zero (the slot cold lanes read); then per
+// wavefront a strip: slot 0 = piece of the segment open at the tile start, slot 1 + j = closed segment j, slot T + 1 + lane =
+// scratch for predicated-off writes.  One array, so that every LDS address is an offset from LDS address 0.
+constexpr int kBsfLdsFloats = kBsfHot + 1 + (kBsfThreads / 64) * (64 * kIPT + 1 + 64);
+
+// The body of the block partial sums for the workgroup `vblock` of `vgrid` (its own launch: blockIdx / gridDim; inside the
+// merged front kernel of a step: the workgroup's index among the partial-sum workgroups).
 template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false>
-__global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
-                                                              const LoopState* __restrict__ state, PendingClose pc) {
+__device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, const BsfView& f, const float* __restrict__ xg,
+                                                 const unsigned int vblock, const unsigned int vgrid) {
     static_assert(IPT == 8, "one flag byte per lane; lanes fetch their entries as 16-byte words");
     static_assert(!(W16 && COLD), "the 16-bit stream addresses the hot cache only");
     constexpr int T = 64 * IPT;
     constexpr int WAVES = kBsfThreads / 64;
     constexpr int Q = IPT / 4;
     constexpr int STRIP = T + 1 + 64;
-    // LDS: [0, 4 * (kBsfHot + 1)) hot cache + one permanent zero (the slot cold lanes read); then per wavefront a strip:
-    // slot 0 = piece of the segment open at the tile start, slot 1 + j = closed segment j, slot T + 1 + lane = scratch
-    // for predicated-off writes.  One array, so that every LDS address below is an offset from LDS address 0.
-    __shared__ __attribute__((aligned(16))) float s_lds[kBsfHot + 1 + WAVES * STRIP];
-    if (state != nullptr && state->done) return;
-    // the previous step's close, if the loop driver left it to this kernel (the LDS it uses is not yet in use)
-    if (pc.active && run_pending_close(pc, reinterpret_cast<double*>(s_lds))) return;
-    PGH_STAMP_BEGIN(g_times_partial)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
 #ifndef PGH_XCD_AFFINE
 #define PGH_XCD_AFFINE 1
 #endif
-    const int label = PGH_XCD_AFFINE ? (blockIdx.x & 7) : (int)((blockIdx.x * 8u) / gridDim.x);
-    const int slot = PGH_XCD_AFFINE ? (blockIdx.x >> 3) : (int)(blockIdx.x % (gridDim.x >> 3));
+    const int label = PGH_XCD_AFFINE ? (vblock & 7) : (int)((vblock * 8u) / vgrid);
+    const int slot = PGH_XCD_AFFINE ? (vblock >> 3) : (int)(vblock % (vgrid >> 3));
     const int b = label % f.num_blocks;
     const int per = 8 / f.num_blocks;
     const int rank = (slot * per + label / f.num_blocks) * WAVES + wave;
-    const int stride = (gridDim.x >> 3) * per * WAVES;
+    const int stride = (vgrid >> 3) * per * WAVES;
     float* __restrict__ psum = f.psum;
     const int64_t base = f.xg_base[b];
     const uint32_t hot = (uint32_t)min(kBsfHot, f.blk_size);
@@ -800,11 +800,66 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
         }
     }
 #undef PGH_STEP
+}
+
+template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false>
+__global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
+                                                              const LoopState* __restrict__ state, PendingClose pc) {
+    __shared__ __attribute__((aligned(16))) float s_lds[kBsfLdsFloats];
+    if (state != nullptr && state->done) return;
+    // the previous step's close, if the loop driver left it to this kernel (the LDS it uses is not yet in use)
+    if (pc.active && run_pending_close(pc, reinterpret_cast<double*>(s_lds))) return;
+    PGH_STAMP_BEGIN(g_times_partial)
+    bsf_partial_body<IPT, HAS_VAL, COLD, W16>(s_lds, f, xg, blockIdx.x, gridDim.x);
 #if PGH_PROBE_TIMES
     // wavefronts leave one by one: the workgroup's end = the latest of them (the clock only grows, so the maximum over
     // launches is the last launch's)
-    if (lane == 0 && blockIdx.x < 4096) atomicMax(&g_times_partial[2 * blockIdx.x + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) atomicMax(&g_times_partial[2 * blockIdx.x + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
+}
+
+// The FRONT of a step as one launch: the block partial sums (VALU-bound: 3.4 TB/s) and phase A of the cold image
+// (bandwidth-bound) do not depend on each other, so their workgroups share one grid -- a CU that has finished its
+// partial-sum workgroup takes a phase A share at once (no drain between two launches, no dependent boundary), and with the
+// roles interleaved in dispatch order the two kinds of work run side by side on different CUs.  Both roles need most of a
+// CU's LDS, so a CU holds one workgroup at a time.  Role of a workgroup: groups of 8 consecutive workgroups (one per XCD:
+// the partial sums keep their XCD-affine column blocks) take the same role.
+//   order 0: all partial-sum groups, then phase A;  3: phase A first;  1 / 2: alternating, phase A / partial sums first
+// The cross-tile fix-ups (they need ALL partial sums of the step) move into k_pb_finish (PbFormat::fix_ent).
+template <bool HAS_VAL, bool W16>
+__global__ __launch_bounds__(kBsfThreads) void k_step_front(BsfView bv, PbView pv, const float* __restrict__ xg,
+                                                             const LoopState* __restrict__ state, PendingClose pc, int n_partial,
+                                                             int n_gather, int order) {
+    constexpr int kFloats = kBsfLdsFloats > kPbChunk + 1 ? kBsfLdsFloats : kPbChunk + 1;
+    __shared__ __attribute__((aligned(16))) float s_lds[kFloats];
+    static_assert(kPbThreads == kBsfThreads, "both roles of the front kernel use the same workgroup shape");
+    if (state != nullptr && state->done) return;
+    if (pc.active && run_pending_close(pc, reinterpret_cast<double*>(s_lds))) return;
+    const int grp = blockIdx.x >> 3, sub = blockIdx.x & 7;
+    const int pg = n_partial >> 3, gg = (n_gather + 7) >> 3;
+    int role, idx;                                     // role 0 = block partial sums, 1 = phase A
+    if (order == 0) {
+        role = grp < pg ? 0 : 1;
+        idx = role == 0 ? grp : grp - pg;
+    } else if (order == 3) {
+        role = grp < gg ? 1 : 0;
+        idx = role == 1 ? grp : grp - gg;
+    } else {
+        const int m = pg < gg ? pg : gg;
+        if (grp < 2 * m) {
+            role = ((grp & 1) != 0) == (order == 1) ? 0 : 1;
+            idx = grp >> 1;
+        } else {
+            role = pg > gg ? 0 : 1;
+            idx = grp - m;
+        }
+    }
+    if (role == 0) {
+        bsf_partial_body<kIPT, HAS_VAL, false, W16>(s_lds, bv, xg, (unsigned int)(idx * 8 + sub), (unsigned int)n_partial);
+    } else {
+        const int share = idx * 8 + sub;
+        if (share < n_gather) pb_gather_body<HAS_VAL>(s_lds, reinterpret_cast<uint32_t*>(s_lds + kPbChunk), pv, xg, share);
+    }
 }
 
 // build time: where the fix-up of tile t goes (index into the partial vectors, -1 = nothing to fix), so that the
@@ -898,10 +953,61 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, 
     BsfFormat& f = g->bsf;
     const BsfView v = view_of(f);
     const int main_grid = r.num_cus;                  // one workgroup per CU; a multiple of 8 (XCD-affine blocks)
+    // diagnostic (timing only: the fix-ups then race with the partial sums): phase A on a second stream, concurrently
+    static const int probe_conc = env_int("PGH_PROBE_CONC", 0);
+    static hipStream_t conc_stream = nullptr;
+    static hipEvent_t conc_fork = nullptr, conc_join = nullptr;
+    if (probe_conc && stage == 0 && f.pb.enabled && f.pb.num_tasks > 0) {
+        if (conc_stream == nullptr) {
+            PGH_HIP(hipStreamCreateWithFlags(&conc_stream, hipStreamNonBlocking));
+            PGH_HIP(hipEventCreateWithFlags(&conc_fork, hipEventDisableTiming));
+            PGH_HIP(hipEventCreateWithFlags(&conc_join, hipEventDisableTiming));
+        }
+        FixView nofix{};
+        nofix.num_tiles = 0;
+        hipStream_t main_stream = r.stream;
+        PGH_HIP(hipEventRecord(conc_fork, main_stream));
+        PGH_HIP(hipStreamWaitEvent(conc_stream, conc_fork, 0));
+        if (probe_conc == 2) {            // phase A first in the main queue, the partial sums beside it
+            r.stream = conc_stream;
+            PGH_TRY(bsf_launch_partial(g, xg, state, 1));
+            r.stream = main_stream;
+            PGH_TRY(pb_launch_gather(g, xg, state, nofix));
+        } else {
+            r.stream = conc_stream;
+            PGH_TRY(pb_launch_gather(g, xg, state, nofix));
+            r.stream = main_stream;
+            PGH_TRY(bsf_launch_partial(g, xg, state, 1));
+        }
+        PGH_HIP(hipEventRecord(conc_join, conc_stream));
+        PGH_HIP(hipStreamWaitEvent(main_stream, conc_join, 0));
+        return 0;
+    }
     // the previous step's close rides in this launch when the loop driver deferred it (PendingClose, pgh_kernels.h)
     PendingClose pc = pending_close_slot();
     if (stage == 2 || state == nullptr || pc.state != state) pc.active = 0;
     else pending_close_slot().active = 0;             // consumed
+    // whole step in one go on a graph with a hot-only stream and a cold image: ONE front launch (k_step_front); the finish
+    // kernel then closes the cross-tile segments.  PGH_FRONT=0 keeps the two launches; PGH_FRONT_ORDER picks the role order.
+    static const int front_on = env_int("PGH_FRONT", 1), front_order = env_int("PGH_FRONT_ORDER", 1);
+    if (stage == 0 && front_on && f.pb.enabled && !f.pb.k1_cold && f.pb.num_tasks > 0 && f.pb.item_fix != nullptr && (main_grid & 7) == 0) {
+        const PbView pv = pb_view_of(g);
+        const int gather_groups = (f.pb.num_tasks + 7) >> 3;
+        const int grid = main_grid + gather_groups * 8;
+        {
+            ProfScope prof(PGH_K_SPMV);
+            if (f.colf16 != nullptr) {
+                if (f.val) k_step_front<true, true><<<grid, kBsfThreads, 0, r.stream>>>(v, pv, xg, state, pc, main_grid, f.pb.num_tasks, front_order);
+                else k_step_front<false, true><<<grid, kBsfThreads, 0, r.stream>>>(v, pv, xg, state, pc, main_grid, f.pb.num_tasks, front_order);
+            } else {
+                if (f.val) k_step_front<true, false><<<grid, kBsfThreads, 0, r.stream>>>(v, pv, xg, state, pc, main_grid, f.pb.num_tasks, front_order);
+                else k_step_front<false, false><<<grid, kBsfThreads, 0, r.stream>>>(v, pv, xg, state, pc, main_grid, f.pb.num_tasks, front_order);
+            }
+        }
+        PGH_HIP(hipGetLastError());
+        f.fix_pending = true;
+        return 0;
+    }
     if (stage != 2) {
         ProfScope prof(PGH_K_SPMV);
         if (f.colf16 != nullptr) {
@@ -1471,6 +1577,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         k_bsf_fixlist<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.tile, f.seg_row, f.num_tiles, f.fix_seg);
         PGH_HIP(hipGetLastError());
         PGH_HIP(hipStreamSynchronize(r.stream));
+        PGH_TRY(pb_attach_fixlist(f));                 // the cold image's work items learn the fix-ups of their rows
         (void)hipFree(f.seg_row);                       // build-time only in this layout
         f.seg_row = nullptr;
         if (f.pb.enabled && !f.pb.k1_cold && env_int("PGH_STREAM16", 1)) {       // hot-only stream: 2 bytes per entry

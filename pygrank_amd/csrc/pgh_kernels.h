@@ -255,6 +255,44 @@ __device__ __forceinline__ void bsf_fixup_tiles(const FixView& f, int first_tile
     }
 }
 
+// The same fix-ups from a LIST of closing tiles (k_pb_finish: the tiles whose segment belongs to the rows of the work item in
+// hand, PbFormat::fix_ent -- {closing tile, segment, first tile of the carry chain, row}).  All threads of the workgroup
+// call it together (`count` is uniform).
+struct FixList {
+    const int4*   ent;
+    const double* tail_carry;
+    const double* head_partial;
+    float*        psum;
+};
+__device__ __forceinline__ void bsf_fixup_list(const FixList& f, int begin, int count, int nthreads) {
+    const int lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < count; i0 += nthreads) {
+        const int i = i0 + (int)threadIdx.x;
+        int4 e = make_int4(0, -1, 0, 0);
+        if (i < count) e = f.ent[begin + i];
+        const int t = e.x, dst = e.y, first = e.z;
+        const int len = dst >= 0 ? t - first : 0;
+        const bool is_long = len >= 32;
+        if (dst >= 0 && !is_long) {
+            double total = 0.0;
+            for (int s = first; s < t; ++s) total += f.tail_carry[s];
+            total += f.head_partial[t];
+            f.psum[dst] = (float)total;
+        }
+        unsigned long long todo = __ballot(is_long);
+        while (todo != 0ULL) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1ULL;
+            const int c_first = __shfl(first, src, 64), c_t = __shfl(t, src, 64);
+            double part_sum = 0.0;
+            for (int s = c_first + lane; s < c_t; s += 64) part_sum += f.tail_carry[s];
+            part_sum = wave_reduce_sum(part_sum);
+            const double total = __shfl(part_sum, 0, 64) + f.head_partial[c_t];
+            if (lane == src) f.psum[dst] = (float)total;
+        }
+    }
+}
+
 // diagnostic builds only (-DPGH_PROBE_TIMES=1): every workgroup stamps its start and end (100 MHz wall clock) so that the host
 // can print how evenly a launch's workgroups finish (tools/probe_variants.py with PGH_DUMP_TIMES=1)
 #ifndef PGH_PROBE_TIMES
@@ -347,6 +385,38 @@ __device__ __forceinline__ bool run_pending_close(const PendingClose& pc, double
     return done;
 }
 
+// device view of the propagation-blocking image (PbFormat, pgh_pb.hip)
+struct PbView {
+    const uint16_t* sloc;
+    const float*    val;
+    const uint32_t* dstg;
+    const int4*     task;
+    const int*      task_range;
+    float*          tmp;
+    const int4*     item_a;            // work list of k_pb_finish (PbFormat::item_a / item_b)
+    const int4*     item_b;
+    int             num_items;
+    const int*      sched;             // item order (PbFormat::sched); static deal: slices sched_begin[w] .. sched_begin[w + 1]
+    const int*      sched_begin;
+    uint32_t*       work_counter;      // hand-out of the schedule's tail: next position (null without a tail)
+    int             tail_begin, tail_count;   // sched[tail_begin .. tail_begin + tail_count): handed out dynamically
+    uint32_t*       hub_ticket;
+    const uint16_t* drow;
+    double*         hub_part;          // [num_bins] sums of the pieces of split hub rows
+    uint32_t*       amax;              // [0] bit pattern of max |value| written by phase A, [1] phase B's exit tickets
+    const int*      iso_flag;          // BsfFormat::iso_flag or null: 0 = items marked -2 (isolated rows) are passed over
+    const int2*     item_fix;          // per item: {first, count} of its cross-tile fix-ups in fix.ent (null: none attached)
+    FixList         fix;               // what k_pb_finish needs to close the cross-tile segments of an item's rows itself
+    int             do_fix;            // 1 = this launch does them (the step's front kernel left them: k_step_front)
+    int64_t         cold_prefix[9];
+    int64_t         xg_base[8];
+    int             num_blocks, hot, chunk, num_chunks, num_bins;
+    int64_t         num_cold;          // referenced cold sources in total
+};
+
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // slot the loop driver fills (pgh_spmv.hip) and the next blocked-format launch consumes (pgh_bsf.hip)
 PendingClose& pending_close_slot();
 
@@ -374,7 +444,9 @@ int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, co
 template <int MODE>
 int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, const LoopState* state, int* num_partials);
 void pb_destroy(PbFormat& p);
+PbView pb_view_of(const pgh_graph_s* g);       // first slice of the graph's cold image
 int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, int stage = 0);
+int pb_attach_fixlist(BsfFormat& f);     // after the stream's fix_seg / seg_row exist: per-item fix lists of k_pb_finish
 template <int MODE>
 int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* state, int* num_partials);
 template <int MODE>

@@ -42,18 +42,13 @@
 #include <vector>
 
 #include "pgh_kernels.h"
+#include "pgh_pb_gather.h"
 
-// diagnostic builds only (tools/build_variants.sh): 1 no chunk fill, 2 fills only, 4 no stores (phase A); 8 no loads,
-// 16 no atomics (phase B), 32 no epilogue
-#ifndef PGH_PROBE_PB
-#define PGH_PROBE_PB 0
-#endif
 
 namespace pgh {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kPbChunk = 32768;          // sources per chunk: 128 KB of LDS in phase A
 #ifndef PGH_PB_ROWS
 #define PGH_PB_ROWS 4096
 #endif
@@ -91,7 +86,6 @@ constexpr int kPbMaxPieces = 1024;               // at most this many; beyond, i
 // (PGH_PB_HEAVY / PGH_PB_HUBMAX override the first two for tests: small graphs have no such rows)               // a row with more cold entries keeps them in the blocked stream
 constexpr int kPbMaxChunks = 8192;               // 13-bit chunk field of the sort key
 constexpr int kPbMaxBins = 32767;                // 15-bit bin field
-constexpr int kPbThreads = 1024;
 constexpr uint64_t kLow29 = (1ULL << 29) - 1;
 
 template <typename T>
@@ -199,34 +193,6 @@ __global__ void k_pb_place(const uint64_t* __restrict__ keys, const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------- run-time kernels
-struct PbView {
-    const uint16_t* sloc;
-    const float*    val;
-    const uint32_t* dstg;
-    const int4*     task;
-    const int*      task_range;
-    float*          tmp;
-    const int4*     item_a;            // work list of k_pb_finish (PbFormat::item_a / item_b)
-    const int4*     item_b;
-    int             num_items;
-    const int*      sched;             // item order (PbFormat::sched); static deal: slices sched_begin[w] .. sched_begin[w + 1]
-    const int*      sched_begin;
-    uint32_t*       work_counter;      // hand-out of the schedule's tail: next position (null without a tail)
-    int             tail_begin, tail_count;   // sched[tail_begin .. tail_begin + tail_count): handed out dynamically
-    uint32_t*       hub_ticket;
-    const uint16_t* drow;
-    double*         hub_part;          // [num_bins] sums of the pieces of split hub rows
-    uint32_t*       amax;              // [0] bit pattern of max |value| written by phase A, [1] phase B's exit tickets
-    const int*      iso_flag;          // BsfFormat::iso_flag or null: 0 = items marked -2 (isolated rows) are passed over
-    int64_t         cold_prefix[9];
-    int64_t         xg_base[8];
-    int             num_blocks, hot, chunk, num_chunks, num_bins;
-    int64_t         num_cold;          // referenced cold sources in total
-};
-
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 PGH_STAMP_DECL(g_times_gather)
 PGH_STAMP_DECL(g_times_finish)
 #if PGH_PROBE_TIMES
@@ -234,137 +200,17 @@ __device__ unsigned int g_item_ticks[1 << 15];      // per work item of k_pb_fin
 __device__ unsigned int g_item_begin[1 << 15];      // ... and its start relative to the workgroup's start
 #endif
 
-// ---- phase A
+// ---- phase A (body: pgh_pb_gather.h, shared with the merged front kernel of a step in pgh_bsf.hip)
 template <bool HAS_VAL>
 __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float* __restrict__ xg, const LoopState* __restrict__ state,
                                                           FixView fix) {
-    __shared__ float s_x[kPbChunk];
-    __shared__ uint32_t s_amax;
+    __shared__ float s_x[kPbChunk + 1];
     if (state != nullptr && state->done) return;
     PGH_STAMP_BEGIN(g_times_gather)
-    if (threadIdx.x == 0) s_amax = 0u;
     // the cross-tile fix-ups of the blocked stream ride along (one launch and one dependent boundary fewer per step):
     // they touch nothing this kernel reads, and the next kernel (k_pb_finish) is the first to read their results
     bsf_fixup_tiles(fix, blockIdx.x * kPbThreads, gridDim.x * kPbThreads);
-    uint32_t amax = 0u;                 // bit pattern of max |value| this thread wrote (NaN > inf > finite as integers)
-    // this workgroup's share of the entry stream: consecutive pieces, each inside one chunk; the LDS image of the chunk
-    // is refilled only when the chunk changes
-    const int piece_begin = f.task_range[blockIdx.x], piece_end = f.task_range[blockIdx.x + 1];
-    int loaded = -1;
-    for (int piece = piece_begin; piece < piece_end; ++piece) {
-        const int4 task = f.task[piece];
-        if (task.x != loaded && !(PGH_PROBE_PB & 1)) {
-            __syncthreads();
-            // cold ids [first_id, first_id + chunk) -> positions in the gather vector, block by block: the block loop is
-            // unrolled so that the layout tables are read with constant indices (scalar loads), and a thread keeps 8
-            // independent loads in flight
-            const int64_t first_id = (int64_t)task.x * f.chunk;
-            const int64_t last_id = min(first_id + f.chunk, f.num_cold);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                if (b >= f.num_blocks) continue;
-                const int64_t lo = max(first_id, f.cold_prefix[b]), hi = min(last_id, f.cold_prefix[b + 1]);
-                if (lo >= hi) continue;                     // wavefront-uniform
-                const float* __restrict__ src = xg + f.xg_base[b] + f.hot - f.cold_prefix[b];      // src[id] = value of cold id
-                // rounds of 8 loads per thread (the whole chunk in one round of 32 was measured: 7 us SLOWER per launch; 16-byte
-                // loads from the first aligned element on -- one round of 8 per chunk -- no different: 77.6 vs 78.0 us, the fills
-                // of one share hide behind the streams of the others)
-                constexpr int FU = 8;
-                for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kPbThreads * FU) {
-                    float v[FU];
-#pragma unroll
-                    for (int u = 0; u < FU; ++u) {
-                        const int64_t id = i0 + (int64_t)u * kPbThreads;
-                        v[u] = src[min(id, hi - 1)];
-                    }
-#pragma unroll
-                    for (int u = 0; u < FU; ++u) {
-                        const int64_t id = i0 + (int64_t)u * kPbThreads;
-                        if (id < hi) s_x[id - first_id] = v[u];
-                    }
-                }
-            }
-            __syncthreads();
-            loaded = task.x;
-        }
-        // every lane takes one group of 8 consecutive entries (pieces are whole groups): one 16-byte load of source
-        // indices, one 4-byte load of the group's place in B order, two 16-byte stores of values
-        const int64_t body_begin = task.y, body_end = task.z;
-        // Software pipeline over rounds of P groups per lane: the loads of round i + 1 are issued BEFORE the gathers and
-        // stores of round i.  vmcnt counts loads and stores in one in-order queue, so a loop that loads, gathers, stores
-        // and only then loads again makes every round wait for the previous round's stores to complete (measured:
-        // reads alone 40 us, with the stores 80 us -- no overlap at all).
-        constexpr int P = HAS_VAL ? 2 : 4;
-        if (PGH_PROBE_PB & 2) continue;
-        struct Round {
-            u16x8    s8[P];
-            uint32_t to[P];
-            f32x4    w0[HAS_VAL ? P : 1], w1[HAS_VAL ? P : 1];
-        };
-        const int64_t step = (int64_t)kPbThreads * 8 * P;
-        auto fetch = [&](Round& r, int64_t e0) __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                const int64_t e = e0 + (int64_t)q * kPbThreads * 8;
-                const bool ok = e < body_end;
-                r.s8[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(f.sloc + e)) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                r.to[q] = ok ? __builtin_nontemporal_load(f.dstg + (e >> 3)) : 0u;
-                if (HAS_VAL) {
-                    r.w0[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(f.val + e)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    r.w1[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(f.val + e + 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        };
-        auto emit = [&](const Round& r, int64_t e0) __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                const int64_t e = e0 + (int64_t)q * kPbThreads * 8;
-                if (e >= body_end) continue;
-                f32x4 lo, hi;
-                lo.x = s_x[r.s8[q][0]];
-                lo.y = s_x[r.s8[q][1]];
-                lo.z = s_x[r.s8[q][2]];
-                lo.w = s_x[r.s8[q][3]];
-                hi.x = s_x[r.s8[q][4]];
-                hi.y = s_x[r.s8[q][5]];
-                hi.z = s_x[r.s8[q][6]];
-                hi.w = s_x[r.s8[q][7]];
-                if (HAS_VAL) {
-                    lo *= r.w0[q];
-                    hi *= r.w1[q];
-                }
-                if (PGH_PROBE_PB & 4) {
-                    if (lo.x + hi.w == 123.456f) f.tmp[e] = lo.y;
-                    continue;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    amax = max(amax, max(__float_as_uint(lo[k]) & 0x7fffffffu, __float_as_uint(hi[k]) & 0x7fffffffu));
-                float* __restrict__ dst = (PGH_PROBE_PB & 64) ? f.tmp + e : f.tmp + (int64_t)r.to[q] * 8;   // 64: diagnostic, sequential stores
-                *reinterpret_cast<f32x4*>(dst) = lo;
-                *reinterpret_cast<f32x4*>(dst + 4) = hi;
-            }
-        };
-        Round r0, r1;
-        int64_t e0 = body_begin + (int64_t)threadIdx.x * 8;
-        fetch(r0, e0);
-        while (e0 < body_end) {
-            fetch(r1, e0 + step);
-            emit(r0, e0);
-            e0 += step;
-            if (e0 >= body_end) break;
-            fetch(r0, e0 + step);
-            emit(r1, e0);
-            e0 += step;
-        }
-    }
-    // max |value| of this launch: wavefront -> workgroup -> one global atomic
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, d, 64));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0 && amax != 0u) atomicMax(&s_amax, amax);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_amax != 0u) atomicMax(f.amax, s_amax);
+    pb_gather_body<HAS_VAL>(s_x, reinterpret_cast<uint32_t*>(s_x + kPbChunk), f, xg, blockIdx.x);
     PGH_STAMP_END(g_times_gather)
 }
 
@@ -502,6 +348,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         item = take_tail();
     }
     int4 bin = make_int4(0, 0, 0, 0), epi = make_int4(0, 0, -1, 0);
+    int2 fx = make_int2(0, 0);              // the item's cross-tile fix-ups (f.do_fix)
+    const bool do_fix = f.do_fix != 0;
     Round R;
     // items marked -2 cover isolated rows (no entry, referenced by nobody): unless this run's operands are non-zero there
     // they hold zeros in both iterates and are passed over (the item shrinks to no rows: barriers only)
@@ -509,6 +357,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     if (item >= 0) {
         bin = f.item_a[item];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
         epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1 (-2: isolated rows), first item of the split row}
+        if (do_fix) fx = f.item_fix[item];
         fetch(bin, 0, R);
     }
 #if PGH_PROBE_TIMES
@@ -538,6 +387,10 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0x1f;
         const bool hub = ((bin.y >> 21) & 1) != 0;
         const int pieces = (int)((unsigned)bin.y >> 22) + 1;
+        // the segments of this item's rows that span tiles of the blocked stream are closed here when the step's front kernel
+        // left that to this launch: psum slots nobody else touches, read by this workgroup's epilogue after the barriers below
+        // (a hub row: by whoever runs its epilogue, further down)
+        if (do_fix && !hub) bsf_fixup_list(f.fix, fx.x, fx.y, THREADS);
         const int E = min(51, 62 - count_bits);
         const double S = __longlong_as_double((long long)(1023 + E - e) << 52);
         const double inv_S = __longlong_as_double((long long)(1023 - E + e) << 52);
@@ -593,9 +446,11 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             next = take_tail();
         }
         int4 next_bin = make_int4(0, 0, 0, 0), next_epi = make_int4(0, 0, -1, 0);
+        int2 next_fx = make_int2(0, 0);
         if (next >= 0) {
             next_bin = f.item_a[next];
             next_epi = f.item_b[next];
+            if (do_fix) next_fx = f.item_fix[next];
 
             if (PGH_FIN_PREFETCH) fetch(next_bin, 0, R);
         }
@@ -642,6 +497,10 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                     s_hub = (float)total;
                     (void)atomicExch(f.hub_ticket + epi.z, 0u);       // re-arm for the next launch
                 }
+                __syncthreads();
+            }
+            if (do_fix && s_last) {                        // workgroup-uniform: the row's cross-tile segments first
+                bsf_fixup_list(f.fix, fx.x, fx.y, THREADS);
                 __syncthreads();
             }
             if (s_last && tid == 0) {                      // the row's epilogue (one row: the direct lookup)
@@ -721,6 +580,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         item = next;
         bin = next_bin;
         epi = next_epi;
+        fx = next_fx;
     }
     if (!flushed_head) flush(blockIdx.x);
     // the last workgroup to leave re-arms the words for the next launch (every workgroup has read amax long before its
@@ -753,6 +613,12 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.drow = p.drow;
     v.amax = p.amax;
     v.iso_flag = f.iso_flag;
+    v.item_fix = p.item_fix;
+    v.fix.ent = p.fix_ent;
+    v.fix.tail_carry = f.tail_carry;
+    v.fix.head_partial = f.head_partial;
+    v.fix.psum = f.psum;
+    v.do_fix = 0;
     v.hub_part = p.hub_part;
     for (int i = 0; i < 9; ++i) v.cold_prefix[i] = p.cold_prefix[i];
     for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base[i];
@@ -766,6 +632,8 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
 }
 
 }  // namespace
+
+PbView pb_view_of(const pgh_graph_s* g) { return pb_view(g->bsf, g->bsf.pb); }
 
 // Decides whether the cold tail gets its own image and, if so, lays out the bins.  keys: the sorted stream
 // (block << 58 | row << 29 | col), is_hot: 1 = stays in the stream; on success entries of rows too heavy for a bin are
@@ -1210,6 +1078,74 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     return 0;
 }
 
+// Per-item lists of the blocked stream's cross-tile fix-ups (called by bsf_build once fix_seg and seg_row exist): the
+// closing tiles sorted by the row their segment belongs to; every work item of k_pb_finish gets the range of its rows.
+namespace {
+__global__ void k_pb_fix_keys(const int32_t* __restrict__ fix_seg, const int32_t* __restrict__ seg_row, int num_tiles,
+                              uint64_t* __restrict__ keys) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < num_tiles; t += gridDim.x * blockDim.x) {
+        const int seg = fix_seg[t];
+        keys[t] = seg >= 0 ? ((uint64_t)(uint32_t)seg_row[seg] << 32) | (uint32_t)t : ~0ULL;
+    }
+}
+__global__ void k_pb_fix_entries(const uint64_t* __restrict__ keys, int num_tiles, const int32_t* __restrict__ fix_seg,
+                                 const int4* __restrict__ tile, int4* __restrict__ ent) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_tiles; i += gridDim.x * blockDim.x) {
+        const uint64_t k = keys[i];
+        if (k == ~0ULL) {
+            ent[i] = make_int4(0, -1, 0, -1);
+            continue;
+        }
+        const int t = (int)(uint32_t)k;
+        ent[i] = make_int4(t, fix_seg[t], tile[t].w, (int)(k >> 32));
+    }
+}
+// first position whose row is >= `row` (valid keys sort first: rows are below 2^31, the filler is ~0)
+__device__ __forceinline__ int fix_lower_bound(const uint64_t* __restrict__ keys, int count, int64_t row) {
+    int lo = 0, hi = count;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint64_t k = keys[mid];
+        const int64_t r = k == ~0ULL ? (int64_t)1 << 40 : (int64_t)(k >> 32);
+        if (r < row) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__global__ void k_pb_item_fix(const uint64_t* __restrict__ keys, int num_tiles, const int4* __restrict__ item_b, int num_items,
+                              int2* __restrict__ item_fix) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_items; i += gridDim.x * blockDim.x) {
+        const int4 e = item_b[i];
+        const int lo = fix_lower_bound(keys, num_tiles, (int64_t)e.x), hi = fix_lower_bound(keys, num_tiles, (int64_t)e.x + e.y);
+        item_fix[i] = make_int2(lo, hi - lo);
+    }
+}
+}  // namespace
+
+int pb_attach_fixlist(BsfFormat& f) {
+    PbFormat& p = f.pb;
+    if (!p.enabled || p.num_items <= 0 || f.fix_seg == nullptr || f.seg_row == nullptr || f.num_tiles <= 0) return 0;
+    Runtime& r = rt();
+    PbBuf<uint64_t> keys, sorted;
+    PGH_TRY(keys.alloc((size_t)f.num_tiles));
+    PGH_TRY(sorted.alloc((size_t)f.num_tiles));
+    k_pb_fix_keys<<<pb_blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.fix_seg, f.seg_row, f.num_tiles, keys.p);
+    size_t temp_bytes = 0;
+    PGH_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys.p, sorted.p, f.num_tiles, 0, 64, r.stream));
+    PbBuf<char> temp;
+    PGH_TRY(temp.alloc(temp_bytes));
+    PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys.p, sorted.p, f.num_tiles, 0, 64, r.stream));
+    PGH_HIP(hipMalloc(&p.fix_ent, sizeof(int4) * (size_t)(f.num_tiles + 1)));
+    PGH_HIP(hipMalloc(&p.item_fix, sizeof(int2) * (size_t)(p.num_items + 1)));
+    k_pb_fix_entries<<<pb_blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(sorted.p, f.num_tiles, f.fix_seg, f.tile, p.fix_ent);
+    k_pb_item_fix<<<pb_blocks_for(p.num_items), kBlock, 0, r.stream>>>(sorted.p, f.num_tiles, p.item_b, p.num_items, p.item_fix);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    p.num_fix = f.num_tiles;
+    p.device_bytes += (int64_t)f.num_tiles * 16 + (int64_t)p.num_items * 8;
+    return 0;
+}
+
 void pb_plan_release(PbPlan* plan) {
     (void)hipFree(plan->row_bin);
     delete[] plan->host_bins;
@@ -1278,7 +1214,12 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
     const BsfFormat& f = g->bsf;
     const PbFormat& p = f.pb;
     Runtime& r = rt();
-    const PbView v = pb_view(f, p);
+    PbView v = pb_view(f, p);
+    if (f.fix_pending) {                               // the front kernel of this step left the cross-tile fix-ups to this launch
+        PGH_CHECK(p.item_fix != nullptr, "propagation blocking: no fix lists attached to the work items");
+        v.do_fix = 1;
+        g->bsf.fix_pending = false;
+    }
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
     const bool large = p.bin_rows > kPbBinRows;
@@ -1340,6 +1281,8 @@ void pb_destroy(PbFormat& p) {
     (void)hipFree(p.sched);
     (void)hipFree(p.sched_begin);
     (void)hipFree(p.work_counter);
+    (void)hipFree(p.fix_ent);
+    (void)hipFree(p.item_fix);
     (void)hipFree(p.bin);
     (void)hipFree(p.drow);
     p = PbFormat();
