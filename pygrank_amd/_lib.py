@@ -31,7 +31,7 @@ class LoopCfg(C.Structure):
 
 class LoopResult(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("spmv_count", C.c_int32),
-                ("reserved", C.c_int32), ("last_error", C.c_double), ("loop_ms", C.c_double)]
+                ("flags", C.c_int32), ("last_error", C.c_double), ("loop_ms", C.c_double)]
 
 
 # name -> (restype, argtypes); every symbol include/pgh.h declares

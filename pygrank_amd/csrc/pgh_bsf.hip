@@ -1182,6 +1182,23 @@ int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int) 
 }
 
 // output-side vector: original -> internal
+// row sums of M (pgh_graph_s::degrees, caller ids) in the internal id space of a square relabelled graph
+int bsf_ensure_degrees(pgh_graph_s* g) {
+    BsfFormat& f = g->bsf;
+    if (f.deg_int != nullptr) return 0;
+    PGH_CHECK(g->n_rows == g->n_cols && g->degrees != nullptr, "internal-space degrees need a square graph");
+    float* d = nullptr;
+    PGH_HIP(hipMalloc(&d, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1)));
+    const int rc = bsf_out_to_internal(g, g->degrees, d, 0.f);
+    if (rc != 0) {
+        (void)hipFree(d);
+        return rc;
+    }
+    f.deg_int = d;
+    f.device_bytes += (int64_t)f.n_out * 4;
+    return 0;
+}
+
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole) {
     BsfFormat& f = g->bsf;
     k_permute_in<<<blocks_for(f.n_out), kBlock, 0, rt().stream>>>(src, f.relabelled ? f.perm : nullptr, nullptr, f.n_out,
@@ -1212,6 +1229,7 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.colf16);
     (void)hipFree(f.iperm);
     (void)hipFree(f.flags8);
+    (void)hipFree(f.deg_int);
     (void)hipFree(f.fix_seg);
     (void)hipFree(f.psum);
     (void)hipFree(f.meta);

@@ -43,7 +43,7 @@ struct Runtime {
     hipStream_t stream = nullptr;        // the stream every kernel is launched on
     int         num_cus = 256;
     // scratch for reductions: device partials + pinned host mirror for scalar results
-    double*     d_partials = nullptr;    // [kMaxPartials * 2]
+    double*     d_partials = nullptr;    // [kMaxPartials * kPartialRegions]
     double*     d_scalars = nullptr;     // [kNumScalars]
     double*     h_scalars = nullptr;     // pinned
     // profiling
@@ -95,6 +95,7 @@ void pool_trim();
 #define PGH_PROBE_SKIP 0
 #endif
 constexpr int kMaxPartials = 4096;   // upper bound on workgroups contributing block partials
+constexpr int kPartialRegions = 6;   // Runtime::d_partials: sums, deltas / residuals, and the fused residual's R, D, T (+ spare)
 constexpr int kNumScalars = 64;
 
 // RAII-less helper: time one launch with events when profiling is on.
@@ -230,6 +231,7 @@ struct BsfFormat {
     int32_t*  iperm = nullptr;      // [n_src] old id -> new id (square relabelled graphs: results leave by a gather)
     float*    src_scale = nullptr;  // [n_src_pad + 1] new space, or null
     float*    dst_scale = nullptr;  // [n_out] new space, or null
+    float*    deg_int = nullptr;    // [n_out] row sums of M in the internal id space (square graphs; bsf_ensure_degrees, lazily)
     // square relabelled graphs: isolated ids (never referenced, empty row) sort last, slots [iso_begin[b], blk_size) of block b
     bool      has_iso = false;
     int       iso_begin[8] = {0};

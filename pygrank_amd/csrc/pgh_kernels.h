@@ -50,6 +50,36 @@ struct LoopState {
     int    pad;
 };
 
+// Residual of a PageRank step INSIDE the finish kernel (k_pb_finish<..., RES>; L1 / Mabs rules).  The residual
+// sum_i |y_i * inv - x_i * scale| needs inv = 1 / sum(y) of the step that is being written, which is only known when the
+// kernel ends -- but it can be PREDICTED: sum(y) = a * scale * sum_j deg_j * x_j + b * sum(p) with deg = the row sums of M
+// (column sums of M^T), up to the f32 roundings of the step (a relative 1e-8: the stored degrees and the products the
+// kernels form round differently), and that bias barely moves from one step to the next, so the prediction is multiplied
+// by the ratio measured / predicted of the previous step: it then misses by 1e-10 .. 1e-12.  The kernel evaluates
+//     R' = sum_i |y_i * inv' - x_i * scale|   and   D = sum_i sign(y_i * inv' - x_i * scale) * y_i
+// against the predicted inv', and the close takes  R = R' + (inv - inv') * D : exact but for rows whose term changes sign
+// between inv' and inv, each wrong by less than 2 |inv - inv'| y_i -- in total less than 2 |inv - inv'| sum(y).  The close
+// therefore knows the residual to within that bound; when the tolerance lies inside it (or anything is not finite) the
+// step is PAUSED: the host re-evaluates it with the separate residual kernel and goes on without the fusion.  The stopping
+// decision is the one the separate kernel would take, always.  The kernel also accumulates T = sum_j deg_j * y_j for the
+// next prediction; the first step of a run has no prediction: it accumulates sum(p) in D's place and uses the separate kernel.
+struct LoopAux {
+    double pred_inv[2];   // predicted 1 / sum(y) of step k at [k & 1]
+    double pred_raw[2];   // the uncorrected prediction of sum(y) of step k at [k & 1] (0: none)
+    double sum_p;         // sum of the (normalised) personalization
+    double worst_miss;    // largest |inv - inv'| / |inv| seen by a checking close of this run (diagnostic)
+};
+struct ResParams {
+    const float*   x_prev;   // previous iterate (internal ids, un-normalised; its quotient is LoopState::scale)
+    const float*   deg;      // row sums of M in internal ids
+    const LoopAux* aux;
+    double*        part_r;   // per-workgroup / per-tail-item partials, like partial_sum
+    double*        part_d;
+    double*        part_t;
+    int            step;     // k
+    int            first;    // 1: no prediction yet (D accumulates sum(p), R is not used)
+};
+
 // The close of a step (k_step_close: fold the partials, update the loop state, evaluate the stopping rule) can be
 // DEFERRED into the first kernel of the next step: every workgroup of that kernel folds the same partials in the same
 // order (so they all reach the same verdict, and the same bits as k_step_close), workgroup 0 writes the state.  One
@@ -64,6 +94,15 @@ struct PendingClose {
     int           num_sum, num_res;
     int           use_quotient, check, err_kind;
     int           active;
+    // fused residual (ResParams): 0 = off, 1 = the finish kernel evaluated the residual against the predicted quotient,
+    // 2 = first step of such a run (residual from the separate kernel; sum(p) arrives in part_d)
+    int           res_mode;
+    int           step;
+    LoopAux*      aux;
+    const double* part_r;
+    const double* part_d;
+    const double* part_t;
+    double        a, b;           // the step is y = a * scale * (M^T x) + b * p
 };
 
 // The isolated tail of every column block of a square relabelled graph (BsfFormat::iso_begin): rows without entries that
@@ -353,36 +392,131 @@ __device__ __forceinline__ double fold_partials_wide(const double* __restrict__ 
     return r;
 }
 
-// the deferred close (see PendingClose); returns true when the loop has ended, i.e. the calling kernel must do nothing
-__device__ __forceinline__ bool run_pending_close(const PendingClose& pc, double* s4) {
-    const double S = fold_partials_wide(pc.partial_sum, pc.num_sum, 0, s4);
-    double err = 0.0;
-    if (pc.check) {
-        __syncthreads();
-        err = fold_partials_wide(pc.res_partials, pc.num_res, pc.err_kind == PGH_ERR_LINF, s4);
-        if (pc.err_kind == PGH_ERR_MABS) err /= (double)pc.n;
-    }
-    const bool done = pc.check && err <= pc.tol;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        LoopState* state = pc.state;
-        state->sum = S;
-        state->scale = pc.use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
-        const int steps = state->steps + 1;
-        state->steps = steps;
-        if (pc.check) {
-            state->err = err;
-            if (done) {
-                state->done = 1;
-                state->converged = 1;
-            }
+// K arrays of `count` partials folded at once (sums), same order as fold_partials_wide: one barrier pair for all of them.
+// s: LDS scratch of 4 * K doubles.
+template <int K>
+__device__ __forceinline__ void fold_partials_multi(const double* const (&arr)[K], int count, double (&out)[K], double* s) {
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    if (threadIdx.x < 256) {
+        for (int i = threadIdx.x; i < count; i += 256) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += arr[k][i];
         }
-        if (pc.progress != nullptr) {
-            __hip_atomic_store(pc.progress + 1, done ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(pc.progress, steps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = wave_reduce_sum(acc[k]);
     }
     __syncthreads();
-    return done;
+    if (threadIdx.x < 256 && (threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) s[k * 4 + (threadIdx.x >> 6)] = acc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = ((s[k * 4] + s[k * 4 + 1]) + s[k * 4 + 2]) + s[k * 4 + 3];
+}
+
+// What a close decides, from the folded partials (shared by k_step_close and the deferred close so that both produce the
+// same bits).  verdict: 0 = go on, 1 = converged, 2 = paused (fused residual: the quotient's prediction missed, kPredGuard).
+struct CloseOutcome {
+    double S, scale, err, next_pred, next_raw, sum_p, miss;
+    int    verdict;
+};
+__device__ __forceinline__ CloseOutcome close_outcome(const PendingClose& pc, double S, double err_plain, double R, double D, double T) {
+    CloseOutcome o;
+    o.S = S;
+    o.scale = pc.use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+    o.err = err_plain;
+    o.miss = 0.0;
+    o.verdict = 0;
+    o.sum_p = 0.0;
+    o.next_pred = 1.0;
+    o.next_raw = 0.0;
+    double slack = 0.0;                  // the residual is known to within this (fused residual)
+    if (pc.res_mode != 0) {
+        o.sum_p = pc.res_mode == 2 ? D : pc.aux->sum_p;
+        if (pc.use_quotient) {
+            // with the factors as the epilogue forms them: a_eff = (float)(a * scale), (float)b (epi_apply)
+            o.next_raw = (double)(float)(pc.a * o.scale) * T + (double)(float)pc.b * o.sum_p;
+            const double raw_now = pc.aux->pred_raw[pc.step & 1];
+            const double ratio = (pc.res_mode == 1 && raw_now != 0.0) ? S / raw_now : 1.0;
+            const double S_next = o.next_raw * (ratio == ratio && fabs(ratio - 1.0) < 1e-4 ? ratio : 1.0);
+            o.next_pred = S_next != 0.0 ? 1.0 / S_next : 0.0;
+        }
+        if (pc.res_mode == 1 && pc.check) {
+            const double ip = pc.aux->pred_inv[pc.step & 1];
+            o.err = R + (o.scale - ip) * D;
+            o.miss = fabs(o.scale - ip) / fmax(fabs(o.scale), 1e-300);
+            slack = 2.0 * fabs(o.scale - ip) * fabs(S);
+        }
+    }
+    if (pc.check) {
+        if (pc.err_kind == PGH_ERR_MABS) {
+            o.err /= (double)pc.n;
+            slack /= (double)pc.n;
+        }
+        if (pc.res_mode == 1 && !(fabs(o.err - pc.tol) > 2.0 * slack)) o.verdict = 2;      // too close to call (or not finite)
+        else if (o.err <= pc.tol) o.verdict = 1;
+    }
+    return o;
+}
+// the state update of a close (one thread)
+__device__ __forceinline__ void close_commit(const PendingClose& pc, const CloseOutcome& o) {
+    LoopState* state = pc.state;
+    if (o.verdict == 2) {                // paused: the step stays open, the host re-evaluates it
+        state->done = 2;
+        if (o.miss > pc.aux->worst_miss) pc.aux->worst_miss = o.miss;
+        if (pc.progress != nullptr) __hip_atomic_store(pc.progress + 1, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    state->sum = o.S;
+    state->scale = o.scale;
+    const int steps = state->steps + 1;
+    state->steps = steps;
+    if (pc.res_mode != 0) {
+        pc.aux->pred_inv[(pc.step + 1) & 1] = o.next_pred;
+        pc.aux->pred_raw[(pc.step + 1) & 1] = o.next_raw;
+        if (pc.res_mode == 2) pc.aux->sum_p = o.sum_p;
+        if (o.miss > pc.aux->worst_miss) pc.aux->worst_miss = o.miss;
+    }
+    if (pc.check) {
+        state->err = o.err;
+        if (o.verdict == 1) {
+            state->done = 1;
+            state->converged = 1;
+        }
+    }
+    if (pc.progress != nullptr) {        // host-visible progress word (pinned, mapped): lets the host run ahead without syncs
+        __hip_atomic_store(pc.progress + 1, o.verdict == 1 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(pc.progress, steps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// the deferred close (see PendingClose); returns true when the loop has ended or paused, i.e. the calling kernel must do
+// nothing.  s: LDS scratch of 16 doubles.
+__device__ __forceinline__ bool run_pending_close(const PendingClose& pc, double* s) {
+    double S, err = 0.0, R = 0.0, D = 0.0, T = 0.0;
+    if (pc.res_mode == 0) {
+        S = fold_partials_wide(pc.partial_sum, pc.num_sum, 0, s);
+        if (pc.check) {
+            __syncthreads();
+            err = fold_partials_wide(pc.res_partials, pc.num_res, pc.err_kind == PGH_ERR_LINF, s);
+        }
+    } else {
+        const double* const arr[4] = {pc.partial_sum, pc.part_t, pc.part_d, pc.part_r};
+        double out[4];
+        fold_partials_multi<4>(arr, pc.num_sum, out, s);
+        S = out[0], T = out[1], D = out[2], R = out[3];
+        if (pc.res_mode == 2 && pc.check) {
+            __syncthreads();
+            err = fold_partials_wide(pc.res_partials, pc.num_res, 0, s);
+        }
+    }
+    const CloseOutcome o = close_outcome(pc, S, err, R, D, T);
+    if (blockIdx.x == 0 && threadIdx.x == 0) close_commit(pc, o);
+    __syncthreads();
+    return o.verdict != 0;
 }
 
 // device view of the propagation-blocking image (PbFormat, pgh_pb.hip)
@@ -446,6 +580,8 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
 void pb_destroy(PbFormat& p);
 PbView pb_view_of(const pgh_graph_s* g);       // first slice of the graph's cold image
 int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, int stage = 0);
+void pb_set_residual(const ResParams* rp);   // the next pb_launch_finish<EPI_AXPBY> evaluates the residual in the kernel (ResParams)
+int bsf_ensure_degrees(pgh_graph_s* g);       // BsfFormat::deg_int
 int pb_attach_fixlist(BsfFormat& f);     // after the stream's fix_seg / seg_row exist: per-item fix lists of k_pb_finish
 template <int MODE>
 int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* state, int* num_partials);

@@ -228,22 +228,26 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
 // summed in f64 registers and reduced in a fixed order.  A row split into pieces: every piece publishes its sum with a
 // device-scope atomic and takes a ticket; the last arriver adds the pieces in index order (deterministic whatever the
 // arrival order) and runs the row's epilogue.
-template <int MODE, int NB, int ROWS, int THREADS>
+// RES (PageRank epilogue only): the step's residual is evaluated here as well, against the predicted quotient (ResParams,
+// pgh_kernels.h) -- two more operands per row (the previous iterate, the row sum of M), three more partial sums.
+template <int MODE, int NB, int ROWS, int THREADS, bool RES = false>
 __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb_finish(PbView f, RowSums rs, const float* __restrict__ dst_scale, EpiParams ep,
                                                         const LoopState* __restrict__ state, double* __restrict__ partial_sum,
-                                                        double* __restrict__ partial_delta) {
+                                                        double* __restrict__ partial_delta, ResParams rp) {
+    static_assert(!RES || MODE == EPI_AXPBY, "the in-kernel residual is PageRank's");
     constexpr int WAVES = THREADS / 64;
     // groups per thread and stream round in flight (three 16-byte loads each), rows per thread and epilogue round.  Both
     // shapes keep 16 wavefronts per CU (128 registers): 4 workgroups of 256 threads (32 KB of row sums each) or one of
     // 1024; what covers the latencies an item exposes (stream, atomics, epilogue rounds) is the depth of each round plus
     // the other workgroups of the CU.
     constexpr int P = THREADS > 512 ? 2 : PGH_FIN_P;
-    constexpr int G = (THREADS > 512 || NB > 4) ? 2 : PGH_FIN_G;
+    // (with the in-kernel residual: two more operands per row -- 2 rows in flight measured 108 us, 3: 112-114, 4: 119)
+    constexpr int G = (THREADS > 512 || NB > 4 || RES) ? 2 : PGH_FIN_G;
     constexpr int WORDS = ROWS / 64 + 1;                   // map words an item can touch per block (unaligned first row)
     __shared__ unsigned long long s_row[ROWS];
     __shared__ unsigned long long s_mask[NB * WORDS];      // the item's slice of the row -> segment map (BsfFormat::meta)
     __shared__ int s_base[NB * WORDS];
-    __shared__ double s_red[WAVES];
+    __shared__ double s_red[RES ? 4 * WAVES : WAVES];
     __shared__ float s_hub;
     __shared__ int s_last;
     double scale = 1.0;
@@ -260,6 +264,20 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     const int e = (int)(amax >> 23) - 126;                 // amax < 2^e (denormals: e = -126, still an upper bound)
     constexpr double kMagic = 6755399441055744.0;          // 1.5 * 2^52: fma(v, S, magic) holds round(v * S) in its low bits
     double sum_y = 0.0, delta = 0.0;
+    // in-kernel residual: R' and D against the predicted quotient, T for the next prediction (first step: sum(p) in D)
+    double res_r = 0.0, res_d = 0.0, res_t = 0.0;
+    const double inv_pred = RES && !rp.first ? rp.aux->pred_inv[rp.step & 1] : 1.0;
+    const bool res_first = RES && rp.first != 0;
+    auto residual_row = [&](float y, float x_prev, float deg, float pv) __attribute__((always_inline)) {
+        res_t += (double)deg * (double)y;
+        if (res_first) {
+            res_d += (double)pv;
+        } else {
+            const double d = (double)y * inv_pred - (double)x_prev * scale;
+            res_r += fabs(d);
+            res_d += d < 0.0 ? -(double)y : (double)y;
+        }
+    };
 
     struct Round {
         u16x8 r8[P];
@@ -291,6 +309,26 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     // partials of sum(y) (and delta) accumulated since the last flush -> slot `where`: wavefront shuffle, then a fixed-order
     // sum over the wavefronts; the accumulators start over
     auto flush = [&](int where) __attribute__((always_inline)) {
+        if (RES) {
+            // four sums at once: one barrier pair
+            const double v0 = wave_reduce_sum(sum_y), v1 = wave_reduce_sum(res_r), v2 = wave_reduce_sum(res_d), v3 = wave_reduce_sum(res_t);
+            if ((tid & 63) == 0) {
+                s_red[tid >> 6] = v0;
+                s_red[WAVES + (tid >> 6)] = v1;
+                s_red[2 * WAVES + (tid >> 6)] = v2;
+                s_red[3 * WAVES + (tid >> 6)] = v3;
+            }
+            __syncthreads();
+            if (tid < 4) {
+                double total = 0.0;
+                for (int w = 0; w < WAVES; ++w) total += s_red[tid * WAVES + w];
+                double* out = tid == 0 ? partial_sum : (tid == 1 ? rp.part_r : (tid == 2 ? rp.part_d : rp.part_t));
+                out[where] = total;
+            }
+            __syncthreads();
+            sum_y = 0.0, res_r = 0.0, res_d = 0.0, res_t = 0.0;
+            return;
+        }
         double v = wave_reduce_sum(sum_y);
         if ((tid & 63) == 0) s_red[tid >> 6] = v;
         __syncthreads();
@@ -375,11 +413,22 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                 const int row_end = epi.x + epi.y;
                 for (int row0 = epi.x + tid; row0 < row_end; row0 += THREADS * UI) {
                     EpiOps ops[UI];
+                    float xp[UI], dg[UI];
 #pragma unroll
-                    for (int u = 0; u < UI; ++u) ops[u] = epi_load<MODE>(ep, min(row0 + u * THREADS, row_end - 1));
+                    for (int u = 0; u < UI; ++u) {
+                        const int row = min(row0 + u * THREADS, row_end - 1);
+                        ops[u] = epi_load<MODE>(ep, row);
+                        if (RES) {
+                            xp[u] = ld_off(rp.x_prev, (uint32_t)row << 2);
+                            dg[u] = ld_off(rp.deg, (uint32_t)row << 2);
+                        }
+                    }
 #pragma unroll
                     for (int u = 0; u < UI; ++u)
-                        if (row0 + u * THREADS < row_end) epi_apply<MODE>(ep, ops[u], a_eff, row0 + u * THREADS, 0.f, sum_y, delta);
+                        if (row0 + u * THREADS < row_end) {
+                            const float y = epi_apply<MODE>(ep, ops[u], a_eff, row0 + u * THREADS, 0.f, sum_y, delta);
+                            if (RES) residual_row(y, xp[u], dg[u], ops[u].v);
+                        }
                 }
             }
             epi.y = 0;
@@ -507,7 +556,9 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                 const int64_t row = epi.x;
                 double sum = block_row_sum<NB>(rs, row) + (double)s_hub;
                 if (dst_scale != nullptr) sum *= (double)dst_scale[row];
-                apply_epilogue<MODE>(ep, a_eff, (int)row, (float)sum, sum_y, delta);
+                const EpiOps ops = epi_load<MODE>(ep, (int)row);
+                const float y = epi_apply<MODE>(ep, ops, a_eff, (int)row, (float)sum, sum_y, delta);
+                if (RES) residual_row(y, rp.x_prev[row], rp.deg[row], ops.v);
             }
         } else {
             __syncthreads();
@@ -526,6 +577,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             for (int g0 = (row_lo >> 6) + wave; g0 <= g_hi; g0 += WAVES * G) {
                 EpiOps ops[G];
                 float dsc[G];
+                float xp[RES ? G : 1], dg[RES ? G : 1];
                 float vals[G][NB];
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
@@ -545,6 +597,10 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                     }
                     ops[u] = epi_load<MODE>(ep, row);
                     dsc[u] = dst_scale != nullptr ? ld_off(dst_scale, (uint32_t)row << 2) : 1.f;
+                    if (RES) {
+                        xp[u] = ld_off(rp.x_prev, (uint32_t)row << 2);
+                        dg[u] = ld_off(rp.deg, (uint32_t)row << 2);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
@@ -559,7 +615,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                     for (int b = 0; b < NB; ++b) sum += (double)vals[u][b];      // blocks past num_blocks contribute 0
                     sum += (double)cold;
                     if (dst_scale != nullptr) sum *= (double)dsc[u];
-                    epi_apply<MODE>(ep, ops[u], a_eff, row, (float)sum, sum_y, delta);
+                    const float y = epi_apply<MODE>(ep, ops[u], a_eff, row, (float)sum, sum_y, delta);
+                    if (RES) residual_row(y, xp[u], dg[u], ops[u].v);
                 }
             }
         }
@@ -1208,6 +1265,16 @@ int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, co
     return 0;
 }
 
+// the in-kernel residual of the next PageRank finish launch (pb_set_residual; the loop driver sets it per step)
+namespace {
+ResParams g_residual = {};
+bool      g_residual_set = false;
+}  // namespace
+void pb_set_residual(const ResParams* rp) {
+    g_residual_set = rp != nullptr;
+    if (rp != nullptr) g_residual = *rp;
+}
+
 // phase B + the MODE epilogue for every output row; block partials of sum(y) / delta land in rt().d_partials
 template <int MODE>
 int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, const LoopState* state, int* num_partials) {
@@ -1224,13 +1291,29 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
     double* pdel = r.d_partials + kMaxPartials;
     const bool large = p.bin_rows > kPbBinRows;
     const int grid = p.sched_groups;                   // persistent: as many workgroups as the CUs hold at once
+    ResParams rp = g_residual;
+    const bool res = MODE == EPI_AXPBY && g_residual_set;
+    g_residual_set = false;
     {
         ProfScope prof(PGH_K_PB_ACCUM);
         const bool wide = f.num_blocks > 4;               // 8 column blocks: 8-way row partitions
-        if (large && wide) k_pb_finish<MODE, 8, kPbBinRowsLarge, kPbBThreadsLarge><<<grid, kPbBThreadsLarge, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel);
-        else if (large) k_pb_finish<MODE, 4, kPbBinRowsLarge, kPbBThreadsLarge><<<grid, kPbBThreadsLarge, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel);
-        else if (wide) k_pb_finish<MODE, 8, kPbBinRows, kPbBThreads><<<grid, kPbBThreads, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel);
-        else k_pb_finish<MODE, 4, kPbBinRows, kPbBThreads><<<grid, kPbBThreads, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel);
+#define PGH_FINISH(NBLK, ROWS_, THREADS_, RES_) \
+    k_pb_finish<MODE, NBLK, ROWS_, THREADS_, RES_><<<grid, THREADS_, 0, r.stream>>>(v, rs, f.dst_scale, ep, state, psum, pdel, rp)
+        if constexpr (MODE == EPI_AXPBY) {
+            if (res) {
+                if (large && wide) PGH_FINISH(8, kPbBinRowsLarge, kPbBThreadsLarge, true);
+                else if (large) PGH_FINISH(4, kPbBinRowsLarge, kPbBThreadsLarge, true);
+                else if (wide) PGH_FINISH(8, kPbBinRows, kPbBThreads, true);
+                else PGH_FINISH(4, kPbBinRows, kPbBThreads, true);
+            }
+        }
+        if (!res) {
+            if (large && wide) PGH_FINISH(8, kPbBinRowsLarge, kPbBThreadsLarge, false);
+            else if (large) PGH_FINISH(4, kPbBinRowsLarge, kPbBThreadsLarge, false);
+            else if (wide) PGH_FINISH(8, kPbBinRows, kPbBThreads, false);
+            else PGH_FINISH(4, kPbBinRows, kPbBThreads, false);
+        }
+#undef PGH_FINISH
     }
     PGH_HIP(hipGetLastError());
     PGH_STAMP_DUMP(g_times_finish, grid, "k_pb_finish")

@@ -111,7 +111,7 @@ extern "C" int pgh_init(int device_ordinal) {
     r.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     PGH_HIP(hipStreamCreateWithFlags(&r.own_stream, hipStreamNonBlocking));
     r.stream = r.own_stream;
-    PGH_HIP(hipMalloc(&r.d_partials, sizeof(double) * kMaxPartials * 2));
+    PGH_HIP(hipMalloc(&r.d_partials, sizeof(double) * kMaxPartials * kPartialRegions));
     PGH_HIP(hipMalloc(&r.d_scalars, sizeof(double) * kNumScalars));
     PGH_HIP(hipHostMalloc(&r.h_scalars, sizeof(double) * kNumScalars, hipHostMallocDefault));
     PGH_HIP(hipEventCreate(&r.ev_a));

@@ -445,6 +445,22 @@ __global__ __launch_bounds__(WG) void k_step_close(LoopState* __restrict__ state
     }
 }
 
+// the close of a recursive step from its PendingClose record, as a launch of its own (the last enqueued step of a run,
+// PGH_DEFER_CLOSE=0, the re-evaluation of a paused step): same folds, same bits as the deferred form (run_pending_close)
+__global__ __launch_bounds__(WG) void k_step_close_rec(PendingClose pc) {
+    __shared__ double s_red[16];
+    if (pc.state->done) return;
+    (void)run_pending_close(pc, s_red);
+}
+
+// a paused step (fused residual, kPredGuard) is re-opened by the host before it re-evaluates it
+__global__ void k_state_resume(LoopState* state, int* progress) {
+    if (state->done == 2) {
+        state->done = 0;
+        if (progress != nullptr) __hip_atomic_store(progress + 1, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 pgh_graph_s* g_dist_iso_graph = nullptr;     // the slice a partitioned run watches (pgh_dist_watch_isolated)
 
 // raises the isolated-row flag when v is not zero on an isolated row (loops whose operands do not pass through
@@ -461,7 +477,15 @@ __global__ __launch_bounds__(WG) void k_iso_watch(const float* __restrict__ v, i
     if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(iso.flag, 1);
 }
 
-__global__ void k_state_init(LoopState* state, double scale) {
+__global__ void k_state_init(LoopState* state, double scale, LoopAux* aux = nullptr) {
+    if (aux != nullptr) {
+        aux->pred_inv[0] = 1.0;
+        aux->pred_inv[1] = 1.0;
+        aux->pred_raw[0] = 0.0;
+        aux->pred_raw[1] = 0.0;
+        aux->sum_p = 0.0;
+        aux->worst_miss = 0.0;
+    }
     state->scale = scale;
     state->err = 0.0;
     state->sum = 0.0;
@@ -577,6 +601,7 @@ int residual_grid(int64_t n) {
 // Lazily created device loop state + pinned mirror
 LoopState* g_state = nullptr;
 LoopState* g_state_host = nullptr;
+LoopAux*   g_aux = nullptr;          // fused-residual scalars of the recursive loops (ResParams)
 
 // Host-visible progress of the device loop: {steps executed, done flag}, written by k_step_close into pinned mapped
 // memory.  The host keeps a window of iterations enqueued ahead of the last step it has seen complete, so the stream
@@ -598,8 +623,7 @@ int flush_pending_close() {
     if (!pc.active) return 0;
     pc.active = 0;
     ProfScope prof(PGH_K_FINAL);
-    k_step_close<<<1, WG, 0, rt().stream>>>(pc.state, pc.partial_sum, pc.num_sum, pc.res_partials, pc.num_res, pc.use_quotient, pc.check,
-                                            pc.err_kind, pc.tol, (int64_t)pc.n, nullptr, pc.progress);
+    k_step_close_rec<<<1, WG, 0, rt().stream>>>(pc);
     PGH_HIP(hipGetLastError());
     return 0;
 }
@@ -607,6 +631,8 @@ int flush_pending_close() {
 int ensure_state() {
     if (g_state) return 0;
     PGH_HIP(hipMalloc(&g_state, sizeof(LoopState)));
+    PGH_HIP(hipMalloc(&g_aux, sizeof(LoopAux)));
+    PGH_HIP(hipMemset(g_aux, 0, sizeof(LoopAux)));
     PGH_HIP(hipHostMalloc(&g_state_host, sizeof(LoopState), hipHostMallocDefault));
     void* hp = nullptr;
     PGH_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -1278,7 +1304,6 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     const int linf = (cfg->err_kind == PGH_ERR_LINF);
     const int rgrid = residual_grid(n_int);
     double* pres = r.d_partials + kMaxPartials;      // residual partials share the delta region
-    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
     // ConvergenceManager.has_converged is evaluated before every step with iteration = step index
     // (convergence.py:85): step k runs iff k < max_iters and the check at iteration k did not fire.
     const int max_steps = cfg->max_iters - 1 > 0 ? cfg->max_iters - 1 : 0;
@@ -1291,11 +1316,20 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     // the separate launch
     static const bool defer_env = getenv("PGH_DEFER_CLOSE") == nullptr || atoi(getenv("PGH_DEFER_CLOSE")) != 0;
     const bool defer = defer_env && sp.blocked && !overlap;
+    // PageRank with the L1 / Mabs rule on a graph with a cold image: the residual is evaluated inside the finish kernel
+    // against the predicted quotient (ResParams, pgh_kernels.h) -- no residual launch from the second step on.
+    // PGH_FUSED_RES=0 keeps the separate kernel.
+    static const bool fuse_env = getenv("PGH_FUSED_RES") == nullptr || atoi(getenv("PGH_FUSED_RES")) != 0;
+    bool fused = fuse_env && MODE == EPI_AXPBY && sp.blocked && g->bsf.pb.enabled && !overlap && pre_scale == nullptr &&
+                 (cfg->err_kind == PGH_ERR_L1 || cfg->err_kind == PGH_ERR_MABS) && ep.v != nullptr;
+    if (fused) PGH_TRY(bsf_ensure_degrees(g));
+    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0, g_aux);
     pending_close_slot().active = 0;
     int count_seen = 0;   // partials per step (the same for every step of a run)
-    // the close of step k as the record the next blocked-format launch executes (PendingClose)
-    auto stash_close = [&](PendingClose& pc, int k) {
+    // the close of step k as a record: executed by the next blocked-format launch (deferred) or by k_step_close_rec
+    auto make_close = [&](int k) {
         const int it = k + 1;
+        PendingClose pc{};
         pc.state = g_state;
         pc.partial_sum = r.d_partials;
         pc.res_partials = pres;
@@ -1305,9 +1339,19 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         pc.num_sum = count_seen;
         pc.num_res = rgrid;
         pc.use_quotient = cfg->use_quotient;
+        // the check that follows step k happens at iteration k + 1 (skipped when that iteration hits max_iters)
         pc.check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
         pc.err_kind = cfg->err_kind;
         pc.active = 1;
+        pc.res_mode = fused ? (k == 1 ? 2 : 1) : 0;
+        pc.step = k;
+        pc.aux = g_aux;
+        pc.part_r = r.d_partials + 2 * kMaxPartials;
+        pc.part_d = r.d_partials + 3 * kMaxPartials;
+        pc.part_t = r.d_partials + 4 * kMaxPartials;
+        pc.a = ep.a;
+        pc.b = ep.b;
+        return pc;
     };
     // every launch of step k (it produces x_k from x_{k-1})
     auto enqueue_step = [&](int k) -> int {
@@ -1316,12 +1360,22 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         EpiParams epk = ep;
         epk.y = yout;
         int count = 0;
+        ResParams rp{};
+        if (fused) {
+            rp.x_prev = xin;
+            rp.deg = g->bsf.deg_int;
+            rp.aux = g_aux;
+            rp.part_r = r.d_partials + 2 * kMaxPartials;
+            rp.part_d = r.d_partials + 3 * kMaxPartials;
+            rp.part_t = r.d_partials + 4 * kMaxPartials;
+            rp.step = k;
+            rp.first = k == 1 ? 1 : 0;
+            pb_set_residual(&rp);                  // consumed by the finish launch of this step
+        }
         PGH_TRY((launch_step<MODE>(g, epk, use_xg ? g->bsf.xg : xin, g_state, &count,
                                    (overlap && k > 1) ? g_ev_closed : nullptr)));
         count_seen = count;
-        // the check that follows step k happens at iteration k + 1 (skipped when that iteration hits max_iters)
-        const int it = k + 1;
-        const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
+        const PendingClose pc = make_close(k);
         hipStream_t main_stream = r.stream;
         struct StreamGuard {                     // whatever happens below, the engine's stream is put back
             Runtime& rt_;
@@ -1333,18 +1387,17 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             PGH_HIP(hipStreamWaitEvent(g_side_stream, g_ev_combined, 0));
             r.stream = g_side_stream;            // ProfScope and the launches below follow rt().stream
         }
-        if (check) {
+        if (pc.check && pc.res_mode != 1) {
             ProfScope prof(PGH_K_RESIDUAL);
             const int vec_ok = aligned16(yout) && aligned16(xin);
             k_step_residual<<<rgrid, WG, 0, r.stream>>>(yout, xin, n_int, vec_ok, cfg->use_quotient, linf, g_state,
                                                         r.d_partials, count, pres, iso_tail);
         }
         if (defer) {
-            stash_close(pending_close_slot(), k);
+            pending_close_slot() = pc;
         } else {
             ProfScope prof(PGH_K_FINAL);
-            k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, pres, rgrid, cfg->use_quotient,
-                                                 check, cfg->err_kind, cfg->tol, n, nullptr, g_progress_dev);
+            k_step_close_rec<<<1, WG, 0, r.stream>>>(pc);
         }
         if (overlap) {
             r.stream = main_stream;
@@ -1354,25 +1407,57 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     };
     int enq = 0;          // steps enqueued so far
     bool done = false;
-    while (!done && enq < max_steps) {
-        if (poll) {
-            PGH_TRY(progress_wait(enq, window, &done));
-            if (done) break;
+    for (;;) {
+        while (!done && enq < max_steps) {
+            if (poll) {
+                PGH_TRY(progress_wait(enq, window, &done));
+                if (done) break;
+            }
+            // (hipGraphs were measured for this loop, tools/graph_probe.hip + profiles/r02/loop_graph_*.log: dependent tiny kernels
+            // cost 2.7 us each in a stream and 1.7 us INSIDE one graph, but between two graph launches the gap is 2.7 us again,
+            // hipGraphLaunch takes 8 us of host time and an instantiate 140-300 us.  A graph short enough not to run far past the
+            // converged step -- two steps, eight kernels -- gains nothing (2.72 us per kernel), and the loop built on such pairs
+            // measured 520 instead of 286 us per run at scale 10 and 469.6 instead of 474.6 GTEPS at scale 23.)
+            const int upto = (enq + batch < max_steps) ? enq + batch : max_steps;
+            for (; enq < upto; ++enq) PGH_TRY(enqueue_step(enq + 1));
+            PGH_HIP(hipGetLastError());
+            if (!poll || enq >= max_steps) PGH_TRY(flush_pending_close());
+            if (!poll) {
+                if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
+                PGH_TRY(fetch_state());
+                done = g_state_host->done != 0;
+            }
         }
-        // (hipGraphs were measured for this loop, tools/graph_probe.hip + profiles/r02/loop_graph_*.log: dependent tiny kernels
-        // cost 2.7 us each in a stream and 1.7 us INSIDE one graph, but between two graph launches the gap is 2.7 us again,
-        // hipGraphLaunch takes 8 us of host time and an instantiate 140-300 us.  A graph short enough not to run far past the
-        // converged step -- two steps, eight kernels -- gains nothing (2.72 us per kernel), and the loop built on such pairs
-        // measured 520 instead of 286 us per run at scale 10 and 469.6 instead of 474.6 GTEPS at scale 23.)
-        const int upto = (enq + batch < max_steps) ? enq + batch : max_steps;
-        for (; enq < upto; ++enq) PGH_TRY(enqueue_step(enq + 1));
-        PGH_HIP(hipGetLastError());
-        if (!poll || enq >= max_steps) PGH_TRY(flush_pending_close());
-        if (!poll) {
-            if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
-            PGH_TRY(fetch_state());
-            done = g_state_host->done != 0;
+        if (!fused) break;
+        // a close of the fused residual may have PAUSED the loop (the quotient's prediction missed by more than kPredGuard):
+        // the step it was closing is complete but for its residual -- evaluate that with the separate kernel, close the step
+        // the plain way and go on without the fusion
+        if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
+        PGH_TRY(flush_pending_close());
+        PGH_TRY(fetch_state());
+        if (g_state_host->done != 2) break;
+        const int k = g_state_host->steps + 1;       // the paused step
+        fused = false;
+        k_state_resume<<<1, 1, 0, r.stream>>>(g_state, g_progress_dev);
+        if (poll) progress_reset();
+        {
+            const float* xin = buf[(k - 1) & 1];
+            const float* yout = buf[k & 1];
+            PendingClose pc = make_close(k);
+            {
+                ProfScope prof(PGH_K_RESIDUAL);
+                k_step_residual<<<rgrid, WG, 0, r.stream>>>(yout, xin, n_int, aligned16(yout) && aligned16(xin), cfg->use_quotient, linf,
+                                                            g_state, r.d_partials, count_seen, pres, iso_tail);
+            }
+            ProfScope prof(PGH_K_FINAL);
+            k_step_close_rec<<<1, WG, 0, r.stream>>>(pc);
+            PGH_HIP(hipGetLastError());
         }
+        PGH_TRY(fetch_state());
+        if (poll) g_progress_host[0] = g_state_host->steps;
+        enq = k;
+        done = g_state_host->done != 0;
+        res->flags |= 1;
     }
     if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
     PGH_TRY(flush_pending_close());                  // a no-op once the loop has ended on the device
@@ -1392,6 +1477,14 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     res->converged = g_state_host->converged;
     res->spmv_count = steps;
     res->last_error = g_state_host->err;
+    static const bool debug_res = getenv("PGH_DEBUG_RES") != nullptr;
+    if (debug_res) {
+        LoopAux h{};
+        PGH_HIP(hipMemcpy(&h, g_aux, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pgh] recursive run: %d steps, err %.6e, in-kernel residual %s%s, worst quotient miss %.3e, sum(p) %.12f\n", steps,
+                g_state_host->err, fuse_env && (res->flags & 1) == 0 && fused ? "on" : "off", (res->flags & 1) ? " (paused once)" : "",
+                h.worst_miss, h.sum_p);
+    }
     return 0;
 }
 

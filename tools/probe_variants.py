@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--ef", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--copy", action="store_true")
+    ap.add_argument("--seeds", type=int, default=0, help="personalization = this many seed nodes with out-edges (the bench's shape); 0 = dense 1/n")
     ap.add_argument("libs", nargs="+")
     args = ap.parse_args()
     for path in args.libs:
@@ -29,6 +30,16 @@ def main():
         vp, vr = L.c_vec(), L.c_vec()
         lib.pgh_vec_alloc(n, C.byref(vp)), lib.pgh_vec_alloc(n, C.byref(vr))
         lib.pgh_vec_fill(vp, 1.0 / n)
+        if args.seeds > 0:
+            import numpy as np
+            lib.pgh_graph_degrees(g, vr)
+            deg = np.empty(n, dtype=np.float32)
+            lib.pgh_vec_d2h_f32(vr, deg.ctypes.data_as(C.c_void_p), n)
+            cand = np.flatnonzero(deg > 0)
+            pick = np.sort(np.random.default_rng(1).choice(cand, size=args.seeds, replace=False))
+            p = np.zeros(n, dtype=np.float32)
+            p[pick] = 1.0 / args.seeds
+            lib.pgh_vec_h2d_f32(vp, p.ctypes.data_as(C.c_void_p), n)
         bytes_iter = 8 * nnz + 16 * n
         out = [f"{os.path.basename(path):28s} n={n} nnz={nnz}"]
         for profile in (0, 1):
