@@ -162,13 +162,14 @@ def single_gpu(args):
     for step in range(args.warmup):
         run(step)
     L.check(lib.pgh_sync())
-    spmv_total, loop_ms_total, iters = 0, 0.0, []
+    spmv_total, loop_ms_total, iters, paused = 0, 0.0, [], 0
     t0 = time.perf_counter()
     for step in range(args.warmup, total):
         ranks, info = run(step)
         spmv_total += info["spmv"]
         loop_ms_total += info["loop_ms"]
         iters.append(info["iterations"])
+        paused += info.get("flags", 0) & 1
     L.check(lib.pgh_sync())
     elapsed = time.perf_counter() - t0
     gteps = nnz * spmv_total / elapsed / 1e9
@@ -296,7 +297,8 @@ def single_gpu(args):
         config=dict(workload=f"single-GPU PPR on RMAT scale-{scale} ef-{ef} (BASELINE.json configs[1])", n=n, nnz=nnz,
                     alpha=ALPHA, tol=TOL, error_type="L1", seeds=SEEDS, iterations_per_step=iters,
                     spmv_per_step=spmv_total / args.steps, device_loop_ms_per_step=round(loop_ms_total / args.steps, 4),
-                    graph_build_s=round(build_s, 2), parallelism="1 GPU"),
+                    graph_build_s=round(build_s, 2), parallelism="1 GPU",
+                    runs_with_a_paused_in_kernel_residual=paused),
         roofline=roofline, cpu_baseline=cpu, parity=parity, secondary=secondary)
 
 

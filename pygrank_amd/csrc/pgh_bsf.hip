@@ -22,7 +22,6 @@
 //
 // Reference counterpart of the arithmetic: conv(signal, M) = signal @ M (pygrank/core/backend/numpy.py:64-65).
 #include "pgh_kernels.h"
-#include "pgh_pb_gather.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -818,50 +817,12 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
 #endif
 }
 
-// The FRONT of a step as one launch: the block partial sums (VALU-bound: 3.4 TB/s) and phase A of the cold image
-// (bandwidth-bound) do not depend on each other, so their workgroups share one grid -- a CU that has finished its
-// partial-sum workgroup takes a phase A share at once (no drain between two launches, no dependent boundary), and with the
-// roles interleaved in dispatch order the two kinds of work run side by side on different CUs.  Both roles need most of a
-// CU's LDS, so a CU holds one workgroup at a time.  Role of a workgroup: groups of 8 consecutive workgroups (one per XCD:
-// the partial sums keep their XCD-affine column blocks) take the same role.
-//   order 0: all partial-sum groups, then phase A;  3: phase A first;  1 / 2: alternating, phase A / partial sums first
-// The cross-tile fix-ups (they need ALL partial sums of the step) move into k_pb_finish (PbFormat::fix_ent).
-template <bool HAS_VAL, bool W16>
-__global__ __launch_bounds__(kBsfThreads) void k_step_front(BsfView bv, PbView pv, const float* __restrict__ xg,
-                                                             const LoopState* __restrict__ state, PendingClose pc, int n_partial,
-                                                             int n_gather, int order) {
-    constexpr int kFloats = kBsfLdsFloats > kPbChunk + 1 ? kBsfLdsFloats : kPbChunk + 1;
-    __shared__ __attribute__((aligned(16))) float s_lds[kFloats];
-    static_assert(kPbThreads == kBsfThreads, "both roles of the front kernel use the same workgroup shape");
-    if (state != nullptr && state->done) return;
-    if (pc.active && run_pending_close(pc, reinterpret_cast<double*>(s_lds))) return;
-    const int grp = blockIdx.x >> 3, sub = blockIdx.x & 7;
-    const int pg = n_partial >> 3, gg = (n_gather + 7) >> 3;
-    int role, idx;                                     // role 0 = block partial sums, 1 = phase A
-    if (order == 0) {
-        role = grp < pg ? 0 : 1;
-        idx = role == 0 ? grp : grp - pg;
-    } else if (order == 3) {
-        role = grp < gg ? 1 : 0;
-        idx = role == 1 ? grp : grp - gg;
-    } else {
-        const int m = pg < gg ? pg : gg;
-        if (grp < 2 * m) {
-            role = ((grp & 1) != 0) == (order == 1) ? 0 : 1;
-            idx = grp >> 1;
-        } else {
-            role = pg > gg ? 0 : 1;
-            idx = grp - m;
-        }
-    }
-    if (role == 0) {
-        bsf_partial_body<kIPT, HAS_VAL, false, W16>(s_lds, bv, xg, (unsigned int)(idx * 8 + sub), (unsigned int)n_partial);
-    } else {
-        const int share = idx * 8 + sub;
-        if (share < n_gather) pb_gather_body<HAS_VAL>(s_lds, reinterpret_cast<uint32_t*>(s_lds + kPbChunk), pv, xg, share);
-    }
-}
-
+// (Round 3 measured the block partial sums and phase A as ONE launch -- workgroups of both roles in one grid, the cross-tile
+// fix-ups either inside k_pb_finish's work items or behind a device counter at the end of the phase A workgroups: 126-132 us
+// against 58 + 73 + the boundary for the two launches, whatever the order of the roles.  A CU moves ~21 GB/s whatever it runs
+// (the chip's 5.4 TB/s copy ceiling is 256 such CUs), a phase A workgroup alone on the chip takes as long as all of them
+// together, so nothing overlaps by putting the VALU-bound role and the bandwidth-bound role on different CUs; and both need
+// most of a CU's LDS, so they cannot share one.  profiles/r03/front_merge_rejected.log.)
 // build time: where the fix-up of tile t goes (index into the partial vectors, -1 = nothing to fix), so that the
 // per-iteration kernel below needs no dependent loads
 __global__ void k_bsf_fixlist(const int4* __restrict__ tile, const int32_t* __restrict__ seg_row, int num_tiles,
@@ -953,61 +914,10 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, 
     BsfFormat& f = g->bsf;
     const BsfView v = view_of(f);
     const int main_grid = r.num_cus;                  // one workgroup per CU; a multiple of 8 (XCD-affine blocks)
-    // diagnostic (timing only: the fix-ups then race with the partial sums): phase A on a second stream, concurrently
-    static const int probe_conc = env_int("PGH_PROBE_CONC", 0);
-    static hipStream_t conc_stream = nullptr;
-    static hipEvent_t conc_fork = nullptr, conc_join = nullptr;
-    if (probe_conc && stage == 0 && f.pb.enabled && f.pb.num_tasks > 0) {
-        if (conc_stream == nullptr) {
-            PGH_HIP(hipStreamCreateWithFlags(&conc_stream, hipStreamNonBlocking));
-            PGH_HIP(hipEventCreateWithFlags(&conc_fork, hipEventDisableTiming));
-            PGH_HIP(hipEventCreateWithFlags(&conc_join, hipEventDisableTiming));
-        }
-        FixView nofix{};
-        nofix.num_tiles = 0;
-        hipStream_t main_stream = r.stream;
-        PGH_HIP(hipEventRecord(conc_fork, main_stream));
-        PGH_HIP(hipStreamWaitEvent(conc_stream, conc_fork, 0));
-        if (probe_conc == 2) {            // phase A first in the main queue, the partial sums beside it
-            r.stream = conc_stream;
-            PGH_TRY(bsf_launch_partial(g, xg, state, 1));
-            r.stream = main_stream;
-            PGH_TRY(pb_launch_gather(g, xg, state, nofix));
-        } else {
-            r.stream = conc_stream;
-            PGH_TRY(pb_launch_gather(g, xg, state, nofix));
-            r.stream = main_stream;
-            PGH_TRY(bsf_launch_partial(g, xg, state, 1));
-        }
-        PGH_HIP(hipEventRecord(conc_join, conc_stream));
-        PGH_HIP(hipStreamWaitEvent(main_stream, conc_join, 0));
-        return 0;
-    }
     // the previous step's close rides in this launch when the loop driver deferred it (PendingClose, pgh_kernels.h)
     PendingClose pc = pending_close_slot();
     if (stage == 2 || state == nullptr || pc.state != state) pc.active = 0;
     else pending_close_slot().active = 0;             // consumed
-    // whole step in one go on a graph with a hot-only stream and a cold image: ONE front launch (k_step_front); the finish
-    // kernel then closes the cross-tile segments.  PGH_FRONT=0 keeps the two launches; PGH_FRONT_ORDER picks the role order.
-    static const int front_on = env_int("PGH_FRONT", 1), front_order = env_int("PGH_FRONT_ORDER", 1);
-    if (stage == 0 && front_on && f.pb.enabled && !f.pb.k1_cold && f.pb.num_tasks > 0 && f.pb.item_fix != nullptr && (main_grid & 7) == 0) {
-        const PbView pv = pb_view_of(g);
-        const int gather_groups = (f.pb.num_tasks + 7) >> 3;
-        const int grid = main_grid + gather_groups * 8;
-        {
-            ProfScope prof(PGH_K_SPMV);
-            if (f.colf16 != nullptr) {
-                if (f.val) k_step_front<true, true><<<grid, kBsfThreads, 0, r.stream>>>(v, pv, xg, state, pc, main_grid, f.pb.num_tasks, front_order);
-                else k_step_front<false, true><<<grid, kBsfThreads, 0, r.stream>>>(v, pv, xg, state, pc, main_grid, f.pb.num_tasks, front_order);
-            } else {
-                if (f.val) k_step_front<true, false><<<grid, kBsfThreads, 0, r.stream>>>(v, pv, xg, state, pc, main_grid, f.pb.num_tasks, front_order);
-                else k_step_front<false, false><<<grid, kBsfThreads, 0, r.stream>>>(v, pv, xg, state, pc, main_grid, f.pb.num_tasks, front_order);
-            }
-        }
-        PGH_HIP(hipGetLastError());
-        f.fix_pending = true;
-        return 0;
-    }
     if (stage != 2) {
         ProfScope prof(PGH_K_SPMV);
         if (f.colf16 != nullptr) {
@@ -1595,9 +1505,9 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         k_bsf_fixlist<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.tile, f.seg_row, f.num_tiles, f.fix_seg);
         PGH_HIP(hipGetLastError());
         PGH_HIP(hipStreamSynchronize(r.stream));
-        PGH_TRY(pb_attach_fixlist(f));                 // the cold image's work items learn the fix-ups of their rows
         (void)hipFree(f.seg_row);                       // build-time only in this layout
         f.seg_row = nullptr;
+
         if (f.pb.enabled && !f.pb.k1_cold && env_int("PGH_STREAM16", 1)) {       // hot-only stream: 2 bytes per entry
             const uint32_t hot4 = (uint32_t)(kBsfHot < blk ? kBsfHot : blk) << 2;
             PGH_HIP(hipMalloc(&f.colf16, sizeof(uint16_t) * (size_t)f.num_tiles * 512 + 64));

@@ -173,11 +173,6 @@ struct PbFormat {
     int*      sched = nullptr;      // [num_items]
     int*      sched_begin = nullptr;// [sched_groups + 1]
     uint32_t* work_counter = nullptr; // hand-out of the schedule's tail (one device word), or null without a tail
-    // cross-tile fix-ups of the blocked stream by work item (pb_attach_fixlist): when the step's front kernel runs the block
-    // partial sums and phase A as ONE launch, k_pb_finish closes the segments that span tiles for the rows of each item
-    int4*     fix_ent = nullptr;    // [num_fix] {closing tile, segment, first tile of the chain, row}, sorted by row
-    int2*     item_fix = nullptr;   // [num_items] {first, count} into fix_ent
-    int       num_fix = 0;
     int       tail_begin = 0, tail_count = 0;   // sched[tail_begin .. +tail_count): items handed out on the device
     int64_t   device_bytes = 0;
 };
@@ -249,7 +244,6 @@ struct BsfFormat {
                                     // block (xg_base[b] = b * xg_live): a smaller cold region for the same gathers
     float*    xg = nullptr;         // [n_src_pad + 1] gather-source work buffer (new space)
     float*    tmp_out = nullptr;    // [n_out] work buffer (new space) for the single-step entry points
-    bool      fix_pending = false;  // the last front launch left the cross-tile fix-ups to the finish kernel
     int64_t   device_bytes = 0;
 };
 

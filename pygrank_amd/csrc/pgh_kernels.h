@@ -294,44 +294,6 @@ __device__ __forceinline__ void bsf_fixup_tiles(const FixView& f, int first_tile
     }
 }
 
-// The same fix-ups from a LIST of closing tiles (k_pb_finish: the tiles whose segment belongs to the rows of the work item in
-// hand, PbFormat::fix_ent -- {closing tile, segment, first tile of the carry chain, row}).  All threads of the workgroup
-// call it together (`count` is uniform).
-struct FixList {
-    const int4*   ent;
-    const double* tail_carry;
-    const double* head_partial;
-    float*        psum;
-};
-__device__ __forceinline__ void bsf_fixup_list(const FixList& f, int begin, int count, int nthreads) {
-    const int lane = threadIdx.x & 63;
-    for (int i0 = 0; i0 < count; i0 += nthreads) {
-        const int i = i0 + (int)threadIdx.x;
-        int4 e = make_int4(0, -1, 0, 0);
-        if (i < count) e = f.ent[begin + i];
-        const int t = e.x, dst = e.y, first = e.z;
-        const int len = dst >= 0 ? t - first : 0;
-        const bool is_long = len >= 32;
-        if (dst >= 0 && !is_long) {
-            double total = 0.0;
-            for (int s = first; s < t; ++s) total += f.tail_carry[s];
-            total += f.head_partial[t];
-            f.psum[dst] = (float)total;
-        }
-        unsigned long long todo = __ballot(is_long);
-        while (todo != 0ULL) {
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1ULL;
-            const int c_first = __shfl(first, src, 64), c_t = __shfl(t, src, 64);
-            double part_sum = 0.0;
-            for (int s = c_first + lane; s < c_t; s += 64) part_sum += f.tail_carry[s];
-            part_sum = wave_reduce_sum(part_sum);
-            const double total = __shfl(part_sum, 0, 64) + f.head_partial[c_t];
-            if (lane == src) f.psum[dst] = (float)total;
-        }
-    }
-}
-
 // diagnostic builds only (-DPGH_PROBE_TIMES=1): every workgroup stamps its start and end (100 MHz wall clock) so that the host
 // can print how evenly a launch's workgroups finish (tools/probe_variants.py with PGH_DUMP_TIMES=1)
 #ifndef PGH_PROBE_TIMES
@@ -519,6 +481,14 @@ __device__ __forceinline__ bool run_pending_close(const PendingClose& pc, double
     return o.verdict != 0;
 }
 
+// Where the 8 values of B-order group G of the cold image live in PbFormat::tmp: inside every block of 64 groups the 64
+// low quads come first, then the 64 high quads -- so that both 16-byte stores of phase A (lane = group) and both 16-byte
+// loads of phase B cover CONTIGUOUS memory when the lanes of a wavefront hold consecutive groups (they mostly do: a
+// (chunk, bin) run is ~80 groups).  With the quads of a group side by side every such instruction touched every second
+// 16 bytes: half-filled requests on both sides.
+__device__ __forceinline__ uint32_t pb_tmp_quad(uint32_t group, int high) {
+    return ((group >> 6) << 9) + ((uint32_t)high << 8) + ((group & 63u) << 2);
+}
 // device view of the propagation-blocking image (PbFormat, pgh_pb.hip)
 struct PbView {
     const uint16_t* sloc;
@@ -539,9 +509,6 @@ struct PbView {
     double*         hub_part;          // [num_bins] sums of the pieces of split hub rows
     uint32_t*       amax;              // [0] bit pattern of max |value| written by phase A, [1] phase B's exit tickets
     const int*      iso_flag;          // BsfFormat::iso_flag or null: 0 = items marked -2 (isolated rows) are passed over
-    const int2*     item_fix;          // per item: {first, count} of its cross-tile fix-ups in fix.ent (null: none attached)
-    FixList         fix;               // what k_pb_finish needs to close the cross-tile segments of an item's rows itself
-    int             do_fix;            // 1 = this launch does them (the step's front kernel left them: k_step_front)
     int64_t         cold_prefix[9];
     int64_t         xg_base[8];
     int             num_blocks, hot, chunk, num_chunks, num_bins;
@@ -578,11 +545,11 @@ int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, co
 template <int MODE>
 int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, const LoopState* state, int* num_partials);
 void pb_destroy(PbFormat& p);
-PbView pb_view_of(const pgh_graph_s* g);       // first slice of the graph's cold image
 int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, int stage = 0);
+
 void pb_set_residual(const ResParams* rp);   // the next pb_launch_finish<EPI_AXPBY> evaluates the residual in the kernel (ResParams)
 int bsf_ensure_degrees(pgh_graph_s* g);       // BsfFormat::deg_int
-int pb_attach_fixlist(BsfFormat& f);     // after the stream's fix_seg / seg_row exist: per-item fix lists of k_pb_finish
+
 template <int MODE>
 int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* state, int* num_partials);
 template <int MODE>

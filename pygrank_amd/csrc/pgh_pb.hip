@@ -287,7 +287,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     auto fetch = [&](const int4& bin, int round, Round& R) __attribute__((always_inline)) {
         const bool hub = ((bin.y >> 21) & 1) != 0;
         const int groups = finite || hub ? bin.w : 0;
-        const float* __restrict__ tmp = f.tmp + (int64_t)bin.z * 8;
+        const float* __restrict__ tmp = f.tmp;
         const uint16_t* __restrict__ drow = f.drow + (int64_t)bin.z * 8;
 #pragma unroll
         for (int q = 0; q < P; ++q) {
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             const bool ok = g < groups && !(PGH_PROBE_PB & 8);
             R.r8[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + (int64_t)g * 8))
                          : u16x8{0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff};
-            R.lo[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + (int64_t)g * 8)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            R.hi[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + (int64_t)g * 8 + 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.lo[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 0))) : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.hi[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 1))) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -386,8 +386,6 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         item = take_tail();
     }
     int4 bin = make_int4(0, 0, 0, 0), epi = make_int4(0, 0, -1, 0);
-    int2 fx = make_int2(0, 0);              // the item's cross-tile fix-ups (f.do_fix)
-    const bool do_fix = f.do_fix != 0;
     Round R;
     // items marked -2 cover isolated rows (no entry, referenced by nobody): unless this run's operands are non-zero there
     // they hold zeros in both iterates and are passed over (the item shrinks to no rows: barriers only)
@@ -395,7 +393,6 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     if (item >= 0) {
         bin = f.item_a[item];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
         epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1 (-2: isolated rows), first item of the split row}
-        if (do_fix) fx = f.item_fix[item];
         fetch(bin, 0, R);
     }
 #if PGH_PROBE_TIMES
@@ -436,10 +433,6 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         const int rows = bin.y & 0xffff, count_bits = (bin.y >> 16) & 0x1f;
         const bool hub = ((bin.y >> 21) & 1) != 0;
         const int pieces = (int)((unsigned)bin.y >> 22) + 1;
-        // the segments of this item's rows that span tiles of the blocked stream are closed here when the step's front kernel
-        // left that to this launch: psum slots nobody else touches, read by this workgroup's epilogue after the barriers below
-        // (a hub row: by whoever runs its epilogue, further down)
-        if (do_fix && !hub) bsf_fixup_list(f.fix, fx.x, fx.y, THREADS);
         const int E = min(51, 62 - count_bits);
         const double S = __longlong_as_double((long long)(1023 + E - e) << 52);
         const double inv_S = __longlong_as_double((long long)(1023 - E + e) << 52);
@@ -495,11 +488,9 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             next = take_tail();
         }
         int4 next_bin = make_int4(0, 0, 0, 0), next_epi = make_int4(0, 0, -1, 0);
-        int2 next_fx = make_int2(0, 0);
         if (next >= 0) {
             next_bin = f.item_a[next];
             next_epi = f.item_b[next];
-            if (do_fix) next_fx = f.item_fix[next];
 
             if (PGH_FIN_PREFETCH) fetch(next_bin, 0, R);
         }
@@ -546,10 +537,6 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                     s_hub = (float)total;
                     (void)atomicExch(f.hub_ticket + epi.z, 0u);       // re-arm for the next launch
                 }
-                __syncthreads();
-            }
-            if (do_fix && s_last) {                        // workgroup-uniform: the row's cross-tile segments first
-                bsf_fixup_list(f.fix, fx.x, fx.y, THREADS);
                 __syncthreads();
             }
             if (s_last && tid == 0) {                      // the row's epilogue (one row: the direct lookup)
@@ -637,7 +624,6 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         item = next;
         bin = next_bin;
         epi = next_epi;
-        fx = next_fx;
     }
     if (!flushed_head) flush(blockIdx.x);
     // the last workgroup to leave re-arms the words for the next launch (every workgroup has read amax long before its
@@ -670,12 +656,6 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.drow = p.drow;
     v.amax = p.amax;
     v.iso_flag = f.iso_flag;
-    v.item_fix = p.item_fix;
-    v.fix.ent = p.fix_ent;
-    v.fix.tail_carry = f.tail_carry;
-    v.fix.head_partial = f.head_partial;
-    v.fix.psum = f.psum;
-    v.do_fix = 0;
     v.hub_part = p.hub_part;
     for (int i = 0; i < 9; ++i) v.cold_prefix[i] = p.cold_prefix[i];
     for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base[i];
@@ -689,8 +669,6 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
 }
 
 }  // namespace
-
-PbView pb_view_of(const pgh_graph_s* g) { return pb_view(g->bsf, g->bsf.pb); }
 
 // Decides whether the cold tail gets its own image and, if so, lays out the bins.  keys: the sorted stream
 // (block << 58 | row << 29 | col), is_hot: 1 = stays in the stream; on success entries of rows too heavy for a bin are
@@ -994,7 +972,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     PGH_HIP(hipMalloc(&p.task_range, sizeof(int) * (size_t)(shares + 1)));
     if (!tasks.empty()) PGH_HIP(hipMemcpyAsync(p.task, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMemcpyAsync(p.task_range, ranges.data(), sizeof(int) * (shares + 1), hipMemcpyHostToDevice, r.stream));
-    PGH_HIP(hipMalloc(&p.tmp, sizeof(float) * (size_t)(padded + 8)));
+    PGH_HIP(hipMalloc(&p.tmp, sizeof(float) * (size_t)(((padded / 8 + 63) / 64 + 1) * 512)));      // whole blocks of 64 groups (pb_tmp_quad)
     PGH_HIP(hipMalloc(&p.amax, sizeof(uint32_t) * 2));
     PGH_HIP(hipMemsetAsync(p.amax, 0, sizeof(uint32_t) * 2, r.stream));
     // ---- work list of k_pb_finish: the bins in row order (`mine` is sorted by first row; the pieces of a split hub row are
@@ -1135,74 +1113,6 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     return 0;
 }
 
-// Per-item lists of the blocked stream's cross-tile fix-ups (called by bsf_build once fix_seg and seg_row exist): the
-// closing tiles sorted by the row their segment belongs to; every work item of k_pb_finish gets the range of its rows.
-namespace {
-__global__ void k_pb_fix_keys(const int32_t* __restrict__ fix_seg, const int32_t* __restrict__ seg_row, int num_tiles,
-                              uint64_t* __restrict__ keys) {
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < num_tiles; t += gridDim.x * blockDim.x) {
-        const int seg = fix_seg[t];
-        keys[t] = seg >= 0 ? ((uint64_t)(uint32_t)seg_row[seg] << 32) | (uint32_t)t : ~0ULL;
-    }
-}
-__global__ void k_pb_fix_entries(const uint64_t* __restrict__ keys, int num_tiles, const int32_t* __restrict__ fix_seg,
-                                 const int4* __restrict__ tile, int4* __restrict__ ent) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_tiles; i += gridDim.x * blockDim.x) {
-        const uint64_t k = keys[i];
-        if (k == ~0ULL) {
-            ent[i] = make_int4(0, -1, 0, -1);
-            continue;
-        }
-        const int t = (int)(uint32_t)k;
-        ent[i] = make_int4(t, fix_seg[t], tile[t].w, (int)(k >> 32));
-    }
-}
-// first position whose row is >= `row` (valid keys sort first: rows are below 2^31, the filler is ~0)
-__device__ __forceinline__ int fix_lower_bound(const uint64_t* __restrict__ keys, int count, int64_t row) {
-    int lo = 0, hi = count;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const uint64_t k = keys[mid];
-        const int64_t r = k == ~0ULL ? (int64_t)1 << 40 : (int64_t)(k >> 32);
-        if (r < row) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
-__global__ void k_pb_item_fix(const uint64_t* __restrict__ keys, int num_tiles, const int4* __restrict__ item_b, int num_items,
-                              int2* __restrict__ item_fix) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_items; i += gridDim.x * blockDim.x) {
-        const int4 e = item_b[i];
-        const int lo = fix_lower_bound(keys, num_tiles, (int64_t)e.x), hi = fix_lower_bound(keys, num_tiles, (int64_t)e.x + e.y);
-        item_fix[i] = make_int2(lo, hi - lo);
-    }
-}
-}  // namespace
-
-int pb_attach_fixlist(BsfFormat& f) {
-    PbFormat& p = f.pb;
-    if (!p.enabled || p.num_items <= 0 || f.fix_seg == nullptr || f.seg_row == nullptr || f.num_tiles <= 0) return 0;
-    Runtime& r = rt();
-    PbBuf<uint64_t> keys, sorted;
-    PGH_TRY(keys.alloc((size_t)f.num_tiles));
-    PGH_TRY(sorted.alloc((size_t)f.num_tiles));
-    k_pb_fix_keys<<<pb_blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.fix_seg, f.seg_row, f.num_tiles, keys.p);
-    size_t temp_bytes = 0;
-    PGH_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys.p, sorted.p, f.num_tiles, 0, 64, r.stream));
-    PbBuf<char> temp;
-    PGH_TRY(temp.alloc(temp_bytes));
-    PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys.p, sorted.p, f.num_tiles, 0, 64, r.stream));
-    PGH_HIP(hipMalloc(&p.fix_ent, sizeof(int4) * (size_t)(f.num_tiles + 1)));
-    PGH_HIP(hipMalloc(&p.item_fix, sizeof(int2) * (size_t)(p.num_items + 1)));
-    k_pb_fix_entries<<<pb_blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(sorted.p, f.num_tiles, f.fix_seg, f.tile, p.fix_ent);
-    k_pb_item_fix<<<pb_blocks_for(p.num_items), kBlock, 0, r.stream>>>(sorted.p, f.num_tiles, p.item_b, p.num_items, p.item_fix);
-    PGH_HIP(hipGetLastError());
-    PGH_HIP(hipStreamSynchronize(r.stream));
-    p.num_fix = f.num_tiles;
-    p.device_bytes += (int64_t)f.num_tiles * 16 + (int64_t)p.num_items * 8;
-    return 0;
-}
-
 void pb_plan_release(PbPlan* plan) {
     (void)hipFree(plan->row_bin);
     delete[] plan->host_bins;
@@ -1256,6 +1166,8 @@ int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, co
     {
         ProfScope prof(PGH_K_PB_GATHER);
         if (p.num_tasks > 0) {
+            // (diagnostic of round 3: launched with a quarter of its workgroups this kernel takes 63 us instead of 76 -- a workgroup's
+            // share costs the same alone on the chip as with all others running: the per-CU memory path bounds it, ~21 GB/s)
             if (p.val) k_pb_gather<true><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
             else k_pb_gather<false><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
         }
@@ -1281,12 +1193,7 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
     const BsfFormat& f = g->bsf;
     const PbFormat& p = f.pb;
     Runtime& r = rt();
-    PbView v = pb_view(f, p);
-    if (f.fix_pending) {                               // the front kernel of this step left the cross-tile fix-ups to this launch
-        PGH_CHECK(p.item_fix != nullptr, "propagation blocking: no fix lists attached to the work items");
-        v.do_fix = 1;
-        g->bsf.fix_pending = false;
-    }
+    const PbView v = pb_view(f, p);
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
     const bool large = p.bin_rows > kPbBinRows;
@@ -1364,8 +1271,6 @@ void pb_destroy(PbFormat& p) {
     (void)hipFree(p.sched);
     (void)hipFree(p.sched_begin);
     (void)hipFree(p.work_counter);
-    (void)hipFree(p.fix_ent);
-    (void)hipFree(p.item_fix);
     (void)hipFree(p.bin);
     (void)hipFree(p.drow);
     p = PbFormat();

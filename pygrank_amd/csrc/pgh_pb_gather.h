@@ -68,32 +68,43 @@ __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t
         // stores of round i.  vmcnt counts loads and stores in one in-order queue, so a loop that loads, gathers, stores
         // and only then loads again makes every round wait for the previous round's stores to complete (measured:
         // reads alone 40 us, with the stores 80 us -- no overlap at all).
-        constexpr int P = HAS_VAL ? 2 : 4;
+#ifndef PGH_GATHER_P
+#define PGH_GATHER_P 4
+#endif
+        constexpr int P = HAS_VAL ? PGH_GATHER_P / 2 : PGH_GATHER_P;
         if (PGH_PROBE_PB & 2) continue;
         struct Round {
             u16x8    s8[P];
             uint32_t to[P];
             f32x4    w0[HAS_VAL ? P : 1], w1[HAS_VAL ? P : 1];
         };
-        const int64_t step = (int64_t)kPbThreads * 8 * P;
-        auto fetch = [&](Round& r, int64_t e0) __attribute__((always_inline)) {
+        // Branch-free rounds: the round base is uniform, a lane past the end of the piece repeats the piece's LAST group
+        // (same loads, same values, same destination: a benign duplicate store), so every load and store is issued
+        // unconditionally and the compiler emits counted waits.  (Loads under `ok ? load : 0` had become divergent branches
+        // with an s_waitcnt inside each -- nothing stayed in flight across the stages: a workgroup alone on the chip took
+        // 63 us for its share, 31 of them waiting for its own stores.)
+        if (body_end <= body_begin) continue;
+        constexpr int kRound = kPbThreads * 8 * P;           // entries per round
+        const int span = (int)(body_end - body_begin);       // pieces are far below 2^31 entries
+        const int last = span - 8;                            // first entry of the piece's last group
+        const uint16_t* __restrict__ sl = f.sloc + body_begin;
+        const uint32_t* __restrict__ dg = f.dstg + (body_begin >> 3);
+        const float* __restrict__ vl = HAS_VAL ? f.val + body_begin : nullptr;
+        auto fetch = [&](Round& r, int rb) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < P; ++q) {
-                const int64_t e = e0 + (int64_t)q * kPbThreads * 8;
-                const bool ok = e < body_end;
-                r.s8[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(f.sloc + e)) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                r.to[q] = ok ? __builtin_nontemporal_load(f.dstg + (e >> 3)) : 0u;
+                const int e = min(rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8), last);
+                r.s8[q] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(sl + e));
+                r.to[q] = __builtin_nontemporal_load(dg + (e >> 3));
                 if (HAS_VAL) {
-                    r.w0[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(f.val + e)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    r.w1[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(f.val + e + 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    r.w0[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vl + e));
+                    r.w1[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vl + e + 4));
                 }
             }
         };
-        auto emit = [&](const Round& r, int64_t e0) __attribute__((always_inline)) {
+        auto emit = [&](const Round& r, int rb) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < P; ++q) {
-                const int64_t e = e0 + (int64_t)q * kPbThreads * 8;
-                if (e >= body_end) continue;
                 f32x4 lo, hi;
                 lo.x = s_x[r.s8[q][0]];
                 lo.y = s_x[r.s8[q][1]];
@@ -108,28 +119,31 @@ __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t
                     hi *= r.w1[q];
                 }
                 if (PGH_PROBE_PB & 4) {
-                    if (lo.x + hi.w == 123.456f) f.tmp[e] = lo.y;
+                    if (lo.x + hi.w == 123.456f) f.tmp[body_begin + rb] = lo.y;
                     continue;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     amax = max(amax, max(__float_as_uint(lo[k]) & 0x7fffffffu, __float_as_uint(hi[k]) & 0x7fffffffu));
-                float* __restrict__ dst = (PGH_PROBE_PB & 64) ? f.tmp + e : f.tmp + (int64_t)r.to[q] * 8;   // 64: diagnostic, sequential stores
-                *reinterpret_cast<f32x4*>(dst) = lo;
-                *reinterpret_cast<f32x4*>(dst + 4) = hi;
+                uint32_t group = r.to[q];
+                if (PGH_PROBE_PB & 64)                       // diagnostic: sequential stores
+                    group = (uint32_t)((body_begin + min(rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8), last)) >> 3);
+                *reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 0)) = lo;
+                *reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 1)) = hi;
             }
         };
         Round r0, r1;
-        int64_t e0 = body_begin + (int64_t)threadIdx.x * 8;
-        fetch(r0, e0);
-        while (e0 < body_end) {
-            fetch(r1, e0 + step);
-            emit(r0, e0);
-            e0 += step;
-            if (e0 >= body_end) break;
-            fetch(r0, e0 + step);
-            emit(r1, e0);
-            e0 += step;
+        int rb = 0;
+        fetch(r0, rb);
+        for (;;) {
+            fetch(r1, rb + kRound);                           // (clamped: the last round re-reads the last group)
+            emit(r0, rb);
+            rb += kRound;
+            if (rb >= span) break;
+            fetch(r0, rb + kRound);
+            emit(r1, rb);
+            rb += kRound;
+            if (rb >= span) break;
         }
     }
     // max |value| of this launch: wavefront -> workgroup -> one global atomic

@@ -171,7 +171,7 @@ class RecursiveGraphFilter(GraphFilter):
         L.check(entry(g._h, *[v._h for v in vectors], x._h, C.byref(cfg), C.byref(res)))
         ranks.np = x                       # updated in place by the engine; drops the host mirror
         self.last_loop = dict(iterations=res.iterations, converged=bool(res.converged), spmv=res.spmv_count,
-                              last_error=res.last_error, loop_ms=res.loop_ms)
+                              last_error=res.last_error, loop_ms=res.loop_ms, flags=res.flags)
         self.convergence.finish_device_loop(res.iterations, res.converged)
         return True
 
