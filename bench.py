@@ -326,8 +326,236 @@ def _emit(line):
 def multi_gpu(args):
     os.environ["NCCL_DEBUG"] = os.environ.get("PGH_NCCL_DEBUG", "WARN")
     _stdout_to_stderr()
-    from pygrank_amd.distributed import bench_row_partitioned
     return bench_row_partitioned(args, RMAT, ALPHA, TOL, MAX_ITERS, SEEDS, HBM_PEAK_GBS)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# --gpus N: the row-partitioned path (pygrank_amd.distributed), its parity leg against the oracle and the same graph on ONE GPU
+# ----------------------------------------------------------------------------------------------------------------
+def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak):
+    import math
+    import torch
+    import torch.distributed as dist
+    from pygrank_amd import _lib as L
+    from pygrank_amd.device import DeviceVector
+    from pygrank_amd.distributed import DistributedPageRank, rmat_partitioned
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    # PGH_DIST_BACKEND=gloo with several ranks on ONE GPU: a functional test of the multi-rank device path (streams,
+    # events, in-place collectives on device scalars) on boxes with a single GPU; never a measurement
+    device_index = local_rank % torch.cuda.device_count() if use_cuda else 0
+    if use_cuda:
+        torch.cuda.set_device(device_index)
+    L.ensure_init(device_index)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=os.environ.get("PGH_DIST_BACKEND", "nccl" if use_cuda else "gloo"))
+    if args.scale is None:                      # weak scaling: fixed edges per GPU; configs[4] at 8 GPUs
+        scale, ef = (27, 8) if world == 8 else (23 + int(math.log2(world)), 16)
+    else:
+        scale, ef = args.scale, (args.ef or 16)
+    if args.ef is not None and args.scale is None:
+        ef = args.ef
+    t0 = time.time()
+    pg = rmat_partitioned(scale, ef, rank, world, **rmat)
+    L.check(L.lib().pgh_sync())
+    build_s = time.time() - t0
+    n, n_local, lo = pg.n, pg.n_local, pg.row_begin
+    nnz_t = torch.tensor([pg.graph.nnz], dtype=torch.float64, device="cuda" if use_cuda else "cpu")
+    dist.all_reduce(nnz_t)
+    nnz_total = int(nnz_t.item())
+    nnz_m = torch.tensor([float(pg.graph.nnz)], dtype=torch.float64, device="cuda" if use_cuda else "cpu")
+    dist.all_reduce(nnz_m, op=dist.ReduceOp.MAX)
+    balance = round(float(nnz_m.item()) * world / max(nnz_total, 1), 4)          # max over ranks / mean
+    deg = np.asarray(pg.graph.degrees())                     # row sums of M for every (relabelled) source
+    candidates = np.flatnonzero(deg > 0)
+    total = args.warmup + args.steps
+    personalizations = []
+    for step in range(total):
+        rng = np.random.default_rng(1 + step)
+        seeds = np.sort(rng.choice(candidates, size=min(num_seeds, len(candidates)), replace=False))
+        p = np.zeros(n_local)
+        mine = seeds[(seeds >= lo) & (seeds < lo + n_local)] - lo
+        p[mine] = 1.0
+        personalizations.append(DeviceVector.from_host(p))
+    ranker = DistributedPageRank(alpha=alpha, tol=tol, error_type="l1", max_iters=max_iters)
+    for step in range(args.warmup):
+        ranker.rank(pg, personalizations[step])
+    dist.barrier()
+    if use_cuda:
+        torch.cuda.synchronize()
+    spmv_total, iters = 0, []
+    t0 = time.perf_counter()
+    for step in range(args.warmup, total):
+        ranker.rank(pg, personalizations[step])
+        spmv_total += ranker.spmv
+        iters.append(ranker.iteration)
+    if use_cuda:
+        torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_cuda else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    # roofline leg on rank 0: HIP-event time of the step kernels, per-GPU algorithmic bytes
+    lib = L.lib()
+    L.check(lib.pgh_profile_reset())
+    L.check(lib.pgh_profile_enable(1))
+    ranker.rank(pg, personalizations[total - 1])
+    L.check(lib.pgh_profile_enable(0))
+    prof = {}
+    for kid, name in ((L.K_SPMV, "spmv"), (L.K_PB_GATHER, "pb_gather"), (L.K_PB_ACCUM, "pb_finish"), (L.K_FIXUP, "fixup"),
+                      (L.K_COMBINE, "combine"), (L.K_RESIDUAL, "residual"), (L.K_FINAL, "close")):
+        cnt, ms = C.c_int64(), C.c_double()
+        L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
+        if name == "spmv":
+            steps_profiled = max(cnt.value, 1)
+        prof[name] = (ms.value / steps_profiled * 1e3) if cnt.value else None     # us per iteration (a kind may launch twice)
+    # every launch of one iteration counts (as in the single-GPU line): step + residual + the scalar folds / closes
+    step_us = sum(v for v in prof.values() if v)
+    names = dict(spmv="k_bsf_partial", pb_gather="k_pb_gather", pb_finish="k_pb_finish<AXPBY>", fixup="k_bsf_fixup",
+                 combine="k_bsf_combine<AXPBY>", residual="k_step_residual", close="k_dist_close_sum + k_dist_fold + k_dist_close_err")
+    step_kernels = " + ".join(names[k] for k, v in prof.items() if v)
+    alg_bytes = 8 * pg.graph.nnz + 4 * n + 16 * n_local
+    achieved = alg_bytes / (step_us * 1e-6) / 1e9 if step_us else None
+    # ---- parity + CPU baseline of the N-rank line: the same partitioned code path on a graph the oracle finishes in
+    # seconds (every rank takes part; rank 0 compares the un-permuted slices with the oracle's scipy loop and times it)
+    parity, cpu = None, None
+    if not args.no_cpu:
+        parity, cpu = _parity_leg(dist, rank, world, min(scale, 20), ef, rmat, alpha, tol, max_iters, num_seeds, use_cuda)
+    # what the line says about this rank's slice, read BEFORE the same-graph leg gives the slice up
+    graph_format = pg.graph.format()
+    nnz_local = pg.graph.nnz
+    exchange = dict(exchange_bytes_per_iteration_per_gpu=ranker._buffers.exchange_bytes,
+                    gather_vector_slots=ranker._buffers.nb * ranker._buffers.live, column_blocks=ranker._buffers.nb)
+    # ---- the same graph on ONE GPU (rank 0, single-GPU engine) while the other ranks wait: the same-graph speed-up the
+    # north star quotes (>= 6x at 8 GPUs on the 1 B-edge graph) next to the weak-scaling value, and a full-size cross-check
+    same_graph = None
+    if world > 1 and not getattr(args, "no_same_graph", False):
+        same_graph = _same_graph_leg(dist, rank, world, pg, ranker, personalizations[total - 1], scale, ef, rmat, alpha, tol,
+                                     max_iters, num_seeds, total, use_cuda, nnz_total * spmv_total / elapsed / 1e9)
+    if rank != 0:
+        return None
+    return dict(
+        metric="edges*iters/sec (GTEPS) for PPR alpha=0.85 to tol=1e-6", value=round(nnz_total * spmv_total / elapsed / 1e9, 2),
+        unit="GTEPS", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
+        higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+        config=dict(workload=f"row-partitioned PPR on RMAT scale-{scale} ef-{ef} over {world} GPUs (BASELINE.json configs[4] shape)",
+                    n=n, nnz=nnz_total, alpha=alpha, tol=tol, error_type="L1", seeds=num_seeds, iterations_per_step=iters,
+                    spmv_per_step=spmv_total / args.steps, graph_build_s=round(build_s, 2),
+                    parallelism=f"1-D row partition x{world}, all-gather of the gather vector + 2 scalar all-reduces per iteration",
+                    nnz_per_rank_max_over_mean=balance, **exchange),
+        roofline=dict(bound="hbm", kernel=step_kernels + " (one PPR iteration of rank 0's slice, exchange excluded)",
+                      achieved=round(achieved, 1) if achieved else None, peak=hbm_peak, unit="GB/s",
+                      frac=round(achieved / hbm_peak, 4) if achieved else None, traffic=None,
+                      algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(step_us, 2), format=graph_format,
+                      kernels_avg_us=prof),
+        cpu_baseline=cpu, parity=parity, same_graph_1gpu=same_graph)
+
+
+def _device_of(use_cuda):
+    import torch
+    return torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+
+
+def _gather_slices(dist, local, world, use_cuda):
+    """Every rank's equal-sized f32 slice -> one array on every rank (new id order)."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32)).to(_device_of(use_cuda))
+    out = torch.empty(t.numel() * world, dtype=torch.float32, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy()
+
+
+def _parity_leg(dist, rank, world, scale, ef, rmat, alpha, tol, max_iters, num_seeds, use_cuda):
+    from pygrank_amd.device import DeviceVector
+    from pygrank_amd.distributed import DistributedPageRank, rmat_partitioned
+    from oracle import ref_loops as orc, rmat_np          # the checker: imported by the bench's parity leg only
+    import scipy.sparse as sp
+    pgp = rmat_partitioned(scale, ef, rank, world, **rmat)
+    perm = pgp.perm
+    A = rmat_np.rmat_csr(scale, ef, seed=0) if rank == 0 else None
+    # personalization on ORIGINAL ids, identical on every rank (the seeds are drawn from a rank-independent rule)
+    rng = np.random.default_rng(1)
+    p_old = np.zeros(pgp.n)
+    p_old[rng.choice(pgp.n, size=min(num_seeds, pgp.n), replace=False)] = 1.0
+    lo = pgp.row_begin
+    ranker = DistributedPageRank(alpha=alpha, tol=tol, error_type="l1", max_iters=max_iters)
+    out = ranker.rank(pgp, DeviceVector.from_host(p_old[perm[lo:lo + pgp.n_local]]))
+    new_order = _gather_slices(dist, np.asarray(out), world, use_cuda)
+    if rank != 0:
+        return None, None
+    got = np.zeros(pgp.n)
+    got[perm] = new_order
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    t0 = time.perf_counter()
+    want, cpu_iters = orc.pagerank(M, p_old, alpha=alpha, error_type="l1", tol=tol, max_iters=max_iters,
+                                   eps=float(np.finfo(np.float32).eps))
+    cpu_s = time.perf_counter() - t0
+    parity = dict(rel_linf=float(np.max(np.abs(got - want)) / np.max(np.abs(want))), gpu_iterations=int(ranker.iteration),
+                  cpu_iterations=int(cpu_iters), bound=1e-6,
+                  workload=f"the same {world}-rank partitioned path on RMAT scale-{scale} ef-{ef} vs the oracle's scipy loop")
+    cpu = dict(value=round(M.nnz * (cpu_iters - 1) / cpu_s / 1e9, 4), unit="GTEPS", cores=1, kind="port",
+               sample=f"1 full PPR run ({cpu_iters - 1} SpMV) on the RMAT scale-{scale} ef-{ef} graph of the parity leg, scipy x @ M "
+                      f"fp64 single thread, {cpu_s:.2f} s")
+    return parity, cpu
+
+
+def _same_graph_leg(dist, rank, world, pg, ranker, p_last, scale, ef, rmat, alpha, tol, max_iters, num_seeds, total, use_cuda,
+                    value_n):
+    """Rank 0 runs the same graph / same personalization on its GPU alone (single-GPU engine) while the other ranks wait;
+    every rank contributes its slice of the partitioned result and of the personalization for a full-size comparison.
+    Call it LAST: rank 0 gives up its slice (graph image, exchange buffers) before it builds the whole graph, so the two
+    never sit in HBM together."""
+    from pygrank_amd import _lib as L
+    out = ranker.rank(pg, p_last)                           # the partitioned result of the last personalization, again
+    full_new = _gather_slices(dist, np.asarray(out), world, use_cuda)          # new id order
+    p_full_new = _gather_slices(dist, np.asarray(p_last), world, use_cuda)
+    iterations_partitioned = int(ranker.iteration)
+    result = None
+    if rank == 0:
+        try:
+            import gc
+            import pygrank_amd as pgm
+            from pygrank_amd.synthetic import rmat_graph
+            perm = np.array(pg.perm)                        # host copy: the slice goes away next
+            n_all = pg.n
+            ranker._buffers = None
+            ranker._buffers_for = None
+            pg.graph.destroy()
+            del out
+            gc.collect()
+            if use_cuda:
+                import torch
+                torch.cuda.empty_cache()
+            pgm.load_backend("hip")
+            adj = rmat_graph(scale, ef, seed=0, normalization="col", **rmat)
+            p_old = np.zeros(n_all)
+            p_old[perm] = p_full_new                        # back to ORIGINAL ids
+            sig = pgm.to_signal(adj, p_old)
+            rk = pgm.PageRank(alpha=alpha, error_type=pgm.L1, tol=tol, max_iters=max_iters)
+            rk.rank(adj, sig)                               # warm-up
+            L.check(L.lib().pgh_sync())
+            t0 = time.perf_counter()
+            spmv, runs, ranks1 = 0, 3, None
+            for _ in range(runs):
+                ranks1 = rk.rank(adj, sig)
+                spmv += rk.last_loop["spmv"]
+            L.check(L.lib().pgh_sync())
+            dt = time.perf_counter() - t0
+            one = adj.array.nnz * spmv / dt / 1e9
+            got = np.zeros(n_all)
+            got[perm] = full_new
+            ref = np.asarray(ranks1.np, dtype=np.float64)
+            result = dict(gteps_1gpu=round(one, 2), speedup_vs_1gpu_same_graph=round(value_n / one, 3) if one > 0 else None,
+                          iterations_1gpu=int(rk.convergence.iteration), iterations_partitioned=iterations_partitioned,
+                          rel_linf_partitioned_vs_1gpu=float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))),
+                          workload=f"the bench graph (RMAT scale-{scale} ef-{ef}) on rank 0's GPU alone, same personalization")
+        except Exception as exc:                            # the line then SAYS that the number is missing, and why
+            result = dict(error=str(exc)[:300], speedup_vs_1gpu_same_graph=None)
+    dist.barrier()
+    return result
 
 
 def spawn_ranks(args):

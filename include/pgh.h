@@ -119,6 +119,11 @@ int     pgh_mat_div_cols(pgh_mat_t m, const double* divisors_host /* [b] */, pgh
  * {(M^T)^k p} of its personalization -- the device form of the optimisation dict (abstract_filters.py:232-246), so that a
  * tuner probe (autotune/parameterized.py:135-145) costs one pass over an [n, K] slab instead of K SpMVs. */
 int     pgh_mat_gemv(pgh_mat_t m, const double* coeffs_host, int32_t count, pgh_vec_t out);
+/* The same for P coefficient vectors at once: out[i, q] (+)= sum_{j < count} m[i, j] * coeffs[j * probes + q] (f64
+ * accumulation; probes <= out.b <= 64; accumulate != 0 adds to out instead of overwriting it: slabs of more than 64
+ * powers are folded chunk by chunk).  MANY probes of an optimiser (autotune/parameterized.py:94-145: every probe is a
+ * coefficient vector over the same powers) cost ONE pass over the slab. */
+int     pgh_mat_gemm(pgh_mat_t m, const double* coeffs_host, int32_t count, int32_t probes, int32_t accumulate, pgh_mat_t out);
 /* out[:, 0:count] = m[:, first:first+count]  /  m[:, first:first+src.b] = src  (batches wider than 64 columns) */
 int     pgh_mat_get_cols(pgh_mat_t m, int32_t first, pgh_mat_t out);
 int     pgh_mat_set_cols(pgh_mat_t m, int32_t first, pgh_mat_t src);
@@ -154,6 +159,10 @@ int pgh_graph_info(pgh_graph_t g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz
 int pgh_graph_format(pgh_graph_t g, char* buf, int buflen);
 /* degrees(M): row sums of the un-transposed M, specification.py:105; numpy.py:76-77 */
 int pgh_graph_degrees(pgh_graph_t g, pgh_vec_t out);
+/* degrees of graph_dropout(M, rate): the row sums of M under the same (seed, entry) mask pgh_spmv_dropout applies -- the
+ * torch backends take degrees() of the dropped matrix (pytorch.py:34-38,100-104), so AbsorbingWalks and
+ * SymmetricAbsorbingRandomWalks with graph_dropout > 0 see degrees that match their convolutions. */
+int pgh_graph_degrees_dropout(pgh_graph_t g, double rate, uint64_t seed, pgh_vec_t out);
 /* download the stored CSR(M^T) (verification / CPU baseline hand-off) */
 int pgh_graph_download(pgh_graph_t g, int64_t* indptr_t, int32_t* indices_t, float* data_t);
 

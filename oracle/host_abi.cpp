@@ -384,6 +384,18 @@ int pgh_mat_gemv(pgh_mat_t m, const double* c, int32_t count, pgh_vec_t out) {
     }
     return 0;
 }
+int pgh_mat_gemm(pgh_mat_t m, const double* c, int32_t count, int32_t probes, int32_t accumulate, pgh_mat_t out) {
+    CHECK(m && out && (c || count == 0) && count >= 0 && count <= m->b && count <= 64 && probes >= 1 && probes <= out->b && probes <= 64 &&
+              out->n == m->n, "pgh_mat_gemm: shape mismatch");
+    for (int64_t i = 0; i < m->n; ++i)
+        for (int32_t q = 0; q < probes; ++q) {
+            double acc = 0;
+            for (int32_t j = 0; j < count; ++j) acc += (double)m->data[i * m->b + j] * c[(int64_t)j * probes + q];
+            float& o = out->data[i * out->b + q];
+            o = accumulate ? (float)((double)o + acc) : (float)acc;
+        }
+    return 0;
+}
 int pgh_mat_get_cols(pgh_mat_t m, int32_t first, pgh_mat_t out) {
     CHECK(m && out && m->n == out->n && first >= 0 && first + out->b <= m->b, "pgh_mat_get_cols: shape mismatch");
     for (int64_t i = 0; i < m->n; ++i)
@@ -532,6 +544,23 @@ int pgh_spmv_dropout(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y, double rate, uint6
         }
         y->data[r] = (float)acc;
     }
+    return 0;
+}
+
+int pgh_graph_degrees_dropout(pgh_graph_t g, double rate, uint64_t seed, pgh_vec_t out) {
+    CHECK(g && out && out->n == g->n_rows && rate >= 0.0 && rate < 1.0, "pgh_graph_degrees_dropout: bad argument");
+    const uint32_t threshold = (uint32_t)std::floor(rate * 4294967296.0);
+    const float keep = (float)(1.0 / (1.0 - rate));
+    std::vector<double> acc((size_t)g->n_rows, 0.0);
+    for (int64_t k = 0; k < g->nnz; ++k) {
+        uint64_t z = (seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ULL)) + 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z = z ^ (z >> 31);
+        const float f = (uint32_t)(z >> 32) >= threshold ? keep : 0.f;
+        if (f != 0.f) acc[(size_t)g->col[k]] += (double)(g->val[k] * f);
+    }
+    for (int64_t i = 0; i < g->n_rows; ++i) out->data[i] = (float)acc[(size_t)i];
     return 0;
 }
 

@@ -87,6 +87,7 @@ SIGNATURES = {
     "pgh_mat_col_abssum": (C.c_int, [c_mat, C.c_void_p]),
     "pgh_mat_div_cols": (C.c_int, [c_mat, C.c_void_p, c_mat]),
     "pgh_mat_gemv": (C.c_int, [c_mat, C.c_void_p, C.c_int32, c_vec]),
+    "pgh_mat_gemm": (C.c_int, [c_mat, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_mat]),
     "pgh_mat_get_cols": (C.c_int, [c_mat, C.c_int32, c_mat]),
     "pgh_mat_set_cols": (C.c_int, [c_mat, C.c_int32, c_mat]),
     "pgh_mat_get_col": (C.c_int, [c_mat, C.c_int32, c_vec]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "pgh_graph_info": (C.c_int, [c_graph, c_i64p, c_i64p, c_i64p, c_i64p]),
     "pgh_graph_format": (C.c_int, [c_graph, C.c_char_p, C.c_int]),
     "pgh_graph_degrees": (C.c_int, [c_graph, c_vec]),
+    "pgh_graph_degrees_dropout": (C.c_int, [c_graph, C.c_double, C.c_uint64, c_vec]),
     "pgh_graph_download": (C.c_int, [c_graph, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgh_spmv": (C.c_int, [c_graph, c_vec, c_vec]),
     "pgh_spmv_dropout": (C.c_int, [c_graph, c_vec, c_vec, C.c_double, C.c_uint64]),

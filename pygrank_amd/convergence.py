@@ -14,44 +14,49 @@ from pygrank_amd.measures import L1, Mabs, MaxDifference
 
 
 class ConvergenceManager:
+    """convergence.py:9-104.  ``has_converged`` is asked once BEFORE every step; it counts the call, gives up at
+    ``max_iters`` (silently for ``error_type="iters"`` or without an exception type, loudly otherwise) and otherwise
+    compares the iterate with the one it saw last time."""
+
     def __init__(self, tol=1.E-6, error_type=Mabs, max_iters=100, end_modulo=1, iter_exception=Exception):
-        self.tol = tol
-        self.error_type = error_type
-        self.max_iters = max_iters
-        self.iteration = 0
-        self.last_ranks = None
-        self._start_time = None
-        self.elapsed_time = None
+        self.tol, self.error_type = tol, error_type
+        self.max_iters, self.end_modulo = max_iters, end_modulo
         self.iter_exception = iter_exception
-        self.end_modulo = end_modulo
+        self.iteration, self.last_ranks = 0, None
+        self.elapsed_time = self._start_time = None
 
-    def start(self, restart_timer=True):                     # convergence.py:62-75
-        if restart_timer or self._start_time is None:
-            self._start_time = time()
-            self.elapsed_time = None
-            self.iteration = 0
+    def start(self, restart_timer=True):
         self.last_ranks = None
+        if self._start_time is not None and not restart_timer:
+            return                                          # a nested run keeps the clock and the count (convergence.py:62-75)
+        self._start_time, self.elapsed_time, self.iteration = time(), None, 0
 
-    def has_converged(self, new_ranks):                      # convergence.py:77-94
+    def _out_of_iterations(self):
+        return "Could not converge within " + str(self.max_iters) + " iterations"
+
+    def _counts_only(self):
+        return self.error_type == "iters"
+
+    def has_converged(self, new_ranks):
         self.iteration += 1
+        stop = False
         if self.iteration >= self.max_iters:
-            if self.error_type == "iters" or self.iter_exception is None:
-                self.elapsed_time = time() - self._start_time
-                return True
-            raise self.iter_exception("Could not converge within " + str(self.max_iters) + " iterations")
-        converged = False if self.last_ranks is None else self._has_converged(self.last_ranks, new_ranks)
-        self.last_ranks = new_ranks
+            if not self._counts_only() and self.iter_exception is not None:
+                raise self.iter_exception(self._out_of_iterations())
+            stop = True
+        else:
+            previous, self.last_ranks = self.last_ranks, new_ranks
+            stop = previous is not None and self._has_converged(previous, new_ranks)
         self.elapsed_time = time() - self._start_time
-        return converged
+        return stop
 
-    def _has_converged(self, prev_ranks, ranks):             # convergence.py:96-101
-        if self.error_type == "iters":
-            return False
-        if self.iteration % self.end_modulo != 0:
+    def _has_converged(self, prev_ranks, ranks):
+        """The comparison itself: skipped on iterations that are not a multiple of end_modulo and in counting mode."""
+        if self._counts_only() or self.iteration % self.end_modulo:
             return False
         return self.error_type(prev_ranks)(ranks) <= self.effective_tolerance()
 
-    def effective_tolerance(self):                           # convergence.py:101
+    def effective_tolerance(self):                           # convergence.py:101: never below the engine's epsilon
         return 0 if self.tol is None else max(self.tol, backend.epsilon())
 
     # ---- device-loop plumbing ----------------------------------------------------------------------
@@ -65,12 +70,12 @@ class ConvergenceManager:
         return None
 
     def finish_device_loop(self, iterations, converged):
-        """Mirror of the loop exit of has_converged for a loop that ran on the device."""
+        """What has_converged leaves behind at loop exit, for a loop that ran on the device."""
         self.iteration = int(iterations)
         self.elapsed_time = time() - self._start_time
-        if not converged and self.error_type != "iters" and self.iter_exception is not None \
-                and self.iteration >= self.max_iters:
-            raise self.iter_exception("Could not converge within " + str(self.max_iters) + " iterations")
+        ran_out = not converged and self.iteration >= self.max_iters
+        if ran_out and not self._counts_only() and self.iter_exception is not None:
+            raise self.iter_exception(self._out_of_iterations())
 
     def __str__(self):
-        return str(self.iteration) + " iterations (" + str(self.elapsed_time) + " sec)"
+        return f"{self.iteration} iterations ({self.elapsed_time} sec)"

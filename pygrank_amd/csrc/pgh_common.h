@@ -102,6 +102,7 @@ constexpr int kNumScalars = 64;
 struct ProfScope {
     int id;
     bool on;
+    hipEvent_t end = nullptr;   // this scope's own end event (scopes may nest; the pending list may be drained meanwhile)
     explicit ProfScope(int kernel_id);
     ~ProfScope();
 };

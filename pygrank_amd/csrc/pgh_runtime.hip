@@ -63,16 +63,24 @@ ProfScope::ProfScope(int kernel_id) : id(kernel_id), on(g_rt.profiling) {
         pr.a = g_prof_free.back().first;
         pr.b = g_prof_free.back().second;
         g_prof_free.pop_back();
-    } else if (hipEventCreate(&pr.a) != hipSuccess || hipEventCreate(&pr.b) != hipSuccess) {
-        on = false;
-        return;
+    } else {
+        if (hipEventCreate(&pr.a) != hipSuccess) {
+            on = false;
+            return;
+        }
+        if (hipEventCreate(&pr.b) != hipSuccess) {
+            (void)hipEventDestroy(pr.a);
+            on = false;
+            return;
+        }
     }
+    end = pr.b;
     (void)hipEventRecord(pr.a, g_rt.stream);
     g_prof_pending.push_back(pr);
 }
 ProfScope::~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(g_prof_pending.back().b, g_rt.stream);
+    (void)hipEventRecord(end, g_rt.stream);
     if (g_prof_pending.size() >= 16384) prof_drain();
 }
 
@@ -997,6 +1005,65 @@ extern "C" int pgh_mat_gemv(pgh_mat_t m, const double* coeffs_host, int32_t coun
         PGH_HIP(hipStreamSynchronize(r.stream));           // the caller's array may go away
     }
     k_mat_gemv<<<grid_for(m->n, 8), kBlock, 0, r.stream>>>(m->data, m->n, m->b, d, count, out->data);
+    PGH_HIP(hipGetLastError());
+    pool_free(d);
+    return 0;
+}
+
+// [n, count] x [count, P] with P <= 64: the lanes of a row share the row's values (same address: one request) and hold four
+// probes each; the coefficients sit in LDS as doubles.  Reads the slab once whatever P is.
+namespace {
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_mat_gemm(const float* __restrict__ m, int64_t n, int b, const double* __restrict__ coeffs, int count,
+                                                      int probes, int ld_out, int accumulate, float* __restrict__ out) {
+    __shared__ double s_c[64 * 64];
+    for (int j = threadIdx.x; j < count * probes; j += kBlock) s_c[j] = coeffs[j];
+    __syncthreads();
+    constexpr int ROWS = kBlock / LPR;
+    const int q0 = (threadIdx.x % LPR) * 4, r_in = threadIdx.x / LPR;
+    for (int64_t i = blockIdx.x * (int64_t)ROWS + r_in; i < n; i += (int64_t)gridDim.x * ROWS) {
+        const float* __restrict__ row = m + i * b;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < count; ++j) {
+            const double a = (double)row[j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + u < probes) acc[u] += a * s_c[j * probes + q0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (q0 + u < probes) {
+                float* o = out + i * ld_out + q0 + u;
+                *o = accumulate ? (float)((double)*o + acc[u]) : (float)acc[u];
+            }
+    }
+}
+}  // namespace
+
+extern "C" int pgh_mat_gemm(pgh_mat_t m, const double* coeffs_host, int32_t count, int32_t probes, int32_t accumulate, pgh_mat_t out) {
+    PGH_CHECK(m && out && (coeffs_host || count == 0), "pgh_mat_gemm: null argument");
+    PGH_CHECK(count >= 0 && count <= m->b && count <= 64 && probes >= 1 && probes <= out->b && probes <= 64 && out->n == m->n,
+              "pgh_mat_gemm: shape mismatch");
+    if (m->n == 0) return 0;
+    Runtime& r = rt();
+    double* d = nullptr;
+    const size_t elems = (size_t)(count > 0 ? count : 1) * (size_t)probes;
+    PGH_TRY(pool_alloc(sizeof(double) * elems, (void**)&d));
+    if (count > 0) {
+        PGH_HIP(hipMemcpyAsync(d, coeffs_host, sizeof(double) * (size_t)count * probes, hipMemcpyHostToDevice, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));           // the caller's array may go away
+    }
+    const int lpr = probes > 32 ? 16 : (probes > 16 ? 8 : (probes > 8 ? 4 : (probes > 4 ? 2 : 1)));
+    const int grid = grid_for(m->n * lpr, 4);
+#define PGH_GEMM(LPR) k_mat_gemm<LPR><<<grid, kBlock, 0, r.stream>>>(m->data, m->n, m->b, d, count, probes, out->b, accumulate, out->data)
+    switch (lpr) {
+        case 16: PGH_GEMM(16); break;
+        case 8: PGH_GEMM(8); break;
+        case 4: PGH_GEMM(4); break;
+        case 2: PGH_GEMM(2); break;
+        default: PGH_GEMM(1); break;
+    }
+#undef PGH_GEMM
     PGH_HIP(hipGetLastError());
     pool_free(d);
     return 0;

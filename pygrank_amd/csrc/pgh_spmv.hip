@@ -495,6 +495,10 @@ __global__ void k_state_init(LoopState* state, double scale, LoopAux* aux = null
     state->pad = 0;
 }
 
+__global__ void k_f64_to_f32_plain(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+
 __global__ void k_scale_copy(const float* __restrict__ in, float* __restrict__ out, int64_t n, double factor) {
     const float f = (float)factor;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -808,6 +812,36 @@ extern "C" int pgh_spmv_dropout(pgh_graph_t g, pgh_vec_t x, pgh_vec_t y, double 
     k_spmv_fixup<float, EpiF32<EPI_PLAIN>><<<sg.fix_grid, WG, 0, r.stream>>>(v, epi, nullptr, r.d_partials + sg.main_grid,
                                                                             r.d_partials + kMaxPartials + sg.main_grid);
     PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+namespace {
+// row sums of the masked M = column sums of the masked CSR(M^T): one f64 atomic per surviving entry
+__global__ void k_dropout_degrees(const int32_t* __restrict__ col, const float* __restrict__ val, int64_t nnz, EdgeDropout drop,
+                                  double* __restrict__ acc) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        const float f = dropout_factor(drop.seed, (uint64_t)e, drop.threshold, drop.keep_scale);
+        if (f != 0.f) atomicAdd(acc + col[e], (double)(val[e] * f));
+    }
+}
+}  // namespace
+
+extern "C" int pgh_graph_degrees_dropout(pgh_graph_t g, double rate, uint64_t seed, pgh_vec_t out) {
+    PGH_CHECK(g && out && out->n == g->n_rows, "pgh_graph_degrees_dropout: length mismatch");
+    PGH_CHECK(rate >= 0.0 && rate < 1.0, "pgh_graph_degrees_dropout: rate must lie in [0, 1)");
+    if (g->n_rows == 0) return 0;
+    Runtime& r = rt();
+    double* acc = nullptr;
+    PGH_TRY(pool_alloc(sizeof(double) * (size_t)g->n_rows, (void**)&acc));
+    PGH_HIP(hipMemsetAsync(acc, 0, sizeof(double) * (size_t)g->n_rows, r.stream));
+    EdgeDropout drop;
+    drop.seed = seed;
+    drop.threshold = (uint32_t)floor(rate * 4294967296.0);
+    drop.keep_scale = (float)(1.0 / (1.0 - rate));
+    if (g->nnz > 0) k_dropout_degrees<<<residual_grid(g->nnz), WG, 0, r.stream>>>(g->col, g->val, g->nnz, drop, acc);
+    k_f64_to_f32_plain<<<residual_grid(g->n_rows), WG, 0, r.stream>>>(acc, out->data, g->n_rows);
+    PGH_HIP(hipGetLastError());
+    pool_free(acc);
     return 0;
 }
 

@@ -327,6 +327,18 @@ class DeviceMatrix:
         L.check(L.lib().pgh_mat_gemv(self._h, _ptr(c), len(c), out._h))
         return out
 
+    def gemm(self, coeffs, out=None, accumulate=False):
+        """self[:, :K] @ coeffs for a [K, P] coefficient matrix (P <= 64, pgh_mat_gemm): [n, P]; with `out` and
+        `accumulate` the product is added to an existing slab (slabs of more than 64 powers, chunk by chunk)."""
+        c = np.ascontiguousarray(coeffs, dtype=np.float64)
+        if c.ndim != 2:
+            raise Exception("gemm expects a [terms, probes] coefficient matrix")
+        if out is None:
+            out = DeviceMatrix.empty(self.n, c.shape[1])
+            accumulate = False
+        L.check(L.lib().pgh_mat_gemm(self._h, _ptr(c), int(c.shape[0]), int(c.shape[1]), 1 if accumulate else 0, out._h))
+        return out
+
     def set_column(self, j, vec):
         L.check(L.lib().pgh_mat_set_col(self._h, int(j), vec._h))
 
@@ -411,6 +423,10 @@ class DeviceGraph:
                                                     0, C.byref(h)))
         return DeviceGraph(h, W.shape, len(data))
 
+    def destroy(self):
+        """Releases the device images now (a partitioned bench frees its slice before it builds the whole graph)."""
+        self.__del__()
+
     def __del__(self):
         try:
             if self._h is not None and L._lib is not None:
@@ -481,7 +497,10 @@ class DroppedGraph:
         return y
 
     def degrees(self):
-        raise L.EngineError("degrees() of a dropped graph is not available (take them from the graph itself)")
+        """Row sums of the dropped M (pgh_graph_degrees_dropout): the same mask the convolutions apply."""
+        out = DeviceVector.empty(self.shape[0])
+        L.check(L.lib().pgh_graph_degrees_dropout(self.base._h, float(self.rate), int(self.seed), out._h))
+        return out
 
     def format(self):
         return f"dropout {self.rate} (seed {self.seed}) over " + self.base.format()

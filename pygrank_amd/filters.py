@@ -37,13 +37,17 @@ def _device_graph(M):
 class GraphFilter(NodeRanking):
     """abstract_filters.py:11-106."""
 
+    # collaborators a filter builds for itself from its keyword arguments when none is handed in: attribute -> factory
+    _BUILT_FROM_KWARGS = (("preprocessor", default_preprocessor), ("convergence", ConvergenceManager))
+
     def __init__(self, preprocessor=None, convergence=None, personalization_transform=None, preserve_norm=True,
                  **kwargs):
-        self.preprocessor = call(default_preprocessor, kwargs) if preprocessor is None else preprocessor
-        self.convergence = call(ConvergenceManager, kwargs) if convergence is None else convergence
-        self.personalization_transform = Tautology() if personalization_transform is None else personalization_transform
+        given = dict(preprocessor=preprocessor, convergence=convergence)
+        for attribute, factory in self._BUILT_FROM_KWARGS:
+            setattr(self, attribute, given[attribute] if given[attribute] is not None else call(factory, kwargs))
+        ensure_used_args(kwargs, [factory for _, factory in self._BUILT_FROM_KWARGS])   # a keyword nobody declares is a typo
+        self.personalization_transform = personalization_transform or Tautology()
         self.preserve_norm = preserve_norm
-        ensure_used_args(kwargs, [default_preprocessor, ConvergenceManager])
 
     def _prepare(self, personalization):
         pass
@@ -114,22 +118,41 @@ class GraphFilter(NodeRanking):
     def _step(self, M, personalization, ranks, *args, **kwargs):
         raise Exception("Use a derived class of GraphFilter that implements the _step method")
 
-    def __add__(self, other):                                                     # abstract_filters.py:86-95
-        if isinstance(other, ConvergenceManager):
-            self.convergence = other
-        elif hasattr(other, "__name__") and other.__name__ == "preprocess":
-            self.preprocessor = other
-        elif isinstance(other, Postprocessor):
-            self.use_quotient = other
-        else:
-            raise Exception("Can only add convergence managers and preprocessors to graph filters")
+    def _slot_for(self, part):
+        """Which attribute `filter + part` replaces (abstract_filters.py:86-95): a convergence manager, a preprocessor
+        (recognised by the name preprocessor() gives its outcome) or a postprocessor that takes the quotient's place."""
+        if isinstance(part, ConvergenceManager):
+            return "convergence"
+        if getattr(part, "__name__", None) == "preprocess":
+            return "preprocessor"
+        if isinstance(part, Postprocessor):
+            return "use_quotient"
+        return None
+
+    def __add__(self, part):
+        slot = self._slot_for(part)
+        if slot is None:
+            raise Exception("a graph filter takes convergence managers, preprocessors and quotient postprocessors, not "
+                            + type(part).__name__)
+        setattr(self, slot, part)
         return self
 
-    def __lshift__(self, ranker):                                                 # abstract_filters.py:97-101
-        if not isinstance(ranker, NodeRanking):
-            raise Exception("pygrank can only shift rankers into filters")
-        self.personalization_transform = ranker
-        return ranker
+    def __lshift__(self, ranker):
+        """`ranker >> filter`: the ranker's outcome becomes this filter's personalization (abstract_filters.py:97-101)."""
+        if isinstance(ranker, NodeRanking):
+            self.personalization_transform = ranker
+            return ranker
+        raise Exception("only node ranking algorithms can be chained into a graph filter")
+
+    def _reference(self):
+        return "graph filter"
+
+    def cite(self):                                                               # abstract_filters.py:82-86
+        own = super().cite()
+        upstream = self.personalization_transform
+        if isinstance(upstream, Tautology) and upstream.ranker is None:
+            return own
+        return upstream.cite() + "\n  passed to " + own
 
 
 # =====================================================================================================
@@ -140,19 +163,26 @@ class RecursiveGraphFilter(GraphFilter):
 
     def __init__(self, use_quotient=True, converge_to_eigenvectors=False, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.use_quotient = use_quotient
-        self.converge_to_eigenvectors = converge_to_eigenvectors
+        self.use_quotient, self.converge_to_eigenvectors = use_quotient, converge_to_eigenvectors
 
-    def _step(self, M, personalization, ranks, *args, **kwargs):                  # abstract_filters.py:126-136
-        ranks.np = self._formula(M, personalization, ranks, *args, **kwargs)
-        if isinstance(ranks.np, GraphSignal):
-            ranks.np = ranks.np.np
-        if isinstance(self.use_quotient, Postprocessor):
-            ranks.np = self.use_quotient(ranks)
-        elif self.use_quotient:
-            ranks.np = backend.safe_div(ranks, backend.sum(ranks))
-        if self.converge_to_eigenvectors:
+    def _quotient(self, ranks):
+        """What follows the formula in every step (abstract_filters.py:130-134): a postprocessor in the quotient's place,
+        the plain division by the sum, or nothing."""
+        rule = self.use_quotient
+        if isinstance(rule, Postprocessor):
+            return rule(ranks)
+        return backend.safe_div(ranks, backend.sum(ranks)) if rule else ranks.np
+
+    def _step(self, M, personalization, ranks, *args, **kwargs):
+        outcome = self._formula(M, personalization, ranks, *args, **kwargs)
+        ranks.np = outcome.np if isinstance(outcome, GraphSignal) else outcome
+        ranks.np = self._quotient(ranks)
+        if self.converge_to_eigenvectors:                   # the personalization follows the iterate (abstract_filters.py:135-136)
             personalization.np = ranks.np
+
+    def references(self):
+        extra = ["unbiased convergence to the eigenvector"] if self.converge_to_eigenvectors else []
+        return super().references() + extra
 
     def _formula(self, M, personalization, ranks, *args, **kwargs):
         raise Exception("Use a derived class of RecursiveGraphFilter that implements the _formula method")
@@ -182,6 +212,9 @@ class PageRank(RecursiveGraphFilter):
     def __init__(self, alpha=0.85, *args, **kwargs):
         self.alpha = alpha
         super().__init__(*args, **kwargs)
+
+    def _reference(self):
+        return f"personalized PageRank (restart probability {1 - self.alpha:.3g})"
 
     def _formula(self, M, personalization, ranks, *args, **kwargs):               # adhoc.py:34-36
         return backend.conv(ranks, M) * self.alpha + personalization * (1 - self.alpha)
@@ -260,6 +293,9 @@ class AbsorbingWalks(RecursiveGraphFilter):
         super().__init__(*args, **kwargs)
         self.alpha = alpha
 
+    def _reference(self):
+        return f"partially absorbing random walks (absorption scale {(1 - self.alpha) / self.alpha:.3g})"
+
     def _start(self, M, personalization, ranks, absorption=None, **kwargs):       # adhoc.py:157-159
         self.absorption = to_signal(personalization.graph, absorption) * ((1 - self.alpha) / self.alpha)
         self.degrees = backend.degrees(M)
@@ -293,6 +329,9 @@ class SymmetricAbsorbingRandomWalks(RecursiveGraphFilter):
     def __init__(self, alpha=0.5, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.alpha = alpha
+
+    def _reference(self):
+        return "symmetric partially absorbing random walks"
 
     def _start(self, M, personalization, ranks, **kwargs):                        # adhoc.py:348-353
         d = backend.degrees(M)
@@ -366,35 +405,58 @@ class ImpulseGraphFilter(GraphFilter):
 # =====================================================================================================
 class _PowerSlab:
     """The device form of the optimisation dict (abstract_filters.py:232-246): the powers
-    {(M^T)^k p, k = 0, 1, ...} of ONE personalization as the columns of an [n, 64] slab in HBM, extended on demand (one
-    conv per new column), with the L1 and L-inf norm of every column on the host.  A filter evaluated from it costs one
-    pass over the slab (pgh_mat_gemv) instead of one SpMV per term -- what a tuner that probes hundreds of coefficient
-    vectors on the same personalization (autotune/parameterized.py:135-145) needs."""
+    {(M^T)^k p, k = 0, 1, ...} of ONE personalization as the columns of [n, 64] slabs in HBM (as many slabs as the
+    longest expansion asked for needs), extended on demand (one conv per new column), with the L1 and L-inf norm of every
+    column on the host.  A filter evaluated from it costs one pass over the slabs (pgh_mat_gemv) instead of one SpMV
+    per term, and P filters cost one pass as well (pgh_mat_gemm) -- what a tuner that probes hundreds of coefficient
+    vectors on the same personalization (autotune/parameterized.py:94-145) needs."""
     WIDTH = 64
+    MAX_TERMS = 4096          # 64 slabs; beyond that the step-by-step route takes over
 
     def __init__(self, graph, p):
-        from pygrank_amd.device import DeviceMatrix
         self.graph = graph
-        self.mat = DeviceMatrix.empty(len(p), self.WIDTH)
+        self.n = len(p)
+        self.slabs = []
         self.count = 0
         self.l1, self.linf = [], []
         self._last = None
         self._push(p)
 
     def _push(self, col):
-        self.mat.set_column(self.count, col)
+        from pygrank_amd.device import DeviceMatrix
+        slab, at = divmod(self.count, self.WIDTH)
+        if slab == len(self.slabs):
+            self.slabs.append(DeviceMatrix.empty(self.n, self.WIDTH))
+        self.slabs[slab].set_column(at, col)
         self.l1.append(float(col.abssum()))
         self.linf.append(float(backend.max(backend.abs(col))) if len(col) else 0.0)
         self._last = col
         self.count += 1
 
     def ensure(self, columns):
-        """Makes the first `columns` powers available; False when they do not fit the slab."""
-        if columns > self.WIDTH:
+        """Makes the first `columns` powers available; False when that is more than a slab set may hold."""
+        if columns > self.MAX_TERMS:
             return False
         while self.count < columns:
             self._push(self.graph.conv(self._last))
         return True
+
+    def combine(self, coeffs):
+        """sum_k coeffs[k] * power_k as a DeviceVector (coeffs: 1-D, at most `count` long)."""
+        c = np.asarray(coeffs, dtype=np.float64)
+        out = None
+        for slab, first in zip(self.slabs, range(0, len(c), self.WIDTH)):
+            part = slab.gemv(c[first:first + self.WIDTH])
+            out = part if out is None else out + part
+        return out if out is not None else backend.repeat(0.0, self.n)
+
+    def combine_many(self, coeff_matrix):
+        """[terms, P] coefficients -> [n, P] slab of results (P <= 64): every slab is read once for all P probes."""
+        c = np.asarray(coeff_matrix, dtype=np.float64)
+        out = None
+        for slab, first in zip(self.slabs, range(0, c.shape[0], self.WIDTH)):
+            out = slab.gemm(c[first:first + self.WIDTH], out=out, accumulate=out is not None)
+        return out
 
 
 class ClosedFormGraphFilter(GraphFilter):
@@ -410,28 +472,40 @@ class ClosedFormGraphFilter(GraphFilter):
         self.optimization_dict = optimization_dict
         self._active_dict = None
 
-    def _start(self, M, personalization, ranks, *args, **kwargs):                 # abstract_filters.py:196-213
-        self.coefficient = None
+    _FORMS = ("taylor", "chebyshev")
+
+    def _start(self, M, personalization, ranks, *args, **kwargs):
+        """abstract_filters.py:196-213: the sum starts empty, the running term is the personalization itself."""
+        self.coefficient, self.ranks_power = None, personalization.np
         if self.coefficient_type == "chebyshev":
             self.prev_term = 0
-        self.ranks_power = personalization.np
         ranks.np = backend.repeat(0.0, backend.length(ranks.np))
 
-    def _recursion(self, result, next_term, next_coefficient):                    # abstract_filters.py:215-230
-        if self.coefficient_type == "chebyshev":
-            if self.convergence.iteration == 2:
-                self.prev_term = next_term
-            if self.convergence.iteration > 2:
+    def _recursion(self, result, next_term, next_coefficient):
+        """One term of the expansion (abstract_filters.py:215-230) -> (sum so far, term to propagate next).  "taylor": the
+        term as it comes.  "chebyshev", as the reference defines it: from the third iteration on the term is 2 * term -
+        previous term, the previous term being whatever was propagated at iteration 2 or later; a zero coefficient skips
+        the addition (at iteration 2 and before, the reference adds even then)."""
+        form = self.coefficient_type
+        if form not in self._FORMS:
+            raise Exception("Invalid coefficient type")
+        it = self.convergence.iteration
+        skip_zero = form == "taylor" or it > 2
+        if form == "chebyshev" and it >= 2:
+            if it > 2:
                 next_term = 2 * next_term - self.prev_term
-                self.prev_term = next_term
-                if self.coefficient == 0:
-                    return result, next_term
-            return result + next_term * next_coefficient, next_term
-        elif self.coefficient_type == "taylor":
-            if self.coefficient == 0:
-                return result, next_term
-            return result + next_term * next_coefficient, next_term
-        raise Exception("Invalid coefficient type")
+            self.prev_term = next_term
+        if skip_zero and self.coefficient == 0:
+            return result, next_term
+        return result + next_term * next_coefficient, next_term
+
+    def references(self):
+        refs = super().references()
+        if self.coefficient_type == "chebyshev":
+            refs.append("Chebyshev recurrence of the terms")
+        if self.optimization_dict is not None:
+            refs.append("stored powers of the personalization (optimization dictionary)")
+        return refs
 
     def _prepare(self, personalization):                                          # abstract_filters.py:232-239
         if self.optimization_dict is not None:
@@ -477,42 +551,109 @@ class ClosedFormGraphFilter(GraphFilter):
             self.convergence.iteration = saved
         return coeffs
 
-    def _fused_from_powers(self, M, personalization, ranks, out_scale):
-        """optimization_dict route: the filter as ONE pass over the stored powers of this personalization.  The stopping
-        iteration follows ConvergenceManager (convergence.py:77-101) on the exact change of every step, |c_k| * ||term_k||
-        (the reference compares result_k with result_{k-1} = result_k - c_k term_k)."""
+    def _slab_for(self, M, personalization):
+        """The power slab of this personalization inside the active optimisation dict, or None when this configuration
+        cannot be served from stored powers."""
         cm = self.convergence
         g = _device_graph(M)
         p = personalization.np
         if type(cm) is not ConvergenceManager or cm.device_error_kind() is None or g is None or g.shape[0] != g.shape[1] \
                 or not isinstance(p, DeviceVector) or self.coefficient_type != "taylor" or self._active_dict is None:
-            return False
+            return None
         slab = self._active_dict.get("powers")
         if not isinstance(slab, _PowerSlab) or slab.graph is not g:
             slab = _PowerSlab(g, p)
             self._active_dict["powers"] = slab
-        kind, tol, n = cm.device_error_kind(), cm.effective_tolerance(), max(len(p), 1)
+        return slab
+
+    def _expansion(self, slab, n):
+        """Coefficients of the terms ConvergenceManager (convergence.py:77-101) lets through, decided on the exact change of
+        every step, |c_k| * ||term_k|| (the reference compares result_k with result_{k-1} = result_k - c_k term_k).  Returns
+        (coeffs, iteration at exit, converged, last change) or None when the slab cannot hold that many powers;
+        ``convergence.iteration`` is left as it was."""
+        cm = self.convergence
+        kind, tol = cm.device_error_kind(), cm.effective_tolerance()
+        saved = cm.iteration
         coeffs, prev, it, converged, delta = [], None, 0, False, None
-        while True:
-            it += 1
-            if it >= cm.max_iters:
-                break
-            if delta is not None and kind != L.ERR_ITERS and it % cm.end_modulo == 0 and delta <= tol:
-                converged = True
-                break
-            cm.iteration = it                           # _coefficient reads convergence.iteration
-            prev = self._coefficient(prev)
-            if not slab.ensure(it):
-                return False                            # more terms than the slab holds: the step-by-step route
-            c = float(prev)
-            coeffs.append(c)
-            norm = slab.linf[it - 1] if kind == L.ERR_LINF else slab.l1[it - 1]
-            delta = abs(c) * norm / (n if kind == L.ERR_MABS else 1)
-        ranks.np = slab.mat.gemv(np.asarray(coeffs, dtype=np.float64) * float(out_scale)) if coeffs \
-            else backend.repeat(0.0, len(p))
+        try:
+            while True:
+                it += 1
+                if it >= cm.max_iters:
+                    break
+                if delta is not None and kind != L.ERR_ITERS and it % cm.end_modulo == 0 and delta <= tol:
+                    converged = True
+                    break
+                cm.iteration = it                           # _coefficient reads convergence.iteration
+                prev = self._coefficient(prev)
+                if not slab.ensure(it):
+                    return None
+                c = float(prev)
+                coeffs.append(c)
+                norm = slab.linf[it - 1] if kind == L.ERR_LINF else slab.l1[it - 1]
+                delta = abs(c) * norm / (n if kind == L.ERR_MABS else 1)
+        finally:
+            cm.iteration = saved
+        return coeffs, it, converged, delta
+
+    def _fused_from_powers(self, M, personalization, ranks, out_scale):
+        """optimization_dict route: the filter as ONE pass over the stored powers of this personalization."""
+        slab = self._slab_for(M, personalization)
+        if slab is None:
+            return False
+        n = max(len(personalization.np), 1)
+        plan = self._expansion(slab, n)
+        if plan is None:
+            return False                                    # more terms than slabs may hold: the step-by-step route
+        coeffs, it, converged, delta = plan
+        ranks.np = slab.combine(np.asarray(coeffs, dtype=np.float64) * float(out_scale)) if coeffs \
+            else backend.repeat(0.0, len(personalization.np))
         self.last_loop = dict(iterations=it, converged=converged, spmv=0, last_error=delta, loop_ms=0.0, terms=len(coeffs))
-        cm.finish_device_loop(it, converged)
+        self.convergence.finish_device_loop(it, converged)
         return True
+
+    def rank_many(self, graph, personalization, variants):
+        """The ranks of SEVERAL filters of this class on ONE personalization as the columns of an [n, P] device slab
+        (P <= 64) -- the probes of an optimiser (autotune/parameterized.py:94-145: every probe differs in the coefficients
+        only) or the candidate parameters of a sweep, evaluated in one pass over the stored powers (pgh_mat_gemm).
+        `variants`: filters like this one (same graph pipeline, same convergence settings are NOT required: every variant
+        stops by its own rule).  Needs an optimisation dict on self (its powers are shared) and the "taylor" form; returns
+        (DeviceMatrix, [iterations of every variant])."""
+        if self.optimization_dict is None:
+            raise Exception("rank_many evaluates stored powers: construct the filter with optimization_dict={}")
+        if len(variants) < 1 or len(variants) > 64:
+            raise Exception("rank_many takes 1 to 64 variants")
+        personalization = to_signal(graph, personalization)
+        self._prepare(personalization)
+        personalization = self.personalization_transform(personalization)
+        raw = personalization.np
+        norm = raw.abssum() if isinstance(raw, DeviceVector) else backend.sum(backend.abs(raw))
+        from pygrank_amd.device import DeviceMatrix
+        if norm == 0:
+            return DeviceMatrix.from_columns([backend.repeat(0.0, len(raw))] * len(variants)), [0] * len(variants)
+        personalization = to_signal(personalization, personalization.np / norm)
+        M = self.preprocessor(self._prepare_graph(personalization.graph, personalization))
+        slab = self._slab_for(M, personalization)
+        if slab is None:
+            raise Exception("rank_many needs the engine's graph, the taylor form and a plain ConvergenceManager")
+        n = max(len(personalization.np), 1)
+        columns, iterations = [], []
+        for v in variants:
+            if not isinstance(v, ClosedFormGraphFilter) or v.coefficient_type != "taylor":
+                raise Exception("rank_many variants must be taylor-form closed-form filters")
+            v.convergence.start()
+            plan = v._expansion(slab, n)
+            if plan is None:
+                raise Exception("a variant needs more powers than the slabs may hold")
+            coeffs, it, converged, _ = plan
+            v.convergence.finish_device_loop(it, converged)
+            scale = norm if v.preserve_norm else 1.0
+            columns.append(np.asarray(coeffs, dtype=np.float64) * scale)
+            iterations.append(it)
+        terms = max((len(c) for c in columns), default=0)
+        C_ = np.zeros((max(terms, 1), len(columns)))
+        for q, c in enumerate(columns):
+            C_[:len(c), q] = c
+        return slab.combine_many(C_), iterations
 
     def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
         if args or kwargs or type(self)._step is not ClosedFormGraphFilter._step \
@@ -553,6 +694,9 @@ class GenericGraphFilter(ClosedFormGraphFilter):
             return 0
         return self.weights[self.convergence.iteration - 1]
 
+    def _reference(self):
+        return f"graph filter with {len(self.weights)} hop weights"
+
 
 class HeatKernel(ClosedFormGraphFilter):
     """adhoc.py:93-122."""
@@ -564,6 +708,9 @@ class HeatKernel(ClosedFormGraphFilter):
     def _coefficient(self, previous_coefficient):                                 # adhoc.py:113-116
         return 1. if previous_coefficient is None else (previous_coefficient * self.t / (self.convergence.iteration + 1))
 
+    def _reference(self):
+        return f"heat kernel (t = {self.t:g})"
+
 
 class PageRankClosed(ClosedFormGraphFilter):
     """adhoc.py:63-90."""
@@ -574,5 +721,8 @@ class PageRankClosed(ClosedFormGraphFilter):
 
     def _coefficient(self, previous_coefficient):                                 # adhoc.py:83-84
         return 1. if previous_coefficient is None else (previous_coefficient * self.alpha)
+
+    def _reference(self):
+        return f"PageRank as a power series (alpha = {self.alpha:g})"
 
 

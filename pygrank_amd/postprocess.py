@@ -38,6 +38,15 @@ class Postprocessor(NodeRanking):
         self.ranker = ranker
         return ranker
 
+    # self-description: the wrapped algorithm's parts, then this step (postprocess.py: references() of every postprocessor
+    # extends the inner ranker's list)
+    def _reference(self):
+        return type(self).__name__.lower() + " postprocessing"
+
+    def references(self):
+        inner = list(self.ranker.references()) if self.ranker is not None else []
+        return inner + [self._reference()]
+
     # a wrapped filter's collaborators show through, so that ``postprocessor.convergence`` works like the filter's
     preprocessor = property(lambda self: self.ranker.preprocessor)
     convergence = property(lambda self: self.ranker.convergence,
@@ -46,6 +55,9 @@ class Postprocessor(NodeRanking):
 
 class Tautology(Postprocessor):
     """Changes nothing; without an inner ranker ``rank`` turns its input into a signal."""
+
+    def references(self):
+        return list(self.ranker.references()) if self.ranker is not None else ["tautology"]
 
     def transform(self, ranks, *args, **kwargs):
         return ranks

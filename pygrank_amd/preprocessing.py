@@ -16,47 +16,47 @@ from pygrank_amd.signals import _IdentityMap
 
 
 class Adjacency:
-    """preprocessing.py:9-28: wrapper that lets immutable matrix primitives carry pygrank metadata."""
+    """preprocessing.py:9-28: a thin owner of a backend matrix -- backend graph types are immutable handles, so the
+    metadata a preprocessor attaches (cache of outcomes, node order) hangs on this object instead."""
 
     def __init__(self, array):
         self.array = array
-        if hasattr(array, "shape"):
-            self.shape = array.shape
-
-    def _np(self):
-        return self.array
-
-    def sum(self, axis=None):
-        return self.array.sum(axis)
-
-    def tocoo(self):
-        return self.array.tocoo()
+        shape = getattr(array, "shape", None)
+        if shape is not None:
+            self.shape = shape
 
     def __len__(self):
         return len(self.array)
 
+    def __getattr__(self, name):
+        # sum / tocoo of the wrapped matrix (what the reference forwards explicitly); anything else is not part of a graph
+        if name in ("sum", "tocoo"):
+            return getattr(self.array, name)
+        raise AttributeError(name)
+
+    def _np(self):
+        return self.array
+
 
 class AdjacencyWrapper:
-    """fastgraph/wrapgraph.py:4-22: O(1) wrap of a scipy matrix as a graph whose nodes are range(n)."""
+    """fastgraph/wrapgraph.py:4-22: a scipy matrix presented as a graph over the nodes 0 .. n - 1, in O(1)."""
 
     def __init__(self, adj, directed=True):
-        if hasattr(adj, "array"):
-            adj = adj.array
-        self.adj = adj
-        self.num_nodes = adj.shape[0]
+        self.adj = getattr(adj, "array", adj)               # an Adjacency hands over what it owns
         self.directed = directed
+        self.num_nodes = self.adj.shape[0]
 
     def is_directed(self):
         return self.directed
 
-    def __iter__(self):
-        return iter(range(self.num_nodes))
+    def to_scipy_sparse_array(self):
+        return self.adj
 
     def __len__(self):
         return self.num_nodes
 
-    def to_scipy_sparse_array(self):
-        return self.adj
+    def __iter__(self):
+        yield from range(self.num_nodes)
 
 
 def _row_sums(M):                                           # numpy.py:76-77
@@ -171,37 +171,45 @@ def to_sparse_matrix(G, normalization="auto", weight="weight", renormalize=False
     return ret
 
 
-def obj2id(obj):                                            # preprocessing.py:165-170
-    if isinstance(obj, object) and not isinstance(obj, str):
-        if not hasattr(obj, "uuid"):
-            obj.uuid = uuid.uuid1()
-        return str(obj.uuid)
-    return str(hash(obj))
+def obj2id(obj):
+    """A stable key for an argument (preprocessing.py:165-170): strings by hash, every other object by a uuid that is
+    attached to it on first sight -- so two equal-looking graphs stay distinct and a graph keeps its key while it lives."""
+    if isinstance(obj, str):
+        return str(hash(obj))
+    tag = getattr(obj, "uuid", None)
+    if tag is None:
+        tag = obj.uuid = uuid.uuid1()
+    return str(tag)
 
 
-def _idfier(*args, **kwargs):                               # preprocessing.py:173-178
-    return "[" + ",".join(obj2id(arg) for arg in args) + "]" + \
-        "{" + ",".join(v + ":" + obj2id(kwarg) for v, kwarg in kwargs.items()) + "}" + backend.backend_name()
+def _call_key(args, kwargs):
+    """Key of a call for MethodHasher: positional identities, named identities, and the active backend (a graph
+    preprocessed under another backend is another object)."""
+    positional = ",".join(map(obj2id, args))
+    named = ",".join(name + ":" + obj2id(value) for name, value in kwargs.items())
+    return f"[{positional}]{{{named}}}{backend.backend_name()}"
 
 
 class MethodHasher:
-    """preprocessing.py:181-230: memoises a method on the identity of its arguments and the backend name."""
+    """preprocessing.py:181-230: remembers the outcome of a method per call key (_call_key) while the caller promises not
+    to mutate the arguments; without that promise every call goes through."""
 
     def __init__(self, method, assume_immutability=True):
+        self._method, self._stored = method, {}
         self.assume_immutability = assume_immutability
-        self._method = method
-        self._stored = dict()
 
     def clear_hashed(self):
-        self._stored = dict()
+        self._stored.clear()
 
     def __call__(self, *args, **kwargs):
         if not self.assume_immutability:
             return self._method(*args, **kwargs)
-        desc = _idfier(*args, **kwargs)
-        if desc not in self._stored:
-            self._stored[desc] = self._method(*args, **kwargs)
-        return self._stored[desc]
+        key = _call_key(args, kwargs)
+        try:
+            return self._stored[key]
+        except KeyError:
+            outcome = self._stored[key] = self._method(*args, **kwargs)
+            return outcome
 
 
 def preprocessor(normalization="auto", assume_immutability=False, weight="weight", renormalize=False,

@@ -283,12 +283,17 @@ def check_optimization_dict(pg):                             # tests/test_filter
 
 
 def check_power_slab_serves_tuner_probes(pg):
-    """with an optimisation dict the powers {(M^T)^k p} of a personalization live in ONE device slab and every
+    """with an optimisation dict the powers {(M^T)^k p} of a personalization live in device slabs and every
     further filter on that personalization (a tuner probing weight vectors, autotune/parameterized.py:135-145) is one pass
-    over it -- same results and iteration counts as the step-by-step loops, no further convolutions."""
+    over them.  Checked against the ORACLE's restatement of the reference loop (oracle/ref_loops.py: generic_filter /
+    heat_kernel / pagerank_closed -- abstract_filters.py:196-256), not against the engine's own step-by-step route: ranks to
+    1e-6, equal iteration counts, no further convolutions."""
     import cases
+    from oracle import ref_loops as orc
     A, directed, p = cases.GRAPHS["rmat10_dir"]()
     graph = pg.AdjacencyWrapper(A, directed=directed)
+    M = orc.normalize(A, "auto", directed)
+    eps32 = float(np.finfo(np.float32).eps)
     pre = pg.preprocessor(assume_immutability=True)
     signal = pg.to_signal(graph, p.copy())
     cache = dict()
@@ -298,25 +303,72 @@ def check_power_slab_serves_tuner_probes(pg):
     for weights in probes:
         cached = pg.GenericGraphFilter(weights, preprocessor=pre, optimization_dict=cache, tol=1e-8, max_iters=100)
         got = np.asarray(cached.rank(signal).np, dtype=np.float64)
-        plain = pg.GenericGraphFilter(weights, preprocessor=pre, tol=1e-8, max_iters=100)
-        want = np.asarray(plain.rank(signal).np, dtype=np.float64)
-        assert cached.convergence.iteration == plain.convergence.iteration, weights
+        want, want_iters = orc.generic_filter(M, p, weights, tol=1e-8, max_iters=100, eps=eps32)
+        assert cached.convergence.iteration == want_iters, (weights, cached.convergence.iteration, want_iters)
         assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), weights
         assert cached.last_loop["spmv"] == 0 and cached.last_loop["terms"] == cached.convergence.iteration - 1
         slab = next(iter(cache.values()))["powers"]
         columns = max(columns or 0, slab.count)
-        assert slab.count == columns                      # the slab only ever grows to the longest probe
+        assert slab.count == columns                      # the slabs only ever grow to the longest probe
     assert len(cache) == 1 and columns <= 14
     # HeatKernel to a tolerance through the same slab machinery, and the non-convergence exception
     hk = pg.HeatKernel(3, preprocessor=pre, optimization_dict=dict(), tol=1e-7, max_iters=60)
-    ref = pg.HeatKernel(3, preprocessor=pre, tol=1e-7, max_iters=60)
-    a, b = np.asarray(hk.rank(signal).np, dtype=np.float64), np.asarray(ref.rank(signal).np, dtype=np.float64)
-    assert hk.convergence.iteration == ref.convergence.iteration and np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(b))
+    a = np.asarray(hk.rank(signal).np, dtype=np.float64)
+    b, b_iters = orc.heat_kernel(M, p, t=3, tol=1e-7, max_iters=60, eps=eps32)
+    assert hk.convergence.iteration == b_iters and np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(b))
     try:
         pg.HeatKernel(3, preprocessor=pre, optimization_dict=dict(), tol=1e-12, max_iters=5).rank(signal)
         raise AssertionError("expected a non-convergence exception")
     except Exception as exc:
         assert "converge" in str(exc)
+    # expansions of MORE than one slab's 64 powers (the route used to leave convergence.iteration behind when it
+    # gave up at 65 terms): PageRankClosed alpha = 0.9 needs ~150 terms for 1e-7, HeatKernel t = 30 ~90
+    for make, ref in ((lambda **kw: pg.PageRankClosed(0.9, preprocessor=pre, tol=1e-7, max_iters=400, **kw),
+                       lambda: orc.pagerank_closed(M, p, alpha=0.9, tol=1e-7, max_iters=400, eps=eps32)),
+                      (lambda **kw: pg.HeatKernel(30, preprocessor=pre, tol=1e-7, max_iters=400, **kw),
+                       lambda: orc.heat_kernel(M, p, t=30, tol=1e-7, max_iters=400, eps=eps32))):
+        long_cache = dict()
+        algo = make(optimization_dict=long_cache)
+        got = np.asarray(algo.rank(signal).np, dtype=np.float64)
+        want, want_iters = ref()
+        assert want_iters > 66 and algo.convergence.iteration == want_iters, (algo.convergence.iteration, want_iters)
+        assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
+        assert algo.last_loop["spmv"] == 0 and len(next(iter(long_cache.values()))["powers"].slabs) >= 2
+        again = make(optimization_dict=long_cache)      # second probe: served from the slabs, same answer
+        assert np.array_equal(np.asarray(again.rank(signal).np), np.asarray(algo.rank(signal).np))
+
+
+def check_rank_many_probes_in_one_pass(pg):
+    """SURVEY.md 8f-2 "many probes as one GEMM": P coefficient vectors on one personalization -> an [n, P] slab from ONE pass
+    over the stored powers (pgh_mat_gemm); every column against the oracle's loop for that probe (abstract_filters.py:
+    196-256 as restated in oracle/ref_loops.py), with that probe's own stopping iteration."""
+    import cases
+    from oracle import ref_loops as orc
+    A, directed, p = cases.GRAPHS["rmat10_dir"]()
+    graph = pg.AdjacencyWrapper(A, directed=directed)
+    M = orc.normalize(A, "auto", directed)
+    eps32 = float(np.finfo(np.float32).eps)
+    pre = pg.preprocessor(assume_immutability=True)
+    rng = np.random.default_rng(9)
+    weight_sets = [list(rng.random(int(k))) for k in rng.integers(3, 40, size=21)] + [[1.0], [0.0, 0.0, 1.0]]
+    cache = dict()
+    head = pg.GenericGraphFilter(weight_sets[0], preprocessor=pre, optimization_dict=cache, tol=1e-8, max_iters=100)
+    variants = [pg.GenericGraphFilter(w, preprocessor=pre, tol=1e-8, max_iters=100) for w in weight_sets]
+    slab, iterations = head.rank_many(graph, p.copy(), variants)
+    got = np.asarray(slab.numpy() if hasattr(slab, "numpy") else slab, dtype=np.float64)
+    assert got.shape == (len(p), len(weight_sets))
+    for q, w in enumerate(weight_sets):
+        want, want_iters = orc.generic_filter(M, p, w, tol=1e-8, max_iters=100, eps=eps32)
+        assert iterations[q] == want_iters, (q, iterations[q], want_iters)
+        assert np.max(np.abs(got[:, q] - want)) <= 1e-6 * np.max(np.abs(want)), q
+    # heat kernels of different t through the same powers (a parameter sweep), one of them beyond 64 terms
+    ts = [1.0, 3.0, 5.0, 30.0]
+    hk = [pg.HeatKernel(t, preprocessor=pre, tol=1e-7, max_iters=400) for t in ts]
+    slab, iterations = head.rank_many(graph, p.copy(), hk)
+    got = np.asarray(slab.numpy(), dtype=np.float64)
+    for q, t in enumerate(ts):
+        want, want_iters = orc.heat_kernel(M, p, t=t, tol=1e-7, max_iters=400, eps=eps32)
+        assert iterations[q] == want_iters and np.max(np.abs(got[:, q] - want)) <= 1e-6 * np.max(np.abs(want)), t
 
 
 def check_device_postprocessors_and_measures(pg):
@@ -401,3 +453,22 @@ def check_warm_start_and_propagate(pg):                      # abstract_filters.
 
 
 ALL = [v for k, v in sorted(globals().items()) if k.startswith("check_") and callable(v)]
+
+
+def check_algorithms_describe_themselves(pg):
+    """NodeRanking.cite / references / __str__ (signals.py:228-249; abstract_filters.py:79-86,145-149,186-194): a list of parts,
+    read out as "first with second, third and last"; a chained personalization transform is cited ahead of the filter."""
+    plain = pg.PageRank(0.85)
+    assert plain.references() == [plain._reference()] and str(plain) == plain.cite() == plain._reference()
+    eig = pg.PageRank(0.9, converge_to_eigenvectors=True)
+    assert len(eig.references()) == 2 and " with " in eig.cite() and " and " not in eig.cite()
+    cheb = pg.HeatKernel(3, coefficient_type="chebyshev", optimization_dict=dict())
+    refs = cheb.references()
+    assert len(refs) == 3 and cheb.cite() == refs[0] + " with " + refs[1] + " and " + refs[2]
+    post = pg.Normalize(pg.Ordinals(pg.AbsorbingWalks(0.9)))
+    assert len(post.references()) == 3 and post.references()[0] == pg.AbsorbingWalks(0.9)._reference()
+    chained = pg.PageRank(0.5) >> pg.HeatKernel(2)
+    assert chained.cite().endswith("passed to " + pg.HeatKernel(2).cite()) and chained.cite().startswith(pg.PageRank(0.5).cite())
+    for algo in (pg.SymmetricAbsorbingRandomWalks(), pg.GenericGraphFilter([0.5, 0.5]), pg.PageRankClosed(0.7), pg.Top(3), pg.Threshold(0.1),
+                 pg.Sweep(pg.PageRank()), pg.LinearSweep(pg.PageRank()), pg.Transformer(), pg.Tautology()):
+        assert isinstance(str(algo), str) and len(str(algo)) > 3

@@ -156,6 +156,11 @@ def check_graph_dropout(pg):
         ref = masked @ x
         scale = np.abs(masked) @ np.abs(x)
         assert np.all(np.abs(got - ref) <= 2.5 * EPS32 * scale + 1e-30), rate
+        # degrees of the dropped graph = row sums of the masked M (pytorch.py:100-104 on the dropped matrix): column sums of
+        # the masked CSR(M^T), exactly rebuilt here
+        deg = _np(pg.degrees(dropped))
+        deg_ref = np.asarray(masked.sum(axis=0)).ravel()
+        assert np.all(np.abs(deg - deg_ref) <= 4 * EPS32 * np.abs(deg_ref) + 1e-30), rate
         again = pg.graph_dropout(g, rate)                          # a new mask at every call (abstract_filters.py:59-62)
         assert again.seed != dropped.seed and not np.array_equal(_np(pg.conv(_vec(pg, x), again)), got)
     # E[dropout] = identity: the mean over masks approaches the plain product
@@ -177,6 +182,11 @@ def check_graph_dropout(pg):
     assert np.array_equal(outs[0], outs[1]) and abs(outs[0].sum() - 20.0) < 1e-3
     base = np.asarray(pg.PageRank(0.85, error_type="iters", max_iters=12).rank(graph, p.copy()).np)
     assert not np.allclose(outs[0], base) and np.corrcoef(outs[0], base)[0, 1] > 0.9
+    # filters that ask for degrees(M) in _start run with a dropped graph too
+    for algo in (pg.AbsorbingWalks(0.85, error_type="iters", max_iters=8), pg.SymmetricAbsorbingRandomWalks(error_type="iters", max_iters=8)):
+        pg.backend.hip.set_dropout_seed(11)
+        out = np.asarray(algo.rank(graph, p.copy(), graph_dropout=0.3).np)
+        assert np.all(np.isfinite(out)) and out.sum() > 0
 
 
 def check_fused_steps(pg):
