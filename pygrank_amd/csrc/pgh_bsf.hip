@@ -273,7 +273,7 @@ __global__ void k_bsf_meta_init(SegMeta* __restrict__ meta, int64_t count) {
 __global__ void k_bsf_block_starts(const uint64_t* __restrict__ keys, int64_t E, int B, int64_t* __restrict__ starts) {
     const int b = threadIdx.x;
     if (b > B) return;
-    const uint64_t target = (uint64_t)b << 58;
+    const uint64_t target = b < 64 ? (uint64_t)b << 58 : ~0ULL;        // b == B == 64: past every key
     int64_t lo = 0, hi = E;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -283,8 +283,8 @@ __global__ void k_bsf_block_starts(const uint64_t* __restrict__ keys, int64_t E,
 }
 
 struct PadLayout {
-    int64_t src_start[9];     // first sorted entry of every block (src_start[B] = E)
-    int64_t dst_start[9];     // first padded slot of every block (multiples of the tile size)
+    int64_t src_start[kMaxBlocks + 1];     // first sorted entry of every block (src_start[B] = E)
+    int64_t dst_start[kMaxBlocks + 1];     // first padded slot of every block (multiples of the tile size)
     int     B;
 };
 
@@ -303,8 +303,8 @@ __global__ void k_bsf_pad(PadLayout pl, const uint64_t* __restrict__ keys, const
 }
 
 struct TileBuild {
-    int64_t block_start[9];
-    int     tile_begin[9];
+    int64_t block_start[kMaxBlocks + 1];
+    int     tile_begin[kMaxBlocks + 1];
     int     B;
 };
 
@@ -1142,6 +1142,7 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.deg_int);
     (void)hipFree(f.fix_seg);
     (void)hipFree(f.psum);
+    (void)hipFree(f.psum64);
     (void)hipFree(f.meta);
     (void)hipFree(f.live_dev);
     (void)hipFree(f.val);
@@ -1213,6 +1214,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     PGH_CHECK(n_src < (1LL << 28) && n_out < (1LL << 28), "blocked format needs fewer than 2^28 rows/columns");
     if (relabel && n_src != n_out) relabel = false;
     const int B = force_blocks > 0 ? force_blocks : bsf_auto_blocks(n_src);
+    PGH_CHECK(B >= 1 && B <= kMaxBlocks && (B <= 8 || (target != nullptr && target != &g->bsf)), "blocked format: unsupported number of column blocks");
     const int blk = (int)((n_src + B - 1) / B);
     const int n_src_pad = B * blk;
     f.num_blocks = B;
@@ -1243,12 +1245,13 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         unsigned int live_nodes = 0;
         PGH_HIP(hipMemcpyAsync(&live_nodes, live_count.p, sizeof(unsigned int), hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
-        for (int b = 0; b < B; ++b) {
+        f.live_nodes = iso_on ? (int64_t)live_nodes : -1;
+        for (int b = 0; b < B && b < 8; ++b) {
             // ranks r = b, b + B, ... land in block b at slot r / B: the first isolated slot, rounded up to whole float4s
             const int64_t first_iso = ((int64_t)live_nodes - b + B - 1) / B;
             f.iso_begin[b] = (int)std::min<int64_t>(blk, (std::max<int64_t>(first_iso, 0) + 3) & ~(int64_t)3);
         }
-        f.has_iso = iso_on;
+        f.has_iso = iso_on && B <= 8;
         f.iso_row_blocks = B;
     } else if (g->part_perm != nullptr && g->part_live_nodes >= 0 && n_out > 0 && n_out % blk == 0 && g->row_begin % blk == 0 &&
                (target == nullptr || target == &g->bsf)) {
@@ -1300,20 +1303,21 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     k_bsf_sentinels<<<1, 64, 0, r.stream>>>(keys_a.p, E - B, B, n_src_pad);
     PGH_HIP(hipGetLastError());
     {
+        const int sort_bits = B > 8 ? 64 : 61;             // block id from bit 58 up
         size_t temp_bytes = 0;
-        if (val) PGH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a.p, keys_b.p, vals_a.p, f.val, (int)E, 0, 61, r.stream));
-        else PGH_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_a.p, keys_b.p, (int)E, 0, 61, r.stream));
+        if (val) PGH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a.p, keys_b.p, vals_a.p, f.val, (int)E, 0, sort_bits, r.stream));
+        else PGH_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_a.p, keys_b.p, (int)E, 0, sort_bits, r.stream));
         DevBuf<char> temp;
         PGH_TRY(temp.alloc(temp_bytes));
-        if (val) PGH_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.p, keys_b.p, vals_a.p, f.val, (int)E, 0, 61, r.stream));
-        else PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)E, 0, 61, r.stream));
+        if (val) PGH_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.p, keys_b.p, vals_a.p, f.val, (int)E, 0, sort_bits, r.stream));
+        else PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)E, 0, sort_bits, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
     // ---- referenced prefix of every block (over ALL entries), then the cold tail moves to its own image (pgh_pb.hip)
-    int live_all[8] = {0};
+    int live_all[kMaxBlocks] = {0};
     {
         DevBuf<int32_t> d_live;
-        PGH_TRY(d_live.alloc(8, true));
+        PGH_TRY(d_live.alloc(kMaxBlocks, true));
         k_bsf_live<<<blocks_for(E), kBlock, 0, r.stream>>>(keys_b.p, E, blk, d_live.p);
         PGH_HIP(hipMemcpyAsync(live_all, d_live.p, sizeof(live_all), hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
@@ -1369,15 +1373,15 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     //      Pad entries repeat the block's sentinel key: no flag, they only feed the sentinel's never-closed segment.
     TileBuild tb;
     tb.B = B;
-    int64_t h[9] = {0};
+    int64_t h[kMaxBlocks + 1] = {0};
     {
         DevBuf<int64_t> starts;
-        PGH_TRY(starts.alloc(9));
-        k_bsf_block_starts<<<1, 64, 0, r.stream>>>(keys_b.p, E, B, starts.p);
+        PGH_TRY(starts.alloc(kMaxBlocks + 1));
+        k_bsf_block_starts<<<1, 128, 0, r.stream>>>(keys_b.p, E, B, starts.p);
         PGH_HIP(hipMemcpyAsync(h, starts.p, sizeof(int64_t) * (B + 1), hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
         int tiles = 0;
-        for (int b = 0; b <= 8; ++b) {
+        for (int b = 0; b <= kMaxBlocks; ++b) {
             tb.tile_begin[b] = tiles;
             f.tile_begin[b] = tiles;
             tb.block_start[b] = (int64_t)tiles * kTile;
@@ -1397,7 +1401,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     {
         PadLayout pl;
         pl.B = B;
-        for (int b = 0; b <= 8; ++b) {
+        for (int b = 0; b <= kMaxBlocks; ++b) {
             pl.src_start[b] = b <= B ? h[b] : E;
             pl.dst_start[b] = tb.block_start[b];
         }
@@ -1427,7 +1431,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     // are never used, but they must stay inside the allocation: found by tools/stress_gpu.py as a rare memory fault)
     PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1)));
     PGH_HIP(hipMemsetAsync(f.seg_row, 0xff, sizeof(int32_t) * (size_t)(f.num_segs + 1), r.stream));
-    if (!batch_layout) {                               // SpMV layout: the row -> segment map of the compact partial sums
+    if (!batch_layout || f.want_meta) {                // SpMV layouts: the row -> segment map of the compact partial sums
         f.meta_words = ((int64_t)(f.n_out > 0 ? f.n_out : 1) + 63) / 64;
         PGH_HIP(hipMalloc(&f.meta, sizeof(SegMeta) * (size_t)(f.meta_words * B)));
         k_bsf_meta_init<<<blocks_for(f.meta_words * B), kBlock, 0, r.stream>>>(f.meta, f.meta_words * B);

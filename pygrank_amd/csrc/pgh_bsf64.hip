@@ -1,0 +1,527 @@
+// The f64 route of the reference's "chebyshev" recurrence on the blocked segment-flag stream.
+//
+// Reference counterpart: ClosedFormGraphFilter._recursion with coefficient_type "chebyshev" (abstract_filters.py:216-224)
+// over conv(signal, M) = signal @ M (pygrank/core/backend/numpy.py:64-65).  Why f64: EpiPoly64 in pgh_spmv.hip (the
+// recurrence S_k = (2 M^T - I) S_{k-1} amplifies every rounding of a term; an f32 evaluation cannot hold 1e-6).
+//
+// Round 2 ran this route over the row-major CSR(M^T) (k_spmv_merge<..., double, ...>: 1.3 ms per term at RMAT scale 23, 0.12 of
+// the HBM roofline -- every one of the 134 M gathers is an 8-byte request to the L2 / fabric).  This file gives the route the
+// layout decisions of the f32 stream (pgh_bsf.hip), with 8-byte operands:
+//   * a second blocked image of the graph (pgh_graph_s::bsf64, built on first use like the multi-seed image): sources
+//     relabelled by descending reference count, dealt to 8 XCD-affine column blocks, entries sorted by (block, row, col), a
+//     flag bit opens every row segment, blocks padded to whole 512-entry wavefront tiles; cold entries STAY in the stream
+//     (an f64 propagation-blocking image would double the cold bytes);
+//   * k_bsf64_partial: one 1024-thread workgroup per CU; the first 20 224 doubles of the block's hot-first slice of the
+//     gather vector fill the LDS (158 KB), the rest of the slice is gathered through the XCD's own L2 (a block's referenced
+//     prefix is ~3.9 MB at scale 23: L2 hit rate 0.88); f64 segmented sums (DPP scans on register pairs), closed segments
+//     leave as 8-byte stores into the compact partial-sum array, pieces that cross tiles as carries;
+//   * k_bsf64_fixup closes the cross-tile segments in a fixed order; k_bsf64_combine folds a row's <= 8 block segments
+//     (SegMeta, as in the f32 layout), applies the recurrence's epilogue in f64 and writes the next gather vector.
+// Deterministic and atomic-free like the f32 path.
+#include "pgh_kernels.h"
+
+#include <cstdlib>
+
+using namespace pgh;
+
+namespace {
+
+constexpr int kT = 64 * PGH_BSF_IPT;           // entries per wavefront tile (the tile table of bsf_build)
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr int kHot64 = 20224;                  // doubles of the gather vector cached in LDS per workgroup (the LDS holds nothing else)
+constexpr int kLdsDoubles = kHot64 + 1;
+// diagnostic builds only: 1 = no cold gathers, 2 = no hot-cache reads, 4 = no stores of a lane's later segments, 8 = no scans.
+// Measured at RMAT scale 23 (profiles/r03/cheb_f64_blocked.log): 376 us as shipped; 190 without the cold gathers (a divergent
+// 8-byte gather instruction costs the CU ~50 cycles WHATEVER the number of active lanes: 32 blocks leave 10 % of the lanes
+// cold instead of 30 % and take the same time; exec-masked loads likewise), 335 without the stores, 377 without the LDS
+// reads, 373 without the scans, 146 with all four off (stream + arithmetic).
+#ifndef PGH_B64_PROBE
+#define PGH_B64_PROBE 0
+#endif
+static_assert(PGH_BSF_IPT == 8, "a lane owns 8 consecutive entries (two 16-byte words)");
+static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of one CU");
+
+struct View64 {
+    const uint32_t* colf;        // [num_entries] source (new id) | bit 31 = first entry of a row segment
+    const float*    val;         // [num_entries] or null (value-free)
+    const int4*     tile;        // {entry_start, entry_count, seg_base, chain_first}
+    double*         tail;        // [num_tiles] piece of the segment still open at the end of the tile
+    double*         head;        // [num_tiles] piece of the segment that was open when the tile started
+    double*         psum;        // [num_segs + pad] compact block partial sums
+    int             num_blocks;
+    int             blk;
+    int             tile_begin[kMaxBlocks + 1];
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+    v += dpp_i32<0x111, 0xf>(0, v);      // row_shr:1
+    v += dpp_i32<0x112, 0xf>(0, v);      // row_shr:2
+    v += dpp_i32<0x114, 0xf>(0, v);      // row_shr:4
+    v += dpp_i32<0x118, 0xf>(0, v);      // row_shr:8
+    v += dpp_i32<0x142, 0xa>(0, v);      // row_bcast:15 -> rows 1, 3
+    v += dpp_i32<0x143, 0xc>(0, v);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// inclusive segmented sum: keep = 0 on lanes that start a new segment, 1 on lanes that continue the previous lane's
+__device__ __forceinline__ double wave_segmented_sum64(int keep, double val) {
+#define PGH_SEG64(CTRL, MASK)                                      \
+    {                                                              \
+        const double v2 = dpp_f64<CTRL, MASK>(0.0, val);           \
+        const int k2 = dpp_i32<CTRL, MASK>(1, keep);               \
+        val += keep ? v2 : 0.0;                                    \
+        keep &= k2;                                                \
+    }
+    PGH_SEG64(0x111, 0xf)
+    PGH_SEG64(0x112, 0xf)
+    PGH_SEG64(0x114, 0xf)
+    PGH_SEG64(0x118, 0xf)
+    PGH_SEG64(0x142, 0xa)
+    PGH_SEG64(0x143, 0xc)
+#undef PGH_SEG64
+    return val;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool HAS_VAL>
+__global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const double* __restrict__ xg, const LoopState* __restrict__ state) {
+    __shared__ __attribute__((aligned(16))) double s_lds[kLdsDoubles];
+    if (state != nullptr && state->done) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
+    // (more than 8 blocks: an XCD's workgroups share out its num_blocks / 8 blocks -- every block's hot set is a different
+    // 11 776 sources, so the LDS of the chip caches num_blocks x 11 776 of them)
+    const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int b, rank, stride;
+    if (f.num_blocks <= 8) {
+        const int per = 8 / f.num_blocks;
+        b = label % f.num_blocks;
+        rank = (slot * per + label / f.num_blocks) * kWaves + wave;
+        stride = (gridDim.x >> 3) * per * kWaves;
+    } else {
+        const int q = f.num_blocks >> 3;                   // blocks per XCD; (gridDim.x / 8) workgroups per XCD, a multiple of q
+        b = label + 8 * (slot % q);
+        rank = (slot / q) * kWaves + wave;
+        stride = ((gridDim.x >> 3) / q) * kWaves;
+    }
+    const uint32_t base = (uint32_t)b * (uint32_t)f.blk;
+    const uint32_t hot = (uint32_t)min(kHot64, f.blk);
+    {
+        const double* __restrict__ src = xg + base;
+        for (uint32_t i = tid; i < hot; i += kThreads) s_lds[i] = src[i];
+        if (tid == 0) s_lds[hot] = 0.0;
+    }
+    __syncthreads();
+    const int t_end = f.tile_begin[b + 1];
+    int t = f.tile_begin[b] + rank;
+    if (t >= t_end) return;
+
+    struct Words {
+        u32x4 c[2];
+        f32x4 v[2];
+        int   seg_base;
+    };
+    auto load_words = [&](int tile, Words& w) __attribute__((always_inline)) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(f.colf + (int64_t)tile * kT + lane * 8);
+        w.c[0] = __builtin_nontemporal_load(p);
+        w.c[1] = __builtin_nontemporal_load(p + 1);
+        if (HAS_VAL) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(f.val + (int64_t)tile * kT + lane * 8);
+            w.v[0] = __builtin_nontemporal_load(q);
+            w.v[1] = __builtin_nontemporal_load(q + 1);
+        }
+        w.seg_base = f.tile[tile].z;
+    };
+    struct Gathered {
+        double       c[8];           // from the block's cold slice (hot lanes address outside the buffer: 0, no memory access)
+        uint32_t     at[4];          // slots of the LDS hot cache (cold lanes: its zero slot) as 16-bit pairs, read when the tile is summed
+        float        v[HAS_VAL ? 8 : 1];
+        unsigned int bits;
+        int          seg_base;
+    };
+    // the block's cold slice [hot, blk) of the gather vector as a buffer: value = h + c, no select and no divergent branch
+    const __amdgpu_buffer_rsrc_t cold_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(xg + base + hot), 0, (int)(((uint32_t)f.blk - hot) << 3), 0x00020000);
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    auto gather = [&](const Words& w, Gathered& g) __attribute__((always_inline)) {
+        unsigned int bits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t word = w.c[k >> 2][k & 3];
+            bits |= (word >> 31) << k;
+            const uint32_t loc = (word & 0x7fffffffu) - base;
+            const uint32_t slot16 = min(loc, hot);
+            g.at[k >> 1] = (k & 1) ? (g.at[k >> 1] | (slot16 << 16)) : slot16;
+            if (PGH_B64_PROBE & 1) g.c[k] = 0.0;
+            else {
+                const i32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(cold_rsrc, (int)((loc - hot) << 3), 0, 0);
+                g.c[k] = __hiloint2double(raw.y, raw.x);
+            }
+            if (HAS_VAL) g.v[k] = w.v[k >> 2][k & 3];
+        }
+        g.bits = bits;
+        g.seg_base = w.seg_base;
+    };
+    auto reduce = [&](const Gathered& g, int tile) __attribute__((always_inline)) {
+        const unsigned int bits = g.bits;
+        double h[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t slot16 = (k & 1) ? (g.at[k >> 1] >> 16) : (g.at[k >> 1] & 0xffffu);
+            h[k] = (PGH_B64_PROBE & 2) ? (double)slot16 : s_lds[slot16];
+        }
+        const int mine = __popc(bits);
+        const int incl = wave_inclusive_sum(mine);         // flags in lanes <= this one
+        const int before = incl - mine;
+        // The j-th flag of the tile (j = before + flags seen in this lane) closes the running sum: j = 0 closes the piece of
+        // the segment that was open when the tile started (-> head carry), j >= 1 closes segment j - 1 of the tile, whose sum
+        // belongs at psum[seg_base + j].  Sums closed by a lane's second and later flags are complete and leave at once
+        // (8-byte stores; neighbouring lanes write neighbouring slots); what its FIRST flag closes may have begun in
+        // earlier lanes: it waits for the stitch below.  (The first version staged all of this through an LDS strip per
+        // wavefront -- 18 more LDS instructions per tile than the 8 hot-cache reads, and the LDS is what bounds this kernel.)
+        double* __restrict__ dst = f.psum + g.seg_base + before;
+        int seen = 0;
+        double acc = 0.0, head_sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if ((bits >> k) & 1u) {
+                if (seen != 0 && !(PGH_B64_PROBE & 4)) dst[seen] = acc;
+                else head_sum = acc;
+                ++seen;
+                acc = 0.0;
+            }
+            double x = h[k] + g.c[k];
+            if (HAS_VAL) x *= (double)g.v[k];
+            acc += x;
+        }
+        // stitch across lanes: what follows a lane's last flag continues into the next lanes up to their first flag
+        const double val = (PGH_B64_PROBE & 8) ? acc : wave_segmented_sum64(mine ? 0 : 1, acc);
+        const double ev = dpp_f64<0x138, 0xf>(0.0, val);   // wave_shr:1: what the earlier lanes hold of the segment this
+        if (bits != 0u) {                                  // lane's first flag closes
+            const double first = head_sum + ev;
+            if (before == 0) f.head[tile] = first;
+            else dst[0] = first;
+        }
+        if (lane == 63) f.tail[tile] = val;
+    };
+
+    // Software pipeline per wavefront (loads are issued unconditionally on clamped tile indices, clamped results are never
+    // consumed).  What bounds the kernel is the number of 8-byte cold gathers the L2 has in flight, so the value-free shape
+    // keeps the gathers of TWO tiles in flight behind the sums (stream words one tile ahead of the gathers); valued streams
+    // carry 8 more registers per set and keep one.
+    const int t_last = t_end - 1;
+    if (!HAS_VAL) {
+        Words wa, wb;
+        Gathered g0, g1, g2;
+        load_words(t, wa);
+        load_words(min(t + stride, t_last), wb);
+        gather(wa, g0);
+        load_words(min(t + 2 * stride, t_last), wa);
+        gather(wb, g1);
+#define PGH_STEP64(WL, WG_, GN, GC)                          \
+    load_words(min(t + 3 * stride, t_last), WL);             \
+    gather(WG_, GN);                                         \
+    reduce(GC, t);                                           \
+    t += stride;                                             \
+    if (t >= t_end) break;
+        for (;;) {
+            PGH_STEP64(wb, wa, g2, g0)
+            PGH_STEP64(wa, wb, g0, g1)
+            PGH_STEP64(wb, wa, g1, g2)
+            PGH_STEP64(wa, wb, g2, g0)
+            PGH_STEP64(wb, wa, g0, g1)
+            PGH_STEP64(wa, wb, g1, g2)
+        }
+#undef PGH_STEP64
+    } else {
+        Words wa, wb;
+        Gathered g0, g1;
+        load_words(t, wa);
+        load_words(min(t + stride, t_last), wb);
+        gather(wa, g0);
+        for (;;) {
+            load_words(min(t + 2 * stride, t_last), wa);
+            gather(wb, g1);
+            reduce(g0, t);
+            t += stride;
+            if (t >= t_end) break;
+            load_words(min(t + 2 * stride, t_last), wb);
+            gather(wa, g0);
+            reduce(g1, t);
+            t += stride;
+            if (t >= t_end) break;
+        }
+    }
+}
+
+// where the fix-up of tile t goes (index into psum, -1 = nothing to fix): the segment open at the tile start closes here
+__global__ void k_bsf64_fixlist(const int4* __restrict__ tile, const int32_t* __restrict__ seg_row, int num_tiles, int32_t* __restrict__ fix_seg) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < num_tiles; t += gridDim.x * blockDim.x) {
+        const int4 ti = tile[t];
+        fix_seg[t] = (ti.w >= 0 && ti.z >= 0 && seg_row[ti.z] >= 0) ? ti.z : -1;
+    }
+}
+
+// segments that cross tiles: carries of the chain's tiles in ascending order + the head piece (fixed order); chains of 32+
+// tiles (hub rows) are summed by the whole wavefront
+__global__ __launch_bounds__(WG) void k_bsf64_fixup(const int32_t* __restrict__ fix_seg, const int4* __restrict__ tile,
+                                                     const double* __restrict__ tail, const double* __restrict__ head,
+                                                     double* __restrict__ psum, int num_tiles, const LoopState* __restrict__ state) {
+    if (state != nullptr && state->done) return;
+    const int lane = threadIdx.x & 63;
+    const int stride = gridDim.x * WG;
+    for (int t0 = blockIdx.x * WG; t0 < num_tiles; t0 += stride) {
+        const int t = t0 + (int)threadIdx.x;
+        const int dst = t < num_tiles ? fix_seg[t] : -1;
+        const int first = dst >= 0 ? tile[t].w : 0;
+        const int len = dst >= 0 ? t - first : 0;
+        const bool is_long = len >= 32;
+        if (dst >= 0 && !is_long) {
+            double total = 0.0;
+            for (int s = first; s < t; ++s) total += tail[s];
+            psum[dst] = total + head[t];
+        }
+        unsigned long long todo = __ballot(is_long);
+        while (todo != 0ULL) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1ULL;
+            const int c_first = __shfl(first, src, 64), c_t = __shfl(t, src, 64);
+            double part = 0.0;
+            for (int s = c_first + lane; s < c_t; s += 64) part += tail[s];
+            part = wave_reduce_sum(part);
+            const double total = __shfl(part, 0, 64) + head[c_t];
+            if (lane == src) psum[dst] = total;
+        }
+    }
+}
+
+struct Epi64 {
+    double        a, b, c;       // term_out = a * (M^T term) + b * term;  result += c * term_out
+    const double* term;
+    double*       term_out;
+    double*       r;
+    double*       xg_out;        // next gather vector: term_out * src_scale
+    const float*  src_scale;     // or null
+    const float*  dst_scale;     // or null
+    int           err_linf;
+};
+
+// rows [iso_from, blk) of every block are isolated (no entries, referenced by nobody); flag = 0: the personalization is zero
+// on all of them, so they stay zero in every term and are passed over
+struct IsoRows {
+    const int* flag;
+    int        blk;
+    int        iso_from;
+};
+
+__global__ __launch_bounds__(WG) void k_bsf64_combine(const SegMeta* __restrict__ meta, int64_t words, const double* __restrict__ psum,
+                                                       int num_blocks, int64_t n_out, Epi64 ep, const LoopState* __restrict__ state,
+                                                       double* __restrict__ partial_sum, double* __restrict__ partial_delta, IsoRows iso) {
+    __shared__ double s_red[4];
+    if (state != nullptr && state->done) return;
+    double sum_y = 0.0, delta = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    const bool skip_iso = iso.flag != nullptr && *iso.flag == 0;
+    for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n_out; i += stride) {
+        if (skip_iso && (int)((uint32_t)i % (uint32_t)iso.blk) >= iso.iso_from) continue;
+        const int64_t w = i >> 6;
+        const unsigned long long bit = 1ULL << (i & 63);
+        // the row's segment of every column block, eight blocks at a time: map words first, then the sums (block order)
+        double s = 0.0;
+        for (int b0 = 0; b0 < num_blocks; b0 += 8) {
+            SegMeta m[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (b0 + b < num_blocks) m[b] = meta[(int64_t)(b0 + b) * words + w];
+            double v[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                v[b] = 0.0;
+                if (b0 + b < num_blocks && (m[b].mask & bit)) v[b] = psum[m[b].base + __popcll(m[b].mask & (bit - 1ULL))];
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) s += v[b];
+        }
+        if (ep.dst_scale != nullptr) s *= (double)ep.dst_scale[i];
+        double y = ep.a * s;
+        if (ep.b != 0.0) y += ep.b * ep.term[i];
+        ep.term_out[i] = y;
+        ep.xg_out[i] = ep.src_scale != nullptr ? y * (double)ep.src_scale[i] : y;
+        sum_y += y;
+        const double r_old = ep.r[i];
+        const double r_new = r_old + ep.c * y;
+        ep.r[i] = r_new;
+        const double d = fabs(r_new - r_old);
+        delta = ep.err_linf ? fmax(delta, d) : delta + d;
+    }
+    const double bs = block_reduce_256<0>(sum_y, s_red);
+    if (threadIdx.x == 0) partial_sum[blockIdx.x] = bs;
+    const double bd = ep.err_linf ? block_reduce_256<1>(delta, s_red) : block_reduce_256<0>(delta, s_red);
+    if (threadIdx.x == 0) partial_delta[blockIdx.x] = bd;
+}
+
+// caller-space f32 personalization -> internal-space f64 vectors of the loop: term_0 = p, result_1 = c1 * p, gather = p * src_scale
+__global__ void k_bsf64_bring(const float* __restrict__ p, const int32_t* __restrict__ perm, const float* __restrict__ src_scale,
+                              int64_t n_int, int64_t n_valid, double c1, double* __restrict__ term, double* __restrict__ res,
+                              double* __restrict__ xg, int* __restrict__ iso_flag, int blk, int iso_from) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_int; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = perm ? perm[i] : (i < n_valid ? i : -1);
+        const double v = o >= 0 ? (double)p[o] : 0.0;
+        if (iso_flag != nullptr && v != 0.0 && (int)((uint32_t)i % (uint32_t)blk) >= iso_from) atomicOr(iso_flag, 1);
+        term[i] = v;
+        res[i] = c1 * v;
+        xg[i] = src_scale != nullptr ? v * (double)src_scale[i] : v;
+    }
+}
+
+__global__ void k_bsf64_take(const double* __restrict__ res, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, double factor,
+                             float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_int; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = perm ? perm[i] : (i < n_valid ? i : -1);
+        if (o >= 0) out[o] = (float)(res[i] * factor);
+    }
+}
+
+inline int grid_for(int64_t n, int per_cu) {
+    int64_t blocks = (n + WG - 1) / WG;
+    const int64_t cap = (int64_t)rt().num_cus * per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+namespace pgh {
+
+// first slot of every block from which all rows are isolated: ranks r >= live_nodes sit at slots r / B >= ceil(live_nodes / B)
+static int iso_from_of(const BsfFormat& f) {
+    if (f.live_nodes < 0) return f.blk_size;
+    const int64_t from = (f.live_nodes + f.num_blocks - 1) / f.num_blocks;
+    return (int)(from < f.blk_size ? from : f.blk_size);
+}
+
+bool bsf64_usable(const pgh_graph_s* g) {
+    const char* off = getenv("PGH_CHEB_CSR");          // 1: the round-2 route over the row-major CSR (checker / measurements)
+    if (off != nullptr && atoi(off) != 0) return false;
+    return g->n_rows == g->n_cols && g->n_cols > 0 && g->nnz > 0 && g->part_perm == nullptr;
+}
+
+int bsf64_ensure(pgh_graph_s* g) {
+    BsfFormat& f = g->bsf64;
+    if (f.enabled) return 0;
+    Runtime& r = rt();
+    const bool valfree = g->keep_mult != nullptr;
+    // eight XCD-affine blocks once a block's slice is worth an L2 of its own; small graphs: one block, all of it in LDS
+    // Column blocks: every block's hot set is another kHot64 sources in some CU's LDS, and a cold gather is what the kernel
+    // pays for (a divergent 8-byte load keeps a CU's address unit busy for ~4 cycles per lane) -- so many blocks, as long as
+    // a block still feeds 256 / B workgroups of 16 wavefronts and the (row, block) segments stay few next to the entries.
+    // Eight XCD-affine blocks once the graph outgrows one hot cache.  More blocks (16 / 32 / 64 are supported: an XCD's
+    // workgroups share out its blocks) put more sources into some CU's LDS, but every block is another lookup per row in
+    // the combine: measured at scale 23, 8 / 16 / 32 / 64 blocks: combine 116 / 192 / 344 / 682 us for 40 / 70 / 100 us less
+    // in the partial sums.
+    int B = g->n_rows > (int64_t)kHot64 ? 8 : 1;
+    const char* forced = getenv("PGH_BLOCKS64");
+    if (forced != nullptr) {
+        const int fb = atoi(forced);
+        if (fb == 1 || fb == 8 || fb == 16 || fb == 32 || fb == 64) B = fb;
+    }
+    f.want_meta = true;
+    PGH_TRY(bsf_build(g, valfree ? nullptr : g->val, g->keep_mult, g->keep_src, g->keep_dst, true, B, &f));
+    PGH_HIP(hipMalloc(&f.psum64, sizeof(double) * (size_t)(f.num_segs + kT + 64)));
+    PGH_HIP(hipMemsetAsync(f.psum64, 0, sizeof(double) * (size_t)(f.num_segs + kT + 64), r.stream));
+    PGH_HIP(hipMalloc(&f.fix_seg, sizeof(int32_t) * (size_t)(f.num_tiles + 1)));
+    k_bsf64_fixlist<<<grid_for(f.num_tiles, 16), WG, 0, r.stream>>>(f.tile, f.seg_row, f.num_tiles, f.fix_seg);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    f.device_bytes += (int64_t)(f.num_segs + kT + 64) * 8 + (int64_t)f.num_tiles * 4;
+    if (f.live_nodes >= 0) PGH_HIP(hipMalloc(&f.iso_flag, sizeof(int)));
+    return 0;
+}
+
+int64_t bsf64_length(const pgh_graph_s* g) { return g->bsf64.n_out; }
+
+int bsf64_bring(pgh_graph_s* g, const float* p, double c1, double* term, double* res, double* xg) {
+    const BsfFormat& f = g->bsf64;
+    if (f.iso_flag != nullptr) PGH_HIP(hipMemsetAsync(f.iso_flag, 0, sizeof(int), rt().stream));
+    k_bsf64_bring<<<grid_for(f.n_out, 16), WG, 0, rt().stream>>>(p, f.perm, f.src_scale, f.n_out, g->n_cols, c1, term, res, xg, f.iso_flag,
+                                                                  f.blk_size, iso_from_of(f));
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+int bsf64_take(pgh_graph_s* g, const double* res, double factor, float* out) {
+    const BsfFormat& f = g->bsf64;
+    k_bsf64_take<<<grid_for(f.n_out, 16), WG, 0, rt().stream>>>(res, f.perm, f.n_out, g->n_cols, factor, out);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+// one term of the recurrence: term_out = a * (M^T term) + b * term, result += c * term_out; xg holds term * src_scale on
+// entry and term_out * src_scale on return.  Block partials of sum(term_out) / delta land in partial_sum / partial_delta.
+int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term, double* term_out, double* result, double* xg,
+               int err_linf, const LoopState* state, double* partial_sum, double* partial_delta, int* num_partials) {
+    Runtime& r = rt();
+    BsfFormat& f = g->bsf64;
+    View64 v;
+    v.colf = f.colf;
+    v.val = f.val;
+    v.tile = f.tile;
+    v.tail = f.tail_carry;
+    v.head = f.head_partial;
+    v.psum = f.psum64;
+    v.num_blocks = f.num_blocks;
+    v.blk = f.blk_size;
+    for (int i = 0; i <= kMaxBlocks; ++i) v.tile_begin[i] = f.tile_begin[i];
+    const int unit = f.num_blocks > 8 ? f.num_blocks : 8;                // whole XCD rounds, and whole rounds of an XCD's blocks
+    const int main_grid = r.num_cus >= unit ? r.num_cus / unit * unit : unit;
+    {
+        ProfScope prof(PGH_K_SPMV);
+        if (f.val) k_bsf64_partial<true><<<main_grid, kThreads, 0, r.stream>>>(v, xg, state);
+        else k_bsf64_partial<false><<<main_grid, kThreads, 0, r.stream>>>(v, xg, state);
+    }
+    {
+        ProfScope prof(PGH_K_FIXUP);
+        int fix_grid = (f.num_tiles + WG - 1) / WG;
+        fix_grid = fix_grid < 1 ? 1 : (fix_grid > 1024 ? 1024 : fix_grid);
+        k_bsf64_fixup<<<fix_grid, WG, 0, r.stream>>>(f.fix_seg, f.tile, f.tail_carry, f.head_partial, f.psum64, f.num_tiles, state);
+    }
+    Epi64 ep;
+    ep.a = a;
+    ep.b = b;
+    ep.c = c;
+    ep.term = term;
+    ep.term_out = term_out;
+    ep.r = result;
+    ep.xg_out = xg;
+    ep.src_scale = f.src_scale;
+    ep.dst_scale = f.dst_scale;
+    ep.err_linf = err_linf;
+    const int cgrid = grid_for((f.n_out + 3) / 4, 8);
+    {
+        ProfScope prof(PGH_K_COMBINE);
+        IsoRows iso;
+        iso.flag = f.iso_flag;
+        iso.blk = f.blk_size;
+        iso.iso_from = iso_from_of(f);
+        k_bsf64_combine<<<cgrid, WG, 0, r.stream>>>(f.meta, f.meta_words, f.psum64, f.num_blocks, f.n_out, ep, state, partial_sum, partial_delta, iso);
+    }
+    PGH_HIP(hipGetLastError());
+    if (num_partials) *num_partials = cgrid;
+    return 0;
+}
+
+}  // namespace pgh

@@ -179,6 +179,9 @@ struct PbFormat {
 };
 constexpr int kPbMaxSlices = 8;
 
+// column blocks of an image: at most 8 in the SpMV / multi-seed layouts, up to 64 in the f64 image (pgh_bsf64.hip)
+constexpr int kMaxBlocks = 64;
+
 // one word of the row -> segment map of the blocked SpMV layout (see BsfFormat::psum)
 struct SegMeta {
     unsigned long long mask;
@@ -211,7 +214,7 @@ struct BsfFormat {
                                     // SpMV layout needs it at build time only)
     int       num_tiles = 0;
     int4*     tile = nullptr;       // [num_tiles] {entry_start, entry_count, seg_base, chain_first}
-    int       tile_begin[9] = {0};  // tile range of every block
+    int       tile_begin[kMaxBlocks + 1] = {0};  // tile range of every block
     double*   tail_carry = nullptr; // [num_tiles]
     double*   head_partial = nullptr;
     float*    part = nullptr;       // multi-seed layout only: per-tile head sums
@@ -221,6 +224,8 @@ struct BsfFormat {
     // written sequentially by k_bsf_partial; the epilogue finds the segments of a row through one SegMeta word per
     // (block, 64 rows): bit r of mask = row 64 w + r has a segment in the block, base = index of the word's first segment
     float*    psum = nullptr;       // [num_segs + pad]
+    double*   psum64 = nullptr;     // f64 image (pgh_bsf64.hip): the same compact partial sums in f64
+    bool      want_meta = false;    // set before bsf_build: a multi-seed-style image (cold entries in the stream) that also gets `meta`
     SegMeta*  meta = nullptr;       // [B][meta_words]
     int64_t   meta_words = 0;       // ceil(n_out / 64)
     int32_t*  perm = nullptr;       // [n_src] new id -> old id, or null (identity)
@@ -230,6 +235,7 @@ struct BsfFormat {
     float*    deg_int = nullptr;    // [n_out] row sums of M in the internal id space (square graphs; bsf_ensure_degrees, lazily)
     // square relabelled graphs: isolated ids (never referenced, empty row) sort last, slots [iso_begin[b], blk_size) of block b
     bool      has_iso = false;
+    int64_t   live_nodes = -1;      // ids that are referenced or hold entries (they sort first), -1 = unknown
     int       iso_begin[8] = {0};
     int       iso_row_blocks = 0;   // row blocks the thresholds cover: num_blocks (square graphs) or the blocks of a rank's slice
     int32_t*  seed_list = nullptr;  // [2^16] original ids of the non-zeros of a run's operands (bsf_bring_pair), lazily allocated
@@ -269,6 +275,8 @@ struct pgh_graph_s {
     BsfFormat bsf;
     // multi-seed (SpMM) layout: one column block, built on first use from the factors kept below
     BsfFormat bsf_mm;
+    // f64 image of the "chebyshev" recurrence (pgh_bsf64.hip): 8 XCD-affine blocks, cold entries in the stream, built on first use
+    BsfFormat bsf64;
     int32_t*  keep_mult = nullptr;   // [nnz] edge multiplicities of the value-free factorisation (generator graphs)
     float*    keep_src = nullptr;    // [n_rows] source scale, caller id space
     float*    keep_dst = nullptr;    // [n_cols] output scale

@@ -503,6 +503,7 @@ extern "C" int pgh_graph_destroy(pgh_graph_t g) {
     (void)hipFree(g->head_partial);
     bsf_destroy(g->bsf);
     bsf_destroy(g->bsf_mm);
+    bsf_destroy(g->bsf64);
     (void)hipFree(g->keep_mult);
     (void)hipFree(g->keep_src);
     (void)hipFree(g->keep_dst);

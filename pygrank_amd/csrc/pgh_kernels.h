@@ -569,6 +569,14 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
 int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t* perm, int32_t* iperm);
 int bsf_auto_blocks(int64_t n_src);
 void bsf_destroy(BsfFormat& f);
+// pgh_bsf64.hip: the f64 route of the "chebyshev" recurrence on a blocked image of its own (pgh_graph_s::bsf64)
+bool bsf64_usable(const pgh_graph_s* g);
+int bsf64_ensure(pgh_graph_s* g);
+int64_t bsf64_length(const pgh_graph_s* g);      // length of the loop's internal-space vectors (the gather vector: + 1)
+int bsf64_bring(pgh_graph_s* g, const float* p, double c1, double* term, double* res, double* xg);
+int bsf64_take(pgh_graph_s* g, const double* res, double factor, float* out);
+int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term, double* term_out, double* result, double* xg,
+               int err_linf, const LoopState* state, double* partial_sum, double* partial_delta, int* num_partials);
 int finish_graph(pgh_graph_s* g);
 
 }  // namespace pgh

@@ -1584,14 +1584,21 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
         return 0;
     }
     PGH_CHECK(g->items_per_tile == WG * kIPT, "graph tile table was built for a different tile size");
-    DevF64 p64, res64, t0, t1;
-    PGH_TRY(p64.alloc(n));
-    PGH_TRY(res64.alloc(n));
-    PGH_TRY(t0.alloc(n));
-    PGH_TRY(t1.alloc(n));
+    // square graphs: the blocked f64 image (pgh_bsf64.hip; vectors live in its internal id space); otherwise the row-major CSR
+    const bool blocked = bsf64_usable(g);
+    if (blocked) PGH_TRY(bsf64_ensure(g));
+    const int64_t nv = blocked ? bsf64_length(g) : n;
+    DevF64 p64, res64, t0, t1, xg64;
+    PGH_TRY(p64.alloc(nv));
+    PGH_TRY(res64.alloc(nv));
+    PGH_TRY(t0.alloc(nv));
+    PGH_TRY(t1.alloc(nv));
+    if (blocked) PGH_TRY(xg64.alloc(nv + 1));
     const int cgrid = residual_grid(n);
     const double c1 = coeff(1);
-    if (n > 0) {
+    if (blocked) {
+        PGH_TRY(bsf64_bring(g, p->data, c1, p64.p, res64.p, xg64.p));
+    } else if (n > 0) {
         k_f32_to_f64<<<cgrid, WG, 0, r.stream>>>(p->data, p64.p, n, 1.0);
         k_f32_to_f64<<<cgrid, WG, 0, r.stream>>>(p->data, res64.p, n, c1);      // result_1 = c_1 * p (result_0 = 0)
     }
@@ -1650,19 +1657,24 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
                 epi.term_out = tbuf[k & 1];
                 epi.r = res64.p;
                 epi.err_linf = (cfg->err_kind == PGH_ERR_LINF);
-                {
-                    ProfScope prof(PGH_K_SPMV);
-                    k_spmv_merge<kIPT, double, EpiPoly64><<<sg.main_grid, WG, 0, r.stream>>>(v, epi, term, g_state, psum, pdel);
-                }
-                {
-                    ProfScope prof(PGH_K_FIXUP);
-                    k_spmv_fixup<double, EpiPoly64><<<sg.fix_grid, WG, 0, r.stream>>>(v, epi, g_state, psum + sg.main_grid, pdel + sg.main_grid);
+                int count = sg.total();
+                if (blocked) {
+                    PGH_TRY(bsf64_step(g, epi.a, epi.b, epi.c, term, tbuf[k & 1], res64.p, xg64.p, epi.err_linf, g_state, psum, pdel, &count));
+                } else {
+                    {
+                        ProfScope prof(PGH_K_SPMV);
+                        k_spmv_merge<kIPT, double, EpiPoly64><<<sg.main_grid, WG, 0, r.stream>>>(v, epi, term, g_state, psum, pdel);
+                    }
+                    {
+                        ProfScope prof(PGH_K_FIXUP);
+                        k_spmv_fixup<double, EpiPoly64><<<sg.fix_grid, WG, 0, r.stream>>>(v, epi, g_state, psum + sg.main_grid, pdel + sg.main_grid);
+                    }
                 }
                 const int chk_it = k + 1;
                 const int check = (cfg->err_kind != PGH_ERR_ITERS) && (chk_it < max_iters) && (chk_it % cfg->end_modulo == 0);
                 {
                     ProfScope prof(PGH_K_FINAL);
-                    k_step_close<<<1, WG, 0, r.stream>>>(g_state, psum, sg.total(), pdel, sg.total(), 0, check, cfg->err_kind, cfg->tol, n,
+                    k_step_close<<<1, WG, 0, r.stream>>>(g_state, psum, count, pdel, count, 0, check, cfg->err_kind, cfg->tol, n,
                                                          nullptr, g_progress_dev);
                 }
                 term = tbuf[k & 1];
@@ -1679,7 +1691,8 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
         err = g_state_host->steps > 0 ? g_state_host->err : err;
         it = 2 + spmv;
     }
-    if (n > 0) k_f64_to_f32<<<cgrid, WG, 0, r.stream>>>(res64.p, result->data, n, cfg->out_scale);
+    if (blocked) PGH_TRY(bsf64_take(g, res64.p, cfg->out_scale, result->data));
+    else if (n > 0) k_f64_to_f32<<<cgrid, WG, 0, r.stream>>>(res64.p, result->data, n, cfg->out_scale);
     PGH_HIP(hipGetLastError());
     PGH_TRY(timer.stop(&res->loop_ms));
     res->iterations = it;

@@ -239,6 +239,47 @@ def check_fused_steps(pg):
             assert abs(e.value - want) <= 1e-12 * max(1.0, want), name
 
 
+def check_chebyshev_f64_route_on_blocked_stream(pg):
+    """The f64 route of the "chebyshev" recurrence (abstract_filters.py:216-224) on graphs large enough for its own blocked
+    image (pgh_bsf64.hip: 8 / 16 / 32 column blocks, LDS hot cache + in-stream cold gathers, value-free and valued streams)
+    against the oracle at 1e-6 with equal iteration counts, and against the row-major CSR route of the same engine."""
+    import os
+    from oracle import ref_loops as orc
+    rng = np.random.default_rng(11)
+    A = rmat_np.rmat_csr(15, 16, seed=4)                       # 32 768 nodes: beyond one hot cache (20 224 doubles)
+    W = sp.csr_array(A)
+    W.data = rng.uniform(0.5, 2.0, W.nnz)                      # weights that do not factor: the valued stream
+    p = np.zeros(A.shape[0])
+    p[rmat_np.seed_nodes(A, 40, seed=2)] = rng.uniform(0.5, 1.5, 40)
+    saved = {k: os.environ.get(k) for k in ("PGH_BLOCKS64", "PGH_CHEB_CSR")}
+    try:
+        for label, graph, normalization, blocks in (("col", A, "col", None), ("symmetric", sp.csr_array(A + A.T), "symmetric", None),
+                                                    ("weighted", W, "col", None), ("col/16", A, "col", "16"), ("col/32", A, "col", "32")):
+            M = orc.normalize(graph, normalization, True)
+            want, want_iters = orc.heat_kernel(M, p, t=5, coefficient_type="chebyshev", tol=1e-9, max_iters=40, error_type="l1", eps=EPS32)
+            results = {}
+            for route in ("blocked", "csr"):
+                os.environ.pop("PGH_BLOCKS64", None)
+                os.environ.pop("PGH_CHEB_CSR", None)
+                if blocks is not None:
+                    os.environ["PGH_BLOCKS64"] = blocks
+                if route == "csr":
+                    os.environ["PGH_CHEB_CSR"] = "1"
+                ranker = pg.HeatKernel(5, coefficient_type="chebyshev", error_type=pg.L1, tol=1e-9, max_iters=40,
+                                       preprocessor=pg.preprocessor(normalization=normalization, assume_immutability=False))
+                got = np.asarray(ranker.rank(pg.AdjacencyWrapper(graph, directed=True), p.copy()).np, dtype=np.float64)
+                assert ranker.convergence.iteration == want_iters, (label, route)
+                assert np.max(np.abs(got - want)) / np.max(np.abs(want)) <= 1e-6, (label, route)
+                results[route] = got
+            assert np.max(np.abs(results["blocked"] - results["csr"])) / np.max(np.abs(want)) <= 1e-7, label
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def check_loop_is_deterministic(pg):
     A = rmat_np.rmat_csr(14, 8, seed=2)
     p = np.zeros(A.shape[0])
