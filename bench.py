@@ -326,7 +326,23 @@ def _emit(line):
 def multi_gpu(args):
     os.environ["NCCL_DEBUG"] = os.environ.get("PGH_NCCL_DEBUG", "WARN")
     _stdout_to_stderr()
-    return bench_row_partitioned(args, RMAT, ALPHA, TOL, MAX_ITERS, SEEDS, HBM_PEAK_GBS)
+    # A rank that waits on a peer for ever would leave the driver without a line AND without an exit code: the whole N-GPU
+    # run is bounded (PGH_BENCH_WATCHDOG_S, default 1500 s); past it the rank says so and ends its process with code 3
+    # (pygrank_amd.distributed bounds its own waits on collectives the same way, PGH_DIST_TIMEOUT_S).
+    import threading
+
+    def _expired():
+        sys.stderr.write(f"[bench] rank {os.environ.get('RANK', '0')}: the N-GPU run did not finish within its watchdog; exiting with code 3 "
+                         "(retry with PGH_DIST_SINGLE_COMM=1 PGH_DIST_SINGLE_STREAM=1)\n")
+        sys.stderr.flush()
+        os._exit(3)
+    watchdog = threading.Timer(float(os.environ.get("PGH_BENCH_WATCHDOG_S", "1500")), _expired)
+    watchdog.daemon = True
+    watchdog.start()
+    try:
+        return bench_row_partitioned(args, RMAT, ALPHA, TOL, MAX_ITERS, SEEDS, HBM_PEAK_GBS)
+    finally:
+        watchdog.cancel()
 
 
 # ----------------------------------------------------------------------------------------------------------------

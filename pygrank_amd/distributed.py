@@ -13,6 +13,7 @@ semantics are those of GraphFilter.rank + RecursiveGraphFilter._step + Convergen
 import ctypes as C
 import math
 import os
+import sys
 import time
 
 import numpy as np
@@ -203,6 +204,25 @@ class _Buffers:
 _EXCHANGE_GROUPS = {}
 
 
+def _bounded_wait(event, what):
+    """Host wait for a CUDA event with a deadline (PGH_DIST_TIMEOUT_S, default 600 s).  A collective that never completes
+    -- a peer that died, communicators that block each other -- would otherwise hang the job for good: the rank says what it
+    was waiting for and ends the PROCESS with a non-zero code (the launcher then takes the other ranks down); nothing is
+    re-executed.  PGH_DIST_SINGLE_COMM=1 / PGH_DIST_SINGLE_STREAM=1 are the conservative settings to try next."""
+    limit = float(os.environ.get("PGH_DIST_TIMEOUT_S", "600"))
+    start = time.monotonic()
+    spins = 0
+    while not event.query():
+        spins += 1
+        if spins > 2000:
+            time.sleep(0.0005)
+            if time.monotonic() - start > limit:
+                sys.stderr.write(f"[pygrank_amd.distributed] rank {os.environ.get('RANK', '0')}: {what} did not complete within {limit:.0f} s "
+                                 "-- a collective is stalled; exiting (retry with PGH_DIST_SINGLE_COMM=1 PGH_DIST_SINGLE_STREAM=1)\n")
+                sys.stderr.flush()
+                os._exit(3)
+
+
 def _exchange_group(dist, world):
     """The communicator of the gather-vector exchange, created once per process and world size."""
     if world <= 1 or os.environ.get("PGH_DIST_SINGLE_COMM", "0") == "1":
@@ -269,7 +289,9 @@ class DistributedPageRank:
             """(done, steps, converged, scale) once everything enqueued before this call has run."""
             bufs.state_host.copy_(bufs.state, non_blocking=True)
             if device.type == "cuda":
-                self._stream.synchronize()
+                landed = torch.cuda.Event()
+                landed.record(self._stream)
+                _bounded_wait(landed, "the loop state of the last step")
             ints = bufs.state_host.view(torch.int32)
             return int(ints[6]), int(ints[7]), int(ints[8]), float(bufs.state_host[0])
 
@@ -309,7 +331,10 @@ class DistributedPageRank:
         L.check(lib.pgh_dist_state_init(state))
         if cuda:
             if getattr(self, "_side", None) is None:
-                self._side = (torch.cuda.Stream(), torch.cuda.Stream())
+                # PGH_DIST_SINGLE_STREAM=1: exchange and scalars queue on the compute stream (no overlap, no cross-stream order
+                # for the collectives to disagree on between ranks) -- the fallback for a first run on new hardware
+                single = os.environ.get("PGH_DIST_SINGLE_STREAM", "0") == "1"
+                self._side = (self._stream, self._stream) if single else (torch.cuda.Stream(), torch.cuda.Stream())
             main, (xs, ss) = self._stream, self._side
             ev_fin, ev_hot, ev_cold, ev_err = (torch.cuda.Event() for _ in range(4))
             for ev in (ev_hot, ev_cold, ev_err):
@@ -338,7 +363,7 @@ class DistributedPageRank:
             if pending:
                 # the check that followed the previous step: its flag travels while the stages above run
                 if cuda:
-                    ev_err.synchronize()
+                    _bounded_wait(ev_err, "the residual all-reduce of the previous step")
                 pending = False
                 if int(bufs.state_host.view(torch.int32)[6]):
                     converged = True            # whatever the stages above computed is never folded into an iterate
@@ -390,7 +415,7 @@ class DistributedPageRank:
             main.wait_event(ev_cold)
         if pending and not converged:
             if cuda:
-                ev_err.synchronize()
+                _bounded_wait(ev_err, "the residual all-reduce of the last step")
             converged = bool(int(bufs.state_host.view(torch.int32)[6]))
         done, steps, conv, scale = read_state()
         self.elapsed = time.perf_counter() - t0

@@ -5,6 +5,8 @@ size"): RMAT scale 23, edge factor 16 (8.4 M nodes, 131 M edges), the production
   configs[1]  PPR alpha = 0.85, L1 <= 1e-6     vs the oracle's scipy loop on the engine's own matrix (about 5 s of host time)
   configs[3]  HeatKernel t = 5, 31 iterations  taylor and chebyshev vs the oracle (about 15 s each), linearity of the filter
   configs[2]  64 personalizations at once      sampled columns equal single-seed runs, mass conservation, per-column stops
+  configs[4]  the 1 B-edge graph (scale 27, ef 8) through the row-partitioned path with ONE rank over RCCL vs the single-GPU
+              engine on the same graph, + the 8-way slice layout at scale 22 vs the oracle (8 ranks over xGMI: the driver's run)
 """
 import numpy as np
 import pytest
@@ -143,3 +145,53 @@ def test_cfg3_batch64_scale23(big):
         want, want_iters = orc.pagerank(big["M"], feats[:, j], alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
         assert info[j]["iterations"] == want_iters, j
         assert _rel(out[:, j], want) <= 1e-6, j
+
+
+def _run_cfg5_worker(tmp_path, mode, scale, ef, extra_env=None):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
+    env.update(extra_env or {})
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_worker_cfg5.py"), str(tmp_path), mode, str(scale), str(ef)],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+def test_cfg5_graph_one_rank(gpu_engine, tmp_path):
+    """BASELINE.json configs[4]'s graph at its size -- RMAT scale 27 / ef 8, 134 M nodes, 1.07 G edges -- through the
+    row-partitioned path (relabelled slice generation, pgh_dist_* stages, RCCL collectives with one rank) against the
+    single-GPU engine on the same graph: equal iteration counts, <= 1e-6 rel-Linf, mass conservation, nothing on padding
+    ids, linearity of the filter in the personalization.  (The oracle cannot run 1 G edges in test time: it pins the same
+    path at scale 22 below and both engines at scale <= 23 elsewhere.)"""
+    _run_cfg5_worker(tmp_path, "big", 27, 8)
+    import os
+    out = np.load(os.path.join(tmp_path, "big.npz"))
+    assert int(out["n"]) == 1 << 27 and int(out["nnz"]) > 1_000_000_000
+    assert "propagation-blocking image" in str(out["format"])
+    for name in ("a", "b", "ab"):
+        assert int(out[name + "_iters_part"]) == int(out[name + "_iters_single"]), name
+        assert float(out[name + "_rel_linf"]) <= 1e-6, (name, float(out[name + "_rel_linf"]))
+        psum = float(out[name + "_psum"])
+        assert abs(float(out[name + "_sum_part"]) - psum) <= 1e-5 * psum and abs(float(out[name + "_sum_single"]) - psum) <= 1e-5 * psum
+        assert float(out[name + "_pad_mass"]) == 0.0
+    assert float(out["linearity_rel_linf"]) <= 2e-6           # runs of 13 iterations each: only f32 rounding separates them
+
+
+def test_cfg5_eight_way_slice_layout_vs_oracle(gpu_engine, tmp_path):
+    """The layout a rank of the 8-GPU run works on (8 column blocks, PGH_BLOCKS=8, cold image forced) at scale 22 / ef 8,
+    one rank holding all 8 blocks, against the oracle's scipy loop on the numpy twin of the generator."""
+    import os
+    import scipy.sparse as sp
+    from oracle import ref_loops as orc, rmat_np
+    _run_cfg5_worker(tmp_path, "slice", 22, 8, dict(PGH_BLOCKS="8", PGH_PB="1", PGH_PB_FORCE="1"))
+    out = np.load(os.path.join(tmp_path, "slice.npz"))
+    assert "8 column blocks" in str(out["format"]), str(out["format"])
+    A = rmat_np.rmat_csr(22, 8, seed=0)
+    assert int(out["nnz"]) == A.nnz
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    want, want_iters = orc.pagerank(M, out["p"], alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000, eps=float(np.finfo(np.float32).eps))
+    assert int(out["iters"]) == want_iters
+    assert _rel(out["ranks"], want) <= 1e-6
