@@ -443,8 +443,7 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
     # what the line says about this rank's slice, read BEFORE the same-graph leg gives the slice up
     graph_format = pg.graph.format()
     nnz_local = pg.graph.nnz
-    exchange = dict(exchange_bytes_per_iteration_per_gpu=ranker._buffers.exchange_bytes,
-                    gather_vector_slots=ranker._buffers.nb * ranker._buffers.live, column_blocks=ranker._buffers.nb)
+    exchange = dict(ranker.exchange)
     # ---- the same graph on ONE GPU (rank 0, single-GPU engine) while the other ranks wait: the same-graph speed-up the
     # north star quotes (>= 6x at 8 GPUs on the 1 B-edge graph) next to the weak-scaling value, and a full-size cross-check
     same_graph = None
@@ -539,6 +538,8 @@ def _same_graph_leg(dist, rank, world, pg, ranker, p_last, scale, ef, rmat, alph
             n_all = pg.n
             ranker._buffers = None
             ranker._buffers_for = None
+            from pygrank_amd.distributed import release_native_comms
+            release_native_comms()                          # the engine's RCCL communicators hold the run's gather buffers
             pg.graph.destroy()
             del out
             gc.collect()
@@ -629,7 +630,9 @@ def main():
     if args.gpus > 1 or world > 1 or args.force_partitioned:
         import torch.distributed as dist
         if dist.is_initialized():
+            from pygrank_amd.distributed import release_native_comms
             dist.barrier()
+            release_native_comms()
             dist.destroy_process_group()
     if result is not None:
         _emit(json.dumps(result))

@@ -296,6 +296,52 @@ int pgh_dist_watch_isolated(pgh_graph_t g, pgh_vec_t p_local, pgh_vec_t y_start)
 int pgh_dist_release_isolated(pgh_graph_t g);
 int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old, double* state);
 int pgh_dist_close_err(double* state, int32_t kind, double tol, int64_t n_global);
+/* The two parts of a block's slice in two regions of the gather vector: slots [0, hot) of block b start at hot_bases[b]
+ * (read by the block partial sums: hot = what pgh_graph_hot_prefix reports), slots [hot, live) at cold_bases[b] (read by the
+ * cold image's phase A).  With the regions laid out [j][rank][hot] and [j][rank][live - hot] both halves of the exchange
+ * are plain all-gathers on contiguous memory.  Only for graphs whose stream is hot-only (hot prefix > 0). */
+int pgh_graph_set_gather_bases_split(pgh_graph_t g, const int64_t* hot_bases, const int64_t* cold_bases /* [num_blocks] each */);
+
+/* ---- the whole row-partitioned PageRank run behind ONE call: the engine drives RCCL itself (csrc/pgh_dist.hip) -------------
+ * One process per GPU.  A communicator wraps two RCCL communicators (gather-vector exchange / scalar reductions; one when
+ * num_ids == 1), three HIP streams (compute / exchange / scalars; one with PGH_DIST_SINGLE_STREAM=1) and the run's buffers.
+ * Rank 0 draws num_ids ids with pgh_comm_unique_id and hands the bytes to every rank by any means (pygrank_amd/distributed.py
+ * broadcasts them with torch.distributed); every rank then calls pgh_comm_create (collective).
+ * pgh_dist_ppr_run = GraphFilter.rank + RecursiveGraphFilter._step + ConvergenceManager (abstract_filters.py:44-65,126-136;
+ * convergence.py:77-101) for PageRank(alpha) on this rank's slice of a partitioned graph (pgh_graph_rmat_part /
+ * pgh_graph_from_csr_part): p_local in, ranks_local out (new id space, this rank's rows).  Collective; host waits are bounded
+ * by PGH_DIST_TIMEOUT_S (default 600 s) and end in an error return.  No reference counterpart. */
+#define PGH_COMM_ID_BYTES 128
+typedef struct pgh_comm_s* pgh_comm_t;
+typedef struct {
+    double  alpha;
+    double  tol;            /* already max(tol, epsilon), convergence.py:101                                  */
+    int64_t n_global;       /* Mabs divides by the global number of nodes                                      */
+    int32_t err_kind;       /* PGH_ERR_*                                                                       */
+    int32_t max_iters;
+    int32_t end_modulo;
+    int32_t use_quotient;
+    int32_t preserve_norm;
+    int32_t reserved;
+} pgh_dist_cfg;
+typedef struct {
+    int32_t iterations;     /* ConvergenceManager.iteration at loop exit (0: the personalization is all zeros)  */
+    int32_t spmv_count;
+    int32_t converged;
+    int32_t column_blocks;
+    int32_t split_regions;  /* 1 = hot prefixes and cold parts are exchanged as two contiguous regions          */
+    int32_t reserved;
+    double  last_error;
+    double  loop_ms;        /* HIP-event time of the loop on the compute stream                                 */
+    int64_t exchange_bytes; /* received per rank and iteration                                                  */
+    int64_t gather_slots;
+} pgh_dist_result;
+int pgh_comm_unique_id(uint8_t* id /* [PGH_COMM_ID_BYTES] */);
+int pgh_comm_create(const uint8_t* ids /* [num_ids * PGH_COMM_ID_BYTES] */, int32_t num_ids, int32_t world, int32_t rank, pgh_comm_t* out);
+int pgh_comm_destroy(pgh_comm_t comm);
+int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t comm, pgh_vec_t p_local, pgh_vec_t ranks_local, const pgh_dist_cfg* cfg,
+                     pgh_dist_result* res);
+
 /* new id -> original id of a relabelled (partitioned) graph, and the first row this graph holds */
 int pgh_graph_perm(pgh_graph_t g, int32_t* new_to_old, int64_t* row_begin);
 

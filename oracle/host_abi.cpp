@@ -1106,6 +1106,18 @@ int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old, double* st
     st->err = scaled_res(kind == PGH_ERR_LINF ? PGH_ERR_LINF : PGH_ERR_L1, y_new->data, st->scale, y_old->data, st->prev_scale, y_new->n);
     return 0;
 }
+// The RCCL-driven loop of csrc/pgh_dist.hip has no host twin: the multi-rank tests on CPU go through the staged pgh_dist_*
+// calls above with gloo collectives (pygrank_amd/distributed.py falls back to them when these refuse).
+int pgh_graph_set_gather_bases_split(pgh_graph_t, const int64_t*, const int64_t*) {
+    return fail("pgh_graph_set_gather_bases_split: not available in the host double");
+}
+int pgh_comm_unique_id(uint8_t*) { return fail("pgh_comm_unique_id: not available in the host double"); }
+int pgh_comm_create(const uint8_t*, int32_t, int32_t, int32_t, pgh_comm_t*) { return fail("pgh_comm_create: not available in the host double"); }
+int pgh_comm_destroy(pgh_comm_t) { return 0; }
+int pgh_dist_ppr_run(pgh_graph_t, pgh_comm_t, pgh_vec_t, pgh_vec_t, const pgh_dist_cfg*, pgh_dist_result*) {
+    return fail("pgh_dist_ppr_run: not available in the host double");
+}
+
 int pgh_dist_close_err(double* state, int32_t kind, double tol, int64_t n_global) {
     DistState* st = reinterpret_cast<DistState*>(state);
     if (st->done) return 0;

@@ -34,6 +34,19 @@ class LoopResult(C.Structure):
                 ("flags", C.c_int32), ("last_error", C.c_double), ("loop_ms", C.c_double)]
 
 
+class DistCfg(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("tol", C.c_double), ("n_global", C.c_int64), ("err_kind", C.c_int32), ("max_iters", C.c_int32),
+                ("end_modulo", C.c_int32), ("use_quotient", C.c_int32), ("preserve_norm", C.c_int32), ("reserved", C.c_int32)]
+
+
+class DistResult(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("spmv_count", C.c_int32), ("converged", C.c_int32), ("column_blocks", C.c_int32),
+                ("split_regions", C.c_int32), ("reserved", C.c_int32), ("last_error", C.c_double), ("loop_ms", C.c_double),
+                ("exchange_bytes", C.c_int64), ("gather_slots", C.c_int64)]
+
+
+COMM_ID_BYTES = 128
+
 # name -> (restype, argtypes); every symbol include/pgh.h declares
 SIGNATURES = {
     "pgh_init": (C.c_int, [C.c_int]),
@@ -133,6 +146,11 @@ SIGNATURES = {
     "pgh_dist_close_err": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int64]),
     "pgh_dist_prescale": (C.c_int, [c_graph, c_vec, c_vec]),
     "pgh_graph_perm": (C.c_int, [c_graph, C.c_void_p, c_i64p]),
+    "pgh_graph_set_gather_bases_split": (C.c_int, [c_graph, C.c_void_p, C.c_void_p]),
+    "pgh_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pgh_comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pgh_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pgh_dist_ppr_run": (C.c_int, [c_graph, C.c_void_p, c_vec, c_vec, C.POINTER(DistCfg), C.POINTER(DistResult)]),
     "pgh_graph_rmat_part": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.POINTER(c_graph)]),
     "pgh_graph_rmat": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int32,

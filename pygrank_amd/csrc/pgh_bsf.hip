@@ -1504,7 +1504,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipMemcpyAsync(f.live, f.live_dev, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
         for (int b = 0; b < 8; ++b) f.live[b] = live_all[b] > f.live[b] ? live_all[b] : f.live[b];   // the cold image's sources count too
-        for (int b = 0; b < 8; ++b) f.xg_base[b] = (int64_t)b * blk;
+        for (int b = 0; b < 8; ++b) f.xg_base[b] = f.xg_base_cold[b] = (int64_t)b * blk;
         PGH_HIP(hipMalloc(&f.fix_seg, sizeof(int32_t) * (size_t)(f.num_tiles + 1)));
         k_bsf_fixlist<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.tile, f.seg_row, f.num_tiles, f.fix_seg);
         PGH_HIP(hipGetLastError());
@@ -1530,7 +1530,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
             top = (top + 63) / 64 * 64;
             if (top < blk) {
                 f.xg_live = top;
-                for (int b = 0; b < 8; ++b) f.xg_base[b] = (int64_t)b * top;
+                for (int b = 0; b < 8; ++b) f.xg_base[b] = f.xg_base_cold[b] = (int64_t)b * top;
             }
         }
         f.device_bytes += (int64_t)f.num_tiles * 64;

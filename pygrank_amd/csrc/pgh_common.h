@@ -245,6 +245,8 @@ struct BsfFormat {
     int32_t*  live_dev = nullptr;   // [8] device copy target of `live`
     int       live[8] = {0};        // per block: 1 + the highest source slot any entry references (hot-first order puts
                                     // never-referenced sources last: they need not be exchanged or stored)
+    int64_t   xg_base_cold[8] = {0}; // slot s >= hot of block b lives at xg_base_cold[b] + s (= xg_base[b] unless a partitioned run
+                                    // keeps the hot prefixes and the cold parts of the blocks in two regions, pgh_graph_set_gather_bases_split)
     int64_t   xg_base[8] = {0};     // first element of every block's slice inside the gather vector (default b * blk_size;
                                     // a partitioned run lays the slices out as the trimmed all-gather delivers them)
     int       xg_live = 0;          // > 0: the engine's own gather vector `xg` stores only the first xg_live slots of every

@@ -658,7 +658,7 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.iso_flag = f.iso_flag;
     v.hub_part = p.hub_part;
     for (int i = 0; i < 9; ++i) v.cold_prefix[i] = p.cold_prefix[i];
-    for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base[i];
+    for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base_cold[i];      // phase A reads slots >= hot only
     v.num_blocks = f.num_blocks;
     v.hot = p.hot;
     v.chunk = p.chunk;

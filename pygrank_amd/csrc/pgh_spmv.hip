@@ -913,7 +913,8 @@ int check_dist_graph(pgh_graph_t g, pgh_vec_t xg_full, const char* who) {
     if (xg_full != nullptr) {
         const int64_t hot = (int64_t)PGH_BSF_HOT < f.blk_size ? (int64_t)PGH_BSF_HOT : f.blk_size;
         for (int b = 0; b < f.num_blocks; ++b) {
-            const int64_t need = f.xg_base[b] + (f.live[b] > hot ? f.live[b] : hot);
+            const int64_t need_hot = f.xg_base[b] + hot, need_cold = f.live[b] > hot ? f.xg_base_cold[b] + f.live[b] : 0;
+            const int64_t need = need_hot > need_cold ? need_hot : need_cold;
             PGH_CHECK(xg_full->n >= need, std::string(who) + ": gather vector shorter than the layout set by pgh_graph_set_gather_bases");
         }
     }
@@ -1038,7 +1039,24 @@ extern "C" int pgh_graph_set_gather_bases(pgh_graph_t g, const int64_t* bases) {
     BsfFormat& f = g->bsf;
     for (int b = 0; b < f.num_blocks; ++b) {
         PGH_CHECK(bases[b] >= 0 && bases[b] < (1LL << 31), "pgh_graph_set_gather_bases: base out of range");
-        f.xg_base[b] = bases[b];
+        f.xg_base[b] = f.xg_base_cold[b] = bases[b];
+    }
+    return 0;
+}
+
+extern "C" int pgh_graph_set_gather_bases_split(pgh_graph_t g, const int64_t* hot_bases, const int64_t* cold_bases) {
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_graph_set_gather_bases_split"));
+    PGH_CHECK(hot_bases != nullptr && cold_bases != nullptr, "pgh_graph_set_gather_bases_split: null argument");
+    BsfFormat& f = g->bsf;
+    // only a hot-only stream reads the two parts of a block's slice from different kernels (block partial sums: slots below
+    // hot; the cold image's phase A: slots from hot on)
+    PGH_CHECK(f.colf16 != nullptr && f.pb.enabled, "pgh_graph_set_gather_bases_split: the stream of this graph is not hot-only");
+    const int64_t hot = (int64_t)PGH_BSF_HOT < f.blk_size ? (int64_t)PGH_BSF_HOT : f.blk_size;
+    for (int b = 0; b < f.num_blocks; ++b) {
+        PGH_CHECK(hot_bases[b] >= 0 && hot_bases[b] < (1LL << 31) && cold_bases[b] >= 0 && cold_bases[b] < (1LL << 31),
+                  "pgh_graph_set_gather_bases_split: base out of range");
+        f.xg_base[b] = hot_bases[b];
+        f.xg_base_cold[b] = cold_bases[b] - hot;           // slot s >= hot of the block sits at cold_bases[b] + (s - hot)
     }
     return 0;
 }

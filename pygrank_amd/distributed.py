@@ -233,8 +233,48 @@ def _exchange_group(dist, world):
     return _EXCHANGE_GROUPS[key]
 
 
+_NATIVE_COMMS = {}
+
+
+def _native_comm(dist, device):
+    """The engine's own RCCL communicator pair (csrc/pgh_dist.hip), created once per process: rank 0 draws the ids, the bytes
+    travel through torch.distributed, every rank joins.  None when the run is not RCCL-on-GPU (gloo / CPU tests, the host
+    double) or PGH_DIST_NATIVE=0 asks for the Python-driven loop."""
+    if device.type != "cuda" or dist.get_backend() != "nccl" or os.environ.get("PGH_DIST_NATIVE", "1") == "0":
+        return None
+    if not L.runtime_name().startswith("hip:"):
+        return None
+    world, rank = dist.get_world_size(), dist.get_rank()
+    key = (world, rank)
+    if key not in _NATIVE_COMMS:
+        import torch
+        lib = L.lib()
+        num_ids = 1 if os.environ.get("PGH_DIST_SINGLE_COMM", "0") == "1" else 2
+        ids = (C.c_uint8 * (L.COMM_ID_BYTES * num_ids))()
+        if rank == 0:
+            for i in range(num_ids):
+                L.check(lib.pgh_comm_unique_id(C.cast(C.byref(ids, i * L.COMM_ID_BYTES), C.c_void_p)))
+        wire = torch.tensor(list(ids), dtype=torch.uint8, device=device)
+        dist.broadcast(wire, src=0)
+        ids = (C.c_uint8 * (L.COMM_ID_BYTES * num_ids))(*wire.cpu().tolist())
+        handle = C.c_void_p()
+        L.check(lib.pgh_comm_create(C.cast(ids, C.c_void_p), num_ids, world, rank, C.byref(handle)))
+        _NATIVE_COMMS[key] = handle
+    return _NATIVE_COMMS[key]
+
+
+def release_native_comms():
+    """Destroys the engine's RCCL communicators of this process (before torch.distributed is torn down)."""
+    for handle in _NATIVE_COMMS.values():
+        L.lib().pgh_comm_destroy(handle)
+    _NATIVE_COMMS.clear()
+
+
 class DistributedPageRank:
     """PageRank(alpha) with ConvergenceManager(tol, error_type, max_iters, end_modulo) on a PartitionedGraph.
+
+    On GPUs over RCCL the whole run is ONE engine call (pgh_dist_ppr_run: the engine drives RCCL, streams and events itself);
+    the Python-driven loop below is the same choreography call by call -- what gloo / CPU runs use, and PGH_DIST_NATIVE=0.
 
     The loop is device-driven: the iteration's scalars (sum(y), residual, quotient, done flag) live in an 8-double
     device tensor, the RCCL all-reduces act on its elements in place, and every engine call turns into a no-op once the
@@ -264,6 +304,9 @@ class DistributedPageRank:
         lib = L.lib()
         g = pgraph.graph
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        comm = _native_comm(dist, device)
+        if comm is not None:
+            return self._rank_native(pgraph, p_local, comm, lib)
         if self._buffers is None or self._buffers_for is not pgraph:
             self._buffers = _Buffers(pgraph, device, dist)
             self._buffers_for = pgraph
@@ -305,6 +348,25 @@ class DistributedPageRank:
                 # every later single-GPU call of this process goes back to the engine's own stream
                 L.check(lib.pgh_sync())
                 L.check(lib.pgh_set_stream(None))
+
+    def _rank_native(self, pgraph, p_local, comm, lib):
+        cfg = L.DistCfg(alpha=float(self.alpha), tol=0.0 if self.tol is None else max(float(self.tol), self.epsilon), n_global=int(pgraph.n),
+                        err_kind=self._KINDS[self.error_type], max_iters=int(self.max_iters), end_modulo=int(self.end_modulo),
+                        use_quotient=1 if self.use_quotient else 0, preserve_norm=1 if self.preserve_norm else 0, reserved=0)
+        res = L.DistResult()
+        out = DeviceVector.empty(pgraph.n_local)
+        t0 = time.perf_counter()
+        L.check(lib.pgh_dist_ppr_run(pgraph.graph._h, comm, p_local._h, out._h, C.byref(cfg), C.byref(res)))
+        self.elapsed = time.perf_counter() - t0
+        self.iteration, self.spmv, self.converged = int(res.iterations), int(res.spmv_count), bool(res.converged)
+        self.last_error, self.loop_ms = float(res.last_error), float(res.loop_ms)
+        self.exchange = dict(exchange_bytes_per_iteration_per_gpu=int(res.exchange_bytes), gather_vector_slots=int(res.gather_slots),
+                             column_blocks=int(res.column_blocks), split_regions=bool(res.split_regions), driver="engine (RCCL)")
+        if res.iterations == 0:
+            return p_local
+        if not self.converged and self.error_type != "iters" and self.iteration >= self.max_iters:
+            raise Exception("Could not converge within " + str(self.max_iters) + " iterations")
+        return out
 
     def _rank_on_stream(self, pgraph, p_local, bufs, dist, lib, g, device, kind, tol, state, sum_view, err_view, err_op,
                         local_kind, read_state, torch):
@@ -422,6 +484,8 @@ class DistributedPageRank:
         assert steps == spmv, (steps, spmv)
         self.iteration, self.spmv, self.converged = it, spmv, converged
         self.last_error = float(bufs.state_host[6])
+        self.exchange = dict(exchange_bytes_per_iteration_per_gpu=bufs.exchange_bytes, gather_vector_slots=bufs.nb * bufs.live,
+                             column_blocks=bufs.nb, split_regions=False, driver="python (torch.distributed)")
         if not converged and self.error_type != "iters" and it >= self.max_iters:
             raise Exception("Could not converge within " + str(self.max_iters) + " iterations")
         factor = scale * (norm if self.preserve_norm else 1.0)                 # abstract_filters.py:63-64

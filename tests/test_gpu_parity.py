@@ -141,10 +141,12 @@ def test_full_size_properties_rmat20(gpu_engine):
     assert again.convergence.iteration == 2
 
 
-@pytest.mark.parametrize("world,backend,scale,single_queue", [(1, "nccl", 14, False), (2, "gloo", 14, False), (4, "gloo", 14, False),
-                                                              (2, "gloo", 18, False), (2, "gloo", 18, True), (1, "nccl", 14, True)],
-                         ids=["rccl_x1", "gloo_x2", "gloo_x4", "gloo_x2_cold_image", "gloo_x2_cold_image_single_queue", "rccl_x1_single_queue"])
-def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, scale, single_queue):
+@pytest.mark.parametrize("world,backend,scale,mode", [(1, "nccl", 14, ""), (2, "gloo", 14, ""), (4, "gloo", 14, ""), (2, "gloo", 18, ""),
+                                                      (2, "gloo", 18, "single_queue"), (1, "nccl", 14, "single_queue"),
+                                                      (1, "nccl", 18, ""), (1, "nccl", 18, "python_driver")],
+                         ids=["rccl_x1", "gloo_x2", "gloo_x4", "gloo_x2_cold_image", "gloo_x2_cold_image_single_queue", "rccl_x1_single_queue",
+                              "rccl_x1_cold_image_split_regions", "rccl_x1_cold_image_python_driver"])
+def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, scale, mode):
     """The N > 1 code path on the real engine: relabelled slice generation, the device-driven pgh_dist_* loop, in-place
     collectives on device scalars, the trimmed all-gather -- against the oracle.  World size 1 runs over RCCL; world sizes
     2 and 4 share the single GPU of this box and exchange through gloo (functional coverage of the multi-rank device
@@ -161,8 +163,13 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(29611 + world), os.path.join(root, "tests", "dist_worker.py"), str(tmp_path), str(scale), str(ef)]
     env = dict(os.environ, PYTHONPATH=root, PGH_TEST_ENGINE="hip", PGH_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if single_queue:                     # the conservative switches of a first multi-GPU run: one communicator, one stream
+    # RCCL runs go through the engine's own loop (pgh_dist_ppr_run: RCCL, streams and events driven from C++, hot prefixes and
+    # cold parts of the gather vector exchanged as two contiguous regions); gloo runs and "python_driver" through the staged
+    # pgh_dist_* calls from pygrank_amd/distributed.py
+    if mode == "single_queue":           # the conservative switches of a first multi-GPU run: one communicator, one stream
         env.update(PGH_DIST_SINGLE_COMM="1", PGH_DIST_SINGLE_STREAM="1")
+    if mode == "python_driver":
+        env.update(PGH_DIST_NATIVE="0")
     if scale > 14:                       # four column blocks over two ranks: two all-gathers per exchange, like bench.py --gpus 2
         env.update(PGH_PB="1", PGH_PB_FORCE="1", PGH_DEBUG="1", PGH_BLOCKS="4", PGH_PB_HEAVY="64", PGH_PB_HUBMAX="500")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
