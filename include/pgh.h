@@ -248,6 +248,13 @@ int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y);
  * results[j] is what pgh_ppr_run would report for seed j.  out_scales (nullable): per-column preserve_norm factor. */
 int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales,
                       pgh_loop_result* per_column_results);
+/* The same two with graph_dropout(M, rate) (specification.py:13; pytorch.py:34-38) evaluated inside the batch kernel: the mask is
+ * the one pgh_spmv_dropout applies -- a hash of (seed, index of the entry in CSR(M^T) order), so a multi-edge is kept or dropped
+ * as a whole -- and the filters draw a fresh mask for every step (abstract_filters.py:61): step k of the batch run uses
+ * seed0 + k - 1.  rate == 0 is the plain call. */
+int pgh_spmm_dropout(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y, double rate, uint64_t seed);
+int pgh_ppr_run_batch_dropout(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales,
+                              double rate, uint64_t seed0, pgh_loop_result* per_column_results);
 
 /* ---------------------------------------------------------------- row-partitioned step ---- */
 /* The path shards with one exchange per iteration: every rank holds a contiguous slice of the rows of M^T in a

@@ -873,6 +873,72 @@ int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loo
     return 0;
 }
 
+// the batch entry points with graph_dropout: the mask of pgh_spmv_dropout (a hash of (seed, index of the entry in CSR(M^T) order))
+static inline float dropped_row_dot(const pgh_graph_s* g, const float* x, int64_t row, uint64_t seed, uint32_t threshold, float keep) {
+    double acc = 0;
+    for (int64_t k = g->rowptr[row]; k < g->rowptr[row + 1]; ++k) {
+        uint64_t z = (seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ULL)) + 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z = z ^ (z >> 31);
+        const float f = (uint32_t)(z >> 32) >= threshold ? keep : 0.f;
+        acc += (double)((g->val[k] * f) * x[g->col[k]]);
+    }
+    return (float)acc;
+}
+int pgh_spmm_dropout(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y, double rate, uint64_t seed) {
+    if (rate == 0.0) return pgh_spmm(g, x, y);
+    CHECK(g && x && y && x->n == g->n_rows && y->n == g->n_cols && x->b == y->b, "pgh_spmm_dropout: shape mismatch");
+    CHECK(x->b >= 1 && x->b <= 64 && rate > 0.0 && rate < 1.0, "pgh_spmm_dropout: batch width in [1, 64], rate in [0, 1)");
+    const uint32_t threshold = (uint32_t)std::floor(rate * 4294967296.0);
+    const float keep = (float)(1.0 / (1.0 - rate));
+    std::vector<float> col(g->n_rows);
+    for (int32_t j = 0; j < x->b; ++j) {
+        for (int64_t i = 0; i < g->n_rows; ++i) col[i] = x->data[i * x->b + j];
+        for (int64_t r = 0; r < g->n_cols; ++r) y->data[r * y->b + j] = dropped_row_dot(g, col.data(), r, seed, threshold, keep);
+    }
+    return 0;
+}
+int pgh_ppr_run_batch_dropout(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales, double rate,
+                              uint64_t seed0, pgh_loop_result* results) {
+    if (rate == 0.0) return pgh_ppr_run_batch(g, p, ranks, cfg, out_scales, results);
+    CHECK(g && p && ranks && cfg && results && p->n == g->n_cols && ranks->n == g->n_cols && p->b == ranks->b,
+          "pgh_ppr_run_batch_dropout: shape mismatch");
+    CHECK(p->b >= 1 && p->b <= 64 && rate > 0.0 && rate < 1.0, "pgh_ppr_run_batch_dropout: batch width in [1, 64], rate in [0, 1)");
+    const int64_t n = g->n_cols;
+    const uint32_t threshold = (uint32_t)std::floor(rate * 4294967296.0);
+    const float keep = (float)(1.0 / (1.0 - rate));
+    for (int32_t j = 0; j < p->b; ++j) {
+        pgh_vec_t vp, vr;
+        pgh_vec_alloc(n, &vp);
+        pgh_vec_alloc(n, &vr);
+        for (int64_t i = 0; i < n; ++i) {
+            vp->data[i] = p->data[i * p->b + j];
+            vr->data[i] = ranks->data[i * p->b + j];
+        }
+        pgh_loop_cfg c = *cfg;
+        if (out_scales) c.out_scale = out_scales[j];
+        const std::vector<float> pn = normalised(vp, &c);
+        uint64_t step = 0;                                   // step k of every column uses the mask of seed0 + k - 1
+        const int rc = recursive_run(g, vr, &c, &results[j], pn.data(), [&](const float* x, double xs, float* y) {
+            const float a = (float)(c.alpha * xs), b = (float)(1.0 - c.alpha);
+            const uint64_t seed = seed0 + step++;
+            double sum = 0;
+            for (int64_t r = 0; r < n; ++r) {
+                const float v = a * dropped_row_dot(g, x, r, seed, threshold, keep) + b * pn[r];
+                y[r] = v;
+                sum += v;
+            }
+            return sum;
+        });
+        for (int64_t i = 0; i < n; ++i) ranks->data[i * p->b + j] = vr->data[i];
+        pgh_vec_free(vp);
+        pgh_vec_free(vr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static int rmat_build(int32_t scale, int32_t ef, double a, double b, double c, uint64_t seed, int32_t normalization,
                       int32_t symmetrize, int64_t row_begin, int64_t row_end, int32_t part_rank, int32_t part_count,
                       pgh_graph_t* out) {

@@ -131,6 +131,9 @@ SIGNATURES = {
                                C.POINTER(LoopResult)]),
     "pgh_spmm": (C.c_int, [c_graph, c_mat, c_mat]),
     "pgh_ppr_run_batch": (C.c_int, [c_graph, c_mat, c_mat, C.POINTER(LoopCfg), C.c_void_p, C.POINTER(LoopResult)]),
+    "pgh_spmm_dropout": (C.c_int, [c_graph, c_mat, c_mat, C.c_double, C.c_uint64]),
+    "pgh_ppr_run_batch_dropout": (C.c_int, [c_graph, c_mat, c_mat, C.POINTER(LoopCfg), C.c_void_p, C.c_double, C.c_uint64,
+                                            C.POINTER(LoopResult)]),
     "pgh_ppr_step_dist": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, C.c_double, c_vec, c_vec, c_f64p]),
     "pgh_graph_gather_layout": (C.c_int, [c_graph, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_void_p]),
     "pgh_graph_set_gather_bases": (C.c_int, [c_graph, C.c_void_p]),

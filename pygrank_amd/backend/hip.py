@@ -28,6 +28,13 @@ def set_dropout_seed(seed):
     _dropout_calls[0] = int(seed)
 
 
+def take_dropout_seeds(count):
+    """Reserves `count` consecutive mask seeds (a fused batch run draws one per step) and returns the first."""
+    first = _dropout_calls[0] + 1
+    _dropout_calls[0] += int(count)
+    return first
+
+
 def graph_dropout(M, dropout):            # specification.py:13; identity and O(1) for dropout == 0 (called 2 + #steps times)
     if dropout == 0:
         return M

@@ -1152,6 +1152,7 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.head_partial);
     (void)hipFree(f.part);
     (void)hipFree(f.mm_close);
+    (void)hipFree(f.mm_edge);
     (void)hipFree(f.iso_flag);
     (void)hipFree(f.seed_list);
     (void)hipFree(f.seed_count);

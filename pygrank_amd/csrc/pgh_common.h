@@ -220,6 +220,8 @@ struct BsfFormat {
     float*    part = nullptr;       // multi-seed layout only: per-tile head sums
     int32_t*  mm_close = nullptr;   // multi-seed layout only: closing row of every entry (k_mm_close_rows, pgh_spmm.hip)
     uint8_t*  mm_row_has = nullptr; // multi-seed layout only: 1 = the row of M^T holds entries (k_mm_mark_rows)
+    int32_t*  mm_edge = nullptr;    // multi-seed layout, graph_dropout only: index of every stream entry in CSR(M^T) order (-1 = pad), the
+                                    // argument of the dropout hash; copies of a multi-edge share one index (k_mm_edge_ids)
     // SpMV layout: block partial sums are stored COMPACTLY, one float per (block, row) segment in stream order (psum),
     // written sequentially by k_bsf_partial; the epilogue finds the segments of a row through one SegMeta word per
     // (block, 64 rows): bit r of mask = row 64 w + r has a segment in the block, base = index of the word's first segment

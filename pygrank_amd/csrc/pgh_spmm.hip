@@ -100,6 +100,53 @@ __global__ __launch_bounds__(WG) void k_mm_mark_rows(const int32_t* __restrict__
     }
 }
 
+// graph_dropout in the batch kernel: the mask of pgh_spmv_dropout -- a hash of (seed, index of the entry in CSR(M^T) order) --
+// evaluated per stream entry; the index rides in a word of its own (BsfFormat::mm_edge) that only dropout launches read
+struct MMDrop {
+    const int32_t* edge;
+    uint64_t       seed;
+    uint32_t       threshold;    // floor(rate * 2^32)
+    float          keep_scale;   // 1 / (1 - rate)
+};
+
+// index in CSR(M^T) order of every entry of the multi-seed stream (built once, on the first dropout launch): the entry's
+// row is that of its segment, its source is the column word; both go back to the caller's ids and the source is looked up
+// in the row (sorted indices: binary search)
+__global__ __launch_bounds__(WG) void k_mm_edge_ids(const uint32_t* __restrict__ colf, const int4* __restrict__ tile,
+                                                     const int32_t* __restrict__ seg_row, int num_tiles, const int32_t* __restrict__ perm,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     int32_t* __restrict__ edge) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    const int stride = gridDim.x * (WG / 64);
+    for (int t = wave; t < num_tiles; t += stride) {
+        const int4 ti = tile[t];
+        const int64_t base = ti.x;
+        int before = 0;
+        for (int c = 0; c < kTileMM / 64; ++c) {
+            const int e = c * 64 + lane;
+            const uint32_t w = colf[base + e];
+            const unsigned long long mask = __ballot((w >> 31) != 0);
+            const int k = before + __popcll(mask & (~0ULL >> (63 - lane)));       // flags at positions <= e
+            const int seg = ti.z + k;                                             // ti.z = the segment open at the tile start
+            const int row_new = seg >= 0 ? seg_row[seg] : -1;
+            int out = -1;
+            if (row_new >= 0) {
+                const int row_old = perm ? perm[row_new] : row_new;
+                const int col_old = perm ? perm[w & 0x7fffffffu] : (int)(w & 0x7fffffffu);
+                int lo = rowptr[row_old], hi = rowptr[row_old + 1];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (col[mid] < col_old) lo = mid + 1; else hi = mid;
+                }
+                out = lo;
+            }
+            edge[base + e] = out;
+            before += __popcll(mask);
+        }
+    }
+}
+
 // One wavefront = four groups of 16 lanes; a group walks its own 512-entry tile and a lane holds 4 of the <= 64 batch
 // columns, so ONE 16-byte load instruction of the wavefront fetches four 256-byte rows of the gather slab (the first
 // version fetched one row per instruction with lane = column and kept 8 of them in flight between dependent scalar
@@ -115,9 +162,9 @@ __global__ __launch_bounds__(WG) void k_mm_mark_rows(const int32_t* __restrict__
 // not change the hit rate (8.9-9.5 ms per step against 8.7).
 // Narrow batches: a row of <= 32 (<= 16) columns needs 8 (4) lanes, so the wavefront is cut into 8 (16) groups and one load
 // instruction fetches 8 (16) rows; a lane then holds 2 (4) of the 16 stream words of its group's round.
-template <bool HAS_VAL, int LPR>
+template <bool HAS_VAL, int LPR, bool DROP = false>
 __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __restrict__ xg, int ld, int b, float* __restrict__ sums,
-                                                    const BatchState* __restrict__ state) {
+                                                    const BatchState* __restrict__ state, MMDrop drop = MMDrop{}) {
     if (state != nullptr && state->all_done) return;
     constexpr int G = 64 / LPR;                            // groups (tiles in flight) per wavefront
     constexpr int W = 16 / LPR;                            // stream words of a 16-entry round per lane
@@ -131,7 +178,7 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
     struct Words {
         uint32_t w[W];
         int      c[W];
-        float    v[W];
+        float    v[W];               // the entry's value; with DROP: times the mask's factor (0 or 1 / (1 - rate))
     };
     for (int t0 = wave * G; t0 < f.num_tiles; t0 += stride) {
         const int t = t0 + lane / LPR;
@@ -145,6 +192,10 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
                 q.w[k] = __builtin_nontemporal_load(f.colf + at + k);
                 q.c[k] = has ? __builtin_nontemporal_load(f.close + at + k) : -1;
                 q.v[k] = HAS_VAL ? __builtin_nontemporal_load(f.val + at + k) : 1.f;
+                if (DROP) {
+                    const int edge = __builtin_nontemporal_load(drop.edge + at + k);
+                    q.v[k] *= edge >= 0 ? dropout_factor(drop.seed, (uint64_t)edge, drop.threshold, drop.keep_scale) : 0.f;
+                }
             }
         };
         // entry j of the round lives in word j % W of lane j / W of the group
@@ -163,7 +214,7 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
                 const int e = 8 * half + j;
                 const int ends = __builtin_amdgcn_ds_bpermute(pull + 4 * (e / W), q.c[e % W]);
                 f32x4 xv = x[j];
-                if (HAS_VAL) xv *= __int_as_float(__builtin_amdgcn_ds_bpermute(pull + 4 * (e / W), __float_as_int(q.v[e % W])));
+                if (HAS_VAL || DROP) xv *= __int_as_float(__builtin_amdgcn_ds_bpermute(pull + 4 * (e / W), __float_as_int(q.v[e % W])));
                 a0 += (double)xv.x;
                 a1 += (double)xv.y;
                 a2 += (double)xv.z;
@@ -595,7 +646,20 @@ MMView mm_view(const BsfFormat& f) {
 }
 
 // sums <- M^T-times-gather-slab (plain row sums in the internal id space); sums must have its structural zeros in place
-int mm_partial(pgh_graph_s* g, const float* xg, int ld, int b, float* sums, const BatchState* state) {
+int ensure_mm_edge_ids(pgh_graph_s* g) {
+    BsfFormat& f = g->bsf_mm;
+    if (f.mm_edge != nullptr) return 0;
+    PGH_CHECK(g->rowptr != nullptr && g->col != nullptr, "graph_dropout on a batch needs the CSR image of the graph");
+    PGH_HIP(hipMalloc(&f.mm_edge, sizeof(int32_t) * (size_t)f.num_entries));
+    k_mm_edge_ids<<<blocks_for((int64_t)f.num_tiles * 64, 64), WG, 0, rt().stream>>>(f.colf, f.tile, f.seg_row, f.num_tiles, f.perm, g->rowptr,
+                                                                                      g->col, f.mm_edge);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    f.device_bytes += (int64_t)f.num_entries * 4;
+    return 0;
+}
+
+int mm_partial(pgh_graph_s* g, const float* xg, int ld, int b, float* sums, const BatchState* state, const MMDrop* drop = nullptr) {
     Runtime& r = rt();
     const BsfFormat& f = g->bsf_mm;
     const MMView v = mm_view(f);
@@ -612,7 +676,17 @@ int mm_partial(pgh_graph_s* g, const float* xg, int ld, int b, float* sums, cons
         if (per_cu < 1) per_cu = 1;
     }
     const int grid = r.num_cus * per_cu;
-    {
+    if (drop != nullptr) {          // graph_dropout: the same shapes with the mask word (the value-free stream gets a factor per entry)
+        ProfScope prof(PGH_K_SPMM);
+        switch (which) {
+            case 0: k_mm_partial<false, 16, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, *drop); break;
+            case 1: k_mm_partial<false, 8, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, *drop); break;
+            case 2: k_mm_partial<false, 4, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, *drop); break;
+            case 3: k_mm_partial<true, 16, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, *drop); break;
+            case 4: k_mm_partial<true, 8, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, *drop); break;
+            default: k_mm_partial<true, 4, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, *drop); break;
+        }
+    } else {
         ProfScope prof(PGH_K_SPMM);
         switch (which) {
             case 0: k_mm_partial<false, 16><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
@@ -638,7 +712,30 @@ int combine_grid() { return rt().num_cus * 8; }
 // =================================================================================================
 // C-ABI
 // =================================================================================================
-extern "C" int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
+namespace {
+// the mask of one launch: null for rate == 0
+int make_drop(pgh_graph_s* g, double rate, uint64_t seed, MMDrop* out, const MMDrop** use) {
+    *use = nullptr;
+    if (rate == 0.0) return 0;
+    PGH_CHECK(rate > 0.0 && rate < 1.0, "graph_dropout: the rate must lie in [0, 1)");
+    PGH_TRY(ensure_mm_edge_ids(g));
+    out->edge = g->bsf_mm.mm_edge;
+    out->seed = seed;
+    out->threshold = (uint32_t)floor(rate * 4294967296.0);
+    out->keep_scale = (float)(1.0 / (1.0 - rate));
+    *use = out;
+    return 0;
+}
+int spmm_impl(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y, double rate, uint64_t seed);
+int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales, double rate, uint64_t seed0,
+               pgh_loop_result* results);
+}  // namespace
+
+extern "C" int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) { return spmm_impl(g, x, y, 0.0, 0); }
+extern "C" int pgh_spmm_dropout(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y, double rate, uint64_t seed) { return spmm_impl(g, x, y, rate, seed); }
+
+namespace {
+int spmm_impl(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y, double rate, uint64_t seed) {
     PGH_CHECK(g && x && y, "pgh_spmm: null argument");
     PGH_CHECK(x->n == g->n_rows && y->n == g->n_cols && x->b == y->b, "pgh_spmm: shape mismatch");
     PGH_CHECK(x->b >= 1 && x->b <= kLanes, "pgh_spmm: the batch width must be in [1, 64]");
@@ -662,7 +759,10 @@ extern "C" int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
         q.row_scale = f.src_scale;
         k_mm_permute_in<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(q, f.perm, n_int, g->n_rows, b, ld);
     }
-    PGH_TRY(mm_partial(g, xg.as<float>(), ld, b, sums.as<float>(), nullptr));
+    MMDrop drop_store;
+    const MMDrop* drop = nullptr;
+    PGH_TRY(make_drop(g, rate, seed, &drop_store, &drop));
+    PGH_TRY(mm_partial(g, xg.as<float>(), ld, b, sums.as<float>(), nullptr, drop));
     CombineParams c{};
     c.sums = sums.as<float>();
     c.dst_scale = f.dst_scale;
@@ -678,10 +778,24 @@ extern "C" int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
     return 0;
 }
 
+}  // namespace
+
 // Batched PageRank: b independent runs of PageRank(alpha) with the SAME ConvergenceManager settings; column j stops
 // at its own iteration (frozen afterwards), exactly as b calls of pgh_ppr_run would.
 extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales,
                                  pgh_loop_result* results) {
+    return batch_impl(g, p, ranks, cfg, out_scales, 0.0, 0, results);
+}
+// ... with graph_dropout (abstract_filters.py:61: a fresh mask for every step): step k of the batch multiplies by the matrix
+// masked with seed0 + k - 1, the mask pgh_spmv_dropout(seed0 + k - 1) would apply
+extern "C" int pgh_ppr_run_batch_dropout(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales,
+                                         double rate, uint64_t seed0, pgh_loop_result* results) {
+    return batch_impl(g, p, ranks, cfg, out_scales, rate, seed0, results);
+}
+
+namespace {
+int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales, double rate, uint64_t seed0,
+               pgh_loop_result* results) {
     PGH_CHECK(g && p && ranks && cfg && results, "pgh_ppr_run_batch: null argument");
     PGH_CHECK(g->n_rows == g->n_cols && p->n == g->n_cols && ranks->n == g->n_cols && p->b == ranks->b, "pgh_ppr_run_batch: shape mismatch");
     PGH_CHECK(p->b >= 1 && p->b <= kLanes, "pgh_ppr_run_batch: the batch width must be in [1, 64]");
@@ -739,7 +853,10 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
             const int k = enq + 1;
             float* yin = buf[(k - 1) & 1];
             float* yout = buf[k & 1];
-            PGH_TRY(mm_partial(g, xg.as<float>(), ld, b, sums.as<float>(), state));
+            MMDrop drop_store;
+            const MMDrop* drop = nullptr;
+            PGH_TRY(make_drop(g, rate, seed0 + (uint64_t)(k - 1), &drop_store, &drop));
+            PGH_TRY(mm_partial(g, xg.as<float>(), ld, b, sums.as<float>(), state, drop));
             CombineParams c{};
             c.sums = sums.as<float>();
             c.dst_scale = f.dst_scale;
@@ -798,3 +915,4 @@ extern "C" int pgh_ppr_run_batch(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, co
     }
     return 0;
 }
+}  // namespace

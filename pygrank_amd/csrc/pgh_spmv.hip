@@ -73,16 +73,6 @@ struct EpiPoly64 {
     }
 };
 
-// graph_dropout(M, rate) (pytorch.py:34-38: torch.nn.functional.dropout on the edge values): an entry survives with
-// probability 1 - rate and is then scaled by 1 / (1 - rate); the mask is a pure function of (seed, entry index in
-// CSR(M^T) order), so a dropped graph is a (graph, rate, seed) triple and costs no memory.  Host twin: tests/kernel_checks.py.
-__device__ __forceinline__ float dropout_factor(uint64_t seed, uint64_t entry, uint32_t threshold, float keep_scale) {
-    uint64_t z = (seed ^ (entry * 0xD6E8FEB86659FD93ULL)) + 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32) >= threshold ? keep_scale : 0.f;
-}
 struct NoDropout {
     static constexpr bool kOn = false;
     uint64_t seed;

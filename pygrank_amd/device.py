@@ -491,7 +491,11 @@ class DroppedGraph:
 
     def conv(self, x):
         if isinstance(x, DeviceMatrix):
-            return DeviceMatrix.from_columns([self.conv(c) for c in x.columns()])
+            if self.shape[0] != self.shape[1] or x.b > 64:
+                return DeviceMatrix.from_columns([self.conv(c) for c in x.columns()])
+            out = DeviceMatrix.empty(self.shape[1], x.b)                 # one pass over the adjacency for the whole slab
+            L.check(L.lib().pgh_spmm_dropout(self.base._h, x._h, out._h, self.rate, self.seed))
+            return out
         y = DeviceVector.empty(self.shape[1])
         L.check(L.lib().pgh_spmv_dropout(self.base._h, x._h, y._h, self.rate, self.seed))
         return y

@@ -252,7 +252,9 @@ class PageRank(RecursiveGraphFilter):
         keeps its own quotient, residual and stopping iteration."""
         from pygrank_amd.device import DeviceMatrix
         cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), 1.0)
-        batched = (not args and not kwargs and cfg is not None and self._plain_quotient()
+        dropout = float(kwargs.get("graph_dropout", 0) or 0)
+        only_dropout = not kwargs or (set(kwargs) == {"graph_dropout"} and 0 <= dropout < 1)
+        batched = (not args and only_dropout and cfg is not None and self._plain_quotient()
                    and type(self)._formula is PageRank._formula and type(self)._step is RecursiveGraphFilter._step
                    and isinstance(self.personalization_transform, Tautology) and self.personalization_transform.ranker is None)
         M = self.preprocessor(graph) if batched else None
@@ -273,7 +275,14 @@ class PageRank(RecursiveGraphFilter):
             scales = (C.c_double * chunk.b)(*[(float(nrm) if self.preserve_norm else 1.0) for nrm in norms])
             cfg.start_from_p = 1                                                  # ranks start as a copy of p (:56)
             self.convergence.start()
-            L.check(L.lib().pgh_ppr_run_batch(g._h, P._h, R._h, C.byref(cfg), scales, results))
+            if dropout > 0:
+                # graph_dropout(M, rate) of every step (abstract_filters.py:59-62) inside the batch kernel: one mask per step,
+                # seeds reserved up front (the loop stops on the device)
+                from pygrank_amd.backend import hip as _hip
+                seed0 = _hip.take_dropout_seeds(max(int(cfg.max_iters), 1))
+                L.check(L.lib().pgh_ppr_run_batch_dropout(g._h, P._h, R._h, C.byref(cfg), scales, dropout, seed0, results))
+            else:
+                L.check(L.lib().pgh_ppr_run_batch(g._h, P._h, R._h, C.byref(cfg), scales, results))
             info = [dict(iterations=r.iterations, converged=bool(r.converged), spmv=r.spmv_count, loop_ms=r.loop_ms)
                     for r in results]
             self.last_batches.append(info)

@@ -189,6 +189,64 @@ def check_graph_dropout(pg):
         assert np.all(np.isfinite(out)) and out.sum() > 0
 
 
+def check_graph_dropout_batched(pg):
+    """graph_dropout inside the multi-seed kernel ("per-iteration edge masking in the SpMM kernel"): a slab
+    product against scipy on the rebuilt mask, and propagate(..., graph_dropout=) as ONE batched device loop against a host
+    loop that rebuilds the mask of every step (seed0 + k - 1) -- on a multigraph (value-free stream, repeated entries share
+    one mask bit) and on a weighted graph (valued stream)."""
+    def mask_of(MT, rate, seed):
+        e = np.arange(MT.nnz, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            h = rmat_np.splitmix64(np.uint64(seed) ^ (e * np.uint64(0xD6E8FEB86659FD93)))
+        keep = (h >> np.uint64(32)).astype(np.int64) >= int(np.floor(rate * 4294967296.0))
+        data = (MT.data.astype(F32) * np.float32(1.0 / (1.0 - rate))).astype(F32).astype(np.float64) * keep
+        return sp.csr_array((data, MT.indices, MT.indptr), shape=MT.shape)
+
+    rng = np.random.default_rng(21)
+    A = rmat_np.rmat_csr(11, 8, seed=5)                            # duplicate edges: weights 1, 2, 3 ...
+    W = sp.csr_array(A)
+    W.data = rng.uniform(0.5, 2.0, W.nnz)
+    for label, adj in (("multigraph", A), ("weighted", W)):
+        n = adj.shape[0]
+        graph = pg.AdjacencyWrapper(adj, directed=True)
+        pre = pg.preprocessor(normalization="col", assume_immutability=True)
+        g = pre(graph)
+        g = getattr(g, "array", g)
+        MT = g.download_transposed()
+        rate, b = 0.3, 5
+        X = rng.random((n, b)).astype(F32).astype(np.float64)
+        pg.backend.hip.set_dropout_seed(100)
+        dropped = pg.graph_dropout(g, rate)
+        got = np.asarray(pg.conv(pg.to_primitive(X), dropped))
+        masked = mask_of(MT, rate, dropped.seed)
+        ref, scale = masked @ X, np.abs(masked) @ np.abs(X)
+        assert got.shape == ref.shape and np.all(np.abs(got - ref) <= 2.5 * EPS32 * scale + 1e-30), label
+        # ---- the batched loop: 7 iterations = 6 steps, each with its own mask
+        F = np.zeros((n, b))
+        for j in range(b):
+            F[rng.choice(n, 15, replace=False), j] = rng.random(15) + 0.5
+        ranker = pg.PageRank(0.85, preprocessor=pre, error_type="iters", max_iters=7)
+        pg.backend.hip.set_dropout_seed(500)
+        out = np.asarray(ranker.propagate(graph, pg.to_primitive(F), graph_dropout=rate))
+        assert hasattr(ranker, "last_batches") and all(c["spmv"] == 6 for c in ranker.last_batches[0]), label
+        for j in range(b):
+            norm = np.abs(F[:, j]).sum()
+            pj = (F[:, j].astype(F32) / np.float32(norm)).astype(np.float64)
+            x, quot = pj.copy(), 1.0
+            for k in range(6):
+                y = 0.85 * quot * (mask_of(MT, rate, 501 + k) @ x) + 0.15 * pj
+                quot, x = 1.0 / y.sum(), y
+            want = x * quot * norm
+            assert np.max(np.abs(out[:, j] - want)) <= 2e-6 * np.max(np.abs(want)), (label, j)
+        # a different seed gives a different outcome; rate 0 through the same entry point is the plain batch
+        pg.backend.hip.set_dropout_seed(900)
+        other = np.asarray(ranker.propagate(graph, pg.to_primitive(F), graph_dropout=rate))
+        assert not np.array_equal(other, out)
+        plain = np.asarray(ranker.propagate(graph, pg.to_primitive(F)))
+        zero = np.asarray(ranker.propagate(graph, pg.to_primitive(F), graph_dropout=0))
+        assert np.array_equal(plain, zero)
+
+
 def check_fused_steps(pg):
     from pygrank_amd import _lib as L
     from pygrank_amd.device import DeviceVector
