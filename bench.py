@@ -580,23 +580,27 @@ def spawn_ranks(args):
     rank per GPU) and relay rank 0's JSON line.  This parent has not touched the GPU (no HIP call, no torch.cuda query) and
     never replaces itself with another program."""
     import socket
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     entry = os.path.abspath(getattr(sys.modules["__main__"], "__file__", __file__))     # tests enter through a wrapper
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), entry] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["PYTHONPATH"] = ROOT + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True)
-    line = None
-    for out in proc.stdout:
-        if out.lstrip().startswith("{"):
-            line = out.strip()
-        else:
-            sys.stderr.write(out)
-    rc = proc.wait()
+    rc, line = 1, None
+    for attempt in range(2):                    # the port is free when it is picked, not necessarily when the launcher binds it
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), entry] + sys.argv[1:]
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True)
+        line = None
+        for out in proc.stdout:
+            if out.lstrip().startswith("{"):
+                line = out.strip()
+            else:
+                sys.stderr.write(out)
+        rc = proc.wait()
+        if line is not None or rc == 3:         # a result, or a watchdog exit (retrying a stalled collective helps nobody)
+            break
     if line is not None:
         print(line, flush=True)
     return rc if rc != 0 or line is not None else 1

@@ -91,6 +91,13 @@ int pgh_filter_out(pgh_vec_t x, pgh_vec_t exclude, pgh_vec_t out, int64_t* out_l
  * that sort before x[i] in descending order of value (ties: lower index first, as python's stable sorted(reverse=True));
  * value of the k-th largest entry (k >= 1).  One device radix sort each. */
 int pgh_vec_ordinals(pgh_vec_t x, pgh_vec_t out);
+/* AUC of scores against binary labels (non-zero = positive), ties at their mid-rank: what sklearn.metrics.roc_curve + auc
+ * compute in the reference (measures/supervised.py:255-263), with one device sort.  *num_positive receives the number of
+ * positives (the caller raises when all labels agree, :259-260). */
+int pgh_auc(pgh_vec_t labels, pgh_vec_t scores, double* auc, int64_t* num_positive);
+/* Threshold("gap") (algorithms/postprocess/postprocess.py:328-343): the score after the first largest relative drop of the
+ * descending order; 0 when there is none. */
+int pgh_vec_gap_threshold(pgh_vec_t x, double* threshold);
 int pgh_vec_kth_largest(pgh_vec_t x, int64_t k, double* value);
 
 /* reductions: sum/min/max/mean/dot, specification.py:29-43,109; f64 accumulation */

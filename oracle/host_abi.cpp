@@ -375,6 +375,49 @@ int pgh_vec_kth_largest(pgh_vec_t x, int64_t k, double* value) {
     *value = x->data[order_desc(x)[k - 1]];
     return 0;
 }
+// AUC as the pair statistic it is (supervised.py:255-263): P(score of a positive > score of a negative) + P(equal) / 2,
+// counted from the descending order with ties grouped -- written differently from the engine's mid-rank sum on purpose
+int pgh_auc(pgh_vec_t labels, pgh_vec_t scores, double* auc, int64_t* num_positive) {
+    CHECK(labels && scores && auc && labels->n == scores->n, "pgh_auc: bad arguments");
+    const std::vector<int64_t> order = order_desc(scores);
+    const int64_t n = scores->n;
+    double pos_total = 0;
+    for (int64_t i = 0; i < n; ++i) pos_total += labels->data[i] != 0.f ? 1.0 : 0.0;
+    double wins = 0, pos_seen = 0;                      // positives strictly above the current tie group
+    for (int64_t k = 0; k < n;) {
+        int64_t e = k;
+        double gp = 0, gn = 0;
+        while (e < n && scores->data[order[e]] == scores->data[order[k]]) {
+            if (labels->data[order[e]] != 0.f) gp += 1; else gn += 1;
+            ++e;
+        }
+        wins += gn * pos_seen + 0.5 * gn * gp;
+        pos_seen += gp;
+        k = e;
+    }
+    const double neg_total = (double)n - pos_total;
+    if (num_positive) *num_positive = (int64_t)pos_total;
+    *auc = (pos_total > 0 && neg_total > 0) ? wins / (pos_total * neg_total) : 0.0;
+    return 0;
+}
+int pgh_vec_gap_threshold(pgh_vec_t x, double* threshold) {              // postprocess.py:328-343, the reference's loop
+    CHECK(x && threshold, "pgh_vec_gap_threshold: null argument");
+    const std::vector<int64_t> order = order_desc(x);
+    double max_diff = 0, thr = 0, prev = 0;
+    for (int64_t k = 0; k < x->n; ++k) {
+        const double v = (double)x->data[order[k]];
+        if (prev > 0) {
+            const double diff = (prev - v) / prev;
+            if (diff > max_diff) {
+                max_diff = diff;
+                thr = v;
+            }
+        }
+        prev = v;
+    }
+    *threshold = thr;
+    return 0;
+}
 int pgh_mat_gemv(pgh_mat_t m, const double* c, int32_t count, pgh_vec_t out) {
     CHECK(m && out && (c || count == 0) && count >= 0 && count <= m->b && out->n == m->n, "pgh_mat_gemv: shape mismatch");
     for (int64_t i = 0; i < m->n; ++i) {

@@ -22,7 +22,7 @@ from pygrank_amd.signals import GraphSignal, NodeRanking, to_signal
 from pygrank_amd.preprocessing import (Adjacency, AdjacencyWrapper, MethodHasher, obj2id, preprocessor,
                                        to_sparse_matrix)
 from pygrank_amd.utils import call, ensure_used_args, remove_used_args
-from pygrank_amd.measures import (L1, L2, MSQ, MSQRT, Cos, Dot, Euclidean, Mabs, MaxDifference, RMabs, Supervised)
+from pygrank_amd.measures import (AUC, L1, L2, MSQ, MSQRT, Cos, Dot, Euclidean, Mabs, MaxDifference, RMabs, Supervised)
 from pygrank_amd.convergence import ConvergenceManager
 from pygrank_amd.postprocess import (LinearSweep, Normalize, Ordinals, Postprocessor, Sweep, Tautology, Threshold, Top,
                                      Transformer)

@@ -87,6 +87,8 @@ SIGNATURES = {
     "pgh_filter_out": (C.c_int, [c_vec, c_vec, c_vec, c_i64p]),
     "pgh_vec_ordinals": (C.c_int, [c_vec, c_vec]),
     "pgh_vec_kth_largest": (C.c_int, [c_vec, C.c_int64, c_f64p]),
+    "pgh_auc": (C.c_int, [c_vec, c_vec, c_f64p, c_i64p]),
+    "pgh_vec_gap_threshold": (C.c_int, [c_vec, c_f64p]),
     "pgh_reduce": (C.c_int, [C.c_int, c_vec, c_f64p]),
     "pgh_dot": (C.c_int, [c_vec, c_vec, c_f64p]),
     "pgh_residual": (C.c_int, [C.c_int, c_vec, c_vec, c_f64p]),

@@ -1130,6 +1130,124 @@ extern "C" int pgh_vec_kth_largest(pgh_vec_t x, int64_t k, double* value) {
     return 0;
 }
 
+namespace {
+// Ranks of the positives in the DESCENDING order of the scores, ties at their mid-rank (what sklearn's roc_curve / auc
+// amount to, supervised.py:255-263): an element at sorted position k whose tie group spans [gs, ge] has ascending mid-rank
+// n - (gs + ge) / 2.  The group is found by two binary searches in the sorted keys (positives only).
+__global__ void k_auc_partials(const float* __restrict__ keys, const int32_t* __restrict__ order, const float* __restrict__ labels,
+                               int64_t n, double* __restrict__ part_rank, double* __restrict__ part_pos) {
+    __shared__ double s_scratch[4];
+    double rank_sum = 0.0, pos = 0.0;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        if (labels[order[k]] == 0.f) continue;
+        const float key = keys[k];
+        int64_t lo = 0, hi = k;                            // first index whose key is not above this one
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] > key) lo = mid + 1; else hi = mid;
+        }
+        const int64_t gs = lo;
+        lo = k, hi = n;                                    // first index whose key is below this one
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] >= key) lo = mid + 1; else hi = mid;
+        }
+        const int64_t ge = lo - 1;
+        rank_sum += (double)n - 0.5 * (double)(gs + ge);
+        pos += 1.0;
+    }
+    const double a = block_reduce_256<0>(rank_sum, s_scratch);
+    __syncthreads();
+    const double b = block_reduce_256<0>(pos, s_scratch);
+    if (threadIdx.x == 0) {
+        part_rank[blockIdx.x] = a;
+        part_pos[blockIdx.x] = b;
+    }
+}
+
+// relative drop between neighbours of the descending order (postprocess.py:335-343): drop_k = (v_k - v_{k+1}) / v_k for v_k > 0
+__global__ void k_gap_max(const float* __restrict__ keys, int64_t n, double* __restrict__ part_max) {
+    __shared__ double s_scratch[4];
+    double best = 0.0;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k + 1 < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const double prev = (double)keys[k], cur = (double)keys[k + 1];
+        if (prev > 0.0) best = fmax(best, (prev - cur) / prev);
+    }
+    const double r = block_reduce_256<1>(best, s_scratch);
+    if (threadIdx.x == 0) part_max[blockIdx.x] = r;
+}
+// the FIRST position that reaches the largest drop (the reference keeps the first: strict ">")
+__global__ void k_gap_first(const float* __restrict__ keys, int64_t n, const double* __restrict__ target, double* __restrict__ part_min) {
+    __shared__ double s_scratch[4];
+    const double want = target[0];
+    double first = 1e300;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k + 1 < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const double prev = (double)keys[k], cur = (double)keys[k + 1];
+        if (prev > 0.0 && (prev - cur) / prev == want) first = fmin(first, (double)k);
+    }
+    const double r = block_reduce_256<2>(first, s_scratch);
+    if (threadIdx.x == 0) part_min[blockIdx.x] = r;
+}
+}  // namespace
+
+// AUC of `scores` against binary `labels` (non-zero = positive) with one device sort: (sum of the positives' mid-ranks -
+// n_pos (n_pos + 1) / 2) / (n_pos n_neg).  Reference: measures/supervised.py:255-263 (sklearn.metrics.roc_curve + auc).
+extern "C" int pgh_auc(pgh_vec_t labels, pgh_vec_t scores, double* out, int64_t* num_positive) {
+    PGH_CHECK(labels && scores && out && labels->n == scores->n, "pgh_auc: bad arguments");
+    Runtime& r = rt();
+    const int64_t n = scores->n;
+    float* keys = nullptr;
+    int32_t* order = nullptr;
+    PGH_TRY(sort_descending(scores, &keys, &order));
+    int grid = grid_for(n, 8);
+    if (grid > kMaxPartials) grid = kMaxPartials;
+    if (n > 0) k_auc_partials<<<grid, kBlock, 0, r.stream>>>(keys, order, labels->data, n, r.d_partials, r.d_partials + kMaxPartials);
+    else PGH_HIP(hipMemsetAsync(r.d_partials, 0, sizeof(double) * 2 * kMaxPartials, r.stream));
+    k_reduce_final<0><<<1, kBlock, 0, r.stream>>>(r.d_partials, n > 0 ? grid : 1, r.d_scalars);
+    k_reduce_final<0><<<1, kBlock, 0, r.stream>>>(r.d_partials + kMaxPartials, n > 0 ? grid : 1, r.d_scalars + 1);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipMemcpyAsync(r.h_scalars, r.d_scalars, sizeof(double) * 2, hipMemcpyDeviceToHost, r.stream));
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    pool_free(keys);
+    pool_free(order);
+    const double rank_sum = r.h_scalars[0], pos = r.h_scalars[1], neg = (double)n - pos;
+    if (num_positive) *num_positive = (int64_t)pos;
+    *out = (pos > 0.0 && neg > 0.0) ? (rank_sum - pos * (pos + 1.0) / 2.0) / (pos * neg) : 0.0;   // the caller raises when all labels agree
+    return 0;
+}
+
+// Threshold("gap") (postprocess.py:328-343): the score that follows the largest relative drop of the descending order (the
+// first such drop), 0 when no positive score is followed by a smaller one
+extern "C" int pgh_vec_gap_threshold(pgh_vec_t x, double* threshold) {
+    PGH_CHECK(x && threshold, "pgh_vec_gap_threshold: null argument");
+    Runtime& r = rt();
+    const int64_t n = x->n;
+    *threshold = 0.0;
+    if (n < 2) return 0;
+    float* keys = nullptr;
+    int32_t* order = nullptr;
+    PGH_TRY(sort_descending(x, &keys, &order));
+    int grid = grid_for(n, 8);
+    if (grid > kMaxPartials) grid = kMaxPartials;
+    k_gap_max<<<grid, kBlock, 0, r.stream>>>(keys, n, r.d_partials);
+    k_reduce_final<1><<<1, kBlock, 0, r.stream>>>(r.d_partials, grid, r.d_scalars);
+    k_gap_first<<<grid, kBlock, 0, r.stream>>>(keys, n, r.d_scalars, r.d_partials + kMaxPartials);
+    k_reduce_final<2><<<1, kBlock, 0, r.stream>>>(r.d_partials + kMaxPartials, grid, r.d_scalars + 1);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipMemcpyAsync(r.h_scalars, r.d_scalars, sizeof(double) * 2, hipMemcpyDeviceToHost, r.stream));
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    const double drop = r.h_scalars[0], at = r.h_scalars[1];
+    if (drop > 0.0 && at < 1e299) {
+        float v = 0.f;
+        PGH_HIP(hipMemcpyAsync(&v, keys + (int64_t)at + 1, sizeof(float), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        *threshold = (double)v;
+    }
+    pool_free(keys);
+    pool_free(order);
+    return 0;
+}
+
 extern "C" int pgh_mat_div_cols(pgh_mat_t m, const double* divisors_host, pgh_mat_t out) {
     PGH_CHECK(m && out && divisors_host && m->n == out->n && m->b == out->b, "pgh_mat_div_cols: shape mismatch");
     if (m->n == 0) return 0;

@@ -191,6 +191,12 @@ class DeviceVector:
         L.check(L.lib().pgh_vec_kth_largest(self._h, int(k), C.byref(out)))
         return out.value
 
+    def gap_threshold(self):
+        """Threshold("gap") (postprocess.py:328-343): the score after the first largest relative drop of the descending order."""
+        out = C.c_double()
+        L.check(L.lib().pgh_vec_gap_threshold(self._h, C.byref(out)))
+        return out.value
+
     def dot(self, other):
         out = C.c_double()
         L.check(L.lib().pgh_dot(self._h, other._h, C.byref(out)))

@@ -4,8 +4,8 @@ measures on vectors already in HBM (RMabs, MSQ, MSQRT, L2, Eucli
 Restates pygrank/measures/supervised.py:18-47 (Supervised.to_numpy), :93-98 (MaxDifference), :101-106 (Mabs),
 :133-138 (L1).  When both operands are HBM vectors the residual is ONE fused HIP reduction
 (pgh_residual: |a - b| folded into an f64 sum / max) instead of the reference's three passes
-(subtract, abs, sum).  The evaluation measures of the reference (AUC, NDCG, ...) are out of scope
-(SURVEY.md 2 rows 18-19).
+(subtract, abs, sum).  AUC (supervised.py:255-263) is one device sort (pgh_auc); the other evaluation measures of the
+reference (NDCG, ...) are out of scope.
 """
 import ctypes as C
 import numbers
@@ -117,6 +117,19 @@ class Cos(_Pairwise):                                        # supervised.py:208
     def evaluate(self, scores):
         known, scores = self._pair(scores)
         return backend.safe_div(known.dot(scores), (known.dot(known) * scores.dot(scores)) ** 0.5)
+
+
+class AUC(_Pairwise):                                        # supervised.py:255-263 (sklearn roc_curve + auc in the reference)
+    """Area under the ROC curve of the scores against binary known scores, ties at their mid-rank, with ONE device sort
+    (pgh_auc) instead of a trip through sklearn on the host."""
+
+    def evaluate(self, scores):
+        known, scores = self._pair(scores)
+        out, positives = C.c_double(), C.c_int64()
+        L.check(L.lib().pgh_auc(known._h, scores._h, C.byref(out), C.byref(positives)))
+        if positives.value == 0 or positives.value == len(scores):
+            raise Exception("Cannot evaluate AUC when all labels are the same")
+        return out.value
 
 
 class Dot(_Pairwise):                                        # supervised.py:217-222

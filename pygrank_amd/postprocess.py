@@ -168,16 +168,8 @@ class Threshold(Postprocessor):
         ensure_used_args(kwargs)
         x = _device(ranks)
         threshold = self.threshold
-        if threshold == "gap":
-            import numpy as np
-            v = np.sort(np.asarray(x, dtype=np.float64))[::-1]
-            threshold = 0
-            prev, rest = v[:-1], v[1:]
-            ok = prev > 0
-            if ok.any():
-                drop = np.where(ok, (prev - rest) / np.where(ok, prev, 1.0), -1.0)
-                if drop.max() > 0:
-                    threshold = float(rest[int(np.argmax(drop))])     # first largest drop, as the reference's strict ">"
+        if threshold == "gap":                       # one device sort + two reductions (pgh_vec_gap_threshold)
+            threshold = x.gap_threshold()
         return ((x >= threshold) if self.inclusive else (x > threshold)) * 1.0
 
 

@@ -404,6 +404,14 @@ def check_device_postprocessors_and_measures(pg):
         got = np.asarray(algo.rank(graph, p.copy()).np, dtype=np.float64)
         want = gold["post|" + key]
         assert np.max(np.abs(got - want)) <= 2e-6 * np.max(np.abs(want)), (key, np.max(np.abs(got - want)) / np.max(np.abs(want)))
+    # AUC with one device sort against sklearn's values (ties at their mid-rank; an f32 copy of the scores may tie what f64 kept apart)
+    labels = pg.to_array(gold["auc|labels"])
+    for key, scores in (("ranks", gold["ranks"]), ("coarse", gold["auc|coarse_scores"]), ("random", gold["measure|u"])):
+        got, want = float(pg.AUC(labels)(pg.to_array(scores))), float(gold["auc|" + key])
+        assert abs(got - want) <= 2e-6, (key, got, want)
+    import pytest
+    with pytest.raises(Exception, match="all labels are the same"):
+        pg.AUC(pg.to_array(np.ones(len(gold["ranks"]))))(pg.to_array(gold["ranks"]))
     u, v = gold["measure|u"], gold["measure|v"]
     du, dv = pg.to_array(u), pg.to_array(v)
     for key, m in (("rmabs", pg.RMabs), ("msq", pg.MSQ), ("msqrt", pg.MSQRT), ("l2", pg.L2), ("euclidean", pg.Euclidean),

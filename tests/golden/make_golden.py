@@ -97,6 +97,15 @@ def main():
     for key, m in (("rmabs", pg.RMabs), ("msq", pg.MSQ), ("msqrt", pg.MSQRT), ("l2", pg.L2), ("euclidean", pg.Euclidean),
                    ("cos", pg.Cos), ("dot", pg.Dot)):
         post["measure|" + key] = np.float64(m(u)(v))
+    # AUC (measures/supervised.py:255-263: sklearn roc_curve + auc) of the fixed ranks against binary labels, without ties and with
+    # many (scores quantised to 2 decimals of their maximum; zero scores)
+    rng3 = np.random.default_rng(17)
+    labels = (rng3.random(A.shape[0]) < 0.3).astype(np.float64)
+    coarse = np.round(post["ranks"] / post["ranks"].max(), 2)
+    post["auc|labels"], post["auc|coarse_scores"] = labels, coarse
+    post["auc|ranks"] = np.float64(pg.AUC(labels)(post["ranks"]))
+    post["auc|coarse"] = np.float64(pg.AUC(labels)(coarse))
+    post["auc|random"] = np.float64(pg.AUC(labels)(u))
     np.savez_compressed(os.path.join(HERE, "golden_post.npz"), **post)
 
     # normalised CSR fixtures (preprocessing.py:99-142) + degrees (numpy.py:76-77)
