@@ -43,7 +43,7 @@ ALPHA, TOL, MAX_ITERS, SEEDS = 0.85, 1e-6, 1000, 100
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 # HBM traffic of the step kernels: rocprofv3 --pmc passes of this same command (tools/gpu_bench_call.sh), summarised by
 # tools/summarize_pmc.py with the guide's gfx950 corrections; counters cannot be read from inside the timed process
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "bench_n1_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "bench_n1_pmc.json")
 # the launches of one PPR iteration, in stream order (HIP-event ids of include/pgh.h)
 STEP_KERNELS = ("spmv", "fixup", "pb_gather", "pb_finish", "combine", "residual", "close")
 
@@ -73,10 +73,14 @@ def measured_traffic(scale, ef, blocked):
     if pmc.get("_meta", {}).get("csrc_sha16") != csrc_sha16():
         return None, "stale: " + os.path.relpath(PMC_SUMMARY, ROOT) + " was collected from other kernel sources"
     total = 0.0
+    steps = max([row.get("dispatches", 0) for name, row in pmc.items() if name.startswith("k_bsf_partial")] or [0])
     for name, row in pmc.items():
-        # the PPR iteration's launches: the AXPBY epilogue is MODE 1 (the PMC run also holds the secondary filters' <2,.> / <3,.>)
+        # the PPR iteration's launches: the AXPBY epilogue is MODE 1 (the PMC run also holds the secondary filters' <2,.> / <3,.>);
+        # a kernel that does not run in every iteration (the separate residual: first step of a run only, the close: once per
+        # run) counts with its share of the launches
         if name.startswith(("k_bsf_partial", "k_bsf_fixup", "k_bsf_combine<1,", "k_pb_gather", "k_pb_finish<1,", "k_step_residual", "k_step_close")):
-            total += row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
+            share = min(1.0, row.get("dispatches", steps) / steps) if steps else 1.0
+            total += share * (row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"])
     return (int(total), os.path.relpath(PMC_SUMMARY, ROOT)) if total > 0 else (None, None)
 
 
@@ -205,7 +209,10 @@ def single_gpu(args):
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=alg_bytes,
                     avg_launch_us=round(step_us, 2), measured_copy_gbs=ceiling,
-                    frac_of_measured_copy=round(achieved / ceiling, 4) if ceiling else None, format=g.format(),
+                    frac_of_measured_copy=round(achieved / ceiling, 4) if ceiling else None,
+                    # bytes the counters saw (not the nominal ones) over the same time, against the measured copy rate
+                    traffic_frac_of_measured_copy=round(traffic / (step_us * 1e-6) / 1e9 / ceiling, 4) if traffic and ceiling else None,
+                    format=g.format(),
                     kernels_avg_us={k: (round(v["avg_us"], 2) if v["avg_us"] else None) for k, v in prof.items()},
                     launches_per_iteration={k: round(v["launches"] / iterations, 3) for k, v in prof.items() if v["launches"]})
 

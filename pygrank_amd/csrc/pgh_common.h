@@ -151,6 +151,9 @@ struct PbFormat {
     float*    val = nullptr;        // [padded] or null (value-free)
     uint32_t* dstg = nullptr;       // [padded / 8] group of B order that receives this group's values
     int       num_tasks = 0;
+    int       tmp_planes = 1;       // tmp keeps the low / high quads of 64 groups in two planes (long (chunk, bin) runs) or side by side
+    int       short_piece = 16384;  // phase A: pieces below this many entries run rounds of one group per lane (PGH_GATHER_SHORT)
+    int64_t   avg_piece = 0;        // entries per phase A piece on average (selects the round size of k_pb_gather)
     int4*     task = nullptr;       // phase A pieces {chunk, entry_begin, entry_end, 0}: consecutive ranges of the entry stream
     int*      task_range = nullptr; // [num_tasks + 1] pieces of every phase A workgroup (equal shares of the stream)
     // B order: [bin][chunk] runs (the same runs): a bin is one contiguous range

@@ -497,8 +497,11 @@ __device__ __forceinline__ bool run_pending_close(const PendingClose& pc, double
 // loads of phase B cover CONTIGUOUS memory when the lanes of a wavefront hold consecutive groups (they mostly do: a
 // (chunk, bin) run is ~80 groups).  With the quads of a group side by side every such instruction touched every second
 // 16 bytes: half-filled requests on both sides.
-__device__ __forceinline__ uint32_t pb_tmp_quad(uint32_t group, int high) {
-    return ((group >> 6) << 9) + ((uint32_t)high << 8) + ((group & 63u) << 2);
+// Images whose (chunk, bin) runs are short -- the slices of a partitioned graph gather from 2-16x more chunks: ~1-5 groups per
+// run -- keep the two quads of a group side by side instead (planes == 0): an isolated group then touches ONE 32-byte range
+// instead of two 16-byte ranges in different lines (measured on the slices of the N-GPU bench, profiles/r03/partition_slices.log).
+__device__ __forceinline__ uint32_t pb_tmp_quad(uint32_t group, int high, int planes) {
+    return planes ? ((group >> 6) << 9) + ((uint32_t)high << 8) + ((group & 63u) << 2) : (group << 3) + ((uint32_t)high << 2);
 }
 // device view of the propagation-blocking image (PbFormat, pgh_pb.hip)
 struct PbView {
@@ -508,6 +511,8 @@ struct PbView {
     const int4*     task;
     const int*      task_range;
     float*          tmp;
+    int             tmp_planes;  // layout of tmp (pb_tmp_quad)
+    int             short_piece; // phase A pieces with fewer entries run rounds of one group per lane
     const int4*     item_a;            // work list of k_pb_finish (PbFormat::item_a / item_b)
     const int4*     item_b;
     int             num_items;

@@ -201,7 +201,7 @@ __device__ unsigned int g_item_begin[1 << 15];      // ... and its start relativ
 #endif
 
 // ---- phase A (body: pgh_pb_gather.h, shared with the merged front kernel of a step in pgh_bsf.hip)
-template <bool HAS_VAL>
+template <bool HAS_VAL, int PG>
 __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float* __restrict__ xg, const LoopState* __restrict__ state,
                                                           FixView fix) {
     __shared__ float s_x[kPbChunk + 1];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float*
     // the cross-tile fix-ups of the blocked stream ride along (one launch and one dependent boundary fewer per step):
     // they touch nothing this kernel reads, and the next kernel (k_pb_finish) is the first to read their results
     bsf_fixup_tiles(fix, blockIdx.x * kPbThreads, gridDim.x * kPbThreads);
-    pb_gather_body<HAS_VAL>(s_x, reinterpret_cast<uint32_t*>(s_x + kPbChunk), f, xg, blockIdx.x);
+    pb_gather_body<HAS_VAL, PG>(s_x, reinterpret_cast<uint32_t*>(s_x + kPbChunk), f, xg, blockIdx.x);
     PGH_STAMP_END(g_times_gather)
 }
 
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             const bool ok = g < groups && !(PGH_PROBE_PB & 8);
             R.r8[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + (int64_t)g * 8))
                          : u16x8{0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff};
-            R.lo[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 0))) : f32x4{0.f, 0.f, 0.f, 0.f};
-            R.hi[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 1))) : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.lo[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 0, f.tmp_planes))) : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.hi[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 1, f.tmp_planes))) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -644,6 +644,9 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.task = p.task;
     v.task_range = p.task_range;
     v.tmp = p.tmp;
+    v.tmp_planes = p.tmp_planes;
+    static const int short_env = getenv("PGH_GATHER_SHORT") != nullptr ? atoi(getenv("PGH_GATHER_SHORT")) : -1;
+    v.short_piece = short_env >= 0 ? short_env : p.short_piece;
     v.item_a = p.item_a;
     v.item_b = p.item_b;
     v.num_items = p.num_items;
@@ -957,6 +960,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     }
     const int shares = (int)ranges.size() - 1;
     p.num_tasks = shares;
+    p.avg_piece = tasks.empty() ? 0 : padded / (int64_t)tasks.size();
     if (getenv("PGH_DEBUG") != nullptr && atoi(getenv("PGH_DEBUG")) != 0) {
         int64_t mn = padded, mx = 0;
         int most = 0;
@@ -973,6 +977,12 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     if (!tasks.empty()) PGH_HIP(hipMemcpyAsync(p.task, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMemcpyAsync(p.task_range, ranges.data(), sizeof(int) * (shares + 1), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMalloc(&p.tmp, sizeof(float) * (size_t)(((padded / 8 + 63) / 64 + 1) * 512)));      // whole blocks of 64 groups (pb_tmp_quad)
+    {
+        // (chunk, bin) runs of a dozen groups or more: the two-plane layout of tmp; shorter runs: quads side by side
+        const double per_cell = (double)padded / ((double)std::max(p.num_chunks, 1) * (double)std::max(p.num_bins, 1));
+        p.tmp_planes = per_cell >= 96.0 ? 1 : 0;
+        if (getenv("PGH_PB_PLANES") != nullptr) p.tmp_planes = atoi(getenv("PGH_PB_PLANES")) != 0 ? 1 : 0;
+    }
     PGH_HIP(hipMalloc(&p.amax, sizeof(uint32_t) * 2));
     PGH_HIP(hipMemsetAsync(p.amax, 0, sizeof(uint32_t) * 2, r.stream));
     // ---- work list of k_pb_finish: the bins in row order (`mine` is sorted by first row; the pieces of a split hub row are
@@ -1168,8 +1178,8 @@ int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, co
         if (p.num_tasks > 0) {
             // (diagnostic of round 3: launched with a quarter of its workgroups this kernel takes 63 us instead of 76 -- a workgroup's
             // share costs the same alone on the chip as with all others running: the per-CU memory path bounds it, ~21 GB/s)
-            if (p.val) k_pb_gather<true><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
-            else k_pb_gather<false><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
+            if (p.val) k_pb_gather<true, PGH_GATHER_P><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
+            else k_pb_gather<false, PGH_GATHER_P><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
         }
     }
     PGH_STAMP_DUMP(g_times_gather, p.num_tasks, "k_pb_gather")

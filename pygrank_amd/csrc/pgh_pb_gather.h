@@ -16,7 +16,98 @@ constexpr int kPbThreads = 1024;
 
 // s_x: kPbChunk floats of LDS (the chunk's slice of the gather vector), s_amax: one more LDS word.  vblock: which share of
 // the A-order stream this workgroup takes (PbFormat::task_range).
-template <bool HAS_VAL>
+// One piece of the A-order stream (whole groups of 8 entries, all inside the chunk whose slice of the gather vector sits in
+// s_x): every lane takes one group per round slot -- one 16-byte load of source indices, one 4-byte load of the group's place
+// in B order, 8 LDS gathers, two 16-byte stores of values.  P = round slots per lane (a round = 1024 x 8 x P entries).
+template <bool HAS_VAL, int P>
+__device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, const PbView& f, const int64_t body_begin, const int64_t body_end,
+                                                uint32_t& amax) {
+        // Software pipeline over rounds of P groups per lane: the loads of round i + 1 are issued BEFORE the gathers and
+        // stores of round i.  vmcnt counts loads and stores in one in-order queue, so a loop that loads, gathers, stores
+        // and only then loads again makes every round wait for the previous round's stores to complete (measured:
+        // reads alone 40 us, with the stores 80 us -- no overlap at all).
+        struct Round {
+            u16x8    s8[P];
+            uint32_t to[P];
+            f32x4    w0[HAS_VAL ? P : 1], w1[HAS_VAL ? P : 1];
+        };
+        // Branch-free loads: the round base is uniform, a lane past the end of the piece repeats the piece's LAST group, so
+        // every load is issued unconditionally and the compiler emits counted waits.  (Loads under `ok ? load : 0` had become
+        // divergent branches with an s_waitcnt inside each -- nothing stayed in flight across the stages: a workgroup alone on
+        // the chip took 63 us for its share, 31 of them waiting for its own stores.)
+        constexpr int kRound = kPbThreads * 8 * P;           // entries per round
+        const int span = (int)(body_end - body_begin);       // pieces are far below 2^31 entries
+        const int last = span - 8;                            // first entry of the piece's last group
+        const uint16_t* __restrict__ sl = f.sloc + body_begin;
+        const uint32_t* __restrict__ dg = f.dstg + (body_begin >> 3);
+        const float* __restrict__ vl = HAS_VAL ? f.val + body_begin : nullptr;
+        auto fetch = [&](Round& r, int rb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int e = min(rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8), last);
+                r.s8[q] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(sl + e));
+                r.to[q] = __builtin_nontemporal_load(dg + (e >> 3));
+                if (HAS_VAL) {
+                    r.w0[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vl + e));
+                    r.w1[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vl + e + 4));
+                }
+            }
+        };
+        auto emit = [&](const Round& r, int rb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                // (the LOADS of a lane past the end of the piece are clamped and unconditional; its gathers and its stores are
+                // skipped: on the short pieces of a partitioned slice most lanes of a round are past the end, and thousands of
+                // duplicate stores to the piece's last group queue up on one memory channel)
+                if (rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8) > last) continue;
+                f32x4 lo, hi;
+                lo.x = s_x[r.s8[q][0]];
+                lo.y = s_x[r.s8[q][1]];
+                lo.z = s_x[r.s8[q][2]];
+                lo.w = s_x[r.s8[q][3]];
+                hi.x = s_x[r.s8[q][4]];
+                hi.y = s_x[r.s8[q][5]];
+                hi.z = s_x[r.s8[q][6]];
+                hi.w = s_x[r.s8[q][7]];
+                if (HAS_VAL) {
+                    lo *= r.w0[q];
+                    hi *= r.w1[q];
+                }
+                if (PGH_PROBE_PB & 4) {
+                    if (lo.x + hi.w == 123.456f) f.tmp[body_begin + rb] = lo.y;
+                    continue;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    amax = max(amax, max(__float_as_uint(lo[k]) & 0x7fffffffu, __float_as_uint(hi[k]) & 0x7fffffffu));
+                uint32_t group = r.to[q];
+                if (PGH_PROBE_PB & 64)                       // diagnostic: sequential stores
+                    group = (uint32_t)((body_begin + min(rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8), last)) >> 3);
+                *reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 0, f.tmp_planes)) = lo;
+                *reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 1, f.tmp_planes)) = hi;
+            }
+        };
+        Round r0, r1;
+        int rb = 0;
+        fetch(r0, rb);
+        for (;;) {
+            fetch(r1, rb + kRound);                           // (clamped: the last round re-reads the last group)
+            emit(r0, rb);
+            rb += kRound;
+            if (rb >= span) break;
+            fetch(r0, rb + kRound);
+            emit(r1, rb);
+            rb += kRound;
+            if (rb >= span) break;
+        }
+}
+
+// PG: round slots per lane on long pieces.  One GPU's graph has ~190 K entries per piece at scale 23: rounds of 4.  The slices of
+// a partitioned graph gather from a source space 2-16x larger -- 2-16x more chunks, and a long tail of pieces of a few
+// thousand entries (88 .. 437 K on the 8-way slice of configs[4]): pieces below PbView::short_piece entries (16 K) run rounds of
+// 1.  Same-box sweep of that line on the slices of the N = 2 / 4 / 8 bench, phase A us: none 113 / 153 / 194-204, 8 K 115 /
+// 153 / 188, 16 K 114 / 154 / 189, 32 K 132 / 175 / 189 (profiles/r03/partition_slices.log).
+template <bool HAS_VAL, int PG>
 __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t* __restrict__ s_amax, const PbView& f,
                                                const float* __restrict__ xg, const int vblock) {
     if (threadIdx.x == 0) *s_amax = 0u;
@@ -61,90 +152,15 @@ __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t
             __syncthreads();
             loaded = task.x;
         }
-        // every lane takes one group of 8 consecutive entries (pieces are whole groups): one 16-byte load of source
-        // indices, one 4-byte load of the group's place in B order, two 16-byte stores of values
         const int64_t body_begin = task.y, body_end = task.z;
-        // Software pipeline over rounds of P groups per lane: the loads of round i + 1 are issued BEFORE the gathers and
-        // stores of round i.  vmcnt counts loads and stores in one in-order queue, so a loop that loads, gathers, stores
-        // and only then loads again makes every round wait for the previous round's stores to complete (measured:
-        // reads alone 40 us, with the stores 80 us -- no overlap at all).
 #ifndef PGH_GATHER_P
 #define PGH_GATHER_P 4
 #endif
-        constexpr int P = HAS_VAL ? PGH_GATHER_P / 2 : PGH_GATHER_P;
         if (PGH_PROBE_PB & 2) continue;
-        struct Round {
-            u16x8    s8[P];
-            uint32_t to[P];
-            f32x4    w0[HAS_VAL ? P : 1], w1[HAS_VAL ? P : 1];
-        };
-        // Branch-free rounds: the round base is uniform, a lane past the end of the piece repeats the piece's LAST group
-        // (same loads, same values, same destination: a benign duplicate store), so every load and store is issued
-        // unconditionally and the compiler emits counted waits.  (Loads under `ok ? load : 0` had become divergent branches
-        // with an s_waitcnt inside each -- nothing stayed in flight across the stages: a workgroup alone on the chip took
-        // 63 us for its share, 31 of them waiting for its own stores.)
         if (body_end <= body_begin) continue;
-        constexpr int kRound = kPbThreads * 8 * P;           // entries per round
-        const int span = (int)(body_end - body_begin);       // pieces are far below 2^31 entries
-        const int last = span - 8;                            // first entry of the piece's last group
-        const uint16_t* __restrict__ sl = f.sloc + body_begin;
-        const uint32_t* __restrict__ dg = f.dstg + (body_begin >> 3);
-        const float* __restrict__ vl = HAS_VAL ? f.val + body_begin : nullptr;
-        auto fetch = [&](Round& r, int rb) __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                const int e = min(rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8), last);
-                r.s8[q] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(sl + e));
-                r.to[q] = __builtin_nontemporal_load(dg + (e >> 3));
-                if (HAS_VAL) {
-                    r.w0[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vl + e));
-                    r.w1[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vl + e + 4));
-                }
-            }
-        };
-        auto emit = [&](const Round& r, int rb) __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                f32x4 lo, hi;
-                lo.x = s_x[r.s8[q][0]];
-                lo.y = s_x[r.s8[q][1]];
-                lo.z = s_x[r.s8[q][2]];
-                lo.w = s_x[r.s8[q][3]];
-                hi.x = s_x[r.s8[q][4]];
-                hi.y = s_x[r.s8[q][5]];
-                hi.z = s_x[r.s8[q][6]];
-                hi.w = s_x[r.s8[q][7]];
-                if (HAS_VAL) {
-                    lo *= r.w0[q];
-                    hi *= r.w1[q];
-                }
-                if (PGH_PROBE_PB & 4) {
-                    if (lo.x + hi.w == 123.456f) f.tmp[body_begin + rb] = lo.y;
-                    continue;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    amax = max(amax, max(__float_as_uint(lo[k]) & 0x7fffffffu, __float_as_uint(hi[k]) & 0x7fffffffu));
-                uint32_t group = r.to[q];
-                if (PGH_PROBE_PB & 64)                       // diagnostic: sequential stores
-                    group = (uint32_t)((body_begin + min(rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8), last)) >> 3);
-                *reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 0)) = lo;
-                *reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 1)) = hi;
-            }
-        };
-        Round r0, r1;
-        int rb = 0;
-        fetch(r0, rb);
-        for (;;) {
-            fetch(r1, rb + kRound);                           // (clamped: the last round re-reads the last group)
-            emit(r0, rb);
-            rb += kRound;
-            if (rb >= span) break;
-            fetch(r0, rb + kRound);
-            emit(r1, rb);
-            rb += kRound;
-            if (rb >= span) break;
-        }
+        constexpr int PL = HAS_VAL ? (PG > 1 ? PG / 2 : 1) : PG;
+        if (body_end - body_begin >= (int64_t)f.short_piece) pb_stream_piece<HAS_VAL, PL>(s_x, f, body_begin, body_end, amax);
+        else pb_stream_piece<HAS_VAL, 1>(s_x, f, body_begin, body_end, amax);
     }
     // max |value| of this launch: wavefront -> workgroup -> one global atomic
 #pragma unroll
