@@ -1189,14 +1189,17 @@ int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t
 }
 
 // number of column blocks: keep a block's slice of the gather vector around 8 MB (hot-first, so its reused prefix
-// fits a 4 MB L2), at most 4: every block is one more partial vector written and read per step, and with the cold
-// entries in their own image (pgh_pb.hip) the hot-cache coverage of blocks 5..8 no longer pays for that (measured at
-// scale 24 / 25 / 26: 757 / 1634 / 3711 us per step with 4 blocks against 839 / 1666 / 3827 with 8,
-// profiles/r01/pb_large_graphs.log).  Override with PGH_BLOCKS for experiments.
+// fits a 4 MB L2) up to 4 blocks; EIGHT from 16 MB of gather vector on (scale 22).  Every block is one more LDS hot cache
+// (29 696 more sources out of the cold image) and one more row segment per row.  Rounds 1-2 measured 4 against 8 blocks with
+// dense [B][n] partial vectors and separate fix-up / combine launches and kept 4 (profiles/r01/pb_large_graphs.log,
+// profiles/r02/blocks_sweep_scale23.log); with compact partial sums and the fused finish kernel the balance has turned -- round 3,
+// one PPR iteration over all launches at scale 22 / 23 / 24 / 25, 4 -> 8 blocks: 136 -> 132, 245 -> 237, 544 -> 523, 1513 -> 1165 us
+// (phase A loses a quarter of its entries, the block partial sums gain 8 us; profiles/r03/blocks_sweep.log).
+// Override with PGH_BLOCKS for experiments.
 int bsf_auto_blocks(int64_t n_src) {
     int B = 1;
-    const int most = env_int("PGH_PB", 1) == 0 ? 8 : 4;
-    while (B < most && n_src * 4 > (int64_t)B * (8 << 20)) B <<= 1;
+    while (B < 4 && n_src * 4 > (int64_t)B * (8 << 20)) B <<= 1;
+    if (n_src * 4 > (int64_t)(16 << 20)) B = 8;
     const int forced = env_int("PGH_BLOCKS", 0);
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) B = forced;
     return B;

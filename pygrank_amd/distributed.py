@@ -74,7 +74,7 @@ def _auto_blocks(n):
     blocks = 1
     while blocks < 4 and n * 4 > blocks * (8 << 20):
         blocks <<= 1
-    return blocks
+    return 8 if n * 4 > (16 << 20) else blocks
 
 
 def partition_scipy(M, rank, world):

@@ -1,6 +1,6 @@
 """The BASELINE.json configurations at their FULL size on the real engine ("configs not exercised at their
 size"): RMAT scale 23, edge factor 16 (8.4 M nodes, 131 M edges), the production layout the default heuristics choose
-(4 column blocks, 16-bit hot-only stream, propagation-blocking image of the cold tail).
+(8 column blocks, 16-bit hot-only stream, propagation-blocking image of the cold tail).
 
   configs[1]  PPR alpha = 0.85, L1 <= 1e-6     vs the oracle's scipy loop on the engine's own matrix (about 5 s of host time)
   configs[3]  HeatKernel t = 5, 31 iterations  taylor and chebyshev vs the oracle (about 15 s each), linearity of the filter
@@ -24,7 +24,7 @@ def big(gpu_engine):
     adj = rmat_graph(SCALE, EF, seed=0, normalization="col", a=0.57, b=0.19, c=0.19)
     g = adj.array
     fmt = g.format()
-    assert "propagation-blocking image" in fmt and "(2 B/edge)" in fmt and "4 column blocks" in fmt, fmt
+    assert "propagation-blocking image" in fmt and "(2 B/edge)" in fmt and "8 column blocks" in fmt, fmt
     MT = g.download_transposed()
     M = sp.csr_array(MT.T.astype(np.float64))          # the engine's own (f32-rounded) matrix: the oracle runs on it
     deg = np.asarray(pg.degrees(g))
