@@ -245,6 +245,12 @@ int pgh_sarw_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg
 int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, int32_t chebyshev,
                  pgh_vec_t result, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 
+/* The terms of the reference's "chebyshev" recurrence (abstract_filters.py:216-224) as f32 columns of a slab:
+ * out[:, first_col + j] = T_{skip + 1 + j} for j < count, with T_1 = p, T_2 = M^T p, T_k = 2 M^T T_{k-1} - T_{k-1}, evaluated in f64
+ * from T_1 on.  What optimization_dict (abstract_filters.py:232-246) stores for this form: a filter is then one pgh_mat_gemv /
+ * pgh_mat_gemm over the slab.  chebyshev must be non-zero (the taylor form's terms are plain powers: pgh_spmv). */
+int pgh_poly_terms(pgh_graph_t g, pgh_vec_t p, int32_t chebyshev, int32_t skip, int32_t count, pgh_mat_t out, int32_t first_col);
+
 /* ---------------------------------------------------------------- multi-seed batch (SpMM) --------- */
 /* Y = M^T X for a row-major [n, b] slab (b <= 64): the b conv() calls of NodeRanking.propagate
  * (signals.py:225-226) / tuner probes / sweeps in ONE pass over the adjacency. */

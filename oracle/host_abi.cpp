@@ -881,6 +881,27 @@ static inline uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 // multi-seed entry points: column-by-column restatement (NodeRanking.propagate, signals.py:225-226)
+// terms of the "chebyshev" recurrence in f64 over the f32 matrix values (abstract_filters.py:216-224), rounded once per column
+int pgh_poly_terms(pgh_graph_t g, pgh_vec_t p, int32_t chebyshev, int32_t skip, int32_t count, pgh_mat_t out, int32_t first_col) {
+    CHECK(g && p && out && chebyshev != 0 && g->n_rows == g->n_cols && p->n == g->n_cols && out->n == g->n_cols, "pgh_poly_terms: bad arguments");
+    CHECK(skip >= 0 && count >= 1 && first_col >= 0 && first_col + count <= out->b, "pgh_poly_terms: column range outside the slab");
+    const int64_t n = g->n_cols;
+    std::vector<double> term(n), next(n);
+    for (int64_t i = 0; i < n; ++i) term[i] = (double)p->data[i];
+    for (int k = 1; k <= skip + count; ++k) {
+        if (k > 1) {
+            for (int64_t r = 0; r < n; ++r) {
+                double acc = 0;
+                for (int64_t e = g->rowptr[r]; e < g->rowptr[r + 1]; ++e) acc += (double)g->val[e] * term[g->col[e]];
+                next[r] = k > 2 ? 2.0 * acc - term[r] : acc;
+            }
+            term.swap(next);
+        }
+        if (k > skip)
+            for (int64_t i = 0; i < n; ++i) out->data[i * out->b + first_col + (k - 1 - skip)] = (float)term[i];
+    }
+    return 0;
+}
 int pgh_spmm(pgh_graph_t g, pgh_mat_t x, pgh_mat_t y) {
     CHECK(g && x && y && x->n == g->n_rows && y->n == g->n_cols && x->b == y->b, "pgh_spmm: shape mismatch");
     CHECK(x->b >= 1 && x->b <= 64, "pgh_spmm: the batch width must be in [1, 64]");

@@ -131,6 +131,7 @@ SIGNATURES = {
     "pgh_sarw_run": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_poly_run": (C.c_int, [c_graph, c_vec, C.c_void_p, C.c_int32, C.c_int32, c_vec, C.POINTER(LoopCfg),
                                C.POINTER(LoopResult)]),
+    "pgh_poly_terms": (C.c_int, [c_graph, c_vec, C.c_int32, C.c_int32, C.c_int32, c_mat, C.c_int32]),
     "pgh_spmm": (C.c_int, [c_graph, c_mat, c_mat]),
     "pgh_ppr_run_batch": (C.c_int, [c_graph, c_mat, c_mat, C.POINTER(LoopCfg), C.c_void_p, C.POINTER(LoopResult)]),
     "pgh_spmm_dropout": (C.c_int, [c_graph, c_mat, c_mat, C.c_double, C.c_uint64]),

@@ -387,6 +387,16 @@ __global__ void k_bsf64_bring(const float* __restrict__ p, const int32_t* __rest
     }
 }
 
+// one term of the recurrence as an f32 column of a row-major [n, ld] slab in the caller's ids (the chebyshev slab of
+// optimization_dict users: filters._PowerSlab)
+__global__ void k_bsf64_take_col(const double* __restrict__ vec, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid,
+                                 float* __restrict__ mat, int ld, int col) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_int; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = perm ? perm[i] : (i < n_valid ? i : -1);
+        if (o >= 0) mat[o * ld + col] = (float)vec[i];
+    }
+}
+
 __global__ void k_bsf64_take(const double* __restrict__ res, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, double factor,
                              float* __restrict__ out) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_int; i += (int64_t)gridDim.x * blockDim.x) {
@@ -470,10 +480,17 @@ int bsf64_take(pgh_graph_s* g, const double* res, double factor, float* out) {
     return 0;
 }
 
+int bsf64_take_col(pgh_graph_s* g, const double* vec, float* mat, int ld, int col) {
+    const BsfFormat& f = g->bsf64;
+    k_bsf64_take_col<<<grid_for(f.n_out, 16), WG, 0, rt().stream>>>(vec, f.perm, f.n_out, g->n_cols, mat, ld, col);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
 // one term of the recurrence: term_out = a * (M^T term) + b * term, result += c * term_out; xg holds term * src_scale on
 // entry and term_out * src_scale on return.  Block partials of sum(term_out) / delta land in partial_sum / partial_delta.
 int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term, double* term_out, double* result, double* xg,
-               int err_linf, const LoopState* state, double* partial_sum, double* partial_delta, int* num_partials) {
+               int err_linf, const LoopState* state, double* partial_sum, double* partial_delta, int* num_partials, bool every_row) {
     Runtime& r = rt();
     BsfFormat& f = g->bsf64;
     View64 v;
@@ -514,7 +531,7 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
     {
         ProfScope prof(PGH_K_COMBINE);
         IsoRows iso;
-        iso.flag = f.iso_flag;
+        iso.flag = every_row ? nullptr : f.iso_flag;       // every_row: term_out is read in full afterwards (pgh_poly_terms)
         iso.blk = f.blk_size;
         iso.iso_from = iso_from_of(f);
         k_bsf64_combine<<<cgrid, WG, 0, r.stream>>>(f.meta, f.meta_words, f.psum64, f.num_blocks, f.n_out, ep, state, partial_sum, partial_delta, iso);

@@ -1712,6 +1712,43 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
 
 }  // namespace
 
+// The terms T_1 = p, T_2 = M^T p, T_k = 2 M^T T_{k-1} - T_{k-1} of the reference's "chebyshev" recurrence
+// (abstract_filters.py:216-224) as f32 columns of a slab: out[:, first_col + j] = T_{skip + 1 + j}, j < count.  The recurrence runs
+// in f64 on the blocked f64 image from T_1 on (a term rounded to f32 must not feed the next ones); a filter of this form is then
+// ONE pass over the stored terms, like the Krylov powers of the taylor form (optimization_dict users, filters._PowerSlab).
+extern "C" int pgh_poly_terms(pgh_graph_t g, pgh_vec_t p, int32_t chebyshev, int32_t skip, int32_t count, pgh_mat_t out, int32_t first_col) {
+    PGH_CHECK(g && p && out, "pgh_poly_terms: null argument");
+    PGH_CHECK(chebyshev != 0, "pgh_poly_terms: the taylor form's terms are plain powers (pgh_spmv)");
+    PGH_CHECK(g->n_rows == g->n_cols && p->n == g->n_cols && out->n == g->n_cols, "pgh_poly_terms: shape mismatch");
+    PGH_CHECK(skip >= 0 && count >= 1 && first_col >= 0 && first_col + count <= out->b, "pgh_poly_terms: column range outside the slab");
+    PGH_CHECK(bsf64_usable(g), "pgh_poly_terms: this graph has no blocked f64 image");
+    PGH_TRY(ensure_state());
+    PGH_TRY(bsf64_ensure(g));
+    Runtime& r = rt();
+    const int64_t nv = bsf64_length(g);
+    DevF64 t0, t1, dummy, xg64;
+    PGH_TRY(t0.alloc(nv));
+    PGH_TRY(t1.alloc(nv));
+    PGH_TRY(dummy.alloc(nv));
+    PGH_TRY(xg64.alloc(nv + 1));
+    PGH_TRY(bsf64_bring(g, p->data, 0.0, t0.p, dummy.p, xg64.p));            // T_1 = p
+    double* tbuf[2] = {t1.p, t0.p};                                           // T_k lives in tbuf[k & 1]
+    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
+    const int last = skip + count;
+    for (int k = 1; k <= last; ++k) {
+        if (k > 1) {
+            const bool cheb = k > 2;
+            int num = 0;
+            PGH_TRY(bsf64_step(g, cheb ? 2.0 : 1.0, cheb ? -1.0 : 0.0, 0.0, tbuf[(k - 1) & 1], tbuf[k & 1], dummy.p, xg64.p, 0, nullptr,
+                               r.d_partials, r.d_partials + kMaxPartials, &num, true));      // every row: the term leaves in full
+        }
+        if (k > skip) PGH_TRY(bsf64_take_col(g, tbuf[k & 1], out->data, out->b, first_col + (k - 1 - skip)));
+    }
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    return 0;
+}
+
 // SymmetricAbsorbingRandomWalks (adhoc.py:317-369).  With deg = degrees(M) and absorption a = (1 + sqrt(1 + 4 deg)) / 2
 // (adhoc.py:349-350) the formula  conv(r / a, M) * deg / (a + deg) + p * a / (a + deg)  (adhoc.py:351-353,362-364) is the
 // absorbing-walk epilogue ((M^T x) deg + p lam) / (lam + deg) with lam = a, applied to the pre-scaled iterate x = r / a.

@@ -422,14 +422,17 @@ class _PowerSlab:
     WIDTH = 64
     MAX_TERMS = 4096          # 64 slabs; beyond that the step-by-step route takes over
 
-    def __init__(self, graph, p):
+    def __init__(self, graph, p, chebyshev=False):
         self.graph = graph
         self.n = len(p)
         self.slabs = []
         self.count = 0
         self.l1, self.linf = [], []
         self._last = None
-        self._push(p)
+        self.chebyshev = bool(chebyshev)
+        self._p = p
+        if not self.chebyshev:
+            self._push(p)
 
     def _push(self, col):
         from pygrank_amd.device import DeviceMatrix
@@ -446,8 +449,30 @@ class _PowerSlab:
         """Makes the first `columns` powers available; False when that is more than a slab set may hold."""
         if columns > self.MAX_TERMS:
             return False
+        if self.chebyshev:
+            return self._ensure_chebyshev(columns)
         while self.count < columns:
             self._push(self.graph.conv(self._last))
+        return True
+
+    def _ensure_chebyshev(self, columns):
+        """The terms T_k of the reference's "chebyshev" recurrence (abstract_filters.py:216-224) as slab columns: they come out
+        of the engine's f64 recurrence (pgh_poly_terms) 32 at a time -- a term rounded to f32 must not feed the next ones, so an
+        extension recomputes from T_1."""
+        from pygrank_amd.device import DeviceMatrix
+        while self.count < columns:
+            slab, at = divmod(self.count, self.WIDTH)
+            if slab == len(self.slabs):
+                self.slabs.append(DeviceMatrix.empty(self.n, self.WIDTH))
+            chunk = min(32, self.WIDTH - at)
+            rc = L.lib().pgh_poly_terms(self.graph._h, self._p._h, 1, self.count, chunk, self.slabs[slab]._h, at)
+            if rc != 0:
+                return False                                 # no blocked f64 image for this graph: the step-by-step route
+            for j in range(chunk):
+                col = self.slabs[slab].column(at + j)
+                self.l1.append(float(col.abssum()))
+                self.linf.append(float(backend.max(backend.abs(col))) if len(col) else 0.0)
+            self.count += chunk
         return True
 
     def combine(self, coeffs):
@@ -567,12 +592,14 @@ class ClosedFormGraphFilter(GraphFilter):
         g = _device_graph(M)
         p = personalization.np
         if type(cm) is not ConvergenceManager or cm.device_error_kind() is None or g is None or g.shape[0] != g.shape[1] \
-                or not isinstance(p, DeviceVector) or self.coefficient_type != "taylor" or self._active_dict is None:
+                or not isinstance(p, DeviceVector) or self.coefficient_type not in self._FORMS or self._active_dict is None:
             return None
-        slab = self._active_dict.get("powers")
+        cheb = self.coefficient_type == "chebyshev"
+        key = "terms_chebyshev" if cheb else "powers"
+        slab = self._active_dict.get(key)
         if not isinstance(slab, _PowerSlab) or slab.graph is not g:
-            slab = _PowerSlab(g, p)
-            self._active_dict["powers"] = slab
+            slab = _PowerSlab(g, p, chebyshev=cheb)
+            self._active_dict[key] = slab
         return slab
 
     def _expansion(self, slab, n):
@@ -625,8 +652,8 @@ class ClosedFormGraphFilter(GraphFilter):
         (P <= 64) -- the probes of an optimiser (autotune/parameterized.py:94-145: every probe differs in the coefficients
         only) or the candidate parameters of a sweep, evaluated in one pass over the stored powers (pgh_mat_gemm).
         `variants`: filters like this one (same graph pipeline, same convergence settings are NOT required: every variant
-        stops by its own rule).  Needs an optimisation dict on self (its powers are shared) and the "taylor" form; returns
-        (DeviceMatrix, [iterations of every variant])."""
+        stops by its own rule).  Needs an optimisation dict on self (its powers -- or, for the "chebyshev" form, the terms of
+        the f64 recurrence -- are shared); returns (DeviceMatrix, [iterations of every variant])."""
         if self.optimization_dict is None:
             raise Exception("rank_many evaluates stored powers: construct the filter with optimization_dict={}")
         if len(variants) < 1 or len(variants) > 64:
@@ -643,12 +670,12 @@ class ClosedFormGraphFilter(GraphFilter):
         M = self.preprocessor(self._prepare_graph(personalization.graph, personalization))
         slab = self._slab_for(M, personalization)
         if slab is None:
-            raise Exception("rank_many needs the engine's graph, the taylor form and a plain ConvergenceManager")
+            raise Exception("rank_many needs the engine's graph and a plain ConvergenceManager")
         n = max(len(personalization.np), 1)
         columns, iterations = [], []
         for v in variants:
-            if not isinstance(v, ClosedFormGraphFilter) or v.coefficient_type != "taylor":
-                raise Exception("rank_many variants must be taylor-form closed-form filters")
+            if not isinstance(v, ClosedFormGraphFilter) or v.coefficient_type != self.coefficient_type:
+                raise Exception("rank_many variants must be closed-form filters of the same coefficient type")
             v.convergence.start()
             plan = v._expansion(slab, n)
             if plan is None:

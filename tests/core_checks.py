@@ -338,6 +338,46 @@ def check_power_slab_serves_tuner_probes(pg):
         assert np.array_equal(np.asarray(again.rank(signal).np), np.asarray(algo.rank(signal).np))
 
 
+def check_chebyshev_slab_serves_tuner_probes(pg):
+    """SURVEY.md 8f-2 for the reference's "chebyshev" coefficient type (abstract_filters.py:216-224): the terms T_k of the
+    recurrence come out of the engine's f64 route once (pgh_poly_terms) and live as slab columns; every further filter of that
+    form on the personalization -- single probes and rank_many -- is a pass over them.  Against the oracle's loop: ranks to
+    1e-6, equal iteration counts, no further convolutions."""
+    import cases
+    from oracle import ref_loops as orc
+    eps32 = float(np.finfo(np.float32).eps)
+    for gkey in ("rmat10_dir", "rmat12_sym"):
+        A, directed, p = cases.GRAPHS[gkey]()
+        graph = pg.AdjacencyWrapper(A, directed=directed)
+        M = orc.normalize(A, "auto", directed)
+        pre = pg.preprocessor(assume_immutability=True)
+        signal = pg.to_signal(graph, p.copy())
+        cache = dict()
+        rng = np.random.default_rng(6)
+        probes = [list(rng.random(10)) for _ in range(3)] + [[1, 0.5, 0, 0.25, 0.1]]
+        for weights in probes:
+            algo = pg.GenericGraphFilter(weights, coefficient_type="chebyshev", preprocessor=pre, optimization_dict=cache, tol=1e-8, max_iters=60)
+            got = np.asarray(algo.rank(signal).np, dtype=np.float64)
+            want, want_iters = orc.generic_filter(M, p, weights, coefficient_type="chebyshev", tol=1e-8, max_iters=60, eps=eps32)
+            assert algo.convergence.iteration == want_iters, (gkey, weights, algo.convergence.iteration, want_iters)
+            assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), (gkey, weights)
+            assert algo.last_loop["spmv"] == 0
+        slab = next(iter(cache.values()))["terms_chebyshev"]
+        assert slab.chebyshev and slab.count == 32 and len(cache) == 1
+        hk = pg.HeatKernel(5, coefficient_type="chebyshev", preprocessor=pre, optimization_dict=cache, error_type="iters", max_iters=31)
+        a = np.asarray(hk.rank(signal).np, dtype=np.float64)
+        b, b_iters = orc.heat_kernel(M, p, t=5, coefficient_type="chebyshev", error_type="iters", max_iters=31)
+        assert hk.convergence.iteration == b_iters == 31 and np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(b)), gkey
+        # many probes in one pass over the terms
+        variants = [pg.GenericGraphFilter(w, coefficient_type="chebyshev", preprocessor=pre, tol=1e-8, max_iters=60) for w in probes]
+        slab_out, iterations = variants[0].__class__(probes[0], coefficient_type="chebyshev", preprocessor=pre, optimization_dict=cache, tol=1e-8,
+                                                     max_iters=60).rank_many(graph, p.copy(), variants)
+        cols = np.asarray(slab_out)
+        for q, weights in enumerate(probes):
+            want, want_iters = orc.generic_filter(M, p, weights, coefficient_type="chebyshev", tol=1e-8, max_iters=60, eps=eps32)
+            assert iterations[q] == want_iters and np.max(np.abs(cols[:, q] - want)) <= 1e-6 * np.max(np.abs(want)), (gkey, q)
+
+
 def check_rank_many_probes_in_one_pass(pg):
     """SURVEY.md 8f-2 "many probes as one GEMM": P coefficient vectors on one personalization -> an [n, P] slab from ONE pass
     over the stored powers (pgh_mat_gemm); every column against the oracle's loop for that probe (abstract_filters.py:
