@@ -84,6 +84,21 @@ def measured_traffic(scale, ef, blocked):
     return (int(total), os.path.relpath(PMC_SUMMARY, ROOT)) if total > 0 else (None, None)
 
 
+def measured_batch_traffic(scale, ef, width):
+    """HBM bytes of one batch step of the multi-seed loop (k_mm_partial + fix-up + combine + residual) from the committed PMC
+    summary of tools/probe_batch_kernels.py (profiles/r03/spmm_final_pmc.json; same hash rule as the headline's traffic)."""
+    path = os.path.join(ROOT, "profiles", "r03", "spmm_final_pmc.json")
+    if (scale, ef, width) != (23, 16, 64) or not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        pmc = json.load(f)
+    if pmc.get("_meta", {}).get("csrc_sha16") != csrc_sha16():
+        return dict(measured_gb_per_step=None, measured_traffic_source="stale: " + os.path.relpath(path, ROOT))
+    total = sum(row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"] for name, row in pmc.items()
+                if name.startswith(("k_mm_partial", "k_mm_fixup", "k_mm_combine", "k_mm_residual")))
+    return dict(measured_gb_per_step=round(total / 1e9, 2), measured_traffic_source=os.path.relpath(path, ROOT))
+
+
 def stream_ceiling_gbs(lib, L):
     """What a plain streaming copy reaches on this box right now (read + written bytes per second, engine's pgh_vec_copy on
     256 MB vectors): the practical HBM ceiling beside the 8 TB/s datasheet peak."""
@@ -267,7 +282,7 @@ def single_gpu(args):
             secondary["ppr_l1_1e-6_batch_of_64_seeds"] = dict(
                 edge_vector_products_per_s_G=round(nnz * products / dt / 1e9, 1), device_step_us=round(info[0]["loop_ms"] / steps * 1e3, 1),
                 nominal_gbs=round((8 * nnz + 4 * n + 12 * n * width) / (info[0]["loop_ms"] / steps * 1e-3) / 1e9, 1),
-                batch_steps=steps, width=width)
+                batch_steps=steps, width=width, **measured_batch_traffic(scale, ef, width))
             del feats
         except Exception as exc:                     # a side measurement never takes the headline down
             secondary["ppr_l1_1e-6_batch_of_64_seeds"] = dict(error=str(exc))

@@ -377,23 +377,25 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
     }
 }
 
-// per-column fold of the block partials: lane = column, the WG / 64 wavefronts take interleaved rows of the partial table
-// and are combined in wavefront order (fixed summation order)
+// per-column fold of the block partials ([count][64] doubles): one workgroup per column, thread t adds rows t, t + 256, ...,
+// then the lanes and the four wavefronts are combined in a fixed order (deterministic).  (One workgroup for all 64 columns --
+// the first version -- read the 1 MB of partials through a single CU: 128 us per fold, two folds per batch step.)
 __global__ __launch_bounds__(WG) void k_mm_fold(const double* __restrict__ partials, int count, int linf, double* __restrict__ out) {
-    __shared__ double s_red[WG / 64][kLanes];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ double s_red[WG / 64];
+    const int col = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double acc = 0.0;
-    for (int i = w; i < count; i += WG / 64) {
-        const double v = partials[(int64_t)i * kLanes + lane];
+    for (int i = threadIdx.x; i < count; i += WG) {
+        const double v = partials[(int64_t)i * kLanes + col];
         acc = linf ? fmax(acc, v) : acc + v;
     }
-    s_red[w][lane] = acc;
+    acc = linf ? wave_reduce_max(acc) : wave_reduce_sum(acc);
+    if (lane == 0) s_red[w] = acc;
     __syncthreads();
-    if (w == 0) {
-        double t = s_red[0][lane];
+    if (threadIdx.x == 0) {
+        double t = s_red[0];
 #pragma unroll
-        for (int k = 1; k < WG / 64; ++k) t = linf ? fmax(t, s_red[k][lane]) : t + s_red[k][lane];
-        out[lane] = t;
+        for (int k = 1; k < WG / 64; ++k) t = linf ? fmax(t, s_red[k]) : t + s_red[k];
+        out[col] = t;
     }
 }
 
@@ -871,14 +873,14 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
                 ProfScope prof(PGH_K_COMBINE);
                 k_mm_combine<<<cgrid, WG, 0, r.stream>>>(c, n_int, ld, b, state, partial.as<double>());
             }
-            k_mm_fold<<<1, WG, 0, r.stream>>>(partial.as<double>(), cgrid, 0, reinterpret_cast<double*>(state) + 2 * kLanes);   // -> state.sum
+            k_mm_fold<<<kLanes, WG, 0, r.stream>>>(partial.as<double>(), cgrid, 0, reinterpret_cast<double*>(state) + 2 * kLanes);   // -> state.sum
             const int it = k + 1;
             const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
             if (check) {
                 ProfScope prof(PGH_K_RESIDUAL);
                 k_mm_residual<<<cgrid, WG, 0, r.stream>>>(yout, yin, n_int, ld, b, cfg->use_quotient, linf, state, partial.as<double>(),
                                                           skip_dead ? p_rows.as<uint8_t>() : nullptr);
-                k_mm_fold<<<1, WG, 0, r.stream>>>(partial.as<double>(), cgrid, linf, reinterpret_cast<double*>(state) + kLanes);     // -> state.err
+                k_mm_fold<<<kLanes, WG, 0, r.stream>>>(partial.as<double>(), cgrid, linf, reinterpret_cast<double*>(state) + kLanes);     // -> state.err
             }
             k_mm_close<<<1, kLanes, 0, r.stream>>>(state, cfg->use_quotient, check, cfg->err_kind, cfg->tol, n);
         }
