@@ -308,6 +308,15 @@ int pgh_dist_partial(pgh_graph_t g, pgh_vec_t xg_full, const double* state);
 int pgh_dist_partial_stage(pgh_graph_t g, pgh_vec_t xg_full, const double* state, int32_t stage);
 int pgh_graph_hot_prefix(pgh_graph_t g, int32_t* hot_slots);
 int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, pgh_vec_t y_local, pgh_vec_t xg_local_out, double* state);
+/* pgh_dist_combine with the AbsorbingWalks formula (adhoc.py:157-169) on the slice's rows: deg_local / lam_local = this rank's slice of
+ * degrees(M) and of absorption * (1 - alpha) / alpha. */
+int pgh_dist_combine_absorb(pgh_graph_t g, pgh_vec_t p_local, pgh_vec_t deg_local, pgh_vec_t lam_local, pgh_vec_t y_local,
+                            pgh_vec_t xg_local_out, double* state);
+/* ... and with the step of the closed-form filters (abstract_filters.py:215-230, taylor form): term_out = a * (M^T term) + b * term,
+ * result += c * term_out on the slice's rows; state[1] receives this rank's share of |result_new - result_old| (sum, or max with
+ * err_linf) for the caller's all-reduce; pgh_dist_close_sum(state, 0) then counts the step, pgh_dist_close_err decides. */
+int pgh_dist_combine_poly(pgh_graph_t g, pgh_vec_t term_local, pgh_vec_t term_out_local, double a, double b, pgh_vec_t result_local,
+                          double c, int32_t err_linf, pgh_vec_t xg_local_out, double* state);
 int pgh_dist_close_sum(double* state, int32_t use_quotient);
 /* Isolated rows of a rank's slice (ids without any edge sort last in every block of a generated partition).  Between these two
  * calls the loop passes over them as long as p_local and the start iterate are zero there (checked on the device by the first

@@ -1215,6 +1215,40 @@ int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p, double alpha, pgh_vec_t y, pgh_
     std::copy(y->data, y->data + y->n, xg_local->data);
     return 0;
 }
+static double absorb_step(const pgh_graph_s* g, const float* x, double xs, const float* p, const float* deg, const float* lam, float* y);
+int pgh_dist_combine_absorb(pgh_graph_t g, pgh_vec_t p, pgh_vec_t deg, pgh_vec_t lam, pgh_vec_t y, pgh_vec_t xg_local, double* state) {
+    CHECK(g && p && deg && lam && y && xg_local && state, "pgh_dist_combine_absorb: null argument");
+    CHECK(p->n == g->n_cols && deg->n == g->n_cols && lam->n == g->n_cols && y->n == g->n_cols && xg_local->n == g->n_cols,
+          "pgh_dist_combine_absorb: local vector length mismatch");
+    DistState* st = reinterpret_cast<DistState*>(state);
+    if (st->done) return 0;
+    CHECK(g->pending_xg != nullptr, "pgh_dist_combine_absorb: no pgh_dist_partial before it");
+    st->sum = absorb_step(g, g->pending_xg, st->scale, p->data, deg->data, lam->data, y->data);
+    std::copy(y->data, y->data + y->n, xg_local->data);
+    return 0;
+}
+int pgh_dist_combine_poly(pgh_graph_t g, pgh_vec_t term, pgh_vec_t term_out, double a, double b, pgh_vec_t result, double c, int32_t err_linf,
+                          pgh_vec_t xg_local, double* state) {
+    CHECK(g && term && term_out && result && xg_local && state, "pgh_dist_combine_poly: null argument");
+    CHECK(term->n == g->n_cols && term_out->n == g->n_cols && result->n == g->n_cols && xg_local->n == g->n_cols,
+          "pgh_dist_combine_poly: local vector length mismatch");
+    DistState* st = reinterpret_cast<DistState*>(state);
+    if (st->done) return 0;
+    CHECK(g->pending_xg != nullptr, "pgh_dist_combine_poly: no pgh_dist_partial before it");
+    double delta = 0;
+    for (int64_t r = 0; r < g->n_cols; ++r) {
+        float y = (float)a * row_dot(g, g->pending_xg, r);
+        if (b != 0.0) y += (float)b * term->data[r];
+        term_out->data[r] = y;
+        const float r_old = result->data[r], r_new = r_old + (float)c * y;
+        result->data[r] = r_new;
+        const double d = std::fabs((double)r_new - (double)r_old);
+        delta = err_linf ? std::max(delta, d) : delta + d;
+    }
+    st->err = delta;
+    std::copy(term_out->data, term_out->data + term_out->n, xg_local->data);
+    return 0;
+}
 // the host restatement processes every row in every step: nothing to watch
 int pgh_dist_watch_isolated(pgh_graph_t g, pgh_vec_t p_local, pgh_vec_t y_start) {
     CHECK(g && p_local && y_start, "pgh_dist_watch_isolated: null argument");

@@ -145,6 +145,8 @@ SIGNATURES = {
     "pgh_dist_partial_stage": (C.c_int, [c_graph, c_vec, C.c_void_p, C.c_int32]),
     "pgh_graph_hot_prefix": (C.c_int, [c_graph, C.POINTER(C.c_int32)]),
     "pgh_dist_combine": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, c_vec, C.c_void_p]),
+    "pgh_dist_combine_absorb": (C.c_int, [c_graph, c_vec, c_vec, c_vec, c_vec, c_vec, C.c_void_p]),
+    "pgh_dist_combine_poly": (C.c_int, [c_graph, c_vec, c_vec, C.c_double, C.c_double, c_vec, C.c_double, C.c_int32, c_vec, C.c_void_p]),
     "pgh_dist_close_sum": (C.c_int, [C.c_void_p, C.c_int32]),
     "pgh_dist_watch_isolated": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgh_dist_release_isolated": (C.c_int, [C.c_void_p]),

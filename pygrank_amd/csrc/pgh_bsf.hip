@@ -1004,6 +1004,8 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
 }
 
 template int bsf_launch_combine<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const LoopState*, int*);
+template int bsf_launch_combine<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const LoopState*, int*);
+template int bsf_launch_combine<EPI_POLY>(pgh_graph_s*, const EpiParams&, const LoopState*, int*);
 template int bsf_launch<EPI_PLAIN>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);
 template int bsf_launch<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);
 template int bsf_launch<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const float*, const LoopState*, int*, hipEvent_t);

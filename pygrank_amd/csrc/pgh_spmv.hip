@@ -1106,6 +1106,65 @@ extern "C" int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, 
     return 0;
 }
 
+// The same stage with the AbsorbingWalks formula (adhoc.py:157-169): y = ((M^T x) * scale * deg + p * lam) / (lam + deg) on the
+// slice's rows; deg_local / lam_local: this rank's slice of degrees(M) and of absorption * (1 - alpha) / alpha.
+extern "C" int pgh_dist_combine_absorb(pgh_graph_t g, pgh_vec_t p_local, pgh_vec_t deg_local, pgh_vec_t lam_local, pgh_vec_t y_local,
+                                       pgh_vec_t xg_local_out, double* state) {
+    PGH_CHECK(p_local && deg_local && lam_local && y_local && xg_local_out && state, "pgh_dist_combine_absorb: null argument");
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_dist_combine_absorb"));
+    PGH_CHECK(p_local->n == g->n_cols && deg_local->n == g->n_cols && lam_local->n == g->n_cols && y_local->n == g->n_cols &&
+              xg_local_out->n == g->n_cols, "pgh_dist_combine_absorb: local vector length mismatch");
+    BsfFormat& f = g->bsf;
+    Runtime& r = rt();
+    EpiParams ep{};
+    ep.a = 1.0;                                    // the kernel multiplies by state->scale
+    ep.v = p_local->data;
+    ep.deg = deg_local->data;
+    ep.lam = lam_local->data;
+    ep.y = y_local->data;
+    if (f.src_scale != nullptr) {
+        ep.xg_out = xg_local_out->data;
+        ep.src_scale = f.src_scale + g->row_begin;
+    }
+    int count = 0;
+    PGH_TRY((bsf_launch_combine<EPI_ABSORB>(g, ep, reinterpret_cast<const LoopState*>(state), &count)));
+    if (f.src_scale == nullptr) PGH_TRY(pgh_vec_copy(xg_local_out, y_local));
+    k_dist_fold<<<1, WG, 0, r.stream>>>(state, r.d_partials, count, 0, 2);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+// ... and with the step of the closed-form filters (abstract_filters.py:215-230, taylor form): term_out = a * (M^T term) + b * term,
+// result += c * term_out on the slice's rows; this rank's share of |result_new - result_old| (sum or max) lands in state[1] for the
+// caller's all-reduce, the next gather slice (term_out * source scale) in xg_local_out.
+extern "C" int pgh_dist_combine_poly(pgh_graph_t g, pgh_vec_t term_local, pgh_vec_t term_out_local, double a, double b, pgh_vec_t result_local,
+                                     double c, int32_t err_linf, pgh_vec_t xg_local_out, double* state) {
+    PGH_CHECK(term_local && term_out_local && result_local && xg_local_out && state, "pgh_dist_combine_poly: null argument");
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_dist_combine_poly"));
+    PGH_CHECK(term_local->n == g->n_cols && term_out_local->n == g->n_cols && result_local->n == g->n_cols && xg_local_out->n == g->n_cols &&
+              term_local->data != term_out_local->data, "pgh_dist_combine_poly: local vector length mismatch");
+    BsfFormat& f = g->bsf;
+    Runtime& r = rt();
+    EpiParams ep{};
+    ep.a = a;
+    ep.b = b;
+    ep.v = b != 0.0 ? term_local->data : nullptr;
+    ep.y = term_out_local->data;
+    ep.r = result_local->data;
+    ep.c = c;
+    ep.err_linf = err_linf ? 1 : 0;
+    if (f.src_scale != nullptr) {
+        ep.xg_out = xg_local_out->data;
+        ep.src_scale = f.src_scale + g->row_begin;
+    }
+    int count = 0;
+    PGH_TRY((bsf_launch_combine<EPI_POLY>(g, ep, reinterpret_cast<const LoopState*>(state), &count)));
+    if (f.src_scale == nullptr) PGH_TRY(pgh_vec_copy(xg_local_out, term_out_local));
+    k_dist_fold<<<1, WG, 0, r.stream>>>(state, r.d_partials + kMaxPartials, count, err_linf ? 1 : 0, 1);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
 // Isolated rows of a rank's slice (ids without any edge sort last in every block of a generated partition): while the loop's
 // operands are zero on them they stay zero, and the finish kernel / the residual pass over them.  The caller brackets a run
 // with these two calls; in between the flag is 0 unless p or the start iterate touch such a row.

@@ -283,6 +283,15 @@ class DistributedPageRank:
     never waits for the host."""
 
     _KINDS = {"mabs": L.ERR_MABS, "l1": L.ERR_L1, "linf": L.ERR_LINF, "iters": L.ERR_ITERS}
+    _native_formula = True            # pgh_dist_ppr_run implements this class's step (subclasses with another formula: the staged loop)
+
+    def _prepare_run(self, pgraph, p, bufs, lib):
+        """Per-run operands of the step formula, and the isolated rows to watch (p: the normalised personalization slice)."""
+        L.check(lib.pgh_dist_watch_isolated(pgraph.graph._h, p._h, bufs.v_y[0]._h))
+
+    def _combine(self, lib, g, p, y, xg_local, state):
+        """The finish stage of one step on this rank's rows: PageRank._formula (adhoc.py:34-36)."""
+        L.check(lib.pgh_dist_combine(g._h, p._h, self.alpha, y._h, xg_local._h, state))
 
     def __init__(self, alpha=0.85, tol=1e-6, error_type="mabs", max_iters=100, end_modulo=1, use_quotient=True,
                  preserve_norm=True, epsilon=float(np.finfo(np.float32).eps)):
@@ -304,7 +313,8 @@ class DistributedPageRank:
         lib = L.lib()
         g = pgraph.graph
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        comm = _native_comm(dist, device)
+        self._dist, self._device = dist, device
+        comm = _native_comm(dist, device) if self._native_formula else None
         if comm is not None:
             return self._rank_native(pgraph, p_local, comm, lib)
         if self._buffers is None or self._buffers_for is not pgraph:
@@ -387,7 +397,7 @@ class DistributedPageRank:
         cur = 0
         bufs.y[1 - cur].zero_()                  # the rows a run passes over (isolated ids) must hold zeros in both iterates
         L.check(lib.pgh_vec_copy(bufs.v_y[cur]._h, p._h))
-        L.check(lib.pgh_dist_watch_isolated(g._h, p._h, bufs.v_y[cur]._h))
+        self._prepare_run(pgraph, p, bufs, lib)
         L.check(lib.pgh_dist_prescale(g._h, bufs.v_y[cur]._h, bufs.v_xg_local._h))
         bufs.all_gather(dist, "all")
         L.check(lib.pgh_dist_state_init(state))
@@ -432,7 +442,7 @@ class DistributedPageRank:
                     break
             if cuda:
                 main.wait_event(ev_err)         # quotient and done flag of the previous step; its residual has read y[nxt]
-            L.check(lib.pgh_dist_combine(g._h, p._h, self.alpha, bufs.v_y[nxt]._h, bufs.v_xg_local._h, state))
+            self._combine(lib, g, p, bufs.v_y[nxt], bufs.v_xg_local, state)
             if cuda:
                 ev_fin.record(main)
             with on(xs if cuda else None):                                        # ---- X: the next gather vector over xGMI
@@ -492,6 +502,147 @@ class DistributedPageRank:
         out = bufs.v_y[cur] * factor
         L.check(lib.pgh_sync())
         return out
+
+
+class DistributedAbsorbingWalks(DistributedPageRank):
+    """AbsorbingWalks(alpha) (adhoc.py:125-174) on a PartitionedGraph: the loop, the exchange and the stopping rule of
+    DistributedPageRank with the step ``(conv(ranks, M) * deg + p * lam) / (lam + deg)``, deg = degrees(M) and lam = absorption *
+    (1 - alpha) / alpha on this rank's rows (pgh_dist_combine_absorb).  absorption: this rank's slice (new ids) or None = 1."""
+    _native_formula = False
+
+    def __init__(self, alpha=1 - 1.e-6, absorption=None, **kwargs):
+        super().__init__(alpha=alpha, **kwargs)
+        self.absorption = absorption
+
+    def _prepare_run(self, pgraph, p, bufs, lib):
+        lo, m = pgraph.row_begin, pgraph.n_local
+        # degrees(M) = row sums of M: a rank holds its COLUMNS of M (its rows of M^T), so its row sums are partial -- summed over the ranks
+        import torch
+        deg_all = torch.from_numpy(np.asarray(pgraph.graph.degrees(), dtype=np.float64)).to(self._device)
+        self._dist.all_reduce(deg_all)
+        self._deg = DeviceVector.from_host(deg_all[lo:lo + m].cpu().numpy())
+        lam = (np.ones(m) if self.absorption is None else np.asarray(self.absorption, dtype=np.float64)) * ((1 - self.alpha) / self.alpha)
+        self._lam = DeviceVector.from_host(lam)
+        # an isolated row is p * lam / (lam + 0) = p: zero while p is zero there -- unless lam is zero too (0 / 0 in the reference):
+        # such a run processes every row
+        watch = bufs.v_y[0] if float(lam.min(initial=1.0)) > 0 else DeviceVector.from_host(np.ones(m))
+        L.check(lib.pgh_dist_watch_isolated(pgraph.graph._h, p._h, watch._h))
+
+    def _combine(self, lib, g, p, y, xg_local, state):
+        L.check(lib.pgh_dist_combine_absorb(g._h, p._h, self._deg._h, self._lam._h, y._h, xg_local._h, state))
+
+
+class DistributedClosedFormFilter:
+    """ClosedFormGraphFilter (abstract_filters.py:152-270, taylor form) on a PartitionedGraph: result = sum_k c_k (M^T)^(k-1) p with the
+    stopping rule of ConvergenceManager on the change of the result (convergence.py:77-101).  `coefficient(previous, iteration)` is
+    the filter's _coefficient (see DistributedHeatKernel / DistributedPageRankClosed).  One exchange per term: the all-gather of the
+    term's gather slice, and one 8-byte all-reduce of the change.  The staged loop without run-ahead (the host reads the flag once per
+    term): functional coverage of the filters next to PageRank, not a tuned path."""
+
+    _KINDS = DistributedPageRank._KINDS
+
+    def __init__(self, coefficient, tol=1e-6, error_type="mabs", max_iters=100, end_modulo=1, preserve_norm=True,
+                 epsilon=float(np.finfo(np.float32).eps)):
+        self.coefficient, self.tol, self.error_type = coefficient, tol, error_type
+        self.max_iters, self.end_modulo, self.preserve_norm, self.epsilon = max_iters, end_modulo, preserve_norm, epsilon
+        self.iteration, self.spmv, self._buffers = 0, 0, None
+
+    def rank(self, pgraph, p_local):
+        import torch
+        import torch.distributed as dist
+        lib, g = L.lib(), pgraph.graph
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        if self._buffers is None or self._buffers_for is not pgraph:
+            self._buffers, self._buffers_for = _Buffers(pgraph, device, dist), pgraph
+        bufs = self._buffers
+        # one stream for the engine's launches and torch's collectives / tensor ops (as DistributedPageRank.rank)
+        if device.type == "cuda":
+            if getattr(self, "_stream", None) is None:
+                self._stream = torch.cuda.Stream()
+            L.check(lib.pgh_sync())
+            L.check(lib.pgh_set_stream(C.c_void_p(self._stream.cuda_stream)))
+            ctx = torch.cuda.stream(self._stream)
+        else:
+            ctx = _NullCtx()
+        try:
+            with ctx:
+                return self._rank_on_stream(pgraph, p_local, bufs, dist, lib, g, device, torch)
+        finally:
+            if device.type == "cuda":
+                L.check(lib.pgh_sync())
+                L.check(lib.pgh_set_stream(None))
+
+    def _rank_on_stream(self, pgraph, p_local, bufs, dist, lib, g, device, torch):
+        kind = self._KINDS[self.error_type]
+        tol = 0.0 if self.tol is None else max(self.tol, self.epsilon)
+        linf = 1 if kind == L.ERR_LINF else 0
+        scalar = lambda value, op: DistributedPageRank._all_reduce(self, bufs, dist, value, op)      # noqa: E731
+        norm = scalar(p_local.abssum(), dist.ReduceOp.SUM)
+        if norm == 0:
+            self.iteration = 0
+            return p_local
+        state = C.c_void_p(bufs.state.data_ptr())
+        err_view = bufs.state[1:2]
+        n_local = pgraph.n_local
+        res_t = torch.zeros(n_local, dtype=torch.float32, device=device)
+        v_res = DeviceVector.wrap(res_t.data_ptr(), n_local, keepalive=res_t)
+        p = p_local / norm
+        c = self.coefficient(None, 1)                                            # iteration 1: result_1 = c_1 p
+        L.check(lib.pgh_vec_copy(bufs.v_y[0]._h, p._h))
+        first = p * float(c)                                                     # (kept alive until the copy has been enqueued)
+        L.check(lib.pgh_vec_copy(v_res._h, first._h))
+        L.check(lib.pgh_dist_prescale(g._h, bufs.v_y[0]._h, bufs.v_xg_local._h))
+        bufs.all_gather(dist, "all")
+        L.check(lib.pgh_dist_state_init(state))
+        delta = abs(float(c)) * (1.0 if not linf else scalar(float(backend_max_abs(p)), dist.ReduceOp.MAX))
+        if kind == L.ERR_MABS:
+            delta /= pgraph.n
+        cur, it, spmv, converged = 0, 2, 0, False
+        t0 = time.perf_counter()
+        while True:                                                              # `it` = the iteration has_converged is asked about
+            if it >= self.max_iters:
+                break
+            if kind != L.ERR_ITERS and it % self.end_modulo == 0 and delta <= tol:
+                converged = True
+                break
+            c = self.coefficient(c, it)
+            nxt = 1 - cur
+            L.check(lib.pgh_dist_partial_stage(g._h, bufs.v_xg_full._h, state, 0))
+            L.check(lib.pgh_dist_combine_poly(g._h, bufs.v_y[cur]._h, bufs.v_y[nxt]._h, 1.0, 0.0, v_res._h, float(c), linf,
+                                              bufs.v_xg_local._h, state))
+            bufs.all_gather(dist, "all")
+            dist.all_reduce(err_view, op=dist.ReduceOp.MAX if linf else dist.ReduceOp.SUM)
+            bufs.state_host.copy_(bufs.state)                                    # the host decides (one read per term)
+            delta = float(bufs.state_host[1]) / (pgraph.n if kind == L.ERR_MABS else 1)
+            cur, spmv, it = nxt, spmv + 1, it + 1
+        self.elapsed = time.perf_counter() - t0
+        self.iteration, self.spmv, self.converged, self.last_error = it, spmv, converged, delta
+        if not converged and self.error_type != "iters" and it >= self.max_iters:
+            raise Exception("Could not converge within " + str(self.max_iters) + " iterations")
+        out = v_res * (norm if self.preserve_norm else 1.0)
+        L.check(lib.pgh_sync())
+        return out
+
+
+def backend_max_abs(vec):
+    from pygrank_amd import backend
+    return backend.max(backend.abs(vec)) if len(vec) else 0.0
+
+
+class DistributedHeatKernel(DistributedClosedFormFilter):
+    """HeatKernel(t) (adhoc.py:93-122) on a PartitionedGraph."""
+
+    def __init__(self, t=3, **kwargs):
+        super().__init__(lambda prev, it: 1.0 if prev is None else prev * t / (it + 1), **kwargs)     # adhoc.py:113-116
+        self.t = t
+
+
+class DistributedPageRankClosed(DistributedClosedFormFilter):
+    """PageRankClosed(alpha) (adhoc.py:63-90) on a PartitionedGraph."""
+
+    def __init__(self, alpha=0.85, **kwargs):
+        super().__init__(lambda prev, it: 1.0 if prev is None else prev * alpha, **kwargs)           # adhoc.py:83-84
+        self.alpha = alpha
 
 
 class _NullCtx:

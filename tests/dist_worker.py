@@ -47,6 +47,18 @@ def main():
         out = ranker.rank(graph, DeviceVector.from_host(p_local))
         results[name + "_ranks"] = np.asarray(out)
         results[name + "_iters"] = ranker.iteration
+    from pygrank_amd.distributed import DistributedAbsorbingWalks
+    absorbing = DistributedAbsorbingWalks(alpha=0.85, error_type="l1", tol=1e-6, max_iters=500)
+    out = absorbing.rank(graph, DeviceVector.from_host(p_local))
+    results["absorb_ranks"] = np.asarray(out)
+    results["absorb_iters"] = absorbing.iteration
+    from pygrank_amd.distributed import DistributedHeatKernel, DistributedPageRankClosed
+    for name, algo in (("heat", DistributedHeatKernel(t=3, error_type="l1", tol=1e-7, max_iters=100)),
+                       ("heat_mabs", DistributedHeatKernel(t=5, error_type="mabs", tol=1e-9, max_iters=100)),
+                       ("closed", DistributedPageRankClosed(alpha=0.85, error_type="linf", tol=1e-5, max_iters=300))):
+        out = algo.rank(graph, DeviceVector.from_host(p_local))
+        results[name + "_ranks"] = np.asarray(out)
+        results[name + "_iters"] = algo.iteration
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), perm=perm, lo=lo, n_local=graph.n_local, nnz=graph.graph.nnz, **results)
     dist.barrier()
     dist.destroy_process_group()

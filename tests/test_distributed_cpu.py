@@ -50,6 +50,25 @@ def test_row_partitioned_pagerank_gloo(tmp_path, oracle_build_dir, world):
             got[perm[lo:lo + m]] = part[name + "_ranks"]
             assert int(part[name + "_iters"]) == want_iters, name
         assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), name
+    # AbsorbingWalks on the same partition (adhoc.py:157-169; DistributedAbsorbingWalks -> pgh_dist_combine_absorb)
+    want, want_iters = orc.absorbing_walks(M, p_old, alpha=0.85, error_type="l1", tol=1e-6, max_iters=500, eps=EPS32)
+    got = np.zeros(n)
+    for part in parts:
+        lo, m = int(part["lo"]), int(part["n_local"])
+        got[perm[lo:lo + m]] = part["absorb_ranks"]
+        assert int(part["absorb_iters"]) == want_iters
+    assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
+    # closed-form filters on the same partition (DistributedClosedFormFilter -> pgh_dist_combine_poly)
+    for name, ref in (("heat", lambda: orc.heat_kernel(M, p_old, t=3, error_type="l1", tol=1e-7, max_iters=100, eps=EPS32)),
+                      ("heat_mabs", lambda: orc.heat_kernel(M, p_old, t=5, error_type="mabs", tol=1e-9, max_iters=100, eps=EPS32)),
+                      ("closed", lambda: orc.pagerank_closed(M, p_old, alpha=0.85, error_type="linf", tol=1e-5, max_iters=300, eps=EPS32))):
+        want, want_iters = ref()
+        got = np.zeros(n)
+        for part in parts:
+            lo, m = int(part["lo"]), int(part["n_local"])
+            got[perm[lo:lo + m]] = part[name + "_ranks"]
+            assert int(part[name + "_iters"]) == want_iters, (name, int(part[name + "_iters"]), want_iters)
+        assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), name
 
 
 def test_bench_two_ranks_prints_one_json_line(oracle_build_dir):

@@ -197,6 +197,25 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
             got[perm[lo:lo + m]] = part[name + "_ranks"]
             assert int(part[name + "_iters"]) == want_iters, name
         assert rel_linf(got, want) <= 1e-6, name
+    # AbsorbingWalks on the same partition (the staged loop with pgh_dist_combine_absorb)
+    want, want_iters = orc.absorbing_walks(M, p_old, alpha=0.85, error_type="l1", tol=1e-6, max_iters=500, eps=EPS32)
+    got = np.zeros(n)
+    for part in parts:
+        lo, m = int(part["lo"]), int(part["n_local"])
+        got[perm[lo:lo + m]] = part["absorb_ranks"]
+        assert int(part["absorb_iters"]) == want_iters
+    assert rel_linf(got, want) <= 1e-6
+    # closed-form filters on the same partition (DistributedClosedFormFilter -> pgh_dist_combine_poly)
+    for name, ref in (("heat", lambda: orc.heat_kernel(M, p_old, t=3, error_type="l1", tol=1e-7, max_iters=100, eps=EPS32)),
+                      ("heat_mabs", lambda: orc.heat_kernel(M, p_old, t=5, error_type="mabs", tol=1e-9, max_iters=100, eps=EPS32)),
+                      ("closed", lambda: orc.pagerank_closed(M, p_old, alpha=0.85, error_type="linf", tol=1e-5, max_iters=300, eps=EPS32))):
+        want, want_iters = ref()
+        got = np.zeros(n)
+        for part in parts:
+            lo, m = int(part["lo"]), int(part["n_local"])
+            got[perm[lo:lo + m]] = part[name + "_ranks"]
+            assert int(part[name + "_iters"]) == want_iters, (name, int(part[name + "_iters"]), want_iters)
+        assert rel_linf(got, want) <= 1e-6, name
 
 
 def test_randomised_stress(gpu_engine):
