@@ -251,14 +251,27 @@ def _native_comm(dist, device):
         lib = L.lib()
         num_ids = 1 if os.environ.get("PGH_DIST_SINGLE_COMM", "0") == "1" else 2
         ids = (C.c_uint8 * (L.COMM_ID_BYTES * num_ids))()
+        ok = 1
         if rank == 0:
             for i in range(num_ids):
-                L.check(lib.pgh_comm_unique_id(C.cast(C.byref(ids, i * L.COMM_ID_BYTES), C.c_void_p)))
-        wire = torch.tensor(list(ids), dtype=torch.uint8, device=device)
+                if lib.pgh_comm_unique_id(C.cast(C.byref(ids, i * L.COMM_ID_BYTES), C.c_void_p)) != 0:
+                    ok = 0
+        wire = torch.tensor(list(ids) + [ok], dtype=torch.uint8, device=device)      # the ids and "rank 0 could draw them"
         dist.broadcast(wire, src=0)
-        ids = (C.c_uint8 * (L.COMM_ID_BYTES * num_ids))(*wire.cpu().tolist())
+        got = wire.cpu().tolist()
+        ids, ok = (C.c_uint8 * (L.COMM_ID_BYTES * num_ids))(*got[:-1]), (ok if rank == 0 else int(got[-1]))
         handle = C.c_void_p()
-        L.check(lib.pgh_comm_create(C.cast(ids, C.c_void_p), num_ids, world, rank, C.byref(handle)))
+        if ok and lib.pgh_comm_create(C.cast(ids, C.c_void_p), num_ids, world, rank, C.byref(handle)) != 0:
+            ok = 0
+        # every rank takes the same road: one that could not set its communicators up sends all of them to the Python-driven loop
+        agree = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0:
+            sys.stderr.write(f"[pygrank_amd.distributed] rank {rank}: the engine's RCCL communicators could not be created "
+                             f"({lib.pgh_last_error().decode('utf-8', 'replace') if not ok else 'on another rank'}); using the Python-driven loop\n")
+            if handle.value:
+                lib.pgh_comm_destroy(handle)
+            handle = None
         _NATIVE_COMMS[key] = handle
     return _NATIVE_COMMS[key]
 
@@ -266,7 +279,8 @@ def _native_comm(dist, device):
 def release_native_comms():
     """Destroys the engine's RCCL communicators of this process (before torch.distributed is torn down)."""
     for handle in _NATIVE_COMMS.values():
-        L.lib().pgh_comm_destroy(handle)
+        if handle is not None:
+            L.lib().pgh_comm_destroy(handle)
     _NATIVE_COMMS.clear()
 
 
