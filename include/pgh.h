@@ -351,7 +351,11 @@ typedef struct {
     int32_t end_modulo;
     int32_t use_quotient;
     int32_t preserve_norm;
-    int32_t reserved;
+    int32_t every_row;      /* 1: no row of the slice is passed over (an absorption of 0 on an isolated node is 0 / 0 in the reference) */
+    /* AbsorbingWalks (adhoc.py:157-169) instead of PageRank when both are set: this rank's slice of degrees(M) and of
+     * absorption * (1 - alpha) / alpha; the step is pgh_dist_combine_absorb */
+    pgh_vec_t deg_local;
+    pgh_vec_t lam_local;
 } pgh_dist_cfg;
 typedef struct {
     int32_t iterations;     /* ConvergenceManager.iteration at loop exit (0: the personalization is all zeros)  */

@@ -36,7 +36,8 @@ class LoopResult(C.Structure):
 
 class DistCfg(C.Structure):
     _fields_ = [("alpha", C.c_double), ("tol", C.c_double), ("n_global", C.c_int64), ("err_kind", C.c_int32), ("max_iters", C.c_int32),
-                ("end_modulo", C.c_int32), ("use_quotient", C.c_int32), ("preserve_norm", C.c_int32), ("reserved", C.c_int32)]
+                ("end_modulo", C.c_int32), ("use_quotient", C.c_int32), ("preserve_norm", C.c_int32), ("every_row", C.c_int32),
+                ("deg_local", C.c_void_p), ("lam_local", C.c_void_p)]
 
 
 class DistResult(C.Structure):

@@ -338,7 +338,9 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     int cur = 0;
     PGH_HIP(hipMemsetAsync(c->y[1], 0, sizeof(float) * (size_t)n_local, c->main));      // rows a run passes over hold zeros in both iterates
     PGH_TRY(pgh_vec_copy(&v_y[0], &v_p));
-    PGH_TRY(pgh_dist_watch_isolated(g, &v_p, &v_y[0]));
+    const bool absorbing = cfg->deg_local != nullptr && cfg->lam_local != nullptr;
+    PGH_CHECK(!absorbing || (cfg->deg_local->n == n_local && cfg->lam_local->n == n_local), "pgh_dist_ppr_run: deg / lam must have the slice's length");
+    if (!cfg->every_row) PGH_TRY(pgh_dist_watch_isolated(g, &v_p, &v_y[0]));
     PGH_TRY(pgh_dist_prescale(g, &v_y[0], &v_xg_local));
     const int64_t cold_region = (int64_t)c->nb * c->hot;
     if (c->hot > 0) {
@@ -379,7 +381,9 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
             }
         }
         PGH_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));      // quotient and done flag of the previous step; its residual has read y[nxt]
-        if ((rc = pgh_dist_combine(g, &v_p, cfg->alpha, &v_y[nxt], &v_xg_local, c->state)) != 0) break;
+        rc = absorbing ? pgh_dist_combine_absorb(g, &v_p, cfg->deg_local, cfg->lam_local, &v_y[nxt], &v_xg_local, c->state)
+                       : pgh_dist_combine(g, &v_p, cfg->alpha, &v_y[nxt], &v_xg_local, c->state);
+        if (rc != 0) break;
         PGH_HIP(hipEventRecord(c->ev_fin, c->main));
         // ---- X: the next gather vector over xGMI
         PGH_HIP(hipStreamWaitEvent(c->xs, c->ev_fin, 0));

@@ -299,6 +299,9 @@ class DistributedPageRank:
     _KINDS = {"mabs": L.ERR_MABS, "l1": L.ERR_L1, "linf": L.ERR_LINF, "iters": L.ERR_ITERS}
     _native_formula = True            # pgh_dist_ppr_run implements this class's step (subclasses with another formula: the staged loop)
 
+    def _native_operands(self, pgraph):
+        return None
+
     def _prepare_run(self, pgraph, p, bufs, lib):
         """Per-run operands of the step formula, and the isolated rows to watch (p: the normalised personalization slice)."""
         L.check(lib.pgh_dist_watch_isolated(pgraph.graph._h, p._h, bufs.v_y[0]._h))
@@ -374,9 +377,12 @@ class DistributedPageRank:
                 L.check(lib.pgh_set_stream(None))
 
     def _rank_native(self, pgraph, p_local, comm, lib):
+        extra = self._native_operands(pgraph)               # None: PageRank; (deg, lam, every_row): AbsorbingWalks
         cfg = L.DistCfg(alpha=float(self.alpha), tol=0.0 if self.tol is None else max(float(self.tol), self.epsilon), n_global=int(pgraph.n),
                         err_kind=self._KINDS[self.error_type], max_iters=int(self.max_iters), end_modulo=int(self.end_modulo),
-                        use_quotient=1 if self.use_quotient else 0, preserve_norm=1 if self.preserve_norm else 0, reserved=0)
+                        use_quotient=1 if self.use_quotient else 0, preserve_norm=1 if self.preserve_norm else 0,
+                        every_row=int(extra[2]) if extra else 0, deg_local=extra[0]._h if extra else None,
+                        lam_local=extra[1]._h if extra else None)
         res = L.DistResult()
         out = DeviceVector.empty(pgraph.n_local)
         t0 = time.perf_counter()
@@ -522,24 +528,31 @@ class DistributedAbsorbingWalks(DistributedPageRank):
     """AbsorbingWalks(alpha) (adhoc.py:125-174) on a PartitionedGraph: the loop, the exchange and the stopping rule of
     DistributedPageRank with the step ``(conv(ranks, M) * deg + p * lam) / (lam + deg)``, deg = degrees(M) and lam = absorption *
     (1 - alpha) / alpha on this rank's rows (pgh_dist_combine_absorb).  absorption: this rank's slice (new ids) or None = 1."""
-    _native_formula = False
-
     def __init__(self, alpha=1 - 1.e-6, absorption=None, **kwargs):
         super().__init__(alpha=alpha, **kwargs)
         self.absorption = absorption
 
-    def _prepare_run(self, pgraph, p, bufs, lib):
-        lo, m = pgraph.row_begin, pgraph.n_local
-        # degrees(M) = row sums of M: a rank holds its COLUMNS of M (its rows of M^T), so its row sums are partial -- summed over the ranks
+    def _operands(self, pgraph):
+        """(deg, lam, every_row) on this rank's rows.  degrees(M) = row sums of M: a rank holds its COLUMNS of M (its rows of M^T), so
+        its row sums are partial -- summed over the ranks (once per graph)."""
         import torch
-        deg_all = torch.from_numpy(np.asarray(pgraph.graph.degrees(), dtype=np.float64)).to(self._device)
-        self._dist.all_reduce(deg_all)
-        self._deg = DeviceVector.from_host(deg_all[lo:lo + m].cpu().numpy())
+        lo, m = pgraph.row_begin, pgraph.n_local
+        if getattr(self, "_deg_for", None) is not pgraph:
+            deg_all = torch.from_numpy(np.asarray(pgraph.graph.degrees(), dtype=np.float64)).to(self._device)
+            self._dist.all_reduce(deg_all)
+            self._deg, self._deg_for = DeviceVector.from_host(deg_all[lo:lo + m].cpu().numpy()), pgraph
         lam = (np.ones(m) if self.absorption is None else np.asarray(self.absorption, dtype=np.float64)) * ((1 - self.alpha) / self.alpha)
         self._lam = DeviceVector.from_host(lam)
         # an isolated row is p * lam / (lam + 0) = p: zero while p is zero there -- unless lam is zero too (0 / 0 in the reference):
         # such a run processes every row
-        watch = bufs.v_y[0] if float(lam.min(initial=1.0)) > 0 else DeviceVector.from_host(np.ones(m))
+        return self._deg, self._lam, not float(lam.min(initial=1.0)) > 0
+
+    def _native_operands(self, pgraph):
+        return self._operands(pgraph)
+
+    def _prepare_run(self, pgraph, p, bufs, lib):
+        _, _, every_row = self._operands(pgraph)
+        watch = DeviceVector.from_host(np.ones(pgraph.n_local)) if every_row else bufs.v_y[0]
         L.check(lib.pgh_dist_watch_isolated(pgraph.graph._h, p._h, watch._h))
 
     def _combine(self, lib, g, p, y, xg_local, state):
