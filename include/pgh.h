@@ -371,6 +371,13 @@ typedef struct {
 } pgh_dist_result;
 int pgh_comm_unique_id(uint8_t* id /* [PGH_COMM_ID_BYTES] */);
 int pgh_comm_create(const uint8_t* ids /* [num_ids * PGH_COMM_ID_BYTES] */, int32_t num_ids, int32_t world, int32_t rank, pgh_comm_t* out);
+/* The same communicator with the collectives performed by the HOST (MPI, gloo, ...) through two callbacks: the engine still drives the
+ * loop, its streams and its events.  A callback gets device pointers and the HIP stream the exchange is ordered on and must have completed
+ * the exchange, in stream order on that stream, when it returns; dtype: 0 f32, 1 f64, 2 i32; op: 0 sum, 1 max; all-gather: `count` f32
+ * elements per rank, received in rank order; all-reduce: in place.  Return non-zero to abort the run. */
+typedef int (*pgh_allgather_fn)(void* user, const void* send_dev, void* recv_dev, int64_t count, int32_t dtype, void* hip_stream);
+typedef int (*pgh_allreduce_fn)(void* user, void* buf_dev, int64_t count, int32_t dtype, int32_t op, void* hip_stream);
+int pgh_comm_create_external(int32_t world, int32_t rank, pgh_allgather_fn all_gather, pgh_allreduce_fn all_reduce, void* user, pgh_comm_t* out);
 int pgh_comm_destroy(pgh_comm_t comm);
 int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t comm, pgh_vec_t p_local, pgh_vec_t ranks_local, const pgh_dist_cfg* cfg,
                      pgh_dist_result* res);

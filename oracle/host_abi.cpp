@@ -1277,6 +1277,9 @@ int pgh_graph_set_gather_bases_split(pgh_graph_t, const int64_t*, const int64_t*
 }
 int pgh_comm_unique_id(uint8_t*) { return fail("pgh_comm_unique_id: not available in the host double"); }
 int pgh_comm_create(const uint8_t*, int32_t, int32_t, int32_t, pgh_comm_t*) { return fail("pgh_comm_create: not available in the host double"); }
+int pgh_comm_create_external(int32_t, int32_t, pgh_allgather_fn, pgh_allreduce_fn, void*, pgh_comm_t*) {
+    return fail("pgh_comm_create_external: not available in the host double");
+}
 int pgh_comm_destroy(pgh_comm_t) { return 0; }
 int pgh_dist_ppr_run(pgh_graph_t, pgh_comm_t, pgh_vec_t, pgh_vec_t, const pgh_dist_cfg*, pgh_dist_result*) {
     return fail("pgh_dist_ppr_run: not available in the host double");

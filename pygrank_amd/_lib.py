@@ -47,6 +47,8 @@ class DistResult(C.Structure):
 
 
 COMM_ID_BYTES = 128
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol include/pgh.h declares
 SIGNATURES = {
@@ -158,6 +160,7 @@ SIGNATURES = {
     "pgh_graph_set_gather_bases_split": (C.c_int, [c_graph, C.c_void_p, C.c_void_p]),
     "pgh_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pgh_comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pgh_comm_create_external": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "pgh_comm_destroy": (C.c_int, [C.c_void_p]),
     "pgh_dist_ppr_run": (C.c_int, [c_graph, C.c_void_p, c_vec, c_vec, C.POINTER(DistCfg), C.POINTER(DistResult)]),
     "pgh_graph_rmat_part": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int32,

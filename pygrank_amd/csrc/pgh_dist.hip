@@ -98,9 +98,34 @@ struct pgh_comm_s {
     double*     state = nullptr;         // [8] device (pgh_dist_* layout)
     double*     state_host = nullptr;    // [8] pinned
     int32_t*    agree = nullptr;         // [2] device words of the layout negotiation
+    // collectives supplied by the host instead of RCCL (pgh_comm_create_external): MPI, gloo, a test harness ...
+    pgh_allgather_fn ext_gather = nullptr;
+    pgh_allreduce_fn ext_reduce = nullptr;
+    void*            ext_user = nullptr;
 };
 
 namespace {
+
+// one all-gather / all-reduce of the run: RCCL on `st`, or the host's callback (which completes the exchange in stream order on `st`
+// before it returns: dtype 0 = f32, 1 = f64, 2 = i32; op 0 = sum, 1 = max)
+int comm_all_gather(pgh_comm_s* c, const void* send, void* recv, size_t count, ncclComm_t comm, hipStream_t st) {
+    if (c->ext_gather != nullptr) {
+        PGH_CHECK(c->ext_gather(c->ext_user, send, recv, (int64_t)count, 0, (void*)st) == 0, "pgh_dist_ppr_run: the host's all-gather callback failed");
+        return 0;
+    }
+    PGH_RCCL(g_rccl.AllGather(send, recv, count, ncclFloat32, comm, st));
+    return 0;
+}
+int comm_all_reduce(pgh_comm_s* c, void* buf, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm, hipStream_t st) {
+    if (c->ext_reduce != nullptr) {
+        const int32_t dtype = dt == ncclFloat32 ? 0 : (dt == ncclFloat64 ? 1 : 2);
+        PGH_CHECK(c->ext_reduce(c->ext_user, buf, (int64_t)count, dtype, op == ncclMax ? 1 : 0, (void*)st) == 0,
+                  "pgh_dist_ppr_run: the host's all-reduce callback failed");
+        return 0;
+    }
+    PGH_RCCL(g_rccl.AllReduce(buf, buf, count, dt, op, comm, st));
+    return 0;
+}
 
 void free_buffers(pgh_comm_s* c) {
     (void)hipFree(c->xg_full);
@@ -160,7 +185,7 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g) {
     // every rank must lay the gather vector out the same way: live = max over ranks, hot prefix = min over ranks
     int32_t h_agree[2] = {top, -hot_slots};
     PGH_HIP(hipMemcpyAsync(c->agree, h_agree, sizeof(h_agree), hipMemcpyHostToDevice, c->main));
-    PGH_RCCL(g_rccl.AllReduce(c->agree, c->agree, 2, ncclInt32, ncclMax, c->s, c->main));
+    PGH_TRY(comm_all_reduce(c, c->agree, 2, ncclInt32, ncclMax, c->s, c->main));
     PGH_HIP(hipMemcpyAsync(h_agree, c->agree, sizeof(h_agree), hipMemcpyDeviceToHost, c->main));
     PGH_HIP(hipEventRecord(c->ev_host, c->main));
     PGH_TRY(bounded_wait(c->ev_host, "the layout negotiation"));
@@ -212,8 +237,7 @@ int gather_part(pgh_comm_s* c, int64_t region, int lo, int hi, hipStream_t st) {
     if (hi <= lo) return 0;
     const int64_t len = hi - lo;
     for (int j = 0; j < c->bpr; ++j)
-        PGH_RCCL(g_rccl.AllGather(c->xg_local + (int64_t)j * c->blk + lo, c->xg_full + region + (int64_t)j * c->world * len, (size_t)len,
-                                  ncclFloat32, c->x, st));
+        PGH_TRY(comm_all_gather(c, c->xg_local + (int64_t)j * c->blk + lo, c->xg_full + region + (int64_t)j * c->world * len, (size_t)len, c->x, st));
     return 0;
 }
 
@@ -277,6 +301,39 @@ extern "C" int pgh_comm_create(const uint8_t* ids, int32_t num_ids, int32_t worl
     return 0;
 }
 
+// A communicator whose collectives the HOST performs (MPI, gloo, ...): the engine still drives the loop, its streams and its
+// events, and calls back for every exchange.  A callback receives device pointers and the HIP stream the exchange is ordered on; it
+// must have completed the exchange, in stream order on that stream, when it returns (the simplest form: synchronise the stream,
+// exchange through host memory, copy back).  Every rank issues the same callbacks in the same order.
+extern "C" int pgh_comm_create_external(int32_t world, int32_t rank, pgh_allgather_fn all_gather, pgh_allreduce_fn all_reduce, void* user,
+                                        pgh_comm_t* out) {
+    PGH_CHECK(out != nullptr && all_gather != nullptr && all_reduce != nullptr && world >= 1 && rank >= 0 && rank < world,
+              "pgh_comm_create_external: bad arguments");
+    PGH_TRY(ensure_init());
+    pgh_comm_s* c = new pgh_comm_s();
+    c->world = world;
+    c->rank = rank;
+    c->ext_gather = all_gather;
+    c->ext_reduce = all_reduce;
+    c->ext_user = user;
+    const bool single_stream = getenv("PGH_DIST_SINGLE_STREAM") != nullptr && atoi(getenv("PGH_DIST_SINGLE_STREAM")) != 0;
+    PGH_HIP(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
+    if (single_stream) {
+        c->xs = c->ss = c->main;
+    } else {
+        PGH_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+        PGH_HIP(hipStreamCreateWithFlags(&c->ss, hipStreamNonBlocking));
+    }
+    c->own_streams = true;
+    for (hipEvent_t* ev : {&c->ev_fin, &c->ev_hot, &c->ev_cold, &c->ev_err, &c->ev_host})
+        PGH_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    PGH_HIP(hipMalloc(&c->state, sizeof(double) * 8));
+    PGH_HIP(hipHostMalloc(&c->state_host, sizeof(double) * 8, hipHostMallocDefault));
+    PGH_HIP(hipMalloc(&c->agree, sizeof(int32_t) * 2));
+    *out = c;
+    return 0;
+}
+
 extern "C" int pgh_comm_destroy(pgh_comm_t c) {
     if (c == nullptr) return 0;
     if (rt().initialised) (void)hipDeviceSynchronize();
@@ -323,7 +380,7 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     double local_abs = 0.0;
     PGH_TRY(pgh_reduce(PGH_ABSSUM, p_local, &local_abs));
     PGH_HIP(hipMemcpyAsync(c->state, &local_abs, sizeof(double), hipMemcpyHostToDevice, c->main));
-    PGH_RCCL(g_rccl.AllReduce(c->state, c->state, 1, ncclFloat64, ncclSum, c->s, c->main));
+    PGH_TRY(comm_all_reduce(c, c->state, 1, ncclFloat64, ncclSum, c->s, c->main));
     PGH_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double), hipMemcpyDeviceToHost, c->main));
     PGH_HIP(hipEventRecord(c->ev_host, c->main));
     PGH_TRY(bounded_wait(c->ev_host, "the all-reduce of the personalization's norm"));
@@ -404,11 +461,11 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
         PGH_HIP(hipStreamWaitEvent(c->ss, c->ev_fin, 0));
         {
             StreamSwap on_scalars(c->ss);
-            PGH_RCCL(g_rccl.AllReduce(c->state + 2, c->state + 2, 1, ncclFloat64, ncclSum, c->s, c->ss));
+            if ((rc = comm_all_reduce(c, c->state + 2, 1, ncclFloat64, ncclSum, c->s, c->ss)) != 0) break;
             if ((rc = pgh_dist_close_sum(c->state, cfg->use_quotient)) != 0) break;
             if (check) {
                 if ((rc = pgh_dist_residual(local_kind, &v_y[cur], &v_y[1 - cur], c->state)) != 0) break;
-                PGH_RCCL(g_rccl.AllReduce(c->state + 1, c->state + 1, 1, ncclFloat64, err_op, c->s, c->ss));
+                if ((rc = comm_all_reduce(c, c->state + 1, 1, ncclFloat64, err_op, c->s, c->ss)) != 0) break;
                 if ((rc = pgh_dist_close_err(c->state, kind, cfg->tol, cfg->n_global)) != 0) break;
                 PGH_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->ss));
             }

@@ -240,12 +240,20 @@ def _native_comm(dist, device):
     """The engine's own RCCL communicator pair (csrc/pgh_dist.hip), created once per process: rank 0 draws the ids, the bytes
     travel through torch.distributed, every rank joins.  None when the run is not RCCL-on-GPU (gloo / CPU tests, the host
     double) or PGH_DIST_NATIVE=0 asks for the Python-driven loop."""
-    if device.type != "cuda" or dist.get_backend() != "nccl" or os.environ.get("PGH_DIST_NATIVE", "1") == "0":
-        return None
-    if not L.runtime_name().startswith("hip:"):
+    mode = os.environ.get("PGH_DIST_NATIVE", "1")
+    if device.type != "cuda" or mode == "0" or not L.runtime_name().startswith("hip:"):
         return None
     world, rank = dist.get_world_size(), dist.get_rank()
     key = (world, rank)
+    if dist.get_backend() != "nccl":
+        # the engine's loop with the collectives done by the HOST through torch.distributed (pgh_comm_create_external): opt-in
+        # (PGH_DIST_NATIVE=external) -- every exchange then goes through host memory; what it is for: running the engine-driven
+        # choreography with several ranks where RCCL cannot (ranks sharing one GPU in tests; MPI-style hosts do the same from C)
+        if mode != "external":
+            return None
+        if key not in _NATIVE_COMMS:
+            _NATIVE_COMMS[key] = _external_comm(dist, world, rank)
+        return _NATIVE_COMMS[key]
     if key not in _NATIVE_COMMS:
         import torch
         lib = L.lib()
@@ -274,6 +282,53 @@ def _native_comm(dist, device):
             handle = None
         _NATIVE_COMMS[key] = handle
     return _NATIVE_COMMS[key]
+
+
+_EXTERNAL_KEEPALIVE = []
+
+
+def _external_comm(dist, world, rank):
+    """pgh_comm_create_external with callbacks that move every exchange through host memory and torch.distributed (gloo)."""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    dtypes = {0: (torch.float32, 4), 1: (torch.float64, 8), 2: (torch.int32, 4)}
+
+    def gather(user, send, recv, count, dtype, stream):
+        try:
+            tdt, size = dtypes[int(dtype)]
+            if hip.hipStreamSynchronize(stream) != 0:
+                return 1
+            mine = torch.empty(int(count), dtype=tdt)
+            if hip.hipMemcpy(mine.data_ptr(), send, int(count) * size, 2) != 0:          # device -> host
+                return 1
+            everyone = torch.empty(int(count) * world, dtype=tdt)
+            dist.all_gather_into_tensor(everyone, mine)
+            return 0 if hip.hipMemcpy(recv, everyone.data_ptr(), int(count) * size * world, 1) == 0 else 1
+        except Exception as exc:                                                          # never unwind through the C frames
+            sys.stderr.write(f"[pygrank_amd.distributed] all-gather callback: {exc}\n")
+            return 1
+
+    def reduce(user, buf, count, dtype, op, stream):
+        try:
+            tdt, size = dtypes[int(dtype)]
+            if hip.hipStreamSynchronize(stream) != 0:
+                return 1
+            host = torch.empty(int(count), dtype=tdt)
+            if hip.hipMemcpy(host.data_ptr(), buf, int(count) * size, 2) != 0:
+                return 1
+            dist.all_reduce(host, op=dist.ReduceOp.MAX if int(op) == 1 else dist.ReduceOp.SUM)
+            return 0 if hip.hipMemcpy(buf, host.data_ptr(), int(count) * size, 1) == 0 else 1
+        except Exception as exc:
+            sys.stderr.write(f"[pygrank_amd.distributed] all-reduce callback: {exc}\n")
+            return 1
+
+    cb_gather, cb_reduce = L.ALLGATHER_FN(gather), L.ALLREDUCE_FN(reduce)
+    _EXTERNAL_KEEPALIVE.extend([cb_gather, cb_reduce, hip])
+    handle = C.c_void_p()
+    L.check(L.lib().pgh_comm_create_external(world, rank, C.cast(cb_gather, C.c_void_p), C.cast(cb_reduce, C.c_void_p), None, C.byref(handle)))
+    return handle
 
 
 def release_native_comms():
@@ -391,7 +446,8 @@ class DistributedPageRank:
         self.iteration, self.spmv, self.converged = int(res.iterations), int(res.spmv_count), bool(res.converged)
         self.last_error, self.loop_ms = float(res.last_error), float(res.loop_ms)
         self.exchange = dict(exchange_bytes_per_iteration_per_gpu=int(res.exchange_bytes), gather_vector_slots=int(res.gather_slots),
-                             column_blocks=int(res.column_blocks), split_regions=bool(res.split_regions), driver="engine (RCCL)")
+                             column_blocks=int(res.column_blocks), split_regions=bool(res.split_regions),
+                             driver="engine (RCCL)" if self._dist.get_backend() == "nccl" else "engine (host collectives)")
         if res.iterations == 0:
             return p_local
         if not self.converged and self.error_type != "iters" and self.iteration >= self.max_iters:

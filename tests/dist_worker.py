@@ -47,6 +47,8 @@ def main():
         out = ranker.rank(graph, DeviceVector.from_host(p_local))
         results[name + "_ranks"] = np.asarray(out)
         results[name + "_iters"] = ranker.iteration
+    results["driver"] = str(ranker.exchange.get("driver"))
+    results["split_regions"] = int(bool(ranker.exchange.get("split_regions")))
     from pygrank_amd.distributed import DistributedAbsorbingWalks
     absorbing = DistributedAbsorbingWalks(alpha=0.85, error_type="l1", tol=1e-6, max_iters=500)
     out = absorbing.rank(graph, DeviceVector.from_host(p_local))
