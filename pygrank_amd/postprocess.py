@@ -33,10 +33,10 @@ class Postprocessor(NodeRanking):
         return self._apply(inner, remove_used_args(self.ranker.rank, kwargs))      # keywords the inner ranker did not take
 
     def __lshift__(self, ranker):
-        if not isinstance(ranker, NodeRanking):
-            raise Exception("pygrank can only shift rankers into postprocessors")
-        self.ranker = ranker
-        return ranker
+        if isinstance(ranker, NodeRanking):
+            self.ranker = ranker
+            return ranker
+        raise Exception("only a ranker can be shifted into a postprocessor, got " + type(ranker).__name__)
 
     # self-description: the wrapped algorithm's parts, then this step (postprocess.py: references() of every postprocessor
     # extends the inner ranker's list)
@@ -63,16 +63,24 @@ class Tautology(Postprocessor):
         return ranks
 
     def rank(self, graph=None, personalization=None, *args, **kwargs):
-        if self.ranker is None:
-            return to_signal(graph, personalization)
-        return self.ranker.rank(graph, personalization, *args, **kwargs)
+        inner = self.ranker
+        return to_signal(graph, personalization) if inner is None else inner.rank(graph, personalization, *args, **kwargs)
 
 
 def _is_ranker(obj):
     return callable(getattr(obj, "rank", None))
 
 
-class Normalize(Postprocessor):
+class _NoOptions(Postprocessor):
+    """Postprocessors whose transformation takes no keyword of its own: whatever is still there when the call arrives was
+    meant for nobody (the reference's ``ensure_used_args`` at the top of every ``_transform``); the work is in ``_values``."""
+
+    def _transform(self, ranks, **leftover):
+        ensure_used_args(leftover)
+        return self._values(ranks)
+
+
+class Normalize(_NoOptions):
     """Rescales ranks by their maximum ("max", default), sum ("sum"), Euclidean norm ("L2"), or onto [0, 1] ("range").
     ``Normalize("sum", ranker)`` and ``Normalize(ranker, "sum")`` are the same thing (postprocess.py:124-131)."""
 
@@ -84,18 +92,13 @@ class Normalize(Postprocessor):
         super().__init__(ranker if ranker is not None else Tautology())
         self.method = method
 
-    def _transform(self, ranks, **kwargs):
-        ensure_used_args(kwargs)
-        if self.method not in self._METHODS:
-            raise Exception("Can only normalize towards max, sum, range, or L2")
+    def _values(self, ranks):
+        how = self.method
+        if how not in self._METHODS:
+            raise Exception("Normalize: method must be one of " + ", ".join(self._METHODS) + ", not " + repr(how))
         x = ranks.np
-        low = float(backend.min(x)) if self.method == "range" else 0.0
-        if self.method == "sum":
-            high = float(backend.sum(x))
-        elif self.method == "L2":
-            high = float(backend.dot(x, x)) ** 0.5
-        else:
-            high = float(backend.max(x))
+        low = float(backend.min(x)) if how == "range" else 0.0
+        high = float({"sum": backend.sum, "L2": lambda v: float(backend.dot(v, v)) ** 0.5}.get(how, backend.max)(x))
         if high == low:
             return ranks                                           # constant (or zero) signals stay as they are
         return (x - low) / (high - low)
@@ -113,18 +116,17 @@ def _swap(first, second):
     return (first if first is not None else Tautology()), second
 
 
-class Ordinals(Postprocessor):
+class Ordinals(_NoOptions):
     """1 for the highest rank, 2 for the second highest, ... (postprocess.py:163-195); ties keep node order."""
 
     def __init__(self, ranker=None):
-        super().__init__(Tautology() if ranker is None else ranker)
+        super().__init__(_swap(ranker, None)[0])
 
-    def _transform(self, ranks, **kwargs):
-        ensure_used_args(kwargs)
+    def _values(self, ranks):
         return _device(ranks).ordinals()
 
 
-class Transformer(Postprocessor):
+class Transformer(_NoOptions):
     """Element-by-element expression, backend.exp by default (postprocess.py:198-243)."""
 
     def __init__(self, ranker=None, expr=None):
@@ -132,12 +134,11 @@ class Transformer(Postprocessor):
         super().__init__(ranker)
         self.expr = backend.exp if expr is None else expr
 
-    def _transform(self, ranks, **kwargs):
-        ensure_used_args(kwargs)
+    def _values(self, ranks):
         return self.expr(ranks.np)
 
 
-class Top(Postprocessor):
+class Top(_NoOptions):
     """1 for the top-scored nodes, 0 for the rest; ``fraction_of_training`` >= 1 counts nodes, < 1 is a share of the graph
     (postprocess.py:246-290: every node that ties with the last kept one is kept too)."""
 
@@ -146,8 +147,7 @@ class Top(Postprocessor):
         super().__init__(ranker)
         self.fraction_of_training = 1 if fraction is None else fraction
 
-    def _transform(self, ranks, **kwargs):
-        ensure_used_args(kwargs)
+    def _values(self, ranks):
         x = _device(ranks)
         keep = self.fraction_of_training
         keep = int(keep * len(x)) if keep < 1 else int(keep)
@@ -155,7 +155,7 @@ class Top(Postprocessor):
         return (x >= threshold) * 1.0
 
 
-class Threshold(Postprocessor):
+class Threshold(_NoOptions):
     """1 above a threshold, 0 elsewhere (postprocess.py:293-350); "gap" = the score after the largest relative drop."""
 
     def __init__(self, ranker=None, threshold=0, inclusive=False):
@@ -164,21 +164,19 @@ class Threshold(Postprocessor):
         self.threshold = 0 if threshold is None else threshold
         self.inclusive = inclusive
 
-    def _transform(self, ranks, **kwargs):
-        ensure_used_args(kwargs)
+    def _values(self, ranks):
         x = _device(ranks)
-        threshold = self.threshold
-        if threshold == "gap":                       # one device sort + two reductions (pgh_vec_gap_threshold)
-            threshold = x.gap_threshold()
-        return ((x >= threshold) if self.inclusive else (x > threshold)) * 1.0
+        # "gap": one device sort + two reductions (pgh_vec_gap_threshold)
+        cut = x.gap_threshold() if self.threshold == "gap" else self.threshold
+        return ((x >= cut) if self.inclusive else (x > cut)) * 1.0
 
 
-class _UniformBaseline(Postprocessor):
+class _UniformBaseline(_NoOptions):
     """Sweep family: personalized ranks set against the same ranker's non-personalized outcome, computed once per graph."""
 
     def __init__(self, ranker=None, uniform_ranker=None):
         super().__init__(ranker)
-        self.uniform_ranker = ranker if uniform_ranker is None else uniform_ranker
+        self.uniform_ranker = uniform_ranker if uniform_ranker is not None else ranker
         self._baseline = {}
 
     def _uniforms(self, ranks):
@@ -188,22 +186,19 @@ class _UniformBaseline(Postprocessor):
         return self._baseline[key][1]
 
     def __lshift__(self, ranker):
-        super().__lshift__(ranker)
-        self.uniform_ranker = ranker
-        return ranker
+        self.uniform_ranker = super().__lshift__(ranker)
+        return self.uniform_ranker
 
 
 class Sweep(_UniformBaseline):
     """ranks / (1e-12 + uniform ranks) (postprocess.py:353-404)."""
 
-    def _transform(self, ranks, **kwargs):
-        ensure_used_args(kwargs)
+    def _values(self, ranks):
         return _device(ranks) / (self._uniforms(ranks) + 1.E-12)
 
 
 class LinearSweep(_UniformBaseline):
     """ranks - uniform ranks (postprocess.py:407-450)."""
 
-    def _transform(self, ranks, **kwargs):
-        ensure_used_args(kwargs)
+    def _values(self, ranks):
         return _device(ranks) - self._uniforms(ranks)

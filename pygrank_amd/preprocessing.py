@@ -111,9 +111,9 @@ def normalize_adjacency(M, normalization, reduction=None):
         return -M + sp.eye(M.shape[0]).tocsr()
     if callable(normalization):                             # preprocessing.py:139-140
         return normalization(M)
-    if normalization != "none":
-        raise Exception("Supported normalizations: none, col, symmetric, both, laplacian, auto")
-    return M
+    if normalization == "none":
+        return M
+    raise Exception(f"normalization {normalization!r}: expected none, col, symmetric, both, laplacian, auto or a callable")
 
 
 def graph_to_scipy(G, weight="weight"):
@@ -141,11 +141,12 @@ def to_sparse_matrix(G, normalization="auto", weight="weight", renormalize=False
         ret._pygrank_preprocessed[name] = ret
         ret._pygrank_node2id = G._pygrank_node2id
         return ret
-    normalization = normalization.lower() if isinstance(normalization, str) else normalization
-    if normalization == "auto":                             # preprocessing.py:101-102
-        normalization = "col" if G.is_directed() else "symmetric"
+    if isinstance(normalization, str):
+        normalization = normalization.lower()
+        if normalization == "auto":                         # preprocessing.py:101-102: directed graphs get "col"
+            normalization = ("symmetric", "col")[bool(G.is_directed())]
     M = sp.csr_array(graph_to_scipy(G, weight), dtype=np.float64)
-    renormalize = float(renormalize)
+    renormalize = float(renormalize)                        # False / True are 0 / 1 self-loops
     on_device = (name == "hip" and normalization in ("col", "symmetric", "both", "none") and renormalize == 0
                  and reduction is None and transform_adjacency is _identity and not cors
                  and (normalization in ("col", "none") or M.shape[0] == M.shape[1]))
@@ -154,12 +155,13 @@ def to_sparse_matrix(G, normalization="auto", weight="weight", renormalize=False
         from pygrank_amd.device import DeviceGraph
         ret = Adjacency(DeviceGraph.from_adjacency(M, normalization))
     else:
-        if renormalize != 0:                                # preprocessing.py:107-108
+        if renormalize:                                     # preprocessing.py:107-108
             M = M + sp.eye(M.shape[0]).tocsr() * renormalize
         M = normalize_adjacency(M, normalization, reduction)
         M = M if isinstance(M, sp.csr_array) else sp.csr_array(M)
-        M = transform_adjacency(M)                          # preprocessing.py:143
-        ret = Adjacency(backend.scipy_sparse_to_backend(M)) # preprocessing.py:144-145: upload to HBM
+        # preprocessing.py:143-145: the caller's last word on the matrix, then the upload to HBM
+        M = transform_adjacency(M)
+        ret = Adjacency(backend.scipy_sparse_to_backend(M))
     if cors:                                                # preprocessing.py:146-148
         ret._pygrank_preprocessed = {name: ret, "numpy": Adjacency(M)}
     else:
@@ -167,7 +169,7 @@ def to_sparse_matrix(G, normalization="auto", weight="weight", renormalize=False
     if isinstance(G, AdjacencyWrapper):
         ret._pygrank_node2id = _IdentityMap(len(G))         # {v: i} over range(n) without n dict entries
     else:
-        ret._pygrank_node2id = {v: i for i, v in enumerate(G)}   # preprocessing.py:151
+        ret._pygrank_node2id = {node: at for at, node in enumerate(G)}   # preprocessing.py:151: iteration order
     return ret
 
 
@@ -215,14 +217,13 @@ class MethodHasher:
 def preprocessor(normalization="auto", assume_immutability=False, weight="weight", renormalize=False,
                  reduction=None, transform_adjacency=_identity, cors=False):
     """preprocessing.py:233-287."""
-    if assume_immutability:
-        ret = MethodHasher(preprocessor(assume_immutability=False, normalization=normalization, weight=weight,
-                                        renormalize=renormalize, reduction=reduction, cors=cors,
-                                        transform_adjacency=transform_adjacency))
-        ret.__name__ = "preprocess"
-        return ret
+    options = dict(normalization=normalization, weight=weight, renormalize=renormalize, reduction=reduction, cors=cors,
+                   transform_adjacency=transform_adjacency)
 
     def preprocess(G):
-        return to_sparse_matrix(G, normalization=normalization, weight=weight, renormalize=renormalize,
-                                reduction=reduction, cors=cors, transform_adjacency=transform_adjacency)
-    return preprocess
+        return to_sparse_matrix(G, **options)
+    if not assume_immutability:
+        return preprocess
+    remembered = MethodHasher(preprocess)                   # one outcome per graph identity and backend
+    remembered.__name__ = preprocess.__name__
+    return remembered

@@ -63,10 +63,9 @@ class GraphSignal(MutableMapping):
         self._host = None
 
     def filter(self, exclude=None):                       # signals.py:68-75
-        if exclude is not None:
-            exclude = to_signal(self, exclude)
-            return backend.filter_out(self._np, exclude._np)
-        return self._np
+        if exclude is None:
+            return self._np
+        return backend.filter_out(self._np, to_signal(self, exclude)._np)
 
     def __rshift__(self, other):
         return other(self)
@@ -80,13 +79,15 @@ class GraphSignal(MutableMapping):
     def __getitem__(self, key):
         return float(self._mirror()[self.node2id[key]])
 
+    def _store(self, key, value):
+        self._np[self.node2id[key]] = value
+        self._host = None                                 # the host mirror is stale now
+
     def __setitem__(self, key, value):
-        self._np[self.node2id[key]] = float(value)
-        self._host = None
+        self._store(key, float(value))
 
     def __delitem__(self, key):
-        self._np[self.node2id[key]] = 0
-        self._host = None
+        self._store(key, 0.0)                             # a signal has no holes: deleting a node zeroes it
 
     def __iter__(self):
         return iter(self.node2id)
@@ -99,11 +100,11 @@ class GraphSignal(MutableMapping):
 
     # ---- arithmetic (signals.py:114-178)
     def _compliant(self, other):
-        if isinstance(other, GraphSignal):
-            if id(other.graph) != id(self.graph):
-                raise Exception("Can not operate between graph signals of different graphs")
-            return other.np
-        return other
+        if not isinstance(other, GraphSignal):
+            return other
+        if other.graph is not self.graph:
+            raise Exception("the operands are graph signals of two different graphs")
+        return other.np
 
     def _new(self, value):
         return GraphSignal(self.graph, value, self.node2id)
@@ -142,12 +143,11 @@ class GraphSignal(MutableMapping):
         return self
 
     def normalized(self, normalize=True, copy=True):      # signals.py:180-193
-        if copy:
-            return GraphSignal(self.graph, backend.copy(self._np), self.node2id).normalized(normalize, copy=False)
+        target = self._new(backend.copy(self._np)) if copy else self
         if normalize:
-            self._np = backend.self_normalize(self._np)
-            self._host = None
-        return self
+            target._np = backend.self_normalize(target._np)
+            target._host = None
+        return target
 
 
 class _IdentityMap:
