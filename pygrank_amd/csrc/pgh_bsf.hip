@@ -1003,6 +1003,166 @@ int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopS
     return bsf_launch_combine<MODE>(g, ep, state, num_partials);
 }
 
+// ---- small graphs: everything of a recursive step after the block partial sums as ONE launch of ONE workgroup ------------------
+// A graph of a few thousand rows is launch-bound: partial sums -> fix-ups -> epilogue -> residual are four dependent launches of
+// 3-6 us each for well under a microsecond of work (profiles/r02/small_window_sweep.log).  Up to kSmallTailRows rows (one column
+// block, no cold image) the last three run here: cross-tile fix-ups, the MODE epilogue of every row (y, next gather vector, sum(y)),
+// the residual |y * inv - x * scale| (supervised.py:93-138) and the close (ConvergenceManager, convergence.py:77-101; the same
+// close_outcome / close_commit as every other loop) -- one workgroup, __syncthreads between the stages (the wavefronts of a
+// workgroup share the CU's L1, so what one stage wrote the next one reads).  Two launches per iteration instead of four.
+constexpr int kSmallTailThreads = 1024;
+constexpr int kSmallTailRows = 12288;
+
+template <int KIND>      // 0 sum, 1 max; every thread returns the result; fixed order (wavefronts 0 .. 15): deterministic
+__device__ __forceinline__ double small_block_reduce(double v, double* s16) {
+    v = KIND == 0 ? wave_reduce_sum(v) : wave_reduce_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = s16[0];
+#pragma unroll
+    for (int w = 1; w < kSmallTailThreads / 64; ++w) r = KIND == 0 ? r + s16[w] : fmax(r, s16[w]);
+    return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kSmallTailThreads) void k_small_tail(FixView fix, RowSums rs, int n_out, const float* __restrict__ dst_scale,
+                                                                  EpiParams ep, const float* __restrict__ x_prev, PendingClose pc) {
+    __shared__ double s16[kSmallTailThreads / 64];
+    LoopState* state = pc.state;
+    // What bounds this kernel is its chain of dependent loads (~0.7 us each: everything was written by other CUs a moment ago), so
+    // every load that does not depend on the fix-ups is issued BEFORE them: the state, the first round's map words and operands,
+    // and the fix-up's own two index loads side by side.
+    const int done = state->done;
+    const double scale = state->scale;
+    // a thread owns rows t, t + 1024, ...: U of them in flight per round (map word -> segment sum is a dependent pair of loads),
+    // their y and x kept in registers for the residual, which needs 1 / sum(y) first
+    constexpr int R = kSmallTailRows / kSmallTailThreads, U = 4;
+    static_assert(R % U == 0, "rounds of U rows");
+    float yk[R], xk[R];
+    RowLookup<1> q[U];
+    EpiOps ops[U];
+    float ds[U];
+    auto load_round = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = min((int)threadIdx.x + (c + u) * kSmallTailThreads, n_out - 1);      // clamped: loads stay unconditional
+            row_lookup_meta<1>(rs, row, q[u]);
+            ops[u] = epi_load<MODE>(ep, row);
+            ds[u] = dst_scale != nullptr ? dst_scale[row] : 1.f;
+            xk[c + u] = pc.check ? x_prev[row] : 0.f;
+        }
+    };
+    load_round(0);
+    {
+        // cross-tile fix-ups (bsf_fixup_tiles' arithmetic and order; here the two index loads of a tile do not wait for each other)
+        const int lane = threadIdx.x & 63;
+        for (int t0 = 0; t0 < fix.num_tiles; t0 += kSmallTailThreads) {
+            const int t = t0 + (int)threadIdx.x;
+            const int tc = min(t, fix.num_tiles - 1);
+            const int seg = fix.fix_seg[tc];
+            const int dst = (t < fix.num_tiles && !done) ? seg : -1;          // a finished loop: the partial sums are left alone
+            const int chain = fix.tile[tc].w;
+            const double head = fix.head_partial[tc];
+            const int first = dst >= 0 ? chain : 0;
+            const int len = dst >= 0 ? t - first : 0;
+            const bool is_long = len >= 32;
+            if (dst >= 0 && !is_long) {
+                double total = 0.0;
+                for (int k = first; k < t; ++k) total += fix.tail_carry[k];
+                total += head;
+                fix.psum[dst] = (float)total;
+            }
+            unsigned long long todo = __ballot(is_long);
+            while (todo != 0ULL) {
+                const int src = __builtin_ctzll(todo);
+                todo &= todo - 1ULL;
+                const int c_first = __shfl(first, src, 64), c_t = __shfl(t, src, 64);
+                double part_sum = 0.0;
+                for (int k = c_first + lane; k < c_t; k += 64) part_sum += fix.tail_carry[k];
+                part_sum = wave_reduce_sum(part_sum);
+                const double total = __shfl(part_sum, 0, 64) + __shfl(head, src, 64);
+                if (lane == src) fix.psum[dst] = (float)total;
+            }
+        }
+    }
+    if (done) return;                                    // workgroup-uniform
+    __syncthreads();
+    const float a_eff = (float)(ep.a * scale);
+    double sum_y = 0.0, delta = 0.0;
+#pragma unroll
+    for (int c = 0; c < R; c += U) {
+        if (c * kSmallTailThreads >= n_out) {              // workgroup-uniform: no row left for this round
+#pragma unroll
+            for (int u = 0; u < U; ++u) yk[c + u] = xk[c + u] = 0.f;
+            continue;
+        }
+        if (c > 0) load_round(c);
+        float v[U][1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) row_lookup_vals<1>(rs, min((int)threadIdx.x + (c + u) * kSmallTailThreads, n_out - 1), q[u], v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = (int)threadIdx.x + (c + u) * kSmallTailThreads;
+            yk[c + u] = 0.f;
+            if (row < n_out) {
+                double sum = (double)v[u][0];
+                if (dst_scale != nullptr) sum *= (double)ds[u];
+                yk[c + u] = epi_apply<MODE>(ep, ops[u], a_eff, row, (float)sum, sum_y, delta);
+            } else {
+                xk[c + u] = 0.f;
+            }
+        }
+    }
+    const double S = small_block_reduce<0>(sum_y, s16);
+    double err = 0.0;
+    if (pc.check) {
+        const int linf = pc.err_kind == PGH_ERR_LINF;
+        const double inv = pc.use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;      // abstract_filters.py:133-134
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {                                               // rows past the end hold 0 - 0
+            const double d = fabs((double)yk[c] * inv - (double)xk[c] * scale);
+            acc = linf ? fmax(acc, d) : acc + d;
+        }
+        err = linf ? small_block_reduce<1>(acc, s16) : small_block_reduce<0>(acc, s16);
+    }
+    if (threadIdx.x == 0) close_commit(pc, close_outcome(pc, S, err, 0.0, 0.0, 0.0));
+}
+
+bool bsf_small_tail_usable(const pgh_graph_s* g) {
+    const char* sw = getenv("PGH_SMALL_TAIL");             // read per call: the parity tests run both sequences in one process
+    const bool off = sw != nullptr && atoi(sw) == 0;
+    const BsfFormat& f = g->bsf;
+    return !off && f.enabled && !f.pb.enabled && f.num_blocks == 1 && f.meta != nullptr && f.n_out <= kSmallTailRows &&
+           f.n_out == f.n_src_pad;
+}
+
+// block partial sums + the tail above: one recursive step of a small graph, closed (pc) in the same launch
+template <int MODE>
+int bsf_launch_small(pgh_graph_s* g, const EpiParams& ep, const float* xg, const float* x_prev, const LoopState* state,
+                     const PendingClose& pc) {
+    PGH_TRY(bsf_launch_partial(g, xg, state, 1));
+    BsfFormat& f = g->bsf;
+    FixView fix;
+    fix.fix_seg = f.fix_seg;
+    fix.tile = f.tile;
+    fix.tail_carry = f.tail_carry;
+    fix.head_partial = f.head_partial;
+    fix.psum = f.psum;
+    fix.num_tiles = f.num_tiles;
+    PendingClose rec = pc;
+    rec.res_mode = 0;
+    {
+        ProfScope prof(PGH_K_COMBINE);
+        k_small_tail<MODE><<<1, kSmallTailThreads, 0, rt().stream>>>(fix, row_sums_of(f), f.n_out, f.dst_scale, ep, x_prev, rec);
+    }
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+template int bsf_launch_small<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const float*, const float*, const LoopState*, const PendingClose&);
+template int bsf_launch_small<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const float*, const float*, const LoopState*, const PendingClose&);
+
 template int bsf_launch_combine<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const LoopState*, int*);
 template int bsf_launch_combine<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const LoopState*, int*);
 template int bsf_launch_combine<EPI_POLY>(pgh_graph_s*, const EpiParams&, const LoopState*, int*);

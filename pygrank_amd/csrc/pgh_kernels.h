@@ -440,7 +440,7 @@ __device__ __forceinline__ void close_commit(const PendingClose& pc, const Close
     if (o.verdict == 2) {                // paused: the step stays open, the host re-evaluates it
         state->done = 2;
         if (o.miss > pc.aux->worst_miss) pc.aux->worst_miss = o.miss;
-        if (pc.progress != nullptr) __hip_atomic_store(pc.progress + 1, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (pc.progress != nullptr) __hip_atomic_store(pc.progress + 1, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     state->sum = o.S;
@@ -460,9 +460,11 @@ __device__ __forceinline__ void close_commit(const PendingClose& pc, const Close
             state->converged = 1;
         }
     }
+    // (relaxed stores: the host only PACES itself by these words and reads every result after a stream synchronisation; a
+    // system-scope release here is a write-back of the XCD's whole L2 in the middle of the launch that carries the close)
     if (pc.progress != nullptr) {        // host-visible progress word (pinned, mapped): lets the host run ahead without syncs
         __hip_atomic_store(pc.progress + 1, o.verdict == 1 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(pc.progress, steps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(pc.progress, steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -568,6 +570,11 @@ int bsf_ensure_degrees(pgh_graph_s* g);       // BsfFormat::deg_int
 
 template <int MODE>
 int bsf_launch_combine(pgh_graph_s* g, const EpiParams& ep, const LoopState* state, int* num_partials);
+// small graphs (pgh_bsf.hip, k_small_tail): block partial sums + ONE one-workgroup launch for fix-ups, epilogue, residual and close
+bool bsf_small_tail_usable(const pgh_graph_s* g);
+template <int MODE>
+int bsf_launch_small(pgh_graph_s* g, const EpiParams& ep, const float* xg, const float* x_prev, const LoopState* state,
+                     const PendingClose& pc);
 template <int MODE>
 int bsf_launch(pgh_graph_s* g, const EpiParams& ep, const float* xg, const LoopState* state, int* num_partials,
                hipEvent_t before_combine = nullptr);

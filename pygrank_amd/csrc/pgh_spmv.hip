@@ -430,7 +430,7 @@ __global__ __launch_bounds__(WG) void k_step_close(LoopState* __restrict__ state
         }
         if (progress != nullptr) {      // host-visible progress word (pinned, mapped): lets the host run ahead without syncs
             __hip_atomic_store(progress + 1, state->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(progress, state->steps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(progress, state->steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(WG) void k_step_close_rec(PendingClose pc) {
 __global__ void k_state_resume(LoopState* state, int* progress) {
     if (state->done == 2) {
         state->done = 0;
-        if (progress != nullptr) __hip_atomic_store(progress + 1, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (progress != nullptr) __hip_atomic_store(progress + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1421,6 +1421,9 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     // against the predicted quotient (ResParams, pgh_kernels.h) -- no residual launch from the second step on.
     // PGH_FUSED_RES=0 keeps the separate kernel.
     static const bool fuse_env = getenv("PGH_FUSED_RES") == nullptr || atoi(getenv("PGH_FUSED_RES")) != 0;
+    // small graphs (a few thousand rows, no cold image): fix-ups, epilogue, residual and close are ONE launch of one workgroup
+    // (k_small_tail, pgh_bsf.hip) -- two launches per iteration instead of four.  PGH_SMALL_TAIL=0 keeps the general sequence.
+    const bool small_tail = (MODE == EPI_AXPBY || MODE == EPI_ABSORB) && sp.blocked && !overlap && bsf_small_tail_usable(g);
     bool fused = fuse_env && MODE == EPI_AXPBY && sp.blocked && g->bsf.pb.enabled && !overlap && pre_scale == nullptr &&
                  (cfg->err_kind == PGH_ERR_L1 || cfg->err_kind == PGH_ERR_MABS) && ep.v != nullptr;
     if (fused) PGH_TRY(bsf_ensure_degrees(g));
@@ -1461,6 +1464,10 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         EpiParams epk = ep;
         epk.y = yout;
         int count = 0;
+        if (small_tail) {                        // partial sums + one one-workgroup launch that also closes the step
+            PGH_TRY((bsf_launch_small<MODE>(g, epk, use_xg ? g->bsf.xg : xin, xin, g_state, make_close(k))));
+            return 0;
+        }
         ResParams rp{};
         if (fused) {
             rp.x_prev = xin;

@@ -349,6 +349,51 @@ def check_loop_is_deterministic(pg):
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])   # atomic-free, fixed order
 
 
+def check_small_graph_tail_launch(pg):
+    """Graphs of up to 12 K rows close a recursive step with ONE one-workgroup launch (k_small_tail: fix-ups, epilogue,
+    residual, ConvergenceManager) instead of three; PGH_SMALL_TAIL=0 keeps the general sequence.  Both against the oracle
+    (1e-6 of the largest rank, equal iteration counts) and against each other, for every stopping rule, with and without the
+    quotient, for AbsorbingWalks, on row counts around the 1024-thread rounds of the kernel."""
+    import os
+    saved = os.environ.get("PGH_SMALL_TAIL")
+    try:
+        for scale, ef, seed in ((6, 4, 0), (10, 8, 1), (12, 8, 2), (13, 6, 3)):
+            A = rmat_np.rmat_csr(scale, ef, seed=seed)
+            if scale == 13:
+                A = sp.csr_array(A[:8191, :8191])                 # not a multiple of anything
+            n = A.shape[0]
+            p = np.zeros(n)
+            p[rmat_np.seed_nodes(A, 5, seed=seed)] = np.arange(1, 6)
+            M = sp.csr_array(orc.normalize(A, "col", True))
+            graph = pg.AdjacencyWrapper(A, directed=True)
+            cases = [("pagerank", dict(error_type="l1", tol=1e-6, max_iters=500)), ("pagerank", dict(error_type="mabs", tol=1e-8, max_iters=500)),
+                     ("pagerank", dict(error_type="linf", tol=1e-7, max_iters=500)), ("pagerank", dict(error_type="iters", max_iters=17)),
+                     ("pagerank", dict(error_type="l1", tol=1e-6, max_iters=500, use_quotient=False)),
+                     ("absorbing", dict(error_type="l1", tol=1e-6, max_iters=500))]
+            for name, kw in cases:
+                if name == "pagerank":
+                    want, want_iters = orc.pagerank(M, p, alpha=0.85, eps=EPS32, **kw)
+                else:
+                    want, want_iters = orc.absorbing_walks(M, p, alpha=0.85, eps=EPS32, **kw)
+                outcomes = []
+                measure = {"l1": pg.L1, "mabs": pg.Mabs, "linf": pg.MaxDifference, "iters": "iters"}[kw["error_type"]]
+                for switch in ("1", "0"):
+                    os.environ["PGH_SMALL_TAIL"] = switch
+                    pre = pg.preprocessor(assume_immutability=True, normalization="col")
+                    opts = dict(kw, error_type=measure, preprocessor=pre)
+                    algo = pg.PageRank(0.85, **opts) if name == "pagerank" else pg.AbsorbingWalks(0.85, **opts)
+                    got = _np(algo.rank(graph, p.copy()).np)
+                    assert algo.convergence.iteration == want_iters, (scale, name, kw, switch, algo.convergence.iteration, want_iters)
+                    assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), (scale, name, kw, switch)
+                    outcomes.append(got)
+                assert np.max(np.abs(outcomes[0] - outcomes[1])) <= 4 * EPS32 * np.max(np.abs(want)), (scale, name, kw)
+    finally:
+        if saved is None:
+            os.environ.pop("PGH_SMALL_TAIL", None)
+        else:
+            os.environ["PGH_SMALL_TAIL"] = saved
+
+
 def check_error_reporting(pg):
     import pytest
     from pygrank_amd import _lib as L
