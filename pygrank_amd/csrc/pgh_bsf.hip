@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(kSmallTailThreads) void k_small_tail(FixView fix, R
             row_lookup_meta<1>(rs, row, q[u]);
             ops[u] = epi_load<MODE>(ep, row);
             ds[u] = dst_scale != nullptr ? dst_scale[row] : 1.f;
-            xk[c + u] = pc.check ? x_prev[row] : 0.f;
+            xk[c + u] = (MODE != EPI_POLY && pc.check) ? x_prev[row] : 0.f;
         }
     };
     load_round(0);
@@ -1116,7 +1116,10 @@ __global__ __launch_bounds__(kSmallTailThreads) void k_small_tail(FixView fix, R
     }
     const double S = small_block_reduce<0>(sum_y, s16);
     double err = 0.0;
-    if (pc.check) {
+    if (MODE == EPI_POLY) {
+        // closed-form filters stop on the change of the accumulated result (abstract_filters.py:232-246), which the epilogue summed
+        err = pc.err_kind == PGH_ERR_LINF ? small_block_reduce<1>(delta, s16) : small_block_reduce<0>(delta, s16);
+    } else if (pc.check) {
         const int linf = pc.err_kind == PGH_ERR_LINF;
         const double inv = pc.use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;      // abstract_filters.py:133-134
         double acc = 0.0;
@@ -1162,6 +1165,7 @@ int bsf_launch_small(pgh_graph_s* g, const EpiParams& ep, const float* xg, const
 }
 template int bsf_launch_small<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const float*, const float*, const LoopState*, const PendingClose&);
 template int bsf_launch_small<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const float*, const float*, const LoopState*, const PendingClose&);
+template int bsf_launch_small<EPI_POLY>(pgh_graph_s*, const EpiParams&, const float*, const float*, const LoopState*, const PendingClose&);
 
 template int bsf_launch_combine<EPI_AXPBY>(pgh_graph_s*, const EpiParams&, const LoopState*, int*);
 template int bsf_launch_combine<EPI_ABSORB>(pgh_graph_s*, const EpiParams&, const LoopState*, int*);

@@ -1932,6 +1932,7 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
     const bool poll = g_progress_dev != nullptr;
     const int batch = poll ? 1 : batch_for(g);
     const int window = window_for(g);
+    const bool small_tail = sp.blocked && bsf_small_tail_usable(g);
     if (poll) progress_reset();
     // host-side mirror of the reference loop for iteration 2 (uses err of step 1), then device batches
     it = 2;
@@ -1971,9 +1972,21 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
                     ep.xg_live = g->bsf.xg_live;
                 }
                 int count = 0;
-                PGH_TRY((launch_step<EPI_POLY>(g, ep, scaled_gather ? g->bsf.xg : term, g_state, &count)));
                 const int chk_it = k + 1;         // the comparison of result_k with result_{k-1}
                 const int check = (cfg->err_kind != PGH_ERR_ITERS) && (chk_it < max_iters) && (chk_it % cfg->end_modulo == 0);
+                if (small_tail) {                 // small graphs: fix-ups, epilogue and close in one one-workgroup launch (k_small_tail)
+                    PendingClose pc{};
+                    pc.state = g_state;
+                    pc.progress = g_progress_dev;
+                    pc.tol = cfg->tol;
+                    pc.n = (long long)n;
+                    pc.check = check;
+                    pc.err_kind = cfg->err_kind;
+                    PGH_TRY((bsf_launch_small<EPI_POLY>(g, ep, scaled_gather ? g->bsf.xg : term, nullptr, g_state, pc)));
+                    term = tout;
+                    continue;
+                }
+                PGH_TRY((launch_step<EPI_POLY>(g, ep, scaled_gather ? g->bsf.xg : term, g_state, &count)));
                 {
                     ProfScope prof(PGH_K_FINAL);
                     k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, r.d_partials + kMaxPartials,

@@ -353,7 +353,7 @@ def check_small_graph_tail_launch(pg):
     """Graphs of up to 12 K rows close a recursive step with ONE one-workgroup launch (k_small_tail: fix-ups, epilogue,
     residual, ConvergenceManager) instead of three; PGH_SMALL_TAIL=0 keeps the general sequence.  Both against the oracle
     (1e-6 of the largest rank, equal iteration counts) and against each other, for every stopping rule, with and without the
-    quotient, for AbsorbingWalks, on row counts around the 1024-thread rounds of the kernel."""
+    quotient, for AbsorbingWalks and the taylor form of HeatKernel, on row counts around the 1024-thread rounds of the kernel."""
     import os
     saved = os.environ.get("PGH_SMALL_TAIL")
     try:
@@ -369,10 +369,14 @@ def check_small_graph_tail_launch(pg):
             cases = [("pagerank", dict(error_type="l1", tol=1e-6, max_iters=500)), ("pagerank", dict(error_type="mabs", tol=1e-8, max_iters=500)),
                      ("pagerank", dict(error_type="linf", tol=1e-7, max_iters=500)), ("pagerank", dict(error_type="iters", max_iters=17)),
                      ("pagerank", dict(error_type="l1", tol=1e-6, max_iters=500, use_quotient=False)),
-                     ("absorbing", dict(error_type="l1", tol=1e-6, max_iters=500))]
+                     ("absorbing", dict(error_type="l1", tol=1e-6, max_iters=500)),
+                     ("heat", dict(error_type="l1", tol=1e-6, max_iters=100)), ("heat", dict(error_type="linf", tol=1e-5, max_iters=100)),
+                     ("heat", dict(error_type="iters", max_iters=12))]       # (stopping rules well above the f32 resolution of the result)
             for name, kw in cases:
                 if name == "pagerank":
                     want, want_iters = orc.pagerank(M, p, alpha=0.85, eps=EPS32, **kw)
+                elif name == "heat":
+                    want, want_iters = orc.heat_kernel(M, p, t=3, eps=EPS32, **kw)
                 else:
                     want, want_iters = orc.absorbing_walks(M, p, alpha=0.85, eps=EPS32, **kw)
                 outcomes = []
@@ -381,7 +385,8 @@ def check_small_graph_tail_launch(pg):
                     os.environ["PGH_SMALL_TAIL"] = switch
                     pre = pg.preprocessor(assume_immutability=True, normalization="col")
                     opts = dict(kw, error_type=measure, preprocessor=pre)
-                    algo = pg.PageRank(0.85, **opts) if name == "pagerank" else pg.AbsorbingWalks(0.85, **opts)
+                    algo = (pg.PageRank(0.85, **opts) if name == "pagerank" else pg.HeatKernel(3, **opts) if name == "heat"
+                            else pg.AbsorbingWalks(0.85, **opts))
                     got = _np(algo.rank(graph, p.copy()).np)
                     assert algo.convergence.iteration == want_iters, (scale, name, kw, switch, algo.convergence.iteration, want_iters)
                     assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), (scale, name, kw, switch)
