@@ -1137,7 +1137,7 @@ bool bsf_small_tail_usable(const pgh_graph_s* g) {
     const char* sw = getenv("PGH_SMALL_TAIL");             // read per call: the parity tests run both sequences in one process
     const bool off = sw != nullptr && atoi(sw) == 0;
     const BsfFormat& f = g->bsf;
-    return !off && f.enabled && !f.pb.enabled && f.num_blocks == 1 && f.meta != nullptr && f.n_out <= kSmallTailRows &&
+    return !off && f.enabled && !f.pb.enabled && f.num_blocks == 1 && f.meta != nullptr && f.n_out >= 1 && f.n_out <= kSmallTailRows &&
            f.n_out == f.n_src_pad;
 }
 
