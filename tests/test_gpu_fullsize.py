@@ -4,6 +4,8 @@ size"): RMAT scale 23, edge factor 16 (8.4 M nodes, 131 M edges), the production
 
   configs[1]  PPR alpha = 0.85, L1 <= 1e-6     vs the oracle's scipy loop on the engine's own matrix (about 5 s of host time)
   configs[3]  HeatKernel t = 5, 31 iterations  taylor and chebyshev vs the oracle (about 15 s each), linearity of the filter
+  (also)      AbsorbingWalks (L1 rule), PageRank with the max-difference rule and no quotient at scale 23; PageRank and
+              SymmetricAbsorbingRandomWalks on the symmetrised scale-22 graph ("symmetric" normalisation) vs the oracle
   configs[2]  64 personalizations at once      sampled columns equal single-seed runs, mass conservation, per-column stops
   configs[4]  the 1 B-edge graph (scale 27, ef 8) through the row-partitioned path with ONE rank over RCCL vs the single-GPU
               engine on the same graph, + the 8-way slice layout at scale 22 vs the oracle (8 ranks over xGMI: the driver's run)
@@ -115,6 +117,51 @@ def test_cfg4_heat_kernel_scale23_vs_oracle(big, coefficient_type):
     hq = np.asarray(hk.rank(big["adj"], q.copy()).np, dtype=np.float64)
     hpq = np.asarray(hk.rank(big["adj"], p + 2.0 * q).np, dtype=np.float64)
     assert _rel(hpq, got + 2.0 * hq) <= (2e-6 if coefficient_type == "taylor" else 1e-6)
+
+
+def test_absorbing_walks_and_other_stopping_rules_scale23_vs_oracle(big):
+    """The other recursive filter and the other residuals of SURVEY.md 8a (a9, a12) at the full size: AbsorbingWalks with the L1
+    rule, PageRank with the max-difference rule and without the quotient -- equal iteration counts, 1e-6 of the largest rank."""
+    from oracle import ref_loops as orc
+    pg = big["pg"]
+    p = big["seeds"](3)
+    aw = pg.AbsorbingWalks(0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+    got = np.asarray(aw.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, want_iters = orc.absorbing_walks(big["M"], p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
+    assert aw.convergence.iteration == want_iters, (aw.convergence.iteration, want_iters)
+    assert _rel(got, want) <= 1e-6
+    pr = pg.PageRank(0.85, error_type=pg.MaxDifference, tol=1e-6, max_iters=1000, use_quotient=False)
+    got = np.asarray(pr.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, want_iters = orc.pagerank(big["M"], p, alpha=0.85, error_type="linf", tol=1e-6, max_iters=1000, use_quotient=False)
+    assert pr.convergence.iteration == want_iters, (pr.convergence.iteration, want_iters)
+    assert _rel(got, want) <= 1e-6
+
+
+def test_symmetrised_graph_scale22_vs_oracle(gpu_engine):
+    """A + A^T with the "symmetric" normalisation (both scale vectors in play: the gather vector carries one, the epilogue the other)
+    on the production layout; PageRank and SymmetricAbsorbingRandomWalks for a fixed number of iterations against the oracle on the
+    engine's own matrix, and the symmetry of that matrix."""
+    import scipy.sparse as sp
+    from oracle import ref_loops as orc
+    from pygrank_amd.synthetic import rmat_graph
+    pg = gpu_engine
+    adj = rmat_graph(22, 16, seed=0, symmetrize=True, a=0.57, b=0.19, c=0.19)
+    g = adj.array
+    assert "propagation-blocking image" in g.format(), g.format()
+    MT = g.download_transposed()
+    M = sp.csr_array(MT.T.astype(np.float64))
+    assert abs(M - M.T).max() <= 1e-12                   # D^-1/2 (A + A^T) D^-1/2 in f32: symmetric bit for bit
+    rng = np.random.default_rng(5)
+    p = np.zeros(g.shape[0])
+    p[np.sort(rng.choice(np.flatnonzero(np.asarray(pg.degrees(g)) > 0), 100, replace=False))] = 1.0
+    pr = pg.PageRank(0.85, error_type="iters", max_iters=21)
+    got = np.asarray(pr.rank(adj, p.copy()).np, dtype=np.float64)
+    want, iters = orc.pagerank(M, p, alpha=0.85, error_type="iters", max_iters=21)
+    assert pr.convergence.iteration == iters == 21 and _rel(got, want) <= 1e-6
+    sarw = pg.SymmetricAbsorbingRandomWalks(error_type="iters", max_iters=11)
+    got = np.asarray(sarw.rank(adj, p.copy()).np, dtype=np.float64)
+    want, iters = orc.symmetric_absorbing_walks(M, p, error_type="iters", max_iters=11)
+    assert sarw.convergence.iteration == iters == 11 and _rel(got, want) <= 1e-6
 
 
 def test_cfg3_batch64_scale23(big):
