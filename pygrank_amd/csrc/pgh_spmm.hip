@@ -38,6 +38,12 @@ struct BatchState {
     int    b;
 };
 
+#ifndef PGH_MM_RES_U
+#define PGH_MM_RES_U 8
+#endif
+#ifndef PGH_MM_COMB_U
+#define PGH_MM_COMB_U 2
+#endif
 struct MMView {
     const uint32_t* colf;
     const float*    val;
@@ -308,7 +314,13 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * rows_per_wave + lane / lpr;
     const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
-    constexpr int U = 2;
+    constexpr int U = PGH_MM_COMB_U;
+    int fl_next[U];                                        // row flags one trip ahead (see k_mm_residual)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t r = first + u * stride;
+        fl_next[u] = (live && r < n) ? (c.p_row_nz != nullptr ? (int)c.p_row_nz[r] : 3) : 0;
+    }
     for (int64_t r0 = first; r0 < n; r0 += stride * U) {
         f32x4 sum[U], pv[U], yo[U];
         float d[U], sc[U];
@@ -317,7 +329,9 @@ __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, i
         for (int u = 0; u < U; ++u) {
             const int64_t r = r0 + u * stride;
             const bool in_range = live && r < n;
-            fl[u] = in_range ? (c.p_row_nz != nullptr ? (int)c.p_row_nz[r] : 3) : 0;
+            fl[u] = fl_next[u];
+            const int64_t rn = r + stride * U;
+            fl_next[u] = (live && rn < n) ? (c.p_row_nz != nullptr ? (int)c.p_row_nz[rn] : 3) : 0;
             const bool ok = in_range && fl[u] != 0;
             const int64_t at = (ok ? r : 0) * ld + c4;
             sum[u] = (ok && (fl[u] & 2)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.sums + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -420,8 +434,16 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
     }
     const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * rows_per_wave + lane / lpr;
     const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
-    constexpr int U = 4;
+    constexpr int U = PGH_MM_RES_U;
     if (any) {
+        // the row flags of a trip are fetched one trip ahead (a flag -> row load chain per trip left the loads of half-dead trips
+        // -- 55 % of the rows of the bench graph are skipped -- with too little in flight: 3.0 TB/s)
+        uint8_t fl_next[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = first + u * stride;
+            fl_next[u] = (r < n && row_flags != nullptr) ? row_flags[r] : (uint8_t)1;
+        }
         for (int64_t r0 = first; r0 < n; r0 += stride * U) {
             f32x4 a[U], o[U];
             bool use[U];
@@ -429,7 +451,9 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
             for (int u = 0; u < U; ++u) {
                 const int64_t r = r0 + u * stride;
                 // rows that are zero in every iterate (row flags 0: no entries, no personalization) add |0 - 0|: not read
-                use[u] = r < n && (row_flags == nullptr || row_flags[r] != 0);
+                use[u] = r < n && fl_next[u] != 0;
+                const int64_t rn = r + stride * U;
+                fl_next[u] = (rn < n && row_flags != nullptr) ? row_flags[rn] : (uint8_t)1;
                 const int64_t at = (use[u] ? r : 0) * ld + c4;
                 a[u] = use[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
                 o[u] = use[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
