@@ -335,6 +335,14 @@ __device__ __forceinline__ void bsf_fixup_tiles(const FixView& f, int first_tile
             for (double v : en) mean += v / n_;                                                                         \
             fprintf(stderr, "[pgh times] %s: %d workgroups, start max %.1f us; end min %.1f p10 %.1f median %.1f mean %.1f p90 %.1f max %.1f us\n", \
                     LABEL, n_, st[n_ - 1], en[0], en[n_ / 10], en[n_ / 2], mean, en[n_ * 9 / 10], en[n_ - 1]);          \
+            if (getenv("PGH_DUMP_TIMES_RAW") != nullptr) {                                                              \
+                FILE* raw_ = fopen(getenv("PGH_DUMP_TIMES_RAW"), "a");                                                  \
+                if (raw_ != nullptr) {                                                                                  \
+                    for (int i = 0; i < n_; ++i)                                                                        \
+                        fprintf(raw_, "%s,%d,%.2f,%.2f\n", LABEL, i, (h[2 * i] - t0) * 0.01, (h[2 * i + 1] - t0) * 0.01); \
+                    fclose(raw_);                                                                                       \
+                }                                                                                                       \
+            }                                                                                                           \
         }                                                                                                               \
     }
 #else

@@ -921,7 +921,10 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     std::vector<int4> tasks;
     std::vector<int> ranges(1, 0);
     {
-        const int64_t fill_cost = getenv("PGH_PB_FILLCOST") != nullptr ? atoll(getenv("PGH_PB_FILLCOST")) : 24576;   // a 128 KB fill ~ this many entries of streaming
+        const int64_t fill_cost = getenv("PGH_PB_FILLCOST") != nullptr ? atoll(getenv("PGH_PB_FILLCOST")) : 65536;   // what a change of chunk costs a share, in entries of streaming:
+        // measured per share at scale 23 (PGH_PROBE_TIMES build, profiles/r03/finish_schedule_r03.log): 3.5 us + 0.22 us per 1000 entries +
+        // 9.5 us per piece (the 128 KB fill in four dependent rounds, the drained and refilled stream pipeline) = 43 K entries; the
+        // sweep 4 K .. 384 K has its minimum at 64-96 K (phase A 56-57 -> 52-53 us; round 2's 24 K counted the bytes only)
         // every share that starts inside a chunk pays one more fill, so the total grows with the number of shares: the
         // smallest per-share budget that needs no more shares than there are CUs is searched for (a fixed 1.16 x mean left 9
         // of 256 CUs without a share at scale 23)
@@ -960,6 +963,18 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     }
     const int shares = (int)ranges.size() - 1;
     p.num_tasks = shares;
+    if (getenv("PGH_DEBUG_SHARES") != nullptr) {           // diagnostic: what every share of phase A holds (to set against its time)
+        FILE* out = fopen(getenv("PGH_DEBUG_SHARES"), "w");
+        if (out != nullptr) {
+            fprintf(out, "share,pieces,entries,first_chunk,last_chunk\n");
+            for (int b = 0; b < shares; ++b) {
+                int64_t e = 0;
+                for (int t = ranges[b]; t < ranges[b + 1]; ++t) e += tasks[t].z - tasks[t].y;
+                fprintf(out, "%d,%d,%lld,%d,%d\n", b, ranges[b + 1] - ranges[b], (long long)e, tasks[ranges[b]].x, tasks[ranges[b + 1] - 1].x);
+            }
+            fclose(out);
+        }
+    }
     p.avg_piece = tasks.empty() ? 0 : padded / (int64_t)tasks.size();
     if (getenv("PGH_DEBUG") != nullptr && atoi(getenv("PGH_DEBUG")) != 0) {
         int64_t mn = padded, mx = 0;
@@ -989,7 +1004,10 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     // consecutive), the row stretches between them cut into epilogue-only items, hub items first (they are the longest).
     {
         std::vector<int4> hub_a, hub_b, reg_a, reg_b, iso_a, iso_b;
-        const int stretch = p.bin_rows > 1024 ? 1024 : p.bin_rows;   // rows per epilogue-only item: small, they level the schedule
+        // rows per epilogue-only item (an item costs ~6 us + 4.5 us per 1000 rows: 512 / 1024 / 2048 / 4096 rows measured 96.9 / 89.5 /
+        // 87.6 / 91.8 us per finish launch at scale 23, 192.8 / 188.3 / 185.9 / 184.7 at scale 24)
+        int stretch = p.bin_rows > 2048 ? 2048 : p.bin_rows;
+        if (getenv("PGH_FIN_STRETCH") != nullptr) stretch = std::max(64, std::min(p.bin_rows, atoi(getenv("PGH_FIN_STRETCH"))));
         // rows [lo, hi) have no cold entries in the image.  The part that lies in the isolated tail of its block (BsfFormat::
         // iso_begin: rows without any entry that nobody references) goes into items of its own, marked -2: k_pb_finish passes
         // over them unless the run's operands are non-zero there (BsfFormat::iso_flag).
@@ -1084,16 +1102,79 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             if (tail < 0) tail = 0;
             const int head = p.num_items - tail;
             std::vector<double> cost(p.num_items);
-            for (int i = 0; i < p.num_items; ++i)            // PGH_DEBUG only: 10.6 us + 0.34 ns per entry + 2.4 ns per row
-                cost[i] = 0.34 * 8.0 * (double)all_a[i].w + 2.4 * (double)all_b[i].y + 10600.0;
             std::vector<int> flat, begin(1, 0);
             flat.reserve(p.num_items);
-            for (int w = 0; w < groups; ++w) {
-                for (int i = w; i < head; i += groups) flat.push_back(i);
-                begin.push_back((int)flat.size());
+            // The deal counts WORK, not list positions: an isolated stretch that is passed over costs ~3 us, every other item 10-35 us
+            // (profiles/r03/finish_schedule_r03.log), so the stretches are dealt on their own: round-robin over the items that do work,
+            // in row order (at any moment the workgroups sweep the same stretch of the image), then the isolated stretches from the
+            // other end.  Dealing them as equals (PGH_FIN_DEAL=0, rounds 2-3) left workgroups with 22 .. 95 us of static work around a
+            // mean of 53.  PGH_FIN_DEAL=2: longest first by the measured cost model with the cheapest items as the tail -- 3.5 us better
+            // at scale 23, 40 us WORSE at scale 24 and 3 us worse at scale 22 (the sweep over the image is lost): not the default.
+            static const int deal = getenv("PGH_FIN_DEAL") != nullptr ? atoi(getenv("PGH_FIN_DEAL")) : 1;
+            // measured cost of an item (us; PGH_PROBE_TIMES build at scale 23, profiles/r03/finish_schedule_r03.log): 6.1 + 0.30 per 1000
+            // entries + 4.5 per 1000 rows + 3.9 when it has entries at all; an isolated stretch that is passed over 3.3
+            for (int i = 0; i < p.num_items; ++i) {
+                const double entries = 8.0 * (double)all_a[i].w, rows = (double)all_b[i].y;
+                cost[i] = all_b[i].z == -2 ? 3300.0 : 6100.0 + 0.30 * entries + 4.5 * rows + (entries > 0 ? 3900.0 : 0.0);
             }
+            std::vector<int> tail_items;
+            if (deal == 2) {
+                // longest first: the TAIL (handed out on the device) is made of the cheapest items that do work -- the end of the launch
+                // is levelled in steps of ~10 us instead of ~30 -- and the head is dealt to the least loaded workgroup in descending
+                // order of cost, every workgroup walking its share from the longest item to the shortest
+                const int first_plain = (int)(hub_a.size() + iso_a.size());
+                std::vector<int> plain(plain_items);
+                for (int i = 0; i < plain_items; ++i) plain[i] = first_plain + i;
+                std::stable_sort(plain.begin(), plain.end(), [&](int x, int y) { return cost[x] < cost[y]; });
+                std::vector<char> in_tail(p.num_items, 0);
+                for (int i = 0; i < tail; ++i) {
+                    tail_items.push_back(plain[i]);
+                    in_tail[plain[i]] = 1;
+                }
+                std::sort(tail_items.begin(), tail_items.end(), [&](int x, int y) { return cost[x] > cost[y] || (cost[x] == cost[y] && x < y); });
+                std::vector<int> order;
+                for (int i = 0; i < p.num_items; ++i)
+                    if (!in_tail[i]) order.push_back(i);
+                std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
+                std::vector<std::vector<int>> mine_of(groups);
+                std::vector<std::pair<double, int>> heap;           // (load, workgroup): min-heap by load, ties by index
+                for (int w = 0; w < groups; ++w) heap.emplace_back(0.0, w);
+                auto later = [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x > y; };
+                std::make_heap(heap.begin(), heap.end(), later);
+                for (int i : order) {
+                    std::pop_heap(heap.begin(), heap.end(), later);
+                    heap.back().first += cost[i];
+                    mine_of[heap.back().second].push_back(i);
+                    std::push_heap(heap.begin(), heap.end(), later);
+                }
+                for (int w = 0; w < groups; ++w) {
+                    flat.insert(flat.end(), mine_of[w].begin(), mine_of[w].end());
+                    begin.push_back((int)flat.size());
+                }
+            } else if (deal == 1) {
+                std::vector<std::vector<int>> mine_of(groups);
+                int k = 0;
+                for (int i = 0; i < head; ++i)
+                    if (all_b[i].z != -2) mine_of[k++ % groups].push_back(i);
+                int back = 0;
+                for (int i = 0; i < head; ++i)
+                    if (all_b[i].z == -2) mine_of[groups - 1 - (back++ % groups)].push_back(i);
+                for (int w = 0; w < groups; ++w) {
+                    flat.insert(flat.end(), mine_of[w].begin(), mine_of[w].end());
+                    begin.push_back((int)flat.size());
+                }
+            } else {
+                for (int w = 0; w < groups; ++w) {
+                    for (int i = w; i < head; i += groups) flat.push_back(i);
+                    begin.push_back((int)flat.size());
+                }
+            }
+            if (deal >= 2) {
+                p.tail_begin = (int)flat.size();               // sched[tail_begin ..): the tail, whatever the item numbers
+                flat.insert(flat.end(), tail_items.begin(), tail_items.end());
+            } else
             for (int i = head; i < p.num_items; ++i) flat.push_back(i);
-            p.tail_begin = head;
+            if (deal < 2) p.tail_begin = head;
             p.tail_count = tail;
             if (tail > 0) {
                 PGH_HIP(hipMalloc(&p.work_counter, sizeof(uint32_t)));

@@ -134,7 +134,7 @@ __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t
                 // rounds of 8 loads per thread (the whole chunk in one round of 32 was measured: 7 us SLOWER per launch; 16-byte
                 // loads from the first aligned element on -- one round of 8 per chunk -- no different: 77.6 vs 78.0 us, the fills
                 // of one share hide behind the streams of the others)
-                constexpr int FU = 8;
+                constexpr int FU = 8;                       // (16: no different, 57 us either way)
                 for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kPbThreads * FU) {
                     float v[FU];
 #pragma unroll
