@@ -1109,7 +1109,9 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             // in row order (at any moment the workgroups sweep the same stretch of the image), then the isolated stretches from the
             // other end.  Dealing them as equals (PGH_FIN_DEAL=0, rounds 2-3) left workgroups with 22 .. 95 us of static work around a
             // mean of 53.  PGH_FIN_DEAL=2: longest first by the measured cost model with the cheapest items as the tail -- 3.5 us better
-            // at scale 23, 40 us WORSE at scale 24 and 3 us worse at scale 22 (the sweep over the image is lost): not the default.
+            // at scale 23, 40 us WORSE at scale 24 and 3 us worse at scale 22 (the sweep over the image is lost): not the default.  Longest
+            // first with the row-order tail, longest first inside windows of 1024 items, the cheapest items as the tail of deal 1: all
+            // measured, all slower than deal 1 on at least two of the three scales (same log).
             static const int deal = getenv("PGH_FIN_DEAL") != nullptr ? atoi(getenv("PGH_FIN_DEAL")) : 1;
             // measured cost of an item (us; PGH_PROBE_TIMES build at scale 23, profiles/r03/finish_schedule_r03.log): 6.1 + 0.30 per 1000
             // entries + 4.5 per 1000 rows + 3.9 when it has entries at all; an isolated stretch that is passed over 3.3
@@ -1169,12 +1171,12 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
                     begin.push_back((int)flat.size());
                 }
             }
-            if (deal >= 2) {
+            if (deal == 2) {
                 p.tail_begin = (int)flat.size();               // sched[tail_begin ..): the tail, whatever the item numbers
                 flat.insert(flat.end(), tail_items.begin(), tail_items.end());
             } else
             for (int i = head; i < p.num_items; ++i) flat.push_back(i);
-            if (deal < 2) p.tail_begin = head;
+            if (deal != 2) p.tail_begin = head;
             p.tail_count = tail;
             if (tail > 0) {
                 PGH_HIP(hipMalloc(&p.work_counter, sizeof(uint32_t)));
