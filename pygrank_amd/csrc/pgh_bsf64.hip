@@ -95,10 +95,12 @@ __device__ __forceinline__ double wave_segmented_sum64(int keep, double val) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+PGH_STAMP_DECL(g_times_partial64)
 template <bool HAS_VAL>
 __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const double* __restrict__ xg, const LoopState* __restrict__ state) {
     __shared__ __attribute__((aligned(16))) double s_lds[kLdsDoubles];
     if (state != nullptr && state->done) return;
+    PGH_STAMP_BEGIN(g_times_partial64)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-affine block assignment: workgroups whose dispatch slots share blockIdx % 8 share an XCD (speed only)
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const doub
             if (t >= t_end) break;
         }
     }
+    PGH_STAMP_END(g_times_partial64)
 }
 
 // where the fix-up of tile t goes (index into psum, -1 = nothing to fix): the segment open at the tile start closes here
@@ -510,6 +513,7 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
         if (f.val) k_bsf64_partial<true><<<main_grid, kThreads, 0, r.stream>>>(v, xg, state);
         else k_bsf64_partial<false><<<main_grid, kThreads, 0, r.stream>>>(v, xg, state);
     }
+    PGH_STAMP_DUMP(g_times_partial64, main_grid, "k_bsf64_partial")
     {
         ProfScope prof(PGH_K_FIXUP);
         int fix_grid = (f.num_tiles + WG - 1) / WG;

@@ -20,7 +20,10 @@ def main():
     ap.add_argument("--scale", type=int, default=23)
     ap.add_argument("--runs", type=int, default=3)
     ap.add_argument("--normalization", default="col")
+    ap.add_argument("--lib", default=None, help="a diagnostic build of the engine (tools/build_variants.sh) instead of the product library")
     args = ap.parse_args()
+    if args.lib:
+        L.LIB_PATH = os.path.abspath(args.lib)
     pg.load_backend("hip")
     lib = L.lib()
     adj = rmat_graph(args.scale, 16, seed=0, normalization=args.normalization)
