@@ -921,7 +921,10 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     std::vector<int4> tasks;
     std::vector<int> ranges(1, 0);
     {
-        const int64_t fill_cost = getenv("PGH_PB_FILLCOST") != nullptr ? atoll(getenv("PGH_PB_FILLCOST")) : 65536;   // what a change of chunk costs a share, in entries of streaming:
+        // (images with more than 4 chunks per CU -- the 8-way slices of configs[4]: 1260 chunks -- keep round 2's 24 K: every share
+        // crosses ~5 chunks there whatever the price, and the higher one only unbalances the entries: phase A 172 us against 188)
+        const int64_t fill_cost = getenv("PGH_PB_FILLCOST") != nullptr ? atoll(getenv("PGH_PB_FILLCOST"))
+                                                                        : (p.num_chunks > 4 * r.num_cus ? 24576 : 65536);   // what a change of chunk costs a share, in entries of streaming:
         // measured per share at scale 23 (PGH_PROBE_TIMES build, profiles/r03/finish_schedule_r03.log): 3.5 us + 0.22 us per 1000 entries +
         // 9.5 us per piece (the 128 KB fill in four dependent rounds, the drained and refilled stream pipeline) = 43 K entries; the
         // sweep 4 K .. 384 K has its minimum at 64-96 K (phase A 56-57 -> 52-53 us; round 2's 24 K counted the bytes only)
