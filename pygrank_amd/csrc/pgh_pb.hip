@@ -921,13 +921,11 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     std::vector<int4> tasks;
     std::vector<int> ranges(1, 0);
     {
-        // (images with more than 4 chunks per CU -- the 8-way slices of configs[4]: 1260 chunks -- keep round 2's 24 K: every share
-        // crosses ~5 chunks there whatever the price, and the higher one only unbalances the entries: phase A 172 us against 188)
+        // (thin chunks -- fewer than 160 K entries each: the 4- and 8-way slices of the N-GPU bench, 127 K and 61 K -- keep 24 K: every
+        // share crosses several chunks there whatever the price, and the higher one only unbalances the entries: phase A 106 against
+        // 113 us and 153 against 166-189)
         const int64_t fill_cost = getenv("PGH_PB_FILLCOST") != nullptr ? atoll(getenv("PGH_PB_FILLCOST"))
-                                                                        : (p.num_chunks > 4 * r.num_cus ? 24576 : 65536);   // what a change of chunk costs a share, in entries of streaming:
-        // measured per share at scale 23 (PGH_PROBE_TIMES build, profiles/r03/finish_schedule_r03.log): 3.5 us + 0.22 us per 1000 entries +
-        // 9.5 us per piece (the 128 KB fill in four dependent rounds, the drained and refilled stream pipeline) = 43 K entries; the
-        // sweep 4 K .. 384 K has its minimum at 64-96 K (phase A 56-57 -> 52-53 us; round 2's 24 K counted the bytes only)
+                                                                        : (padded / std::max(p.num_chunks, 1) < 163840 ? 24576 : 65536);
         // every share that starts inside a chunk pays one more fill, so the total grows with the number of shares: the
         // smallest per-share budget that needs no more shares than there are CUs is searched for (a fixed 1.16 x mean left 9
         // of 256 CUs without a share at scale 23)

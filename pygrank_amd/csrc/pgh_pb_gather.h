@@ -5,6 +5,9 @@
 
 // diagnostic builds only (tools/build_variants.sh): 1 no chunk fill, 2 fills only, 4 no stores (phase A); 8 no loads,
 // 16 no atomics (phase B), 32 no epilogue
+#ifndef PGH_FILL_GLDS
+#define PGH_FILL_GLDS 1
+#endif
 #ifndef PGH_PROBE_PB
 #define PGH_PROBE_PB 0
 #endif
@@ -134,7 +137,17 @@ __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t
                 // rounds of 8 loads per thread (the whole chunk in one round of 32 was measured: 7 us SLOWER per launch; 16-byte
                 // loads from the first aligned element on -- one round of 8 per chunk -- no different: 77.6 vs 78.0 us, the fills
                 // of one share hide behind the streams of the others)
-                constexpr int FU = 8;                       // (16: no different, 57 us either way)
+#if PGH_FILL_GLDS
+                // LDS-direct loads (global_load_lds_dword: no destination registers, so the whole slice is in flight at once -- one
+                // memory round trip per fill instead of four rounds of 8 loads per thread; the destination of a wavefront's
+                // instruction is its uniform base + 4 bytes per lane, which is exactly a contiguous copy)
+                for (int64_t w0 = lo + (threadIdx.x & ~63); w0 < hi; w0 += kPbThreads) {
+                    const int64_t id = w0 + (threadIdx.x & 63);
+                    if (id < hi)
+                        __builtin_amdgcn_global_load_lds(src + id, (__attribute__((address_space(3))) void*)(s_x + (w0 - first_id)), 4, 0, 0);
+                }
+#else
+                constexpr int FU = 8;
                 for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kPbThreads * FU) {
                     float v[FU];
 #pragma unroll
@@ -148,6 +161,7 @@ __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t
                         if (id < hi) s_x[id - first_id] = v[u];
                     }
                 }
+#endif
             }
             __syncthreads();
             loaded = task.x;
