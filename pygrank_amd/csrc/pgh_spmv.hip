@@ -1933,6 +1933,9 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
     const int batch = poll ? 1 : batch_for(g);
     const int window = window_for(g);
     const bool small_tail = sp.blocked && bsf_small_tail_usable(g);
+    static const bool defer_env = getenv("PGH_DEFER_CLOSE") == nullptr || atoi(getenv("PGH_DEFER_CLOSE")) != 0;
+    const bool defer = defer_env && sp.blocked && !small_tail;
+    pending_close_slot().active = 0;
     if (poll) progress_reset();
     // host-side mirror of the reference loop for iteration 2 (uses err of step 1), then device batches
     it = 2;
@@ -1987,7 +1990,23 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
                     continue;
                 }
                 PGH_TRY((launch_step<EPI_POLY>(g, ep, scaled_gather ? g->bsf.xg : term, g_state, &count)));
-                {
+                if (defer) {
+                    // blocked layout: the close of this term rides in the first kernel of the next one, as in the recursive loops
+                    // (PendingClose; one launch and one dependent boundary fewer per term)
+                    PendingClose pc{};
+                    pc.state = g_state;
+                    pc.partial_sum = r.d_partials;
+                    pc.res_partials = r.d_partials + kMaxPartials;
+                    pc.progress = g_progress_dev;
+                    pc.tol = cfg->tol;
+                    pc.n = (long long)n;
+                    pc.num_sum = count;
+                    pc.num_res = count;
+                    pc.check = check;
+                    pc.err_kind = cfg->err_kind;
+                    pc.active = 1;
+                    pending_close_slot() = pc;
+                } else {
                     ProfScope prof(PGH_K_FINAL);
                     k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, r.d_partials + kMaxPartials,
                                                          count, 0, check, cfg->err_kind, cfg->tol, n, nullptr, g_progress_dev);
@@ -1995,11 +2014,13 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
                 term = tout;
             }
             PGH_HIP(hipGetLastError());
+            if (!poll || next_it >= max_iters) PGH_TRY(flush_pending_close());
             if (!poll) {
                 PGH_TRY(fetch_state());
                 done = g_state_host->done != 0;
             }
         }
+        PGH_TRY(flush_pending_close());               // a no-op once the loop has ended on the device
         PGH_TRY(fetch_state());
         spmv = g_state_host->steps;
         converged = g_state_host->converged != 0;
