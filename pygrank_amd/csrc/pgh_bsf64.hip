@@ -97,9 +97,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 PGH_STAMP_DECL(g_times_partial64)
 template <bool HAS_VAL>
-__global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const double* __restrict__ xg, const LoopState* __restrict__ state) {
+__global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const double* __restrict__ xg, const LoopState* __restrict__ state,
+                                                            PendingClose pc) {
     __shared__ __attribute__((aligned(16))) double s_lds[kLdsDoubles];
     if (state != nullptr && state->done) return;
+    // the previous term's close, if the loop driver left it to this kernel (PendingClose; the LDS it uses is not yet in use)
+    if (pc.active && run_pending_close(pc, s_lds)) return;
     PGH_STAMP_BEGIN(g_times_partial64)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -510,8 +513,11 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
     const int main_grid = r.num_cus >= unit ? r.num_cus / unit * unit : unit;
     {
         ProfScope prof(PGH_K_SPMV);
-        if (f.val) k_bsf64_partial<true><<<main_grid, kThreads, 0, r.stream>>>(v, xg, state);
-        else k_bsf64_partial<false><<<main_grid, kThreads, 0, r.stream>>>(v, xg, state);
+        PendingClose pc = pending_close_slot();
+        if (state == nullptr || pc.state != state) pc.active = 0;
+        else pending_close_slot().active = 0;              // consumed
+        if (f.val) k_bsf64_partial<true><<<main_grid, kThreads, 0, r.stream>>>(v, xg, state, pc);
+        else k_bsf64_partial<false><<<main_grid, kThreads, 0, r.stream>>>(v, xg, state, pc);
     }
     PGH_STAMP_DUMP(g_times_partial64, main_grid, "k_bsf64_partial")
     {

@@ -1698,6 +1698,9 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
     const bool poll = g_progress_dev != nullptr;
     const int batch = poll ? 1 : batch_for(g);
     const int window = window_for(g);
+    static const bool defer_env64 = getenv("PGH_DEFER_CLOSE") == nullptr || atoi(getenv("PGH_DEFER_CLOSE")) != 0;
+    const bool defer64 = defer_env64 && blocked;
+    pending_close_slot().active = 0;
     if (poll) progress_reset();
     it = 2;
     bool stop = false;
@@ -1746,7 +1749,21 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
                 }
                 const int chk_it = k + 1;
                 const int check = (cfg->err_kind != PGH_ERR_ITERS) && (chk_it < max_iters) && (chk_it % cfg->end_modulo == 0);
-                {
+                if (defer64) {                     // blocked f64 image: the close rides in the next term's k_bsf64_partial
+                    PendingClose pc{};
+                    pc.state = g_state;
+                    pc.partial_sum = psum;
+                    pc.res_partials = pdel;
+                    pc.progress = g_progress_dev;
+                    pc.tol = cfg->tol;
+                    pc.n = (long long)n;
+                    pc.num_sum = count;
+                    pc.num_res = count;
+                    pc.check = check;
+                    pc.err_kind = cfg->err_kind;
+                    pc.active = 1;
+                    pending_close_slot() = pc;
+                } else {
                     ProfScope prof(PGH_K_FINAL);
                     k_step_close<<<1, WG, 0, r.stream>>>(g_state, psum, count, pdel, count, 0, check, cfg->err_kind, cfg->tol, n,
                                                          nullptr, g_progress_dev);
@@ -1754,11 +1771,13 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
                 term = tbuf[k & 1];
             }
             PGH_HIP(hipGetLastError());
+            if (!poll || next_it >= max_iters) PGH_TRY(flush_pending_close());
             if (!poll) {
                 PGH_TRY(fetch_state());
                 done = g_state_host->done != 0;
             }
         }
+        PGH_TRY(flush_pending_close());               // a no-op once the loop has ended on the device
         PGH_TRY(fetch_state());
         spmv = g_state_host->steps;
         converged = g_state_host->converged != 0;
