@@ -1108,53 +1108,17 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             // The deal counts WORK, not list positions: an isolated stretch that is passed over costs ~3 us, every other item 10-35 us
             // (profiles/r03/finish_schedule_r03.log), so the stretches are dealt on their own: round-robin over the items that do work,
             // in row order (at any moment the workgroups sweep the same stretch of the image), then the isolated stretches from the
-            // other end.  Dealing them as equals (PGH_FIN_DEAL=0, rounds 2-3) left workgroups with 22 .. 95 us of static work around a
-            // mean of 53.  PGH_FIN_DEAL=2: longest first by the measured cost model with the cheapest items as the tail -- 3.5 us better
-            // at scale 23, 40 us WORSE at scale 24 and 3 us worse at scale 22 (the sweep over the image is lost): not the default.  Longest
-            // first with the row-order tail, longest first inside windows of 1024 items, the cheapest items as the tail of deal 1: all
-            // measured, all slower than deal 1 on at least two of the three scales (same log).
-            static const int deal = getenv("PGH_FIN_DEAL") != nullptr ? atoi(getenv("PGH_FIN_DEAL")) : 1;
+            // other end.  Dealing them as equals (rounds 2-3) left workgroups with 22 .. 95 us of static work around a mean of 53.
+            // Longest first by the measured cost model (whole head, or inside windows of 1024 items; with the row-order tail or with the
+            // cheapest items as the tail), a snake over the rounds: all measured, all slower on at least two of the scales 22-24 -- what
+            // they give up is the common sweep over the image (same log).
             // measured cost of an item (us; PGH_PROBE_TIMES build at scale 23, profiles/r03/finish_schedule_r03.log): 6.1 + 0.30 per 1000
             // entries + 4.5 per 1000 rows + 3.9 when it has entries at all; an isolated stretch that is passed over 3.3
             for (int i = 0; i < p.num_items; ++i) {
                 const double entries = 8.0 * (double)all_a[i].w, rows = (double)all_b[i].y;
                 cost[i] = all_b[i].z == -2 ? 3300.0 : 6100.0 + 0.30 * entries + 4.5 * rows + (entries > 0 ? 3900.0 : 0.0);
             }
-            std::vector<int> tail_items;
-            if (deal == 2) {
-                // longest first: the TAIL (handed out on the device) is made of the cheapest items that do work -- the end of the launch
-                // is levelled in steps of ~10 us instead of ~30 -- and the head is dealt to the least loaded workgroup in descending
-                // order of cost, every workgroup walking its share from the longest item to the shortest
-                const int first_plain = (int)(hub_a.size() + iso_a.size());
-                std::vector<int> plain(plain_items);
-                for (int i = 0; i < plain_items; ++i) plain[i] = first_plain + i;
-                std::stable_sort(plain.begin(), plain.end(), [&](int x, int y) { return cost[x] < cost[y]; });
-                std::vector<char> in_tail(p.num_items, 0);
-                for (int i = 0; i < tail; ++i) {
-                    tail_items.push_back(plain[i]);
-                    in_tail[plain[i]] = 1;
-                }
-                std::sort(tail_items.begin(), tail_items.end(), [&](int x, int y) { return cost[x] > cost[y] || (cost[x] == cost[y] && x < y); });
-                std::vector<int> order;
-                for (int i = 0; i < p.num_items; ++i)
-                    if (!in_tail[i]) order.push_back(i);
-                std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
-                std::vector<std::vector<int>> mine_of(groups);
-                std::vector<std::pair<double, int>> heap;           // (load, workgroup): min-heap by load, ties by index
-                for (int w = 0; w < groups; ++w) heap.emplace_back(0.0, w);
-                auto later = [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x > y; };
-                std::make_heap(heap.begin(), heap.end(), later);
-                for (int i : order) {
-                    std::pop_heap(heap.begin(), heap.end(), later);
-                    heap.back().first += cost[i];
-                    mine_of[heap.back().second].push_back(i);
-                    std::push_heap(heap.begin(), heap.end(), later);
-                }
-                for (int w = 0; w < groups; ++w) {
-                    flat.insert(flat.end(), mine_of[w].begin(), mine_of[w].end());
-                    begin.push_back((int)flat.size());
-                }
-            } else if (deal == 1) {
+            {
                 std::vector<std::vector<int>> mine_of(groups);
                 int k = 0;
                 for (int i = 0; i < head; ++i)
@@ -1166,16 +1130,8 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
                     flat.insert(flat.end(), mine_of[w].begin(), mine_of[w].end());
                     begin.push_back((int)flat.size());
                 }
-            } else {
-                for (int w = 0; w < groups; ++w) {
-                    for (int i = w; i < head; i += groups) flat.push_back(i);
-                    begin.push_back((int)flat.size());
-                }
             }
-            if (deal == 2) {
-                p.tail_begin = (int)flat.size();               // sched[tail_begin ..): the tail, whatever the item numbers
-                flat.insert(flat.end(), tail_items.begin(), tail_items.end());
-            } else {
+            {
                 for (int i = head; i < p.num_items; ++i) flat.push_back(i);
                 // A SHORT tail (fewer items than half the workgroups) is handed out longest first: the launch then ends on its cheapest
                 // items (scale 23: 87.7 -> 84.1 us); a long one stays in row order, where the common sweep matters more (scale 24:
@@ -1184,7 +1140,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
                 if (ts != nullptr ? atoi(ts) != 0 : 2 * tail < groups)
                     std::stable_sort(flat.begin() + head, flat.end(), [&](int x, int y) { return cost[x] > cost[y]; });
             }
-            if (deal != 2) p.tail_begin = head;
+            p.tail_begin = head;
             p.tail_count = tail;
             if (tail > 0) {
                 PGH_HIP(hipMalloc(&p.work_counter, sizeof(uint32_t)));
