@@ -363,7 +363,8 @@ typedef struct {
     int32_t converged;
     int32_t column_blocks;
     int32_t split_regions;  /* 1 = hot prefixes and cold parts are exchanged as two contiguous regions          */
-    int32_t reserved;
+    int32_t flags;          /* bit 1: the residual was evaluated inside the finish kernel (one 4-scalar all-reduce per
+                             * iteration); bit 0: ... and one step had to be re-evaluated by the separate kernel        */
     double  last_error;
     double  loop_ms;        /* HIP-event time of the loop on the compute stream                                 */
     int64_t exchange_bytes; /* received per rank and iteration                                                  */
@@ -381,6 +382,15 @@ int pgh_comm_create_external(int32_t world, int32_t rank, pgh_allgather_fn all_g
 int pgh_comm_destroy(pgh_comm_t comm);
 int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t comm, pgh_vec_t p_local, pgh_vec_t ranks_local, const pgh_dist_cfg* cfg,
                      pgh_dist_result* res);
+/* ClosedFormGraphFilter (abstract_filters.py:152-270, taylor form: HeatKernel / PageRankClosed / GenericGraphFilter) on a partition,
+ * the whole run behind one call: result = sum_k coeffs[k - 1] (M^T)^(k-1) p / |p|_1 on this rank's rows, stopped by
+ * ConvergenceManager on the change of the result (convergence.py:77-101; cfg->alpha / use_quotient / every_row / deg / lam unused).
+ * One all-gather of the term's gather slice and one 8-byte all-reduce of the change per term; the stopping rule runs on the device. */
+int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t comm, pgh_vec_t p_local, const double* coeffs, int32_t num_coeffs, pgh_vec_t result_local,
+                      const pgh_dist_cfg* cfg, pgh_dist_result* res);
+/* Upper bound, in seconds, of every host wait on a collective from now on (<= 0: back to PGH_DIST_TIMEOUT_S, default 600 s): a first
+ * run on new hardware can be probed with a short one (pygrank_amd/distributed.py does, before it trusts the engine's loop). */
+int pgh_dist_set_timeout(double seconds);
 
 /* new id -> original id of a relabelled (partitioned) graph, and the first row this graph holds */
 int pgh_graph_perm(pgh_graph_t g, int32_t* new_to_old, int64_t* row_begin);

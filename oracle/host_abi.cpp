@@ -1284,6 +1284,10 @@ int pgh_comm_destroy(pgh_comm_t) { return 0; }
 int pgh_dist_ppr_run(pgh_graph_t, pgh_comm_t, pgh_vec_t, pgh_vec_t, const pgh_dist_cfg*, pgh_dist_result*) {
     return fail("pgh_dist_ppr_run: not available in the host double");
 }
+int pgh_dist_poly_run(pgh_graph_t, pgh_comm_t, pgh_vec_t, const double*, int32_t, pgh_vec_t, const pgh_dist_cfg*, pgh_dist_result*) {
+    return fail("pgh_dist_poly_run: not available in the host double");
+}
+int pgh_dist_set_timeout(double) { return 0; }
 
 int pgh_dist_close_err(double* state, int32_t kind, double tol, int64_t n_global) {
     DistState* st = reinterpret_cast<DistState*>(state);

@@ -42,7 +42,7 @@ class DistCfg(C.Structure):
 
 class DistResult(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("spmv_count", C.c_int32), ("converged", C.c_int32), ("column_blocks", C.c_int32),
-                ("split_regions", C.c_int32), ("reserved", C.c_int32), ("last_error", C.c_double), ("loop_ms", C.c_double),
+                ("split_regions", C.c_int32), ("flags", C.c_int32), ("last_error", C.c_double), ("loop_ms", C.c_double),
                 ("exchange_bytes", C.c_int64), ("gather_slots", C.c_int64)]
 
 
@@ -163,6 +163,8 @@ SIGNATURES = {
     "pgh_comm_create_external": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "pgh_comm_destroy": (C.c_int, [C.c_void_p]),
     "pgh_dist_ppr_run": (C.c_int, [c_graph, C.c_void_p, c_vec, c_vec, C.POINTER(DistCfg), C.POINTER(DistResult)]),
+    "pgh_dist_poly_run": (C.c_int, [c_graph, C.c_void_p, c_vec, C.c_void_p, C.c_int32, c_vec, C.POINTER(DistCfg), C.POINTER(DistResult)]),
+    "pgh_dist_set_timeout": (C.c_int, [C.c_double]),
     "pgh_graph_rmat_part": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.POINTER(c_graph)]),
     "pgh_graph_rmat": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int32,

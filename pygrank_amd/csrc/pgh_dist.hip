@@ -97,7 +97,9 @@ struct pgh_comm_s {
     float*      p_norm = nullptr;
     double*     state = nullptr;         // [8] device (pgh_dist_* layout)
     double*     state_host = nullptr;    // [8] pinned
-    int32_t*    agree = nullptr;         // [2] device words of the layout negotiation
+    LoopAux*    aux = nullptr;           // the in-kernel residual's predictions (ResParams, pgh_kernels.h)
+    double*     red = nullptr;           // [4] {S, T, D, R'}: this rank's sums, all-reduced in place once per iteration
+    int32_t*    agree = nullptr;         // [4] device words of the layout negotiation
     // collectives supplied by the host instead of RCCL (pgh_comm_create_external): MPI, gloo, a test harness ...
     pgh_allgather_fn ext_gather = nullptr;
     pgh_allreduce_fn ext_reduce = nullptr;
@@ -138,8 +140,13 @@ void free_buffers(pgh_comm_s* c) {
 }
 
 // host wait with a deadline: 0 = the event completed
+double default_wait_limit_s() { return getenv("PGH_DIST_TIMEOUT_S") != nullptr ? atof(getenv("PGH_DIST_TIMEOUT_S")) : 600.0; }
+double& wait_limit_s() {
+    static double limit = default_wait_limit_s();
+    return limit;
+}
 int bounded_wait(hipEvent_t ev, const char* what) {
-    static const double limit = getenv("PGH_DIST_TIMEOUT_S") != nullptr ? atof(getenv("PGH_DIST_TIMEOUT_S")) : 600.0;
+    const double limit = wait_limit_s();
     const auto start = std::chrono::steady_clock::now();
     long spins = 0;
     for (;;) {
@@ -173,7 +180,7 @@ inline int grid_of(int64_t n) {
 // gather-vector layout and buffers for graph g (collective: every rank calls it with its slice of the same partition).  The
 // layout is negotiated on every run (one 8-byte all-reduce: a handle is no proof that the graph behind it is the one of the
 // last run); the buffers are kept while their sizes fit.
-int prepare_graph(pgh_comm_s* c, pgh_graph_t g) {
+int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     Runtime& r = rt();
     int32_t nb = 0, live8[8] = {0}, hot_slots = 0;
     int64_t blk = 0;
@@ -182,13 +189,20 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g) {
     PGH_CHECK(nb % c->world == 0, "pgh_dist_ppr_run: the column blocks of the slice do not divide among the ranks");
     int32_t top = 0;
     for (int b = 0; b < nb; ++b) top = live8[b] > top ? live8[b] : top;
-    // every rank must lay the gather vector out the same way: live = max over ranks, hot prefix = min over ranks
-    int32_t h_agree[2] = {top, -hot_slots};
+    // every rank must lay the gather vector out the same way: live = max over ranks, hot prefix = min over ranks; and every rank
+    // must close the steps the same way: the in-kernel residual only when every slice can (min), the slice's degrees recomputed
+    // when any rank lacks them (max)
+    int32_t h_agree[4] = {top, -hot_slots, (fused != nullptr && *fused) ? 0 : 1, g->bsf.deg_int == nullptr ? 1 : 0};
     PGH_HIP(hipMemcpyAsync(c->agree, h_agree, sizeof(h_agree), hipMemcpyHostToDevice, c->main));
-    PGH_TRY(comm_all_reduce(c, c->agree, 2, ncclInt32, ncclMax, c->s, c->main));
+    PGH_TRY(comm_all_reduce(c, c->agree, 4, ncclInt32, ncclMax, c->s, c->main));
     PGH_HIP(hipMemcpyAsync(h_agree, c->agree, sizeof(h_agree), hipMemcpyDeviceToHost, c->main));
     PGH_HIP(hipEventRecord(c->ev_host, c->main));
     PGH_TRY(bounded_wait(c->ev_host, "the layout negotiation"));
+    if (fused != nullptr) *fused = h_agree[2] == 0;
+    if (h_agree[3] != 0 && g->bsf.deg_int != nullptr) {       // some rank rebuilds its degrees: the all-reduce needs everybody
+        (void)hipFree(g->bsf.deg_int);
+        g->bsf.deg_int = nullptr;
+    }
     const int64_t live = std::min<int64_t>(blk, ((int64_t)h_agree[0] + 63) / 64 * 64);
     const int64_t hot_all = -h_agree[1];
     // split regions only when the exchange's hot prefix is exactly what the block partial sums read
@@ -259,6 +273,32 @@ extern "C" int pgh_comm_unique_id(uint8_t* id /* [PGH_COMM_ID_BYTES] */) {
     return 0;
 }
 
+namespace {
+// streams, events and scalars of a communicator; on failure the caller destroys the half-built object (pgh_comm_destroy frees
+// whatever exists)
+int comm_resources(pgh_comm_s* c, bool two_comms) {
+    const bool single_stream = getenv("PGH_DIST_SINGLE_STREAM") != nullptr && atoi(getenv("PGH_DIST_SINGLE_STREAM")) != 0;
+    PGH_HIP(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
+    c->own_streams = true;
+    if (single_stream) {
+        c->xs = c->ss = c->main;
+    } else {
+        PGH_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+        // one communicator: RCCL wants its operations in ONE order, so exchange and scalars share the side stream
+        if (two_comms) PGH_HIP(hipStreamCreateWithFlags(&c->ss, hipStreamNonBlocking));
+        else c->ss = c->xs;
+    }
+    for (hipEvent_t* ev : {&c->ev_fin, &c->ev_hot, &c->ev_cold, &c->ev_err, &c->ev_host})
+        PGH_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    PGH_HIP(hipMalloc(&c->state, sizeof(double) * 8));
+    PGH_HIP(hipHostMalloc(&c->state_host, sizeof(double) * 8, hipHostMallocDefault));
+    PGH_HIP(hipMalloc(&c->aux, sizeof(LoopAux)));
+    PGH_HIP(hipMalloc(&c->red, sizeof(double) * 4));
+    PGH_HIP(hipMalloc(&c->agree, sizeof(int32_t) * 4));
+    return 0;
+}
+}  // namespace
+
 extern "C" int pgh_comm_create(const uint8_t* ids, int32_t num_ids, int32_t world, int32_t rank, pgh_comm_t* out) {
     PGH_CHECK(ids != nullptr && out != nullptr && (num_ids == 1 || num_ids == 2) && world >= 1 && rank >= 0 && rank < world,
               "pgh_comm_create: bad arguments");
@@ -278,25 +318,14 @@ extern "C" int pgh_comm_create(const uint8_t* ids, int32_t num_ids, int32_t worl
     }
     if (rc != ncclSuccess) {
         const std::string msg = std::string("pgh_comm_create: ncclCommInitRank: ") + g_rccl.GetErrorString(rc);
-        delete c;
+        (void)pgh_comm_destroy(c);             // the first communicator, when only the second failed
         return fail(msg);
     }
-    const bool single_stream = getenv("PGH_DIST_SINGLE_STREAM") != nullptr && atoi(getenv("PGH_DIST_SINGLE_STREAM")) != 0;
-    PGH_HIP(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
-    if (single_stream) {
-        c->xs = c->ss = c->main;
-    } else {
-        PGH_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
-        // one communicator: RCCL wants its operations in ONE order, so exchange and scalars share the side stream
-        if (num_ids == 2) PGH_HIP(hipStreamCreateWithFlags(&c->ss, hipStreamNonBlocking));
-        else c->ss = c->xs;
+    if (comm_resources(c, num_ids == 2) != 0) {
+        const std::string msg = pgh_last_error();
+        (void)pgh_comm_destroy(c);
+        return fail(msg);
     }
-    c->own_streams = true;
-    for (hipEvent_t* ev : {&c->ev_fin, &c->ev_hot, &c->ev_cold, &c->ev_err, &c->ev_host})
-        PGH_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    PGH_HIP(hipMalloc(&c->state, sizeof(double) * 8));
-    PGH_HIP(hipHostMalloc(&c->state_host, sizeof(double) * 8, hipHostMallocDefault));
-    PGH_HIP(hipMalloc(&c->agree, sizeof(int32_t) * 2));
     *out = c;
     return 0;
 }
@@ -316,20 +345,11 @@ extern "C" int pgh_comm_create_external(int32_t world, int32_t rank, pgh_allgath
     c->ext_gather = all_gather;
     c->ext_reduce = all_reduce;
     c->ext_user = user;
-    const bool single_stream = getenv("PGH_DIST_SINGLE_STREAM") != nullptr && atoi(getenv("PGH_DIST_SINGLE_STREAM")) != 0;
-    PGH_HIP(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
-    if (single_stream) {
-        c->xs = c->ss = c->main;
-    } else {
-        PGH_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
-        PGH_HIP(hipStreamCreateWithFlags(&c->ss, hipStreamNonBlocking));
+    if (comm_resources(c, true) != 0) {
+        const std::string msg = pgh_last_error();
+        (void)pgh_comm_destroy(c);
+        return fail(msg);
     }
-    c->own_streams = true;
-    for (hipEvent_t* ev : {&c->ev_fin, &c->ev_hot, &c->ev_cold, &c->ev_err, &c->ev_host})
-        PGH_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    PGH_HIP(hipMalloc(&c->state, sizeof(double) * 8));
-    PGH_HIP(hipHostMalloc(&c->state_host, sizeof(double) * 8, hipHostMallocDefault));
-    PGH_HIP(hipMalloc(&c->agree, sizeof(int32_t) * 2));
     *out = c;
     return 0;
 }
@@ -339,6 +359,8 @@ extern "C" int pgh_comm_destroy(pgh_comm_t c) {
     if (rt().initialised) (void)hipDeviceSynchronize();
     free_buffers(c);
     (void)hipFree(c->state);
+    (void)hipFree(c->aux);
+    (void)hipFree(c->red);
     (void)hipFree(c->agree);
     (void)hipHostFree(c->state_host);
     for (hipEvent_t ev : {c->ev_fin, c->ev_hot, c->ev_cold, c->ev_err, c->ev_host})
@@ -354,6 +376,65 @@ extern "C" int pgh_comm_destroy(pgh_comm_t c) {
     return 0;
 }
 
+namespace {
+
+// Whatever way a run ends: its timing events are destroyed, the isolated-row flag goes back to "process every row" IN ORDER with
+// the engine's own stream (the release is enqueued on the communicator's compute queue, which is then drained), and after a
+// failure nothing of the run is left in flight on the three queues -- unless a collective has stalled (bounded_wait gave up):
+// draining would then wait for ever, so the queues are left alone and the caller is expected to end the process.
+struct RunScope {
+    pgh_comm_s* c;
+    pgh_graph_t g;
+    hipEvent_t  t_begin = nullptr, t_end = nullptr;
+    bool        ok = false, stalled = false;
+    int drain(hipStream_t st, const char* what) {
+        if (hipEventRecord(c->ev_host, st) != hipSuccess) return 1;
+        return bounded_wait(c->ev_host, what);
+    }
+    ~RunScope() {
+        if (t_begin) (void)hipEventDestroy(t_begin);
+        if (t_end) (void)hipEventDestroy(t_end);
+        pb_set_residual(nullptr);
+        if (stalled) return;
+        if (!ok) {
+            if (c->xs != c->main) (void)drain(c->xs, "the exchange queue after a failed run");
+            if (c->ss != c->main && c->ss != c->xs) (void)drain(c->ss, "the scalar queue after a failed run");
+        }
+        (void)pgh_dist_release_isolated(g);          // on rt().stream == c->main (StreamSwap outlives this scope)
+        (void)drain(c->main, "the compute queue at the end of the run");
+    }
+};
+
+// row sums of M on this rank's rows (BsfFormat::deg_int of a slice): a rank holds its COLUMNS of M, so pgh_graph_s::degrees are
+// partial sums over all ranks' ids -- summed over the ranks once per graph (collective), the slice kept with the graph
+int ensure_slice_degrees(pgh_comm_s* c, pgh_graph_t g) {
+    BsfFormat& f = g->bsf;
+    if (f.deg_int != nullptr) return 0;
+    const int64_t n_all = g->n_rows;
+    float* all = nullptr;
+    PGH_HIP(hipMalloc(&all, sizeof(float) * (size_t)(n_all > 0 ? n_all : 1)));
+    int rc = 0;
+    if (hipMemcpyAsync(all, g->degrees, sizeof(float) * (size_t)n_all, hipMemcpyDeviceToDevice, c->main) != hipSuccess) rc = fail("ensure_slice_degrees: copy failed");
+    if (rc == 0 && c->world > 1) rc = comm_all_reduce(c, all, (size_t)n_all, ncclFloat32, ncclSum, c->s, c->main);
+    float* mine = nullptr;
+    if (rc == 0 && hipMalloc(&mine, sizeof(float) * (size_t)(g->n_cols > 0 ? g->n_cols : 1)) != hipSuccess) rc = fail("ensure_slice_degrees: out of device memory");
+    if (rc == 0 && hipMemcpyAsync(mine, all + g->row_begin, sizeof(float) * (size_t)g->n_cols, hipMemcpyDeviceToDevice, c->main) != hipSuccess)
+        rc = fail("ensure_slice_degrees: copy failed");
+    if (rc == 0 && hipEventRecord(c->ev_host, c->main) != hipSuccess) rc = fail("ensure_slice_degrees: event");
+    if (rc == 0) rc = bounded_wait(c->ev_host, "the all-reduce of the slice's degrees");
+    if (rc == 0) {
+        (void)hipFree(all);
+        f.deg_int = mine;
+        f.device_bytes += (int64_t)g->n_cols * 4;
+        return 0;
+    }
+    // (a stalled all-reduce may still be writing `all`: it is leaked rather than freed under it)
+    (void)hipFree(mine);
+    return rc;
+}
+
+}  // namespace
+
 extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, pgh_vec_t ranks_local, const pgh_dist_cfg* cfg,
                                 pgh_dist_result* res) {
     PGH_CHECK(g && c && p_local && ranks_local && cfg && res, "pgh_dist_ppr_run: null argument");
@@ -363,55 +444,71 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     Runtime& r = rt();
     memset(res, 0, sizeof(*res));
     PGH_HIP(hipStreamSynchronize(r.stream));               // the caller's operands are in place; from here on: the communicator's queues
-    PGH_TRY(prepare_graph(c, g));
-    const int64_t n_local = c->n_local;
     const int kind = cfg->err_kind;
+    const bool absorbing = cfg->deg_local != nullptr && cfg->lam_local != nullptr;
+    // the in-kernel residual (ResParams, pgh_kernels.h): PageRank with the L1 / Mabs rule on slices with a cold image -- on EVERY
+    // rank (prepare_graph lets the ranks agree)
+    bool fused = !absorbing && (kind == PGH_ERR_L1 || kind == PGH_ERR_MABS) && dist_can_fuse(g);
+    PGH_TRY(prepare_graph(c, g, &fused));
+    const int64_t n_local = c->n_local;
+    PGH_CHECK(!absorbing || (cfg->deg_local->n == n_local && cfg->lam_local->n == n_local), "pgh_dist_ppr_run: deg / lam must have the slice's length");
     const int local_kind = kind == PGH_ERR_LINF ? PGH_ERR_LINF : PGH_ERR_L1;
     const ncclRedOp_t err_op = kind == PGH_ERR_LINF ? ncclMax : ncclSum;
     StreamSwap on_main(c->main);
-    struct IsoGuard {
-        pgh_graph_t g;
-        ~IsoGuard() { (void)pgh_dist_release_isolated(g); }
-    } iso_guard{g};
+    RunScope scope{c, g};
     pgh_vec_s v_p{c->p_norm, n_local, false}, v_xg_full{c->xg_full, c->n_xg, false}, v_xg_local{c->xg_local, n_local, false};
     pgh_vec_s v_y[2] = {{c->y[0], n_local, false}, {c->y[1], n_local, false}};
+    int rc = 0;
+#define PGH_RUN(expr)                                    \
+    do {                                                 \
+        if ((rc = (expr)) != 0) return rc;               \
+    } while (0)
+#define PGH_RUN_HIP(expr)                                                                                       \
+    do {                                                                                                        \
+        const hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (pgh_dist_ppr_run)"); \
+    } while (0)
+    auto wait_host = [&](hipEvent_t ev, const char* what) -> int {
+        const int w = bounded_wait(ev, what);
+        if (w != 0) scope.stalled = true;
+        return w;
+    };
+    if (fused) PGH_RUN(ensure_slice_degrees(c, g));
 
     // ---- prologue of GraphFilter.rank (abstract_filters.py:52-56): global L1 norm, x0 = p / norm
     double local_abs = 0.0;
-    PGH_TRY(pgh_reduce(PGH_ABSSUM, p_local, &local_abs));
-    PGH_HIP(hipMemcpyAsync(c->state, &local_abs, sizeof(double), hipMemcpyHostToDevice, c->main));
-    PGH_TRY(comm_all_reduce(c, c->state, 1, ncclFloat64, ncclSum, c->s, c->main));
-    PGH_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double), hipMemcpyDeviceToHost, c->main));
-    PGH_HIP(hipEventRecord(c->ev_host, c->main));
-    PGH_TRY(bounded_wait(c->ev_host, "the all-reduce of the personalization's norm"));
+    PGH_RUN(pgh_reduce(PGH_ABSSUM, p_local, &local_abs));
+    PGH_RUN_HIP(hipMemcpyAsync(c->state, &local_abs, sizeof(double), hipMemcpyHostToDevice, c->main));
+    PGH_RUN(comm_all_reduce(c, c->state, 1, ncclFloat64, ncclSum, c->s, c->main));
+    PGH_RUN_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double), hipMemcpyDeviceToHost, c->main));
+    PGH_RUN_HIP(hipEventRecord(c->ev_host, c->main));
+    PGH_RUN(wait_host(c->ev_host, "the all-reduce of the personalization's norm"));
     const double norm = c->state_host[0];
     if (norm == 0.0) {
-        PGH_TRY(pgh_vec_copy(ranks_local, p_local));
-        PGH_HIP(hipStreamSynchronize(c->main));
+        PGH_RUN(pgh_vec_copy(ranks_local, p_local));
         res->iterations = 0;
+        scope.ok = true;
         return 0;
     }
     k_div_into<<<grid_of(n_local), 256, 0, c->main>>>(p_local->data, c->p_norm, n_local, (float)norm);     // the backend's f32 `p / norm`
     int cur = 0;
-    PGH_HIP(hipMemsetAsync(c->y[1], 0, sizeof(float) * (size_t)n_local, c->main));      // rows a run passes over hold zeros in both iterates
-    PGH_TRY(pgh_vec_copy(&v_y[0], &v_p));
-    const bool absorbing = cfg->deg_local != nullptr && cfg->lam_local != nullptr;
-    PGH_CHECK(!absorbing || (cfg->deg_local->n == n_local && cfg->lam_local->n == n_local), "pgh_dist_ppr_run: deg / lam must have the slice's length");
-    if (!cfg->every_row) PGH_TRY(pgh_dist_watch_isolated(g, &v_p, &v_y[0]));
-    PGH_TRY(pgh_dist_prescale(g, &v_y[0], &v_xg_local));
+    PGH_RUN_HIP(hipMemsetAsync(c->y[1], 0, sizeof(float) * (size_t)n_local, c->main));      // rows a run passes over hold zeros in both iterates
+    PGH_RUN(pgh_vec_copy(&v_y[0], &v_p));
+    if (!cfg->every_row) PGH_RUN(pgh_dist_watch_isolated(g, &v_p, &v_y[0]));
+    PGH_RUN(pgh_dist_prescale(g, &v_y[0], &v_xg_local));
     const int64_t cold_region = (int64_t)c->nb * c->hot;
     if (c->hot > 0) {
-        PGH_TRY(gather_part(c, 0, 0, c->hot, c->main));
-        PGH_TRY(gather_part(c, cold_region, c->hot, c->live, c->main));
+        PGH_RUN(gather_part(c, 0, 0, c->hot, c->main));
+        PGH_RUN(gather_part(c, cold_region, c->hot, c->live, c->main));
     } else {
-        PGH_TRY(gather_part(c, 0, 0, c->live, c->main));
+        PGH_RUN(gather_part(c, 0, 0, c->live, c->main));
     }
-    PGH_TRY(pgh_dist_state_init(c->state));
-    for (hipEvent_t ev : {c->ev_hot, c->ev_cold, c->ev_err}) PGH_HIP(hipEventRecord(ev, c->main));
-    hipEvent_t t_begin = nullptr, t_end = nullptr;
-    PGH_HIP(hipEventCreate(&t_begin));
-    PGH_HIP(hipEventCreate(&t_end));
-    PGH_HIP(hipEventRecord(t_begin, c->main));
+    PGH_RUN(pgh_dist_state_init(c->state));
+    if (fused) PGH_RUN(dist_aux_init(c->aux));
+    for (hipEvent_t ev : {c->ev_hot, c->ev_cold, c->ev_err}) PGH_RUN_HIP(hipEventRecord(ev, c->main));
+    PGH_RUN_HIP(hipEventCreate(&scope.t_begin));
+    PGH_RUN_HIP(hipEventCreate(&scope.t_end));
+    PGH_RUN_HIP(hipEventRecord(scope.t_begin, c->main));
 
     auto stages = [&]() -> int {
         PGH_HIP(hipStreamWaitEvent(c->main, c->ev_hot, 0));
@@ -420,94 +517,136 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
         PGH_TRY(pgh_dist_partial_stage(g, &v_xg_full, c->state, 2));
         return 0;
     };
+    // the scalars of a step the plain way, on the scalar queue (the caller has swapped rt().stream to it): all-reduce of sum(y)
+    // -> lazy quotient -> residual -> all-reduce -> stopping rule -> 64 bytes of state to the host
+    auto scalars_plain = [&](bool check, bool with_sum) -> int {
+        if (with_sum) {
+            PGH_TRY(comm_all_reduce(c, c->state + 2, 1, ncclFloat64, ncclSum, c->s, c->ss));
+            PGH_TRY(pgh_dist_close_sum(c->state, cfg->use_quotient));
+        }
+        if (check) {
+            PGH_TRY(pgh_dist_residual(local_kind, &v_y[cur], &v_y[1 - cur], c->state));
+            PGH_TRY(comm_all_reduce(c, c->state + 1, 1, ncclFloat64, err_op, c->s, c->ss));
+            PGH_TRY(pgh_dist_close_err(c->state, kind, cfg->tol, cfg->n_global));
+            PGH_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->ss));
+        }
+        return 0;
+    };
     const int max_iters = cfg->max_iters;
     int it = 1, spmv = 0;                      // `it` = ConvergenceManager.iteration of the pending has_converged call
     bool pending = false, staged = false, converged = false;
-    int rc = 0;
     while (it < max_iters) {                   // convergence.py:86
         const int nxt = 1 - cur;
-        if (!staged && (rc = stages()) != 0) break;
+        if (!staged) PGH_RUN(stages());
         staged = false;
         if (pending) {
             // the check that followed the previous step: its flag has travelled while the stages above were enqueued
-            if ((rc = bounded_wait(c->ev_err, "the residual all-reduce of the previous step")) != 0) break;
+            PGH_RUN(wait_host(c->ev_err, "the scalar all-reduce of the previous step"));
             pending = false;
-            if (reinterpret_cast<const int*>(c->state_host)[6] != 0) {
+            int flag = reinterpret_cast<const int*>(c->state_host)[6];
+            if (flag == 2) {
+                // the in-kernel residual could not vouch for its verdict (the quotient's prediction missed by more than the
+                // distance to the tolerance, or a value was negative / not finite): the step is complete but for its residual --
+                // the separate kernel evaluates it, and the run goes on without the fusion.  Every rank sees the same flag.
+                fused = false;
+                res->flags |= 1;
+                {
+                    StreamSwap on_scalars(c->ss);
+                    PGH_RUN(dist_resume(c->state));
+                    PGH_RUN(pgh_dist_close_sum(c->state, cfg->use_quotient));
+                    PGH_RUN(scalars_plain(true, false));
+                }
+                PGH_RUN_HIP(hipEventRecord(c->ev_err, c->ss));
+                PGH_RUN(wait_host(c->ev_err, "the re-evaluated residual of a paused step"));
+                flag = reinterpret_cast<const int*>(c->state_host)[6];
+                if (flag == 0) {
+                    PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));
+                    PGH_RUN(stages());         // the speculated stages may have seen the pause and done nothing
+                }
+            }
+            if (flag != 0) {
                 converged = true;              // whatever the stages above computed is never folded into an iterate
                 break;
             }
         }
-        PGH_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));      // quotient and done flag of the previous step; its residual has read y[nxt]
-        rc = absorbing ? pgh_dist_combine_absorb(g, &v_p, cfg->deg_local, cfg->lam_local, &v_y[nxt], &v_xg_local, c->state)
-                       : pgh_dist_combine(g, &v_p, cfg->alpha, &v_y[nxt], &v_xg_local, c->state);
-        if (rc != 0) break;
-        PGH_HIP(hipEventRecord(c->ev_fin, c->main));
-        // ---- X: the next gather vector over xGMI
-        PGH_HIP(hipStreamWaitEvent(c->xs, c->ev_fin, 0));
-        if (c->hot > 0) {
-            if ((rc = gather_part(c, 0, 0, c->hot, c->xs)) != 0) break;
-            PGH_HIP(hipEventRecord(c->ev_hot, c->xs));
-            if ((rc = gather_part(c, cold_region, c->hot, c->live, c->xs)) != 0) break;
+        PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));      // quotient and done flag of the previous step; its residual has read y[nxt]
+        if (fused) {
+            PGH_RUN(dist_combine_fused(g, c->p_norm, cfg->alpha, c->y[nxt], c->xg_local, c->y[cur], g->bsf.deg_int, c->state, c->aux, spmv + 1, c->red));
         } else {
-            if ((rc = gather_part(c, 0, 0, c->live, c->xs)) != 0) break;
-            PGH_HIP(hipEventRecord(c->ev_hot, c->xs));
+            PGH_RUN(absorbing ? pgh_dist_combine_absorb(g, &v_p, cfg->deg_local, cfg->lam_local, &v_y[nxt], &v_xg_local, c->state)
+                              : pgh_dist_combine(g, &v_p, cfg->alpha, &v_y[nxt], &v_xg_local, c->state));
         }
-        PGH_HIP(hipEventRecord(c->ev_cold, c->xs));
+        PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));
+        // ---- X: the next gather vector over xGMI
+        PGH_RUN_HIP(hipStreamWaitEvent(c->xs, c->ev_fin, 0));
+        if (c->hot > 0) {
+            PGH_RUN(gather_part(c, 0, 0, c->hot, c->xs));
+            PGH_RUN_HIP(hipEventRecord(c->ev_hot, c->xs));
+            PGH_RUN(gather_part(c, cold_region, c->hot, c->live, c->xs));
+        } else {
+            PGH_RUN(gather_part(c, 0, 0, c->live, c->xs));
+            PGH_RUN_HIP(hipEventRecord(c->ev_hot, c->xs));
+        }
+        PGH_RUN_HIP(hipEventRecord(c->ev_cold, c->xs));
         cur = nxt;
         ++spmv;
         ++it;
         const bool check = it < max_iters && kind != PGH_ERR_ITERS && it % cfg->end_modulo == 0;
         // ---- S: the scalars of the step
-        PGH_HIP(hipStreamWaitEvent(c->ss, c->ev_fin, 0));
+        PGH_RUN_HIP(hipStreamWaitEvent(c->ss, c->ev_fin, 0));
         {
             StreamSwap on_scalars(c->ss);
-            if ((rc = comm_all_reduce(c, c->state + 2, 1, ncclFloat64, ncclSum, c->s, c->ss)) != 0) break;
-            if ((rc = pgh_dist_close_sum(c->state, cfg->use_quotient)) != 0) break;
-            if (check) {
-                if ((rc = pgh_dist_residual(local_kind, &v_y[cur], &v_y[1 - cur], c->state)) != 0) break;
-                if ((rc = comm_all_reduce(c, c->state + 1, 1, ncclFloat64, err_op, c->s, c->ss)) != 0) break;
-                if ((rc = pgh_dist_close_err(c->state, kind, cfg->tol, cfg->n_global)) != 0) break;
-                PGH_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->ss));
+            if (fused) {
+                // ONE all-reduce: {S, T, D, R'}; the first step of a run has no prediction and takes the separate residual
+                PGH_RUN(comm_all_reduce(c, c->red, 4, ncclFloat64, ncclSum, c->s, c->ss));
+                PGH_RUN(dist_close_fused(c->state, c->aux, c->red, spmv, check ? 1 : 0, kind, cfg->tol, cfg->n_global, cfg->use_quotient,
+                                         cfg->alpha, 1.0 - cfg->alpha));
+                if (spmv == 1) PGH_RUN(scalars_plain(check, false));
+                else if (check) PGH_RUN_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->ss));
+            } else {
+                PGH_RUN(scalars_plain(check, true));
             }
         }
-        PGH_HIP(hipEventRecord(c->ev_err, c->ss));
+        PGH_RUN_HIP(hipEventRecord(c->ev_err, c->ss));
         if (it >= max_iters) break;
         if (check) {
             pending = true;
-            if ((rc = stages()) != 0) break;   // speculate: the next step's first two stages need the exchange only
+            PGH_RUN(stages());                 // speculate: the next step's first two stages need the exchange only
             staged = true;
         }
     }
-    if (rc == 0) {
-        PGH_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));
-        PGH_HIP(hipStreamWaitEvent(c->main, c->ev_cold, 0));
-        if (pending && !converged) {
-            rc = bounded_wait(c->ev_err, "the residual all-reduce of the last step");
-            if (rc == 0) converged = reinterpret_cast<const int*>(c->state_host)[6] != 0;
+    PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));
+    PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_cold, 0));
+    if (pending && !converged) {
+        PGH_RUN(wait_host(c->ev_err, "the scalar all-reduce of the last step"));
+        int flag = reinterpret_cast<const int*>(c->state_host)[6];
+        if (flag == 2) {                       // (a pause at the very last check: same re-evaluation as inside the loop)
+            res->flags |= 1;
+            {
+                StreamSwap on_scalars(c->ss);
+                PGH_RUN(dist_resume(c->state));
+                PGH_RUN(pgh_dist_close_sum(c->state, cfg->use_quotient));
+                PGH_RUN(scalars_plain(true, false));
+            }
+            PGH_RUN_HIP(hipEventRecord(c->ev_err, c->ss));
+            PGH_RUN(wait_host(c->ev_err, "the re-evaluated residual of a paused step"));
+            PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));
+            flag = reinterpret_cast<const int*>(c->state_host)[6];
         }
+        converged = flag != 0;
     }
-    if (rc == 0) {
-        PGH_HIP(hipEventRecord(t_end, c->main));
-        PGH_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->main));
-        PGH_HIP(hipEventRecord(c->ev_host, c->main));
-        rc = bounded_wait(c->ev_host, "the loop state of the last step");
-    }
-    if (rc != 0) {
-        (void)hipEventDestroy(t_begin);
-        (void)hipEventDestroy(t_end);
-        return rc;
-    }
+    PGH_RUN_HIP(hipEventRecord(scope.t_end, c->main));
+    PGH_RUN_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->main));
+    PGH_RUN_HIP(hipEventRecord(c->ev_host, c->main));
+    PGH_RUN(wait_host(c->ev_host, "the loop state of the last step"));
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, t_begin, t_end);
-    (void)hipEventDestroy(t_begin);
-    (void)hipEventDestroy(t_end);
+    (void)hipEventElapsedTime(&ms, scope.t_begin, scope.t_end);
     const int steps = reinterpret_cast<const int*>(c->state_host)[7];
     PGH_CHECK(steps == spmv, "pgh_dist_ppr_run: the device ran a different number of steps than the host enqueued");
     const double scale = c->state_host[0];
     const double factor = scale * (cfg->preserve_norm ? norm : 1.0);           // abstract_filters.py:63-64
     k_scale_into<<<grid_of(n_local), 256, 0, c->main>>>(c->y[cur], ranks_local->data, n_local, factor);
-    PGH_HIP(hipGetLastError());
-    PGH_HIP(hipStreamSynchronize(c->main));
+    PGH_RUN_HIP(hipGetLastError());
     res->iterations = it;
     res->spmv_count = spmv;
     res->converged = converged ? 1 : 0;
@@ -517,5 +656,189 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     res->gather_slots = (int64_t)c->nb * c->live;
     res->column_blocks = c->nb;
     res->split_regions = c->hot > 0 ? 1 : 0;
+    if (fused || (res->flags & 1)) res->flags |= 2;        // bit 1: the run used the in-kernel residual (bit 0: and paused it once)
+    scope.ok = true;
+    return 0;
+#undef PGH_RUN
+#undef PGH_RUN_HIP
+}
+
+// ClosedFormGraphFilter (abstract_filters.py:152-270, taylor form) on a partition, the whole run behind one call like
+// pgh_dist_ppr_run: result = sum_k coeffs[k - 1] (M^T)^(k-1) p with ConvergenceManager's rule on the change of the result
+// (convergence.py:77-101).  Same three queues: C = block partial sums -> phase A -> finish with the accumulate epilogue
+// (pgh_dist_combine_poly), X = the split all-gather of the term's gather slice, S = ONE all-reduce of the change per term and the
+// stopping rule on the device; the host reads the flag of term k after it has enqueued the first two stages of term k + 1.
+// HeatKernel / PageRankClosed pass their coefficient schedules (adhoc.py:83-84,113-116); coefficients past num_coeffs are 0.
+extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, const double* coeffs, int32_t num_coeffs,
+                                 pgh_vec_t result_local, const pgh_dist_cfg* cfg, pgh_dist_result* res) {
+    PGH_CHECK(g && c && p_local && result_local && cfg && res && (coeffs != nullptr || num_coeffs == 0), "pgh_dist_poly_run: null argument");
+    PGH_CHECK(p_local->n == g->n_cols && result_local->n == g->n_cols && p_local->data != result_local->data,
+              "pgh_dist_poly_run: vectors must have the slice's length");
+    PGH_CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
+    PGH_TRY(ensure_init());
+    Runtime& r = rt();
+    memset(res, 0, sizeof(*res));
+    PGH_HIP(hipStreamSynchronize(r.stream));
+    PGH_TRY(prepare_graph(c, g, nullptr));
+    const int64_t n_local = c->n_local;
+    const int kind = cfg->err_kind;
+    const int linf = kind == PGH_ERR_LINF ? 1 : 0;
+    const ncclRedOp_t err_op = linf ? ncclMax : ncclSum;
+    auto coeff = [&](int it) -> double { return (it >= 1 && it <= num_coeffs) ? coeffs[it - 1] : 0.0; };
+    StreamSwap on_main(c->main);
+    RunScope scope{c, g};
+    pgh_vec_s v_xg_full{c->xg_full, c->n_xg, false}, v_xg_local{c->xg_local, n_local, false};
+    pgh_vec_s v_y[2] = {{c->y[0], n_local, false}, {c->y[1], n_local, false}};
+    int rc = 0;
+#define PGH_RUN(expr)                                    \
+    do {                                                 \
+        if ((rc = (expr)) != 0) return rc;               \
+    } while (0)
+#define PGH_RUN_HIP(expr)                                                                                       \
+    do {                                                                                                        \
+        const hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (pgh_dist_poly_run)"); \
+    } while (0)
+    auto wait_host = [&](hipEvent_t ev, const char* what) -> int {
+        const int w = bounded_wait(ev, what);
+        if (w != 0) scope.stalled = true;
+        return w;
+    };
+    // ---- prologue: global L1 norm (and, for the max rule, the global max |p|) in one round trip each
+    double local[2] = {0.0, 0.0};
+    PGH_RUN(pgh_reduce(PGH_ABSSUM, p_local, &local[0]));
+    if (linf && n_local > 0) {
+        double hi = 0.0, lo = 0.0;
+        PGH_RUN(pgh_reduce(PGH_MAX, p_local, &hi));
+        PGH_RUN(pgh_reduce(PGH_MIN, p_local, &lo));
+        local[1] = fmax(fabs(hi), fabs(lo));
+    }
+    PGH_RUN_HIP(hipMemcpyAsync(c->state, local, sizeof(local), hipMemcpyHostToDevice, c->main));
+    PGH_RUN(comm_all_reduce(c, c->state, 1, ncclFloat64, ncclSum, c->s, c->main));
+    if (linf) PGH_RUN(comm_all_reduce(c, c->state + 1, 1, ncclFloat64, ncclMax, c->s, c->main));
+    PGH_RUN_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(local), hipMemcpyDeviceToHost, c->main));
+    PGH_RUN_HIP(hipEventRecord(c->ev_host, c->main));
+    PGH_RUN(wait_host(c->ev_host, "the all-reduce of the personalization's norm"));
+    const double norm = c->state_host[0];
+    if (norm == 0.0) {
+        PGH_RUN(pgh_vec_copy(result_local, p_local));
+        res->iterations = 0;
+        scope.ok = true;
+        return 0;
+    }
+    const float p_absmax = (float)c->state_host[1] / (float)norm;
+    const double c1 = coeff(1);
+    k_div_into<<<grid_of(n_local), 256, 0, c->main>>>(p_local->data, c->y[0], n_local, (float)norm);        // term_1 = p / norm
+    PGH_RUN(pgh_ewise_vs(PGH_MUL, &v_y[0], c1, 0, result_local));                                           // result_1 = c_1 term_1
+    PGH_RUN(pgh_dist_prescale(g, &v_y[0], &v_xg_local));
+    const int64_t cold_region = (int64_t)c->nb * c->hot;
+    auto exchange = [&](hipStream_t st, bool events) -> int {
+        if (c->hot > 0) {
+            PGH_TRY(gather_part(c, 0, 0, c->hot, st));
+            if (events) PGH_HIP(hipEventRecord(c->ev_hot, st));
+            PGH_TRY(gather_part(c, cold_region, c->hot, c->live, st));
+        } else {
+            PGH_TRY(gather_part(c, 0, 0, c->live, st));
+            if (events) PGH_HIP(hipEventRecord(c->ev_hot, st));
+        }
+        if (events) PGH_HIP(hipEventRecord(c->ev_cold, st));
+        return 0;
+    };
+    PGH_RUN(exchange(c->main, false));
+    PGH_RUN(pgh_dist_state_init(c->state));
+    for (hipEvent_t ev : {c->ev_hot, c->ev_cold, c->ev_err}) PGH_RUN_HIP(hipEventRecord(ev, c->main));
+    PGH_RUN_HIP(hipEventCreate(&scope.t_begin));
+    PGH_RUN_HIP(hipEventCreate(&scope.t_end));
+    PGH_RUN_HIP(hipEventRecord(scope.t_begin, c->main));
+    // the change of the first term decides only whether the loop stops at iteration 2: |result_1 - 0| = |c_1| sum |p / norm| = |c_1|
+    double delta = fabs(c1) * (linf ? (double)p_absmax : 1.0);
+    if (kind == PGH_ERR_MABS) delta /= (double)cfg->n_global;
+    auto stages = [&]() -> int {
+        PGH_HIP(hipStreamWaitEvent(c->main, c->ev_hot, 0));
+        PGH_TRY(pgh_dist_partial_stage(g, &v_xg_full, c->state, 1));
+        PGH_HIP(hipStreamWaitEvent(c->main, c->ev_cold, 0));
+        PGH_TRY(pgh_dist_partial_stage(g, &v_xg_full, c->state, 2));
+        return 0;
+    };
+    const int max_iters = cfg->max_iters;
+    int it = 2, spmv = 0, cur = 0;             // `it` = the iteration has_converged is asked about
+    bool converged = false, pending = false, staged = false;
+    if (it < max_iters && kind != PGH_ERR_ITERS && it % cfg->end_modulo == 0 && delta <= cfg->tol) converged = true;
+    while (!converged && it < max_iters) {
+        const int nxt = 1 - cur;
+        if (!staged) PGH_RUN(stages());
+        staged = false;
+        if (pending) {
+            PGH_RUN(wait_host(c->ev_err, "the all-reduce of the previous term's change"));
+            pending = false;
+            if (reinterpret_cast<const int*>(c->state_host)[6] != 0) {
+                converged = true;
+                break;
+            }
+        }
+        PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));      // the done flag of the previous term; its all-reduce has read state[1]
+        PGH_RUN(pgh_dist_combine_poly(g, &v_y[cur], &v_y[nxt], 1.0, 0.0, result_local, coeff(it), linf, &v_xg_local, c->state));
+        PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));
+        PGH_RUN_HIP(hipStreamWaitEvent(c->xs, c->ev_fin, 0));
+        PGH_RUN(exchange(c->xs, true));
+        cur = nxt;
+        ++spmv;
+        ++it;
+        const bool check = it < max_iters && kind != PGH_ERR_ITERS && it % cfg->end_modulo == 0;
+        PGH_RUN_HIP(hipStreamWaitEvent(c->ss, c->ev_fin, 0));
+        {
+            StreamSwap on_scalars(c->ss);
+            PGH_RUN(pgh_dist_close_sum(c->state, 0));                // counts the step
+            if (check) {
+                PGH_RUN(comm_all_reduce(c, c->state + 1, 1, ncclFloat64, err_op, c->s, c->ss));
+                PGH_RUN(pgh_dist_close_err(c->state, kind, cfg->tol, cfg->n_global));
+                PGH_RUN_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->ss));
+            }
+        }
+        PGH_RUN_HIP(hipEventRecord(c->ev_err, c->ss));
+        if (it >= max_iters) break;
+        if (check) {
+            pending = true;
+            PGH_RUN(stages());
+            staged = true;
+        }
+    }
+    PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));
+    PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_cold, 0));
+    if (pending && !converged) {
+        PGH_RUN(wait_host(c->ev_err, "the all-reduce of the last term's change"));
+        converged = reinterpret_cast<const int*>(c->state_host)[6] != 0;
+    }
+    PGH_RUN_HIP(hipEventRecord(scope.t_end, c->main));
+    PGH_RUN_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->main));
+    PGH_RUN_HIP(hipEventRecord(c->ev_host, c->main));
+    PGH_RUN(wait_host(c->ev_host, "the loop state of the last term"));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, scope.t_begin, scope.t_end);
+    const int steps = reinterpret_cast<const int*>(c->state_host)[7];
+    PGH_CHECK(steps == spmv, "pgh_dist_poly_run: the device ran a different number of steps than the host enqueued");
+    if (cfg->preserve_norm && norm != 1.0) {
+        pgh_vec_s v_res{result_local->data, n_local, false};
+        PGH_RUN(pgh_ewise_vs(PGH_MUL, &v_res, norm, 0, &v_res));
+    }
+    PGH_RUN_HIP(hipGetLastError());
+    res->iterations = it;
+    res->spmv_count = spmv;
+    res->converged = converged ? 1 : 0;
+    res->last_error = spmv > 0 ? c->state_host[6] : delta;
+    res->loop_ms = (double)ms;
+    res->exchange_bytes = 4LL * c->live * c->bpr * (c->world - 1);
+    res->gather_slots = (int64_t)c->nb * c->live;
+    res->column_blocks = c->nb;
+    res->split_regions = c->hot > 0 ? 1 : 0;
+    scope.ok = true;
+    return 0;
+#undef PGH_RUN
+#undef PGH_RUN_HIP
+}
+
+// upper bound of every host wait on a collective from now on (seconds; <= 0: back to PGH_DIST_TIMEOUT_S / 600 s)
+extern "C" int pgh_dist_set_timeout(double seconds) {
+    wait_limit_s() = seconds > 0.0 ? seconds : default_wait_limit_s();
     return 0;
 }

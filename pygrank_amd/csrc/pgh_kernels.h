@@ -58,7 +58,8 @@ struct LoopState {
 // by the ratio measured / predicted of the previous step: it then misses by 1e-10 .. 1e-12.  The kernel evaluates
 //     R' = sum_i |y_i * inv' - x_i * scale|   and   D = sum_i sign(y_i * inv' - x_i * scale) * y_i
 // against the predicted inv', and the close takes  R = R' + (inv - inv') * D : exact but for rows whose term changes sign
-// between inv' and inv, each wrong by less than 2 |inv - inv'| y_i -- in total less than 2 |inv - inv'| sum(y).  The close
+// between inv' and inv, each wrong by less than 2 |inv - inv'| |y_i| -- in total less than 2 |inv - inv'| sum(y) while no y_i is
+// negative (a workgroup that meets a negative y_i -- a signed personalization -- reports R' = NaN, which pauses).  The close
 // therefore knows the residual to within that bound; when the tolerance lies inside it (or anything is not finite) the
 // step is PAUSED: the host re-evaluates it with the separate residual kernel and goes on without the fusion.  The stopping
 // decision is the one the separate kernel would take, always.  The kernel also accumulates T = sum_j deg_j * y_j for the
@@ -574,6 +575,14 @@ void pb_destroy(PbFormat& p);
 int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, int stage = 0);
 
 void pb_set_residual(const ResParams* rp);   // the next pb_launch_finish<EPI_AXPBY> evaluates the residual in the kernel (ResParams)
+// the partitioned loop's fused scalars (pgh_spmv.hip; driven by pgh_dist.hip)
+bool dist_can_fuse(const pgh_graph_s* g);
+int dist_aux_init(LoopAux* aux);
+int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float* y_local, float* xg_local_out, const float* x_prev,
+                       const float* deg_local, double* state, LoopAux* aux, int step, double* red);
+int dist_close_fused(double* state, LoopAux* aux, const double* red, int step, int check, int err_kind, double tol, int64_t n_global,
+                     int use_quotient, double a, double b);
+int dist_resume(double* state);
 int bsf_ensure_degrees(pgh_graph_s* g);       // BsfFormat::deg_int
 
 template <int MODE>

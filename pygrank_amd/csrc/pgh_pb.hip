@@ -266,10 +266,15 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     double sum_y = 0.0, delta = 0.0;
     // in-kernel residual: R' and D against the predicted quotient, T for the next prediction (first step: sum(p) in D)
     double res_r = 0.0, res_d = 0.0, res_t = 0.0;
+    // (the close bounds what the predicted quotient can cost by 2 |inv - inv'| sum_i |y_i| and takes sum(y) for that sum: a
+    // NEGATIVE y -- a signed personalization -- voids the bound, so such a workgroup reports R' = NaN and the close pauses the
+    // fusion: the separate residual kernel decides, as for every other value it cannot vouch for)
+    bool res_neg = false;
     const double inv_pred = RES && !rp.first ? rp.aux->pred_inv[rp.step & 1] : 1.0;
     const bool res_first = RES && rp.first != 0;
     auto residual_row = [&](float y, float x_prev, float deg, float pv) __attribute__((always_inline)) {
         res_t += (double)deg * (double)y;
+        res_neg = res_neg || y < 0.f;
         if (res_first) {
             res_d += (double)pv;
         } else {
@@ -311,7 +316,9 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     auto flush = [&](int where) __attribute__((always_inline)) {
         if (RES) {
             // four sums at once: one barrier pair
-            const double v0 = wave_reduce_sum(sum_y), v1 = wave_reduce_sum(res_r), v2 = wave_reduce_sum(res_d), v3 = wave_reduce_sum(res_t);
+            const double v0 = wave_reduce_sum(sum_y), v2 = wave_reduce_sum(res_d), v3 = wave_reduce_sum(res_t);
+            double v1 = wave_reduce_sum(res_r);
+            if (__any(res_neg)) v1 = __longlong_as_double(0x7ff8000000000000LL);
             if ((tid & 63) == 0) {
                 s_red[tid >> 6] = v0;
                 s_red[WAVES + (tid >> 6)] = v1;
@@ -327,6 +334,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             }
             __syncthreads();
             sum_y = 0.0, res_r = 0.0, res_d = 0.0, res_t = 0.0;
+            res_neg = false;
             return;
         }
         double v = wave_reduce_sum(sum_y);

@@ -1230,8 +1230,131 @@ extern "C" int pgh_dist_close_err(double* state, int32_t kind, double tol, int64
     return 0;
 }
 
+// ---- the partitioned loop with the residual evaluated inside the finish kernel (k_pb_finish<..., RES>; pgh_dist.hip drives it) ----
+// Each rank evaluates its share of S = sum(y), T = sum(deg * y), D and R' (ResParams, pgh_kernels.h) against the SAME predicted
+// quotient (the prediction is made from all-reduced values, so every rank holds the same bits); ONE 4-scalar all-reduce per
+// iteration then lets every rank close the step identically -- instead of all-reduce(sum) -> quotient -> residual launch ->
+// all-reduce(residual) -> stopping rule.
+namespace {
+
+__global__ __launch_bounds__(WG) void k_dist_fold4(double* __restrict__ red, const double* __restrict__ d_state, const double* p0,
+                                                    const double* p1, const double* p2, const double* p3, int count) {
+    __shared__ double s16[16];
+    if (reinterpret_cast<const LoopState*>(d_state)->done) return;
+    const double* const arr[4] = {p0, p1, p2, p3};
+    double out[4];
+    fold_partials_multi<4>(arr, count, out, s16);
+    if (threadIdx.x < 4) red[threadIdx.x] = out[threadIdx.x];
+}
+
+// red = {S, T, D, R'} summed over the ranks; the same close_outcome / close_commit as the single-GPU loop
+__global__ void k_dist_close_fused(double* d, PendingClose pc, const double* __restrict__ red) {
+    LoopState* st = reinterpret_cast<LoopState*>(d);
+    if (st->done) return;
+    d[5] = st->scale;                       // the previous iterate's quotient (what a separate residual launch reads)
+    st->sum = red[0];                       // kept when the close pauses: the re-evaluation's pgh_dist_close_sum starts from it
+    const CloseOutcome o = close_outcome(pc, red[0], 0.0, red[3], red[2], red[1]);
+    close_commit(pc, o);
+    if (pc.check && o.verdict != 2) d[6] = o.err;
+}
+
+__global__ void k_dist_resume(double* d) {
+    LoopState* st = reinterpret_cast<LoopState*>(d);
+    if (st->done == 2) st->done = 0;
+}
+
+__global__ void k_aux_init(LoopAux* aux) {
+    aux->pred_inv[0] = aux->pred_inv[1] = 1.0;
+    aux->pred_raw[0] = aux->pred_raw[1] = 0.0;
+    aux->sum_p = 0.0;
+    aux->worst_miss = 0.0;
+}
+
+}  // namespace
+
 namespace pgh {
 PendingClose& pending_close_slot() { return g_pending_close; }
+
+bool dist_can_fuse(const pgh_graph_s* g) {
+    static const bool fuse_env = getenv("PGH_FUSED_RES") == nullptr || atoi(getenv("PGH_FUSED_RES")) != 0;
+    return fuse_env && g != nullptr && g->bsf.enabled && g->bsf.pb.enabled && g->degrees != nullptr;
+}
+
+int dist_aux_init(LoopAux* aux) {
+    k_aux_init<<<1, 1, 0, rt().stream>>>(aux);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+// the finish stage of step `step` (PageRank) with the in-kernel residual: y, the next gather slice, and this rank's
+// {S, T, D, R'} in red[0..3] (device)
+int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float* y_local, float* xg_local_out, const float* x_prev,
+                       const float* deg_local, double* state, LoopAux* aux, int step, double* red) {
+    BsfFormat& f = g->bsf;
+    Runtime& r = rt();
+    PGH_CHECK(f.pb.enabled && deg_local != nullptr, "dist_combine_fused: the slice has no cold image / no degrees");
+    EpiParams ep{};
+    ep.a = alpha;
+    ep.b = 1.0 - alpha;
+    ep.v = p_local;
+    ep.y = y_local;
+    if (f.src_scale != nullptr) {
+        ep.xg_out = xg_local_out;
+        ep.src_scale = f.src_scale + g->row_begin;
+    }
+    ResParams rp{};
+    rp.x_prev = x_prev;
+    rp.deg = deg_local;
+    rp.aux = aux;
+    rp.part_r = r.d_partials + 2 * kMaxPartials;
+    rp.part_d = r.d_partials + 3 * kMaxPartials;
+    rp.part_t = r.d_partials + 4 * kMaxPartials;
+    rp.step = step;
+    rp.first = step == 1 ? 1 : 0;
+    pb_set_residual(&rp);
+    int count = 0;
+    const int rc = bsf_launch_combine<EPI_AXPBY>(g, ep, reinterpret_cast<const LoopState*>(state), &count);
+    pb_set_residual(nullptr);               // consumed by the launch; never left armed behind a failed one
+    if (rc != 0) return rc;
+    if (f.src_scale == nullptr) PGH_HIP(hipMemcpyAsync(xg_local_out, y_local, sizeof(float) * (size_t)g->n_cols, hipMemcpyDeviceToDevice, r.stream));
+    {
+        ProfScope prof(PGH_K_FINAL);
+        k_dist_fold4<<<1, WG, 0, r.stream>>>(red, state, r.d_partials, rp.part_t, rp.part_d, rp.part_r, count);
+    }
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+// closes step `step` from the all-reduced {S, T, D, R'}: quotient, next prediction, and -- when `check` -- the stopping rule
+// (verdict "paused" = state done == 2: the caller re-evaluates the step with pgh_dist_residual, dist_resume first)
+int dist_close_fused(double* state, LoopAux* aux, const double* red, int step, int check, int err_kind, double tol, int64_t n_global,
+                     int use_quotient, double a, double b) {
+    PendingClose pc{};
+    pc.state = reinterpret_cast<LoopState*>(state);
+    pc.tol = tol;
+    pc.n = (long long)n_global;
+    pc.use_quotient = use_quotient;
+    pc.check = step == 1 ? 0 : check;        // the first step has no prediction: its residual comes from the separate kernel
+    pc.err_kind = err_kind;
+    pc.active = 1;
+    pc.res_mode = step == 1 ? 2 : 1;
+    pc.step = step;
+    pc.aux = aux;
+    pc.a = a;
+    pc.b = b;
+    {
+        ProfScope prof(PGH_K_FINAL);
+        k_dist_close_fused<<<1, 1, 0, rt().stream>>>(state, pc, red);
+    }
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+int dist_resume(double* state) {
+    k_dist_resume<<<1, 1, 0, rt().stream>>>(state);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
 }  // namespace pgh
 
 // =================================================================================================
@@ -1480,8 +1603,9 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             rp.first = k == 1 ? 1 : 0;
             pb_set_residual(&rp);                  // consumed by the finish launch of this step
         }
-        PGH_TRY((launch_step<MODE>(g, epk, use_xg ? g->bsf.xg : xin, g_state, &count,
-                                   (overlap && k > 1) ? g_ev_closed : nullptr)));
+        const int rc_step = launch_step<MODE>(g, epk, use_xg ? g->bsf.xg : xin, g_state, &count, (overlap && k > 1) ? g_ev_closed : nullptr);
+        if (fused) pb_set_residual(nullptr);     // consumed by the finish launch; never left armed behind a step that failed before it
+        PGH_TRY(rc_step);
         count_seen = count;
         const PendingClose pc = make_close(k);
         hipStream_t main_stream = r.stream;

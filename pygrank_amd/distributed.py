@@ -143,11 +143,11 @@ class _Buffers:
         top = torch.tensor([int(live.max())], dtype=torch.int64, device=device)
         dist.all_reduce(top, op=dist.ReduceOp.MAX)
         self.live = min(self.blk, (int(top.item()) + 63) // 64 * 64)
-        bases = np.zeros(8, dtype=np.int64)
+        self.bases = np.zeros(8, dtype=np.int64)
         for b in range(self.nb):
             r, j = divmod(b, self.bpr)
-            bases[b] = (j * world + r) * self.live
-        L.check(lib.pgh_graph_set_gather_bases(g._h, bases.ctypes.data_as(C.c_void_p)))
+            self.bases[b] = (j * world + r) * self.live
+        self.apply_bases(g)
         n_xg = self.nb * self.live + _HOT_PAD
         self.xg_full = torch.zeros(n_xg, dtype=torch.float32, device=device)
         self.xg_local = torch.zeros(n_local, dtype=torch.float32, device=device)
@@ -174,6 +174,13 @@ class _Buffers:
         # the big exchange and the scalar reductions use communicators of their own so that neither queues behind the other
         # (one exchange communicator per process, not per graph: PGH_DIST_SINGLE_COMM=1 keeps everything on the default one)
         self.pg_exchange = _exchange_group(dist, world)
+
+    def apply_bases(self, g):
+        """Tells the graph where every block's slice starts inside THIS object's gather vector.  The bases are state of the graph,
+        not of the buffers: the engine's own loop (pgh_dist_ppr_run) lays the same graph out its own way -- two regions -- on every
+        run, so a Python-driven run re-applies its layout every time it starts (cached buffers used to read a torch
+        gather vector through the native split bases after an engine run on the same graph)."""
+        L.check(L.lib().pgh_graph_set_gather_bases(g._h, self.bases.ctypes.data_as(C.c_void_p)))
 
     def _pieces(self, j, lo, hi):
         """views of slots [lo, hi) of the blocks j, bpr + j, ... (one per rank) inside xg_full, and of this rank's slice"""
@@ -240,11 +247,13 @@ def _native_comm(dist, device):
     """The engine's own RCCL communicator pair (csrc/pgh_dist.hip), created once per process: rank 0 draws the ids, the bytes
     travel through torch.distributed, every rank joins.  None when the run is not RCCL-on-GPU (gloo / CPU tests, the host
     double) or PGH_DIST_NATIVE=0 asks for the Python-driven loop."""
-    mode = os.environ.get("PGH_DIST_NATIVE", "1")
+    mode = os.environ.get("PGH_DIST_NATIVE", "auto")
     if device.type != "cuda" or mode == "0" or not L.runtime_name().startswith("hip:"):
         return None
     world, rank = dist.get_world_size(), dist.get_rank()
     key = (world, rank)
+    if key in _NATIVE_COMMS:
+        return _NATIVE_COMMS[key]
     if dist.get_backend() != "nccl":
         # the engine's loop with the collectives done by the HOST through torch.distributed (pgh_comm_create_external): opt-in
         # (PGH_DIST_NATIVE=external) -- every exchange then goes through host memory; what it is for: running the engine-driven
@@ -281,7 +290,63 @@ def _native_comm(dist, device):
                 lib.pgh_comm_destroy(handle)
             handle = None
         _NATIVE_COMMS[key] = handle
+        # More than one rank over RCCL: the engine's loop (two communicators of its own on three streams) proves itself on a small
+        # graph first -- against the Python-driven loop over torch's communicator, with short bounded waits -- and every rank takes
+        # the Python-driven loop when it does not (this pool has no multi-GPU box, so the first N > 1 run of the engine
+        # loop is a user's, or the driver's scaling bench).  PGH_DIST_NATIVE=1 skips the probe, =0 never uses the engine loop.
+        if handle is not None and world > 1 and mode == "auto":
+            PREFLIGHT[key] = _preflight(dist, device, rank, world, lib)
+            if PREFLIGHT[key] != "ok":
+                sys.stderr.write(f"[pygrank_amd.distributed] rank {rank}: the engine-driven RCCL loop failed its probe ({PREFLIGHT[key]}); "
+                                 "using the Python-driven loop\n")
+                # a communicator with a stalled collective cannot be destroyed without waiting for it: it is abandoned
+                _NATIVE_COMMS[key] = None
     return _NATIVE_COMMS[key]
+
+
+PREFLIGHT = {}          # (world, rank) -> "ok" | what went wrong: the engine loop's probe of this process (bench.py reports it)
+
+
+def _preflight(dist, device, rank, world, lib):
+    """One small partitioned PageRank through the engine's loop and through the Python-driven loop; "ok" when every rank got
+    the same iteration count and ranks from both.  Collective.  Host waits on the engine's collectives are bounded by
+    PGH_DIST_PREFLIGHT_S (default 30 s) while it runs."""
+    import torch
+    verdict = "ok"
+    L.check(lib.pgh_dist_set_timeout(float(os.environ.get("PGH_DIST_PREFLIGHT_S", "30"))))
+    try:
+        pg = rmat_partitioned(16, 8, rank, world, seed=0)
+        rng = np.random.default_rng(1)
+        p_new = np.zeros(pg.n)
+        p_new[rng.choice(pg.n, 20, replace=False)] = 1.0                        # in NEW ids: the same on every rank
+        p_local = DeviceVector.from_host(p_new[pg.row_begin:pg.row_begin + pg.n_local])
+        kw = dict(alpha=0.85, tol=1e-6, error_type="l1", max_iters=200)
+        native = DistributedPageRank(**kw)
+        native._dist, native._device = dist, device
+        try:
+            got = np.asarray(native._rank_native(pg, p_local, _NATIVE_COMMS[(world, rank)], lib), dtype=np.float64)
+        except Exception as exc:                                                   # EngineError of a bounded wait, ...
+            got, verdict = None, f"engine loop: {str(exc)[:200]}"
+        staged = DistributedPageRank(**kw)
+        staged._native_formula = False
+        want = np.asarray(staged.rank(pg, p_local), dtype=np.float64)
+        if got is not None:
+            top = torch.tensor([float(np.max(np.abs(want), initial=0.0))], dtype=torch.float64, device=device)
+            dist.all_reduce(top, op=dist.ReduceOp.MAX)
+            if native.iteration != staged.iteration:
+                verdict = f"iterations differ: engine {native.iteration}, staged {staged.iteration}"
+            elif float(np.max(np.abs(got - want), initial=0.0)) > 1e-6 * float(top.item()):
+                verdict = "ranks differ between the engine loop and the staged loop"
+        pg.graph.destroy()
+    except Exception as exc:
+        verdict = f"probe: {str(exc)[:200]}"
+    finally:
+        lib.pgh_dist_set_timeout(0.0)
+    agree = torch.tensor([1 if verdict == "ok" else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    if int(agree.item()) == 0 and verdict == "ok":
+        verdict = "failed on another rank"
+    return verdict
 
 
 _EXTERNAL_KEEPALIVE = []
@@ -393,6 +458,7 @@ class DistributedPageRank:
             self._buffers = _Buffers(pgraph, device, dist)
             self._buffers_for = pgraph
         bufs = self._buffers
+        bufs.apply_bases(g)
         kind = self._KINDS[self.error_type]
         tol = 0.0 if self.tol is None else max(self.tol, self.epsilon)          # convergence.py:101
         # One stream for everything: the engine launches on it (pgh_set_stream) and torch.distributed orders its
@@ -447,6 +513,7 @@ class DistributedPageRank:
         self.last_error, self.loop_ms = float(res.last_error), float(res.loop_ms)
         self.exchange = dict(exchange_bytes_per_iteration_per_gpu=int(res.exchange_bytes), gather_vector_slots=int(res.gather_slots),
                              column_blocks=int(res.column_blocks), split_regions=bool(res.split_regions),
+                             in_kernel_residual=bool(res.flags & 2), paused_in_kernel_residual=bool(res.flags & 1),
                              driver="engine (RCCL)" if self._dist.get_backend() == "nccl" else "engine (host collectives)")
         if res.iterations == 0:
             return p_local
@@ -623,6 +690,7 @@ class DistributedClosedFormFilter:
     term): functional coverage of the filters next to PageRank, not a tuned path."""
 
     _KINDS = DistributedPageRank._KINDS
+    _native_formula = True            # False (on an instance): always the staged Python loop
 
     def __init__(self, coefficient, tol=1e-6, error_type="mabs", max_iters=100, end_modulo=1, preserve_norm=True,
                  epsilon=float(np.finfo(np.float32).eps)):
@@ -635,9 +703,13 @@ class DistributedClosedFormFilter:
         import torch.distributed as dist
         lib, g = L.lib(), pgraph.graph
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        comm = _native_comm(dist, device) if self._native_formula else None
+        if comm is not None:
+            return self._rank_native(pgraph, p_local, comm, lib, dist)
         if self._buffers is None or self._buffers_for is not pgraph:
             self._buffers, self._buffers_for = _Buffers(pgraph, device, dist), pgraph
         bufs = self._buffers
+        bufs.apply_bases(g)
         # one stream for the engine's launches and torch's collectives / tensor ops (as DistributedPageRank.rank)
         if device.type == "cuda":
             if getattr(self, "_stream", None) is None:
@@ -655,7 +727,35 @@ class DistributedClosedFormFilter:
                 L.check(lib.pgh_sync())
                 L.check(lib.pgh_set_stream(None))
 
+    def _rank_native(self, pgraph, p_local, comm, lib, dist):
+        """The whole run as ONE engine call (pgh_dist_poly_run): the coefficient schedule is evaluated up front."""
+        coeffs, c = [], None
+        for it in range(1, max(int(self.max_iters), 2)):
+            c = float(self.coefficient(c, it))
+            coeffs.append(c)
+        arr = (C.c_double * len(coeffs))(*coeffs)
+        cfg = L.DistCfg(alpha=0.0, tol=0.0 if self.tol is None else max(float(self.tol), self.epsilon), n_global=int(pgraph.n),
+                        err_kind=self._KINDS[self.error_type], max_iters=int(self.max_iters), end_modulo=int(self.end_modulo),
+                        use_quotient=0, preserve_norm=1 if self.preserve_norm else 0, every_row=1, deg_local=None, lam_local=None)
+        res = L.DistResult()
+        out = DeviceVector.empty(pgraph.n_local)
+        t0 = time.perf_counter()
+        L.check(lib.pgh_dist_poly_run(pgraph.graph._h, comm, p_local._h, C.cast(arr, C.c_void_p), len(coeffs), out._h, C.byref(cfg),
+                                      C.byref(res)))
+        self.elapsed = time.perf_counter() - t0
+        self.iteration, self.spmv, self.converged = int(res.iterations), int(res.spmv_count), bool(res.converged)
+        self.last_error, self.loop_ms = float(res.last_error), float(res.loop_ms)
+        self.exchange = dict(exchange_bytes_per_iteration_per_gpu=int(res.exchange_bytes), gather_vector_slots=int(res.gather_slots),
+                             column_blocks=int(res.column_blocks), split_regions=bool(res.split_regions),
+                             driver="engine (RCCL)" if dist.get_backend() == "nccl" else "engine (host collectives)")
+        if res.iterations == 0:
+            return p_local
+        if not self.converged and self.error_type != "iters" and self.iteration >= self.max_iters:
+            raise Exception("Could not converge within " + str(self.max_iters) + " iterations")
+        return out
+
     def _rank_on_stream(self, pgraph, p_local, bufs, dist, lib, g, device, torch):
+        self.exchange = dict(driver="python (torch.distributed)")
         kind = self._KINDS[self.error_type]
         tol = 0.0 if self.tol is None else max(self.tol, self.epsilon)
         linf = 1 if kind == L.ERR_LINF else 0

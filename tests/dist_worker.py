@@ -47,6 +47,14 @@ def main():
         out = ranker.rank(graph, DeviceVector.from_host(p_local))
         results[name + "_ranks"] = np.asarray(out)
         results[name + "_iters"] = ranker.iteration
+        results[name + "_fused"] = int(bool(ranker.exchange.get("in_kernel_residual", False)))
+    # a personalization with NEGATIVE entries: the in-kernel residual cannot vouch for its bound and hands the step to the separate
+    # kernel (paused once), the result is the oracle's all the same
+    signs = np.where(np.arange(graph.n) % 3 == 0, -0.25, 1.0)
+    ranker = DistributedPageRank(alpha=0.85, error_type="l1", tol=1e-6, max_iters=500)
+    out = ranker.rank(graph, DeviceVector.from_host((p_old * signs)[perm[lo:lo + graph.n_local]]))
+    results["signed_ranks"], results["signed_iters"] = np.asarray(out), ranker.iteration
+    results["signed_paused"] = int(bool(ranker.exchange.get("paused_in_kernel_residual", False)))
     results["driver"] = str(ranker.exchange.get("driver"))
     results["split_regions"] = int(bool(ranker.exchange.get("split_regions")))
     from pygrank_amd.distributed import DistributedAbsorbingWalks
@@ -61,6 +69,16 @@ def main():
         out = algo.rank(graph, DeviceVector.from_host(p_local))
         results[name + "_ranks"] = np.asarray(out)
         results[name + "_iters"] = algo.iteration
+    results["closed_form_driver"] = str(algo.exchange.get("driver"))
+    # the gather bases are state of the GRAPH: a Python-driven filter that keeps its buffers must find its own layout again after
+    # an engine-driven run on the same graph has laid the gather vector out in two regions
+    staged = DistributedHeatKernel(t=3, error_type="l1", tol=1e-7, max_iters=100)
+    staged._native_formula = False
+    first = np.asarray(staged.rank(graph, DeviceVector.from_host(p_local)))
+    DistributedPageRank(alpha=0.85, error_type="l1", tol=1e-6, max_iters=500).rank(graph, DeviceVector.from_host(p_local))
+    again = np.asarray(staged.rank(graph, DeviceVector.from_host(p_local)))
+    results["interleaved_equal"] = int(np.array_equal(first, again))
+    results["interleaved_vs_engine"] = float(np.max(np.abs(first - results["heat_ranks"]), initial=0.0))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), perm=perm, lo=lo, n_local=graph.n_local, nnz=graph.graph.nnz, **results)
     dist.barrier()
     dist.destroy_process_group()

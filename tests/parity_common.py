@@ -73,3 +73,59 @@ def tol_is_fp32_safe(kwargs):
         return True
     tol = kwargs.get("tol", 1e-6)
     return tol is not None and tol >= EPS32
+
+
+def partition_personalization(n):
+    """The personalization tests/dist_worker.py feeds every rank (ORIGINAL ids)."""
+    rng = np.random.default_rng(1)
+    p_old = np.zeros(n)
+    p_old[rng.choice(n, 20, replace=False)] = rng.random(20) + 0.5
+    return p_old
+
+
+def assemble(parts, perm, key, n):
+    """The ranks' slices (new id order) of result `key`, un-permuted into ORIGINAL ids."""
+    got = np.zeros(n)
+    for part in parts:
+        lo, m = int(part["lo"]), int(part["n_local"])
+        got[perm[lo:lo + m]] = part[key]
+    return got
+
+
+def check_partition_against_oracle(parts, scale, ef):
+    """What tests/dist_worker.py wrote, rank by rank, against the oracle on the un-partitioned graph: PageRank under the three
+    stopping rules / without the quotient / from a personalization with negative entries, AbsorbingWalks, HeatKernel,
+    PageRankClosed -- <= 1e-6 and equal iteration counts -- and the interleaved run of a Python-driven filter."""
+    import scipy.sparse as sp
+    from oracle import rmat_np
+    n = 1 << scale
+    perm = parts[0]["perm"]
+    assert sorted(perm.tolist()) == list(range(n))                     # a permutation, identical on every rank
+    for part in parts[1:]:
+        assert np.array_equal(part["perm"], perm)
+    A = rmat_np.rmat_csr(scale, ef, seed=0)
+    assert sum(int(part["nnz"]) for part in parts) == A.nnz
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    p_old = partition_personalization(n)
+    runs = {"l1": (p_old, dict(error_type="l1", tol=1e-6, max_iters=500)), "mabs": (p_old, dict(error_type="mabs", tol=1e-7, max_iters=500)),
+            "iters": (p_old, dict(error_type="iters", max_iters=21)),
+            "noquot": (p_old, dict(error_type="linf", tol=1e-7, max_iters=500, use_quotient=False)),
+            "signed": (p_old * np.where(np.arange(n) % 3 == 0, -0.25, 1.0), dict(error_type="l1", tol=1e-6, max_iters=500))}
+    for name, (p, kw) in runs.items():
+        want, want_iters = orc.pagerank(M, p, alpha=0.85, eps=EPS32, **kw)
+        assert all(int(part[name + "_iters"]) == want_iters for part in parts), (name, [int(part[name + "_iters"]) for part in parts], want_iters)
+        assert rel_linf(assemble(parts, perm, name + "_ranks", n), want) <= 1e-6, name
+    # AbsorbingWalks (adhoc.py:157-169) and the closed-form filters (abstract_filters.py:215-230) on the same partition
+    others = (("absorb", lambda: orc.absorbing_walks(M, p_old, alpha=0.85, error_type="l1", tol=1e-6, max_iters=500, eps=EPS32)),
+              ("heat", lambda: orc.heat_kernel(M, p_old, t=3, error_type="l1", tol=1e-7, max_iters=100, eps=EPS32)),
+              ("heat_mabs", lambda: orc.heat_kernel(M, p_old, t=5, error_type="mabs", tol=1e-9, max_iters=100, eps=EPS32)),
+              ("closed", lambda: orc.pagerank_closed(M, p_old, alpha=0.85, error_type="linf", tol=1e-5, max_iters=300, eps=EPS32)))
+    for name, ref in others:
+        want, want_iters = ref()
+        assert all(int(part[name + "_iters"]) == want_iters for part in parts), (name, [int(part[name + "_iters"]) for part in parts], want_iters)
+        assert rel_linf(assemble(parts, perm, name + "_ranks", n), want) <= 1e-6, name
+    # a Python-driven filter that keeps its buffers, an engine-driven run in between: the same bits before and after (ADVICE r3)
+    assert all(int(part["interleaved_equal"]) == 1 for part in parts)
+    want_heat = others[1][1]()[0]
+    assert all(float(part["interleaved_vs_engine"]) <= 1e-6 * np.max(np.abs(want_heat)) for part in parts)
+    return A, M
