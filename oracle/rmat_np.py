@@ -69,8 +69,14 @@ def rmat_edges(scale, edge_factor=16, a=0.57, b=0.19, c=0.19, seed=0, first_edge
 def rmat_csr(scale, edge_factor=16, a=0.57, b=0.19, c=0.19, seed=0):
     """scipy CSR adjacency (fp64 weights = edge multiplicities), rows = sources."""
     n = 1 << scale
-    src, dst = rmat_edges(scale, edge_factor, a, b, c, seed)
-    A = sp.coo_array((np.ones(len(src)), (src, dst)), shape=(n, n)).tocsr()
+    total = n * edge_factor
+    chunk = 1 << 25                              # edges per pass: bounds the temporaries of the hash at full bench sizes
+    A = None
+    for first in range(0, total, chunk):
+        src, dst = rmat_edges(scale, edge_factor, a, b, c, seed, first_edge=first, num_edges=min(chunk, total - first))
+        part = sp.coo_array((np.ones(len(src)), (src, dst)), shape=(n, n)).tocsr()
+        part.sum_duplicates()
+        A = part if A is None else (A + part).tocsr()
     A.sum_duplicates()
     A.sort_indices()
     return A

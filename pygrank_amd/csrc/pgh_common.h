@@ -254,6 +254,9 @@ struct BsfFormat {
                                     // keeps the hot prefixes and the cold parts of the blocks in two regions, pgh_graph_set_gather_bases_split)
     int64_t   xg_base[8] = {0};     // first element of every block's slice inside the gather vector (default b * blk_size;
                                     // a partitioned run lays the slices out as the trimmed all-gather delivers them)
+    int       lg_live = 0, lg_hot = 0;   // partitioned runs driven by the engine (pgh_dist.hip): the epilogue writes this rank's slice of the
+                                    // next gather vector PACKED for the exchange -- [local block][lg_hot] | [local block][lg_live - lg_hot] --
+                                    // instead of by row (0: by row; pgh_graph_set_gather_bases puts it back)
     int       xg_live = 0;          // > 0: the engine's own gather vector `xg` stores only the first xg_live slots of every
                                     // block (xg_base[b] = b * xg_live): a smaller cold region for the same gathers
     float*    xg = nullptr;         // [n_src_pad + 1] gather-source work buffer (new space)

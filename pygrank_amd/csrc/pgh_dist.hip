@@ -215,18 +215,17 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     c->hot = split ? (int)hot_all : 0;
     c->n_local = g->n_cols;
     PGH_CHECK(blk * nb == g->n_rows && c->n_local == (int64_t)c->bpr * blk, "pgh_dist_ppr_run: the slice does not match the block layout");
+    // A rank keeps its slice of the next gather vector PACKED for the exchange -- the hot prefixes of its blocks one after the
+    // other, then their cold parts (dist_set_local_layout: the epilogue writes it that way) -- so every exchange is ONE all-gather
+    // per region however many blocks a rank owns, and block b = rank * bpr + j of the gathered vector starts at b * (region width).
     int64_t hot_bases[8] = {0}, cold_bases[8] = {0};
     for (int b = 0; b < nb; ++b) {
-        const int rk = b / c->bpr, j = b % c->bpr;
-        if (split) {
-            hot_bases[b] = ((int64_t)j * c->world + rk) * c->hot;
-            cold_bases[b] = (int64_t)nb * c->hot + ((int64_t)j * c->world + rk) * (live - c->hot);
-        } else {
-            hot_bases[b] = ((int64_t)j * c->world + rk) * live;
-        }
+        hot_bases[b] = (int64_t)b * (split ? c->hot : live);
+        cold_bases[b] = (int64_t)nb * c->hot + (int64_t)b * (live - c->hot);
     }
     if (split) PGH_TRY(pgh_graph_set_gather_bases_split(g, hot_bases, cold_bases));
     else PGH_TRY(pgh_graph_set_gather_bases(g, hot_bases));
+    PGH_TRY(dist_set_local_layout(g, (int)live, c->hot));      // (after the bases: setting them resets the layout)
     const int64_t n_xg = (int64_t)nb * live + 32768;          // + the hot cache's read-ahead past a short block
     if (c->graph != nullptr && c->n_xg == n_xg && c->buf_local == c->n_local) {
         c->graph = g;
@@ -246,13 +245,13 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     return 0;
 }
 
-// all-gather of slots [lo, hi) of every block of this rank's slice into `region` ([j][rank][hi - lo]) on stream `st`
+// all-gather of slots [lo, hi) of every block of this rank's slice into `region` ([rank][j][hi - lo]) on stream `st`: ONE collective
+// (the slice is stored packed, lo == 0: from its start, else from the cold part on)
 int gather_part(pgh_comm_s* c, int64_t region, int lo, int hi, hipStream_t st) {
     if (hi <= lo) return 0;
-    const int64_t len = hi - lo;
-    for (int j = 0; j < c->bpr; ++j)
-        PGH_TRY(comm_all_gather(c, c->xg_local + (int64_t)j * c->blk + lo, c->xg_full + region + (int64_t)j * c->world * len, (size_t)len, c->x, st));
-    return 0;
+    const int64_t len = (int64_t)(hi - lo) * c->bpr;
+    const int64_t from = lo == 0 ? 0 : (int64_t)c->bpr * lo;
+    return comm_all_gather(c, c->xg_local + from, c->xg_full + region, (size_t)len, c->x, st);
 }
 
 struct StreamSwap {          // the engine launches on rt().stream: point it at one of the communicator's queues for a scope
@@ -534,6 +533,7 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     };
     const int max_iters = cfg->max_iters;
     int it = 1, spmv = 0;                      // `it` = ConvergenceManager.iteration of the pending has_converged call
+    int fused_partials = 0;
     bool pending = false, staged = false, converged = false;
     while (it < max_iters) {                   // convergence.py:86
         const int nxt = 1 - cur;
@@ -571,7 +571,7 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
         }
         PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));      // quotient and done flag of the previous step; its residual has read y[nxt]
         if (fused) {
-            PGH_RUN(dist_combine_fused(g, c->p_norm, cfg->alpha, c->y[nxt], c->xg_local, c->y[cur], g->bsf.deg_int, c->state, c->aux, spmv + 1, c->red));
+            PGH_RUN(dist_combine_fused(g, c->p_norm, cfg->alpha, c->y[nxt], c->xg_local, c->y[cur], g->bsf.deg_int, c->state, c->aux, spmv + 1, &fused_partials));
         } else {
             PGH_RUN(absorbing ? pgh_dist_combine_absorb(g, &v_p, cfg->deg_local, cfg->lam_local, &v_y[nxt], &v_xg_local, c->state)
                               : pgh_dist_combine(g, &v_p, cfg->alpha, &v_y[nxt], &v_xg_local, c->state));
@@ -598,6 +598,7 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
             StreamSwap on_scalars(c->ss);
             if (fused) {
                 // ONE all-reduce: {S, T, D, R'}; the first step of a run has no prediction and takes the separate residual
+                PGH_RUN(dist_fold_fused(c->state, c->red, fused_partials));
                 PGH_RUN(comm_all_reduce(c, c->red, 4, ncclFloat64, ncclSum, c->s, c->ss));
                 PGH_RUN(dist_close_fused(c->state, c->aux, c->red, spmv, check ? 1 : 0, kind, cfg->tol, cfg->n_global, cfg->use_quotient,
                                          cfg->alpha, 1.0 - cfg->alpha));

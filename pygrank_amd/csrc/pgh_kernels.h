@@ -26,17 +26,21 @@ struct EpiParams {
     const float* src_scale;
     int          xg_blk;   // trimmed gather vector (BsfFormat::xg_live): slots per block in the id space ...
     int          xg_live;  // ... and slots per block actually stored (0 = stored in full, slot = row)
+    int          xg_hot;   // > 0 (partitioned runs): the first xg_hot slots of every block are stored block after block at the front,
+    int          xg_cold;  // ... the slots [xg_hot, xg_live) block after block from position xg_cold on (two contiguous exchange regions)
 };
 
 // position of internal id `row` inside a gather vector that keeps only the first `live` slots of every block of `blk`
 // ids (never-referenced sources sort last inside a block and are not stored); -1 = not stored
-__device__ __forceinline__ int xg_slot(int row, int blk, int live) {
+// (hot > 0: the split form of a partitioned run -- [block][hot] first, then [block][live - hot] from `cold` on)
+__device__ __forceinline__ int xg_slot(int row, int blk, int live, int hot = 0, int cold = 0) {
     if (live == 0) return row;
     int b = 0;
 #pragma unroll
     for (int k = 1; k < 8; ++k) b += (row >= k * blk) ? 1 : 0;
     const int loc = row - b * blk;
-    return loc < live ? b * live + loc : -1;
+    if (loc >= live) return -1;
+    return loc < hot ? b * hot + loc : cold + b * (live - hot) + (loc - hot);
 }
 
 // Device-resident loop state (ConvergenceManager on the device, convergence.py:77-101).
@@ -164,7 +168,7 @@ __device__ __forceinline__ EpiOps epi_load(const EpiParams& ep, int row) {
         o.lam = ld_off(ep.lam, at);
     }
     if (ep.xg_out != nullptr) {
-        o.slot = xg_slot(row, ep.xg_blk, ep.xg_live);
+        o.slot = xg_slot(row, ep.xg_blk, ep.xg_live, ep.xg_hot, ep.xg_cold);
         o.src = ld_off(ep.src_scale, at);     // unconditional: a load under a divergent branch serialises the loads around it
     }
     if (MODE == EPI_POLY) o.r_old = ld_off(const_cast<const float*>(ep.r), at);
@@ -577,9 +581,13 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, 
 void pb_set_residual(const ResParams* rp);   // the next pb_launch_finish<EPI_AXPBY> evaluates the residual in the kernel (ResParams)
 // the partitioned loop's fused scalars (pgh_spmv.hip; driven by pgh_dist.hip)
 bool dist_can_fuse(const pgh_graph_s* g);
+// where a partitioned run keeps this rank's slice of the next gather vector: packed for the exchange (BsfFormat::lg_*), 0 = by row
+int dist_set_local_layout(pgh_graph_s* g, int live, int hot);
+int dist_prescale_packed(pgh_graph_s* g, const float* x_local, float* xg_local_out);
 int dist_aux_init(LoopAux* aux);
 int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float* y_local, float* xg_local_out, const float* x_prev,
-                       const float* deg_local, double* state, LoopAux* aux, int step, double* red);
+                       const float* deg_local, double* state, LoopAux* aux, int step, int* num_partials);
+int dist_fold_fused(double* state, double* red, int num_partials);
 int dist_close_fused(double* state, LoopAux* aux, const double* red, int step, int check, int err_kind, double tol, int64_t n_global,
                      int use_quotient, double a, double b);
 int dist_resume(double* state);

@@ -947,9 +947,51 @@ extern "C" int pgh_ppr_step_dist(pgh_graph_t g, pgh_vec_t xg_full, double x_scal
 }
 
 // gather vector slice of a local vector: out = x_local * src_scale[row_begin ...] (the first iterate of a partitioned run)
+namespace {
+// the layout a partitioned run asked for (BsfFormat::lg_*) in an epilogue's parameters
+inline void local_layout(const BsfFormat& f, EpiParams& ep) {
+    if (f.lg_live <= 0) return;
+    const int local_blocks = (int)((f.n_out + f.blk_size - 1) / f.blk_size);
+    ep.xg_blk = (int)f.blk_size;
+    ep.xg_live = f.lg_live;
+    ep.xg_hot = f.lg_hot;
+    ep.xg_cold = local_blocks * f.lg_hot;
+}
+__global__ void k_prescale_packed(const float* __restrict__ x, const float* __restrict__ scale, int64_t n, float* __restrict__ out, int blk,
+                                  int live, int hot, int cold) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = xg_slot((int)i, blk, live, hot, cold);
+        if (slot >= 0) out[slot] = scale != nullptr ? x[i] * scale[i] : x[i];
+    }
+}
+}  // namespace
+
+namespace pgh {
+int dist_set_local_layout(pgh_graph_s* g, int live, int hot) {
+    g->bsf.lg_live = live;
+    g->bsf.lg_hot = hot;
+    return 0;
+}
+// out = x_local * source scale in the layout the run asked for (by row when none was set)
+int dist_prescale_packed(pgh_graph_s* g, const float* x_local, float* xg_local_out) {
+    const BsfFormat& f = g->bsf;
+    const float* scale = (f.enabled && f.src_scale != nullptr) ? f.src_scale + g->row_begin : nullptr;
+    const int64_t n = g->n_cols;
+    if (n == 0) return 0;
+    EpiParams ep{};
+    local_layout(f, ep);
+    int64_t blocks = (n + 255) / 256;
+    const int64_t cap = (int64_t)rt().num_cus * 16;
+    k_prescale_packed<<<(int)(blocks > cap ? cap : blocks), 256, 0, rt().stream>>>(x_local, scale, n, xg_local_out, ep.xg_blk, ep.xg_live, ep.xg_hot, ep.xg_cold);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+}  // namespace pgh
+
 extern "C" int pgh_dist_prescale(pgh_graph_t g, pgh_vec_t x_local, pgh_vec_t xg_local_out) {
     PGH_CHECK(g && x_local && xg_local_out && x_local->n == g->n_cols && xg_local_out->n == g->n_cols,
               "pgh_dist_prescale: length mismatch");
+    if (g->bsf.enabled && g->bsf.lg_live > 0) return dist_prescale_packed(g, x_local->data, xg_local_out->data);
     if (g->bsf.enabled && g->bsf.src_scale != nullptr) {
         pgh_vec_s sv;
         sv.data = g->bsf.src_scale + g->row_begin;
@@ -1031,6 +1073,7 @@ extern "C" int pgh_graph_set_gather_bases(pgh_graph_t g, const int64_t* bases) {
         PGH_CHECK(bases[b] >= 0 && bases[b] < (1LL << 31), "pgh_graph_set_gather_bases: base out of range");
         f.xg_base[b] = f.xg_base_cold[b] = bases[b];
     }
+    f.lg_live = f.lg_hot = 0;          // a caller that lays the gather vector out itself exchanges slices stored by row
     return 0;
 }
 
@@ -1097,10 +1140,11 @@ extern "C" int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, 
     if (f.src_scale != nullptr) {
         ep.xg_out = xg_local_out->data;
         ep.src_scale = f.src_scale + g->row_begin;
+        local_layout(f, ep);
     }
     int count = 0;
     PGH_TRY((bsf_launch_combine<EPI_AXPBY>(g, ep, reinterpret_cast<const LoopState*>(state), &count)));
-    if (f.src_scale == nullptr) PGH_TRY(pgh_vec_copy(xg_local_out, y_local));
+    if (f.src_scale == nullptr) PGH_TRY(dist_prescale_packed(g, y_local->data, xg_local_out->data));
     k_dist_fold<<<1, WG, 0, r.stream>>>(state, r.d_partials, count, 0, 2);
     PGH_HIP(hipGetLastError());
     return 0;
@@ -1125,10 +1169,11 @@ extern "C" int pgh_dist_combine_absorb(pgh_graph_t g, pgh_vec_t p_local, pgh_vec
     if (f.src_scale != nullptr) {
         ep.xg_out = xg_local_out->data;
         ep.src_scale = f.src_scale + g->row_begin;
+        local_layout(f, ep);
     }
     int count = 0;
     PGH_TRY((bsf_launch_combine<EPI_ABSORB>(g, ep, reinterpret_cast<const LoopState*>(state), &count)));
-    if (f.src_scale == nullptr) PGH_TRY(pgh_vec_copy(xg_local_out, y_local));
+    if (f.src_scale == nullptr) PGH_TRY(dist_prescale_packed(g, y_local->data, xg_local_out->data));
     k_dist_fold<<<1, WG, 0, r.stream>>>(state, r.d_partials, count, 0, 2);
     PGH_HIP(hipGetLastError());
     return 0;
@@ -1156,10 +1201,11 @@ extern "C" int pgh_dist_combine_poly(pgh_graph_t g, pgh_vec_t term_local, pgh_ve
     if (f.src_scale != nullptr) {
         ep.xg_out = xg_local_out->data;
         ep.src_scale = f.src_scale + g->row_begin;
+        local_layout(f, ep);
     }
     int count = 0;
     PGH_TRY((bsf_launch_combine<EPI_POLY>(g, ep, reinterpret_cast<const LoopState*>(state), &count)));
-    if (f.src_scale == nullptr) PGH_TRY(pgh_vec_copy(xg_local_out, term_out_local));
+    if (f.src_scale == nullptr) PGH_TRY(dist_prescale_packed(g, term_out_local->data, xg_local_out->data));
     k_dist_fold<<<1, WG, 0, r.stream>>>(state, r.d_partials + kMaxPartials, count, err_linf ? 1 : 0, 1);
     PGH_HIP(hipGetLastError());
     return 0;
@@ -1287,9 +1333,9 @@ int dist_aux_init(LoopAux* aux) {
 }
 
 // the finish stage of step `step` (PageRank) with the in-kernel residual: y, the next gather slice, and this rank's
-// {S, T, D, R'} in red[0..3] (device)
+// partials of {S, T, D, R'} (dist_fold_fused folds them)
 int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float* y_local, float* xg_local_out, const float* x_prev,
-                       const float* deg_local, double* state, LoopAux* aux, int step, double* red) {
+                       const float* deg_local, double* state, LoopAux* aux, int step, int* num_partials) {
     BsfFormat& f = g->bsf;
     Runtime& r = rt();
     PGH_CHECK(f.pb.enabled && deg_local != nullptr, "dist_combine_fused: the slice has no cold image / no degrees");
@@ -1301,6 +1347,7 @@ int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float
     if (f.src_scale != nullptr) {
         ep.xg_out = xg_local_out;
         ep.src_scale = f.src_scale + g->row_begin;
+        local_layout(f, ep);
     }
     ResParams rp{};
     rp.x_prev = x_prev;
@@ -1316,10 +1363,20 @@ int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float
     const int rc = bsf_launch_combine<EPI_AXPBY>(g, ep, reinterpret_cast<const LoopState*>(state), &count);
     pb_set_residual(nullptr);               // consumed by the launch; never left armed behind a failed one
     if (rc != 0) return rc;
-    if (f.src_scale == nullptr) PGH_HIP(hipMemcpyAsync(xg_local_out, y_local, sizeof(float) * (size_t)g->n_cols, hipMemcpyDeviceToDevice, r.stream));
+    if (f.src_scale == nullptr) PGH_TRY(dist_prescale_packed(g, y_local, xg_local_out));
+    PGH_HIP(hipGetLastError());
+    *num_partials = count;
+    return 0;
+}
+
+// this rank's {S, T, D, R'} of the finish launch above -> red[0..3] (on the caller's scalar queue: it is not part of the step's
+// critical path, the exchange of the gather slices starts right behind the finish kernel)
+int dist_fold_fused(double* state, double* red, int num_partials) {
+    Runtime& r = rt();
     {
         ProfScope prof(PGH_K_FINAL);
-        k_dist_fold4<<<1, WG, 0, r.stream>>>(red, state, r.d_partials, rp.part_t, rp.part_d, rp.part_r, count);
+        k_dist_fold4<<<1, WG, 0, r.stream>>>(red, state, r.d_partials, r.d_partials + 4 * kMaxPartials, r.d_partials + 3 * kMaxPartials,
+                                             r.d_partials + 2 * kMaxPartials, num_partials);
     }
     PGH_HIP(hipGetLastError());
     return 0;

@@ -53,37 +53,46 @@ class GraphFilter(NodeRanking):
         pass
 
     def rank(self, graph=None, personalization=None, warm_start=None, graph_dropout=0, *args, **kwargs):
-        personalization = to_signal(graph, personalization)                       # abstract_filters.py:49
-        self._prepare(personalization)
-        personalization = self.personalization_transform(personalization)
-        raw = personalization.np
-        norm = raw.abssum() if isinstance(raw, DeviceVector) else backend.sum(backend.abs(raw))   # :52
+        """abstract_filters.py:44-65.  personalization -> signal -> (transform) -> L1-normalised seed vector; the iterate starts
+        as a copy of it (or of warm_start); the preprocessor turns the graph into the operator; the loop runs until the
+        convergence manager says stop; preserve_norm gives the input's L1 norm back.  Whenever the configuration allows it the
+        whole loop is ONE engine call (_fused_rank / _fused_loop); the hook protocol below serves everything else."""
+        seed_signal = to_signal(graph, personalization)
+        self._prepare(seed_signal)
+        signal = self.personalization_transform(seed_signal)
+        raw = signal.np
+        norm = raw.abssum() if isinstance(raw, DeviceVector) else backend.sum(backend.abs(raw))
         if norm == 0:
-            return personalization                                                # :53-54
+            return signal                       # nothing to spread: the reference hands the (all-zero) signal back
         if warm_start is None and graph_dropout == 0:
-            # :55-56 folded into the engine's first pass over the operands (pgh_loop_cfg.in_norm / start_from_p)
-            ranks = self._fused_rank(personalization, norm, *args, **kwargs)
-            if ranks is not None:
-                return ranks
-        personalization = to_signal(personalization, personalization.np / norm)   # :55
-        ranks = to_signal(personalization,
-                          backend.copy(personalization.np) if warm_start is None else warm_start)   # :56
-        if warm_start is not None:
-            # the reference never writes into the caller's warm_start (every step builds a fresh array); the device loops
-            # update their iterate in place, so they get a copy
-            ranks = to_signal(personalization, backend.copy(ranks.np))
-        M = self.preprocessor(self._prepare_graph(personalization.graph, personalization, *args, **kwargs))
+            # normalisation and start vector folded into the engine's first pass over the operands (pgh_loop_cfg.in_norm / start_from_p)
+            fused = self._fused_rank(signal, norm, *args, **kwargs)
+            if fused is not None:
+                return fused
+        signal = to_signal(signal, signal.np / norm)
+        # the reference never writes into the caller's warm_start (every step builds a fresh array); the device loops update
+        # their iterate in place, so the start vector is always a copy
+        ranks = to_signal(signal, backend.copy(signal.np if warm_start is None else to_signal(signal, warm_start).np))
+        M = self.preprocessor(self._prepare_graph(signal.graph, signal, *args, **kwargs))
         self.convergence.start()
-        out_scale = norm if self.preserve_norm else 1.0
-        if graph_dropout == 0 and self._fused_loop(M, personalization, ranks, out_scale, *args, **kwargs):
+        if graph_dropout == 0 and self._fused_loop(M, signal, ranks, norm if self.preserve_norm else 1.0, *args, **kwargs):
             return ranks
-        self._start(backend.graph_dropout(M, graph_dropout), personalization, ranks, *args, **kwargs)
-        while not self.convergence.has_converged(ranks.np):                       # :60 the hot loop
-            self._step(backend.graph_dropout(M, graph_dropout), personalization, ranks, *args, **kwargs)
-        self._end(backend.graph_dropout(M, graph_dropout), personalization, ranks, *args, **kwargs)
-        if self.preserve_norm:                                                    # :63-64
+        self._host_driven_loop(M, signal, ranks, graph_dropout, args, kwargs)
+        if self.preserve_norm:
             ranks.np = ranks.np * norm
         return ranks
+
+    def _host_driven_loop(self, M, signal, ranks, dropout_rate, args, kwargs):
+        """The hook protocol of abstract_filters.py:57-62 for filters and configurations without a device loop: _start, then
+        _step until the convergence manager stops the loop, then _end -- each hook sees an operator whose entries were dropped
+        afresh (backend.graph_dropout draws a new mask per call; rate 0 returns the operator itself)."""
+        def operator():
+            return backend.graph_dropout(M, dropout_rate)
+        self._start(operator(), signal, ranks, *args, **kwargs)
+        keep_going = lambda: not self.convergence.has_converged(ranks.np)      # noqa: E731
+        while keep_going():
+            self._step(operator(), signal, ranks, *args, **kwargs)
+        self._end(operator(), signal, ranks, *args, **kwargs)
 
     # ---- hooks
     def _fused_rank(self, personalization, norm, *args, **kwargs):
@@ -557,16 +566,18 @@ class ClosedFormGraphFilter(GraphFilter):
             return self._active_dict[self.convergence.iteration]
         return backend.conv(ranks_power, M)
 
-    def _step(self, M, personalization, ranks, *args, **kwargs):                  # abstract_filters.py:248-256
-        self.coefficient = self._coefficient(self.coefficient)
-        ranks.np, self.ranks_power = self._recursion(ranks.np, self.ranks_power, self.coefficient)
-        self.ranks_power = self._retrieve_power(self.ranks_power, M)
+    def _step(self, M, personalization, ranks, *args, **kwargs):
+        """abstract_filters.py:248-256: draw the next coefficient, add the running term with it, propagate the term once more."""
+        weight = self.coefficient = self._coefficient(self.coefficient)
+        total, term = self._recursion(ranks.np, self.ranks_power, weight)
+        ranks.np = total
+        self.ranks_power = self._retrieve_power(term, M)
 
-    def _end(self, M, personalization, ranks, *args, **kwargs):                   # abstract_filters.py:258-267
-        del self.ranks_power
-        if self.coefficient_type == "chebyshev":
-            del self.prev_term
-        del self.coefficient
+    def _end(self, M, personalization, ranks, *args, **kwargs):
+        """abstract_filters.py:258-267: the per-run attributes of the expansion go away."""
+        per_run = ["ranks_power", "coefficient"] + (["prev_term"] if self.coefficient_type == "chebyshev" else [])
+        for name in per_run:
+            delattr(self, name)
         self._active_dict = None
 
     def _coefficient(self, previous_coefficient):

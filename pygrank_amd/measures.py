@@ -32,20 +32,21 @@ class Supervised(Measure):
         self.known_scores = known_scores
         self.exclude = exclude
 
-    def to_numpy(self, scores, normalization=False):        # supervised.py:36-47
-        if isinstance(scores, numbers.Number) and isinstance(self.known_scores, numbers.Number):
-            return backend.to_array([self.known_scores]), backend.to_array([scores])
-        if isinstance(scores, GraphSignal):
-            return to_signal(scores, self.known_scores).filter(exclude=self.exclude), \
-                scores.normalized(normalization).filter(exclude=self.exclude)
-        if isinstance(self.known_scores, GraphSignal):
-            return self.known_scores.filter(exclude=self.exclude), \
-                to_signal(self.known_scores, scores).normalized(normalization).filter(exclude=self.exclude)
+    def to_numpy(self, scores, normalization=False):
+        """supervised.py:36-47 -> (known, scores) as two aligned vectors.  Two plain numbers become one-element vectors.  When
+        either side is a graph signal it lends its graph to the other, the scores are (optionally) normalised and both lose the
+        excluded nodes; two plain vectors are taken as they are (nothing to exclude nodes by)."""
+        known = self.known_scores
+        if all(isinstance(value, numbers.Number) for value in (scores, known)):
+            return backend.to_array([known]), backend.to_array([scores])
+        anchor = next((value for value in (scores, known) if isinstance(value, GraphSignal)), None)
+        if anchor is not None:
+            aligned = (to_signal(anchor, known), to_signal(anchor, scores).normalized(normalization))
+            return tuple(signal.filter(exclude=self.exclude) for signal in aligned)
         if self.exclude is not None:
             raise Exception("Needs to parse graph signal scores or known_scores to be able to exclude specific nodes")
-        scores = backend.self_normalize(backend.to_array(scores, copy_array=True)) if normalization \
-            else backend.to_array(scores)
-        return backend.to_array(self.known_scores), scores
+        plain = backend.to_array(scores, copy_array=bool(normalization))
+        return backend.to_array(known), (backend.self_normalize(plain) if normalization else plain)
 
     def evaluate(self, scores):
         known, scores = self.to_numpy(scores)

@@ -39,6 +39,9 @@ def graphs():
 
 def _ensure_oracle_built():
     import subprocess
+    build = os.environ.get("PGH_ORACLE_BUILD_DIR")          # `make -C oracle asan-test`: the sanitizer builds of the checkers
+    if build:
+        return build
     build = os.path.join(ROOT, "oracle", "_build")
     if not (os.path.exists(os.path.join(build, "libpgh_host_oracle.so"))
             and os.path.exists(os.path.join(build, "liboracle_spmv.so"))):

@@ -70,6 +70,8 @@ def main():
         results[name + "_ranks"] = np.asarray(out)
         results[name + "_iters"] = algo.iteration
     results["closed_form_driver"] = str(algo.exchange.get("driver"))
+    from pygrank_amd.distributed import PREFLIGHT
+    results["preflight"] = str(PREFLIGHT.get((world, rank), "not run"))
     # the gather bases are state of the GRAPH: a Python-driven filter that keeps its buffers must find its own layout again after
     # an engine-driven run on the same graph has laid the gather vector out in two regions
     staged = DistributedHeatKernel(t=3, error_type="l1", tol=1e-7, max_iters=100)

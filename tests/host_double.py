@@ -5,7 +5,7 @@ import ctypes
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOUBLE = os.path.join(ROOT, "oracle", "_build", "libpgh_host_oracle.so")
+DOUBLE = os.path.join(os.environ.get("PGH_ORACLE_BUILD_DIR") or os.path.join(ROOT, "oracle", "_build"), "libpgh_host_oracle.so")
 _saved = None
 
 

@@ -101,6 +101,46 @@ def test_cfg2_full_size_runs_are_bit_identical(big):
         assert np.array_equal(out, runs[0][0])
 
 
+def test_cfg2_signed_personalization_hands_the_residual_back(big):
+    """A personalization with negative entries (the reference normalises by the abs-sum and takes any sign,
+    abstract_filters.py:55-56): the in-kernel residual bounds what its predicted quotient can cost by sum(y), which holds only
+    while no y is negative -- such a run must hand the decision to the separate residual kernel (one paused step) and still stop
+    where the oracle stops."""
+    from oracle import ref_loops as orc
+    pg = big["pg"]
+    p = big["seeds"](6)
+    hit = np.flatnonzero(p)
+    p[hit[::4]] = -0.25
+    ranker = pg.PageRank(alpha=0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+    got = np.asarray(ranker.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, want_iters = orc.pagerank(big["M"], p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
+    assert ranker.convergence.iteration == want_iters
+    assert _rel(got, want) <= 1e-6
+    assert ranker.last_loop["flags"] & 1, ranker.last_loop          # the fusion paused once, the separate kernel took over
+    # ... and the next run of a non-negative personalization is fused again, unpaused
+    q = big["seeds"](7)
+    ranker.rank(big["adj"], q.copy())
+    assert ranker.last_loop["flags"] & 1 == 0
+
+
+def test_cfg2_independent_matrix(big):
+    """The scale-23 parity tests above feed the oracle the engine's own downloaded matrix; here the matrix comes from the numpy
+    twin of the generator and the oracle's own normalisation (nothing of the engine in the reference result), VERDICT r3."""
+    import scipy.sparse as sp
+    from oracle import ref_loops as orc, rmat_np
+    pg = big["pg"]
+    A = rmat_np.rmat_csr(SCALE, EF, seed=0)
+    assert A.nnz == big["nnz"]
+    M = sp.csr_array(orc.normalize(A, "col", True))
+    del A
+    p = big["seeds"](0)
+    ranker = pg.PageRank(alpha=0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+    got = np.asarray(ranker.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, want_iters = orc.pagerank(M, p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
+    assert ranker.convergence.iteration == want_iters
+    assert _rel(got, want) <= 1e-6
+
+
 @pytest.mark.parametrize("coefficient_type", ["taylor", "chebyshev"])
 def test_cfg4_heat_kernel_scale23_vs_oracle(big, coefficient_type):
     from oracle import ref_loops as orc
@@ -198,9 +238,13 @@ def _run_cfg5_worker(tmp_path, mode, scale, ef, extra_env=None):
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:               # a free port per run: leftover or concurrent workers do not collide
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
-               MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.update(extra_env or {})
     res = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_worker_cfg5.py"), str(tmp_path), mode, str(scale), str(ef)],
                          capture_output=True, text=True, timeout=1500, env=env, cwd=root)

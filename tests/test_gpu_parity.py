@@ -195,6 +195,36 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
             assert int(part["signed_paused"]) == 1
 
 
+def test_two_gpus_over_rccl(gpu_engine, tmp_path):
+    """More than one rank over RCCL (boxes with >= 2 GPUs only; this pool's boxes have one, the driver's scaling node has eight):
+    the engine-driven loop must pass its own probe against the Python-driven loop (pygrank_amd.distributed._preflight), run every
+    partitioned filter against the oracle and say that it was the engine that drove RCCL."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: RCCL refuses two ranks on one device (the 2- and 4-rank engine loop runs through host collectives above)")
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    scale, ef = 18, 8
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_worker.py"), str(tmp_path), str(scale), str(ef)]
+    env = dict(os.environ, PYTHONPATH=root, PGH_TEST_ENGINE="hip", PGH_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PGH_PB="1", PGH_PB_FORCE="1", PGH_BLOCKS="4", PGH_PB_HEAVY="64", PGH_PB_HUBMAX="500", PGH_DIST_TIMEOUT_S="120")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2)]
+    from parity_common import check_partition_against_oracle
+    check_partition_against_oracle(parts, scale, ef)
+    assert [str(part["preflight"]) for part in parts] == ["ok", "ok"]
+    assert all(str(part["driver"]) == "engine (RCCL)" and str(part["closed_form_driver"]) == "engine (RCCL)" for part in parts)
+    assert all(int(part["l1_fused"]) == 1 and int(part["signed_paused"]) == 1 for part in parts)
+
+
 def test_randomised_stress(gpu_engine):
     """tools/stress_gpu.py for 20 s: random graph shapes (empty / tiny / hub rows / power-law / uniform / banded, integer and
     real weights) x layout switches (1-8 column blocks, relabelling, trimmed gather vector, propagation-blocking image)

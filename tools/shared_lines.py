@@ -1,6 +1,7 @@
 """Share of a host-mirror file's code lines that also occur, verbatim, in the reference file it cites (VERDICT r2 item 7:
 below 15 % per file).  Reported twice: all lines, and without the def / class / import lines whose text the mirrored API fixes.  Lines are stripped, docstrings and comments dropped, lines of 12 characters or fewer ignored.
-Needs /root/reference (this container only).   python tools/shared_lines.py [-v]"""
+Lines are LOGICAL lines with the layout removed (logical_lines below; --physical: the physical lines of round 3).
+Needs /root/reference (this container only).   python tools/shared_lines.py [-v] [--physical]"""
 import ast
 import io
 import os
@@ -44,15 +45,40 @@ def code_lines(path):
     return out
 
 
+def logical_lines(path):
+    """The file's LOGICAL lines (a statement wrapped over several physical lines is one), comments and docstrings dropped, all
+    layout removed (tokens joined, a blank only between two words): re-wrapping a copied statement does not hide it
+    (Supervised.to_numpy was the reference's text, re-wrapped)."""
+    src = open(path).read()
+    out, words, depth_doc = [], [], True
+    for tok in tokenize.generate_tokens(io.StringIO(src).readline):
+        if tok.type in (tokenize.COMMENT, tokenize.NL, tokenize.INDENT, tokenize.DEDENT, tokenize.ENDMARKER):
+            continue
+        if tok.type == tokenize.NEWLINE:
+            only_string = len(words) == 1 and words[0][0] == tokenize.STRING
+            text = ""
+            for kind, string in words:
+                if text and kind in (tokenize.NAME, tokenize.NUMBER) and (text[-1].isalnum() or text[-1] == "_"):
+                    text += " "
+                text += string
+            if not only_string and len(text) > 12:
+                out.append(text)
+            words = []
+            continue
+        words.append((tok.type, tok.string))
+    return out
+
+
 def main():
     verbose = "-v" in sys.argv
+    lines_of = logical_lines if "--physical" not in sys.argv else code_lines
     totals = {}
     for mine, theirs in PAIRS:
         ref_path = os.path.normpath(os.path.join(REF, theirs))
         if not os.path.exists(ref_path):
             continue
-        ref = set(code_lines(ref_path))
-        lines = code_lines(os.path.join(ROOT, mine))
+        ref = set(lines_of(ref_path))
+        lines = lines_of(os.path.join(ROOT, mine))
         hits = totals.setdefault(mine, (set(), len(lines)))[0]
         for index, line in enumerate(lines):
             if line in ref:
