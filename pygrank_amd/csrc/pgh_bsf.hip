@@ -361,7 +361,7 @@ __global__ void k_pair_scan(const float* __restrict__ v, const float* __restrict
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < span; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < n_pad) {
             v_int[i] = 0.f;
-            y0[i] = 0.f;
+            if (y0 != nullptr) y0[i] = 0.f;
         }
         if (xg != nullptr && i < xg_len) xg[i] = 0.f;
         if (i < n_orig && (v[i] != 0.f || (ranks != nullptr && ranks[i] != 0.f))) {
@@ -385,7 +385,7 @@ __global__ void k_pair_scatter(const int32_t* __restrict__ list, const int* __re
         if (in_norm != 1.f) a = a / in_norm;                // the same f32 division as the backend's `p / norm`
         if (start_from_v) b = a;
         v_int[i] = a;
-        y0[i] = b;
+        if (y0 != nullptr) y0[i] = b;
         if (iso.flag != nullptr && (a != 0.f || b != 0.f) && iso.holds(i)) atomicOr(iso.flag, 1);
         if (xg) {
             const int slot = xg_slot(i, xg_blk, xg_live);
@@ -423,7 +423,7 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
             if (in_norm != 1.f) a[u] = a[u] / in_norm;    // the same f32 division as the backend's `p / norm`
             if (start_from_v) b[u] = a[u];
             v_int[i] = a[u];
-            y0[i] = b[u];
+            if (y0 != nullptr) y0[i] = b[u];
             // an operand that is not zero on an isolated row: the run cannot pass over those rows
             if (iso.flag != nullptr && (a[u] != 0.f || b[u] != 0.f) && iso.holds(i)) atomicOr(iso.flag, 1);
             if (xg) {
@@ -436,21 +436,32 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
 
 // dst[old] = src[iperm[old]] * factor
 // (isolated rows that the loop passed over hold zeros: not gathered)
-__global__ void k_permute_out_gather(const float* __restrict__ src, const int32_t* __restrict__ iperm, int64_t n, float factor,
-                                     float* __restrict__ dst, IsoTail iso = IsoTail{}) {
-    constexpr int U = 8;                                   // index -> gather chains in flight per thread
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// A workgroup walks a CONTIGUOUS chunk of old ids.  Ties of the relabelling keep ascending ids (build_count_perm: a stable sort), and
+// most ids of a power-law graph share a handful of small reference counts, so the new ids of consecutive old ids are a few
+// ascending sequences per column block: every line of src a chunk touches is used up by the chunk itself (the CU's L1, its XCD's
+// L2).  Round 3 walked the ids with a grid-wide stride: the 32 entries of a line were fetched by 32 different CUs (54 us at scale 23).
+#ifndef PGH_OUT_CHUNK
+#define PGH_OUT_CHUNK 4096
+#endif
+__global__ __launch_bounds__(kBlock) void k_permute_out_gather(const float* __restrict__ src, const int32_t* __restrict__ iperm, int64_t n,
+                                                                float factor, float* __restrict__ dst, IsoTail iso = IsoTail{}) {
+    constexpr int U = PGH_OUT_CHUNK / kBlock;              // index -> gather chains in flight per thread
     const bool skip_iso = iso.flag != nullptr && *iso.flag == 0;
-    for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
+    for (int64_t base = (int64_t)blockIdx.x * PGH_OUT_CHUNK; base < n; base += (int64_t)gridDim.x * PGH_OUT_CHUNK) {
         int at[U];
         float x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) at[u] = i0 + u * stride < n ? iperm[i0 + u * stride] : 0;
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + u * kBlock + threadIdx.x;
+            at[u] = i < n ? iperm[i] : 0;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u] = (skip_iso && iso.holds(at[u])) ? 0.f : src[at[u]];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (i0 + u * stride < n) dst[i0 + u * stride] = x[u] * factor;
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + u * kBlock + threadIdx.x;
+            if (i < n) dst[i] = x[u] * factor;
+        }
     }
 }
 __global__ void k_permute_out(const float* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_pad, int64_t n_valid,
@@ -1287,8 +1298,12 @@ int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor) {
     BsfFormat& f = g->bsf;
     if (f.relabelled && f.iperm != nullptr) {          // gather through the inverse map: coalesced stores (the scatter form
-        k_permute_out_gather<<<blocks_for(f.n_out_orig), kBlock, 0, rt().stream>>>(src, f.iperm, f.n_out_orig, (float)factor, dst,   // writes 4 bytes per line)
-                                                                                    iso_tail_of(f));
+        int64_t chunks = ((int64_t)f.n_out_orig + PGH_OUT_CHUNK - 1) / PGH_OUT_CHUNK;
+        const int64_t cap = (int64_t)rt().num_cus * 8;
+        if (chunks > cap) chunks = cap;
+        if (chunks < 1) chunks = 1;
+        k_permute_out_gather<<<(int)chunks, kBlock, 0, rt().stream>>>(src, f.iperm, f.n_out_orig, (float)factor, dst, iso_tail_of(f));   // (the scatter form
+                                                                                                                                      // writes 4 bytes per line)
         PGH_HIP(hipGetLastError());
         return 0;
     }

@@ -100,6 +100,11 @@ struct pgh_comm_s {
     LoopAux*    aux = nullptr;           // the in-kernel residual's predictions (ResParams, pgh_kernels.h)
     double*     red = nullptr;           // [4] {S, T, D, R'}: this rank's sums, all-reduced in place once per iteration
     int32_t*    agree = nullptr;         // [4] device words of the layout negotiation
+    // host-visible word of the loop: {steps closed << 32 | done flag}, written by the closes of a step (publish_progress) into pinned
+    // mapped memory -- the host paces itself by it instead of copying the 64-byte state back after every check
+    volatile unsigned long long* progress_host = nullptr;
+    unsigned long long*          progress_dev = nullptr;
+    bool        one_gather = false;      // single queue: the whole packed slice travels as ONE all-gather (nothing to overlap with)
     // collectives supplied by the host instead of RCCL (pgh_comm_create_external): MPI, gloo, a test harness ...
     pgh_allgather_fn ext_gather = nullptr;
     pgh_allreduce_fn ext_reduce = nullptr;
@@ -218,10 +223,18 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     // A rank keeps its slice of the next gather vector PACKED for the exchange -- the hot prefixes of its blocks one after the
     // other, then their cold parts (dist_set_local_layout: the epilogue writes it that way) -- so every exchange is ONE all-gather
     // per region however many blocks a rank owns, and block b = rank * bpr + j of the gathered vector starts at b * (region width).
+    // (single queue: the whole packed slice is one all-gather, [rank][hot prefixes | cold parts]; the bases say where a block's two
+    // parts landed)
     int64_t hot_bases[8] = {0}, cold_bases[8] = {0};
     for (int b = 0; b < nb; ++b) {
-        hot_bases[b] = (int64_t)b * (split ? c->hot : live);
-        cold_bases[b] = (int64_t)nb * c->hot + (int64_t)b * (live - c->hot);
+        if (c->one_gather && split) {
+            const int rk = b / c->bpr, j = b % c->bpr;
+            hot_bases[b] = (int64_t)rk * c->bpr * live + (int64_t)j * c->hot;
+            cold_bases[b] = (int64_t)rk * c->bpr * live + (int64_t)c->bpr * c->hot + (int64_t)j * (live - c->hot);
+        } else {
+            hot_bases[b] = (int64_t)b * (split ? c->hot : live);
+            cold_bases[b] = (int64_t)nb * c->hot + (int64_t)b * (live - c->hot);
+        }
     }
     if (split) PGH_TRY(pgh_graph_set_gather_bases_split(g, hot_bases, cold_bases));
     else PGH_TRY(pgh_graph_set_gather_bases(g, hot_bases));
@@ -254,6 +267,22 @@ int gather_part(pgh_comm_s* c, int64_t region, int lo, int hi, hipStream_t st) {
     return comm_all_gather(c, c->xg_local + from, c->xg_full + region, (size_t)len, c->x, st);
 }
 
+// the exchange of a step: this rank's packed slice of the next gather vector -> every rank's xg_full.  Three queues: the hot
+// prefixes first (ev_hot: all that the next step's block partial sums read), then the cold bulk (ev_cold), so that the bulk travels
+// while those sums run; one queue: ONE all-gather of the whole slice.
+int exchange_slices(pgh_comm_s* c, hipStream_t st, bool events) {
+    if (c->one_gather || c->hot == 0) {
+        PGH_TRY(comm_all_gather(c, c->xg_local, c->xg_full, (size_t)((int64_t)c->bpr * c->live), c->x, st));
+        if (events) PGH_HIP(hipEventRecord(c->ev_hot, st));
+    } else {
+        PGH_TRY(gather_part(c, 0, 0, c->hot, st));
+        if (events) PGH_HIP(hipEventRecord(c->ev_hot, st));
+        PGH_TRY(gather_part(c, (int64_t)c->nb * c->hot, c->hot, c->live, st));
+    }
+    if (events) PGH_HIP(hipEventRecord(c->ev_cold, st));
+    return 0;
+}
+
 struct StreamSwap {          // the engine launches on rt().stream: point it at one of the communicator's queues for a scope
     hipStream_t saved;
     explicit StreamSwap(hipStream_t s) : saved(rt().stream) { rt().stream = s; }
@@ -276,7 +305,11 @@ namespace {
 // streams, events and scalars of a communicator; on failure the caller destroys the half-built object (pgh_comm_destroy frees
 // whatever exists)
 int comm_resources(pgh_comm_s* c, bool two_comms) {
-    const bool single_stream = getenv("PGH_DIST_SINGLE_STREAM") != nullptr && atoi(getenv("PGH_DIST_SINGLE_STREAM")) != 0;
+    // one queue when asked for (PGH_DIST_SINGLE_STREAM=1: the conservative setting of a first run on new hardware) and when there is
+    // nobody to exchange with: three queues exist to hide the exchange behind the step, and every cross-queue event costs
+    // microseconds (one rank over RCCL at scale 23: 467 GTEPS on three queues, 496 on one; PGH_DIST_SINGLE_STREAM=0 forces three)
+    const char* ss_env = getenv("PGH_DIST_SINGLE_STREAM");
+    const bool single_stream = ss_env != nullptr ? atoi(ss_env) != 0 : c->world == 1;
     PGH_HIP(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
     c->own_streams = true;
     if (single_stream) {
@@ -294,7 +327,39 @@ int comm_resources(pgh_comm_s* c, bool two_comms) {
     PGH_HIP(hipMalloc(&c->aux, sizeof(LoopAux)));
     PGH_HIP(hipMalloc(&c->red, sizeof(double) * 4));
     PGH_HIP(hipMalloc(&c->agree, sizeof(int32_t) * 4));
+    void* hp = nullptr;
+    PGH_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    c->progress_host = reinterpret_cast<volatile unsigned long long*>(hp);
+    c->progress_host[0] = 0ULL;
+    void* dp = nullptr;
+    PGH_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+    c->progress_dev = reinterpret_cast<unsigned long long*>(dp);
+    c->one_gather = c->xs == c->main;
     return 0;
+}
+
+// host wait for the close of step `step` (or any raised flag): 0 = seen, *flag = the done flag that came with it
+int wait_step(pgh_comm_s* c, int step, int* flag, const char* what) {
+    const double limit = wait_limit_s();
+    const auto start = std::chrono::steady_clock::now();
+    long spins = 0;
+    for (;;) {
+        const unsigned long long w = __atomic_load_n(const_cast<const unsigned long long*>(c->progress_host), __ATOMIC_ACQUIRE);
+        if ((int)(w >> 32) >= step || (unsigned int)w != 0u) {
+            *flag = (int)(unsigned int)w;
+            return 0;
+        }
+        if (++spins > 20000) {
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+            if ((spins & 1023) == 0) {
+                const hipError_t e = hipStreamQuery(c->ss);                    // a device fault ends the wait at once
+                if (e != hipSuccess && e != hipErrorNotReady) return fail(std::string("pgh_dist: waiting for ") + what + ": " + hipGetErrorString(e));
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() > limit)
+                return fail(std::string("pgh_dist: ") + what + " did not complete within PGH_DIST_TIMEOUT_S -- a collective is stalled (a peer "
+                            "gone, or communicators blocking each other: retry with a single communicator / stream)");
+        }
+    }
 }
 }  // namespace
 
@@ -362,6 +427,7 @@ extern "C" int pgh_comm_destroy(pgh_comm_t c) {
     (void)hipFree(c->red);
     (void)hipFree(c->agree);
     (void)hipHostFree(c->state_host);
+    if (c->progress_host != nullptr) (void)hipHostFree(const_cast<unsigned long long*>(c->progress_host));
     for (hipEvent_t ev : {c->ev_fin, c->ev_hot, c->ev_cold, c->ev_err, c->ev_host})
         if (ev) (void)hipEventDestroy(ev);
     if (g_rccl.handle != nullptr) {
@@ -495,13 +561,8 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     PGH_RUN(pgh_vec_copy(&v_y[0], &v_p));
     if (!cfg->every_row) PGH_RUN(pgh_dist_watch_isolated(g, &v_p, &v_y[0]));
     PGH_RUN(pgh_dist_prescale(g, &v_y[0], &v_xg_local));
-    const int64_t cold_region = (int64_t)c->nb * c->hot;
-    if (c->hot > 0) {
-        PGH_RUN(gather_part(c, 0, 0, c->hot, c->main));
-        PGH_RUN(gather_part(c, cold_region, c->hot, c->live, c->main));
-    } else {
-        PGH_RUN(gather_part(c, 0, 0, c->live, c->main));
-    }
+    PGH_RUN(exchange_slices(c, c->main, false));
+    c->progress_host[0] = 0ULL;                // (the previous run has drained: nobody writes the word any more)
     PGH_RUN(pgh_dist_state_init(c->state));
     if (fused) PGH_RUN(dist_aux_init(c->aux));
     for (hipEvent_t ev : {c->ev_hot, c->ev_cold, c->ev_err}) PGH_RUN_HIP(hipEventRecord(ev, c->main));
@@ -526,10 +587,14 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
         if (check) {
             PGH_TRY(pgh_dist_residual(local_kind, &v_y[cur], &v_y[1 - cur], c->state));
             PGH_TRY(comm_all_reduce(c, c->state + 1, 1, ncclFloat64, err_op, c->s, c->ss));
-            PGH_TRY(pgh_dist_close_err(c->state, kind, cfg->tol, cfg->n_global));
-            PGH_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->ss));
+            PGH_TRY(dist_close_err(c->state, kind, cfg->tol, cfg->n_global, c->progress_dev));
         }
         return 0;
+    };
+    auto wait_close = [&](int step, int* flag, const char* what) -> int {
+        const int w = wait_step(c, step, flag, what);
+        if (w != 0) scope.stalled = true;
+        return w;
     };
     const int max_iters = cfg->max_iters;
     int it = 1, spmv = 0;                      // `it` = ConvergenceManager.iteration of the pending has_converged call
@@ -541,24 +606,24 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
         staged = false;
         if (pending) {
             // the check that followed the previous step: its flag has travelled while the stages above were enqueued
-            PGH_RUN(wait_host(c->ev_err, "the scalar all-reduce of the previous step"));
+            int flag = 0;
+            PGH_RUN(wait_close(spmv, &flag, "the scalar all-reduce of the previous step"));
             pending = false;
-            int flag = reinterpret_cast<const int*>(c->state_host)[6];
             if (flag == 2) {
                 // the in-kernel residual could not vouch for its verdict (the quotient's prediction missed by more than the
                 // distance to the tolerance, or a value was negative / not finite): the step is complete but for its residual --
                 // the separate kernel evaluates it, and the run goes on without the fusion.  Every rank sees the same flag.
                 fused = false;
                 res->flags |= 1;
+                c->progress_host[0] = 0ULL;    // (the queues are idle behind the pause: every later kernel saw the flag and left)
                 {
                     StreamSwap on_scalars(c->ss);
-                    PGH_RUN(dist_resume(c->state));
+                    PGH_RUN(dist_resume(c->state, nullptr));
                     PGH_RUN(pgh_dist_close_sum(c->state, cfg->use_quotient));
                     PGH_RUN(scalars_plain(true, false));
                 }
                 PGH_RUN_HIP(hipEventRecord(c->ev_err, c->ss));
-                PGH_RUN(wait_host(c->ev_err, "the re-evaluated residual of a paused step"));
-                flag = reinterpret_cast<const int*>(c->state_host)[6];
+                PGH_RUN(wait_close(spmv, &flag, "the re-evaluated residual of a paused step"));
                 if (flag == 0) {
                     PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));
                     PGH_RUN(stages());         // the speculated stages may have seen the pause and done nothing
@@ -579,15 +644,7 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
         PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));
         // ---- X: the next gather vector over xGMI
         PGH_RUN_HIP(hipStreamWaitEvent(c->xs, c->ev_fin, 0));
-        if (c->hot > 0) {
-            PGH_RUN(gather_part(c, 0, 0, c->hot, c->xs));
-            PGH_RUN_HIP(hipEventRecord(c->ev_hot, c->xs));
-            PGH_RUN(gather_part(c, cold_region, c->hot, c->live, c->xs));
-        } else {
-            PGH_RUN(gather_part(c, 0, 0, c->live, c->xs));
-            PGH_RUN_HIP(hipEventRecord(c->ev_hot, c->xs));
-        }
-        PGH_RUN_HIP(hipEventRecord(c->ev_cold, c->xs));
+        PGH_RUN(exchange_slices(c, c->xs, true));
         cur = nxt;
         ++spmv;
         ++it;
@@ -601,9 +658,8 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
                 PGH_RUN(dist_fold_fused(c->state, c->red, fused_partials));
                 PGH_RUN(comm_all_reduce(c, c->red, 4, ncclFloat64, ncclSum, c->s, c->ss));
                 PGH_RUN(dist_close_fused(c->state, c->aux, c->red, spmv, check ? 1 : 0, kind, cfg->tol, cfg->n_global, cfg->use_quotient,
-                                         cfg->alpha, 1.0 - cfg->alpha));
+                                         cfg->alpha, 1.0 - cfg->alpha, c->progress_dev));
                 if (spmv == 1) PGH_RUN(scalars_plain(check, false));
-                else if (check) PGH_RUN_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->ss));
             } else {
                 PGH_RUN(scalars_plain(check, true));
             }
@@ -619,20 +675,20 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));
     PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_cold, 0));
     if (pending && !converged) {
-        PGH_RUN(wait_host(c->ev_err, "the scalar all-reduce of the last step"));
-        int flag = reinterpret_cast<const int*>(c->state_host)[6];
+        int flag = 0;
+        PGH_RUN(wait_close(spmv, &flag, "the scalar all-reduce of the last step"));
         if (flag == 2) {                       // (a pause at the very last check: same re-evaluation as inside the loop)
             res->flags |= 1;
+            c->progress_host[0] = 0ULL;
             {
                 StreamSwap on_scalars(c->ss);
-                PGH_RUN(dist_resume(c->state));
+                PGH_RUN(dist_resume(c->state, nullptr));
                 PGH_RUN(pgh_dist_close_sum(c->state, cfg->use_quotient));
                 PGH_RUN(scalars_plain(true, false));
             }
             PGH_RUN_HIP(hipEventRecord(c->ev_err, c->ss));
-            PGH_RUN(wait_host(c->ev_err, "the re-evaluated residual of a paused step"));
+            PGH_RUN(wait_close(spmv, &flag, "the re-evaluated residual of a paused step"));
             PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));
-            flag = reinterpret_cast<const int*>(c->state_host)[6];
         }
         converged = flag != 0;
     }
@@ -732,20 +788,8 @@ extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local,
     k_div_into<<<grid_of(n_local), 256, 0, c->main>>>(p_local->data, c->y[0], n_local, (float)norm);        // term_1 = p / norm
     PGH_RUN(pgh_ewise_vs(PGH_MUL, &v_y[0], c1, 0, result_local));                                           // result_1 = c_1 term_1
     PGH_RUN(pgh_dist_prescale(g, &v_y[0], &v_xg_local));
-    const int64_t cold_region = (int64_t)c->nb * c->hot;
-    auto exchange = [&](hipStream_t st, bool events) -> int {
-        if (c->hot > 0) {
-            PGH_TRY(gather_part(c, 0, 0, c->hot, st));
-            if (events) PGH_HIP(hipEventRecord(c->ev_hot, st));
-            PGH_TRY(gather_part(c, cold_region, c->hot, c->live, st));
-        } else {
-            PGH_TRY(gather_part(c, 0, 0, c->live, st));
-            if (events) PGH_HIP(hipEventRecord(c->ev_hot, st));
-        }
-        if (events) PGH_HIP(hipEventRecord(c->ev_cold, st));
-        return 0;
-    };
-    PGH_RUN(exchange(c->main, false));
+    PGH_RUN(exchange_slices(c, c->main, false));
+    c->progress_host[0] = 0ULL;
     PGH_RUN(pgh_dist_state_init(c->state));
     for (hipEvent_t ev : {c->ev_hot, c->ev_cold, c->ev_err}) PGH_RUN_HIP(hipEventRecord(ev, c->main));
     PGH_RUN_HIP(hipEventCreate(&scope.t_begin));
@@ -770,9 +814,14 @@ extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local,
         if (!staged) PGH_RUN(stages());
         staged = false;
         if (pending) {
-            PGH_RUN(wait_host(c->ev_err, "the all-reduce of the previous term's change"));
+            int flag = 0;
+            const int w = wait_step(c, spmv, &flag, "the all-reduce of the previous term's change");
+            if (w != 0) {
+                scope.stalled = true;
+                return w;
+            }
             pending = false;
-            if (reinterpret_cast<const int*>(c->state_host)[6] != 0) {
+            if (flag != 0) {
                 converged = true;
                 break;
             }
@@ -781,7 +830,7 @@ extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local,
         PGH_RUN(pgh_dist_combine_poly(g, &v_y[cur], &v_y[nxt], 1.0, 0.0, result_local, coeff(it), linf, &v_xg_local, c->state));
         PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));
         PGH_RUN_HIP(hipStreamWaitEvent(c->xs, c->ev_fin, 0));
-        PGH_RUN(exchange(c->xs, true));
+        PGH_RUN(exchange_slices(c, c->xs, true));
         cur = nxt;
         ++spmv;
         ++it;
@@ -792,8 +841,7 @@ extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local,
             PGH_RUN(pgh_dist_close_sum(c->state, 0));                // counts the step
             if (check) {
                 PGH_RUN(comm_all_reduce(c, c->state + 1, 1, ncclFloat64, err_op, c->s, c->ss));
-                PGH_RUN(pgh_dist_close_err(c->state, kind, cfg->tol, cfg->n_global));
-                PGH_RUN_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->ss));
+                PGH_RUN(dist_close_err(c->state, kind, cfg->tol, cfg->n_global, c->progress_dev));
             }
         }
         PGH_RUN_HIP(hipEventRecord(c->ev_err, c->ss));
@@ -807,8 +855,13 @@ extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local,
     PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));
     PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_cold, 0));
     if (pending && !converged) {
-        PGH_RUN(wait_host(c->ev_err, "the all-reduce of the last term's change"));
-        converged = reinterpret_cast<const int*>(c->state_host)[6] != 0;
+        int flag = 0;
+        const int w = wait_step(c, spmv, &flag, "the all-reduce of the last term's change");
+        if (w != 0) {
+            scope.stalled = true;
+            return w;
+        }
+        converged = flag != 0;
     }
     PGH_RUN_HIP(hipEventRecord(scope.t_end, c->main));
     PGH_RUN_HIP(hipMemcpyAsync(c->state_host, c->state, sizeof(double) * 8, hipMemcpyDeviceToHost, c->main));

@@ -589,8 +589,9 @@ int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float
                        const float* deg_local, double* state, LoopAux* aux, int step, int* num_partials);
 int dist_fold_fused(double* state, double* red, int num_partials);
 int dist_close_fused(double* state, LoopAux* aux, const double* red, int step, int check, int err_kind, double tol, int64_t n_global,
-                     int use_quotient, double a, double b);
-int dist_resume(double* state);
+                     int use_quotient, double a, double b, unsigned long long* progress);
+int dist_resume(double* state, unsigned long long* progress);
+int dist_close_err(double* state, int kind, double tol, int64_t n_global, unsigned long long* progress);
 int bsf_ensure_degrees(pgh_graph_s* g);       // BsfFormat::deg_int
 
 template <int MODE>

@@ -1041,7 +1041,14 @@ __global__ void k_dist_close_sum(double* d, int use_quotient) {
 }
 
 // after the all-reduce of the residual: ConvergenceManager._has_converged (convergence.py:96-101)
-__global__ void k_dist_close_err(double* d, int kind, double tol, double n_global) {
+// (progress: host-visible word of the engine-driven loop, pgh_dist.hip -- {steps closed << 32 | done flag} in pinned mapped memory,
+// ONE 64-bit store, so the host never pairs a new step count with an old flag; null for callers that read the state themselves)
+__device__ __forceinline__ void publish_progress(unsigned long long* progress, const LoopState* st) {
+    if (progress != nullptr)
+        __hip_atomic_store(progress, ((unsigned long long)(unsigned int)st->steps << 32) | (unsigned int)st->done, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_dist_close_err(double* d, int kind, double tol, double n_global, unsigned long long* progress = nullptr) {
     LoopState* st = reinterpret_cast<LoopState*>(d);
     if (st->done) return;
     double e = st->err;
@@ -1051,6 +1058,7 @@ __global__ void k_dist_close_err(double* d, int kind, double tol, double n_globa
         st->done = 1;
         st->converged = 1;
     }
+    publish_progress(progress, st);
 }
 
 }  // namespace
@@ -1294,7 +1302,7 @@ __global__ __launch_bounds__(WG) void k_dist_fold4(double* __restrict__ red, con
 }
 
 // red = {S, T, D, R'} summed over the ranks; the same close_outcome / close_commit as the single-GPU loop
-__global__ void k_dist_close_fused(double* d, PendingClose pc, const double* __restrict__ red) {
+__global__ void k_dist_close_fused(double* d, PendingClose pc, const double* __restrict__ red, unsigned long long* progress, int publish) {
     LoopState* st = reinterpret_cast<LoopState*>(d);
     if (st->done) return;
     d[5] = st->scale;                       // the previous iterate's quotient (what a separate residual launch reads)
@@ -1302,11 +1310,13 @@ __global__ void k_dist_close_fused(double* d, PendingClose pc, const double* __r
     const CloseOutcome o = close_outcome(pc, red[0], 0.0, red[3], red[2], red[1]);
     close_commit(pc, o);
     if (pc.check && o.verdict != 2) d[6] = o.err;
+    if (publish) publish_progress(progress, st);
 }
 
-__global__ void k_dist_resume(double* d) {
+__global__ void k_dist_resume(double* d, unsigned long long* progress) {
     LoopState* st = reinterpret_cast<LoopState*>(d);
     if (st->done == 2) st->done = 0;
+    publish_progress(progress, st);
 }
 
 __global__ void k_aux_init(LoopAux* aux) {
@@ -1385,7 +1395,7 @@ int dist_fold_fused(double* state, double* red, int num_partials) {
 // closes step `step` from the all-reduced {S, T, D, R'}: quotient, next prediction, and -- when `check` -- the stopping rule
 // (verdict "paused" = state done == 2: the caller re-evaluates the step with pgh_dist_residual, dist_resume first)
 int dist_close_fused(double* state, LoopAux* aux, const double* red, int step, int check, int err_kind, double tol, int64_t n_global,
-                     int use_quotient, double a, double b) {
+                     int use_quotient, double a, double b, unsigned long long* progress) {
     PendingClose pc{};
     pc.state = reinterpret_cast<LoopState*>(state);
     pc.tol = tol;
@@ -1401,14 +1411,24 @@ int dist_close_fused(double* state, LoopAux* aux, const double* red, int step, i
     pc.b = b;
     {
         ProfScope prof(PGH_K_FINAL);
-        k_dist_close_fused<<<1, 1, 0, rt().stream>>>(state, pc, red);
+        // (the first step's verdict comes from the separate residual: its close publishes)
+        k_dist_close_fused<<<1, 1, 0, rt().stream>>>(state, pc, red, progress, (step != 1 || !check) ? 1 : 0);
     }
     PGH_HIP(hipGetLastError());
     return 0;
 }
 
-int dist_resume(double* state) {
-    k_dist_resume<<<1, 1, 0, rt().stream>>>(state);
+int dist_resume(double* state, unsigned long long* progress) {
+    k_dist_resume<<<1, 1, 0, rt().stream>>>(state, progress);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+// pgh_dist_close_err that also publishes {steps, done} to the host-visible word
+int dist_close_err(double* state, int kind, double tol, int64_t n_global, unsigned long long* progress) {
+    {
+        ProfScope prof(PGH_K_FINAL);
+        k_dist_close_err<<<1, 1, 0, rt().stream>>>(state, kind, tol, (double)n_global, progress);
+    }
     PGH_HIP(hipGetLastError());
     return 0;
 }
@@ -1539,12 +1559,18 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             if (on) (void)iso_flag_release(g_);
         }
     } iso_guard{g, watch_iso};
+    // the iterate a run starts from.  Started from the personalization itself (GraphFilter.rank without warm_start), x0 IS the
+    // internal-space personalization: step 1 reads that vector and the even steps' output buffer is never initialised (33 MB fewer
+    // written per run at scale 23; the rows a run passes over are read by nobody, see IsoTail)
+    const float* x0 = nullptr;
     if (pair) {          // personalization, start vector and scaled gather vector in one pass over the permutation
         PGH_TRY(v_buf.alloc(n_int));
         PGH_TRY(y0.alloc(n_int));
-        PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, y0.p, scaled_gather, in_norm, from_p, watch_iso));
+        const bool alias = from_p && (MODE == EPI_AXPBY || MODE == EPI_ABSORB);
+        PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, alias ? nullptr : y0.p, scaled_gather, in_norm, from_p, watch_iso));
         ep.v = v_buf.p;
         buf[0] = y0.p;
+        if (alias) x0 = v_buf.p;
     } else {
         PGH_TRY(sp.bring(ep.v, v_buf, &ep.v));
     }
@@ -1555,7 +1581,10 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     }
     PGH_TRY(y1.alloc(n_int));
     buf[1] = y1.p;
-    if (watch_iso) PGH_HIP(hipMemsetAsync(y1.p, 0, sizeof(float) * (size_t)n_int, r.stream));      // the rows nobody will write
+    // the rows nobody will write (isolated rows a run passes over): nobody reads them either -- the residual kernels stop at
+    // IsoTail::begin on 16-byte aligned operands (pool allocations are), the way out of the id space writes zeros without looking --
+    // so they are cleared only for operands the vector path of the residual would refuse
+    if (watch_iso && !(aligned16(y1.p) && aligned16(buf[0]))) PGH_HIP(hipMemsetAsync(y1.p, 0, sizeof(float) * (size_t)n_int, r.stream));
     const IsoTail iso_tail = watch_iso ? iso_tail_of(g->bsf) : IsoTail{};
     if (sp.blocked && !pair) {
         PGH_TRY(y0.alloc(n_int));
@@ -1575,7 +1604,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         PGH_CHECK(sp.blocked && g->bsf.n_out == g->bsf.n_src_pad, "a pre-scaled step needs the blocked layout of a square graph");
         PGH_TRY(gs_buf.alloc(n_int + 1));
         PGH_TRY(bsf_to_internal(g, pre_scale, gs_buf.p, g->bsf.src_scale != nullptr, 0.f));     // pre_scale[perm] * source scale
-        PGH_TRY(bsf_make_gather(g, buf[0], gs_buf.p));
+        PGH_TRY(bsf_make_gather(g, x0 != nullptr ? x0 : buf[0], gs_buf.p));
         ep.xg_out = g->bsf.xg;
         ep.src_scale = gs_buf.p;
         ep.xg_blk = g->bsf.blk_size;
@@ -1638,8 +1667,9 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         return pc;
     };
     // every launch of step k (it produces x_k from x_{k-1})
+    auto input_of = [&](int k) -> const float* { return (k == 1 && x0 != nullptr) ? x0 : buf[(k - 1) & 1]; };
     auto enqueue_step = [&](int k) -> int {
-        const float* xin = buf[(k - 1) & 1];
+        const float* xin = input_of(k);
         float* yout = buf[k & 1];
         EpiParams epk = ep;
         epk.y = yout;
@@ -1730,7 +1760,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         k_state_resume<<<1, 1, 0, r.stream>>>(g_state, g_progress_dev);
         if (poll) progress_reset();
         {
-            const float* xin = buf[(k - 1) & 1];
+            const float* xin = input_of(k);
             const float* yout = buf[k & 1];
             PendingClose pc = make_close(k);
             {
@@ -1754,7 +1784,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     const int steps = g_state_host->steps;
     // result lives in buf[steps & 1]; apply the pending quotient and preserve_norm factor
     const double factor = g_state_host->scale * cfg->out_scale;
-    const float* final_buf = buf[steps & 1];
+    const float* final_buf = (steps == 0 && x0 != nullptr) ? x0 : buf[steps & 1];
     if (sp.blocked) {
         PGH_TRY(bsf_to_original(g, final_buf, ranks->data, factor));
     } else if (n > 0 && (final_buf != ranks->data || factor != 1.0)) {

@@ -144,10 +144,12 @@ def test_full_size_properties_rmat20(gpu_engine):
 @pytest.mark.parametrize("world,backend,scale,mode", [(1, "nccl", 14, ""), (2, "gloo", 14, ""), (4, "gloo", 14, ""), (2, "gloo", 18, ""),
                                                       (2, "gloo", 18, "single_queue"), (1, "nccl", 14, "single_queue"),
                                                       (1, "nccl", 18, ""), (1, "nccl", 18, "python_driver"),
-                                                      (2, "gloo", 18, "engine_loop"), (4, "gloo", 14, "engine_loop")],
+                                                      (2, "gloo", 18, "engine_loop"), (4, "gloo", 14, "engine_loop"),
+                                                      (2, "gloo", 18, "engine_loop_single_queue"), (1, "nccl", 18, "three_queues")],
                          ids=["rccl_x1", "gloo_x2", "gloo_x4", "gloo_x2_cold_image", "gloo_x2_cold_image_single_queue", "rccl_x1_single_queue",
                               "rccl_x1_cold_image_split_regions", "rccl_x1_cold_image_python_driver",
-                              "gloo_x2_cold_image_engine_loop", "gloo_x4_engine_loop"])
+                              "gloo_x2_cold_image_engine_loop", "gloo_x4_engine_loop", "gloo_x2_cold_image_engine_loop_single_queue",
+                              "rccl_x1_cold_image_three_queues"])
 def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, scale, mode):
     """The N > 1 code path on the real engine: relabelled slice generation, the device-driven pgh_dist_* loop, in-place
     collectives on device scalars, the trimmed all-gather -- against the oracle.  World size 1 runs over RCCL; world sizes
@@ -170,8 +172,12 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
         env.update(PGH_DIST_SINGLE_COMM="1", PGH_DIST_SINGLE_STREAM="1")
     if mode == "python_driver":
         env.update(PGH_DIST_NATIVE="0")
-    if mode == "engine_loop":            # the ENGINE's loop with several ranks (region offsets of every rank, split exchange, ...):
+    if mode.startswith("engine_loop"):   # the ENGINE's loop with several ranks (region offsets of every rank, split exchange, ...):
         env.update(PGH_DIST_NATIVE="external")      # the collectives come back to the host (pgh_comm_create_external over gloo)
+    if mode == "engine_loop_single_queue":          # ... on ONE queue: the whole packed slice of a rank as a single all-gather
+        env.update(PGH_DIST_SINGLE_STREAM="1")
+    if mode == "three_queues":           # one rank runs on one queue by default (nobody to overlap an exchange with): force the three
+        env.update(PGH_DIST_SINGLE_STREAM="0")
     if scale > 14:                       # four column blocks over two ranks: two all-gathers per exchange, like bench.py --gpus 2
         env.update(PGH_PB="1", PGH_PB_FORCE="1", PGH_DEBUG="1", PGH_BLOCKS="4", PGH_PB_HEAVY="64", PGH_PB_HUBMAX="500")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -180,7 +186,8 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
         assert "[pgh] pb:" in res.stderr, res.stderr[-3000:]
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     driver = {"": "engine (RCCL)" if backend == "nccl" else "python (torch.distributed)", "single_queue": "engine (RCCL)" if backend == "nccl"
-              else "python (torch.distributed)", "python_driver": "python (torch.distributed)", "engine_loop": "engine (host collectives)"}[mode]
+              else "python (torch.distributed)", "python_driver": "python (torch.distributed)", "engine_loop": "engine (host collectives)",
+              "engine_loop_single_queue": "engine (host collectives)", "three_queues": "engine (RCCL)"}[mode]
     assert all(str(part["driver"]) == driver for part in parts), [str(part["driver"]) for part in parts]
     if scale > 14 and driver.startswith("engine"):
         assert all(int(part["split_regions"]) == 1 for part in parts)      # hot prefixes and cold parts exchanged as two regions
