@@ -1324,6 +1324,8 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.fix_seg);
     (void)hipFree(f.psum);
     (void)hipFree(f.psum64);
+    (void)hipFree(f.c64_src);
+    (void)hipFree(f.c64_begin);
     (void)hipFree(f.meta);
     (void)hipFree(f.live_dev);
     (void)hipFree(f.val);

@@ -22,3 +22,5 @@ for r in rows[idx - 2: idx + 14]:
     print(f'{(int(r["Start_Timestamp"]) - t0) / 1e3:9.1f} us  +{(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:7.1f} us  {r["Kernel_Name"][:90]}')
 PY
 timeout 600 python bench.py --gpus 1 > $O/c_bench.json 2> $O/c_bench.err; echo "bench rc=$?"; cat $O/c_bench.json; tail -3 $O/c_bench.err
+timeout 300 python tools/probe_cheb.py > $O/c_cheb.log 2>&1; tail -8 $O/c_cheb.log
+timeout 300 python tools/probe_cheb.py --lib tools/variants/libpgh_b64d3.so > $O/c_cheb_d3.log 2>&1; tail -8 $O/c_cheb_d3.log
