@@ -43,7 +43,7 @@ ALPHA, TOL, MAX_ITERS, SEEDS = 0.85, 1e-6, 1000, 100
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 # HBM traffic of the step kernels: rocprofv3 --pmc passes of this same command (tools/gpu_bench_call.sh), summarised by
 # tools/summarize_pmc.py with the guide's gfx950 corrections; counters cannot be read from inside the timed process
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "bench_n1_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "bench_n1_pmc.json")
 # the launches of one PPR iteration, in stream order (HIP-event ids of include/pgh.h)
 STEP_KERNELS = ("spmv", "fixup", "pb_gather", "pb_finish", "combine", "residual", "close")
 
@@ -86,8 +86,8 @@ def measured_traffic(scale, ef, blocked):
 
 def measured_batch_traffic(scale, ef, width):
     """HBM bytes of one batch step of the multi-seed loop (k_mm_partial + fix-up + combine + residual) from the committed PMC
-    summary of tools/probe_batch_kernels.py (profiles/r03/spmm_final_pmc.json; same hash rule as the headline's traffic)."""
-    path = os.path.join(ROOT, "profiles", "r03", "spmm_final_pmc.json")
+    summary of tools/probe_batch_kernels.py (profiles/r04/spmm_final_pmc.json; same hash rule as the headline's traffic)."""
+    path = os.path.join(ROOT, "profiles", "r04", "spmm_final_pmc.json")
     if (scale, ef, width) != (23, 16, 64) or not os.path.exists(path):
         return {}
     with open(path) as f:
@@ -453,7 +453,8 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
     # every launch of one iteration counts (as in the single-GPU line): step + residual + the scalar folds / closes
     step_us = sum(v for v in prof.values() if v)
     names = dict(spmv="k_bsf_partial", pb_gather="k_pb_gather", pb_finish="k_pb_finish<AXPBY>", fixup="k_bsf_fixup",
-                 combine="k_bsf_combine<AXPBY>", residual="k_step_residual", close="k_dist_close_sum + k_dist_fold + k_dist_close_err")
+                 combine="k_bsf_combine<AXPBY>", residual="k_step_residual (first step only with the in-kernel residual)",
+                 close="k_dist_fold4 + k_dist_close_fused (k_dist_close_sum + k_dist_fold + k_dist_close_err without the in-kernel residual)")
     step_kernels = " + ".join(names[k] for k, v in prof.items() if v)
     alg_bytes = 8 * pg.graph.nnz + 4 * n + 16 * n_local
     achieved = alg_bytes / (step_us * 1e-6) / 1e9 if step_us else None
@@ -481,7 +482,9 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
         config=dict(workload=f"row-partitioned PPR on RMAT scale-{scale} ef-{ef} over {world} GPUs (BASELINE.json configs[4] shape)",
                     n=n, nnz=nnz_total, alpha=alpha, tol=tol, error_type="L1", seeds=num_seeds, iterations_per_step=iters,
                     spmv_per_step=spmv_total / args.steps, graph_build_s=round(build_s, 2),
-                    parallelism=f"1-D row partition x{world}, all-gather of the gather vector + 2 scalar all-reduces per iteration",
+                    parallelism=f"1-D row partition x{world}, all-gather of the gather vector + " +
+                                ("ONE 4-scalar all-reduce" if exchange.get("in_kernel_residual") else "2 scalar all-reduces") + " per iteration",
+                    engine_loop_probe=_probe_verdict(world, rank),
                     nnz_per_rank_max_over_mean=balance, **exchange),
         roofline=dict(bound="hbm", kernel=step_kernels + " (one PPR iteration of rank 0's slice, exchange excluded)",
                       achieved=round(achieved, 1) if achieved else None, peak=hbm_peak, unit="GB/s",
@@ -489,6 +492,13 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
                       algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(step_us, 2), format=graph_format,
                       kernels_avg_us=prof),
         cpu_baseline=cpu, parity=parity, same_graph_1gpu=same_graph)
+
+
+def _probe_verdict(world, rank):
+    """What pygrank_amd.distributed found when it probed the engine-driven RCCL loop on a small graph before trusting it with N > 1
+    ("ok", what failed -- the run then used the Python-driven loop -- or "not run": one rank, PGH_DIST_NATIVE=0/1, gloo)."""
+    from pygrank_amd.distributed import PREFLIGHT
+    return str(PREFLIGHT.get((world, rank), "not run"))
 
 
 def _device_of(use_cuda):

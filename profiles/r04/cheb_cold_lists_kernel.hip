@@ -22,6 +22,8 @@
 
 #include <cstdlib>
 
+#include <hipcub/hipcub.hpp>
+
 using namespace pgh;
 
 namespace {
@@ -29,21 +31,39 @@ namespace {
 constexpr int kT = 64 * PGH_BSF_IPT;           // entries per wavefront tile (the tile table of bsf_build)
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
-constexpr int kHot64 = 20224;                  // doubles of the gather vector cached in LDS per workgroup (the LDS holds nothing else)
-constexpr int kLdsDoubles = kHot64 + 1;
+// LDS of a workgroup: the hot cache (the first kHot64 doubles of the block's hot-first slice of the gather vector), a zero slot, and
+// one strip of kStrip doubles per wavefront for the gathered COLD values of the tile in hand (below)
+constexpr int kStrip = 256;
+constexpr int kHot64 = 16128;
+constexpr int kLdsDoubles = kHot64 + 1 + kWaves * kStrip;
+// Stream words (k_c64_fill rewrites what bsf_build left): bit 31 = first entry of a row segment, bits 30-29 = kind --
+//   0 hot        bits 0-28: slot of the LDS hot cache
+//   2 listed     bits 0-8:  index j into the tile's cold list (c64_src): the wavefront gathers the list with ceil(count / 64)
+//                           FULL buffer-load instructions and parks the values in its strip; the entry reads strip[j]
+//   1 overflow   bits 0-28: slot - kHot64 of a cold entry beyond the kStrip-th of its tile: gathered by its own lane (rare)
+// Why: a divergent 8-byte gather INSTRUCTION costs the CU ~50 cycles whether 6 or 30 of its 64 lanes are cold
+// (profiles/r03/cheb_f64_blocked.log); a lane-owns-its-entries kernel issues 8 of them per tile with ~19 cold lanes each, the
+// list needs 2-3 with 64.
+constexpr uint32_t kKindListed = 0x40000000u, kKindOver = 0x20000000u, kKindMask = 0x60000000u;
 // diagnostic builds only: 1 = no cold gathers, 2 = no hot-cache reads, 4 = no stores of a lane's later segments, 8 = no scans.
-// Measured at RMAT scale 23 (profiles/r03/cheb_f64_blocked.log): 376 us as shipped; 190 without the cold gathers (a divergent
-// 8-byte gather instruction costs the CU ~50 cycles WHATEVER the number of active lanes: 32 blocks leave 10 % of the lanes
-// cold instead of 30 % and take the same time; exec-masked loads likewise), 335 without the stores, 377 without the LDS
-// reads, 373 without the scans, 146 with all four off (stream + arithmetic).
+// Measured at RMAT scale 23 on the round-3 kernel (every lane gathered its own cold entries; profiles/r03/cheb_f64_blocked.log): 376 us
+// as shipped; 190 without the cold gathers (a divergent 8-byte gather instruction costs the CU ~50 cycles WHATEVER the number of
+// active lanes: 32 blocks leave 10 % of the lanes cold instead of 30 % and take the same time; exec-masked loads likewise), 335
+// without the stores, 377 without the LDS reads, 373 without the scans, 146 with all four off (stream + arithmetic).
 #ifndef PGH_B64_PROBE
 #define PGH_B64_PROBE 0
+#endif
+// gathered tiles in flight behind the sums of the value-free shape (3: two, 2: one)
+#ifndef PGH_B64_DEPTH
+#define PGH_B64_DEPTH 2
 #endif
 static_assert(PGH_BSF_IPT == 8, "a lane owns 8 consecutive entries (two 16-byte words)");
 static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of one CU");
 
 struct View64 {
-    const uint32_t* colf;        // [num_entries] source (new id) | bit 31 = first entry of a row segment
+    const uint32_t* colf;        // [num_entries] stream words (kinds above)
+    const uint32_t* cold_src;    // the tiles' cold lists: byte offsets into the block's cold slice
+    const int32_t*  cold_begin;  // [num_tiles + 1]
     const float*    val;         // [num_entries] or null (value-free)
     const int4*     tile;        // {entry_start, entry_count, seg_base, chain_first}
     double*         tail;        // [num_tiles] piece of the segment still open at the end of the tile
@@ -133,11 +153,15 @@ __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const doub
     const int t_end = f.tile_begin[b + 1];
     int t = f.tile_begin[b] + rank;
     if (t >= t_end) return;
+    double* __restrict__ strip = s_lds + kHot64 + 1 + wave * kStrip;
+    const uint32_t strip_at = (uint32_t)(kHot64 + 1 + wave * kStrip);
 
+    constexpr int kRounds = kStrip / 64;       // list rounds of 64 gathers
     struct Words {
-        u32x4 c[2];
-        f32x4 v[2];
-        int   seg_base;
+        u32x4    c[2];
+        f32x4    v[2];
+        uint32_t idx[kRounds];   // this lane's gathers of the tile's cold list (beyond the list: past the buffer, no access)
+        int      seg_base, cold_n;
     };
     auto load_words = [&](int tile, Words& w) __attribute__((always_inline)) {
         const u32x4* p = reinterpret_cast<const u32x4*>(f.colf + (int64_t)tile * kT + lane * 8);
@@ -149,45 +173,75 @@ __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const doub
             w.v[1] = __builtin_nontemporal_load(q + 1);
         }
         w.seg_base = f.tile[tile].z;
+        const int cb = f.cold_begin[tile];
+        w.cold_n = f.cold_begin[tile + 1] - cb;                 // wavefront-uniform
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int j = r * 64 + lane;
+            w.idx[r] = j < w.cold_n ? __builtin_nontemporal_load(f.cold_src + cb + j) : 0xfffffff8u;
+        }
     };
     struct Gathered {
-        double       c[8];           // from the block's cold slice (hot lanes address outside the buffer: 0, no memory access)
-        uint32_t     at[4];          // slots of the LDS hot cache (cold lanes: its zero slot) as 16-bit pairs, read when the tile is summed
+        double       c[kRounds];     // the tile's cold list, round by round (lane = list position % 64)
+        uint32_t     at[4];          // LDS slots of the lane's 8 entries as 16-bit pairs: hot cache, zero slot, or the strip
         float        v[HAS_VAL ? 8 : 1];
-        unsigned int bits;
-        int          seg_base;
+        unsigned int bits;           // bits 0-7: segment flags, bits 8-15: entries of kind "overflow"
+        int          seg_base, cold_n;
     };
-    // the block's cold slice [hot, blk) of the gather vector as a buffer: value = h + c, no select and no divergent branch
+    // the block's cold slice [hot, blk) of the gather vector as a buffer (offsets past it: 0, no memory access)
     const __amdgpu_buffer_rsrc_t cold_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(xg + base + hot), 0, (int)(((uint32_t)f.blk - hot) << 3), 0x00020000);
     typedef int i32x2 __attribute__((ext_vector_type(2)));
     auto gather = [&](const Words& w, Gathered& g) __attribute__((always_inline)) {
-        unsigned int bits = 0;
+        unsigned int bits = 0, over = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t word = w.c[k >> 2][k & 3];
             bits |= (word >> 31) << k;
-            const uint32_t loc = (word & 0x7fffffffu) - base;
-            const uint32_t slot16 = min(loc, hot);
+            const uint32_t kind = word & kKindMask, low = word & 0x1fffffffu;
+            // hot: its slot; listed: its place in the strip; overflow: the zero slot (its value comes by its own load below)
+            const uint32_t slot16 = kind == 0u ? low : (kind == kKindListed ? strip_at + low : hot);
             g.at[k >> 1] = (k & 1) ? (g.at[k >> 1] | (slot16 << 16)) : slot16;
-            if (PGH_B64_PROBE & 1) g.c[k] = 0.0;
-            else {
-                const i32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(cold_rsrc, (int)((loc - hot) << 3), 0, 0);
-                g.c[k] = __hiloint2double(raw.y, raw.x);
-            }
+            over |= (kind == kKindOver ? 1u : 0u) << k;
             if (HAS_VAL) g.v[k] = w.v[k >> 2][k & 3];
         }
-        g.bits = bits;
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            if ((PGH_B64_PROBE & 1) || r * 64 >= w.cold_n) g.c[r] = 0.0;            // wavefront-uniform: the instruction is not issued
+            else {
+                const i32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(cold_rsrc, (int)w.idx[r], 0, 0);
+                g.c[r] = __hiloint2double(raw.y, raw.x);
+            }
+        }
+        g.bits = bits | (over << 8);
         g.seg_base = w.seg_base;
+        g.cold_n = w.cold_n;
     };
     auto reduce = [&](const Gathered& g, int tile) __attribute__((always_inline)) {
-        const unsigned int bits = g.bits;
+        const unsigned int bits = g.bits & 0xffu, over = g.bits >> 8;
+        // the gathered list -> the wavefront's strip (LDS operations of one wavefront execute in order: no barrier), then every
+        // entry reads ITS slot: hot cache, strip or zero -- the same 8 LDS reads per lane as without the list
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r)
+            if (r * 64 < g.cold_n) strip[r * 64 + lane] = g.c[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         double h[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t slot16 = (k & 1) ? (g.at[k >> 1] >> 16) : (g.at[k >> 1] & 0xffffu);
             h[k] = (PGH_B64_PROBE & 2) ? (double)slot16 : s_lds[slot16];
         }
+        if (__builtin_expect(__any(over != 0u), 0)) {        // a tile with more than kStrip cold entries: the rest by lane
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((over >> k) & 1u) {                    // (its word again: the pipeline keeps no copy for so rare a case)
+                    const uint32_t word = f.colf[(int64_t)tile * kT + lane * 8 + k];
+                    const i32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(cold_rsrc, (int)((word & 0x1fffffffu) << 3), 0, 0);
+                    h[k] = __hiloint2double(raw.y, raw.x);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();                       // the strip is free for the next tile's list
         const int mine = __popc(bits);
         const int incl = wave_inclusive_sum(mine);         // flags in lanes <= this one
         const int before = incl - mine;
@@ -195,8 +249,7 @@ __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const doub
         // the segment that was open when the tile started (-> head carry), j >= 1 closes segment j - 1 of the tile, whose sum
         // belongs at psum[seg_base + j].  Sums closed by a lane's second and later flags are complete and leave at once
         // (8-byte stores; neighbouring lanes write neighbouring slots); what its FIRST flag closes may have begun in
-        // earlier lanes: it waits for the stitch below.  (The first version staged all of this through an LDS strip per
-        // wavefront -- 18 more LDS instructions per tile than the 8 hot-cache reads, and the LDS is what bounds this kernel.)
+        // earlier lanes: it waits for the stitch below.
         double* __restrict__ dst = f.psum + g.seg_base + before;
         int seen = 0;
         double acc = 0.0, head_sum = 0.0;
@@ -208,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const doub
                 ++seen;
                 acc = 0.0;
             }
-            double x = h[k] + g.c[k];
+            double x = h[k];
             if (HAS_VAL) x *= (double)g.v[k];
             acc += x;
         }
@@ -228,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const doub
     // keeps the gathers of TWO tiles in flight behind the sums (stream words one tile ahead of the gathers); valued streams
     // carry 8 more registers per set and keep one.
     const int t_last = t_end - 1;
-    if (!HAS_VAL) {
+    if (!HAS_VAL && PGH_B64_DEPTH == 3) {
         Words wa, wb;
         Gathered g0, g1, g2;
         load_words(t, wa);
@@ -271,6 +324,51 @@ __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const doub
         }
     }
     PGH_STAMP_END(g_times_partial64)
+}
+
+// ---- build time: the tiles' cold lists.  One wavefront per tile; an entry's place j in its tile's list = the number of cold entries
+// before it in (k, lane) order (ballots).  Pass 1 counts (capped at kStrip: the rest stays with its lane, kind "overflow"),
+// an exclusive scan gives the lists' offsets, pass 2 writes the lists and rewrites the stream words (kinds: top of the file).
+struct TileBlocks {
+    int tile_begin[kMaxBlocks + 1];
+    int num_blocks, blk;
+};
+__device__ __forceinline__ int block_of_tile(const TileBlocks& tb, int tile) {
+    int b = 0;
+    while (b + 1 < tb.num_blocks && tile >= tb.tile_begin[b + 1]) ++b;
+    return b;
+}
+template <bool FILL>
+__global__ __launch_bounds__(WG) void k_c64_lists(TileBlocks tb, uint32_t* __restrict__ colf, int num_tiles, int32_t* __restrict__ count,
+                                                  const int32_t* __restrict__ begin, uint32_t* __restrict__ cold_src) {
+    const int lane = threadIdx.x & 63;
+    const int tile = (int)((blockIdx.x * (int64_t)WG + threadIdx.x) >> 6);
+    if (tile >= num_tiles) return;
+    const int b = block_of_tile(tb, tile);
+    const uint32_t base = (uint32_t)b * (uint32_t)tb.blk, hot = (uint32_t)min(kHot64, tb.blk);
+    uint32_t* words = colf + (int64_t)tile * kT + lane * 8;
+    int running = 0;
+    const int cb = FILL ? begin[tile] : 0;
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t word = words[k];
+        const uint32_t loc = (word & 0x7fffffffu) - base;
+        const bool cold = loc >= hot;
+        const unsigned long long mask = __ballot(cold);
+        const int j = running + __popcll(mask & ((1ULL << lane) - 1ULL));
+        running += __popcll(mask);
+        if (FILL) {
+            uint32_t out = (word & 0x80000000u);
+            if (!cold) out |= loc;
+            else if (j < kStrip) {
+                out |= kKindListed | (uint32_t)j;
+                cold_src[cb + j] = (loc - hot) << 3;
+            } else {
+                out |= kKindOver | (loc - hot);
+            }
+            words[k] = out;
+        }
+    }
+    if (!FILL && lane == 0) count[tile] = running < kStrip ? running : kStrip;
 }
 
 // where the fix-up of tile t goes (index into psum, -1 = nothing to fix): the segment open at the tile start closes here
@@ -462,6 +560,35 @@ int bsf64_ensure(pgh_graph_s* g) {
     PGH_HIP(hipMalloc(&f.fix_seg, sizeof(int32_t) * (size_t)(f.num_tiles + 1)));
     k_bsf64_fixlist<<<grid_for(f.num_tiles, 16), WG, 0, r.stream>>>(f.tile, f.seg_row, f.num_tiles, f.fix_seg);
     PGH_HIP(hipGetLastError());
+    {   // the tiles' cold lists (k_c64_lists)
+        TileBlocks tb;
+        for (int i = 0; i <= kMaxBlocks; ++i) tb.tile_begin[i] = f.tile_begin[i];
+        tb.num_blocks = f.num_blocks;
+        tb.blk = f.blk_size;
+        const int tiles = f.num_tiles;
+        int32_t* counts = nullptr;
+        PGH_HIP(hipMalloc(&counts, sizeof(int32_t) * (size_t)(tiles + 1)));
+        PGH_HIP(hipMalloc(&f.c64_begin, sizeof(int32_t) * (size_t)(tiles + 1)));
+        PGH_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)(tiles + 1), r.stream));
+        const int lgrid = (int)(((int64_t)tiles * 64 + WG - 1) / WG);
+        if (tiles > 0) k_c64_lists<false><<<lgrid, WG, 0, r.stream>>>(tb, f.colf, tiles, counts, nullptr, nullptr);
+        size_t temp_bytes = 0;
+        PGH_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, counts, f.c64_begin, tiles + 1, r.stream));
+        void* temp = nullptr;
+        PGH_HIP(hipMalloc(&temp, temp_bytes > 0 ? temp_bytes : 1));
+        PGH_HIP(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, counts, f.c64_begin, tiles + 1, r.stream));
+        int32_t total = 0;
+        PGH_HIP(hipMemcpyAsync(&total, f.c64_begin + tiles, sizeof(int32_t), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        (void)hipFree(temp);
+        (void)hipFree(counts);
+        PGH_HIP(hipMalloc(&f.c64_src, sizeof(uint32_t) * (size_t)(total + 64)));
+        if (tiles > 0) k_c64_lists<true><<<lgrid, WG, 0, r.stream>>>(tb, f.colf, tiles, nullptr, f.c64_begin, f.c64_src);
+        PGH_HIP(hipGetLastError());
+        f.device_bytes += (int64_t)total * 4 + (int64_t)tiles * 4;
+        if (getenv("PGH_DEBUG") != nullptr && atoi(getenv("PGH_DEBUG")) != 0)
+            fprintf(stderr, "[pgh] bsf64: %d tiles, %d listed cold entries (%.1f %% of the stream)\n", tiles, total, 100.0 * total / ((double)tiles * kT + 1));
+    }
     PGH_HIP(hipStreamSynchronize(r.stream));
     f.device_bytes += (int64_t)(f.num_segs + kT + 64) * 8 + (int64_t)f.num_tiles * 4;
     if (f.live_nodes >= 0) PGH_HIP(hipMalloc(&f.iso_flag, sizeof(int)));
@@ -501,6 +628,8 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
     BsfFormat& f = g->bsf64;
     View64 v;
     v.colf = f.colf;
+    v.cold_src = f.c64_src;
+    v.cold_begin = f.c64_begin;
     v.val = f.val;
     v.tile = f.tile;
     v.tail = f.tail_carry;

@@ -356,7 +356,23 @@ constexpr int kSeedListCap = 1 << 16;
 
 __global__ void k_pair_scan(const float* __restrict__ v, const float* __restrict__ ranks, int64_t n_orig, int64_t n_pad, int64_t xg_len,
                             float* __restrict__ v_int, float* __restrict__ y0, float* __restrict__ xg, int32_t* __restrict__ list,
-                            int* __restrict__ count) {
+                            int* __restrict__ count, LoopState* init_state, LoopAux* init_aux) {
+    // the loop state of the run that follows starts here (one launch fewer in front of the first step: k_state_init)
+    if (init_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (init_aux != nullptr) {
+            init_aux->pred_inv[0] = init_aux->pred_inv[1] = 1.0;
+            init_aux->pred_raw[0] = init_aux->pred_raw[1] = 0.0;
+            init_aux->sum_p = 0.0;
+            init_aux->worst_miss = 0.0;
+        }
+        init_state->scale = 1.0;
+        init_state->err = 0.0;
+        init_state->sum = 0.0;
+        init_state->done = 0;
+        init_state->steps = 0;
+        init_state->converged = 0;
+        init_state->pad = 0;
+    }
     const int64_t span = n_pad > xg_len ? n_pad : xg_len;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < span; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < n_pad) {
@@ -371,13 +387,11 @@ __global__ void k_pair_scan(const float* __restrict__ v, const float* __restrict
     }
 }
 
-__global__ void k_pair_scatter(const int32_t* __restrict__ list, const int* __restrict__ count, const float* __restrict__ v,
-                               const float* __restrict__ ranks, const int32_t* __restrict__ iperm, const float* __restrict__ scale,
-                               float* __restrict__ v_int, float* __restrict__ y0, float* __restrict__ xg, int xg_blk, int xg_live,
-                               float in_norm, int start_from_v, IsoTail iso) {
-    const int total = *count;
-    if (total > kSeedListCap) return;                       // dense operands: k_permute_in_pair does the work
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < total; k += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pair_scatter(const int32_t* __restrict__ list, int total, const float* __restrict__ v,
+                                             const float* __restrict__ ranks, const int32_t* __restrict__ iperm, const float* __restrict__ scale,
+                                             float* __restrict__ v_int, float* __restrict__ y0, float* __restrict__ xg, int xg_blk, int xg_live,
+                                             float in_norm, int start_from_v, const IsoTail& iso) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
         const int old = list[k];
         const int i = iperm[old];
         float a = v[old];
@@ -394,11 +408,20 @@ __global__ void k_pair_scatter(const int32_t* __restrict__ list, const int* __re
     }
 }
 
+// (seed_count != null: k_pair_scan has run.  Few enough non-zeros: they are scattered from its list -- the first blocks of this
+// launch do it, the others leave at once; else the gather pass over every slot, as without the scan)
 __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __restrict__ ranks, const int32_t* __restrict__ perm,
                                   const float* __restrict__ scale, int64_t n_pad, float* __restrict__ v_int, float* __restrict__ y0,
                                   float* __restrict__ xg, int xg_blk, int xg_live, float in_norm, int start_from_v,
-                                  IsoTail iso = IsoTail{}, const int* __restrict__ seed_count = nullptr) {
-    if (seed_count != nullptr && *seed_count <= kSeedListCap) return;      // the scan / scatter pair has done it
+                                  IsoTail iso = IsoTail{}, const int* __restrict__ seed_count = nullptr,
+                                  const int32_t* __restrict__ seed_list = nullptr, const int32_t* __restrict__ iperm = nullptr) {
+    if (seed_count != nullptr) {
+        const int total = *seed_count;
+        if (total <= kSeedListCap) {
+            pair_scatter(seed_list, total, v, ranks, iperm, scale, v_int, y0, xg, xg_blk, xg_live, in_norm, start_from_v, iso);
+            return;
+        }
+    }
     // four independent (index -> gather) chains per thread and round: one chain per round leaves the loop latency-bound
     constexpr int U = 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -438,8 +461,8 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
 // (isolated rows that the loop passed over hold zeros: not gathered)
 // A workgroup walks a CONTIGUOUS chunk of old ids.  Ties of the relabelling keep ascending ids (build_count_perm: a stable sort), and
 // most ids of a power-law graph share a handful of small reference counts, so the new ids of consecutive old ids are a few
-// ascending sequences per column block: every line of src a chunk touches is used up by the chunk itself (the CU's L1, its XCD's
-// L2).  Round 3 walked the ids with a grid-wide stride: the 32 entries of a line were fetched by 32 different CUs (54 us at scale 23).
+// ascending sequences per column block: the lines of src a chunk touches are its own.  (Round 3 walked the ids with a grid-wide
+// stride; measured the same at scale 23, 54-55 us either way: see profiles/r04/default_rule.log for what the counters say.)
 #ifndef PGH_OUT_CHUNK
 #define PGH_OUT_CHUNK 4096
 #endif
@@ -1202,7 +1225,8 @@ bool bsf_can_bring_pair(const pgh_graph_s* g) {
     return f.enabled && f.relabelled && f.perm != nullptr && f.n_out == f.n_src_pad;
 }
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
-                   bool start_from_v, bool watch_iso) {
+                   bool start_from_v, bool watch_iso, LoopState* init_state, LoopAux* init_aux, bool* state_inited) {
+    if (state_inited != nullptr) *state_inited = false;
     BsfFormat& f = g->bsf;
     IsoTail iso = IsoTail{};
     if (watch_iso && f.iso_flag != nullptr) {          // the flag starts at 0; any non-zero operand on an isolated row raises it
@@ -1220,14 +1244,13 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
         const int64_t xg_len = want_xg ? (f.xg_live > 0 ? (int64_t)f.num_blocks * f.xg_live : (int64_t)f.n_src_pad) + 1 : 0;
         const int64_t span = f.n_src_pad > xg_len ? f.n_src_pad : xg_len;
         k_pair_scan<<<blocks_for(span), kBlock, 0, rt().stream>>>(v, start_from_v ? nullptr : ranks, f.n_out_orig, f.n_src_pad, xg_len, v_int, y0,
-                                                                  want_xg ? f.xg : nullptr, f.seed_list, f.seed_count);
-        k_pair_scatter<<<64, kBlock, 0, rt().stream>>>(f.seed_list, f.seed_count, v, ranks, f.iperm, f.src_scale, v_int, y0,
-                                                       want_xg ? f.xg : nullptr, f.blk_size, f.xg_live, in_norm, start_from_v ? 1 : 0, iso);
+                                                                  want_xg ? f.xg : nullptr, f.seed_list, f.seed_count, init_state, init_aux);
+        if (state_inited != nullptr && init_state != nullptr) *state_inited = true;
         seed_count = f.seed_count;
     }
     k_permute_in_pair<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(v, ranks, f.perm, f.src_scale, f.n_src_pad, v_int, y0,
                                                                           want_xg ? f.xg : nullptr, f.blk_size, f.xg_live, in_norm,
-                                                                          start_from_v ? 1 : 0, iso, seed_count);
+                                                                          start_from_v ? 1 : 0, iso, seed_count, f.seed_list, f.iperm);
     PGH_HIP(hipGetLastError());
     return 0;
 }
@@ -1324,8 +1347,6 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.fix_seg);
     (void)hipFree(f.psum);
     (void)hipFree(f.psum64);
-    (void)hipFree(f.c64_src);
-    (void)hipFree(f.c64_begin);
     (void)hipFree(f.meta);
     (void)hipFree(f.live_dev);
     (void)hipFree(f.val);

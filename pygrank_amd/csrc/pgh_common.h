@@ -230,8 +230,6 @@ struct BsfFormat {
     // (block, 64 rows): bit r of mask = row 64 w + r has a segment in the block, base = index of the word's first segment
     float*    psum = nullptr;       // [num_segs + pad]
     double*   psum64 = nullptr;     // f64 image (pgh_bsf64.hip): the same compact partial sums in f64
-    uint32_t* c64_src = nullptr;    // f64 image: the cold entries' gather offsets, tile after tile (a tile's list: c64_begin[t] .. c64_begin[t + 1])
-    int32_t*  c64_begin = nullptr;  // [num_tiles + 1]
     bool      want_meta = false;    // set before bsf_build: a multi-seed-style image (cold entries in the stream) that also gets `meta`
     SegMeta*  meta = nullptr;       // [B][meta_words]
     int64_t   meta_words = 0;       // ceil(n_out / 64)

@@ -349,16 +349,18 @@ int wait_step(pgh_comm_s* c, int step, int* flag, const char* what) {
             *flag = (int)(unsigned int)w;
             return 0;
         }
-        if (++spins > 20000) {
-            std::this_thread::sleep_for(std::chrono::microseconds(100));
-            if ((spins & 1023) == 0) {
-                const hipError_t e = hipStreamQuery(c->ss);                    // a device fault ends the wait at once
-                if (e != hipSuccess && e != hipErrorNotReady) return fail(std::string("pgh_dist: waiting for ") + what + ": " + hipGetErrorString(e));
-            }
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() > limit)
-                return fail(std::string("pgh_dist: ") + what + " did not complete within PGH_DIST_TIMEOUT_S -- a collective is stalled (a peer "
-                            "gone, or communicators blocking each other: retry with a single communicator / stream)");
+        if ((++spins & 4095) != 0) continue;
+        // (a close normally lands within a step's time, a few hundred microseconds: the host spins through that -- a sleep here is
+        // a late enqueue of the next finish kernel -- and only a wait that has lasted 20 ms yields the core between looks)
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+        if (waited > 0.02) {
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+            const hipError_t e = hipStreamQuery(c->ss);                        // a device fault ends the wait at once
+            if (e != hipSuccess && e != hipErrorNotReady) return fail(std::string("pgh_dist: waiting for ") + what + ": " + hipGetErrorString(e));
         }
+        if (waited > limit)
+            return fail(std::string("pgh_dist: ") + what + " did not complete within PGH_DIST_TIMEOUT_S -- a collective is stalled (a peer "
+                        "gone, or communicators blocking each other: retry with a single communicator / stream)");
     }
 }
 }  // namespace

@@ -609,7 +609,8 @@ bool bsf_can_bring_pair(const pgh_graph_s* g);
 IsoTail iso_tail_of(const BsfFormat& f);
 int iso_flag_release(pgh_graph_s* g);
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
-                   bool start_from_v, bool watch_iso = false);
+                   bool start_from_v, bool watch_iso = false, LoopState* init_state = nullptr, LoopAux* init_aux = nullptr,
+                   bool* state_inited = nullptr);
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
 int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int);
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);

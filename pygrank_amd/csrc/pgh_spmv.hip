@@ -1563,11 +1563,13 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     // internal-space personalization: step 1 reads that vector and the even steps' output buffer is never initialised (33 MB fewer
     // written per run at scale 23; the rows a run passes over are read by nobody, see IsoTail)
     const float* x0 = nullptr;
+    bool state_inited = false;                   // the scan pass of the operands starts the loop state as well
     if (pair) {          // personalization, start vector and scaled gather vector in one pass over the permutation
         PGH_TRY(v_buf.alloc(n_int));
         PGH_TRY(y0.alloc(n_int));
         const bool alias = from_p && (MODE == EPI_AXPBY || MODE == EPI_ABSORB);
-        PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, alias ? nullptr : y0.p, scaled_gather, in_norm, from_p, watch_iso));
+        PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, alias ? nullptr : y0.p, scaled_gather, in_norm, from_p, watch_iso, g_state, g_aux,
+                               &state_inited));
         ep.v = v_buf.p;
         buf[0] = y0.p;
         if (alias) x0 = v_buf.p;
@@ -1636,7 +1638,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     bool fused = fuse_env && MODE == EPI_AXPBY && sp.blocked && g->bsf.pb.enabled && !overlap && pre_scale == nullptr &&
                  (cfg->err_kind == PGH_ERR_L1 || cfg->err_kind == PGH_ERR_MABS) && ep.v != nullptr;
     if (fused) PGH_TRY(bsf_ensure_degrees(g));
-    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0, g_aux);
+    if (!state_inited) k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0, g_aux);
     pending_close_slot().active = 0;
     int count_seen = 0;   // partials per step (the same for every step of a run)
     // the close of step k as a record: executed by the next blocked-format launch (deferred) or by k_step_close_rec
@@ -1725,7 +1727,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         return 0;
     };
     int enq = 0;          // steps enqueued so far
-    bool done = false;
+    bool done = false, state_fetched = false;
     for (;;) {
         while (!done && enq < max_steps) {
             if (poll) {
@@ -1754,7 +1756,9 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
         PGH_TRY(flush_pending_close());
         PGH_TRY(fetch_state());
+        state_fetched = true;                        // nothing is enqueued between here and the end of the run
         if (g_state_host->done != 2) break;
+        state_fetched = false;
         const int k = g_state_host->steps + 1;       // the paused step
         fused = false;
         k_state_resume<<<1, 1, 0, r.stream>>>(g_state, g_progress_dev);
@@ -1778,9 +1782,11 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         done = g_state_host->done != 0;
         res->flags |= 1;
     }
-    if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
-    PGH_TRY(flush_pending_close());                  // a no-op once the loop has ended on the device
-    PGH_TRY(fetch_state());
+    if (!state_fetched) {
+        if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
+        PGH_TRY(flush_pending_close());              // a no-op once the loop has ended on the device
+        PGH_TRY(fetch_state());
+    }
     const int steps = g_state_host->steps;
     // result lives in buf[steps & 1]; apply the pending quotient and preserve_norm factor
     const double factor = g_state_host->scale * cfg->out_scale;
