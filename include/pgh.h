@@ -216,7 +216,9 @@ typedef struct {
      * the personalization the loop uses is p / in_norm (abstract_filters.py:55; 0 means 1), and with start_from_p != 0
      * the starting vector is that same p / in_norm (abstract_filters.py:56 without warm_start) -- `ranks` is then
      * output only. */
-    double  in_norm;
+    double  in_norm;        /* < 0: the engine computes sum |p| itself (abstract_filters.py:52; pgh_loop_result::in_norm reports it --
+                             * 0 there means "all zeros": `ranks` is then untouched and the caller hands the personalization back,
+                             * abstract_filters.py:53-54) -- and out_scale < 0 stands for "times that norm" (preserve_norm)   */
     int32_t start_from_p;
     int32_t reserved;
 } pgh_loop_cfg;
@@ -228,6 +230,7 @@ typedef struct {
     int32_t flags;          /* bit 0: the in-kernel residual paused once and the run went on with the separate residual kernel */
     double  last_error;     /* residual of the last executed check                                */
     double  loop_ms;        /* HIP-event time of the loop on the engine stream                    */
+    double  in_norm;        /* the L1 norm of the personalization when the run computed it (cfg in_norm < 0), else 0 */
 } pgh_loop_result;
 
 /* ranks: in = starting vector (copy of p or warm_start), out = final ranks. */

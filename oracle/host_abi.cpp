@@ -742,28 +742,63 @@ static std::vector<float> normalised(pgh_vec_t p, const pgh_loop_cfg* cfg) {
     }
     return out;
 }
-int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
-    CHECK(g && p && ranks && cfg && res, "pgh_ppr_run: null argument");
+// pgh_loop_cfg::in_norm < 0: the engine computes sum |p| itself (abstract_filters.py:52), out_scale < 0 = "times that norm".
+// Returns the configuration with both resolved; *norm = 0 means "hand the personalization back" (the caller returns at once).
+static pgh_loop_cfg resolve_norm(pgh_vec_t p, const pgh_loop_cfg* cfg, double* norm, bool* wanted) {
+    pgh_loop_cfg c = *cfg;
+    *wanted = cfg->in_norm < 0.0;
+    *norm = cfg->in_norm;
+    if (*wanted) {
+        double s = 0.0;
+        for (int64_t i = 0; i < p->n; ++i) s += std::fabs((double)p->data[i]);
+        *norm = s;
+        c.in_norm = s;
+    }
+    if (cfg->out_scale < 0.0) c.out_scale = *norm;
+    return c;
+}
+#define PGH_RESOLVE_NORM(P, CFG, RES)                              \
+    double norm_ = 0.0;                                            \
+    bool norm_wanted_ = false;                                     \
+    const pgh_loop_cfg cfg_ = resolve_norm(P, CFG, &norm_, &norm_wanted_); \
+    if (norm_wanted_ && norm_ == 0.0) {                            \
+        memset(RES, 0, sizeof(*RES));                              \
+        (RES)->iterations = 1;                                     \
+        return 0;                                                  \
+    }                                                              \
+    const pgh_loop_cfg* cfg = &cfg_;
+#define PGH_REPORT_NORM(RC, RES)                                   \
+    if ((RC) == 0 && norm_wanted_) (RES)->in_norm = norm_;
+
+int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg_in, pgh_loop_result* res) {
+    CHECK(g && p && ranks && cfg_in && res, "pgh_ppr_run: null argument");
     CHECK(p->n == g->n_cols, "pgh_ppr_run: personalization length mismatch");
+    PGH_RESOLVE_NORM(p, cfg_in, res)
     const std::vector<float> pn = normalised(p, cfg);
-    return recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
+    const int rc = recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
         return ppr_step(g, x, xs, pn.data(), cfg->alpha, y);
     });
+    PGH_REPORT_NORM(rc, res)
+    return rc;
 }
-int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg,
+int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg_in,
                    pgh_loop_result* res) {
-    CHECK(g && p && lam && ranks && cfg && res, "pgh_absorb_run: null argument");
+    CHECK(g && p && lam && ranks && cfg_in && res, "pgh_absorb_run: null argument");
     CHECK(p->n == g->n_cols && lam->n == g->n_cols, "pgh_absorb_run: vector length mismatch");
+    PGH_RESOLVE_NORM(p, cfg_in, res)
     const std::vector<float> pn = normalised(p, cfg);
-    return recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
+    const int rc = recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
         return absorb_step(g, x, xs, pn.data(), g->degrees.data(), lam->data, y);
     });
+    PGH_REPORT_NORM(rc, res)
+    return rc;
 }
 
 // SymmetricAbsorbingRandomWalks (adhoc.py:348-364) written the way the reference writes it: precomputed skews, pre-scaled iterate
-int pgh_sarw_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
-    CHECK(g && p && ranks && cfg && res, "pgh_sarw_run: null argument");
+int pgh_sarw_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg_in, pgh_loop_result* res) {
+    CHECK(g && p && ranks && cfg_in && res, "pgh_sarw_run: null argument");
     CHECK(p->n == g->n_cols && g->n_rows == g->n_cols, "pgh_sarw_run: shape mismatch");
+    PGH_RESOLVE_NORM(p, cfg_in, res)
     const int64_t n = g->n_cols;
     const std::vector<float> pn = normalised(p, cfg);
     std::vector<float> left(n), post(n), skew(n), xs_buf(n);
@@ -774,7 +809,7 @@ int pgh_sarw_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg
         post[i] = (float)(deg / (a + deg));
         skew[i] = (float)(a / (a + deg));
     }
-    return recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
+    const int rc = recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
         for (int64_t i = 0; i < n; ++i) xs_buf[i] = x[i] * left[i];
         const float s = (float)xs;
         double sum = 0;
@@ -785,6 +820,8 @@ int pgh_sarw_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg
         }
         return sum;
     });
+    PGH_REPORT_NORM(rc, res)
+    return rc;
 }
 
 int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, int32_t chebyshev,

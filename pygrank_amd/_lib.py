@@ -31,7 +31,7 @@ class LoopCfg(C.Structure):
 
 class LoopResult(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("spmv_count", C.c_int32),
-                ("flags", C.c_int32), ("last_error", C.c_double), ("loop_ms", C.c_double)]
+                ("flags", C.c_int32), ("last_error", C.c_double), ("loop_ms", C.c_double), ("in_norm", C.c_double)]
 
 
 class DistCfg(C.Structure):

@@ -356,9 +356,37 @@ constexpr int kSeedListCap = 1 << 16;
 
 __global__ void k_pair_scan(const float* __restrict__ v, const float* __restrict__ ranks, int64_t n_orig, int64_t n_pad, int64_t xg_len,
                             float* __restrict__ v_int, float* __restrict__ y0, float* __restrict__ xg, int32_t* __restrict__ list,
-                            int* __restrict__ count, LoopState* init_state, LoopAux* init_aux) {
-    // the loop state of the run that follows starts here (one launch fewer in front of the first step: k_state_init)
-    if (init_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+                            int* __restrict__ count, double* __restrict__ norm_partials) {
+    __shared__ double s_red[4];
+    double abs_sum = 0.0;                        // this thread's share of sum |v| (GraphFilter.rank's norm, abstract_filters.py:52)
+    const int64_t span = n_pad > xg_len ? n_pad : xg_len;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < span; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_pad) {
+            v_int[i] = 0.f;
+            if (y0 != nullptr) y0[i] = 0.f;
+        }
+        if (xg != nullptr && i < xg_len) xg[i] = 0.f;
+        if (i < n_orig) {
+            const float vi = v[i];
+            abs_sum += fabs((double)vi);
+            if (vi != 0.f || (ranks != nullptr && ranks[i] != 0.f)) {
+                const int pos = atomicAdd(count, 1);
+                if (pos < kSeedListCap) list[pos] = (int32_t)i;
+            }
+        }
+    }
+    if (norm_partials != nullptr) {              // fixed order: a thread's ids, the workgroup's tree, the workgroups in k_scan_close
+        const double total = block_reduce_256<0>(abs_sum, s_red);
+        if (threadIdx.x == 0) norm_partials[blockIdx.x] = total;
+    }
+}
+
+// one workgroup behind the scan: starts the loop state of the run that follows (k_state_init's work) and folds the scan's
+// partials of sum |v| into LoopAux::in_norm
+__global__ __launch_bounds__(kBlock) void k_scan_close(const double* __restrict__ norm_partials, int count, LoopState* init_state,
+                                                       LoopAux* init_aux) {
+    __shared__ double s4[4];
+    if (init_state != nullptr && threadIdx.x == 0) {
         if (init_aux != nullptr) {
             init_aux->pred_inv[0] = init_aux->pred_inv[1] = 1.0;
             init_aux->pred_raw[0] = init_aux->pred_raw[1] = 0.0;
@@ -373,17 +401,9 @@ __global__ void k_pair_scan(const float* __restrict__ v, const float* __restrict
         init_state->converged = 0;
         init_state->pad = 0;
     }
-    const int64_t span = n_pad > xg_len ? n_pad : xg_len;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < span; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i < n_pad) {
-            v_int[i] = 0.f;
-            if (y0 != nullptr) y0[i] = 0.f;
-        }
-        if (xg != nullptr && i < xg_len) xg[i] = 0.f;
-        if (i < n_orig && (v[i] != 0.f || (ranks != nullptr && ranks[i] != 0.f))) {
-            const int pos = atomicAdd(count, 1);
-            if (pos < kSeedListCap) list[pos] = (int32_t)i;
-        }
+    if (norm_partials != nullptr && init_aux != nullptr) {
+        const double norm = fold_partials_wide(norm_partials, count, 0, s4);
+        if (threadIdx.x == 0) init_aux->in_norm = norm;
     }
 }
 
@@ -414,7 +434,10 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
                                   const float* __restrict__ scale, int64_t n_pad, float* __restrict__ v_int, float* __restrict__ y0,
                                   float* __restrict__ xg, int xg_blk, int xg_live, float in_norm, int start_from_v,
                                   IsoTail iso = IsoTail{}, const int* __restrict__ seed_count = nullptr,
-                                  const int32_t* __restrict__ seed_list = nullptr, const int32_t* __restrict__ iperm = nullptr) {
+                                  const int32_t* __restrict__ seed_list = nullptr, const int32_t* __restrict__ iperm = nullptr,
+                                  const LoopAux* __restrict__ norm_from = nullptr) {
+    // the norm the scan has just summed (a zero personalization divides by 1: every vector of the run is zero, the caller is told)
+    if (norm_from != nullptr) in_norm = norm_from->in_norm != 0.0 ? (float)norm_from->in_norm : 1.f;
     if (seed_count != nullptr) {
         const int total = *seed_count;
         if (total <= kSeedListCap) {
@@ -1220,6 +1243,7 @@ int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale,
 }
 
 // recursive loops on square relabelled graphs: both loop operands (and the scaled gather vector) in one launch
+bool bsf_can_norm_on_device(const pgh_graph_s* g) { return bsf_can_bring_pair(g) && g->bsf.iperm != nullptr && rt().num_cus * 16 <= kMaxPartials; }
 bool bsf_can_bring_pair(const pgh_graph_s* g) {
     const BsfFormat& f = g->bsf;
     return f.enabled && f.relabelled && f.perm != nullptr && f.n_out == f.n_src_pad;
@@ -1234,8 +1258,11 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
         iso = iso_tail_of(f);
     }
     const int* seed_count = nullptr;
-    // (small graphs: the gather pass takes a few microseconds, two more launches would cost more)
-    if (f.iperm != nullptr && f.n_src_pad >= (1 << 21) && env_int("PGH_SEED_LIST", 1) != 0) {
+    const bool norm_here = in_norm < 0.f;              // the caller left GraphFilter.rank's norm to this pass
+    PGH_CHECK(!norm_here || (f.iperm != nullptr && init_aux != nullptr), "bsf_bring_pair: the norm cannot be computed on this layout");
+    // (small graphs: the gather pass takes a few microseconds, two more launches would cost more -- unless the scan also saves the
+    // caller a reduction and a host round trip for the norm)
+    if (f.iperm != nullptr && (norm_here || (f.n_src_pad >= (1 << 21) && env_int("PGH_SEED_LIST", 1) != 0))) {
         if (f.seed_list == nullptr) {
             PGH_HIP(hipMalloc(&f.seed_list, sizeof(int32_t) * (size_t)kSeedListCap));
             PGH_HIP(hipMalloc(&f.seed_count, sizeof(int)));
@@ -1243,14 +1270,20 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
         PGH_HIP(hipMemsetAsync(f.seed_count, 0, sizeof(int), rt().stream));
         const int64_t xg_len = want_xg ? (f.xg_live > 0 ? (int64_t)f.num_blocks * f.xg_live : (int64_t)f.n_src_pad) + 1 : 0;
         const int64_t span = f.n_src_pad > xg_len ? f.n_src_pad : xg_len;
-        k_pair_scan<<<blocks_for(span), kBlock, 0, rt().stream>>>(v, start_from_v ? nullptr : ranks, f.n_out_orig, f.n_src_pad, xg_len, v_int, y0,
-                                                                  want_xg ? f.xg : nullptr, f.seed_list, f.seed_count, init_state, init_aux);
-        if (state_inited != nullptr && init_state != nullptr) *state_inited = true;
+        const int scan_grid = blocks_for(span);         // <= 16 workgroups per CU: within kMaxPartials
+        double* norm_partials = norm_here ? rt().d_partials : nullptr;     // (no step is in flight: the region is free)
+        k_pair_scan<<<scan_grid, kBlock, 0, rt().stream>>>(v, start_from_v ? nullptr : ranks, f.n_out_orig, f.n_src_pad, xg_len, v_int, y0,
+                                                           want_xg ? f.xg : nullptr, f.seed_list, f.seed_count, norm_partials);
+        if (norm_here || init_state != nullptr) {
+            k_scan_close<<<1, kBlock, 0, rt().stream>>>(norm_partials, scan_grid, init_state, init_aux);
+            if (state_inited != nullptr && init_state != nullptr) *state_inited = true;
+        }
         seed_count = f.seed_count;
     }
     k_permute_in_pair<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(v, ranks, f.perm, f.src_scale, f.n_src_pad, v_int, y0,
                                                                           want_xg ? f.xg : nullptr, f.blk_size, f.xg_live, in_norm,
-                                                                          start_from_v ? 1 : 0, iso, seed_count, f.seed_list, f.iperm);
+                                                                          start_from_v ? 1 : 0, iso, seed_count, f.seed_list, f.iperm,
+                                                                          norm_here ? init_aux : nullptr);
     PGH_HIP(hipGetLastError());
     return 0;
 }

@@ -124,6 +124,8 @@ int comm_all_gather(pgh_comm_s* c, const void* send, void* recv, size_t count, n
     return 0;
 }
 int comm_all_reduce(pgh_comm_s* c, void* buf, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm, hipStream_t st) {
+    // (a rank alone reduces with nobody: in place, the result is already there -- one launch fewer in the dependent chain of a step)
+    if (c->world == 1 && c->ext_reduce == nullptr && !(getenv("PGH_DIST_REDUCE_ALONE") != nullptr && atoi(getenv("PGH_DIST_REDUCE_ALONE")) != 0)) return 0;
     if (c->ext_reduce != nullptr) {
         const int32_t dtype = dt == ncclFloat32 ? 0 : (dt == ncclFloat64 ? 1 : 2);
         PGH_CHECK(c->ext_reduce(c->ext_user, buf, (int64_t)count, dtype, op == ncclMax ? 1 : 0, (void*)st) == 0,

@@ -73,6 +73,7 @@ struct LoopAux {
     double pred_raw[2];   // the uncorrected prediction of sum(y) of step k at [k & 1] (0: none)
     double sum_p;         // sum of the (normalised) personalization
     double worst_miss;    // largest |inv - inv'| / |inv| seen by a checking close of this run (diagnostic)
+    double in_norm;       // L1 norm of the caller's personalization when the run computed it itself (pgh_loop_cfg::in_norm < 0)
 };
 struct ResParams {
     const float*   x_prev;   // previous iterate (internal ids, un-normalised; its quotient is LoopState::scale)
@@ -608,9 +609,12 @@ int bsf_to_internal(pgh_graph_s* g, const float* src, float* dst, bool prescale,
 bool bsf_can_bring_pair(const pgh_graph_s* g);
 IsoTail iso_tail_of(const BsfFormat& f);
 int iso_flag_release(pgh_graph_s* g);
+// (in_norm < 0: the pass computes the L1 norm of v itself -- k_pair_scan sums |v| beside listing its non-zeros -- divides by it and
+// leaves it in init_aux->in_norm; init_state / init_aux: the loop state of the run is started by the same launches)
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
                    bool start_from_v, bool watch_iso = false, LoopState* init_state = nullptr, LoopAux* init_aux = nullptr,
                    bool* state_inited = nullptr);
+bool bsf_can_norm_on_device(const pgh_graph_s* g);
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
 int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int);
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);

@@ -596,6 +596,7 @@ int residual_grid(int64_t n) {
 LoopState* g_state = nullptr;
 LoopState* g_state_host = nullptr;
 LoopAux*   g_aux = nullptr;          // fused-residual scalars of the recursive loops (ResParams)
+LoopAux*   g_aux_host = nullptr;     // pinned mirror, fetched with the state
 
 // Host-visible progress of the device loop: {steps executed, done flag}, written by k_step_close into pinned mapped
 // memory.  The host keeps a window of iterations enqueued ahead of the last step it has seen complete, so the stream
@@ -624,10 +625,16 @@ int flush_pending_close() {
 
 int ensure_state() {
     if (g_state) return 0;
-    PGH_HIP(hipMalloc(&g_state, sizeof(LoopState)));
-    PGH_HIP(hipMalloc(&g_aux, sizeof(LoopAux)));
-    PGH_HIP(hipMemset(g_aux, 0, sizeof(LoopAux)));
-    PGH_HIP(hipHostMalloc(&g_state_host, sizeof(LoopState), hipHostMallocDefault));
+    static_assert(sizeof(LoopState) % 8 == 0, "LoopAux follows LoopState in one allocation");
+    void* both = nullptr;
+    PGH_HIP(hipMalloc(&both, sizeof(LoopState) + sizeof(LoopAux)));
+    PGH_HIP(hipMemset(both, 0, sizeof(LoopState) + sizeof(LoopAux)));
+    g_state = reinterpret_cast<LoopState*>(both);
+    g_aux = reinterpret_cast<LoopAux*>(reinterpret_cast<char*>(both) + sizeof(LoopState));
+    void* both_host = nullptr;
+    PGH_HIP(hipHostMalloc(&both_host, sizeof(LoopState) + sizeof(LoopAux), hipHostMallocDefault));
+    g_state_host = reinterpret_cast<LoopState*>(both_host);
+    g_aux_host = reinterpret_cast<LoopAux*>(reinterpret_cast<char*>(both_host) + sizeof(LoopState));
     void* hp = nullptr;
     PGH_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
     g_progress_host = (volatile int*)hp;
@@ -650,7 +657,8 @@ int ensure_state() {
 }
 
 int fetch_state() {
-    PGH_HIP(hipMemcpyAsync(g_state_host, g_state, sizeof(LoopState), hipMemcpyDeviceToHost, rt().stream));
+    // (state and aux are ONE allocation: the norm a run computed for itself comes back with the state, one copy)
+    PGH_HIP(hipMemcpyAsync(g_state_host, g_state, sizeof(LoopState) + sizeof(LoopAux), hipMemcpyDeviceToHost, rt().stream));
     PGH_HIP(hipStreamSynchronize(rt().stream));
     return 0;
 }
@@ -1525,8 +1533,24 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     DevF32 v_buf, deg_buf, lam_buf, y0, y1, pn_buf;
     const bool scaled_gather = sp.blocked && g->bsf.src_scale != nullptr;
     const bool pair = sp.blocked && bsf_can_bring_pair(g);
-    // GraphFilter.rank's prologue (abstract_filters.py:55-56) folded into the loop: p / in_norm, start vector = that
-    const float in_norm = (cfg->in_norm != 0.0) ? (float)cfg->in_norm : 1.f;
+    // GraphFilter.rank's prologue (abstract_filters.py:52-56) folded into the loop: p / in_norm, start vector = that.
+    // in_norm < 0: the norm itself (sum |p|) is left to the engine too -- summed by the scan pass of the operands on layouts that
+    // have one (no reduction launch, no host round trip before the first step), by pgh_reduce otherwise; res->in_norm reports it,
+    // and out_scale < 0 stands for "times that norm" (preserve_norm).  A zero norm: the caller gets the personalization back
+    // (abstract_filters.py:53-54) -- res->in_norm says so, whatever the loop computed on its all-zero vectors is dropped.
+    const bool norm_wanted = cfg->in_norm < 0.0;
+    const bool norm_on_device = norm_wanted && pair && bsf_can_norm_on_device(g);
+    double host_norm = cfg->in_norm;
+    if (norm_wanted && !norm_on_device) {
+        pgh_vec_s pv{const_cast<float*>(ep.v), n, false};
+        PGH_TRY(pgh_reduce(PGH_ABSSUM, &pv, &host_norm));
+        res->in_norm = host_norm;
+        if (host_norm == 0.0) {
+            res->iterations = 1;
+            return 0;
+        }
+    }
+    const float in_norm = norm_on_device ? -1.f : ((host_norm != 0.0) ? (float)host_norm : 1.f);
     const bool from_p = cfg->start_from_p != 0;
     if (!pair && (in_norm != 1.f || from_p)) {       // layouts without the fused permutation: materialise the prologue
         pgh_vec_s pv, tv;
@@ -1789,7 +1813,9 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     }
     const int steps = g_state_host->steps;
     // result lives in buf[steps & 1]; apply the pending quotient and preserve_norm factor
-    const double factor = g_state_host->scale * cfg->out_scale;
+    const double norm_used = norm_on_device ? g_aux_host->in_norm : host_norm;
+    if (norm_wanted) res->in_norm = norm_used;
+    const double factor = g_state_host->scale * (cfg->out_scale < 0.0 ? norm_used : cfg->out_scale);
     const float* final_buf = (steps == 0 && x0 != nullptr) ? x0 : buf[steps & 1];
     if (sp.blocked) {
         PGH_TRY(bsf_to_original(g, final_buf, ranks->data, factor));

@@ -60,15 +60,16 @@ class GraphFilter(NodeRanking):
         seed_signal = to_signal(graph, personalization)
         self._prepare(seed_signal)
         signal = self.personalization_transform(seed_signal)
+        if warm_start is None and graph_dropout == 0:
+            # norm, normalisation and start vector folded into the engine's first pass over the operands (pgh_loop_cfg.in_norm < 0,
+            # start_from_p): no reduction and no host round trip in front of the first step.  A zero norm comes back as the signal.
+            fused = self._fused_rank(signal, *args, **kwargs)
+            if fused is not None:
+                return fused
         raw = signal.np
         norm = raw.abssum() if isinstance(raw, DeviceVector) else backend.sum(backend.abs(raw))
         if norm == 0:
             return signal                       # nothing to spread: the reference hands the (all-zero) signal back
-        if warm_start is None and graph_dropout == 0:
-            # normalisation and start vector folded into the engine's first pass over the operands (pgh_loop_cfg.in_norm / start_from_p)
-            fused = self._fused_rank(signal, norm, *args, **kwargs)
-            if fused is not None:
-                return fused
         signal = to_signal(signal, signal.np / norm)
         # the reference never writes into the caller's warm_start (every step builds a fresh array); the device loops update
         # their iterate in place, so the start vector is always a copy
@@ -95,9 +96,9 @@ class GraphFilter(NodeRanking):
         self._end(operator(), signal, ranks, *args, **kwargs)
 
     # ---- hooks
-    def _fused_rank(self, personalization, norm, *args, **kwargs):
-        """Whole rank() after the norm check inside the engine, starting from the UN-normalised personalization; returns
-        the ranks signal or None when this filter / configuration has no such route."""
+    def _fused_rank(self, personalization, *args, **kwargs):
+        """Whole rank() inside the engine, norm included, starting from the UN-normalised personalization; returns the ranks
+        signal (the personalization itself when its norm is zero) or None when this filter / configuration has no such route."""
         return None
 
     def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
@@ -208,6 +209,8 @@ class RecursiveGraphFilter(GraphFilter):
             return False
         res = L.LoopResult()
         L.check(entry(g._h, *[v._h for v in vectors], x._h, C.byref(cfg), C.byref(res)))
+        if cfg.in_norm < 0 and res.in_norm == 0:
+            return "zero"                  # an all-zero personalization: nothing was run, nothing is counted
         ranks.np = x                       # updated in place by the engine; drops the host mirror
         self.last_loop = dict(iterations=res.iterations, converged=bool(res.converged), spmv=res.spmv_count,
                               last_error=res.last_error, loop_ms=res.loop_ms, flags=res.flags)
@@ -238,22 +241,27 @@ class PageRank(RecursiveGraphFilter):
             return False
         return self._run_recursive(L.lib().pgh_ppr_run, _device_graph(M), cfg, ranks, p)
 
-    def _fused_rank(self, personalization, norm, *args, **kwargs):
+    def _fused_rank(self, personalization, *args, **kwargs):
         if args or kwargs or not self._plain_quotient() or type(self)._formula is not PageRank._formula \
                 or type(self)._step is not RecursiveGraphFilter._step or type(self)._prepare_graph is not GraphFilter._prepare_graph:
             return None
         p = personalization.np
-        cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), norm if self.preserve_norm else 1.0)
+        cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), -1.0 if self.preserve_norm else 1.0)     # -1: times the norm
         if cfg is None or not isinstance(p, DeviceVector):
             return None
         M = self.preprocessor(personalization.graph)
         g = _device_graph(M)
         if g is None or g.shape[0] != g.shape[1] or g.shape[0] != len(p):
             return None
-        cfg.in_norm, cfg.start_from_p = float(norm), 1
+        cfg.in_norm, cfg.start_from_p = -1.0, 1            # the engine sums |p| itself
+        before = dict(vars(self.convergence))
         self.convergence.start()
         ranks = to_signal(personalization, DeviceVector.empty(len(p)))
-        return ranks if self._run_recursive(L.lib().pgh_ppr_run, g, cfg, ranks, p) else None
+        outcome = self._run_recursive(L.lib().pgh_ppr_run, g, cfg, ranks, p)
+        if outcome == "zero":                              # abstract_filters.py:53-54: returned before the manager is started
+            vars(self.convergence).update(before)
+            return personalization
+        return ranks if outcome else None
 
     def propagate(self, graph, features, *args, **kwargs):
         """signals.py:225-226 semantics (one rank() per feature column), run as multi-seed batches of up to 64 columns
