@@ -233,6 +233,11 @@ typedef struct {
     double  in_norm;        /* the L1 norm of the personalization when the run computed it (cfg in_norm < 0), else 0 */
 } pgh_loop_result;
 
+/* pgh_ppr_run on graph_dropout(M, rate) with a fresh mask per step (abstract_filters.py:59-62; pytorch.py:34-38) as ONE device loop:
+ * step k multiplies by the matrix masked with seed seed0 + k - 1 -- the mask of pgh_spmv_dropout, evaluated inside the step's
+ * kernels on whichever layout the graph carries (blocked stream + cold image: one index word per entry, built on first use). */
+int pgh_ppr_run_dropout(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, double rate, uint64_t seed0,
+                        pgh_loop_result* res);
 /* ranks: in = starting vector (copy of p or warm_start), out = final ranks. */
 int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg,

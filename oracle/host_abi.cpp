@@ -781,6 +781,41 @@ int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg*
     PGH_REPORT_NORM(rc, res)
     return rc;
 }
+// PageRank on graph_dropout(M, rate) with the mask of step k = pgh_spmv_dropout's for seed seed0 + k - 1
+int pgh_ppr_run_dropout(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg_in, double rate, uint64_t seed0,
+                        pgh_loop_result* res) {
+    CHECK(g && p && ranks && cfg_in && res, "pgh_ppr_run_dropout: null argument");
+    CHECK(p->n == g->n_cols, "pgh_ppr_run_dropout: personalization length mismatch");
+    CHECK(rate >= 0.0 && rate < 1.0, "pgh_ppr_run_dropout: rate must lie in [0, 1)");
+    PGH_RESOLVE_NORM(p, cfg_in, res)
+    const std::vector<float> pn = normalised(p, cfg);
+    const uint32_t threshold = (uint32_t)std::floor(rate * 4294967296.0);
+    const float keep = (float)(1.0 / (1.0 - rate));
+    uint64_t step_no = 0;
+    const int rc = recursive_run(g, ranks, cfg, res, pn.data(), [&](const float* x, double xs, float* y) {
+        const uint64_t seed = seed0 + step_no++;
+        const float a = (float)(cfg->alpha * xs), b = (float)(1.0 - cfg->alpha);
+        double sum = 0;
+        for (int64_t r = 0; r < g->n_cols; ++r) {
+            double acc = 0;
+            for (int64_t k = g->rowptr[r]; k < g->rowptr[r + 1]; ++k) {
+                uint64_t z = (seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ULL)) + 0x9E3779B97F4A7C15ULL;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+                z = z ^ (z >> 31);
+                const float f = (uint32_t)(z >> 32) >= threshold ? keep : 0.f;
+                acc += (double)((g->val[k] * f) * x[g->col[k]]);
+            }
+            const float v = a * (float)acc + b * pn[r];
+            y[r] = v;
+            sum += v;
+        }
+        return sum;
+    });
+    PGH_REPORT_NORM(rc, res)
+    return rc;
+}
+
 int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg_in,
                    pgh_loop_result* res) {
     CHECK(g && p && lam && ranks && cfg_in && res, "pgh_absorb_run: null argument");

@@ -125,7 +125,8 @@ __global__ void k_bsf_keys(const int32_t* __restrict__ rowptr, const int32_t* __
             const int64_t o = offs ? offs[k] : k;
             const int m = mult ? mult[k] : 1;
             for (int q = 0; q < m; ++q) keys[o + q] = key;
-            if (vals_out) vals_out[o] = val[k];
+            if (vals_out)                                  // (value AND multiplicity: every copy carries the value -- the entry-index
+                for (int q = 0; q < m; ++q) vals_out[o + q] = val[k];       // words of graph_dropout are built that way)
         }
     }
 }
@@ -619,9 +620,9 @@ constexpr int kBsfLdsFloats = kBsfHot + 1 + (kBsfThreads / 64) * (64 * kIPT + 1 
 
 // The body of the block partial sums for the workgroup `vblock` of `vgrid` (its own launch: blockIdx / gridDim; inside the
 // merged front kernel of a step: the workgroup's index among the partial-sum workgroups).
-template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false>
+template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false, bool DROP = false>
 __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, const BsfView& f, const float* __restrict__ xg,
-                                                 const unsigned int vblock, const unsigned int vgrid) {
+                                                 const unsigned int vblock, const unsigned int vgrid, const DropView dv = DropView{}) {
     static_assert(IPT == 8, "one flag byte per lane; lanes fetch their entries as 16-byte words");
     static_assert(!(W16 && COLD), "the 16-bit stream addresses the hot cache only");
     constexpr int T = 64 * IPT;
@@ -670,6 +671,7 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
     struct Stream {
         u32x4        c[Q];
         u32x4        v[Q];
+        u32x4        e[DROP ? Q : 1];    // graph_dropout: the entries' indices in CSR(M^T) order (laid out like the values)
         unsigned int bits;           // segment-start flags of the lane's IPT entries
         int          seg_base;
     };
@@ -685,6 +687,8 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
             : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(f.colf + (int64_t)tb * T), 0, clamp32(blk_tiles * T * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(HAS_VAL ? f.val + (int64_t)tb * T : nullptr), 0, HAS_VAL ? clamp32(blk_tiles * T * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t edge_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t*>(DROP ? dv.edge + (int64_t)tb * T : nullptr), 0, DROP ? clamp32(blk_tiles * T * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t flag_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(f.flags8 + (int64_t)tb * 64), 0, clamp32(blk_tiles * 64), 0x00020000);
     const int lane32 = PGH_TILE_TRANSPOSE ? lane * 16 : lane * (IPT * 4);
@@ -702,6 +706,10 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
 #pragma unroll
             for (int q = 0; q < Q; ++q) st.v[q] = __builtin_amdgcn_raw_buffer_load_b128(val_rsrc, lane32 + kQStep * q, rel * (T * 4), kNT);
         }
+        if (DROP) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) st.e[q] = __builtin_amdgcn_raw_buffer_load_b128(edge_rsrc, lane32 + kQStep * q, rel * (T * 4), kNT);
+        }
         st.bits = __builtin_amdgcn_raw_buffer_load_b8(flag_rsrc, lane, rel * 64, 0);
         st.seg_base = f.tile[tile].z;
     };
@@ -710,19 +718,23 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
     struct Gathered {
         float        h[IPT];
         float        c[IPT];
-        float        v[HAS_VAL ? IPT : 1];
+        float        v[(HAS_VAL || DROP) ? IPT : 1];      // the entry's value; with DROP: times its mask factor (0 or 1 / (1 - rate))
         unsigned int bits;
         int          seg_base;
     };
     auto gather = [&](const Stream& st, Gathered& g) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
+            if (DROP) {
+                const float m = dropout_factor(dv.seed, (uint64_t)st.e[k >> 2][k & 3], dv.threshold, dv.keep_scale);
+                g.v[k] = HAS_VAL ? __uint_as_float(st.v[k >> 2][k & 3]) * m : m;
+            }
             if (W16) {                    // halfword k of the lane's 16 bytes = byte offset / 2 into the hot cache
                 const uint32_t pair = st.c[0][k >> 1];
                 const uint32_t off = (k & 1) ? (pair >> 16) << 1 : (pair & 0xffffu) << 1;
                 g.h[k] = *reinterpret_cast<const float*>(lds + off);
                 g.c[k] = 0.f;
-                if (HAS_VAL) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
+                if (HAS_VAL && !DROP) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
                 continue;
             }
             const uint32_t w = st.c[k >> 2][k & 3];
@@ -737,7 +749,7 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
             // COLD = false: the stream holds hot entries only (the cold ones live in the propagation-blocking image)
             g.c[k] = COLD ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cold_rsrc, w - hot4, 0, PGH_COLD_AUX)) : 0.f;
 #endif
-            if (HAS_VAL) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
+            if (HAS_VAL && !DROP) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);
         }
         g.bits = st.bits;            // fetched with the stream, three tiles ahead: as old as the column words used above
         g.seg_base = st.seg_base;
@@ -767,7 +779,7 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
             asm("v_mad_i32_i24 %0, %1, -4, %2" : "=v"(o4) : "v"(m), "v"(o4));                          \
             asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(accb) : "v"(m), "v"(accb));                           \
             float xv = g0.h[K] + g0.c[K];                                                              \
-            if (HAS_VAL) xv *= g0.v[K];                                                                \
+            if (HAS_VAL || DROP) xv *= g0.v[K];                                                        \
             accb = __builtin_bit_cast(int, __builtin_bit_cast(float, accb) + xv);                      \
         }
         PGH_ENTRY(0) PGH_ENTRY(1) PGH_ENTRY(2) PGH_ENTRY(3) PGH_ENTRY(4) PGH_ENTRY(5) PGH_ENTRY(6) PGH_ENTRY(7)
@@ -858,15 +870,15 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
 #undef PGH_STEP
 }
 
-template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false>
+template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false, bool DROP = false>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
-                                                              const LoopState* __restrict__ state, PendingClose pc) {
+                                                              const LoopState* __restrict__ state, PendingClose pc, DropView dv = DropView{}) {
     __shared__ __attribute__((aligned(16))) float s_lds[kBsfLdsFloats];
     if (state != nullptr && state->done) return;
     // the previous step's close, if the loop driver left it to this kernel (the LDS it uses is not yet in use)
     if (pc.active && run_pending_close(pc, reinterpret_cast<double*>(s_lds))) return;
     PGH_STAMP_BEGIN(g_times_partial)
-    bsf_partial_body<IPT, HAS_VAL, COLD, W16>(s_lds, f, xg, blockIdx.x, gridDim.x);
+    bsf_partial_body<IPT, HAS_VAL, COLD, W16, DROP>(s_lds, f, xg, blockIdx.x, gridDim.x, dv);
 #if PGH_PROBE_TIMES
     // wavefronts leave one by one: the workgroup's end = the latest of them (the clock only grows, so the maximum over
     // launches is the last launch's)
@@ -977,7 +989,19 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, 
     else pending_close_slot().active = 0;             // consumed
     if (stage != 2) {
         ProfScope prof(PGH_K_SPMV);
-        if (f.colf16 != nullptr) {
+        const DropView dv = bsf_dropout_view(f.drop_edge);
+        if (dv.edge != nullptr) {                      // graph_dropout: the same kernels with the mask factor per entry
+            if (f.colf16 != nullptr) {
+                if (f.val) k_bsf_partial<kIPT, true, false, true, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc, dv);
+                else k_bsf_partial<kIPT, false, false, true, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc, dv);
+            } else if (f.pb.enabled && !f.pb.k1_cold) {
+                if (f.val) k_bsf_partial<kIPT, true, false, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc, dv);
+                else k_bsf_partial<kIPT, false, false, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc, dv);
+            } else {
+                if (f.val) k_bsf_partial<kIPT, true, true, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc, dv);
+                else k_bsf_partial<kIPT, false, true, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc, dv);
+            }
+        } else if (f.colf16 != nullptr) {
             if (f.val) k_bsf_partial<kIPT, true, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc);
             else k_bsf_partial<kIPT, false, false, true><<<main_grid, kBsfThreads, 0, r.stream>>>(v, xg, state, pc);
         } else if (f.pb.enabled && !f.pb.k1_cold) {
@@ -1324,6 +1348,79 @@ int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int) 
     return 0;
 }
 
+// ---- graph_dropout on the blocked layouts -------------------------------------------------------------------------------------
+namespace {
+double   g_drop_rate = 0.0;
+uint64_t g_drop_seed = 0;
+bool     g_drop_on = false;
+__global__ void k_index_bits(float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = __int_as_float((int)i);
+}
+}  // namespace
+void bsf_set_dropout(double rate, uint64_t seed) {
+    g_drop_on = rate > 0.0;
+    g_drop_rate = rate;
+    g_drop_seed = seed;
+}
+void bsf_clear_dropout() { g_drop_on = false; }
+DropView bsf_dropout_view(const int32_t* edge) {
+    DropView dv{};
+    if (g_drop_on && edge != nullptr) {
+        dv.edge = edge;
+        dv.seed = g_drop_seed;
+        dv.threshold = (uint32_t)floor(g_drop_rate * 4294967296.0);
+        dv.keep_scale = (float)(1.0 / (1.0 - g_drop_rate));
+    }
+    return dv;
+}
+bool bsf_dropout_usable(const pgh_graph_s* g) {
+    static const bool off = getenv("PGH_DROPOUT_CSR") != nullptr && atoi(getenv("PGH_DROPOUT_CSR")) != 0;      // 1: always the row-major kernel
+    return !off && g->bsf.enabled && g->bsf.pb_slices <= 1 && g->rowptr != nullptr && g->col != nullptr && g->nnz > 0 &&
+           (g->bsf.val != nullptr || g->keep_mult != nullptr);
+}
+// The index in CSR(M^T) order of every entry of the stream and of the cold image (the words the dropout kernels read), built on the
+// first dropout launch: the image is built a SECOND time with the entry's index in the place of its value -- same keys, same
+// sort, same hot / cold split, same padding, so the value arrays of that shadow image ARE the index words in the layout of the
+// kernels (a copy of a multigraph entry carries the index of its entry: one mask bit per entry of the matrix) -- and everything
+// else of the shadow is released again.
+int bsf_ensure_edge_ids(pgh_graph_s* g) {
+    BsfFormat& f = g->bsf;
+    if (f.drop_edge != nullptr) return 0;
+    PGH_CHECK(bsf_dropout_usable(g), "graph_dropout: this graph has no blocked route");
+    Runtime& r = rt();
+    DevBuf<float> ids;
+    PGH_TRY(ids.alloc(g->nnz));
+    k_index_bits<<<blocks_for(g->nnz), kBlock, 0, r.stream>>>(ids.p, g->nnz);
+    PGH_HIP(hipGetLastError());
+    const BsfFormat saved = g->bsf;
+    g->bsf = BsfFormat();
+    const int rc = bsf_build(g, ids.p, saved.val == nullptr ? g->keep_mult : nullptr, nullptr, nullptr, saved.relabelled, saved.num_blocks);
+    BsfFormat shadow = g->bsf;
+    g->bsf = saved;
+    if (rc != 0) {
+        const std::string keep = pgh_last_error();
+        bsf_destroy(shadow);
+        return fail(keep);
+    }
+    const bool same = shadow.num_tiles == f.num_tiles && shadow.num_entries == f.num_entries && shadow.num_blocks == f.num_blocks &&
+                      shadow.pb.enabled == f.pb.enabled && shadow.pb.num_entries == f.pb.num_entries && shadow.pb.num_tasks == f.pb.num_tasks &&
+                      (shadow.colf16 != nullptr) == (f.colf16 != nullptr) && shadow.val != nullptr && (!f.pb.enabled || shadow.pb.val != nullptr);
+    if (!same) {
+        bsf_destroy(shadow);
+        return fail("graph_dropout: the index image does not match the graph's blocked image");
+    }
+    f.drop_edge = reinterpret_cast<int32_t*>(shadow.val);
+    shadow.val = nullptr;
+    f.device_bytes += f.num_entries * 4;
+    if (f.pb.enabled) {
+        f.pb.drop_edge = reinterpret_cast<int32_t*>(shadow.pb.val);
+        shadow.pb.val = nullptr;
+        f.device_bytes += f.pb.num_entries * 4;
+    }
+    bsf_destroy(shadow);
+    return 0;
+}
+
 // output-side vector: original -> internal
 // row sums of M (pgh_graph_s::degrees, caller ids) in the internal id space of a square relabelled graph
 int bsf_ensure_degrees(pgh_graph_s* g) {
@@ -1380,6 +1477,7 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.fix_seg);
     (void)hipFree(f.psum);
     (void)hipFree(f.psum64);
+    (void)hipFree(f.drop_edge);
     (void)hipFree(f.meta);
     (void)hipFree(f.live_dev);
     (void)hipFree(f.val);

@@ -149,6 +149,7 @@ struct PbFormat {
     // A order: [chunk][bin] runs, each padded to whole groups of 8 entries
     uint16_t* sloc = nullptr;       // [padded] source index inside its chunk
     float*    val = nullptr;        // [padded] or null (value-free)
+    int32_t*  drop_edge = nullptr;  // [padded] index in CSR(M^T) order of every A-order entry (graph_dropout; bsf_ensure_edge_ids) or null
     uint32_t* dstg = nullptr;       // [padded / 8] group of B order that receives this group's values
     int       num_tasks = 0;
     int       tmp_planes = 1;       // tmp keeps the low / high quads of 64 groups in two planes (long (chunk, bin) runs) or side by side
@@ -254,6 +255,7 @@ struct BsfFormat {
                                     // keeps the hot prefixes and the cold parts of the blocks in two regions, pgh_graph_set_gather_bases_split)
     int64_t   xg_base[8] = {0};     // first element of every block's slice inside the gather vector (default b * blk_size;
                                     // a partitioned run lays the slices out as the trimmed all-gather delivers them)
+    int32_t*  drop_edge = nullptr;  // index in CSR(M^T) order of every stream entry, laid out like `val` (graph_dropout; bsf_ensure_edge_ids)
     int       lg_live = 0, lg_hot = 0;   // partitioned runs driven by the engine (pgh_dist.hip): the epilogue writes this rank's slice of the
                                     // next gather vector PACKED for the exchange -- [local block][lg_hot] | [local block][lg_live - lg_hot] --
                                     // instead of by row (0: by row; pgh_graph_set_gather_bases puts it back)

@@ -216,6 +216,17 @@ __device__ __forceinline__ float dropout_factor(uint64_t seed, uint64_t entry, u
     return (uint32_t)(z >> 32) >= threshold ? keep_scale : 0.f;
 }
 
+// graph_dropout on the blocked layouts (single vectors): every entry of the stream and of the cold image carries its index in
+// CSR(M^T) order in a word of its own (BsfFormat::drop_edge / PbFormat::drop_edge, built on the first dropout launch:
+// bsf_ensure_edge_ids), so the mask is the one of the row-major kernel, of the multi-seed kernel and of degrees(dropped graph) --
+// repeated entries of a multigraph share one bit.  edge == nullptr: no dropout.
+struct DropView {
+    const int32_t* edge;
+    uint64_t       seed;
+    uint32_t       threshold;    // floor(rate * 2^32)
+    float          keep_scale;   // 1 / (1 - rate)
+};
+
 // Row sum of the blocked SpMV layout: the row's segment of every column block, found through the block's SegMeta
 // word (BsfFormat::psum / meta), added in block order in f64.
 struct RowSums {
@@ -580,6 +591,13 @@ void pb_destroy(PbFormat& p);
 int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, int stage = 0);
 
 void pb_set_residual(const ResParams* rp);   // the next pb_launch_finish<EPI_AXPBY> evaluates the residual in the kernel (ResParams)
+// graph_dropout: the launches of the NEXT step's block partial sums and phase A multiply every entry by its mask factor (rate in
+// [0, 1), seed: pgh_spmv_dropout's); cleared by bsf_clear_dropout.  bsf_ensure_edge_ids builds the entry -> CSR index words once.
+bool bsf_dropout_usable(const pgh_graph_s* g);
+int bsf_ensure_edge_ids(pgh_graph_s* g);
+void bsf_set_dropout(double rate, uint64_t seed);
+void bsf_clear_dropout();
+DropView bsf_dropout_view(const int32_t* edge);
 // the partitioned loop's fused scalars (pgh_spmv.hip; driven by pgh_dist.hip)
 bool dist_can_fuse(const pgh_graph_s* g);
 // where a partitioned run keeps this rank's slice of the next gather vector: packed for the exchange (BsfFormat::lg_*), 0 = by row

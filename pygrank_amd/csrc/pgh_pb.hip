@@ -201,16 +201,16 @@ __device__ unsigned int g_item_begin[1 << 15];      // ... and its start relativ
 #endif
 
 // ---- phase A (body: pgh_pb_gather.h, shared with the merged front kernel of a step in pgh_bsf.hip)
-template <bool HAS_VAL, int PG>
+template <bool HAS_VAL, int PG, bool DROP = false>
 __global__ __launch_bounds__(kPbThreads) void k_pb_gather(PbView f, const float* __restrict__ xg, const LoopState* __restrict__ state,
-                                                          FixView fix) {
+                                                          FixView fix, DropView dv = DropView{}) {
     __shared__ float s_x[kPbChunk + 1];
     if (state != nullptr && state->done) return;
     PGH_STAMP_BEGIN(g_times_gather)
     // the cross-tile fix-ups of the blocked stream ride along (one launch and one dependent boundary fewer per step):
     // they touch nothing this kernel reads, and the next kernel (k_pb_finish) is the first to read their results
     bsf_fixup_tiles(fix, blockIdx.x * kPbThreads, gridDim.x * kPbThreads);
-    pb_gather_body<HAS_VAL, PG>(s_x, reinterpret_cast<uint32_t*>(s_x + kPbChunk), f, xg, blockIdx.x);
+    pb_gather_body<HAS_VAL, PG, DROP>(s_x, reinterpret_cast<uint32_t*>(s_x + kPbChunk), f, xg, blockIdx.x, dv);
     PGH_STAMP_END(g_times_gather)
 }
 
@@ -1233,7 +1233,11 @@ int pb_launch_gather(pgh_graph_s* g, const float* xg, const LoopState* state, co
         if (p.num_tasks > 0) {
             // (diagnostic of round 3: launched with a quarter of its workgroups this kernel takes 63 us instead of 76 -- a workgroup's
             // share costs the same alone on the chip as with all others running: the per-CU memory path bounds it, ~21 GB/s)
-            if (p.val) k_pb_gather<true, PGH_GATHER_P><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
+            const DropView dv = bsf_dropout_view(p.drop_edge);
+            if (dv.edge != nullptr) {                  // graph_dropout: the mask factor per cold entry
+                if (p.val) k_pb_gather<true, PGH_GATHER_P, true><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix, dv);
+                else k_pb_gather<false, PGH_GATHER_P, true><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix, dv);
+            } else if (p.val) k_pb_gather<true, PGH_GATHER_P><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
             else k_pb_gather<false, PGH_GATHER_P><<<p.num_tasks, kPbThreads, 0, r.stream>>>(v, xg, state, fix);
         }
     }
@@ -1323,6 +1327,7 @@ template int pb_launch_finish<EPI_POLY>(pgh_graph_s*, const RowSums&, const EpiP
 void pb_destroy(PbFormat& p) {
     (void)hipFree(p.sloc);
     (void)hipFree(p.val);
+    (void)hipFree(p.drop_edge);
     (void)hipFree(p.task);
     (void)hipFree(p.task_range);
     (void)hipFree(p.tmp);

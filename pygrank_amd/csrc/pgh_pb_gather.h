@@ -22,17 +22,19 @@ constexpr int kPbThreads = 1024;
 // One piece of the A-order stream (whole groups of 8 entries, all inside the chunk whose slice of the gather vector sits in
 // s_x): every lane takes one group per round slot -- one 16-byte load of source indices, one 4-byte load of the group's place
 // in B order, 8 LDS gathers, two 16-byte stores of values.  P = round slots per lane (a round = 1024 x 8 x P entries).
-template <bool HAS_VAL, int P>
+template <bool HAS_VAL, int P, bool DROP = false>
 __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, const PbView& f, const int64_t body_begin, const int64_t body_end,
-                                                uint32_t& amax) {
+                                                uint32_t& amax, const DropView& dv = DropView{}) {
         // Software pipeline over rounds of P groups per lane: the loads of round i + 1 are issued BEFORE the gathers and
         // stores of round i.  vmcnt counts loads and stores in one in-order queue, so a loop that loads, gathers, stores
         // and only then loads again makes every round wait for the previous round's stores to complete (measured:
         // reads alone 40 us, with the stores 80 us -- no overlap at all).
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
         struct Round {
             u16x8    s8[P];
             uint32_t to[P];
             f32x4    w0[HAS_VAL ? P : 1], w1[HAS_VAL ? P : 1];
+            i32x4    e0[DROP ? P : 1], e1[DROP ? P : 1];        // graph_dropout: the entries' indices in CSR(M^T) order
         };
         // Branch-free loads: the round base is uniform, a lane past the end of the piece repeats the piece's LAST group, so
         // every load is issued unconditionally and the compiler emits counted waits.  (Loads under `ok ? load : 0` had become
@@ -44,6 +46,7 @@ __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, c
         const uint16_t* __restrict__ sl = f.sloc + body_begin;
         const uint32_t* __restrict__ dg = f.dstg + (body_begin >> 3);
         const float* __restrict__ vl = HAS_VAL ? f.val + body_begin : nullptr;
+        const int32_t* __restrict__ el = DROP ? dv.edge + body_begin : nullptr;
         auto fetch = [&](Round& r, int rb) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < P; ++q) {
@@ -53,6 +56,10 @@ __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, c
                 if (HAS_VAL) {
                     r.w0[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vl + e));
                     r.w1[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vl + e + 4));
+                }
+                if (DROP) {
+                    r.e0[q] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(el + e));
+                    r.e1[q] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(el + e + 4));
                 }
             }
         };
@@ -75,6 +82,13 @@ __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, c
                 if (HAS_VAL) {
                     lo *= r.w0[q];
                     hi *= r.w1[q];
+                }
+                if (DROP) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lo[k] *= dropout_factor(dv.seed, (uint64_t)(uint32_t)r.e0[q][k], dv.threshold, dv.keep_scale);
+                        hi[k] *= dropout_factor(dv.seed, (uint64_t)(uint32_t)r.e1[q][k], dv.threshold, dv.keep_scale);
+                    }
                 }
                 if (PGH_PROBE_PB & 4) {
                     if (lo.x + hi.w == 123.456f) f.tmp[body_begin + rb] = lo.y;
@@ -110,9 +124,9 @@ __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, c
 // thousand entries (88 .. 437 K on the 8-way slice of configs[4]): pieces below PbView::short_piece entries (16 K) run rounds of
 // 1.  Same-box sweep of that line on the slices of the N = 2 / 4 / 8 bench, phase A us: none 113 / 153 / 194-204, 8 K 115 /
 // 153 / 188, 16 K 114 / 154 / 189, 32 K 132 / 175 / 189 (profiles/r03/partition_slices.log).
-template <bool HAS_VAL, int PG>
+template <bool HAS_VAL, int PG, bool DROP = false>
 __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t* __restrict__ s_amax, const PbView& f,
-                                               const float* __restrict__ xg, const int vblock) {
+                                               const float* __restrict__ xg, const int vblock, const DropView& dv = DropView{}) {
     if (threadIdx.x == 0) *s_amax = 0u;
     uint32_t amax = 0u;                 // bit pattern of max |value| this thread wrote (NaN > inf > finite as integers)
     // this workgroup's share of the entry stream: consecutive pieces, each inside one chunk; the LDS image of the chunk
@@ -173,8 +187,9 @@ __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t
         if (PGH_PROBE_PB & 2) continue;
         if (body_end <= body_begin) continue;
         constexpr int PL = HAS_VAL ? (PG > 1 ? PG / 2 : 1) : PG;
-        if (body_end - body_begin >= (int64_t)f.short_piece) pb_stream_piece<HAS_VAL, PL>(s_x, f, body_begin, body_end, amax);
-        else pb_stream_piece<HAS_VAL, 1>(s_x, f, body_begin, body_end, amax);
+        constexpr int PD = DROP ? 1 : PL;                     // the mask's hashes take the registers of the deeper rounds
+        if (body_end - body_begin >= (int64_t)f.short_piece) pb_stream_piece<HAS_VAL, PD, DROP>(s_x, f, body_begin, body_end, amax, dv);
+        else pb_stream_piece<HAS_VAL, 1, DROP>(s_x, f, body_begin, body_end, amax, dv);
     }
     // max |value| of this launch: wavefront -> workgroup -> one global atomic
 #pragma unroll

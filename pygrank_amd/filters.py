@@ -60,10 +60,12 @@ class GraphFilter(NodeRanking):
         seed_signal = to_signal(graph, personalization)
         self._prepare(seed_signal)
         signal = self.personalization_transform(seed_signal)
-        if warm_start is None and graph_dropout == 0:
+        if warm_start is None:
             # norm, normalisation and start vector folded into the engine's first pass over the operands (pgh_loop_cfg.in_norm < 0,
             # start_from_p): no reduction and no host round trip in front of the first step.  A zero norm comes back as the signal.
-            fused = self._fused_rank(signal, *args, **kwargs)
+            # graph_dropout > 0: the same loop with a fresh mask per step inside the step's kernels (pgh_ppr_run_dropout).
+            fused = self._fused_rank(signal, *args, **kwargs) if graph_dropout == 0 else \
+                self._fused_rank(signal, *args, dropout=graph_dropout, **kwargs)
             if fused is not None:
                 return fused
         raw = signal.np
@@ -96,9 +98,10 @@ class GraphFilter(NodeRanking):
         self._end(operator(), signal, ranks, *args, **kwargs)
 
     # ---- hooks
-    def _fused_rank(self, personalization, *args, **kwargs):
+    def _fused_rank(self, personalization, *args, dropout=0, **kwargs):
         """Whole rank() inside the engine, norm included, starting from the UN-normalised personalization; returns the ranks
-        signal (the personalization itself when its norm is zero) or None when this filter / configuration has no such route."""
+        signal (the personalization itself when its norm is zero) or None when this filter / configuration has no such route.
+        dropout: graph_dropout of every step."""
         return None
 
     def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
@@ -241,9 +244,13 @@ class PageRank(RecursiveGraphFilter):
             return False
         return self._run_recursive(L.lib().pgh_ppr_run, _device_graph(M), cfg, ranks, p)
 
-    def _fused_rank(self, personalization, *args, **kwargs):
+    fused_dropout = True          # False (on an instance): rank(..., graph_dropout=) takes the hook protocol, one engine call per primitive
+
+    def _fused_rank(self, personalization, *args, dropout=0, **kwargs):
         if args or kwargs or not self._plain_quotient() or type(self)._formula is not PageRank._formula \
                 or type(self)._step is not RecursiveGraphFilter._step or type(self)._prepare_graph is not GraphFilter._prepare_graph:
+            return None
+        if dropout and not (self.fused_dropout and 0 < dropout < 1):
             return None
         p = personalization.np
         cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), -1.0 if self.preserve_norm else 1.0)     # -1: times the norm
@@ -257,7 +264,17 @@ class PageRank(RecursiveGraphFilter):
         before = dict(vars(self.convergence))
         self.convergence.start()
         ranks = to_signal(personalization, DeviceVector.empty(len(p)))
-        outcome = self._run_recursive(L.lib().pgh_ppr_run, g, cfg, ranks, p)
+        entry = L.lib().pgh_ppr_run
+        if dropout:
+            # the masks the hook protocol would draw (abstract_filters.py:57-62): one for _start, one per step, one for _end -- step k
+            # runs on the (k + 1)-th of them, so both routes compute the same thing from the same seed
+            from pygrank_amd.backend import hip as _hip
+            first = _hip.take_dropout_seeds(max(int(cfg.max_iters), 1) + 1)
+            lib, rate, seed0 = L.lib(), float(dropout), int(first) + 1
+
+            def entry(gh, ph, xh, cfg_ref, res_ref):
+                return lib.pgh_ppr_run_dropout(gh, ph, xh, cfg_ref, rate, seed0, res_ref)
+        outcome = self._run_recursive(entry, g, cfg, ranks, p)
         if outcome == "zero":                              # abstract_filters.py:53-54: returned before the manager is started
             vars(self.convergence).update(before)
             return personalization

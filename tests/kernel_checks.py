@@ -169,18 +169,56 @@ def check_graph_dropout(pg):
     for _ in range(200):
         acc += _np(pg.conv(_vec(pg, x), pg.graph_dropout(g, 0.5)))
     assert np.abs(acc / 200 - plain).sum() <= 0.12 * np.abs(plain).sum()
-    # filter level: rank(..., graph_dropout=) takes the per-step route; deterministic under a fixed seed
+    # filter level: rank(..., graph_dropout=) is ONE device loop (pgh_ppr_run_dropout) with a fresh mask per step inside the step's
+    # kernels -- against a host loop that rebuilds every step's mask, against the hook protocol (one engine call per backend
+    # primitive: fused_dropout = False) from the same seed, and deterministic under a fixed seed
     graph = pg.AdjacencyWrapper(A, directed=True)
+    pre = pg.preprocessor(normalization="col", assume_immutability=True)
     p = np.zeros(A.shape[0])
     p[:20] = 1.0
     outs = []
     for _ in range(2):
         pg.backend.hip.set_dropout_seed(7)
-        ranker = pg.PageRank(0.85, error_type="iters", max_iters=12)
+        ranker = pg.PageRank(0.85, preprocessor=pre, error_type="iters", max_iters=12)
         outs.append(np.asarray(ranker.rank(graph, p.copy(), graph_dropout=0.3).np))
-        assert not hasattr(ranker, "last_loop") and ranker.convergence.iteration == 12
+        assert ranker.last_loop["spmv"] == 11 and ranker.convergence.iteration == 12
     assert np.array_equal(outs[0], outs[1]) and abs(outs[0].sum() - 20.0) < 1e-3
-    base = np.asarray(pg.PageRank(0.85, error_type="iters", max_iters=12).rank(graph, p.copy()).np)
+    gm = getattr(pre(graph), "array", pre(graph))
+    MTm = gm.download_transposed()
+
+    def masked_at(seed, rate=0.3):
+        e = np.arange(MTm.nnz, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            h = rmat_np.splitmix64(np.uint64(seed) ^ (e * np.uint64(0xD6E8FEB86659FD93)))
+        keep = (h >> np.uint64(32)).astype(np.int64) >= int(np.floor(rate * 4294967296.0))
+        data = (MTm.data.astype(F32) * np.float32(1.0 / (1.0 - rate))).astype(F32).astype(np.float64) * keep
+        return sp.csr_array((data, MTm.indices, MTm.indptr), shape=MTm.shape)
+    pn = (p.astype(F32) / np.float32(20.0)).astype(np.float64)
+    x, quot = pn.copy(), 1.0
+    for k in range(11):                                            # seed 7: _start draws mask 8, step k + 1 runs on mask 9 + k
+        y = 0.85 * quot * (masked_at(9 + k) @ x) + 0.15 * pn
+        quot, x = 1.0 / y.sum(), y
+    want = x * quot * 20.0
+    assert np.max(np.abs(outs[0] - want)) <= 2e-6 * np.max(np.abs(want))
+    pg.backend.hip.set_dropout_seed(7)
+    hooks = pg.PageRank(0.85, preprocessor=pre, error_type="iters", max_iters=12)
+    hooks.fused_dropout = False
+    by_hooks = np.asarray(hooks.rank(graph, p.copy(), graph_dropout=0.3).np)
+    assert not hasattr(hooks, "last_loop") and hooks.convergence.iteration == 12
+    assert np.max(np.abs(by_hooks - outs[0])) <= 2e-6 * np.max(np.abs(outs[0]))
+    # a tolerance instead of a count: the loop stops on the device, on the residual of the masked iteration
+    pg.backend.hip.set_dropout_seed(7)
+    stopping = pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=0.35, max_iters=200)
+    by_tol = np.asarray(stopping.rank(graph, p.copy(), graph_dropout=0.3).np)
+    x, quot, prev, prev_quot, its = pn.copy(), 1.0, None, 1.0, 1
+    while its < 200:
+        if prev is not None and np.abs(x * quot - prev * prev_quot).sum() <= 0.35:
+            break
+        y = 0.85 * quot * (masked_at(9 + its - 1) @ x) + 0.15 * pn
+        prev, prev_quot, x, quot, its = x, quot, y, 1.0 / y.sum(), its + 1
+    assert 2 < its < 200 and stopping.convergence.iteration == its
+    assert np.max(np.abs(by_tol - x * quot * 20.0)) <= 2e-6 * np.max(np.abs(x * quot)) * 20.0
+    base = np.asarray(pg.PageRank(0.85, preprocessor=pre, error_type="iters", max_iters=12).rank(graph, p.copy()).np)
     assert not np.allclose(outs[0], base) and np.corrcoef(outs[0], base)[0, 1] > 0.9
     # filters that ask for degrees(M) in _start run with a dropped graph too
     for algo in (pg.AbsorbingWalks(0.85, error_type="iters", max_iters=8), pg.SymmetricAbsorbingRandomWalks(error_type="iters", max_iters=8)):
