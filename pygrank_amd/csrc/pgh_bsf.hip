@@ -384,9 +384,15 @@ __global__ void k_pair_scan(const float* __restrict__ v, const float* __restrict
 
 // one workgroup behind the scan: starts the loop state of the run that follows (k_state_init's work) and folds the scan's
 // partials of sum |v| into LoopAux::in_norm
+// ... and clears two words for the launches that follow: the isolated-row flag (the scatter / gather pass raises it) and the list
+// counter of the NEXT run (the counters alternate, so no memset stands in front of a run's scan)
 __global__ __launch_bounds__(kBlock) void k_scan_close(const double* __restrict__ norm_partials, int count, LoopState* init_state,
-                                                       LoopAux* init_aux) {
+                                                       LoopAux* init_aux, int* iso_flag, int* next_seed_count) {
     __shared__ double s4[4];
+    if (threadIdx.x == 0) {
+        if (iso_flag != nullptr) *iso_flag = 0;
+        if (next_seed_count != nullptr) *next_seed_count = 0;
+    }
     if (init_state != nullptr && threadIdx.x == 0) {
         if (init_aux != nullptr) {
             init_aux->pred_inv[0] = init_aux->pred_inv[1] = 1.0;
@@ -1277,10 +1283,9 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
     if (state_inited != nullptr) *state_inited = false;
     BsfFormat& f = g->bsf;
     IsoTail iso = IsoTail{};
-    if (watch_iso && f.iso_flag != nullptr) {          // the flag starts at 0; any non-zero operand on an isolated row raises it
-        PGH_HIP(hipMemsetAsync(f.iso_flag, 0, sizeof(int), rt().stream));
-        iso = iso_tail_of(f);
-    }
+    const bool watching = watch_iso && f.iso_flag != nullptr;      // the flag starts at 0; any non-zero operand on an isolated row raises it
+    bool flag_cleared = false;
+    if (watching) iso = iso_tail_of(f);
     const int* seed_count = nullptr;
     const bool norm_here = in_norm < 0.f;              // the caller left GraphFilter.rank's norm to this pass
     PGH_CHECK(!norm_here || (f.iperm != nullptr && init_aux != nullptr), "bsf_bring_pair: the norm cannot be computed on this layout");
@@ -1289,21 +1294,25 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
     if (f.iperm != nullptr && (norm_here || (f.n_src_pad >= (1 << 21) && env_int("PGH_SEED_LIST", 1) != 0))) {
         if (f.seed_list == nullptr) {
             PGH_HIP(hipMalloc(&f.seed_list, sizeof(int32_t) * (size_t)kSeedListCap));
-            PGH_HIP(hipMalloc(&f.seed_count, sizeof(int)));
+            PGH_HIP(hipMalloc(&f.seed_count, sizeof(int) * 2));          // two counters, used in turn: a run's closing launch clears the
+            PGH_HIP(hipMemsetAsync(f.seed_count, 0, sizeof(int) * 2, rt().stream));      // other one for the run after it
+            f.seed_turn = 0;
         }
-        PGH_HIP(hipMemsetAsync(f.seed_count, 0, sizeof(int), rt().stream));
+        int* count_now = f.seed_count + f.seed_turn;
+        int* count_next = f.seed_count + (1 - f.seed_turn);
+        f.seed_turn = 1 - f.seed_turn;
         const int64_t xg_len = want_xg ? (f.xg_live > 0 ? (int64_t)f.num_blocks * f.xg_live : (int64_t)f.n_src_pad) + 1 : 0;
         const int64_t span = f.n_src_pad > xg_len ? f.n_src_pad : xg_len;
         const int scan_grid = blocks_for(span);         // <= 16 workgroups per CU: within kMaxPartials
         double* norm_partials = norm_here ? rt().d_partials : nullptr;     // (no step is in flight: the region is free)
         k_pair_scan<<<scan_grid, kBlock, 0, rt().stream>>>(v, start_from_v ? nullptr : ranks, f.n_out_orig, f.n_src_pad, xg_len, v_int, y0,
-                                                           want_xg ? f.xg : nullptr, f.seed_list, f.seed_count, norm_partials);
-        if (norm_here || init_state != nullptr) {
-            k_scan_close<<<1, kBlock, 0, rt().stream>>>(norm_partials, scan_grid, init_state, init_aux);
-            if (state_inited != nullptr && init_state != nullptr) *state_inited = true;
-        }
-        seed_count = f.seed_count;
+                                                           want_xg ? f.xg : nullptr, f.seed_list, count_now, norm_partials);
+        k_scan_close<<<1, kBlock, 0, rt().stream>>>(norm_partials, scan_grid, init_state, init_aux, watching ? f.iso_flag : nullptr, count_next);
+        flag_cleared = watching;
+        if (state_inited != nullptr && init_state != nullptr) *state_inited = true;
+        seed_count = count_now;
     }
+    if (watching && !flag_cleared) PGH_HIP(hipMemsetAsync(f.iso_flag, 0, sizeof(int), rt().stream));
     k_permute_in_pair<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(v, ranks, f.perm, f.src_scale, f.n_src_pad, v_int, y0,
                                                                           want_xg ? f.xg : nullptr, f.blk_size, f.xg_live, in_norm,
                                                                           start_from_v ? 1 : 0, iso, seed_count, f.seed_list, f.iperm,

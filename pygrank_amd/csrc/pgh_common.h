@@ -245,7 +245,8 @@ struct BsfFormat {
     int       iso_begin[8] = {0};
     int       iso_row_blocks = 0;   // row blocks the thresholds cover: num_blocks (square graphs) or the blocks of a rank's slice
     int32_t*  seed_list = nullptr;  // [2^16] original ids of the non-zeros of a run's operands (bsf_bring_pair), lazily allocated
-    int*      seed_count = nullptr; // how many there are (more than the list holds: the gather pass runs)
+    int*      seed_count = nullptr; // [2] how many there are (more than the list holds: the gather pass runs); the two words are used in turn
+    int       seed_turn = 0;
     int*      iso_flag = nullptr;   // device word, set per run: 0 = the loop operands are zero on every isolated row, so those rows
                                     // stay zero and k_pb_finish / k_step_residual skip them; non-zero = they are processed
     int32_t*  live_dev = nullptr;   // [8] device copy target of `live`

@@ -227,6 +227,48 @@ def check_graph_dropout(pg):
         assert np.all(np.isfinite(out)) and out.sum() > 0
 
 
+def dropout_on_cold_image_check(pg):
+    """graph_dropout on a graph whose cold entries live in the propagation-blocking image (scale 18: run with PGH_PB=1 PGH_PB_FORCE=1
+    PGH_BLOCKS=4, tests/test_gpu_parity.py does): the stream kernel AND phase A multiply by the mask of the entry's index in CSR(M^T)
+    order -- conv against scipy on the rebuilt mask (multigraph: repeated entries share one bit), the device loop against a host loop."""
+    A = rmat_np.rmat_csr(18, 8, seed=3)
+    graph = pg.AdjacencyWrapper(A, directed=True)
+    pre = pg.preprocessor(normalization="col", assume_immutability=True)
+    g = getattr(pre(graph), "array", pre(graph))
+    assert "propagation-blocking image" in g.format(), g.format()
+    MT = g.download_transposed()
+    rng = np.random.default_rng(12)
+    x = rng.random(A.shape[0]).astype(F32).astype(np.float64)
+
+    def masked_at(seed, rate):
+        e = np.arange(MT.nnz, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            h = rmat_np.splitmix64(np.uint64(seed) ^ (e * np.uint64(0xD6E8FEB86659FD93)))
+        keep = (h >> np.uint64(32)).astype(np.int64) >= int(np.floor(rate * 4294967296.0))
+        data = (MT.data.astype(F32) * np.float32(1.0 / (1.0 - rate))).astype(F32).astype(np.float64) * keep
+        return sp.csr_array((data, MT.indices, MT.indptr), shape=MT.shape)
+    for rate in (0.2, 0.7):
+        pg.backend.hip.set_dropout_seed(60)
+        dropped = pg.graph_dropout(g, rate)
+        got = _np(pg.conv(_vec(pg, x), dropped))
+        masked = masked_at(dropped.seed, rate)
+        ref, scale = masked @ x, np.abs(masked) @ np.abs(x)
+        assert np.all(np.abs(got - ref) <= 4 * EPS32 * scale + 1e-30), rate
+    p = np.zeros(A.shape[0])
+    p[rng.choice(A.shape[0], 50, replace=False)] = 1.0
+    pg.backend.hip.set_dropout_seed(200)
+    ranker = pg.PageRank(0.85, preprocessor=pre, error_type="iters", max_iters=8)
+    out = np.asarray(ranker.rank(graph, p.copy(), graph_dropout=0.3).np)
+    assert ranker.last_loop["spmv"] == 7
+    pn = (p.astype(F32) / np.float32(50.0)).astype(np.float64)
+    xk, quot = pn.copy(), 1.0
+    for k in range(7):                                             # seed 200: _start draws mask 201, step k + 1 runs on mask 202 + k
+        y = 0.85 * quot * (masked_at(202 + k, 0.3) @ xk) + 0.15 * pn
+        quot, xk = 1.0 / y.sum(), y
+    want = xk * quot * 50.0
+    assert np.max(np.abs(out - want)) <= 2e-6 * np.max(np.abs(want))
+
+
 def check_graph_dropout_batched(pg):
     """graph_dropout inside the multi-seed kernel ("per-iteration edge masking in the SpMM kernel"): a slab
     product against scipy on the rebuilt mask, and propagate(..., graph_dropout=) as ONE batched device loop against a host

@@ -232,6 +232,22 @@ def test_two_gpus_over_rccl(gpu_engine, tmp_path):
     assert all(int(part["l1_fused"]) == 1 and int(part["signed_paused"]) == 1 for part in parts)
 
 
+def test_graph_dropout_on_the_cold_image(gpu_engine):
+    """graph_dropout of single vectors on the production layout -- hot-only 16-bit stream + propagation-blocking image of the cold
+    entries -- forced onto a scale-18 graph (kernel_checks.dropout_on_cold_image_check); the small-graph layouts run in
+    test_kernels[check_graph_dropout], the bench graph in tests/test_gpu_fullsize.py."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]\nimport pygrank_amd as pg\npg.load_backend('hip')\nimport kernel_checks\n"
+            "kernel_checks.dropout_on_cold_image_check(pg)\nprint('dropout cold image ok')\n"
+            % (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")))
+    env = dict(os.environ, PYTHONPATH=root, PGH_PB="1", PGH_PB_FORCE="1", PGH_BLOCKS="4", PGH_PB_HEAVY="64", PGH_PB_HUBMAX="500")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0 and "dropout cold image ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
 def test_randomised_stress(gpu_engine):
     """tools/stress_gpu.py for 20 s: random graph shapes (empty / tiny / hub rows / power-law / uniform / banded, integer and
     real weights) x layout switches (1-8 column blocks, relabelling, trimmed gather vector, propagation-blocking image)
