@@ -361,16 +361,28 @@ __global__ void k_pair_scan(const float* __restrict__ v, const float* __restrict
     __shared__ double s_red[4];
     double abs_sum = 0.0;                        // this thread's share of sum |v| (GraphFilter.rank's norm, abstract_filters.py:52)
     const int64_t span = n_pad > xg_len ? n_pad : xg_len;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < span; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i < n_pad) {
-            v_int[i] = 0.f;
-            if (y0 != nullptr) y0[i] = 0.f;
+    // four ids per thread and round, their loads issued together (one id per round left every load alone in flight: the scan took
+    // 21-24 us at scale 23 once it also summed |v|, 14 us with the loads side by side)
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < span; i0 += stride * U) {
+        float vi[U], ri[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            vi[u] = i < n_orig ? v[i] : 0.f;
+            ri[u] = (ranks != nullptr && i < n_orig) ? ranks[i] : 0.f;
         }
-        if (xg != nullptr && i < xg_len) xg[i] = 0.f;
-        if (i < n_orig) {
-            const float vi = v[i];
-            abs_sum += fabs((double)vi);
-            if (vi != 0.f || (ranks != nullptr && ranks[i] != 0.f)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n_pad) {
+                v_int[i] = 0.f;
+                if (y0 != nullptr) y0[i] = 0.f;
+            }
+            if (xg != nullptr && i < xg_len) xg[i] = 0.f;
+            abs_sum += fabs((double)vi[u]);
+            if (vi[u] != 0.f || ri[u] != 0.f) {
                 const int pos = atomicAdd(count, 1);
                 if (pos < kSeedListCap) list[pos] = (int32_t)i;
             }
