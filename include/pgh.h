@@ -372,7 +372,8 @@ typedef struct {
     int32_t column_blocks;
     int32_t split_regions;  /* 1 = hot prefixes and cold parts are exchanged as two contiguous regions          */
     int32_t flags;          /* bit 1: the residual was evaluated inside the finish kernel (one 4-scalar all-reduce per
-                             * iteration); bit 0: ... and one step had to be re-evaluated by the separate kernel        */
+                             * iteration); bit 0: ... and one step had to be re-evaluated by the separate kernel; bit 2: the
+                             * finish kernel ran as two launches (exchanged rows first: the exchange starts behind the first)  */
     double  last_error;
     double  loop_ms;        /* HIP-event time of the loop on the compute stream                                 */
     int64_t exchange_bytes; /* received per rank and iteration                                                  */

@@ -86,7 +86,7 @@ struct pgh_comm_s {
     int         world = 1, rank = 0;
     hipStream_t main = nullptr, xs = nullptr, ss = nullptr;      // xs == ss == main: PGH_DIST_SINGLE_STREAM
     bool        own_streams = false;
-    hipEvent_t  ev_fin = nullptr, ev_hot = nullptr, ev_cold = nullptr, ev_err = nullptr, ev_host = nullptr;
+    hipEvent_t  ev_fin = nullptr, ev_fin2 = nullptr, ev_hot = nullptr, ev_cold = nullptr, ev_err = nullptr, ev_host = nullptr;
     // buffers of the graph the communicator last ran on
     pgh_graph_t graph = nullptr;
     int         nb = 0, bpr = 0, live = 0, hot = 0;
@@ -285,6 +285,17 @@ int exchange_slices(pgh_comm_s* c, hipStream_t st, bool events) {
     return 0;
 }
 
+// The finish kernel of a step in TWO launches when the exchange has somewhere to go (more than one rank, three queues, a cold image):
+// first the items that hold rows whose slots of the next gather vector are exchanged (the referenced prefix of every block: the
+// hottest rows), then the rest -- the all-gathers start behind the first launch and travel while the second runs (VERDICT r3 item
+// 1b).  PGH_DIST_FINISH_SPLIT=0 keeps one launch, =2 forces two even where nothing travels (tests).
+bool finish_in_two(const pgh_comm_s* c, const pgh_graph_s* g) {
+    const char* env = getenv("PGH_DIST_FINISH_SPLIT");
+    const int mode = env != nullptr ? atoi(env) : 1;
+    if (mode == 0 || !g->bsf.enabled || !g->bsf.pb.enabled) return false;
+    return mode == 2 || (c->world > 1 && !c->one_gather);
+}
+
 struct StreamSwap {          // the engine launches on rt().stream: point it at one of the communicator's queues for a scope
     hipStream_t saved;
     explicit StreamSwap(hipStream_t s) : saved(rt().stream) { rt().stream = s; }
@@ -322,7 +333,7 @@ int comm_resources(pgh_comm_s* c, bool two_comms) {
         if (two_comms) PGH_HIP(hipStreamCreateWithFlags(&c->ss, hipStreamNonBlocking));
         else c->ss = c->xs;
     }
-    for (hipEvent_t* ev : {&c->ev_fin, &c->ev_hot, &c->ev_cold, &c->ev_err, &c->ev_host})
+    for (hipEvent_t* ev : {&c->ev_fin, &c->ev_fin2, &c->ev_hot, &c->ev_cold, &c->ev_err, &c->ev_host})
         PGH_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     PGH_HIP(hipMalloc(&c->state, sizeof(double) * 8));
     PGH_HIP(hipHostMalloc(&c->state_host, sizeof(double) * 8, hipHostMallocDefault));
@@ -432,7 +443,7 @@ extern "C" int pgh_comm_destroy(pgh_comm_t c) {
     (void)hipFree(c->agree);
     (void)hipHostFree(c->state_host);
     if (c->progress_host != nullptr) (void)hipHostFree(const_cast<unsigned long long*>(c->progress_host));
-    for (hipEvent_t ev : {c->ev_fin, c->ev_hot, c->ev_cold, c->ev_err, c->ev_host})
+    for (hipEvent_t ev : {c->ev_fin, c->ev_fin2, c->ev_hot, c->ev_cold, c->ev_err, c->ev_host})
         if (ev) (void)hipEventDestroy(ev);
     if (g_rccl.handle != nullptr) {
         if (c->s != nullptr && c->s != c->x) (void)g_rccl.CommDestroy(c->s);
@@ -464,6 +475,7 @@ struct RunScope {
         if (t_begin) (void)hipEventDestroy(t_begin);
         if (t_end) (void)hipEventDestroy(t_end);
         pb_set_residual(nullptr);
+        pb_set_finish_phase(0, 0);
         if (stalled) return;
         if (!ok) {
             if (c->xs != c->main) (void)drain(c->xs, "the exchange queue after a failed run");
@@ -603,6 +615,8 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     const int max_iters = cfg->max_iters;
     int it = 1, spmv = 0;                      // `it` = ConvergenceManager.iteration of the pending has_converged call
     int fused_partials = 0;
+    const bool two_launches = finish_in_two(c, g);
+    res->flags |= two_launches ? 4 : 0;
     bool pending = false, staged = false, converged = false;
     while (it < max_iters) {                   // convergence.py:86
         const int nxt = 1 - cur;
@@ -639,13 +653,22 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
             }
         }
         PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));      // quotient and done flag of the previous step; its residual has read y[nxt]
-        if (fused) {
-            PGH_RUN(dist_combine_fused(g, c->p_norm, cfg->alpha, c->y[nxt], c->xg_local, c->y[cur], g->bsf.deg_int, c->state, c->aux, spmv + 1, &fused_partials));
+        auto finish = [&]() -> int {
+            if (fused) return dist_combine_fused(g, c->p_norm, cfg->alpha, c->y[nxt], c->xg_local, c->y[cur], g->bsf.deg_int, c->state, c->aux, spmv + 1, &fused_partials);
+            return absorbing ? pgh_dist_combine_absorb(g, &v_p, cfg->deg_local, cfg->lam_local, &v_y[nxt], &v_xg_local, c->state)
+                             : pgh_dist_combine(g, &v_p, cfg->alpha, &v_y[nxt], &v_xg_local, c->state);
+        };
+        if (two_launches) {
+            pb_set_finish_phase(1, c->live);
+            PGH_RUN(finish());
+            PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));          // every exchanged slot is written: the exchange may start
+            pb_set_finish_phase(2, c->live);
+            PGH_RUN(finish());
         } else {
-            PGH_RUN(absorbing ? pgh_dist_combine_absorb(g, &v_p, cfg->deg_local, cfg->lam_local, &v_y[nxt], &v_xg_local, c->state)
-                              : pgh_dist_combine(g, &v_p, cfg->alpha, &v_y[nxt], &v_xg_local, c->state));
+            PGH_RUN(finish());
+            PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));
         }
-        PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));
+        PGH_RUN_HIP(hipEventRecord(c->ev_fin2, c->main));             // ... and the step's sums are complete: the scalars may start
         // ---- X: the next gather vector over xGMI
         PGH_RUN_HIP(hipStreamWaitEvent(c->xs, c->ev_fin, 0));
         PGH_RUN(exchange_slices(c, c->xs, true));
@@ -654,7 +677,7 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
         ++it;
         const bool check = it < max_iters && kind != PGH_ERR_ITERS && it % cfg->end_modulo == 0;
         // ---- S: the scalars of the step
-        PGH_RUN_HIP(hipStreamWaitEvent(c->ss, c->ev_fin, 0));
+        PGH_RUN_HIP(hipStreamWaitEvent(c->ss, c->ev_fin2, 0));
         {
             StreamSwap on_scalars(c->ss);
             if (fused) {
@@ -810,6 +833,8 @@ extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local,
         return 0;
     };
     const int max_iters = cfg->max_iters;
+    const bool two_launches = finish_in_two(c, g);
+    res->flags |= two_launches ? 4 : 0;
     int it = 2, spmv = 0, cur = 0;             // `it` = the iteration has_converged is asked about
     bool converged = false, pending = false, staged = false;
     if (it < max_iters && kind != PGH_ERR_ITERS && it % cfg->end_modulo == 0 && delta <= cfg->tol) converged = true;
@@ -831,15 +856,22 @@ extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local,
             }
         }
         PGH_RUN_HIP(hipStreamWaitEvent(c->main, c->ev_err, 0));      // the done flag of the previous term; its all-reduce has read state[1]
+        if (two_launches) {
+            pb_set_finish_phase(1, c->live);
+            PGH_RUN(pgh_dist_combine_poly(g, &v_y[cur], &v_y[nxt], 1.0, 0.0, result_local, coeff(it), linf, &v_xg_local, c->state));
+            PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));
+            pb_set_finish_phase(2, c->live);
+        }
         PGH_RUN(pgh_dist_combine_poly(g, &v_y[cur], &v_y[nxt], 1.0, 0.0, result_local, coeff(it), linf, &v_xg_local, c->state));
-        PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));
+        if (!two_launches) PGH_RUN_HIP(hipEventRecord(c->ev_fin, c->main));
+        PGH_RUN_HIP(hipEventRecord(c->ev_fin2, c->main));
         PGH_RUN_HIP(hipStreamWaitEvent(c->xs, c->ev_fin, 0));
         PGH_RUN(exchange_slices(c, c->xs, true));
         cur = nxt;
         ++spmv;
         ++it;
         const bool check = it < max_iters && kind != PGH_ERR_ITERS && it % cfg->end_modulo == 0;
-        PGH_RUN_HIP(hipStreamWaitEvent(c->ss, c->ev_fin, 0));
+        PGH_RUN_HIP(hipStreamWaitEvent(c->ss, c->ev_fin2, 0));
         {
             StreamSwap on_scalars(c->ss);
             PGH_RUN(pgh_dist_close_sum(c->state, 0));                // counts the step

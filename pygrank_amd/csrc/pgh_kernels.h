@@ -552,6 +552,9 @@ struct PbView {
     double*         hub_part;          // [num_bins] sums of the pieces of split hub rows
     uint32_t*       amax;              // [0] bit pattern of max |value| written by phase A, [1] phase B's exit tickets
     const int*      iso_flag;          // BsfFormat::iso_flag or null: 0 = items marked -2 (isolated rows) are passed over
+    // the finish kernel in two launches (partitioned runs with more than one rank): phase 1 = the items that hold a row whose slot of
+    // the next gather vector is EXCHANGED (slot inside its block < phase_live), phase 2 = the others; 0 = everything in one launch
+    int             phase, phase_blk, phase_live;
     int64_t         cold_prefix[9];
     int64_t         xg_base[8];
     int             num_blocks, hot, chunk, num_chunks, num_bins;
@@ -591,6 +594,9 @@ void pb_destroy(PbFormat& p);
 int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, int stage = 0);
 
 void pb_set_residual(const ResParams* rp);   // the next pb_launch_finish<EPI_AXPBY> evaluates the residual in the kernel (ResParams)
+// the next pb_launch_finish runs only its phase-1 / phase-2 items (PbView::phase; live: exchanged slots per block); phase 2 puts its
+// partial sums behind phase 1's, and *num_partials of the phase-2 launch counts both
+void pb_set_finish_phase(int phase, int live);
 // graph_dropout: the launches of the NEXT step's block partial sums and phase A multiply every entry by its mask factor (rate in
 // [0, 1), seed: pgh_spmv_dropout's); cleared by bsf_clear_dropout.  bsf_ensure_edge_ids builds the entry -> CSR index words once.
 bool bsf_dropout_usable(const pgh_graph_s* g);

@@ -374,7 +374,16 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     const int tail_count = f.tail_count;
     int at = f.sched_begin[blockIdx.x];
     const int at_end = f.sched_begin[blockIdx.x + 1];
-    int slot = blockIdx.x, item = -1;       // partial-sum slot of the item in hand
+    // two-launch form (PbView::phase): phase 2 keeps its partials behind phase 1's; an item belongs to phase 1 when one of its rows has
+    // an exchanged slot -- its first row's slot inside the block lies below phase_live, or its rows run into the next block
+    const int slot0 = f.phase == 2 ? (int)gridDim.x + tail_count : 0;
+    auto in_phase = [&](const int4& e) __attribute__((always_inline)) {
+        if (f.phase == 0) return true;
+        const int loc = (int)((unsigned)e.x % (unsigned)f.phase_blk);
+        const bool exchanged = loc < f.phase_live || loc + max(e.y, 1) > f.phase_blk;
+        return exchanged == (f.phase == 1);
+    };
+    int slot = slot0 + blockIdx.x, item = -1;       // partial-sum slot of the item in hand
     bool in_tail = at >= at_end;
     auto take_tail = [&]() __attribute__((always_inline)) {        // -> item index or -1; all threads call it together
         if (tail_count == 0) return -1;
@@ -383,13 +392,13 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         __syncthreads();
         const int k = s_next;
         if (k >= tail_count) return -1;
-        slot = gridDim.x + k;
+        slot = slot0 + gridDim.x + k;
         return f.sched[f.tail_begin + k];
     };
     bool flushed_head = false;
     if (!in_tail) item = f.sched[at];
     else {
-        flush(blockIdx.x);                  // no static items: the workgroup's partial is zero
+        flush(slot0 + blockIdx.x);          // no static items: the workgroup's partial is zero
         flushed_head = true;
         item = take_tail();
     }
@@ -398,10 +407,12 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     // items marked -2 cover isolated rows (no entry, referenced by nobody): unless this run's operands are non-zero there
     // they hold zeros in both iterates and are passed over (the item shrinks to no rows: barriers only)
     const bool skip_iso = f.iso_flag != nullptr && *f.iso_flag == 0;
+    bool mine = false;                      // the item in hand belongs to this launch's phase
     if (item >= 0) {
         bin = f.item_a[item];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
         epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1 (-2: isolated rows), first item of the split row}
-        fetch(bin, 0, R);
+        mine = in_phase(epi);
+        if (mine) fetch(bin, 0, R);
     }
 #if PGH_PROBE_TIMES
     const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
@@ -410,6 +421,28 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
 #if PGH_PROBE_TIMES
         const unsigned long long item_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
+        if (!mine) {                           // the other launch's item: only the walk over the schedule goes on (workgroup-uniform)
+            const int cur_slot = slot;
+            int next = -1;
+            if (!in_tail && ++at < at_end) next = f.sched[at];
+            else {
+                in_tail = true;
+                next = take_tail();
+            }
+            if (cur_slot != slot0 + (int)blockIdx.x) flush(cur_slot);
+            else if (in_tail) {
+                flush(slot0 + blockIdx.x);
+                flushed_head = true;
+            }
+            item = next;
+            if (item >= 0) {
+                bin = f.item_a[item];
+                epi = f.item_b[item];
+                mine = in_phase(epi);
+                if (mine) fetch(bin, 0, R);
+            }
+            continue;
+        }
         if (epi.z == -2) {
             // isolated rows: no entry, no segment in any block.  Passed over while the run's operands are zero there; otherwise
             // the epilogue of an empty row sum, streamed (no row map, no partial sums), and the item is empty from here on.
@@ -496,11 +529,12 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             next = take_tail();
         }
         int4 next_bin = make_int4(0, 0, 0, 0), next_epi = make_int4(0, 0, -1, 0);
+        bool next_mine = false;
         if (next >= 0) {
             next_bin = f.item_a[next];
             next_epi = f.item_b[next];
-
-            if (PGH_FIN_PREFETCH) fetch(next_bin, 0, R);
+            next_mine = in_phase(next_epi);
+            if (PGH_FIN_PREFETCH && next_mine) fetch(next_bin, 0, R);
         }
 #pragma unroll
         for (int u = 0; u < MPT; ++u) {
@@ -623,21 +657,22 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         }
 #endif
         // the head's partial leaves when the slice is done, a tail item's partial after the item
-        if (cur_slot != blockIdx.x) flush(cur_slot);
+        if (cur_slot != slot0 + (int)blockIdx.x) flush(cur_slot);
         else if (in_tail) {
-            flush(blockIdx.x);
+            flush(slot0 + blockIdx.x);
             flushed_head = true;
         }
-        if (!PGH_FIN_PREFETCH && next >= 0) fetch(next_bin, 0, R);
+        if (!PGH_FIN_PREFETCH && next >= 0 && next_mine) fetch(next_bin, 0, R);
         item = next;
         bin = next_bin;
         epi = next_epi;
+        mine = next_mine;
     }
-    if (!flushed_head) flush(blockIdx.x);
+    if (!flushed_head) flush(slot0 + blockIdx.x);
     // the last workgroup to leave re-arms the words for the next launch (every workgroup has read amax long before its
-    // ticket; the next phase A starts after this kernel)
+    // ticket; the next phase A starts after this kernel).  Phase 1 of a two-launch finish leaves amax to phase 2.
     if (tid == 0 && atomicAdd(f.amax + 1, 1u) == gridDim.x - 1) {
-        f.amax[0] = 0u;
+        if (f.phase != 1) f.amax[0] = 0u;
         f.amax[1] = 0u;
         if (tail_count > 0) *f.work_counter = 0u;
     }
@@ -667,6 +702,9 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.drow = p.drow;
     v.amax = p.amax;
     v.iso_flag = f.iso_flag;
+    v.phase = 0;
+    v.phase_blk = f.blk_size > 0 ? f.blk_size : 1;
+    v.phase_live = 0;
     v.hub_part = p.hub_part;
     for (int i = 0; i < 9; ++i) v.cold_prefix[i] = p.cold_prefix[i];
     for (int i = 0; i < 8; ++i) v.xg_base[i] = f.xg_base_cold[i];      // phase A reads slots >= hot only
@@ -1255,6 +1293,13 @@ void pb_set_residual(const ResParams* rp) {
     g_residual_set = rp != nullptr;
     if (rp != nullptr) g_residual = *rp;
 }
+namespace {
+int g_finish_phase = 0, g_finish_live = 0;
+}  // namespace
+void pb_set_finish_phase(int phase, int live) {
+    g_finish_phase = phase;
+    g_finish_live = live;
+}
 
 // phase B + the MODE epilogue for every output row; block partials of sum(y) / delta land in rt().d_partials
 template <int MODE>
@@ -1262,14 +1307,19 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
     const BsfFormat& f = g->bsf;
     const PbFormat& p = f.pb;
     Runtime& r = rt();
-    const PbView v = pb_view(f, p);
+    PbView v = pb_view(f, p);
+    v.phase = g_finish_phase;
+    v.phase_live = g_finish_live;
+    const int phase = g_finish_phase;
+    g_finish_phase = 0;                                // consumed
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
     const bool large = p.bin_rows > kPbBinRows;
     const int grid = p.sched_groups;                   // persistent: as many workgroups as the CUs hold at once
+    PGH_CHECK(phase == 0 || 2 * (grid + p.tail_count) <= kMaxPartials, "finish kernel: too many partial sums for the two-launch form");
     ResParams rp = g_residual;
     const bool res = MODE == EPI_AXPBY && g_residual_set;
-    g_residual_set = false;
+    if (phase != 1) g_residual_set = false;            // (phase 2 of a two-launch finish evaluates the residual of its rows as well)
     {
         ProfScope prof(PGH_K_PB_ACCUM);
         const bool wide = f.num_blocks > 4;               // 8 column blocks: 8-way row partitions
@@ -1316,7 +1366,8 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
         }
     }
 #endif
-    if (num_partials) *num_partials = grid + p.tail_count;            // one per workgroup, then one per tail item
+    // one per workgroup, then one per tail item; the second launch of the two-launch form reports both launches' slots
+    if (num_partials) *num_partials = (phase == 2 ? 2 : 1) * (grid + p.tail_count);
     return 0;
 }
 template int pb_launch_finish<EPI_PLAIN>(pgh_graph_s*, const RowSums&, const EpiParams&, const LoopState*, int*);

@@ -514,6 +514,7 @@ class DistributedPageRank:
         self.exchange = dict(exchange_bytes_per_iteration_per_gpu=int(res.exchange_bytes), gather_vector_slots=int(res.gather_slots),
                              column_blocks=int(res.column_blocks), split_regions=bool(res.split_regions),
                              in_kernel_residual=bool(res.flags & 2), paused_in_kernel_residual=bool(res.flags & 1),
+                             finish_in_two_launches=bool(res.flags & 4),
                              driver="engine (RCCL)" if self._dist.get_backend() == "nccl" else "engine (host collectives)")
         if res.iterations == 0:
             return p_local
@@ -747,6 +748,7 @@ class DistributedClosedFormFilter:
         self.last_error, self.loop_ms = float(res.last_error), float(res.loop_ms)
         self.exchange = dict(exchange_bytes_per_iteration_per_gpu=int(res.exchange_bytes), gather_vector_slots=int(res.gather_slots),
                              column_blocks=int(res.column_blocks), split_regions=bool(res.split_regions),
+                             finish_in_two_launches=bool(res.flags & 4),
                              driver="engine (RCCL)" if dist.get_backend() == "nccl" else "engine (host collectives)")
         if res.iterations == 0:
             return p_local

@@ -48,6 +48,7 @@ def main():
         results[name + "_ranks"] = np.asarray(out)
         results[name + "_iters"] = ranker.iteration
         results[name + "_fused"] = int(bool(ranker.exchange.get("in_kernel_residual", False)))
+        results[name + "_two_launches"] = int(bool(ranker.exchange.get("finish_in_two_launches", False)))
     # a personalization with NEGATIVE entries: the in-kernel residual cannot vouch for its bound and hands the step to the separate
     # kernel (paused once), the result is the oracle's all the same
     signs = np.where(np.arange(graph.n) % 3 == 0, -0.25, 1.0)
@@ -70,6 +71,7 @@ def main():
         results[name + "_ranks"] = np.asarray(out)
         results[name + "_iters"] = algo.iteration
     results["closed_form_driver"] = str(algo.exchange.get("driver"))
+    results["closed_form_two_launches"] = int(bool(algo.exchange.get("finish_in_two_launches", False)))
     from pygrank_amd.distributed import PREFLIGHT
     results["preflight"] = str(PREFLIGHT.get((world, rank), "not run"))
     # the gather bases are state of the GRAPH: a Python-driven filter that keeps its buffers must find its own layout again after

@@ -176,8 +176,8 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
         env.update(PGH_DIST_NATIVE="external")      # the collectives come back to the host (pgh_comm_create_external over gloo)
     if mode == "engine_loop_single_queue":          # ... on ONE queue: the whole packed slice of a rank as a single all-gather
         env.update(PGH_DIST_SINGLE_STREAM="1")
-    if mode == "three_queues":           # one rank runs on one queue by default (nobody to overlap an exchange with): force the three
-        env.update(PGH_DIST_SINGLE_STREAM="0")
+    if mode == "three_queues":           # one rank runs on one queue by default (nobody to overlap an exchange with): force the three,
+        env.update(PGH_DIST_SINGLE_STREAM="0", PGH_DIST_FINISH_SPLIT="2")      # and the finish kernel in two launches (N > 1 does by itself)
     if scale > 14:                       # four column blocks over two ranks: two all-gathers per exchange, like bench.py --gpus 2
         env.update(PGH_PB="1", PGH_PB_FORCE="1", PGH_DEBUG="1", PGH_BLOCKS="4", PGH_PB_HEAVY="64", PGH_PB_HUBMAX="500")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -200,6 +200,10 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
         for part in parts:
             assert int(part["l1_fused"]) == 1 and int(part["mabs_fused"]) == 1 and int(part["noquot_fused"]) == 0
             assert int(part["signed_paused"]) == 1
+            # more than one rank on three queues (and the forced one-rank case): the finish kernel in two launches, exchanged rows first
+            two = (world > 1 and mode == "engine_loop") or mode == "three_queues"
+            assert int(part["l1_two_launches"]) == int(two) and int(part["noquot_two_launches"]) == int(two), (mode, world)
+            assert int(part["closed_form_two_launches"]) == int(two)
 
 
 def test_two_gpus_over_rccl(gpu_engine, tmp_path):
