@@ -285,15 +285,18 @@ int exchange_slices(pgh_comm_s* c, hipStream_t st, bool events) {
     return 0;
 }
 
-// The finish kernel of a step in TWO launches when the exchange has somewhere to go (more than one rank, three queues, a cold image):
-// first the items that hold rows whose slots of the next gather vector are exchanged (the referenced prefix of every block: the
-// hottest rows), then the rest -- the all-gathers start behind the first launch and travel while the second runs (VERDICT r3 item
-// 1b).  PGH_DIST_FINISH_SPLIT=0 keeps one launch, =2 forces two even where nothing travels (tests).
+// The finish kernel of a step in TWO launches when the exchange is what a step waits for (three queues, a cold image, 32 MB or more
+// received per rank and iteration: 141 MB at configs[4]): first the items that hold rows whose slots of the next gather vector are
+// exchanged (the referenced prefix of every block: the hottest rows), then the rest -- the all-gathers start behind the first launch and
+// travel while the second runs.  Two launches cost: measured with one rank at scale 23, 86 -> 133 us for the two
+// (each ends on its slowest workgroup, a workgroup holds 1-2 items of a phase instead of 3 of the step), so a small exchange keeps
+// one.  PGH_DIST_FINISH_SPLIT=0 keeps one launch always, =2 forces two (tests).
 bool finish_in_two(const pgh_comm_s* c, const pgh_graph_s* g) {
     const char* env = getenv("PGH_DIST_FINISH_SPLIT");
     const int mode = env != nullptr ? atoi(env) : 1;
     if (mode == 0 || !g->bsf.enabled || !g->bsf.pb.enabled) return false;
-    return mode == 2 || (c->world > 1 && !c->one_gather);
+    const int64_t received = 4LL * c->live * c->bpr * (c->world - 1);
+    return mode == 2 || (c->world > 1 && !c->one_gather && received >= (32LL << 20));
 }
 
 struct StreamSwap {          // the engine launches on rt().stream: point it at one of the communicator's queues for a scope

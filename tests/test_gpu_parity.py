@@ -174,6 +174,7 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
         env.update(PGH_DIST_NATIVE="0")
     if mode.startswith("engine_loop"):   # the ENGINE's loop with several ranks (region offsets of every rank, split exchange, ...):
         env.update(PGH_DIST_NATIVE="external")      # the collectives come back to the host (pgh_comm_create_external over gloo)
+        env.update(PGH_DIST_FINISH_SPLIT="2")       # ... and the finish kernel in two launches, as a large exchange has it
     if mode == "engine_loop_single_queue":          # ... on ONE queue: the whole packed slice of a rank as a single all-gather
         env.update(PGH_DIST_SINGLE_STREAM="1")
     if mode == "three_queues":           # one rank runs on one queue by default (nobody to overlap an exchange with): force the three,
@@ -201,7 +202,7 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
             assert int(part["l1_fused"]) == 1 and int(part["mabs_fused"]) == 1 and int(part["noquot_fused"]) == 0
             assert int(part["signed_paused"]) == 1
             # more than one rank on three queues (and the forced one-rank case): the finish kernel in two launches, exchanged rows first
-            two = (world > 1 and mode == "engine_loop") or mode == "three_queues"
+            two = mode in ("engine_loop", "engine_loop_single_queue", "three_queues")      # forced by the test (PGH_DIST_FINISH_SPLIT=2)
             assert int(part["l1_two_launches"]) == int(two) and int(part["noquot_two_launches"]) == int(two), (mode, world)
             assert int(part["closed_form_two_launches"]) == int(two)
 
