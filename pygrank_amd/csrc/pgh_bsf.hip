@@ -95,11 +95,11 @@ __global__ void k_iota(int32_t* p, int64_t n) {
 }
 
 // rank r (descending count) -> new id = (r % B) * blk + r / B
-__global__ void k_make_perm(const int32_t* __restrict__ sorted_ids, int64_t n, int B, int blk, int32_t* __restrict__ perm,
+__global__ void k_make_perm(const int32_t* __restrict__ sorted_ids, int64_t n, int B, int blk, int64_t head, int32_t* __restrict__ perm,
                             int32_t* __restrict__ iperm) {
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
         const int old = sorted_ids[r];
-        const int nw = (int)(r % B) * blk + (int)(r / B);
+        const int nw = (int)deal_new_id(r, B, blk, head);
         iperm[old] = nw;
         perm[nw] = old;
     }
@@ -1522,10 +1522,13 @@ void bsf_destroy(BsfFormat& f) {
 }
 
 // Relabelling shared by the single-GPU layout and the row-partitioned generator: ids sorted by descending reference
-// count (stable: ties keep ascending id), rank r -> new id (r % B) * blk + r / B, i.e. dealt round-robin to B
-// contiguous hot-first blocks.  perm[new] = old (pad slots -1, perm has B * blk entries), iperm[old] = new.
-int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t* perm, int32_t* iperm) {
+// count (stable: ties keep ascending id), rank r -> new id deal_new_id(r, B, blk, head): dealt to B contiguous hot-first blocks,
+// the first `head` ranks one by one, the rest in runs of kDealRun.  perm[new] = old (pad slots -1, perm has B * blk entries), iperm[old] = new.
+int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t* perm, int32_t* iperm, int64_t head) {
     Runtime& r = rt();
+    PGH_CHECK(head >= n || B == 1 || (head % ((int64_t)B * kDealRun) == 0 && blk % kDealRun == 0 &&
+                                      (n + (int64_t)kDealRun * B - 1) / ((int64_t)kDealRun * B) * kDealRun <= blk),
+              "relabelling: a column block must hold whole runs of the deal (kDealRun ids) and its share of the ranks");
     DevBuf<unsigned int> cnt_sorted;
     DevBuf<int32_t> ids, ids_sorted;
     PGH_TRY(cnt_sorted.alloc(n));
@@ -1538,7 +1541,7 @@ int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t
     PGH_TRY(temp.alloc(temp_bytes));
     PGH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(temp.p, temp_bytes, cnt, cnt_sorted.p, ids.p, ids_sorted.p, (int)n, 0, 32, r.stream));
     k_fill_perm_pad<<<blocks_for((int64_t)B * blk), kBlock, 0, r.stream>>>(perm, (int64_t)B * blk);
-    k_make_perm<<<blocks_for(n), kBlock, 0, r.stream>>>(ids_sorted.p, n, B, blk, perm, iperm);
+    k_make_perm<<<blocks_for(n), kBlock, 0, r.stream>>>(ids_sorted.p, n, B, blk, head, perm, iperm);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(r.stream));
     return 0;
@@ -1575,7 +1578,8 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     if (relabel && n_src != n_out) relabel = false;
     const int B = force_blocks > 0 ? force_blocks : bsf_auto_blocks(n_src);
     PGH_CHECK(B >= 1 && B <= kMaxBlocks && (B <= 8 || (target != nullptr && target != &g->bsf)), "blocked format: unsupported number of column blocks");
-    const int blk = (int)((n_src + B - 1) / B);
+    // (whole runs of the deal per block: deal_new_id)
+    const int blk = B > 1 ? (int)((n_src + (int64_t)kDealRun * B - 1) / ((int64_t)kDealRun * B)) * kDealRun : (int)n_src;
     const int n_src_pad = B * blk;
     f.num_blocks = B;
     f.blk_size = blk;
@@ -1601,14 +1605,16 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_TRY(live_count.alloc(1, true));
         k_relabel_keys<<<blocks_for(n_src), kBlock, 0, r.stream>>>(cnt.p, g->rowptr, n_src, key.p, live_count.p);
         const bool iso_on = env_int("PGH_ISO", 1) != 0;          // 0: the round-1 order (ties by id), no isolated tail (diagnostic)
-        PGH_TRY(build_count_perm(iso_on ? key.p : cnt.p, n_src, B, blk, f.perm, iperm.p));
+        // the 4096 hottest ranks of every block one by one (their entries decide how evenly the blocks / XCDs are loaded), the tail in runs
+        f.deal_head = (B > 1 && env_int("PGH_DEAL_RUNS", 1) != 0) ? (int64_t)B * 4096 : kDealHeadAll;
+        PGH_TRY(build_count_perm(iso_on ? key.p : cnt.p, n_src, B, blk, f.perm, iperm.p, f.deal_head));
         unsigned int live_nodes = 0;
         PGH_HIP(hipMemcpyAsync(&live_nodes, live_count.p, sizeof(unsigned int), hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
         f.live_nodes = iso_on ? (int64_t)live_nodes : -1;
         for (int b = 0; b < B && b < 8; ++b) {
-            // ranks r = b, b + B, ... land in block b at slot r / B: the first isolated slot, rounded up to whole float4s
-            const int64_t first_iso = ((int64_t)live_nodes - b + B - 1) / B;
+            // the first slot of block b whose rank is isolated (ranks ascend with the slot: deal_rank_of), rounded up to whole float4s
+            const int64_t first_iso = deal_first_slot((int64_t)live_nodes, b, B, blk, f.deal_head);
             f.iso_begin[b] = (int)std::min<int64_t>(blk, (std::max<int64_t>(first_iso, 0) + 3) & ~(int64_t)3);
         }
         f.has_iso = iso_on && B <= 8;
@@ -1621,7 +1627,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         if (row_blocks >= 1 && row_blocks <= 8 && first_block + row_blocks <= B) {
             for (int j = 0; j < 8; ++j) f.iso_begin[j] = blk;
             for (int j = 0; j < row_blocks; ++j) {
-                const int64_t first_iso = (g->part_live_nodes - (first_block + j) + B - 1) / B;
+                const int64_t first_iso = deal_first_slot(g->part_live_nodes, first_block + j, B, blk, kDealHeadAll);     // partitions: one by one
                 f.iso_begin[j] = (int)std::min<int64_t>(blk, (std::max<int64_t>(first_iso, 0) + 3) & ~(int64_t)3);
             }
             f.has_iso = true;

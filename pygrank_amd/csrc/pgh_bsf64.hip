@@ -423,10 +423,11 @@ inline int grid_for(int64_t n, int per_cu) {
 
 namespace pgh {
 
-// first slot of every block from which all rows are isolated: ranks r >= live_nodes sit at slots r / B >= ceil(live_nodes / B)
+// first slot from which the rows of EVERY block are isolated (ranks >= live_nodes; deal_rank_of)
 static int iso_from_of(const BsfFormat& f) {
     if (f.live_nodes < 0) return f.blk_size;
-    const int64_t from = (f.live_nodes + f.num_blocks - 1) / f.num_blocks;
+    int64_t from = 0;                                    // one line for all blocks: the last of their first isolated slots
+    for (int b = 0; b < f.num_blocks; ++b) from = std::max(from, deal_first_slot(f.live_nodes, b, f.num_blocks, f.blk_size, f.deal_head));
     return (int)(from < f.blk_size ? from : f.blk_size);
 }
 

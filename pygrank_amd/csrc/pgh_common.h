@@ -94,6 +94,35 @@ void pool_trim();
 #ifndef PGH_PROBE_SKIP
 #define PGH_PROBE_SKIP 0
 #endif
+// The relabelling deals the ranks (sources by descending reference count) to the B column blocks: the first `head` ranks -- the heavy
+// hitters, whose entries must spread evenly over the blocks / XCDs / ranks -- one by one (new = (r % B) * blk + r / B, as rounds 1-3
+// dealt every rank), the long tail in RUNS of kDealRun: 32 consecutive ranks are 32 consecutive slots of one block -- one 128-byte
+// line of every internal-space vector.  Ids of equal reference count are consecutive ranks in ascending id order (stable sort), so
+// the way out of the id space (dst[old] = src[new[old]]) touches a third of the lines per gather instruction that the one-by-one deal
+// did (tools/permute_probe.hip: 40.4 -> 23.7 us for the gathers of the bench graph).  head is a multiple of B * kDealRun, block sizes
+// are multiples of kDealRun; head >= n (partitions: kDealHeadAll) = the one-by-one deal throughout.
+constexpr int kDealRun = 32;
+constexpr int64_t kDealHeadAll = (int64_t)1 << 40;
+__host__ __device__ inline int64_t deal_new_id(int64_t r, int B, int64_t blk, int64_t head) {
+    if (r < head) return (r % B) * blk + r / B;
+    const int64_t t = r - head, run = t / kDealRun;
+    return (run % B) * blk + head / B + (run / B) * kDealRun + t % kDealRun;
+}
+// rank of slot `loc` of block b (ascending in loc), and the first slot of block b whose rank is >= `rank` (blk when there is none)
+__host__ __device__ inline int64_t deal_rank_of(int b, int64_t loc, int B, int64_t head) {
+    if (loc < head / B) return loc * B + b;
+    const int64_t t = loc - head / B;
+    return head + ((t / kDealRun) * B + b) * kDealRun + t % kDealRun;
+}
+inline int64_t deal_first_slot(int64_t rank, int b, int B, int64_t blk, int64_t head) {
+    int64_t lo = 0, hi = blk;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (deal_rank_of(b, mid, B, head) >= rank) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
 constexpr int kMaxPartials = 4096;   // upper bound on workgroups contributing block partials
 constexpr int kPartialRegions = 6;   // Runtime::d_partials: sums, deltas / residuals, and the fused residual's R, D, T (+ spare)
 constexpr int kNumScalars = 64;
@@ -242,6 +271,7 @@ struct BsfFormat {
     // square relabelled graphs: isolated ids (never referenced, empty row) sort last, slots [iso_begin[b], blk_size) of block b
     bool      has_iso = false;
     int64_t   live_nodes = -1;      // ids that are referenced or hold entries (they sort first), -1 = unknown
+    int64_t   deal_head = pgh::kDealHeadAll;  // ranks below it were dealt to the blocks one by one, the others in runs (deal_new_id)
     int       iso_begin[8] = {0};
     int       iso_row_blocks = 0;   // row blocks the thresholds cover: num_blocks (square graphs) or the blocks of a rank's slice
     int32_t*  seed_list = nullptr;  // [2^16] original ids of the non-zeros of a run's operands (bsf_bring_pair), lazily allocated

@@ -123,7 +123,12 @@ struct IsoTail {
         if (blk <= 0) return false;
         const unsigned int r32 = (unsigned int)row;            // ids are below 2^31
         const int b = shift >= 0 ? (int)(r32 >> shift) : (int)(r32 / (unsigned int)blk);
-        return b < num_blocks && (int)(r32 - (unsigned int)b * (unsigned int)blk) >= begin[b];
+        // (a chain of selects over the 8 table entries: indexing a kernel-argument array with a per-lane value sends the table through
+        // scratch memory -- the way out of the id space took 54 us with it, 40 without, tools/permute_probe.hip)
+        int first = begin[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) first = b == k ? begin[k] : first;
+        return b < num_blocks && (int)(r32 - (unsigned int)b * (unsigned int)blk) >= first;
     }
 };
 
@@ -644,7 +649,7 @@ int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int);
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);
 int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel,
               int force_blocks = 0, BsfFormat* target = nullptr);
-int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t* perm, int32_t* iperm);
+int build_count_perm(const unsigned int* cnt, int64_t n, int B, int blk, int32_t* perm, int32_t* iperm, int64_t head = kDealHeadAll);
 int bsf_auto_blocks(int64_t n_src);
 void bsf_destroy(BsfFormat& f);
 // pgh_bsf64.hip: the f64 route of the "chebyshev" recurrence on a blocked image of its own (pgh_graph_s::bsf64)

@@ -95,7 +95,7 @@ def partition_scipy(M, rank, world):
     blk = n_pad // blocks
     order = np.argsort(-np.diff(M.indptr), kind="stable")               # rank by descending source count
     r = np.arange(n, dtype=np.int64)
-    new_of_rank = (r % blocks) * blk + r // blocks
+    new_of_rank = (r % blocks) * blk + r // blocks                       # partitions deal the ranks one by one (nnz balance between the ranks)
     perm = np.full(n_pad, -1, dtype=np.int32)
     perm[new_of_rank] = order
     iperm = np.empty(n, dtype=np.int64)
@@ -314,8 +314,12 @@ def _preflight(dist, device, rank, world, lib):
     import torch
     verdict = "ok"
     L.check(lib.pgh_dist_set_timeout(float(os.environ.get("PGH_DIST_PREFLIGHT_S", "30"))))
+    # the probe's slices get a cold image whatever their size (PGH_PB_FORCE, read at build time), so that what runs is the loop of the
+    # large graphs: split regions, the residual inside the finish kernel, ONE 4-scalar all-reduce, the slice degrees' all-reduce
+    saved_env = {k: os.environ.get(k) for k in ("PGH_PB", "PGH_PB_FORCE")}
+    os.environ.update(PGH_PB="1", PGH_PB_FORCE="1")
     try:
-        pg = rmat_partitioned(16, 8, rank, world, seed=0)
+        pg = rmat_partitioned(20, 8, rank, world, seed=0)
         rng = np.random.default_rng(1)
         p_new = np.zeros(pg.n)
         p_new[rng.choice(pg.n, 20, replace=False)] = 1.0                        # in NEW ids: the same on every rank
@@ -342,6 +346,11 @@ def _preflight(dist, device, rank, world, lib):
         verdict = f"probe: {str(exc)[:200]}"
     finally:
         lib.pgh_dist_set_timeout(0.0)
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     agree = torch.tensor([1 if verdict == "ok" else 0], dtype=torch.int32, device=device)
     dist.all_reduce(agree, op=dist.ReduceOp.MIN)
     if int(agree.item()) == 0 and verdict == "ok":
