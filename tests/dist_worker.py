@@ -74,6 +74,14 @@ def main():
     results["closed_form_two_launches"] = int(bool(algo.exchange.get("finish_in_two_launches", False)))
     from pygrank_amd.distributed import PREFLIGHT
     results["preflight"] = str(PREFLIGHT.get((world, rank), "not run"))
+    # the probe itself (it runs by itself only with more than one rank over RCCL): here with whatever ranks this run has
+    results["preflight_selftest"] = "not run"
+    if on_gpu and dist.get_backend() == "nccl" and os.environ.get("PGH_DIST_NATIVE", "auto") in ("auto", "1"):
+        import torch
+        from pygrank_amd import distributed as D
+        device = torch.device("cuda", torch.cuda.current_device())
+        if D._native_comm(dist, device) is not None:
+            results["preflight_selftest"] = str(D._preflight(dist, device, rank, world, _lib.lib()))
     # the gather bases are state of the GRAPH: a Python-driven filter that keeps its buffers must find its own layout again after
     # an engine-driven run on the same graph has laid the gather vector out in two regions
     staged = DistributedHeatKernel(t=3, error_type="l1", tol=1e-7, max_iters=100)

@@ -195,6 +195,8 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
     from parity_common import check_partition_against_oracle
     check_partition_against_oracle(parts, scale, ef)
     assert all(str(part["closed_form_driver"]) == driver for part in parts), [str(part["closed_form_driver"]) for part in parts]
+    if driver == "engine (RCCL)":        # the probe that guards N > 1 (engine loop vs Python-driven loop on slices with a cold image)
+        assert all(str(part["preflight_selftest"]) == "ok" for part in parts), [str(part["preflight_selftest"]) for part in parts]
     if scale > 14 and driver.startswith("engine"):
         # slices with a cold image: the residual of the L1 / Mabs rules is evaluated inside the finish kernel (ONE 4-scalar all-reduce
         # per iteration), and a personalization with negative entries makes it hand one step to the separate kernel
