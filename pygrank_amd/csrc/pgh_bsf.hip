@@ -1605,8 +1605,13 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_TRY(live_count.alloc(1, true));
         k_relabel_keys<<<blocks_for(n_src), kBlock, 0, r.stream>>>(cnt.p, g->rowptr, n_src, key.p, live_count.p);
         const bool iso_on = env_int("PGH_ISO", 1) != 0;          // 0: the round-1 order (ties by id), no isolated tail (diagnostic)
-        // the 4096 hottest ranks of every block one by one (their entries decide how evenly the blocks / XCDs are loaded), the tail in runs
-        f.deal_head = (B > 1 && env_int("PGH_DEAL_RUNS", 1) != 0) ? (int64_t)B * 4096 : kDealHeadAll;
+        // the hottest ranks of every block one by one (their entries decide how evenly the blocks / XCDs are loaded, and their ROWS are
+        // the heavy ones: kept apart in the row order), the tail in runs.  PGH_DEAL_HEAD: slots per block dealt one by one (a multiple of
+        // 32).  Same box, scale 23 (profiles/r04/default_rule.log): head 4096 / 29 696 / 131 072 / everything one by one -- the bench
+        // 563 / 570 / 571 / 568 GTEPS (block partial sums 69.0 / 67.1 / 66.6 / 67.0 us), the 2-iteration default-rule run 364 / 360 /
+        // 360 / 341 GTEPS: runs among the hot rows cost the step kernels what they save on the way out.
+        const int head_slots = env_int("PGH_DEAL_HEAD", 131072) / kDealRun * kDealRun;
+        f.deal_head = (B > 1 && env_int("PGH_DEAL_RUNS", 1) != 0) ? (int64_t)B * head_slots : kDealHeadAll;
         PGH_TRY(build_count_perm(iso_on ? key.p : cnt.p, n_src, B, blk, f.perm, iperm.p, f.deal_head));
         unsigned int live_nodes = 0;
         PGH_HIP(hipMemcpyAsync(&live_nodes, live_count.p, sizeof(unsigned int), hipMemcpyDeviceToHost, r.stream));
