@@ -295,6 +295,8 @@ bool finish_in_two(const pgh_comm_s* c, const pgh_graph_s* g) {
     const char* env = getenv("PGH_DIST_FINISH_SPLIT");
     const int mode = env != nullptr ? atoi(env) : 1;
     if (mode == 0 || !g->bsf.enabled || !g->bsf.pb.enabled) return false;
+    // (both launches keep a partial sum per workgroup and per tail item: they must fit the partial buffers)
+    if (2 * (g->bsf.pb.sched_groups + g->bsf.pb.tail_count) > kMaxPartials) return false;
     const int64_t received = 4LL * c->live * c->bpr * (c->world - 1);
     return mode == 2 || (c->world > 1 && !c->one_gather && received >= (32LL << 20));
 }
