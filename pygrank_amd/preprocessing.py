@@ -181,7 +181,14 @@ def obj2id(obj):
     tag = getattr(obj, "uuid", None)
     if tag is None:
         tag = obj.uuid = uuid.uuid1()
-    return str(tag)
+    text = getattr(obj, "_uuid_text", None)                 # (formatting a uuid costs more than the dictionary lookup it keys)
+    if text is None or text[0] is not tag:
+        text = (tag, str(tag))
+        try:
+            obj._uuid_text = text
+        except AttributeError:
+            pass
+    return text[1]
 
 
 def _call_key(args, kwargs):

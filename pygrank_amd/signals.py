@@ -10,6 +10,7 @@ from collections.abc import MutableMapping
 import numpy as np
 
 from pygrank_amd import backend
+from pygrank_amd.device import DeviceVector
 
 
 def _node_count(graph):
@@ -32,6 +33,8 @@ def _dense_values(obj, count, node2id):
     count), nothing means all ones, a node -> value mapping is staged on the host and uploaded once."""
     if obj is None:
         return backend.repeat(1.0, count)
+    if type(obj) is DeviceVector and len(obj) == count:      # the engine's own vector: nothing to look at (the hot path of rank())
+        return obj
     if backend.is_array(obj):
         have = backend.length(obj)
         if have != count:
@@ -55,7 +58,8 @@ class GraphSignal(MutableMapping):
     # ---- backend primitive
     @property
     def np(self):                                         # signals.py:81-83
-        return backend.to_array(self._np)
+        value = self._np
+        return value if type(value) is DeviceVector else backend.to_array(value)
 
     @np.setter
     def np(self, value):                                  # signals.py:85-87
