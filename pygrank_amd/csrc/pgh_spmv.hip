@@ -1494,16 +1494,13 @@ int window_for(pgh_graph_t g) {
 
 struct LoopTimer {
     hipEvent_t a = nullptr, b = nullptr;
+    ~LoopTimer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
     int start() {
-        // (one pair of events for the life of the process: a run is a few hundred microseconds, creating and destroying two events
-        // per run is a few of them)
-        static hipEvent_t pair[2] = {nullptr, nullptr};
-        if (pair[0] == nullptr) {
-            PGH_HIP(hipEventCreate(&pair[0]));
-            PGH_HIP(hipEventCreate(&pair[1]));
-        }
-        a = pair[0];
-        b = pair[1];
+        PGH_HIP(hipEventCreate(&a));
+        PGH_HIP(hipEventCreate(&b));
         PGH_HIP(hipEventRecord(a, rt().stream));
         return 0;
     }
