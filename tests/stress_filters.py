@@ -49,8 +49,43 @@ def main():
         adj.is_directed = lambda: True
         p = np.zeros(n)
         p[rng.integers(0, n, min(n, 7))] = 0.5 + rng.random(min(n, 7))
-        desc = f"#{done} n={n} nnz={A.nnz} norm={norm} " + " ".join(f"{k}={os.environ[k]}" for k in ("PGH_BLOCKS", "PGH_RELABEL", "PGH_PB", "PGH_TRIM"))
-        which = int(rng.integers(0, 5))
+        shape = float(rng.random())
+        if shape < 0.15:                                           # a dense personalization (the gather pass instead of the seed list)
+            p = 0.1 + rng.random(n)
+        elif shape < 0.35 and norm == "col":                       # negative entries: the in-kernel residual must hand the decision back
+            p[rng.integers(0, n, min(n, 3))] = -0.3
+            if abs(p.sum()) < 0.2:
+                p[int(np.argmax(p))] += 1.0
+        desc = f"#{done} n={n} nnz={A.nnz} norm={norm} p={'dense' if shape < 0.15 else ('signed' if shape < 0.35 and norm == 'col' else 'seeds')} " \
+            + " ".join(f"{k}={os.environ[k]}" for k in ("PGH_BLOCKS", "PGH_RELABEL", "PGH_PB", "PGH_TRIM"))
+        which = int(rng.integers(0, 6))
+        if which == 5:
+            # rank(..., graph_dropout=) as one device loop on whatever layout the switches gave: against a host loop that rebuilds every
+            # step's mask with the numpy twin of the hash (the mask of step k + 1: seed0 + 2 + k, tests/kernel_checks.py)
+            from oracle import rmat_np
+            MT = g.download_transposed()
+            rate, steps = float(rng.choice([0.2, 0.5])), int(rng.integers(2, 7))
+            pg.backend.hip.set_dropout_seed(1000 + done)
+            ranker = pg.PageRank(0.85, error_type="iters", max_iters=steps + 1)
+            got = np.asarray(ranker.rank(adj, p.copy(), graph_dropout=rate).np)
+            norm1 = np.abs(p).sum()
+            pn = (p.astype(np.float32) / np.float32(norm1)).astype(np.float64)
+            x, quot = pn.copy(), 1.0
+            e = np.arange(MT.nnz, dtype=np.uint64)
+            for k in range(steps):
+                with np.errstate(over="ignore"):
+                    h = rmat_np.splitmix64(np.uint64(1000 + done + 2 + k) ^ (e * np.uint64(0xD6E8FEB86659FD93)))
+                keep = (h >> np.uint64(32)).astype(np.int64) >= int(np.floor(rate * 4294967296.0))
+                data = (MT.data.astype(np.float32) * np.float32(1.0 / (1.0 - rate))).astype(np.float32).astype(np.float64) * keep
+                y = 0.85 * quot * (sp.csr_array((data, MT.indices, MT.indptr), shape=MT.shape) @ x) + 0.15 * pn
+                quot, x = (1.0 / y.sum() if y.sum() != 0 else 0.0), y
+            want = x * quot * norm1
+            rel = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-30)
+            if rel > 4e-6 or ranker.last_loop["spmv"] != steps:
+                print("MISMATCH dropout loop", desc, "rate", rate, "steps", steps, "rel", rel, flush=True)
+                sys.exit(1)
+            done += 1
+            continue
         if which == 0:
             kw = dict(alpha=float(rng.choice([0.5, 0.85, 0.99])), use_quotient=bool(rng.integers(0, 2)))
             err = str(rng.choice(["l1", "mabs", "linf"]))
