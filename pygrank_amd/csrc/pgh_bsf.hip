@@ -749,7 +749,11 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
             }
             if (W16) {                    // halfword k of the lane's 16 bytes = byte offset / 2 into the hot cache
                 const uint32_t pair = st.c[0][k >> 1];
+#if PGH_PROBE_GATHER == 9        // the hot gathers without bank conflicts (wrong sums): lane l reads word l of a 256-byte row, still behind the stream word
+                const uint32_t off = (((k & 1) ? pair >> 31 : (pair >> 15) & 1u) << 2) + (lane << 2) + (k << 8);
+#else
                 const uint32_t off = (k & 1) ? (pair >> 16) << 1 : (pair & 0xffffu) << 1;
+#endif
                 g.h[k] = *reinterpret_cast<const float*>(lds + off);
                 g.c[k] = 0.f;
                 if (HAS_VAL && !DROP) g.v[k] = __uint_as_float(st.v[k >> 2][k & 3]);

@@ -507,7 +507,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                 for (int q = 0; q < P; ++q) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const int r = (int)R.r8[q][k];
+                        int r = (int)R.r8[q][k];
+                        if (PGH_PROBE_PB & 256) r = (r >> 15) + ((tid & 63) + 64 * k) % rows;   // diagnostic: atomics without bank / address conflicts (wrong sums)
                         const float v = k < 4 ? R.lo[q][k] : R.hi[q][k - 4];
                         const long long fixed = __double_as_longlong(__builtin_fma((double)v, S, kMagic)) - __double_as_longlong(kMagic);
                         if (hub) {

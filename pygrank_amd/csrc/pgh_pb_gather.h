@@ -4,7 +4,7 @@
 #include "pgh_kernels.h"
 
 // diagnostic builds only (tools/build_variants.sh): 1 no chunk fill, 2 fills only, 4 no stores (phase A); 8 no loads,
-// 16 no atomics (phase B), 32 no epilogue
+// 16 no atomics (phase B), 32 no epilogue, 64 sequential stores, 128 conflict-free LDS gathers (phase A), 256 conflict-free LDS atomics (phase B)
 #ifndef PGH_FILL_GLDS
 #define PGH_FILL_GLDS 1
 #endif
@@ -71,6 +71,17 @@ __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, c
                 // duplicate stores to the piece's last group queue up on one memory channel)
                 if (rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8) > last) continue;
                 f32x4 lo, hi;
+                if (PGH_PROBE_PB & 128) {                    // diagnostic: the LDS gathers without bank conflicts (wrong values)
+                    const int at = (int)(threadIdx.x & 63u) + 64 * q;
+                    lo.x = s_x[(r.s8[q][0] >> 15) + at];
+                    lo.y = s_x[(r.s8[q][1] >> 15) + at + 512];
+                    lo.z = s_x[(r.s8[q][2] >> 15) + at + 1024];
+                    lo.w = s_x[(r.s8[q][3] >> 15) + at + 1536];
+                    hi.x = s_x[(r.s8[q][4] >> 15) + at + 2048];
+                    hi.y = s_x[(r.s8[q][5] >> 15) + at + 2560];
+                    hi.z = s_x[(r.s8[q][6] >> 15) + at + 3072];
+                    hi.w = s_x[(r.s8[q][7] >> 15) + at + 3584];
+                } else {
                 lo.x = s_x[r.s8[q][0]];
                 lo.y = s_x[r.s8[q][1]];
                 lo.z = s_x[r.s8[q][2]];
@@ -79,6 +90,7 @@ __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, c
                 hi.y = s_x[r.s8[q][5]];
                 hi.z = s_x[r.s8[q][6]];
                 hi.w = s_x[r.s8[q][7]];
+                }
                 if (HAS_VAL) {
                     lo *= r.w0[q];
                     hi *= r.w1[q];

@@ -325,22 +325,40 @@ def _preflight(dist, device, rank, world, lib):
         p_new[rng.choice(pg.n, 20, replace=False)] = 1.0                        # in NEW ids: the same on every rank
         p_local = DeviceVector.from_host(p_new[pg.row_begin:pg.row_begin + pg.n_local])
         kw = dict(alpha=0.85, tol=1e-6, error_type="l1", max_iters=200)
-        native = DistributedPageRank(**kw)
-        native._dist, native._device = dist, device
-        try:
-            got = np.asarray(native._rank_native(pg, p_local, _NATIVE_COMMS[(world, rank)], lib), dtype=np.float64)
-        except Exception as exc:                                                   # EngineError of a bounded wait, ...
-            got, verdict = None, f"engine loop: {str(exc)[:200]}"
+        # two legs of the engine loop: as this process would run a small exchange (one finish launch), and with the finish kernel in
+        # two launches -- what a large exchange (configs[4]) switches on and nothing smaller would exercise over RCCL
+        legs = [("", None)]
+        if "PGH_DIST_FINISH_SPLIT" not in os.environ:
+            legs.append(("two-launch finish: ", "2"))
+        runs = []
+        for label, split in legs:
+            native = DistributedPageRank(**kw)
+            native._dist, native._device = dist, device
+            if split is not None:
+                os.environ["PGH_DIST_FINISH_SPLIT"] = split
+            try:
+                got = np.asarray(native._rank_native(pg, p_local, _NATIVE_COMMS[(world, rank)], lib), dtype=np.float64)
+                runs.append((label, native.iteration, got))
+            except Exception as exc:                                               # EngineError of a bounded wait, ...
+                verdict = f"{label}engine loop: {str(exc)[:200]}"
+            finally:
+                if split is not None:
+                    os.environ.pop("PGH_DIST_FINISH_SPLIT", None)
+            if verdict != "ok":
+                break                                                              # (a stalled communicator takes no further run)
         staged = DistributedPageRank(**kw)
         staged._native_formula = False
         want = np.asarray(staged.rank(pg, p_local), dtype=np.float64)
-        if got is not None:
+        if verdict == "ok":
             top = torch.tensor([float(np.max(np.abs(want), initial=0.0))], dtype=torch.float64, device=device)
             dist.all_reduce(top, op=dist.ReduceOp.MAX)
-            if native.iteration != staged.iteration:
-                verdict = f"iterations differ: engine {native.iteration}, staged {staged.iteration}"
-            elif float(np.max(np.abs(got - want), initial=0.0)) > 1e-6 * float(top.item()):
-                verdict = "ranks differ between the engine loop and the staged loop"
+            for label, iterations, got in runs:
+                if iterations != staged.iteration:
+                    verdict = f"{label}iterations differ: engine {iterations}, staged {staged.iteration}"
+                elif float(np.max(np.abs(got - want), initial=0.0)) > 1e-6 * float(top.item()):
+                    verdict = label + "ranks differ between the engine loop and the staged loop"
+                if verdict != "ok":
+                    break
         pg.graph.destroy()
     except Exception as exc:
         verdict = f"probe: {str(exc)[:200]}"
