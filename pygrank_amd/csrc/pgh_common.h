@@ -287,7 +287,7 @@ struct BsfFormat {
     int64_t   xg_base[8] = {0};     // first element of every block's slice inside the gather vector (default b * blk_size;
                                     // a partitioned run lays the slices out as the trimmed all-gather delivers them)
     int32_t*  drop_edge = nullptr;  // index in CSR(M^T) order of every stream entry, laid out like `val` (graph_dropout; bsf_ensure_edge_ids)
-    int       lg_live = 0, lg_hot = 0;   // partitioned runs driven by the engine (pgh_dist.hip): the epilogue writes this rank's slice of the
+    int       lg_live = 0, lg_hot = 0, lg_cold = -1;   // partitioned runs driven by the engine (pgh_dist.hip): the epilogue writes this rank's slice of the
                                     // next gather vector PACKED for the exchange -- [local block][lg_hot] | [local block][lg_live - lg_hot] --
                                     // instead of by row (0: by row; pgh_graph_set_gather_bases puts it back)
     int       xg_live = 0;          // > 0: the engine's own gather vector `xg` stores only the first xg_live slots of every

@@ -92,7 +92,8 @@ struct pgh_comm_s {
     int         nb = 0, bpr = 0, live = 0, hot = 0;
     int64_t     blk = 0, n_xg = 0, n_local = 0, buf_local = 0;
     float*      xg_full = nullptr;
-    float*      xg_local = nullptr;
+    float*      xg_local = nullptr;   // this rank's slice inside xg_full (prepare_graph)
+    int64_t     local_off = 0, cold_rel = 0;
     float*      y[2] = {nullptr, nullptr};
     float*      p_norm = nullptr;
     double*     state = nullptr;         // [8] device (pgh_dist_* layout)
@@ -116,6 +117,10 @@ namespace {
 // one all-gather / all-reduce of the run: RCCL on `st`, or the host's callback (which completes the exchange in stream order on `st`
 // before it returns: dtype 0 = f32, 1 = f64, 2 = i32; op 0 = sum, 1 = max)
 int comm_all_gather(pgh_comm_s* c, const void* send, void* recv, size_t count, ncclComm_t comm, hipStream_t st) {
+    // (a rank alone: its slice already lies where the gathered vector wants it; PGH_DIST_GATHER_ALONE=1 makes the call all the same,
+    // so that one GPU can exercise RCCL's all-gather: tests)
+    if (c->world == 1 && c->ext_gather == nullptr && !(getenv("PGH_DIST_GATHER_ALONE") != nullptr && atoi(getenv("PGH_DIST_GATHER_ALONE")) != 0))
+        return 0;
     if (c->ext_gather != nullptr) {
         PGH_CHECK(c->ext_gather(c->ext_user, send, recv, (int64_t)count, 0, (void*)st) == 0, "pgh_dist_ppr_run: the host's all-gather callback failed");
         return 0;
@@ -137,8 +142,7 @@ int comm_all_reduce(pgh_comm_s* c, void* buf, size_t count, ncclDataType_t dt, n
 }
 
 void free_buffers(pgh_comm_s* c) {
-    (void)hipFree(c->xg_full);
-    (void)hipFree(c->xg_local);
+    (void)hipFree(c->xg_full);         // (xg_local points into it)
     (void)hipFree(c->y[0]);
     (void)hipFree(c->y[1]);
     (void)hipFree(c->p_norm);
@@ -240,9 +244,20 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     }
     if (split) PGH_TRY(pgh_graph_set_gather_bases_split(g, hot_bases, cold_bases));
     else PGH_TRY(pgh_graph_set_gather_bases(g, hot_bases));
-    PGH_TRY(dist_set_local_layout(g, (int)live, c->hot));      // (after the bases: setting them resets the layout)
+    // The slice is written IN PLACE: the epilogue of a step stores this rank's slots straight into their places of the gathered
+    // vector (ncclAllGather's in-place form: send = recv + rank * count), so no collective copies a rank's own slots and a rank alone
+    // has nothing to exchange at all.  One region: the packed slice [hot prefixes | cold parts] is rank r's stretch of the vector;
+    // two regions: its hot prefixes are rank r's stretch of the hot region, its cold parts rank r's stretch of the cold region.
+    // (Safe: a step's finish kernel is the last reader-free point of the vector on this rank -- the block partial sums and phase A of
+    // the step have run, the next all-gather is enqueued behind it -- and peers write only their own stretches.)
+    const bool two_regions = split && !c->one_gather;
+    c->local_off = two_regions ? (int64_t)c->rank * c->bpr * c->hot : (int64_t)c->rank * c->bpr * live;
+    c->cold_rel = two_regions ? (int64_t)nb * c->hot + (int64_t)c->rank * c->bpr * (live - c->hot) - c->local_off : (int64_t)c->bpr * c->hot;
+    PGH_CHECK(c->cold_rel >= 0 && c->cold_rel < (1LL << 31), "pgh_dist_ppr_run: the gather vector is too long for the slice layout");
+    PGH_TRY(dist_set_local_layout(g, (int)live, c->hot, (int)c->cold_rel));      // (after the bases: setting them resets the layout)
     const int64_t n_xg = (int64_t)nb * live + 32768;          // + the hot cache's read-ahead past a short block
     if (c->graph != nullptr && c->n_xg == n_xg && c->buf_local == c->n_local) {
+        c->xg_local = c->xg_full + c->local_off;
         c->graph = g;
         return 0;
     }
@@ -251,7 +266,7 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     c->buf_local = c->n_local;
     PGH_HIP(hipMalloc(&c->xg_full, sizeof(float) * (size_t)c->n_xg));
     PGH_HIP(hipMemsetAsync(c->xg_full, 0, sizeof(float) * (size_t)c->n_xg, r.stream));
-    PGH_HIP(hipMalloc(&c->xg_local, sizeof(float) * (size_t)c->n_local));
+    c->xg_local = c->xg_full + c->local_off;
     PGH_HIP(hipMalloc(&c->y[0], sizeof(float) * (size_t)c->n_local));
     PGH_HIP(hipMalloc(&c->y[1], sizeof(float) * (size_t)c->n_local));
     PGH_HIP(hipMalloc(&c->p_norm, sizeof(float) * (size_t)c->n_local));
@@ -265,7 +280,7 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
 int gather_part(pgh_comm_s* c, int64_t region, int lo, int hi, hipStream_t st) {
     if (hi <= lo) return 0;
     const int64_t len = (int64_t)(hi - lo) * c->bpr;
-    const int64_t from = lo == 0 ? 0 : (int64_t)c->bpr * lo;
+    const int64_t from = lo == 0 ? 0 : c->cold_rel;
     return comm_all_gather(c, c->xg_local + from, c->xg_full + region, (size_t)len, c->x, st);
 }
 

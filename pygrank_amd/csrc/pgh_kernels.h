@@ -612,7 +612,7 @@ DropView bsf_dropout_view(const int32_t* edge);
 // the partitioned loop's fused scalars (pgh_spmv.hip; driven by pgh_dist.hip)
 bool dist_can_fuse(const pgh_graph_s* g);
 // where a partitioned run keeps this rank's slice of the next gather vector: packed for the exchange (BsfFormat::lg_*), 0 = by row
-int dist_set_local_layout(pgh_graph_s* g, int live, int hot);
+int dist_set_local_layout(pgh_graph_s* g, int live, int hot, int cold = -1);
 int dist_prescale_packed(pgh_graph_s* g, const float* x_local, float* xg_local_out);
 int dist_aux_init(LoopAux* aux);
 int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float* y_local, float* xg_local_out, const float* x_prev,

@@ -986,7 +986,7 @@ inline void local_layout(const BsfFormat& f, EpiParams& ep) {
     ep.xg_blk = (int)f.blk_size;
     ep.xg_live = f.lg_live;
     ep.xg_hot = f.lg_hot;
-    ep.xg_cold = local_blocks * f.lg_hot;
+    ep.xg_cold = f.lg_cold >= 0 ? f.lg_cold : local_blocks * f.lg_hot;
 }
 __global__ void k_prescale_packed(const float* __restrict__ x, const float* __restrict__ scale, int64_t n, float* __restrict__ out, int blk,
                                   int live, int hot, int cold) {
@@ -998,9 +998,12 @@ __global__ void k_prescale_packed(const float* __restrict__ x, const float* __re
 }  // namespace
 
 namespace pgh {
-int dist_set_local_layout(pgh_graph_s* g, int live, int hot) {
+// (cold: where the cold parts start, in slots from the slice's first hot slot -- right behind the hot prefixes (-1) unless the
+// slice is written straight into its places of the gathered vector, whose two regions lie apart: pgh_dist.hip::prepare_graph)
+int dist_set_local_layout(pgh_graph_s* g, int live, int hot, int cold) {
     g->bsf.lg_live = live;
     g->bsf.lg_hot = hot;
+    g->bsf.lg_cold = cold;
     return 0;
 }
 // out = x_local * source scale in the layout the run asked for (by row when none was set)
@@ -1112,7 +1115,7 @@ extern "C" int pgh_graph_set_gather_bases(pgh_graph_t g, const int64_t* bases) {
         PGH_CHECK(bases[b] >= 0 && bases[b] < (1LL << 31), "pgh_graph_set_gather_bases: base out of range");
         f.xg_base[b] = f.xg_base_cold[b] = bases[b];
     }
-    f.lg_live = f.lg_hot = 0;          // a caller that lays the gather vector out itself exchanges slices stored by row
+    f.lg_live = f.lg_hot = 0, f.lg_cold = -1;          // a caller that lays the gather vector out itself exchanges slices stored by row
     return 0;
 }
 

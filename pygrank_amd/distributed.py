@@ -29,7 +29,8 @@ class PartitionedGraph:
 
     def __init__(self, graph, rank, world):
         self.graph, self.rank, self.world = graph, rank, world
-        self.n = graph.shape[0]                 # global number of nodes (length of the gather vector)
+        self.n = graph.shape[0]                 # global id count (length of the gather vector; a caller's matrix is padded to it)
+        self.n_nodes = self.n                   # nodes of the caller's graph: what the Mabs rule averages over (partition_scipy sets it)
         self.n_local = graph.shape[1]           # rows of M^T held here
         self.row_begin = rank * self.n_local
         self._perm = None
@@ -114,7 +115,9 @@ def partition_scipy(M, rank, world):
     L.check(L.lib().pgh_graph_from_csr_part(n_pad, n_local, local.nnz, indptr.ctypes.data_as(C.c_void_p),
                                             indices.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p), lo, blocks,
                                             perm.ctypes.data_as(C.c_void_p), C.byref(h)))
-    return PartitionedGraph(DeviceGraph(h, (n_pad, n_local), local.nnz), rank, world)
+    out = PartitionedGraph(DeviceGraph(h, (n_pad, n_local), local.nnz), rank, world)
+    out.n_nodes = n                     # the padding ids are not nodes: Mabs divides by the caller's count (measures: sum / len)
+    return out
 
 
 _HOT_PAD = 32768          # the engine's LDS hot cache reads up to this many leading slots of a block's slice
@@ -526,7 +529,7 @@ class DistributedPageRank:
 
     def _rank_native(self, pgraph, p_local, comm, lib):
         extra = self._native_operands(pgraph)               # None: PageRank; (deg, lam, every_row): AbsorbingWalks
-        cfg = L.DistCfg(alpha=float(self.alpha), tol=0.0 if self.tol is None else max(float(self.tol), self.epsilon), n_global=int(pgraph.n),
+        cfg = L.DistCfg(alpha=float(self.alpha), tol=0.0 if self.tol is None else max(float(self.tol), self.epsilon), n_global=int(pgraph.n_nodes),
                         err_kind=self._KINDS[self.error_type], max_iters=int(self.max_iters), end_modulo=int(self.end_modulo),
                         use_quotient=1 if self.use_quotient else 0, preserve_norm=1 if self.preserve_norm else 0,
                         every_row=int(extra[2]) if extra else 0, deg_local=extra[0]._h if extra else None,
@@ -639,7 +642,7 @@ class DistributedPageRank:
                     if check:
                         L.check(lib.pgh_dist_residual(local_kind, bufs.v_y[cur]._h, bufs.v_y[1 - cur]._h, state))
                         dist.all_reduce(err_view, op=err_op)
-                        L.check(lib.pgh_dist_close_err(state, kind, tol, pgraph.n))
+                        L.check(lib.pgh_dist_close_err(state, kind, tol, pgraph.n_nodes))
                         bufs.state_host.copy_(bufs.state, non_blocking=True)
                 finally:
                     if cuda:
@@ -762,7 +765,7 @@ class DistributedClosedFormFilter:
             c = float(self.coefficient(c, it))
             coeffs.append(c)
         arr = (C.c_double * len(coeffs))(*coeffs)
-        cfg = L.DistCfg(alpha=0.0, tol=0.0 if self.tol is None else max(float(self.tol), self.epsilon), n_global=int(pgraph.n),
+        cfg = L.DistCfg(alpha=0.0, tol=0.0 if self.tol is None else max(float(self.tol), self.epsilon), n_global=int(pgraph.n_nodes),
                         err_kind=self._KINDS[self.error_type], max_iters=int(self.max_iters), end_modulo=int(self.end_modulo),
                         use_quotient=0, preserve_norm=1 if self.preserve_norm else 0, every_row=1, deg_local=None, lam_local=None)
         res = L.DistResult()
@@ -808,7 +811,7 @@ class DistributedClosedFormFilter:
         L.check(lib.pgh_dist_state_init(state))
         delta = abs(float(c)) * (1.0 if not linf else scalar(float(backend_max_abs(p)), dist.ReduceOp.MAX))
         if kind == L.ERR_MABS:
-            delta /= pgraph.n
+            delta /= pgraph.n_nodes
         cur, it, spmv, converged = 0, 2, 0, False
         t0 = time.perf_counter()
         while True:                                                              # `it` = the iteration has_converged is asked about
@@ -825,7 +828,7 @@ class DistributedClosedFormFilter:
             bufs.all_gather(dist, "all")
             dist.all_reduce(err_view, op=dist.ReduceOp.MAX if linf else dist.ReduceOp.SUM)
             bufs.state_host.copy_(bufs.state)                                    # the host decides (one read per term)
-            delta = float(bufs.state_host[1]) / (pgraph.n if kind == L.ERR_MABS else 1)
+            delta = float(bufs.state_host[1]) / (pgraph.n_nodes if kind == L.ERR_MABS else 1)
             cur, spmv, it = nxt, spmv + 1, it + 1
         self.elapsed = time.perf_counter() - t0
         self.iteration, self.spmv, self.converged, self.last_error = it, spmv, converged, delta

@@ -114,3 +114,20 @@ def test_partition_balance_eight_ways(host_engine):
         nnz = [rmat_partitioned(16, 16, r, world).graph.nnz for r in range(world)]
         assert max(nnz) <= 1.05 * np.mean(nnz), (world, nnz)
         assert sum(nnz) == rmat_np.rmat_csr(16, 16, seed=0).nnz
+
+
+def test_randomised_partitions_against_the_oracle(oracle_build_dir):
+    """tests/stress_partitioned.py for a few seconds with two ranks (gloo, host double, the Python-driven loop): random graphs (generated
+    slices and callers' matrices with ragged id counts), layouts, filters, stopping rules and personalizations against the oracle on the
+    un-partitioned graph.  (Its first minute found the Mabs rule dividing by the PADDED id count of a caller's matrix -- one iteration
+    early on a 483-node graph; PartitionedGraph.n_nodes.)  The GPU run of the same harness drives the engine's own loop."""
+    port = 29900 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "stress_partitioned.py"), "--seconds", "12", "--seed", "5", "--max-scale", "11"]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", PGH_TEST_ENGINE="host", PGH_DIST_BACKEND="gloo")
+    env.pop("PGH_DIST_NATIVE", None)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "partitioned stress ok" in res.stdout, res.stdout[-2000:]
+    cases = int(res.stdout.split("partitioned stress ok:")[1].split()[0])
+    assert cases >= 50, res.stdout[-500:]

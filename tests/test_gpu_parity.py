@@ -168,6 +168,10 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
     # RCCL runs go through the engine's own loop (pgh_dist_ppr_run: RCCL, streams and events driven from C++, hot prefixes and
     # cold parts of the gather vector exchanged as two contiguous regions); gloo runs and "python_driver" through the staged
     # pgh_dist_* calls from pygrank_amd/distributed.py
+    if backend == "nccl" and (mode or scale > 14):
+        # a rank alone has nothing to exchange and nothing to add: the engine skips its collectives (the slice is written in place)
+        # -- all but the plain scale-14 case make the RCCL calls all the same, so that ncclAllGather (in place) and ncclAllReduce run
+        env.update(PGH_DIST_GATHER_ALONE="1", PGH_DIST_REDUCE_ALONE="1")
     if mode == "single_queue":           # the conservative switches of a first multi-GPU run: one communicator, one stream
         env.update(PGH_DIST_SINGLE_COMM="1", PGH_DIST_SINGLE_STREAM="1")
     if mode == "python_driver":
