@@ -52,12 +52,13 @@ def main():
     pg.load_backend("hip")
     dist.init_process_group(backend=os.environ.get("PGH_DIST_BACKEND", "gloo"))
     rank, world = dist.get_rank(), dist.get_world_size()
+    ctl = dist.new_group(backend="gloo")                   # the harness's own traffic (host tensors), whatever the filters exchange over
     rng = np.random.default_rng(args.seed)                 # the SAME stream on every rank: every draw below is collective
     deadline = time.time() + args.seconds
     done, borderline, by_kind, drivers = 0, 0, {}, set()
     while True:
         go = torch.tensor([1 if time.time() < deadline else 0])
-        dist.broadcast(go, 0)                              # rank 0's clock decides for everybody
+        dist.broadcast(go, 0, group=ctl)                              # rank 0's clock decides for everybody
         if int(go.item()) == 0:
             break
         # ---- the graph and its layout
@@ -147,7 +148,7 @@ def main():
             drivers.add(str(getattr(algo, "exchange", {}).get("driver")))
             # every rank's slice -> rank 0 (gloo), un-permuted into original ids
             sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([n_local if out is not None else 0], dtype=torch.int64))
+            dist.all_gather(sizes, torch.tensor([n_local if out is not None else 0], dtype=torch.int64), group=ctl)
             ok_everywhere = all(int(s.item()) > 0 for s in sizes)
             want, want_iters, want_failure = None, -1, None
             try:
@@ -158,7 +159,7 @@ def main():
                 assert (want_failure is not None) == (failure is not None), (what, failure, want_failure)
             else:
                 slices = [torch.zeros(int(s.item()), dtype=torch.float64) for s in sizes]
-                dist.all_gather(slices, torch.from_numpy(np.ascontiguousarray(out)))
+                dist.all_gather(slices, torch.from_numpy(np.ascontiguousarray(out)), group=ctl)
                 got = np.zeros(n)
                 for r, piece in enumerate(slices):
                     ids = perm[r * n_local:(r + 1) * n_local]
@@ -186,7 +187,7 @@ def main():
         os.environ.pop(key, None)
     if rank == 0:
         print(f"partitioned stress ok: {done} cases in {args.seconds:.0f} s (seed {args.seed}, world {world}, drivers {sorted(drivers)}, {borderline} stopped a step apart): {by_kind}")
-    dist.barrier()
+    dist.barrier(group=ctl)
     dist.destroy_process_group()
 
 
