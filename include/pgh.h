@@ -227,7 +227,8 @@ typedef struct {
     int32_t iterations;     /* value of ConvergenceManager.iteration at loop exit                 */
     int32_t converged;      /* 1 = tolerance met; 0 = max_iters reached (caller raises unless ITERS) */
     int32_t spmv_count;     /* SpMV launches that contributed to the result                        */
-    int32_t flags;          /* bit 0: the in-kernel residual paused once and the run went on with the separate residual kernel */
+    int32_t flags;          /* bit 0: the in-kernel residual paused once and the run went on with the separate residual kernel;
+                               bit 1: the run evaluated its residual inside the finish kernel; bit 2: from the first step on */
     double  last_error;     /* residual of the last executed check                                */
     double  loop_ms;        /* HIP-event time of the loop on the engine stream                    */
     double  in_norm;        /* the L1 norm of the personalization when the run computed it (cfg in_norm < 0), else 0 */

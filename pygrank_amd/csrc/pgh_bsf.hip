@@ -411,6 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_close(const double* __restrict_
             init_aux->pred_raw[0] = init_aux->pred_raw[1] = 0.0;
             init_aux->sum_p = 0.0;
             init_aux->worst_miss = 0.0;
+            init_aux->t0_fix = init_aux->sp_fix = 0;
         }
         init_state->scale = 1.0;
         init_state->err = 0.0;
@@ -429,7 +430,8 @@ __global__ __launch_bounds__(kBlock) void k_scan_close(const double* __restrict_
 __device__ __forceinline__ void pair_scatter(const int32_t* __restrict__ list, int total, const float* __restrict__ v,
                                              const float* __restrict__ ranks, const int32_t* __restrict__ iperm, const float* __restrict__ scale,
                                              float* __restrict__ v_int, float* __restrict__ y0, float* __restrict__ xg, int xg_blk, int xg_live,
-                                             float in_norm, int start_from_v, const IsoTail& iso) {
+                                             float in_norm, int start_from_v, const IsoTail& iso, const float* __restrict__ pred_deg,
+                                             double& pred_t, double& pred_p) {
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
         const int old = list[k];
         const int i = iperm[old];
@@ -439,6 +441,10 @@ __device__ __forceinline__ void pair_scatter(const int32_t* __restrict__ list, i
         if (start_from_v) b = a;
         v_int[i] = a;
         if (y0 != nullptr) y0[i] = b;
+        if (pred_deg != nullptr) {
+            pred_t += (double)pred_deg[i] * (double)b;
+            pred_p += (double)a;
+        }
         if (iso.flag != nullptr && (a != 0.f || b != 0.f) && iso.holds(i)) atomicOr(iso.flag, 1);
         if (xg) {
             const int slot = xg_slot(i, xg_blk, xg_live);
@@ -454,13 +460,30 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
                                   float* __restrict__ xg, int xg_blk, int xg_live, float in_norm, int start_from_v,
                                   IsoTail iso = IsoTail{}, const int* __restrict__ seed_count = nullptr,
                                   const int32_t* __restrict__ seed_list = nullptr, const int32_t* __restrict__ iperm = nullptr,
-                                  const LoopAux* __restrict__ norm_from = nullptr) {
+                                  const LoopAux* __restrict__ norm_from = nullptr, const float* __restrict__ pred_deg = nullptr,
+                                  LoopAux* __restrict__ pred_aux = nullptr) {
+    // pred_deg (row sums of M, internal ids): the sums of the first step's prediction go to pred_aux->t0_fix / sp_fix
+    __shared__ double s_pred[4];
+    double pred_t = 0.0, pred_p = 0.0;
+    auto pred_publish = [&]() __attribute__((always_inline)) {          // (called by whole workgroups)
+        const double bt = block_reduce_256<0>(pred_t, s_pred);
+        __syncthreads();
+        const double bp = block_reduce_256<0>(pred_p, s_pred);
+        if (threadIdx.x == 0 && (bt != 0.0 || bp != 0.0)) {
+            // (sums beyond the fixed point's range leave a prediction that misses: the close's bound notices and pauses)
+            const double lim = 4.0e6;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&pred_aux->t0_fix), (unsigned long long)(long long)llrint(fmin(fmax(bt, -lim), lim) * kPredFix));
+            atomicAdd(reinterpret_cast<unsigned long long*>(&pred_aux->sp_fix), (unsigned long long)(long long)llrint(fmin(fmax(bp, -lim), lim) * kPredFix));
+        }
+    };
     // the norm the scan has just summed (a zero personalization divides by 1: every vector of the run is zero, the caller is told)
     if (norm_from != nullptr) in_norm = norm_from->in_norm != 0.0 ? (float)norm_from->in_norm : 1.f;
     if (seed_count != nullptr) {
         const int total = *seed_count;
         if (total <= kSeedListCap) {
-            pair_scatter(seed_list, total, v, ranks, iperm, scale, v_int, y0, xg, xg_blk, xg_live, in_norm, start_from_v, iso);
+            if (blockIdx.x * (int64_t)blockDim.x >= total) return;      // (workgroup-uniform)
+            pair_scatter(seed_list, total, v, ranks, iperm, scale, v_int, y0, xg, xg_blk, xg_live, in_norm, start_from_v, iso, pred_deg, pred_t, pred_p);
+            if (pred_deg != nullptr) pred_publish();
             return;
         }
     }
@@ -489,6 +512,10 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
             if (start_from_v) b[u] = a[u];
             v_int[i] = a[u];
             if (y0 != nullptr) y0[i] = b[u];
+            if (pred_deg != nullptr) {
+                pred_t += (double)pred_deg[i] * (double)b[u];
+                pred_p += (double)a[u];
+            }
             // an operand that is not zero on an isolated row: the run cannot pass over those rows
             if (iso.flag != nullptr && (a[u] != 0.f || b[u] != 0.f) && iso.holds(i)) atomicOr(iso.flag, 1);
             if (xg) {
@@ -497,6 +524,7 @@ __global__ void k_permute_in_pair(const float* __restrict__ v, const float* __re
             }
         }
     }
+    if (pred_deg != nullptr) pred_publish();
 }
 
 // dst[old] = src[iperm[old]] * factor
@@ -899,6 +927,7 @@ __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const fl
     if (state != nullptr && state->done) return;
     // the previous step's close, if the loop driver left it to this kernel (the LDS it uses is not yet in use)
     if (pc.active && run_pending_close(pc, reinterpret_cast<double*>(s_lds))) return;
+    if (pc.first_pred && blockIdx.x == 0 && threadIdx.x == 0) first_prediction(pc);      // read by the finish launch of this step
     PGH_STAMP_BEGIN(g_times_partial)
     bsf_partial_body<IPT, HAS_VAL, COLD, W16, DROP>(s_lds, f, xg, blockIdx.x, gridDim.x, dv);
 #if PGH_PROBE_TIMES
@@ -1007,8 +1036,8 @@ int bsf_launch_partial(pgh_graph_s* g, const float* xg, const LoopState* state, 
     const int main_grid = r.num_cus;                  // one workgroup per CU; a multiple of 8 (XCD-affine blocks)
     // the previous step's close rides in this launch when the loop driver deferred it (PendingClose, pgh_kernels.h)
     PendingClose pc = pending_close_slot();
-    if (stage == 2 || state == nullptr || pc.state != state) pc.active = 0;
-    else pending_close_slot().active = 0;             // consumed
+    if (stage == 2 || state == nullptr || pc.state != state) pc.active = 0, pc.first_pred = 0;
+    else pending_close_slot().active = 0, pending_close_slot().first_pred = 0;      // consumed
     if (stage != 2) {
         ProfScope prof(PGH_K_SPMV);
         const DropView dv = bsf_dropout_view(f.drop_edge);
@@ -1295,7 +1324,7 @@ bool bsf_can_bring_pair(const pgh_graph_s* g) {
     return f.enabled && f.relabelled && f.perm != nullptr && f.n_out == f.n_src_pad;
 }
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
-                   bool start_from_v, bool watch_iso, LoopState* init_state, LoopAux* init_aux, bool* state_inited) {
+                   bool start_from_v, bool watch_iso, LoopState* init_state, LoopAux* init_aux, bool* state_inited, const float* pred_deg) {
     if (state_inited != nullptr) *state_inited = false;
     BsfFormat& f = g->bsf;
     IsoTail iso = IsoTail{};
@@ -1329,10 +1358,13 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
         seed_count = count_now;
     }
     if (watching && !flag_cleared) PGH_HIP(hipMemsetAsync(f.iso_flag, 0, sizeof(int), rt().stream));
+    // (the sums of the first step's prediction need the closing launch of the scan to have cleared them)
+    const bool predicting = pred_deg != nullptr && init_aux != nullptr && seed_count != nullptr && init_state != nullptr;
     k_permute_in_pair<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(v, ranks, f.perm, f.src_scale, f.n_src_pad, v_int, y0,
                                                                           want_xg ? f.xg : nullptr, f.blk_size, f.xg_live, in_norm,
                                                                           start_from_v ? 1 : 0, iso, seed_count, f.seed_list, f.iperm,
-                                                                          norm_here ? init_aux : nullptr);
+                                                                          norm_here ? init_aux : nullptr, predicting ? pred_deg : nullptr,
+                                                                          predicting ? init_aux : nullptr);
     PGH_HIP(hipGetLastError());
     return 0;
 }

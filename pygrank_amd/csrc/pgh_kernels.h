@@ -74,7 +74,11 @@ struct LoopAux {
     double sum_p;         // sum of the (normalised) personalization
     double worst_miss;    // largest |inv - inv'| / |inv| seen by a checking close of this run (diagnostic)
     double in_norm;       // L1 norm of the caller's personalization when the run computed it itself (pgh_loop_cfg::in_norm < 0)
+    // what the way INTO the id space sums for the FIRST step's prediction (k_permute_in_pair: block sums added as 2^-40 fixed point,
+    // so that the order of the workgroups does not show): sum_j deg_j * x0_j and sum_j p_j of the normalised operands
+    long long t0_fix, sp_fix;
 };
+constexpr double kPredFix = 1099511627776.0;      // 2^40
 struct ResParams {
     const float*   x_prev;   // previous iterate (internal ids, un-normalised; its quotient is LoopState::scale)
     const float*   deg;      // row sums of M in internal ids
@@ -109,6 +113,7 @@ struct PendingClose {
     const double* part_d;
     const double* part_t;
     double        a, b;           // the step is y = a * scale * (M^T x) + b * p
+    int           first_pred;     // 1: no close to run, but the prediction of step 1 is made from LoopAux::t0_fix / sp_fix (first_prediction)
 };
 
 // The isolated tail of every column block of a square relabelled graph (BsfFormat::iso_begin): rows without entries that
@@ -498,6 +503,20 @@ __device__ __forceinline__ void close_commit(const PendingClose& pc, const Close
     }
 }
 
+// The prediction of the FIRST step (its residual inside the finish kernel too): sum(y_1) = a * scale_0 * sum_j deg_j x0_j
+// + b * sum(p), both sums made by the pass that brought the operands into the id space.  One thread of the first kernel of step 1
+// (a sum that does not fit the fixed point, or none: the prediction is garbage, the close's bound sees it and pauses).
+__device__ __forceinline__ void first_prediction(const PendingClose& pc) {
+    LoopAux* aux = pc.aux;
+    const double t0 = (double)aux->t0_fix / kPredFix, sp = (double)aux->sp_fix / kPredFix;
+    aux->sum_p = sp;
+    if (pc.use_quotient) {
+        const double raw = (double)(float)(pc.a * pc.state->scale) * t0 + (double)(float)pc.b * sp;
+        aux->pred_raw[1] = raw;
+        aux->pred_inv[1] = raw != 0.0 ? 1.0 / raw : 0.0;
+    }
+}
+
 // the deferred close (see PendingClose); returns true when the loop has ended or paused, i.e. the calling kernel must do
 // nothing.  s: LDS scratch of 16 doubles.
 __device__ __forceinline__ bool run_pending_close(const PendingClose& pc, double* s) {
@@ -642,7 +661,7 @@ int iso_flag_release(pgh_graph_s* g);
 // leaves it in init_aux->in_norm; init_state / init_aux: the loop state of the run is started by the same launches)
 int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_int, float* y0, bool want_xg, float in_norm,
                    bool start_from_v, bool watch_iso = false, LoopState* init_state = nullptr, LoopAux* init_aux = nullptr,
-                   bool* state_inited = nullptr);
+                   bool* state_inited = nullptr, const float* pred_deg = nullptr);
 bool bsf_can_norm_on_device(const pgh_graph_s* g);
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
 int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int);

@@ -1628,12 +1628,25 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     // written per run at scale 23; the rows a run passes over are read by nobody, see IsoTail)
     const float* x0 = nullptr;
     bool state_inited = false;                   // the scan pass of the operands starts the loop state as well
+    // PageRank with the L1 / Mabs rule on a graph with a cold image: the residual is evaluated inside the finish kernel
+    // against the predicted quotient (ResParams, pgh_kernels.h).  PGH_FUSED_RES=0 keeps the separate kernel.
+    // (a dropped matrix has other column sums every step: the quotient cannot be predicted from the degrees)
+    static const bool fuse_env = getenv("PGH_FUSED_RES") == nullptr || atoi(getenv("PGH_FUSED_RES")) != 0;
+    const bool overlap = g_side_stream != nullptr && sp.blocked;     // the row-major kernel applies its epilogue in place
+    bool fused = fuse_env && MODE == EPI_AXPBY && sp.blocked && g->bsf.pb.enabled && !overlap && pre_scale == nullptr && !dropping &&
+                 (cfg->err_kind == PGH_ERR_L1 || cfg->err_kind == PGH_ERR_MABS) && ep.v != nullptr;
+    if (fused) PGH_TRY(bsf_ensure_degrees(g));
+    // ... from the FIRST step on when the pass that brings the operands into the id space can sum what its prediction needs
+    // (first_prediction, pgh_kernels.h; PGH_FIRST_PRED=0: the first step's residual from the separate kernel, as in round 3)
+    static const bool first_env = getenv("PGH_FIRST_PRED") == nullptr || atoi(getenv("PGH_FIRST_PRED")) != 0;
+    bool first_pred = false;
     if (pair) {          // personalization, start vector and scaled gather vector in one pass over the permutation
         PGH_TRY(v_buf.alloc(n_int));
         PGH_TRY(y0.alloc(n_int));
         const bool alias = from_p && (MODE == EPI_AXPBY || MODE == EPI_ABSORB);
         PGH_TRY(bsf_bring_pair(g, ep.v, ranks->data, v_buf.p, alias ? nullptr : y0.p, scaled_gather, in_norm, from_p, watch_iso, g_state, g_aux,
-                               &state_inited));
+                               &state_inited, (fused && first_env) ? g->bsf.deg_int : nullptr));
+        first_pred = fused && first_env && state_inited;
         ep.v = v_buf.p;
         buf[0] = y0.p;
         if (alias) x0 = v_buf.p;
@@ -1687,22 +1700,13 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     const int batch = poll ? 1 : batch_for(g);
     const int window = window_for(g);
     if (poll) progress_reset();
-    const bool overlap = g_side_stream != nullptr && sp.blocked;     // the row-major kernel applies its epilogue in place
     // blocked layout: the close of step k rides in the first kernel of step k + 1 (PendingClose); PGH_DEFER_CLOSE=0 keeps
     // the separate launch
     static const bool defer_env = getenv("PGH_DEFER_CLOSE") == nullptr || atoi(getenv("PGH_DEFER_CLOSE")) != 0;
     const bool defer = defer_env && sp.blocked && !overlap;
-    // PageRank with the L1 / Mabs rule on a graph with a cold image: the residual is evaluated inside the finish kernel
-    // against the predicted quotient (ResParams, pgh_kernels.h) -- no residual launch from the second step on.
-    // PGH_FUSED_RES=0 keeps the separate kernel.
-    static const bool fuse_env = getenv("PGH_FUSED_RES") == nullptr || atoi(getenv("PGH_FUSED_RES")) != 0;
     // small graphs (a few thousand rows, no cold image): fix-ups, epilogue, residual and close are ONE launch of one workgroup
     // (k_small_tail, pgh_bsf.hip) -- two launches per iteration instead of four.  PGH_SMALL_TAIL=0 keeps the general sequence.
     const bool small_tail = (MODE == EPI_AXPBY || MODE == EPI_ABSORB) && sp.blocked && !overlap && bsf_small_tail_usable(g);
-    // (a dropped matrix has other column sums every step: the quotient cannot be predicted from the degrees)
-    bool fused = fuse_env && MODE == EPI_AXPBY && sp.blocked && g->bsf.pb.enabled && !overlap && pre_scale == nullptr && !dropping &&
-                 (cfg->err_kind == PGH_ERR_L1 || cfg->err_kind == PGH_ERR_MABS) && ep.v != nullptr;
-    if (fused) PGH_TRY(bsf_ensure_degrees(g));
     if (!state_inited) k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0, g_aux);
     pending_close_slot().active = 0;
     int count_seen = 0;   // partials per step (the same for every step of a run)
@@ -1723,7 +1727,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         pc.check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
         pc.err_kind = cfg->err_kind;
         pc.active = 1;
-        pc.res_mode = fused ? (k == 1 ? 2 : 1) : 0;
+        pc.res_mode = fused ? ((k == 1 && !first_pred) ? 2 : 1) : 0;
         pc.step = k;
         pc.aux = g_aux;
         pc.part_r = r.d_partials + 2 * kMaxPartials;
@@ -1758,8 +1762,18 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
             rp.part_d = r.d_partials + 3 * kMaxPartials;
             rp.part_t = r.d_partials + 4 * kMaxPartials;
             rp.step = k;
-            rp.first = k == 1 ? 1 : 0;
+            rp.first = (k == 1 && !first_pred) ? 1 : 0;
             pb_set_residual(&rp);                  // consumed by the finish launch of this step
+        }
+        if (k == 1 && first_pred) {              // made by the first kernel of this step, read by its finish launch
+            PendingClose fp{};
+            fp.state = g_state;
+            fp.aux = g_aux;
+            fp.a = ep.a;
+            fp.b = ep.b;
+            fp.use_quotient = cfg->use_quotient;
+            fp.first_pred = 1;
+            pending_close_slot() = fp;
         }
         const int rc_step = launch_step<MODE>(g, epk, use_xg ? g->bsf.xg : xin, g_state, &count, (overlap && k > 1) ? g_ev_closed : nullptr);
         if (fused) pb_set_residual(nullptr);     // consumed by the finish launch; never left armed behind a step that failed before it
@@ -1797,6 +1811,7 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     };
     int enq = 0;          // steps enqueued so far
     bool done = false, state_fetched = false;
+    res->flags |= (fused ? 2 : 0) | (first_pred ? 4 : 0);
     for (;;) {
         while (!done && enq < max_steps) {
             if (poll) {

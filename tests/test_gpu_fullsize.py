@@ -117,10 +117,31 @@ def test_cfg2_signed_personalization_hands_the_residual_back(big):
     assert ranker.convergence.iteration == want_iters
     assert _rel(got, want) <= 1e-6
     assert ranker.last_loop["flags"] & 1, ranker.last_loop          # the fusion paused once, the separate kernel took over
-    # ... and the next run of a non-negative personalization is fused again, unpaused
+    assert ranker.last_loop["spmv"] == want_iters - 1
+    # ... and the next run of a non-negative personalization is fused again, unpaused, from its FIRST step on (the pass that brings
+    # the operands into the id space sums what the first prediction needs: flags bits 1 and 2)
     q = big["seeds"](7)
     ranker.rank(big["adj"], q.copy())
-    assert ranker.last_loop["flags"] & 1 == 0
+    assert ranker.last_loop["flags"] & 7 == 6, ranker.last_loop
+
+
+def test_cfg2_first_step_prediction(big):
+    """The residual of the FIRST step inside the finish kernel: the quotient of step 1 is predicted from
+    sum(deg * x0) and sum(p), summed by the pass that brings the operands into the id space -- seed-set, dense and warm-started
+    runs stop where the oracle stops, unpaused, and the reference-default rule (Mabs 1e-6: ONE step at this size) with them."""
+    from oracle import ref_loops as orc
+    pg = big["pg"]
+    n = big["M"].shape[0]
+    dense = np.random.default_rng(5).random(n)
+    for p, kw, okw in ((big["seeds"](8), dict(error_type=pg.L1, tol=1e-6), dict(error_type="l1", tol=1e-6)),
+                       (dense, dict(error_type=pg.L1, tol=1e-5), dict(error_type="l1", tol=1e-5)),
+                       (big["seeds"](9), dict(), dict(error_type="mabs", tol=1e-6))):
+        ranker = pg.PageRank(alpha=0.85, max_iters=1000, **kw)
+        got = np.asarray(ranker.rank(big["adj"], p.copy()).np, dtype=np.float64)
+        want, want_iters = orc.pagerank(big["M"], p, alpha=0.85, max_iters=1000, **okw)
+        assert ranker.convergence.iteration == want_iters
+        assert _rel(got, want) <= 1e-6
+        assert ranker.last_loop["flags"] & 7 == 6, ranker.last_loop
 
 
 def test_cfg2_graph_dropout_device_loop(big):
