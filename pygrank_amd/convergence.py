@@ -47,8 +47,12 @@ class ConvergenceManager:
         else:
             previous, self.last_ranks = self.last_ranks, new_ranks
             stop = previous is not None and self._has_converged(previous, new_ranks)
-        self.elapsed_time = time() - self._start_time
+        self._stamp()
         return stop
+
+    def _stamp(self):
+        """elapsed_time = seconds since start(): refreshed by every has_converged call and at the exit of a device loop."""
+        self.elapsed_time = time() - self._start_time
 
     def _has_converged(self, prev_ranks, ranks):
         """The comparison itself: skipped on iterations that are not a multiple of end_modulo and in counting mode."""
@@ -62,7 +66,7 @@ class ConvergenceManager:
     # ---- device-loop plumbing ----------------------------------------------------------------------
     def device_error_kind(self):
         """PGH_ERR_* code when the stopping rule can be evaluated on the device, else None."""
-        if self.error_type == "iters":
+        if self._counts_only():
             return L.ERR_ITERS
         for cls, kind in ((Mabs, L.ERR_MABS), (L1, L.ERR_L1), (MaxDifference, L.ERR_LINF)):
             if self.error_type is cls:
@@ -72,7 +76,7 @@ class ConvergenceManager:
     def finish_device_loop(self, iterations, converged):
         """What has_converged leaves behind at loop exit, for a loop that ran on the device."""
         self.iteration = int(iterations)
-        self.elapsed_time = time() - self._start_time
+        self._stamp()
         ran_out = not converged and self.iteration >= self.max_iters
         if ran_out and not self._counts_only() and self.iter_exception is not None:
             raise self.iter_exception(self._out_of_iterations())
