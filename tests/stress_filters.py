@@ -27,6 +27,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=20)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
+    if os.environ.get("PGH_TEST_ENGINE") == "host":               # replay a seed on the host double (no GPU)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import host_double
+        host_double.install()
     pg.load_backend("hip")
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
@@ -54,8 +58,11 @@ def main():
             p = 0.1 + rng.random(n)
         elif shape < 0.35 and norm == "col":                       # negative entries: the in-kernel residual must hand the decision back
             p[rng.integers(0, n, min(n, 3))] = -0.3
-            if abs(p.sum()) < 0.2:
-                p[int(np.argmax(p))] += 1.0
+            # (the L1 quotient divides by sum(y) = alpha * sum(M^T x) + (1 - alpha) * sum(p / |p|_1): a personalization whose sum is
+            # negative enough makes that ZERO in exact arithmetic -- p = (-0.3, -0.3) at alpha = 0.5 -- and every evaluation garbage,
+            # the reference's included; the draws keep sum(p) >= 0.3 |p|_1)
+            if p.sum() < 0.3 * np.abs(p).sum():
+                p[int(np.argmax(p))] += 1.0 + np.abs(p).sum()
         desc = f"#{done} n={n} nnz={A.nnz} norm={norm} p={'dense' if shape < 0.15 else ('signed' if shape < 0.35 and norm == 'col' else 'seeds')} " \
             + " ".join(f"{k}={os.environ[k]}" for k in ("PGH_BLOCKS", "PGH_RELABEL", "PGH_PB", "PGH_TRIM"))
         which = int(rng.integers(0, 6))
@@ -165,7 +172,8 @@ def main():
         try:
             got = np.asarray(ranker.rank(adj, p.copy()).np)
         except Exception as exc:                                   # non-convergence must agree with the oracle too
-            print("EXCEPTION", desc, type(ranker).__name__, exc, flush=True)
+            print("EXCEPTION", desc, type(ranker).__name__, exc, "oracle:", it, "A:", A.toarray().tolist() if n <= 4 else "", "p:", p.tolist() if n <= 4 else "",
+                  {k: v for k, v in vars(ranker).items() if k in ("alpha", "use_quotient")}, vars(ranker.convergence).get("tol"), flush=True)
             sys.exit(1)
         its = ranker.convergence.iteration
         tolerance_based = which in (0, 1)

@@ -173,7 +173,10 @@ def main():
                 top = float(np.max(np.abs(want)))
                 if top > 0:
                     err = float(np.max(np.abs(got - want))) / top
-                    assert err <= 2e-6, (what, err)            # (tests/stress_filters.py holds random cases to the same bound)
+                    # (tests/stress_filters.py holds random cases to the same bound; a signed personalization loses digits to
+                    # cancellation in ANY f32 evaluation -- the host double, an independent f32 implementation, misses the oracle by
+                    # 2.7e-6 where the engine misses it by 2.6e-6, seed 24 case 2395 -- so those are held to 6e-6)
+                    assert err <= (6e-6 if shape == 3 else 2e-6), (what, err)
                 else:
                     assert not np.any(got), what
         except AssertionError:
