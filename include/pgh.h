@@ -230,7 +230,9 @@ typedef struct {
     int32_t flags;          /* bit 0: the in-kernel residual paused once and the run went on with the separate residual kernel;
                                bit 1: the run evaluated its residual inside the finish kernel; bit 2: from the first step on */
     double  last_error;     /* residual of the last executed check                                */
-    double  loop_ms;        /* HIP-event time of the loop on the engine stream                    */
+    double  loop_ms;        /* HIP-event time of the loop on the engine stream (the way out of the engine's id space that follows
+                               is not in it and may still be RUNNING when the call returns: engine calls are ordered on the engine's
+                               stream and transfers to the host synchronise; pgh_sync() before a raw pointer is used elsewhere) */
     double  in_norm;        /* the L1 norm of the personalization when the run computed it (cfg in_norm < 0), else 0 */
 } pgh_loop_result;
 

@@ -1877,13 +1877,16 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     if (norm_wanted) res->in_norm = norm_used;
     const double factor = g_state_host->scale * (cfg->out_scale < 0.0 ? norm_used : cfg->out_scale);
     const float* final_buf = (steps == 0 && x0 != nullptr) ? x0 : buf[steps & 1];
+    // the loop is over and its state is on the host: the clock stops here, and the way out of the id space is left RUNNING when this
+    // call returns (every engine call is ordered behind it on the engine's stream; transfers to the host synchronise) -- the caller's
+    // host work between two runs, 25-35 us of Python per rank(), overlaps with it instead of following it
+    PGH_TRY(timer.stop(&res->loop_ms));
     if (sp.blocked) {
         PGH_TRY(bsf_to_original(g, final_buf, ranks->data, factor));
     } else if (n > 0 && (final_buf != ranks->data || factor != 1.0)) {
         k_scale_copy<<<residual_grid(n), WG, 0, r.stream>>>(final_buf, ranks->data, n, factor);
     }
     PGH_HIP(hipGetLastError());
-    PGH_TRY(timer.stop(&res->loop_ms));
     res->iterations = steps + 1;                 // ConvergenceManager.iteration at loop exit
     res->converged = g_state_host->converged;
     res->spmv_count = steps;
@@ -2102,10 +2105,10 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
         err = g_state_host->steps > 0 ? g_state_host->err : err;
         it = 2 + spmv;
     }
+    PGH_TRY(timer.stop(&res->loop_ms));           // (as in recursive_run: the way out is left running)
     if (blocked) PGH_TRY(bsf64_take(g, res64.p, cfg->out_scale, result->data));
     else if (n > 0) k_f64_to_f32<<<cgrid, WG, 0, r.stream>>>(res64.p, result->data, n, cfg->out_scale);
     PGH_HIP(hipGetLastError());
-    PGH_TRY(timer.stop(&res->loop_ms));
     res->iterations = it;
     res->converged = converged ? 1 : 0;
     res->spmv_count = spmv;
@@ -2364,13 +2367,13 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
         err = g_state_host->steps > 0 ? g_state_host->err : err;
         it = 2 + spmv;                 // iteration value at loop exit
     }
+    PGH_TRY(timer.stop(&res->loop_ms));           // (as in recursive_run: the way out is left running)
     if (sp.blocked) {
         PGH_TRY(bsf_to_original(g, result_int, result->data, cfg->out_scale));
     } else if (n > 0 && cfg->out_scale != 1.0) {
         k_scale_copy<<<residual_grid(n), WG, 0, r.stream>>>(result->data, result->data, n, cfg->out_scale);
     }
     PGH_HIP(hipGetLastError());
-    PGH_TRY(timer.stop(&res->loop_ms));
     res->iterations = it;
     res->converged = converged ? 1 : 0;
     res->spmv_count = spmv;
