@@ -357,8 +357,10 @@ constexpr int kSeedListCap = 1 << 16;
 
 __global__ void k_pair_scan(const float* __restrict__ v, const float* __restrict__ ranks, int64_t n_orig, int64_t n_pad, int64_t xg_len,
                             float* __restrict__ v_int, float* __restrict__ y0, float* __restrict__ xg, int32_t* __restrict__ list,
-                            int* __restrict__ count, double* __restrict__ norm_partials) {
+                            int* __restrict__ count, double* __restrict__ norm_partials, LoopAux* __restrict__ stamp) {
     __shared__ double s_red[4];
+    // the run's first kernel: its start on the device's clock (LoopAux::t_begin; the closing launch leaves the field alone)
+    if (stamp != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamp->t_begin = __builtin_amdgcn_s_memrealtime();
     double abs_sum = 0.0;                        // this thread's share of sum |v| (GraphFilter.rank's norm, abstract_filters.py:52)
     const int64_t span = n_pad > xg_len ? n_pad : xg_len;
     // four ids per thread and round, their loads issued together (one id per round left every load alone in flight: the scan took
@@ -1351,7 +1353,7 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
         const int scan_grid = blocks_for(span);         // <= 16 workgroups per CU: within kMaxPartials
         double* norm_partials = norm_here ? rt().d_partials : nullptr;     // (no step is in flight: the region is free)
         k_pair_scan<<<scan_grid, kBlock, 0, rt().stream>>>(v, start_from_v ? nullptr : ranks, f.n_out_orig, f.n_src_pad, xg_len, v_int, y0,
-                                                           want_xg ? f.xg : nullptr, f.seed_list, count_now, norm_partials);
+                                                           want_xg ? f.xg : nullptr, f.seed_list, count_now, norm_partials, init_aux);
         k_scan_close<<<1, kBlock, 0, rt().stream>>>(norm_partials, scan_grid, init_state, init_aux, watching ? f.iso_flag : nullptr, count_next);
         flag_cleared = watching;
         if (state_inited != nullptr && init_state != nullptr) *state_inited = true;

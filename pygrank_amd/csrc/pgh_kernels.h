@@ -77,6 +77,7 @@ struct LoopAux {
     // what the way INTO the id space sums for the FIRST step's prediction (k_permute_in_pair: block sums added as 2^-40 fixed point,
     // so that the order of the workgroups does not show): sum_j deg_j * x0_j and sum_j p_j of the normalised operands
     long long t0_fix, sp_fix;
+    unsigned long long t_begin;   // the device's constant-rate clock (s_memrealtime) when the run's first kernel started: loop_ms without events
 };
 constexpr double kPredFix = 1099511627776.0;      // 2^40
 struct ResParams {
@@ -113,6 +114,7 @@ struct PendingClose {
     const double* part_d;
     const double* part_t;
     double        a, b;           // the step is y = a * scale * (M^T x) + b * p
+    unsigned long long tag;       // this run's number: part of the checksum of the state a close publishes (a stale block never fits)
     int           first_pred;     // 1: no close to run, but the prediction of step 1 is made from LoopAux::t0_fix / sp_fix (first_prediction)
 };
 
@@ -469,6 +471,30 @@ __device__ __forceinline__ CloseOutcome close_outcome(const PendingClose& pc, do
     }
     return o;
 }
+// What the host reads at the END of a run without copying the state back (pgh_spmv.hip::published_state): the closes of a loop leave
+// {scale, err, in_norm, steps | done | converged, device ticks since the run's first kernel} and a checksum of the five with the run's
+// number, beside the progress words (bytes 16-63 of the same pinned, mapped 64 bytes).  Relaxed stores: the host accepts the words only
+// when the checksum fits them and this run, and the progress words agree.
+constexpr unsigned long long kPublishMagic = 0x9e3779b97f4a7c15ULL;
+__host__ __device__ __forceinline__ unsigned long long publish_checksum(unsigned long long a, unsigned long long b, unsigned long long c,
+                                                                        unsigned long long d, unsigned long long e, unsigned long long tag) {
+    return a ^ ((b << 1) | (b >> 63)) ^ ((c << 2) | (c >> 62)) ^ ((d << 3) | (d >> 61)) ^ ((e << 4) | (e >> 60)) ^ (tag * kPublishMagic);
+}
+__device__ __forceinline__ void publish_state(int* progress, const LoopState* st, const LoopAux* aux, unsigned long long tag) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(progress) + 2;
+    const unsigned long long a = (unsigned long long)__double_as_longlong(st->scale), b = (unsigned long long)__double_as_longlong(st->err),
+                             c = (unsigned long long)__double_as_longlong(aux != nullptr ? aux->in_norm : 0.0),
+                             d = ((unsigned long long)(unsigned)st->steps << 32) | ((unsigned long long)(unsigned)(st->done & 0xff) << 8) |
+                                 (unsigned long long)(unsigned)(st->converged & 0xff),
+                             e = aux != nullptr ? __builtin_amdgcn_s_memrealtime() - aux->t_begin : 0ULL;
+    __hip_atomic_store(w + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 3, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 4, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 5, publish_checksum(a, b, c, d, e, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // the state update of a close (one thread)
 __device__ __forceinline__ void close_commit(const PendingClose& pc, const CloseOutcome& o) {
     LoopState* state = pc.state;
@@ -498,6 +524,7 @@ __device__ __forceinline__ void close_commit(const PendingClose& pc, const Close
     // (relaxed stores: the host only PACES itself by these words and reads every result after a stream synchronisation; a
     // system-scope release here is a write-back of the XCD's whole L2 in the middle of the launch that carries the close)
     if (pc.progress != nullptr) {        // host-visible progress word (pinned, mapped): lets the host run ahead without syncs
+        if (pc.tag != 0ULL) publish_state(pc.progress, state, pc.aux, pc.tag);
         __hip_atomic_store(pc.progress + 1, o.verdict == 1 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(pc.progress, steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
