@@ -751,12 +751,11 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     if (const char* v = getenv("PGH_PB_HUBMAX")) hub_max = std::max(8, atoi(v));
     plan->heavy_row = heavy_row;
     std::vector<int4> split;               // {row, first bin, pieces, -} of every row with more than one hub bin
-    auto lay_out = [&](int bin_rows) {
+    auto lay_out = [&](int bin_rows, int bin_fill) {
         bins.clear();
         split.clear();
         cold = in_image = 0;
         heavy_rows = false;
-        static const int bin_fill = getenv("PGH_PB_BINFILL") != nullptr ? std::max(1, atoi(getenv("PGH_PB_BINFILL"))) : kPbBinFill;
         const int64_t bin_entries = (int64_t)bin_fill * bin_rows;
         int row0 = 0, rows = 0;
         int64_t fill = 0, largest = 0;     // cold entries of the open bin, and of its largest row
@@ -797,12 +796,23 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     };
     int bin_rows = kPbBinRows;
     if (const char* shape = getenv("PGH_PB_BINROWS")) bin_rows = atoi(shape) > kPbBinRows ? kPbBinRowsLarge : kPbBinRows;   // diagnostic
-    lay_out(bin_rows);
+    const char* fill_env = getenv("PGH_PB_BINFILL");
+    int bin_fill = fill_env != nullptr ? std::max(1, atoi(fill_env)) : kPbBinFill;
+    auto mean_run = [&]() { return (double)in_image / ((double)chunks * (double)std::max<size_t>(bins.size(), 1)); };
+    lay_out(bin_rows, bin_fill);
+    // Fuller bins where the (chunk, bin) runs are short (round 4, profiles/r04/pb_large_graphs.log): twice the entries per bin = half
+    // the bins = runs twice as long.  Same-box sweeps of the fill, GTEPS: scale 23 (146 entries per run at fill 6) 562 / 544 / 554 for
+    // 6 / 9 / 12 -- stays 6; scale 24 (82) 510 / 512 / 517 / 517 for 6 / 9 / 12 / 16; scale 25 (46) 408 / 458 / 449 / 464 / 443 for
+    // 6 / 9 / 12 / 16 / 24; the slices of the 2 / 4 / 8-GPU bench 265 -> 243, 292 -> 279, 421 -> 403 us per step for 6 -> 12.
+    if (fill_env == nullptr && mean_run() < 100.0) {
+        bin_fill = 2 * kPbBinFill;
+        lay_out(bin_rows, bin_fill);
+    }
     // measured (profiles/r01/partition_slices_pb.log, pb_large_graphs.log): at 55 entries per run the small shape is 3 %
     // faster (scale 24), at 31 it is 3 % faster on a partitioned slice but 7 % slower at scale 25, at 14 it does not pay
-    if ((double)in_image / ((double)chunks * (double)std::max<size_t>(bins.size(), 1)) < 40.0 && kPbBinRowsLarge > bin_rows && getenv("PGH_PB_BINROWS") == nullptr) {
+    if (mean_run() < 40.0 && kPbBinRowsLarge > bin_rows && getenv("PGH_PB_BINROWS") == nullptr) {
         bin_rows = kPbBinRowsLarge;              // short runs: fewer, larger bins
-        lay_out(bin_rows);
+        lay_out(bin_rows, bin_fill);
     }
     plan->bin_rows = bin_rows;
     const int64_t num_bins = (int64_t)bins.size();
