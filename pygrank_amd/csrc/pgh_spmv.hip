@@ -1883,7 +1883,9 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
         // the step it was closing is complete but for its residual -- evaluate that with the separate kernel, close the step
         // the plain way and go on without the fusion
         if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
-        PGH_TRY(flush_pending_close());
+        // (the loop is known to be over: the record still waiting belongs to a step that did nothing -- its launch would return at once)
+        if (done) pending_close_slot().active = 0;
+        else PGH_TRY(flush_pending_close());
         if (!(poll && published_state(enq, run_tag, &published_ms))) PGH_TRY(fetch_state());
         state_fetched = true;                        // nothing is enqueued between here and the end of the run
         if (g_state_host->done != 2) break;
@@ -1913,7 +1915,8 @@ int recursive_run(pgh_graph_t g, EpiParams ep, pgh_vec_t ranks, const pgh_loop_c
     }
     if (!state_fetched) {
         if (overlap && enq > 0) PGH_HIP(hipStreamWaitEvent(r.stream, g_ev_closed, 0));
-        PGH_TRY(flush_pending_close());              // a no-op once the loop has ended on the device
+        if (done) pending_close_slot().active = 0;   // (as above)
+        else PGH_TRY(flush_pending_close());
         if (!(poll && published_state(enq, run_tag, &published_ms))) PGH_TRY(fetch_state());
     }
     const int steps = g_state_host->steps;

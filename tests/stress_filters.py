@@ -102,6 +102,7 @@ def main():
             ranker = pg.PageRank(kw["alpha"], use_quotient=kw["use_quotient"], error_type={"l1": pg.L1, "mabs": pg.Mabs, "linf": pg.MaxDifference}[err],
                                  tol=tol, max_iters=300)
             same_steps = lambda k: orc.pagerank(M, p, error_type="iters", max_iters=k, eps=EPS32, **kw)[0]   # noqa: E731
+            at_tol = lambda f: orc.pagerank(M, p, error_type=err, tol=tol * f, max_iters=300, eps=EPS32, **kw)[1]   # noqa: E731
             try:
                 want, it = orc.pagerank(M, p, error_type=err, tol=tol, max_iters=300, eps=EPS32, **kw)
             except Exception:                                      # does not converge in 300 iterations: the engine must say so too
@@ -115,6 +116,7 @@ def main():
         elif which == 1:
             ranker = pg.AbsorbingWalks(0.85, error_type=pg.L1, tol=1e-6, max_iters=300)
             same_steps = lambda k: orc.absorbing_walks(M, p, alpha=0.85, error_type="iters", max_iters=k, eps=EPS32)[0]   # noqa: E731
+            at_tol = lambda f: orc.absorbing_walks(M, p, alpha=0.85, error_type="l1", tol=1e-6 * f, max_iters=300, eps=EPS32)[1]   # noqa: E731
             try:
                 want, it = orc.absorbing_walks(M, p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=300, eps=EPS32)
             except Exception:
@@ -184,12 +186,32 @@ def main():
         slack = max(1, it // 25)
         # a residual within f32 rounding of the tolerance may stop an iteration apart: the result is then compared with the
         # oracle stopped after the engine's number of steps
+        if tolerance_based and abs(its - it) > slack:
+            # a residual that is NOT monotone (alpha = 0.99 on a near-bipartite graph: seed 51 #4476 dips to 0.99984e-6 at step 136 in
+            # f64, 1.0058e-6 in f32, and next falls below the tolerance ten steps later) stops wherever its rounding puts the dip: the
+            # engine's count must then be the oracle's at a tolerance 3 % tighter or looser
+            try:
+                near = sorted((at_tol(0.97), at_tol(1.03)))
+            except Exception:
+                near = [it, it]
+            if near[0] - 1 <= its <= near[1] + 1:
+                slack = abs(its - it)
         if tolerance_based and its != it and abs(its - it) <= slack:
             want = same_steps(its)
         rel = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-30)
+        if os.environ.get("PGH_STRESS_TRACE") and its != it:
+            print("NOTE", desc, type(ranker).__name__, {k: v for k, v in vars(ranker).items() if k in ("alpha", "use_quotient")},
+                  getattr(ranker.convergence, "tol", None), getattr(ranker.convergence.error_type, "__name__", ranker.convergence.error_type),
+                  "iterations", its, it, "rel", rel, flush=True)
         bound = 4e-6 if which == 3 else 2e-6                        # chebyshev: parity_common.py
         if rel > bound or (tolerance_based and abs(its - it) > slack) or (not tolerance_based and its != it):
-            print("MISMATCH", type(ranker).__name__, desc, "rel", rel, "iterations", its, it, flush=True)
+            print("MISMATCH", type(ranker).__name__, desc, "rel", rel, "iterations", its, it,
+                  {k: v for k, v in vars(ranker).items() if k in ("alpha", "use_quotient", "t", "coefficient_type")},
+                  getattr(ranker.convergence, "tol", None), getattr(ranker.convergence.error_type, "__name__", ranker.convergence.error_type), flush=True)
+            if os.environ.get("PGH_STRESS_DUMP"):                  # the case as data: replayed offline (tools/scratch)
+                coo = sp.coo_array(A)
+                np.savez(os.path.join(os.environ["PGH_STRESS_DUMP"], "case_data.npz"), row=coo.row, col=coo.col, val=coo.data, n=n, p=p, got=got,
+                         want=want, its=its, it=it, norm=norm)
             sys.exit(1)
         done += 1
     print(f"filters stress ok: {done} runs in {args.seconds:.0f} s (seed {args.seed})", flush=True)
