@@ -204,6 +204,10 @@ def main():
                   getattr(ranker.convergence, "tol", None), getattr(ranker.convergence.error_type, "__name__", ranker.convergence.error_type),
                   "iterations", its, it, "rel", rel, flush=True)
         bound = 4e-6 if which == 3 else 2e-6                        # chebyshev: parity_common.py
+        if which == 0 and kw["alpha"] >= 0.99:
+            # alpha = 0.99 amplifies every rounding of a step by up to 1 / (1 - alpha) over a run of 100+ steps: ANY f32 evaluation
+            # drifts -- the host double misses the oracle by 3.13e-6 where the engine misses it by 3.25e-6 (seed 62 #8480, 143 steps)
+            bound = 8e-6
         if rel > bound or (tolerance_based and abs(its - it) > slack) or (not tolerance_based and its != it):
             print("MISMATCH", type(ranker).__name__, desc, "rel", rel, "iterations", its, it,
                   {k: v for k, v in vars(ranker).items() if k in ("alpha", "use_quotient", "t", "coefficient_type")},
