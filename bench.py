@@ -286,6 +286,24 @@ def single_gpu(args):
             del feats
         except Exception as exc:                     # a side measurement never takes the headline down
             secondary["ppr_l1_1e-6_batch_of_64_seeds"] = dict(error=str(exc))
+        # real-valued edge weights (nx ... weight="weight", preprocessing.py:103): the same structure with weights in [0.1, 1.1),
+        # "col" normalisation on the device -> the VALUED stream (2-byte index + f32 value per entry); nominal bytes as the headline
+        if not args.no_weighted:
+            try:
+                import scipy.sparse as sp
+                MTw = g.download_transposed()
+                MTw = sp.csr_array((np.random.default_rng(7).random(MTw.nnz) + 0.1, MTw.indices, MTw.indptr), shape=MTw.shape)
+                Ww = sp.csr_array(MTw.T)
+                Ww.sort_indices()
+                del MTw
+                wadj = pg.preprocessor(normalization="col", assume_immutability=True)(pg.AdjacencyWrapper(Ww, directed=True))
+                del Ww
+                side("ppr_l1_1e-6_real_weights", pg.PageRank(alpha=ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS), wadj, alg_bytes, nnz,
+                     signals=[pg.to_signal(wadj, sig.np) for sig in personalizations[:3]])
+                secondary["ppr_l1_1e-6_real_weights"]["format"] = wadj.array.format().split(",")[2].strip()
+                del wadj
+            except Exception as exc:
+                secondary["ppr_l1_1e-6_real_weights"] = dict(error=str(exc)[:300])
         if not args.no_symmetric:
             sym = rmat_graph(scale, ef, seed=0, symmetrize=True, **RMAT)          # A + A^T, "symmetric" normalisation
             nnz_s = sym.array.nnz
@@ -473,6 +491,12 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
     if world > 1 and not getattr(args, "no_same_graph", False):
         same_graph = _same_graph_leg(dist, rank, world, pg, ranker, personalizations[total - 1], scale, ef, rmat, alpha, tol,
                                      max_iters, num_seeds, total, use_cuda, nnz_total * spmv_total / elapsed / 1e9)
+    # ---- configs[2] across the ranks as a REPLICA SPLIT (last sentence): every rank holds the whole scale-23 graph
+    # and runs 64 of the 64 x N seed sets; nothing is exchanged.  Last of all: every rank gives its slice up first.
+    replicas = None
+    if not args.no_secondary:
+        replicas = _replica_batch_leg(dist, rank, world, pg, ranker, min(scale, 23), 16 if scale >= 23 else ef, rmat, alpha, tol, max_iters,
+                                      use_cuda)
     if rank != 0:
         return None
     return dict(
@@ -491,7 +515,7 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
                       frac=round(achieved / hbm_peak, 4) if achieved else None, traffic=None,
                       algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(step_us, 2), format=graph_format,
                       kernels_avg_us=prof),
-        cpu_baseline=cpu, parity=parity, same_graph_1gpu=same_graph)
+        cpu_baseline=cpu, parity=parity, same_graph_1gpu=same_graph, secondary=dict(batch_of_64_seeds_replicas=replicas))
 
 
 def _probe_verdict(world, rank):
@@ -607,6 +631,63 @@ def _same_graph_leg(dist, rank, world, pg, ranker, p_last, scale, ef, rmat, alph
     return result
 
 
+def _replica_batch_leg(dist, rank, world, pg, ranker, scale, ef, rmat, alpha, tol, max_iters, use_cuda):
+    """NodeRanking.propagate (pygrank/core/signals.py:225-226) of 64 x N seed sets, 64 per rank, every rank on its own copy of
+    the whole graph (pygrank_amd.distributed.ReplicatedPropagation; zero communication).  Whole-job edge-vector products per
+    second over the slowest rank's time.  A failure is reported on the line, it never takes the headline down."""
+    import torch
+    result = None
+    try:
+        import gc
+        import pygrank_amd as pgm
+        from pygrank_amd import _lib as L
+        from pygrank_amd.device import DeviceMatrix
+        from pygrank_amd.distributed import ReplicatedPropagation, release_native_comms
+        from pygrank_amd.synthetic import rmat_graph
+        ranker._buffers = None
+        ranker._buffers_for = None
+        release_native_comms()
+        if pg.graph._h is not None:
+            pg.graph.destroy()
+        gc.collect()
+        if use_cuda:
+            torch.cuda.empty_cache()
+        pgm.load_backend("hip")
+        adj = rmat_graph(scale, ef, seed=0, normalization="col", **rmat)
+        g = adj.array
+        n, nnz = g.shape[0], g.nnz
+        candidates = np.flatnonzero(np.asarray(pgm.degrees(g)) > 0)
+        per_rank = 64 if scale >= 16 else 4                       # (CPU tests of the contract run a scale-11 graph on the host double)
+        width = per_rank * world
+        feats = DeviceMatrix.empty(n, width)                      # the same [n, 64 N] feature matrix on every rank
+        for j in range(width):
+            col = np.zeros(n)
+            col[seeds_for(100 + j, candidates)] = 1.0
+            feats.set_column(j, pgm.to_signal(adj, col).np)
+        split = ReplicatedPropagation(pgm.PageRank(alpha=alpha, error_type=pgm.L1, tol=tol, max_iters=max_iters))
+        split.propagate(adj, feats, gather=False)                 # warm-up: builds the multi-seed image
+        dist.barrier()
+        t0 = time.perf_counter()
+        split.propagate(adj, feats, gather=False)
+        L.check(L.lib().pgh_sync())
+        dt = time.perf_counter() - t0
+        info = split.last_batches[0]
+        t = torch.tensor([dt, float(sum(c["spmv"] for c in info))], dtype=torch.float64, device=_device_of(use_cuda))
+        worst = t.clone()
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        steps = max(c["spmv"] for c in info)
+        result = dict(edge_vector_products_per_s_G=round(nnz * float(t[1].item()) / float(worst[0].item()) / 1e9, 1),
+                      seed_sets=width, seed_sets_per_rank=per_rank, ranks=world, slowest_rank_ms=round(float(worst[0].item()) * 1e3, 2),
+                      rank0_device_step_us=round(info[0]["loop_ms"] / steps * 1e3, 1), rank0_columns=list(split.columns),
+                      workload=f"64 x {world} seed sets on RMAT scale-{scale} ef-{ef}, one whole-graph replica per rank, no exchange")
+        del feats, adj
+    except Exception as exc:
+        result = dict(error=str(exc)[:300])
+    dist.barrier()
+    return result
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process tree (torch.distributed.run, one
     rank per GPU) and relay rank 0's JSON line.  This parent has not touched the GPU (no HIP call, no torch.cuda query) and
@@ -647,6 +728,7 @@ def main():
     ap.add_argument("--ef", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements (other stopping rules / filters)")
+    ap.add_argument("--no-weighted", action="store_true", help="skip the real-valued-weights side measurement")
     ap.add_argument("--no-symmetric", action="store_true", help="skip the symmetrised-graph side measurement")
     ap.add_argument("--no-same-graph", action="store_true", help="N > 1: skip the single-GPU run of the same graph on rank 0")
     ap.add_argument("--force-partitioned", action="store_true", help="run the row-partitioned path even with one rank")

@@ -860,6 +860,100 @@ class DistributedPageRankClosed(DistributedClosedFormFilter):
         self.alpha = alpha
 
 
+def replica_columns(width, rank, world):
+    """Rank `rank`'s contiguous share [lo, hi) of `width` feature columns; the shares differ by at most one column."""
+    return width * rank // world, width * (rank + 1) // world
+
+
+class _DeviceMemoryView:
+    """Engine-owned device memory seen through the CUDA array interface (what torch.as_tensor wraps without a copy)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = dict(shape=tuple(int(s) for s in shape), typestr="<f4", data=(int(ptr), False), version=2)
+
+
+class ReplicatedPropagation:
+    """NodeRanking.propagate (pygrank/core/signals.py:225-226) across the GPUs of a node as a REPLICA SPLIT (last
+    sentence: "cfg3-style batches can alternatively be split across GPUs with zero communication").  Every rank holds the whole
+    graph (the scale-23 bench graph is 1 GB of images in 288 GB of HBM) and the same feature matrix; rank r runs the columns
+    [r * B / P, (r + 1) * B / P) through `ranker.propagate` -- the single-GPU multi-seed loop (pgh_ppr_run_batch: every column keeps
+    its own quotient, residual and stopping iteration) -- and nothing is exchanged until the result slabs are, optionally,
+    all-gathered at the end.  `ranker` is any filter of pygrank_amd with a `propagate` (PageRank takes the batched route)."""
+
+    def __init__(self, ranker):
+        self.ranker = ranker
+        self.columns, self.last_batches, self.elapsed = (0, 0), [], None
+
+    def propagate(self, graph, features, *args, gather=True, **kwargs):
+        """features: [n, B] (DeviceMatrix, array or list of columns), the same on every rank.  Returns the [n, B] ranks on every
+        rank (gather=True: one all-gather of the result slabs) or this rank's [n, hi - lo] share (gather=False; `self.columns`)."""
+        import torch
+        import torch.distributed as dist
+        from pygrank_amd import backend
+        from pygrank_amd.device import DeviceMatrix
+        world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+        F = features if isinstance(features, DeviceMatrix) else backend.to_primitive(features)
+        if not isinstance(F, DeviceMatrix):
+            F = DeviceMatrix.from_columns(list(F) if isinstance(F, (list, tuple)) else [F])
+        lo, hi = replica_columns(F.b, rank, world)
+        self.columns = (lo, hi)
+        t0 = time.perf_counter()
+        mine = None
+        if hi > lo:
+            share = F if (lo, hi) == (0, F.b) else F.get_cols(lo, hi - lo)
+            mine = self.ranker.propagate(graph, share, *args, **kwargs)
+            if not isinstance(mine, DeviceMatrix):          # the per-column fallback of NodeRanking.propagate returns signals
+                mine = DeviceMatrix.from_columns([backend.to_primitive(getattr(col, "np", col)) for col in mine])
+            self.last_batches = getattr(self.ranker, "last_batches", [])
+        L.check(L.lib().pgh_sync())
+        self.elapsed = time.perf_counter() - t0
+        if not gather or (world == 1 and os.environ.get("PGH_REPLICA_GATHER_ALONE", "0") != "1"):     # (=1: tests run the all-gather with one rank)
+            return mine
+        return self._all_gather(F.n, F.b, mine, rank, world, dist, torch)
+
+    def _all_gather(self, n, width, mine, rank, world, dist, torch):
+        """Every rank's share -> the [n, width] slab on every rank.  Shares are padded to the widest one (equal counts per rank,
+        ncclAllGather's contract); over RCCL the slabs travel device to device, with gloo (CPU tests, ranks sharing a GPU) through
+        host memory."""
+        from pygrank_amd.device import DeviceMatrix
+        shares = [replica_columns(width, r, world) for r in range(world)]
+        wmax = max(hi - lo for lo, hi in shares)
+        out = DeviceMatrix.empty(n, width)
+        lib = L.lib()
+        on_device = dist.get_backend() == "nccl" and torch.cuda.is_available() and L.runtime_name().startswith("hip:")
+        if on_device:
+            device = torch.device("cuda", torch.cuda.current_device())
+            recv = torch.zeros((world, n, wmax), dtype=torch.float32, device=device)
+            try:
+                if mine is not None:
+                    view = torch.as_tensor(_DeviceMemoryView(lib.pgh_mat_ptr(mine._h), (n, mine.b)), device=device)
+                    recv[rank, :, :mine.b].copy_(view)
+                dist.all_gather_into_tensor(recv.view(-1), recv[rank].reshape(-1).clone())
+                whole = torch.as_tensor(_DeviceMemoryView(lib.pgh_mat_ptr(out._h), (n, width)), device=device)
+                for r, (lo, hi) in enumerate(shares):
+                    if hi > lo:
+                        whole[:, lo:hi].copy_(recv[r, :, :hi - lo])
+                torch.cuda.synchronize(device)
+                return out
+            except (TypeError, RuntimeError, AttributeError) as exc:      # no zero-copy view on this torch build: through the host
+                sys.stderr.write(f"[pygrank_amd.distributed] replica all-gather on the device failed ({str(exc)[:120]}); staging through the host\n")
+        send = torch.zeros((n, wmax), dtype=torch.float32)
+        if mine is not None:
+            send[:, :mine.b] = torch.from_numpy(mine.numpy().astype(np.float32))
+        recv = torch.zeros((world, n, wmax), dtype=torch.float32)
+        if on_device:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            recv_d = recv.to(dev)
+            dist.all_gather_into_tensor(recv_d.view(-1), send.to(dev).view(-1))
+            recv = recv_d.cpu()
+        else:
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+        full = np.empty((n, width), dtype=np.float64)
+        for r, (lo, hi) in enumerate(shares):
+            full[:, lo:hi] = recv[r, :, :hi - lo].numpy()
+        return DeviceMatrix.from_host(full)
+
+
 class _NullCtx:
     def __enter__(self):
         return None

@@ -80,6 +80,10 @@ def test_bench_launcherless_spawns_its_ranks(oracle_build_dir):
     same = out["same_graph_1gpu"]
     assert same["rel_linf_partitioned_vs_1gpu"] <= 1e-6 and same["iterations_1gpu"] == same["iterations_partitioned"]
     assert same["speedup_vs_1gpu_same_graph"] > 0
+    # SURVEY.md 8e, last sentence: the multi-seed batch as a replica split beside the partitioned headline
+    replicas = out["secondary"]["batch_of_64_seeds_replicas"]
+    assert "error" not in replicas, replicas
+    assert replicas["ranks"] == 2 and replicas["seed_sets"] == 2 * replicas["seed_sets_per_rank"] and replicas["edge_vector_products_per_s_G"] > 0
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -131,3 +135,46 @@ def test_randomised_partitions_against_the_oracle(oracle_build_dir):
     assert "partitioned stress ok" in res.stdout, res.stdout[-2000:]
     cases = int(res.stdout.split("partitioned stress ok:")[1].split()[0])
     assert cases >= 50, res.stdout[-500:]
+
+
+def check_replica_split(parts, scale, ef, width):
+    """What tests/dist_worker_replicas.py wrote against the oracle: every rank holds the same [n, width] result, column j of it is the
+    oracle's PageRank of feature column j (<= 1e-6, the rank that ran it reports the oracle's iteration count), an all-zero column comes
+    back as it went in (abstract_filters.py:53-54)."""
+    import dist_worker_replicas
+    world = len(parts)
+    n = 1 << scale
+    M = sp.csr_array(orc.normalize(rmat_np.rmat_csr(scale, ef, seed=0), "col", True))
+    F = dist_worker_replicas.features(n, width)
+    shares = [(width * r // world, width * (r + 1) // world) for r in range(world)]
+    assert [(int(part["lo"]), int(part["hi"])) for part in parts] == shares
+    for name, kw in (("l1", dict(error_type="l1", tol=1e-6, max_iters=500)), ("mabs", dict(error_type="mabs", tol=1e-7, max_iters=500))):
+        whole = parts[0][name + "_ranks"]
+        assert whole.shape == (n, width)
+        for part in parts:
+            assert np.array_equal(part[name + "_ranks"], whole), name          # the same bits on every rank after the all-gather
+            assert int(part[name + "_share_equal"]) == 1
+        for j in range(width):
+            owner = [r for r, (lo, hi) in enumerate(shares) if lo <= j < hi][0]
+            if not F[:, j].any():
+                assert not whole[:, j].any()
+                continue
+            want, want_iters = orc.pagerank(M, F[:, j], alpha=0.85, eps=EPS32, **kw)
+            assert np.max(np.abs(whole[:, j] - want)) <= 1e-6 * np.max(np.abs(want)), (name, j)
+            assert int(parts[owner][name + "_iters"][j]) == want_iters, (name, j)
+
+
+@pytest.mark.parametrize("world,width", [(2, 5), (4, 6), (4, 3)])
+def test_replica_split_of_a_seed_batch_gloo(tmp_path, oracle_build_dir, world, width):
+    """SURVEY.md 8e, last sentence: multi-seed batches split across the ranks with zero communication (every rank holds the whole
+    graph) -- uneven shares, a rank without columns (width 3 on 4 ranks), an all-zero column."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    scale, ef = 10, 8
+    port = 29600 + world * 7 + width + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_replicas.py"), str(tmp_path), str(scale), str(ef), str(width)]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    check_replica_split(parts, scale, ef, width)

@@ -191,6 +191,32 @@ def test_cfg2_independent_matrix(big):
     assert _rel(got, want) <= 1e-6
 
 
+def test_cfg2_real_valued_weights_scale23_vs_oracle(big):
+    """the bench graph with REAL edge weights (nx ... weight="weight", pygrank/core/utils/preprocessing.py:103): the raw
+    weighted adjacency goes through the preprocessor ("col" on the device) into the VALUED stream (2-byte index + f32 value per entry,
+    cold tail in the propagation-blocking image); the oracle normalises the same raw adjacency itself in fp64 and runs the reference's
+    loop -- <= 1e-6, equal iteration counts, under the L1 rule and under the reference's default rule."""
+    import scipy.sparse as sp
+    from oracle import ref_loops as orc
+    pg = big["pg"]
+    MT = big["g"].download_transposed()
+    MT = sp.csr_array((np.random.default_rng(7).random(MT.nnz) + 0.1, MT.indices, MT.indptr), shape=MT.shape)
+    W = sp.csr_array(MT.T)                                   # rows = sources
+    W.sort_indices()
+    del MT
+    adj = pg.preprocessor(normalization="col", assume_immutability=True)(pg.AdjacencyWrapper(W, directed=True))
+    fmt = adj.array.format()
+    assert "f32-valued entries (6 B/edge)" in fmt and "propagation-blocking image" in fmt, fmt
+    M = orc.normalize(W, "col", True)
+    p = big["seeds"](4)
+    for kw_engine, kw_oracle in ((dict(error_type=pg.L1, tol=1e-6, max_iters=1000), dict(error_type="l1", tol=1e-6, max_iters=1000)), ({}, {})):
+        ranker = pg.PageRank(alpha=0.85, **kw_engine)
+        got = np.asarray(ranker.rank(adj, p.copy()).np, dtype=np.float64)
+        want, want_iters = orc.pagerank(M, p, alpha=0.85, **kw_oracle)
+        assert ranker.convergence.iteration == want_iters, (kw_oracle, ranker.convergence.iteration, want_iters)
+        assert _rel(got, want) <= 1e-6, kw_oracle
+
+
 @pytest.mark.parametrize("coefficient_type", ["taylor", "chebyshev"])
 def test_cfg4_heat_kernel_scale23_vs_oracle(big, coefficient_type):
     from oracle import ref_loops as orc

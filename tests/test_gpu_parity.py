@@ -213,6 +213,28 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
             assert int(part["closed_form_two_launches"]) == int(two)
 
 
+@pytest.mark.parametrize("world,backend,width", [(2, "gloo", 5), (1, "nccl", 6)], ids=["gloo_x2", "rccl_x1_device_gather"])
+def test_replica_split_of_a_seed_batch_on_one_gpu(gpu_engine, tmp_path, world, backend, width):
+    """SURVEY.md 8e, last sentence: a batch of seed sets split across ranks that each hold the whole graph (NodeRanking.propagate,
+    pygrank/core/signals.py:225-226 -> pgh_ppr_run_batch on every rank's share, no communication before the final all-gather of the
+    result slabs).  Two ranks share this box's GPU over gloo (slabs staged through the host); one rank over RCCL runs the
+    device-to-device all-gather.  Against the oracle: <= 1e-6 per column, equal iteration counts."""
+    import os
+    import subprocess
+    import sys
+    from test_distributed_cpu import check_replica_split
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scale, ef = 13, 8
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29671 + world), os.path.join(root, "tests", "dist_worker_replicas.py"), str(tmp_path), str(scale), str(ef), str(width)]
+    env = dict(os.environ, PYTHONPATH=root, PGH_TEST_ENGINE="hip", PGH_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PGH_REPLICA_GATHER_ALONE="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "staging through the host" not in res.stderr, res.stderr[-2000:]       # the RCCL leg gathers device to device
+    check_replica_split([np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)], scale, ef, width)
+
+
 def test_two_gpus_over_rccl(gpu_engine, tmp_path):
     """More than one rank over RCCL (boxes with >= 2 GPUs only; this pool's boxes have one, the driver's scaling node has eight):
     the engine-driven loop must pass its own probe against the Python-driven loop (pygrank_amd.distributed._preflight), run every
