@@ -288,7 +288,7 @@ def single_gpu(args):
             secondary["ppr_l1_1e-6_batch_of_64_seeds"] = dict(error=str(exc))
         # real-valued edge weights (nx ... weight="weight", preprocessing.py:103): the same structure with weights in [0.1, 1.1),
         # "col" normalisation on the device -> the VALUED stream (2-byte index + f32 value per entry); nominal bytes as the headline
-        if not args.no_weighted:
+        if not getattr(args, "no_weighted", False):
             try:
                 import scipy.sparse as sp
                 MTw = g.download_transposed()
@@ -300,7 +300,8 @@ def single_gpu(args):
                 del Ww
                 side("ppr_l1_1e-6_real_weights", pg.PageRank(alpha=ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS), wadj, alg_bytes, nnz,
                      signals=[pg.to_signal(wadj, sig.np) for sig in personalizations[:3]])
-                secondary["ppr_l1_1e-6_real_weights"]["format"] = wadj.array.format().split(",")[2].strip()
+                secondary["ppr_l1_1e-6_real_weights"]["format"] = next((part.strip() for part in wadj.array.format().split(",") if "B/edge" in part),
+                                                                       wadj.array.format()[:60])
                 del wadj
             except Exception as exc:
                 secondary["ppr_l1_1e-6_real_weights"] = dict(error=str(exc)[:300])

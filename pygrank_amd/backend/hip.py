@@ -35,6 +35,11 @@ def take_dropout_seeds(count):
     return first
 
 
+def peek_dropout_seed():
+    """The seed the next graph_dropout call would draw (nothing is reserved)."""
+    return _dropout_calls[0] + 1
+
+
 def graph_dropout(M, dropout):            # specification.py:13; identity and O(1) for dropout == 0 (called 2 + #steps times)
     if dropout == 0:
         return M

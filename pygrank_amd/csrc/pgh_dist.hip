@@ -203,16 +203,21 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     // every rank must lay the gather vector out the same way: live = max over ranks, hot prefix = min over ranks; and every rank
     // must close the steps the same way: the in-kernel residual only when every slice can (min), the slice's degrees recomputed
     // when any rank lacks them (max)
-    int32_t h_agree[4] = {top, -hot_slots, (fused != nullptr && *fused) ? 0 : 1, g->bsf.deg_int == nullptr ? 1 : 0};
+    // (the degree word counts only where this rank could fuse at all: a run that cannot -- closed-form filters, AbsorbingWalks, the
+    // max rule -- neither needs the slice's degrees nor gives anybody's up)
+    const bool may_fuse = fused != nullptr && *fused;
+    int32_t h_agree[4] = {top, -hot_slots, may_fuse ? 0 : 1, (may_fuse && g->bsf.deg_int == nullptr) ? 1 : 0};
     PGH_HIP(hipMemcpyAsync(c->agree, h_agree, sizeof(h_agree), hipMemcpyHostToDevice, c->main));
     PGH_TRY(comm_all_reduce(c, c->agree, 4, ncclInt32, ncclMax, c->s, c->main));
     PGH_HIP(hipMemcpyAsync(h_agree, c->agree, sizeof(h_agree), hipMemcpyDeviceToHost, c->main));
     PGH_HIP(hipEventRecord(c->ev_host, c->main));
     PGH_TRY(bounded_wait(c->ev_host, "the layout negotiation"));
     if (fused != nullptr) *fused = h_agree[2] == 0;
-    if (h_agree[3] != 0 && g->bsf.deg_int != nullptr) {       // some rank rebuilds its degrees: the all-reduce needs everybody
+    // some rank rebuilds its degrees and the run fuses on every rank: the all-reduce of ensure_slice_degrees needs everybody
+    if (h_agree[2] == 0 && h_agree[3] != 0 && g->bsf.deg_int != nullptr) {
         (void)hipFree(g->bsf.deg_int);
         g->bsf.deg_int = nullptr;
+        g->bsf.device_bytes -= (int64_t)g->n_cols * 4;
     }
     const int64_t live = std::min<int64_t>(blk, ((int64_t)h_agree[0] + 63) / 64 * 64);
     const int64_t hot_all = -h_agree[1];

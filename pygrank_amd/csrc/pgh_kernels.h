@@ -648,6 +648,7 @@ void pb_set_residual(const ResParams* rp);   // the next pb_launch_finish<EPI_AX
 // the next pb_launch_finish runs only its phase-1 / phase-2 items (PbView::phase; live: exchanged slots per block); phase 2 puts its
 // partial sums behind phase 1's, and *num_partials of the phase-2 launch counts both
 void pb_set_finish_phase(int phase, int live);
+int  pb_pending_finish_phase();      // the phase the NEXT finish launch will run (0: the whole step in one launch)
 // graph_dropout: the launches of the NEXT step's block partial sums and phase A multiply every entry by its mask factor (rate in
 // [0, 1), seed: pgh_spmv_dropout's); cleared by bsf_clear_dropout.  bsf_ensure_edge_ids builds the entry -> CSR index words once.
 bool bsf_dropout_usable(const pgh_graph_s* g);

@@ -1311,6 +1311,7 @@ void pb_set_finish_phase(int phase, int live) {
     g_finish_phase = phase;
     g_finish_live = live;
 }
+int pb_pending_finish_phase() { return g_finish_phase; }
 
 // phase B + the MODE epilogue for every output row; block partials of sum(y) / delta land in rt().d_partials
 template <int MODE>

@@ -1226,8 +1226,11 @@ extern "C" int pgh_dist_combine(pgh_graph_t g, pgh_vec_t p_local, double alpha, 
         local_layout(f, ep);
     }
     int count = 0;
+    // (a two-launch finish: the packed slice is rewritten behind the FIRST launch only -- the exchange reads it while the second
+    // runs, and the rows of the second launch hold no exchanged slot)
+    const bool second_launch = pb_pending_finish_phase() == 2;
     PGH_TRY((bsf_launch_combine<EPI_AXPBY>(g, ep, reinterpret_cast<const LoopState*>(state), &count)));
-    if (f.src_scale == nullptr) PGH_TRY(dist_prescale_packed(g, y_local->data, xg_local_out->data));
+    if (f.src_scale == nullptr && !second_launch) PGH_TRY(dist_prescale_packed(g, y_local->data, xg_local_out->data));
     k_dist_fold<<<1, WG, 0, r.stream>>>(state, r.d_partials, count, 0, 2);
     PGH_HIP(hipGetLastError());
     return 0;
@@ -1255,8 +1258,11 @@ extern "C" int pgh_dist_combine_absorb(pgh_graph_t g, pgh_vec_t p_local, pgh_vec
         local_layout(f, ep);
     }
     int count = 0;
+    // (a two-launch finish: the packed slice is rewritten behind the FIRST launch only -- the exchange reads it while the second
+    // runs, and the rows of the second launch hold no exchanged slot)
+    const bool second_launch = pb_pending_finish_phase() == 2;
     PGH_TRY((bsf_launch_combine<EPI_ABSORB>(g, ep, reinterpret_cast<const LoopState*>(state), &count)));
-    if (f.src_scale == nullptr) PGH_TRY(dist_prescale_packed(g, y_local->data, xg_local_out->data));
+    if (f.src_scale == nullptr && !second_launch) PGH_TRY(dist_prescale_packed(g, y_local->data, xg_local_out->data));
     k_dist_fold<<<1, WG, 0, r.stream>>>(state, r.d_partials, count, 0, 2);
     PGH_HIP(hipGetLastError());
     return 0;
@@ -1287,8 +1293,11 @@ extern "C" int pgh_dist_combine_poly(pgh_graph_t g, pgh_vec_t term_local, pgh_ve
         local_layout(f, ep);
     }
     int count = 0;
+    // (a two-launch finish: the packed slice is rewritten behind the FIRST launch only -- the exchange reads it while the second
+    // runs, and the rows of the second launch hold no exchanged slot)
+    const bool second_launch = pb_pending_finish_phase() == 2;
     PGH_TRY((bsf_launch_combine<EPI_POLY>(g, ep, reinterpret_cast<const LoopState*>(state), &count)));
-    if (f.src_scale == nullptr) PGH_TRY(dist_prescale_packed(g, term_out_local->data, xg_local_out->data));
+    if (f.src_scale == nullptr && !second_launch) PGH_TRY(dist_prescale_packed(g, term_out_local->data, xg_local_out->data));
     k_dist_fold<<<1, WG, 0, r.stream>>>(state, r.d_partials + kMaxPartials, count, err_linf ? 1 : 0, 1);
     PGH_HIP(hipGetLastError());
     return 0;
@@ -1445,10 +1454,11 @@ int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float
     rp.first = step == 1 ? 1 : 0;
     pb_set_residual(&rp);
     int count = 0;
+    const bool second_launch = pb_pending_finish_phase() == 2;      // (see pgh_dist_combine)
     const int rc = bsf_launch_combine<EPI_AXPBY>(g, ep, reinterpret_cast<const LoopState*>(state), &count);
     pb_set_residual(nullptr);               // consumed by the launch; never left armed behind a failed one
     if (rc != 0) return rc;
-    if (f.src_scale == nullptr) PGH_TRY(dist_prescale_packed(g, y_local, xg_local_out));
+    if (f.src_scale == nullptr && !second_launch) PGH_TRY(dist_prescale_packed(g, y_local, xg_local_out));
     PGH_HIP(hipGetLastError());
     *num_partials = count;
     return 0;

@@ -250,10 +250,13 @@ def _native_comm(dist, device):
     """The engine's own RCCL communicator pair (csrc/pgh_dist.hip), created once per process: rank 0 draws the ids, the bytes
     travel through torch.distributed, every rank joins.  None when the run is not RCCL-on-GPU (gloo / CPU tests, the host
     double) or PGH_DIST_NATIVE=0 asks for the Python-driven loop."""
-    mode = os.environ.get("PGH_DIST_NATIVE", "auto")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    # One rank: the engine loop (measured and tested on this pool).  MORE than one rank over RCCL has never run anywhere yet (this
+    # pool has single-GPU boxes), so there the Python-driven loop over torch's communicator is the default and the engine loop is
+    # opt-in: PGH_DIST_NATIVE=auto (probe first, below) or =1 (no probe); =0 never uses it (ADVICE r4).
+    mode = os.environ.get("PGH_DIST_NATIVE", "auto" if world == 1 else "0")
     if device.type != "cuda" or mode == "0" or not L.runtime_name().startswith("hip:"):
         return None
-    world, rank = dist.get_world_size(), dist.get_rank()
     key = (world, rank)
     if key in _NATIVE_COMMS:
         return _NATIVE_COMMS[key]
@@ -299,6 +302,16 @@ def _native_comm(dist, device):
         # loop is a user's, or the driver's scaling bench).  PGH_DIST_NATIVE=1 skips the probe, =0 never uses the engine loop.
         if handle is not None and world > 1 and mode == "auto":
             PREFLIGHT[key] = _preflight(dist, device, rank, world, lib)
+            if PREFLIGHT[key].startswith("stalled"):
+                # A collective of the engine loop never completed: its RCCL kernels are still spinning on this GPU (RunScope leaves
+                # them in flight), so nothing else can be trusted to run here -- not the staged loop over torch's communicator, not a
+                # hipFree (it would wait for every queue of the device).  The process ends with a non-zero code and says how to
+                # relaunch; the launcher takes the other ranks down.  Nothing is re-executed from a process that has touched the GPU.
+                sys.stderr.write(f"[pygrank_amd.distributed] rank {rank}: the engine-driven RCCL loop STALLED in its probe ({PREFLIGHT[key]}); "
+                                 "this process cannot continue on a GPU with collectives in flight -- relaunch with PGH_DIST_NATIVE=0 "
+                                 "(the Python-driven loop), or with PGH_DIST_SINGLE_COMM=1 PGH_DIST_SINGLE_STREAM=1\n")
+                sys.stderr.flush()
+                os._exit(3)
             if PREFLIGHT[key] != "ok":
                 sys.stderr.write(f"[pygrank_amd.distributed] rank {rank}: the engine-driven RCCL loop failed its probe ({PREFLIGHT[key]}); "
                                  "using the Python-driven loop\n")
@@ -311,23 +324,30 @@ PREFLIGHT = {}          # (world, rank) -> "ok" | what went wrong: the engine lo
 
 
 def _preflight(dist, device, rank, world, lib):
-    """One small partitioned PageRank through the engine's loop and through the Python-driven loop; "ok" when every rank got
-    the same iteration count and ranks from both.  Collective.  Host waits on the engine's collectives are bounded by
-    PGH_DIST_PREFLIGHT_S (default 30 s) while it runs."""
+    """One small partitioned PageRank through the engine's loop and through the Python-driven loop.  "ok" when, on every rank, the
+    engine loop's iterate equals the staged loop's iterate after the SAME number of steps (<= 1e-6 of the largest rank) and its
+    stopping iteration lies between those of the staged loop at a tolerance 5 % looser and 5 % tighter (the two routes evaluate the
+    residual differently -- in the finish kernel against a predicted quotient / by the separate kernel -- and residuals near the
+    tolerance are not monotone: demanding the identical count would demote a healthy engine loop).  A verdict that starts
+    with "stalled" means a bounded wait on a collective expired: the caller must end the process (see _native_comm).  Collective.
+    Host waits on the engine's collectives are bounded by PGH_DIST_PREFLIGHT_S (default 30 s) while it runs."""
     import torch
     verdict = "ok"
+    stalled = False
     L.check(lib.pgh_dist_set_timeout(float(os.environ.get("PGH_DIST_PREFLIGHT_S", "30"))))
     # the probe's slices get a cold image whatever their size (PGH_PB_FORCE, read at build time), so that what runs is the loop of the
     # large graphs: split regions, the residual inside the finish kernel, ONE 4-scalar all-reduce, the slice degrees' all-reduce
     saved_env = {k: os.environ.get(k) for k in ("PGH_PB", "PGH_PB_FORCE")}
     os.environ.update(PGH_PB="1", PGH_PB_FORCE="1")
+    pg = None
     try:
         pg = rmat_partitioned(20, 8, rank, world, seed=0)
         rng = np.random.default_rng(1)
         p_new = np.zeros(pg.n)
         p_new[rng.choice(pg.n, 20, replace=False)] = 1.0                        # in NEW ids: the same on every rank
         p_local = DeviceVector.from_host(p_new[pg.row_begin:pg.row_begin + pg.n_local])
-        kw = dict(alpha=0.85, tol=1e-6, error_type="l1", max_iters=200)
+        tol = 1e-6
+        kw = dict(alpha=0.85, error_type="l1", max_iters=200)
         # two legs of the engine loop: as this process would run a small exchange (one finish launch), and with the finish kernel in
         # two launches -- what a large exchange (configs[4]) switches on and nothing smaller would exercise over RCCL
         legs = [("", None)]
@@ -335,7 +355,7 @@ def _preflight(dist, device, rank, world, lib):
             legs.append(("two-launch finish: ", "2"))
         runs = []
         for label, split in legs:
-            native = DistributedPageRank(**kw)
+            native = DistributedPageRank(tol=tol, **kw)
             native._dist, native._device = dist, device
             if split is not None:
                 os.environ["PGH_DIST_FINISH_SPLIT"] = split
@@ -343,26 +363,32 @@ def _preflight(dist, device, rank, world, lib):
                 got = np.asarray(native._rank_native(pg, p_local, _NATIVE_COMMS[(world, rank)], lib), dtype=np.float64)
                 runs.append((label, native.iteration, got))
             except Exception as exc:                                               # EngineError of a bounded wait, ...
-                verdict = f"{label}engine loop: {str(exc)[:200]}"
+                stalled = "stalled" in str(exc) or "did not complete within" in str(exc)
+                verdict = f"{'stalled: ' if stalled else ''}{label}engine loop: {str(exc)[:200]}"
             finally:
                 if split is not None:
                     os.environ.pop("PGH_DIST_FINISH_SPLIT", None)
             if verdict != "ok":
                 break                                                              # (a stalled communicator takes no further run)
-        staged = DistributedPageRank(**kw)
-        staged._native_formula = False
-        want = np.asarray(staged.rank(pg, p_local), dtype=np.float64)
-        if verdict == "ok":
-            top = torch.tensor([float(np.max(np.abs(want), initial=0.0))], dtype=torch.float64, device=device)
-            dist.all_reduce(top, op=dist.ReduceOp.MAX)
-            for label, iterations, got in runs:
-                if iterations != staged.iteration:
-                    verdict = f"{label}iterations differ: engine {iterations}, staged {staged.iteration}"
+        if not stalled:
+            # the staged loop over torch's communicator: only on queues that are known to be drained
+            def staged_run(**over):
+                staged = DistributedPageRank(**dict(kw, **over))
+                staged._native_formula = False
+                return np.asarray(staged.rank(pg, p_local), dtype=np.float64), staged.iteration
+            _, upper = staged_run(tol=tol / 1.05)                                  # a tighter tolerance stops no earlier
+            _, lower = staged_run(tol=tol * 1.05)
+            for label, iterations, got in runs if verdict == "ok" else []:
+                want, _ = staged_run(error_type="iters", max_iters=iterations)     # the same number of steps, whatever the rule says
+                top = torch.tensor([float(np.max(np.abs(want), initial=0.0))], dtype=torch.float64, device=device)
+                dist.all_reduce(top, op=dist.ReduceOp.MAX)
+                if not lower <= iterations <= upper:
+                    verdict = f"{label}stopping iteration {iterations} outside [{lower}, {upper}] of the staged loop at tol x 1.05 / tol / 1.05"
                 elif float(np.max(np.abs(got - want), initial=0.0)) > 1e-6 * float(top.item()):
-                    verdict = label + "ranks differ between the engine loop and the staged loop"
+                    verdict = label + f"ranks differ between the engine loop and the staged loop after {iterations - 1} steps"
                 if verdict != "ok":
                     break
-        pg.graph.destroy()
+            pg.graph.destroy()                                                     # (hipFree: never behind a stalled collective)
     except Exception as exc:
         verdict = f"probe: {str(exc)[:200]}"
     finally:
@@ -372,11 +398,18 @@ def _preflight(dist, device, rank, world, lib):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+    if stalled:
+        if pg is not None:
+            _ABANDONED.append(pg)                                                  # its device memory is never freed in this process
+        return verdict                                                             # no further collective: every rank that stalled exits
     agree = torch.tensor([1 if verdict == "ok" else 0], dtype=torch.int32, device=device)
     dist.all_reduce(agree, op=dist.ReduceOp.MIN)
     if int(agree.item()) == 0 and verdict == "ok":
         verdict = "failed on another rank"
     return verdict
+
+
+_ABANDONED = []         # graphs of a stalled probe: kept alive so that nothing frees device memory under a collective in flight
 
 
 _EXTERNAL_KEEPALIVE = []

@@ -269,7 +269,7 @@ class PageRank(RecursiveGraphFilter):
             # the masks the hook protocol would draw (abstract_filters.py:57-62): one for _start, one per step, one for _end -- step k
             # runs on the (k + 1)-th of them, so both routes compute the same thing from the same seed
             from pygrank_amd.backend import hip as _hip
-            first = _hip.take_dropout_seeds(max(int(cfg.max_iters), 1) + 1)
+            first = _hip.peek_dropout_seed()
             lib, rate, seed0 = L.lib(), float(dropout), int(first) + 1
 
             def entry(gh, ph, xh, cfg_ref, res_ref):
@@ -278,6 +278,10 @@ class PageRank(RecursiveGraphFilter):
         if outcome == "zero":                              # abstract_filters.py:53-54: returned before the manager is started
             vars(self.convergence).update(before)
             return personalization
+        if dropout and outcome:
+            # ... and leaves the seed counter where the hook protocol would: it draws iterations + 1 masks (_start, iterations - 1
+            # steps, _end), however early the tolerance stopped the run; a run that fell back (outcome False) has drawn none
+            _hip.take_dropout_seeds(int(self.convergence.iteration) + 1)
         return ranks if outcome else None
 
     def propagate(self, graph, features, *args, **kwargs):

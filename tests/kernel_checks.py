@@ -206,6 +206,18 @@ def check_graph_dropout(pg):
     by_hooks = np.asarray(hooks.rank(graph, p.copy(), graph_dropout=0.3).np)
     assert not hasattr(hooks, "last_loop") and hooks.convergence.iteration == 12
     assert np.max(np.abs(by_hooks - outs[0])) <= 2e-6 * np.max(np.abs(outs[0]))
+    # both routes leave the seed counter in the same place (iterations + 1 masks drawn: _start, every step, _end), so consecutive
+    # rank(..., graph_dropout=) calls after ONE set_dropout_seed are reproducible across the routes ...
+    assert pg.backend.hip.peek_dropout_seed() == 7 + 13 + 1
+    second = []
+    for fused in (True, False):
+        pg.backend.hip.set_dropout_seed(7)
+        both = pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=0.35, max_iters=200)     # ... also when a tolerance stops the run early
+        both.fused_dropout = fused
+        both.rank(graph, p.copy(), graph_dropout=0.3)
+        assert pg.backend.hip.peek_dropout_seed() == 7 + both.convergence.iteration + 1 + 1, (fused, both.convergence.iteration)
+        second.append(np.asarray(both.rank(graph, p.copy(), graph_dropout=0.3).np))
+    assert np.max(np.abs(second[0] - second[1])) <= 2e-6 * np.max(np.abs(second[1]))
     # a tolerance instead of a count: the loop stops on the device, on the residual of the masked iteration
     pg.backend.hip.set_dropout_seed(7)
     stopping = pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=0.35, max_iters=200)

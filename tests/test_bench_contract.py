@@ -22,7 +22,9 @@ def test_single_gpu_leg_fields(host_engine):
     assert line["parity"]["gpu_iterations"] == line["parity"]["cpu_iterations"]
     assert set(line["secondary"]) == {"ppr_mabs_default_tol1e-6", "ppr_50_iterations", "heat_kernel_t5_31_iterations",
                                       "heat_kernel_t5_31_iterations_chebyshev", "absorbing_walks_a085_l1_1e-6",
-                                      "ppr_l1_1e-6_symmetrised_graph", "ppr_l1_1e-6_batch_of_64_seeds"}
+                                      "ppr_l1_1e-6_symmetrised_graph", "ppr_l1_1e-6_batch_of_64_seeds", "ppr_l1_1e-6_real_weights"}
+    weighted = line["secondary"]["ppr_l1_1e-6_real_weights"]
+    assert "error" not in weighted and weighted["gteps"] >= 0 and weighted["iterations"] > 2, weighted
     batch = line["secondary"]["ppr_l1_1e-6_batch_of_64_seeds"]
     assert "error" not in batch and batch["width"] == 64 and batch["edge_vector_products_per_s_G"] > 0
     assert line["secondary"]["ppr_50_iterations"]["spmv_per_run"] == 50

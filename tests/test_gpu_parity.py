@@ -254,7 +254,8 @@ def test_two_gpus_over_rccl(gpu_engine, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "dist_worker.py"), str(tmp_path), str(scale), str(ef)]
     env = dict(os.environ, PYTHONPATH=root, PGH_TEST_ENGINE="hip", PGH_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               PGH_PB="1", PGH_PB_FORCE="1", PGH_BLOCKS="4", PGH_PB_HEAVY="64", PGH_PB_HUBMAX="500", PGH_DIST_TIMEOUT_S="120")
+               PGH_PB="1", PGH_PB_FORCE="1", PGH_BLOCKS="4", PGH_PB_HEAVY="64", PGH_PB_HUBMAX="500", PGH_DIST_TIMEOUT_S="120",
+               PGH_DIST_NATIVE="auto")         # (with more than one rank the engine loop is opt-in: probe, then the engine drives RCCL)
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2)]
