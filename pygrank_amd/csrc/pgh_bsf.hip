@@ -595,6 +595,9 @@ struct BsfView {
     int             tile_begin[9];
 };
 
+#ifndef PGH_SEG_DPP_FUSED
+#define PGH_SEG_DPP_FUSED 1
+#endif
 // ---- wavefront scans on the DPP crossbar (no LDS traffic): Hillis-Steele inside the 16-lane rows, then the two
 // row broadcasts (lane 15 -> next row on rows 1/3, lane 31 -> rows 2/3) that complete a 64-lane inclusive scan
 template <int CTRL, int ROW_MASK>
@@ -619,6 +622,35 @@ __device__ __forceinline__ int wave_inclusive_sum(int v) {
 // the previous lane's segment.  Per step: val += keep * val[l - d]; keep *= keep[l - d]  (lanes without a source read
 // 0 / 1), i.e. two DPP operand fetches, one fma and one multiply.
 __device__ __forceinline__ float wave_segmented_sum(float keep, float val) {
+#if PGH_SEG_DPP_FUSED
+    // Round 5: the DPP operand rides in the arithmetic instruction itself.  `v_fmac_f32_dpp val, val, keep` adds keep * val[l - d];
+    // `v_mul_f32_dpp keep, keep, keep` multiplies by keep[l - d]; a lane WITHOUT a source lane is not written at all (bound_ctrl off),
+    // which is the "+ 0" / "* 1" the scan wants there -- 2 vector instructions per step instead of 6 (two v_mov identities, two
+    // v_mov_dpp, fma, mul: 36 of the kernel's 127 vector instructions per tile, profiles/r05/bsf_partial_valu.log).  Inline asm is
+    // opaque to the hazard recognizer: a VGPR written by a VALU instruction needs 2 wait states before a DPP read of it
+    // (CDNA3 ISA 4.5) -- the s_nop in front of every fmac covers val (one instruction in between) and keep (two).
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(val), "+v"(keep));
+    return val;
+#else
 #define PGH_SEG_STEP(CTRL, MASK)                                   \
     {                                                              \
         const float v2 = dpp_f32<CTRL, MASK>(0.f, val);            \
@@ -634,6 +666,7 @@ __device__ __forceinline__ float wave_segmented_sum(float keep, float val) {
     PGH_SEG_STEP(0x143, 0xc)
 #undef PGH_SEG_STEP
     return val;
+#endif
 }
 
 // One tile = 64 * IPT consecutive entries of one column block, owned by ONE wavefront: no workgroup barrier is
@@ -782,7 +815,9 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
 #if PGH_PROBE_GATHER == 9        // the hot gathers without bank conflicts (wrong sums): lane l reads word l of a 256-byte row, still behind the stream word
                 const uint32_t off = (((k & 1) ? pair >> 31 : (pair >> 15) & 1u) << 2) + (lane << 2) + (k << 8);
 #else
-                const uint32_t off = (k & 1) ? (pair >> 16) << 1 : (pair & 0xffffu) << 1;
+                uint32_t off;            // halfword k & 1 of the pair, times 2: ONE sub-dword-addressed shift (the compiler finds it for the high half only)
+                if (k & 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off) : "v"(1), "v"(pair));
+                else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(off) : "v"(1), "v"(pair));
 #endif
                 g.h[k] = *reinterpret_cast<const float*>(lds + off);
                 g.c[k] = 0.f;
@@ -830,7 +865,7 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
             if (!(PGH_PROBE_SKIP & 2) || K == 7) *reinterpret_cast<int*>(lds + a) = accb;              \
             asm("v_mad_i32_i24 %0, %1, -4, %2" : "=v"(o4) : "v"(m), "v"(o4));                          \
             asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(accb) : "v"(m), "v"(accb));                           \
-            float xv = g0.h[K] + g0.c[K];                                                              \
+            float xv = COLD ? g0.h[K] + g0.c[K] : g0.h[K];      /* (x + 0.f is not folded: -0) */     \
             if (HAS_VAL || DROP) xv *= g0.v[K];                                                        \
             accb = __builtin_bit_cast(int, __builtin_bit_cast(float, accb) + xv);                      \
         }
@@ -1551,6 +1586,7 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.seed_list);
     (void)hipFree(f.seed_count);
     (void)hipFree(f.mm_row_has);
+    (void)hipFree(f.mm_rowop);
     (void)hipFree(f.perm);
     (void)hipFree(f.src_scale);
     (void)hipFree(f.dst_scale);

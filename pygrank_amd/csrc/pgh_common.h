@@ -253,6 +253,8 @@ struct BsfFormat {
     float*    part = nullptr;       // multi-seed layout only: per-tile head sums
     int32_t*  mm_close = nullptr;   // multi-seed layout only: closing row of every entry (k_mm_close_rows, pgh_spmm.hip)
     uint8_t*  mm_row_has = nullptr; // multi-seed layout only: 1 = the row of M^T holds entries (k_mm_mark_rows)
+    float*    mm_rowop = nullptr;   // multi-seed layout only: [n_out][4] {dst scale, gather scale s', 1 / s', row sum of M} per row: the epilogue's
+                                    // row operands as ONE 16-byte word (k_mm_rowops, pgh_spmm.hip)
     int32_t*  mm_edge = nullptr;    // multi-seed layout, graph_dropout only: index of every stream entry in CSR(M^T) order (-1 = pad), the
                                     // argument of the dropout hash; copies of a multi-edge share one index (k_mm_edge_ids)
     // SpMV layout: block partial sums are stored COMPACTLY, one float per (block, row) segment in stream order (psum),

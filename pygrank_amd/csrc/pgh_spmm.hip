@@ -28,13 +28,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTileMM = 64 * PGH_BSF_IPT;        // same tile table as the single-vector layout
 
 struct BatchState {
-    double scale[kLanes];
+    double scale[kLanes];        // quotient of the current iterate (1 / sum(y_k); 1 without the quotient)
     double err[kLanes];
     double sum[kLanes];
+    double pred_inv[kLanes];     // PREDICTED quotient of the step being written (in-kernel residual, see k_mm_step)
+    double pred_raw[kLanes];     // the uncorrected prediction it came from
+    double sum_p[kLanes];        // sum of the column's personalization (measured by the first step)
     int    done[kLanes];
     int    steps[kLanes];
     int    converged[kLanes];
+    // the four words the host polls after every step (copied to a pinned ring): every column has stopped / the in-kernel residual
+    // of step `steps` could not vouch for its verdict on some column and the step waits for the separate kernel / executed steps
     int    all_done;
+    int    paused;
+    int    executed;
     int    b;
 };
 
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(WG) void k_mm_edge_ids(const uint32_t* __restrict__
 template <bool HAS_VAL, int LPR, bool DROP = false>
 __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __restrict__ xg, int ld, int b, float* __restrict__ sums,
                                                     const BatchState* __restrict__ state, MMDrop drop = MMDrop{}) {
-    if (state != nullptr && state->all_done) return;
+    if (state != nullptr && (state->all_done | state->paused)) return;
     constexpr int G = 64 / LPR;                            // groups (tiles in flight) per wavefront
     constexpr int W = 16 / LPR;                            // stream words of a 16-entry round per lane
     const int lane = threadIdx.x & 63;
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
 
 // one wavefront per closing tile: fixed-order sum of the chain of tail carries + the head piece
 __global__ __launch_bounds__(WG) void k_mm_fixup(MMView f, int ld, int b, float* __restrict__ sums, const BatchState* __restrict__ state) {
-    if (state != nullptr && state->all_done) return;
+    if (state != nullptr && (state->all_done | state->paused)) return;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
     const int stride = gridDim.x * (WG / 64);
@@ -293,7 +300,7 @@ struct CombineParams {
 __global__ __launch_bounds__(WG) void k_mm_combine(CombineParams c, int64_t n, int ld, int b, const BatchState* __restrict__ state,
                                                     double* __restrict__ partial_sum /* [grid][64] */) {
     __shared__ double s_red[WG / 64][kLanes];
-    if (state != nullptr && state->all_done) return;
+    if (state != nullptr && (state->all_done | state->paused)) return;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
     const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
     const int l = lane & (lpr - 1), c4 = 4 * l;
@@ -413,11 +420,164 @@ __global__ __launch_bounds__(WG) void k_mm_fold(const double* __restrict__ parti
     }
 }
 
-__global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y, const float* __restrict__ y_old, int64_t n, int ld, int b,
-                                                     int use_quotient, int linf, const BatchState* __restrict__ state,
-                                                     double* __restrict__ partial_res, const uint8_t* __restrict__ row_flags) {
+// ---------------------------------------------------------------------------------------------------------------------------
+// The batch loop keeps ONE slab per iterate: the GATHER slab xg = y * s' (s' = the source scale of the row, 1 where that is zero:
+// such a row is never gathered and its slab row holds y itself).  y is what the epilogue computes in registers and never stores;
+// the previous iterate's row comes back as xg_old * (1 / s') (one rounding, 6e-8 relative: it enters the residual only), the ranks
+// leave through k_mm_permute_out2 the same way.  Two slabs ping-pong, so a paused step can be re-evaluated from both.
+// (Round 4 wrote y AND xg every step and read both iterates again in a residual pass of its own: 4.8 GB per batch step at scale 23 /
+// b = 64 against 3.0 GB here.)
+//
+// The residual of a step inside its epilogue (RecursiveGraphFilter._step's quotient + ConvergenceManager per column,
+// abstract_filters.py:126-136, convergence.py:96-101): sum_r |y_r * inv - yold_r * scale| needs inv = 1 / sum(y) of the very step being
+// written.  As in the single-vector loop (ResParams, pgh_kernels.h) it is PREDICTED per column -- sum(y) = a * sum_j deg_j yold_j + b *
+// sum(p), corrected by the last step's measured / predicted ratio -- the kernel evaluates R' and D = sum sign(.) y against inv', the
+// close takes R = R' + (inv - inv') D, exact but for rows whose term changes sign between inv' and inv: bounded by 2 |inv - inv'|
+// sum|y|.  A column whose tolerance lies inside that bound (or that met a negative / non-finite y: R' = NaN) PAUSES the step for the
+// whole batch: every later launch is a no-op, the host runs the separate residual kernel for the step and goes on without the fusion.
+struct StepParams {
+    const float* sums;       // [n, ld] plain row sums (structural zeros never written)
+    const f32x4* rowop;      // [n] {dst scale, s', 1 / s', row sum of M} (k_mm_rowops)
+    const float* p;          // [n, ld] personalization
+    const uint8_t* row_flags;// [n] (PermuteIn2::row_flags) bit 0: the row of p holds a non-zero; bit 1: the row has entries; 0: zero for ever
+    const float* xg_old;     // [n, ld]
+    float*       xg_new;     // [n, ld]
+    double       alpha;
+    int          mode;       // 0: S and T only; 1: + the in-kernel residual against state->pred_inv; 2: first step (D = sum of p)
+};
+
+__global__ __launch_bounds__(WG) void k_mm_step(StepParams c, int64_t n, int ld, int b, const BatchState* __restrict__ state,
+                                                 double* __restrict__ partials /* [4][grid][64]: S, T, R', D */) {
+    __shared__ double s_red[4][WG / 64][kLanes];
+    if (state->all_done | state->paused) return;
+    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
+    const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
+    const int l = lane & (lpr - 1), c4 = 4 * l;
+    const bool live = c4 < b;
+    f32x4 a, frozen = {0.f, 0.f, 0.f, 0.f};
+    double inv_p[4], scl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool col = c4 + k < b;
+        scl[k] = col ? state->scale[c4 + k] : 1.0;
+        a[k] = (float)(c.alpha * scl[k]);
+        inv_p[k] = (col && c.mode == 1) ? state->pred_inv[c4 + k] : 1.0;
+        if (!col || state->done[c4 + k] != 0) frozen[k] = 1.f;
+    }
+    const float bc = (float)(1.0 - c.alpha);
+    double S[4] = {0.0, 0.0, 0.0, 0.0}, T[4] = {0.0, 0.0, 0.0, 0.0}, R[4] = {0.0, 0.0, 0.0, 0.0}, D[4] = {0.0, 0.0, 0.0, 0.0};
+    bool neg = false;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * rows_per_wave + lane / lpr;
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
+    constexpr int U = PGH_MM_COMB_U;
+    int fl_next[U];                                        // row flags one trip ahead: the loads of a trip do not wait for its flags
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t r = first + u * stride;
+        fl_next[u] = (live && r < n) ? (int)c.row_flags[r] : 0;
+    }
+    for (int64_t r0 = first; r0 < n; r0 += stride * U) {
+        f32x4 sum[U], pv[U], xo[U], op[U];
+        int fl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u * stride;
+            fl[u] = fl_next[u];
+            const int64_t rn = r + stride * U;
+            fl_next[u] = (live && rn < n) ? (int)c.row_flags[rn] : 0;
+            const bool ok = fl[u] != 0;
+            const int64_t at = (ok ? r : 0) * ld + c4;
+            sum[u] = (ok && (fl[u] & 2)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.sums + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            pv[u] = (ok && (fl[u] & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.p + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xo[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.xg_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            op[u] = ok ? c.rowop[r] : f32x4{1.f, 1.f, 1.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (fl[u] == 0) continue;
+            const int64_t r = r0 + u * stride;
+            f32x4 out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float yo = xo[u][k] * op[u][2];                       // the previous iterate's y (one rounding)
+                const float y = a[k] * (sum[u][k] * op[u][0]) + bc * pv[u][k];
+                if (frozen[k] != 0.f) {
+                    out[k] = xo[u][k];                                       // a stopped column keeps its row bit for bit
+                    continue;
+                }
+                out[k] = y * op[u][1];
+                S[k] += (double)y;
+                T[k] += (double)op[u][3] * (double)y;
+                neg = neg || !(y >= 0.f);
+                if (c.mode == 2) {
+                    D[k] += (double)pv[u][k];
+                } else if (c.mode == 1) {
+                    const double d = (double)y * inv_p[k] - (double)yo * scl[k];
+                    R[k] += fabs(d);
+                    D[k] += d < 0.0 ? -(double)y : (double)y;
+                }
+            }
+            *reinterpret_cast<f32x4*>(c.xg_new + r * ld + c4) = out;
+        }
+    }
+    if (c.mode == 1 && neg) R[0] = R[1] = R[2] = R[3] = __builtin_nan("");      // (poisons the lane's four columns: a pause, never a wrong verdict)
+    // the lane groups hold the same columns: fold them in group order, then the wavefronts in wavefront order
+    for (int j = threadIdx.x; j < 4 * (WG / 64) * kLanes; j += WG) (&s_red[0][0][0])[j] = 0.0;      // columns beyond 4 * lanes
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double t0 = S[k], t1 = T[k], t2 = R[k], t3 = D[k];
+        for (int off = lpr; off < 64; off += lpr) {
+            t0 += __shfl_down(S[k], off, 64);
+            t1 += __shfl_down(T[k], off, 64);
+            t2 += __shfl_down(R[k], off, 64);
+            t3 += __shfl_down(D[k], off, 64);
+        }
+        if (lane < lpr) {
+            s_red[0][wave_in_wg][c4 + k] = t0;
+            s_red[1][wave_in_wg][c4 + k] = t1;
+            s_red[2][wave_in_wg][c4 + k] = t2;
+            s_red[3][wave_in_wg][c4 + k] = t3;
+        }
+    }
+    __syncthreads();
+    {
+        const int q = wave_in_wg;                          // WG / 64 == 4 wavefronts: wavefront q folds quantity q
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < WG / 64; ++w) t += s_red[q][w][lane];
+        partials[((int64_t)q * gridDim.x + blockIdx.x) * kLanes + lane] = t;
+    }
+}
+static_assert(WG / 64 == 4, "k_mm_step folds its four quantities with four wavefronts");
+
+// per-column fold of the step's partials: workgroup (col, q) adds partials[q][0 .. count)[col] in a fixed order
+__global__ __launch_bounds__(WG) void k_mm_fold4(const double* __restrict__ partials, int count, const BatchState* __restrict__ state,
+                                                  double* __restrict__ out /* [4][64] */) {
+    __shared__ double s_red[WG / 64];
+    if (state->all_done | state->paused) return;
+    const int col = blockIdx.x, q = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += WG) acc += partials[((int64_t)q * count + i) * kLanes + col];
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) s_red[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = s_red[0];
+#pragma unroll
+        for (int k = 1; k < WG / 64; ++k) t += s_red[k];
+        out[q * kLanes + col] = t;
+    }
+}
+
+// the separate residual pass (first step of a run, the max rule, graph_dropout, paused steps): sum_r |y_r / S - yold_r * scale| per
+// column from the two gather slabs (y = xg * (1 / s')); S = the step's folded sum(y) (folded[0]), scale = the previous quotient
+__global__ __launch_bounds__(WG) void k_mm_residual2(const float* __restrict__ xg_new, const float* __restrict__ xg_old, const f32x4* __restrict__ rowop,
+                                                      int64_t n, int ld, int b, int use_quotient, int linf, const BatchState* __restrict__ state,
+                                                      const double* __restrict__ folded, double* __restrict__ partial_res,
+                                                      const uint8_t* __restrict__ row_flags, int resume) {
     __shared__ double s_red[WG / 64][kLanes];
-    if (state->all_done) return;
+    if (state->all_done | (resume ? 0 : state->paused)) return;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
     const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
     const int l = lane & (lpr - 1), c4 = 4 * l;
@@ -426,7 +586,7 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const bool col = c4 + k < b;
-        const double S = col ? state->sum[c4 + k] : 1.0;
+        const double S = col ? folded[c4 + k] : 1.0;
         inv[k] = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
         scale[k] = col ? state->scale[c4 + k] : 1.0;
         want[k] = col && !state->done[c4 + k];
@@ -436,40 +596,38 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
     const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
     constexpr int U = PGH_MM_RES_U;
     if (any) {
-        // the row flags of a trip are fetched one trip ahead (a flag -> row load chain per trip left the loads of half-dead trips
-        // -- 55 % of the rows of the bench graph are skipped -- with too little in flight: 3.0 TB/s)
         uint8_t fl_next[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t r = first + u * stride;
-            fl_next[u] = (r < n && row_flags != nullptr) ? row_flags[r] : (uint8_t)1;
+            fl_next[u] = r < n ? row_flags[r] : (uint8_t)0;
         }
         for (int64_t r0 = first; r0 < n; r0 += stride * U) {
             f32x4 a[U], o[U];
+            float un[U];
             bool use[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t r = r0 + u * stride;
-                // rows that are zero in every iterate (row flags 0: no entries, no personalization) add |0 - 0|: not read
-                use[u] = r < n && fl_next[u] != 0;
+                use[u] = fl_next[u] != 0;                 // rows that are zero in every iterate add |0 - 0|: not read
                 const int64_t rn = r + stride * U;
-                fl_next[u] = (rn < n && row_flags != nullptr) ? row_flags[rn] : (uint8_t)1;
+                fl_next[u] = rn < n ? row_flags[rn] : (uint8_t)0;
                 const int64_t at = (use[u] ? r : 0) * ld + c4;
-                a[u] = use[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                o[u] = use[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                a[u] = use[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xg_new + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                o[u] = use[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xg_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                un[u] = use[u] ? rowop[r][2] : 1.f;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (!use[u]) continue;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const double d = fabs((double)a[u][k] * inv[k] - (double)o[u][k] * scale[k]);
+                    const double d = fabs((double)(a[u][k] * un[u]) * inv[k] - (double)(o[u][k] * un[u]) * scale[k]);
                     acc[k] = linf ? fmax(acc[k], d) : acc[k] + d;
                 }
             }
         }
     }
-    // fold the lane groups (same columns) in group order, then the wavefronts in wavefront order
     for (int j = threadIdx.x; j < (WG / 64) * kLanes; j += WG) (&s_red[0][0])[j] = 0.0;      // columns beyond 4 * lanes
     __syncthreads();
 #pragma unroll
@@ -490,20 +648,82 @@ __global__ __launch_bounds__(WG) void k_mm_residual(const float* __restrict__ y,
     }
 }
 
-// closes a batched step: per-column quotient, step count and ConvergenceManager check (convergence.py:96-101)
-__global__ void k_mm_close(BatchState* __restrict__ state, int use_quotient, int check, int err_kind, double tol, int64_t n_orig) {
+// per-column fold of one quantity ([count][64] partials; sum or max), resume: also behind a pending pause
+__global__ __launch_bounds__(WG) void k_mm_fold1(const double* __restrict__ partials, int count, int linf, const BatchState* __restrict__ state,
+                                                  double* __restrict__ out, int resume) {
+    __shared__ double s_red[WG / 64];
+    if (state->all_done | (resume ? 0 : state->paused)) return;
+    const int col = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += WG) {
+        const double v = partials[(int64_t)i * kLanes + col];
+        acc = linf ? fmax(acc, v) : acc + v;
+    }
+    acc = linf ? wave_reduce_max(acc) : wave_reduce_sum(acc);
+    if (lane == 0) s_red[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = s_red[0];
+#pragma unroll
+        for (int k = 1; k < WG / 64; ++k) t = linf ? fmax(t, s_red[k]) : t + s_red[k];
+        out[col] = t;
+    }
+}
+
+// closes a batched step: per-column quotient, step count, ConvergenceManager check (convergence.py:96-101) and the NEXT step's predicted
+// quotient.  mode 1: the residual came from k_mm_step against the predicted quotient (folded[2], folded[3]); mode 0 / 2: from the
+// separate kernel (state->err holds the folded value; 2 = first step: folded[3] is sum(p)).  resume: this close answers a pause.
+struct CloseParams {
+    double tol, alpha;
+    long long n_orig;
+    int use_quotient, check, err_kind, mode, resume;
+};
+__global__ void k_mm_close2(BatchState* __restrict__ state, const double* __restrict__ folded, const double* __restrict__ err_folded, CloseParams cp) {
     const int lane = threadIdx.x;
-    const bool live = lane < state->b;
+    if (state->all_done | (cp.resume ? 0 : state->paused)) return;
+    const bool live = lane < state->b && !state->done[lane];
+    const double S = folded[lane], T = folded[kLanes + lane], R = folded[2 * kLanes + lane], D = folded[3 * kLanes + lane];
+    const double scale_new = cp.use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+    const double sum_p = cp.mode == 2 ? D : state->sum_p[lane];
+    // with the factors as k_mm_step forms them: (float)(alpha * scale), (float)(1 - alpha)
+    const double next_raw = (double)(float)(cp.alpha * scale_new) * T + (double)(float)(1.0 - cp.alpha) * sum_p;
+    const double raw_now = state->pred_raw[lane];
+    const double ratio = (cp.mode == 1 && raw_now != 0.0) ? S / raw_now : 1.0;
+    const double S_next = next_raw * ((ratio == ratio && fabs(ratio - 1.0) < 1e-4) ? ratio : 1.0);
+    const double pred_next = cp.use_quotient ? (S_next != 0.0 ? 1.0 / S_next : 0.0) : 1.0;
+    double err = 0.0, slack = 0.0;
+    int verdict = 0;
+    if (cp.check && live) {
+        if (cp.mode == 1) {
+            const double ip = state->pred_inv[lane];
+            err = R + (scale_new - ip) * D;
+            slack = 2.0 * fabs(scale_new - ip) * fabs(S);
+        } else {
+            err = err_folded[lane];
+        }
+        if (cp.err_kind == PGH_ERR_MABS) {
+            err /= (double)cp.n_orig;
+            slack /= (double)cp.n_orig;
+        }
+        if (cp.mode == 1 && !(fabs(err - cp.tol) > 2.0 * slack)) verdict = 2;       // too close to call (or not finite)
+        else if (err <= cp.tol) verdict = 1;
+    }
+    const unsigned long long pause = __ballot(verdict == 2);
+    if (pause != 0ULL) {                                   // nothing of the step is committed: the host re-evaluates it (mode 0, resume)
+        if (lane == 0) state->paused = 1;
+        return;
+    }
     int done = 1;
-    if (live && !state->done[lane]) {
-        const double S = state->sum[lane];
-        state->scale[lane] = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+    if (live) {
+        state->scale[lane] = scale_new;
+        state->sum[lane] = S;
+        state->sum_p[lane] = sum_p;
+        state->pred_inv[lane] = pred_next;
+        state->pred_raw[lane] = next_raw;
         state->steps[lane] += 1;
-        if (check) {
-            double e = state->err[lane];
-            if (err_kind == PGH_ERR_MABS) e /= (double)n_orig;
-            state->err[lane] = e;
-            if (e <= tol) {
+        if (cp.check) {
+            state->err[lane] = err;
+            if (verdict == 1) {
                 state->done[lane] = 1;
                 state->converged[lane] = 1;
             }
@@ -511,7 +731,11 @@ __global__ void k_mm_close(BatchState* __restrict__ state, int use_quotient, int
         done = state->done[lane];
     }
     const unsigned long long all = __ballot(done != 0);
-    if (lane == 0) state->all_done = (all == ~0ULL) ? 1 : 0;
+    if (lane == 0) {
+        state->all_done = (all == ~0ULL) ? 1 : 0;
+        state->paused = 0;
+        state->executed += 1;
+    }
 }
 
 __global__ void k_mm_state_init(BatchState* state, int b) {
@@ -519,12 +743,103 @@ __global__ void k_mm_state_init(BatchState* state, int b) {
     state->scale[lane] = 1.0;
     state->err[lane] = 0.0;
     state->sum[lane] = 0.0;
+    state->pred_inv[lane] = 1.0;
+    state->pred_raw[lane] = 0.0;
+    state->sum_p[lane] = 0.0;
     state->done[lane] = lane < b ? 0 : 1;
     state->steps[lane] = 0;
     state->converged[lane] = 0;
     if (lane == 0) {
         state->all_done = 0;
+        state->paused = 0;
+        state->executed = 0;
         state->b = b;
+    }
+}
+
+// the epilogue's row operands in the multi-seed id space, one 16-byte word per row (ensure_mm_layout)
+__global__ __launch_bounds__(WG) void k_mm_rowops(const float* __restrict__ dst_scale, const float* __restrict__ src_scale, const float* __restrict__ degrees,
+                                                   const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, f32x4* __restrict__ out) {
+    for (int64_t r = blockIdx.x * (int64_t)WG + threadIdx.x; r < n_int; r += (int64_t)gridDim.x * WG) {
+        const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
+        const float s = src_scale != nullptr ? src_scale[r] : 1.f;
+        const float sp = s != 0.f ? s : 1.f;               // a row nobody gathers keeps y itself in the slab
+        out[r] = f32x4{dst_scale != nullptr ? dst_scale[r] : 1.f, sp, 1.f / sp, (o >= 0 && degrees != nullptr) ? degrees[o] : 0.f};
+    }
+}
+
+// caller-space slabs -> the loop's internal slabs in ONE pass: the personalization (rows that hold a non-zero only: nobody reads the
+// others), the first gather slab (start iterate * s', every row), zeros in the rows of the second slab that no step will ever write,
+// and the row flags.  (Round 4 wrote three whole slabs here.)
+struct PermuteIn2 {
+    const float* src_p;      // caller's personalization [n, b]
+    const float* src_x;      // caller's start iterate [n, b]; may equal src_p
+    float*       out_p;      // [n_int, ld]
+    float*       out_xg0;    // [n_int, ld]
+    float*       out_xg1;    // [n_int, ld]
+    const f32x4* rowop;
+    uint8_t*     row_flags;  // [n_int] bit 0: the row of p holds a non-zero; bit 1: the row of M^T holds entries (row_has; all rows when null)
+    const uint8_t* row_has;
+};
+__global__ __launch_bounds__(WG) void k_mm_permute_in2(PermuteIn2 q, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, int b, int ld) {
+    const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
+    const int lane = threadIdx.x & 63, l = lane & (lpr - 1), c4 = 4 * l;
+    if (c4 >= ld) return;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + (threadIdx.x >> 6)) * rows_per_wave + lane / lpr;
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
+    const bool vec = (b & 3) == 0;
+    for (int64_t r = first; r < n_int; r += stride) {
+        const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
+        auto fetch = [&](const float* src) __attribute__((always_inline)) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (o >= 0) {
+                if (vec) v = *reinterpret_cast<const f32x4*>(src + o * b + c4);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c4 + k < b) v[k] = src[o * b + c4 + k];
+                }
+            }
+            return v;
+        };
+        const int64_t at = r * ld + c4;
+        const f32x4 vp = fetch(q.src_p);
+        const bool nz = vp.x != 0.f || vp.y != 0.f || vp.z != 0.f || vp.w != 0.f;
+        const unsigned long long any = __ballot(nz) >> (lane & ~(lpr - 1));       // this row's lanes from bit 0 on
+        const int flags = ((any & ((1ULL << lpr) - 1ULL)) != 0ULL ? 1 : 0) | ((q.row_has == nullptr || q.row_has[r] != 0) ? 2 : 0);
+        if (l == 0) q.row_flags[r] = (uint8_t)flags;
+        if (flags & 1) *reinterpret_cast<f32x4*>(q.out_p + at) = vp;
+        const f32x4 vx = q.src_x == q.src_p ? vp : fetch(q.src_x);
+        *reinterpret_cast<f32x4*>(q.out_xg0 + at) = vx * q.rowop[r][1];
+        if (flags == 0) *reinterpret_cast<f32x4*>(q.out_xg1 + at) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// ranks out of the loop: dst[old id] = xg[r] * (1 / s') * column factor (rows whose flag is 0 are zero: the caller has cleared dst)
+__global__ __launch_bounds__(WG) void k_mm_permute_out2(const float* __restrict__ xg, const f32x4* __restrict__ rowop, const int32_t* __restrict__ perm,
+                                                         int64_t n_int, int64_t n_valid, int b, int ld, const double* __restrict__ col_factor,
+                                                         float* __restrict__ dst, const uint8_t* __restrict__ row_flags) {
+    const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
+    const int lane = threadIdx.x & 63, l = lane & (lpr - 1), c4 = 4 * l;
+    if (c4 >= b) return;
+    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + (threadIdx.x >> 6)) * rows_per_wave + lane / lpr;
+    const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
+    const bool vec = (b & 3) == 0;
+    f32x4 factor = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (c4 + k < b) factor[k] = (float)col_factor[c4 + k];
+    for (int64_t r = first; r < n_int; r += stride) {
+        if (row_flags[r] == 0) continue;
+        const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
+        if (o < 0) continue;
+        const f32x4 v = (__builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xg + r * ld + c4)) * rowop[r][2]) * factor;
+        if (vec) *reinterpret_cast<f32x4*>(dst + o * b + c4) = v;
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c4 + k < b) dst[o * b + c4 + k] = v[k];
+        }
     }
 }
 
@@ -655,6 +970,12 @@ int ensure_mm_layout(pgh_graph_s* g) {
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(rt().stream));
     f.device_bytes += f.n_out;
+    PGH_HIP(hipMalloc(&f.mm_rowop, sizeof(float) * 4 * (size_t)(f.n_out > 0 ? f.n_out : 1)));
+    k_mm_rowops<<<blocks_for(f.n_out), WG, 0, rt().stream>>>(f.dst_scale, f.src_scale, g->degrees, f.perm, f.n_out, g->n_rows,
+                                                              reinterpret_cast<f32x4*>(f.mm_rowop));
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    f.device_bytes += (int64_t)f.n_out * 16;
     return 0;
 }
 
@@ -820,6 +1141,25 @@ extern "C" int pgh_ppr_run_batch_dropout(pgh_graph_t g, pgh_mat_t p, pgh_mat_t r
 }
 
 namespace {
+// what the host polls after every step: the tail of BatchState, copied to a pinned ring by the stream (no queue drain per look)
+struct BatchPoll {
+    int all_done, paused, executed, b;
+};
+constexpr int kPollRing = 8;
+struct PollRing {
+    BatchPoll* host = nullptr;       // pinned [kPollRing]
+    hipEvent_t ev[kPollRing] = {nullptr};
+};
+int poll_ring(PollRing** out) {
+    static PollRing ring;
+    if (ring.host == nullptr) {
+        PGH_HIP(hipHostMalloc(reinterpret_cast<void**>(&ring.host), sizeof(BatchPoll) * kPollRing, hipHostMallocDefault));
+        for (int i = 0; i < kPollRing; ++i) PGH_HIP(hipEventCreateWithFlags(&ring.ev[i], hipEventDisableTiming));
+    }
+    *out = &ring;
+    return 0;
+}
+
 int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* cfg, const double* out_scales, double rate, uint64_t seed0,
                pgh_loop_result* results) {
     PGH_CHECK(g && p && ranks && cfg && results, "pgh_ppr_run_batch: null argument");
@@ -832,98 +1172,145 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
     const int b = p->b, ld = (b + 3) & ~3;
     const int64_t n = g->n_cols, n_int = f.n_out;
     const size_t slab = sizeof(float) * (size_t)n_int * ld;
-    DevBytes pint, xg, sums, y0, y1, partial, state_mem, factors, p_rows;
-    PGH_TRY(p_rows.alloc((size_t)n_int));
+    const f32x4* rowop = reinterpret_cast<const f32x4*>(f.mm_rowop);
+    DevBytes pint, xg0, xg1, sums, partial, folded, state_mem, factors, row_flags;
+    PGH_TRY(row_flags.alloc((size_t)n_int));
     // rows without entries and without personalization are zero in every iterate when the loop starts from p (they are then
-    // zero in the start iterate too): the second iterate buffer gets its zeros here, after that nobody touches those rows
+    // zero in the start iterate too): nobody reads or writes them after the way in
     const bool skip_dead = cfg->start_from_p != 0 && f.mm_row_has != nullptr;
     PGH_TRY(pint.alloc(slab));
-    PGH_TRY(xg.alloc(slab));
+    PGH_TRY(xg0.alloc(slab));
+    PGH_TRY(xg1.alloc(slab));
     PGH_TRY(sums.alloc(slab));
-    PGH_TRY(y0.alloc(slab));
-    PGH_TRY(y1.alloc(slab));
     const int cgrid = combine_grid();
-    PGH_TRY(partial.alloc(sizeof(double) * (size_t)cgrid * kLanes));
+    PGH_TRY(partial.alloc(sizeof(double) * 4 * (size_t)cgrid * kLanes));
+    PGH_TRY(folded.alloc(sizeof(double) * 5 * kLanes));                  // S, T, R', D of the step + the separate kernel's residual
     PGH_TRY(state_mem.alloc(sizeof(BatchState)));
     PGH_TRY(factors.alloc(sizeof(double) * kLanes));
     BatchState* state = state_mem.as<BatchState>();
+    PollRing* ring = nullptr;
+    PGH_TRY(poll_ring(&ring));
     hipEvent_t ev_a, ev_b;
     PGH_HIP(hipEventCreate(&ev_a));
     PGH_HIP(hipEventCreate(&ev_b));
     PGH_HIP(hipEventRecord(ev_a, r.stream));
-    if (skip_dead) PGH_HIP(hipMemsetAsync(y1.p, 0, slab, r.stream));    // rows nobody will ever write (sums of rows without entries are not read)
-    else PGH_HIP(hipMemsetAsync(sums.p, 0, slab, r.stream));            // structural zeros of the rows without entries
+    if (!skip_dead) PGH_HIP(hipMemsetAsync(sums.p, 0, slab, r.stream));      // structural zeros of the rows without entries (every row is processed)
     k_mm_state_init<<<1, kLanes, 0, r.stream>>>(state, b);
     {
-        PermuteIn q{};
-        q.src_a = p->data;
-        q.src_b = cfg->start_from_p ? p->data : ranks->data;                  // abstract_filters.py:56 without warm_start
-        q.out_a = pint.as<float>();
-        q.a_row_nz = p_rows.as<uint8_t>();
-        q.row_has = skip_dead ? f.mm_row_has : nullptr;          // null: every row counts as holding entries
-        q.out_b = y0.as<float>();
-        q.out_bs = xg.as<float>();
-        q.row_scale = f.src_scale;
-        k_mm_permute_in<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(q, f.perm, n_int, n, b, ld);
+        PermuteIn2 q{};
+        q.src_p = p->data;
+        q.src_x = cfg->start_from_p ? p->data : ranks->data;                  // abstract_filters.py:56 without / with warm_start
+        q.out_p = pint.as<float>();
+        q.out_xg0 = xg0.as<float>();
+        q.out_xg1 = xg1.as<float>();
+        q.rowop = rowop;
+        q.row_flags = row_flags.as<uint8_t>();
+        q.row_has = skip_dead ? f.mm_row_has : nullptr;                       // null: every row counts as holding entries
+        k_mm_permute_in2<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(q, f.perm, n_int, n, b, ld);
     }
-    float* buf[2] = {y0.as<float>(), y1.as<float>()};
+    float* buf[2] = {xg0.as<float>(), xg1.as<float>()};
+    double* fold = folded.as<double>();
     const int linf = cfg->err_kind == PGH_ERR_LINF;
     const int max_steps = cfg->max_iters - 1 > 0 ? cfg->max_iters - 1 : 0;
-    BatchState host_state;
-    memset(&host_state, 0, sizeof(host_state));
-    bool done = false;
-    int enq = 0;
-    while (!done && enq < max_steps) {
-        const int upto = (enq + 4 < max_steps) ? enq + 4 : max_steps;
-        for (; enq < upto; ++enq) {
-            const int k = enq + 1;
-            float* yin = buf[(k - 1) & 1];
-            float* yout = buf[k & 1];
-            MMDrop drop_store;
-            const MMDrop* drop = nullptr;
-            PGH_TRY(make_drop(g, rate, seed0 + (uint64_t)(k - 1), &drop_store, &drop));
-            PGH_TRY(mm_partial(g, xg.as<float>(), ld, b, sums.as<float>(), state, drop));
-            CombineParams c{};
-            c.sums = sums.as<float>();
-            c.dst_scale = f.dst_scale;
-            c.src_scale = f.src_scale;
-            c.p = pint.as<float>();
-            c.p_row_nz = p_rows.as<uint8_t>();
-            c.y_old = yin;
-            c.y = yout;
-            c.xg_out = xg.as<float>();
-            c.alpha = cfg->alpha;
-            {
-                ProfScope prof(PGH_K_COMBINE);
-                k_mm_combine<<<cgrid, WG, 0, r.stream>>>(c, n_int, ld, b, state, partial.as<double>());
-            }
-            k_mm_fold<<<kLanes, WG, 0, r.stream>>>(partial.as<double>(), cgrid, 0, reinterpret_cast<double*>(state) + 2 * kLanes);   // -> state.sum
-            const int it = k + 1;
-            const int check = (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0);
-            if (check) {
-                ProfScope prof(PGH_K_RESIDUAL);
-                k_mm_residual<<<cgrid, WG, 0, r.stream>>>(yout, yin, n_int, ld, b, cfg->use_quotient, linf, state, partial.as<double>(),
-                                                          skip_dead ? p_rows.as<uint8_t>() : nullptr);
-                k_mm_fold<<<kLanes, WG, 0, r.stream>>>(partial.as<double>(), cgrid, linf, reinterpret_cast<double*>(state) + kLanes);     // -> state.err
-            }
-            k_mm_close<<<1, kLanes, 0, r.stream>>>(state, cfg->use_quotient, check, cfg->err_kind, cfg->tol, n);
+    // the in-kernel residual: sum rules, the plain matrix (a dropped matrix has other column sums every step), PGH_MM_FUSED=0 turns it off
+    bool fused = (cfg->err_kind == PGH_ERR_L1 || cfg->err_kind == PGH_ERR_MABS) && rate == 0.0 &&
+                 !(getenv("PGH_MM_FUSED") != nullptr && atoi(getenv("PGH_MM_FUSED")) == 0);
+    int flags = fused ? 2 : 0;
+    CloseParams cp{};
+    cp.tol = cfg->tol;
+    cp.alpha = cfg->alpha;
+    cp.n_orig = n;
+    cp.use_quotient = cfg->use_quotient;
+    cp.err_kind = cfg->err_kind;
+    auto check_of = [&](int k) { const int it = k + 1; return (cfg->err_kind != PGH_ERR_ITERS) && (it < cfg->max_iters) && (it % cfg->end_modulo == 0); };
+    // the separate residual of step k + its close (first step, max rule, dropout, a paused step)
+    auto close_plain = [&](int k, int mode, int resume) -> int {
+        const int check = check_of(k) ? 1 : 0;
+        if (check) {
+            ProfScope prof(PGH_K_RESIDUAL);
+            k_mm_residual2<<<cgrid, WG, 0, r.stream>>>(buf[k & 1], buf[(k - 1) & 1], rowop, n_int, ld, b, cfg->use_quotient, linf, state, fold,
+                                                       partial.as<double>(), row_flags.as<uint8_t>(), resume);
+            k_mm_fold1<<<kLanes, WG, 0, r.stream>>>(partial.as<double>(), cgrid, linf, state, fold + 4 * kLanes, resume);
+        }
+        CloseParams c2 = cp;
+        c2.check = check;
+        c2.mode = mode;
+        c2.resume = resume;
+        k_mm_close2<<<1, kLanes, 0, r.stream>>>(state, fold, fold + 4 * kLanes, c2);
+        PGH_HIP(hipGetLastError());
+        return 0;
+    };
+    auto enqueue_step = [&](int k) -> int {
+        MMDrop drop_store;
+        const MMDrop* drop = nullptr;
+        PGH_TRY(make_drop(g, rate, seed0 + (uint64_t)(k - 1), &drop_store, &drop));
+        PGH_TRY(mm_partial(g, buf[(k - 1) & 1], ld, b, sums.as<float>(), state, drop));
+        const int mode = k == 1 ? 2 : (fused ? 1 : 0);
+        StepParams c{};
+        c.sums = sums.as<float>();
+        c.rowop = rowop;
+        c.p = pint.as<float>();
+        c.row_flags = row_flags.as<uint8_t>();
+        c.xg_old = buf[(k - 1) & 1];
+        c.xg_new = buf[k & 1];
+        c.alpha = cfg->alpha;
+        c.mode = mode;
+        {
+            ProfScope prof(PGH_K_COMBINE);
+            k_mm_step<<<cgrid, WG, 0, r.stream>>>(c, n_int, ld, b, state, partial.as<double>());
+        }
+        k_mm_fold4<<<dim3(kLanes, 4), WG, 0, r.stream>>>(partial.as<double>(), cgrid, state, fold);
+        if (mode == 1) {
+            CloseParams c2 = cp;
+            c2.check = check_of(k) ? 1 : 0;
+            c2.mode = 1;
+            k_mm_close2<<<1, kLanes, 0, r.stream>>>(state, fold, fold + 4 * kLanes, c2);
+        } else {
+            PGH_TRY(close_plain(k, mode, 0));
         }
         PGH_HIP(hipGetLastError());
-        PGH_HIP(hipMemcpyAsync(&host_state, state, sizeof(BatchState), hipMemcpyDeviceToHost, r.stream));
-        PGH_HIP(hipStreamSynchronize(r.stream));
-        done = host_state.all_done != 0;
+        PGH_HIP(hipMemcpyAsync(&ring->host[k % kPollRing], &state->all_done, sizeof(BatchPoll), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipEventRecord(ring->ev[k % kPollRing], r.stream));
+        return 0;
+    };
+    // the host keeps up to three steps enqueued beyond the last one whose outcome it has seen; launches behind a stop or a pause are no-ops
+    int enq = 0, seen = 0;
+    bool stop = false;
+    while (!stop) {
+        while (enq < max_steps && enq - seen < 3) {
+            PGH_TRY(enqueue_step(enq + 1));
+            ++enq;
+        }
+        if (seen == enq) break;
+        const int k = seen + 1;
+        PGH_HIP(hipEventSynchronize(ring->ev[k % kPollRing]));
+        const BatchPoll poll = ring->host[k % kPollRing];
+        ++seen;
+        if (poll.paused) {
+            // step k ran but for its close; the steps enqueued behind it saw the pause and did nothing.  The separate kernel decides, the
+            // run goes on without the fusion (a negative or non-finite value would pause every step)
+            flags |= 1;
+            fused = false;
+            PGH_TRY(close_plain(k, 0, 1));
+            PGH_HIP(hipMemcpyAsync(&ring->host[0], &state->all_done, sizeof(BatchPoll), hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipStreamSynchronize(r.stream));
+            enq = seen;
+            stop = ring->host[0].all_done != 0;
+        } else if (poll.all_done) {
+            stop = true;
+        }
     }
+    BatchState host_state;
     PGH_HIP(hipMemcpyAsync(&host_state, state, sizeof(BatchState), hipMemcpyDeviceToHost, r.stream));
     PGH_HIP(hipStreamSynchronize(r.stream));
-    // the iterate of a column that stopped early was copied forward unchanged by every later executed step
+    // the slab row of a column that stopped early was copied forward unchanged by every later executed step
     double h_factors[kLanes];
     for (int j = 0; j < kLanes; ++j) h_factors[j] = j < b ? host_state.scale[j] * (out_scales ? out_scales[j] : cfg->out_scale) : 1.0;
     PGH_HIP(hipMemcpyAsync(factors.p, h_factors, sizeof(h_factors), hipMemcpyHostToDevice, r.stream));
-    int executed = 0;                                    // steps that ran before every column had stopped
-    for (int j = 0; j < b; ++j) executed = host_state.steps[j] > executed ? host_state.steps[j] : executed;
-    if (skip_dead) PGH_HIP(hipMemsetAsync(ranks->data, 0, sizeof(float) * (size_t)n * b, r.stream));      // the rows that stayed zero
-    k_mm_permute_out<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(buf[executed & 1], f.perm, n_int, n, b, ld, factors.as<double>(), ranks->data,
-                                                                                   skip_dead ? p_rows.as<uint8_t>() : nullptr);
+    const int executed = host_state.executed;              // steps that ran before every column had stopped
+    PGH_HIP(hipMemsetAsync(ranks->data, 0, sizeof(float) * (size_t)n * b, r.stream));      // the rows that stayed zero / ids without a row
+    k_mm_permute_out2<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(buf[executed & 1], rowop, f.perm, n_int, n, b, ld, factors.as<double>(),
+                                                                                    ranks->data, row_flags.as<uint8_t>());
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipEventRecord(ev_b, r.stream));
     PGH_HIP(hipEventSynchronize(ev_b));
@@ -938,6 +1325,7 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
         results[j].spmv_count = host_state.steps[j];
         results[j].last_error = host_state.err[j];
         results[j].loop_ms = (double)ms;
+        results[j].flags = flags;
     }
     return 0;
 }
