@@ -892,9 +892,14 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
         // (a fixed number of predicated stores: no loop of unknown length between the counted waits)
 #if !(PGH_PROBE_SKIP & 1)
         float* __restrict__ dst = psum + (g0.seg_base + 1);
+        // (a tile closes ~45 segments on the bench graph: one predicated store serves it; the seven others hide behind ONE
+        // wave-uniform test instead of a vector compare and an exec branch each)
+        if (lane < closed) dst[lane] = seg[1 + lane];
+        if (closed > 64) {
 #pragma unroll
-        for (int k = 0; k < IPT; ++k)
-            if (64 * k + lane < closed) dst[64 * k + lane] = seg[1 + 64 * k + lane];
+            for (int k = 1; k < IPT; ++k)
+                if (64 * k + lane < closed) dst[64 * k + lane] = seg[1 + 64 * k + lane];
+        }
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
