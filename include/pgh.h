@@ -54,7 +54,8 @@ int pgh_timer_elapsed_ms(pgh_timer_t t, double* ms);   /* synchronises on the st
 /* per-kernel HIP-event profiling of the propagation kernels (bench.py roofline leg) */
 enum { PGH_K_SPMV = 0, PGH_K_FIXUP = 1, PGH_K_RESIDUAL = 2, PGH_K_FINAL = 3, PGH_K_SPMM = 4, PGH_K_COMBINE = 5,
        PGH_K_PB_GATHER = 6, PGH_K_PB_ACCUM = 7,     /* propagation-blocking passes of the cold tail (pgh_pb.hip) */
-       PGH_K_COUNT = 8 };
+       PGH_K_PACK = 8,                              /* per-destination packing of a partition's exchange (pgh_dist_pack) */
+       PGH_K_COUNT = 9 };
 int pgh_profile_enable(int on);
 int pgh_profile_reset(void);
 int pgh_profile_read(int kernel_id, int64_t* launches, double* total_ms);
@@ -298,6 +299,24 @@ int pgh_dist_prescale(pgh_graph_t g, pgh_vec_t x_local, pgh_vec_t xg_local_out);
 int pgh_graph_gather_layout(pgh_graph_t g, int32_t* num_blocks, int64_t* blk_size, int32_t* live /* [8] */);
 int pgh_graph_set_gather_bases(pgh_graph_t g, const int64_t* bases /* [num_blocks] */);
 
+/* Need lists ("grouped ncclSend/ncclRecv for exact uneven slices"; pygrank has no distributed counterpart,
+ * documentation/tips.md:5-7).  A slice whose cold entries all live in the propagation-blocking image numbers its cold sources
+ * COMPACTLY: block b of the gathered vector holds, from cold_bases[b] on (pgh_graph_set_gather_bases_split), the values of the
+ * counts[b] cold slots (slot >= hot prefix) THIS slice references, in ascending slot order -- a rank of an 8-way partition references
+ * ~43 % of the live slots.  counts all zero: the slice keeps the dense layout (small slices, PGH_DIST_NEED_LISTS=0) and
+ * pgh_graph_set_gather_bases applies.  pgh_dist_need_list copies block b's slots (slot - hot) to the host; the caller sends them to
+ * the block's owner once per graph.  The owner registers what its peers asked for (pgh_dist_set_send_lists: `segments` stretches,
+ * destination-major, stretch k = cold slots of its local block local_block[k]) and packs its slice of the next gather vector for
+ * all of them with ONE launch per step (pgh_dist_pack); the stretches travel point to point (ncclSend / ncclRecv, all_to_all).
+ * pgh_dist_compact_from_dense applies a slice's own list to a dense copy of a block's cold part (communicators without
+ * point-to-point transfers; single-process probes). */
+int pgh_dist_need_counts(pgh_graph_t g, int64_t* counts /* [num_blocks] */);
+int pgh_dist_need_list(pgh_graph_t g, int32_t block, uint32_t* out_host /* [counts[block]] */);
+int pgh_dist_set_send_lists(pgh_graph_t g, const uint32_t* slots_host, const int32_t* local_block /* [segments] */,
+                            const int64_t* seg_offsets /* [segments + 1] */, int32_t segments);
+int pgh_dist_pack(pgh_graph_t g, pgh_vec_t xg_local, pgh_vec_t send_buf);
+int pgh_dist_compact_from_dense(pgh_graph_t g, int32_t block, pgh_vec_t dense, int64_t dense_base, pgh_vec_t compact_out, int64_t out_base);
+
 /* Device-driven partitioned loop: the scalars of the iteration stay in DEVICE memory, the collectives (RCCL
  * all-reduce, issued by the caller on the engine stream) act on them in place, and no call below synchronises with
  * the host.  `state` = 64 bytes of device memory owned by the caller, viewed as 8 doubles:
@@ -376,7 +395,9 @@ typedef struct {
     int32_t split_regions;  /* 1 = hot prefixes and cold parts are exchanged as two contiguous regions          */
     int32_t flags;          /* bit 1: the residual was evaluated inside the finish kernel (one 4-scalar all-reduce per
                              * iteration); bit 0: ... and one step had to be re-evaluated by the separate kernel; bit 2: the
-                             * finish kernel ran as two launches (exchanged rows first: the exchange starts behind the first)  */
+                             * finish kernel ran as two launches (exchanged rows first: the exchange starts behind the first);
+                             * bit 3: the cold parts travelled by need lists (point to point), bit 4: by all-gather with this slice
+                             * copying its referenced slots out of it (neither: the dense layout and the all-gather alone)     */
     double  last_error;
     double  loop_ms;        /* HIP-event time of the loop on the compute stream                                 */
     int64_t exchange_bytes; /* received per rank and iteration                                                  */
@@ -391,6 +412,13 @@ int pgh_comm_create(const uint8_t* ids /* [num_ids * PGH_COMM_ID_BYTES] */, int3
 typedef int (*pgh_allgather_fn)(void* user, const void* send_dev, void* recv_dev, int64_t count, int32_t dtype, void* hip_stream);
 typedef int (*pgh_allreduce_fn)(void* user, void* buf_dev, int64_t count, int32_t dtype, int32_t op, void* hip_stream);
 int pgh_comm_create_external(int32_t world, int32_t rank, pgh_allgather_fn all_gather, pgh_allreduce_fn all_reduce, void* user, pgh_comm_t* out);
+/* ... and, optionally, the point-to-point exchange of the need lists (pgh_dist_need_counts): 4-byte elements, rank r's stretch of `send_dev`
+ * starts at send_offs[r] and holds send_counts[r] elements, what rank r sent lands at recv_offs[r] (recv_counts[r] elements); the stretch
+ * a rank sends to itself is included.  Without it a host-collective communicator keeps the all-gather and compact slices copy their
+ * slots out of it (pgh_dist_compact_from_dense). */
+typedef int (*pgh_alltoallv_fn)(void* user, const void* send_dev, const int64_t* send_counts, const int64_t* send_offs, void* recv_dev,
+                                const int64_t* recv_counts, const int64_t* recv_offs, void* hip_stream);
+int pgh_comm_set_alltoallv(pgh_comm_t c, pgh_alltoallv_fn all_to_all_v);
 int pgh_comm_destroy(pgh_comm_t comm);
 int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t comm, pgh_vec_t p_local, pgh_vec_t ranks_local, const pgh_dist_cfg* cfg,
                      pgh_dist_result* res);

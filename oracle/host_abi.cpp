@@ -1335,6 +1335,25 @@ int pgh_dist_close_sum(double* state, int32_t use_quotient) {
     st->steps += 1;
     return 0;
 }
+// need lists: the host restatement keeps the dense gather layout (it has no hot / cold split at all): every count is zero, which the
+// callers read as "this slice exchanges by all-gather"
+int pgh_dist_need_counts(pgh_graph_t g, int64_t* counts) {
+    CHECK(g && g->gather_blk > 0 && counts, "pgh_dist_need_counts: not a partitioned graph");
+    for (int b = 0; b < g->gather_blocks; ++b) counts[b] = 0;
+    return 0;
+}
+int pgh_dist_need_list(pgh_graph_t, int32_t, uint32_t*) { return fail("pgh_dist_need_list: the host restatement keeps the dense layout"); }
+int pgh_dist_set_send_lists(pgh_graph_t g, const uint32_t*, const int32_t*, const int64_t* seg_offsets, int32_t segments) {
+    CHECK(g && (segments == 0 || (seg_offsets && seg_offsets[segments] == 0)), "pgh_dist_set_send_lists: the host restatement keeps the dense layout");
+    return 0;
+}
+int pgh_dist_pack(pgh_graph_t g, pgh_vec_t xg_local, pgh_vec_t send_buf) {
+    CHECK(g && xg_local && send_buf, "pgh_dist_pack: null argument");
+    return 0;                                               // no lists: nothing to pack
+}
+int pgh_dist_compact_from_dense(pgh_graph_t, int32_t, pgh_vec_t, int64_t, pgh_vec_t, int64_t) {
+    return fail("pgh_dist_compact_from_dense: the host restatement keeps the dense layout");
+}
 int pgh_dist_residual(int32_t kind, pgh_vec_t y_new, pgh_vec_t y_old, double* state) {
     CHECK(y_new && y_old && state && y_new->n == y_old->n, "pgh_dist_residual: bad arguments");
     DistState* st = reinterpret_cast<DistState*>(state);
@@ -1352,6 +1371,7 @@ int pgh_comm_create(const uint8_t*, int32_t, int32_t, int32_t, pgh_comm_t*) { re
 int pgh_comm_create_external(int32_t, int32_t, pgh_allgather_fn, pgh_allreduce_fn, void*, pgh_comm_t*) {
     return fail("pgh_comm_create_external: not available in the host double");
 }
+int pgh_comm_set_alltoallv(pgh_comm_t, pgh_alltoallv_fn) { return fail("pgh_comm_set_alltoallv: not available in the host double"); }
 int pgh_comm_destroy(pgh_comm_t) { return 0; }
 int pgh_dist_ppr_run(pgh_graph_t, pgh_comm_t, pgh_vec_t, pgh_vec_t, const pgh_dist_cfg*, pgh_dist_result*) {
     return fail("pgh_dist_ppr_run: not available in the host double");

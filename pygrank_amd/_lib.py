@@ -49,6 +49,8 @@ class DistResult(C.Structure):
 COMM_ID_BYTES = 128
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                           C.POINTER(C.c_int64), C.c_void_p)
 
 # name -> (restype, argtypes); every symbol include/pgh.h declares
 SIGNATURES = {
@@ -155,6 +157,11 @@ SIGNATURES = {
     "pgh_dist_watch_isolated": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgh_dist_release_isolated": (C.c_int, [C.c_void_p]),
     "pgh_dist_residual": (C.c_int, [C.c_int32, c_vec, c_vec, C.c_void_p]),
+    "pgh_dist_need_counts": (C.c_int, [c_graph, C.c_void_p]),
+    "pgh_dist_need_list": (C.c_int, [c_graph, C.c_int32, C.c_void_p]),
+    "pgh_dist_set_send_lists": (C.c_int, [c_graph, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "pgh_dist_pack": (C.c_int, [c_graph, c_vec, c_vec]),
+    "pgh_dist_compact_from_dense": (C.c_int, [c_graph, C.c_int32, c_vec, C.c_int64, c_vec, C.c_int64]),
     "pgh_dist_close_err": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int64]),
     "pgh_dist_prescale": (C.c_int, [c_graph, c_vec, c_vec]),
     "pgh_graph_perm": (C.c_int, [c_graph, C.c_void_p, c_i64p]),
@@ -162,6 +169,7 @@ SIGNATURES = {
     "pgh_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pgh_comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "pgh_comm_create_external": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pgh_comm_set_alltoallv": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgh_comm_destroy": (C.c_int, [C.c_void_p]),
     "pgh_dist_ppr_run": (C.c_int, [c_graph, C.c_void_p, c_vec, c_vec, C.POINTER(DistCfg), C.POINTER(DistResult)]),
     "pgh_dist_poly_run": (C.c_int, [c_graph, C.c_void_p, c_vec, C.c_void_p, C.c_int32, c_vec, C.POINTER(DistCfg), C.POINTER(DistResult)]),
@@ -177,7 +185,7 @@ ADD, SUB, MUL, DIV, POW, MAXOP, MINOP, GT, GE, LT, LE, EQ, NE = range(13)
 ABS, EXP, LOG, NEG, SQRT, SAFE_INV = range(6)
 SUM, ABSSUM, MAX, MIN = range(4)
 ERR_MABS, ERR_L1, ERR_LINF, ERR_ITERS = range(4)
-K_SPMV, K_FIXUP, K_RESIDUAL, K_FINAL, K_SPMM, K_COMBINE, K_PB_GATHER, K_PB_ACCUM = range(8)
+K_SPMV, K_FIXUP, K_RESIDUAL, K_FINAL, K_SPMM, K_COMBINE, K_PB_GATHER, K_PB_ACCUM, K_PACK = range(9)
 
 _lib = None
 _initialised = False

@@ -1592,6 +1592,8 @@ void bsf_destroy(BsfFormat& f) {
     (void)hipFree(f.seed_count);
     (void)hipFree(f.mm_row_has);
     (void)hipFree(f.mm_rowop);
+    (void)hipFree(f.need_idx);
+    (void)hipFree(f.send_rows);
     (void)hipFree(f.perm);
     (void)hipFree(f.src_scale);
     (void)hipFree(f.dst_scale);
@@ -1662,6 +1664,8 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     const int n_src_pad = B * blk;
     f.num_blocks = B;
     f.blk_size = blk;
+    // slices of a row partition: need lists (PGH_DIST_NEED_LISTS=0: the dense cold layout of rounds 1-4, exchanged by all-gather alone)
+    f.want_compact = !batch_layout && g->part_perm != nullptr && env_int("PGH_DIST_NEED_LISTS", 1) != 0;
     f.n_src = (int)n_src;
     f.n_src_pad = n_src_pad;
     f.relabelled = relabel;

@@ -253,6 +253,14 @@ struct BsfFormat {
     float*    part = nullptr;       // multi-seed layout only: per-tile head sums
     int32_t*  mm_close = nullptr;   // multi-seed layout only: closing row of every entry (k_mm_close_rows, pgh_spmm.hip)
     uint8_t*  mm_row_has = nullptr; // multi-seed layout only: 1 = the row of M^T holds entries (k_mm_mark_rows)
+    // need lists of a partition slice (pgh_dist_need_counts): the cold image numbers the cold sources THIS slice references
+    // compactly, block by block -- the exchange then moves those slots only, and a chunk of phase A holds referenced sources only
+    bool      want_compact = false;
+    uint32_t* need_idx = nullptr;   // [need_prefix[num_blocks]] slot - hot of every referenced cold slot, ascending, block-major
+    int64_t   need_prefix[9] = {0}; // compact cold ids of block b: [need_prefix[b], need_prefix[b + 1]); all zero: the dense layout
+    uint32_t* send_rows = nullptr;  // [send_total] local rows whose slots the peers asked for (pgh_dist_set_send_lists), destination-major
+    int64_t   send_total = 0;
+    unsigned long long send_stamp = 0;   // who registered the send lists: 0 = a caller (pgh_dist_set_send_lists), else the engine loop's set-up
     float*    mm_rowop = nullptr;   // multi-seed layout only: [n_out][4] {dst scale, gather scale s', 1 / s', row sum of M} per row: the epilogue's
                                     // row operands as ONE 16-byte word (k_mm_rowops, pgh_spmm.hip)
     int32_t*  mm_edge = nullptr;    // multi-seed layout, graph_dropout only: index of every stream entry in CSR(M^T) order (-1 = pad), the

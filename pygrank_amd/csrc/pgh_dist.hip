@@ -41,6 +41,10 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -62,6 +66,10 @@ int load_rccl() {
     PGH_RCCL_SYM(CommDestroy, "ncclCommDestroy")
     PGH_RCCL_SYM(AllGather, "ncclAllGather")
     PGH_RCCL_SYM(AllReduce, "ncclAllReduce")
+    PGH_RCCL_SYM(Send, "ncclSend")
+    PGH_RCCL_SYM(Recv, "ncclRecv")
+    PGH_RCCL_SYM(GroupStart, "ncclGroupStart")
+    PGH_RCCL_SYM(GroupEnd, "ncclGroupEnd")
     PGH_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef PGH_RCCL_SYM
     g_rccl.handle = h;
@@ -109,7 +117,18 @@ struct pgh_comm_s {
     // collectives supplied by the host instead of RCCL (pgh_comm_create_external): MPI, gloo, a test harness ...
     pgh_allgather_fn ext_gather = nullptr;
     pgh_allreduce_fn ext_reduce = nullptr;
+    pgh_alltoallv_fn ext_alltoallv = nullptr;
     void*            ext_user = nullptr;
+    // need lists (pgh_dist_need_counts): the cold parts travel point to point, every rank receives the slots its slice references
+    bool        lists = false;           // this run exchanges the cold parts by need lists
+    bool        compact_copy = false;    // dense exchange, compact image: the slice copies its slots out of the gathered vector
+    int64_t     need_total = 0, compact_at = 0, dense_cold_at = 0;
+    int64_t     send_counts[8] = {0}, send_offs[8] = {0}, recv_counts[8] = {0}, recv_offs[8] = {0};
+    float*      send_buf = nullptr;
+    int64_t     send_cap = 0;
+    unsigned long long lists_stamp = 0;
+    int64_t     dense_cold_base[8] = {0}, compact_base[8] = {0};
+    int64_t     exchange_bytes = 0;     // received per rank and iteration with the layout of the last prepare_graph
 };
 
 namespace {
@@ -141,7 +160,35 @@ int comm_all_reduce(pgh_comm_s* c, void* buf, size_t count, ncclDataType_t dt, n
     return 0;
 }
 
+// every rank's stretch for every other rank, point to point (4-byte elements; the stretch a rank keeps for itself is a device copy)
+int comm_all_to_all_v(pgh_comm_s* c, const void* send, const int64_t* scounts, const int64_t* soffs, void* recv, const int64_t* rcounts,
+                      const int64_t* roffs, hipStream_t st) {
+    if (c->ext_alltoallv != nullptr) {
+        PGH_CHECK(c->ext_alltoallv(c->ext_user, send, scounts, soffs, recv, rcounts, roffs, (void*)st) == 0,
+                  "pgh_dist: the host's all-to-all callback failed");
+        return 0;
+    }
+    const char* sb = static_cast<const char*>(send);
+    char* rb = static_cast<char*>(recv);
+    if (scounts[c->rank] > 0)
+        PGH_HIP(hipMemcpyAsync(rb + 4 * roffs[c->rank], sb + 4 * soffs[c->rank], 4 * (size_t)scounts[c->rank], hipMemcpyDeviceToDevice, st));
+    if (c->world == 1) return 0;
+    PGH_CHECK(c->ext_gather == nullptr, "pgh_dist: a host-collective communicator without an all-to-all callback cannot exchange need lists");
+    PGH_RCCL(g_rccl.GroupStart());
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
+        if (scounts[r] > 0) PGH_RCCL(g_rccl.Send(sb + 4 * soffs[r], (size_t)scounts[r], ncclFloat32, r, c->x, st));
+        if (rcounts[r] > 0) PGH_RCCL(g_rccl.Recv(rb + 4 * roffs[r], (size_t)rcounts[r], ncclFloat32, r, c->x, st));
+    }
+    PGH_RCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
 void free_buffers(pgh_comm_s* c) {
+    (void)hipFree(c->send_buf);
+    c->send_buf = nullptr;
+    c->send_cap = 0;
+    c->lists_stamp = 0;
     (void)hipFree(c->xg_full);         // (xg_local points into it)
     (void)hipFree(c->y[0]);
     (void)hipFree(c->y[1]);
@@ -188,27 +235,101 @@ inline int grid_of(int64_t n) {
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+struct StreamSwap {          // the engine launches on rt().stream: point it at one of the communicator's queues for a scope
+    hipStream_t saved;
+    explicit StreamSwap(hipStream_t s) : saved(rt().stream) { rt().stream = s; }
+    ~StreamSwap() { rt().stream = saved; }
+};
+
 // gather-vector layout and buffers for graph g (collective: every rank calls it with its slice of the same partition).  The
 // layout is negotiated on every run (one 8-byte all-reduce: a handle is no proof that the graph behind it is the one of the
 // last run); the buffers are kept while their sizes fit.
+unsigned long long g_lists_stamp = 0;
+
+// once per graph and communicator: every rank tells the owners of the blocks which of their cold slots its slice references; what the
+// peers asked of this rank becomes the graph's send lists (one pack launch per step), the counts become the step's point-to-point sizes
+int setup_need_lists(pgh_comm_s* c, pgh_graph_t g, const int64_t* need8) {
+    BsfFormat& f = g->bsf;
+    const int nb = c->nb, bpr = c->bpr, world = c->world;
+    int64_t need_prefix[9] = {0};
+    for (int b = 0; b < 8; ++b) need_prefix[b + 1] = need_prefix[b] + (b < nb ? need8[b] : 0);
+    int64_t* d_counts = nullptr;
+    PGH_HIP(hipMalloc(&d_counts, sizeof(int64_t) * (size_t)(world * nb)));
+    std::vector<int64_t> counts_all((size_t)world * nb, 0);
+    uint32_t* d_asked = nullptr;
+    int rc = 0;
+    auto bail = [&](int code) {
+        (void)hipFree(d_counts);
+        (void)hipFree(d_asked);
+        return code;
+    };
+    if (hipMemcpyAsync(d_counts + (int64_t)c->rank * nb, need8, sizeof(int64_t) * (size_t)nb, hipMemcpyHostToDevice, c->main) != hipSuccess)
+        return bail(fail("setup_need_lists: copy failed"));
+    if ((rc = comm_all_gather(c, d_counts + (int64_t)c->rank * nb, d_counts, (size_t)nb * 2, c->x, c->main)) != 0) return bail(rc);
+    if (hipMemcpyAsync(counts_all.data(), d_counts, sizeof(int64_t) * counts_all.size(), hipMemcpyDeviceToHost, c->main) != hipSuccess ||
+        hipEventRecord(c->ev_host, c->main) != hipSuccess)
+        return bail(fail("setup_need_lists: copy failed"));
+    if ((rc = bounded_wait(c->ev_host, "the exchange of the need-list sizes")) != 0) return bail(rc);
+    int64_t scounts[8] = {0}, soffs[8] = {0}, rcounts[8] = {0}, roffs[8] = {0}, asked_total = 0;
+    for (int s = 0; s < world; ++s) {
+        soffs[s] = need_prefix[s * bpr];
+        scounts[s] = need_prefix[(s + 1) * bpr] - need_prefix[s * bpr];
+        roffs[s] = asked_total;
+        for (int j = 0; j < bpr; ++j) rcounts[s] += counts_all[(size_t)s * nb + c->rank * bpr + j];
+        asked_total += rcounts[s];
+    }
+    PGH_CHECK(asked_total < (1LL << 31), "setup_need_lists: the send lists are too long");
+    if (hipMalloc(&d_asked, sizeof(uint32_t) * (size_t)(asked_total > 0 ? asked_total : 1)) != hipSuccess) return bail(fail("setup_need_lists: out of device memory"));
+    if ((rc = comm_all_to_all_v(c, f.need_idx, scounts, soffs, d_asked, rcounts, roffs, c->main)) != 0) return bail(rc);
+    if (hipEventRecord(c->ev_host, c->main) != hipSuccess) return bail(fail("setup_need_lists: event"));
+    if ((rc = bounded_wait(c->ev_host, "the exchange of the need lists")) != 0) return bail(rc);
+    std::vector<int64_t> seg_off((size_t)world * bpr + 1, 0);
+    std::vector<int32_t> seg_block((size_t)world * bpr, 0);
+    for (int rk = 0; rk < world; ++rk)
+        for (int j = 0; j < bpr; ++j) {
+            const size_t k = (size_t)rk * bpr + j;
+            seg_block[k] = j;
+            seg_off[k + 1] = seg_off[k] + counts_all[(size_t)rk * nb + c->rank * bpr + j];
+        }
+    if ((rc = dist_set_send_lists_device(g, d_asked, seg_block.data(), seg_off.data(), world * bpr)) != 0) return bail(rc);
+    for (int s = 0; s < 8; ++s) {
+        c->send_counts[s] = s < world ? rcounts[s] : 0;      // what rank s asked of this rank
+        c->send_offs[s] = s < world ? roffs[s] : 0;
+        c->recv_counts[s] = s < world ? scounts[s] : 0;      // what this rank asked of rank s: its blocks' stretch of the compact region
+        c->recv_offs[s] = s < world ? soffs[s] : 0;
+    }
+    if (c->send_cap < asked_total) {
+        (void)hipFree(c->send_buf);
+        c->send_buf = nullptr;
+        c->send_cap = 0;
+        if (hipMalloc(&c->send_buf, sizeof(float) * (size_t)(asked_total > 0 ? asked_total : 1)) != hipSuccess) return bail(fail("setup_need_lists: out of device memory"));
+        c->send_cap = asked_total > 0 ? asked_total : 1;
+    }
+    f.send_stamp = ++g_lists_stamp;
+    c->lists_stamp = f.send_stamp;
+    return bail(0);
+}
+
 int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     Runtime& r = rt();
     int32_t nb = 0, live8[8] = {0}, hot_slots = 0;
-    int64_t blk = 0;
+    int64_t blk = 0, need8[8] = {0};
     PGH_TRY(pgh_graph_gather_layout(g, &nb, &blk, live8));
     PGH_TRY(pgh_graph_hot_prefix(g, &hot_slots));
+    PGH_TRY(pgh_dist_need_counts(g, need8));
     PGH_CHECK(nb % c->world == 0, "pgh_dist_ppr_run: the column blocks of the slice do not divide among the ranks");
     int32_t top = 0;
     for (int b = 0; b < nb; ++b) top = live8[b] > top ? live8[b] : top;
+    const bool compact = g->bsf.need_idx != nullptr;        // the slice numbers its cold sources compactly (need lists)
     // every rank must lay the gather vector out the same way: live = max over ranks, hot prefix = min over ranks; and every rank
     // must close the steps the same way: the in-kernel residual only when every slice can (min), the slice's degrees recomputed
-    // when any rank lacks them (max)
+    // when any rank lacks them (max); need lists only when every slice is compact
     // (the degree word counts only where this rank could fuse at all: a run that cannot -- closed-form filters, AbsorbingWalks, the
     // max rule -- neither needs the slice's degrees nor gives anybody's up)
     const bool may_fuse = fused != nullptr && *fused;
-    int32_t h_agree[4] = {top, -hot_slots, may_fuse ? 0 : 1, (may_fuse && g->bsf.deg_int == nullptr) ? 1 : 0};
+    int32_t h_agree[5] = {top, -hot_slots, may_fuse ? 0 : 1, (may_fuse && g->bsf.deg_int == nullptr) ? 1 : 0, compact ? 0 : 1};
     PGH_HIP(hipMemcpyAsync(c->agree, h_agree, sizeof(h_agree), hipMemcpyHostToDevice, c->main));
-    PGH_TRY(comm_all_reduce(c, c->agree, 4, ncclInt32, ncclMax, c->s, c->main));
+    PGH_TRY(comm_all_reduce(c, c->agree, 5, ncclInt32, ncclMax, c->s, c->main));
     PGH_HIP(hipMemcpyAsync(h_agree, c->agree, sizeof(h_agree), hipMemcpyDeviceToHost, c->main));
     PGH_HIP(hipEventRecord(c->ev_host, c->main));
     PGH_TRY(bounded_wait(c->ev_host, "the layout negotiation"));
@@ -224,59 +345,106 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     // split regions only when the exchange's hot prefix is exactly what the block partial sums read
     const bool split = hot_all > 0 && hot_all < live && hot_all % 64 == 0 && hot_all == hot_slots &&
                        !(getenv("PGH_DIST_SPLIT") != nullptr && atoi(getenv("PGH_DIST_SPLIT")) == 0);
+    // need lists: every slice compact, the hot prefixes a region of their own, a communicator that can move stretches point to point
+    const bool can_p2p = c->ext_gather == nullptr || c->ext_alltoallv != nullptr;
+    const char* xenv = getenv("PGH_DIST_EXCHANGE");
+    const bool lists = compact && h_agree[4] == 0 && split && can_p2p && !(xenv != nullptr && std::string(xenv) == "allgather");
     c->nb = nb;
     c->blk = blk;
     c->bpr = nb / c->world;
     c->live = (int)live;
     c->hot = split ? (int)hot_all : 0;
     c->n_local = g->n_cols;
+    c->lists = lists;
+    c->compact_copy = compact && !lists;
     PGH_CHECK(blk * nb == g->n_rows && c->n_local == (int64_t)c->bpr * blk, "pgh_dist_ppr_run: the slice does not match the block layout");
+    int64_t need_prefix[9] = {0};
+    for (int b = 0; b < 8; ++b) need_prefix[b + 1] = need_prefix[b] + (b < nb ? need8[b] : 0);
+    c->need_total = compact ? need_prefix[nb] : 0;
     // A rank keeps its slice of the next gather vector PACKED for the exchange -- the hot prefixes of its blocks one after the
     // other, then their cold parts (dist_set_local_layout: the epilogue writes it that way) -- so every exchange is ONE all-gather
     // per region however many blocks a rank owns, and block b = rank * bpr + j of the gathered vector starts at b * (region width).
     // (single queue: the whole packed slice is one all-gather, [rank][hot prefixes | cold parts]; the bases say where a block's two
     // parts landed)
     int64_t hot_bases[8] = {0}, cold_bases[8] = {0};
-    for (int b = 0; b < nb; ++b) {
-        if (c->one_gather && split) {
-            const int rk = b / c->bpr, j = b % c->bpr;
-            hot_bases[b] = (int64_t)rk * c->bpr * live + (int64_t)j * c->hot;
-            cold_bases[b] = (int64_t)rk * c->bpr * live + (int64_t)c->bpr * c->hot + (int64_t)j * (live - c->hot);
-        } else {
-            hot_bases[b] = (int64_t)b * (split ? c->hot : live);
-            cold_bases[b] = (int64_t)nb * c->hot + (int64_t)b * (live - c->hot);
+    int64_t n_xg = 0;
+    if (lists) {
+        // [block][hot] | [block][the cold slots THIS slice references] | this rank's own cold parts [j][live - hot]: the hot prefixes are
+        // all-gathered in place, the cold parts are packed per destination (pgh_dist_pack) and travel point to point
+        for (int b = 0; b < nb; ++b) {
+            hot_bases[b] = (int64_t)b * c->hot;
+            cold_bases[b] = (int64_t)nb * c->hot + need_prefix[b];
         }
+        c->compact_at = (int64_t)nb * c->hot;
+        c->dense_cold_at = (c->compact_at + c->need_total + 63) / 64 * 64;
+        c->local_off = (int64_t)c->rank * c->bpr * c->hot;
+        c->cold_rel = c->dense_cold_at - c->local_off;
+        n_xg = c->dense_cold_at + (int64_t)c->bpr * (live - c->hot) + 32768;
+        PGH_TRY(pgh_graph_set_gather_bases_split(g, hot_bases, cold_bases));
+    } else {
+        for (int b = 0; b < nb; ++b) {
+            if (c->one_gather && split) {
+                const int rk = b / c->bpr, j = b % c->bpr;
+                hot_bases[b] = (int64_t)rk * c->bpr * live + (int64_t)j * c->hot;
+                cold_bases[b] = (int64_t)rk * c->bpr * live + (int64_t)c->bpr * c->hot + (int64_t)j * (live - c->hot);
+            } else {
+                hot_bases[b] = (int64_t)b * (split ? c->hot : live);
+                cold_bases[b] = (int64_t)nb * c->hot + (int64_t)b * (live - c->hot);
+            }
+        }
+        n_xg = (int64_t)nb * live;
+        if (c->compact_copy) {
+            // dense exchange, compact image (some peer's slice is dense, or the host's collectives cannot move stretches): the gathered
+            // vector is laid out as ever and this slice copies the slots it references out of it, block by block, behind every exchange
+            c->compact_at = (n_xg + 63) / 64 * 64;
+            int64_t compact_bases[8] = {0};
+            for (int b = 0; b < nb; ++b) {
+                c->dense_cold_base[b] = split ? cold_bases[b] : hot_bases[b] + hot_slots;
+                compact_bases[b] = c->compact_at + need_prefix[b];
+                c->compact_base[b] = compact_bases[b];
+            }
+            n_xg = c->compact_at + c->need_total;
+            PGH_TRY(pgh_graph_set_gather_bases_split(g, hot_bases, compact_bases));
+        } else if (split) {
+            PGH_TRY(pgh_graph_set_gather_bases_split(g, hot_bases, cold_bases));
+        } else {
+            PGH_TRY(pgh_graph_set_gather_bases(g, hot_bases));
+        }
+        // The slice is written IN PLACE: the epilogue of a step stores this rank's slots straight into their places of the gathered
+        // vector (ncclAllGather's in-place form: send = recv + rank * count), so no collective copies a rank's own slots and a rank alone
+        // has nothing to exchange at all.  One region: the packed slice [hot prefixes | cold parts] is rank r's stretch of the vector;
+        // two regions: its hot prefixes are rank r's stretch of the hot region, its cold parts rank r's stretch of the cold region.
+        // (Safe: a step's finish kernel is the last reader-free point of the vector on this rank -- the block partial sums and phase A of
+        // the step have run, the next all-gather is enqueued behind it -- and peers write only their own stretches.)
+        const bool two_regions = split && !c->one_gather;
+        c->local_off = two_regions ? (int64_t)c->rank * c->bpr * c->hot : (int64_t)c->rank * c->bpr * live;
+        c->cold_rel = two_regions ? (int64_t)nb * c->hot + (int64_t)c->rank * c->bpr * (live - c->hot) - c->local_off : (int64_t)c->bpr * c->hot;
+        n_xg += 32768;                                     // + the hot cache's read-ahead past a short block
     }
-    if (split) PGH_TRY(pgh_graph_set_gather_bases_split(g, hot_bases, cold_bases));
-    else PGH_TRY(pgh_graph_set_gather_bases(g, hot_bases));
-    // The slice is written IN PLACE: the epilogue of a step stores this rank's slots straight into their places of the gathered
-    // vector (ncclAllGather's in-place form: send = recv + rank * count), so no collective copies a rank's own slots and a rank alone
-    // has nothing to exchange at all.  One region: the packed slice [hot prefixes | cold parts] is rank r's stretch of the vector;
-    // two regions: its hot prefixes are rank r's stretch of the hot region, its cold parts rank r's stretch of the cold region.
-    // (Safe: a step's finish kernel is the last reader-free point of the vector on this rank -- the block partial sums and phase A of
-    // the step have run, the next all-gather is enqueued behind it -- and peers write only their own stretches.)
-    const bool two_regions = split && !c->one_gather;
-    c->local_off = two_regions ? (int64_t)c->rank * c->bpr * c->hot : (int64_t)c->rank * c->bpr * live;
-    c->cold_rel = two_regions ? (int64_t)nb * c->hot + (int64_t)c->rank * c->bpr * (live - c->hot) - c->local_off : (int64_t)c->bpr * c->hot;
     PGH_CHECK(c->cold_rel >= 0 && c->cold_rel < (1LL << 31), "pgh_dist_ppr_run: the gather vector is too long for the slice layout");
     PGH_TRY(dist_set_local_layout(g, (int)live, c->hot, (int)c->cold_rel));      // (after the bases: setting them resets the layout)
-    const int64_t n_xg = (int64_t)nb * live + 32768;          // + the hot cache's read-ahead past a short block
-    if (c->graph != nullptr && c->n_xg == n_xg && c->buf_local == c->n_local) {
-        c->xg_local = c->xg_full + c->local_off;
-        c->graph = g;
-        return 0;
+    c->exchange_bytes = lists ? 4LL * ((int64_t)c->hot * c->bpr * (c->world - 1)) : 4LL * c->live * c->bpr * (c->world - 1);
+    if (!(c->graph != nullptr && c->n_xg == n_xg && c->buf_local == c->n_local)) {
+        free_buffers(c);
+        c->n_xg = n_xg;
+        c->buf_local = c->n_local;
+        PGH_HIP(hipMalloc(&c->xg_full, sizeof(float) * (size_t)c->n_xg));
+        PGH_HIP(hipMemsetAsync(c->xg_full, 0, sizeof(float) * (size_t)c->n_xg, r.stream));
+        PGH_HIP(hipMalloc(&c->y[0], sizeof(float) * (size_t)c->n_local));
+        PGH_HIP(hipMalloc(&c->y[1], sizeof(float) * (size_t)c->n_local));
+        PGH_HIP(hipMalloc(&c->p_norm, sizeof(float) * (size_t)c->n_local));
+        PGH_HIP(hipStreamSynchronize(r.stream));
     }
-    free_buffers(c);
-    c->n_xg = n_xg;
-    c->buf_local = c->n_local;
-    PGH_HIP(hipMalloc(&c->xg_full, sizeof(float) * (size_t)c->n_xg));
-    PGH_HIP(hipMemsetAsync(c->xg_full, 0, sizeof(float) * (size_t)c->n_xg, r.stream));
     c->xg_local = c->xg_full + c->local_off;
-    PGH_HIP(hipMalloc(&c->y[0], sizeof(float) * (size_t)c->n_local));
-    PGH_HIP(hipMalloc(&c->y[1], sizeof(float) * (size_t)c->n_local));
-    PGH_HIP(hipMalloc(&c->p_norm, sizeof(float) * (size_t)c->n_local));
-    PGH_HIP(hipStreamSynchronize(r.stream));
     c->graph = g;
+    if (lists) {
+        // the send lists are state of the GRAPH, the point-to-point sizes state of the communicator: both are this pair's when the
+        // stamp the last set-up left on the graph is the communicator's (a Python-driven run in between re-registers its own lists)
+        if (g->bsf.send_stamp == 0 || g->bsf.send_stamp != c->lists_stamp) PGH_TRY(setup_need_lists(c, g, need8));
+        int64_t received = 0;
+        for (int s = 0; s < c->world; ++s) received += s == c->rank ? 0 : c->recv_counts[s];
+        c->exchange_bytes += 4LL * received;
+    }
     return 0;
 }
 
@@ -291,15 +459,35 @@ int gather_part(pgh_comm_s* c, int64_t region, int lo, int hi, hipStream_t st) {
 
 // the exchange of a step: this rank's packed slice of the next gather vector -> every rank's xg_full.  Three queues: the hot
 // prefixes first (ev_hot: all that the next step's block partial sums read), then the cold bulk (ev_cold), so that the bulk travels
-// while those sums run; one queue: ONE all-gather of the whole slice.
+// while those sums run; one queue: ONE all-gather of the whole slice.  Need lists: the cold bulk is ONE pack launch (every
+// destination's stretch) and one group of point-to-point transfers into the compact cold region.
 int exchange_slices(pgh_comm_s* c, hipStream_t st, bool events) {
+    pgh_vec_s v_full{c->xg_full, c->n_xg, false};
+    if (c->lists) {
+        PGH_TRY(gather_part(c, 0, 0, c->hot, st));
+        if (events) PGH_HIP(hipEventRecord(c->ev_hot, st));
+        {
+            StreamSwap on_exchange(st);
+            pgh_vec_s v_local{c->xg_local, c->n_xg - c->local_off, false}, v_send{c->send_buf, c->send_cap, false};
+            PGH_TRY(pgh_dist_pack(c->graph, &v_local, &v_send));
+        }
+        PGH_TRY(comm_all_to_all_v(c, c->send_buf, c->send_counts, c->send_offs, c->xg_full + c->compact_at, c->recv_counts, c->recv_offs, st));
+        if (events) PGH_HIP(hipEventRecord(c->ev_cold, st));
+        return 0;
+    }
     if (c->one_gather || c->hot == 0) {
         PGH_TRY(comm_all_gather(c, c->xg_local, c->xg_full, (size_t)((int64_t)c->bpr * c->live), c->x, st));
-        if (events) PGH_HIP(hipEventRecord(c->ev_hot, st));
+        if (events && !c->compact_copy) PGH_HIP(hipEventRecord(c->ev_hot, st));
     } else {
         PGH_TRY(gather_part(c, 0, 0, c->hot, st));
         if (events) PGH_HIP(hipEventRecord(c->ev_hot, st));
         PGH_TRY(gather_part(c, (int64_t)c->nb * c->hot, c->hot, c->live, st));
+    }
+    if (c->compact_copy) {
+        StreamSwap on_exchange(st);
+        for (int b = 0; b < c->nb; ++b)
+            PGH_TRY(pgh_dist_compact_from_dense(c->graph, b, &v_full, c->dense_cold_base[b], &v_full, c->compact_base[b]));
+        if (events && (c->one_gather || c->hot == 0)) PGH_HIP(hipEventRecord(c->ev_hot, st));
     }
     if (events) PGH_HIP(hipEventRecord(c->ev_cold, st));
     return 0;
@@ -317,15 +505,10 @@ bool finish_in_two(const pgh_comm_s* c, const pgh_graph_s* g) {
     if (mode == 0 || !g->bsf.enabled || !g->bsf.pb.enabled) return false;
     // (both launches keep a partial sum per workgroup and per tail item: they must fit the partial buffers)
     if (2 * (g->bsf.pb.sched_groups + g->bsf.pb.tail_count) > kMaxPartials) return false;
-    const int64_t received = 4LL * c->live * c->bpr * (c->world - 1);
+    const int64_t received = c->exchange_bytes;
     return mode == 2 || (c->world > 1 && !c->one_gather && received >= (32LL << 20));
 }
 
-struct StreamSwap {          // the engine launches on rt().stream: point it at one of the communicator's queues for a scope
-    hipStream_t saved;
-    explicit StreamSwap(hipStream_t s) : saved(rt().stream) { rt().stream = s; }
-    ~StreamSwap() { rt().stream = saved; }
-};
 
 }  // namespace
 
@@ -364,7 +547,7 @@ int comm_resources(pgh_comm_s* c, bool two_comms) {
     PGH_HIP(hipHostMalloc(&c->state_host, sizeof(double) * 8, hipHostMallocDefault));
     PGH_HIP(hipMalloc(&c->aux, sizeof(LoopAux)));
     PGH_HIP(hipMalloc(&c->red, sizeof(double) * 4));
-    PGH_HIP(hipMalloc(&c->agree, sizeof(int32_t) * 4));
+    PGH_HIP(hipMalloc(&c->agree, sizeof(int32_t) * 8));
     void* hp = nullptr;
     PGH_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
     c->progress_host = reinterpret_cast<volatile unsigned long long*>(hp);
@@ -455,6 +638,12 @@ extern "C" int pgh_comm_create_external(int32_t world, int32_t rank, pgh_allgath
         return fail(msg);
     }
     *out = c;
+    return 0;
+}
+
+extern "C" int pgh_comm_set_alltoallv(pgh_comm_t c, pgh_alltoallv_fn all_to_all_v) {
+    PGH_CHECK(c != nullptr && c->ext_gather != nullptr, "pgh_comm_set_alltoallv: a communicator of pgh_comm_create_external, please");
+    c->ext_alltoallv = all_to_all_v;
     return 0;
 }
 
@@ -642,6 +831,7 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     int fused_partials = 0;
     const bool two_launches = finish_in_two(c, g);
     res->flags |= two_launches ? 4 : 0;
+    res->flags |= c->lists ? 8 : (c->compact_copy ? 16 : 0);       // how the cold parts of the gather vector travel
     bool pending = false, staged = false, converged = false;
     while (it < max_iters) {                   // convergence.py:86
         const int nxt = 1 - cur;
@@ -761,7 +951,7 @@ extern "C" int pgh_dist_ppr_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local, 
     res->converged = converged ? 1 : 0;
     res->last_error = c->state_host[6];
     res->loop_ms = (double)ms;
-    res->exchange_bytes = 4LL * c->live * c->bpr * (c->world - 1);
+    res->exchange_bytes = c->exchange_bytes;
     res->gather_slots = (int64_t)c->nb * c->live;
     res->column_blocks = c->nb;
     res->split_regions = c->hot > 0 ? 1 : 0;
@@ -860,6 +1050,7 @@ extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local,
     const int max_iters = cfg->max_iters;
     const bool two_launches = finish_in_two(c, g);
     res->flags |= two_launches ? 4 : 0;
+    res->flags |= c->lists ? 8 : (c->compact_copy ? 16 : 0);       // how the cold parts of the gather vector travel
     int it = 2, spmv = 0, cur = 0;             // `it` = the iteration has_converged is asked about
     bool converged = false, pending = false, staged = false;
     if (it < max_iters && kind != PGH_ERR_ITERS && it % cfg->end_modulo == 0 && delta <= cfg->tol) converged = true;
@@ -942,7 +1133,7 @@ extern "C" int pgh_dist_poly_run(pgh_graph_t g, pgh_comm_t c, pgh_vec_t p_local,
     res->converged = converged ? 1 : 0;
     res->last_error = spmv > 0 ? c->state_host[6] : delta;
     res->loop_ms = (double)ms;
-    res->exchange_bytes = 4LL * c->live * c->bpr * (c->world - 1);
+    res->exchange_bytes = c->exchange_bytes;
     res->gather_slots = (int64_t)c->nb * c->live;
     res->column_blocks = c->nb;
     res->split_regions = c->hot > 0 ? 1 : 0;

@@ -631,6 +631,9 @@ struct PbPlan {
     int4*    host_split = nullptr; // {row, first bin, pieces, -} of the hub rows with several bins (new[]), owned by the plan
     int4*    host_bins = nullptr;  // {first row, rows, -, entries} of every bin (new[]), owned by the plan
     bool     heavy_rows = false;   // some rows keep their cold entries in the blocked stream
+    // need lists (BsfFormat::want_compact): dense cold id (block-major slot - hot) -> compact id of the referenced ones, or null
+    uint32_t* cold_rank = nullptr;
+    int64_t  dense_prefix[9] = {0}, compact_prefix[9] = {0};
 };
 int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int hot, unsigned char* is_hot, PbPlan* plan, bool* use);
 int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, const float* cold_vals, int64_t count, const int* live, int hot);
@@ -661,6 +664,8 @@ bool dist_can_fuse(const pgh_graph_s* g);
 // where a partitioned run keeps this rank's slice of the next gather vector: packed for the exchange (BsfFormat::lg_*), 0 = by row
 int dist_set_local_layout(pgh_graph_s* g, int live, int hot, int cold = -1);
 int dist_prescale_packed(pgh_graph_s* g, const float* x_local, float* xg_local_out);
+// pgh_dist_set_send_lists with the requested slots already on the device (the engine's loop receives them there)
+int dist_set_send_lists_device(pgh_graph_s* g, const uint32_t* slots_dev, const int32_t* local_block, const int64_t* seg_offsets, int32_t segments);
 int dist_aux_init(LoopAux* aux);
 int dist_combine_fused(pgh_graph_s* g, const float* p_local, double alpha, float* y_local, float* xg_local_out, const float* x_prev,
                        const float* deg_local, double* state, LoopAux* aux, int step, int* num_partials);

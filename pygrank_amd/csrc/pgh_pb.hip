@@ -131,9 +131,33 @@ __global__ void k_pb_keep_heavy(const uint64_t* __restrict__ keys, int64_t E, co
 }
 
 struct PbLayout {
-    int64_t cold_prefix[9];
+    int64_t cold_prefix[9];            // dense numbering: first cold id of every block
     int     blk, hot, chunk;
+    const uint32_t* rank;              // need lists: dense cold id -> compact cold id (null: the dense numbering is the image's)
 };
+
+// need lists: marks the dense cold ids that an entry of the image references
+__global__ void k_pb_mark_cold(const uint64_t* __restrict__ keys, const unsigned char* __restrict__ is_hot, int64_t E, PbLayout L,
+                               uint32_t* __restrict__ mark) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        if (is_hot[e]) continue;
+        const uint64_t key = keys[e];
+        if (((key >> 29) & kLow29) == kLow29) continue;           // sentinel / pad
+        const int b = (int)(key >> 58);
+        const int64_t loc = (int64_t)(key & kLow29) - (int64_t)b * L.blk;
+        mark[L.cold_prefix[b] + (loc - L.hot)] = 1u;
+    }
+}
+// ... and lists them: need_idx[compact id] = slot - hot inside its block
+__global__ void k_pb_need_idx(const uint32_t* __restrict__ mark, const uint32_t* __restrict__ rank, int64_t dense_total, PbLayout L, int num_blocks,
+                              uint32_t* __restrict__ need_idx) {
+    for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < dense_total; d += (int64_t)gridDim.x * blockDim.x) {
+        if (mark[d] == 0u) continue;
+        int b = 0;
+        for (int k = 1; k < num_blocks; ++k) b += d >= L.cold_prefix[k] ? 1 : 0;
+        need_idx[rank[d]] = (uint32_t)(d - L.cold_prefix[b]);
+    }
+}
 
 // stream key -> cell key (chunk << 45 | bin << 30 | row_in_bin << 15 | source_in_chunk)
 __global__ void k_pb_keys(const uint64_t* __restrict__ keys, int64_t count, PbLayout L, const int32_t* __restrict__ row_bin,
@@ -143,7 +167,8 @@ __global__ void k_pb_keys(const uint64_t* __restrict__ keys, int64_t count, PbLa
         const int b = (int)(key >> 58);
         const int64_t row = (int64_t)((key >> 29) & kLow29);
         const int64_t loc = (int64_t)(key & kLow29) - (int64_t)b * L.blk;
-        const int64_t cold_id = L.cold_prefix[b] + (loc - L.hot);
+        const int64_t dense_id = L.cold_prefix[b] + (loc - L.hot);
+        const int64_t cold_id = L.rank != nullptr ? (int64_t)L.rank[dense_id] : dense_id;
         const uint64_t c = (uint64_t)(cold_id / L.chunk), sl = (uint64_t)(cold_id % L.chunk);
         uint64_t w = (uint64_t)(row_bin[row] - first_bin);
         const uint64_t pieces = (uint64_t)(((unsigned)bin[w].y >> 22) & 0x3ffu) + 1u;      // a split hub row: piece by source chunk
@@ -731,8 +756,40 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     Runtime& r = rt();
     int64_t cold_sources = 0;
     for (int b = 0; b < f.num_blocks; ++b) cold_sources += live[b] > hot ? live[b] - hot : 0;
-    const int64_t chunks = (cold_sources + kPbChunk - 1) / kPbChunk;
-    if (chunks < 1 || chunks > kPbMaxChunks || f.n_out >= (1 << 28)) return 0;
+    plan->dense_prefix[0] = 0;
+    for (int b = 0; b < 8; ++b) plan->dense_prefix[b + 1] = plan->dense_prefix[b] + (b < f.num_blocks && live[b] > hot ? live[b] - hot : 0);
+    for (int b = 0; b < 9; ++b) plan->compact_prefix[b] = plan->dense_prefix[b];
+    // ---- need lists (partition slices): only the cold sources this slice REFERENCES get a cold id -- a rank of an 8-way partition
+    // references ~43 % of the live slots: fewer chunks, longer (chunk, bin) runs, and an exchange of those slots alone
+    PbBuf<uint32_t> mark;
+    if (f.want_compact && cold_sources > 0 && cold_sources < (1LL << 31)) {
+        PbLayout L{};
+        for (int b = 0; b < 9; ++b) L.cold_prefix[b] = plan->dense_prefix[b];
+        L.blk = f.blk_size;
+        L.hot = hot;
+        L.chunk = kPbChunk;
+        PGH_TRY(mark.alloc(cold_sources + 1, true));
+        PGH_HIP(hipMalloc(&plan->cold_rank, sizeof(uint32_t) * (size_t)(cold_sources + 1)));
+        k_pb_mark_cold<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, is_hot, E, L, mark.p);
+        PGH_HIP(hipGetLastError());
+        size_t scan_bytes = 0;
+        PGH_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, mark.p, plan->cold_rank, (int)(cold_sources + 1), r.stream));
+        PbBuf<char> scan_temp;
+        PGH_TRY(scan_temp.alloc(scan_bytes));
+        PGH_HIP(hipcub::DeviceScan::ExclusiveSum(scan_temp.p, scan_bytes, mark.p, plan->cold_rank, (int)(cold_sources + 1), r.stream));
+        uint32_t at[9] = {0};
+        for (int b = 0; b <= 8; ++b)
+            PGH_HIP(hipMemcpyAsync(&at[b], plan->cold_rank + plan->dense_prefix[b], sizeof(uint32_t), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        for (int b = 0; b <= 8; ++b) plan->compact_prefix[b] = (int64_t)at[b];
+    }
+    const int64_t cold_ids = plan->compact_prefix[8];             // == cold_sources without need lists
+    const int64_t chunks = (cold_ids + kPbChunk - 1) / kPbChunk;
+    if (chunks < 1 || chunks > kPbMaxChunks || f.n_out >= (1 << 28)) {
+        (void)hipFree(plan->cold_rank);
+        plan->cold_rank = nullptr;
+        return 0;
+    }
     PbBuf<uint32_t> d_counts;
     PGH_TRY(d_counts.alloc(f.n_out, true));
     k_pb_row_counts<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, is_hot, E, d_counts.p);
@@ -816,7 +873,12 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     }
     plan->bin_rows = bin_rows;
     const int64_t num_bins = (int64_t)bins.size();
-    if (num_bins < 1 || num_bins > kPbMaxBins || in_image + 8 * chunks * num_bins >= 2147483647LL) return 0;
+    auto no_image = [&]() {
+        (void)hipFree(plan->cold_rank);
+        plan->cold_rank = nullptr;
+        return 0;
+    };
+    if (num_bins < 1 || num_bins > kPbMaxBins || in_image + 8 * chunks * num_bins >= 2147483647LL) return no_image();
     const double run = (double)in_image / ((double)chunks * (double)num_bins);
     const char* force = getenv("PGH_PB_FORCE");
     const bool forced = force != nullptr && atoi(force) != 0;
@@ -829,7 +891,28 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     // gain.
     // Valued graphs stream 4 more bytes per cold entry in phase A: 13 M cold entries measure -3 % (scale 21 upload).
     const int64_t least = (f.val != nullptr ? 16 : 10) * (1LL << 20);
-    if (!forced && (in_image < least || in_image * 20 < E || run < 10.0)) return 0;
+    if (!forced && (in_image < least || in_image * 20 < E || run < 10.0)) return no_image();
+    // rows that keep their cold entries in the blocked stream read the DENSE cold slots from there: such a slice cannot number its cold
+    // sources compactly (its exchange stays the all-gather); the plan is laid out again for the dense numbering
+    if (plan->cold_rank != nullptr && heavy_rows) {
+        (void)hipFree(plan->cold_rank);
+        plan->cold_rank = nullptr;
+        for (int b = 0; b < 9; ++b) plan->compact_prefix[b] = plan->dense_prefix[b];
+        f.want_compact = false;
+        return pb_plan(f, keys, E, live, hot, is_hot, plan, use);
+    }
+    if (plan->cold_rank != nullptr) {
+        // the lists themselves: kept with the graph (pgh_dist_need_list), block-major
+        PbLayout L{};
+        for (int b = 0; b < 9; ++b) L.cold_prefix[b] = plan->dense_prefix[b];
+        (void)hipFree(f.need_idx);
+        f.need_idx = nullptr;
+        PGH_HIP(hipMalloc(&f.need_idx, sizeof(uint32_t) * (size_t)(cold_ids > 0 ? cold_ids : 1)));
+        k_pb_need_idx<<<pb_blocks_for(cold_sources), kBlock, 0, r.stream>>>(mark.p, plan->cold_rank, cold_sources, L, f.num_blocks, f.need_idx);
+        PGH_HIP(hipGetLastError());
+        for (int b = 0; b < 9; ++b) f.need_prefix[b] = plan->compact_prefix[b];
+        f.device_bytes += cold_ids * 4;
+    }
     PGH_HIP(hipMalloc(&plan->row_bin, sizeof(int32_t) * (size_t)f.n_out));
     PGH_HIP(hipMemcpyAsync(plan->row_bin, row_bin.data(), sizeof(int32_t) * f.n_out, hipMemcpyHostToDevice, r.stream));
     k_pb_keep_heavy<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, E, plan->row_bin, is_hot);
@@ -890,11 +973,11 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     PGH_HIP(hipMalloc(&p.bin, sizeof(int4) * (size_t)(p.num_bins > 0 ? p.num_bins : 1)));
     PGH_HIP(hipMemcpyAsync(p.bin, mine.data(), sizeof(int4) * mine.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipStreamSynchronize(r.stream));
-    p.cold_prefix[0] = 0;
-    for (int b = 0; b < 8; ++b) p.cold_prefix[b + 1] = p.cold_prefix[b] + (b < f.num_blocks && live[b] > hot ? live[b] - hot : 0);
+    for (int b = 0; b < 9; ++b) p.cold_prefix[b] = plan->compact_prefix[b];       // (== the dense prefix without need lists)
     p.num_chunks = plan->num_chunks;
     PbLayout L;
-    for (int b = 0; b < 9; ++b) L.cold_prefix[b] = p.cold_prefix[b];
+    for (int b = 0; b < 9; ++b) L.cold_prefix[b] = plan->dense_prefix[b];
+    L.rank = plan->cold_rank;
     L.blk = f.blk_size;
     L.hot = hot;
     L.chunk = kPbChunk;
@@ -1229,6 +1312,8 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
 
 void pb_plan_release(PbPlan* plan) {
     (void)hipFree(plan->row_bin);
+    (void)hipFree(plan->cold_rank);
+    plan->cold_rank = nullptr;
     delete[] plan->host_bins;
     delete[] plan->host_split;
     plan->host_split = nullptr;

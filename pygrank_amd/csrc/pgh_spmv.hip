@@ -975,7 +975,9 @@ int check_dist_graph(pgh_graph_t g, pgh_vec_t xg_full, const char* who) {
     if (xg_full != nullptr) {
         const int64_t hot = (int64_t)PGH_BSF_HOT < f.blk_size ? (int64_t)PGH_BSF_HOT : f.blk_size;
         for (int b = 0; b < f.num_blocks; ++b) {
-            const int64_t need_hot = f.xg_base[b] + hot, need_cold = f.live[b] > hot ? f.xg_base_cold[b] + f.live[b] : 0;
+            // (need lists: block b's compact cold values sit at xg_base_cold[b] + hot .. + hot + its count)
+            const int64_t cold_count = f.need_idx != nullptr ? f.need_prefix[b + 1] - f.need_prefix[b] : (f.live[b] > hot ? f.live[b] - hot : 0);
+            const int64_t need_hot = f.xg_base[b] + hot, need_cold = cold_count > 0 ? f.xg_base_cold[b] + hot + cold_count : 0;
             const int64_t need = need_hot > need_cold ? need_hot : need_cold;
             PGH_CHECK(xg_full->n >= need, std::string(who) + ": gather vector shorter than the layout set by pgh_graph_set_gather_bases");
         }
@@ -1152,6 +1154,8 @@ extern "C" int pgh_graph_set_gather_bases(pgh_graph_t g, const int64_t* bases) {
     PGH_TRY(check_dist_graph(g, nullptr, "pgh_graph_set_gather_bases"));
     PGH_CHECK(bases != nullptr, "pgh_graph_set_gather_bases: null argument");
     BsfFormat& f = g->bsf;
+    PGH_CHECK(f.need_idx == nullptr, "pgh_graph_set_gather_bases: this slice numbers its cold sources compactly (pgh_dist_need_counts): lay the "
+                                     "gather vector out with pgh_graph_set_gather_bases_split");
     for (int b = 0; b < f.num_blocks; ++b) {
         PGH_CHECK(bases[b] >= 0 && bases[b] < (1LL << 31), "pgh_graph_set_gather_bases: base out of range");
         f.xg_base[b] = f.xg_base_cold[b] = bases[b];
@@ -1174,6 +1178,157 @@ extern "C" int pgh_graph_set_gather_bases_split(pgh_graph_t g, const int64_t* ho
         f.xg_base[b] = hot_bases[b];
         f.xg_base_cold[b] = cold_bases[b] - hot;           // slot s >= hot of the block sits at cold_bases[b] + (s - hot)
     }
+    f.lg_live = f.lg_hot = 0, f.lg_cold = -1;              // (as pgh_graph_set_gather_bases: slices stored by row unless the engine's loop says otherwise)
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Need lists ("grouped ncclSend/ncclRecv for exact uneven slices"; no reference counterpart).  A slice whose cold entries
+// all live in the propagation-blocking image numbers its cold sources COMPACTLY (pgh_pb.hip::pb_plan): block b of the gathered vector
+// holds, from cold_bases[b] on, the values of the cold slots (>= the hot prefix) THIS slice references, in ascending slot order.  The
+// exchange then moves those slots only: every rank tells the owners of the blocks what it needs (once per graph), an owner packs its
+// slice per destination (pgh_dist_pack) and the packed stretches travel point to point.
+extern "C" int pgh_dist_need_counts(pgh_graph_t g, int64_t* counts) {
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_dist_need_counts"));
+    PGH_CHECK(counts != nullptr, "pgh_dist_need_counts: null argument");
+    const BsfFormat& f = g->bsf;
+    for (int b = 0; b < f.num_blocks; ++b) counts[b] = f.need_idx != nullptr ? f.need_prefix[b + 1] - f.need_prefix[b] : 0;
+    return 0;
+}
+
+extern "C" int pgh_dist_need_list(pgh_graph_t g, int32_t block, uint32_t* out_host) {
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_dist_need_list"));
+    const BsfFormat& f = g->bsf;
+    PGH_CHECK(f.need_idx != nullptr && block >= 0 && block < f.num_blocks, "pgh_dist_need_list: the slice has no need lists / no such block");
+    const int64_t count = f.need_prefix[block + 1] - f.need_prefix[block];
+    if (count == 0) return 0;
+    PGH_CHECK(out_host != nullptr, "pgh_dist_need_list: null argument");
+    PGH_HIP(hipMemcpyAsync(out_host, f.need_idx + f.need_prefix[block], sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost, rt().stream));
+    PGH_HIP(hipStreamSynchronize(rt().stream));
+    return 0;
+}
+
+namespace {
+// slots (slot - hot, per segment) -> local rows of this rank's slice: segment k asks for cold slots of local block local_block[k]
+__global__ void k_send_rows(const uint32_t* __restrict__ slots, const int64_t* __restrict__ seg_off, const int32_t* __restrict__ seg_block, int segments,
+                            int blk, int hot, int64_t total, uint32_t* __restrict__ rows) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = segments - 1;                     // the segment that holds position i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg_off[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        rows[i] = (uint32_t)seg_block[lo] * (uint32_t)blk + (uint32_t)hot + slots[i];
+    }
+}
+__global__ void k_dist_pack(const float* __restrict__ xg_local, const uint32_t* __restrict__ rows, int64_t total, int blk, int live, int hot, int cold,
+                            float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = xg_slot((int)rows[i], blk, live, hot, cold);
+        out[i] = slot >= 0 ? xg_local[slot] : 0.f;
+    }
+}
+__global__ void k_compact_from_dense(const float* __restrict__ dense, const uint32_t* __restrict__ need_idx, int64_t first, int64_t count,
+                                     int64_t dense_base, float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = dense[dense_base + need_idx[first + i]];
+}
+inline int grid_1d(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)rt().num_cus * 16;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+}  // namespace
+
+// What the peers asked of THIS rank's blocks: `segments` stretches, destination-major; stretch k holds seg_offsets[k + 1] - seg_offsets[k]
+// cold slots (slot - hot, as pgh_dist_need_list hands them out) of this rank's local block local_block[k].  Host arrays; kept with the graph.
+extern "C" int pgh_dist_set_send_lists(pgh_graph_t g, const uint32_t* slots_host, const int32_t* local_block, const int64_t* seg_offsets,
+                                       int32_t segments) {
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_dist_set_send_lists"));
+    PGH_CHECK(segments >= 0 && (segments == 0 || (local_block != nullptr && seg_offsets != nullptr)), "pgh_dist_set_send_lists: bad arguments");
+    const int64_t total = segments > 0 ? seg_offsets[segments] : 0;
+    if (total == 0) return dist_set_send_lists_device(g, nullptr, local_block, seg_offsets, segments);
+    PGH_CHECK(slots_host != nullptr && total < (1LL << 31), "pgh_dist_set_send_lists: bad lists");
+    uint32_t* d_slots = nullptr;
+    PGH_HIP(hipMalloc(&d_slots, sizeof(uint32_t) * (size_t)total));
+    int rc = 0;
+    if (hipMemcpyAsync(d_slots, slots_host, sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice, rt().stream) != hipSuccess ||
+        hipStreamSynchronize(rt().stream) != hipSuccess)
+        rc = fail("pgh_dist_set_send_lists: copy failed");
+    if (rc == 0) rc = dist_set_send_lists_device(g, d_slots, local_block, seg_offsets, segments);
+    (void)hipFree(d_slots);
+    return rc;
+}
+
+namespace pgh {
+int dist_set_send_lists_device(pgh_graph_s* g, const uint32_t* d_slots, const int32_t* local_block, const int64_t* seg_offsets, int32_t segments) {
+    BsfFormat& f = g->bsf;
+    Runtime& r = rt();
+    (void)hipFree(f.send_rows);
+    f.send_rows = nullptr;
+    f.send_total = 0;
+    f.send_stamp = 0;
+    const int64_t total = segments > 0 ? seg_offsets[segments] : 0;
+    if (total == 0) return 0;
+    PGH_CHECK(d_slots != nullptr && total < (1LL << 31), "pgh_dist_set_send_lists: bad lists");
+    const int local_blocks = (int)(g->n_cols / (f.blk_size > 0 ? f.blk_size : 1));
+    const int hot = PGH_BSF_HOT < f.blk_size ? PGH_BSF_HOT : f.blk_size;
+    for (int k = 0; k < segments; ++k)
+        PGH_CHECK(local_block[k] >= 0 && local_block[k] < local_blocks && seg_offsets[k + 1] >= seg_offsets[k], "pgh_dist_set_send_lists: bad segment");
+    int64_t* d_off = nullptr;
+    int32_t* d_blk = nullptr;
+    PGH_HIP(hipMalloc(&f.send_rows, sizeof(uint32_t) * (size_t)total));
+    int rc = 0;
+    if (hipMalloc(&d_off, sizeof(int64_t) * (size_t)(segments + 1)) != hipSuccess || hipMalloc(&d_blk, sizeof(int32_t) * (size_t)segments) != hipSuccess)
+        rc = fail("pgh_dist_set_send_lists: out of device memory");
+    if (rc == 0 && (hipMemcpyAsync(d_off, seg_offsets, sizeof(int64_t) * (size_t)(segments + 1), hipMemcpyHostToDevice, r.stream) != hipSuccess ||
+                    hipMemcpyAsync(d_blk, local_block, sizeof(int32_t) * (size_t)segments, hipMemcpyHostToDevice, r.stream) != hipSuccess))
+        rc = fail("pgh_dist_set_send_lists: copy failed");
+    if (rc == 0) {
+        k_send_rows<<<grid_1d(total), 256, 0, r.stream>>>(d_slots, d_off, d_blk, segments, (int)f.blk_size, hot, total, f.send_rows);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(r.stream) != hipSuccess) rc = fail("pgh_dist_set_send_lists: kernel failed");
+    }
+    (void)hipFree(d_off);
+    (void)hipFree(d_blk);
+    if (rc != 0) {
+        (void)hipFree(f.send_rows);
+        f.send_rows = nullptr;
+        return rc;
+    }
+    f.send_total = total;
+    return 0;
+}
+}  // namespace pgh
+
+// send_buf[i] = the value of the i-th requested slot in this rank's slice of the next gather vector (stored by row, or packed as the engine's
+// loop lays it out: dist_set_local_layout).  One launch for every destination.
+extern "C" int pgh_dist_pack(pgh_graph_t g, pgh_vec_t xg_local, pgh_vec_t send_buf) {
+    PGH_CHECK(xg_local && send_buf, "pgh_dist_pack: null argument");
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_dist_pack"));
+    const BsfFormat& f = g->bsf;
+    PGH_CHECK(send_buf->n >= f.send_total, "pgh_dist_pack: the send buffer is shorter than the lists");
+    if (f.send_total == 0) return 0;
+    EpiParams ep{};
+    local_layout(f, ep);
+    ProfScope prof(PGH_K_PACK);
+    k_dist_pack<<<grid_1d(f.send_total), 256, 0, rt().stream>>>(xg_local->data, f.send_rows, f.send_total, ep.xg_blk, ep.xg_live, ep.xg_hot, ep.xg_cold,
+                                                                   send_buf->data);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
+// The lists applied to a DENSE copy of block `block`'s slice (dense[dense_base + slot - hot] = value of slot): compact_out[i] = the i-th
+// referenced cold slot.  What communicators without point-to-point transfers (and single-process probes) use behind an all-gather.
+extern "C" int pgh_dist_compact_from_dense(pgh_graph_t g, int32_t block, pgh_vec_t dense, int64_t dense_base, pgh_vec_t compact_out, int64_t out_base) {
+    PGH_CHECK(dense && compact_out, "pgh_dist_compact_from_dense: null argument");
+    PGH_TRY(check_dist_graph(g, nullptr, "pgh_dist_compact_from_dense"));
+    const BsfFormat& f = g->bsf;
+    PGH_CHECK(f.need_idx != nullptr && block >= 0 && block < f.num_blocks, "pgh_dist_compact_from_dense: the slice has no need lists / no such block");
+    const int64_t count = f.need_prefix[block + 1] - f.need_prefix[block];
+    PGH_CHECK(out_base >= 0 && compact_out->n >= out_base + count && dense_base >= 0, "pgh_dist_compact_from_dense: output too short");
+    if (count == 0) return 0;
+    k_compact_from_dense<<<grid_1d(count), 256, 0, rt().stream>>>(dense->data, f.need_idx, f.need_prefix[block], count, dense_base, compact_out->data + out_base);
+    PGH_HIP(hipGetLastError());
     return 0;
 }
 

@@ -128,8 +128,15 @@ class _Buffers:
 
     Gather-vector layout.  The engine cuts the source id space into `nb` hot-first column blocks of `blk` slots; rank r
     owns blocks r*bpr .. r*bpr + bpr - 1 (bpr = nb / world).  Only the first L slots of a block can be referenced by
-    anybody (pgh_graph_gather_layout; L = max over ranks), so the exchange is bpr all-gathers of L floats per rank and
-    the gather vector is stored as [j][rank][L]: block r*bpr + j starts at (j * world + r) * L."""
+    anybody (pgh_graph_gather_layout; L = max over ranks), so the DENSE exchange is bpr all-gathers of L floats per rank and
+    the gather vector is stored as [j][rank][L]: block r*bpr + j starts at (j * world + r) * L.
+
+    Need lists ("grouped ncclSend/ncclRecv for exact uneven slices"; pgh_dist_need_counts).  A slice whose cold entries
+    all live in the propagation-blocking image numbers its cold sources compactly: it wants, per block, only the cold slots it
+    references (a rank of an 8-way partition: ~43 % of the live ones).  When EVERY rank's slice does, the exchange of a step is: the hot
+    prefixes all-gathered as before ([j][rank][hot], a few hundred KB), then ONE pack launch (pgh_dist_pack: every destination's
+    stretch) and ONE all_to_all of the packed stretches into the compact cold region [block][its referenced slots].  When only some
+    ranks' slices are compact, the dense all-gather stays and those ranks compact their copy locally (pgh_dist_compact_from_dense)."""
 
     def __init__(self, pgraph, device, dist):
         import torch
@@ -137,6 +144,7 @@ class _Buffers:
         lib = L.lib()
         g = pgraph.graph
         n_local, world = pgraph.n_local, pgraph.world
+        rank = pgraph.rank
         nb, blk = C.c_int32(), C.c_int64()
         live = np.zeros(8, dtype=np.int32)
         L.check(lib.pgh_graph_gather_layout(g._h, C.byref(nb), C.byref(blk), live.ctypes.data_as(C.c_void_p)))
@@ -146,12 +154,49 @@ class _Buffers:
         top = torch.tensor([int(live.max())], dtype=torch.int64, device=device)
         dist.all_reduce(top, op=dist.ReduceOp.MAX)
         self.live = min(self.blk, (int(top.item()) + 63) // 64 * 64)
+        self.world = world
+        # Hot / cold split of the exchange: when the slice's stream is hot-only (every cold entry lives in the
+        # propagation-blocking image) the block partial sums read just the first `hot` slots of every block, so those
+        # are exchanged first (a few hundred KB) and the bulk of the gather vector travels while they run.
+        hs = C.c_int32()
+        L.check(lib.pgh_graph_hot_prefix(g._h, C.byref(hs)))
+        self._engine_hot = hs.value
+        self.engine_streams = None          # (exchange stream, compute stream) while a three-queue run is on: where pack / compaction launch
+        counts = np.zeros(8, dtype=np.int64)
+        L.check(lib.pgh_dist_need_counts(g._h, counts.ctypes.data_as(C.c_void_p)))
+        self.compact = bool(counts[:self.nb].sum() > 0)                          # this slice numbers its cold sources compactly
+        agree = torch.tensor([hs.value, 1 if self.compact else 0], dtype=torch.int64, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)                             # every rank must split the same way
+        hot = int(agree[0].item())
+        self.hot = (min(hot, self.live) + 63) // 64 * 64 if 0 < hot < self.live else 0
+        self.lists = bool(int(agree[1].item())) and self.hot > 0 and os.environ.get("PGH_DIST_EXCHANGE", "lists") != "allgather"
+        assert not self.compact or self.hot == hs.value, "a compact slice has a hot-only stream: the hot prefix is the engine's"
+        self.need_counts = counts[:self.nb].copy()
+        self.need_prefix = np.concatenate(([0], np.cumsum(self.need_counts)))
+        need_total = int(self.need_prefix[-1])
         self.bases = np.zeros(8, dtype=np.int64)
-        for b in range(self.nb):
-            r, j = divmod(b, self.bpr)
-            self.bases[b] = (j * world + r) * self.live
+        self.cold_bases = None
+        if self.lists:
+            # [j][rank][hot] | [block][referenced cold slots]
+            dense_len = self.nb * self.hot
+            for b in range(self.nb):
+                r, j = divmod(b, self.bpr)
+                self.bases[b] = (j * world + r) * self.hot
+            self.cold_bases = np.zeros(8, dtype=np.int64)
+            self.cold_bases[:self.nb] = dense_len + self.need_prefix[:-1]
+            self.cold_at = dense_len
+        else:
+            dense_len = self.nb * self.live
+            for b in range(self.nb):
+                r, j = divmod(b, self.bpr)
+                self.bases[b] = (j * world + r) * self.live
+            if self.compact:
+                # the dense exchange lands as before; this rank's image reads its cold sources from a compact copy behind it
+                self.cold_bases = np.zeros(8, dtype=np.int64)
+                self.cold_bases[:self.nb] = dense_len + self.need_prefix[:-1]
+                self.cold_at = dense_len
+        n_xg = dense_len + (need_total if self.compact else 0) + _HOT_PAD
         self.apply_bases(g)
-        n_xg = self.nb * self.live + _HOT_PAD
         self.xg_full = torch.zeros(n_xg, dtype=torch.float32, device=device)
         self.xg_local = torch.zeros(n_local, dtype=torch.float32, device=device)
         self.y = [torch.zeros(n_local, dtype=torch.float32, device=device) for _ in range(2)]
@@ -164,37 +209,114 @@ class _Buffers:
         self.v_xg_local = DeviceVector.wrap(self.xg_local.data_ptr(), n_local, keepalive=self.xg_local)
         self.v_y = [DeviceVector.wrap(t.data_ptr(), n_local, keepalive=t) for t in self.y]
         self.exchange_bytes = 4 * self.live * self.bpr * (world - 1)            # received per rank and iteration
-        self.world = world
-        # Hot / cold split of the exchange: when the slice's stream is hot-only (every cold entry lives in the
-        # propagation-blocking image) the block partial sums read just the first `hot` slots of every block, so those
-        # are exchanged first (a few hundred KB) and the bulk of the gather vector travels while they run.
-        hs = C.c_int32()
-        L.check(lib.pgh_graph_hot_prefix(g._h, C.byref(hs)))
-        agree = torch.tensor([hs.value], dtype=torch.int64, device=device)
-        dist.all_reduce(agree, op=dist.ReduceOp.MIN)                             # every rank must split the same way
-        hot = int(agree.item())
-        self.hot = (min(hot, self.live) + 63) // 64 * 64 if 0 < hot < self.live else 0
         # the big exchange and the scalar reductions use communicators of their own so that neither queues behind the other
         # (one exchange communicator per process, not per graph: PGH_DIST_SINGLE_COMM=1 keeps everything on the default one)
         self.pg_exchange = _exchange_group(dist, world)
+        if self.lists:
+            self._setup_lists(pgraph, device, dist, lib, g, rank, world)
+
+    def _setup_lists(self, pgraph, device, dist, lib, g, rank, world):
+        """Once per graph: every rank tells the owner of each block which of its cold slots it references."""
+        torch = self.torch
+        bpr, nb = self.bpr, self.nb
+        mine = torch.from_numpy(self.need_counts.astype(np.int64)).to(device)
+        everyone = torch.zeros(world * nb, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(everyone, mine)
+        counts_all = everyone.cpu().numpy().reshape(world, nb)                  # [asking rank][block]
+        lists = []
+        for b in range(nb):
+            arr = np.zeros(int(self.need_counts[b]), dtype=np.uint32)
+            if len(arr):
+                L.check(lib.pgh_dist_need_list(g._h, b, arr.ctypes.data_as(C.c_void_p)))
+            lists.append(arr)
+        ask = np.concatenate(lists) if lists else np.zeros(0, dtype=np.uint32)   # block-major = owner-major
+        ask_splits = [int(self.need_counts[s * bpr:(s + 1) * bpr].sum()) for s in range(world)]
+        asked_splits = [int(counts_all[r, rank * bpr:(rank + 1) * bpr].sum()) for r in range(world)]
+        asked = torch.zeros(sum(asked_splits), dtype=torch.int32)
+        self._all_to_all(dist, asked, torch.from_numpy(ask.view(np.int32).copy()), asked_splits, ask_splits, device)
+        seg_counts = [int(counts_all[r, rank * bpr + j]) for r in range(world) for j in range(bpr)]       # destination-major
+        seg_off = np.concatenate(([0], np.cumsum(seg_counts))).astype(np.int64)
+        seg_block = np.array([j for _ in range(world) for j in range(bpr)], dtype=np.int32)
+        slots = np.ascontiguousarray(asked.numpy().view(np.uint32))
+        L.check(lib.pgh_dist_set_send_lists(g._h, slots.ctypes.data_as(C.c_void_p), seg_block.ctypes.data_as(C.c_void_p),
+                                            seg_off.ctypes.data_as(C.c_void_p), len(seg_counts)))
+        self.send_splits, self.recv_splits = asked_splits, ask_splits
+        self.send_buf = torch.zeros(max(sum(asked_splits), 1), dtype=torch.float32, device=device)
+        self.v_send = DeviceVector.wrap(self.send_buf.data_ptr(), self.send_buf.numel(), keepalive=self.send_buf)
+        self.exchange_bytes = 4 * (self.hot * bpr * (world - 1) + sum(ask_splits) - ask_splits[rank])
+        # what the host-side count says this rank receives per step (asserted against the engine's figure by the tests)
+        self.exchange_slots = dict(hot=self.hot * bpr * (world - 1), cold=sum(ask_splits) - ask_splits[rank], cold_dense=(self.live - self.hot) * bpr * (world - 1))
+
+    def _all_to_all(self, dist, recv, send, recv_splits, send_splits, device):
+        """all_to_all_single with uneven splits on `self.pg_exchange`; gloo moves host tensors only: device tensors are staged."""
+        torch = self.torch
+        staged = dist.get_backend() != "nccl" and (recv.is_cuda or send.is_cuda)
+        on_dev = dist.get_backend() == "nccl" and not recv.is_cuda
+        if staged:
+            r_host, s_host = torch.zeros(recv.numel(), dtype=recv.dtype), send.cpu()
+            dist.all_to_all_single(r_host, s_host, recv_splits, send_splits, group=self.pg_exchange)
+            recv.copy_(r_host)
+        elif on_dev:                                                              # (setup lists are host arrays; RCCL wants device memory)
+            r_dev, s_dev = torch.zeros(recv.numel(), dtype=recv.dtype, device=device), send.to(device)
+            dist.all_to_all_single(r_dev, s_dev, recv_splits, send_splits, group=self.pg_exchange)
+            recv.copy_(r_dev.cpu())
+        else:
+            dist.all_to_all_single(recv, send, recv_splits, send_splits, group=self.pg_exchange)
 
     def apply_bases(self, g):
         """Tells the graph where every block's slice starts inside THIS object's gather vector.  The bases are state of the graph,
         not of the buffers: the engine's own loop (pgh_dist_ppr_run) lays the same graph out its own way -- two regions -- on every
         run, so a Python-driven run re-applies its layout every time it starts (cached buffers used to read a torch
         gather vector through the native split bases after an engine run on the same graph)."""
-        L.check(L.lib().pgh_graph_set_gather_bases(g._h, self.bases.ctypes.data_as(C.c_void_p)))
+        if self.cold_bases is not None:
+            L.check(L.lib().pgh_graph_set_gather_bases_split(g._h, self.bases.ctypes.data_as(C.c_void_p), self.cold_bases.ctypes.data_as(C.c_void_p)))
+        else:
+            L.check(L.lib().pgh_graph_set_gather_bases(g._h, self.bases.ctypes.data_as(C.c_void_p)))
 
     def _pieces(self, j, lo, hi):
         """views of slots [lo, hi) of the blocks j, bpr + j, ... (one per rank) inside xg_full, and of this rank's slice"""
-        L_ = self.live
+        L_ = self.hot if self.lists else self.live
         outs = [self.xg_full[(j * self.world + r) * L_ + lo:(j * self.world + r) * L_ + hi] for r in range(self.world)]
         return outs, self.xg_local[j * self.blk + lo:j * self.blk + hi]
 
-    def all_gather(self, dist, part="all"):
+    def _on_exchange_stream(self, launch):
+        """Engine launches that belong to the exchange (pack, local compaction) run on the exchange queue of a three-queue run."""
+        if self.engine_streams is None:
+            return launch()
+        lib = L.lib()
+        L.check(lib.pgh_set_stream(C.c_void_p(self.engine_streams[0].cuda_stream)))
+        try:
+            return launch()
+        finally:
+            L.check(lib.pgh_set_stream(C.c_void_p(self.engine_streams[1].cuda_stream)))
+
+    def _compact_own_copy(self, g):
+        """dense exchange, compact image: the referenced cold slots of every block, out of the dense copy"""
+        lib = L.lib()
+        hot = self._engine_hot
+
+        def launch():
+            for b in range(self.nb):
+                if self.need_counts[b]:
+                    L.check(lib.pgh_dist_compact_from_dense(g._h, b, self.v_xg_full._h, int(self.bases[b]) + hot, self.v_xg_full._h,
+                                                            self.cold_at + int(self.need_prefix[b])))
+        self._on_exchange_stream(launch)
+
+    def all_gather(self, dist, part="all", graph=None):
         """xg_local (this rank's slice of the next gather vector) -> every rank's xg_full, live prefixes only.
-        part: "all", or "hot" / "cold" = slots [0, hot) / [hot, live) of every block."""
+        part: "all", or "hot" / "cold" = slots [0, hot) / [hot, live) of every block.  graph: the slice's DeviceGraph (need lists)."""
         group = self.pg_exchange
+        if self.lists:
+            if part in ("all", "hot"):
+                for j in range(self.bpr):
+                    outs, mine = self._pieces(j, 0, self.hot)
+                    dist.all_gather(outs, mine, group=group)
+            if part in ("all", "cold"):
+                self._on_exchange_stream(lambda: L.check(L.lib().pgh_dist_pack(graph._h, self.v_xg_local._h, self.v_send._h)))
+                n_send, n_recv = sum(self.send_splits), sum(self.recv_splits)
+                self._all_to_all(dist, self.xg_full[self.cold_at:self.cold_at + n_recv], self.send_buf[:n_send], self.recv_splits, self.send_splits,
+                                 self.xg_full.device)
+            return
         if part == "all" or self.hot == 0:
             if part == "hot":
                 return
@@ -202,13 +324,16 @@ class _Buffers:
             for j in range(self.bpr):
                 dist.all_gather_into_tensor(self.xg_full[j * per:(j + 1) * per], self.xg_local[j * self.blk:j * self.blk + self.live],
                                             group=group)
+            if self.compact:
+                self._compact_own_copy(graph)
             return
         lo, hi = (0, self.hot) if part == "hot" else (self.hot, self.live)
-        if hi <= lo:
-            return                                                               # the hot prefixes are the whole live range
-        for j in range(self.bpr):
-            outs, mine = self._pieces(j, lo, hi)
-            dist.all_gather(outs, mine, group=group)
+        if hi > lo:                                                              # (else: the hot prefixes are the whole live range)
+            for j in range(self.bpr):
+                outs, mine = self._pieces(j, lo, hi)
+                dist.all_gather(outs, mine, group=group)
+        if part == "cold" and self.compact:
+            self._compact_own_copy(graph)
 
 
 _EXCHANGE_GROUPS = {}
@@ -452,10 +577,37 @@ def _external_comm(dist, world, rank):
             sys.stderr.write(f"[pygrank_amd.distributed] all-reduce callback: {exc}\n")
             return 1
 
-    cb_gather, cb_reduce = L.ALLGATHER_FN(gather), L.ALLREDUCE_FN(reduce)
-    _EXTERNAL_KEEPALIVE.extend([cb_gather, cb_reduce, hip])
+    def exchange(user, send, scounts, soffs, recv, rcounts, roffs, stream):
+        """the need lists' point-to-point stretches (4-byte elements) as one all_to_all through host memory"""
+        try:
+            if hip.hipStreamSynchronize(stream) != 0:
+                return 1
+            ssplits, rsplits = [int(scounts[r]) for r in range(world)], [int(rcounts[r]) for r in range(world)]
+            out = torch.empty(max(sum(ssplits), 1), dtype=torch.int32)
+            at = 0
+            for r in range(world):
+                if ssplits[r] and hip.hipMemcpy(out.data_ptr() + 4 * at, (send or 0) + 4 * int(soffs[r]), 4 * ssplits[r], 2) != 0:
+                    return 1
+                at += ssplits[r]
+            got = torch.empty(max(sum(rsplits), 1), dtype=torch.int32)
+            dist.all_to_all_single(got[:sum(rsplits)], out[:sum(ssplits)], rsplits, ssplits)
+            at = 0
+            for r in range(world):
+                if rsplits[r] and hip.hipMemcpy((recv or 0) + 4 * int(roffs[r]), got.data_ptr() + 4 * at, 4 * rsplits[r], 1) != 0:
+                    return 1
+                at += rsplits[r]
+            return 0
+        except Exception as exc:
+            sys.stderr.write(f"[pygrank_amd.distributed] all-to-all callback: {exc}\n")
+            return 1
+
+    cb_gather, cb_reduce, cb_exchange = L.ALLGATHER_FN(gather), L.ALLREDUCE_FN(reduce), L.ALLTOALLV_FN(exchange)
+    _EXTERNAL_KEEPALIVE.extend([cb_gather, cb_reduce, cb_exchange, hip])
     handle = C.c_void_p()
     L.check(L.lib().pgh_comm_create_external(world, rank, C.cast(cb_gather, C.c_void_p), C.cast(cb_reduce, C.c_void_p), None, C.byref(handle)))
+    # PGH_DIST_EXTERNAL_A2A=0: a host with all-gather and all-reduce only -- compact slices then copy their slots out of the gathered vector
+    if os.environ.get("PGH_DIST_EXTERNAL_A2A", "1") != "0":
+        L.check(L.lib().pgh_comm_set_alltoallv(handle, C.cast(cb_exchange, C.c_void_p)))
     return handle
 
 
@@ -578,6 +730,7 @@ class DistributedPageRank:
                              column_blocks=int(res.column_blocks), split_regions=bool(res.split_regions),
                              in_kernel_residual=bool(res.flags & 2), paused_in_kernel_residual=bool(res.flags & 1),
                              finish_in_two_launches=bool(res.flags & 4),
+                             exchange={0: "all-gather", 8: "need lists (point to point)", 16: "all-gather + local compaction"}[res.flags & 24],
                              driver="engine (RCCL)" if self._dist.get_backend() == "nccl" else "engine (host collectives)")
         if res.iterations == 0:
             return p_local
@@ -595,6 +748,7 @@ class DistributedPageRank:
              epilogue of step k, ahead of the epilogue of step k + 1, beside everything in between.
         The host reads the done flag of step k only after it has enqueued the first two stages of step k + 1."""
         cuda = device.type == "cuda"
+        bufs.engine_streams = None               # (the prologue's exchange runs on the compute queue)
         # ---- prologue of GraphFilter.rank (abstract_filters.py:52-56): global L1 norm, x0 = p / norm
         norm = self._all_reduce(bufs, dist, p_local.abssum(), dist.ReduceOp.SUM)
         if norm == 0:
@@ -606,7 +760,7 @@ class DistributedPageRank:
         L.check(lib.pgh_vec_copy(bufs.v_y[cur]._h, p._h))
         self._prepare_run(pgraph, p, bufs, lib)
         L.check(lib.pgh_dist_prescale(g._h, bufs.v_y[cur]._h, bufs.v_xg_local._h))
-        bufs.all_gather(dist, "all")
+        bufs.all_gather(dist, "all", g)
         L.check(lib.pgh_dist_state_init(state))
         if cuda:
             if getattr(self, "_side", None) is None:
@@ -615,6 +769,7 @@ class DistributedPageRank:
                 single = os.environ.get("PGH_DIST_SINGLE_STREAM", "0") == "1"
                 self._side = (self._stream, self._stream) if single else (torch.cuda.Stream(), torch.cuda.Stream())
             main, (xs, ss) = self._stream, self._side
+            bufs.engine_streams = (xs, main) if xs is not main else None
             ev_fin, ev_hot, ev_cold, ev_err = (torch.cuda.Event() for _ in range(4))
             for ev in (ev_hot, ev_cold, ev_err):
                 ev.record(main)                   # the initial exchange and state are in place once `main` gets here
@@ -655,10 +810,10 @@ class DistributedPageRank:
             with on(xs if cuda else None):                                        # ---- X: the next gather vector over xGMI
                 if cuda:
                     xs.wait_event(ev_fin)
-                bufs.all_gather(dist, "hot")
+                bufs.all_gather(dist, "hot", g)
                 if cuda:
                     ev_hot.record(xs)
-                bufs.all_gather(dist, "cold")
+                bufs.all_gather(dist, "cold", g)
                 if cuda:
                     ev_cold.record(xs)
             cur = nxt
@@ -701,8 +856,11 @@ class DistributedPageRank:
         assert steps == spmv, (steps, spmv)
         self.iteration, self.spmv, self.converged = it, spmv, converged
         self.last_error = float(bufs.state_host[6])
+        bufs.engine_streams = None
         self.exchange = dict(exchange_bytes_per_iteration_per_gpu=bufs.exchange_bytes, gather_vector_slots=bufs.nb * bufs.live,
-                             column_blocks=bufs.nb, split_regions=False, driver="python (torch.distributed)")
+                             column_blocks=bufs.nb, split_regions=False, driver="python (torch.distributed)",
+                             exchange="need lists (all_to_all)" if bufs.lists else "all-gather", compact_cold_image=bufs.compact,
+                             **({"exchange_slots": bufs.exchange_slots} if bufs.lists else {}))
         if not converged and self.error_type != "iters" and it >= self.max_iters:
             raise Exception("Could not converge within " + str(self.max_iters) + " iterations")
         factor = scale * (norm if self.preserve_norm else 1.0)                 # abstract_filters.py:63-64
@@ -812,6 +970,7 @@ class DistributedClosedFormFilter:
         self.exchange = dict(exchange_bytes_per_iteration_per_gpu=int(res.exchange_bytes), gather_vector_slots=int(res.gather_slots),
                              column_blocks=int(res.column_blocks), split_regions=bool(res.split_regions),
                              finish_in_two_launches=bool(res.flags & 4),
+                             exchange={0: "all-gather", 8: "need lists (point to point)", 16: "all-gather + local compaction"}[res.flags & 24],
                              driver="engine (RCCL)" if dist.get_backend() == "nccl" else "engine (host collectives)")
         if res.iterations == 0:
             return p_local
@@ -820,7 +979,8 @@ class DistributedClosedFormFilter:
         return out
 
     def _rank_on_stream(self, pgraph, p_local, bufs, dist, lib, g, device, torch):
-        self.exchange = dict(driver="python (torch.distributed)")
+        self.exchange = dict(driver="python (torch.distributed)", exchange="need lists (all_to_all)" if bufs.lists else "all-gather")
+        bufs.engine_streams = None
         kind = self._KINDS[self.error_type]
         tol = 0.0 if self.tol is None else max(self.tol, self.epsilon)
         linf = 1 if kind == L.ERR_LINF else 0
@@ -840,7 +1000,7 @@ class DistributedClosedFormFilter:
         first = p * float(c)                                                     # (kept alive until the copy has been enqueued)
         L.check(lib.pgh_vec_copy(v_res._h, first._h))
         L.check(lib.pgh_dist_prescale(g._h, bufs.v_y[0]._h, bufs.v_xg_local._h))
-        bufs.all_gather(dist, "all")
+        bufs.all_gather(dist, "all", g)
         L.check(lib.pgh_dist_state_init(state))
         delta = abs(float(c)) * (1.0 if not linf else scalar(float(backend_max_abs(p)), dist.ReduceOp.MAX))
         if kind == L.ERR_MABS:
@@ -858,7 +1018,7 @@ class DistributedClosedFormFilter:
             L.check(lib.pgh_dist_partial_stage(g._h, bufs.v_xg_full._h, state, 0))
             L.check(lib.pgh_dist_combine_poly(g._h, bufs.v_y[cur]._h, bufs.v_y[nxt]._h, 1.0, 0.0, v_res._h, float(c), linf,
                                               bufs.v_xg_local._h, state))
-            bufs.all_gather(dist, "all")
+            bufs.all_gather(dist, "all", g)
             dist.all_reduce(err_view, op=dist.ReduceOp.MAX if linf else dist.ReduceOp.SUM)
             bufs.state_host.copy_(bufs.state)                                    # the host decides (one read per term)
             delta = float(bufs.state_host[1]) / (pgraph.n_nodes if kind == L.ERR_MABS else 1)

@@ -58,6 +58,19 @@ def main():
     results["signed_paused"] = int(bool(ranker.exchange.get("paused_in_kernel_residual", False)))
     results["driver"] = str(ranker.exchange.get("driver"))
     results["split_regions"] = int(bool(ranker.exchange.get("split_regions")))
+    # how the cold parts travelled, and what the run says it received per iteration against the host-side count: the hot prefixes of
+    # the peers' blocks + the cold slots of the peers' blocks that THIS slice references (pgh_dist_need_counts)
+    import ctypes as C
+    need = np.zeros(8, dtype=np.int64)
+    _lib.check(_lib.lib().pgh_dist_need_counts(graph.graph._h, need.ctypes.data_as(C.c_void_p)))
+    nb, blk, hs = C.c_int32(), C.c_int64(), C.c_int32()
+    _lib.check(_lib.lib().pgh_graph_gather_layout(graph.graph._h, C.byref(nb), C.byref(blk), None))
+    _lib.check(_lib.lib().pgh_graph_hot_prefix(graph.graph._h, C.byref(hs)))
+    bpr = nb.value // world
+    results["exchange_kind"] = str(ranker.exchange.get("exchange"))
+    results["exchange_bytes"] = int(ranker.exchange.get("exchange_bytes_per_iteration_per_gpu", -1))
+    results["expected_list_bytes"] = int(4 * (hs.value * bpr * (world - 1) + need[:nb.value].sum() - need[rank * bpr:(rank + 1) * bpr].sum()))
+    results["need_total"] = int(need[:nb.value].sum())
     from pygrank_amd.distributed import DistributedAbsorbingWalks
     absorbing = DistributedAbsorbingWalks(alpha=0.85, error_type="l1", tol=1e-6, max_iters=500)
     out = absorbing.rank(graph, DeviceVector.from_host(p_local))

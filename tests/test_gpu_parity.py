@@ -145,11 +145,14 @@ def test_full_size_properties_rmat20(gpu_engine):
                                                       (2, "gloo", 18, "single_queue"), (1, "nccl", 14, "single_queue"),
                                                       (1, "nccl", 18, ""), (1, "nccl", 18, "python_driver"),
                                                       (2, "gloo", 18, "engine_loop"), (4, "gloo", 14, "engine_loop"),
-                                                      (2, "gloo", 18, "engine_loop_single_queue"), (1, "nccl", 18, "three_queues")],
+                                                      (2, "gloo", 18, "engine_loop_single_queue"), (1, "nccl", 18, "three_queues"),
+                                                      (2, "gloo", 18, "engine_loop_no_a2a"), (2, "gloo", 18, "python_allgather"),
+                                                      (2, "gloo", 18, "dense_images"), (4, "gloo", 18, "engine_loop")],
                          ids=["rccl_x1", "gloo_x2", "gloo_x4", "gloo_x2_cold_image", "gloo_x2_cold_image_single_queue", "rccl_x1_single_queue",
                               "rccl_x1_cold_image_split_regions", "rccl_x1_cold_image_python_driver",
                               "gloo_x2_cold_image_engine_loop", "gloo_x4_engine_loop", "gloo_x2_cold_image_engine_loop_single_queue",
-                              "rccl_x1_cold_image_three_queues"])
+                              "rccl_x1_cold_image_three_queues", "gloo_x2_cold_image_engine_loop_without_all_to_all",
+                              "gloo_x2_cold_image_python_driver_all_gather", "gloo_x2_cold_image_dense_layout", "gloo_x4_cold_image_engine_loop"])
 def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, scale, mode):
     """The N > 1 code path on the real engine: relabelled slice generation, the device-driven pgh_dist_* loop, in-place
     collectives on device scalars, the trimmed all-gather -- against the oracle.  World size 1 runs over RCCL; world sizes
@@ -176,6 +179,12 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
         env.update(PGH_DIST_SINGLE_COMM="1", PGH_DIST_SINGLE_STREAM="1")
     if mode == "python_driver":
         env.update(PGH_DIST_NATIVE="0")
+    if mode == "engine_loop_no_a2a":     # a host with all-gather / all-reduce only: compact slices copy their slots out of the gathered vector
+        env.update(PGH_DIST_EXTERNAL_A2A="0")
+    if mode == "python_allgather":       # the same fallback in the Python-driven loop
+        env.update(PGH_DIST_EXCHANGE="allgather")
+    if mode == "dense_images":           # rounds 1-4: the cold image numbers every live cold slot, the exchange is the all-gather alone
+        env.update(PGH_DIST_NEED_LISTS="0")
     if mode.startswith("engine_loop"):   # the ENGINE's loop with several ranks (region offsets of every rank, split exchange, ...):
         env.update(PGH_DIST_NATIVE="external")      # the collectives come back to the host (pgh_comm_create_external over gloo)
         env.update(PGH_DIST_FINISH_SPLIT="2")       # ... and the finish kernel in two launches, as a large exchange has it
@@ -192,8 +201,21 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     driver = {"": "engine (RCCL)" if backend == "nccl" else "python (torch.distributed)", "single_queue": "engine (RCCL)" if backend == "nccl"
               else "python (torch.distributed)", "python_driver": "python (torch.distributed)", "engine_loop": "engine (host collectives)",
-              "engine_loop_single_queue": "engine (host collectives)", "three_queues": "engine (RCCL)"}[mode]
+              "engine_loop_single_queue": "engine (host collectives)", "three_queues": "engine (RCCL)",
+              "engine_loop_no_a2a": "engine (host collectives)", "python_allgather": "python (torch.distributed)",
+              "dense_images": "python (torch.distributed)"}[mode]
     assert all(str(part["driver"]) == driver for part in parts), [str(part["driver"]) for part in parts]
+    # how the cold parts travelled (need lists wherever every slice has a cold image), and the received bytes a run reports
+    # against the host-side count of the slots this slice references in its peers' blocks
+    if scale > 14:
+        kind = {"engine_loop_no_a2a": "all-gather + local compaction", "python_allgather": "all-gather", "dense_images": "all-gather"}.get(mode, "need lists")
+        assert all(str(part["exchange_kind"]).startswith(kind) for part in parts), [str(part["exchange_kind"]) for part in parts]
+        assert all((int(part["need_total"]) > 0) == (mode != "dense_images") for part in parts)
+        if kind == "need lists":
+            for part in parts:
+                assert int(part["exchange_bytes"]) == int(part["expected_list_bytes"]), (int(part["exchange_bytes"]), int(part["expected_list_bytes"]))
+    else:
+        assert all(int(part["need_total"]) == 0 and str(part["exchange_kind"]) == "all-gather" for part in parts)
     if scale > 14 and driver.startswith("engine"):
         assert all(int(part["split_regions"]) == 1 for part in parts)      # hot prefixes and cold parts exchanged as two regions
     from parity_common import check_partition_against_oracle

@@ -35,12 +35,31 @@ for world in args.worlds:
     top = min(blk.value, (int(live.max()) + 63) // 64 * 64)
     bpr = nb.value // world
     bases = np.zeros(8, dtype=np.int64)
-    for b in range(nb.value):
-        r, j = divmod(b, bpr)
-        bases[b] = (j * world + r) * top
-    L.check(lib.pgh_graph_set_gather_bases(g._h, bases.ctypes.data_as(C.c_void_p)))
+    need = np.zeros(8, dtype=np.int64)
+    L.check(lib.pgh_dist_need_counts(g._h, need.ctypes.data_as(C.c_void_p)))
+    hs = C.c_int32()
+    L.check(lib.pgh_graph_hot_prefix(g._h, C.byref(hs)))
     rng = np.random.default_rng(0)
-    xg = DeviceVector.from_host(rng.random(nb.value * top + _HOT_PAD).astype(np.float32))
+    if need.sum() > 0:
+        # need lists: [block][hot] | [block][the cold slots this slice references] -- what a rank of the N-GPU run gathers from
+        hot = hs.value
+        cold_bases = np.zeros(8, dtype=np.int64)
+        for b in range(nb.value):
+            bases[b] = b * hot
+        cold_bases[:nb.value] = nb.value * hot + np.concatenate(([0], np.cumsum(need[:nb.value])))[:-1]
+        L.check(lib.pgh_graph_set_gather_bases_split(g._h, bases.ctypes.data_as(C.c_void_p), cold_bases.ctypes.data_as(C.c_void_p)))
+        xg_len = nb.value * hot + int(need.sum())
+        received = 4 * (hot * bpr * (world - 1) + int(need[bpr:nb.value].sum()))
+        print(f"world={world}: need lists -- this rank references {int(need.sum())} of {nb.value * (top - hot)} live cold slots "
+              f"({need.sum() / max(nb.value * (top - hot), 1):.3f}); received per iteration {received / 1e6:.1f} MB "
+              f"(all-gather of the live prefixes: {4 * top * bpr * (world - 1) / 1e6:.1f} MB)", flush=True)
+    else:
+        for b in range(nb.value):
+            r, j = divmod(b, bpr)
+            bases[b] = (j * world + r) * top
+        L.check(lib.pgh_graph_set_gather_bases(g._h, bases.ctypes.data_as(C.c_void_p)))
+        xg_len = nb.value * top
+    xg = DeviceVector.from_host(rng.random(xg_len + _HOT_PAD).astype(np.float32))
     if args.seeds:
         p_host = np.zeros(part.n_local, dtype=np.float32)
         p_host[:100] = 1.0
