@@ -75,6 +75,29 @@ for world in args.worlds:
             L.check(lib.pgh_profile_reset())
             L.check(lib.pgh_profile_enable(1))
         L.check(lib.pgh_ppr_step_dist(g._h, xg._h, 1.0, p._h, 0.85, y._h, out._h, None))
+    pack_note = ""
+    if need.sum() > 0:
+        # the pack launch of the need-list exchange: every destination's stretch in one kernel.  What the peers ask of this rank is, by
+        # symmetry, what it asks of them: its own list of its own blocks stands in for each of the `world` destinations
+        mine = []
+        for j in range(bpr):
+            arr = np.zeros(int(need[j]), dtype=np.uint32)
+            if len(arr):
+                L.check(lib.pgh_dist_need_list(g._h, j, arr.ctypes.data_as(C.c_void_p)))
+            mine.append(arr)
+        slots = np.concatenate(mine * world)
+        seg_counts = [len(mine[j]) for _ in range(world) for j in range(bpr)]
+        seg_off = np.concatenate(([0], np.cumsum(seg_counts))).astype(np.int64)
+        seg_block = np.array([j for _ in range(world) for j in range(bpr)], dtype=np.int32)
+        L.check(lib.pgh_dist_set_send_lists(g._h, slots.ctypes.data_as(C.c_void_p), seg_block.ctypes.data_as(C.c_void_p),
+                                            seg_off.ctypes.data_as(C.c_void_p), len(seg_counts)))
+        send = DeviceVector.from_host(np.zeros(len(slots), dtype=np.float32))
+        for _ in range(args.steps):
+            L.check(lib.pgh_dist_pack(g._h, out._h, send._h))
+        cnt, ms = C.c_int64(), C.c_double()
+        L.check(lib.pgh_profile_read(L.K_PACK, C.byref(cnt), C.byref(ms)))
+        pack_note = f" | pack launch (all {world} destinations, {len(slots)} slots = {len(slots) * 4 / 1e6:.1f} MB): {ms.value / max(cnt.value, 1) * 1e3:.1f} us"
+        del send
     L.check(lib.pgh_profile_enable(0))
     if args.seeds:
         L.check(lib.pgh_dist_release_isolated(g._h))
@@ -85,5 +108,5 @@ for world in args.worlds:
         prof[name] = ms.value / cnt.value * 1e3 if cnt.value else 0.0
     step = sum(prof.values())
     print(f"world={world} scale={scale} ef={ef} slice nnz={g.nnz} n_local={part.n_local} step={step:7.1f} us "
-          f"({g.nnz / step / 1e3:6.1f} GTEPS per rank) " + " ".join(f"{k}={v:.1f}" for k, v in prof.items()) + f" | {g.format()}", flush=True)
+          f"({g.nnz / step / 1e3:6.1f} GTEPS per rank) " + " ".join(f"{k}={v:.1f}" for k, v in prof.items()) + pack_note + f" | {g.format()}", flush=True)
     del xg, p, y, out, part, g
