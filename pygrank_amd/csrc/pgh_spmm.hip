@@ -175,10 +175,25 @@ __global__ __launch_bounds__(WG) void k_mm_edge_ids(const uint32_t* __restrict__
 // not change the hit rate (8.9-9.5 ms per step against 8.7).
 // Narrow batches: a row of <= 32 (<= 16) columns needs 8 (4) lanes, so the wavefront is cut into 8 (16) groups and one load
 // instruction fetches 8 (16) rows; a lane then holds 2 (4) of the 16 stream words of its group's round.
-template <bool HAS_VAL, int LPR, bool DROP = false>
+// SPARSE (round 5): the rows of the gather slab that are all zeros are not fetched at all.  A PageRank batch starts from seed sets: the
+// first iterate has a few thousand non-zero rows, the second the seeds' out-neighbours -- gathering them costs a 256-byte L2 miss per
+// entry for nothing (adding +0 changes no sum, bit for bit).  One byte per row (SparseGate::map, written by whoever writes the slab)
+// is looked up with the stream word, 16 entries ahead of the gather; the sources are hot-first, so the bytes of the often-referenced
+// ones share a few lines.  The dense and the sparse form are BOTH launched for every step: each evaluates the same test on the
+// device (non-zero rows of the slab against the rows that can be non-zero) and the one it does not select returns at once.
+struct SparseGate {
+    const uint8_t* map;      // [n] 1 = the row of the gather slab holds a non-zero (null: always dense)
+    const int*     nz_rows;  // non-zero rows of the slab
+    const int*     live_rows;// rows that take part in the run at all
+};
+__device__ __forceinline__ bool mm_take_sparse(const SparseGate& sg) {
+    return sg.map != nullptr && (long long)(*sg.nz_rows) * 4 < (long long)(*sg.live_rows);
+}
+template <bool HAS_VAL, int LPR, bool DROP = false, bool SPARSE = false>
 __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __restrict__ xg, int ld, int b, float* __restrict__ sums,
-                                                    const BatchState* __restrict__ state, MMDrop drop = MMDrop{}) {
+                                                    const BatchState* __restrict__ state, MMDrop drop = MMDrop{}, SparseGate sg = SparseGate{}) {
     if (state != nullptr && (state->all_done | state->paused)) return;
+    if (mm_take_sparse(sg) != SPARSE) return;
     constexpr int G = 64 / LPR;                            // groups (tiles in flight) per wavefront
     constexpr int W = 16 / LPR;                            // stream words of a 16-entry round per lane
     const int lane = threadIdx.x & 63;
@@ -203,6 +218,7 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
 #pragma unroll
             for (int k = 0; k < W; ++k) {
                 q.w[k] = __builtin_nontemporal_load(f.colf + at + k);
+                if (SPARSE) q.w[k] |= (uint32_t)sg.map[q.w[k] & 0x3fffffffu] << 30;      // (ids stay below 2^28: bit 30 is free)
                 q.c[k] = has ? __builtin_nontemporal_load(f.close + at + k) : -1;
                 q.v[k] = HAS_VAL ? __builtin_nontemporal_load(f.val + at + k) : 1.f;
                 if (DROP) {
@@ -216,8 +232,10 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int e = 8 * half + j;
-                const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute(pull + 4 * (e / W), (int)q.w[e % W]) & 0x7fffffffu;
-                x[j] = live ? *reinterpret_cast<const f32x4*>(xg + (int64_t)src * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(pull + 4 * (e / W), (int)q.w[e % W]);
+                const uint32_t src = word & (SPARSE ? 0x3fffffffu : 0x7fffffffu);
+                const bool fetch = SPARSE ? (live && (word & 0x40000000u) != 0u) : live;
+                x[j] = fetch ? *reinterpret_cast<const f32x4*>(xg + (int64_t)src * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // f64: a lane adds up to 512 terms serially
@@ -257,28 +275,78 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
     }
 }
 
-// one wavefront per closing tile: fixed-order sum of the chain of tail carries + the head piece
+// cross-tile segments: fixed-order sum of the chain of tail carries + the head piece.  A group of lanes_per_row(ld) lanes per closing
+// tile, a float4 per lane (round 4: one wavefront per tile and a float per lane -- 181 us of dependent loads at scale 23 / b = 64)
+__host__ __device__ inline int lanes_per_row(int ld) { return ld <= 16 ? 4 : (ld <= 32 ? 8 : 16); }
 __global__ __launch_bounds__(WG) void k_mm_fixup(MMView f, int ld, int b, float* __restrict__ sums, const BatchState* __restrict__ state) {
     if (state != nullptr && (state->all_done | state->paused)) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
-    const int stride = gridDim.x * (WG / 64);
-    for (int t = wave; t < f.num_tiles; t += stride) {
-        const int4 ti = f.tile[t];
-        if (ti.w < 0 || ti.z < 0) continue;
-        const int row = f.seg_row[ti.z];
-        if (row < 0) continue;
-        double total = 0.0;
-        for (int s = ti.w; s < t; ++s) total += (double)f.tail[(int64_t)s * kLanes + lane];
-        total += (double)f.head[(int64_t)t * kLanes + lane];
-        if (lane < b) sums[(int64_t)row * ld + lane] = (float)total;
+    const int lpr = lanes_per_row(ld), per_wave = 64 / lpr;
+    const int lane = threadIdx.x & 63, l = lane & (lpr - 1), c4 = 4 * l;
+    const int first = (blockIdx.x * (WG / 64) + (threadIdx.x >> 6)) * per_wave + lane / lpr;
+    const int stride = gridDim.x * (WG / 64) * per_wave;
+    // the kernel is a chain of dependent loads (tile -> segment row -> carries): four tiles per lane group travel together
+    constexpr int UF = 4;
+    for (int t0 = first; t0 < f.num_tiles; t0 += stride * UF) {
+        int4 ti[UF];
+        int row[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int t = t0 + u * stride;
+            ti[u] = t < f.num_tiles ? f.tile[t] : make_int4(0, 0, -1, -1);
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u) row[u] = (ti[u].w >= 0 && ti[u].z >= 0) ? f.seg_row[ti[u].z] : -1;
+        f32x4 head[UF], tail0[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int t = t0 + u * stride;
+            const bool ok = row[u] >= 0 && c4 < ld;
+            head[u] = ok ? *reinterpret_cast<const f32x4*>(f.head + (int64_t)t * kLanes + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            tail0[u] = (ok && ti[u].w < t) ? *reinterpret_cast<const f32x4*>(f.tail + (int64_t)ti[u].w * kLanes + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int t = t0 + u * stride;
+            if (row[u] < 0 || c4 >= ld) continue;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int s = ti[u].w;
+            if (s < t) {
+                a0 = (double)tail0[u].x, a1 = (double)tail0[u].y, a2 = (double)tail0[u].z, a3 = (double)tail0[u].w;
+                ++s;
+            }
+            // a hub row's chain runs over hundreds of tiles (the heaviest row of the bench graph: ~480): eight carries travel together and
+            // are added in tile order -- one dependent load per carry was what the 181 us of round 4's fix-up pass were
+            constexpr int UC = 8;
+            for (; s + UC <= t; s += UC) {
+                f32x4 v[UC];
+#pragma unroll
+                for (int k = 0; k < UC; ++k) v[k] = *reinterpret_cast<const f32x4*>(f.tail + (int64_t)(s + k) * kLanes + c4);
+#pragma unroll
+                for (int k = 0; k < UC; ++k) {
+                    a0 += (double)v[k].x;
+                    a1 += (double)v[k].y;
+                    a2 += (double)v[k].z;
+                    a3 += (double)v[k].w;
+                }
+            }
+            for (; s < t; ++s) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(f.tail + (int64_t)s * kLanes + c4);
+                a0 += (double)v.x;
+                a1 += (double)v.y;
+                a2 += (double)v.z;
+                a3 += (double)v.w;
+            }
+            a0 += (double)head[u].x;
+            a1 += (double)head[u].y;
+            a2 += (double)head[u].z;
+            a3 += (double)head[u].w;
+            *reinterpret_cast<f32x4*>(sums + (int64_t)row[u] * ld + c4) = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+        }
     }
 }
 
 // lanes that move one row of the [n, ld] slabs as float4s: 16 for up to 64 columns, 8 for up to 32, 4 for up to 16 (the
 // other kernels of the batch use the same shape as k_mm_partial); a wavefront moves 64 / lanes rows per pass
-__host__ __device__ inline int lanes_per_row(int ld) { return ld <= 16 ? 4 : (ld <= 32 ? 8 : 16); }
-
 struct CombineParams {
     const float* sums;       // [n, ld] plain row sums (structural zeros never written)
     const float* dst_scale;  // [n] or null
@@ -435,6 +503,38 @@ __global__ __launch_bounds__(WG) void k_mm_fold(const double* __restrict__ parti
 // close takes R = R' + (inv - inv') D, exact but for rows whose term changes sign between inv' and inv: bounded by 2 |inv - inv'|
 // sum|y|.  A column whose tolerance lies inside that bound (or that met a negative / non-finite y: R' = NaN) PAUSES the step for the
 // whole batch: every later launch is a no-op, the host runs the separate residual kernel for the step and goes on without the fusion.
+// one byte per row of a wavefront's pass (rows row0 .. row0 + 64 / lpr - 1, row0 a multiple of that count; votes = ballot of "my part
+// of my row holds a non-zero") as whole dwords from lane 0; returns the number of rows that hold a non-zero (wave-uniform).  Rows a
+// pass does not touch are rows that stay zero for the whole run: their byte may be written as 0.
+template <int LPR>
+__device__ __forceinline__ int mm_store_row_bytes_t(uint8_t* __restrict__ map, int64_t row0, int64_t n, unsigned long long votes, int lane) {
+    constexpr int ROWS = 64 / LPR, WORDS = ROWS / 4;
+    constexpr unsigned long long kGroup = LPR == 16 ? 0xffffULL : (LPR == 8 ? 0xffULL : 0xfULL);
+    uint32_t w[WORDS];
+    int count = 0;
+#pragma unroll
+    for (int k = 0; k < WORDS; ++k) {
+        w[k] = 0u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bool nz = ((votes >> ((4 * k + g) * LPR)) & kGroup) != 0ULL;
+            w[k] |= (nz ? 1u : 0u) << (8 * g);
+            count += nz ? 1 : 0;
+        }
+    }
+    if (lane == 0 && row0 < n) {                               // (the map is padded to whole passes)
+        uint32_t* out = reinterpret_cast<uint32_t*>(map + row0);
+#pragma unroll
+        for (int k = 0; k < WORDS; ++k) out[k] = w[k];
+    }
+    return count;
+}
+__device__ __forceinline__ int mm_store_row_bytes(uint8_t* __restrict__ map, int64_t row0, int64_t n, unsigned long long votes, int lpr, int lane) {
+    if (lpr == 16) return mm_store_row_bytes_t<16>(map, row0, n, votes, lane);
+    if (lpr == 8) return mm_store_row_bytes_t<8>(map, row0, n, votes, lane);
+    return mm_store_row_bytes_t<4>(map, row0, n, votes, lane);
+}
+
 struct StepParams {
     const float* sums;       // [n, ld] plain row sums (structural zeros never written)
     const f32x4* rowop;      // [n] {dst scale, s', 1 / s', row sum of M} (k_mm_rowops)
@@ -444,8 +544,17 @@ struct StepParams {
     float*       xg_new;     // [n, ld]
     double       alpha;
     int          mode;       // 0: S and T only; 1: + the in-kernel residual against state->pred_inv; 2: first step (D = sum of p)
+    uint8_t*     nz_map;     // [n] <- 1 where the written row of xg_new holds a non-zero (k_mm_partial<SPARSE>), or null
+    int*         nz_part;    // [grid] <- the number of such rows per workgroup (folded by k_mm_close2)
+    const int*   nz_prev;    // non-zero rows of xg_old, and the rows that take part in the run: the map is kept while nz_prev * 4 < live_rows
+    const int*   live_rows;
+    int          affine;     // 1: the workgroups of an XCD take a contiguous eighth of every window (diagnostic)
 };
 
+// TRACK: the form that also writes the non-zero map.  It needs 134+ registers (three wavefronts per SIMD instead of four: 900 us instead of
+// 690 for the pass at scale 23), so it is a kernel of its own that runs only while the iterate is sparse; both forms are launched for
+// every step and the one the device-side test does not select returns at once (as the two forms of k_mm_partial do).
+template <bool TRACK>
 __global__ __launch_bounds__(WG) void k_mm_step(StepParams c, int64_t n, int ld, int b, const BatchState* __restrict__ state,
                                                  double* __restrict__ partials /* [4][grid][64]: S, T, R', D */) {
     __shared__ double s_red[4][WG / 64][kLanes];
@@ -467,7 +576,17 @@ __global__ __launch_bounds__(WG) void k_mm_step(StepParams c, int64_t n, int ld,
     const float bc = (float)(1.0 - c.alpha);
     double S[4] = {0.0, 0.0, 0.0, 0.0}, T[4] = {0.0, 0.0, 0.0, 0.0}, R[4] = {0.0, 0.0, 0.0, 0.0}, D[4] = {0.0, 0.0, 0.0, 0.0};
     bool neg = false;
-    const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + wave_in_wg) * rows_per_wave + lane / lpr;
+    int nz_count = 0;
+    // The non-zero map of the slab this step writes is kept only WHILE THE ITERATE IS SPARSE (the gate of k_mm_partial<SPARSE>): once a
+    // quarter of the rows hold a non-zero the pass is dense for the rest of the run (this workgroup reports "every row": sticky), and
+    // the epilogue spends nothing on the map -- it costs ~150 us of a 690-us pass at scale 23 while it is written.
+    const bool track = c.nz_map != nullptr && (long long)(*c.nz_prev) * 4 < (long long)(*c.live_rows);
+    if (track != TRACK) return;
+    // passes of 64 / lpr rows, the whole grid streaming through one window of the slabs (a wavefront per 16-KB chunk was measured: 832 us
+    // against 689 for this pass).  The workgroups that share an XCD (blockIdx % 8) take a CONTIGUOUS eighth of every window, so the map
+    // bytes of one 64-byte line come from one L2.
+    const int64_t vb = c.affine ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    const int64_t first = (vb * (WG / 64) + wave_in_wg) * rows_per_wave + lane / lpr;
     const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
     constexpr int U = PGH_MM_COMB_U;
     int fl_next[U];                                        // row flags one trip ahead: the loads of a trip do not wait for its flags
@@ -492,8 +611,10 @@ __global__ __launch_bounds__(WG) void k_mm_step(StepParams c, int64_t n, int ld,
             xo[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.xg_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
             op[u] = ok ? c.rowop[r] : f32x4{1.f, 1.f, 1.f, 0.f};
         }
+        bool nzl[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            nzl[u] = false;
             if (fl[u] == 0) continue;
             const int64_t r = r0 + u * stride;
             f32x4 out;
@@ -518,8 +639,19 @@ __global__ __launch_bounds__(WG) void k_mm_step(StepParams c, int64_t n, int ld,
                 }
             }
             *reinterpret_cast<f32x4*>(c.xg_new + r * ld + c4) = out;
+            if (TRACK) nzl[u] = out.x != 0.f || out.y != 0.f || out.z != 0.f || out.w != 0.f;
+        }
+        if (TRACK) {
+            // one byte per row of the pass: does the row hold a non-zero?  (the lanes of a row vote; rows a pass skips are zero for ever)
+#pragma unroll
+            for (int u = 0; u < U; ++u) nz_count += mm_store_row_bytes(c.nz_map, r0 - lane / lpr + u * stride, n, __ballot(nzl[u]), lpr, lane);
         }
     }
+    // (the count leaves per workgroup and is folded by the step's close: 8192 atomic adds to ONE word cost 250 us of the pass)
+    __shared__ int s_nz[WG / 64];
+    if (lane == 0) s_nz[wave_in_wg] = nz_count;
+    __syncthreads();
+    if (c.nz_part != nullptr && threadIdx.x == 0) c.nz_part[blockIdx.x] = TRACK ? s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3] : (blockIdx.x == 0 ? *c.live_rows : 0);
     if (c.mode == 1 && neg) R[0] = R[1] = R[2] = R[3] = __builtin_nan("");      // (poisons the lane's four columns: a pause, never a wrong verdict)
     // the lane groups hold the same columns: fold them in group order, then the wavefronts in wavefront order
     for (int j = threadIdx.x; j < 4 * (WG / 64) * kLanes; j += WG) (&s_red[0][0][0])[j] = 0.0;      // columns beyond 4 * lanes
@@ -677,6 +809,9 @@ struct CloseParams {
     double tol, alpha;
     long long n_orig;
     int use_quotient, check, err_kind, mode, resume;
+    const int* nz_part;      // [nz_parts] per-workgroup counts of k_mm_step (or null)
+    int* nz_total;           // <- their sum
+    int nz_parts;
 };
 __global__ void k_mm_close2(BatchState* __restrict__ state, const double* __restrict__ folded, const double* __restrict__ err_folded, CloseParams cp) {
     const int lane = threadIdx.x;
@@ -736,6 +871,13 @@ __global__ void k_mm_close2(BatchState* __restrict__ state, const double* __rest
         state->paused = 0;
         state->executed += 1;
     }
+    if (cp.nz_part != nullptr) {                           // non-zero rows of the slab this step wrote: the gate of the next gather pass
+        int t = 0;
+        for (int i = lane; i < cp.nz_parts; i += kLanes) t += cp.nz_part[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (lane == 0) *cp.nz_total = t;
+    }
 }
 
 __global__ void k_mm_state_init(BatchState* state, int b) {
@@ -780,6 +922,9 @@ struct PermuteIn2 {
     const f32x4* rowop;
     uint8_t*     row_flags;  // [n_int] bit 0: the row of p holds a non-zero; bit 1: the row of M^T holds entries (row_has; all rows when null)
     const uint8_t* row_has;
+    uint8_t*     nz_map;     // [n_int] <- 1 where the row of out_xg0 holds a non-zero (k_mm_partial<SPARSE>)
+    int*         nz_rows;    // [wavefronts of the grid] <- their number, per wavefront (k_mm_count_fold)
+    int*         live_rows;  // [wavefronts of the grid] <- the rows whose flags are not 0 (the rows that take part in the run)
 };
 __global__ __launch_bounds__(WG) void k_mm_permute_in2(PermuteIn2 q, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, int b, int ld) {
     const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
@@ -788,6 +933,7 @@ __global__ __launch_bounds__(WG) void k_mm_permute_in2(PermuteIn2 q, const int32
     const int64_t first = (blockIdx.x * (int64_t)(WG / 64) + (threadIdx.x >> 6)) * rows_per_wave + lane / lpr;
     const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
     const bool vec = (b & 3) == 0;
+    int nz_count = 0, live_count = 0;
     for (int64_t r = first; r < n_int; r += stride) {
         const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
         auto fetch = [&](const float* src) __attribute__((always_inline)) {
@@ -812,6 +958,39 @@ __global__ __launch_bounds__(WG) void k_mm_permute_in2(PermuteIn2 q, const int32
         const f32x4 vx = q.src_x == q.src_p ? vp : fetch(q.src_x);
         *reinterpret_cast<f32x4*>(q.out_xg0 + at) = vx * q.rowop[r][1];
         if (flags == 0) *reinterpret_cast<f32x4*>(q.out_xg1 + at) = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool xnz = vx.x != 0.f || vx.y != 0.f || vx.z != 0.f || vx.w != 0.f;
+        const unsigned long long anyx = __ballot(xnz) >> (lane & ~(lpr - 1));
+        const bool row_nz = (anyx & ((1ULL << lpr) - 1ULL)) != 0ULL;
+        (void)row_nz;
+        // (wave-uniform counts by ballot: lanes beyond the row length have left the kernel, a shuffle would read their registers)
+        nz_count += mm_store_row_bytes(q.nz_map, r - lane / lpr, n_int, __ballot(xnz), lpr, lane);
+        live_count += __popcll(__ballot(l == 0 && flags != 0));
+    }
+    if (lane == 0) {                                       // per wavefront: folded by k_mm_count_fold (no same-address atomics)
+        q.nz_rows[blockIdx.x * (WG / 64) + (threadIdx.x >> 6)] = nz_count;
+        q.live_rows[blockIdx.x * (WG / 64) + (threadIdx.x >> 6)] = live_count;
+    }
+}
+__global__ __launch_bounds__(WG) void k_mm_count_fold(const int* __restrict__ a, const int* __restrict__ b, int count, int* __restrict__ out_a, int* __restrict__ out_b) {
+    __shared__ int s_a[WG / 64], s_b[WG / 64];
+    int ta = 0, tb = 0;
+    for (int i = threadIdx.x; i < count; i += WG) {
+        ta += a[i];
+        tb += b[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        ta += __shfl_xor(ta, d, 64);
+        tb += __shfl_xor(tb, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_a[threadIdx.x >> 6] = ta;
+        s_b[threadIdx.x >> 6] = tb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *out_a = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+        *out_b = s_b[0] + s_b[1] + s_b[2] + s_b[3];
     }
 }
 
@@ -1006,7 +1185,8 @@ int ensure_mm_edge_ids(pgh_graph_s* g) {
     return 0;
 }
 
-int mm_partial(pgh_graph_s* g, const float* xg, int ld, int b, float* sums, const BatchState* state, const MMDrop* drop = nullptr) {
+int mm_partial(pgh_graph_s* g, const float* xg, int ld, int b, float* sums, const BatchState* state, const MMDrop* drop = nullptr,
+               const SparseGate* gate = nullptr) {
     Runtime& r = rt();
     const BsfFormat& f = g->bsf_mm;
     const MMView v = mm_view(f);
@@ -1034,14 +1214,26 @@ int mm_partial(pgh_graph_s* g, const float* xg, int ld, int b, float* sums, cons
             default: k_mm_partial<true, 4, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, *drop); break;
         }
     } else {
+        // both forms of the pass for every step: each evaluates the gate on the device, the one it does not select returns at once
+        const SparseGate sg = gate != nullptr ? *gate : SparseGate{};
         ProfScope prof(PGH_K_SPMM);
         switch (which) {
-            case 0: k_mm_partial<false, 16><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
-            case 1: k_mm_partial<false, 8><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
-            case 2: k_mm_partial<false, 4><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
-            case 3: k_mm_partial<true, 16><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
-            case 4: k_mm_partial<true, 8><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
-            default: k_mm_partial<true, 4><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state); break;
+            case 0: k_mm_partial<false, 16><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+            case 1: k_mm_partial<false, 8><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+            case 2: k_mm_partial<false, 4><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+            case 3: k_mm_partial<true, 16><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+            case 4: k_mm_partial<true, 8><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+            default: k_mm_partial<true, 4><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+        }
+        if (sg.map != nullptr) {
+            switch (which) {
+                case 0: k_mm_partial<false, 16, false, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+                case 1: k_mm_partial<false, 8, false, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+                case 2: k_mm_partial<false, 4, false, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+                case 3: k_mm_partial<true, 16, false, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+                case 4: k_mm_partial<true, 8, false, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+                default: k_mm_partial<true, 4, false, true><<<grid, WG, 0, r.stream>>>(v, xg, ld, b, sums, state, MMDrop{}, sg); break;
+            }
         }
     }
     {
@@ -1053,6 +1245,7 @@ int mm_partial(pgh_graph_s* g, const float* xg, int ld, int b, float* sums, cons
 }
 
 int combine_grid() { return rt().num_cus * 8; }
+int cgrid_of() { return combine_grid(); }
 
 }  // namespace
 
@@ -1173,8 +1366,16 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
     const int64_t n = g->n_cols, n_int = f.n_out;
     const size_t slab = sizeof(float) * (size_t)n_int * ld;
     const f32x4* rowop = reinterpret_cast<const f32x4*>(f.mm_rowop);
-    DevBytes pint, xg0, xg1, sums, partial, folded, state_mem, factors, row_flags;
-    PGH_TRY(row_flags.alloc((size_t)n_int));
+    DevBytes pint, xg0, xg1, sums, partial, folded, state_mem, factors, row_flags, nz_maps, nz_counts;
+    PGH_TRY(row_flags.alloc((size_t)((n_int + 63) / 64 * 64 + 64)));      // whole 64-row chunks (k_mm_step reads a chunk's flags as one line)
+    // non-zero rows of the two gather slabs (k_mm_partial<SPARSE>): a byte per row, and {rows that hold a non-zero [2], rows in the run}
+    const int64_t map_len = (n_int + 63) / 64 * 64 + 64;         // whole passes of 16 rows, 16-byte aligned halves
+    PGH_TRY(nz_maps.alloc(2 * (size_t)map_len));
+    const int in_grid = blocks_for(n_int * lanes_per_row(ld));
+    PGH_TRY(nz_counts.alloc(sizeof(int) * (size_t)(4 + cgrid_of() + 2 * in_grid * (WG / 64))));
+    uint8_t* nz_map[2] = {nz_maps.as<uint8_t>(), nz_maps.as<uint8_t>() + map_len};
+    int* nz_cnt = nz_counts.as<int>();
+    const bool sparse_gate = rate == 0.0 && !(getenv("PGH_MM_SPARSE") != nullptr && atoi(getenv("PGH_MM_SPARSE")) == 0);
     // rows without entries and without personalization are zero in every iterate when the loop starts from p (they are then
     // zero in the start iterate too): nobody reads or writes them after the way in
     const bool skip_dead = cfg->start_from_p != 0 && f.mm_row_has != nullptr;
@@ -1196,8 +1397,15 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
     PGH_HIP(hipEventRecord(ev_a, r.stream));
     if (!skip_dead) PGH_HIP(hipMemsetAsync(sums.p, 0, slab, r.stream));      // structural zeros of the rows without entries (every row is processed)
     k_mm_state_init<<<1, kLanes, 0, r.stream>>>(state, b);
+    PGH_HIP(hipMemsetAsync(nz_maps.p, 0, 2 * (size_t)map_len, r.stream));       // rows nobody ever writes hold zeros: their bytes stay 0
+    PGH_HIP(hipMemsetAsync(nz_counts.p, 0, sizeof(int) * 4, r.stream));
+    int* nz_part = nz_cnt + 4;                                           // [cgrid] k_mm_step's per-workgroup counts
+    int* in_part = nz_part + cgrid_of();                                 // [2][in_grid * 4] the way in's per-wavefront counts
     {
         PermuteIn2 q{};
+        q.nz_map = nz_map[0];
+        q.nz_rows = in_part;
+        q.live_rows = in_part + in_grid * (WG / 64);
         q.src_p = p->data;
         q.src_x = cfg->start_from_p ? p->data : ranks->data;                  // abstract_filters.py:56 without / with warm_start
         q.out_p = pint.as<float>();
@@ -1206,7 +1414,8 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
         q.rowop = rowop;
         q.row_flags = row_flags.as<uint8_t>();
         q.row_has = skip_dead ? f.mm_row_has : nullptr;                       // null: every row counts as holding entries
-        k_mm_permute_in2<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(q, f.perm, n_int, n, b, ld);
+        k_mm_permute_in2<<<in_grid, WG, 0, r.stream>>>(q, f.perm, n_int, n, b, ld);
+        k_mm_count_fold<<<1, WG, 0, r.stream>>>(q.nz_rows, q.live_rows, in_grid * (WG / 64), nz_cnt + 0, nz_cnt + 2);
     }
     float* buf[2] = {xg0.as<float>(), xg1.as<float>()};
     double* fold = folded.as<double>();
@@ -1236,6 +1445,9 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
         c2.check = check;
         c2.mode = mode;
         c2.resume = resume;
+        c2.nz_part = sparse_gate ? nz_part : nullptr;
+        c2.nz_parts = cgrid;
+        c2.nz_total = nz_cnt + (k & 1);
         k_mm_close2<<<1, kLanes, 0, r.stream>>>(state, fold, fold + 4 * kLanes, c2);
         PGH_HIP(hipGetLastError());
         return 0;
@@ -1244,7 +1456,13 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
         MMDrop drop_store;
         const MMDrop* drop = nullptr;
         PGH_TRY(make_drop(g, rate, seed0 + (uint64_t)(k - 1), &drop_store, &drop));
-        PGH_TRY(mm_partial(g, buf[(k - 1) & 1], ld, b, sums.as<float>(), state, drop));
+        SparseGate gate{};
+        if (sparse_gate) {
+            gate.map = nz_map[(k - 1) & 1];
+            gate.nz_rows = nz_cnt + ((k - 1) & 1);
+            gate.live_rows = nz_cnt + 2;
+        }
+        PGH_TRY(mm_partial(g, buf[(k - 1) & 1], ld, b, sums.as<float>(), state, drop, sparse_gate ? &gate : nullptr));
         const int mode = k == 1 ? 2 : (fused ? 1 : 0);
         StepParams c{};
         c.sums = sums.as<float>();
@@ -1255,15 +1473,24 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
         c.xg_new = buf[k & 1];
         c.alpha = cfg->alpha;
         c.mode = mode;
+        c.nz_map = sparse_gate ? nz_map[k & 1] : nullptr;
+        c.nz_part = sparse_gate ? nz_part : nullptr;
+        c.nz_prev = nz_cnt + ((k - 1) & 1);
+        c.live_rows = nz_cnt + 2;
+        c.affine = getenv("PGH_MM_AFFINE") != nullptr && atoi(getenv("PGH_MM_AFFINE")) != 0;
         {
             ProfScope prof(PGH_K_COMBINE);
-            k_mm_step<<<cgrid, WG, 0, r.stream>>>(c, n_int, ld, b, state, partial.as<double>());
+            k_mm_step<false><<<cgrid, WG, 0, r.stream>>>(c, n_int, ld, b, state, partial.as<double>());
+            if (sparse_gate) k_mm_step<true><<<cgrid, WG, 0, r.stream>>>(c, n_int, ld, b, state, partial.as<double>());
         }
         k_mm_fold4<<<dim3(kLanes, 4), WG, 0, r.stream>>>(partial.as<double>(), cgrid, state, fold);
         if (mode == 1) {
             CloseParams c2 = cp;
             c2.check = check_of(k) ? 1 : 0;
             c2.mode = 1;
+            c2.nz_part = sparse_gate ? nz_part : nullptr;
+            c2.nz_parts = cgrid;
+            c2.nz_total = nz_cnt + (k & 1);
             k_mm_close2<<<1, kLanes, 0, r.stream>>>(state, fold, fold + 4 * kLanes, c2);
         } else {
             PGH_TRY(close_plain(k, mode, 0));

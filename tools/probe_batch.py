@@ -31,7 +31,9 @@ def main():
         feats[np.sort(rng.choice(cand, 100, replace=False)), j] = 1.0
     F = pg.to_primitive(feats)
     ranker = pg.PageRank(0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+    out = None
     for rep in range(2):
+        del out                                   # (a result kept across the call costs the next one a 2 GB hipMalloc: 0-300 ms of wall)
         L.check(L.lib().pgh_sync())
         t0 = time.perf_counter()
         out = ranker.propagate(adj, F)
