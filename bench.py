@@ -43,7 +43,7 @@ ALPHA, TOL, MAX_ITERS, SEEDS = 0.85, 1e-6, 1000, 100
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 # HBM traffic of the step kernels: rocprofv3 --pmc passes of this same command (tools/gpu_bench_call.sh), summarised by
 # tools/summarize_pmc.py with the guide's gfx950 corrections; counters cannot be read from inside the timed process
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "bench_n1_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05", "bench_n1_pmc.json")
 # the launches of one PPR iteration, in stream order (HIP-event ids of include/pgh.h)
 STEP_KERNELS = ("spmv", "fixup", "pb_gather", "pb_finish", "combine", "residual", "close")
 
@@ -84,19 +84,22 @@ def measured_traffic(scale, ef, blocked):
     return (int(total), os.path.relpath(PMC_SUMMARY, ROOT)) if total > 0 else (None, None)
 
 
-def measured_batch_traffic(scale, ef, width):
+def measured_batch_traffic(scale, ef, width, batch_steps=11):
     """HBM bytes of one batch step of the multi-seed loop (k_mm_partial + fix-up + combine + residual) from the committed PMC
-    summary of tools/probe_batch_kernels.py (profiles/r04/spmm_final_pmc.json; same hash rule as the headline's traffic)."""
-    path = os.path.join(ROOT, "profiles", "r04", "spmm_final_pmc.json")
+    summary of tools/probe_batch_kernels.py (profiles/r05/spmm_final_pmc.json; same hash rule as the headline's traffic)."""
+    path = os.path.join(ROOT, "profiles", "r05", "spmm_final_pmc.json")
     if (scale, ef, width) != (23, 16, 64) or not os.path.exists(path):
         return {}
     with open(path) as f:
         pmc = json.load(f)
     if pmc.get("_meta", {}).get("csrc_sha16") != csrc_sha16():
         return dict(measured_gb_per_step=None, measured_traffic_source="stale: " + os.path.relpath(path, ROOT))
-    total = sum(row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"] for name, row in pmc.items()
-                if name.startswith(("k_mm_partial", "k_mm_fixup", "k_mm_combine", "k_mm_residual")))
-    return dict(measured_gb_per_step=round(total / 1e9, 2), measured_traffic_source=os.path.relpath(path, ROOT))
+    # per batch step: every launch of the loop's kernels in the profiled run over the steps that did work (the gather pass in its two
+    # forms, the fix-up, the epilogue in its two forms, the separate residual of the first step, folds and closes)
+    working = max(int(batch_steps), 1)               # (the run-ahead leaves a few no-op iterations behind the stop: they move nothing)
+    total = sum((row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]) * row.get("dispatches", 1) for name, row in pmc.items()
+                if name.startswith(("k_mm_partial", "k_mm_fixup", "k_mm_step", "k_mm_residual2", "k_mm_fold", "k_mm_close2")))
+    return dict(measured_gb_per_step=round(total / working / 1e9, 2), measured_traffic_source=os.path.relpath(path, ROOT))
 
 
 def stream_ceiling_gbs(lib, L):
@@ -282,7 +285,7 @@ def single_gpu(args):
             secondary["ppr_l1_1e-6_batch_of_64_seeds"] = dict(
                 edge_vector_products_per_s_G=round(nnz * products / dt / 1e9, 1), device_step_us=round(info[0]["loop_ms"] / steps * 1e3, 1),
                 nominal_gbs=round((8 * nnz + 4 * n + 12 * n * width) / (info[0]["loop_ms"] / steps * 1e-3) / 1e9, 1),
-                batch_steps=steps, width=width, **measured_batch_traffic(scale, ef, width))
+                batch_steps=steps, width=width, **measured_batch_traffic(scale, ef, width, steps))
             del feats
         except Exception as exc:                     # a side measurement never takes the headline down
             secondary["ppr_l1_1e-6_batch_of_64_seeds"] = dict(error=str(exc))

@@ -35,6 +35,18 @@ def main():
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     done = 0
+    # what the harness PROVES, leg by leg: how many runs land within north_star's 1e-6, within 2e-6, above; and how far
+    # the stopping iterations lie from the oracle's.  Every run outside the four analysed classes -- alpha >= 0.99, runs of more than
+    # 100 steps, a signed personalization, the "chebyshev" recurrence -- is HELD to 1e-6.
+    stats = {}
+
+    def record(leg, rel, delta):
+        row = stats.setdefault(leg, dict(runs=0, le_1e6=0, le_2e6=0, above=0, worst=0.0, deltas={}))
+        row["runs"] += 1
+        row["le_1e6" if rel <= 1e-6 else ("le_2e6" if rel <= 2e-6 else "above")] += 1
+        row["worst"] = max(row["worst"], float(rel))
+        row["deltas"][int(delta)] = row["deltas"].get(int(delta), 0) + 1
+
     while time.time() < t_end:
         A = random_graph(rng)
         n = A.shape[0]
@@ -90,6 +102,7 @@ def main():
             rel = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-30)
             # (a signed personalization under a mask that drops half the entries loses digits to cancellation in ANY f32 evaluation: the
             # host double reproduces the engine's 7.65e-6 of seed 41 #3900 to the last digit)
+            record("dropout loop, signed p" if (p < 0).any() else "dropout loop", rel, 0)
             if rel > (2e-5 if (p < 0).any() else 4e-6) or ranker.last_loop["spmv"] != steps:
                 print("MISMATCH dropout loop", desc, "rate", rate, "steps", steps, "rel", rel, flush=True)
                 sys.exit(1)
@@ -164,7 +177,8 @@ def main():
                 # a residual within f32 rounding of the tolerance may stop an iteration apart: the iterates then differ by ~tol.
                 # The columns are not normalised (magnitudes up to 17): the f32 rounding noise of a column's residual
                 # scales with it and reaches tens of percent of tol = 1e-6, i.e. up to two steps of the 0.85 contraction.
-                if abs(its - it) > max(2, it // 25) or rel > 2e-6:
+                record("propagate (per column)", rel, its - it)
+                if abs(its - it) > max(2, it // 25) or rel > 1e-6:
                     print("MISMATCH propagate", desc, "column", j, rel, "iterations", its, it, flush=True)
                     if os.environ.get("PGH_STRESS_DUMP"):          # replay material for a scratch script
                         sp.save_npz(os.path.join(os.environ["PGH_STRESS_DUMP"], "case_graph.npz"), sp.csr_matrix(A))
@@ -203,7 +217,24 @@ def main():
             print("NOTE", desc, type(ranker).__name__, {k: v for k, v in vars(ranker).items() if k in ("alpha", "use_quotient")},
                   getattr(ranker.convergence, "tol", None), getattr(ranker.convergence.error_type, "__name__", ranker.convergence.error_type),
                   "iterations", its, it, "rel", rel, flush=True)
-        bound = 4e-6 if which == 3 else 2e-6                        # chebyshev: parity_common.py
+        signed = bool((p < 0).any())
+        leg = {0: "PageRank", 1: "AbsorbingWalks", 2: "HeatKernel taylor", 3: "HeatKernel chebyshev"}[which]
+        if which == 0 and kw["alpha"] >= 0.99:
+            leg += " alpha=0.99"
+        if signed:
+            leg += ", signed p"
+        if which in (0, 1) and its > 100 and "0.99" not in leg:
+            leg += ", > 100 steps"
+        record(leg, rel, its - it)
+        # north_star's bound for every run outside the analysed classes; the "chebyshev" recurrence S_k = (2 M^T - I) S_{k-1} amplifies
+        # the f32 rounding of the INPUT vectors (x20 on rmat12/heat_cheb) whatever precision the recurrence itself runs in: 4e-6; a signed
+        # personalization loses digits to cancellation in any f32 evaluation (the host double reproduces the engine's misses): 2e-6
+        bound = 4e-6 if which == 3 else (2e-6 if signed else 1e-6)
+        if which in (0, 1) and its > 100 and bound < 2e-6:
+            # a run of hundreds of steps (a slowly mixing graph: rings, bands) carries the f32 rounding of its STORED operands (degrees,
+            # p / |p|) through every step: seed 11 #687 (AbsorbingWalks, 286 steps) misses the oracle by 1.8658913e-06 on the engine AND,
+            # to the last digit, on the host double -- storage, not evaluation.  Held to 2e-6, logged as a leg of its own.
+            bound = 2e-6
         if which == 0 and kw["alpha"] >= 0.99:
             # alpha = 0.99 amplifies every rounding of a step by up to 1 / (1 - alpha) over a run of 100+ steps: ANY f32 evaluation
             # drifts -- the host double misses the oracle by 3.13e-6 where the engine misses it by 3.25e-6 (seed 62 #8480, 143 steps)
@@ -218,6 +249,11 @@ def main():
                          want=want, its=its, it=it, norm=norm)
             sys.exit(1)
         done += 1
+    for leg in sorted(stats):
+        row = stats[leg]
+        deltas = " ".join(f"{k:+d}:{v}" for k, v in sorted(row["deltas"].items()))
+        print(f"  {leg:34s} runs {row['runs']:6d}  rel-Linf <= 1e-6: {row['le_1e6']:6d}  (1e-6, 2e-6]: {row['le_2e6']:4d}  above: {row['above']:4d}  "
+              f"worst {row['worst']:.2e}  iterations engine - oracle: {deltas}", flush=True)
     print(f"filters stress ok: {done} runs in {args.seconds:.0f} s (seed {args.seed})", flush=True)
 
 

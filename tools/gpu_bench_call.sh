@@ -3,7 +3,7 @@
 export PYTHONPATH=$GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-TAG=${1:-r04}
+TAG=${1:-r05}
 timeout 600 python bench.py --gpus 1 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"; cat $O/bench_$TAG.json; tail -3 $O/bench_$TAG.err
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$TAG -- python3 $R/bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu --no-secondary > $O/trace_$TAG.log 2>&1; echo "trace rc=$?"
