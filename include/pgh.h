@@ -242,6 +242,11 @@ typedef struct {
  * kernels on whichever layout the graph carries (blocked stream + cold image: one index word per entry, built on first use). */
 int pgh_ppr_run_dropout(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, double rate, uint64_t seed0,
                         pgh_loop_result* res);
+/* pgh_ppr_run with f64 STORAGE (iterates, sums, quotient, residual in f64 on the blocked f64 image; p and ranks stay f32 vectors): the
+ * reference's numpy backend is fp64 (epsilon() = finfo(float64).eps, pygrank/core/backend/numpy.py:84-86) and its tests run tol = 1e-9
+ * (tests/test_filters.py:189,194), which the f32 engine clamps at fp32 eps.  cfg->tol is used as given (the caller passes max(tol, fp64 eps));
+ * the L1 / Mabs / max rules and "iters"; an exactness mode (one host look per step), not a fast one.  Square graphs with the blocked layout. */
+int pgh_ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 /* ranks: in = starting vector (copy of p or warm_start), out = final ranks. */
 int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg,

@@ -781,6 +781,64 @@ int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg*
     PGH_REPORT_NORM(rc, res)
     return rc;
 }
+// PageRank with f64 storage (include/pgh.h pgh_ppr_run_f64): iterates, sums, quotient and residual in double over the stored f32 matrix
+int pgh_ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    CHECK(g && p && ranks && cfg && res, "pgh_ppr_run_f64: null argument");
+    CHECK(g->n_rows == g->n_cols && p->n == g->n_cols && ranks->n == g->n_cols, "pgh_ppr_run_f64: shape mismatch");
+    CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
+    memset(res, 0, sizeof(*res));
+    const int64_t n = g->n_cols;
+    double norm = cfg->in_norm;
+    if (norm < 0.0) {
+        norm = 0.0;
+        for (int64_t i = 0; i < n; ++i) norm += std::fabs((double)p->data[i]);
+        res->in_norm = norm;
+        if (norm == 0.0) return 0;
+    }
+    if (norm == 0.0) norm = 1.0;
+    std::vector<double> pn(n), cur(n), next(n);
+    for (int64_t i = 0; i < n; ++i) pn[i] = (double)p->data[i] / norm;
+    for (int64_t i = 0; i < n; ++i) cur[i] = cfg->start_from_p ? pn[i] : (double)ranks->data[i];
+    double scale = 1.0, err = 0.0;
+    int it = 1, spmv = 0;
+    bool converged = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (it < cfg->max_iters) {
+        double S = 0.0;
+        for (int64_t r = 0; r < n; ++r) {
+            double acc = 0.0;
+            for (int64_t k = g->rowptr[r]; k < g->rowptr[r + 1]; ++k) acc += (double)g->val[k] * cur[g->col[k]];
+            next[r] = cfg->alpha * scale * acc + (1.0 - cfg->alpha) * pn[r];
+            S += next[r];
+        }
+        const double scale_new = cfg->use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+        ++spmv;
+        ++it;
+        const bool check = cfg->err_kind != PGH_ERR_ITERS && it < cfg->max_iters && it % cfg->end_modulo == 0;
+        if (check) {
+            err = 0.0;
+            for (int64_t i = 0; i < n; ++i) {
+                const double d = std::fabs(next[i] * scale_new - cur[i] * scale);
+                err = cfg->err_kind == PGH_ERR_LINF ? std::max(err, d) : err + d;
+            }
+            if (cfg->err_kind == PGH_ERR_MABS) err /= (double)n;
+        }
+        cur.swap(next);
+        scale = scale_new;
+        if (check && err <= cfg->tol) {
+            converged = true;
+            break;
+        }
+    }
+    const double f = scale * (cfg->out_scale < 0.0 ? norm : cfg->out_scale);
+    for (int64_t i = 0; i < n; ++i) ranks->data[i] = (float)(cur[i] * f);
+    res->iterations = it;
+    res->converged = converged ? 1 : 0;
+    res->spmv_count = spmv;
+    res->last_error = err;
+    res->loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
 // PageRank on graph_dropout(M, rate) with the mask of step k = pgh_spmv_dropout's for seed seed0 + k - 1
 int pgh_ppr_run_dropout(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg_in, double rate, uint64_t seed0,
                         pgh_loop_result* res) {

@@ -132,6 +132,7 @@ SIGNATURES = {
     "pgh_poly_step": (C.c_int, [c_graph, c_vec, c_vec, C.c_double, C.c_double, c_vec, C.c_double, C.c_int, c_f64p]),
     "pgh_scaled_residual": (C.c_int, [C.c_int, c_vec, C.c_double, c_vec, C.c_double, c_f64p]),
     "pgh_ppr_run": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
+    "pgh_ppr_run_f64": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_ppr_run_dropout": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.c_double, C.c_uint64, C.POINTER(LoopResult)]),
     "pgh_absorb_run": (C.c_int, [c_graph, c_vec, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_sarw_run": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),

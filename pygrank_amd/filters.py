@@ -224,12 +224,26 @@ class RecursiveGraphFilter(GraphFilter):
 class PageRank(RecursiveGraphFilter):
     """adhoc.py:9-46: r <- alpha * M^T r + (1 - alpha) * p."""
 
-    def __init__(self, alpha=0.85, *args, **kwargs):
+    def __init__(self, alpha=0.85, *args, dtype=None, **kwargs):
+        """dtype="float64" (an extension of this backend): the loop keeps its iterates, sums, quotient and residual in f64 on the engine's
+        f64 image (pgh_ppr_run_f64) and the tolerance is clamped at fp64 eps like the reference's numpy backend
+        (pygrank/core/backend/numpy.py:84-86) instead of fp32 eps -- e.g. tol=1e-9 as in the reference's tests/test_filters.py:189,194.
+        An exactness mode (one host look per step); personalization and ranks stay f32 vectors."""
         self.alpha = alpha
+        if dtype not in (None, "float32", "float64"):
+            raise Exception("PageRank: dtype is None / 'float32' (the engine's f32 loop) or 'float64'")
+        self.dtype = None if dtype == "float32" else dtype
         super().__init__(*args, **kwargs)
 
     def _reference(self):
         return f"personalized PageRank (restart probability {1 - self.alpha:.3g})"
+
+    def _f64_cfg(self, cfg):
+        """the loop configuration of the f64 route: the tolerance never below fp64 eps (convergence.py:101 with numpy's epsilon())"""
+        import numpy as np
+        tol = self.convergence.tol
+        cfg.tol = 0.0 if tol is None else max(float(tol), float(np.finfo(np.float64).eps))
+        return cfg
 
     def _formula(self, M, personalization, ranks, *args, **kwargs):               # adhoc.py:34-36
         return backend.conv(ranks, M) * self.alpha + personalization * (1 - self.alpha)
@@ -242,6 +256,10 @@ class PageRank(RecursiveGraphFilter):
         p = personalization.np
         if not isinstance(p, DeviceVector):
             return False
+        if self.dtype == "float64":
+            if cfg is None:
+                raise Exception("PageRank(dtype='float64') needs a stopping rule the engine evaluates (Mabs / L1 / MaxDifference / 'iters')")
+            return self._run_recursive(L.lib().pgh_ppr_run_f64, _device_graph(M), self._f64_cfg(cfg), ranks, p)
         return self._run_recursive(L.lib().pgh_ppr_run, _device_graph(M), cfg, ranks, p)
 
     fused_dropout = True          # False (on an instance): rank(..., graph_dropout=) takes the hook protocol, one engine call per primitive
@@ -252,6 +270,8 @@ class PageRank(RecursiveGraphFilter):
             return None
         if dropout and not (self.fused_dropout and 0 < dropout < 1):
             return None
+        if self.dtype == "float64" and dropout:
+            raise Exception("PageRank(dtype='float64') has no graph_dropout route")
         p = personalization.np
         cfg = self._loop_cfg(self.alpha, bool(self.use_quotient), -1.0 if self.preserve_norm else 1.0)     # -1: times the norm
         if cfg is None or not isinstance(p, DeviceVector):
@@ -265,6 +285,8 @@ class PageRank(RecursiveGraphFilter):
         self.convergence.start()
         ranks = to_signal(personalization, DeviceVector.empty(len(p)))
         entry = L.lib().pgh_ppr_run
+        if self.dtype == "float64":
+            entry, cfg = L.lib().pgh_ppr_run_f64, self._f64_cfg(cfg)
         if dropout:
             # the masks the hook protocol would draw (abstract_filters.py:57-62): one for _start, one per step, one for _end -- step k
             # runs on the (k + 1)-th of them, so both routes compute the same thing from the same seed

@@ -500,6 +500,46 @@ def check_warm_start_and_propagate(pg):                      # abstract_filters.
     assert np.allclose(cols[:, 0], np.asarray(pg.PageRank(0.85).rank(graph, p.copy()).np), rtol=1e-6, atol=1e-9)
 
 
+def check_pagerank_float64_storage(pg):
+    """The reference's numpy backend is fp64: epsilon() = finfo(float64).eps (pygrank/core/backend/numpy.py:84-86), and its tests run
+    tol = 1e-9 (tests/test_filters.py:189,194).  The f32 loop clamps that tolerance at fp32 eps; PageRank(dtype="float64") keeps the loop
+    in f64 (pgh_ppr_run_f64) and stops where the REFERENCE stops: the committed golden runs (tests/golden/golden.npz, made by the
+    reference itself) -- er10k: 18 iterations -- and the oracle at fp64 eps, ranks <= 1e-6 (they leave as f32)."""
+    import os
+    import cases
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.npz"))
+    for name, gkey, algo, kwargs in cases.CASES:
+        if algo != "pagerank" or kwargs.get("tol", 1) > 2e-9 or kwargs.get("converge_to_eigenvectors"):
+            continue
+        A, directed, p = cases.GRAPHS[gkey]()
+        kw = {k: v for k, v in kwargs.items() if k not in ("normalization", "renormalize")}
+        pre = pg.preprocessor(normalization=kwargs.get("normalization", "auto"), renormalize=kwargs.get("renormalize", False))
+        ranker = pg.PageRank(preprocessor=pre, dtype="float64", **kw)
+        got = np.asarray(ranker.rank(pg.AdjacencyWrapper(A, directed=directed), p.copy()).np, dtype=np.float64)
+        want_iters = int(golden[name + "|iters"])
+        assert ranker.convergence.iteration == want_iters, (name, ranker.convergence.iteration, want_iters)
+        want = golden[name + "|ranks"]
+        assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), name
+        # the f32 loop cannot honour that tolerance (it stops at fp32 eps): fewer iterations than the reference
+        f32 = pg.PageRank(preprocessor=pre, **kw)
+        f32.rank(pg.AdjacencyWrapper(A, directed=directed), p.copy())
+        assert f32.convergence.iteration < want_iters, name
+    # warm start, the max rule without the quotient, a fixed step count: against the oracle at fp64 eps
+    A, directed, p = cases.GRAPHS["rmat10_dir"]()
+    M = orc.normalize(A, "auto", directed)
+    graph = pg.AdjacencyWrapper(A, directed=directed)
+    for kw_engine, kw_oracle in ((dict(error_type=pg.MaxDifference, tol=1e-11, max_iters=500, use_quotient=False), dict(error_type="linf", tol=1e-11, max_iters=500, use_quotient=False)),
+                                 (dict(error_type="iters", max_iters=30), dict(error_type="iters", max_iters=30)),
+                                 (dict(error_type=pg.L1, tol=1e-10, max_iters=500), dict(error_type="l1", tol=1e-10, max_iters=500))):
+        ranker = pg.PageRank(0.85, dtype="float64", **kw_engine)
+        got = np.asarray(ranker.rank(graph, p.copy()).np, dtype=np.float64)
+        want, want_iters = orc.pagerank(M, p, alpha=0.85, **kw_oracle)
+        assert ranker.convergence.iteration == want_iters, (kw_oracle, ranker.convergence.iteration, want_iters)
+        assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), kw_oracle
+    with pytest.raises(Exception):
+        pg.PageRank(0.85, dtype="float16")
+
+
 ALL = [v for k, v in sorted(globals().items()) if k.startswith("check_") and callable(v)]
 
 
