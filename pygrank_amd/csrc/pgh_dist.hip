@@ -348,7 +348,11 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     // need lists: every slice compact, the hot prefixes a region of their own, a communicator that can move stretches point to point
     const bool can_p2p = c->ext_gather == nullptr || c->ext_alltoallv != nullptr;
     const char* xenv = getenv("PGH_DIST_EXCHANGE");
-    const bool lists = compact && h_agree[4] == 0 && split && can_p2p && !(xenv != nullptr && std::string(xenv) == "allgather");
+    // a rank ALONE references every live slot of its own blocks (the relabelling sorts by reference count: nothing unreferenced lies below
+    // `live`), so its compact numbering is the dense one: the slice is written in place as ever and nothing is packed or copied
+    bool identity = compact && c->world == 1 && split;
+    for (int b = 0; b < nb && identity; ++b) identity = need8[b] == (live8[b] > hot_slots ? live8[b] - hot_slots : 0);
+    const bool lists = compact && !identity && h_agree[4] == 0 && split && can_p2p && !(xenv != nullptr && std::string(xenv) == "allgather");
     c->nb = nb;
     c->blk = blk;
     c->bpr = nb / c->world;
@@ -356,7 +360,7 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     c->hot = split ? (int)hot_all : 0;
     c->n_local = g->n_cols;
     c->lists = lists;
-    c->compact_copy = compact && !lists;
+    c->compact_copy = compact && !lists && !identity;
     PGH_CHECK(blk * nb == g->n_rows && c->n_local == (int64_t)c->bpr * blk, "pgh_dist_ppr_run: the slice does not match the block layout");
     int64_t need_prefix[9] = {0};
     for (int b = 0; b < 8; ++b) need_prefix[b + 1] = need_prefix[b] + (b < nb ? need8[b] : 0);

@@ -925,6 +925,8 @@ struct PermuteIn2 {
     uint8_t*     nz_map;     // [n_int] <- 1 where the row of out_xg0 holds a non-zero (k_mm_partial<SPARSE>)
     int*         nz_rows;    // [wavefronts of the grid] <- their number, per wavefront (k_mm_count_fold)
     int*         live_rows;  // [wavefronts of the grid] <- the rows whose flags are not 0 (the rows that take part in the run)
+    double*      pred_part;  // [2][grid][64] per-workgroup {sum_r deg_r * x0[r], sum_r p[r]} per column: the first step's predicted quotient
+                             // (k_mm_first_pred), or null
 };
 __global__ __launch_bounds__(WG) void k_mm_permute_in2(PermuteIn2 q, const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, int b, int ld) {
     const int lpr = lanes_per_row(ld), rows_per_wave = 64 / lpr;
@@ -934,6 +936,7 @@ __global__ __launch_bounds__(WG) void k_mm_permute_in2(PermuteIn2 q, const int32
     const int64_t stride = (int64_t)gridDim.x * (WG / 64) * rows_per_wave;
     const bool vec = (b & 3) == 0;
     int nz_count = 0, live_count = 0;
+    double t0[4] = {0.0, 0.0, 0.0, 0.0}, sp[4] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t r = first; r < n_int; r += stride) {
         const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
         auto fetch = [&](const float* src) __attribute__((always_inline)) {
@@ -959,6 +962,14 @@ __global__ __launch_bounds__(WG) void k_mm_permute_in2(PermuteIn2 q, const int32
         *reinterpret_cast<f32x4*>(q.out_xg0 + at) = vx * q.rowop[r][1];
         if (flags == 0) *reinterpret_cast<f32x4*>(q.out_xg1 + at) = f32x4{0.f, 0.f, 0.f, 0.f};
         const bool xnz = vx.x != 0.f || vx.y != 0.f || vx.z != 0.f || vx.w != 0.f;
+        if (q.pred_part != nullptr && (xnz || nz)) {
+            const double deg = (double)q.rowop[r][3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t0[k] += deg * (double)vx[k];
+                sp[k] += (double)vp[k];
+            }
+        }
         const unsigned long long anyx = __ballot(xnz) >> (lane & ~(lpr - 1));
         const bool row_nz = (anyx & ((1ULL << lpr) - 1ULL)) != 0ULL;
         (void)row_nz;
@@ -970,6 +981,41 @@ __global__ __launch_bounds__(WG) void k_mm_permute_in2(PermuteIn2 q, const int32
         q.nz_rows[blockIdx.x * (WG / 64) + (threadIdx.x >> 6)] = nz_count;
         q.live_rows[blockIdx.x * (WG / 64) + (threadIdx.x >> 6)] = live_count;
     }
+    if (q.pred_part != nullptr) {
+        // the lane groups hold the same columns: fold them in group order, then the wavefronts in wavefront order (as k_mm_step)
+        __shared__ double s_pred[2][WG / 64][kLanes];
+        const int wave_in_wg = threadIdx.x >> 6;
+        for (int j = threadIdx.x; j < 2 * (WG / 64) * kLanes; j += WG) (&s_pred[0][0][0])[j] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double a0 = t0[k], a1 = sp[k];
+            for (int off = lpr; off < 64; off += lpr) {
+                a0 += __shfl_down(t0[k], off, 64);
+                a1 += __shfl_down(sp[k], off, 64);
+            }
+            if (lane < lpr) {
+                s_pred[0][wave_in_wg][c4 + k] = a0;
+                s_pred[1][wave_in_wg][c4 + k] = a1;
+            }
+        }
+        __syncthreads();
+        if (wave_in_wg < 2) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < WG / 64; ++w) t += s_pred[wave_in_wg][w][lane];
+            q.pred_part[((int64_t)wave_in_wg * gridDim.x + blockIdx.x) * kLanes + lane] = t;
+        }
+    }
+}
+// the first step's predicted quotient per column, from the way in's sums (the single-vector loop's first_prediction): sum(y_1) = a * sum
+// deg x0 + b * sum p with the factors as k_mm_step forms them
+__global__ void k_mm_first_pred(BatchState* __restrict__ state, const double* __restrict__ t0, const double* __restrict__ sp, double alpha, int use_quotient) {
+    const int lane = threadIdx.x;
+    const double raw = (double)(float)alpha * t0[lane] + (double)(float)(1.0 - alpha) * sp[lane];
+    state->sum_p[lane] = sp[lane];
+    state->pred_raw[lane] = raw;
+    state->pred_inv[lane] = use_quotient ? (raw != 0.0 ? 1.0 / raw : 0.0) : 1.0;
 }
 __global__ __launch_bounds__(WG) void k_mm_count_fold(const int* __restrict__ a, const int* __restrict__ b, int count, int* __restrict__ out_a, int* __restrict__ out_b) {
     __shared__ int s_a[WG / 64], s_b[WG / 64];
@@ -994,7 +1040,7 @@ __global__ __launch_bounds__(WG) void k_mm_count_fold(const int* __restrict__ a,
     }
 }
 
-// ranks out of the loop: dst[old id] = xg[r] * (1 / s') * column factor (rows whose flag is 0 are zero: the caller has cleared dst)
+// ranks out of the loop: dst[old id] = xg[r] * (1 / s') * column factor (rows whose flag is 0 are zero for ever: written as zeros)
 __global__ __launch_bounds__(WG) void k_mm_permute_out2(const float* __restrict__ xg, const f32x4* __restrict__ rowop, const int32_t* __restrict__ perm,
                                                          int64_t n_int, int64_t n_valid, int b, int ld, const double* __restrict__ col_factor,
                                                          float* __restrict__ dst, const uint8_t* __restrict__ row_flags) {
@@ -1009,10 +1055,11 @@ __global__ __launch_bounds__(WG) void k_mm_permute_out2(const float* __restrict_
     for (int k = 0; k < 4; ++k)
         if (c4 + k < b) factor[k] = (float)col_factor[c4 + k];
     for (int64_t r = first; r < n_int; r += stride) {
-        if (row_flags[r] == 0) continue;
         const int64_t o = perm ? perm[r] : (r < n_valid ? r : -1);
         if (o < 0) continue;
-        const f32x4 v = (__builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xg + r * ld + c4)) * rowop[r][2]) * factor;
+        // (a row that stayed zero leaves as zeros from here: every caller id has exactly one row, so the destination needs no clearing pass)
+        const f32x4 v = row_flags[r] == 0 ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                          : (__builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xg + r * ld + c4)) * rowop[r][2]) * factor;
         if (vec) *reinterpret_cast<f32x4*>(dst + o * b + c4) = v;
         else {
 #pragma unroll
@@ -1385,7 +1432,7 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
     PGH_TRY(sums.alloc(slab));
     const int cgrid = combine_grid();
     PGH_TRY(partial.alloc(sizeof(double) * 4 * (size_t)cgrid * kLanes));
-    PGH_TRY(folded.alloc(sizeof(double) * 5 * kLanes));                  // S, T, R', D of the step + the separate kernel's residual
+    PGH_TRY(folded.alloc(sizeof(double) * 7 * kLanes));                  // S, T, R', D of the step + the separate kernel's residual + the way in's {T0, sum p}
     PGH_TRY(state_mem.alloc(sizeof(BatchState)));
     PGH_TRY(factors.alloc(sizeof(double) * kLanes));
     BatchState* state = state_mem.as<BatchState>();
@@ -1396,6 +1443,10 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
     PGH_HIP(hipEventCreate(&ev_b));
     PGH_HIP(hipEventRecord(ev_a, r.stream));
     if (!skip_dead) PGH_HIP(hipMemsetAsync(sums.p, 0, slab, r.stream));      // structural zeros of the rows without entries (every row is processed)
+    // the in-kernel residual: sum rules, the plain matrix (a dropped matrix has other column sums every step), PGH_MM_FUSED=0 turns it off
+    const bool fused_first = (cfg->err_kind == PGH_ERR_L1 || cfg->err_kind == PGH_ERR_MABS) && rate == 0.0 &&
+                             !(getenv("PGH_MM_FUSED") != nullptr && atoi(getenv("PGH_MM_FUSED")) == 0);
+    bool step1_predicted = false;                // the way in's sums give step 1 its predicted quotient (PGH_MM_FIRST_PRED=0: the separate kernel)
     k_mm_state_init<<<1, kLanes, 0, r.stream>>>(state, b);
     PGH_HIP(hipMemsetAsync(nz_maps.p, 0, 2 * (size_t)map_len, r.stream));       // rows nobody ever writes hold zeros: their bytes stay 0
     PGH_HIP(hipMemsetAsync(nz_counts.p, 0, sizeof(int) * 4, r.stream));
@@ -1414,16 +1465,25 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
         q.rowop = rowop;
         q.row_flags = row_flags.as<uint8_t>();
         q.row_has = skip_dead ? f.mm_row_has : nullptr;                       // null: every row counts as holding entries
+        // the first step's quotient is predicted from sums of the way in (no separate residual pass for step 1): its per-workgroup
+        // partials borrow the step partials' buffer (2 x in_grid x 64 doubles <= 4 x cgrid x 64 as long as in_grid <= 2 cgrid)
+        const bool first_pred = fused_first && in_grid <= 2 * cgrid && !(getenv("PGH_MM_FIRST_PRED") != nullptr && atoi(getenv("PGH_MM_FIRST_PRED")) == 0);
+        q.pred_part = first_pred ? partial.as<double>() : nullptr;
         k_mm_permute_in2<<<in_grid, WG, 0, r.stream>>>(q, f.perm, n_int, n, b, ld);
         k_mm_count_fold<<<1, WG, 0, r.stream>>>(q.nz_rows, q.live_rows, in_grid * (WG / 64), nz_cnt + 0, nz_cnt + 2);
+        if (first_pred) {
+            double* fold0 = folded.as<double>();
+            k_mm_fold1<<<kLanes, WG, 0, r.stream>>>(partial.as<double>(), in_grid, 0, state, fold0 + 5 * kLanes, 0);
+            k_mm_fold1<<<kLanes, WG, 0, r.stream>>>(partial.as<double>() + (int64_t)in_grid * kLanes, in_grid, 0, state, fold0 + 6 * kLanes, 0);
+            k_mm_first_pred<<<1, kLanes, 0, r.stream>>>(state, fold0 + 5 * kLanes, fold0 + 6 * kLanes, cfg->alpha, cfg->use_quotient);
+        }
+        step1_predicted = first_pred;
     }
     float* buf[2] = {xg0.as<float>(), xg1.as<float>()};
     double* fold = folded.as<double>();
     const int linf = cfg->err_kind == PGH_ERR_LINF;
     const int max_steps = cfg->max_iters - 1 > 0 ? cfg->max_iters - 1 : 0;
-    // the in-kernel residual: sum rules, the plain matrix (a dropped matrix has other column sums every step), PGH_MM_FUSED=0 turns it off
-    bool fused = (cfg->err_kind == PGH_ERR_L1 || cfg->err_kind == PGH_ERR_MABS) && rate == 0.0 &&
-                 !(getenv("PGH_MM_FUSED") != nullptr && atoi(getenv("PGH_MM_FUSED")) == 0);
+    bool fused = fused_first;
     int flags = fused ? 2 : 0;
     CloseParams cp{};
     cp.tol = cfg->tol;
@@ -1463,7 +1523,7 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
             gate.live_rows = nz_cnt + 2;
         }
         PGH_TRY(mm_partial(g, buf[(k - 1) & 1], ld, b, sums.as<float>(), state, drop, sparse_gate ? &gate : nullptr));
-        const int mode = k == 1 ? 2 : (fused ? 1 : 0);
+        const int mode = (k == 1 && !(fused && step1_predicted)) ? 2 : (fused ? 1 : 0);
         StepParams c{};
         c.sums = sums.as<float>();
         c.rowop = rowop;
@@ -1535,7 +1595,6 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
     for (int j = 0; j < kLanes; ++j) h_factors[j] = j < b ? host_state.scale[j] * (out_scales ? out_scales[j] : cfg->out_scale) : 1.0;
     PGH_HIP(hipMemcpyAsync(factors.p, h_factors, sizeof(h_factors), hipMemcpyHostToDevice, r.stream));
     const int executed = host_state.executed;              // steps that ran before every column had stopped
-    PGH_HIP(hipMemsetAsync(ranks->data, 0, sizeof(float) * (size_t)n * b, r.stream));      // the rows that stayed zero / ids without a row
     k_mm_permute_out2<<<blocks_for(n_int * lanes_per_row(ld)), WG, 0, r.stream>>>(buf[executed & 1], rowop, f.perm, n_int, n, b, ld, factors.as<double>(),
                                                                                     ranks->data, row_flags.as<uint8_t>());
     PGH_HIP(hipGetLastError());
