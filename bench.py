@@ -96,7 +96,10 @@ def measured_batch_traffic(scale, ef, width, batch_steps=11):
         return dict(measured_gb_per_step=None, measured_traffic_source="stale: " + os.path.relpath(path, ROOT))
     # per batch step: every launch of the loop's kernels in the profiled run over the steps that did work (the gather pass in its two
     # forms, the fix-up, the epilogue in its two forms, the separate residual of the first step, folds and closes)
-    working = max(int(batch_steps), 1)               # (the run-ahead leaves a few no-op iterations behind the stop: they move nothing)
+    # (the profiled tool runs the batch `runs` times -- warm-up + timed -- and the run-ahead leaves a few no-op iterations behind every
+    # stop: they move nothing)
+    runs = max(int(pmc.get("k_mm_state_init", {}).get("dispatches", 1)), 1)
+    working = max(int(batch_steps), 1) * runs
     total = sum((row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]) * row.get("dispatches", 1) for name, row in pmc.items()
                 if name.startswith(("k_mm_partial", "k_mm_fixup", "k_mm_step", "k_mm_residual2", "k_mm_fold", "k_mm_close2")))
     return dict(measured_gb_per_step=round(total / working / 1e9, 2), measured_traffic_source=os.path.relpath(path, ROOT))
