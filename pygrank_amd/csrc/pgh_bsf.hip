@@ -701,9 +701,15 @@ constexpr int kBsfLdsFloats = kBsfHot + 1 + (kBsfThreads / 64) * (64 * kIPT + 1 
 
 // The body of the block partial sums for the workgroup `vblock` of `vgrid` (its own launch: blockIdx / gridDim; inside the
 // merged front kernel of a step: the workgroup's index among the partial-sum workgroups).
-template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false, bool DROP = false>
+// `mid`: what the kernel has to do before it may touch the stream (the loop-state test, the deferred close) runs BETWEEN the issue of
+// the hot cache's loads and their arrival in LDS: its own loads are queued behind them, so the workgroup pays the longer of the two
+// round trips instead of their sum (true = the loop has ended or paused: nothing to do).
+#ifndef PGH_FILL_OVERLAP
+#define PGH_FILL_OVERLAP 1
+#endif
+template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false, bool DROP = false, typename Mid>
 __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, const BsfView& f, const float* __restrict__ xg,
-                                                 const unsigned int vblock, const unsigned int vgrid, const DropView dv = DropView{}) {
+                                                 const unsigned int vblock, const unsigned int vgrid, const DropView dv, Mid mid) {
     static_assert(IPT == 8, "one flag byte per lane; lanes fetch their entries as 16-byte words");
     static_assert(!(W16 && COLD), "the 16-bit stream addresses the hot cache only");
     constexpr int T = 64 * IPT;
@@ -733,9 +739,24 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
         const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(xg + base);
         f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(s_lds);
         const uint32_t hot4v = hot >> 2;
-        for (uint32_t i = tid; i < hot4v; i += kBsfThreads) dst4[i] = src4[i];
+        if (PGH_FILL_OVERLAP && hot4v > 0) {
+            constexpr int FR = (kBsfHot / 4 + kBsfThreads - 1) / kBsfThreads;
+            f32x4 fr[FR];
+#pragma unroll
+            for (int k = 0; k < FR; ++k) fr[k] = src4[min((uint32_t)tid + (uint32_t)k * kBsfThreads, hot4v - 1)];
+            if (mid()) return;
+#pragma unroll
+            for (int k = 0; k < FR; ++k) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)k * kBsfThreads;
+                if (i < hot4v) dst4[i] = fr[k];
+            }
+        } else {
+            if (mid()) return;
+            for (uint32_t i = tid; i < hot4v; i += kBsfThreads) dst4[i] = src4[i];
+        }
         for (uint32_t i = (hot4v << 2) + tid; i < hot; i += kBsfThreads) s_lds[i] = xg[base + i];
     } else {
+        if (mid()) return;
         for (uint32_t i = tid; i < hot; i += kBsfThreads) s_lds[i] = xg[base + i];
     }
     if (tid == 0) s_lds[hot] = 0.f;
@@ -966,12 +987,15 @@ template <int IPT, bool HAS_VAL, bool COLD, bool W16 = false, bool DROP = false>
 __global__ __launch_bounds__(kBsfThreads) void k_bsf_partial(BsfView f, const float* __restrict__ xg,
                                                               const LoopState* __restrict__ state, PendingClose pc, DropView dv = DropView{}) {
     __shared__ __attribute__((aligned(16))) float s_lds[kBsfLdsFloats];
-    if (state != nullptr && state->done) return;
-    // the previous step's close, if the loop driver left it to this kernel (the LDS it uses is not yet in use)
-    if (pc.active && run_pending_close(pc, reinterpret_cast<double*>(s_lds))) return;
-    if (pc.first_pred && blockIdx.x == 0 && threadIdx.x == 0) first_prediction(pc);      // read by the finish launch of this step
+    __shared__ double s_close[16];
     PGH_STAMP_BEGIN(g_times_partial)
-    bsf_partial_body<IPT, HAS_VAL, COLD, W16, DROP>(s_lds, f, xg, blockIdx.x, gridDim.x, dv);
+    bsf_partial_body<IPT, HAS_VAL, COLD, W16, DROP>(s_lds, f, xg, blockIdx.x, gridDim.x, dv, [&]() __attribute__((always_inline)) {
+        if (state != nullptr && state->done) return true;
+        // the previous step's close, if the loop driver left it to this kernel
+        if (pc.active && run_pending_close(pc, s_close)) return true;
+        if (pc.first_pred && blockIdx.x == 0 && threadIdx.x == 0) first_prediction(pc);      // read by the finish launch of this step
+        return false;
+    });
 #if PGH_PROBE_TIMES
     // wavefronts leave one by one: the workgroup's end = the latest of them (the clock only grows, so the maximum over
     // launches is the last launch's)

@@ -39,6 +39,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "pgh_kernels.h"
@@ -71,6 +73,12 @@ constexpr int kBlock = 256;
 #endif
 #ifndef PGH_FIN_PREFETCH
 #define PGH_FIN_PREFETCH 0
+#endif
+#ifndef PGH_FIN_BF
+#define PGH_FIN_BF 1          // the epilogue's operand loads without run-time branches (a missing operand reads psum's zero slot)
+#endif
+#ifndef PGH_FIN_UNI
+#define PGH_FIN_UNI 1         // item descriptors as wavefront-uniform values (scalar registers, scalar branches on hub / rows)
 #endif
 // rows per bin = 64-bit row sums in LDS during phase B (<= 32768: 15-bit keys).  Two shapes: the small one (32 KB, four
 // workgroups per CU) is the faster kernel; the large one (128 KB, one workgroup per CU) keeps the (chunk, bin) runs
@@ -223,6 +231,7 @@ PGH_STAMP_DECL(g_times_finish)
 #if PGH_PROBE_TIMES
 __device__ unsigned int g_item_ticks[1 << 15];      // per work item of k_pb_finish: duration in 10 ns ticks
 __device__ unsigned int g_item_begin[1 << 15];      // ... and its start relative to the workgroup's start
+__device__ unsigned int g_phase_ticks[8 * 4096];   // per workgroup: ticks in the phases of its items (setup, stream, hand-over, epilogue, tail)
 #endif
 
 // ---- phase A (body: pgh_pb_gather.h, shared with the merged front kernel of a step in pgh_bsf.hip)
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     }
     const float a_eff = (float)(ep.a * scale);
     const int tid = threadIdx.x;
-    const uint32_t amax = __builtin_nontemporal_load(f.amax);
+    const uint32_t amax = PGH_FIN_UNI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(f.amax)) : __builtin_nontemporal_load(f.amax);
     const bool finite = amax < 0x7f800000u;                // inf / NaN among the values: the sums are not representable
     // |value| <= amax < 2^e; an entry gets E = min(51, 62 - count_bits) bits: |value * S| < 2^E with S = 2^(E - e), and a
     // row of <= 2^count_bits entries stays below 2^62
@@ -297,6 +306,29 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     bool res_neg = false;
     const double inv_pred = RES && !rp.first ? rp.aux->pred_inv[rp.step & 1] : 1.0;
     const bool res_first = RES && rp.first != 0;
+    // Branch-free operand loads (PGH_FIN_BF): which operands a run has is decided per LAUNCH, but a load under a run-time branch --
+    // even a wavefront-uniform one -- gets a basic block and a drained wait of its own and splits an epilogue round into several
+    // exposed latencies.  A missing operand therefore reads the zero slot of the partial sums and its use is a select.
+    const bool has_v = ep.v != nullptr, has_xg = ep.xg_out != nullptr, has_ds = dst_scale != nullptr;
+    const uint32_t zero_off = rs.zero_at << 2;
+    const char* const zero_base = reinterpret_cast<const char*>(rs.psum);
+    const char* const v_base = has_v ? reinterpret_cast<const char*>(ep.v) : zero_base;
+    const char* const src_base = has_xg ? reinterpret_cast<const char*>(ep.src_scale) : zero_base;
+    const char* const ds_base = has_ds ? reinterpret_cast<const char*>(dst_scale) : zero_base;
+    const int xg_shift = (ep.xg_blk > 0 && (ep.xg_blk & (ep.xg_blk - 1)) == 0) ? __ffs(ep.xg_blk) - 1 : -1;
+    auto slot_of = [&](int row) __attribute__((always_inline)) {
+        int b;
+        if (xg_shift >= 0) b = (int)((unsigned)row >> xg_shift);
+        else {
+            b = 0;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) b += (row >= k * ep.xg_blk) ? 1 : 0;
+        }
+        const int loc = row - b * ep.xg_blk;
+        const int s = loc < ep.xg_hot ? b * ep.xg_hot + loc : ep.xg_cold + b * (ep.xg_live - ep.xg_hot) + (loc - ep.xg_hot);
+        const int stored = ep.xg_live == 0 ? row : (loc < ep.xg_live ? s : -1);
+        return has_xg ? stored : -1;
+    };
     auto residual_row = [&](float y, float x_prev, float deg, float pv) __attribute__((always_inline)) {
         res_t += (double)deg * (double)y;
         res_neg = res_neg || y < 0.f;
@@ -328,8 +360,16 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             R.lo[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 0, f.tmp_planes))) : f32x4{0.f, 0.f, 0.f, 0.f};
             R.hi[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 1, f.tmp_planes))) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // (the per-lane `ok` branches must meet again HERE, in a block of their own: when their join is also the join of the
+        // workgroup-uniform branches around the call, every value merged there -- the item descriptors -- counts as divergent and
+        // moves from scalar to vector registers, exec masks and all)
+        if (PGH_FIN_UNI) asm volatile("; stream round issued");
     };
 
+    // item descriptors are the same for every lane of the workgroup; said so, they live in scalar registers and the tests on them
+    // (hub, rows, phase) are scalar branches instead of exec masks around every entry of the stream loop
+    auto uni = [](int v) __attribute__((always_inline)) { return PGH_FIN_UNI ? __builtin_amdgcn_readfirstlane(v) : v; };
+    auto uni4 = [&](const int4& v) __attribute__((always_inline)) { return make_int4(uni(v.x), uni(v.y), uni(v.z), uni(v.w)); };
     PGH_STAMP_BEGIN(g_times_finish)
 #if PGH_FIN_STAGGER > 0
     // co-resident workgroups (the persistent grid is a multiple of the CU count: blockIdx / 256 = which of a CU's slots) start
@@ -397,8 +437,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     // one item per workgroup 117 us, second register sets for the stream / epilogue rounds 107-115 us.
     __shared__ int s_next;
     const int tail_count = f.tail_count;
-    int at = f.sched_begin[blockIdx.x];
-    const int at_end = f.sched_begin[blockIdx.x + 1];
+    int at = uni(f.sched_begin[blockIdx.x]);
+    const int at_end = uni(f.sched_begin[blockIdx.x + 1]);
     // two-launch form (PbView::phase): phase 2 keeps its partials behind phase 1's; an item belongs to phase 1 when one of its rows has
     // an exchanged slot -- its first row's slot inside the block lies below phase_live, or its rows run into the next block
     const int slot0 = f.phase == 2 ? (int)gridDim.x + tail_count : 0;
@@ -415,13 +455,13 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         __syncthreads();
         if (tid == 0) s_next = (int)atomicAdd(f.work_counter, 1u);
         __syncthreads();
-        const int k = s_next;
+        const int k = uni(s_next);
         if (k >= tail_count) return -1;
         slot = slot0 + gridDim.x + k;
-        return f.sched[f.tail_begin + k];
+        return uni(f.sched[f.tail_begin + k]);
     };
     bool flushed_head = false;
-    if (!in_tail) item = f.sched[at];
+    if (!in_tail) item = uni(f.sched[at]);
     else {
         flush(slot0 + blockIdx.x);          // no static items: the workgroup's partial is zero
         flushed_head = true;
@@ -434,22 +474,29 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     const bool skip_iso = f.iso_flag != nullptr && *f.iso_flag == 0;
     bool mine = false;                      // the item in hand belongs to this launch's phase
     if (item >= 0) {
-        bin = f.item_a[item];   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
-        epi = f.item_b[item];   // {first row of the epilogue range, rows, split index or -1 (-2: isolated rows), first item of the split row}
+        bin = uni4(f.item_a[item]);   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
+        epi = uni4(f.item_b[item]);   // {first row of the epilogue range, rows, split index or -1 (-2: isolated rows), first item of the split row}
         mine = in_phase(epi);
         if (mine) fetch(bin, 0, R);
     }
 #if PGH_PROBE_TIMES
     const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned int ph[5] = {0u, 0u, 0u, 0u, 0u};
+    unsigned int ph_items = 0u;
+#define PGH_PHASE(K, SINCE) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); ph[K] += (unsigned int)(now_ - SINCE); SINCE = now_; }
+#else
+#define PGH_PHASE(K, SINCE)
 #endif
     while (item >= 0) {
 #if PGH_PROBE_TIMES
         const unsigned long long item_t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long ph_t = item_t0;
+        ++ph_items;
 #endif
         if (!mine) {                           // the other launch's item: only the walk over the schedule goes on (workgroup-uniform)
             const int cur_slot = slot;
             int next = -1;
-            if (!in_tail && ++at < at_end) next = f.sched[at];
+            if (!in_tail && ++at < at_end) next = uni(f.sched[at]);
             else {
                 in_tail = true;
                 next = take_tail();
@@ -461,8 +508,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             }
             item = next;
             if (item >= 0) {
-                bin = f.item_a[item];
-                epi = f.item_b[item];
+                bin = uni4(f.item_a[item]);
+                epi = uni4(f.item_b[item]);
                 mine = in_phase(epi);
                 if (mine) fetch(bin, 0, R);
             }
@@ -515,52 +562,89 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             mreg[u].base = 0;
             if (b < rs.num_blocks && w < words) mreg[u] = rs.meta[(int64_t)b * rs.words + word0 + w];
         }
+        // the id of the item after this one: asked for now, needed after the stream (static slice; the tail's ticket is taken there)
+        const bool next_static = !in_tail && at + 1 < at_end;
+        int next_id_raw = -1;
+        if (PGH_FIN_UNI && next_static) next_id_raw = f.sched[at + 1];
         double hub_sum = 0.0;
         if (!hub)
             for (int i = tid; i < rows; i += THREADS) s_row[i] = 0ULL;
         __syncthreads();
+        PGH_PHASE(0, ph_t)
         const int groups = finite || hub ? bin.w : 0;
         const int nrounds = (groups + THREADS * P - 1) / (THREADS * P);
-        for (int round = 0; round < nrounds; ++round) {
+        // one stream round: every entry of a regular bin is one integer LDS atomic; a hub piece sums its values in registers
+        auto consume = [&](auto is_hub) __attribute__((always_inline)) {
+            constexpr bool HUB = decltype(is_hub)::value;
             if (PGH_PROBE_PB & 16) {
                 float z = 0.f;
 #pragma unroll
                 for (int q = 0; q < P; ++q) z += R.lo[q].x + R.hi[q].w + (float)R.r8[q][3];
                 if (z == 123.456f) s_row[0] = 1ULL;
-            } else {
+                return;
+            }
 #pragma unroll
-                for (int q = 0; q < P; ++q) {
+            for (int q = 0; q < P; ++q) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        int r = (int)R.r8[q][k];
-                        if (PGH_PROBE_PB & 256) r = (r >> 15) + ((tid & 63) + 64 * k) % rows;   // diagnostic: atomics without bank / address conflicts (wrong sums)
-                        const float v = k < 4 ? R.lo[q][k] : R.hi[q][k - 4];
+                for (int k = 0; k < 8; ++k) {
+                    int r = (int)R.r8[q][k];
+                    if (PGH_PROBE_PB & 256) r = (r >> 15) + ((tid & 63) + 64 * k) % rows;   // diagnostic: atomics without bank / address conflicts (wrong sums)
+                    const float v = k < 4 ? R.lo[q][k] : R.hi[q][k - 4];
+                    if (HUB) {
+                        if (r == 0) hub_sum += (double)v;
+                    } else if (r < rows) {
                         const long long fixed = __double_as_longlong(__builtin_fma((double)v, S, kMagic)) - __double_as_longlong(kMagic);
-                        if (hub) {
-                            if (r == 0) hub_sum += (double)v;
-                        } else if (r < rows) {
-                            atomicAdd(&s_row[r], (unsigned long long)fixed);
-                        }
+                        atomicAdd(&s_row[r], (unsigned long long)fixed);
                     }
                 }
             }
-            if (round + 1 < nrounds) fetch(bin, round + 1, R);
+        };
+        if (PGH_FIN_UNI && hub) {
+            for (int round = 0; round < nrounds; ++round) {
+                consume(std::true_type{});
+                if (round + 1 < nrounds) fetch(bin, round + 1, R);
+            }
+        } else if (PGH_FIN_UNI) {
+            for (int round = 0; round < nrounds; ++round) {
+                consume(std::false_type{});
+                if (round + 1 < nrounds) fetch(bin, round + 1, R);
+            }
+        } else {
+            for (int round = 0; round < nrounds; ++round) {
+                if (hub) consume(std::true_type{});
+                else consume(std::false_type{});
+                if (round + 1 < nrounds) fetch(bin, round + 1, R);
+            }
         }
-        // ---- the next item's descriptors are fetched before this item's epilogue
+        PGH_PHASE(1, ph_t)
+        // ---- the next item's descriptors are asked for before this item's epilogue and read after it
         const int cur_slot = slot;
         int next = -1;
-        if (!in_tail && ++at < at_end) next = f.sched[at];
-        else {
-            in_tail = true;
-            next = take_tail();
+        if (PGH_FIN_UNI) {
+            if (next_static) {
+                ++at;
+                next = uni(next_id_raw);
+            } else {
+                in_tail = true;
+                next = take_tail();
+            }
+        } else {
+            if (!in_tail && ++at < at_end) next = f.sched[at];
+            else {
+                in_tail = true;
+                next = take_tail();
+            }
         }
         int4 next_bin = make_int4(0, 0, 0, 0), next_epi = make_int4(0, 0, -1, 0);
         bool next_mine = false;
         if (next >= 0) {
-            next_bin = f.item_a[next];
+            next_bin = f.item_a[next];        // (not yet wavefront-uniform values: the wait for them belongs behind the epilogue)
             next_epi = f.item_b[next];
-            next_mine = in_phase(next_epi);
-            if (PGH_FIN_PREFETCH && next_mine) fetch(next_bin, 0, R);
+            if (!PGH_FIN_UNI || PGH_FIN_PREFETCH) {
+                next_bin = uni4(next_bin), next_epi = uni4(next_epi);
+                next_mine = in_phase(next_epi);
+                if (PGH_FIN_PREFETCH && next_mine) fetch(next_bin, 0, R);
+            }
         }
 #pragma unroll
         for (int u = 0; u < MPT; ++u) {
@@ -617,6 +701,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             }
         } else {
             __syncthreads();
+            PGH_PHASE(2, ph_t)
             // The epilogue walks the item's rows in ALIGNED groups of 64 (lane = row % 64), G groups per wavefront in
             // flight.  The map word of a (block, group) is then wavefront-uniform: one broadcast read of the LDS copy,
             // the lane's bit is a shift, its rank among the group's segments is v_mbcnt -- a handful of vector
@@ -629,11 +714,18 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             const int row_lo = epi.x, row_hi = epi.x + epi.y - 1;
             const int g_hi = (PGH_PROBE_PB & 32) ? -1 : (row_hi >> 6);          // diagnostic: no epilogue
             const char* __restrict__ psum_b = reinterpret_cast<const char*>(rs.psum);
+            constexpr bool STRAIGHT = PGH_FIN_BF && (MODE == EPI_AXPBY || MODE == EPI_PLAIN);
             for (int g0 = (row_lo >> 6) + wave; g0 <= g_hi; g0 += WAVES * G) {
                 EpiOps ops[G];
                 float dsc[G];
                 float xp[RES ? G : 1], dg[RES ? G : 1];
                 float vals[G][NB];
+                // (the slots of the next gather vector first: integer work that must not sit between the loads and read a register
+                // pair one half of which a load is still to fill -- the compiler's 64-bit multiply-add did, and waited for everything)
+                if (STRAIGHT) {
+#pragma unroll
+                    for (int u = 0; u < G; ++u) ops[u].slot = slot_of(((g0 + u * WAVES) << 6) + lane);
+                }
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const int g = min(g0 + u * WAVES, g_hi);                 // wavefront-uniform
@@ -650,8 +742,16 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                         const unsigned int at = has ? first + rank : rs.zero_at;
                         vals[u][b] = *reinterpret_cast<const float*>(psum_b + (at << 2));
                     }
-                    ops[u] = epi_load<MODE>(ep, row);
-                    dsc[u] = dst_scale != nullptr ? ld_off(dst_scale, (uint32_t)row << 2) : 1.f;
+                    if (STRAIGHT) {
+                        const uint32_t at = (uint32_t)row << 2;
+                        ops[u].deg = 0.f, ops[u].lam = 0.f, ops[u].r_old = 0.f;
+                        ops[u].v = MODE == EPI_AXPBY ? *reinterpret_cast<const float*>(v_base + (has_v ? at : zero_off)) : 0.f;
+                        ops[u].src = *reinterpret_cast<const float*>(src_base + (has_xg ? at : zero_off));
+                        dsc[u] = *reinterpret_cast<const float*>(ds_base + (has_ds ? at : zero_off));
+                    } else {
+                        ops[u] = epi_load<MODE>(ep, row);
+                        dsc[u] = dst_scale != nullptr ? ld_off(dst_scale, (uint32_t)row << 2) : 1.f;
+                    }
                     if (RES) {
                         xp[u] = ld_off(rp.x_prev, (uint32_t)row << 2);
                         dg[u] = ld_off(rp.deg, (uint32_t)row << 2);
@@ -661,20 +761,42 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                 for (int u = 0; u < G; ++u) {
                     const int g = g0 + u * WAVES;
                     const int row = (g << 6) + lane;
-                    if (g > g_hi || row < row_lo || row > row_hi) continue;
-                    const int i = row - row_lo;
+                    const bool live = g <= g_hi && row >= row_lo && row <= row_hi;
+                    if (!STRAIGHT && !live) continue;
+                    // STRAIGHT: every group is computed (dead lanes hold a repeated row of the item) and only the stores and the sums
+                    // are predicated -- a path that skips the uses of a group leaves its loads pending where the paths meet, and the
+                    // head of the next round then waits for everything in flight, the last stores included
+                    const int i = live ? row - row_lo : 0;
                     float cold = 0.f;
-                    if (i < rows) cold = finite ? (float)((double)(long long)s_row[i] * inv_S) : __uint_as_float(0x7fc00000u);
+                    if (STRAIGHT) {
+                        const float c = finite ? (float)((double)(long long)s_row[i < rows ? i : 0] * inv_S) : __uint_as_float(0x7fc00000u);
+                        cold = i < rows ? c : 0.f;
+                    } else if (i < rows) cold = finite ? (float)((double)(long long)s_row[i] * inv_S) : __uint_as_float(0x7fc00000u);
                     double sum = 0.0;
 #pragma unroll
                     for (int b = 0; b < NB; ++b) sum += (double)vals[u][b];      // blocks past num_blocks contribute 0
                     sum += (double)cold;
-                    if (dst_scale != nullptr) sum *= (double)dsc[u];
-                    const float y = epi_apply<MODE>(ep, ops[u], a_eff, row, (float)sum, sum_y, delta);
-                    if (RES) residual_row(y, xp[u], dg[u], ops[u].v);
+                    float y;
+                    if (STRAIGHT) {
+                        sum = has_ds ? sum * (double)dsc[u] : sum;
+                        y = a_eff * (float)sum;
+                        if (MODE == EPI_AXPBY) y = has_v ? y + (float)ep.b * ops[u].v : y;
+                        if (live) {
+                            st_off(ep.y, (uint32_t)row << 2, y);
+                            if (ops[u].slot >= 0) st_off(ep.xg_out, (uint32_t)ops[u].slot << 2, y * ops[u].src);
+                        }
+                        y = live ? y : 0.f;                  // (+0 into every sum below: sum(y), T, R', D)
+                        sum_y += (double)y;
+                        if (RES) residual_row(y, live ? xp[u] : 0.f, dg[u], live ? ops[u].v : 0.f);
+                    } else {
+                        if (dst_scale != nullptr) sum *= (double)dsc[u];
+                        y = epi_apply<MODE>(ep, ops[u], a_eff, row, (float)sum, sum_y, delta);
+                        if (RES) residual_row(y, xp[u], dg[u], ops[u].v);
+                    }
                 }
             }
         }
+        PGH_PHASE(3, ph_t)
         __syncthreads();                                   // s_row / s_hub are reused by the next item
 #if PGH_PROBE_TIMES
         if (tid == 0 && item < (1 << 15)) {
@@ -688,12 +810,24 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             flush(slot0 + blockIdx.x);
             flushed_head = true;
         }
+        if (PGH_FIN_UNI && !PGH_FIN_PREFETCH && next >= 0) {
+            next_bin = uni4(next_bin), next_epi = uni4(next_epi);
+            next_mine = in_phase(next_epi);
+        }
         if (!PGH_FIN_PREFETCH && next >= 0 && next_mine) fetch(next_bin, 0, R);
         item = next;
         bin = next_bin;
         epi = next_epi;
         mine = next_mine;
+        PGH_PHASE(4, ph_t)
     }
+#if PGH_PROBE_TIMES
+    if (tid == 0 && blockIdx.x < 4096) {
+        for (int k = 0; k < 5; ++k) g_phase_ticks[8 * blockIdx.x + k] = ph[k];
+        g_phase_ticks[8 * blockIdx.x + 5] = ph_items;
+        g_phase_ticks[8 * blockIdx.x + 6] = (unsigned int)(__builtin_amdgcn_s_memrealtime() - wg_t0);
+    }
+#endif
     if (!flushed_head) flush(slot0 + blockIdx.x);
     // the last workgroup to leave re-arms the words for the next launch (every workgroup has read amax long before its
     // ticket; the next phase A starts after this kernel).  Phase 1 of a two-launch finish leaves amax to phase 2.
@@ -955,6 +1089,50 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
 }
 
 // cold_keys: the entries of the image as stream keys (block << 58 | row << 29 | col), any order; cold_vals: values or null.
+// Shares of the A-order stream for the workgroups of phase A (at most one per CU), balanced by cost = entries + a fixed price
+// for every chunk image a share has to load (the tail chunks hold few entries: a share there crosses many of them).
+// (Round 5 measured the shares instead -- workgroup clocks of calibration launches, the price of a slow share's stretch raised, planned
+// again -- and made the launch slower every round: at ANY price the workgroups end 12 us apart, p10 to p90, and which ones end late
+// follows the CU, not the share's content.  profiles/r05/gather_shares_calibration_rejected.log)
+static void pb_plan_shares(const PbFormat& p, const int64_t* chunk_start, int64_t padded, int64_t fill_cost, int num_cus,
+                           std::vector<int4>& tasks, std::vector<int>& ranges) {
+    // every share that starts inside a chunk pays one more fill, so the total grows with the number of shares: the
+    // smallest per-share budget that needs no more shares than there are CUs is searched for (a fixed 1.16 x mean left 9
+    // of 256 CUs without a share at scale 23)
+    auto build = [&](int64_t target) {
+        tasks.clear();
+        ranges.assign(1, 0);
+        int64_t left = target;
+        for (int c = 0; c < p.num_chunks; ++c) {
+            int64_t lo = chunk_start[c];
+            const int64_t hi = chunk_start[c + 1];
+            while (lo < hi) {
+                if (left < fill_cost + 4096 && (int)tasks.size() > ranges.back()) {
+                    ranges.push_back((int)tasks.size());   // next share
+                    left = target;
+                }
+                int64_t take = std::min<int64_t>(hi - lo, std::max<int64_t>(left - fill_cost, 4096));
+                if (lo + take < hi) take = std::max<int64_t>(8, take & ~(int64_t)7);
+                take = std::min<int64_t>(take, hi - lo);
+                tasks.push_back(make_int4(c, (int)lo, (int)(lo + take), 0));
+                lo += take;
+                left -= fill_cost + take;
+            }
+        }
+        ranges.push_back((int)tasks.size());
+        return (int)ranges.size() - 1;
+    };
+    const double mean = (double)(padded + (int64_t)p.num_chunks * fill_cost) / (double)num_cus;
+    double lo_m = 1.0, hi_m = 1.5;
+    while (build((int64_t)(hi_m * mean) + 8) > num_cus) hi_m *= 1.25;
+    for (int it = 0; it < 24; ++it) {
+        const double mid = 0.5 * (lo_m + hi_m);
+        if (build((int64_t)(mid * mean) + 8) > num_cus) lo_m = mid;
+        else hi_m = mid;
+    }
+    (void)build((int64_t)(hi_m * mean) + 8);
+}
+
 int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, const float* cold_vals, int64_t count, const int* live,
              int hot) {
     Runtime& r = rt();
@@ -1056,8 +1234,6 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(r.stream));
     // ---- phase A shares (positions in A order; chunks and pieces are whole groups of 8)
-    // shares of the stream for the workgroups of phase A (at most one per CU), balanced by cost = entries + a fixed price
-    // for every chunk image a share has to load (the tail chunks hold few entries: a share there crosses many of them)
     std::vector<int4> tasks;
     std::vector<int> ranges(1, 0);
     {
@@ -1066,41 +1242,8 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         // 113 us and 153 against 166-189)
         const int64_t fill_cost = getenv("PGH_PB_FILLCOST") != nullptr ? atoll(getenv("PGH_PB_FILLCOST"))
                                                                         : (padded / std::max(p.num_chunks, 1) < 163840 ? 24576 : 65536);
-        // every share that starts inside a chunk pays one more fill, so the total grows with the number of shares: the
-        // smallest per-share budget that needs no more shares than there are CUs is searched for (a fixed 1.16 x mean left 9
-        // of 256 CUs without a share at scale 23)
-        auto build = [&](int64_t target) {
-            tasks.clear();
-            ranges.assign(1, 0);
-            int64_t left = target;
-            for (int c = 0; c < p.num_chunks; ++c) {
-                int64_t lo = chunk_start[c];
-                const int64_t hi = chunk_start[c + 1];
-                while (lo < hi) {
-                    if (left < fill_cost + 4096 && (int)tasks.size() > ranges.back()) {
-                        ranges.push_back((int)tasks.size());   // next share
-                        left = target;
-                    }
-                    int64_t take = std::min<int64_t>(hi - lo, std::max<int64_t>(left - fill_cost, 4096));
-                    if (lo + take < hi) take = std::max<int64_t>(8, take & ~(int64_t)7);
-                    take = std::min<int64_t>(take, hi - lo);
-                    tasks.push_back(make_int4(c, (int)lo, (int)(lo + take), 0));
-                    lo += take;
-                    left -= fill_cost + take;
-                }
-            }
-            ranges.push_back((int)tasks.size());
-            return (int)ranges.size() - 1;
-        };
-        const double mean = (double)(padded + (int64_t)p.num_chunks * fill_cost) / (double)r.num_cus;
-        double lo_m = 1.0, hi_m = 1.5;
-        while (build((int64_t)(hi_m * mean) + 8) > r.num_cus) hi_m *= 1.25;
-        for (int it = 0; it < 24; ++it) {
-            const double mid = 0.5 * (lo_m + hi_m);
-            if (build((int64_t)(mid * mean) + 8) > r.num_cus) lo_m = mid;
-            else hi_m = mid;
-        }
-        (void)build((int64_t)(hi_m * mean) + 8);
+        std::vector<int64_t> starts(chunk_start.begin(), chunk_start.end());
+        pb_plan_shares(p, starts.data(), padded, fill_cost, r.num_cus, tasks, ranges);
     }
     const int shares = (int)ranges.size() - 1;
     p.num_tasks = shares;
@@ -1441,6 +1584,20 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
     PGH_HIP(hipGetLastError());
     PGH_STAMP_DUMP(g_times_finish, grid, "k_pb_finish")
 #if PGH_PROBE_TIMES
+    if (getenv("PGH_DUMP_PHASES") != nullptr) {            // where the workgroups of the 10th launch spent their time
+        static int dumped_ph = 0;
+        if (dumped_ph++ == 9) {
+            (void)hipStreamSynchronize(r.stream);
+            std::vector<unsigned int> ph(8 * 4096);
+            (void)hipMemcpyFromSymbol(ph.data(), HIP_SYMBOL(g_phase_ticks), sizeof(unsigned int) * 8 * 4096);
+            const int n_ = grid < 4096 ? grid : 4096;
+            double tot[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int w = 0; w < n_; ++w)
+                for (int k = 0; k < 7; ++k) tot[k] += ph[8 * w + k] * 0.01 / n_;
+            fprintf(stderr, "[pgh phases] k_pb_finish: per workgroup (mean us): setup %.1f  stream %.1f  hand-over %.1f  epilogue %.1f  tail %.1f | items %.2f  item loop %.1f\n",
+                    tot[0], tot[1], tot[2], tot[3], tot[4], tot[5] * 100.0, tot[6]);
+        }
+    }
     if (getenv("PGH_DUMP_ITEMS") != nullptr) {             // per-item durations of the 10th launch, with the item descriptors
         static int dumped = 0;
         if (dumped++ == 9) {
