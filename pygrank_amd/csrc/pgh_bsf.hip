@@ -1041,10 +1041,17 @@ __global__ __launch_bounds__(WG) void k_bsf_combine(RowSums rs, int64_t n_out,
     const float a_eff = (float)(ep.a * scale);
     double sum_y = 0.0, delta = 0.0;
     const int64_t stride = (int64_t)gridDim.x * WG;
+    // (no run-time branch around a load: epi_load_z, block_row_sum)
+    const char* const zero = reinterpret_cast<const char*>(rs.psum + rs.zero_at);
+    const bool has_ds = dst_scale != nullptr;
+    const char* const ds_base = has_ds ? reinterpret_cast<const char*>(dst_scale) : zero;
     for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n_out; i += stride) {
+        EpiOps ops = epi_load_z<MODE>(ep, (int)i, zero);
+        const float dsc = *reinterpret_cast<const float*>(ds_base + (has_ds ? (uint32_t)i << 2 : 0u));
+        if (ep.xg_out != nullptr) ops.slot = xg_slot((int)i, ep.xg_blk, ep.xg_live, ep.xg_hot, ep.xg_cold);
         double s = block_row_sum<B>(rs, i);
-        if (dst_scale != nullptr) s *= (double)dst_scale[i];
-        apply_epilogue<MODE>(ep, a_eff, (int)i, (float)s, sum_y, delta);
+        s = has_ds ? s * (double)dsc : s;
+        epi_apply_z<MODE>(ep, ops, a_eff, (int)i, (float)s, true, sum_y, delta);
     }
     const double bs = block_reduce_256<0>(sum_y, s_red);
     if (threadIdx.x == 0) partial_sum[blockIdx.x] = bs;

@@ -333,45 +333,101 @@ struct IsoRows {
     int        iso_from;
 };
 
+// Round 5: the row loop without run-time branches around its loads.  The round-3 form tested `mask & bit` before every one of a row's
+// eight segment loads, `dst_scale != nullptr` / `b != 0` before the operand loads: ten basic blocks with a drained wait each, ten memory
+// round trips per row one after the other (114 us for 253 MB).  Here a missing segment reads the zero slot of the partial sums, a missing
+// operand reads it too (its eight zero bytes are a float 0 as well) and is dropped by a select: two round trips per row (map words,
+// then everything else).  PGH_B64_COMBINE_BF=0: the old form.
+#ifndef PGH_B64_COMBINE_BF
+#define PGH_B64_COMBINE_BF 1
+#endif
 __global__ __launch_bounds__(WG) void k_bsf64_combine(const SegMeta* __restrict__ meta, int64_t words, const double* __restrict__ psum,
                                                        int num_blocks, int64_t n_out, Epi64 ep, const LoopState* __restrict__ state,
-                                                       double* __restrict__ partial_sum, double* __restrict__ partial_delta, IsoRows iso) {
+                                                       double* __restrict__ partial_sum, double* __restrict__ partial_delta, IsoRows iso,
+                                                       unsigned int zero_at) {
     __shared__ double s_red[4];
     if (state != nullptr && state->done) return;
     double sum_y = 0.0, delta = 0.0;
     const int64_t stride = (int64_t)gridDim.x * WG;
     const bool skip_iso = iso.flag != nullptr && *iso.flag == 0;
-    for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n_out; i += stride) {
-        if (skip_iso && (int)((uint32_t)i % (uint32_t)iso.blk) >= iso.iso_from) continue;
-        const int64_t w = i >> 6;
-        const unsigned long long bit = 1ULL << (i & 63);
-        // the row's segment of every column block, eight blocks at a time: map words first, then the sums (block order)
-        double s = 0.0;
-        for (int b0 = 0; b0 < num_blocks; b0 += 8) {
+    if (PGH_B64_COMBINE_BF && num_blocks <= 8) {
+        const bool has_ds = ep.dst_scale != nullptr, has_src = ep.src_scale != nullptr, has_b = ep.b != 0.0;
+        const char* const zero_base = reinterpret_cast<const char*>(psum + zero_at);
+        const char* const ds_base = has_ds ? reinterpret_cast<const char*>(ep.dst_scale) : zero_base;
+        const char* const src_base = has_src ? reinterpret_cast<const char*>(ep.src_scale) : zero_base;
+        const char* const term_base = has_b ? reinterpret_cast<const char*>(ep.term) : zero_base;
+        for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n_out; i += stride) {
+            if (skip_iso && (int)((uint32_t)i % (uint32_t)iso.blk) >= iso.iso_from) continue;
+            const int64_t w = i >> 6;
+            const unsigned int lane_bit = 1u << (i & 31);
+            const bool upper = (i & 32) != 0;
+            // first round trip: the map words of the eight blocks (blocks past num_blocks: word 0 of block 0, dropped below), and
+            // every operand that does not depend on them
             SegMeta m[8];
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
-                if (b0 + b < num_blocks) m[b] = meta[(int64_t)(b0 + b) * words + w];
+            for (int b = 0; b < 8; ++b) m[b] = meta[b < num_blocks ? (int64_t)b * words + w : 0];
+            const int64_t at4 = i << 2, at8 = i << 3;
+            const float dsc = *reinterpret_cast<const float*>(ds_base + (has_ds ? at4 : 0));
+            const float ssc = *reinterpret_cast<const float*>(src_base + (has_src ? at4 : 0));
+            const double tv = *reinterpret_cast<const double*>(term_base + (has_b ? at8 : 0));
+            const double r_old = ep.r[i];
+            // second: the row's segment in every block
             double v[8];
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                v[b] = 0.0;
-                if (b0 + b < num_blocks && (m[b].mask & bit)) v[b] = psum[m[b].base + __popcll(m[b].mask & (bit - 1ULL))];
+                const unsigned int lo = (unsigned int)m[b].mask, hi = (unsigned int)(m[b].mask >> 32);
+                const unsigned int word = upper ? hi : lo;
+                const unsigned int before = upper ? __popc(lo) + __popc(hi & (lane_bit - 1u)) : __popc(lo & (lane_bit - 1u));
+                const bool has = b < num_blocks && (word & lane_bit) != 0u;
+                v[b] = psum[has ? (unsigned int)m[b].base + before : zero_at];
             }
+            double sum = 0.0;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) s += v[b];
+            for (int b = 0; b < 8; ++b) sum += v[b];
+            sum = has_ds ? sum * (double)dsc : sum;
+            double y = ep.a * sum;
+            y = has_b ? y + ep.b * tv : y;
+            ep.term_out[i] = y;
+            ep.xg_out[i] = has_src ? y * (double)ssc : y;
+            sum_y += y;
+            const double r_new = r_old + ep.c * y;
+            ep.r[i] = r_new;
+            const double d = fabs(r_new - r_old);
+            delta = ep.err_linf ? fmax(delta, d) : delta + d;
         }
-        if (ep.dst_scale != nullptr) s *= (double)ep.dst_scale[i];
-        double y = ep.a * s;
-        if (ep.b != 0.0) y += ep.b * ep.term[i];
-        ep.term_out[i] = y;
-        ep.xg_out[i] = ep.src_scale != nullptr ? y * (double)ep.src_scale[i] : y;
-        sum_y += y;
-        const double r_old = ep.r[i];
-        const double r_new = r_old + ep.c * y;
-        ep.r[i] = r_new;
-        const double d = fabs(r_new - r_old);
-        delta = ep.err_linf ? fmax(delta, d) : delta + d;
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n_out; i += stride) {
+            if (skip_iso && (int)((uint32_t)i % (uint32_t)iso.blk) >= iso.iso_from) continue;
+            const int64_t w = i >> 6;
+            const unsigned long long bit = 1ULL << (i & 63);
+            // the row's segment of every column block, eight blocks at a time: map words first, then the sums (block order)
+            double s = 0.0;
+            for (int b0 = 0; b0 < num_blocks; b0 += 8) {
+                SegMeta m[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (b0 + b < num_blocks) m[b] = meta[(int64_t)(b0 + b) * words + w];
+                double v[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    v[b] = 0.0;
+                    if (b0 + b < num_blocks && (m[b].mask & bit)) v[b] = psum[m[b].base + __popcll(m[b].mask & (bit - 1ULL))];
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b) s += v[b];
+            }
+            if (ep.dst_scale != nullptr) s *= (double)ep.dst_scale[i];
+            double y = ep.a * s;
+            if (ep.b != 0.0) y += ep.b * ep.term[i];
+            ep.term_out[i] = y;
+            ep.xg_out[i] = ep.src_scale != nullptr ? y * (double)ep.src_scale[i] : y;
+            sum_y += y;
+            const double r_old = ep.r[i];
+            const double r_new = r_old + ep.c * y;
+            ep.r[i] = r_new;
+            const double d = fabs(r_new - r_old);
+            delta = ep.err_linf ? fmax(delta, d) : delta + d;
+        }
     }
     const double bs = block_reduce_256<0>(sum_y, s_red);
     if (threadIdx.x == 0) partial_sum[blockIdx.x] = bs;
@@ -545,7 +601,9 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
         iso.flag = every_row ? nullptr : f.iso_flag;       // every_row: term_out is read in full afterwards (pgh_poly_terms)
         iso.blk = f.blk_size;
         iso.iso_from = iso_from_of(f);
-        k_bsf64_combine<<<cgrid, WG, 0, r.stream>>>(f.meta, f.meta_words, f.psum64, f.num_blocks, f.n_out, ep, state, partial_sum, partial_delta, iso);
+        // (the pad behind the segments is cleared at build time and never written: its last word is the zero slot)
+        k_bsf64_combine<<<cgrid, WG, 0, r.stream>>>(f.meta, f.meta_words, f.psum64, f.num_blocks, f.n_out, ep, state, partial_sum, partial_delta, iso,
+                                                    (unsigned int)(f.num_segs + kT + 63));
     }
     PGH_HIP(hipGetLastError());
     if (num_partials) *num_partials = cgrid;

@@ -211,6 +211,56 @@ __device__ __forceinline__ float epi_apply(const EpiParams& ep, const EpiOps& o,
     }
     return y;
 }
+// The same two halves WITHOUT run-time branches around the loads (round 5): which operands a run has is decided per launch, but a load
+// under a branch -- even a wavefront-uniform one -- gets a basic block and a drained wait of its own, and a row's operands then arrive
+// one round trip after the other.  A missing operand reads `zero` (>= 4 zero bytes: the zero slot of the partial sums) and its use is a
+// select.  `slot`: the caller's (xg_slot, or -1); `live`: false = the lane repeats a row of another lane -- nothing is stored or summed.
+template <int MODE>
+__device__ __forceinline__ EpiOps epi_load_z(const EpiParams& ep, int row, const char* zero) {
+    EpiOps o;
+    o.v = 0.f, o.deg = 0.f, o.lam = 0.f, o.src = 0.f, o.r_old = 0.f, o.slot = -1;
+    const uint32_t at = (uint32_t)row << 2;
+    if (MODE == EPI_AXPBY || MODE == EPI_POLY) {
+        const bool has_v = ep.v != nullptr;
+        o.v = *reinterpret_cast<const float*>((has_v ? reinterpret_cast<const char*>(ep.v) : zero) + (has_v ? at : 0u));
+    } else if (MODE == EPI_ABSORB) {
+        o.v = ld_off(ep.v, at);
+        o.deg = ld_off(ep.deg, at);
+        o.lam = ld_off(ep.lam, at);
+    }
+    const bool has_xg = ep.xg_out != nullptr;
+    o.src = *reinterpret_cast<const float*>((has_xg ? reinterpret_cast<const char*>(ep.src_scale) : zero) + (has_xg ? at : 0u));
+    if (MODE == EPI_POLY) o.r_old = ld_off(const_cast<const float*>(ep.r), at);
+    return o;
+}
+template <int MODE>
+__device__ __forceinline__ float epi_apply_z(const EpiParams& ep, const EpiOps& o, float a_eff, int row, float sum, bool live,
+                                             double& sum_y, double& delta) {
+    float y;
+    if (MODE == EPI_PLAIN) {
+        y = a_eff * sum;
+    } else if (MODE == EPI_AXPBY || MODE == EPI_POLY) {
+        y = a_eff * sum;
+        y = ep.v != nullptr ? y + (float)ep.b * o.v : y;
+    } else {   // EPI_ABSORB: ((M^T x) * deg + p * lam) / (lam + deg), adhoc.py:167-168
+        y = (a_eff * sum * o.deg + o.v * o.lam) / (o.lam + o.deg);
+    }
+    const uint32_t at = (uint32_t)row << 2;
+    float r_new = 0.f;
+    if (MODE == EPI_POLY) r_new = o.r_old + (float)ep.c * y;
+    if (live) {
+        st_off(ep.y, at, y);
+        if (o.slot >= 0) st_off(ep.xg_out, (uint32_t)o.slot << 2, y * o.src);
+        if (MODE == EPI_POLY) st_off(ep.r, at, r_new);
+    }
+    y = live ? y : 0.f;
+    sum_y += (double)y;
+    if (MODE == EPI_POLY) {
+        const double d = live ? fabs((double)r_new - (double)o.r_old) : 0.0;
+        delta = ep.err_linf ? fmax(delta, d) : delta + d;
+    }
+    return y;
+}
 template <int MODE>
 __device__ __forceinline__ float apply_epilogue(const EpiParams& ep, float a_eff, int row, float sum,
                                                 double& sum_y, double& delta) {
@@ -252,16 +302,17 @@ template <int B>
 __device__ __forceinline__ double block_row_sum(const RowSums& rs, int64_t row) {
     const int64_t w = row >> 6;
     const unsigned long long bit = 1ULL << (row & 63);
-    // all map words first, then all segment sums: two exposed latencies per row instead of two per block
+    // all map words first, then all segment sums: two exposed latencies per row instead of two per block -- and no run-time branch
+    // around a load (a block past num_blocks re-reads block 0's word, a row without a segment the zero slot: a load under `if` gets
+    // a basic block and a drained wait of its own, and the eight of a row then take eight round trips one after the other)
     SegMeta m[B];
 #pragma unroll
-    for (int b = 0; b < B; ++b)
-        if (b < rs.num_blocks) m[b] = rs.meta[(int64_t)b * rs.words + w];
+    for (int b = 0; b < B; ++b) m[b] = rs.meta[(b < rs.num_blocks ? (int64_t)b * rs.words : 0) + w];
     float v[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        v[b] = 0.f;
-        if (b < rs.num_blocks && (m[b].mask & bit)) v[b] = rs.psum[m[b].base + __popcll(m[b].mask & (bit - 1ULL))];
+        const bool has = b < rs.num_blocks && (m[b].mask & bit) != 0ULL;
+        v[b] = rs.psum[has ? (unsigned int)m[b].base + (unsigned int)__popcll(m[b].mask & (bit - 1ULL)) : rs.zero_at];
     }
     double s = 0.0;
 #pragma unroll

@@ -309,11 +309,9 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     // Branch-free operand loads (PGH_FIN_BF): which operands a run has is decided per LAUNCH, but a load under a run-time branch --
     // even a wavefront-uniform one -- gets a basic block and a drained wait of its own and splits an epilogue round into several
     // exposed latencies.  A missing operand therefore reads the zero slot of the partial sums and its use is a select.
-    const bool has_v = ep.v != nullptr, has_xg = ep.xg_out != nullptr, has_ds = dst_scale != nullptr;
+    const bool has_xg = ep.xg_out != nullptr, has_ds = dst_scale != nullptr;
     const uint32_t zero_off = rs.zero_at << 2;
     const char* const zero_base = reinterpret_cast<const char*>(rs.psum);
-    const char* const v_base = has_v ? reinterpret_cast<const char*>(ep.v) : zero_base;
-    const char* const src_base = has_xg ? reinterpret_cast<const char*>(ep.src_scale) : zero_base;
     const char* const ds_base = has_ds ? reinterpret_cast<const char*>(dst_scale) : zero_base;
     const int xg_shift = (ep.xg_blk > 0 && (ep.xg_blk & (ep.xg_blk - 1)) == 0) ? __ffs(ep.xg_blk) - 1 : -1;
     auto slot_of = [&](int row) __attribute__((always_inline)) {
@@ -714,7 +712,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             const int row_lo = epi.x, row_hi = epi.x + epi.y - 1;
             const int g_hi = (PGH_PROBE_PB & 32) ? -1 : (row_hi >> 6);          // diagnostic: no epilogue
             const char* __restrict__ psum_b = reinterpret_cast<const char*>(rs.psum);
-            constexpr bool STRAIGHT = PGH_FIN_BF && (MODE == EPI_AXPBY || MODE == EPI_PLAIN);
+            constexpr bool STRAIGHT = PGH_FIN_BF != 0;
             for (int g0 = (row_lo >> 6) + wave; g0 <= g_hi; g0 += WAVES * G) {
                 EpiOps ops[G];
                 float dsc[G];
@@ -743,11 +741,10 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                         vals[u][b] = *reinterpret_cast<const float*>(psum_b + (at << 2));
                     }
                     if (STRAIGHT) {
-                        const uint32_t at = (uint32_t)row << 2;
-                        ops[u].deg = 0.f, ops[u].lam = 0.f, ops[u].r_old = 0.f;
-                        ops[u].v = MODE == EPI_AXPBY ? *reinterpret_cast<const float*>(v_base + (has_v ? at : zero_off)) : 0.f;
-                        ops[u].src = *reinterpret_cast<const float*>(src_base + (has_xg ? at : zero_off));
-                        dsc[u] = *reinterpret_cast<const float*>(ds_base + (has_ds ? at : zero_off));
+                        const int slot = ops[u].slot;
+                        ops[u] = epi_load_z<MODE>(ep, row, zero_base + zero_off);
+                        ops[u].slot = slot;
+                        dsc[u] = *reinterpret_cast<const float*>(ds_base + (has_ds ? (uint32_t)row << 2 : zero_off));
                     } else {
                         ops[u] = epi_load<MODE>(ep, row);
                         dsc[u] = dst_scale != nullptr ? ld_off(dst_scale, (uint32_t)row << 2) : 1.f;
@@ -779,14 +776,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
                     float y;
                     if (STRAIGHT) {
                         sum = has_ds ? sum * (double)dsc[u] : sum;
-                        y = a_eff * (float)sum;
-                        if (MODE == EPI_AXPBY) y = has_v ? y + (float)ep.b * ops[u].v : y;
-                        if (live) {
-                            st_off(ep.y, (uint32_t)row << 2, y);
-                            if (ops[u].slot >= 0) st_off(ep.xg_out, (uint32_t)ops[u].slot << 2, y * ops[u].src);
-                        }
-                        y = live ? y : 0.f;                  // (+0 into every sum below: sum(y), T, R', D)
-                        sum_y += (double)y;
+                        // (a dead lane adds +0 to every sum: sum(y), delta, T, R', D)
+                        y = epi_apply_z<MODE>(ep, ops[u], a_eff, live ? row : row_lo, (float)sum, live, sum_y, delta);
                         if (RES) residual_row(y, live ? xp[u] : 0.f, dg[u], live ? ops[u].v : 0.f);
                     } else {
                         if (dst_scale != nullptr) sum *= (double)dsc[u];
