@@ -433,14 +433,21 @@ __device__ __forceinline__ void bsf_fixup_tiles(const FixView& f, int first_tile
 #endif
 
 // fold of <= kMaxPartials partials by the first 256 threads of a workgroup of any size >= 256, in the order k_step_close /
+constexpr int kFoldBatch = 6;     // strides of 256 partials in flight per thread (1024 workgroups + the tail's items of the finish kernel: 5-6)
 // fold_partials use (thread t adds partials t, t + 256, ...; wavefront shuffles; wavefronts 0..3 in order): every thread
 // returns the result.  s4: LDS scratch of 4 doubles.
 __device__ __forceinline__ double fold_partials_wide(const double* __restrict__ partials, int count, int linf, double* s4) {
     double acc = 0.0;
     if (threadIdx.x < 256) {
-        for (int i = threadIdx.x; i < count; i += 256) {
-            const double v = partials[i];
-            acc = linf ? fmax(acc, v) : acc + v;
+        // the loads of kFoldBatch strides are issued together, the additions keep their order (round 5: one load, one wait, one add per
+        // stride was five to six memory round trips in the prologue of every block-partial-sums launch -- ~1300 partials, 256 threads)
+        for (int i0 = threadIdx.x; i0 < count; i0 += 256 * kFoldBatch) {
+            double v[kFoldBatch];
+#pragma unroll
+            for (int u = 0; u < kFoldBatch; ++u) v[u] = partials[min(i0 + 256 * u, count - 1)];
+#pragma unroll
+            for (int u = 0; u < kFoldBatch; ++u)
+                if (i0 + 256 * u < count) acc = linf ? fmax(acc, v[u]) : acc + v[u];
         }
         acc = linf ? wave_reduce_max(acc) : wave_reduce_sum(acc);
     }
@@ -461,9 +468,20 @@ __device__ __forceinline__ void fold_partials_multi(const double* const (&arr)[K
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.0;
     if (threadIdx.x < 256) {
-        for (int i = threadIdx.x; i < count; i += 256) {
+        for (int i0 = threadIdx.x; i0 < count; i0 += 256 * kFoldBatch) {
+            double v[K][kFoldBatch];
 #pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] += arr[k][i];
+            for (int u = 0; u < kFoldBatch; ++u) {
+                const int i = min(i0 + 256 * u, count - 1);
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[k][u] = arr[k][i];
+            }
+#pragma unroll
+            for (int u = 0; u < kFoldBatch; ++u)
+                if (i0 + 256 * u < count) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc[k] += v[k][u];
+                }
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] = wave_reduce_sum(acc[k]);
