@@ -734,30 +734,30 @@ __device__ __forceinline__ void bsf_partial_body(float* __restrict__ s_lds, cons
     const uint32_t hot4 = hot << 2;
     // hot cache: 16-byte loads when the slice starts on a 16-byte boundary (one round of 8 loads per thread instead of two
     // rounds of 16)
-    if (((reinterpret_cast<uintptr_t>(xg + base) & 15) == 0)) {
+    {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const bool aligned = (reinterpret_cast<uintptr_t>(xg + base) & 15) == 0;
         const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(xg + base);
         f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(s_lds);
-        const uint32_t hot4v = hot >> 2;
-        if (PGH_FILL_OVERLAP && hot4v > 0) {
-            constexpr int FR = (kBsfHot / 4 + kBsfThreads - 1) / kBsfThreads;
-            f32x4 fr[FR];
+        const uint32_t hot4v = aligned ? hot >> 2 : 0u;        // 16-byte words of the slice that go through registers
+        constexpr int FR = (kBsfHot / 4 + kBsfThreads - 1) / kBsfThreads;
+        f32x4 fr[FR];
+        const bool ahead = PGH_FILL_OVERLAP && hot4v > 0;
+        if (ahead) {
 #pragma unroll
             for (int k = 0; k < FR; ++k) fr[k] = src4[min((uint32_t)tid + (uint32_t)k * kBsfThreads, hot4v - 1)];
-            if (mid()) return;
+        }
+        if (mid()) return;                                     // (ONE call site: the close is a few hundred instructions)
+        if (ahead) {
 #pragma unroll
             for (int k = 0; k < FR; ++k) {
                 const uint32_t i = (uint32_t)tid + (uint32_t)k * kBsfThreads;
                 if (i < hot4v) dst4[i] = fr[k];
             }
         } else {
-            if (mid()) return;
             for (uint32_t i = tid; i < hot4v; i += kBsfThreads) dst4[i] = src4[i];
         }
         for (uint32_t i = (hot4v << 2) + tid; i < hot; i += kBsfThreads) s_lds[i] = xg[base + i];
-    } else {
-        if (mid()) return;
-        for (uint32_t i = tid; i < hot; i += kBsfThreads) s_lds[i] = xg[base + i];
     }
     if (tid == 0) s_lds[hot] = 0.f;
     __syncthreads();

@@ -40,7 +40,7 @@ constexpr int kLdsDoubles = kHot64 + 1;
 #define PGH_B64_PROBE 0
 #endif
 static_assert(PGH_BSF_IPT == 8, "a lane owns 8 consecutive entries (two 16-byte words)");
-static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of one CU");
+static_assert(kLdsDoubles * 8 + 16 * 8 <= 160 * 1024, "LDS budget of one CU");
 
 struct View64 {
     const uint32_t* colf;        // [num_entries] source (new id) | bit 31 = first entry of a row segment
@@ -100,9 +100,7 @@ template <bool HAS_VAL>
 __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const double* __restrict__ xg, const LoopState* __restrict__ state,
                                                             PendingClose pc) {
     __shared__ __attribute__((aligned(16))) double s_lds[kLdsDoubles];
-    if (state != nullptr && state->done) return;
-    // the previous term's close, if the loop driver left it to this kernel (PendingClose; the LDS it uses is not yet in use)
-    if (pc.active && run_pending_close(pc, s_lds)) return;
+    __shared__ double s_close[16];
     PGH_STAMP_BEGIN(g_times_partial64)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,8 +123,30 @@ __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const doub
     const uint32_t base = (uint32_t)b * (uint32_t)f.blk;
     const uint32_t hot = (uint32_t)min(kHot64, f.blk);
     {
+        // the hot cache: all of a thread's loads in flight at once (round 5: one 8-byte load, one wait, one LDS store per stride of 1024 was
+        // twenty round trips one after the other at the head of every launch), and the loop-state test + the previous term's close (PendingClose)
+        // between their issue and their arrival, on an LDS scratch of their own
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
         const double* __restrict__ src = xg + base;
-        for (uint32_t i = tid; i < hot; i += kThreads) s_lds[i] = src[i];
+        const f64x2* __restrict__ src2 = reinterpret_cast<const f64x2*>(src);      // (blocks start on multiples of 32 slots: 16-byte aligned)
+        f64x2* __restrict__ dst2 = reinterpret_cast<f64x2*>(s_lds);
+        const uint32_t hot2 = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) ? hot >> 1 : 0u;
+        constexpr int FR = (kHot64 / 2 + kThreads - 1) / kThreads;
+        f64x2 fr[FR];
+        if (hot2 > 0) {
+#pragma unroll
+            for (int k = 0; k < FR; ++k) fr[k] = src2[min((uint32_t)tid + (uint32_t)k * kThreads, hot2 - 1)];
+        }
+        if (state != nullptr && state->done) return;
+        if (pc.active && run_pending_close(pc, s_close)) return;
+        if (hot2 > 0) {
+#pragma unroll
+            for (int k = 0; k < FR; ++k) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)k * kThreads;
+                if (i < hot2) dst2[i] = fr[k];
+            }
+        }
+        for (uint32_t i = (hot2 << 1) + tid; i < hot; i += kThreads) s_lds[i] = src[i];
         if (tid == 0) s_lds[hot] = 0.0;
     }
     __syncthreads();
