@@ -66,28 +66,10 @@ __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, c
         auto emit = [&](const Round& r, int rb) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < P; ++q) {
-                // (the LOADS of a lane past the end of the piece are clamped and unconditional; its stores are skipped: on the short
-                // pieces of a partitioned slice most lanes of a round are past the end, and thousands of duplicate stores to the
-                // piece's last group queue up on one memory channel.  Its loaded words are still CONSUMED here, on the straight
-                // path -- round 5: with `continue` in their place the skipping path left the round's loads pending, the paths met
-                // at the head of the pipelined loop, and the compiler's wait there was for everything in flight, the previous
-                // round's stores included: the overlap the two register sets exist for did not happen)
-                const bool live = rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8) <= last;
-                {
-                    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-                    u32x4_ w = __builtin_bit_cast(u32x4_, r.s8[q]);
-                    uint32_t to = r.to[q];
-                    asm volatile("" : "+v"(w), "+v"(to));
-                    if (HAS_VAL) {
-                        u32x4_ a = __builtin_bit_cast(u32x4_, r.w0[q]), b = __builtin_bit_cast(u32x4_, r.w1[q]);
-                        asm volatile("" : "+v"(a), "+v"(b));
-                    }
-                    if (DROP) {
-                        u32x4_ a = __builtin_bit_cast(u32x4_, r.e0[q]), b = __builtin_bit_cast(u32x4_, r.e1[q]);
-                        asm volatile("" : "+v"(a), "+v"(b));
-                    }
-                }
-                if (!live) continue;
+                // (the LOADS of a lane past the end of the piece are clamped and unconditional; its gathers and its stores are
+                // skipped: on the short pieces of a partitioned slice most lanes of a round are past the end, and thousands of
+                // duplicate stores to the piece's last group queue up on one memory channel)
+                if (rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8) > last) continue;
                 f32x4 lo, hi;
                 if (PGH_PROBE_PB & 128) {                    // diagnostic: the LDS gathers without bank conflicts (wrong values)
                     const int at = (int)(threadIdx.x & 63u) + 64 * q;
@@ -134,18 +116,24 @@ __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, c
                 *reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 1, f.tmp_planes)) = hi;
             }
         };
-        // ONE exit, at the bottom, and every fetched round is emitted (a round past the end is all dead lanes: its words are consumed,
-        // nothing is gathered or stored).  With a second exit between the halves the path that left there met the loop's head with
-        // the other half's loads pending, and the head's wait was for everything in flight.
+        // (Round 5: the compiler joins the two exits of this loop with a full wait at its head -- every second round waits for the previous
+        // round's stores.  Measured without it -- uniform piece descriptors, the loaded words consumed on the straight path, one exit at
+        // the bottom and a dead round more per piece: phase A 58.5-58.9 against 58.0-59.0 us at scale 23, 393-436 against 388-447 at scale
+        // 25, 1590-1604 against 1520-1562 at scale 27 / ef 8; with the two exits kept: 60.1 / 440-459 / 1632-1686.  The kernel is bound
+        // by what a CU's memory path moves, not by this wait: left as it was.  profiles/r05/gather_shares_calibration_rejected.log)
         Round r0, r1;
-        fetch(r0, 0);
-        for (int rb = 0; rb < span; rb += 2 * kRound) {
-            fetch(r1, rb + kRound);                           // (clamped: a round past the end re-reads the last group)
+        int rb = 0;
+        fetch(r0, rb);
+        for (;;) {
+            fetch(r1, rb + kRound);                           // (clamped: the last round re-reads the last group)
             emit(r0, rb);
-            fetch(r0, rb + 2 * kRound);
-            emit(r1, rb + kRound);
+            rb += kRound;
+            if (rb >= span) break;
+            fetch(r0, rb + kRound);
+            emit(r1, rb);
+            rb += kRound;
+            if (rb >= span) break;
         }
-        emit(r0, span);                                       // (dead: consumes the last fetch)
 }
 
 // PG: round slots per lane on long pieces.  One GPU's graph has ~190 K entries per piece at scale 23: rounds of 4.  The slices of
@@ -160,14 +148,10 @@ __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t
     uint32_t amax = 0u;                 // bit pattern of max |value| this thread wrote (NaN > inf > finite as integers)
     // this workgroup's share of the entry stream: consecutive pieces, each inside one chunk; the LDS image of the chunk
     // is refilled only when the chunk changes
-    // (the pieces are the same for every lane: said so -- readfirstlane -- the piece loop and the round loops inside it are scalar loops
-    // with scalar bounds; as per-lane values they were exec-masked loops whose paths the compiler could only join with full waits)
-    const int piece_begin = __builtin_amdgcn_readfirstlane(f.task_range[vblock]), piece_end = __builtin_amdgcn_readfirstlane(f.task_range[vblock + 1]);
+    const int piece_begin = f.task_range[vblock], piece_end = f.task_range[vblock + 1];
     int loaded = -1;
     for (int piece = piece_begin; piece < piece_end; ++piece) {
-        const int4 task_v = f.task[piece];
-        const int4 task = make_int4(__builtin_amdgcn_readfirstlane(task_v.x), __builtin_amdgcn_readfirstlane(task_v.y),
-                                    __builtin_amdgcn_readfirstlane(task_v.z), 0);
+        const int4 task = f.task[piece];
         if (task.x != loaded && !(PGH_PROBE_PB & 1)) {
             __syncthreads();
             // cold ids [first_id, first_id + chunk) -> positions in the gather vector, block by block: the block loop is
