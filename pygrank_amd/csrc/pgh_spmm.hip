@@ -549,6 +549,7 @@ struct StepParams {
     const int*   nz_prev;    // non-zero rows of xg_old, and the rows that take part in the run: the map is kept while nz_prev * 4 < live_rows
     const int*   live_rows;
     int          affine;     // 1: the workgroups of an XCD take a contiguous eighth of every window (diagnostic)
+    const float* zero;       // [ld] zeros: what a row without the operand reads instead (no load sits under a branch)
 };
 
 // TRACK: the form that also writes the non-zero map.  It needs 134+ registers (three wavefronts per SIMD instead of four: 900 us instead of
@@ -593,23 +594,27 @@ __global__ __launch_bounds__(WG) void k_mm_step(StepParams c, int64_t n, int ld,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int64_t r = first + u * stride;
-        fl_next[u] = (live && r < n) ? (int)c.row_flags[r] : 0;
+        fl_next[u] = (int)c.row_flags[r < n ? r : n - 1];       // (raw: whether the row exists is applied when the flags are USED, a trip later)
     }
+    // Round 5: every load of a trip is issued unconditionally -- a row without the operand reads the zero row instead.  As `cond ? load : 0`
+    // each of the eight loads of a trip sat in a basic block of its own with a full wait behind it: eight round trips one after the other.
+    const float* const zero4 = c.zero + c4;
     for (int64_t r0 = first; r0 < n; r0 += stride * U) {
         f32x4 sum[U], pv[U], xo[U], op[U];
         int fl[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t r = r0 + u * stride;
-            fl[u] = fl_next[u];
+            fl[u] = (live && r < n) ? fl_next[u] : 0;
             const int64_t rn = r + stride * U;
-            fl_next[u] = (live && rn < n) ? (int)c.row_flags[rn] : 0;
+            fl_next[u] = (int)c.row_flags[rn < n ? rn : n - 1];
             const bool ok = fl[u] != 0;
             const int64_t at = (ok ? r : 0) * ld + c4;
-            sum[u] = (ok && (fl[u] & 2)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.sums + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            pv[u] = (ok && (fl[u] & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.p + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            xo[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.xg_old + at)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            op[u] = ok ? c.rowop[r] : f32x4{1.f, 1.f, 1.f, 0.f};
+            sum[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((ok && (fl[u] & 2)) ? c.sums + at : zero4));
+            pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((ok && (fl[u] & 1)) ? c.p + at : zero4));
+            xo[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ok ? c.xg_old + at : zero4));
+            const f32x4 ro = c.rowop[ok ? r : 0];
+            op[u] = ok ? ro : f32x4{1.f, 1.f, 1.f, 0.f};
         }
         bool nzl[U];
 #pragma unroll
@@ -1413,7 +1418,9 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
     const int64_t n = g->n_cols, n_int = f.n_out;
     const size_t slab = sizeof(float) * (size_t)n_int * ld;
     const f32x4* rowop = reinterpret_cast<const f32x4*>(f.mm_rowop);
-    DevBytes pint, xg0, xg1, sums, partial, folded, state_mem, factors, row_flags, nz_maps, nz_counts;
+    DevBytes pint, xg0, xg1, sums, partial, folded, state_mem, factors, row_flags, nz_maps, nz_counts, zero_row;
+    PGH_TRY(zero_row.alloc(sizeof(float) * (size_t)(ld + 4)));
+    PGH_HIP(hipMemsetAsync(zero_row.p, 0, sizeof(float) * (size_t)(ld + 4), r.stream));
     PGH_TRY(row_flags.alloc((size_t)((n_int + 63) / 64 * 64 + 64)));      // whole 64-row chunks (k_mm_step reads a chunk's flags as one line)
     // non-zero rows of the two gather slabs (k_mm_partial<SPARSE>): a byte per row, and {rows that hold a non-zero [2], rows in the run}
     const int64_t map_len = (n_int + 63) / 64 * 64 + 64;         // whole passes of 16 rows, 16-byte aligned halves
@@ -1538,6 +1545,7 @@ int batch_impl(pgh_graph_t g, pgh_mat_t p, pgh_mat_t ranks, const pgh_loop_cfg* 
         c.nz_prev = nz_cnt + ((k - 1) & 1);
         c.live_rows = nz_cnt + 2;
         c.affine = getenv("PGH_MM_AFFINE") != nullptr && atoi(getenv("PGH_MM_AFFINE")) != 0;
+        c.zero = zero_row.as<float>();
         {
             ProfScope prof(PGH_K_COMBINE);
             k_mm_step<false><<<cgrid, WG, 0, r.stream>>>(c, n_int, ld, b, state, partial.as<double>());
