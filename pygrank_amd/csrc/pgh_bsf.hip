@@ -543,19 +543,26 @@ __global__ __launch_bounds__(kBlock) void k_permute_out_gather(const float* __re
     constexpr int U = PGH_OUT_CHUNK / kBlock;              // index -> gather chains in flight per thread
     const bool skip_iso = iso.flag != nullptr && *iso.flag == 0;
     for (int64_t base = (int64_t)blockIdx.x * PGH_OUT_CHUNK; base < n; base += (int64_t)gridDim.x * PGH_OUT_CHUNK) {
+        // (round 5: both rounds of loads unconditional -- an id past the end re-reads the last one, a passed-over row reads slot 0 and
+        // is replaced by a select.  As `i < n ? iperm[i] : 0` and `dead ? 0 : src[at]` every one of the 2 x 16 loads of a thread sat under a
+        // branch with a full wait behind it: 32 round trips one after the other, 42-46 us for a pass that moves 90 MB)
         int at[U];
         float x[U];
+        bool dead[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = base + u * kBlock + threadIdx.x;
-            at[u] = i < n ? iperm[i] : 0;
+            at[u] = iperm[i < n ? i : n - 1];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = (skip_iso && iso.holds(at[u])) ? 0.f : src[at[u]];
+        for (int u = 0; u < U; ++u) {
+            dead[u] = skip_iso && iso.holds(at[u]);
+            x[u] = src[dead[u] ? 0 : at[u]];
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = base + u * kBlock + threadIdx.x;
-            if (i < n) dst[i] = x[u] * factor;
+            if (i < n) dst[i] = dead[u] ? 0.f : x[u] * factor;
         }
     }
 }

@@ -131,10 +131,12 @@ struct IsoTail {
         const unsigned int r32 = (unsigned int)row;            // ids are below 2^31
         const int b = shift >= 0 ? (int)(r32 >> shift) : (int)(r32 / (unsigned int)blk);
         // (a chain of selects over the 8 table entries: indexing a kernel-argument array with a per-lane value sends the table through
-        // scratch memory -- the way out of the id space took 54 us with it, 40 without, tools/permute_probe.hip)
-        int first = begin[0];
+        // scratch memory -- the way out of the id space took 54 us with it, 40 without, tools/permute_probe.hip.  Round 5: and a select
+        // between two LOADS of kernel arguments is folded into one load through a selected address -- a vector load from the argument
+        // segment with a full wait behind it, once per id; readfirstlane makes the entries scalar VALUES before the selects)
+        int first = __builtin_amdgcn_readfirstlane(begin[0]);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) first = b == k ? begin[k] : first;
+        for (int k = 1; k < 8; ++k) first = b == k ? __builtin_amdgcn_readfirstlane(begin[k]) : first;
         return b < num_blocks && (int)(r32 - (unsigned int)b * (unsigned int)blk) >= first;
     }
 };
