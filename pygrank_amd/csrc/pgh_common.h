@@ -186,6 +186,7 @@ struct PbFormat {
     int64_t   avg_piece = 0;        // entries per phase A piece on average (selects the round size of k_pb_gather)
     int4*     task = nullptr;       // phase A pieces {chunk, entry_begin, entry_end, 0}: consecutive ranges of the entry stream
     int*      task_range = nullptr; // [num_tasks + 1] pieces of every phase A workgroup (equal shares of the stream)
+    int4*     first_task = nullptr; // [num_tasks] task[task_range[w]]: a workgroup reads its first piece with its range
     // B order: [bin][chunk] runs (the same runs): a bin is one contiguous range
     float*    tmp = nullptr;        // [padded] gathered (and weighted) source values, written by phase A
     int4*     bin = nullptr;        // [num_bins] {first output row, rows | log2ceil(largest row's entries) << 16, first group, groups}
@@ -206,6 +207,9 @@ struct PbFormat {
     int       sched_groups = 0;
     int*      sched = nullptr;      // [num_items]
     int*      sched_begin = nullptr;// [sched_groups + 1]
+    int4*     first_a = nullptr;    // [sched_groups] item_a / item_b / index of every workgroup's FIRST static item (zeros / -1: none): read with the
+    int4*     first_b = nullptr;    // kernel's other start-up words in one round trip instead of the chain slice -> schedule -> item
+    int*      first_item = nullptr;
     uint32_t* work_counter = nullptr; // hand-out of the schedule's tail (one device word), or null without a tail
     int       tail_begin = 0, tail_count = 0;   // sched[tail_begin .. +tail_count): items handed out on the device
     int64_t   device_bytes = 0;

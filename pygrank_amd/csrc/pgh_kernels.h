@@ -659,6 +659,7 @@ struct PbView {
     const uint32_t* dstg;
     const int4*     task;
     const int*      task_range;
+    const int4*     first_task;        // [num_tasks] the first piece of every phase A workgroup
     float*          tmp;
     int             tmp_planes;  // layout of tmp (pb_tmp_quad)
     int             short_piece; // phase A pieces with fewer entries run rounds of one group per lane
@@ -667,6 +668,9 @@ struct PbView {
     int             num_items;
     const int*      sched;             // item order (PbFormat::sched); static deal: slices sched_begin[w] .. sched_begin[w + 1]
     const int*      sched_begin;
+    const int4*     first_a;           // PbFormat::first_a / first_b / first_item
+    const int4*     first_b;
+    const int*      first_item;
     uint32_t*       work_counter;      // hand-out of the schedule's tail: next position (null without a tail)
     int             tail_begin, tail_count;   // sched[tail_begin .. tail_begin + tail_count): handed out dynamically
     uint32_t*       hub_ticket;

@@ -284,6 +284,14 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     __shared__ double s_red[RES ? 4 * WAVES : WAVES];
     __shared__ float s_hub;
     __shared__ int s_last;
+    // The words a workgroup needs before its first stream round -- the launch's largest value, its slice of the schedule, the descriptors
+    // of its first item, the isolated-row flag -- are ASKED FOR before the first of them is used (round 5: as a chain state -> amax ->
+    // slice -> schedule -> item, each made uniform where it was loaded, they were five round trips at the head of every launch)
+    const uint32_t amax_raw = __builtin_nontemporal_load(f.amax);
+    const int sb0_raw = f.sched_begin[blockIdx.x], sb1_raw = f.sched_begin[blockIdx.x + 1];
+    const int4 fa_raw = f.first_a[blockIdx.x], fb_raw = f.first_b[blockIdx.x];
+    const int fi_raw = f.first_item[blockIdx.x];
+    const int iso_raw = *(f.iso_flag != nullptr ? f.iso_flag : reinterpret_cast<const int*>(f.amax));
     double scale = 1.0;
     if (state != nullptr) {
         if (state->done) return;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     }
     const float a_eff = (float)(ep.a * scale);
     const int tid = threadIdx.x;
-    const uint32_t amax = PGH_FIN_UNI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(f.amax)) : __builtin_nontemporal_load(f.amax);
+    const uint32_t amax = PGH_FIN_UNI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)amax_raw) : amax_raw;
     const bool finite = amax < 0x7f800000u;                // inf / NaN among the values: the sums are not representable
     // |value| <= amax < 2^e; an entry gets E = min(51, 62 - count_bits) bits: |value * S| < 2^E with S = 2^(E - e), and a
     // row of <= 2^count_bits entries stays below 2^62
@@ -435,8 +443,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     // one item per workgroup 117 us, second register sets for the stream / epilogue rounds 107-115 us.
     __shared__ int s_next;
     const int tail_count = f.tail_count;
-    int at = uni(f.sched_begin[blockIdx.x]);
-    const int at_end = uni(f.sched_begin[blockIdx.x + 1]);
+    int at = uni(sb0_raw);
+    const int at_end = uni(sb1_raw);
     // two-launch form (PbView::phase): phase 2 keeps its partials behind phase 1's; an item belongs to phase 1 when one of its rows has
     // an exchanged slot -- its first row's slot inside the block lies below phase_live, or its rows run into the next block
     const int slot0 = f.phase == 2 ? (int)gridDim.x + tail_count : 0;
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
         return uni(f.sched[f.tail_begin + k]);
     };
     bool flushed_head = false;
-    if (!in_tail) item = uni(f.sched[at]);
+    if (!in_tail) item = uni(fi_raw);
     else {
         flush(slot0 + blockIdx.x);          // no static items: the workgroup's partial is zero
         flushed_head = true;
@@ -469,11 +477,12 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     Round R;
     // items marked -2 cover isolated rows (no entry, referenced by nobody): unless this run's operands are non-zero there
     // they hold zeros in both iterates and are passed over (the item shrinks to no rows: barriers only)
-    const bool skip_iso = f.iso_flag != nullptr && *f.iso_flag == 0;
+    const bool skip_iso = f.iso_flag != nullptr && uni(iso_raw) == 0;
     bool mine = false;                      // the item in hand belongs to this launch's phase
     if (item >= 0) {
-        bin = uni4(f.item_a[item]);   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
-        epi = uni4(f.item_b[item]);   // {first row of the epilogue range, rows, split index or -1 (-2: isolated rows), first item of the split row}
+        const bool first_static = !in_tail;   // (its descriptors came with the start-up words; a ticket's item is looked up)
+        bin = first_static ? uni4(fa_raw) : uni4(f.item_a[item]);   // {first row, rows | log2ceil(largest row) << 16 | hub << 21 | (pieces - 1) << 22, first group, groups}
+        epi = first_static ? uni4(fb_raw) : uni4(f.item_b[item]);   // {first row of the epilogue range, rows, split index or -1 (-2: isolated rows), first item of the split row}
         mine = in_phase(epi);
         if (mine) fetch(bin, 0, R);
     }
@@ -837,6 +846,7 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.dstg = p.dstg;
     v.task = p.task;
     v.task_range = p.task_range;
+    v.first_task = p.first_task;
     v.tmp = p.tmp;
     v.tmp_planes = p.tmp_planes;
     static const int short_env = getenv("PGH_GATHER_SHORT") != nullptr ? atoi(getenv("PGH_GATHER_SHORT")) : -1;
@@ -846,6 +856,9 @@ PbView pb_view(const BsfFormat& f, const PbFormat& p) {
     v.num_items = p.num_items;
     v.sched = p.sched;
     v.sched_begin = p.sched_begin;
+    v.first_a = p.first_a;
+    v.first_b = p.first_b;
+    v.first_item = p.first_item;
     v.work_counter = p.work_counter;
     v.tail_begin = p.tail_begin;
     v.tail_count = p.tail_count;
@@ -1266,6 +1279,14 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     PGH_HIP(hipMalloc(&p.task_range, sizeof(int) * (size_t)(shares + 1)));
     if (!tasks.empty()) PGH_HIP(hipMemcpyAsync(p.task, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMemcpyAsync(p.task_range, ranges.data(), sizeof(int) * (shares + 1), hipMemcpyHostToDevice, r.stream));
+    {
+        std::vector<int4> first(shares > 0 ? shares : 1, make_int4(0, 0, 0, 0));
+        for (int w = 0; w < shares; ++w)
+            if (ranges[w] < ranges[w + 1]) first[w] = tasks[ranges[w]];
+        PGH_HIP(hipMalloc(&p.first_task, sizeof(int4) * first.size()));
+        PGH_HIP(hipMemcpyAsync(p.first_task, first.data(), sizeof(int4) * first.size(), hipMemcpyHostToDevice, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+    }
     PGH_HIP(hipMalloc(&p.tmp, sizeof(float) * (size_t)(((padded / 8 + 63) / 64 + 1) * 512)));      // whole blocks of 64 groups (pb_tmp_quad)
     {
         // (chunk, bin) runs of a dozen groups or more: the two-plane layout of tmp; shorter runs: quads side by side
@@ -1425,6 +1446,16 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             PGH_HIP(hipMalloc(&p.sched_begin, sizeof(int) * (size_t)(groups + 1)));
             PGH_HIP(hipMemcpyAsync(p.sched, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice, r.stream));
             PGH_HIP(hipMemcpyAsync(p.sched_begin, begin.data(), sizeof(int) * begin.size(), hipMemcpyHostToDevice, r.stream));
+            std::vector<int4> first_a(groups, make_int4(0, 0, 0, 0)), first_b(groups, make_int4(0, 0, -1, 0));
+            std::vector<int> first_item(groups, -1);
+            for (int w = 0; w < groups; ++w)
+                if (begin[w] < begin[w + 1]) first_item[w] = flat[begin[w]], first_a[w] = all_a[flat[begin[w]]], first_b[w] = all_b[flat[begin[w]]];
+            PGH_HIP(hipMalloc(&p.first_a, sizeof(int4) * (size_t)groups));
+            PGH_HIP(hipMalloc(&p.first_b, sizeof(int4) * (size_t)groups));
+            PGH_HIP(hipMalloc(&p.first_item, sizeof(int) * (size_t)groups));
+            PGH_HIP(hipMemcpyAsync(p.first_a, first_a.data(), sizeof(int4) * (size_t)groups, hipMemcpyHostToDevice, r.stream));
+            PGH_HIP(hipMemcpyAsync(p.first_b, first_b.data(), sizeof(int4) * (size_t)groups, hipMemcpyHostToDevice, r.stream));
+            PGH_HIP(hipMemcpyAsync(p.first_item, first_item.data(), sizeof(int) * (size_t)groups, hipMemcpyHostToDevice, r.stream));
             PGH_HIP(hipStreamSynchronize(r.stream));
             if (getenv("PGH_DEBUG") != nullptr && atoi(getenv("PGH_DEBUG")) != 0) {
                 double lo = 1e300, hi = 0, total = 0;
@@ -1626,6 +1657,7 @@ void pb_destroy(PbFormat& p) {
     (void)hipFree(p.drop_edge);
     (void)hipFree(p.task);
     (void)hipFree(p.task_range);
+    (void)hipFree(p.first_task);
     (void)hipFree(p.tmp);
     (void)hipFree(p.dstg);
     (void)hipFree(p.amax);
@@ -1636,6 +1668,9 @@ void pb_destroy(PbFormat& p) {
     (void)hipFree(p.item_b);
     (void)hipFree(p.sched);
     (void)hipFree(p.sched_begin);
+    (void)hipFree(p.first_a);
+    (void)hipFree(p.first_b);
+    (void)hipFree(p.first_item);
     (void)hipFree(p.work_counter);
     (void)hipFree(p.bin);
     (void)hipFree(p.drow);

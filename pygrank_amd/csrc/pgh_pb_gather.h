@@ -149,9 +149,10 @@ __device__ __forceinline__ void pb_gather_body(float* __restrict__ s_x, uint32_t
     // this workgroup's share of the entry stream: consecutive pieces, each inside one chunk; the LDS image of the chunk
     // is refilled only when the chunk changes
     const int piece_begin = f.task_range[vblock], piece_end = f.task_range[vblock + 1];
+    const int4 first_task = f.first_task[vblock];          // (= task[piece_begin]: asked for WITH the range, not after it)
     int loaded = -1;
     for (int piece = piece_begin; piece < piece_end; ++piece) {
-        const int4 task = f.task[piece];
+        const int4 task = piece == piece_begin ? first_task : f.task[piece];
         if (task.x != loaded && !(PGH_PROBE_PB & 1)) {
             __syncthreads();
             // cold ids [first_id, first_id + chunk) -> positions in the gather vector, block by block: the block loop is
