@@ -189,6 +189,9 @@ struct SparseGate {
 __device__ __forceinline__ bool mm_take_sparse(const SparseGate& sg) {
     return sg.map != nullptr && (long long)(*sg.nz_rows) * 4 < (long long)(*sg.live_rows);
 }
+#ifndef PGH_MM_GATHER_BF
+#define PGH_MM_GATHER_BF 1
+#endif
 template <bool HAS_VAL, int LPR, bool DROP = false, bool SPARSE = false>
 __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __restrict__ xg, int ld, int b, float* __restrict__ sums,
                                                     const BatchState* __restrict__ state, MMDrop drop = MMDrop{}, SparseGate sg = SparseGate{}) {
@@ -235,6 +238,14 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
                 const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(pull + 4 * (e / W), (int)q.w[e % W]);
                 const uint32_t src = word & (SPARSE ? 0x3fffffffu : 0x7fffffffu);
                 const bool fetch = SPARSE ? (live && (word & 0x40000000u) != 0u) : live;
+#if PGH_MM_GATHER_BF
+                if (!SPARSE) {
+                    // (round 5: unconditional -- a lane beyond the batch's columns re-reads its group's first four; as `live ? load : 0` every
+                    // gather sat under a branch and the wait before the sums was for ALL gathers, the eight just issued included)
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xg + (int64_t)src * ld + (live ? c4 : 0));
+                    x[j] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else      // (the sparse form keeps its skipped loads skipped: redirected to a zero row they cost 50 us of a batch step)
+#endif
                 x[j] = fetch ? *reinterpret_cast<const f32x4*>(xg + (int64_t)src * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
