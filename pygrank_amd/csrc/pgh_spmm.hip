@@ -222,7 +222,8 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
             for (int k = 0; k < W; ++k) {
                 q.w[k] = __builtin_nontemporal_load(f.colf + at + k);
                 if (SPARSE) q.w[k] |= (uint32_t)sg.map[q.w[k] & 0x3fffffffu] << 30;      // (ids stay below 2^28: bit 30 is free)
-                q.c[k] = has ? __builtin_nontemporal_load(f.close + at + k) : -1;
+                const int cw = __builtin_nontemporal_load(f.close + at + k);      // (the tile index is clamped: unconditional, then a select)
+                q.c[k] = has ? cw : -1;
                 q.v[k] = HAS_VAL ? __builtin_nontemporal_load(f.val + at + k) : 1.f;
                 if (DROP) {
                     const int edge = __builtin_nontemporal_load(drop.edge + at + k);
@@ -242,8 +243,9 @@ __global__ __launch_bounds__(WG) void k_mm_partial(MMView f, const float* __rest
                 if (!SPARSE) {
                     // (round 5: unconditional -- a lane beyond the batch's columns re-reads its group's first four; as `live ? load : 0` every
                     // gather sat under a branch and the wait before the sums was for ALL gathers, the eight just issued included)
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(xg + (int64_t)src * ld + (live ? c4 : 0));
-                    x[j] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                    // (no select behind it either -- it would wait for the load where it stands: such a lane's sums are never stored where
+                    // anybody reads them)
+                    x[j] = *reinterpret_cast<const f32x4*>(xg + (int64_t)src * ld + (live ? c4 : 0));
                 } else      // (the sparse form keeps its skipped loads skipped: redirected to a zero row they cost 50 us of a batch step)
 #endif
                 x[j] = fetch ? *reinterpret_cast<const f32x4*>(xg + (int64_t)src * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
