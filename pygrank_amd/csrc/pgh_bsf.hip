@@ -1704,6 +1704,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     f.blk_size = blk;
     // slices of a row partition: need lists (PGH_DIST_NEED_LISTS=0: the dense cold layout of rounds 1-4, exchanged by all-gather alone)
     f.want_compact = !batch_layout && g->part_perm != nullptr && env_int("PGH_DIST_NEED_LISTS", 1) != 0;
+    f.whole_graph = g->part_perm == nullptr;
     f.n_src = (int)n_src;
     f.n_src_pad = n_src_pad;
     f.relabelled = relabel;

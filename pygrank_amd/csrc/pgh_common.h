@@ -228,6 +228,7 @@ struct SegMeta {
 
 struct BsfFormat {
     bool      enabled = false;
+    bool      whole_graph = false;  // not a slice of a row partition (pb_plan: the middle bin shape is for whole graphs)
     PbFormat  pb;                   // first slice of the cold image (bins of the lowest rows); flags for the whole image
     PbFormat  pb_more[kPbMaxSlices - 1];   // further slices: each is run (phase A, then phase B) before the next, so that the
     int       pb_slices = 0;        // values handed from A to B are still in the L2 / Infinity Cache when B reads them

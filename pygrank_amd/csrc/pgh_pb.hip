@@ -85,6 +85,11 @@ constexpr int kBlock = 256;
 // long enough on graphs with many chunks (row-partitioned slices gather from the whole source space).
 constexpr int kPbBinRows = PGH_PB_ROWS, kPbBThreads = PGH_PB_BTHREADS;
 constexpr int kPbBinRowsLarge = 16384, kPbBThreadsLarge = 1024;
+// ... and a middle shape (round 5): 8192 rows, 512 threads, two workgroups per CU -- for graphs whose small bins would give a workgroup seven and
+// more items of short runs but whose runs are still long enough at twice the rows (RMAT scales 25-26: finish + phase A -9 ... -12 % at scale 25,
+// -4 % at scale 26; at scale 24 the small shape wins by 3 %, at scale 27 / ef 8 and on the 8-way slice the large one: profiles/r05/
+// large_graphs_bin_shapes.log)
+constexpr int kPbBinRowsMid = 8192, kPbBThreadsMid = 512;
 constexpr int kPbBinFill = 6;                    // entries per bin <= kPbBinFill * rows (balance: the heavy rows come first);
                                                  // PGH_PB_BINFILL sweep at scale 23 (profiles/r02/binfill_sweep.log), k_pb_finish:
                                                  // 4 -> 108.9 us, 6 -> 101.6, 8 -> 108.2, 12 -> 107.7, 16 -> 133.9
@@ -990,7 +995,8 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         close_bin();
     };
     int bin_rows = kPbBinRows;
-    if (const char* shape = getenv("PGH_PB_BINROWS")) bin_rows = atoi(shape) > kPbBinRows ? kPbBinRowsLarge : kPbBinRows;   // diagnostic
+    if (const char* shape = getenv("PGH_PB_BINROWS"))     // diagnostic
+        bin_rows = atoi(shape) > kPbBinRowsMid ? kPbBinRowsLarge : (atoi(shape) > kPbBinRows ? kPbBinRowsMid : kPbBinRows);
     const char* fill_env = getenv("PGH_PB_BINFILL");
     int bin_fill = fill_env != nullptr ? std::max(1, atoi(fill_env)) : kPbBinFill;
     auto mean_run = [&]() { return (double)in_image / ((double)chunks * (double)std::max<size_t>(bins.size(), 1)); };
@@ -1005,6 +1011,11 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     }
     // measured (profiles/r01/partition_slices_pb.log, pb_large_graphs.log): at 55 entries per run the small shape is 3 %
     // faster (scale 24), at 31 it is 3 % faster on a partitioned slice but 7 % slower at scale 25, at 14 it does not pay
+    // (the middle shape first: whole graphs only -- the slices of a partition were measured with the two old shapes)
+    if (mean_run() < 80.0 && kPbBinRowsMid > bin_rows && !f.want_compact && f.whole_graph && getenv("PGH_PB_BINROWS") == nullptr) {
+        bin_rows = kPbBinRowsMid;
+        lay_out(bin_rows, bin_fill);
+    }
     if (mean_run() < 40.0 && kPbBinRowsLarge > bin_rows && getenv("PGH_PB_BINROWS") == nullptr) {
         bin_rows = kPbBinRowsLarge;              // short runs: fewer, larger bins
         lay_out(bin_rows, bin_fill);
@@ -1381,9 +1392,9 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         // order (item i -> workgroup i % groups: neighbouring workgroups touch neighbouring rows), the tail -- PGH_FIN_TAIL
         // percent of the items, never a hub piece -- is handed out on the device (k_pb_finish).
         {
-            const bool large = p.bin_rows > kPbBinRows;
+            const bool large = p.bin_rows > kPbBinRowsMid, mid = p.bin_rows == kPbBinRowsMid;
             const int by_regs = PGH_FIN_WPE * 4 / (kPbBThreads / 64);
-            int groups = r.num_cus * (large ? 1 : (by_regs < 4 ? (by_regs < 1 ? 1 : by_regs) : 4));
+            int groups = r.num_cus * (large ? 1 : (mid ? 2 : (by_regs < 4 ? (by_regs < 1 ? 1 : by_regs) : 4)));
             if (groups > p.num_items) groups = p.num_items;
             if (groups > kMaxPartials) groups = kMaxPartials;
             if (groups < 1) groups = 1;
@@ -1576,7 +1587,7 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
     g_finish_phase = 0;                                // consumed
     double* psum = r.d_partials;
     double* pdel = r.d_partials + kMaxPartials;
-    const bool large = p.bin_rows > kPbBinRows;
+    const bool large = p.bin_rows > kPbBinRowsMid, mid = p.bin_rows == kPbBinRowsMid;
     const int grid = p.sched_groups;                   // persistent: as many workgroups as the CUs hold at once
     PGH_CHECK(phase == 0 || 2 * (grid + p.tail_count) <= kMaxPartials, "finish kernel: too many partial sums for the two-launch form");
     ResParams rp = g_residual;
@@ -1591,6 +1602,8 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
             if (res) {
                 if (large && wide) PGH_FINISH(8, kPbBinRowsLarge, kPbBThreadsLarge, true);
                 else if (large) PGH_FINISH(4, kPbBinRowsLarge, kPbBThreadsLarge, true);
+                else if (mid && wide) PGH_FINISH(8, kPbBinRowsMid, kPbBThreadsMid, true);
+                else if (mid) PGH_FINISH(4, kPbBinRowsMid, kPbBThreadsMid, true);
                 else if (wide) PGH_FINISH(8, kPbBinRows, kPbBThreads, true);
                 else PGH_FINISH(4, kPbBinRows, kPbBThreads, true);
             }
@@ -1598,6 +1611,8 @@ int pb_launch_finish(pgh_graph_s* g, const RowSums& rs, const EpiParams& ep, con
         if (!res) {
             if (large && wide) PGH_FINISH(8, kPbBinRowsLarge, kPbBThreadsLarge, false);
             else if (large) PGH_FINISH(4, kPbBinRowsLarge, kPbBThreadsLarge, false);
+            else if (mid && wide) PGH_FINISH(8, kPbBinRowsMid, kPbBThreadsMid, false);
+            else if (mid) PGH_FINISH(4, kPbBinRowsMid, kPbBThreadsMid, false);
             else if (wide) PGH_FINISH(8, kPbBinRows, kPbBThreads, false);
             else PGH_FINISH(4, kPbBinRows, kPbBThreads, false);
         }

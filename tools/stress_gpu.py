@@ -65,7 +65,8 @@ def main():
         n = A.shape[0]
         for key, val in (("PGH_BLOCKS", str(int(rng.choice([0, 1, 2, 4, 8])))), ("PGH_RELABEL", str(int(rng.integers(0, 2)))),
                          ("PGH_PB", str(int(rng.random() < 0.3))), ("PGH_PB_FORCE", "1"), ("PGH_TRIM", str(int(rng.integers(0, 2)))),
-                         ("PGH_PB_HEAVY", str(int(rng.choice([16384, 8, 64])))), ("PGH_PB_HUBMAX", str(int(rng.choice([262144, 150, 4000]))))):
+                         ("PGH_PB_HEAVY", str(int(rng.choice([16384, 8, 64])))), ("PGH_PB_HUBMAX", str(int(rng.choice([262144, 150, 4000])))),
+                         ("PGH_PB_BINROWS", str(int(rng.choice([4096, 8192, 16384]))))):     # the finish kernel's three shapes
             os.environ[key] = val
         if os.environ["PGH_BLOCKS"] == "0":
             os.environ.pop("PGH_BLOCKS")
