@@ -125,8 +125,15 @@ def main():
                 except Exception:
                     done += 1
                     continue
-                print("MISSING non-convergence exception", desc, flush=True)
-                sys.exit(1)
+                # the engine converged: a run whose residual shrinks ~1 % per step (alpha = 0.99) crosses the tolerance within f32 rounding of it for
+                # several steps, so the engine may stop at 299 where the oracle needs 302 (seed 9062 #8001: a 2-node graph, Mabs 1e-6).  The oracle
+                # then gets the slack the comparison below allows (its // 25 steps) beyond the limit; it must converge there
+                try:
+                    want, it = orc.pagerank(M, p, error_type=err, tol=tol, max_iters=300 + 300 // 25, eps=EPS32, **kw)
+                except Exception:
+                    print("MISSING non-convergence exception", desc, type(ranker).__name__, "engine iterations:", ranker.convergence.iteration,
+                          "A:", A.toarray().tolist() if n <= 4 else "", "p:", p.tolist() if n <= 4 else "", kw, err, tol, flush=True)
+                    sys.exit(1)
         elif which == 1:
             ranker = pg.AbsorbingWalks(0.85, error_type=pg.L1, tol=1e-6, max_iters=300)
             same_steps = lambda k: orc.absorbing_walks(M, p, alpha=0.85, error_type="iters", max_iters=k, eps=EPS32)[0]   # noqa: E731
@@ -139,8 +146,12 @@ def main():
                 except Exception:
                     done += 1
                     continue
-                print("MISSING non-convergence exception", desc, flush=True)
-                sys.exit(1)
+                try:                                                # (as above)
+                    want, it = orc.absorbing_walks(M, p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=300 + 300 // 25, eps=EPS32)
+                except Exception:
+                    print("MISSING non-convergence exception", desc, type(ranker).__name__, "engine iterations:", ranker.convergence.iteration,
+                          "A:", A.toarray().tolist() if n <= 4 else "", "p:", p.tolist() if n <= 4 else "", flush=True)
+                    sys.exit(1)
         elif which in (2, 3):
             ctype = "taylor" if which == 2 else "chebyshev"
             want, it = orc.heat_kernel(M, p, t=3, coefficient_type=ctype, error_type="iters", max_iters=20, eps=EPS32)
@@ -191,6 +202,20 @@ def main():
         try:
             got = np.asarray(ranker.rank(adj, p.copy()).np)
         except Exception as exc:                                   # non-convergence must agree with the oracle too
+            if which in (0, 1) and (p < 0).any():
+                # ... but for a SIGNED personalization: its iterate is a difference of large terms, and an f32 evaluation can end in a limit
+                # cycle of a few ulp whose residual sits just above the tolerance -- seed 9062 #22129 (host double AND engine): AbsorbingWalks
+                # on [[0, 0], [3, 1]], p = (-0.3, 0.904), the oracle stops after 51 steps, the f32 iterates alternate between two states
+                # 3 ulp apart (residual 1.1e-6 against 1e-6) for ever.  Such a run is held to the signed class's bound AT the oracle's
+                # step count, and logged as a leg of its own.
+                stalled = (pg.PageRank(kw["alpha"], use_quotient=kw["use_quotient"], error_type="iters", max_iters=it) if which == 0
+                           else pg.AbsorbingWalks(0.85, error_type="iters", max_iters=it))
+                got_it = np.asarray(stalled.rank(adj, p.copy()).np)
+                rel_it = np.max(np.abs(got_it - want)) / max(np.max(np.abs(want)), 1e-30)
+                record(type(ranker).__name__ + ", signed p, f32 limit cycle above the tolerance", rel_it, 0)
+                if rel_it <= 2e-6:
+                    done += 1
+                    continue
             print("EXCEPTION", desc, type(ranker).__name__, exc, "oracle:", it, "A:", A.toarray().tolist() if n <= 4 else "", "p:", p.tolist() if n <= 4 else "",
                   {k: v for k, v in vars(ranker).items() if k in ("alpha", "use_quotient")}, vars(ranker.convergence).get("tol"), flush=True)
             sys.exit(1)
