@@ -60,7 +60,9 @@ constexpr int kBlock = 256;
 // k_pb_finish build parameters (tools/build_variants.sh): groups per thread and stream round, rows per thread and epilogue
 // round, whether the next item's first stream round is issued before the current item's epilogue
 #ifndef PGH_FIN_P
-#define PGH_FIN_P 2           // measured at scale 23 (profiles/r02/finish_pg_sweep.log): P x G = 4x4 108-113 us, 4x2 114, 2x4 104, 2x8 108, 6x4 118
+#define PGH_FIN_P 1           // measured at scale 23 (profiles/r02/finish_pg_sweep.log): P x G = 4x4 108-113 us, 4x2 114, 2x4 104, 2x8 108, 6x4 118;
+                              // round 5 (descriptors in scalar registers): 1 = 124 registers, nothing spilled, 91.9-93.3 us against 94.8-96.8 for 2
+                              // (128 registers, 8 spilled) and 108-111 for 3; scale 22: 60.8-61.1 against 59.3-59.7
 #endif
 #ifndef PGH_FIN_STAGGER
 #define PGH_FIN_STAGGER 0
@@ -76,6 +78,9 @@ constexpr int kBlock = 256;
 #endif
 #ifndef PGH_FIN_BF
 #define PGH_FIN_BF 1          // the epilogue's operand loads without run-time branches (a missing operand reads psum's zero slot)
+#endif
+#ifndef PGH_FIN_G2
+#define PGH_FIN_G2 2          // epilogue groups in flight per wavefront where the rows carry more operands (8 blocks, the in-kernel residual)
 #endif
 #ifndef PGH_FIN_UNI
 #define PGH_FIN_UNI 1         // item descriptors as wavefront-uniform values (scalar registers, scalar branches on hub / rows)
@@ -279,9 +284,9 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     // shapes keep 16 wavefronts per CU (128 registers): 4 workgroups of 256 threads (32 KB of row sums each) or one of
     // 1024; what covers the latencies an item exposes (stream, atomics, epilogue rounds) is the depth of each round plus
     // the other workgroups of the CU.
-    constexpr int P = THREADS > 512 ? 2 : PGH_FIN_P;
+    constexpr int P = THREADS > 256 ? 2 : PGH_FIN_P;
     // (with the in-kernel residual: two more operands per row -- 2 rows in flight measured 108 us, 3: 112-114, 4: 119)
-    constexpr int G = (THREADS > 512 || NB > 4 || RES) ? 2 : PGH_FIN_G;
+    constexpr int G = (THREADS > 512 || NB > 4 || RES) ? PGH_FIN_G2 : PGH_FIN_G;
     constexpr int WORDS = ROWS / 64 + 1;                   // map words an item can touch per block (unaligned first row)
     __shared__ unsigned long long s_row[ROWS];
     __shared__ unsigned long long s_mask[NB * WORDS];      // the item's slice of the row -> segment map (BsfFormat::meta)
