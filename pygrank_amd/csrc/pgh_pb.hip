@@ -82,6 +82,10 @@ constexpr int kBlock = 256;
 #ifndef PGH_FIN_G2
 #define PGH_FIN_G2 2          // epilogue groups in flight per wavefront where the rows carry more operands (8 blocks, the in-kernel residual)
 #endif
+#ifndef PGH_FIN_PBIG
+#define PGH_FIN_PBIG 1          // ... of the 512- and 1024-thread shapes (2 -> 1: 10 / 8 -> 2 registers spilled; finish -2 % at scale 25, -2 ... -6 % at scale 27 / ef 8,
+                                // no different on the 8-way slice)
+#endif
 #ifndef PGH_FIN_UNI
 #define PGH_FIN_UNI 1         // item descriptors as wavefront-uniform values (scalar registers, scalar branches on hub / rows)
 #endif
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
     // shapes keep 16 wavefronts per CU (128 registers): 4 workgroups of 256 threads (32 KB of row sums each) or one of
     // 1024; what covers the latencies an item exposes (stream, atomics, epilogue rounds) is the depth of each round plus
     // the other workgroups of the CU.
-    constexpr int P = THREADS > 256 ? 2 : PGH_FIN_P;
+    constexpr int P = THREADS > 256 ? PGH_FIN_PBIG : PGH_FIN_P;
     // (with the in-kernel residual: two more operands per row -- 2 rows in flight measured 108 us, 3: 112-114, 4: 119)
     constexpr int G = (THREADS > 512 || NB > 4 || RES) ? PGH_FIN_G2 : PGH_FIN_G;
     constexpr int WORDS = ROWS / 64 + 1;                   // map words an item can touch per block (unaligned first row)
