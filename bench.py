@@ -420,6 +420,7 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
         scale, ef = args.scale, (args.ef or 16)
     if args.ef is not None and args.scale is None:
         ef = args.ef
+    _test_failure("start", rank)
     t0 = time.time()
     pg = rmat_partitioned(scale, ef, rank, world, **rmat)
     L.check(L.lib().pgh_sync())
@@ -461,6 +462,22 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_cuda else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    rung = dict(rung=int(os.environ.get("PGH_BENCH_RUNG", "0")), settings=os.environ.get("PGH_BENCH_RUNG_LABEL", "default"),
+                env={k: os.environ[k] for k in ("PGH_DIST_SINGLE_COMM", "PGH_DIST_SINGLE_STREAM", "PGH_DIST_EXCHANGE", "PGH_DIST_NEED_LISTS",
+                                                "PGH_DIST_NATIVE") if k in os.environ})
+    headline = dict(
+        metric="edges*iters/sec (GTEPS) for PPR alpha=0.85 to tol=1e-6", value=round(nnz_total * spmv_total / elapsed / 1e9, 2),
+        unit="GTEPS", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
+        higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+        config=dict(workload=f"row-partitioned PPR on RMAT scale-{scale} ef-{ef} over {world} GPUs (BASELINE.json configs[4] shape)",
+                    n=n, nnz=nnz_total, alpha=alpha, tol=tol, error_type="L1", seeds=num_seeds, iterations_per_step=iters,
+                    spmv_per_step=spmv_total / args.steps, graph_build_s=round(build_s, 2), nnz_per_rank_max_over_mean=balance,
+                    fallback_rung=rung, **dict(ranker.exchange)))
+    # the timed region is over on every rank: what has been measured is kept where the rank's supervisor finds it, whatever happens in
+    # the legs below (supervise_rank prints it, marked incomplete, when no rung of the ladder gets through all of them)
+    if rank == 0 and os.environ.get("PGH_BENCH_PARTIAL"):
+        _write_atomic(os.environ["PGH_BENCH_PARTIAL"], json.dumps(dict(headline, roofline=None, cpu_baseline=None)))
+    _test_failure("after_timing", rank)
     # roofline leg on rank 0: HIP-event time of the step kernels, per-GPU algorithmic bytes
     lib = L.lib()
     L.check(lib.pgh_profile_reset())
@@ -506,23 +523,31 @@ def bench_row_partitioned(args, rmat, alpha, tol, max_iters, num_seeds, hbm_peak
                                       use_cuda)
     if rank != 0:
         return None
+    headline["config"].update(
+        parallelism=f"1-D row partition x{world}, all-gather of the gather vector + " +
+                    ("ONE 4-scalar all-reduce" if exchange.get("in_kernel_residual") else "2 scalar all-reduces") + " per iteration",
+        engine_loop_probe=_probe_verdict(world, rank), **exchange)
     return dict(
-        metric="edges*iters/sec (GTEPS) for PPR alpha=0.85 to tol=1e-6", value=round(nnz_total * spmv_total / elapsed / 1e9, 2),
-        unit="GTEPS", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
-        higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-        config=dict(workload=f"row-partitioned PPR on RMAT scale-{scale} ef-{ef} over {world} GPUs (BASELINE.json configs[4] shape)",
-                    n=n, nnz=nnz_total, alpha=alpha, tol=tol, error_type="L1", seeds=num_seeds, iterations_per_step=iters,
-                    spmv_per_step=spmv_total / args.steps, graph_build_s=round(build_s, 2),
-                    parallelism=f"1-D row partition x{world}, all-gather of the gather vector + " +
-                                ("ONE 4-scalar all-reduce" if exchange.get("in_kernel_residual") else "2 scalar all-reduces") + " per iteration",
-                    engine_loop_probe=_probe_verdict(world, rank),
-                    nnz_per_rank_max_over_mean=balance, **exchange),
+        headline,
         roofline=dict(bound="hbm", kernel=step_kernels + " (one PPR iteration of rank 0's slice, exchange excluded)",
                       achieved=round(achieved, 1) if achieved else None, peak=hbm_peak, unit="GB/s",
                       frac=round(achieved / hbm_peak, 4) if achieved else None, traffic=None,
                       algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(step_us, 2), format=graph_format,
                       kernels_avg_us=prof),
         cpu_baseline=cpu, parity=parity, same_graph_1gpu=same_graph, secondary=dict(batch_of_64_seeds_replicas=replicas))
+
+
+def _test_failure(where, rank):
+    """Test hook of the supervisors' ladder (tests/test_distributed_cpu.py): PGH_BENCH_TEST_FAIL="rung:rank:code:where[,...]" ends this
+    rank's child with `code` at the named point of the named rung ("hang": it stops answering instead)."""
+    for spec in filter(None, os.environ.get("PGH_BENCH_TEST_FAIL", "").split(",")):
+        f_rung, f_rank, f_code, f_where = spec.split(":")
+        if int(f_rung) == int(os.environ.get("PGH_BENCH_RUNG", "0")) and int(f_rank) == rank and f_where == where:
+            sys.stderr.write(f"[bench] rank {rank}: test hook: failing {where} of rung {f_rung} with {f_code}\n")
+            sys.stderr.flush()
+            if f_code == "hang":
+                time.sleep(10 ** 6)
+            os._exit(int(f_code))
 
 
 def _probe_verdict(world, rank):
@@ -673,16 +698,33 @@ def _replica_batch_leg(dist, rank, world, pg, ranker, scale, ef, rmat, alpha, to
             feats.set_column(j, pgm.to_signal(adj, col).np)
         split = ReplicatedPropagation(pgm.PageRank(alpha=alpha, error_type=pgm.L1, tol=tol, max_iters=max_iters))
         split.propagate(adj, feats, gather=False)                 # warm-up: builds the multi-seed image
-        dist.barrier()
+        setup_ok = True
+    except Exception as exc:
+        setup_ok, result = False, dict(error=str(exc)[:300])
+    # Every rank runs the SAME sequence of collectives whatever happened above (a rank that failed while building its replica
+    # used to skip to the final barrier while the healthy ones waited in all_reduce): agree first, skip the leg on all ranks together
+    ok = torch.tensor([1.0 if setup_ok else 0.0], dtype=torch.float64, device=_device_of(use_cuda))
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) == 0.0:
+        return result if result is not None else dict(error="another rank could not build its replica of the graph")
+    timed = None
+    try:
         t0 = time.perf_counter()
         split.propagate(adj, feats, gather=False)
         L.check(L.lib().pgh_sync())
         dt = time.perf_counter() - t0
         info = split.last_batches[0]
-        t = torch.tensor([dt, float(sum(c["spmv"] for c in info))], dtype=torch.float64, device=_device_of(use_cuda))
-        worst = t.clone()
-        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        timed = [dt, float(sum(c["spmv"] for c in info))]
+    except Exception as exc:
+        result = dict(error=str(exc)[:300])
+    t = torch.tensor(timed if timed is not None else [-1.0, 0.0], dtype=torch.float64, device=_device_of(use_cuda))
+    worst, least = t.clone(), t.clone()
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    dist.all_reduce(least, op=dist.ReduceOp.MIN)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if float(least[0].item()) < 0:
+        return result if result is not None else dict(error="another rank failed inside the timed batch")
+    try:
         steps = max(c["spmv"] for c in info)
         result = dict(edge_vector_products_per_s_G=round(nnz * float(t[1].item()) / float(worst[0].item()) / 1e9, 1),
                       seed_sets=width, seed_sets_per_rank=per_rank, ranks=world, slowest_rank_ms=round(float(worst[0].item()) * 1e3, 2),
@@ -691,14 +733,165 @@ def _replica_batch_leg(dist, rank, world, pg, ranker, scale, ef, rmat, alpha, to
         del feats, adj
     except Exception as exc:
         result = dict(error=str(exc)[:300])
-    dist.barrier()
     return result
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The N-rank run is SUPERVISED: the process the launcher starts for a rank never touches the GPU; it runs the rank's work as a child
+# process, and when any rank's child fails -- an exception, a crash inside RCCL, a watchdog exit (code 3), a stalled collective past the
+# rung's deadline -- every supervisor ends its child (SIGKILL of the child's process group: the kernel driver then tears the queues of a
+# spinning collective down) and all of them start a FRESH child tree one rung further down a ladder of more conservative settings.
+# Nothing is ever re-executed from a process that has initialised the GPU.  The rung that produced the line is in config.fallback_rung.
+# Supervisors of one node agree through files in a scratch directory (the ranks of this bench share one node by contract).
+# ----------------------------------------------------------------------------------------------------------------
+LADDER = (
+    ("default", {}),
+    ("one communicator, one stream", dict(PGH_DIST_SINGLE_COMM="1", PGH_DIST_SINGLE_STREAM="1")),
+    ("one communicator, one stream, dense all-gather, Python-driven loop",
+     dict(PGH_DIST_SINGLE_COMM="1", PGH_DIST_SINGLE_STREAM="1", PGH_DIST_EXCHANGE="allgather", PGH_DIST_NEED_LISTS="0", PGH_DIST_NATIVE="0")),
+)
+
+
+def _sync_dir():
+    """A directory every supervisor of THIS launch derives alike: the launcher (their common parent) and its start time."""
+    import tempfile
+    if os.environ.get("PGH_BENCH_SYNC_DIR"):
+        path = os.environ["PGH_BENCH_SYNC_DIR"]
+    else:
+        ppid = os.getppid()
+        try:
+            with open(f"/proc/{ppid}/stat") as f:
+                started = f.read().rsplit(")", 1)[1].split()[19]          # field 22: start time of the launcher in clock ticks
+        except Exception:
+            started = "0"
+        path = os.path.join(tempfile.gettempdir(), f"pgh_bench_{os.environ.get('MASTER_PORT', '0')}_{ppid}_{started}")
+    os.makedirs(path, exist_ok=True)
+    return path
+
+
+def _write_atomic(path, text):
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def _read_or_none(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def supervise_rank(args):
+    """One rank's supervisor (see the block comment above).  Returns the exit code of this process."""
+    import signal
+    import socket
+    rank, world = int(os.environ["RANK"]), int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    entry = os.path.abspath(getattr(sys.modules["__main__"], "__file__", __file__))
+    sync = _sync_dir()
+    rung_s = float(os.environ.get("PGH_BENCH_RUNG_S", "540"))                # deadline of one rung's child tree
+    first = int(os.environ.get("PGH_BENCH_FIRST_RUNG", "0"))
+    partials = []
+
+    def note(text):
+        sys.stderr.write(f"[bench supervisor] rank {rank}: {text}\n")
+        sys.stderr.flush()
+
+    for rung in range(first, len(LADDER)):
+        label, rung_env = LADDER[rung]
+        port_file = os.path.join(sync, f"rung{rung}.port")
+        if rank == 0:
+            with socket.socket() as sock:                                     # the child tree's own rendezvous (rank 0's child hosts the store)
+                sock.bind(("127.0.0.1", 0))
+                _write_atomic(port_file, str(sock.getsockname()[1]))
+        deadline = time.time() + 120
+        while _read_or_none(port_file) is None and time.time() < deadline:
+            time.sleep(0.05)
+        port = _read_or_none(port_file)
+        if port is None:
+            note(f"rung {rung}: rank 0's supervisor never published a port")
+            return 4
+        env = dict(os.environ, PGH_BENCH_WORKER="1", PGH_BENCH_RUNG=str(rung), PGH_BENCH_RUNG_LABEL=label, MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port.strip(), PGH_BENCH_PARTIAL=os.path.join(sync, f"rung{rung}.partial.json"),
+                   PGH_BENCH_WATCHDOG_S=str(max(rung_s - 20, 30)))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)                         # (the launcher's store belongs to the supervisors' processes)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(rung_env)
+        proc = subprocess.Popen([sys.executable, entry] + sys.argv[1:], stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True,
+                                start_new_session=True)
+        lines = []
+        import threading
+
+        def pump():
+            for out in proc.stdout:
+                if out.lstrip().startswith("{"):
+                    lines.append(out.strip())
+                else:
+                    sys.stderr.write(out)
+        reader = threading.Thread(target=pump, daemon=True)
+        reader.start()
+        t_end = time.time() + rung_s
+        killed = None
+        while proc.poll() is None:
+            time.sleep(0.2)
+            # a peer's child has failed: this rung is lost on every rank -- do not wait for a collective that will never complete
+            failed_peer = next((r for r in range(world) if r != rank and (_read_or_none(os.path.join(sync, f"rung{rung}.rank{r}.rc")) or "0").strip() != "0"), None)
+            if failed_peer is not None:
+                killed = f"rank {failed_peer}'s child failed"
+            elif time.time() > t_end:
+                killed = f"no result within {rung_s:.0f} s"
+            if killed is not None:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+        reader.join(timeout=10)
+        rc = proc.returncode if killed is None else (3 if "within" in killed else 5)
+        if rc == 0 and rank == 0 and not lines:
+            rc = 6                                                              # rank 0's child ended without a line
+        _write_atomic(os.path.join(sync, f"rung{rung}.rank{rank}.rc"), str(rc))
+        if rc != 0:
+            note(f"rung {rung} ({label}): child ended with code {rc}" + (f" ({killed})" if killed else ""))
+        # every supervisor learns every child's outcome (a peer still waits for its child at most until the rung's deadline)
+        t_wait = time.time() + rung_s + 60
+        codes = None
+        while time.time() < t_wait:
+            got = [_read_or_none(os.path.join(sync, f"rung{rung}.rank{r}.rc")) for r in range(world)]
+            if all(v is not None for v in got):
+                codes = [int(v.strip() or "1") for v in got]
+                break
+            time.sleep(0.1)
+        if codes is None:
+            note(f"rung {rung}: a peer's supervisor never reported")
+            return 4
+        if all(c == 0 for c in codes):
+            if rank == 0:
+                print(lines[-1], flush=True)
+            return 0
+        partial = _read_or_none(os.path.join(sync, f"rung{rung}.partial.json"))
+        if partial:
+            partials.append(partial.strip())
+        if rank == 0:
+            note(f"rung {rung} ({label}) failed on ranks {[r for r, c in enumerate(codes) if c != 0]} (codes {codes})"
+                 + ("; starting a fresh child tree one rung down" if rung + 1 < len(LADDER) else "; no rung left"))
+    # no rung produced a complete line: the headline of the first rung whose TIMED REGION completed on every rank (its later legs --
+    # parity, the same graph on one GPU, the replica split -- did not) is still a measurement; the line says what is missing
+    if rank == 0 and partials:
+        out = json.loads(partials[0])
+        out["config"]["incomplete"] = "the run failed after its timed region: parity / same-graph / replica legs are missing"
+        print(json.dumps(out), flush=True)
+        return 0
+    return 0 if partials else 3
 
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process tree (torch.distributed.run, one
     rank per GPU) and relay rank 0's JSON line.  This parent has not touched the GPU (no HIP call, no torch.cuda query) and
-    never replaces itself with another program."""
+    never replaces itself with another program.  The ranks the launcher starts are supervisors (supervise_rank): the fallback
+    ladder lives there, so the driver's own `torch.distributed.run ... bench.py` launch has it too."""
     import socket
     entry = os.path.abspath(getattr(sys.modules["__main__"], "__file__", __file__))     # tests enter through a wrapper
     env = dict(os.environ)
@@ -719,7 +912,7 @@ def spawn_ranks(args):
             else:
                 sys.stderr.write(out)
         rc = proc.wait()
-        if line is not None or rc == 3:         # a result, or a watchdog exit (retrying a stalled collective helps nobody)
+        if line is not None or rc == 3:         # a result, or every rung of the ranks' own ladder failed
             break
     if line is not None:
         print(line, flush=True)
@@ -743,6 +936,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "RANK" not in os.environ:       # no launcher around us: become the launcher's parent
         sys.exit(spawn_ranks(args))
+    if (args.gpus > 1 or world > 1) and os.environ.get("PGH_BENCH_WORKER") != "1" and os.environ.get("PGH_BENCH_LADDER", "1") != "0":
+        sys.exit(supervise_rank(args))                   # a launcher's rank: supervise the work as a child (fallback ladder)
     if args.force_partitioned and args.gpus == 1 and "RANK" not in os.environ:      # plain `python bench.py --force-partitioned`
         for key, val in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29655")):
             os.environ.setdefault(key, val)

@@ -160,6 +160,8 @@ int comm_all_reduce(pgh_comm_s* c, void* buf, size_t count, ncclDataType_t dt, n
     return 0;
 }
 
+inline bool p2p_alone() { return getenv("PGH_DIST_P2P_ALONE") != nullptr && atoi(getenv("PGH_DIST_P2P_ALONE")) != 0; }
+
 // every rank's stretch for every other rank, point to point (4-byte elements; the stretch a rank keeps for itself is a device copy)
 int comm_all_to_all_v(pgh_comm_s* c, const void* send, const int64_t* scounts, const int64_t* soffs, void* recv, const int64_t* rcounts,
                       const int64_t* roffs, hipStream_t st) {
@@ -170,13 +172,17 @@ int comm_all_to_all_v(pgh_comm_s* c, const void* send, const int64_t* scounts, c
     }
     const char* sb = static_cast<const char*>(send);
     char* rb = static_cast<char*>(recv);
-    if (scounts[c->rank] > 0)
+    // PGH_DIST_P2P_ALONE=1 (tests; a box with one GPU): the stretch a rank keeps for itself travels through the grouped ncclSend / ncclRecv
+    // pair like every other one -- RCCL pairs a send to the own rank with the receive of the same group -- so that one GPU executes the
+    // point-to-point path the N-rank exchange consists of
+    const bool self_p2p = p2p_alone() && c->ext_gather == nullptr;
+    if (scounts[c->rank] > 0 && !self_p2p)
         PGH_HIP(hipMemcpyAsync(rb + 4 * roffs[c->rank], sb + 4 * soffs[c->rank], 4 * (size_t)scounts[c->rank], hipMemcpyDeviceToDevice, st));
-    if (c->world == 1) return 0;
+    if (c->world == 1 && !self_p2p) return 0;
     PGH_CHECK(c->ext_gather == nullptr, "pgh_dist: a host-collective communicator without an all-to-all callback cannot exchange need lists");
     PGH_RCCL(g_rccl.GroupStart());
     for (int r = 0; r < c->world; ++r) {
-        if (r == c->rank) continue;
+        if (r == c->rank && !self_p2p) continue;
         if (scounts[r] > 0) PGH_RCCL(g_rccl.Send(sb + 4 * soffs[r], (size_t)scounts[r], ncclFloat32, r, c->x, st));
         if (rcounts[r] > 0) PGH_RCCL(g_rccl.Recv(rb + 4 * roffs[r], (size_t)rcounts[r], ncclFloat32, r, c->x, st));
     }
@@ -350,7 +356,8 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     const char* xenv = getenv("PGH_DIST_EXCHANGE");
     // a rank ALONE references every live slot of its own blocks (the relabelling sorts by reference count: nothing unreferenced lies below
     // `live`), so its compact numbering is the dense one: the slice is written in place as ever and nothing is packed or copied
-    bool identity = compact && c->world == 1 && split;
+    // (PGH_DIST_P2P_ALONE=1: the lone rank goes through compact numbering -> pack launch -> point-to-point transfers to itself all the same)
+    bool identity = compact && c->world == 1 && split && !(p2p_alone() && c->ext_gather == nullptr);
     for (int b = 0; b < nb && identity; ++b) identity = need8[b] == (live8[b] > hot_slots ? live8[b] - hot_slots : 0);
     const bool lists = compact && !identity && h_agree[4] == 0 && split && can_p2p && !(xenv != nullptr && std::string(xenv) == "allgather");
     c->nb = nb;

@@ -170,7 +170,9 @@ class _Buffers:
         hot = int(agree[0].item())
         self.hot = (min(hot, self.live) + 63) // 64 * 64 if 0 < hot < self.live else 0
         self.lists = bool(int(agree[1].item())) and self.hot > 0 and os.environ.get("PGH_DIST_EXCHANGE", "lists") != "allgather"
-        assert not self.compact or self.hot == hs.value, "a compact slice has a hot-only stream: the hot prefix is the engine's"
+        # (a compact slice beside a peer whose slice is NOT hot-only -- no cold image below the entry gate, a heavy row kept in the stream,
+        # PGH_DIST_NEED_LISTS=0 on that rank -- sees hot == 0 here: one dense region, the split bases are the dense block starts, the compact
+        # copy lies behind them and _compact_own_copy reads the cold slots at bases[b] + the ENGINE's hot prefix)
         self.need_counts = counts[:self.nb].copy()
         self.need_prefix = np.concatenate(([0], np.cumsum(self.need_counts)))
         need_total = int(self.need_prefix[-1])

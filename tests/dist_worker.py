@@ -27,6 +27,10 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import host_double
         host_double.install()
+    # ONE rank's slice dense (its cold image numbers every live slot) beside compact peers -- the switch is read when the
+    # slice is built, so it is set in this rank's process only
+    if os.environ.get("PGH_TEST_DENSE_RANK") == os.environ.get("RANK", "0"):
+        os.environ["PGH_DIST_NEED_LISTS"] = "0"
     pg.load_backend("hip")
     dist.init_process_group(backend=os.environ.get("PGH_DIST_BACKEND", "nccl" if on_gpu else "gloo"))
     rank, world = dist.get_rank(), dist.get_world_size()

@@ -57,6 +57,21 @@ def main():
         out[name + "_iters_part"] = int(ranker.iteration)
         out[name + "_sum_part"] = float(got.sum())
         out[name + "_psum"] = float(p_new.sum())
+    # the grouped ncclSend / ncclRecv exchange of the N-rank run, executed by this lone rank TO ITSELF (PGH_DIST_P2P_ALONE=1: compact
+    # numbering of the slice's cold sources -> pack launch -> point-to-point transfers -> finish; without the switch a rank alone writes
+    # its slice in place and exchanges nothing).  The compact numbering of a rank that references every live slot is the identity, so the
+    # run must reproduce the in-place run bit for bit.
+    os.environ["PGH_DIST_P2P_ALONE"] = "1"
+    ranker = DistributedPageRank(**kw)
+    again = np.asarray(ranker.rank(graph, DeviceVector.from_host(part["a"][2])), dtype=np.float64)
+    del os.environ["PGH_DIST_P2P_ALONE"]
+    out["p2p_exchange"] = str(ranker.exchange.get("exchange"))
+    out["p2p_driver"] = str(ranker.exchange.get("driver"))
+    out["p2p_iters"] = int(ranker.iteration)
+    out["p2p_bits_equal"] = int(np.array_equal(again, part["a"][0]))
+    out["p2p_max_abs_diff"] = float(np.max(np.abs(again - part["a"][0])))
+    del again
+    DistributedPageRank(**kw).rank(graph, DeviceVector.from_host(part["a"][2]))       # back to the in-place layout for what follows
     if mode == "big":
         # linearity in the personalization: runs of a FIXED number of iterations (a stopping rule cuts the three runs at
         # different points of their tails) WITHOUT the L1 quotient (renormalising an iterate that lost mass to dangling nodes is
@@ -74,7 +89,7 @@ def main():
         p_old = np.zeros(int(live.sum()))
         got_old[perm[live]] = part["a"][0][live]
         p_old[perm[live]] = part["a"][2][live]
-        np.savez(os.path.join(out_dir, "slice.npz"), ranks=got_old, p=p_old, iters=part["a"][1], nnz=nnz, format=fmt)
+        np.savez(os.path.join(out_dir, "slice.npz"), ranks=got_old, p=p_old, iters=part["a"][1], nnz=nnz, format=fmt, **out)
     else:
         # the partitioned path gives its memory back before the single-GPU engine builds the same graph
         del ranker

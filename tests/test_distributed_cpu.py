@@ -86,6 +86,76 @@ def test_bench_launcherless_spawns_its_ranks(oracle_build_dir):
     assert replicas["ranks"] == 2 and replicas["seed_sets"] == 2 * replicas["seed_sets_per_rank"] and replicas["edge_vector_products_per_s_G"] > 0
 
 
+def _bench_ranks(world, extra_env, scale="11", launcher=True, timeout=900):
+    import json
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    tail = [os.path.join(ROOT, "tests", "bench_dist_worker.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scale", scale, "--ef", "8"]
+    cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port)] if launcher else [sys.executable]) + tail
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", **extra_env)
+    if not launcher:
+        for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(key, None)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    return res, [json.loads(ln) for ln in lines]
+
+
+def test_bench_ladder_restarts_a_failed_rung_as_a_fresh_child_tree(oracle_build_dir):
+    """VERDICT r5 item 1b.  The driver's N > 1 launch (torch.distributed.run -> bench.py): the launcher's ranks are supervisors that never
+    touch the GPU and run the work as a child.  Rank 1's child of rung 0 ends with the watchdog's code 3 at its start while rank 0's child
+    waits in its first collective: rank 0's supervisor ends that child (no waiting for a collective that cannot complete), both start a
+    FRESH child tree one rung down (one communicator, one stream), and the line says which rung produced it."""
+    res, lines = _bench_ranks(2, dict(PGH_BENCH_TEST_FAIL="0:1:3:start"))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert len(lines) == 1, res.stdout
+    rung = lines[0]["config"]["fallback_rung"]
+    assert rung["rung"] == 1 and rung["env"] == dict(PGH_DIST_SINGLE_COMM="1", PGH_DIST_SINGLE_STREAM="1"), rung
+    assert lines[0]["n_gpus"] == 2 and lines[0]["parity"]["rel_linf"] <= 1e-6
+    # (rank 0's child is ended by its supervisor -- code 5 -- or, over gloo, sees the connection of the dead peer reset first)
+    assert "rung 0 (default) failed on ranks" in res.stderr and "starting a fresh child tree one rung down" in res.stderr, res.stderr[-3000:]
+    assert "rung 0 (default): child ended with code 3" in res.stderr, res.stderr[-3000:]
+
+
+def test_bench_ladder_survives_a_hung_rank_and_reaches_the_last_rung(oracle_build_dir):
+    """A rank that stops answering (a stalled collective) is ended at the rung's deadline together with its peers; two failed rungs lead
+    to the last one: dense all-gather, the Python-driven loop, one communicator and one stream -- through the launcher-less entry."""
+    res, lines = _bench_ranks(2, dict(PGH_BENCH_TEST_FAIL="0:0:hang:start,1:1:9:after_timing", PGH_BENCH_RUNG_S="25"), launcher=False)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert len(lines) == 1, res.stdout
+    rung = lines[0]["config"]["fallback_rung"]
+    assert rung["rung"] == 2 and rung["env"]["PGH_DIST_EXCHANGE"] == "allgather" and rung["env"]["PGH_DIST_NEED_LISTS"] == "0", rung
+    assert "no result within 25 s" in res.stderr and "rung 1 (one communicator, one stream) failed on ranks" in res.stderr, res.stderr[-3000:]
+    assert "incomplete" not in lines[0]["config"]
+
+
+def test_bench_ladder_keeps_the_measured_headline_when_every_rung_fails_later(oracle_build_dir):
+    """Every rung's child dies AFTER its timed region (in the legs that follow: roofline, parity, same graph, replicas): the headline
+    the first rung measured is printed, marked incomplete, with exit code 0 -- a measurement is never thrown away."""
+    res, lines = _bench_ranks(2, dict(PGH_BENCH_TEST_FAIL="0:0:9:after_timing,1:0:9:after_timing,2:0:9:after_timing"))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert len(lines) == 1, res.stdout
+    out = lines[0]
+    assert out["config"]["fallback_rung"]["rung"] == 0 and "incomplete" in out["config"]
+    assert out["n_gpus"] == 2 and out["config"]["spmv_per_step"] > 0 and out["ms_per_step"] > 0 and out["roofline"] is None
+
+
+def test_bench_eight_ranks_gloo(oracle_build_dir):
+    """The world == 8 branch of the bench (BASELINE.json configs[4]'s rank count) end to end on the CPU: eight supervised ranks,
+    one block per rank, parity of the 8-way partition against the oracle, the same-graph leg, the replica split of 8 x 4 seed sets."""
+    res, lines = _bench_ranks(8, {}, scale="12", timeout=1500)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert len(lines) == 1, res.stdout
+    out = lines[0]
+    assert out["n_gpus"] == 8 and out["config"]["fallback_rung"]["rung"] == 0
+    assert out["parity"]["rel_linf"] <= 1e-6 and out["parity"]["gpu_iterations"] == out["parity"]["cpu_iterations"]
+    assert out["same_graph_1gpu"]["rel_linf_partitioned_vs_1gpu"] <= 1e-6
+    assert out["secondary"]["batch_of_64_seeds_replicas"]["ranks"] == 8
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_partitioned_upload_of_a_scipy_graph(tmp_path, oracle_build_dir, world):
     """pgh_graph_from_csr_part / distributed.partition_scipy: a caller's (weighted, non-power-of-two) scipy graph is relabelled

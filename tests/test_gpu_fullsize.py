@@ -345,6 +345,16 @@ def test_cfg5_graph_one_rank(gpu_engine, tmp_path):
         assert abs(float(out[name + "_sum_part"]) - psum) <= 1e-5 * psum and abs(float(out[name + "_sum_single"]) - psum) <= 1e-5 * psum
         assert float(out[name + "_pad_mass"]) == 0.0
     assert float(out["linearity_rel_linf"]) <= 2e-6           # runs of 13 iterations each: only f32 rounding separates them
+    _check_p2p_alone(out)
+
+
+def _check_p2p_alone(out):
+    """The need-list exchange (compact cold numbering -> pgh_dist_pack -> grouped ncclSend / ncclRecv) run by one rank to itself
+    (PGH_DIST_P2P_ALONE=1, csrc/pgh_dist.hip comm_all_to_all_v): the engine drove RCCL point to point and reproduced the in-place run."""
+    assert str(out["p2p_driver"]) == "engine (RCCL)" and str(out["p2p_exchange"]).startswith("need lists (point to point)"), \
+        (str(out["p2p_driver"]), str(out["p2p_exchange"]))
+    assert int(out["p2p_iters"]) == int(out["a_iters_part"])
+    assert int(out["p2p_bits_equal"]) == 1, float(out["p2p_max_abs_diff"])
 
 
 def test_cfg5_eight_way_slice_layout_vs_oracle(gpu_engine, tmp_path):
@@ -362,3 +372,4 @@ def test_cfg5_eight_way_slice_layout_vs_oracle(gpu_engine, tmp_path):
     want, want_iters = orc.pagerank(M, out["p"], alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000, eps=float(np.finfo(np.float32).eps))
     assert int(out["iters"]) == want_iters
     assert _rel(out["ranks"], want) <= 1e-6
+    _check_p2p_alone(out)

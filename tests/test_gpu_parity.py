@@ -147,12 +147,16 @@ def test_full_size_properties_rmat20(gpu_engine):
                                                       (2, "gloo", 18, "engine_loop"), (4, "gloo", 14, "engine_loop"),
                                                       (2, "gloo", 18, "engine_loop_single_queue"), (1, "nccl", 18, "three_queues"),
                                                       (2, "gloo", 18, "engine_loop_no_a2a"), (2, "gloo", 18, "python_allgather"),
-                                                      (2, "gloo", 18, "dense_images"), (4, "gloo", 18, "engine_loop")],
+                                                      (2, "gloo", 18, "dense_images"), (4, "gloo", 18, "engine_loop"),
+                                                      (1, "nccl", 18, "p2p_alone"), (1, "nccl", 18, "p2p_alone_three_queues"),
+                                                      (2, "gloo", 18, "mixed_python"), (2, "gloo", 18, "engine_loop_mixed")],
                          ids=["rccl_x1", "gloo_x2", "gloo_x4", "gloo_x2_cold_image", "gloo_x2_cold_image_single_queue", "rccl_x1_single_queue",
                               "rccl_x1_cold_image_split_regions", "rccl_x1_cold_image_python_driver",
                               "gloo_x2_cold_image_engine_loop", "gloo_x4_engine_loop", "gloo_x2_cold_image_engine_loop_single_queue",
                               "rccl_x1_cold_image_three_queues", "gloo_x2_cold_image_engine_loop_without_all_to_all",
-                              "gloo_x2_cold_image_python_driver_all_gather", "gloo_x2_cold_image_dense_layout", "gloo_x4_cold_image_engine_loop"])
+                              "gloo_x2_cold_image_python_driver_all_gather", "gloo_x2_cold_image_dense_layout", "gloo_x4_cold_image_engine_loop",
+                              "rccl_x1_cold_image_send_recv_to_itself", "rccl_x1_cold_image_send_recv_to_itself_three_queues",
+                              "gloo_x2_one_dense_one_compact_slice_python_driver", "gloo_x2_one_dense_one_compact_slice_engine_loop"])
 def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, scale, mode):
     """The N > 1 code path on the real engine: relabelled slice generation, the device-driven pgh_dist_* loop, in-place
     collectives on device scalars, the trimmed all-gather -- against the oracle.  World size 1 runs over RCCL; world sizes
@@ -192,6 +196,12 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
         env.update(PGH_DIST_SINGLE_STREAM="1")
     if mode == "three_queues":           # one rank runs on one queue by default (nobody to overlap an exchange with): force the three,
         env.update(PGH_DIST_SINGLE_STREAM="0", PGH_DIST_FINISH_SPLIT="2")      # and the finish kernel in two launches (N > 1 does by itself)
+    if mode.endswith("mixed") or mode.startswith("mixed"):      # rank 1's slice dense, rank 0's compact -- the all-gather stays,
+        env.update(PGH_TEST_DENSE_RANK="1")                     # the compact slice copies its slots out of the gathered vector
+    if mode.startswith("p2p_alone"):     # the N-rank exchange on one GPU: compact numbering -> pack launch -> grouped ncclSend / ncclRecv of the
+        env.update(PGH_DIST_P2P_ALONE="1")           # rank's stretches TO ITSELF (without the switch a lone rank writes its slice in place)
+    if mode == "p2p_alone_three_queues":
+        env.update(PGH_DIST_SINGLE_STREAM="0", PGH_DIST_FINISH_SPLIT="2")
     if scale > 14:                       # four column blocks over two ranks: two all-gathers per exchange, like bench.py --gpus 2
         env.update(PGH_PB="1", PGH_PB_FORCE="1", PGH_DEBUG="1", PGH_BLOCKS="4", PGH_PB_HEAVY="64", PGH_PB_HUBMAX="500")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -203,16 +213,23 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
               else "python (torch.distributed)", "python_driver": "python (torch.distributed)", "engine_loop": "engine (host collectives)",
               "engine_loop_single_queue": "engine (host collectives)", "three_queues": "engine (RCCL)",
               "engine_loop_no_a2a": "engine (host collectives)", "python_allgather": "python (torch.distributed)",
-              "dense_images": "python (torch.distributed)"}[mode]
+              "dense_images": "python (torch.distributed)", "p2p_alone": "engine (RCCL)", "p2p_alone_three_queues": "engine (RCCL)",
+              "mixed_python": "python (torch.distributed)", "engine_loop_mixed": "engine (host collectives)"}[mode]
     assert all(str(part["driver"]) == driver for part in parts), [str(part["driver"]) for part in parts]
     # how the cold parts travelled (need lists wherever every slice has a cold image), and the received bytes a run reports
     # against the host-side count of the slots this slice references in its peers' blocks
     if scale > 14:
         kind = {"engine_loop_no_a2a": "all-gather + local compaction", "python_allgather": "all-gather", "dense_images": "all-gather"}.get(mode, "need lists")
-        if driver == "engine (RCCL)":        # one rank alone references every live slot of its own blocks: its compact numbering is the dense one,
+        if driver == "engine (RCCL)" and not mode.startswith("p2p_alone"):        # one rank alone references every live slot of its own blocks: its compact numbering is the dense one,
             kind = "all-gather"              # the engine writes the slice in place and packs nothing
-        assert all(str(part["exchange_kind"]).startswith(kind) for part in parts), [str(part["exchange_kind"]) for part in parts]
-        assert all((int(part["need_total"]) > 0) == (mode != "dense_images") for part in parts)
+        if "mixed" in mode:                  # rank 0 compact, rank 1 dense: the dense all-gather on both, rank 0 compacts its own copy
+            assert [int(part["need_total"]) > 0 for part in parts] == [True, False]
+            kinds = [str(part["exchange_kind"]) for part in parts]
+            assert kinds == (["all-gather + local compaction", "all-gather"] if mode == "engine_loop_mixed" else ["all-gather", "all-gather"]), kinds
+            kind = "mixed"
+        else:
+            assert all(str(part["exchange_kind"]).startswith(kind) for part in parts), [str(part["exchange_kind"]) for part in parts]
+            assert all((int(part["need_total"]) > 0) == (mode != "dense_images") for part in parts)
         if kind == "need lists":
             for part in parts:
                 assert int(part["exchange_bytes"]) == int(part["expected_list_bytes"]), (int(part["exchange_bytes"]), int(part["expected_list_bytes"]))
@@ -232,7 +249,7 @@ def test_row_partitioned_path_on_one_gpu(gpu_engine, tmp_path, world, backend, s
             assert int(part["l1_fused"]) == 1 and int(part["mabs_fused"]) == 1 and int(part["noquot_fused"]) == 0
             assert int(part["signed_paused"]) == 1
             # more than one rank on three queues (and the forced one-rank case): the finish kernel in two launches, exchanged rows first
-            two = mode.startswith("engine_loop") or mode == "three_queues"                 # forced by the test (PGH_DIST_FINISH_SPLIT=2)
+            two = mode.startswith("engine_loop") or mode.endswith("three_queues")          # forced by the test (PGH_DIST_FINISH_SPLIT=2)
             assert int(part["l1_two_launches"]) == int(two) and int(part["noquot_two_launches"]) == int(two), (mode, world)
             assert int(part["closed_form_two_launches"]) == int(two)
 
@@ -353,6 +370,56 @@ def test_bench_two_ranks_on_one_gpu(gpu_engine):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["unit"] == "GTEPS"
     assert out["config"]["exchange_bytes_per_iteration_per_gpu"] > 0 and len(out["config"]["iterations_per_step"]) == 2
+
+
+def test_bench_eight_ranks_on_one_gpu(gpu_engine):
+    """the world == 8 branch of bench.py (BASELINE.json configs[4]'s rank count) on the real engine -- eight supervised
+    ranks sharing this box's GPU over gloo, one column block per rank, need-list exchange between all pairs, parity of the 8-way
+    partition against the oracle, the same graph on one GPU, the replica split of 8 x 64 seed sets -- through the driver's launch line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--scale", "17"]
+    env = dict(os.environ, PYTHONPATH=root, PGH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["fallback_rung"]["rung"] == 0
+    assert out["parity"]["rel_linf"] <= 1e-6 and out["parity"]["gpu_iterations"] == out["parity"]["cpu_iterations"]
+    same = out["same_graph_1gpu"]
+    assert same["rel_linf_partitioned_vs_1gpu"] <= 1e-6 and same["iterations_1gpu"] == same["iterations_partitioned"]
+    replicas = out["secondary"]["batch_of_64_seeds_replicas"]
+    assert "error" not in replicas and replicas["ranks"] == 8 and replicas["seed_sets"] == 512, replicas
+
+
+def test_bench_ladder_on_the_gpu(gpu_engine):
+    """VERDICT r5 item 1b on the real engine: rank 1's child of rung 0 stops answering AFTER it has initialised the GPU and joined the
+    first collectives; at the rung's deadline the supervisors (which never touch the GPU) end both children with SIGKILL and start a
+    fresh child tree one rung down on the same GPU; the line names the rung."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29643", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "16",
+           "--no-secondary"]
+    env = dict(os.environ, PYTHONPATH=root, PGH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PGH_BENCH_TEST_FAIL="0:1:hang:after_timing", PGH_BENCH_RUNG_S="90")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    rung = out["config"]["fallback_rung"]
+    assert rung["rung"] == 1 and rung["env"] == dict(PGH_DIST_SINGLE_COMM="1", PGH_DIST_SINGLE_STREAM="1"), rung
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["parity"]["rel_linf"] <= 1e-6 and "incomplete" not in out["config"]
+    assert "no result within 90 s" in res.stderr, res.stderr[-3000:]
 
 
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")], ids=["rccl_x1", "gloo_x2"])
