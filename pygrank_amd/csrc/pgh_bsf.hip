@@ -1478,9 +1478,10 @@ __global__ void k_make_gather(const float* __restrict__ y, const float* __restri
         if (slot >= 0) xg[slot] = y[i] * scale[i];
     }
 }
-int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int) {
+int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int, float* xg_out) {
     BsfFormat& f = g->bsf;
-    k_make_gather<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(y_int, scale_int, f.n_src_pad, f.xg, f.blk_size, f.xg_live);
+    k_make_gather<<<blocks_for(f.n_src_pad), kBlock, 0, rt().stream>>>(y_int, scale_int, f.n_src_pad, xg_out != nullptr ? xg_out : f.xg, f.blk_size,
+                                                                       f.xg_live);
     PGH_HIP(hipGetLastError());
     return 0;
 }

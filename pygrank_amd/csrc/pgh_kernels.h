@@ -772,7 +772,7 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
                    bool* state_inited = nullptr, const float* pred_deg = nullptr);
 bool bsf_can_norm_on_device(const pgh_graph_s* g);
 int bsf_out_to_internal(pgh_graph_s* g, const float* src, float* dst, float hole);
-int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int);
+int bsf_make_gather(pgh_graph_s* g, const float* y_int, const float* scale_int, float* xg_out = nullptr);   // xg_out: a caller's buffer in the layout of BsfFormat::xg
 int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor);
 int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float* src_old, const float* dst_old, bool relabel,
               int force_blocks = 0, BsfFormat* target = nullptr);

@@ -965,6 +965,87 @@ extern "C" int pgh_poly_step(pgh_graph_t g, pgh_vec_t term, pgh_vec_t term_out, 
     return 0;
 }
 
+// =================================================================================================
+// C-ABI: resident iterates -- the backend-primitive route without a way in and out of the id space per conv
+// =================================================================================================
+// The reference's filters reach the engine one backend primitive at a time (pygrank/core/backend/__init__.py:59-80; _formula
+// adhoc.py:34-36, _step abstract_filters.py:126-136, the residual convergence.py:96-101).  pgh_spmv gives every conv the whole round trip:
+// permute the operand into the relabelled id space, three launches, permute the row sums out, a synchronisation.  A RESIDENT iterate
+// stays in the id space between primitives: {x_int [n_int], xg [n_gather]} -- the iterate itself and its gather form (x * source scale in
+// the engine's trimmed layout; n_gather = 0 on layouts whose steps gather from x_int itself).  Elementwise arithmetic and reductions are
+// indifferent to the relabelling (padding slots hold zeros and stay zero under scaling, sums and differences), so the host side
+// (pygrank_amd/device.py LazyVector) keeps such vectors lazy and comes back to the caller's ids only when somebody looks.
+namespace {
+bool resident_usable(const pgh_graph_s* g) {
+    return g != nullptr && g->bsf.enabled && g->n_rows == g->n_cols && g->part_perm == nullptr && g->bsf.n_out == g->bsf.n_src_pad &&
+           !(getenv("PGH_RESIDENT") != nullptr && atoi(getenv("PGH_RESIDENT")) == 0);
+}
+}  // namespace
+
+extern "C" int pgh_graph_resident_len(pgh_graph_t g, int64_t* n_int, int64_t* n_gather) {
+    PGH_CHECK(g && n_int && n_gather, "pgh_graph_resident_len: null argument");
+    *n_int = *n_gather = 0;
+    if (!resident_usable(g)) return 0;       // row-major / rectangular / partitioned images: conv stays pgh_spmv
+    *n_int = g->bsf.n_out;
+    *n_gather = g->bsf.src_scale != nullptr ? g->bsf.n_src_pad + 1 : 0;
+    return 0;
+}
+
+extern "C" int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, pgh_vec_t x_int, pgh_vec_t xg) {
+    PGH_CHECK(resident_usable(g), "pgh_resident_in: this graph's image has no resident form (pgh_graph_resident_len)");
+    BsfFormat& f = g->bsf;
+    PGH_CHECK(x && x_int && x->n == g->n_cols && x_int->n == f.n_out, "pgh_resident_in: vector length mismatch");
+    PGH_CHECK((f.src_scale != nullptr) == (xg != nullptr) && (xg == nullptr || xg->n == f.n_src_pad + 1), "pgh_resident_in: gather form mismatch");
+    PGH_TRY(bsf_out_to_internal(g, x->data, x_int->data, 0.f));
+    if (xg != nullptr) PGH_TRY(bsf_make_gather(g, x_int->data, f.src_scale, xg->data));
+    return 0;
+}
+
+extern "C" int pgh_resident_out(pgh_graph_t g, pgh_vec_t y_int, double factor, pgh_vec_t y) {
+    PGH_CHECK(resident_usable(g), "pgh_resident_out: this graph's image has no resident form (pgh_graph_resident_len)");
+    PGH_CHECK(y && y_int && y->n == g->n_cols && y_int->n == g->bsf.n_out, "pgh_resident_out: vector length mismatch");
+    return bsf_to_original(g, y_int->data, y->data, factor);
+}
+
+extern "C" int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, pgh_vec_t xg, double a, pgh_vec_t v_int, double b,
+                                 pgh_vec_t y_int, pgh_vec_t yg, double* sum_y) {
+    PGH_CHECK(resident_usable(g), "pgh_resident_step: this graph's image has no resident form (pgh_graph_resident_len)");
+    BsfFormat& f = g->bsf;
+    PGH_CHECK(mode == 0 || mode == 1, "pgh_resident_step: mode 0 (y = a M^T x) or 1 (y = a M^T x + b v)");
+    PGH_CHECK(x_int && y_int && x_int->n == f.n_out && y_int->n == f.n_out && x_int->data != y_int->data, "pgh_resident_step: iterate length mismatch / aliasing");
+    PGH_CHECK(mode == 0 || (v_int && v_int->n == f.n_out), "pgh_resident_step: mode 1 needs the resident second operand");
+    const bool scaled = f.src_scale != nullptr;
+    PGH_CHECK(!scaled || (xg && yg && xg->n == f.n_src_pad + 1 && yg->n == f.n_src_pad + 1 && xg->data != yg->data),
+              "pgh_resident_step: this image gathers from the gather form (pgh_graph_resident_len)");
+    PGH_TRY(ensure_state());
+    Runtime& r = rt();
+    k_state_init<<<1, 1, 0, r.stream>>>(g_state, 1.0);
+    EpiParams ep{};
+    ep.a = a;
+    ep.b = b;
+    ep.v = mode == 1 ? v_int->data : nullptr;
+    ep.y = y_int->data;
+    if (scaled) {
+        ep.xg_out = yg->data;
+        ep.src_scale = f.src_scale;
+        ep.xg_blk = f.blk_size;
+        ep.xg_live = f.xg_live;
+    }
+    int count = 0;
+    const float* gather_src = scaled ? xg->data : x_int->data;
+    if (mode == 1) PGH_TRY((launch_step<EPI_AXPBY>(g, ep, gather_src, g_state, &count)));
+    else PGH_TRY((launch_step<EPI_PLAIN>(g, ep, gather_src, g_state, &count)));
+    if (sum_y != nullptr) {
+        ProfScope prof(PGH_K_FINAL);
+        k_step_close<<<1, WG, 0, r.stream>>>(g_state, r.d_partials, count, r.d_partials + kMaxPartials, count, 0, 0, PGH_ERR_L1, -1.0, g->n_cols,
+                                             r.d_scalars);
+        PGH_HIP(hipGetLastError());
+        PGH_TRY(fetch_scalars(1, 2));
+        *sum_y = r.h_scalars[1];
+    }
+    return 0;
+}
+
 // Row-partitioned PageRank step: this rank holds rows [row_begin, row_begin + n_local) of M^T in the
 // globally relabelled id space.  xg_full is the all-gathered gather vector (x * src_scale of every rank's slice);
 // the step writes y_local and this rank's slice of the next gather vector, so the all-gather moves xg directly.
