@@ -265,6 +265,37 @@ def single_gpu(args):
              adj, 8 * nnz + 20 * n, nnz)
         side("absorbing_walks_a085_l1_1e-6", pg.AbsorbingWalks(ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS), adj,
              8 * nnz + 24 * n, nnz)
+        # The backend-primitive route -- what north_star names ("plugs in as a pygrank.core.backends module so PageRank / HeatKernel /
+        # AbsorbingWalks ... are unchanged"): the filters reach the engine ONE PRIMITIVE AT A TIME (conv, *, +, sum, /, abs, -; pygrank/core/
+        # backend/__init__.py:59-80), the whole-loop entry points are switched off.  Lazy vectors (pygrank_amd/device.py) keep the iterate in
+        # the engine's id space: one resident step per formula, one residual launch, two scalars to the host per iteration.  The result is
+        # looked at (the way out of the id space) inside the timed region.
+        def primitives(label, make, per_step):
+            other = make()
+            other._fused_loop = lambda *a, **k: False
+            other._fused_rank = lambda *a, **k: None
+            np.asarray(other.rank(adj, personalizations[0]).np[0])
+            L.check(lib.pgh_sync())
+            t1 = time.perf_counter()
+            steps = 0
+            runs = 3
+            for step in range(runs):
+                out = other.rank(adj, personalizations[step % len(personalizations)])
+                float(out.np[0])                         # somebody looks at the ranks
+                steps += int(other.convergence.iteration) - 1
+            L.check(lib.pgh_sync())
+            dt = time.perf_counter() - t1
+            secondary[label] = dict(gteps=round(nnz * steps / dt / 1e9, 2), wall_step_us=round(dt / steps * 1e6, 1),
+                                    nominal_gbs=round(per_step / (dt / steps) / 1e9, 1), spmv_per_run=steps // runs,
+                                    iterations=int(other.convergence.iteration), route="one engine call per backend primitive (lazy vectors)")
+        try:
+            primitives("ppr_l1_1e-6_backend_primitives", lambda: pg.PageRank(alpha=ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS), alg_bytes)
+            primitives("heat_kernel_t5_31_iterations_backend_primitives", lambda: pg.HeatKernel(5, error_type="iters", max_iters=31), 8 * nnz + 20 * n)
+            primitives("absorbing_walks_a085_l1_1e-6_backend_primitives",
+                       lambda: pg.AbsorbingWalks(ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS), 8 * nnz + 24 * n)
+            secondary["ppr_l1_1e-6_backend_primitives"]["vs_fused_route"] = round(secondary["ppr_l1_1e-6_backend_primitives"]["gteps"] / gteps, 3)
+        except Exception as exc:                     # a side measurement never takes the headline down
+            secondary["ppr_l1_1e-6_backend_primitives"] = dict(error=str(exc)[:300])
         # configs[2]: 64 personalizations at once (NodeRanking.propagate -> pgh_ppr_run_batch); edge-vector products per second,
         # nominal bytes 8 nnz + 4 n + 12 n b per batch step
         try:

@@ -201,6 +201,28 @@ int pgh_poly_step(pgh_graph_t g, pgh_vec_t term, pgh_vec_t term_out, double a, d
  *   err = residual(kind, y * y_scale, x * x_scale) without materialising the scaled vectors. */
 int pgh_scaled_residual(int kind, pgh_vec_t y, double y_scale, pgh_vec_t x, double x_scale, double* err);
 
+/* ---------------------------------------------------------------- resident iterates ---------------- */
+/* The backend-primitive route (pygrank/core/backend/__init__.py:59-80: the reference's filters call conv, sum, abs, -, * ... one
+ * primitive at a time; PageRank._formula adhoc.py:34-36, RecursiveGraphFilter._step abstract_filters.py:126-136, the residual of
+ * ConvergenceManager convergence.py:96-101) without a way in and out of the engine's relabelled id space per conv.  A resident
+ * iterate is a pair of plain vectors in that id space: x_int [n_int] (the iterate; padding slots are zero) and its gather form
+ * xg [n_gather] (what a step gathers from: x_int times the source scale in the image's own layout; n_gather == 0: steps gather from
+ * x_int itself and every xg / yg argument below is NULL).  Elementwise arithmetic between resident vectors of one graph and their
+ * reductions are the ordinary pgh_axpby / pgh_ewise_* / pgh_reduce / pgh_scaled_residual calls on x_int.
+ * n_int == 0: this image has no resident form (row-major, rectangular and partitioned images) -- conv stays pgh_spmv. */
+int pgh_graph_resident_len(pgh_graph_t g, int64_t* n_int, int64_t* n_gather);
+/* caller ids -> the id space (one pass; + the gather form) */
+int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, pgh_vec_t x_int, pgh_vec_t xg);
+/* the gather form of a resident vector that elementwise arithmetic produced (n_gather > 0 only) */
+int pgh_resident_gather(pgh_graph_t g, pgh_vec_t x_int, pgh_vec_t xg);
+/* the id space -> caller ids: y = y_int[new id of .] * factor (to_array / np.asarray of a lazy vector) */
+int pgh_resident_out(pgh_graph_t g, pgh_vec_t y_int, double factor, pgh_vec_t y);
+/* mode 0: y = a * M^T x (conv, numpy.py:64-65);  mode 1: y = a * M^T x + b * v (PageRank._formula with the lazily applied L1 quotient
+ * folded into a).  Writes y_int and its gather form yg; pure (no output aliases an input).  sum_y (nullable) receives sum(y) and
+ * synchronises (backend.sum of the step's outcome, abstract_filters.py:133-134). */
+int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, pgh_vec_t xg, double a, pgh_vec_t v_int, double b,
+                      pgh_vec_t y_int, pgh_vec_t yg, double* sum_y);
+
 /* ---------------------------------------------------------------- whole loops on the device ------- */
 /* GraphFilter.rank's hot loop (abstract_filters.py:58-62) with ConvergenceManager semantics
  * (convergence.py:77-101) evaluated on the device: kernels of an iteration become no-ops once the

@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -633,6 +634,67 @@ int pgh_ppr_step(pgh_graph_t g, pgh_vec_t x, double xs, pgh_vec_t p, double alph
     CHECK(p && p->n == g->n_cols, "pgh_ppr_step: personalization length mismatch");
     const double s = ppr_step(g, x->data, xs, p->data, alpha, y->data);
     if (sum_y) *sum_y = s;
+    return 0;
+}
+// ---- resident iterates (include/pgh.h): the double's "id space" is deliberately NOT the caller's -- ids reversed, three zero padding
+// slots behind them, a gather form that holds twice the iterate -- so that host logic that mixes the two spaces, forgets the padding or
+// gathers from the wrong form fails on the CPU
+static const int64_t kResidentPad = 3;
+static bool resident_ok(const pgh_graph_s* g) {
+    const char* e = getenv("PGH_RESIDENT");
+    return g && g->n_rows == g->n_cols && g->gather_blk == 0 && g->n_cols > 0 && !(e != nullptr && atoi(e) == 0);
+}
+int pgh_graph_resident_len(pgh_graph_t g, int64_t* n_int, int64_t* n_gather) {
+    CHECK(g && n_int && n_gather, "pgh_graph_resident_len: null argument");
+    *n_int = resident_ok(g) ? g->n_cols + kResidentPad : 0;
+    *n_gather = resident_ok(g) ? g->n_cols + kResidentPad + 1 : 0;
+    return 0;
+}
+int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, pgh_vec_t x_int, pgh_vec_t xg) {
+    CHECK(resident_ok(g), "pgh_resident_in: this graph's image has no resident form");
+    const int64_t n = g->n_cols;
+    CHECK(x && x_int && xg && x->n == n && x_int->n == n + kResidentPad && xg->n == n + kResidentPad + 1, "pgh_resident_in: vector length mismatch");
+    for (int64_t i = 0; i < n; ++i) x_int->data[i] = x->data[n - 1 - i];
+    for (int64_t i = n; i < n + kResidentPad; ++i) x_int->data[i] = 0.f;
+    for (int64_t i = 0; i < n + kResidentPad; ++i) xg->data[i] = 2.f * x_int->data[i];
+    return 0;
+}
+int pgh_resident_gather(pgh_graph_t g, pgh_vec_t x_int, pgh_vec_t xg) {
+    CHECK(resident_ok(g), "pgh_resident_gather: this graph's image has no resident form");
+    const int64_t n = g->n_cols;
+    CHECK(x_int && xg && x_int->n == n + kResidentPad && xg->n == n + kResidentPad + 1, "pgh_resident_gather: vector length mismatch");
+    for (int64_t i = 0; i < n + kResidentPad; ++i) xg->data[i] = 2.f * x_int->data[i];
+    return 0;
+}
+int pgh_resident_out(pgh_graph_t g, pgh_vec_t y_int, double factor, pgh_vec_t y) {
+    CHECK(resident_ok(g), "pgh_resident_out: this graph's image has no resident form");
+    const int64_t n = g->n_cols;
+    CHECK(y && y_int && y->n == n && y_int->n == n + kResidentPad, "pgh_resident_out: vector length mismatch");
+    for (int64_t i = 0; i < n; ++i) y->data[n - 1 - i] = y_int->data[i] * (float)factor;
+    return 0;
+}
+int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, pgh_vec_t xg, double a, pgh_vec_t v_int, double b, pgh_vec_t y_int,
+                      pgh_vec_t yg, double* sum_y) {
+    CHECK(resident_ok(g), "pgh_resident_step: this graph's image has no resident form");
+    const int64_t n = g->n_cols;
+    CHECK(mode == 0 || mode == 1, "pgh_resident_step: mode 0 or 1");
+    CHECK(x_int && xg && y_int && yg && x_int->n == n + kResidentPad && y_int->n == n + kResidentPad && xg->n == n + kResidentPad + 1 &&
+              yg->n == n + kResidentPad + 1 && x_int->data != y_int->data && xg->data != yg->data,
+          "pgh_resident_step: iterate length mismatch / aliasing");
+    CHECK(mode == 0 || (v_int && v_int->n == n + kResidentPad), "pgh_resident_step: mode 1 needs the resident second operand");
+    std::vector<float> x((size_t)n);
+    for (int64_t i = 0; i < n; ++i) x[(size_t)(n - 1 - i)] = 0.5f * xg->data[i];        // the step gathers from the gather form
+    double sum = 0;
+    const float fa = (float)a, fb = (float)b;
+    for (int64_t r = 0; r < n; ++r) {
+        float v = fa * row_dot(g, x.data(), r);
+        if (mode == 1) v += fb * v_int->data[n - 1 - r];
+        y_int->data[n - 1 - r] = v;
+        sum += v;
+    }
+    for (int64_t i = n; i < n + kResidentPad; ++i) y_int->data[i] = 0.f;
+    for (int64_t i = 0; i < n + kResidentPad; ++i) yg->data[i] = 2.f * y_int->data[i];
+    if (sum_y) *sum_y = sum;
     return 0;
 }
 int pgh_absorb_step(pgh_graph_t g, pgh_vec_t x, double xs, pgh_vec_t p, pgh_vec_t deg, pgh_vec_t lam, pgh_vec_t y,

@@ -82,7 +82,9 @@ def _exposed(function):
         return _conv_over(function)
 
     def exposed(*args, **kwargs):
-        return function(*map(_primitive_of, args), **{name: _primitive_of(value) for name, value in kwargs.items()})
+        if kwargs:
+            return function(*map(_primitive_of, args), **{name: _primitive_of(value) for name, value in kwargs.items()})
+        return function(*map(_primitive_of, args))
     exposed.__name__, exposed.__doc__ = function.__name__, function.__doc__
     return exposed
 

@@ -46,6 +46,12 @@ struct Runtime {
     double*     d_partials = nullptr;    // [kMaxPartials * kPartialRegions]
     double*     d_scalars = nullptr;     // [kNumScalars]
     double*     h_scalars = nullptr;     // pinned
+    // scalar results come to the host through a MAILBOX in mapped pinned memory (scalars_to_host): the last kernel of a reduction is
+    // followed by a one-thread post {values, tag}, the host polls the tag -- a few microseconds instead of a D2H copy + a stream
+    // synchronisation per backend.sum / residual (the backend-primitive route asks for two scalars per iteration)
+    volatile unsigned long long* mail_host = nullptr;     // [8]: tag, 7 values (bit patterns of doubles)
+    unsigned long long*          mail_dev = nullptr;
+    unsigned long long           mail_tag = 0;
     // profiling
     bool        profiling = false;
     hipEvent_t  ev_a = nullptr, ev_b = nullptr;
@@ -54,6 +60,9 @@ struct Runtime {
 };
 Runtime& rt();
 int ensure_init();
+// h_scalars[first .. first + count) <- d_scalars[first .. first + count) once everything enqueued on the engine's stream has run
+// (count <= 7); PGH_MAILBOX=0: the copy + stream synchronisation of rounds 1-5
+int scalars_to_host(int first, int count);
 
 // Stream-ordered caching allocator for vectors, slabs and loop work buffers.  hipMalloc / hipFree synchronise the
 // device and cost 100+ us each; a PageRank run allocates ~10 n-vectors.  A released block is reused by the next

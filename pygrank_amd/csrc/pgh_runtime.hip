@@ -7,6 +7,8 @@
 #include "pgh_common.h"
 
 #include <hipcub/hipcub.hpp>
+#include <chrono>
+#include <cstring>
 #include <unordered_map>
 #include <map>
 
@@ -124,8 +126,54 @@ extern "C" int pgh_init(int device_ordinal) {
     PGH_HIP(hipHostMalloc(&r.h_scalars, sizeof(double) * kNumScalars, hipHostMallocDefault));
     PGH_HIP(hipEventCreate(&r.ev_a));
     PGH_HIP(hipEventCreate(&r.ev_b));
+    if (!(getenv("PGH_MAILBOX") != nullptr && atoi(getenv("PGH_MAILBOX")) == 0)) {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        PGH_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(hp, 0, 64);
+        PGH_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+        r.mail_host = reinterpret_cast<volatile unsigned long long*>(hp);
+        r.mail_dev = reinterpret_cast<unsigned long long*>(dp);
+        r.mail_tag = 0;
+    }
     r.device = device_ordinal;
     r.initialised = true;
+    return 0;
+}
+
+namespace {
+__global__ void k_post_scalars(const double* __restrict__ src, int count, unsigned long long* __restrict__ mail, unsigned long long tag) {
+    for (int i = 0; i < count; ++i) __hip_atomic_store(mail + 1 + i, (unsigned long long)__double_as_longlong(src[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mail, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);       // the values are visible before the tag is
+}
+}  // namespace
+
+int pgh::scalars_to_host(int first, int count) {
+    Runtime& r = rt();
+    if (r.mail_host != nullptr && count >= 1 && count <= 7) {
+        const unsigned long long tag = ++r.mail_tag;
+        k_post_scalars<<<1, 1, 0, r.stream>>>(r.d_scalars + first, count, r.mail_dev, tag);
+        PGH_HIP(hipGetLastError());
+        const auto start = std::chrono::steady_clock::now();
+        long spins = 0;
+        for (;;) {
+            if (__atomic_load_n(const_cast<unsigned long long*>(r.mail_host), __ATOMIC_ACQUIRE) == tag) {
+                for (int i = 0; i < count; ++i) {
+                    const unsigned long long bits = r.mail_host[1 + i];
+                    memcpy(&r.h_scalars[first + i], &bits, sizeof(double));
+                }
+                return 0;
+            }
+            if ((++spins & 0xfff) == 0) {
+                // the post never came within a generous bound (a fault upstream, a stream that is not running): let the runtime say why
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() > 2.0) break;
+                const hipError_t q = hipStreamQuery(r.stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(std::string("scalars_to_host: ") + hipGetErrorString(q));
+            }
+        }
+    }
+    PGH_HIP(hipMemcpyAsync(r.h_scalars + first, r.d_scalars + first, sizeof(double) * count, hipMemcpyDeviceToHost, r.stream));
+    PGH_HIP(hipStreamSynchronize(r.stream));
     return 0;
 }
 
@@ -228,6 +276,7 @@ extern "C" int pgh_shutdown(void) {
     (void)hipFree(r.d_partials);
     (void)hipFree(r.d_scalars);
     (void)hipHostFree(r.h_scalars);
+    if (r.mail_host != nullptr) (void)hipHostFree(const_cast<unsigned long long*>(r.mail_host));
     (void)hipEventDestroy(r.ev_a);
     (void)hipEventDestroy(r.ev_b);
     (void)hipStreamDestroy(r.own_stream);
@@ -779,8 +828,7 @@ int run_reduce(const float* a, const float* b, double sa, double sb, int64_t n, 
     constexpr int KIND = (MODE == 2 || MODE == 6) ? 1 : (MODE == 3 ? 2 : 0);
     k_reduce_final<KIND><<<1, kBlock, 0, r.stream>>>(r.d_partials, grid, r.d_scalars);
     PGH_HIP(hipGetLastError());
-    PGH_HIP(hipMemcpyAsync(r.h_scalars, r.d_scalars, sizeof(double), hipMemcpyDeviceToHost, r.stream));
-    PGH_HIP(hipStreamSynchronize(r.stream));
+    PGH_TRY(scalars_to_host(0, 1));
     *out = r.h_scalars[0];
     return 0;
 }

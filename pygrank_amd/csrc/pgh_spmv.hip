@@ -750,12 +750,7 @@ bool published_state(int enq, unsigned long long tag, double* loop_ms) {
     }
 }
 
-int fetch_scalars(int first, int count) {
-    Runtime& r = rt();
-    PGH_HIP(hipMemcpyAsync(r.h_scalars + first, r.d_scalars + first, sizeof(double) * count, hipMemcpyDeviceToHost, r.stream));
-    PGH_HIP(hipStreamSynchronize(r.stream));
-    return 0;
-}
+int fetch_scalars(int first, int count) { return scalars_to_host(first, count); }
 
 // Work vectors of the loops come from the runtime's stream-ordered pool (pgh_common.h pool_alloc).
 struct WorkPool {
@@ -999,6 +994,12 @@ extern "C" int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, pgh_vec_t x_int, pgh_
     PGH_TRY(bsf_out_to_internal(g, x->data, x_int->data, 0.f));
     if (xg != nullptr) PGH_TRY(bsf_make_gather(g, x_int->data, f.src_scale, xg->data));
     return 0;
+}
+
+extern "C" int pgh_resident_gather(pgh_graph_t g, pgh_vec_t x_int, pgh_vec_t xg) {
+    PGH_CHECK(resident_usable(g) && g->bsf.src_scale != nullptr, "pgh_resident_gather: this graph's image has no gather form (pgh_graph_resident_len)");
+    PGH_CHECK(x_int && xg && x_int->n == g->bsf.n_out && xg->n == g->bsf.n_src_pad + 1, "pgh_resident_gather: vector length mismatch");
+    return bsf_make_gather(g, x_int->data, g->bsf.src_scale, xg->data);
 }
 
 extern "C" int pgh_resident_out(pgh_graph_t g, pgh_vec_t y_int, double factor, pgh_vec_t y) {

@@ -22,13 +22,35 @@ def _ptr(arr):
 class DeviceVector:
     """Dense f32 vector in HBM."""
 
-    __slots__ = ("_h", "_n", "_keepalive", "uuid", "__weakref__")
+    __slots__ = ("_h", "_n", "_keepalive", "uuid", "_deps", "__weakref__")
     __array_priority__ = 1000      # numpy scalars/arrays defer to our reflected operators
 
     def __init__(self, handle, n, keepalive=None):
         self._h = handle
         self._n = int(n)
         self._keepalive = keepalive
+        self._deps = None
+
+    def _before_write(self):
+        """Called by everything that overwrites this vector's memory in place: lazy expressions that still read it are evaluated first
+        (they stand for the values the vector held when they were formed)."""
+        deps, self._deps = self._deps, None
+        if deps:
+            for ref in deps:
+                dep = ref()
+                if dep is not None:
+                    dep._h                  # noqa: B018 -- evaluates the expression into memory of its own
+        for cache in _RESIDENT_CACHES:
+            cache.pop(id(self), None)
+
+    def _depend(self, lazy):
+        """`lazy` reads this vector's memory when it is evaluated (weak references in a list: vectors compare elementwise and do not hash)."""
+        import weakref
+        if self._deps is None:
+            self._deps = []
+        elif len(self._deps) >= 64:
+            self._deps = [ref for ref in self._deps if ref() is not None]
+        self._deps.append(weakref.ref(lazy))
 
     # ------------------------------------------------------------------ construction
     @staticmethod
@@ -132,7 +154,12 @@ class DeviceVector:
             a, b = (other, self) if reflected else (self, other)
             L.check(L.lib().pgh_ewise_vv(op, a._h, b._h, out._h))
             return out
-        if isinstance(other, (numbers.Number, np.generic)) or (isinstance(other, np.ndarray) and other.ndim == 0):
+        if _is_scalar(other):
+            if LAZY and self._keepalive is None and self._n > 0:
+                # x * s, s * x, x / s: an unevaluated product (LazyVector) -- a * conv(x, M) + b * p then reaches the engine as ONE step
+                factor = _scalar_factor(op, float(other), reflected)
+                if factor is not None:
+                    return LazyVector.scaled(self, factor)
             out = DeviceVector.empty(self._n)
             L.check(L.lib().pgh_ewise_vs(op, self._h, float(other), 1 if reflected else 0, out._h))
             return out
@@ -229,6 +256,7 @@ class DeviceVector:
         raise TypeError("unsupported index " + repr(type(key)))
 
     def __setitem__(self, key, value):
+        self._before_write()
         i = int(key)
         if i < 0:
             i += self._n
@@ -246,6 +274,362 @@ class DeviceVector:
         out = DeviceVector.empty(self._n)
         L.check(L.lib().pgh_axpby(float(a), self._h, float(b), other._h, out._h))
         return out
+
+
+# ======================================================================================================================
+# Lazy vectors: the backend-primitive route without a round trip through the caller's id space per primitive
+# ======================================================================================================================
+LAZY = True                    # False: every primitive is evaluated where it stands (one engine call each; A/B measurements, tests)
+_RESIDENT_CACHES = []          # the per-graph caches of resident copies of plain vectors (DeviceVector._before_write drops its entry)
+_RESIDENT_KINDS = ("res", "conv", "scaled", "axpby", "lin")
+_MAX_DEPTH = 6
+_MEMORY_KINDS = (None, "mat")     # values held in the caller's ids: a plain DeviceVector, an expression already evaluated there
+
+
+def _is_scalar(other):
+    kind = type(other)
+    return kind is float or kind is int or isinstance(other, (numbers.Number, np.generic)) or (kind is np.ndarray and other.ndim == 0)
+
+
+def _scalar_factor(op, value, reflected):
+    """x (op) value as a multiplication, or None."""
+    if op == L.MUL:
+        return value
+    if op == L.DIV and not reflected and value != 0.0 and np.isfinite(value):
+        return 1.0 / value
+    return None
+
+
+def _kind(vec):
+    return vec._kind if isinstance(vec, LazyVector) else None
+
+
+class _Resident:
+    """One vector in the id space of `graph`: y [n_int] and (made on demand) its gather form; sum(y) when a step produced it."""
+    __slots__ = ("graph", "y", "xg", "sum")
+
+    def __init__(self, graph, y, xg=None, total=None):
+        self.graph, self.y, self.xg, self.sum = graph, y, xg, total
+
+    def gather_form(self):
+        if self.xg is None and self.graph._n_gather:
+            self.xg = DeviceVector.empty(self.graph._n_gather)
+            L.check(L.lib().pgh_resident_gather(self.graph._h, self.y._h, self.xg._h))
+        return self.xg
+
+
+class LazyVector(DeviceVector):
+    """A DeviceVector whose value is an expression the engine has not evaluated yet (the reference's filters reach a
+    backend ONE PRIMITIVE AT A TIME -- pygrank/core/backend/__init__.py:59-80; PageRank._formula adhoc.py:34-36 is
+    ``conv(ranks, M) * alpha + personalization * (1 - alpha)``, RecursiveGraphFilter._step abstract_filters.py:126-136 follows it
+    with ``ranks / sum(ranks)``, ConvergenceManager convergence.py:96-101 with ``sum(abs(ranks - previous)) / length``).
+
+    Evaluated primitive by primitive each of those is a pass over an n-vector, and every conv is a round trip through the engine's
+    relabelled id space (pgh_spmv: way in, three launches, way out, a synchronisation).  Here a primitive returns an expression:
+
+      kind        value                                  becomes
+      "res"       scale * R         (R resident)         --
+      "conv"      a * M^T src                            "res" by pgh_resident_step(mode 0)
+      "scaled"    scale * parent    (parent lazy)        "res" sharing the parent's memory
+      "axpby"     a * (node) + b * p, node = M^T src     "res" by ONE pgh_resident_step(mode 1), sum(y) included
+      "lin"       sa * u + sb * v, optionally |.|        "res" by pgh_axpby in the id space; sum / max of |u - v| is ONE
+                                                         pgh_scaled_residual on the resident operands, nothing is written
+      "plain"     b * p             (p in caller ids)    memory of its own (one pgh_ewise_vs) when looked at -> "mat"
+      "mat"       evaluated in the caller's ids          --
+
+    and the way out of the id space (pgh_resident_out) runs when somebody looks at the values in the caller's ids: ``_h`` of a lazy
+    vector is a property that evaluates, so every engine call and every DeviceVector method works on it unchanged.  An expression reads
+    its operands when it is evaluated; DeviceVector._before_write evaluates the pending readers of a vector before the vector is
+    overwritten in place, so the value is always the one of the moment the expression was formed.  Resident memory is never written
+    in place."""
+
+    # (no __slots__ here: the fields of an expression live in the instance dictionary over these class-level defaults, so creating
+    # one -- five per PageRank step -- stores three attributes, not seventeen)
+    _kind = _graph = _res = _src = _p = _u = _v = _mat = None
+    _scale = _a = _b = _sa = _sb = 1.0
+    _abs = False
+    _depth = 0                      # unevaluated expressions below this one; a chain is evaluated before it grows past _MAX_DEPTH
+
+    def __init__(self, n):
+        self._n = n
+        self._keepalive = self._deps = None
+
+    # ---- constructors -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def scaled(vec, factor):
+        out = LazyVector(vec._n)
+        k = _kind(vec)
+        if k == "res":
+            out._kind, out._graph, out._res, out._scale = "res", vec._graph, vec._res, vec._scale * factor
+        elif k == "scaled":
+            out._kind, out._graph, out._src, out._scale, out._depth = "scaled", vec._graph, vec._src, vec._scale * factor, vec._depth
+        elif k in ("conv", "axpby", "lin"):                # evaluated once, shared by every view of it
+            out._kind, out._graph, out._src, out._scale, out._depth = "scaled", vec._graph, vec, factor, vec._depth
+        elif k == "plain":
+            out._kind, out._p, out._b = "plain", vec._p, vec._b * factor
+            vec._p._depend(out)
+        else:                                              # a plain vector, or an expression already evaluated in the caller's ids
+            out._kind, out._p, out._b = "plain", vec, factor
+            vec._depend(out)
+        return out
+
+    @staticmethod
+    def conv(graph, x):
+        out = LazyVector(graph.shape[1])
+        out._kind, out._graph, out._src, out._a = "conv", graph, x, 1.0
+        if _kind(x) not in _RESIDENT_KINDS:
+            x._depend(out)
+        return out._bounded(getattr(x, "_depth", 0) + 1)
+
+    def _bounded(self, depth):
+        """A filter that never looks at its iterate (error_type="iters", no quotient) would nest one expression per step: the chain is
+        evaluated where it passes _MAX_DEPTH."""
+        if depth > _MAX_DEPTH:
+            self._flush()
+            depth = 0
+        self._depth = depth
+        return self
+
+    # ---- evaluation -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _resident_of(graph, vec):
+        """(resident form, scale) of `vec` in the id space of `graph`: an expression of that graph is flushed, a vector in the caller's
+        ids is brought in (and remembered while it lives unwritten: the personalization of a run comes back every step)."""
+        k = _kind(vec)
+        if k in _RESIDENT_KINDS and vec._graph is graph:
+            vec._flush()
+            return vec._res, vec._scale
+        if k == "plain" and _kind(vec._p) in _MEMORY_KINDS:
+            return graph._resident_copy(vec._p), vec._b
+        return graph._resident_copy(vec), 1.0
+
+    def _flush(self):
+        """Turns this expression into a resident vector ("res")."""
+        k = self._kind
+        if k == "res":
+            return
+        self._depth = 0
+        g = self._graph
+        lib = L.lib()
+        if k == "scaled":
+            parent = self._src
+            parent._flush()
+            self._kind, self._res, self._scale, self._src = "res", parent._res, parent._scale * self._scale, None
+            return
+        if k in ("conv", "axpby"):
+            node = self if k == "conv" else self._src
+            if k == "axpby" and (node._kind != "conv" or _shared(node)):
+                # the product M^T src is somebody else's too (ClosedFormGraphFilter keeps it as its next power): evaluated once, kept
+                # there; this expression is then arithmetic in the id space
+                conv_res, conv_scale = self._resident_of(g, node)
+                p_res, p_scale = self._resident_of(g, self._p)
+                y = DeviceVector.empty(g._n_int)
+                L.check(lib.pgh_axpby(conv_scale * self._a, conv_res.y._h, p_scale * self._b, p_res.y._h, y._h))
+                self._kind, self._res, self._scale, self._src, self._p = "res", _Resident(g, y), 1.0, None, None
+                return
+            src_res, src_scale = self._resident_of(g, node._src)
+            y = DeviceVector.empty(g._n_int)
+            yg = DeviceVector.empty(g._n_gather) if g._n_gather else None
+            xg = src_res.gather_form()
+            if k == "conv":
+                L.check(lib.pgh_resident_step(g._h, 0, src_res.y._h, xg._h if xg is not None else None, node._a * src_scale, None, 0.0,
+                                              y._h, yg._h if yg is not None else None, None))
+                total = None
+            else:
+                p_res, p_scale = self._resident_of(g, self._p)
+                got = C.c_double()
+                L.check(lib.pgh_resident_step(g._h, 1, src_res.y._h, xg._h if xg is not None else None, self._a * node._a * src_scale,
+                                              p_res.y._h, self._b * p_scale, y._h, yg._h if yg is not None else None, C.byref(got)))
+                total = got.value
+            self._kind, self._res, self._scale, self._src, self._p = "res", _Resident(g, y, yg, total), 1.0, None, None
+            return
+        if k == "lin":
+            u_res, u_scale = self._resident_of(g, self._u)
+            v_res, v_scale = self._resident_of(g, self._v)
+            y = DeviceVector.empty(g._n_int)
+            L.check(lib.pgh_axpby(self._sa * u_scale, u_res.y._h, self._sb * v_scale, v_res.y._h, y._h))
+            if self._abs:
+                z = DeviceVector.empty(g._n_int)
+                L.check(lib.pgh_ewise_unary(L.ABS, y._h, z._h))
+                y = z
+            self._kind, self._res, self._scale, self._u, self._v, self._abs = "res", _Resident(g, y), 1.0, None, None, False
+            return
+        raise L.EngineError("a lazy vector of kind " + repr(k) + " has no resident form")
+
+    @property
+    def _h(self):
+        """The handle of this vector's values in the CALLER's ids: evaluates the expression (once)."""
+        if self._mat is None:
+            k = self._kind
+            if k == "plain":
+                out = DeviceVector.empty(self._n)
+                L.check(L.lib().pgh_ewise_vs(L.MUL, self._p._h, float(self._b), 0, out._h))
+                self._kind, self._p = "mat", None
+            elif k in _RESIDENT_KINDS:
+                self._flush()
+                out = DeviceVector.empty(self._n)
+                L.check(L.lib().pgh_resident_out(self._graph._h, self._res.y._h, float(self._scale), out._h))
+            else:
+                return None
+            self._mat = out
+        return self._mat._h
+
+    @_h.setter
+    def _h(self, value):            # DeviceVector.__init__ assigns None
+        if value is not None:
+            raise L.EngineError("a lazy vector owns no handle")
+
+    def __del__(self):
+        pass                        # whatever this expression holds is owned by plain vectors
+
+    def _writable(self):
+        """The caller is about to write into this vector's memory: it becomes an ordinary vector in the caller's ids."""
+        self._h                     # noqa: B018
+        self._kind, self._graph, self._res = "mat", None, None
+        return self
+
+    def __setitem__(self, key, value):
+        self._writable()
+        DeviceVector.__setitem__(self, key, value)
+
+    def copy(self):
+        if self._kind == "res":
+            return LazyVector.scaled(self, 1.0)         # resident memory is never written in place: a copy is another view of it
+        return DeviceVector.copy(self)
+
+    # ---- arithmetic that stays lazy ---------------------------------------------------------------------------------
+    def _binary(self, op, other, reflected=False):
+        if self._kind != "mat":
+            if _is_scalar(other):
+                factor = _scalar_factor(op, float(other), reflected)
+                if factor is not None:
+                    return LazyVector.scaled(self, factor)
+            elif isinstance(other, DeviceVector) and other._n == self._n and op in (L.ADD, L.SUB):
+                sign = -1.0 if op == L.SUB else 1.0
+                a, b = (other, self) if reflected else (self, other)
+                out = _linear(a, 1.0, b, sign)
+                if out is not None:
+                    return out
+        return DeviceVector._binary(self, op, other, reflected)
+
+    # (a subclass's reflected operator is tried first only when the subclass DEFINES it: plain + lazy comes here)
+    def __add__(self, o): return self._binary(L.ADD, o)
+    def __radd__(self, o): return self._binary(L.ADD, o, True)
+    def __sub__(self, o): return self._binary(L.SUB, o)
+    def __rsub__(self, o): return self._binary(L.SUB, o, True)
+    def __mul__(self, o): return self._binary(L.MUL, o)
+    def __rmul__(self, o): return self._binary(L.MUL, o, True)
+    def __truediv__(self, o): return self._binary(L.DIV, o)
+    def __neg__(self): return LazyVector.scaled(self, -1.0) if self._kind != "mat" else DeviceVector.__neg__(self)
+
+    def __abs__(self):
+        if self._kind == "lin" and not self._abs:
+            out = LazyVector(self._n)
+            out._kind, out._graph, out._u, out._v, out._sa, out._sb, out._abs = "lin", self._graph, self._u, self._v, self._sa, self._sb, True
+            out._depth = self._depth
+            return out
+        return DeviceVector.__abs__(self)
+
+    # ---- reductions in the id space (padding slots hold zeros) ------------------------------------------------------------
+    def _reduce(self, kind):
+        if self._kind in _RESIDENT_KINDS:
+            if self._kind == "lin" and self._abs and kind in (L.SUM, L.ABSSUM, L.MAX):
+                return _residual_of(self._graph, L.ERR_LINF if kind == L.MAX else L.ERR_L1, self._u, self._sa, self._v, self._sb)
+            if kind in (L.SUM, L.ABSSUM):
+                self._flush()
+                res = self._res
+                if kind == L.SUM and res.sum is not None:
+                    return res.sum * self._scale
+                out = C.c_double()
+                L.check(L.lib().pgh_reduce(kind, res.y._h, C.byref(out)))
+                if kind == L.SUM:
+                    res.sum = out.value
+                    return out.value * self._scale
+                return out.value * abs(self._scale)
+        return DeviceVector._reduce(self, kind)
+
+
+def _references(node):
+    import sys
+    return sys.getrefcount(node)
+
+
+def _unshared_references():
+    """What _references reports for an object held by ONE attribute and the caller's local (the situation of LazyVector._flush when only
+    the expression being evaluated holds its product): measured, not assumed -- the count depends on how the interpreter passes arguments."""
+    class Holder:
+        pass
+    holder = Holder()
+    holder.node = Holder()
+    node = holder.node
+    return _references(node)
+
+
+_UNSHARED = _unshared_references()
+
+
+def _shared(node):
+    """Does anything but the expression being evaluated hold `node`?  Only the cost depends on the answer: a shared product is evaluated
+    on its own and kept (ClosedFormGraphFilter keeps M^T term as its next power), an unshared one is folded into the step."""
+    import sys
+    return sys.getrefcount(node) > _UNSHARED
+
+
+def _linear(a, sa, b, sb):
+    """sa * a + sb * b as an expression in the id space of the graph one of them lives in, or None (evaluate in the caller's ids)."""
+    graph = None
+    for vec in (a, b):
+        if _kind(vec) in _RESIDENT_KINDS:
+            if graph is not None and vec._graph is not graph:
+                return None
+            graph = vec._graph
+    if graph is None:
+        return None
+    # a * conv(x, M) + b * p: ONE engine step
+    for conv, second, sc, weight in ((a, b, sa, sb), (b, a, sb, sa)):
+        node, coeff = conv, sc
+        if _kind(node) == "scaled" and _kind(node._src) == "conv":
+            node, coeff = node._src, coeff * node._scale
+        if _kind(node) != "conv":
+            continue
+        if _kind(second) == "plain" and _kind(second._p) in _MEMORY_KINDS:
+            second, weight = second._p, weight * second._b
+        if _kind(second) not in (None, "mat", "res"):
+            continue
+        out = LazyVector(a._n)
+        out._kind, out._graph, out._src, out._a, out._p, out._b = "axpby", graph, node, coeff, second, weight
+        if _kind(second) != "res":
+            second._depend(out)
+        return out._bounded(node._depth + 1)
+    out = LazyVector(a._n)
+    out._kind, out._graph, out._u, out._v, out._sa, out._sb = "lin", graph, a, b, sa, sb
+    for vec in (a, b):
+        if _kind(vec) not in _RESIDENT_KINDS:
+            (vec._p if _kind(vec) == "plain" else vec)._depend(out)
+    return out._bounded(max(getattr(a, "_depth", 0), getattr(b, "_depth", 0)) + 1)
+
+
+def _residual_of(graph, kind, u, su, v, sv):
+    """sum |su u + sv v| (L1) or max |.| (LINF) over the resident operands: one pgh_scaled_residual, nothing materialised."""
+    u_res, u_scale = LazyVector._resident_of(graph, u)
+    v_res, v_scale = LazyVector._resident_of(graph, v)
+    out = C.c_double()
+    L.check(L.lib().pgh_scaled_residual(kind, u_res.y._h, su * u_scale, v_res.y._h, -sv * v_scale, C.byref(out)))
+    return out.value
+
+
+def lazy_residual(kind, a, b):
+    """residual(kind, a, b) of two vectors without leaving the id space one of them lives in (measures.Supervised.evaluate), or None."""
+    graph = None
+    for vec in (a, b):
+        if _kind(vec) in _RESIDENT_KINDS:
+            if graph is not None and vec._graph is not graph:
+                return None
+            graph = vec._graph
+    if graph is None or len(a) != len(b) or len(a) != graph.shape[1]:
+        return None
+    value = _residual_of(graph, L.ERR_LINF if kind == L.ERR_LINF else L.ERR_L1, a, 1.0, b, -1.0)
+    return value / len(a) if kind == L.ERR_MABS else value
 
 
 class DeviceMatrix:
@@ -374,6 +758,34 @@ class DeviceGraph:
         self._h = handle
         self.shape = tuple(int(s) for s in shape)
         self.nnz = int(nnz)
+        self._n_int = self._n_gather = None         # lengths of a resident iterate and of its gather form (pgh_graph_resident_len)
+        self._resident = {}                          # id(plain vector) -> (weak reference, its resident copy)
+
+    def _resident_lengths(self):
+        if self._n_int is None:
+            a, b = C.c_int64(), C.c_int64()
+            L.check(L.lib().pgh_graph_resident_len(self._h, C.byref(a), C.byref(b)))
+            self._n_int, self._n_gather = a.value, b.value
+            if a.value:
+                _RESIDENT_CACHES.append(self._resident)
+        return self._n_int
+
+    def _resident_copy(self, vec):
+        """`vec` (caller's ids) in this graph's id space; remembered while the vector lives unwritten (a run's personalization is an
+        operand of every step).  At most four copies are kept."""
+        import weakref
+        hit = self._resident.get(id(vec))
+        if hit is not None and hit[0]() is vec:
+            return hit[1]
+        y = DeviceVector.empty(self._n_int)
+        xg = DeviceVector.empty(self._n_gather) if self._n_gather else None
+        L.check(L.lib().pgh_resident_in(self._h, vec._h, y._h, xg._h if xg is not None else None))
+        res = _Resident(self, y, xg)
+        if _kind(vec) in _MEMORY_KINDS and vec._keepalive is None:
+            while len(self._resident) >= 4:
+                self._resident.pop(next(iter(self._resident)))
+            self._resident[id(vec)] = (weakref.ref(vec), res)
+        return res
 
     @staticmethod
     def from_scipy(M):
@@ -440,6 +852,11 @@ class DeviceGraph:
         except Exception:
             pass
         self._h = None
+        try:
+            self._resident.clear()
+            _RESIDENT_CACHES[:] = [c for c in _RESIDENT_CACHES if c is not self._resident]
+        except Exception:
+            pass
 
     def __len__(self):
         return self.shape[0]
@@ -476,6 +893,8 @@ class DeviceGraph:
             y = DeviceMatrix.empty(self.shape[1], x.b)
             L.check(L.lib().pgh_spmm(self._h, x._h, y._h))
             return y
+        if LAZY and self._h is not None and len(x) == self.shape[0] and self._resident_lengths():
+            return LazyVector.conv(self, x)         # evaluated when somebody looks -- fused with what the filter does to it next
         y = DeviceVector.empty(self.shape[1])
         L.check(L.lib().pgh_spmv(self._h, x._h, y._h))
         return y

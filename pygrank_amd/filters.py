@@ -22,7 +22,7 @@ import numpy as np
 from pygrank_amd import _lib as L
 from pygrank_amd import backend
 from pygrank_amd.convergence import ConvergenceManager
-from pygrank_amd.device import DeviceGraph, DeviceVector
+from pygrank_amd.device import DeviceGraph, DeviceVector, LazyVector
 from pygrank_amd.postprocess import Postprocessor, Tautology
 from pygrank_amd.preprocessing import obj2id, preprocessor as default_preprocessor
 from pygrank_amd.signals import GraphSignal, NodeRanking, to_signal
@@ -210,6 +210,9 @@ class RecursiveGraphFilter(GraphFilter):
         x = ranks.np
         if not isinstance(x, DeviceVector):
             return False
+        if isinstance(x, LazyVector):
+            x = x._writable()              # the engine updates the iterate in place: an expression becomes memory of its own first
+        x._before_write()
         res = L.LoopResult()
         L.check(entry(g._h, *[v._h for v in vectors], x._h, C.byref(cfg), C.byref(res)))
         if cfg.in_norm < 0 and res.in_norm == 0:
@@ -769,6 +772,9 @@ class ClosedFormGraphFilter(GraphFilter):
                 or not isinstance(x, DeviceVector):
             return False
         coeffs = np.asarray(self._coefficient_schedule(max(int(self.convergence.max_iters) - 1, 0)), dtype=np.float64)
+        if isinstance(x, LazyVector):
+            x = x._writable()              # written in place by the engine
+        x._before_write()
         res = L.LoopResult()
         L.check(L.lib().pgh_poly_run(g._h, p._h, coeffs.ctypes.data_as(C.c_void_p), len(coeffs),
                                      1 if self.coefficient_type == "chebyshev" else 0, x._h, C.byref(cfg),

@@ -12,7 +12,7 @@ import numbers
 
 from pygrank_amd import _lib as L
 from pygrank_amd import backend
-from pygrank_amd.device import DeviceVector
+from pygrank_amd.device import DeviceVector, lazy_residual
 from pygrank_amd.signals import GraphSignal, to_signal
 
 
@@ -51,6 +51,10 @@ class Supervised(Measure):
     def evaluate(self, scores):
         known, scores = self.to_numpy(scores)
         if isinstance(known, DeviceVector) and isinstance(scores, DeviceVector):
+            # two iterates of one graph that are still in the engine's id space (device.LazyVector): the residual is taken there
+            resident = lazy_residual(self._KIND, known, scores)
+            if resident is not None:
+                return resident
             out = C.c_double()
             L.check(L.lib().pgh_residual(self._KIND, known._h, scores._h, C.byref(out)))
             return out.value

@@ -33,7 +33,7 @@ def _dense_values(obj, count, node2id):
     count), nothing means all ones, a node -> value mapping is staged on the host and uploaded once."""
     if obj is None:
         return backend.repeat(1.0, count)
-    if type(obj) is DeviceVector and len(obj) == count:      # the engine's own vector: nothing to look at (the hot path of rank())
+    if isinstance(obj, DeviceVector) and len(obj) == count:  # the engine's own vector (or an expression over such): nothing to look at
         return obj
     if backend.is_array(obj):
         have = backend.length(obj)
@@ -59,11 +59,12 @@ class GraphSignal(MutableMapping):
     @property
     def np(self):                                         # signals.py:81-83
         value = self._np
-        return value if type(value) is DeviceVector else backend.to_array(value)
+        return value if isinstance(value, DeviceVector) else backend.to_array(value)
 
     @np.setter
     def np(self, value):                                  # signals.py:85-87
-        self._np = backend.to_array(self._compliant(value))
+        value = self._compliant(value)
+        self._np = value if isinstance(value, DeviceVector) else backend.to_array(value)
         self._host = None
 
     def filter(self, exclude=None):                       # signals.py:68-75
@@ -111,6 +112,10 @@ class GraphSignal(MutableMapping):
         return other.np
 
     def _new(self, value):
+        if isinstance(value, DeviceVector) and len(value) == len(self._np):       # the outcome of arithmetic on this signal's own vector
+            out = GraphSignal.__new__(GraphSignal)
+            out.graph, out.node2id, out._host, out._np = self.graph, self.node2id, None, value
+            return out
         return GraphSignal(self.graph, value, self.node2id)
 
     def __add__(self, o): return self._new(self.np + self._compliant(o))

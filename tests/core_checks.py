@@ -574,7 +574,170 @@ def check_differentiable_propagate(pg):
         differentiable_propagate(pg.PageRank(0.9), graph, X)                           # the L1 quotient and a tolerance: not linear
 
 
-ALL = [v for k, v in sorted(globals().items()) if k.startswith("check_") and callable(v)]
+def check_lazy_vectors_are_plain_vectors_to_every_observer(pg):
+    """device.LazyVector (the backend-primitive route, pygrank/core/backend/__init__.py:59-80): whatever stays unevaluated -- conv,
+    scalar products, a * conv + b * p, sums and differences in the engine's id space, |u - v| under sum / max -- has, for everybody who
+    looks, the value the eager primitives give: random expression chains against numpy on the downloaded matrix, reductions, copies,
+    item assignment, operands overwritten after the expression was formed, two graphs, and the fallbacks (vector products, powers,
+    comparisons, scalar addition)."""
+    import scipy.sparse as sp
+    from pygrank_amd import device
+    rng = np.random.default_rng(3)
+    n = 200
+    A = sp.csr_array(sp.random(n, n, density=0.05, random_state=5, format="csr"))
+    A.data[:] = 1.0
+    B = sp.csr_array(sp.random(n, n, density=0.08, random_state=6, format="csr"))
+    pre = pg.preprocessor(normalization="col", assume_immutability=True)
+    MA, MB = pre(pg.AdjacencyWrapper(A, directed=True)), pre(pg.AdjacencyWrapper(B, directed=True))
+    TA, TB = [np.asarray(M.array.download_transposed().todense(), dtype=np.float64) for M in (MA, MB)]      # M^T, as stored
+    x0, p0 = rng.random(n), rng.random(n)
+    x, p = pg.to_array(x0), pg.to_array(p0)
+
+    def close(got, want, tol=2e-6):
+        got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+        assert got.shape == want.shape and np.max(np.abs(got - want)) <= tol * max(np.max(np.abs(want)), 1e-30), np.max(np.abs(got - want))
+
+    c = pg.conv(x, MA)
+    assert isinstance(c, device.LazyVector) and c._kind == "conv" and len(c) == n and c.shape == (n,)
+    close(c, TA @ x0)
+    assert c._kind == "res"                                         # looked at: evaluated once, in the id space and in the caller's ids
+    close(pg.conv(x, MA) * 0.85 + p * 0.15, 0.85 * (TA @ x0) + 0.15 * p0)
+    close(0.15 * p + 0.85 * pg.conv(x, MA), 0.85 * (TA @ x0) + 0.15 * p0)
+    y = pg.conv(x, MA) * 0.85 + p * 0.15
+    assert y._kind == "axpby"
+    total = pg.sum(y)                                               # ONE engine step, sum(y) included
+    assert y._kind == "res" and abs(total - (0.85 * (TA @ x0) + 0.15 * p0).sum()) <= 2e-6 * abs(total)
+    q = y / total
+    assert q._kind == "res" and q._res is y._res                    # a view of the same memory
+    close(q, (0.85 * (TA @ x0) + 0.15 * p0) / total)
+    want_y = (0.85 * (TA @ x0) + 0.15 * p0)
+    z = pg.conv(q, MA)                                              # a resident operand: no way into the id space
+    close(z, TA @ (want_y / total))
+    d = z - q
+    assert d._kind == "lin" and abs(d)._kind == "lin"
+    want_d = TA @ (want_y / total) - want_y / total
+    assert abs(pg.sum(pg.abs(z - q)) - np.abs(want_d).sum()) <= 2e-6 * np.abs(want_d).sum()
+    assert abs(pg.max(pg.abs(z - q)) - np.abs(want_d).max()) <= 2e-6 * np.abs(want_d).max()
+    assert abs(pg.Mabs(q)(z) - np.abs(want_d).mean()) <= 2e-6 * np.abs(want_d).mean()
+    assert abs(pg.L1(z)(q) - np.abs(want_d).sum()) <= 2e-6 * np.abs(want_d).sum()
+    assert abs(pg.MaxDifference(z)(q) - np.abs(want_d).max()) <= 2e-6 * np.abs(want_d).max()
+    close(d, want_d)
+    close(abs(z - q) * 2.0, 2.0 * np.abs(want_d))
+    close(-(z - q), -want_d)
+    close(z + q, TA @ (want_y / total) + want_y / total)
+    close(z - p, TA @ (want_y / total) - p0)                        # a vector in the caller's ids joins the expression
+    close(p - z, p0 - TA @ (want_y / total))
+    # negative entries: max / min do not see the zero padding of the id space
+    neg = pg.conv(x, MA) * -1.0
+    assert abs(pg.max(neg) - (-(TA @ x0)).max()) <= 1e-6 and abs(pg.min(neg) - (-(TA @ x0)).min()) <= 1e-6
+    assert abs(pg.sum(pg.abs(neg)) - np.abs(TA @ x0).sum()) <= 2e-6 * np.abs(TA @ x0).sum()
+    # the fallbacks evaluate in the caller's ids
+    close(pg.conv(x, MA) * p, (TA @ x0) * p0)
+    close(pg.conv(x, MA) / (p + 1.0), (TA @ x0) / (p0 + 1.0))
+    close(pg.conv(x, MA) + 1.0, (TA @ x0) + 1.0)
+    close(pg.conv(x, MA) ** 2, (TA @ x0) ** 2)
+    close(pg.conv(x, MA) > 0.1, ((TA @ x0) > 0.1).astype(np.float64))
+    close(pg.exp(pg.conv(x, MA)), np.exp(TA @ x0), 1e-5)
+    close(pg.conv(x, MA)[pg.to_array((p0 > 0.5).astype(np.float64))], (TA @ x0)[p0 > 0.5])
+    assert abs(pg.dot(pg.conv(x, MA), p) - (TA @ x0) @ p0) <= 1e-5 * abs((TA @ x0) @ p0)
+    assert abs(float(pg.conv(x, MA)[7]) - (TA @ x0)[7]) <= 1e-6
+    # two graphs: an expression of one graph is an ordinary vector to the other
+    close(pg.conv(pg.conv(x, MA), MB), TB @ (TA @ x0))
+    close(pg.conv(x, MA) + pg.conv(x, MB), TA @ x0 + TB @ x0)
+    close(pg.conv(x, MA) * 0.5 + pg.conv(p, MB) * 2.0, 0.5 * (TA @ x0) + 2.0 * (TB @ p0))
+    # an operand overwritten AFTER the expression was formed: the expression keeps the old values
+    w = pg.to_array(x0.copy())
+    e1, e2, e3 = w * 3.0, pg.conv(w, MA), pg.conv(x, MA) * 0.5 + w * 2.0
+    w[5] = 123.0
+    close(e1, 3.0 * x0)
+    close(e2, TA @ x0)
+    close(e3, 0.5 * (TA @ x0) + 2.0 * x0)
+    x5 = x0.copy()
+    x5[5] = 123.0
+    close(w, x5)
+    close(pg.conv(w, MA), TA @ x5)                                   # ... and the remembered resident copy of w went with the write
+    # item assignment into an expression: it becomes memory of its own
+    e = pg.conv(x, MA) * 2.0
+    e[3] = -1.0
+    want_e = 2.0 * (TA @ x0)
+    want_e[3] = -1.0
+    close(e, want_e)
+    close(e * 1.0 + pg.conv(x, MA), want_e + TA @ x0)
+    k = pg.copy(pg.conv(x, MA))
+    close(k, TA @ x0)
+    # a closed-form filter keeps the product as its next power: evaluated once, shared
+    term = pg.conv(x, MA)
+    result = p + term * 0.3
+    nxt = pg.conv(term, MA)
+    close(result, p0 + 0.3 * (TA @ x0))
+    close(nxt, TA @ (TA @ x0))
+    # a filter that never looks at its iterate nests one expression per step: the chain is evaluated before it can exhaust the stack
+    it, want_it = x, x0
+    for _ in range(1500):
+        it = pg.conv(it, MA) * 0.5 + p * 0.5
+        want_it = 0.5 * (TA @ want_it) + 0.5 * p0
+    close(it, want_it, 1e-5)
+    # the switch: every primitive evaluated where it stands
+    device.LAZY = False
+    try:
+        eager = pg.conv(x, MA) * 0.85 + p * 0.15
+        assert type(eager) is device.DeviceVector
+        close(eager, want_y)
+    finally:
+        device.LAZY = True
+
+
+def check_backend_primitive_route_is_one_step_per_formula(pg):
+    """The route the unmodified reference filters take (one backend primitive at a time): per PageRank iteration ONE engine step
+    (a * M^T x + b * p with sum(y)) and ONE residual, no pgh_spmv, nothing in the caller's ids until the result is looked at; a
+    closed-form filter: one step + one pgh_axpby per term.  Counted at the ctypes boundary."""
+    import collections
+    import cases
+    from pygrank_amd import _lib as L
+    A, directed, p = cases.GRAPHS["rmat10_dir"]()
+    graph = pg.AdjacencyWrapper(A, directed=directed)
+    pre = pg.preprocessor(assume_immutability=True)
+    lib = L.lib()
+    counts = collections.Counter()
+    watched = ("pgh_spmv", "pgh_resident_step", "pgh_resident_in", "pgh_resident_out", "pgh_resident_gather", "pgh_scaled_residual",
+               "pgh_residual", "pgh_axpby", "pgh_ewise_vv", "pgh_ewise_vs", "pgh_reduce")
+    originals = {name: getattr(lib, name) for name in watched}
+
+    def counted(name):
+        fn = originals[name]
+
+        def call(*args):
+            counts[name] += 1
+            return fn(*args)
+        return call
+    try:
+        for name in watched:
+            setattr(lib, name, counted(name))
+        for make, per_iteration in ((lambda: pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=1e-6, max_iters=1000),
+                                     dict(pgh_resident_step=1, pgh_scaled_residual=1)),
+                                    (lambda: pg.HeatKernel(5, preprocessor=pre, error_type="iters", max_iters=12), dict(pgh_resident_step=1, pgh_axpby=1))):
+            ranker = make()
+            ranker._fused_loop = lambda *a, **k: False
+            ranker._fused_rank = lambda *a, **k: None
+            sig = pg.to_signal(graph, p)
+            ranker.rank(graph, sig)                      # (the first run also uploads the graph)
+            counts.clear()
+            out = ranker.rank(graph, sig)
+            steps = ranker.convergence.iteration - 1
+            assert steps >= 8
+            assert counts["pgh_spmv"] == 0 and counts["pgh_resident_out"] == 0, dict(counts)      # nobody has looked yet
+            np.asarray(out.np)                           # (a filter that never looks at its iterate is evaluated here, or chain by chain)
+            assert counts["pgh_resident_out"] == 1
+            for name, each in per_iteration.items():
+                assert steps - 2 <= counts[name] <= steps * each + 1, (name, counts[name], steps)
+            assert counts["pgh_resident_in"] <= 3 and counts["pgh_ewise_vv"] <= 2 and counts["pgh_resident_gather"] <= 1, dict(counts)
+            fused = make()
+            want = np.asarray(fused.rank(graph, sig).np)
+            assert fused.convergence.iteration == ranker.convergence.iteration
+            assert np.max(np.abs(np.asarray(out.np) - want)) <= 1e-6 * np.max(np.abs(want))
+    finally:
+        for name, fn in originals.items():
+            setattr(lib, name, fn)
 
 
 def check_algorithms_describe_themselves(pg):
@@ -594,3 +757,6 @@ def check_algorithms_describe_themselves(pg):
     for algo in (pg.SymmetricAbsorbingRandomWalks(), pg.GenericGraphFilter([0.5, 0.5]), pg.PageRankClosed(0.7), pg.Top(3), pg.Threshold(0.1),
                  pg.Sweep(pg.PageRank()), pg.LinearSweep(pg.PageRank()), pg.Transformer(), pg.Tautology()):
         assert isinstance(str(algo), str) and len(str(algo)) > 3
+
+
+ALL = [v for k, v in sorted(globals().items()) if k.startswith("check_") and callable(v)]
