@@ -105,6 +105,13 @@ def measured_batch_traffic(scale, ef, width, batch_steps=11):
     return dict(measured_gb_per_step=round(total / working / 1e9, 2), measured_traffic_source=os.path.relpath(path, ROOT))
 
 
+def build_profile(lib, L):
+    """{phase: ms} of the last graph build (wall time per phase with the engine's stream drained behind each)."""
+    buf = C.create_string_buffer(4096)
+    L.check(lib.pgh_last_build_profile(buf, 4096))
+    return {k: round(float(v), 2) for k, v in (item.split("=") for item in buf.value.decode().split(";") if item)}
+
+
 def stream_ceiling_gbs(lib, L):
     """What a plain streaming copy reaches on this box right now (read + written bytes per second, engine's pgh_vec_copy on
     256 MB vectors): the practical HBM ceiling beside the 8 TB/s datasheet peak."""
@@ -168,6 +175,14 @@ def single_gpu(args):
     adj = rmat_graph(scale, ef, seed=0, normalization="col", **RMAT)
     L.check(lib.pgh_sync())
     build_s = time.time() - t0
+    build_ms = build_profile(lib, L)                 # where that first build of the process spent its time (pgh_last_build_profile)
+    # ... and the same build again: what a rank() pays from its second call on when the caller does not promise immutability
+    # (the reference's default: every rank() re-normalises and re-uploads, pygrank/core/utils/preprocessing.py:233-287)
+    t0 = time.time()
+    again = rmat_graph(scale, ef, seed=0, normalization="col", **RMAT)
+    L.check(lib.pgh_sync())
+    rebuild_s = time.time() - t0
+    del again
     g = adj.array
     n, nnz = g.shape[0], g.nnz
     out_deg = np.asarray(pg.degrees(g))              # row sums of M: > 0 <=> out-degree > 0
@@ -375,7 +390,7 @@ def single_gpu(args):
         config=dict(workload=f"single-GPU PPR on RMAT scale-{scale} ef-{ef} (BASELINE.json configs[1])", n=n, nnz=nnz,
                     alpha=ALPHA, tol=TOL, error_type="L1", seeds=SEEDS, iterations_per_step=iters,
                     spmv_per_step=spmv_total / args.steps, device_loop_ms_per_step=round(loop_ms_total / args.steps, 4),
-                    graph_build_s=round(build_s, 2), parallelism="1 GPU",
+                    graph_build_s=round(build_s, 3), graph_rebuild_s=round(rebuild_s, 3), graph_build_ms=build_ms, parallelism="1 GPU",
                     runs_with_a_paused_in_kernel_residual=paused),
         roofline=roofline, cpu_baseline=cpu, parity=parity, secondary=secondary)
 

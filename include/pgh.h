@@ -158,13 +158,24 @@ int pgh_graph_from_factored_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, con
  * inverses with zero degrees left zero (preprocessing.py:109-138) and M = diag(left) W diag(right) in fp64, in the
  * reference's evaluation order.  Bit-identical to the host route for integer weights (the sums are exact); for real
  * weights the row sums are accumulated in a different order than scipy's, i.e. values agree to 1 ulp of f32. */
-enum { PGH_NORM_COL = 0, PGH_NORM_SYMMETRIC = 1, PGH_NORM_NONE = 2, PGH_NORM_BOTH = 3 };
+enum { PGH_NORM_COL = 0, PGH_NORM_SYMMETRIC = 1, PGH_NORM_NONE = 2, PGH_NORM_BOTH = 3, PGH_NORM_LAPLACIAN = 4 };
 int pgh_graph_from_adjacency(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
                              const double* weights, int32_t normalization, int flags, pgh_graph_t* out);
+/* ... with the two steps of to_sparse_matrix that change the STRUCTURE, on the device too (SURVEY.md 8f-1 names the self-loop term):
+ *   self_loops != 0   the renormalisation trick, W <- W + self_loops * I BEFORE the degree reductions (preprocessing.py:107-108);
+ *   PGH_NORM_LAPLACIAN  M = I - Dl^-1/2 W Dr^-1/2 (preprocessing.py:114-122).
+ * Every row of the uploaded CSR gains its diagonal entries at its end; an entry the caller's row already holds on the diagonal stays a
+ * second entry of the same position (products and row sums add them; pgh_graph_download returns both).  Square adjacencies only. */
+int pgh_graph_from_adjacency_ex(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                                const double* weights, int32_t normalization, double self_loops, int flags, pgh_graph_t* out);
 int pgh_graph_destroy(pgh_graph_t g);
 int pgh_graph_info(pgh_graph_t g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* device_bytes);
 /* human-readable description of the layout the propagation kernels stream (bench.py reports it) */
 int pgh_graph_format(pgh_graph_t g, char* buf, int buflen);
+/* Where the LAST graph build of this process spent its time: "phase=ms;phase=ms;..." (wall time per phase, the engine's stream drained
+ * behind each).  The reference re-normalises and re-uploads on every rank() unless assume_immutability is set
+ * (pygrank/core/utils/preprocessing.py:233-287): time-to-first-rank is format build. */
+int pgh_last_build_profile(char* buf, int buflen);
 /* degrees(M): row sums of the un-transposed M, specification.py:105; numpy.py:76-77 */
 int pgh_graph_degrees(pgh_graph_t g, pgh_vec_t out);
 /* degrees of graph_dropout(M, rate): the row sums of M under the same (seed, entry) mask pgh_spmv_dropout applies -- the

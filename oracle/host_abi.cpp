@@ -525,6 +525,52 @@ int pgh_graph_from_adjacency(int64_t n_rows, int64_t n_cols, int64_t nnz, const 
     return pgh_graph_from_factored_csr(n_rows, n_cols, nnz, indptr, indices, weights.data(), use_left ? left.data() : nullptr,
                                        use_right ? right.data() : nullptr, flags, out);
 }
+int pgh_graph_from_adjacency_ex(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                                const double* w, int32_t normalization, double self_loops, int flags, pgh_graph_t* out) {
+    const bool laplacian = normalization == PGH_NORM_LAPLACIAN;
+    if (self_loops == 0.0 && !laplacian) return pgh_graph_from_adjacency(n_rows, n_cols, nnz, indptr, indices, w, normalization, flags, out);
+    CHECK(normalization >= 0 && normalization <= 4 && n_rows == n_cols, "pgh_graph_from_adjacency_ex: self-loops / the laplacian need a square adjacency");
+    // preprocessing.py:107-108: W + self_loops * I (a diagonal entry at the end of every row), then the reductions of :109-138
+    const int extra = (self_loops != 0.0 ? 1 : 0) + (laplacian ? 1 : 0);
+    std::vector<int64_t> ip(n_rows + 1, 0);
+    std::vector<int32_t> idx((size_t)(nnz + extra * n_rows));
+    std::vector<double> weights(idx.size());
+    for (int64_t r = 0; r < n_rows; ++r) {
+        int64_t at = indptr[r] + extra * r;
+        ip[r] = at;
+        for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k, ++at) {
+            idx[at] = indices[k];
+            weights[at] = w ? w[k] : 1.0;
+        }
+        if (self_loops != 0.0) {
+            idx[at] = (int32_t)r;
+            weights[at++] = self_loops;
+        }
+        if (laplacian) {
+            idx[at] = (int32_t)r;
+            weights[at++] = 0.0;                             // takes the +1 of the identity below
+        }
+    }
+    ip[n_rows] = nnz + extra * n_rows;
+    if (!laplacian) return pgh_graph_from_adjacency(n_rows, n_cols, ip[n_rows], ip.data(), idx.data(), weights.data(), normalization, flags, out);
+    std::vector<double> left(n_rows, 0.0), right(n_cols, 0.0);
+    for (int64_t r = 0; r < n_rows; ++r)
+        for (int64_t k = ip[r]; k < ip[r + 1]; ++k) {
+            left[r] += weights[k];
+            right[idx[k]] += weights[k];
+        }
+    for (auto* v : {&left, &right})
+        for (double& x : *v) {
+            x = std::sqrt(x);
+            if (x != 0.0) x = 1.0 / x;
+        }
+    std::vector<double> data(weights.size());
+    for (int64_t r = 0; r < n_rows; ++r) {
+        for (int64_t k = ip[r]; k < ip[r + 1]; ++k) data[k] = -((left[r] * weights[k]) * right[idx[k]]);      // preprocessing.py:121-122
+        data[ip[r + 1] - 1] = 1.0;
+    }
+    return pgh_graph_from_csr(n_rows, n_cols, ip[n_rows], ip.data(), idx.data(), data.data(), flags, out);
+}
 int pgh_graph_destroy(pgh_graph_t g) {
     delete g;
     return 0;
@@ -643,6 +689,11 @@ static const int64_t kResidentPad = 3;
 static bool resident_ok(const pgh_graph_s* g) {
     const char* e = getenv("PGH_RESIDENT");
     return g && g->n_rows == g->n_cols && g->gather_blk == 0 && g->n_cols > 0 && !(e != nullptr && atoi(e) == 0);
+}
+int pgh_last_build_profile(char* buf, int buflen) {
+    CHECK(buf && buflen > 0, "pgh_last_build_profile: null buffer");
+    buf[0] = 0;                                             // the double builds nothing worth timing
+    return 0;
 }
 int pgh_graph_resident_len(pgh_graph_t g, int64_t* n_int, int64_t* n_gather) {
     CHECK(g && n_int && n_gather, "pgh_graph_resident_len: null argument");

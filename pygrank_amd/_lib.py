@@ -20,7 +20,7 @@ c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)
 
 
-NORM_COL, NORM_SYMMETRIC, NORM_NONE, NORM_BOTH = 0, 1, 2, 3      # include/pgh.h PGH_NORM_*
+NORM_COL, NORM_SYMMETRIC, NORM_NONE, NORM_BOTH, NORM_LAPLACIAN = 0, 1, 2, 3, 4      # include/pgh.h PGH_NORM_*
 
 
 class LoopCfg(C.Structure):
@@ -119,9 +119,12 @@ SIGNATURES = {
                                               C.c_void_p, C.c_int, C.POINTER(c_graph)]),
     "pgh_graph_from_adjacency": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int,
                                            C.POINTER(c_graph)]),
+    "pgh_graph_from_adjacency_ex": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
+                                              C.c_int, C.POINTER(c_graph)]),
     "pgh_graph_destroy": (C.c_int, [c_graph]),
     "pgh_graph_info": (C.c_int, [c_graph, c_i64p, c_i64p, c_i64p, c_i64p]),
     "pgh_graph_format": (C.c_int, [c_graph, C.c_char_p, C.c_int]),
+    "pgh_last_build_profile": (C.c_int, [C.c_char_p, C.c_int]),
     "pgh_graph_degrees": (C.c_int, [c_graph, c_vec]),
     "pgh_graph_degrees_dropout": (C.c_int, [c_graph, C.c_double, C.c_uint64, c_vec]),
     "pgh_graph_download": (C.c_int, [c_graph, C.c_void_p, C.c_void_p, C.c_void_p]),

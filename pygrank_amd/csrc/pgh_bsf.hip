@@ -131,6 +131,33 @@ __global__ void k_bsf_keys(const int32_t* __restrict__ rowptr, const int32_t* __
     }
 }
 
+// ---- the same expansion, one thread per ENTRY (round 6).  k_bsf_keys gives a wavefront a row: a hub row of 10^5 entries is 1 600 serial
+// trips of one wavefront while half the rows are empty -- 50 ms for 10 GB at scale 23, a third of the build.  Here the row
+// of every entry is materialised first (its index scattered to the row's first entry, a running maximum spreads it: one scan), then
+// the expansion is a plain stream over the entries.
+__global__ void k_row_heads(const int32_t* __restrict__ rowptr, int64_t n_out, int32_t* __restrict__ row_of) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x)
+        if (rowptr[r + 1] > rowptr[r]) row_of[rowptr[r]] = (int32_t)r;        // (empty rows own no entry)
+}
+__global__ void k_bsf_keys_flat(const int32_t* __restrict__ row_of, const int32_t* __restrict__ col, const float* __restrict__ val,
+                                const int32_t* __restrict__ mult, const int64_t* __restrict__ offs, int64_t nnz,
+                                const int32_t* __restrict__ iperm_rows, const int32_t* __restrict__ iperm_cols, int blk,
+                                uint64_t* __restrict__ keys, float* __restrict__ vals_out) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t r = row_of[k];
+        const uint64_t nr = (uint64_t)(iperm_rows ? iperm_rows[r] : r);
+        const int c = iperm_cols ? iperm_cols[col[k]] : col[k];
+        const uint64_t key = ((uint64_t)(c / blk) << 58) | (nr << 29) | (uint64_t)c;
+        const int64_t o = offs ? offs[k] : k;
+        const int m = mult ? mult[k] : 1;
+        for (int q = 0; q < m; ++q) keys[o + q] = key;
+        if (vals_out) {
+            const float v = val[k];
+            for (int q = 0; q < m; ++q) vals_out[o + q] = v;
+        }
+    }
+}
+
 __global__ void k_bsf_sentinels(uint64_t* __restrict__ keys, int64_t first, int B, int n_src_pad) {
     const int b = threadIdx.x;
     // the sentinel's segment is never closed, so its product is irrelevant: it gathers from the block's first slot
@@ -1720,7 +1747,20 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_TRY(cnt.alloc(n_src, true));
         PGH_TRY(iperm.alloc(n_src));
         PGH_HIP(hipMalloc(&f.perm, sizeof(int32_t) * (size_t)n_src_pad));
-        if (nnz > 0) k_source_counts<<<blocks_for(nnz), kBlock, 0, r.stream>>>(g->col, mult, nnz, cnt.p);
+        // the reference count of every source: the caller's (the generator's out-degrees, an upload's row sums), the one an earlier image
+        // of this graph counted, or counted now and kept
+        const bool weighted = mult != nullptr;
+        if (g->src_counts != nullptr && g->src_counts_weighted == weighted) {
+            PGH_HIP(hipMemcpyAsync(cnt.p, g->src_counts, sizeof(unsigned int) * (size_t)n_src, hipMemcpyDeviceToDevice, r.stream));
+        } else {
+            if (nnz > 0) k_source_counts<<<blocks_for(nnz), kBlock, 0, r.stream>>>(g->col, mult, nnz, cnt.p);
+            if (g->src_counts == nullptr && n_src > 0 && hipMalloc(&g->src_counts, sizeof(unsigned int) * (size_t)n_src) == hipSuccess) {
+                PGH_HIP(hipMemcpyAsync(g->src_counts, cnt.p, sizeof(unsigned int) * (size_t)n_src, hipMemcpyDeviceToDevice, r.stream));
+                g->src_counts_weighted = weighted;
+                g->device_bytes += (int64_t)n_src * 4;
+            }
+        }
+        build_mark("image: source counts");
         // isolated nodes (never referenced, empty row) sort last: the rows [iso_begin[b], blk) of every block b hold nothing
         // and are referenced by nothing -- they change only through the personalization (k_pb_finish, k_step_residual)
         DevBuf<unsigned int> key, live_count;
@@ -1740,6 +1780,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipMemcpyAsync(&live_nodes, live_count.p, sizeof(unsigned int), hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
         f.live_nodes = iso_on ? (int64_t)live_nodes : -1;
+        build_mark("image: relabelling (sort by count)");
         for (int b = 0; b < B && b < 8; ++b) {
             // the first slot of block b whose rank is isolated (ranks ascend with the slot: deal_rank_of), rounded up to whole float4s
             const int64_t first_iso = deal_first_slot((int64_t)live_nodes, b, B, blk, f.deal_head);
@@ -1779,6 +1820,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipStreamSynchronize(r.stream));
         E = last_off + last_m;
     }
+    build_mark("image: expansion offsets");
     E += B;                                            // one sentinel per block
     PGH_CHECK(E < 2147483647LL, "blocked format: more than 2^31 entries in one graph; partition it (SURVEY.md 8e)");
     DevBuf<uint64_t> keys_a, keys_b;
@@ -1790,12 +1832,30 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_TRY(vals_a.alloc(E, true));
         PGH_HIP(hipMalloc(&f.val, sizeof(float) * (size_t)E));
     }
-    if (nnz > 0)
-        k_bsf_keys<<<blocks_for(n_out * 64), kBlock, 0, r.stream>>>(g->rowptr, g->col, val, mult, offs.p, n_out,
-                                                                    relabel ? iperm.p : nullptr, relabel ? iperm.p : nullptr, blk,
-                                                                    keys_a.p, val ? vals_a.p : nullptr);
+    if (nnz > 0) {
+        if (env_int("PGH_KEYS_BY_ROW", 0) != 0) {          // the round 1-5 expansion (A/B measurements)
+            k_bsf_keys<<<blocks_for(n_out * 64), kBlock, 0, r.stream>>>(g->rowptr, g->col, val, mult, offs.p, n_out,
+                                                                        relabel ? iperm.p : nullptr, relabel ? iperm.p : nullptr, blk,
+                                                                        keys_a.p, val ? vals_a.p : nullptr);
+        } else {
+            // keys_b is free until the sort: its first nnz words hold the row of every entry
+            int32_t* row_of = reinterpret_cast<int32_t*>(keys_b.p);
+            int32_t* row_scan = row_of + nnz;              // (2 nnz words of 4 bytes fit the E >= nnz + 1 words of 8)
+            PGH_HIP(hipMemsetAsync(row_of, 0, sizeof(int32_t) * (size_t)nnz, r.stream));
+            k_row_heads<<<blocks_for(n_out), kBlock, 0, r.stream>>>(g->rowptr, n_out, row_of);
+            size_t temp_bytes = 0;
+            PGH_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, temp_bytes, row_of, row_scan, hipcub::Max(), (int)nnz, r.stream));
+            DevBuf<char> temp;
+            PGH_TRY(temp.alloc(temp_bytes));
+            PGH_HIP(hipcub::DeviceScan::InclusiveScan(temp.p, temp_bytes, row_of, row_scan, hipcub::Max(), (int)nnz, r.stream));
+            k_bsf_keys_flat<<<blocks_for(nnz), kBlock, 0, r.stream>>>(row_scan, g->col, val, mult, offs.p, nnz, relabel ? iperm.p : nullptr,
+                                                                      relabel ? iperm.p : nullptr, blk, keys_a.p, val ? vals_a.p : nullptr);
+            PGH_HIP(hipStreamSynchronize(r.stream));       // (temp goes out of scope)
+        }
+    }
     k_bsf_sentinels<<<1, 64, 0, r.stream>>>(keys_a.p, E - B, B, n_src_pad);
     PGH_HIP(hipGetLastError());
+    build_mark("image: entry keys");
     {
         const int sort_bits = B > 8 ? 64 : 61;             // block id from bit 58 up
         size_t temp_bytes = 0;
@@ -1807,6 +1867,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         else PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)E, 0, sort_bits, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
+    build_mark("image: entry sort");
     // ---- referenced prefix of every block (over ALL entries), then the cold tail moves to its own image (pgh_pb.hip)
     int live_all[kMaxBlocks] = {0};
     {
@@ -1816,6 +1877,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipMemcpyAsync(live_all, d_live.p, sizeof(live_all), hipMemcpyDeviceToHost, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
+    build_mark("image: referenced prefixes");
     const int hot_slots = kBsfHot < blk ? kBsfHot : blk;
     if (!batch_layout && hot_slots < blk && E > B) {
         DevBuf<unsigned char> is_hot;
@@ -1826,6 +1888,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PbPlan plan;
         bool use_pb = false;
         PGH_TRY(pb_plan(f, keys_b.p, E, live_all, hot_slots, is_hot.p, &plan, &use_pb));   // may keep heavy rows in the stream
+        build_mark("cold image: plan");
         if (use_pb) {
             size_t temp_bytes = 0;
             PGH_HIP(hipcub::DevicePartition::Flagged(nullptr, temp_bytes, keys_b.p, is_hot.p, keys_a.p, num_hot.p, (int)E, r.stream));
@@ -1840,6 +1903,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
                 PGH_HIP(hipcub::DevicePartition::Flagged(temp.p, temp_bytes, f.val, is_hot.p, vals_a.p, num_hot.p, (int)E, r.stream));
                 PGH_HIP(hipStreamSynchronize(r.stream));
             }
+            build_mark("cold image: hot / cold split");
             int rc_pb = 0;
             {
                 // the image is built slice by slice: the slice's entries are compacted out of the cold keys first
@@ -1858,6 +1922,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
             }
             pb_plan_release(&plan);
             PGH_TRY(rc_pb);
+            build_mark("cold image: build (schedules)");
             std::swap(keys_a.p, keys_b.p);                 // keys_b: the stream's entries, still sorted by (block, row, col)
             if (val) std::swap(f.val, vals_a.p);
             E = E_hot;
@@ -1904,6 +1969,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
     if (val) (void)hipFree(val_sorted);
+    build_mark("stream: tiles and padding");
     keys_b.~DevBuf<uint64_t>();
     new (&keys_b) DevBuf<uint64_t>();
     PGH_HIP(hipMalloc(&f.colf, sizeof(uint32_t) * (size_t)EP));
@@ -1937,6 +2003,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     PGH_HIP(hipMemsetAsync(f.tail_carry, 0, sizeof(double) * (size_t)(f.num_tiles + 1), r.stream));
     PGH_HIP(hipMemsetAsync(f.head_partial, 0, sizeof(double) * (size_t)(f.num_tiles + 1), r.stream));
     k_bsf_tiles<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(tb, segid.p, f.tile);
+    build_mark("stream: flags, segments, tile table");
     // ---- work buffers and scales
     const size_t n_int = (size_t)(f.n_out > 0 ? f.n_out : 1);
     if (!batch_layout) {
@@ -2030,7 +2097,10 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         f.device_bytes += (int64_t)f.num_tiles * 64;
     }
     f.enabled = true;
+    build_mark("stream: packing, buffers, scales");
     return 0;
 }
 
 }  // namespace pgh
+
+PGH_WARM_KERNEL(k_row_heads)

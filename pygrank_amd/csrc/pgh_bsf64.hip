@@ -631,3 +631,5 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
 }
 
 }  // namespace pgh
+
+PGH_WARM_KERNEL(k_bsf64_fixlist)

@@ -63,6 +63,20 @@ int ensure_init();
 // h_scalars[first .. first + count) <- d_scalars[first .. first + count) once everything enqueued on the engine's stream has run
 // (count <= 7); PGH_MAILBOX=0: the copy + stream synchronisation of rounds 1-5
 int scalars_to_host(int first, int count);
+// Where a graph build spends its time (pgh_last_build_profile, include/pgh.h): build_clock_reset() at the start of a build,
+// build_mark(label) behind every phase -- it waits for the engine's stream and adds the wall time since the previous mark to `label`.
+// Code objects are loaded lazily, per translation unit, by the first launch out of it: 5-25 ms each, paid inside the first graph build of
+// a process (measured: 186 ms for the first scale-23 build against 87 ms for the second).  Every translation unit registers one of its
+// kernels; pgh_init resolves them all (hipFuncGetAttributes), so the load happens at backend_init and not inside the first rank().
+void register_warm_kernel(const void* kernel);
+#define PGH_WARM_KERNEL(KERNEL)                                                                  \
+    namespace {                                                                                  \
+    struct WarmRegistration {                                                                    \
+        WarmRegistration() { ::pgh::register_warm_kernel(reinterpret_cast<const void*>(&KERNEL)); } \
+    } g_warm_registration;                                                                       \
+    }
+void build_clock_reset();
+void build_mark(const char* label);
 
 // Stream-ordered caching allocator for vectors, slabs and loop work buffers.  hipMalloc / hipFree synchronise the
 // device and cost 100+ us each; a PageRank run allocates ~10 n-vectors.  A released block is reused by the next
@@ -344,6 +358,11 @@ struct pgh_graph_s {
     BsfFormat bsf_mm;
     // f64 image of the "chebyshev" recurrence (pgh_bsf64.hip): 8 XCD-affine blocks, cold entries in the stream, built on first use
     BsfFormat bsf64;
+    // reference count of every source (multiplicities included on value-free graphs): the relabelling key of every image.  Handed in
+    // by whoever already has it (the generator: its out-degrees; an upload: row sums over the caller's CSR(M)), else counted once
+    // (k_source_counts) and kept for the images built later (f64, multi-seed, dropout index words).  [n_rows] or null.
+    unsigned int* src_counts = nullptr;
+    bool          src_counts_weighted = false;   // counted with multiplicities (value-free images) or per entry (valued images)
     int32_t*  keep_mult = nullptr;   // [nnz] edge multiplicities of the value-free factorisation (generator graphs)
     float*    keep_src = nullptr;    // [n_rows] source scale, caller id space
     float*    keep_dst = nullptr;    // [n_cols] output scale

@@ -1159,3 +1159,5 @@ extern "C" int pgh_dist_set_timeout(double seconds) {
     wait_limit_s() = seconds > 0.0 ? seconds : default_wait_limit_s();
     return 0;
 }
+
+PGH_WARM_KERNEL(k_scale_into)

@@ -44,6 +44,26 @@ __global__ void k_row_sums(const int64_t* __restrict__ indptr, const double* __r
     }
 }
 
+// reference count of every source from the caller's CSR(M): the entries of its row, multiplicities summed on value-free graphs
+// (what k_source_counts would count with global atomics over CSR(M^T))
+__global__ void k_row_counts(const int64_t* __restrict__ indptr, const int32_t* __restrict__ mult, int64_t n_rows, unsigned int* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    if (mult == nullptr) {
+        for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+            cnt[r] = (unsigned int)(indptr[r + 1] - indptr[r]);
+        return;
+    }
+    for (int64_t r = wave; r < n_rows; r += nwaves) {
+        const int64_t b = indptr[r], e = indptr[r + 1];
+        double acc = 0.0;
+        for (int64_t k = b + lane; k < e; k += 64) acc += (double)mult[k];
+        acc = wave_reduce_sum(acc);
+        if (lane == 0) cnt[r] = (unsigned int)acc;
+    }
+}
+
 // expand CSR(M) into sort keys (col << 32 | row) and f32 values
 __global__ void k_make_keys(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                             const double* __restrict__ data, int64_t n_rows, uint64_t* __restrict__ keys,
@@ -199,6 +219,39 @@ __global__ void k_apply_factors(const int64_t* __restrict__ indptr, const int32_
     }
 }
 
+// W + self_loops * I and the identity of the laplacian (pgh_graph_from_adjacency_ex): row r of the augmented CSR keeps its entries and
+// gains `extra` diagonal entries at its end (weights w0, w1); indptr2[r] = indptr[r] + extra * r
+__global__ void k_augment_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const double* __restrict__ data,
+                               int64_t n_rows, int extra, double w0, double w1, int64_t* __restrict__ indptr2, int32_t* __restrict__ indices2,
+                               double* __restrict__ data2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_rows; r += nwaves) {
+        const int64_t b = indptr[r], e = indptr[r + 1], shift = (int64_t)extra * r;
+        for (int64_t k = b + lane; k < e; k += 64) {
+            indices2[k + shift] = indices[k];
+            data2[k + shift] = data[k];
+        }
+        if (lane < extra) {
+            indices2[e + shift + lane] = (int32_t)r;
+            data2[e + shift + lane] = lane == 0 ? w0 : w1;
+        }
+        if (lane == 0) {
+            indptr2[r] = b + shift;
+            if (r == n_rows - 1) indptr2[n_rows] = e + shift + extra;
+        }
+    }
+}
+// M = I - N (preprocessing.py:122): every value negated, the last entry of every row (the placeholder k_augment_rows appended) is the 1
+__global__ void k_laplacian_finish(const int64_t* __restrict__ indptr, double* __restrict__ data, int64_t n_rows, int64_t nnz) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += stride) data[k] = -data[k];
+}
+__global__ void k_laplacian_ones(const int64_t* __restrict__ indptr, double* __restrict__ data, int64_t n_rows) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) data[indptr[r + 1] - 1] = 1.0;
+}
+
 // expand CSR(M) into sort keys (col << 32 | row) with the entry index as payload
 __global__ void k_make_keys_idx(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t n_rows,
                                 uint64_t* __restrict__ keys, int32_t* __restrict__ idx) {
@@ -285,12 +338,16 @@ struct PartSpec {
     int32_t        num_blocks;
     const int32_t* perm;        // host, [n_rows] new id -> original id (-1 = padding)
 };
-int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const int64_t* indptr, const int32_t* indices,
                         const double* data, bool factored, const double* left, const double* right, int device_norm,
-                        pgh_graph_t* out, const PartSpec* part = nullptr) {
+                        pgh_graph_t* out, const PartSpec* part = nullptr, double self_loops = 0.0) {
+    int64_t nnz = nnz_in;             // (grows by the diagonal entries of pgh_graph_from_adjacency_ex)
+    const bool laplacian = device_norm == PGH_NORM_LAPLACIAN;
+    const int extra_diag = (self_loops != 0.0 ? 1 : 0) + (laplacian ? 1 : 0);
+    PGH_CHECK(extra_diag == 0 || (n_rows == n_cols && device_norm >= 0), "pgh_graph_from_adjacency_ex: self-loops / the laplacian need a square adjacency");
     PGH_TRY(ensure_init());
     PGH_CHECK(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "pgh_graph_from_csr: negative size");
-    PGH_CHECK(n_rows < 2147483647LL && n_cols < 2147483647LL && nnz < 2147483647LL,
+    PGH_CHECK(n_rows < 2147483647LL && n_cols < 2147483647LL && nnz + extra_diag * n_rows < 2147483647LL,
               "pgh_graph_from_csr: int32 index space exceeded; row-partition the graph (SURVEY.md 8e)");
     PGH_CHECK(indptr != nullptr && (nnz == 0 || (indices && (data || device_norm >= 0))), "pgh_graph_from_csr: null array");
     PGH_CHECK(indptr[0] == 0 && indptr[n_rows] == nnz, "pgh_graph_from_csr: indptr does not match nnz");
@@ -299,6 +356,7 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
     g->n_rows = n_rows;
     g->n_cols = n_cols;
     g->nnz = nnz;
+    build_clock_reset();
     int rc = [&]() -> int {
         DevBuf<int64_t> d_indptr;
         DevBuf<int32_t> d_indices, d_mult, idx_a, idx_b, mult_t;
@@ -325,6 +383,26 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
             PGH_CHECK((h_bad & 1u) == 0, "pgh_graph_from_csr: indptr is not non-decreasing within [0, nnz]");
             PGH_CHECK((h_bad & 2u) == 0, "pgh_graph_from_csr: a column index lies outside [0, n_cols)");
         }
+        if (extra_diag > 0 && n_rows > 0) {
+            const int64_t nnz2 = nnz + (int64_t)extra_diag * n_rows;
+            DevBuf<int64_t> ip2;
+            DevBuf<int32_t> idx2;
+            DevBuf<double> data2;
+            PGH_TRY(ip2.alloc(n_rows + 1));
+            PGH_TRY(idx2.alloc(nnz2));
+            PGH_TRY(data2.alloc(nnz2));
+            // (the laplacian's identity rides along as a zero weight: no sum sees it; k_laplacian_ones makes it the 1 after the scaling)
+            k_augment_rows<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, d_data.p, n_rows, extra_diag,
+                                                                             self_loops != 0.0 ? self_loops : 0.0, 0.0, ip2.p, idx2.p, data2.p);
+            PGH_HIP(hipGetLastError());
+            PGH_HIP(hipStreamSynchronize(r.stream));
+            std::swap(d_indptr.p, ip2.p);
+            std::swap(d_indices.p, idx2.p);
+            std::swap(d_data.p, data2.p);
+            nnz = nnz2;
+            g->nnz = nnz;
+        }
+        build_mark("upload: host arrays to HBM, validation");
         PGH_HIP(hipMalloc(&g->degrees, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
         PGH_HIP(hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_cols + 1)));
         PGH_HIP(hipMalloc(&g->col, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
@@ -351,14 +429,15 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
             k_fill_i32<<<blocks_for(n_cols + 1), kBlock, 0, r.stream>>>(g->rowptr, n_cols + 1, 0);
             PGH_HIP(hipGetLastError());
         }
+        build_mark("upload: transposition (sort by column)");
         // ---- scale vectors
         bool have_left = left != nullptr, have_right = right != nullptr;
         if (factored && device_norm >= 0) {
             // to_sparse_matrix's normalisations evaluated in HBM (preprocessing.py:109-138): left from the row sums of W,
             // right from its column sums (rows of the transposed structure); zero-degree rows / columns stay zero
-            have_left = device_norm == PGH_NORM_COL || device_norm == PGH_NORM_SYMMETRIC || device_norm == PGH_NORM_BOTH;
-            have_right = device_norm == PGH_NORM_SYMMETRIC || device_norm == PGH_NORM_BOTH;
-            const int take_sqrt = device_norm == PGH_NORM_SYMMETRIC;
+            have_left = device_norm == PGH_NORM_COL || device_norm == PGH_NORM_SYMMETRIC || device_norm == PGH_NORM_BOTH || laplacian;
+            have_right = device_norm == PGH_NORM_SYMMETRIC || device_norm == PGH_NORM_BOTH || laplacian;
+            const int take_sqrt = device_norm == PGH_NORM_SYMMETRIC || laplacian;
             if (have_left) {
                 PGH_TRY(d_left.alloc(n_rows));
                 if (n_rows > 0) {
@@ -401,7 +480,18 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
             const char* vf = getenv("PGH_VALUES");
             if (vf != nullptr && atoi(vf) != 0) value_free = false;
         }
+        if (laplacian && n_rows > 0) {                        // M = I - N: the values negated, the placeholders of the diagonal become 1
+            k_laplacian_finish<<<blocks_for(nnz), kBlock, 0, r.stream>>>(d_indptr.p, d_data.p, n_rows, nnz);
+            k_laplacian_ones<<<blocks_for(n_rows), kBlock, 0, r.stream>>>(d_indptr.p, d_data.p, n_rows);
+            value_free = false;
+        }
         if (n_rows > 0) k_row_sums<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_data.p, n_rows, g->degrees);
+        if (part == nullptr && n_rows > 0 && n_rows == n_cols && hipMalloc(&g->src_counts, sizeof(unsigned int) * (size_t)n_rows) == hipSuccess) {
+            // the relabelling key of the images (bsf_build), from the rows of the caller's matrix: no histogram over the entries
+            g->src_counts_weighted = value_free;
+            k_row_counts<<<blocks_for(value_free ? n_rows * 64 : n_rows), kBlock, 0, r.stream>>>(d_indptr.p, value_free ? d_mult.p : nullptr, n_rows,
+                                                                                              g->src_counts);
+        }
         if (nnz > 0) {
             if (value_free) PGH_TRY(mult_t.alloc(nnz));
             k_gather_vals<<<blocks_for(nnz), kBlock, 0, r.stream>>>(idx_b.p, d_data.p, value_free ? d_mult.p : nullptr, nnz, g->val,
@@ -409,7 +499,9 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64
             PGH_HIP(hipGetLastError());
         }
         PGH_HIP(hipStreamSynchronize(r.stream));
+        build_mark("upload: normalisation, values of CSR(M^T)");
         PGH_TRY(finish_graph(g));
+        build_mark("row-major tile table");
         // the layout the propagation kernels stream (PGH_FORMAT=csr keeps only the row-major merge-path route)
         const char* fmt = getenv("PGH_FORMAT");
         if (fmt == nullptr || std::string(fmt) != "csr") {
@@ -490,6 +582,15 @@ extern "C" int pgh_graph_from_adjacency(int64_t n_rows, int64_t n_cols, int64_t 
     return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, weights, true, nullptr, nullptr, normalization, out);
 }
 
+extern "C" int pgh_graph_from_adjacency_ex(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                                           const double* weights, int32_t normalization, double self_loops, int flags, pgh_graph_t* out) {
+    (void)flags;
+    PGH_CHECK(normalization >= PGH_NORM_COL && normalization <= PGH_NORM_LAPLACIAN, "pgh_graph_from_adjacency_ex: unknown normalization");
+    PGH_CHECK(normalization == PGH_NORM_NONE || normalization == PGH_NORM_COL || n_rows == n_cols,
+              "pgh_graph_from_adjacency_ex: symmetric / both / laplacian normalisation needs a square adjacency");
+    return graph_from_csr_impl(n_rows, n_cols, nnz, indptr, indices, weights, true, nullptr, nullptr, normalization, out, nullptr, self_loops);
+}
+
 extern "C" int pgh_graph_destroy(pgh_graph_t g) {
     if (!g) return 0;
     if (rt().initialised) (void)hipStreamSynchronize(rt().stream);
@@ -505,6 +606,7 @@ extern "C" int pgh_graph_destroy(pgh_graph_t g) {
     bsf_destroy(g->bsf_mm);
     bsf_destroy(g->bsf64);
     (void)hipFree(g->keep_mult);
+    (void)hipFree(g->src_counts);
     (void)hipFree(g->keep_src);
     (void)hipFree(g->keep_dst);
     (void)hipFree(g->part_perm);
@@ -600,3 +702,5 @@ extern "C" int pgh_filter_out(pgh_vec_t x, pgh_vec_t exclude, pgh_vec_t out, int
     *out_len = count;
     return 0;
 }
+
+PGH_WARM_KERNEL(k_row_sums)

@@ -131,6 +131,21 @@ __global__ void k_rmat_fill(RmatParams P, uint64_t* __restrict__ keys, unsigned 
     }
 }
 
+// ---- degrees without global atomics (round 6; whole-graph generation): the edge list sorted by one end, run lengths = degrees.
+// k_rmat_count / k_indeg add one global atomic per edge into counters whose hubs take a large share of them: 17 + 19 ms of a 0.24-s
+// build at scale 23 against ~4 + ~1 ms for a 32-bit sort + run-length encode / a run-length encode of the already sorted rows.
+struct HiWord {
+    __host__ __device__ __forceinline__ uint32_t operator()(const uint64_t& k) const { return (uint32_t)(k >> 32); }
+};
+__global__ void k_low_words(const uint64_t* __restrict__ keys, int64_t count, uint32_t* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)(keys[i] & 0xffffffffu);
+}
+__global__ void k_scatter_runs(const uint32_t* __restrict__ ids, const int* __restrict__ lengths, const int* __restrict__ num_runs,
+                               unsigned int* __restrict__ out) {
+    const int runs = *num_runs;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < runs; i += gridDim.x * blockDim.x) out[ids[i]] = (unsigned int)lengths[i];
+}
+
 // in-degree weights of the local rows from the run-length encoded keys
 __global__ void k_indeg(const uint64_t* __restrict__ ukeys, const int* __restrict__ counts, int64_t nnz,
                         unsigned int* __restrict__ indeg) {
@@ -272,6 +287,7 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
     g->n_rows = n;          // rows of M = sources = length of the gathered vector
     g->n_cols = n_local;    // rows of the stored M^T slice = length of the output
     g->row_begin = row_begin;
+    build_clock_reset();
     int rc = [&]() -> int {
         DevBuf<unsigned int> outdeg, indeg;
         DevBuf<unsigned long long> counters;
@@ -305,12 +321,17 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
             PGH_HIP(hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * 2, r.stream));
             P.iperm = iperm.p;
         }
-        k_rmat_count<<<blocks_for(P.num_edges), kBlock, 0, r.stream>>>(P, outdeg.p, counters.p);
-        PGH_HIP(hipGetLastError());
-        unsigned long long kept = 0;
-        PGH_HIP(hipMemcpyAsync(&kept, counters.p, sizeof(kept), hipMemcpyDeviceToHost, r.stream));
-        PGH_HIP(hipStreamSynchronize(r.stream));
+        // whole graph, ids as generated: every edge is kept and the degrees come from sorted runs below (no atomic per edge)
+        const bool by_runs = dense && P.num_edges < 2147483647LL && !(getenv("PGH_RMAT_ATOMICS") != nullptr && atoi(getenv("PGH_RMAT_ATOMICS")) != 0);
+        unsigned long long kept = (unsigned long long)P.num_edges;
+        if (!by_runs) {
+            k_rmat_count<<<blocks_for(P.num_edges), kBlock, 0, r.stream>>>(P, outdeg.p, counters.p);
+            PGH_HIP(hipGetLastError());
+            PGH_HIP(hipMemcpyAsync(&kept, counters.p, sizeof(kept), hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipStreamSynchronize(r.stream));
+        }
         PGH_CHECK(kept < 2147483647ULL, "pgh_graph_rmat: more than 2^31 edges in one partition; use more partitions");
+        build_mark("generator: out-degrees");
         const int64_t K = (int64_t)kept;
         int64_t nnz = 0;
         PGH_HIP(hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_local + 1)));
@@ -319,8 +340,32 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
         if (K > 0) {
             PGH_TRY(keys_a.alloc(K));
             PGH_TRY(keys_b.alloc(K));
+            build_mark("generator: allocations");
             k_rmat_fill<<<blocks_for(P.num_edges), kBlock, 0, r.stream>>>(P, keys_a.p, counters.p + 1, dense ? 1 : 0);
             PGH_HIP(hipGetLastError());
+            build_mark("generator: edge keys");
+            DevBuf<uint32_t> run_ids;
+            DevBuf<int> run_lengths, run_count;
+            if (by_runs) {
+                // out-degrees: the sources alone (low words), sorted on `scale` bits, run lengths scattered to their ids
+                PGH_TRY(run_ids.alloc(n));
+                PGH_TRY(run_lengths.alloc(n));
+                PGH_TRY(run_count.alloc(1));
+                uint32_t* words = reinterpret_cast<uint32_t*>(keys_b.p);           // keys_b is free until the edge sort: 2 K words of 4 bytes
+                uint32_t* words_sorted = words + K;
+                k_low_words<<<blocks_for(K), kBlock, 0, r.stream>>>(keys_a.p, K, words);
+                size_t bytes_sort = 0, bytes_rle = 0;
+                PGH_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes_sort, words, words_sorted, (int)K, 0, scale, r.stream));
+                PGH_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes_rle, words_sorted, run_ids.p, run_lengths.p, run_count.p, (int)K, r.stream));
+                DevBuf<char> temp;
+                PGH_TRY(temp.alloc(bytes_sort > bytes_rle ? bytes_sort : bytes_rle));
+                PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, bytes_sort, words, words_sorted, (int)K, 0, scale, r.stream));
+                PGH_HIP(hipcub::DeviceRunLengthEncode::Encode(temp.p, bytes_rle, words_sorted, run_ids.p, run_lengths.p, run_count.p, (int)K, r.stream));
+                k_scatter_runs<<<blocks_for(n), kBlock, 0, r.stream>>>(run_ids.p, run_lengths.p, run_count.p, outdeg.p);
+                PGH_HIP(hipGetLastError());
+                PGH_HIP(hipStreamSynchronize(r.stream));
+                build_mark("generator: out-degrees");
+            }
             int bits_row = 1;
             while ((1LL << bits_row) < n_local) ++bits_row;
             size_t temp_bytes = 0;
@@ -330,6 +375,20 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
                 PGH_TRY(temp.alloc(temp_bytes));
                 PGH_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)K, 0, 32 + bits_row, r.stream));
                 PGH_HIP(hipStreamSynchronize(r.stream));
+            }
+            build_mark("generator: edge sort");
+            if (by_runs) {
+                // in-degrees: the rows (high words) of the sorted edge list, run-length encoded
+                hipcub::TransformInputIterator<uint32_t, HiWord, const uint64_t*> rows(keys_b.p, HiWord());
+                size_t bytes_rle = 0;
+                PGH_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes_rle, rows, run_ids.p, run_lengths.p, run_count.p, (int)K, r.stream));
+                DevBuf<char> temp;
+                PGH_TRY(temp.alloc(bytes_rle));
+                PGH_HIP(hipcub::DeviceRunLengthEncode::Encode(temp.p, bytes_rle, rows, run_ids.p, run_lengths.p, run_count.p, (int)K, r.stream));
+                k_scatter_runs<<<blocks_for(n), kBlock, 0, r.stream>>>(run_ids.p, run_lengths.p, run_count.p, indeg.p);
+                PGH_HIP(hipGetLastError());
+                PGH_HIP(hipStreamSynchronize(r.stream));
+                build_mark("generator: in-degrees");
             }
             // run-length encode duplicates into weights; keys_a is reused for the unique keys
             PGH_TRY(counts.alloc(K));
@@ -345,9 +404,10 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
                 PGH_HIP(hipStreamSynchronize(r.stream));
                 nnz = runs;
             }
+            build_mark("generator: run lengths");
             PGH_HIP(hipMalloc(&g->col, sizeof(int32_t) * (size_t)nnz));
             PGH_HIP(hipMalloc(&g->val, sizeof(float) * (size_t)nnz));
-            k_indeg<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_a.p, counts.p, nnz, indeg.p);
+            if (!by_runs) k_indeg<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_a.p, counts.p, nnz, indeg.p);
             k_rmat_values<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_a.p, counts.p, nnz, n_local, normalization, outdeg.p,
                                                                     indeg.p, g->col, g->val, g->rowptr, deg_acc.p);
             PGH_HIP(hipGetLastError());
@@ -360,7 +420,9 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
         k_f64_to_f32<<<blocks_for(n), kBlock, 0, r.stream>>>(deg_acc.p, g->degrees, n);
         PGH_HIP(hipGetLastError());
         PGH_HIP(hipStreamSynchronize(r.stream));
+        build_mark("generator: values of CSR(M^T), row sums of M");
         PGH_TRY(finish_graph(g));
+        build_mark("row-major tile table");
         // blocked value-free layout: multiplicities as repeated entries, the normalisation as vector scales
         const char* fmt = getenv("PGH_FORMAT");
         if (nnz > 0 && (fmt == nullptr || std::string(fmt) != "csr")) {
@@ -373,6 +435,11 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
                 k_rmat_scales<<<blocks_for(n), kBlock, 0, r.stream>>>(outdeg.p, indeg.p, n, n_local, normalization, src.p,
                                                                       normalization == 1 ? dst.p : nullptr);
                 PGH_HIP(hipGetLastError());
+                if (part_count == 0 && row_begin == 0 && row_end == n && !symmetrize) {
+                    // every generated edge references its source once: the out-degrees ARE the relabelling's reference counts
+                    g->src_counts = outdeg.release();
+                    g->src_counts_weighted = true;
+                }
                 PGH_TRY(bsf_build(g, nullptr, counts.p, normalization == 2 ? nullptr : src.p,
                                   normalization == 1 ? dst.p : nullptr, part_count == 0 && (rl == nullptr || atoi(rl) != 0),
                                   part_blocks));
@@ -407,3 +474,5 @@ extern "C" int pgh_graph_rmat_part(int32_t scale, int32_t edge_factor, double a,
     PGH_CHECK(part_count >= 1, "pgh_graph_rmat_part: part_count must be >= 1");
     return rmat_build(scale, edge_factor, a, b, c, seed, normalization, symmetrize, 0, 0, part_rank, part_count, out);
 }
+
+PGH_WARM_KERNEL(k_low_words)

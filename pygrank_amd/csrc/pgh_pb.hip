@@ -132,6 +132,44 @@ inline int pb_blocks_for(int64_t n) {
 }
 
 // ------------------------------------------------------------------------------------------------- build kernels
+// The planner's input and output without two n-word transfers (round 6): the per-row cold counts go to the host as BYTES (255 = "look
+// me up": the few rows with more are listed beside them), and the row -> bin map is made on the device from the bins' first rows.
+__global__ void k_pb_counts_small(const uint32_t* __restrict__ counts, int n_out, unsigned char* __restrict__ small, uint32_t* __restrict__ big_rows,
+                                  uint32_t* __restrict__ big_counts, uint32_t* __restrict__ big_n, uint32_t cap) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += gridDim.x * blockDim.x) {
+        const uint32_t c = counts[i];
+        small[i] = (unsigned char)(c < 255u ? c : 255u);
+        if (c >= 255u) {
+            const uint32_t at = atomicAdd(big_n, 1u);
+            if (at < cap) {
+                big_rows[at] = (uint32_t)i;
+                big_counts[at] = c;
+            }
+        }
+    }
+}
+// row_bin[i] = the bin that starts at row i (the first piece of a hub row), else the bin that started before it (bins ascend by first row)
+__global__ void k_pb_row_bin(const int32_t* __restrict__ first_row, int num_bins, int n_out, int32_t* __restrict__ row_bin) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += gridDim.x * blockDim.x) {
+        int lo = 0, hi = num_bins;                     // first bin whose first row is >= i
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (first_row[mid] < i) lo = mid + 1;
+            else hi = mid;
+        }
+        row_bin[i] = (lo < num_bins && first_row[lo] == i) ? lo : (lo > 0 ? lo - 1 : 0);
+    }
+}
+__global__ void k_pb_rows_unbinned(const int32_t* __restrict__ rows, int count, int32_t* __restrict__ row_bin) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) row_bin[rows[i]] = -1;
+}
+// every stride_a-th word of a and every stride_b-th word of b, one after the other (the chunk / bin starts of the two orders)
+__global__ void k_pb_pick_starts(const uint32_t* __restrict__ a, int64_t stride_a, int n_a, const uint32_t* __restrict__ b, int64_t stride_b, int n_b,
+                                 uint32_t* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_a + n_b; i += gridDim.x * blockDim.x)
+        out[i] = i < n_a ? a[(int64_t)i * stride_a] : b[(int64_t)(i - n_a) * stride_b];
+}
+
 // cold entries per output row (stream keys: block << 58 | row << 29 | col)
 __global__ void k_pb_row_counts(const uint64_t* __restrict__ keys, const unsigned char* __restrict__ is_hot, int64_t E,
                                 uint32_t* __restrict__ row_cold) {
@@ -945,14 +983,40 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     PbBuf<uint32_t> d_counts;
     PGH_TRY(d_counts.alloc(f.n_out, true));
     k_pb_row_counts<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, is_hot, E, d_counts.p);
-    std::vector<uint32_t> counts(f.n_out);
-    PGH_HIP(hipMemcpyAsync(counts.data(), d_counts.p, sizeof(uint32_t) * f.n_out, hipMemcpyDeviceToHost, r.stream));
-    PGH_HIP(hipStreamSynchronize(r.stream));
+    // the counts as bytes + the list of rows with 255 or more (rounds 1-5 copied n words down and n words of row -> bin map up through
+    // pageable memory: two thirds of the planner's 35 ms at scale 23)
+    std::vector<unsigned char> small((size_t)f.n_out);
+    std::vector<std::pair<uint32_t, uint32_t>> big;          // (row, count), ascending rows
+    {
+        const uint32_t cap = (uint32_t)std::max<int64_t>(1 << 16, f.n_out / 16);
+        PbBuf<unsigned char> d_small;
+        PbBuf<uint32_t> d_rows, d_cnts, d_n;
+        PGH_TRY(d_small.alloc(f.n_out));
+        PGH_TRY(d_rows.alloc(cap));
+        PGH_TRY(d_cnts.alloc(cap));
+        PGH_TRY(d_n.alloc(1, true));
+        k_pb_counts_small<<<pb_blocks_for(f.n_out), kBlock, 0, r.stream>>>(d_counts.p, f.n_out, d_small.p, d_rows.p, d_cnts.p, d_n.p, cap);
+        PGH_HIP(hipGetLastError());
+        uint32_t big_n = 0;
+        PGH_HIP(hipMemcpyAsync(small.data(), d_small.p, (size_t)f.n_out, hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipMemcpyAsync(&big_n, d_n.p, sizeof(uint32_t), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        PGH_CHECK(big_n <= cap, "propagation blocking: more rows with 255 or more cold entries than the planner lists");
+        std::vector<uint32_t> rows(big_n), cnts(big_n);
+        if (big_n > 0) {
+            PGH_HIP(hipMemcpyAsync(rows.data(), d_rows.p, sizeof(uint32_t) * big_n, hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipMemcpyAsync(cnts.data(), d_cnts.p, sizeof(uint32_t) * big_n, hipMemcpyDeviceToHost, r.stream));
+            PGH_HIP(hipStreamSynchronize(r.stream));
+        }
+        big.resize(big_n);
+        for (uint32_t k = 0; k < big_n; ++k) big[k] = {rows[k], cnts[k]};
+        std::sort(big.begin(), big.end());
+    }
+    std::vector<int32_t> unbinned;                            // rows whose cold entries stay in the blocked stream (row_bin = -1)
     // greedy bins: consecutive rows, <= bin_rows rows, <= kPbBinFill * bin_rows entries; a row above kPbHeavyRow entries
     // is a hub bin by itself (above kPbHubMax it gets none: its cold entries stay in the stream);
     // bins without entries are dropped (their rows never receive a cold contribution: `out` stays 0 there)
     std::vector<int4> bins;
-    std::vector<int32_t> row_bin(f.n_out);
     int64_t cold = 0, in_image = 0;
     bool heavy_rows = false;
     int heavy_row = kPbHeavyRow, hub_max = kPbHubMax;
@@ -966,6 +1030,8 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         cold = in_image = 0;
         heavy_rows = false;
         const int64_t bin_entries = (int64_t)bin_fill * bin_rows;
+        unbinned.clear();
+        size_t next_big = 0;
         int row0 = 0, rows = 0;
         int64_t fill = 0, largest = 0;     // cold entries of the open bin, and of its largest row
         auto close_bin = [&]() {
@@ -975,17 +1041,17 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
             largest = 0;
         };
         for (int i = 0; i < f.n_out; ++i) {
-            const int64_t c = counts[i];
+            int64_t c = small[(size_t)i];
+            if (c == 255) c = big[next_big++].second;          // (the list ascends with the rows: every 255 is the next entry)
             cold += c;
             if (c > heavy_row) {                 // hub bins of its own
                 const int64_t pieces = (c + hub_max - 1) / hub_max;
                 close_bin();
                 if (pieces > kPbMaxPieces || pieces > chunks) {       // its cold entries stay in the blocked stream
-                    row_bin[i] = -1;
+                    unbinned.push_back(i);
                     heavy_rows = true;
                     continue;
                 }
-                row_bin[i] = (int32_t)bins.size();
                 if (pieces > 1) split.push_back(make_int4(i, (int)bins.size(), (int)pieces, 0));
                 for (int64_t k = 0; k < pieces; ++k)   // entries are dealt by source chunk: the fills are nominal (their sum is exact)
                     bins.push_back(make_int4(i, 1 | (int)((pieces - 1) << 22), (int)std::min<int64_t>(c, 1 << 30),
@@ -995,8 +1061,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
             }
             if (rows > 0 && (fill + c > bin_entries || rows >= bin_rows)) close_bin();
             if (rows == 0) row0 = i;
-            row_bin[i] = (int32_t)bins.size();   // of a bin that ends up empty: never looked up (no entries)
-            ++rows;
+            ++rows;                              // (row -> bin: k_pb_row_bin, from the bins' first rows)
             fill += c;
             largest = std::max<int64_t>(largest, c);
             in_image += c;
@@ -1072,7 +1137,21 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         f.device_bytes += cold_ids * 4;
     }
     PGH_HIP(hipMalloc(&plan->row_bin, sizeof(int32_t) * (size_t)f.n_out));
-    PGH_HIP(hipMemcpyAsync(plan->row_bin, row_bin.data(), sizeof(int32_t) * f.n_out, hipMemcpyHostToDevice, r.stream));
+    {
+        std::vector<int32_t> first_row((size_t)num_bins);
+        for (int64_t w = 0; w < num_bins; ++w) first_row[(size_t)w] = bins[(size_t)w].x;
+        PbBuf<int32_t> d_first, d_unbinned;
+        PGH_TRY(d_first.alloc((size_t)num_bins));
+        PGH_HIP(hipMemcpyAsync(d_first.p, first_row.data(), sizeof(int32_t) * (size_t)num_bins, hipMemcpyHostToDevice, r.stream));
+        k_pb_row_bin<<<pb_blocks_for(f.n_out), kBlock, 0, r.stream>>>(d_first.p, (int)num_bins, f.n_out, plan->row_bin);
+        if (!unbinned.empty()) {
+            PGH_TRY(d_unbinned.alloc(unbinned.size()));
+            PGH_HIP(hipMemcpyAsync(d_unbinned.p, unbinned.data(), sizeof(int32_t) * unbinned.size(), hipMemcpyHostToDevice, r.stream));
+            k_pb_rows_unbinned<<<pb_blocks_for((int64_t)unbinned.size()), kBlock, 0, r.stream>>>(d_unbinned.p, (int)unbinned.size(), plan->row_bin);
+        }
+        PGH_HIP(hipGetLastError());
+        PGH_HIP(hipStreamSynchronize(r.stream));           // (the host vectors and device temporaries go out of scope)
+    }
     k_pb_keep_heavy<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, E, plan->row_bin, is_hot);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(r.stream));
@@ -1204,6 +1283,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     }
     // ---- keys_b: (chunk, bin, row, source) order.  Runs = cells, padded to whole groups of 8, laid out in both orders.
     const int64_t cells = (int64_t)p.num_chunks * p.num_bins;
+    build_mark("cold image: build (cell keys, sort)");
     PbBuf<uint32_t> counts, first, pad_a, pad_b, start_a, start_b;
     PGH_TRY(counts.alloc(cells + 1, true));
     PGH_TRY(first.alloc(cells + 1));
@@ -1226,12 +1306,21 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
     // starts of the chunks in A order, of the bins in B order, and the padded total
+    // (one strided gather + ONE copy: rounds 1-5 issued a 4-byte copy per chunk and per bin -- 2 150 of them at scale 23, most of the
+    // 2 189 copy launches of a bench process)
     std::vector<uint32_t> chunk_start(p.num_chunks + 1), bin_start(p.num_bins + 1);
-    for (int c = 0; c <= p.num_chunks; ++c)
-        PGH_HIP(hipMemcpyAsync(&chunk_start[c], start_a.p + (int64_t)c * p.num_bins, sizeof(uint32_t), hipMemcpyDeviceToHost, r.stream));
-    for (int w = 0; w <= p.num_bins; ++w)
-        PGH_HIP(hipMemcpyAsync(&bin_start[w], start_b.p + (int64_t)w * p.num_chunks, sizeof(uint32_t), hipMemcpyDeviceToHost, r.stream));
-    PGH_HIP(hipStreamSynchronize(r.stream));
+    {
+        PbBuf<uint32_t> picked;
+        const int n_a = p.num_chunks + 1, n_b = p.num_bins + 1;
+        PGH_TRY(picked.alloc((size_t)(n_a + n_b)));
+        k_pb_pick_starts<<<pb_blocks_for(n_a + n_b), kBlock, 0, r.stream>>>(start_a.p, p.num_bins, n_a, start_b.p, p.num_chunks, n_b, picked.p);
+        PGH_HIP(hipGetLastError());
+        std::vector<uint32_t> host((size_t)(n_a + n_b));
+        PGH_HIP(hipMemcpyAsync(host.data(), picked.p, sizeof(uint32_t) * host.size(), hipMemcpyDeviceToHost, r.stream));
+        PGH_HIP(hipStreamSynchronize(r.stream));
+        std::copy(host.begin(), host.begin() + n_a, chunk_start.begin());
+        std::copy(host.begin() + n_a, host.end(), bin_start.begin());
+    }
     const int64_t padded = chunk_start[p.num_chunks];
     PGH_CHECK(padded == (int64_t)bin_start[p.num_bins] && padded < 2147483647LL, "propagation blocking: layout totals disagree");
     for (int w = 0; w < p.num_bins; ++w) {
@@ -1257,6 +1346,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
                                                                start_a.p, start_b.p, p.sloc, p.val, p.dstg, p.drow);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(r.stream));
+    build_mark("cold image: build (cells, placement)");
     // ---- phase A shares (positions in A order; chunks and pieces are whole groups of 8)
     std::vector<int4> tasks;
     std::vector<int> ranges(1, 0);
@@ -1702,3 +1792,5 @@ void pb_destroy(PbFormat& p) {
 }
 
 }  // namespace pgh
+
+PGH_WARM_KERNEL(pgh::k_pb_pick_starts)

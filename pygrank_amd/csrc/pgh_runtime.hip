@@ -107,6 +107,14 @@ extern "C" int pgh_device_count(int* count) {
     return 0;
 }
 
+namespace {
+std::vector<const void*>& warm_kernels() {
+    static std::vector<const void*> list;      // (function-local: filled by static initialisers of other translation units)
+    return list;
+}
+}  // namespace
+void pgh::register_warm_kernel(const void* kernel) { warm_kernels().push_back(kernel); }
+
 extern "C" int pgh_init(int device_ordinal) {
     Runtime& r = rt();
     if (r.initialised && r.device == device_ordinal) return 0;
@@ -126,6 +134,13 @@ extern "C" int pgh_init(int device_ordinal) {
     PGH_HIP(hipHostMalloc(&r.h_scalars, sizeof(double) * kNumScalars, hipHostMallocDefault));
     PGH_HIP(hipEventCreate(&r.ev_a));
     PGH_HIP(hipEventCreate(&r.ev_b));
+    if (!(getenv("PGH_WARM") != nullptr && atoi(getenv("PGH_WARM")) == 0)) {
+        for (const void* kernel : warm_kernels()) {
+            hipFuncAttributes attr;
+            (void)hipFuncGetAttributes(&attr, kernel);        // loads the code object that holds the kernel
+        }
+        (void)hipGetLastError();
+    }
     if (!(getenv("PGH_MAILBOX") != nullptr && atoi(getenv("PGH_MAILBOX")) == 0)) {
         void* hp = nullptr;
         void* dp = nullptr;
@@ -147,6 +162,41 @@ __global__ void k_post_scalars(const double* __restrict__ src, int count, unsign
     __hip_atomic_store(mail, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);       // the values are visible before the tag is
 }
 }  // namespace
+
+namespace {
+std::vector<std::pair<std::string, double>> g_build_phases;
+std::chrono::steady_clock::time_point       g_build_last;
+}  // namespace
+
+void pgh::build_clock_reset() {
+    g_build_phases.clear();
+    g_build_last = std::chrono::steady_clock::now();
+}
+
+void pgh::build_mark(const char* label) {
+    (void)hipStreamSynchronize(rt().stream);
+    const auto now = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(now - g_build_last).count();
+    g_build_last = now;
+    for (auto& ph : g_build_phases)
+        if (ph.first == label) {
+            ph.second += ms;
+            return;
+        }
+    g_build_phases.emplace_back(label, ms);
+}
+
+extern "C" int pgh_last_build_profile(char* buf, int buflen) {
+    PGH_CHECK(buf != nullptr && buflen > 0, "pgh_last_build_profile: null buffer");
+    std::string out;
+    char num[64];
+    for (const auto& ph : g_build_phases) {
+        snprintf(num, sizeof(num), "=%.3f;", ph.second);
+        out += ph.first + num;
+    }
+    snprintf(buf, (size_t)buflen, "%s", out.c_str());
+    return 0;
+}
 
 int pgh::scalars_to_host(int first, int count) {
     Runtime& r = rt();
@@ -1343,3 +1393,5 @@ extern "C" int pgh_mat_get_col(pgh_mat_t m, int32_t col, pgh_vec_t v) {
     PGH_HIP(hipGetLastError());
     return 0;
 }
+
+PGH_WARM_KERNEL(k_post_scalars)

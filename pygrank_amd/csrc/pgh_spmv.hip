@@ -2795,3 +2795,5 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
     res->last_error = err;
     return 0;
 }
+
+PGH_WARM_KERNEL(k_state_resume)

@@ -806,21 +806,29 @@ class DeviceGraph:
         return DeviceGraph(h, M.shape, len(data))
 
     @staticmethod
-    def from_adjacency(W, normalization):
-        """The preprocessor's "col" / "symmetric" / "both" / "none" normalisation of the raw adjacency W evaluated on the
-        device (include/pgh.h pgh_graph_from_adjacency); unit weights travel as structure only."""
+    def from_adjacency(W, normalization, renormalize=0.0):
+        """The preprocessor's "col" / "symmetric" / "both" / "none" / "laplacian" normalisation of the raw adjacency W -- after the
+        renormalisation trick W + renormalize * I when asked for (preprocessing.py:107-108) -- evaluated on the device (include/pgh.h
+        pgh_graph_from_adjacency / _ex); unit weights travel as structure only."""
         import scipy.sparse as sp
         L.ensure_init()
-        kind = {"col": L.NORM_COL, "symmetric": L.NORM_SYMMETRIC, "none": L.NORM_NONE, "both": L.NORM_BOTH}[normalization]
+        kind = {"col": L.NORM_COL, "symmetric": L.NORM_SYMMETRIC, "none": L.NORM_NONE, "both": L.NORM_BOTH,
+                "laplacian": L.NORM_LAPLACIAN}[normalization]
         W = sp.csr_array(W) if not sp.issparse(W) or W.format != "csr" else W
         indptr = np.ascontiguousarray(W.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(W.indices, dtype=np.int32)
         data = np.ascontiguousarray(W.data, dtype=np.float64)
         unit = len(data) > 0 and bool(np.all(data == 1.0))
         h = L.c_graph()
-        L.check(L.lib().pgh_graph_from_adjacency(W.shape[0], W.shape[1], len(data), _ptr(indptr), _ptr(indices),
-                                                 None if unit else _ptr(data), kind, 0, C.byref(h)))
-        return DeviceGraph(h, W.shape, len(data))
+        if renormalize == 0 and kind != L.NORM_LAPLACIAN:
+            L.check(L.lib().pgh_graph_from_adjacency(W.shape[0], W.shape[1], len(data), _ptr(indptr), _ptr(indices),
+                                                     None if unit else _ptr(data), kind, 0, C.byref(h)))
+            return DeviceGraph(h, W.shape, len(data))
+        L.check(L.lib().pgh_graph_from_adjacency_ex(W.shape[0], W.shape[1], len(data), _ptr(indptr), _ptr(indices),
+                                                    None if unit else _ptr(data), kind, float(renormalize), 0, C.byref(h)))
+        vals = [C.c_int64() for _ in range(4)]
+        L.check(L.lib().pgh_graph_info(h, *[C.byref(v) for v in vals]))
+        return DeviceGraph(h, W.shape, vals[2].value)           # every row gained its diagonal entries
 
     @staticmethod
     def from_factored(W, left=None, right=None):

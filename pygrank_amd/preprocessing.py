@@ -40,6 +40,7 @@ class Adjacency:
 
 class AdjacencyWrapper:
     """fastgraph/wrapgraph.py:4-22: a scipy matrix presented as a graph over the nodes 0 .. n - 1, in O(1)."""
+    _nodes_are_positions = True                             # signals._node_index: the node -> position map is the identity
 
     def __init__(self, adj, directed=True):
         self.adj = getattr(adj, "array", adj)               # an Adjacency hands over what it owns
@@ -147,13 +148,15 @@ def to_sparse_matrix(G, normalization="auto", weight="weight", renormalize=False
             normalization = ("symmetric", "col")[bool(G.is_directed())]
     M = sp.csr_array(graph_to_scipy(G, weight), dtype=np.float64)
     renormalize = float(renormalize)                        # False / True are 0 / 1 self-loops
-    on_device = (name == "hip" and normalization in ("col", "symmetric", "both", "none") and renormalize == 0
+    square = M.shape[0] == M.shape[1]
+    on_device = (name == "hip" and normalization in ("col", "symmetric", "both", "none", "laplacian")
                  and reduction is None and transform_adjacency is _identity and not cors
-                 and (normalization in ("col", "none") or M.shape[0] == M.shape[1]))
+                 and (square or (normalization in ("col", "none") and renormalize == 0)))
     if on_device:
-        # degree reductions, scaling and transposition in HBM; the host only hands over the raw adjacency
+        # degree reductions, scaling, the self-loops of the renormalisation trick (preprocessing.py:107-108), the
+        # laplacian's identity (:114-122) and the transposition in HBM; the host only hands over the raw adjacency
         from pygrank_amd.device import DeviceGraph
-        ret = Adjacency(DeviceGraph.from_adjacency(M, normalization))
+        ret = Adjacency(DeviceGraph.from_adjacency(M, normalization, renormalize))
     else:
         if renormalize:                                     # preprocessing.py:107-108
             M = M + sp.eye(M.shape[0]).tocsr() * renormalize

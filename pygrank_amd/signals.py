@@ -25,6 +25,8 @@ def _node_index(graph):
         return recorded
     if hasattr(graph, "shape"):
         return _IdentityMap(graph.shape[0])
+    if getattr(graph, "_nodes_are_positions", False):    # AdjacencyWrapper: nodes 0 .. n - 1 (wrapgraph.py:4-22) -- no n-entry dictionary
+        return _IdentityMap(len(graph))                  # per signal (0.6 s at 8.4 M nodes, in front of a 2.5-ms loop)
     return {node: position for position, node in enumerate(graph)}
 
 

@@ -696,14 +696,49 @@ def check_device_preprocessor_matches_host(pg):
             assert np.allclose(_np(pg.degrees(gd)), _np(pg.degrees(gh)), rtol=2 * EPS32, atol=1e-30), (name, norm)
             if W.nnz and name.startswith(("rmat13", "unit")) and "host" not in gd.format():
                 assert "value-free" in gd.format(), (name, norm, gd.format())
-    # the preprocessor takes the device route for the standard normalisations and the host route otherwise
+    # the preprocessor takes the device route for every named normalisation -- round 6: the renormalisation trick (W + r I,
+    # preprocessing.py:107-108) and the laplacian (I - N, :114-122) included, whose diagonal entries the device APPENDS to the rows -- and
+    # the host route for callables / reductions / transforms.  Same matrix either way: the device's image with its duplicate positions
+    # summed against the host route's (scipy merges them), <= 1 ulp of f32 where two f32 entries were added; same degrees and products.
     graph = pg.AdjacencyWrapper(A, directed=True)
+    x = np.linspace(0.1, 1.0, A.shape[0])
     for kw in (dict(normalization="col"), dict(normalization="symmetric"), dict(normalization="col", renormalize=True),
-               dict(normalization="laplacian")):
-        dev = to_sparse_matrix(graph, **kw).array.download_transposed()
-        host = to_sparse_matrix(graph, transform_adjacency=lambda m: m, **kw).array.download_transposed()
+               dict(normalization="laplacian"), dict(normalization="symmetric", renormalize=True), dict(normalization="both", renormalize=0.5),
+               dict(normalization="laplacian", renormalize=True), dict(normalization="none", renormalize=2)):
+        dev_adj = to_sparse_matrix(graph, **kw)
+        host_adj = to_sparse_matrix(graph, transform_adjacency=lambda m: m, **kw)
+        dev, host = sp.csr_array(dev_adj.array.download_transposed().astype(np.float64)), sp.csr_array(host_adj.array.download_transposed().astype(np.float64))
+        added = bool(kw.get("renormalize")) or kw["normalization"] == "laplacian"
+        assert dev.nnz == host.nnz + (0 if not added else dev.nnz - host.nnz) and (added or dev.nnz == host.nnz), kw
+        dev.sum_duplicates()
+        host.sum_duplicates()
+        dev.sort_indices()
+        host.sort_indices()
+        dev.eliminate_zeros()
+        host.eliminate_zeros()
         assert np.array_equal(dev.indptr, host.indptr) and np.array_equal(dev.indices, host.indices), kw
-        assert np.array_equal(dev.data, host.data), kw
+        assert np.allclose(dev.data, host.data, rtol=(2.5 * EPS32 if added else 0.0), atol=0), (kw, float(np.max(np.abs(dev.data - host.data))))
+        assert np.allclose(_np(pg.degrees(dev_adj)), _np(pg.degrees(host_adj)), rtol=4 * EPS32, atol=4 * EPS32), kw
+        assert np.allclose(_np(pg.conv(pg.to_array(x), dev_adj)), _np(pg.conv(pg.to_array(x), host_adj)), rtol=1e-5, atol=1e-6), kw
+    # ... and against the REFERENCE's own preprocessor (tests/golden/golden_norm.npz: its outputs for 5 normalisations x renormalize on
+    # two graphs, generated from /root/reference by tests/golden/make_golden.py)
+    import os
+    import cases
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_norm.npz"))
+    for gkey in ("rmat10_dir", "weighted300"):
+        Ag, directed, _ = cases.GRAPHS[gkey]()
+        xg = np.linspace(0.1, 1.0, Ag.shape[0])
+        for normalization in cases.NORMALIZATIONS:
+            for renorm in (False, True):
+                key = f"{gkey}|{normalization}|{int(renorm)}"
+                adj = pg.preprocessor(normalization=normalization, renormalize=renorm)(pg.AdjacencyWrapper(Ag, directed=directed))
+                want = sp.csr_array((gold[key + "|data"], gold[key + "|indices"], gold[key + "|indptr"]), shape=Ag.shape)
+                got = sp.csr_array(adj.array.download_transposed().astype(np.float64).T)
+                got.sum_duplicates()
+                diff = abs(got - want)
+                assert (diff.max() if diff.nnz else 0.0) <= 2.5 * EPS32 * max(abs(want).max(), 1e-30), (key, diff.max())
+                assert np.allclose(_np(pg.degrees(adj)), gold[key + "|degrees"], rtol=4 * EPS32, atol=4 * EPS32), key
+                assert np.allclose(_np(pg.conv(pg.to_array(xg), adj)), gold[key + "|conv"], rtol=1e-5, atol=1e-6), key
 
 
 def check_propagation_blocking_image(pg):
