@@ -52,10 +52,10 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)pooled_free(p);
     }
     int alloc(size_t count, bool zero = false) {
-        PGH_HIP(hipMalloc(&p, sizeof(T) * (count > 0 ? count : 1)));
+        PGH_HIP(pooled_malloc(&p, sizeof(T) * (count > 0 ? count : 1)));
         if (zero) PGH_HIP(hipMemsetAsync(p, 0, sizeof(T) * (count > 0 ? count : 1), rt().stream));
         return 0;
     }
@@ -1445,8 +1445,8 @@ int bsf_bring_pair(pgh_graph_s* g, const float* v, const float* ranks, float* v_
     // caller a reduction and a host round trip for the norm)
     if (f.iperm != nullptr && (norm_here || (f.n_src_pad >= (1 << 21) && env_int("PGH_SEED_LIST", 1) != 0))) {
         if (f.seed_list == nullptr) {
-            PGH_HIP(hipMalloc(&f.seed_list, sizeof(int32_t) * (size_t)kSeedListCap));
-            PGH_HIP(hipMalloc(&f.seed_count, sizeof(int) * 2));          // two counters, used in turn: a run's closing launch clears the
+            PGH_HIP(pooled_malloc(&f.seed_list, sizeof(int32_t) * (size_t)kSeedListCap));
+            PGH_HIP(pooled_malloc(&f.seed_count, sizeof(int) * 2));          // two counters, used in turn: a run's closing launch clears the
             PGH_HIP(hipMemsetAsync(f.seed_count, 0, sizeof(int) * 2, rt().stream));      // other one for the run after it
             f.seed_turn = 0;
         }
@@ -1593,10 +1593,10 @@ int bsf_ensure_degrees(pgh_graph_s* g) {
     if (f.deg_int != nullptr) return 0;
     PGH_CHECK(g->n_rows == g->n_cols && g->degrees != nullptr, "internal-space degrees need a square graph");
     float* d = nullptr;
-    PGH_HIP(hipMalloc(&d, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1)));
+    PGH_HIP(pooled_malloc(&d, sizeof(float) * (size_t)(f.n_out > 0 ? f.n_out : 1)));
     const int rc = bsf_out_to_internal(g, g->degrees, d, 0.f);
     if (rc != 0) {
-        (void)hipFree(d);
+        (void)pooled_free(d);
         return rc;
     }
     f.deg_int = d;
@@ -1634,37 +1634,37 @@ int bsf_to_original(pgh_graph_s* g, const float* src, float* dst, double factor)
 void bsf_destroy(BsfFormat& f) {
     for (int sl = 1; sl < kPbMaxSlices; ++sl) pb_destroy(f.pb_more[sl - 1]);
     pb_destroy(f.pb);
-    (void)hipFree(f.colf);
-    (void)hipFree(f.colf16);
-    (void)hipFree(f.iperm);
-    (void)hipFree(f.flags8);
-    (void)hipFree(f.deg_int);
-    (void)hipFree(f.fix_seg);
-    (void)hipFree(f.psum);
-    (void)hipFree(f.psum64);
-    (void)hipFree(f.drop_edge);
-    (void)hipFree(f.meta);
-    (void)hipFree(f.live_dev);
-    (void)hipFree(f.val);
-    (void)hipFree(f.seg_row);
-    (void)hipFree(f.tile);
-    (void)hipFree(f.tail_carry);
-    (void)hipFree(f.head_partial);
-    (void)hipFree(f.part);
-    (void)hipFree(f.mm_close);
-    (void)hipFree(f.mm_edge);
-    (void)hipFree(f.iso_flag);
-    (void)hipFree(f.seed_list);
-    (void)hipFree(f.seed_count);
-    (void)hipFree(f.mm_row_has);
-    (void)hipFree(f.mm_rowop);
-    (void)hipFree(f.need_idx);
-    (void)hipFree(f.send_rows);
-    (void)hipFree(f.perm);
-    (void)hipFree(f.src_scale);
-    (void)hipFree(f.dst_scale);
-    (void)hipFree(f.xg);
-    (void)hipFree(f.tmp_out);
+    (void)pooled_free(f.colf);
+    (void)pooled_free(f.colf16);
+    (void)pooled_free(f.iperm);
+    (void)pooled_free(f.flags8);
+    (void)pooled_free(f.deg_int);
+    (void)pooled_free(f.fix_seg);
+    (void)pooled_free(f.psum);
+    (void)pooled_free(f.psum64);
+    (void)pooled_free(f.drop_edge);
+    (void)pooled_free(f.meta);
+    (void)pooled_free(f.live_dev);
+    (void)pooled_free(f.val);
+    (void)pooled_free(f.seg_row);
+    (void)pooled_free(f.tile);
+    (void)pooled_free(f.tail_carry);
+    (void)pooled_free(f.head_partial);
+    (void)pooled_free(f.part);
+    (void)pooled_free(f.mm_close);
+    (void)pooled_free(f.mm_edge);
+    (void)pooled_free(f.iso_flag);
+    (void)pooled_free(f.seed_list);
+    (void)pooled_free(f.seed_count);
+    (void)pooled_free(f.mm_row_has);
+    (void)pooled_free(f.mm_rowop);
+    (void)pooled_free(f.need_idx);
+    (void)pooled_free(f.send_rows);
+    (void)pooled_free(f.perm);
+    (void)pooled_free(f.src_scale);
+    (void)pooled_free(f.dst_scale);
+    (void)pooled_free(f.xg);
+    (void)pooled_free(f.tmp_out);
     f = BsfFormat();
 }
 
@@ -1746,7 +1746,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         DevBuf<unsigned int> cnt;
         PGH_TRY(cnt.alloc(n_src, true));
         PGH_TRY(iperm.alloc(n_src));
-        PGH_HIP(hipMalloc(&f.perm, sizeof(int32_t) * (size_t)n_src_pad));
+        PGH_HIP(pooled_malloc(&f.perm, sizeof(int32_t) * (size_t)n_src_pad));
         // the reference count of every source: the caller's (the generator's out-degrees, an upload's row sums), the one an earlier image
         // of this graph counted, or counted now and kept
         const bool weighted = mult != nullptr;
@@ -1754,7 +1754,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
             PGH_HIP(hipMemcpyAsync(cnt.p, g->src_counts, sizeof(unsigned int) * (size_t)n_src, hipMemcpyDeviceToDevice, r.stream));
         } else {
             if (nnz > 0) k_source_counts<<<blocks_for(nnz), kBlock, 0, r.stream>>>(g->col, mult, nnz, cnt.p);
-            if (g->src_counts == nullptr && n_src > 0 && hipMalloc(&g->src_counts, sizeof(unsigned int) * (size_t)n_src) == hipSuccess) {
+            if (g->src_counts == nullptr && n_src > 0 && pooled_malloc(&g->src_counts, sizeof(unsigned int) * (size_t)n_src) == hipSuccess) {
                 PGH_HIP(hipMemcpyAsync(g->src_counts, cnt.p, sizeof(unsigned int) * (size_t)n_src, hipMemcpyDeviceToDevice, r.stream));
                 g->src_counts_weighted = weighted;
                 g->device_bytes += (int64_t)n_src * 4;
@@ -1830,7 +1830,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     PGH_TRY(keys_b.alloc(E));
     if (val) {
         PGH_TRY(vals_a.alloc(E, true));
-        PGH_HIP(hipMalloc(&f.val, sizeof(float) * (size_t)E));
+        PGH_HIP(pooled_malloc(&f.val, sizeof(float) * (size_t)E));
     }
     if (nnz > 0) {
         if (env_int("PGH_KEYS_BY_ROW", 0) != 0) {          // the round 1-5 expansion (A/B measurements)
@@ -1956,7 +1956,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     DevBuf<uint64_t> keys_p;
     PGH_TRY(keys_p.alloc(EP));
     float* val_sorted = f.val;
-    if (val) PGH_HIP(hipMalloc(&f.val, sizeof(float) * (size_t)EP));
+    if (val) PGH_HIP(pooled_malloc(&f.val, sizeof(float) * (size_t)EP));
     {
         PadLayout pl;
         pl.B = B;
@@ -1968,11 +1968,11 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipGetLastError());
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
-    if (val) (void)hipFree(val_sorted);
+    if (val) (void)pooled_free(val_sorted);
     build_mark("stream: tiles and padding");
     keys_b.~DevBuf<uint64_t>();
     new (&keys_b) DevBuf<uint64_t>();
-    PGH_HIP(hipMalloc(&f.colf, sizeof(uint32_t) * (size_t)EP));
+    PGH_HIP(pooled_malloc(&f.colf, sizeof(uint32_t) * (size_t)EP));
     PGH_TRY(flags.alloc(EP));
     PGH_TRY(segid.alloc(EP));
     k_bsf_flags<<<blocks_for(EP), kBlock, 0, r.stream>>>(keys_p.p, EP, f.colf, flags.p);
@@ -1989,17 +1989,17 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     }
     // + 192: k_bsf_partial prefetches the rows of 128 segments per tile unconditionally (reads past a tile's own segments
     // are never used, but they must stay inside the allocation: found by tools/stress_gpu.py as a rare memory fault)
-    PGH_HIP(hipMalloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1)));
+    PGH_HIP(pooled_malloc(&f.seg_row, sizeof(int32_t) * (size_t)(f.num_segs + 1)));
     PGH_HIP(hipMemsetAsync(f.seg_row, 0xff, sizeof(int32_t) * (size_t)(f.num_segs + 1), r.stream));
     if (!batch_layout || f.want_meta) {                // SpMV layouts: the row -> segment map of the compact partial sums
         f.meta_words = ((int64_t)(f.n_out > 0 ? f.n_out : 1) + 63) / 64;
-        PGH_HIP(hipMalloc(&f.meta, sizeof(SegMeta) * (size_t)(f.meta_words * B)));
+        PGH_HIP(pooled_malloc(&f.meta, sizeof(SegMeta) * (size_t)(f.meta_words * B)));
         k_bsf_meta_init<<<blocks_for(f.meta_words * B), kBlock, 0, r.stream>>>(f.meta, f.meta_words * B);
     }
     k_bsf_seg_rows<<<blocks_for(EP), kBlock, 0, r.stream>>>(keys_p.p, segid.p, EP, f.seg_row, f.meta, f.meta_words);
-    PGH_HIP(hipMalloc(&f.tile, sizeof(int4) * (size_t)(f.num_tiles + 1)));
-    PGH_HIP(hipMalloc(&f.tail_carry, sizeof(double) * (size_t)(f.num_tiles + 1)));
-    PGH_HIP(hipMalloc(&f.head_partial, sizeof(double) * (size_t)(f.num_tiles + 1)));
+    PGH_HIP(pooled_malloc(&f.tile, sizeof(int4) * (size_t)(f.num_tiles + 1)));
+    PGH_HIP(pooled_malloc(&f.tail_carry, sizeof(double) * (size_t)(f.num_tiles + 1)));
+    PGH_HIP(pooled_malloc(&f.head_partial, sizeof(double) * (size_t)(f.num_tiles + 1)));
     PGH_HIP(hipMemsetAsync(f.tail_carry, 0, sizeof(double) * (size_t)(f.num_tiles + 1), r.stream));
     PGH_HIP(hipMemsetAsync(f.head_partial, 0, sizeof(double) * (size_t)(f.num_tiles + 1), r.stream));
     k_bsf_tiles<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(tb, segid.p, f.tile);
@@ -2008,19 +2008,19 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     const size_t n_int = (size_t)(f.n_out > 0 ? f.n_out : 1);
     if (!batch_layout) {
         // + one tile of slack: the predicated stores of k_bsf_partial address up to 512 slots past a tile's first segment
-        PGH_HIP(hipMalloc(&f.psum, sizeof(float) * (size_t)(f.num_segs + kTile + 64)));
+        PGH_HIP(pooled_malloc(&f.psum, sizeof(float) * (size_t)(f.num_segs + kTile + 64)));
         PGH_HIP(hipMemsetAsync(f.psum, 0, sizeof(float) * (size_t)(f.num_segs + kTile + 64), r.stream));
-        PGH_HIP(hipMalloc(&f.xg, sizeof(float) * (size_t)(n_src_pad + 1)));
+        PGH_HIP(pooled_malloc(&f.xg, sizeof(float) * (size_t)(n_src_pad + 1)));
         PGH_HIP(hipMemsetAsync(f.xg, 0, sizeof(float) * (size_t)(n_src_pad + 1), r.stream));
-        PGH_HIP(hipMalloc(&f.tmp_out, sizeof(float) * n_int));
+        PGH_HIP(pooled_malloc(&f.tmp_out, sizeof(float) * n_int));
     }
     if (src_old) {
-        PGH_HIP(hipMalloc(&f.src_scale, sizeof(float) * (size_t)(n_src_pad + 1)));
+        PGH_HIP(pooled_malloc(&f.src_scale, sizeof(float) * (size_t)(n_src_pad + 1)));
         PGH_HIP(hipMemsetAsync(f.src_scale, 0, sizeof(float) * (size_t)(n_src_pad + 1), r.stream));
         k_permute_in<<<blocks_for(n_src_pad), kBlock, 0, r.stream>>>(src_old, f.perm, nullptr, n_src_pad, n_src, 0.f, f.src_scale);
     }
     if (dst_old) {
-        PGH_HIP(hipMalloc(&f.dst_scale, sizeof(float) * n_int));
+        PGH_HIP(pooled_malloc(&f.dst_scale, sizeof(float) * n_int));
         // rows use the same relabelling as sources on square graphs; rectangular slices are not relabelled
         k_permute_in<<<blocks_for(f.n_out), kBlock, 0, r.stream>>>(dst_old, relabel ? f.perm : nullptr, nullptr, f.n_out, n_out, 0.f, f.dst_scale);
     }
@@ -2029,7 +2029,7 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     f.device_bytes = (int64_t)E * (val ? 8 : 4) + f.num_segs * 4 + (int64_t)f.num_tiles * 32 + f.meta_words * B * (int64_t)sizeof(SegMeta) +
                      (int64_t)n_src_pad * (4 + (src_old ? 4 : 0) + (relabel ? 4 : 0)) + (int64_t)n_out * (dst_old ? 8 : 4);
     if (f.has_iso && !batch_layout) {                  // "process every row" until a recursive loop watches its operands
-        PGH_HIP(hipMalloc(&f.iso_flag, sizeof(int)));
+        PGH_HIP(pooled_malloc(&f.iso_flag, sizeof(int)));
         PGH_HIP(hipMemsetAsync(f.iso_flag, 0xff, sizeof(int), r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
@@ -2053,11 +2053,11 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
     }
     if (!batch_layout) {
         static_assert(kIPT == 8, "k_bsf_pack digests 8 entries per lane");
-        PGH_HIP(hipMalloc(&f.flags8, (size_t)f.num_tiles * 64 + 64));
+        PGH_HIP(pooled_malloc(&f.flags8, (size_t)f.num_tiles * 64 + 64));
         PackLayout pl;
         pl.num_blocks = B;
         for (int b = 0; b <= 8; ++b) pl.tile_begin[b] = f.tile_begin[b];
-        PGH_HIP(hipMalloc(&f.live_dev, sizeof(int32_t) * 8));
+        PGH_HIP(pooled_malloc(&f.live_dev, sizeof(int32_t) * 8));
         PGH_HIP(hipMemsetAsync(f.live_dev, 0, sizeof(int32_t) * 8, r.stream));
         k_bsf_pack<<<blocks_for((int64_t)f.num_tiles * 64), kBlock, 0, r.stream>>>(f.colf, reinterpret_cast<uint32_t*>(f.val), pl, f.num_tiles, blk, f.flags8,
                                                                                  f.live_dev);
@@ -2066,20 +2066,20 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipStreamSynchronize(r.stream));
         for (int b = 0; b < 8; ++b) f.live[b] = live_all[b] > f.live[b] ? live_all[b] : f.live[b];   // the cold image's sources count too
         for (int b = 0; b < 8; ++b) f.xg_base[b] = f.xg_base_cold[b] = (int64_t)b * blk;
-        PGH_HIP(hipMalloc(&f.fix_seg, sizeof(int32_t) * (size_t)(f.num_tiles + 1)));
+        PGH_HIP(pooled_malloc(&f.fix_seg, sizeof(int32_t) * (size_t)(f.num_tiles + 1)));
         k_bsf_fixlist<<<blocks_for(f.num_tiles), kBlock, 0, r.stream>>>(f.tile, f.seg_row, f.num_tiles, f.fix_seg);
         PGH_HIP(hipGetLastError());
         PGH_HIP(hipStreamSynchronize(r.stream));
-        (void)hipFree(f.seg_row);                       // build-time only in this layout
+        (void)pooled_free(f.seg_row);                       // build-time only in this layout
         f.seg_row = nullptr;
 
         if (f.pb.enabled && !f.pb.k1_cold && env_int("PGH_STREAM16", 1)) {       // hot-only stream: 2 bytes per entry
             const uint32_t hot4 = (uint32_t)(kBsfHot < blk ? kBsfHot : blk) << 2;
-            PGH_HIP(hipMalloc(&f.colf16, sizeof(uint16_t) * (size_t)f.num_tiles * 512 + 64));
+            PGH_HIP(pooled_malloc(&f.colf16, sizeof(uint16_t) * (size_t)f.num_tiles * 512 + 64));
             k_bsf_narrow<<<blocks_for((int64_t)f.num_tiles * 64), kBlock, 0, r.stream>>>(f.colf, f.num_tiles, hot4, f.colf16);
             PGH_HIP(hipGetLastError());
             PGH_HIP(hipStreamSynchronize(r.stream));
-            (void)hipFree(f.colf);
+            (void)pooled_free(f.colf);
             f.colf = nullptr;
             f.device_bytes -= (int64_t)f.num_tiles * 512 * 2;
         }

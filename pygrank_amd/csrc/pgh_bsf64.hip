@@ -534,14 +534,14 @@ int bsf64_ensure(pgh_graph_s* g) {
     }
     f.want_meta = true;
     PGH_TRY(bsf_build(g, valfree ? nullptr : g->val, g->keep_mult, g->keep_src, g->keep_dst, true, B, &f));
-    PGH_HIP(hipMalloc(&f.psum64, sizeof(double) * (size_t)(f.num_segs + kT + 64)));
+    PGH_HIP(pooled_malloc(&f.psum64, sizeof(double) * (size_t)(f.num_segs + kT + 64)));
     PGH_HIP(hipMemsetAsync(f.psum64, 0, sizeof(double) * (size_t)(f.num_segs + kT + 64), r.stream));
-    PGH_HIP(hipMalloc(&f.fix_seg, sizeof(int32_t) * (size_t)(f.num_tiles + 1)));
+    PGH_HIP(pooled_malloc(&f.fix_seg, sizeof(int32_t) * (size_t)(f.num_tiles + 1)));
     k_bsf64_fixlist<<<grid_for(f.num_tiles, 16), WG, 0, r.stream>>>(f.tile, f.seg_row, f.num_tiles, f.fix_seg);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(r.stream));
     f.device_bytes += (int64_t)(f.num_segs + kT + 64) * 8 + (int64_t)f.num_tiles * 4;
-    if (f.live_nodes >= 0) PGH_HIP(hipMalloc(&f.iso_flag, sizeof(int)));
+    if (f.live_nodes >= 0) PGH_HIP(pooled_malloc(&f.iso_flag, sizeof(int)));
     return 0;
 }
 

@@ -86,6 +86,20 @@ void build_mark(const char* label);
 int  pool_alloc(size_t bytes, void** out);
 void pool_free(void* p);
 void pool_trim();
+// Every buffer of a graph build -- temporaries AND the images a graph keeps -- comes from that pool (round 6): hipMalloc / hipFree take
+// locks of the kernel driver that other processes of the node contend for, and a build of ~150 of them met random stalls of 0.2-0.9 s in
+// whatever phase allocated next (profiles/r06/build_stalls.log: 80 ms builds interleaved with 400-1000 ms ones).  From the second build of
+// a graph of the same shape on -- what rank() does on every call when the caller does not promise immutability
+// (pygrank/core/utils/preprocessing.py:233-287) -- no driver call is left.  pooled_free takes pointers of either origin.
+inline hipError_t pooled_malloc_bytes(void** p, size_t bytes) { return pool_alloc(bytes, p) == 0 ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T>
+inline hipError_t pooled_malloc(T** p, size_t bytes) {
+    return pooled_malloc_bytes(reinterpret_cast<void**>(p), bytes);
+}
+inline hipError_t pooled_free(void* p) {
+    pool_free(p);
+    return hipSuccess;
+}
 
 // merge items (rows + nnz) per thread of a 256-thread workgroup; the tile table is built for 256 * PGH_IPT
 #ifndef PGH_IPT

@@ -342,7 +342,7 @@ int prepare_graph(pgh_comm_s* c, pgh_graph_t g, bool* fused) {
     if (fused != nullptr) *fused = h_agree[2] == 0;
     // some rank rebuilds its degrees and the run fuses on every rank: the all-reduce of ensure_slice_degrees needs everybody
     if (h_agree[2] == 0 && h_agree[3] != 0 && g->bsf.deg_int != nullptr) {
-        (void)hipFree(g->bsf.deg_int);
+        (void)pooled_free(g->bsf.deg_int);
         g->bsf.deg_int = nullptr;
         g->bsf.device_bytes -= (int64_t)g->n_cols * 4;
     }

@@ -143,10 +143,10 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)pooled_free(p);
     }
     int alloc(size_t count) {
-        PGH_HIP(hipMalloc(&p, sizeof(T) * (count > 0 ? count : 1)));
+        PGH_HIP(pooled_malloc(&p, sizeof(T) * (count > 0 ? count : 1)));
         return 0;
     }
     T* release() {
@@ -169,10 +169,10 @@ int finish_graph(pgh_graph_s* g) {
     g->items_per_tile = kItemsPerTile;
     g->num_tiles = (int)((total + kItemsPerTile - 1) / kItemsPerTile);
     const int nt = g->num_tiles;
-    PGH_HIP(hipMalloc(&g->tile_coord, sizeof(int2) * (size_t)(nt + 1)));
-    PGH_HIP(hipMalloc(&g->chain_first, sizeof(int32_t) * (size_t)(nt > 0 ? nt : 1)));
-    PGH_HIP(hipMalloc(&g->tail_carry, sizeof(double) * (size_t)(nt > 0 ? nt : 1)));
-    PGH_HIP(hipMalloc(&g->head_partial, sizeof(double) * (size_t)(nt > 0 ? nt : 1)));
+    PGH_HIP(pooled_malloc(&g->tile_coord, sizeof(int2) * (size_t)(nt + 1)));
+    PGH_HIP(pooled_malloc(&g->chain_first, sizeof(int32_t) * (size_t)(nt > 0 ? nt : 1)));
+    PGH_HIP(pooled_malloc(&g->tail_carry, sizeof(double) * (size_t)(nt > 0 ? nt : 1)));
+    PGH_HIP(pooled_malloc(&g->head_partial, sizeof(double) * (size_t)(nt > 0 ? nt : 1)));
     PGH_HIP(hipMemsetAsync(g->tail_carry, 0, sizeof(double) * (size_t)(nt > 0 ? nt : 1), r.stream));
     PGH_HIP(hipMemsetAsync(g->head_partial, 0, sizeof(double) * (size_t)(nt > 0 ? nt : 1), r.stream));
     k_tile_coords<<<blocks_for(nt + 1), kBlock, 0, r.stream>>>(g->rowptr, (int)nT, (int)g->nnz, kItemsPerTile, nt, g->tile_coord);
@@ -251,6 +251,55 @@ __global__ void k_laplacian_finish(const int64_t* __restrict__ indptr, double* _
 __global__ void k_laplacian_ones(const int64_t* __restrict__ indptr, double* __restrict__ data, int64_t n_rows) {
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) data[indptr[r + 1] - 1] = 1.0;
 }
+
+// ---- entry-parallel forms of the per-row passes of an upload (round 6).  A wavefront per row (k_make_keys_idx, k_row_sums_f64,
+// k_apply_factors, k_row_sums, k_row_counts) spends a whole wavefront on every empty row and walks a hub row serially: 72 + 25 ms of a
+// 0.16-s upload at scale 23.  Here the row of every entry is materialised once (row heads scattered, a running maximum spreads them),
+// elementwise passes stream the entries, and row sums are hipcub's load-balanced reduce-by-key over the (ascending) row ids.
+__global__ void k_row_heads64(const int64_t* __restrict__ indptr, int64_t n_rows, int32_t* __restrict__ row_of) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+        if (indptr[r + 1] > indptr[r]) row_of[indptr[r]] = (int32_t)r;
+}
+__global__ void k_make_keys_idx_flat(const int32_t* __restrict__ row_of, const int32_t* __restrict__ indices, int64_t nnz,
+                                     uint64_t* __restrict__ keys, int32_t* __restrict__ idx) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        keys[k] = ((uint64_t)(uint32_t)indices[k] << 32) | (uint64_t)(uint32_t)row_of[k];
+        idx[k] = (int32_t)k;
+    }
+}
+__global__ void k_apply_factors_flat(const int32_t* __restrict__ row_of, const int32_t* __restrict__ indices, double* __restrict__ data,
+                                     const double* __restrict__ left, const double* __restrict__ right, int64_t nnz,
+                                     int32_t* __restrict__ mult, unsigned long long* __restrict__ stats) {
+    unsigned long long bad = 0, sum = 0;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        const double l = left ? left[row_of[k]] : 1.0;
+        const double w = data[k];
+        const double rw = right ? right[indices[k]] : 1.0;
+        const double m = rint(w);
+        if (!(w == m && m >= 1.0 && m <= 32768.0)) ++bad; else sum += (unsigned long long)m;
+        mult[k] = (int32_t)(m >= 1.0 && m <= 32768.0 ? m : 1.0);
+        data[k] = (l * w) * rw;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        bad += __shfl_down(bad, off, 64);
+        sum += __shfl_down(sum, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicAdd(&stats[0], bad);
+        if (sum) atomicAdd(&stats[1], sum);
+    }
+}
+__global__ void k_gather_f64(const int32_t* __restrict__ idx, const double* __restrict__ data, int64_t nnz, double* __restrict__ out) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) out[k] = data[idx[k]];
+}
+template <typename T, typename O>
+__global__ void k_scatter_sums(const int32_t* __restrict__ ids, const T* __restrict__ sums, const int* __restrict__ num, O* __restrict__ out) {
+    const int runs = *num;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < runs; i += gridDim.x * blockDim.x) out[ids[i]] = (O)sums[i];
+}
+struct HiWord32 {
+    __host__ __device__ __forceinline__ int32_t operator()(const uint64_t& k) const { return (int32_t)(k >> 32); }
+};
 
 // expand CSR(M) into sort keys (col << 32 | row) with the entry index as payload
 __global__ void k_make_keys_idx(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t n_rows,
@@ -338,6 +387,29 @@ struct PartSpec {
     int32_t        num_blocks;
     const int32_t* perm;        // host, [n_rows] new id -> original id (-1 = padding)
 };
+// out[r] = sum of vals over the entries whose (ascending) key is r; rows without entries get 0.  T: the type the sums are formed in.
+template <typename T, typename O, typename KeyIt, typename ValIt>
+int sums_by_row(KeyIt keys, ValIt vals, int64_t count, int64_t n_rows, O* out) {
+    Runtime& r = rt();
+    PGH_HIP(hipMemsetAsync(out, 0, sizeof(O) * (size_t)(n_rows > 0 ? n_rows : 1), r.stream));
+    if (count <= 0 || n_rows <= 0) return 0;
+    DevBuf<int32_t> ids;
+    DevBuf<T> sums;
+    DevBuf<int> num;
+    DevBuf<char> temp;
+    PGH_TRY(ids.alloc(n_rows));
+    PGH_TRY(sums.alloc(n_rows));
+    PGH_TRY(num.alloc(1));
+    size_t bytes = 0;
+    PGH_HIP(hipcub::DeviceReduce::ReduceByKey(nullptr, bytes, keys, ids.p, vals, sums.p, num.p, hipcub::Sum(), (int)count, r.stream));
+    PGH_TRY(temp.alloc(bytes));
+    PGH_HIP(hipcub::DeviceReduce::ReduceByKey(temp.p, bytes, keys, ids.p, vals, sums.p, num.p, hipcub::Sum(), (int)count, r.stream));
+    k_scatter_sums<T, O><<<blocks_for(n_rows), kBlock, 0, r.stream>>>(ids.p, sums.p, num.p, out);
+    PGH_HIP(hipGetLastError());
+    PGH_HIP(hipStreamSynchronize(r.stream));               // (the temporaries go out of scope)
+    return 0;
+}
+
 int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const int64_t* indptr, const int32_t* indices,
                         const double* data, bool factored, const double* left, const double* right, int device_norm,
                         pgh_graph_t* out, const PartSpec* part = nullptr, double self_loops = 0.0) {
@@ -363,6 +435,9 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const in
         DevBuf<double> d_data, d_left, d_right;
         DevBuf<uint64_t> keys_a, keys_b;
         DevBuf<unsigned long long> stats;
+        DevBuf<int32_t> row_tmp;
+        int32_t* row_of = nullptr;                             // [nnz] the row of every entry of the caller's CSR(M) (entry-parallel passes)
+        const bool by_row = getenv("PGH_UPLOAD_BY_ROW") != nullptr && atoi(getenv("PGH_UPLOAD_BY_ROW")) != 0;     // rounds 1-5 (A/B)
         PGH_TRY(d_indptr.alloc(n_rows + 1));
         PGH_TRY(d_indices.alloc(nnz));
         PGH_TRY(d_data.alloc(nnz));
@@ -403,17 +478,32 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const in
             g->nnz = nnz;
         }
         build_mark("upload: host arrays to HBM, validation");
-        PGH_HIP(hipMalloc(&g->degrees, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
-        PGH_HIP(hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_cols + 1)));
-        PGH_HIP(hipMalloc(&g->col, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
-        PGH_HIP(hipMalloc(&g->val, sizeof(float) * (size_t)(nnz > 0 ? nnz : 1)));
+        PGH_HIP(pooled_malloc(&g->degrees, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
+        PGH_HIP(pooled_malloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_cols + 1)));
+        PGH_HIP(pooled_malloc(&g->col, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+        PGH_HIP(pooled_malloc(&g->val, sizeof(float) * (size_t)(nnz > 0 ? nnz : 1)));
         // ---- structure first: sort (col, row) keys with the entry index as payload -> rows of M^T, ascending columns
         if (nnz > 0) {
             PGH_TRY(keys_a.alloc(nnz));
             PGH_TRY(keys_b.alloc(nnz));
             PGH_TRY(idx_a.alloc(nnz));
             PGH_TRY(idx_b.alloc(nnz));
-            k_make_keys_idx<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, n_rows, keys_a.p, idx_a.p);
+            if (by_row) {
+                k_make_keys_idx<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, n_rows, keys_a.p, idx_a.p);
+            } else {
+                // the row of every entry of the caller's CSR(M): heads scattered, a running maximum spreads them
+                PGH_TRY(row_tmp.alloc(2 * (size_t)nnz));
+                row_of = row_tmp.p + nnz;
+                PGH_HIP(hipMemsetAsync(row_tmp.p, 0, sizeof(int32_t) * (size_t)nnz, r.stream));
+                k_row_heads64<<<blocks_for(n_rows), kBlock, 0, r.stream>>>(d_indptr.p, n_rows, row_tmp.p);
+                size_t scan_bytes = 0;
+                PGH_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, row_tmp.p, row_of, hipcub::Max(), (int)nnz, r.stream));
+                DevBuf<char> scan_temp;
+                PGH_TRY(scan_temp.alloc(scan_bytes));
+                PGH_HIP(hipcub::DeviceScan::InclusiveScan(scan_temp.p, scan_bytes, row_tmp.p, row_of, hipcub::Max(), (int)nnz, r.stream));
+                k_make_keys_idx_flat<<<blocks_for(nnz), kBlock, 0, r.stream>>>(row_of, d_indices.p, nnz, keys_a.p, idx_a.p);
+                PGH_HIP(hipStreamSynchronize(r.stream));
+            }
             PGH_HIP(hipGetLastError());
             int bits_col = 1;
             while ((1LL << bits_col) < n_cols) ++bits_col;
@@ -441,14 +531,24 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const in
             if (have_left) {
                 PGH_TRY(d_left.alloc(n_rows));
                 if (n_rows > 0) {
-                    k_row_sums_f64<int64_t><<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, nullptr, d_data.p, n_rows, d_left.p);
+                    if (row_of == nullptr) k_row_sums_f64<int64_t><<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, nullptr, d_data.p, n_rows, d_left.p);
+                    else PGH_TRY((sums_by_row<double, double>(row_of, d_data.p, nnz, n_rows, d_left.p)));
                     k_inv_nonzero<<<blocks_for(n_rows), kBlock, 0, r.stream>>>(d_left.p, n_rows, take_sqrt);
                 }
             }
             if (have_right) {
                 PGH_TRY(d_right.alloc(n_cols));
                 if (n_cols > 0) {
-                    k_row_sums_f64<int32_t><<<blocks_for(n_cols * 64), kBlock, 0, r.stream>>>(g->rowptr, idx_b.p, d_data.p, n_cols, d_right.p);
+                    if (row_of == nullptr) {
+                        k_row_sums_f64<int32_t><<<blocks_for(n_cols * 64), kBlock, 0, r.stream>>>(g->rowptr, idx_b.p, d_data.p, n_cols, d_right.p);
+                    } else {
+                        // column sums = row sums of the transposed structure: the weights in its order, keyed by the sorted keys' high words
+                        DevBuf<double> data_t;
+                        PGH_TRY(data_t.alloc(nnz));
+                        k_gather_f64<<<blocks_for(nnz), kBlock, 0, r.stream>>>(idx_b.p, d_data.p, nnz, data_t.p);
+                        hipcub::TransformInputIterator<int32_t, HiWord32, const uint64_t*> cols(keys_b.p, HiWord32());
+                        PGH_TRY((sums_by_row<double, double>(cols, data_t.p, nnz, n_cols, d_right.p)));
+                    }
                     k_inv_nonzero<<<blocks_for(n_cols), kBlock, 0, r.stream>>>(d_right.p, n_cols, take_sqrt);
                 }
             }
@@ -469,9 +569,14 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const in
             PGH_TRY(d_mult.alloc(nnz));
             PGH_TRY(stats.alloc(2));
             PGH_HIP(hipMemsetAsync(stats.p, 0, sizeof(unsigned long long) * 2, r.stream));
-            if (n_rows > 0 && nnz > 0)
-                k_apply_factors<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, d_data.p, have_left ? d_left.p : nullptr,
-                                                                                 have_right ? d_right.p : nullptr, n_rows, d_mult.p, stats.p);
+            if (n_rows > 0 && nnz > 0) {
+                if (row_of == nullptr)
+                    k_apply_factors<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_indices.p, d_data.p, have_left ? d_left.p : nullptr,
+                                                                                     have_right ? d_right.p : nullptr, n_rows, d_mult.p, stats.p);
+                else
+                    k_apply_factors_flat<<<blocks_for(nnz), kBlock, 0, r.stream>>>(row_of, d_indices.p, d_data.p, have_left ? d_left.p : nullptr,
+                                                                                  have_right ? d_right.p : nullptr, nnz, d_mult.p, stats.p);
+            }
             unsigned long long h[2] = {0, 0};
             PGH_HIP(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, r.stream));
             PGH_HIP(hipStreamSynchronize(r.stream));
@@ -485,12 +590,18 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const in
             k_laplacian_ones<<<blocks_for(n_rows), kBlock, 0, r.stream>>>(d_indptr.p, d_data.p, n_rows);
             value_free = false;
         }
-        if (n_rows > 0) k_row_sums<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_data.p, n_rows, g->degrees);
-        if (part == nullptr && n_rows > 0 && n_rows == n_cols && hipMalloc(&g->src_counts, sizeof(unsigned int) * (size_t)n_rows) == hipSuccess) {
+        if (n_rows > 0) {
+            if (row_of == nullptr) k_row_sums<<<blocks_for(n_rows * 64), kBlock, 0, r.stream>>>(d_indptr.p, d_data.p, n_rows, g->degrees);
+            else PGH_TRY((sums_by_row<double, float>(row_of, d_data.p, nnz, n_rows, g->degrees)));
+        }
+        if (part == nullptr && n_rows > 0 && n_rows == n_cols && pooled_malloc(&g->src_counts, sizeof(unsigned int) * (size_t)n_rows) == hipSuccess) {
             // the relabelling key of the images (bsf_build), from the rows of the caller's matrix: no histogram over the entries
             g->src_counts_weighted = value_free;
-            k_row_counts<<<blocks_for(value_free ? n_rows * 64 : n_rows), kBlock, 0, r.stream>>>(d_indptr.p, value_free ? d_mult.p : nullptr, n_rows,
-                                                                                              g->src_counts);
+            if (value_free && row_of != nullptr)
+                PGH_TRY((sums_by_row<int, unsigned int>(row_of, d_mult.p, nnz, n_rows, g->src_counts)));
+            else
+                k_row_counts<<<blocks_for(value_free ? n_rows * 64 : n_rows), kBlock, 0, r.stream>>>(d_indptr.p, value_free ? d_mult.p : nullptr, n_rows,
+                                                                                                  g->src_counts);
         }
         if (nnz > 0) {
             if (value_free) PGH_TRY(mult_t.alloc(nnz));
@@ -510,18 +621,18 @@ int graph_from_csr_impl(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const in
             const int force_blocks = part != nullptr ? part->num_blocks : 0;
             if (part != nullptr) {
                 g->row_begin = part->row_begin;
-                PGH_HIP(hipMalloc(&g->part_perm, sizeof(int32_t) * (size_t)(n_rows > 0 ? n_rows : 1)));
+                PGH_HIP(pooled_malloc(&g->part_perm, sizeof(int32_t) * (size_t)(n_rows > 0 ? n_rows : 1)));
                 PGH_HIP(hipMemcpyAsync(g->part_perm, part->perm, sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice, r.stream));
                 PGH_HIP(hipStreamSynchronize(r.stream));
             }
             if (value_free) {
                 // M^T = diag(right) * W^T * diag(left): the source scale is `left` (rows of M), the output scale `right`
                 if (have_left) {
-                    PGH_HIP(hipMalloc(&g->keep_src, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
+                    PGH_HIP(pooled_malloc(&g->keep_src, sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1)));
                     k_f64_to_f32_g<<<blocks_for(n_rows), kBlock, 0, r.stream>>>(d_left.p, g->keep_src, n_rows);
                 }
                 if (have_right) {
-                    PGH_HIP(hipMalloc(&g->keep_dst, sizeof(float) * (size_t)(n_cols > 0 ? n_cols : 1)));
+                    PGH_HIP(pooled_malloc(&g->keep_dst, sizeof(float) * (size_t)(n_cols > 0 ? n_cols : 1)));
                     k_f64_to_f32_g<<<blocks_for(n_cols), kBlock, 0, r.stream>>>(d_right.p, g->keep_dst, n_cols);
                 }
                 g->keep_mult = mult_t.release();
@@ -594,22 +705,22 @@ extern "C" int pgh_graph_from_adjacency_ex(int64_t n_rows, int64_t n_cols, int64
 extern "C" int pgh_graph_destroy(pgh_graph_t g) {
     if (!g) return 0;
     if (rt().initialised) (void)hipStreamSynchronize(rt().stream);
-    (void)hipFree(g->rowptr);
-    (void)hipFree(g->col);
-    (void)hipFree(g->val);
-    (void)hipFree(g->degrees);
-    (void)hipFree(g->tile_coord);
-    (void)hipFree(g->chain_first);
-    (void)hipFree(g->tail_carry);
-    (void)hipFree(g->head_partial);
+    (void)pooled_free(g->rowptr);
+    (void)pooled_free(g->col);
+    (void)pooled_free(g->val);
+    (void)pooled_free(g->degrees);
+    (void)pooled_free(g->tile_coord);
+    (void)pooled_free(g->chain_first);
+    (void)pooled_free(g->tail_carry);
+    (void)pooled_free(g->head_partial);
     bsf_destroy(g->bsf);
     bsf_destroy(g->bsf_mm);
     bsf_destroy(g->bsf64);
-    (void)hipFree(g->keep_mult);
-    (void)hipFree(g->src_counts);
-    (void)hipFree(g->keep_src);
-    (void)hipFree(g->keep_dst);
-    (void)hipFree(g->part_perm);
+    (void)pooled_free(g->keep_mult);
+    (void)pooled_free(g->src_counts);
+    (void)pooled_free(g->keep_src);
+    (void)pooled_free(g->keep_dst);
+    (void)pooled_free(g->part_perm);
     delete g;
     return 0;
 }

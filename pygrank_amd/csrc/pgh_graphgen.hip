@@ -224,10 +224,10 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)pooled_free(p);
     }
     int alloc(size_t count, bool zero = false) {
-        PGH_HIP(hipMalloc(&p, sizeof(T) * (count > 0 ? count : 1)));
+        PGH_HIP(pooled_malloc(&p, sizeof(T) * (count > 0 ? count : 1)));
         if (zero) PGH_HIP(hipMemsetAsync(p, 0, sizeof(T) * (count > 0 ? count : 1), rt().stream));
         return 0;
     }
@@ -312,7 +312,7 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
             k_part_keys<<<blocks_for(n), kBlock, 0, r.stream>>>(outdeg_old.p, has_in.p, n, live_count.p);     // in place -> sort keys
             PGH_HIP(hipGetLastError());
             PGH_TRY(iperm.alloc(n));
-            PGH_HIP(hipMalloc(&g->part_perm, sizeof(int32_t) * (size_t)n));
+            PGH_HIP(pooled_malloc(&g->part_perm, sizeof(int32_t) * (size_t)n));
             PGH_TRY(build_count_perm(outdeg_old.p, n, part_blocks, (int)(n / part_blocks), g->part_perm, iperm.p));
             unsigned int live_nodes = 0;
             PGH_HIP(hipMemcpyAsync(&live_nodes, live_count.p, sizeof(unsigned int), hipMemcpyDeviceToHost, r.stream));
@@ -334,8 +334,8 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
         build_mark("generator: out-degrees");
         const int64_t K = (int64_t)kept;
         int64_t nnz = 0;
-        PGH_HIP(hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_local + 1)));
-        PGH_HIP(hipMalloc(&g->degrees, sizeof(float) * (size_t)n));
+        PGH_HIP(pooled_malloc(&g->rowptr, sizeof(int32_t) * (size_t)(n_local + 1)));
+        PGH_HIP(pooled_malloc(&g->degrees, sizeof(float) * (size_t)n));
         PGH_TRY(deg_acc.alloc(n, true));
         if (K > 0) {
             PGH_TRY(keys_a.alloc(K));
@@ -405,15 +405,15 @@ static int rmat_build(int32_t scale, int32_t edge_factor, double a, double b, do
                 nnz = runs;
             }
             build_mark("generator: run lengths");
-            PGH_HIP(hipMalloc(&g->col, sizeof(int32_t) * (size_t)nnz));
-            PGH_HIP(hipMalloc(&g->val, sizeof(float) * (size_t)nnz));
+            PGH_HIP(pooled_malloc(&g->col, sizeof(int32_t) * (size_t)nnz));
+            PGH_HIP(pooled_malloc(&g->val, sizeof(float) * (size_t)nnz));
             if (!by_runs) k_indeg<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_a.p, counts.p, nnz, indeg.p);
             k_rmat_values<<<blocks_for(nnz), kBlock, 0, r.stream>>>(keys_a.p, counts.p, nnz, n_local, normalization, outdeg.p,
                                                                     indeg.p, g->col, g->val, g->rowptr, deg_acc.p);
             PGH_HIP(hipGetLastError());
         } else {
-            PGH_HIP(hipMalloc(&g->col, sizeof(int32_t)));
-            PGH_HIP(hipMalloc(&g->val, sizeof(float)));
+            PGH_HIP(pooled_malloc(&g->col, sizeof(int32_t)));
+            PGH_HIP(pooled_malloc(&g->val, sizeof(float)));
             k_fill_i32<<<blocks_for(n_local + 1), kBlock, 0, r.stream>>>(g->rowptr, n_local + 1, 0);
         }
         g->nnz = nnz;

@@ -114,10 +114,10 @@ template <typename T>
 struct PbBuf {
     T* p = nullptr;
     ~PbBuf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)pooled_free(p);
     }
     int alloc(size_t count, bool zero = false) {
-        PGH_HIP(hipMalloc(&p, sizeof(T) * (count > 0 ? count : 1)));
+        PGH_HIP(pooled_malloc(&p, sizeof(T) * (count > 0 ? count : 1)));
         if (zero) PGH_HIP(hipMemsetAsync(p, 0, sizeof(T) * (count > 0 ? count : 1), rt().stream));
         return 0;
     }
@@ -959,7 +959,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         L.hot = hot;
         L.chunk = kPbChunk;
         PGH_TRY(mark.alloc(cold_sources + 1, true));
-        PGH_HIP(hipMalloc(&plan->cold_rank, sizeof(uint32_t) * (size_t)(cold_sources + 1)));
+        PGH_HIP(pooled_malloc(&plan->cold_rank, sizeof(uint32_t) * (size_t)(cold_sources + 1)));
         k_pb_mark_cold<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, is_hot, E, L, mark.p);
         PGH_HIP(hipGetLastError());
         size_t scan_bytes = 0;
@@ -976,7 +976,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     const int64_t cold_ids = plan->compact_prefix[8];             // == cold_sources without need lists
     const int64_t chunks = (cold_ids + kPbChunk - 1) / kPbChunk;
     if (chunks < 1 || chunks > kPbMaxChunks || f.n_out >= (1 << 28)) {
-        (void)hipFree(plan->cold_rank);
+        (void)pooled_free(plan->cold_rank);
         plan->cold_rank = nullptr;
         return 0;
     }
@@ -1097,7 +1097,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     plan->bin_rows = bin_rows;
     const int64_t num_bins = (int64_t)bins.size();
     auto no_image = [&]() {
-        (void)hipFree(plan->cold_rank);
+        (void)pooled_free(plan->cold_rank);
         plan->cold_rank = nullptr;
         return 0;
     };
@@ -1118,7 +1118,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     // rows that keep their cold entries in the blocked stream read the DENSE cold slots from there: such a slice cannot number its cold
     // sources compactly (its exchange stays the all-gather); the plan is laid out again for the dense numbering
     if (plan->cold_rank != nullptr && heavy_rows) {
-        (void)hipFree(plan->cold_rank);
+        (void)pooled_free(plan->cold_rank);
         plan->cold_rank = nullptr;
         for (int b = 0; b < 9; ++b) plan->compact_prefix[b] = plan->dense_prefix[b];
         f.want_compact = false;
@@ -1128,15 +1128,15 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         // the lists themselves: kept with the graph (pgh_dist_need_list), block-major
         PbLayout L{};
         for (int b = 0; b < 9; ++b) L.cold_prefix[b] = plan->dense_prefix[b];
-        (void)hipFree(f.need_idx);
+        (void)pooled_free(f.need_idx);
         f.need_idx = nullptr;
-        PGH_HIP(hipMalloc(&f.need_idx, sizeof(uint32_t) * (size_t)(cold_ids > 0 ? cold_ids : 1)));
+        PGH_HIP(pooled_malloc(&f.need_idx, sizeof(uint32_t) * (size_t)(cold_ids > 0 ? cold_ids : 1)));
         k_pb_need_idx<<<pb_blocks_for(cold_sources), kBlock, 0, r.stream>>>(mark.p, plan->cold_rank, cold_sources, L, f.num_blocks, f.need_idx);
         PGH_HIP(hipGetLastError());
         for (int b = 0; b < 9; ++b) f.need_prefix[b] = plan->compact_prefix[b];
         f.device_bytes += cold_ids * 4;
     }
-    PGH_HIP(hipMalloc(&plan->row_bin, sizeof(int32_t) * (size_t)f.n_out));
+    PGH_HIP(pooled_malloc(&plan->row_bin, sizeof(int32_t) * (size_t)f.n_out));
     {
         std::vector<int32_t> first_row((size_t)num_bins);
         for (int64_t w = 0; w < num_bins; ++w) first_row[(size_t)w] = bins[(size_t)w].x;
@@ -1251,7 +1251,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     p.num_bins = plan->slice_first[slice + 1] - first_bin;
     // this slice's bins (the group ranges are filled in below)
     std::vector<int4> mine(plan->host_bins + first_bin, plan->host_bins + first_bin + p.num_bins);
-    PGH_HIP(hipMalloc(&p.bin, sizeof(int4) * (size_t)(p.num_bins > 0 ? p.num_bins : 1)));
+    PGH_HIP(pooled_malloc(&p.bin, sizeof(int4) * (size_t)(p.num_bins > 0 ? p.num_bins : 1)));
     PGH_HIP(hipMemcpyAsync(p.bin, mine.data(), sizeof(int4) * mine.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipStreamSynchronize(r.stream));
     for (int b = 0; b < 9; ++b) p.cold_prefix[b] = plan->compact_prefix[b];       // (== the dense prefix without need lists)
@@ -1332,14 +1332,14 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         mine[w].w = (int)((bin_start[w + 1] - bin_start[w]) >> 3);
     }
     PGH_HIP(hipMemcpyAsync(p.bin, mine.data(), sizeof(int4) * mine.size(), hipMemcpyHostToDevice, r.stream));
-    PGH_HIP(hipMalloc(&p.sloc, sizeof(uint16_t) * (size_t)(padded + 8)));
-    PGH_HIP(hipMalloc(&p.drow, sizeof(uint16_t) * (size_t)(padded + 8)));
-    PGH_HIP(hipMalloc(&p.dstg, sizeof(uint32_t) * (size_t)(padded / 8 + 1)));
+    PGH_HIP(pooled_malloc(&p.sloc, sizeof(uint16_t) * (size_t)(padded + 8)));
+    PGH_HIP(pooled_malloc(&p.drow, sizeof(uint16_t) * (size_t)(padded + 8)));
+    PGH_HIP(pooled_malloc(&p.dstg, sizeof(uint32_t) * (size_t)(padded / 8 + 1)));
     PGH_HIP(hipMemsetAsync(p.sloc, 0, sizeof(uint16_t) * (size_t)(padded + 8), r.stream));
     PGH_HIP(hipMemsetAsync(p.drow, 0xff, sizeof(uint16_t) * (size_t)(padded + 8), r.stream));
     PGH_HIP(hipMemsetAsync(p.dstg, 0, sizeof(uint32_t) * (size_t)(padded / 8 + 1), r.stream));
     if (cold_vals) {
-        PGH_HIP(hipMalloc(&p.val, sizeof(float) * (size_t)(padded + 8)));
+        PGH_HIP(pooled_malloc(&p.val, sizeof(float) * (size_t)(padded + 8)));
         PGH_HIP(hipMemsetAsync(p.val, 0, sizeof(float) * (size_t)(padded + 8), r.stream));
     }
     k_pb_place<<<pb_blocks_for(count), kBlock, 0, r.stream>>>(keys_b.p, cold_vals ? sorted_vals.p : nullptr, count, p.num_chunks, p.num_bins, first.p,
@@ -1385,26 +1385,26 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         fprintf(stderr, "[pgh] pb: %lld entries (%lld padded), %d chunks, %d bins, phase A: %zu pieces over %d shares (piece %lld..%lld entries, <= %d per share)\n",
                 (long long)count, (long long)padded, p.num_chunks, p.num_bins, tasks.size(), shares, (long long)mn, (long long)mx, most);
     }
-    PGH_HIP(hipMalloc(&p.task, sizeof(int4) * (size_t)(tasks.size() + 1)));
-    PGH_HIP(hipMalloc(&p.task_range, sizeof(int) * (size_t)(shares + 1)));
+    PGH_HIP(pooled_malloc(&p.task, sizeof(int4) * (size_t)(tasks.size() + 1)));
+    PGH_HIP(pooled_malloc(&p.task_range, sizeof(int) * (size_t)(shares + 1)));
     if (!tasks.empty()) PGH_HIP(hipMemcpyAsync(p.task, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice, r.stream));
     PGH_HIP(hipMemcpyAsync(p.task_range, ranges.data(), sizeof(int) * (shares + 1), hipMemcpyHostToDevice, r.stream));
     {
         std::vector<int4> first(shares > 0 ? shares : 1, make_int4(0, 0, 0, 0));
         for (int w = 0; w < shares; ++w)
             if (ranges[w] < ranges[w + 1]) first[w] = tasks[ranges[w]];
-        PGH_HIP(hipMalloc(&p.first_task, sizeof(int4) * first.size()));
+        PGH_HIP(pooled_malloc(&p.first_task, sizeof(int4) * first.size()));
         PGH_HIP(hipMemcpyAsync(p.first_task, first.data(), sizeof(int4) * first.size(), hipMemcpyHostToDevice, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
-    PGH_HIP(hipMalloc(&p.tmp, sizeof(float) * (size_t)(((padded / 8 + 63) / 64 + 1) * 512)));      // whole blocks of 64 groups (pb_tmp_quad)
+    PGH_HIP(pooled_malloc(&p.tmp, sizeof(float) * (size_t)(((padded / 8 + 63) / 64 + 1) * 512)));      // whole blocks of 64 groups (pb_tmp_quad)
     {
         // (chunk, bin) runs of a dozen groups or more: the two-plane layout of tmp; shorter runs: quads side by side
         const double per_cell = (double)padded / ((double)std::max(p.num_chunks, 1) * (double)std::max(p.num_bins, 1));
         p.tmp_planes = per_cell >= 96.0 ? 1 : 0;
         if (getenv("PGH_PB_PLANES") != nullptr) p.tmp_planes = atoi(getenv("PGH_PB_PLANES")) != 0 ? 1 : 0;
     }
-    PGH_HIP(hipMalloc(&p.amax, sizeof(uint32_t) * 2));
+    PGH_HIP(pooled_malloc(&p.amax, sizeof(uint32_t) * 2));
     PGH_HIP(hipMemsetAsync(p.amax, 0, sizeof(uint32_t) * 2, r.stream));
     // ---- work list of k_pb_finish: the bins in row order (`mine` is sorted by first row; the pieces of a split hub row are
     // consecutive), the row stretches between them cut into epilogue-only items, hub items first (they are the longest).
@@ -1477,14 +1477,14 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         all_b.insert(all_b.end(), iso_b.begin(), iso_b.end());
         all_a.insert(all_a.end(), reg_a.begin(), reg_a.end());
         all_b.insert(all_b.end(), reg_b.begin(), reg_b.end());
-        PGH_HIP(hipMalloc(&p.item_a, sizeof(int4) * (size_t)(p.num_items + 1)));
-        PGH_HIP(hipMalloc(&p.item_b, sizeof(int4) * (size_t)(p.num_items + 1)));
+        PGH_HIP(pooled_malloc(&p.item_a, sizeof(int4) * (size_t)(p.num_items + 1)));
+        PGH_HIP(pooled_malloc(&p.item_b, sizeof(int4) * (size_t)(p.num_items + 1)));
         PGH_HIP(hipMemcpyAsync(p.item_a, all_a.data(), sizeof(int4) * all_a.size(), hipMemcpyHostToDevice, r.stream));
         PGH_HIP(hipMemcpyAsync(p.item_b, all_b.data(), sizeof(int4) * all_b.size(), hipMemcpyHostToDevice, r.stream));
         if (p.num_split > 0) {                             // piece sums are indexed by (hub) item, tickets by split row
-            PGH_HIP(hipMalloc(&p.hub_part, sizeof(double) * hub_a.size()));
+            PGH_HIP(pooled_malloc(&p.hub_part, sizeof(double) * hub_a.size()));
             PGH_HIP(hipMemsetAsync(p.hub_part, 0, sizeof(double) * hub_a.size(), r.stream));
-            PGH_HIP(hipMalloc(&p.hub_ticket, sizeof(uint32_t) * (size_t)p.num_split));
+            PGH_HIP(pooled_malloc(&p.hub_ticket, sizeof(uint32_t) * (size_t)p.num_split));
             PGH_HIP(hipMemsetAsync(p.hub_ticket, 0, sizeof(uint32_t) * (size_t)p.num_split, r.stream));
         }
         // ---- schedule: persistent grid = what the CUs hold at once.  The head of the item list is dealt round-robin in row
@@ -1548,21 +1548,21 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
             p.tail_begin = head;
             p.tail_count = tail;
             if (tail > 0) {
-                PGH_HIP(hipMalloc(&p.work_counter, sizeof(uint32_t)));
+                PGH_HIP(pooled_malloc(&p.work_counter, sizeof(uint32_t)));
                 PGH_HIP(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), r.stream));
             }
             p.sched_groups = groups;
-            PGH_HIP(hipMalloc(&p.sched, sizeof(int) * (size_t)(flat.size() + 1)));
-            PGH_HIP(hipMalloc(&p.sched_begin, sizeof(int) * (size_t)(groups + 1)));
+            PGH_HIP(pooled_malloc(&p.sched, sizeof(int) * (size_t)(flat.size() + 1)));
+            PGH_HIP(pooled_malloc(&p.sched_begin, sizeof(int) * (size_t)(groups + 1)));
             PGH_HIP(hipMemcpyAsync(p.sched, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice, r.stream));
             PGH_HIP(hipMemcpyAsync(p.sched_begin, begin.data(), sizeof(int) * begin.size(), hipMemcpyHostToDevice, r.stream));
             std::vector<int4> first_a(groups, make_int4(0, 0, 0, 0)), first_b(groups, make_int4(0, 0, -1, 0));
             std::vector<int> first_item(groups, -1);
             for (int w = 0; w < groups; ++w)
                 if (begin[w] < begin[w + 1]) first_item[w] = flat[begin[w]], first_a[w] = all_a[flat[begin[w]]], first_b[w] = all_b[flat[begin[w]]];
-            PGH_HIP(hipMalloc(&p.first_a, sizeof(int4) * (size_t)groups));
-            PGH_HIP(hipMalloc(&p.first_b, sizeof(int4) * (size_t)groups));
-            PGH_HIP(hipMalloc(&p.first_item, sizeof(int) * (size_t)groups));
+            PGH_HIP(pooled_malloc(&p.first_a, sizeof(int4) * (size_t)groups));
+            PGH_HIP(pooled_malloc(&p.first_b, sizeof(int4) * (size_t)groups));
+            PGH_HIP(pooled_malloc(&p.first_item, sizeof(int) * (size_t)groups));
             PGH_HIP(hipMemcpyAsync(p.first_a, first_a.data(), sizeof(int4) * (size_t)groups, hipMemcpyHostToDevice, r.stream));
             PGH_HIP(hipMemcpyAsync(p.first_b, first_b.data(), sizeof(int4) * (size_t)groups, hipMemcpyHostToDevice, r.stream));
             PGH_HIP(hipMemcpyAsync(p.first_item, first_item.data(), sizeof(int) * (size_t)groups, hipMemcpyHostToDevice, r.stream));
@@ -1586,8 +1586,8 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
 }
 
 void pb_plan_release(PbPlan* plan) {
-    (void)hipFree(plan->row_bin);
-    (void)hipFree(plan->cold_rank);
+    (void)pooled_free(plan->row_bin);
+    (void)pooled_free(plan->cold_rank);
     plan->cold_rank = nullptr;
     delete[] plan->host_bins;
     delete[] plan->host_split;
@@ -1766,28 +1766,28 @@ template int pb_launch_finish<EPI_ABSORB>(pgh_graph_s*, const RowSums&, const Ep
 template int pb_launch_finish<EPI_POLY>(pgh_graph_s*, const RowSums&, const EpiParams&, const LoopState*, int*);
 
 void pb_destroy(PbFormat& p) {
-    (void)hipFree(p.sloc);
-    (void)hipFree(p.val);
-    (void)hipFree(p.drop_edge);
-    (void)hipFree(p.task);
-    (void)hipFree(p.task_range);
-    (void)hipFree(p.first_task);
-    (void)hipFree(p.tmp);
-    (void)hipFree(p.dstg);
-    (void)hipFree(p.amax);
-    (void)hipFree(p.split);
-    (void)hipFree(p.hub_part);
-    (void)hipFree(p.hub_ticket);
-    (void)hipFree(p.item_a);
-    (void)hipFree(p.item_b);
-    (void)hipFree(p.sched);
-    (void)hipFree(p.sched_begin);
-    (void)hipFree(p.first_a);
-    (void)hipFree(p.first_b);
-    (void)hipFree(p.first_item);
-    (void)hipFree(p.work_counter);
-    (void)hipFree(p.bin);
-    (void)hipFree(p.drow);
+    (void)pooled_free(p.sloc);
+    (void)pooled_free(p.val);
+    (void)pooled_free(p.drop_edge);
+    (void)pooled_free(p.task);
+    (void)pooled_free(p.task_range);
+    (void)pooled_free(p.first_task);
+    (void)pooled_free(p.tmp);
+    (void)pooled_free(p.dstg);
+    (void)pooled_free(p.amax);
+    (void)pooled_free(p.split);
+    (void)pooled_free(p.hub_part);
+    (void)pooled_free(p.hub_ticket);
+    (void)pooled_free(p.item_a);
+    (void)pooled_free(p.item_b);
+    (void)pooled_free(p.sched);
+    (void)pooled_free(p.sched_begin);
+    (void)pooled_free(p.first_a);
+    (void)pooled_free(p.first_b);
+    (void)pooled_free(p.first_item);
+    (void)pooled_free(p.work_counter);
+    (void)pooled_free(p.bin);
+    (void)pooled_free(p.drow);
     p = PbFormat();
 }
 

@@ -1199,22 +1199,22 @@ int ensure_mm_layout(pgh_graph_s* g) {
     PGH_TRY(bsf_build(g, valfree ? nullptr : g->val, g->keep_mult, g->keep_src, g->keep_dst, true, 1, &g->bsf_mm));
     BsfFormat& f = g->bsf_mm;
     // [num_tiles][64] f32 carries live in the (otherwise unused) part / xg slots of the batch layout
-    PGH_HIP(hipMalloc(&f.part, sizeof(float) * (size_t)(f.num_tiles + 1) * kLanes));
-    PGH_HIP(hipMalloc(&f.xg, sizeof(float) * (size_t)(f.num_tiles + 1) * kLanes));
+    PGH_HIP(pooled_malloc(&f.part, sizeof(float) * (size_t)(f.num_tiles + 1) * kLanes));
+    PGH_HIP(pooled_malloc(&f.xg, sizeof(float) * (size_t)(f.num_tiles + 1) * kLanes));
     PGH_HIP(hipMemsetAsync(f.part, 0, sizeof(float) * (size_t)(f.num_tiles + 1) * kLanes, rt().stream));
     PGH_HIP(hipMemsetAsync(f.xg, 0, sizeof(float) * (size_t)(f.num_tiles + 1) * kLanes, rt().stream));
-    PGH_HIP(hipMalloc(&f.mm_close, sizeof(int32_t) * (size_t)f.num_entries));
+    PGH_HIP(pooled_malloc(&f.mm_close, sizeof(int32_t) * (size_t)f.num_entries));
     k_mm_close_rows<<<blocks_for((int64_t)f.num_tiles * 64, 64), WG, 0, rt().stream>>>(f.colf, f.tile, f.seg_row, f.num_tiles, f.mm_close);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(rt().stream));
     f.device_bytes += (int64_t)f.num_entries * 4;
-    PGH_HIP(hipMalloc(&f.mm_row_has, (size_t)(f.n_out > 0 ? f.n_out : 1)));
+    PGH_HIP(pooled_malloc(&f.mm_row_has, (size_t)(f.n_out > 0 ? f.n_out : 1)));
     PGH_HIP(hipMemsetAsync(f.mm_row_has, 0, (size_t)(f.n_out > 0 ? f.n_out : 1), rt().stream));
     k_mm_mark_rows<<<blocks_for(f.num_entries), WG, 0, rt().stream>>>(f.mm_close, f.num_entries, f.tile, f.seg_row, f.num_tiles, f.mm_row_has);
     PGH_HIP(hipGetLastError());
     PGH_HIP(hipStreamSynchronize(rt().stream));
     f.device_bytes += f.n_out;
-    PGH_HIP(hipMalloc(&f.mm_rowop, sizeof(float) * 4 * (size_t)(f.n_out > 0 ? f.n_out : 1)));
+    PGH_HIP(pooled_malloc(&f.mm_rowop, sizeof(float) * 4 * (size_t)(f.n_out > 0 ? f.n_out : 1)));
     k_mm_rowops<<<blocks_for(f.n_out), WG, 0, rt().stream>>>(f.dst_scale, f.src_scale, g->degrees, f.perm, f.n_out, g->n_rows,
                                                               reinterpret_cast<f32x4*>(f.mm_rowop));
     PGH_HIP(hipGetLastError());
@@ -1241,7 +1241,7 @@ int ensure_mm_edge_ids(pgh_graph_s* g) {
     BsfFormat& f = g->bsf_mm;
     if (f.mm_edge != nullptr) return 0;
     PGH_CHECK(g->rowptr != nullptr && g->col != nullptr, "graph_dropout on a batch needs the CSR image of the graph");
-    PGH_HIP(hipMalloc(&f.mm_edge, sizeof(int32_t) * (size_t)f.num_entries));
+    PGH_HIP(pooled_malloc(&f.mm_edge, sizeof(int32_t) * (size_t)f.num_entries));
     k_mm_edge_ids<<<blocks_for((int64_t)f.num_tiles * 64, 64), WG, 0, rt().stream>>>(f.colf, f.tile, f.seg_row, f.num_tiles, f.perm, g->rowptr,
                                                                                       g->col, f.mm_edge);
     PGH_HIP(hipGetLastError());

@@ -641,7 +641,7 @@ int ensure_state() {
     if (g_state) return 0;
     static_assert(sizeof(LoopState) % 8 == 0, "LoopAux follows LoopState in one allocation");
     void* both = nullptr;
-    PGH_HIP(hipMalloc(&both, sizeof(LoopState) + sizeof(LoopAux)));
+    PGH_HIP(pooled_malloc(&both, sizeof(LoopState) + sizeof(LoopAux)));
     PGH_HIP(hipMemset(both, 0, sizeof(LoopState) + sizeof(LoopAux)));
     g_state = reinterpret_cast<LoopState*>(both);
     g_aux = reinterpret_cast<LoopAux*>(reinterpret_cast<char*>(both) + sizeof(LoopState));
@@ -1332,13 +1332,13 @@ extern "C" int pgh_dist_set_send_lists(pgh_graph_t g, const uint32_t* slots_host
     if (total == 0) return dist_set_send_lists_device(g, nullptr, local_block, seg_offsets, segments);
     PGH_CHECK(slots_host != nullptr && total < (1LL << 31), "pgh_dist_set_send_lists: bad lists");
     uint32_t* d_slots = nullptr;
-    PGH_HIP(hipMalloc(&d_slots, sizeof(uint32_t) * (size_t)total));
+    PGH_HIP(pooled_malloc(&d_slots, sizeof(uint32_t) * (size_t)total));
     int rc = 0;
     if (hipMemcpyAsync(d_slots, slots_host, sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice, rt().stream) != hipSuccess ||
         hipStreamSynchronize(rt().stream) != hipSuccess)
         rc = fail("pgh_dist_set_send_lists: copy failed");
     if (rc == 0) rc = dist_set_send_lists_device(g, d_slots, local_block, seg_offsets, segments);
-    (void)hipFree(d_slots);
+    (void)pooled_free(d_slots);
     return rc;
 }
 
@@ -1346,7 +1346,7 @@ namespace pgh {
 int dist_set_send_lists_device(pgh_graph_s* g, const uint32_t* d_slots, const int32_t* local_block, const int64_t* seg_offsets, int32_t segments) {
     BsfFormat& f = g->bsf;
     Runtime& r = rt();
-    (void)hipFree(f.send_rows);
+    (void)pooled_free(f.send_rows);
     f.send_rows = nullptr;
     f.send_total = 0;
     f.send_stamp = 0;
@@ -1359,9 +1359,9 @@ int dist_set_send_lists_device(pgh_graph_s* g, const uint32_t* d_slots, const in
         PGH_CHECK(local_block[k] >= 0 && local_block[k] < local_blocks && seg_offsets[k + 1] >= seg_offsets[k], "pgh_dist_set_send_lists: bad segment");
     int64_t* d_off = nullptr;
     int32_t* d_blk = nullptr;
-    PGH_HIP(hipMalloc(&f.send_rows, sizeof(uint32_t) * (size_t)total));
+    PGH_HIP(pooled_malloc(&f.send_rows, sizeof(uint32_t) * (size_t)total));
     int rc = 0;
-    if (hipMalloc(&d_off, sizeof(int64_t) * (size_t)(segments + 1)) != hipSuccess || hipMalloc(&d_blk, sizeof(int32_t) * (size_t)segments) != hipSuccess)
+    if (pooled_malloc(&d_off, sizeof(int64_t) * (size_t)(segments + 1)) != hipSuccess || pooled_malloc(&d_blk, sizeof(int32_t) * (size_t)segments) != hipSuccess)
         rc = fail("pgh_dist_set_send_lists: out of device memory");
     if (rc == 0 && (hipMemcpyAsync(d_off, seg_offsets, sizeof(int64_t) * (size_t)(segments + 1), hipMemcpyHostToDevice, r.stream) != hipSuccess ||
                     hipMemcpyAsync(d_blk, local_block, sizeof(int32_t) * (size_t)segments, hipMemcpyHostToDevice, r.stream) != hipSuccess))
@@ -1370,10 +1370,10 @@ int dist_set_send_lists_device(pgh_graph_s* g, const uint32_t* d_slots, const in
         k_send_rows<<<grid_1d(total), 256, 0, r.stream>>>(d_slots, d_off, d_blk, segments, (int)f.blk_size, hot, total, f.send_rows);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(r.stream) != hipSuccess) rc = fail("pgh_dist_set_send_lists: kernel failed");
     }
-    (void)hipFree(d_off);
-    (void)hipFree(d_blk);
+    (void)pooled_free(d_off);
+    (void)pooled_free(d_blk);
     if (rc != 0) {
-        (void)hipFree(f.send_rows);
+        (void)pooled_free(f.send_rows);
         f.send_rows = nullptr;
         return rc;
     }
