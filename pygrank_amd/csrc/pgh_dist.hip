@@ -264,9 +264,18 @@ int setup_need_lists(pgh_comm_s* c, pgh_graph_t g, const int64_t* need8) {
     std::vector<int64_t> counts_all((size_t)world * nb, 0);
     uint32_t* d_asked = nullptr;
     int rc = 0;
+    // (after a bounded wait has given up on a stalled collective nothing may be freed -- hipFree waits for every queue of the
+    // device, which turns the bounded exit into a hang: the two buffers are then left to the process, like RunScope and _preflight do)
+    bool stalled = false;
     auto bail = [&](int code) {
-        (void)hipFree(d_counts);
-        (void)hipFree(d_asked);
+        if (!stalled) {
+            (void)hipFree(d_counts);
+            (void)hipFree(d_asked);
+        }
+        return code;
+    };
+    auto waited = [&](int code) {
+        stalled = code != 0;
         return code;
     };
     if (hipMemcpyAsync(d_counts + (int64_t)c->rank * nb, need8, sizeof(int64_t) * (size_t)nb, hipMemcpyHostToDevice, c->main) != hipSuccess)
@@ -275,7 +284,7 @@ int setup_need_lists(pgh_comm_s* c, pgh_graph_t g, const int64_t* need8) {
     if (hipMemcpyAsync(counts_all.data(), d_counts, sizeof(int64_t) * counts_all.size(), hipMemcpyDeviceToHost, c->main) != hipSuccess ||
         hipEventRecord(c->ev_host, c->main) != hipSuccess)
         return bail(fail("setup_need_lists: copy failed"));
-    if ((rc = bounded_wait(c->ev_host, "the exchange of the need-list sizes")) != 0) return bail(rc);
+    if ((rc = waited(bounded_wait(c->ev_host, "the exchange of the need-list sizes"))) != 0) return bail(rc);
     int64_t scounts[8] = {0}, soffs[8] = {0}, rcounts[8] = {0}, roffs[8] = {0}, asked_total = 0;
     for (int s = 0; s < world; ++s) {
         soffs[s] = need_prefix[s * bpr];
@@ -284,11 +293,11 @@ int setup_need_lists(pgh_comm_s* c, pgh_graph_t g, const int64_t* need8) {
         for (int j = 0; j < bpr; ++j) rcounts[s] += counts_all[(size_t)s * nb + c->rank * bpr + j];
         asked_total += rcounts[s];
     }
-    PGH_CHECK(asked_total < (1LL << 31), "setup_need_lists: the send lists are too long");
+    if (asked_total >= (1LL << 31)) return bail(fail("setup_need_lists: the send lists are too long"));
     if (hipMalloc(&d_asked, sizeof(uint32_t) * (size_t)(asked_total > 0 ? asked_total : 1)) != hipSuccess) return bail(fail("setup_need_lists: out of device memory"));
     if ((rc = comm_all_to_all_v(c, f.need_idx, scounts, soffs, d_asked, rcounts, roffs, c->main)) != 0) return bail(rc);
     if (hipEventRecord(c->ev_host, c->main) != hipSuccess) return bail(fail("setup_need_lists: event"));
-    if ((rc = bounded_wait(c->ev_host, "the exchange of the need lists")) != 0) return bail(rc);
+    if ((rc = waited(bounded_wait(c->ev_host, "the exchange of the need lists"))) != 0) return bail(rc);
     std::vector<int64_t> seg_off((size_t)world * bpr + 1, 0);
     std::vector<int32_t> seg_block((size_t)world * bpr, 0);
     for (int rk = 0; rk < world; ++rk)

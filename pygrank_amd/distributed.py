@@ -434,6 +434,9 @@ def _native_comm(dist, device):
                 # them in flight), so nothing else can be trusted to run here -- not the staged loop over torch's communicator, not a
                 # hipFree (it would wait for every queue of the device).  The process ends with a non-zero code and says how to
                 # relaunch; the launcher takes the other ranks down.  Nothing is re-executed from a process that has touched the GPU.
+                # (when only SOME ranks stall, the others sit in the staged loop's collectives until somebody ends them -- auto
+                # mode therefore belongs under a launcher that tears the job down when a rank exits: torch.distributed.run does, and so do
+                # bench.py's rank supervisors, which end every child of a rung as soon as one of them fails and start a fresh tree.)
                 sys.stderr.write(f"[pygrank_amd.distributed] rank {rank}: the engine-driven RCCL loop STALLED in its probe ({PREFLIGHT[key]}); "
                                  "this process cannot continue on a GPU with collectives in flight -- relaunch with PGH_DIST_NATIVE=0 "
                                  "(the Python-driven loop), or with PGH_DIST_SINGLE_COMM=1 PGH_DIST_SINGLE_STREAM=1\n")

@@ -320,6 +320,10 @@ class PageRank(RecursiveGraphFilter):
         batched = (not args and only_dropout and cfg is not None and self._plain_quotient()
                    and type(self)._formula is PageRank._formula and type(self)._step is RecursiveGraphFilter._step
                    and isinstance(self.personalization_transform, Tautology) and self.personalization_transform.ranker is None)
+        if self.dtype == "float64":
+            #  the multi-seed loop is an f32 loop: a ranker that promises f64 iterates and an fp64-eps tolerance runs its columns
+            # one by one through pgh_ppr_run_f64 (signals.py:225-226 as written) instead of silently changing precision
+            batched = False
         M = self.preprocessor(graph) if batched else None
         g = _device_graph(M) if batched else None
         if g is None or g.shape[0] != g.shape[1]:
