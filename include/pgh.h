@@ -280,6 +280,12 @@ int pgh_ppr_run_dropout(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_l
  * (tests/test_filters.py:189,194), which the f32 engine clamps at fp32 eps.  cfg->tol is used as given (the caller passes max(tol, fp64 eps));
  * the L1 / Mabs / max rules and "iters"; an exactness mode (one host look per step), not a fast one.  Square graphs with the blocked layout. */
 int pgh_ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
+/* ... and the other recursive filters with f64 iterates, sums, quotient and residual on the same f64 image (round 6): AbsorbingWalks
+ * (adhoc.py:157-169; the reference's default alpha = 1 - 1e-6 with tol = 1e-9 needs them) and SymmetricAbsorbingRandomWalks
+ * (adhoc.py:348-364).  The row weights of their formulas are formed in f64 from the graph's f32 degrees.  pgh_poly_run(chebyshev = 2)
+ * is the taylor form of the closed-form filters with f64 terms and accumulator. */
+int pgh_absorb_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
+int pgh_sarw_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 /* ranks: in = starting vector (copy of p or warm_start), out = final ranks. */
 int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 int pgh_absorb_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg,

@@ -895,7 +895,20 @@ int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg*
     return rc;
 }
 // PageRank with f64 storage (include/pgh.h pgh_ppr_run_f64): iterates, sums, quotient and residual in double over the stored f32 matrix
+static int recursive_run_f64(pgh_graph_t g, int mode, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
 int pgh_ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    return recursive_run_f64(g, 0, p, nullptr, ranks, cfg, res);
+}
+int pgh_absorb_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    CHECK(lam && g && lam->n == g->n_cols, "pgh_absorb_run_f64: absorption length mismatch");
+    return recursive_run_f64(g, 1, p, lam, ranks, cfg, res);
+}
+int pgh_sarw_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    return recursive_run_f64(g, 2, p, nullptr, ranks, cfg, res);
+}
+// mode 0 PageRank (adhoc.py:34-36), 1 AbsorbingWalks (adhoc.py:157-169), 2 SymmetricAbsorbingRandomWalks (adhoc.py:348-364); the walks take
+// the graph's f32 degrees, like the engine
+static int recursive_run_f64(pgh_graph_t g, int mode, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
     CHECK(g && p && ranks && cfg && res, "pgh_ppr_run_f64: null argument");
     CHECK(g->n_rows == g->n_cols && p->n == g->n_cols && ranks->n == g->n_cols, "pgh_ppr_run_f64: shape mismatch");
     CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
@@ -920,8 +933,24 @@ int pgh_ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_
         double S = 0.0;
         for (int64_t r = 0; r < n; ++r) {
             double acc = 0.0;
-            for (int64_t k = g->rowptr[r]; k < g->rowptr[r + 1]; ++k) acc += (double)g->val[k] * cur[g->col[k]];
-            next[r] = cfg->alpha * scale * acc + (1.0 - cfg->alpha) * pn[r];
+            if (mode == 2) {
+                for (int64_t k = g->rowptr[r]; k < g->rowptr[r + 1]; ++k) {
+                    const double dc = (double)g->degrees[g->col[k]];
+                    acc += (double)g->val[k] * (cur[g->col[k]] / ((std::sqrt(dc * 4.0 + 1.0) + 1.0) / 2.0));      // conv(ranks * pre, M)
+                }
+            } else {
+                for (int64_t k = g->rowptr[r]; k < g->rowptr[r + 1]; ++k) acc += (double)g->val[k] * cur[g->col[k]];
+            }
+            const double d = (double)g->degrees[r];
+            if (mode == 0) {
+                next[r] = cfg->alpha * scale * acc + (1.0 - cfg->alpha) * pn[r];
+            } else if (mode == 1) {
+                const double l = (double)lam->data[r];
+                next[r] = (scale * acc * d + pn[r] * l) / (l + d);                          // adhoc.py:167-168
+            } else {
+                const double a = (std::sqrt(d * 4.0 + 1.0) + 1.0) / 2.0;
+                next[r] = scale * acc * (d / (a + d)) + pn[r] * (a / (a + d));              // adhoc.py:363-364
+            }
             S += next[r];
         }
         const double scale_new = cfg->use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
@@ -1057,8 +1086,8 @@ int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
             const int it = cm.iteration;
             const double c = coeff(it);
             prev_res = resv;
-            if (it == 2) prev_term = term;                                   // abstract_filters.py:216-224
-            if (it > 2) {
+            if (chebyshev == 1 && it == 2) prev_term = term;                 // abstract_filters.py:216-224 (chebyshev == 2: taylor in f64)
+            if (chebyshev == 1 && it > 2) {
                 for (int64_t i = 0; i < n; ++i) term[i] = 2.0 * term[i] - prev_term[i];
                 prev_term = term;
             }

@@ -141,6 +141,8 @@ SIGNATURES = {
     "pgh_resident_step": (C.c_int, [c_graph, C.c_int32, c_vec, c_vec, C.c_double, c_vec, C.c_double, c_vec, c_vec, c_f64p]),
     "pgh_ppr_run": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_ppr_run_f64": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
+    "pgh_absorb_run_f64": (C.c_int, [c_graph, c_vec, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
+    "pgh_sarw_run_f64": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_ppr_run_dropout": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.c_double, C.c_uint64, C.POINTER(LoopResult)]),
     "pgh_absorb_run": (C.c_int, [c_graph, c_vec, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_sarw_run": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),

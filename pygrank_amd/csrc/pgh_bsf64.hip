@@ -343,6 +343,10 @@ struct Epi64 {
     const float*  src_scale;     // or null
     const float*  dst_scale;     // or null
     int           err_linf;
+    // per-row weights of the recursive filters in f64 (round 6; AbsorbingWalks adhoc.py:166-169, SymmetricAbsorbingRandomWalks :362-364):
+    // term_out = a * row_w * (M^T term) + b * term, and the next gather vector carries src_w (the walk's pre-scale of the iterate)
+    const double* row_w;         // or null (= 1)
+    const double* src_w;         // or null (= 1)
 };
 
 // rows [iso_from, blk) of every block are isolated (no entries, referenced by nobody); flag = 0: the personalization is zero
@@ -376,6 +380,9 @@ __global__ __launch_bounds__(WG) void k_bsf64_combine(const SegMeta* __restrict_
         const char* const ds_base = has_ds ? reinterpret_cast<const char*>(ep.dst_scale) : zero_base;
         const char* const src_base = has_src ? reinterpret_cast<const char*>(ep.src_scale) : zero_base;
         const char* const term_base = has_b ? reinterpret_cast<const char*>(ep.term) : zero_base;
+        const bool has_rw = ep.row_w != nullptr, has_sw = ep.src_w != nullptr;
+        const char* const rw_base = has_rw ? reinterpret_cast<const char*>(ep.row_w) : zero_base;
+        const char* const sw_base = has_sw ? reinterpret_cast<const char*>(ep.src_w) : zero_base;
         for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n_out; i += stride) {
             if (skip_iso && (int)((uint32_t)i % (uint32_t)iso.blk) >= iso.iso_from) continue;
             const int64_t w = i >> 6;
@@ -390,6 +397,8 @@ __global__ __launch_bounds__(WG) void k_bsf64_combine(const SegMeta* __restrict_
             const float dsc = *reinterpret_cast<const float*>(ds_base + (has_ds ? at4 : 0));
             const float ssc = *reinterpret_cast<const float*>(src_base + (has_src ? at4 : 0));
             const double tv = *reinterpret_cast<const double*>(term_base + (has_b ? at8 : 0));
+            const double rwv = *reinterpret_cast<const double*>(rw_base + (has_rw ? at8 : 0));
+            const double swv = *reinterpret_cast<const double*>(sw_base + (has_sw ? at8 : 0));
             const double r_old = ep.r[i];
             // second: the row's segment in every block
             double v[8];
@@ -406,9 +415,12 @@ __global__ __launch_bounds__(WG) void k_bsf64_combine(const SegMeta* __restrict_
             for (int b = 0; b < 8; ++b) sum += v[b];
             sum = has_ds ? sum * (double)dsc : sum;
             double y = ep.a * sum;
+            y = has_rw ? y * rwv : y;
             y = has_b ? y + ep.b * tv : y;
             ep.term_out[i] = y;
-            ep.xg_out[i] = has_src ? y * (double)ssc : y;
+            double gv = has_src ? y * (double)ssc : y;
+            gv = has_sw ? gv * swv : gv;
+            ep.xg_out[i] = gv;
             sum_y += y;
             const double r_new = r_old + ep.c * y;
             ep.r[i] = r_new;
@@ -438,9 +450,12 @@ __global__ __launch_bounds__(WG) void k_bsf64_combine(const SegMeta* __restrict_
             }
             if (ep.dst_scale != nullptr) s *= (double)ep.dst_scale[i];
             double y = ep.a * s;
+            if (ep.row_w != nullptr) y *= ep.row_w[i];
             if (ep.b != 0.0) y += ep.b * ep.term[i];
             ep.term_out[i] = y;
-            ep.xg_out[i] = ep.src_scale != nullptr ? y * (double)ep.src_scale[i] : y;
+            double gv = ep.src_scale != nullptr ? y * (double)ep.src_scale[i] : y;
+            if (ep.src_w != nullptr) gv *= ep.src_w[i];
+            ep.xg_out[i] = gv;
             sum_y += y;
             const double r_old = ep.r[i];
             const double r_new = r_old + ep.c * y;
@@ -572,8 +587,54 @@ int bsf64_take_col(pgh_graph_s* g, const double* vec, float* mat, int ld, int co
 
 // one term of the recurrence: term_out = a * (M^T term) + b * term, result += c * term_out; xg holds term * src_scale on
 // entry and term_out * src_scale on return.  Block partials of sum(term_out) / delta land in partial_sum / partial_delta.
+// Operands of the f64 recursive filters in the image's id space, from caller-space f32 vectors (padding slots: zeros).
+//   mode 1, AbsorbingWalks (adhoc.py:166-169): y = (s * deg + p * lam) / (lam + deg) = s * row_w + term with row_w = deg / (lam + deg),
+//           term = p_n * lam / (lam + deg)
+//   mode 2, SymmetricAbsorbingRandomWalks (adhoc.py:348-364): d = deg, a = (1 + sqrt(1 + 4 d)) / 2; the iterate is pre-scaled by 1 / a on the
+//           way into the product (src_w), row_w = d / (a + d), term = p_n * a / (a + d)
+__global__ void k_bsf64_walk_operands(int mode, const float* __restrict__ p, const float* __restrict__ deg, const float* __restrict__ lam,
+                                      const int32_t* __restrict__ perm, int64_t n_int, int64_t n_valid, double inv_norm,
+                                      double* __restrict__ row_w, double* __restrict__ src_w, double* __restrict__ term) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_int; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = perm ? perm[i] : (i < n_valid ? i : -1);
+        if (o < 0) {
+            row_w[i] = 0.0;
+            term[i] = 0.0;
+            if (src_w != nullptr) src_w[i] = 1.0;
+            continue;
+        }
+        const double pv = (double)p[o] * inv_norm, d = (double)deg[o];
+        if (mode == 1) {
+            const double l = (double)lam[o];
+            row_w[i] = d / (l + d);
+            term[i] = pv * l / (l + d);
+        } else {
+            const double a = (sqrt(d * 4.0 + 1.0) + 1.0) / 2.0;
+            src_w[i] = 1.0 / a;
+            row_w[i] = d / (a + d);
+            term[i] = pv * (a / (a + d));
+        }
+    }
+}
+__global__ void k_bsf64_scale_by(double* __restrict__ x, const double* __restrict__ w, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= w[i];
+}
+int bsf64_walk_operands(pgh_graph_s* g, int mode, const float* p, const float* deg, const float* lam, double inv_norm, double* row_w,
+                        double* src_w, double* term) {
+    const BsfFormat& f = g->bsf64;
+    k_bsf64_walk_operands<<<grid_for(f.n_out, 16), WG, 0, rt().stream>>>(mode, p, deg, lam, f.perm, f.n_out, g->n_cols, inv_norm, row_w, src_w, term);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+int bsf64_scale_by(pgh_graph_s* g, double* x, const double* w) {
+    k_bsf64_scale_by<<<grid_for(g->bsf64.n_out, 16), WG, 0, rt().stream>>>(x, w, g->bsf64.n_out);
+    PGH_HIP(hipGetLastError());
+    return 0;
+}
+
 int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term, double* term_out, double* result, double* xg,
-               int err_linf, const LoopState* state, double* partial_sum, double* partial_delta, int* num_partials, bool every_row) {
+               int err_linf, const LoopState* state, double* partial_sum, double* partial_delta, int* num_partials, bool every_row,
+               const double* row_w, const double* src_w) {
     Runtime& r = rt();
     BsfFormat& f = g->bsf64;
     View64 v;
@@ -614,6 +675,8 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
     ep.src_scale = f.src_scale;
     ep.dst_scale = f.dst_scale;
     ep.err_linf = err_linf;
+    ep.row_w = row_w;
+    ep.src_w = src_w;
     const int cgrid = grid_for((f.n_out + 3) / 4, 8);
     {
         ProfScope prof(PGH_K_COMBINE);

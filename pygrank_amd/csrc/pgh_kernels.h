@@ -787,7 +787,11 @@ int bsf64_bring(pgh_graph_s* g, const float* p, double c1, double* term, double*
 int bsf64_take(pgh_graph_s* g, const double* res, double factor, float* out);
 int bsf64_take_col(pgh_graph_s* g, const double* vec, float* mat, int ld, int col);
 int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term, double* term_out, double* result, double* xg,
-               int err_linf, const LoopState* state, double* partial_sum, double* partial_delta, int* num_partials, bool every_row = false);
+               int err_linf, const LoopState* state, double* partial_sum, double* partial_delta, int* num_partials, bool every_row = false,
+               const double* row_w = nullptr, const double* src_w = nullptr);
+int bsf64_walk_operands(pgh_graph_s* g, int mode, const float* p, const float* deg, const float* lam, double inv_norm, double* row_w,
+                        double* src_w, double* term);
+int bsf64_scale_by(pgh_graph_s* g, double* x, const double* w);
 int finish_graph(pgh_graph_s* g);
 
 }  // namespace pgh

@@ -2213,6 +2213,17 @@ extern "C" int pgh_ppr_run(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pg
 }
 
 int ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);      // (below: beside the f64 polynomial loop)
+int recursive_run_f64(pgh_graph_t g, int mode, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res);
+extern "C" int pgh_absorb_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    PGH_CHECK(g && p && lam && ranks && cfg && res, "pgh_absorb_run_f64: null argument");
+    PGH_CHECK(p->n == g->n_cols && ranks->n == g->n_cols && lam->n == g->n_cols, "pgh_absorb_run_f64: vector length mismatch");
+    return recursive_run_f64(g, 1, p, lam, ranks, cfg, res);
+}
+extern "C" int pgh_sarw_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    PGH_CHECK(g && p && ranks && cfg && res, "pgh_sarw_run_f64: null argument");
+    PGH_CHECK(p->n == g->n_cols && ranks->n == g->n_cols, "pgh_sarw_run_f64: vector length mismatch");
+    return recursive_run_f64(g, 2, p, nullptr, ranks, cfg, res);
+}
 extern "C" int pgh_ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
     PGH_CHECK(g && p && ranks && cfg && res, "pgh_ppr_run_f64: null argument");
     PGH_CHECK(p->n == g->n_cols && ranks->n == g->n_cols, "pgh_ppr_run_f64: vector length mismatch");
@@ -2268,7 +2279,7 @@ struct DevF64 {
 // The reference's "chebyshev" recurrence in f64 over the row-major CSR(M^T) (see EpiPoly64 for why).  Same loop structure,
 // stopping rule and iteration accounting as the f32 route of pgh_poly_run below.
 int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_coeffs, pgh_vec_t result, const pgh_loop_cfg* cfg,
-                 pgh_loop_result* res) {
+                 pgh_loop_result* res, bool cheb_recurrence) {
     Runtime& r = rt();
     const int64_t n = g->n_cols;
     auto coeff = [&](int it) -> double { return (it >= 1 && it <= num_coeffs) ? coeffs[it - 1] : 0.0; };
@@ -2351,7 +2362,7 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
             const int upto = (next_it + batch < max_iters) ? next_it + batch : max_iters;
             for (; next_it < upto; ++next_it) {
                 const int k = next_it;
-                const bool cheb = k > 2;                   // abstract_filters.py:219-221
+                const bool cheb = cheb_recurrence && k > 2;      // abstract_filters.py:219-221 (taylor: every term is M^T of the last)
                 EpiPoly64 epi;
                 epi.a = cheb ? 2.0 : 1.0;
                 epi.b = cheb ? -1.0 : 0.0;
@@ -2444,10 +2455,15 @@ __global__ __launch_bounds__(WG) void k_residual64(const double* __restrict__ a,
 }
 
 int ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
+    return recursive_run_f64(g, 0, p, nullptr, ranks, cfg, res);
+}
+// mode 0: PageRank (adhoc.py:34-36); 1: AbsorbingWalks with the per-node absorption `lam` (adhoc.py:157-169); 2: SymmetricAbsorbingRandomWalks
+// (adhoc.py:348-364).  The walks' row weights are formed in f64 from the graph's f32 degrees (bsf64_walk_operands).
+int recursive_run_f64(pgh_graph_t g, int mode, pgh_vec_t p, pgh_vec_t lam, pgh_vec_t ranks, const pgh_loop_cfg* cfg, pgh_loop_result* res) {
     Runtime& r = rt();
     memset(res, 0, sizeof(*res));
     const int64_t n = g->n_cols;
-    PGH_CHECK(g->n_rows == g->n_cols && bsf64_usable(g), "pgh_ppr_run_f64: the f64 image needs a square graph with the blocked layout");
+    PGH_CHECK(g->n_rows == g->n_cols && bsf64_usable(g), "pgh_*_run_f64: the f64 image needs a square graph with the blocked layout");
     PGH_CHECK(cfg->end_modulo >= 1, "end_modulo must be >= 1");
     PGH_TRY(bsf64_ensure(g));
     const int64_t nv = bsf64_length(g);
@@ -2481,6 +2497,22 @@ int ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg*
         y[0] = y0.p;
         scale = 1.0;
     }
+    // the walks: row weights, the constant term and (mode 2) the pre-scale of the iterate, in f64 in the image's id space
+    DevF64 row_w, src_w;
+    const double* row_w_p = nullptr;
+    const double* src_w_p = nullptr;
+    if (mode != 0) {
+        PGH_CHECK(mode == 2 || (lam != nullptr && lam->n == n), "pgh_absorb_run_f64: absorption length mismatch");
+        PGH_TRY(row_w.alloc(nv));
+        if (mode == 2) PGH_TRY(src_w.alloc(nv));
+        PGH_TRY(bsf64_walk_operands(g, mode, p->data, g->degrees, mode == 1 ? lam->data : nullptr, 1.0 / norm, row_w.p,
+                                    mode == 2 ? src_w.p : nullptr, pn.p));       // pn: the term of the walk's formula
+        row_w_p = row_w.p;
+        if (mode == 2) {
+            src_w_p = src_w.p;
+            PGH_TRY(bsf64_scale_by(g, xg64.p, src_w.p));    // the first product gathers x_0 / a as well
+        }
+    }
     std::vector<double> host((size_t)(rgrid > kMaxPartials ? rgrid : kMaxPartials));
     auto fold = [&](const double* dev, int count, int linf, double* out) -> int {
         PGH_HIP(hipMemcpyAsync(host.data(), dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, r.stream));
@@ -2499,7 +2531,8 @@ int ppr_run_f64(pgh_graph_t g, pgh_vec_t p, pgh_vec_t ranks, const pgh_loop_cfg*
     while (it < max_iters) {                               // convergence.py:86: the check comes before every step
         const int nxt = 1 - cur;
         int count = 0;
-        PGH_TRY(bsf64_step(g, cfg->alpha * scale, 1.0 - cfg->alpha, 0.0, pn.p, y[nxt], dummy.p, xg64.p, 0, nullptr, psum, pdel, &count, true));
+        const double a_step = mode == 0 ? cfg->alpha * scale : scale, b_step = mode == 0 ? 1.0 - cfg->alpha : 1.0;
+        PGH_TRY(bsf64_step(g, a_step, b_step, 0.0, pn.p, y[nxt], dummy.p, xg64.p, 0, nullptr, psum, pdel, &count, true, row_w_p, src_w_p));
         // (the epilogue's `term` slot holds p / |p| here, so its b * term is PageRank's (1 - alpha) * p; the gathered vector is the previous
         // iterate's y * source scale, its quotient rides in a)
         double S = 0.0;
@@ -2618,8 +2651,11 @@ extern "C" int pgh_poly_run(pgh_graph_t g, pgh_vec_t p, const double* coeffs, in
     memset(res, 0, sizeof(*res));
     // the reference's "chebyshev" recurrence amplifies rounding noise: f64 route (PGH_CHEB_F32=1 keeps it on the f32
     // kernels for measurements)
+    // chebyshev == 2: the TAYLOR form with f64 terms and accumulator (round 6: tolerances below fp32 eps; the caller clamps cfg->tol at
+    // fp64 eps like the reference's numpy backend, pygrank/core/backend/numpy.py:84-86)
+    if (chebyshev == 2) return poly_run_f64(g, p, coeffs, num_coeffs, result, cfg, res, false);
     if (chebyshev && !(getenv("PGH_CHEB_F32") != nullptr && atoi(getenv("PGH_CHEB_F32")) != 0))
-        return poly_run_f64(g, p, coeffs, num_coeffs, result, cfg, res);
+        return poly_run_f64(g, p, coeffs, num_coeffs, result, cfg, res, true);
     auto coeff = [&](int it) -> double { return (it >= 1 && it <= num_coeffs) ? coeffs[it - 1] : 0.0; };
     const int max_iters = cfg->max_iters;
     LoopTimer timer;

@@ -34,6 +34,11 @@ def _device_graph(M):
     return array if isinstance(array, DeviceGraph) else None
 
 
+def _f64_image_usable(g):
+    """The engine's f64 image serves square graphs that carry the blocked layout (csrc/pgh_bsf64.hip bsf64_usable)."""
+    return g is not None and g.shape[0] == g.shape[1] and g.shape[0] > 0 and g.nnz > 0 and "row-major" not in g.format()
+
+
 class GraphFilter(NodeRanking):
     """abstract_filters.py:11-106."""
 
@@ -41,7 +46,14 @@ class GraphFilter(NodeRanking):
     _BUILT_FROM_KWARGS = (("preprocessor", default_preprocessor), ("convergence", ConvergenceManager))
 
     def __init__(self, preprocessor=None, convergence=None, personalization_transform=None, preserve_norm=True,
-                 **kwargs):
+                 dtype=None, **kwargs):
+        """dtype (an extension of this backend; the reference's numpy engine is fp64 throughout, pygrank/core/backend/numpy.py:84-86):
+        None -- the engine's f32 loop, and f64 iterates / sums / quotient / residual on the engine's f64 image whenever the tolerance lies
+        below fp32 eps (where an f32 loop, clamped at fp32 eps by convergence.py:101, stops early: the reference's AbsorbingWalks default
+        alpha = 1 - 1e-6 with tol = 1e-9 takes 21 iterations, an f32 loop 12); "float32" -- always the f32 loop; "float64" -- always f64."""
+        if dtype not in (None, "float32", "float64"):
+            raise Exception("dtype is None (f32, f64 below fp32 eps), 'float32' or 'float64'")
+        self.dtype = dtype
         given = dict(preprocessor=preprocessor, convergence=convergence)
         for attribute, factory in self._BUILT_FROM_KWARGS:
             setattr(self, attribute, given[attribute] if given[attribute] is not None else call(factory, kwargs))
@@ -107,6 +119,21 @@ class GraphFilter(NodeRanking):
     def _fused_loop(self, M, personalization, ranks, out_scale, *args, **kwargs):
         """Runs the whole loop inside the engine when the configuration allows it; returns True when it did."""
         return False
+
+    def _f64_wanted(self):
+        """f64 iterates for this run (see __init__): asked for, or chosen because the tolerance lies below fp32 eps."""
+        if self.dtype == "float64":
+            return True
+        cm = self.convergence
+        if self.dtype == "float32" or type(cm) is not ConvergenceManager or cm.device_error_kind() in (None, L.ERR_ITERS):
+            return False
+        return cm.tol is None or float(cm.tol) < backend.epsilon()
+
+    def _f64_cfg(self, cfg):
+        """the loop configuration of an f64 route: the tolerance never below fp64 eps (convergence.py:101 with numpy's epsilon())"""
+        tol = self.convergence.tol
+        cfg.tol = 0.0 if tol is None else max(float(tol), float(np.finfo(np.float64).eps))
+        return cfg
 
     def _loop_cfg(self, alpha=0.0, use_quotient=False, out_scale=1.0):
         cm = self.convergence
@@ -233,20 +260,10 @@ class PageRank(RecursiveGraphFilter):
         (pygrank/core/backend/numpy.py:84-86) instead of fp32 eps -- e.g. tol=1e-9 as in the reference's tests/test_filters.py:189,194.
         An exactness mode (one host look per step); personalization and ranks stay f32 vectors."""
         self.alpha = alpha
-        if dtype not in (None, "float32", "float64"):
-            raise Exception("PageRank: dtype is None / 'float32' (the engine's f32 loop) or 'float64'")
-        self.dtype = None if dtype == "float32" else dtype
-        super().__init__(*args, **kwargs)
+        super().__init__(*args, dtype=dtype, **kwargs)
 
     def _reference(self):
         return f"personalized PageRank (restart probability {1 - self.alpha:.3g})"
-
-    def _f64_cfg(self, cfg):
-        """the loop configuration of the f64 route: the tolerance never below fp64 eps (convergence.py:101 with numpy's epsilon())"""
-        import numpy as np
-        tol = self.convergence.tol
-        cfg.tol = 0.0 if tol is None else max(float(tol), float(np.finfo(np.float64).eps))
-        return cfg
 
     def _formula(self, M, personalization, ranks, *args, **kwargs):               # adhoc.py:34-36
         return backend.conv(ranks, M) * self.alpha + personalization * (1 - self.alpha)
@@ -259,11 +276,12 @@ class PageRank(RecursiveGraphFilter):
         p = personalization.np
         if not isinstance(p, DeviceVector):
             return False
-        if self.dtype == "float64":
-            if cfg is None:
-                raise Exception("PageRank(dtype='float64') needs a stopping rule the engine evaluates (Mabs / L1 / MaxDifference / 'iters')")
-            return self._run_recursive(L.lib().pgh_ppr_run_f64, _device_graph(M), self._f64_cfg(cfg), ranks, p)
-        return self._run_recursive(L.lib().pgh_ppr_run, _device_graph(M), cfg, ranks, p)
+        if self.dtype == "float64" and cfg is None:
+            raise Exception("PageRank(dtype='float64') needs a stopping rule the engine evaluates (Mabs / L1 / MaxDifference / 'iters')")
+        g = _device_graph(M)
+        if cfg is not None and self._f64_wanted() and _f64_image_usable(g):
+            return self._run_recursive(L.lib().pgh_ppr_run_f64, g, self._f64_cfg(cfg), ranks, p)
+        return self._run_recursive(L.lib().pgh_ppr_run, g, cfg, ranks, p)
 
     fused_dropout = True          # False (on an instance): rank(..., graph_dropout=) takes the hook protocol, one engine call per primitive
 
@@ -288,7 +306,7 @@ class PageRank(RecursiveGraphFilter):
         self.convergence.start()
         ranks = to_signal(personalization, DeviceVector.empty(len(p)))
         entry = L.lib().pgh_ppr_run
-        if self.dtype == "float64":
+        if self._f64_wanted() and not dropout and _f64_image_usable(g):
             entry, cfg = L.lib().pgh_ppr_run_f64, self._f64_cfg(cfg)
         if dropout:
             # the masks the hook protocol would draw (abstract_filters.py:57-62): one for _start, one per step, one for _end -- step k
@@ -394,7 +412,10 @@ class AbsorbingWalks(RecursiveGraphFilter):
         if not isinstance(p, DeviceVector):
             return False
         lam = (to_signal(personalization.graph, absorption) * ((1 - self.alpha) / self.alpha)).np
-        return self._run_recursive(L.lib().pgh_absorb_run, _device_graph(M), cfg, ranks, p, lam)
+        g = _device_graph(M)
+        if cfg is not None and self._f64_wanted() and _f64_image_usable(g):
+            return self._run_recursive(L.lib().pgh_absorb_run_f64, g, self._f64_cfg(cfg), ranks, p, lam)
+        return self._run_recursive(L.lib().pgh_absorb_run, g, cfg, ranks, p, lam)
 
 
 class SymmetricAbsorbingRandomWalks(RecursiveGraphFilter):
@@ -431,6 +452,8 @@ class SymmetricAbsorbingRandomWalks(RecursiveGraphFilter):
         g = _device_graph(M)
         if not isinstance(p, DeviceVector) or g is None or "row-major" in g.format():     # PGH_FORMAT=csr: generic route
             return False
+        if cfg is not None and self._f64_wanted() and _f64_image_usable(g):
+            return self._run_recursive(L.lib().pgh_sarw_run_f64, g, self._f64_cfg(cfg), ranks, p)
         return self._run_recursive(L.lib().pgh_sarw_run, g, cfg, ranks, p)
 
 
@@ -780,8 +803,10 @@ class ClosedFormGraphFilter(GraphFilter):
             x = x._writable()              # written in place by the engine
         x._before_write()
         res = L.LoopResult()
-        L.check(L.lib().pgh_poly_run(g._h, p._h, coeffs.ctypes.data_as(C.c_void_p), len(coeffs),
-                                     1 if self.coefficient_type == "chebyshev" else 0, x._h, C.byref(cfg),
+        form = 1 if self.coefficient_type == "chebyshev" else 0
+        if self._f64_wanted() and _f64_image_usable(g):
+            form, cfg = (form or 2), self._f64_cfg(cfg)      # 2: the taylor form with f64 terms and accumulator
+        L.check(L.lib().pgh_poly_run(g._h, p._h, coeffs.ctypes.data_as(C.c_void_p), len(coeffs), form, x._h, C.byref(cfg),
                                      C.byref(res)))
         ranks.np = x
         self.last_loop = dict(iterations=res.iterations, converged=bool(res.converged), spmv=res.spmv_count,

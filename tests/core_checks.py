@@ -521,7 +521,7 @@ def check_pagerank_float64_storage(pg):
         want = golden[name + "|ranks"]
         assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), name
         # the f32 loop cannot honour that tolerance (it stops at fp32 eps): fewer iterations than the reference
-        f32 = pg.PageRank(preprocessor=pre, **kw)
+        f32 = pg.PageRank(preprocessor=pre, dtype="float32", **kw)      # (dtype=None picks f64 by itself for such a tolerance: round 6)
         f32.rank(pg.AdjacencyWrapper(A, directed=directed), p.copy())
         assert f32.convergence.iteration < want_iters, name
     # warm start, the max rule without the quotient, a fixed step count: against the oracle at fp64 eps
@@ -538,6 +538,49 @@ def check_pagerank_float64_storage(pg):
         assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), kw_oracle
     with pytest.raises(Exception):
         pg.PageRank(0.85, dtype="float16")
+
+
+def check_f64_iterates_for_every_filter(pg):
+    """VERDICT r5 item 6.  The reference's numpy engine is fp64 throughout (pygrank/core/backend/numpy.py:84-86); an f32 loop clamps a
+    tolerance below fp32 eps (convergence.py:101) and stops early.  With dtype=None a tolerance below fp32 eps sends PageRank,
+    AbsorbingWalks, SymmetricAbsorbingRandomWalks and the closed-form filters (taylor and "chebyshev") to f64 iterates on the engine's
+    f64 image: the REFERENCE's iteration counts (its own golden runs: AbsorbingWalks' default alpha = 1 - 1e-6 with tol = 1e-9 takes
+    21 iterations on the 10 K-node graph of configs[0]) and results to 1e-6; dtype="float32" keeps the clamped f32 loop, dtype="float64"
+    forces f64 at any tolerance."""
+    import os
+    import cases
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.npz"))
+    eps32 = float(np.finfo(np.float32).eps)
+    A, directed, p = cases.GRAPHS["er10k"]()
+    graph = pg.AdjacencyWrapper(A, directed=directed)
+    pre = pg.preprocessor(assume_immutability=True)
+    M = orc.normalize(A, "auto", directed)
+    aw = pg.AbsorbingWalks(tol=1e-9, max_iters=1000, preprocessor=pre)
+    got = np.asarray(aw.rank(graph, p.copy()).np, dtype=np.float64)
+    assert aw.convergence.iteration == int(gold["er10k/absorbing_default|iters"]) == 21
+    assert np.max(np.abs(got - gold["er10k/absorbing_default|ranks"])) <= 1e-6 * np.max(np.abs(gold["er10k/absorbing_default|ranks"]))
+    clamped = pg.AbsorbingWalks(tol=1e-9, max_iters=1000, preprocessor=pre, dtype="float32")
+    clamped.rank(graph, p.copy())
+    assert clamped.convergence.iteration == orc.absorbing_walks(M, p, tol=1e-9, max_iters=1000, eps=eps32)[1] < 21
+    # dtype="float64" at an ordinary tolerance: the oracle's fp64 loop, iteration for iteration
+    for make, ref in ((lambda **k: pg.AbsorbingWalks(0.85, tol=1e-6, max_iters=1000, preprocessor=pre, **k),
+                       lambda: orc.absorbing_walks(M, p, alpha=0.85, tol=1e-6, max_iters=1000)),
+                      (lambda **k: pg.SymmetricAbsorbingRandomWalks(error_type=pg.L1, tol=1e-8, max_iters=1000, preprocessor=pre, **k),
+                       lambda: orc.symmetric_absorbing_walks(M, p, error_type="l1", tol=1e-8, max_iters=1000)),
+                      (lambda **k: pg.HeatKernel(3, tol=1e-10, max_iters=200, preprocessor=pre, **k),
+                       lambda: orc.heat_kernel(M, p, t=3, tol=1e-10, max_iters=200)),
+                      (lambda **k: pg.PageRankClosed(0.85, error_type=pg.L1, tol=1e-9, max_iters=1000, preprocessor=pre, **k),
+                       lambda: orc.pagerank_closed(M, p, 0.85, error_type="l1", tol=1e-9, max_iters=1000))):
+        want, want_iters = ref()
+        for dtype in (None, "float64"):
+            ranker = make(dtype=dtype)
+            got = np.asarray(ranker.rank(graph, p.copy()).np, dtype=np.float64)
+            if dtype is None and ranker.convergence.tol >= eps32:
+                continue                                     # (an f32 run at an ordinary tolerance: covered by the golden cases)
+            assert ranker.convergence.iteration == want_iters, (type(ranker).__name__, dtype, ranker.convergence.iteration, want_iters)
+            assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), (type(ranker).__name__, dtype)
+    with pytest.raises(Exception):
+        pg.HeatKernel(3, dtype="float16")
 
 
 def check_differentiable_propagate(pg):

@@ -75,6 +75,13 @@ def tol_is_fp32_safe(kwargs):
     return tol is not None and tol >= EPS32
 
 
+def runs_in_f64(algo, kwargs):
+    """Round 6: a tolerance below fp32 eps sends the engine's whole-loop routes to its f64 image (pygrank_amd/filters.py _f64_wanted), so
+    such a case reproduces the REFERENCE's iteration count and result (the golden vectors as they are), not the count of a loop clamped
+    at fp32 eps.  The per-step routes (a per-iteration parameter list, a personalization that follows the iterate) stay f32."""
+    return not tol_is_fp32_safe(kwargs) and algo != "lowpass" and not kwargs.get("converge_to_eigenvectors")
+
+
 def partition_personalization(n):
     """The personalization tests/dist_worker.py feeds every rank (ORIGINAL ids)."""
     rng = np.random.default_rng(1)

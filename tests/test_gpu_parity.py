@@ -11,7 +11,7 @@ import pytest
 import cases
 import core_checks
 import kernel_checks
-from parity_common import EPS32, rel_linf, run_engine, run_oracle, tol_is_fp32_safe, tolerance_for
+from parity_common import EPS32, rel_linf, run_engine, run_oracle, runs_in_f64, tol_is_fp32_safe, tolerance_for
 
 pytestmark = pytest.mark.gpu
 
@@ -39,10 +39,13 @@ def test_core(gpu_engine, check):
 def test_filters_match_reference(gpu_engine, golden, graphs, name, gkey, algo, kwargs):
     A, directed, p = graphs(gkey)
     got, iters, ranker = run_engine(gpu_engine, A, directed, p, algo, kwargs)
-    want, want_iters = run_oracle(A, directed, p, algo, kwargs, eps=EPS32)   # engine epsilon() is fp32 (convergence.py:101)
+    # engine epsilon() is fp32 (convergence.py:101) -- except that a tolerance below it sends the whole-loop routes to the f64 image, where the
+    # REFERENCE's count and result are reproduced (round 6)
+    f64 = runs_in_f64(algo, kwargs)
+    want, want_iters = run_oracle(A, directed, p, algo, kwargs, **({} if f64 else dict(eps=EPS32)))
     assert iters == want_iters
     assert rel_linf(got, want) <= tolerance_for(kwargs)
-    if tol_is_fp32_safe(kwargs):
+    if tol_is_fp32_safe(kwargs) or f64:
         assert iters == int(golden[name + "|iters"])
         assert rel_linf(got, golden[name + "|ranks"]) <= tolerance_for(kwargs)
     if algo != "lowpass" and not kwargs.get("converge_to_eigenvectors"):
