@@ -187,8 +187,10 @@ def main():
                     want = orc.pagerank(M, feats[:, j], alpha=0.85, error_type="iters", max_iters=its, eps=EPS32)[0]
                 rel = np.max(np.abs(out[:, j] - want)) / max(np.max(np.abs(want)), 1e-30)
                 # a residual within f32 rounding of the tolerance may stop an iteration apart: the iterates then differ by ~tol.
-                # The columns are not normalised (magnitudes up to 17): the f32 rounding noise of a column's residual
-                # scales with it and reaches tens of percent of tol = 1e-6, i.e. up to two steps of the 0.85 contraction.
+                # Round 6 (tools/probe_propagate_stops.py, profiles/r06/propagate_stops.log): these inputs -- three seeds per column on graphs
+                # of a few dozen nodes -- land within a few percent of the tolerance in ~2 % of the columns; the SAME columns through the
+                # single-vector loop stop apart just as often (1.9 % against 2.1 %), and with f64 iterates (dtype="float64") never: what decides
+                # is the f32 trajectory, 1e-7 beside the fp64 one, not the batch loop.
                 record("propagate (per column)", rel, its - it)
                 if abs(its - it) > max(2, it // 25) or rel > 1e-6:
                     print("MISMATCH propagate", desc, "column", j, rel, "iterations", its, it, flush=True)
