@@ -222,17 +222,19 @@ int pgh_scaled_residual(int kind, pgh_vec_t y, double y_scale, pgh_vec_t x, doub
  * reductions are the ordinary pgh_axpby / pgh_ewise_* / pgh_reduce / pgh_scaled_residual calls on x_int.
  * n_int == 0: this image has no resident form (row-major, rectangular and partitioned images) -- conv stays pgh_spmv. */
 int pgh_graph_resident_len(pgh_graph_t g, int64_t* n_int, int64_t* n_gather);
-/* caller ids -> the id space (one pass; + the gather form) */
-int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, pgh_vec_t x_int, pgh_vec_t xg);
+/* caller ids -> the id space (one pass; + the gather form); padding slots get `hole` (0 for iterates; the absorption of mode 2 below
+ * wants 1 there, so that (0 * 0 + 0 * 1) / (1 + 0) is a zero and not 0 / 0) */
+int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, double hole, pgh_vec_t x_int, pgh_vec_t xg);
 /* the gather form of a resident vector that elementwise arithmetic produced (n_gather > 0 only) */
 int pgh_resident_gather(pgh_graph_t g, pgh_vec_t x_int, pgh_vec_t xg);
 /* the id space -> caller ids: y = y_int[new id of .] * factor (to_array / np.asarray of a lazy vector) */
 int pgh_resident_out(pgh_graph_t g, pgh_vec_t y_int, double factor, pgh_vec_t y);
 /* mode 0: y = a * M^T x (conv, numpy.py:64-65);  mode 1: y = a * M^T x + b * v (PageRank._formula with the lazily applied L1 quotient
- * folded into a).  Writes y_int and its gather form yg; pure (no output aliases an input).  sum_y (nullable) receives sum(y) and
- * synchronises (backend.sum of the step's outcome, abstract_filters.py:133-134). */
+ * folded into a);  mode 2: y = (a * M^T x * deg + v * lam) / (lam + deg) (AbsorbingWalks._formula, adhoc.py:166-169; deg_int / lam_int
+ * resident, NULL in the other modes).  Writes y_int and its gather form yg; pure (no output aliases an input).  sum_y (nullable)
+ * receives sum(y) and synchronises (backend.sum of the step's outcome, abstract_filters.py:133-134). */
 int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, pgh_vec_t xg, double a, pgh_vec_t v_int, double b,
-                      pgh_vec_t y_int, pgh_vec_t yg, double* sum_y);
+                      pgh_vec_t deg_int, pgh_vec_t lam_int, pgh_vec_t y_int, pgh_vec_t yg, double* sum_y);
 
 /* ---------------------------------------------------------------- whole loops on the device ------- */
 /* GraphFilter.rank's hot loop (abstract_filters.py:58-62) with ConvergenceManager semantics

@@ -701,13 +701,14 @@ int pgh_graph_resident_len(pgh_graph_t g, int64_t* n_int, int64_t* n_gather) {
     *n_gather = resident_ok(g) ? g->n_cols + kResidentPad + 1 : 0;
     return 0;
 }
-int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, pgh_vec_t x_int, pgh_vec_t xg) {
+int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, double hole, pgh_vec_t x_int, pgh_vec_t xg) {
     CHECK(resident_ok(g), "pgh_resident_in: this graph's image has no resident form");
     const int64_t n = g->n_cols;
-    CHECK(x && x_int && xg && x->n == n && x_int->n == n + kResidentPad && xg->n == n + kResidentPad + 1, "pgh_resident_in: vector length mismatch");
+    CHECK(x && x_int && x->n == n && x_int->n == n + kResidentPad && (xg == nullptr || xg->n == n + kResidentPad + 1), "pgh_resident_in: vector length mismatch");
     for (int64_t i = 0; i < n; ++i) x_int->data[i] = x->data[n - 1 - i];
-    for (int64_t i = n; i < n + kResidentPad; ++i) x_int->data[i] = 0.f;
-    for (int64_t i = 0; i < n + kResidentPad; ++i) xg->data[i] = 2.f * x_int->data[i];
+    for (int64_t i = n; i < n + kResidentPad; ++i) x_int->data[i] = (float)hole;
+    if (xg != nullptr)
+        for (int64_t i = 0; i < n + kResidentPad; ++i) xg->data[i] = 2.f * x_int->data[i];
     return 0;
 }
 int pgh_resident_gather(pgh_graph_t g, pgh_vec_t x_int, pgh_vec_t xg) {
@@ -724,15 +725,16 @@ int pgh_resident_out(pgh_graph_t g, pgh_vec_t y_int, double factor, pgh_vec_t y)
     for (int64_t i = 0; i < n; ++i) y->data[n - 1 - i] = y_int->data[i] * (float)factor;
     return 0;
 }
-int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, pgh_vec_t xg, double a, pgh_vec_t v_int, double b, pgh_vec_t y_int,
-                      pgh_vec_t yg, double* sum_y) {
+int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, pgh_vec_t xg, double a, pgh_vec_t v_int, double b, pgh_vec_t deg_int,
+                      pgh_vec_t lam_int, pgh_vec_t y_int, pgh_vec_t yg, double* sum_y) {
     CHECK(resident_ok(g), "pgh_resident_step: this graph's image has no resident form");
     const int64_t n = g->n_cols;
-    CHECK(mode == 0 || mode == 1, "pgh_resident_step: mode 0 or 1");
+    CHECK(mode >= 0 && mode <= 2, "pgh_resident_step: mode 0, 1 or 2");
+    CHECK(mode != 2 || (deg_int && lam_int && deg_int->n == n + kResidentPad && lam_int->n == n + kResidentPad), "pgh_resident_step: mode 2 needs the resident degrees and absorption");
     CHECK(x_int && xg && y_int && yg && x_int->n == n + kResidentPad && y_int->n == n + kResidentPad && xg->n == n + kResidentPad + 1 &&
               yg->n == n + kResidentPad + 1 && x_int->data != y_int->data && xg->data != yg->data,
           "pgh_resident_step: iterate length mismatch / aliasing");
-    CHECK(mode == 0 || (v_int && v_int->n == n + kResidentPad), "pgh_resident_step: mode 1 needs the resident second operand");
+    CHECK(mode == 0 || (v_int && v_int->n == n + kResidentPad), "pgh_resident_step: modes 1 and 2 need the resident second operand");
     std::vector<float> x((size_t)n);
     for (int64_t i = 0; i < n; ++i) x[(size_t)(n - 1 - i)] = 0.5f * xg->data[i];        // the step gathers from the gather form
     double sum = 0;
@@ -740,6 +742,10 @@ int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, pgh_vec_t xg
     for (int64_t r = 0; r < n; ++r) {
         float v = fa * row_dot(g, x.data(), r);
         if (mode == 1) v += fb * v_int->data[n - 1 - r];
+        if (mode == 2) {
+            const float d = deg_int->data[n - 1 - r], l = lam_int->data[n - 1 - r];
+            v = (v * d + v_int->data[n - 1 - r] * l) / (l + d);                                 // adhoc.py:167-168
+        }
         y_int->data[n - 1 - r] = v;
         sum += v;
     }

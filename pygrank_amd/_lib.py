@@ -135,10 +135,10 @@ SIGNATURES = {
     "pgh_poly_step": (C.c_int, [c_graph, c_vec, c_vec, C.c_double, C.c_double, c_vec, C.c_double, C.c_int, c_f64p]),
     "pgh_scaled_residual": (C.c_int, [C.c_int, c_vec, C.c_double, c_vec, C.c_double, c_f64p]),
     "pgh_graph_resident_len": (C.c_int, [c_graph, c_i64p, c_i64p]),
-    "pgh_resident_in": (C.c_int, [c_graph, c_vec, c_vec, c_vec]),
+    "pgh_resident_in": (C.c_int, [c_graph, c_vec, C.c_double, c_vec, c_vec]),
     "pgh_resident_gather": (C.c_int, [c_graph, c_vec, c_vec]),
     "pgh_resident_out": (C.c_int, [c_graph, c_vec, C.c_double, c_vec]),
-    "pgh_resident_step": (C.c_int, [c_graph, C.c_int32, c_vec, c_vec, C.c_double, c_vec, C.c_double, c_vec, c_vec, c_f64p]),
+    "pgh_resident_step": (C.c_int, [c_graph, C.c_int32, c_vec, c_vec, C.c_double, c_vec, C.c_double, c_vec, c_vec, c_vec, c_vec, c_f64p]),
     "pgh_ppr_run": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_ppr_run_f64": (C.c_int, [c_graph, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),
     "pgh_absorb_run_f64": (C.c_int, [c_graph, c_vec, c_vec, c_vec, C.POINTER(LoopCfg), C.POINTER(LoopResult)]),

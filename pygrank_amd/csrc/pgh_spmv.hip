@@ -986,12 +986,12 @@ extern "C" int pgh_graph_resident_len(pgh_graph_t g, int64_t* n_int, int64_t* n_
     return 0;
 }
 
-extern "C" int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, pgh_vec_t x_int, pgh_vec_t xg) {
+extern "C" int pgh_resident_in(pgh_graph_t g, pgh_vec_t x, double hole, pgh_vec_t x_int, pgh_vec_t xg) {
     PGH_CHECK(resident_usable(g), "pgh_resident_in: this graph's image has no resident form (pgh_graph_resident_len)");
     BsfFormat& f = g->bsf;
     PGH_CHECK(x && x_int && x->n == g->n_cols && x_int->n == f.n_out, "pgh_resident_in: vector length mismatch");
-    PGH_CHECK((f.src_scale != nullptr) == (xg != nullptr) && (xg == nullptr || xg->n == f.n_src_pad + 1), "pgh_resident_in: gather form mismatch");
-    PGH_TRY(bsf_out_to_internal(g, x->data, x_int->data, 0.f));
+    PGH_CHECK(xg == nullptr || (f.src_scale != nullptr && xg->n == f.n_src_pad + 1), "pgh_resident_in: gather form mismatch");
+    PGH_TRY(bsf_out_to_internal(g, x->data, x_int->data, (float)hole));
     if (xg != nullptr) PGH_TRY(bsf_make_gather(g, x_int->data, f.src_scale, xg->data));
     return 0;
 }
@@ -1009,10 +1009,11 @@ extern "C" int pgh_resident_out(pgh_graph_t g, pgh_vec_t y_int, double factor, p
 }
 
 extern "C" int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, pgh_vec_t xg, double a, pgh_vec_t v_int, double b,
-                                 pgh_vec_t y_int, pgh_vec_t yg, double* sum_y) {
+                                 pgh_vec_t deg_int, pgh_vec_t lam_int, pgh_vec_t y_int, pgh_vec_t yg, double* sum_y) {
     PGH_CHECK(resident_usable(g), "pgh_resident_step: this graph's image has no resident form (pgh_graph_resident_len)");
     BsfFormat& f = g->bsf;
-    PGH_CHECK(mode == 0 || mode == 1, "pgh_resident_step: mode 0 (y = a M^T x) or 1 (y = a M^T x + b v)");
+    PGH_CHECK(mode >= 0 && mode <= 2, "pgh_resident_step: mode 0 (y = a M^T x), 1 (y = a M^T x + b v) or 2 (the absorbing walk's formula)");
+    PGH_CHECK(mode != 2 || (deg_int && lam_int && deg_int->n == f.n_out && lam_int->n == f.n_out), "pgh_resident_step: mode 2 needs the resident degrees and absorption");
     PGH_CHECK(x_int && y_int && x_int->n == f.n_out && y_int->n == f.n_out && x_int->data != y_int->data, "pgh_resident_step: iterate length mismatch / aliasing");
     PGH_CHECK(mode == 0 || (v_int && v_int->n == f.n_out), "pgh_resident_step: mode 1 needs the resident second operand");
     const bool scaled = f.src_scale != nullptr;
@@ -1024,8 +1025,12 @@ extern "C" int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, p
     EpiParams ep{};
     ep.a = a;
     ep.b = b;
-    ep.v = mode == 1 ? v_int->data : nullptr;
+    ep.v = mode != 0 ? v_int->data : nullptr;
     ep.y = y_int->data;
+    if (mode == 2) {
+        ep.deg = deg_int->data;
+        ep.lam = lam_int->data;
+    }
     if (scaled) {
         ep.xg_out = yg->data;
         ep.src_scale = f.src_scale;
@@ -1035,6 +1040,7 @@ extern "C" int pgh_resident_step(pgh_graph_t g, int32_t mode, pgh_vec_t x_int, p
     int count = 0;
     const float* gather_src = scaled ? xg->data : x_int->data;
     if (mode == 1) PGH_TRY((launch_step<EPI_AXPBY>(g, ep, gather_src, g_state, &count)));
+    else if (mode == 2) PGH_TRY((launch_step<EPI_ABSORB>(g, ep, gather_src, g_state, &count)));
     else PGH_TRY((launch_step<EPI_PLAIN>(g, ep, gather_src, g_state, &count)));
     if (sum_y != nullptr) {
         ProfScope prof(PGH_K_FINAL);

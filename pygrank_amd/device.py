@@ -150,6 +150,11 @@ class DeviceVector:
         if isinstance(other, DeviceVector):
             if other._n != self._n:
                 raise L.EngineError(f"operands have different lengths {self._n} vs {other._n}")
+            if LAZY and op in (L.MUL, L.ADD) and self._n > 0 and self._keepalive is None and other._keepalive is None \
+                    and _kind(self) in _VV_OPERANDS and _kind(other) in _VV_OPERANDS:
+                # p * lam and lam + deg of AbsorbingWalks._formula (adhoc.py:166-169) are formed again in every step: unevaluated, the
+                # walk's formula is recognised whole (LazyVector "walk") and neither of them is ever computed
+                return LazyVector.elementwise(op, (other, self) if reflected else (self, other))
             out = DeviceVector.empty(self._n)
             a, b = (other, self) if reflected else (self, other)
             L.check(L.lib().pgh_ewise_vv(op, a._h, b._h, out._h))
@@ -281,8 +286,9 @@ class DeviceVector:
 # ======================================================================================================================
 LAZY = True                    # False: every primitive is evaluated where it stands (one engine call each; A/B measurements, tests)
 _RESIDENT_CACHES = []          # the per-graph caches of resident copies of plain vectors (DeviceVector._before_write drops its entry)
-_RESIDENT_KINDS = ("res", "conv", "scaled", "axpby", "lin")
+_RESIDENT_KINDS = ("res", "conv", "scaled", "axpby", "lin", "walk", "cmul", "cmul_add")
 _MAX_DEPTH = 6
+_VV_OPERANDS = (None, "mat", "plain")  # operands of an unevaluated elementwise product / sum in the caller's ids
 _MEMORY_KINDS = (None, "mat")     # values held in the caller's ids: a plain DeviceVector, an expression already evaluated there
 
 
@@ -334,6 +340,9 @@ class LazyVector(DeviceVector):
       "axpby"     a * (node) + b * p, node = M^T src     "res" by ONE pgh_resident_step(mode 1), sum(y) included
       "lin"       sa * u + sb * v, optionally |.|        "res" by pgh_axpby in the id space; sum / max of |u - v| is ONE
                                                          pgh_scaled_residual on the resident operands, nothing is written
+      "walk"      the absorbing walk's formula            "res" by ONE pgh_resident_step(mode 2): (a M^T src * deg + p * lam) / (lam + deg),
+                  (adhoc.py:166-169), recognised piece by piece: conv * deg ("cmul"), + p * lam ("cmul_add"), / (lam + deg)
+      "vv"        u * v or u + v    (caller ids)         memory of its own (one pgh_ewise_vv) when looked at -> "mat"
       "plain"     b * p             (p in caller ids)    memory of its own (one pgh_ewise_vs) when looked at -> "mat"
       "mat"       evaluated in the caller's ids          --
 
@@ -345,7 +354,7 @@ class LazyVector(DeviceVector):
 
     # (no __slots__ here: the fields of an expression live in the instance dictionary over these class-level defaults, so creating
     # one -- five per PageRank step -- stores three attributes, not seventeen)
-    _kind = _graph = _res = _src = _p = _u = _v = _mat = None
+    _kind = _graph = _res = _src = _p = _u = _v = _mat = _op = _d = _lam = None
     _scale = _a = _b = _sa = _sb = 1.0
     _abs = False
     _depth = 0                      # unevaluated expressions below this one; a chain is evaluated before it grows past _MAX_DEPTH
@@ -363,7 +372,7 @@ class LazyVector(DeviceVector):
             out._kind, out._graph, out._res, out._scale = "res", vec._graph, vec._res, vec._scale * factor
         elif k == "scaled":
             out._kind, out._graph, out._src, out._scale, out._depth = "scaled", vec._graph, vec._src, vec._scale * factor, vec._depth
-        elif k in ("conv", "axpby", "lin"):                # evaluated once, shared by every view of it
+        elif k in ("conv", "axpby", "lin", "walk", "cmul", "cmul_add"):      # evaluated once, shared by every view of it
             out._kind, out._graph, out._src, out._scale, out._depth = "scaled", vec._graph, vec, factor, vec._depth
         elif k == "plain":
             out._kind, out._p, out._b = "plain", vec._p, vec._b * factor
@@ -380,6 +389,44 @@ class LazyVector(DeviceVector):
         if _kind(x) not in _RESIDENT_KINDS:
             x._depend(out)
         return out._bounded(getattr(x, "_depth", 0) + 1)
+
+    @staticmethod
+    def elementwise(op, pair):
+        out = LazyVector(pair[0]._n)
+        out._kind, out._op, out._u, out._v = "vv", op, pair[0], pair[1]
+        for vec in pair:
+            (vec._p if _kind(vec) == "plain" else vec)._depend(out)
+        return out
+
+    def _walk_stage(self, op, other):
+        """The next piece of AbsorbingWalks._formula, or None: conv * deg -> "cmul"; cmul + p * lam -> "cmul_add"; cmul_add / (lam + deg) ->
+        "walk" when the two lam and the two deg are the same objects (the filter's attributes)."""
+        k = self._kind
+        if op == L.MUL and _kind(other) in _MEMORY_KINDS and (k == "conv" or (k == "scaled" and _kind(self._src) == "conv")):
+            node, coeff = (self, 1.0) if k == "conv" else (self._src, self._scale)
+            out = LazyVector(self._n)
+            out._kind, out._graph, out._src, out._a, out._d = "cmul", self._graph, node, coeff, other
+            other._depend(out)
+            return out._bounded(node._depth + 1)
+        if op == L.ADD and k == "cmul" and _kind(other) == "vv" and other._op == L.MUL:
+            out = LazyVector(self._n)
+            out._kind, out._graph, out._src, out._a, out._d, out._p = "cmul_add", self._graph, self._src, self._a, self._d, other
+            return out._bounded(self._depth)
+        if op == L.DIV and k == "cmul_add" and _kind(other) == "vv" and other._op == L.ADD:
+            q = self._p
+            for lam, deg in ((other._u, other._v), (other._v, other._u)):
+                if deg is not self._d:
+                    continue
+                p = q._v if q._u is lam else (q._u if q._v is lam else None)
+                if p is None or _kind(lam) not in _VV_OPERANDS or _kind(p) not in _VV_OPERANDS:
+                    continue
+                out = LazyVector(self._n)
+                out._kind, out._graph, out._src, out._a, out._d, out._lam, out._p = "walk", self._graph, self._src, self._a, deg, lam, p
+                for vec in (lam, p):
+                    (vec._p if _kind(vec) == "plain" else vec)._depend(out)
+                deg._depend(out)
+                return out._bounded(self._depth)
+        return None
 
     def _bounded(self, depth):
         """A filter that never looks at its iterate (error_type="iters", no quotient) would nest one expression per step: the chain is
@@ -433,15 +480,50 @@ class LazyVector(DeviceVector):
             xg = src_res.gather_form()
             if k == "conv":
                 L.check(lib.pgh_resident_step(g._h, 0, src_res.y._h, xg._h if xg is not None else None, node._a * src_scale, None, 0.0,
-                                              y._h, yg._h if yg is not None else None, None))
+                                              None, None, y._h, yg._h if yg is not None else None, None))
                 total = None
             else:
                 p_res, p_scale = self._resident_of(g, self._p)
                 got = C.c_double()
                 L.check(lib.pgh_resident_step(g._h, 1, src_res.y._h, xg._h if xg is not None else None, self._a * node._a * src_scale,
-                                              p_res.y._h, self._b * p_scale, y._h, yg._h if yg is not None else None, C.byref(got)))
+                                              p_res.y._h, self._b * p_scale, None, None, y._h, yg._h if yg is not None else None, C.byref(got)))
                 total = got.value
             self._kind, self._res, self._scale, self._src, self._p = "res", _Resident(g, y, yg, total), 1.0, None, None
+            return
+        if k in ("cmul", "cmul_add"):
+            # a piece of the walk's formula that somebody looked at before it was whole: the product in the id space (padding: 0 * 0)
+            node = self._src
+            conv_res, conv_scale = self._resident_of(g, node)
+            d_res = g._resident_copy(self._d)
+            y = DeviceVector.empty(g._n_int)
+            L.check(lib.pgh_ewise_vv(L.MUL, conv_res.y._h, d_res.y._h, y._h))
+            scale = conv_scale * self._a
+            if k == "cmul_add":
+                q_res, q_scale = self._resident_of(g, self._p)
+                z = DeviceVector.empty(g._n_int)
+                L.check(lib.pgh_axpby(scale, y._h, q_scale, q_res.y._h, z._h))
+                y, scale = z, 1.0
+            self._kind, self._res, self._scale, self._src, self._d, self._p = "res", _Resident(g, y), scale, None, None, None
+            return
+        if k == "walk":
+            node = self._src
+            src_res, src_scale = self._resident_of(g, node._src)
+            p_mem = self._p
+            lam_mem = self._lam
+            for vec in (p_mem, lam_mem):
+                if _kind(vec) == "plain":
+                    vec._h                                   # noqa: B018 -- lam = ones * lambda, p = signal / norm: evaluated once, then remembered
+            p_res = g._resident_copy(p_mem)
+            lam_res = g._resident_copy(lam_mem, hole=1.0)    # padding: (0 * 0 + 0 * 1) / (1 + 0)
+            d_res = g._resident_copy(self._d)
+            y = DeviceVector.empty(g._n_int)
+            yg = DeviceVector.empty(g._n_gather) if g._n_gather else None
+            xg = src_res.gather_form()
+            got = C.c_double()
+            L.check(lib.pgh_resident_step(g._h, 2, src_res.y._h, xg._h if xg is not None else None, self._a * node._a * src_scale, p_res.y._h, 1.0,
+                                          d_res.y._h, lam_res.y._h, y._h, yg._h if yg is not None else None, C.byref(got)))
+            self._kind, self._res, self._scale = "res", _Resident(g, y, yg, got.value), 1.0
+            self._src = self._p = self._d = self._lam = None
             return
         if k == "lin":
             u_res, u_scale = self._resident_of(g, self._u)
@@ -465,6 +547,10 @@ class LazyVector(DeviceVector):
                 out = DeviceVector.empty(self._n)
                 L.check(L.lib().pgh_ewise_vs(L.MUL, self._p._h, float(self._b), 0, out._h))
                 self._kind, self._p = "mat", None
+            elif k == "vv":
+                out = DeviceVector.empty(self._n)
+                L.check(L.lib().pgh_ewise_vv(self._op, self._u._h, self._v._h, out._h))
+                self._kind, self._u, self._v = "mat", None, None
             elif k in _RESIDENT_KINDS:
                 self._flush()
                 out = DeviceVector.empty(self._n)
@@ -499,6 +585,13 @@ class LazyVector(DeviceVector):
 
     # ---- arithmetic that stays lazy ---------------------------------------------------------------------------------
     def _binary(self, op, other, reflected=False):
+        if isinstance(other, DeviceVector) and other._n == self._n and op in (L.MUL, L.ADD, L.DIV):
+            a, b = (other, self) if reflected else (self, other)            # a (op) b
+            stage = a._walk_stage(op, b) if isinstance(a, LazyVector) else None
+            if stage is None and op != L.DIV and isinstance(b, LazyVector):  # (products and sums commute)
+                stage = b._walk_stage(op, a)
+            if stage is not None:
+                return stage
         if self._kind != "mat":
             if _is_scalar(other):
                 factor = _scalar_factor(op, float(other), reflected)
@@ -770,21 +863,22 @@ class DeviceGraph:
                 _RESIDENT_CACHES.append(self._resident)
         return self._n_int
 
-    def _resident_copy(self, vec):
+    def _resident_copy(self, vec, hole=0.0):
         """`vec` (caller's ids) in this graph's id space; remembered while the vector lives unwritten (a run's personalization is an
-        operand of every step).  At most four copies are kept."""
+        operand of every step; so are the degrees and the absorption of a walk, whose padding slots take `hole`).  At most six copies are
+        kept."""
         import weakref
         hit = self._resident.get(id(vec))
-        if hit is not None and hit[0]() is vec:
+        if hit is not None and hit[0]() is vec and hit[2] == hole:
             return hit[1]
         y = DeviceVector.empty(self._n_int)
-        xg = DeviceVector.empty(self._n_gather) if self._n_gather else None
-        L.check(L.lib().pgh_resident_in(self._h, vec._h, y._h, xg._h if xg is not None else None))
+        xg = DeviceVector.empty(self._n_gather) if (self._n_gather and hole == 0.0) else None
+        L.check(L.lib().pgh_resident_in(self._h, vec._h, float(hole), y._h, xg._h if xg is not None else None))
         res = _Resident(self, y, xg)
         if _kind(vec) in _MEMORY_KINDS and vec._keepalive is None:
-            while len(self._resident) >= 4:
+            while len(self._resident) >= 6:
                 self._resident.pop(next(iter(self._resident)))
-            self._resident[id(vec)] = (weakref.ref(vec), res)
+            self._resident[id(vec)] = (weakref.ref(vec), res, hole)
         return res
 
     @staticmethod

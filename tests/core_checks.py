@@ -714,6 +714,24 @@ def check_lazy_vectors_are_plain_vectors_to_every_observer(pg):
     nxt = pg.conv(term, MA)
     close(result, p0 + 0.3 * (TA @ x0))
     close(nxt, TA @ (TA @ x0))
+    # the absorbing walk's formula piece by piece (adhoc.py:166-169), whole and interrupted at every stage
+    deg, lam = pg.to_array(rng.random(n) + 0.5), pg.to_array(rng.random(n) + 0.1)
+    deg0, lam0 = np.asarray(deg), np.asarray(lam)
+    walk = (pg.conv(x, MA) * deg + p * lam) / (lam + deg)
+    assert walk._kind == "walk"
+    close(walk, ((TA @ x0) * deg0 + p0 * lam0) / (lam0 + deg0))
+    assert abs(pg.sum((pg.conv(x, MA) * 0.5 * deg + p * lam) / (lam + deg)) - ((0.5 * (TA @ x0) * deg0 + p0 * lam0) / (lam0 + deg0)).sum()) <= 1e-4
+    close(pg.conv(x, MA) * deg, (TA @ x0) * deg0)                                       # "cmul", looked at
+    close(pg.conv(x, MA) * deg + p * lam, (TA @ x0) * deg0 + p0 * lam0)                 # "cmul_add", looked at
+    close((pg.conv(x, MA) * deg + p * lam) / (lam + p), ((TA @ x0) * deg0 + p0 * lam0) / (lam0 + p0))      # not the walk: another divisor
+    close((pg.conv(x, MA) * deg + p * lam) / 2.0, ((TA @ x0) * deg0 + p0 * lam0) / 2.0)
+    close(p * lam, p0 * lam0)                                                           # "vv": an ordinary product to whoever looks
+    close((p * lam) * 2.0 + (lam + deg), 2.0 * p0 * lam0 + lam0 + deg0)
+    close(deg * pg.conv(x, MA), deg0 * (TA @ x0))
+    held = p * lam
+    p[2] = 9.0                                                                          # written after the product was formed
+    close(held, p0 * lam0)
+    p[2] = float(p0[2])
     # a filter that never looks at its iterate nests one expression per step: the chain is evaluated before it can exhaust the stack
     it, want_it = x, x0
     for _ in range(1500):
@@ -758,7 +776,10 @@ def check_backend_primitive_route_is_one_step_per_formula(pg):
             setattr(lib, name, counted(name))
         for make, per_iteration in ((lambda: pg.PageRank(0.85, preprocessor=pre, error_type=pg.L1, tol=1e-6, max_iters=1000),
                                      dict(pgh_resident_step=1, pgh_scaled_residual=1)),
-                                    (lambda: pg.HeatKernel(5, preprocessor=pre, error_type="iters", max_iters=12), dict(pgh_resident_step=1, pgh_axpby=1))):
+                                    (lambda: pg.HeatKernel(5, preprocessor=pre, error_type="iters", max_iters=12), dict(pgh_resident_step=1, pgh_axpby=1)),
+                                    # AbsorbingWalks._formula (adhoc.py:166-169) recognised whole: conv * deg, + p * lam, / (lam + deg)
+                                    (lambda: pg.AbsorbingWalks(0.85, preprocessor=pre, error_type=pg.L1, tol=1e-6, max_iters=1000),
+                                     dict(pgh_resident_step=1, pgh_scaled_residual=1))):
             ranker = make()
             ranker._fused_loop = lambda *a, **k: False
             ranker._fused_rank = lambda *a, **k: None
@@ -773,7 +794,7 @@ def check_backend_primitive_route_is_one_step_per_formula(pg):
             assert counts["pgh_resident_out"] == 1
             for name, each in per_iteration.items():
                 assert steps - 2 <= counts[name] <= steps * each + 1, (name, counts[name], steps)
-            assert counts["pgh_resident_in"] <= 3 and counts["pgh_ewise_vv"] <= 2 and counts["pgh_resident_gather"] <= 1, dict(counts)
+            assert counts["pgh_resident_in"] <= 4 and counts["pgh_ewise_vv"] <= 2 and counts["pgh_resident_gather"] <= 1, dict(counts)
             fused = make()
             want = np.asarray(fused.rank(graph, sig).np)
             assert fused.convergence.iteration == ranker.convergence.iteration
