@@ -43,7 +43,7 @@ ALPHA, TOL, MAX_ITERS, SEEDS = 0.85, 1e-6, 1000, 100
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 # HBM traffic of the step kernels: rocprofv3 --pmc passes of this same command (tools/gpu_bench_call.sh), summarised by
 # tools/summarize_pmc.py with the guide's gfx950 corrections; counters cannot be read from inside the timed process
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05", "bench_n1_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06", "bench_n1_pmc.json")
 # the launches of one PPR iteration, in stream order (HIP-event ids of include/pgh.h)
 STEP_KERNELS = ("spmv", "fixup", "pb_gather", "pb_finish", "combine", "residual", "close")
 
@@ -86,8 +86,8 @@ def measured_traffic(scale, ef, blocked):
 
 def measured_batch_traffic(scale, ef, width, batch_steps=11):
     """HBM bytes of one batch step of the multi-seed loop (k_mm_partial + fix-up + combine + residual) from the committed PMC
-    summary of tools/probe_batch_kernels.py (profiles/r05/spmm_final_pmc.json; same hash rule as the headline's traffic)."""
-    path = os.path.join(ROOT, "profiles", "r05", "spmm_final_pmc.json")
+    summary of tools/probe_batch_kernels.py (profiles/r06/spmm_final_pmc.json; same hash rule as the headline's traffic)."""
+    path = os.path.join(ROOT, "profiles", "r06", "spmm_final_pmc.json")
     if (scale, ef, width) != (23, 16, 64) or not os.path.exists(path):
         return {}
     with open(path) as f:
@@ -280,6 +280,8 @@ def single_gpu(args):
              adj, 8 * nnz + 20 * n, nnz)
         side("absorbing_walks_a085_l1_1e-6", pg.AbsorbingWalks(ALPHA, error_type=pg.L1, tol=TOL, max_iters=MAX_ITERS), adj,
              8 * nnz + 24 * n, nnz)
+        # a tolerance below fp32 eps: f64 iterates on the f64 image, chosen by the filter itself (the reference's iteration counts)
+        side("ppr_l1_1e-9_f64_iterates", pg.PageRank(alpha=ALPHA, error_type=pg.L1, tol=1e-9, max_iters=MAX_ITERS), adj, 8 * nnz + 32 * n, nnz, runs=2)
         # The backend-primitive route -- what north_star names ("plugs in as a pygrank.core.backends module so PageRank / HeatKernel /
         # AbsorbingWalks ... are unchanged"): the filters reach the engine ONE PRIMITIVE AT A TIME (conv, *, +, sum, /, abs, -; pygrank/core/
         # backend/__init__.py:59-80), the whole-loop entry points are switched off.  Lazy vectors (pygrank_amd/device.py) keep the iterate in

@@ -24,7 +24,7 @@ def test_single_gpu_leg_fields(host_engine):
                                       "heat_kernel_t5_31_iterations_chebyshev", "absorbing_walks_a085_l1_1e-6",
                                       "ppr_l1_1e-6_symmetrised_graph", "ppr_l1_1e-6_batch_of_64_seeds", "ppr_l1_1e-6_real_weights",
                                           "ppr_l1_1e-6_backend_primitives", "heat_kernel_t5_31_iterations_backend_primitives",
-                                          "absorbing_walks_a085_l1_1e-6_backend_primitives"}
+                                          "absorbing_walks_a085_l1_1e-6_backend_primitives", "ppr_l1_1e-9_f64_iterates"}
     prim = line["secondary"]["ppr_l1_1e-6_backend_primitives"]
     assert "error" not in prim and prim["spmv_per_run"] > 0, prim
     assert set(("graph_build_s", "graph_rebuild_s", "graph_build_ms")) <= set(line["config"])

@@ -1,8 +1,8 @@
 #!/bin/bash
 # copies the summaries a tools/gpu_bench_call.sh TAG + gpu_sq_call.sh sq_TAG + gpu_pmc_cmd.sh spmm_TAG / cheb_TAG collection left in
-# gpurun_out/ into profiles/<round>/ under the names bench.py and DESIGN.md cite.  usage: bash tools/install_profiles.sh TAG [round dir, default r05]
+# gpurun_out/ into profiles/<round>/ under the names bench.py and DESIGN.md cite.  usage: bash tools/install_profiles.sh TAG [round dir, default r06]
 set -e
-T=$1; O=gpurun_out; P=profiles/${2:-r05}; mkdir -p $P
+T=$1; O=gpurun_out; P=profiles/${2:-r06}; mkdir -p $P
 cp $O/pmc_${T}_summary.json $P/bench_n1_pmc.json
 cp $O/sq_${T}_summary.json $P/bench_n1_sq_counters.json
 cp $O/trace_${T}_kernel_stats.csv $P/bench_n1_kernel_stats.csv
