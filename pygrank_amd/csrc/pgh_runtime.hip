@@ -228,13 +228,31 @@ int pgh::scalars_to_host(int first, int count) {
 }
 
 namespace {
+// Blocks of up to half a slab are CARVED out of slabs of PGH_SLAB_MB (default 1024) MB taken from the driver in one call each: a graph
+// build asks for ~150 buffers, and every driver allocation is a chance to meet the node's allocation stalls (0.2-1.0 s)
+// -- with slabs the first build of a process makes ~10 driver calls instead.  A carved block goes back to the idle lists like any other and
+// is never returned to the driver by itself; a slab none of whose blocks is live goes back whole when memory is short (pool_trim).
+struct Slab {
+    char*  base = nullptr;
+    size_t size = 0, used = 0;
+    int    live = 0;                            // carved blocks handed out and not yet freed
+};
 struct DevicePool {
     std::multimap<size_t, void*> idle;          // size -> block
     std::unordered_map<void*, size_t> live;     // block -> size
-    size_t idle_bytes = 0;
+    size_t idle_bytes = 0;                      // idle blocks that came from the driver one by one (carved ones do not count against the cap)
     size_t cap_bytes = 0;
+    std::vector<Slab> slabs;
+    size_t slab_bytes = ~(size_t)0;             // unset; 0 = no slabs
 };
 DevicePool g_dev_pool;
+
+int slab_of(const DevicePool& P, const void* p) {
+    const char* c = static_cast<const char*>(p);
+    for (size_t i = 0; i < P.slabs.size(); ++i)
+        if (c >= P.slabs[i].base && c < P.slabs[i].base + P.slabs[i].size) return (int)i;
+    return -1;
+}
 }  // namespace
 
 namespace pgh {
@@ -242,8 +260,24 @@ void pool_trim() {
     DevicePool& P = g_dev_pool;
     if (P.idle.empty()) return;
     (void)hipStreamSynchronize(rt().stream);
-    for (auto& kv : P.idle) (void)hipFree(kv.second);
-    P.idle.clear();
+    // blocks that came from the driver one by one go back one by one; a slab goes back when none of its blocks is in use
+    for (auto it = P.idle.begin(); it != P.idle.end();) {
+        const int s = slab_of(P, it->second);
+        if (s >= 0 && P.slabs[(size_t)s].live > 0) {
+            ++it;
+            continue;
+        }
+        if (s < 0) (void)hipFree(it->second);
+        it = P.idle.erase(it);
+    }
+    for (size_t i = 0; i < P.slabs.size();) {
+        if (P.slabs[i].live == 0) {
+            (void)hipFree(P.slabs[i].base);
+            P.slabs.erase(P.slabs.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
     P.idle_bytes = 0;
 }
 
@@ -254,10 +288,50 @@ int pool_alloc(size_t bytes, void** out) {
     auto it = P.idle.find(bytes);
     if (it != P.idle.end()) {
         *out = it->second;
-        P.idle_bytes -= bytes;
+        const int s = slab_of(P, *out);
+        if (s >= 0) ++P.slabs[(size_t)s].live;
+        else P.idle_bytes -= bytes;
         P.idle.erase(it);
         P.live[*out] = bytes;
         return 0;
+    }
+    if (P.slab_bytes == ~(size_t)0) {
+        const char* e = getenv("PGH_SLAB_MB");
+        P.slab_bytes = (size_t)(e != nullptr ? atoll(e) : 1024) << 20;
+    }
+    if (P.slab_bytes > 0 && bytes <= P.slab_bytes / 2) {
+        Slab* slab = nullptr;
+        for (size_t i = P.slabs.size(); i-- > 0;)
+            if (P.slabs[i].size - P.slabs[i].used >= bytes) {
+                slab = &P.slabs[i];
+                break;
+            }
+        if (slab == nullptr) {
+            void* base = nullptr;
+            hipError_t e = hipMalloc(&base, P.slab_bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                pool_trim();
+                e = hipMalloc(&base, P.slab_bytes);
+            }
+            if (e == hipSuccess) {
+                Slab fresh;
+                fresh.base = static_cast<char*>(base);
+                fresh.size = P.slab_bytes;
+                P.slabs.push_back(fresh);
+                slab = &P.slabs.back();
+            } else {
+                (void)hipGetLastError();        // no room for a slab: the block itself may still fit
+            }
+        }
+        if (slab != nullptr) {
+            void* p = slab->base + slab->used;
+            slab->used += bytes;
+            ++slab->live;
+            P.live[p] = bytes;
+            *out = p;
+            return 0;
+        }
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
@@ -283,6 +357,12 @@ void pool_free(void* p) {
     }
     const size_t bytes = it->second;
     P.live.erase(it);
+    const int s = slab_of(P, p);
+    if (s >= 0) {                               // carved: back to the idle lists, whatever the cap says (its memory is the slab's)
+        --P.slabs[(size_t)s].live;
+        P.idle.emplace(bytes, p);
+        return;
+    }
     if (P.cap_bytes == 0) {                    // idle blocks kept: PGH_POOL_MB, default a quarter of the device memory
         const char* e = getenv("PGH_POOL_MB");
         if (e != nullptr) {
@@ -299,13 +379,14 @@ void pool_free(void* p) {
         (void)hipFree(p);
         return;
     }
-    if (P.idle_bytes + bytes > P.cap_bytes) {  // evict the largest idle blocks until the new one fits
+    if (P.idle_bytes + bytes > P.cap_bytes) {  // evict the largest idle blocks (of those that are the driver's own) until the new one fits
         (void)hipStreamSynchronize(rt().stream);
-        while (!P.idle.empty() && P.idle_bytes + bytes > P.cap_bytes) {
-            auto last = std::prev(P.idle.end());
+        for (auto last = P.idle.end(); last != P.idle.begin() && P.idle_bytes + bytes > P.cap_bytes;) {
+            --last;
+            if (slab_of(P, last->second) >= 0) continue;
             (void)hipFree(last->second);
             P.idle_bytes -= last->first;
-            P.idle.erase(last);
+            last = P.idle.erase(last);
         }
     }
     P.idle.emplace(bytes, p);

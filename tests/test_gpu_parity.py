@@ -335,7 +335,8 @@ def test_randomised_stress(gpu_engine):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PYTHONPATH=root, AMD_SERIALIZE_KERNEL="3", HIP_LAUNCH_BLOCKING="1")
+    # (PGH_SLAB_MB=0: every buffer an allocation of its own, so that an access past its end leaves the allocation and faults)
+    env = dict(os.environ, PYTHONPATH=root, AMD_SERIALIZE_KERNEL="3", HIP_LAUNCH_BLOCKING="1", PGH_SLAB_MB="0")
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_gpu.py"), "--seconds", "20", "--seed", "7"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0 and "stress ok" in res.stdout, res.stdout[-1500:] + res.stderr[-2500:]
@@ -349,7 +350,7 @@ def test_randomised_filters(gpu_engine):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PYTHONPATH=root, AMD_SERIALIZE_KERNEL="3", HIP_LAUNCH_BLOCKING="1")
+    env = dict(os.environ, PYTHONPATH=root, AMD_SERIALIZE_KERNEL="3", HIP_LAUNCH_BLOCKING="1", PGH_SLAB_MB="0")
     res = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_filters.py"), "--seconds", "20", "--seed", "11"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0 and "filters stress ok" in res.stdout, res.stdout[-1500:] + res.stderr[-2500:]
