@@ -189,6 +189,38 @@ def test_cfg2_independent_matrix(big):
     want, want_iters = orc.pagerank(M, p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
     assert ranker.convergence.iteration == want_iters
     assert _rel(got, want) <= 1e-6
+    # the other filters and the 64-seed batch against the independent matrix too (configs[3], a12, configs[2])
+    hk = pg.HeatKernel(5, error_type="iters", max_iters=31)
+    got = np.asarray(hk.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, iters = orc.heat_kernel(M, p, t=5, error_type="iters", max_iters=31)
+    assert hk.convergence.iteration == iters == 31 and _rel(got, want) <= 1e-6, _rel(got, want)
+    aw = pg.AbsorbingWalks(0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+    got = np.asarray(aw.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, want_iters = orc.absorbing_walks(M, p, alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
+    assert aw.convergence.iteration == want_iters and _rel(got, want) <= 1e-6, (aw.convergence.iteration, want_iters, _rel(got, want))
+    from pygrank_amd.device import DeviceMatrix
+    feats = np.zeros((big["n"], 64))
+    F = DeviceMatrix.empty(big["n"], 64)
+    for j in range(64):
+        feats[:, j] = big["seeds"](200 + j)
+        F.set_column(j, pg.to_array(feats[:, j]))
+    batch = pg.PageRank(alpha=0.85, error_type=pg.L1, tol=1e-6, max_iters=1000)
+    out = batch.propagate(big["adj"], F)
+    for j in (7, 41):
+        want, want_iters = orc.pagerank(M, feats[:, j], alpha=0.85, error_type="l1", tol=1e-6, max_iters=1000)
+        its = batch.last_batches[0][j]["iterations"]
+        if its != want_iters:
+            # The independent matrix is fp64; the engine's is its f32 rounding, and its iterates are f32: the two trajectories run ~1e-7
+            # apart, and a residual that comes within that of the tolerance is decided one step apart (profiles/r06/propagate_stops.log).
+            # Then the decision must have been that close, and the iterate after the engine's number of steps must be the oracle's.
+            assert abs(its - want_iters) == 1, (j, its, want_iters)
+            k = min(its, want_iters)
+            before = orc.pagerank(M, feats[:, j], alpha=0.85, error_type="iters", max_iters=k - 1)[0]
+            at = orc.pagerank(M, feats[:, j], alpha=0.85, error_type="iters", max_iters=k)[0]
+            margin = np.abs(at - before).sum() / np.abs(feats[:, j]).sum() / 1e-6
+            assert abs(margin - 1.0) <= 0.02, (j, its, want_iters, margin)
+            want = orc.pagerank(M, feats[:, j], alpha=0.85, error_type="iters", max_iters=its)[0]
+        assert _rel(np.asarray(out.column(j), dtype=np.float64), want) <= 1e-6, j
 
 
 def test_cfg2_real_valued_weights_scale23_vs_oracle(big):
