@@ -1878,8 +1878,10 @@ int bsf_build(pgh_graph_s* g, const float* val, const int32_t* mult, const float
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
     build_mark("image: referenced prefixes");
-    const int hot_slots = kBsfHot < blk ? kBsfHot : blk;
-    if (!batch_layout && hot_slots < blk && E > B) {
+    // (the f64 image -- a multi-seed-style layout -- asks for a cold image of its own with ITS hot cache's size: BsfFormat::pb64)
+    const int hot_want = batch_layout && f.pb64 && f.pb_hot > 0 ? f.pb_hot : kBsfHot;
+    const int hot_slots = hot_want < blk ? hot_want : blk;
+    if ((!batch_layout || (f.pb64 && B <= 8)) && hot_slots < blk && E > B) {
         DevBuf<unsigned char> is_hot;
         DevBuf<int64_t> num_hot;
         PGH_TRY(is_hot.alloc(E));

@@ -249,6 +249,10 @@ struct PbFormat {
     int*      first_item = nullptr;
     uint32_t* work_counter = nullptr; // hand-out of the schedule's tail (one device word), or null without a tail
     int       tail_begin = 0, tail_count = 0;   // sched[tail_begin .. +tail_count): items handed out on the device
+    // the cold tail of the f64 image (pgh_bsf64.hip; BsfFormat::pb64): the same orders and work list, doubles handed from A to B
+    bool      f64 = false;
+    double*   tmp64 = nullptr;      // [padded] gathered (and weighted) source values as doubles, group g at [8 g, 8 g + 8); `tmp` stays null
+    unsigned long long* amax64 = nullptr;   // [2] bit pattern of max |value| phase A wrote; the finish kernel's exit tickets
     int64_t   device_bytes = 0;
 };
 constexpr int kPbMaxSlices = 8;
@@ -313,6 +317,10 @@ struct BsfFormat {
     float*    psum = nullptr;       // [num_segs + pad]
     double*   psum64 = nullptr;     // f64 image (pgh_bsf64.hip): the same compact partial sums in f64
     bool      want_meta = false;    // set before bsf_build: a multi-seed-style image (cold entries in the stream) that also gets `meta`
+    // set before bsf_build (the f64 image, round 6): this multi-seed-style image moves its cold tail into a propagation-blocking image of
+    // its own -- pb_hot sources of every block stay in the stream (the f64 hot cache), a chunk of phase A holds pb_chunk sources
+    bool      pb64 = false;
+    int       pb_hot = 0, pb_chunk = 0;
     SegMeta*  meta = nullptr;       // [B][meta_words]
     int64_t   meta_words = 0;       // ceil(n_out / 64)
     int32_t*  perm = nullptr;       // [n_src] new id -> old id, or null (identity)

@@ -944,6 +944,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     const char* env = getenv("PGH_PB");
     if (env != nullptr && atoi(env) == 0) return 0;
     Runtime& r = rt();
+    const int chunk = f.pb_chunk > 0 ? f.pb_chunk : kPbChunk;         // (the f64 image: 16 K doubles fill the LDS of phase A)
     int64_t cold_sources = 0;
     for (int b = 0; b < f.num_blocks; ++b) cold_sources += live[b] > hot ? live[b] - hot : 0;
     plan->dense_prefix[0] = 0;
@@ -957,7 +958,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         for (int b = 0; b < 9; ++b) L.cold_prefix[b] = plan->dense_prefix[b];
         L.blk = f.blk_size;
         L.hot = hot;
-        L.chunk = kPbChunk;
+        L.chunk = chunk;
         PGH_TRY(mark.alloc(cold_sources + 1, true));
         PGH_HIP(pooled_malloc(&plan->cold_rank, sizeof(uint32_t) * (size_t)(cold_sources + 1)));
         k_pb_mark_cold<<<pb_blocks_for(E), kBlock, 0, r.stream>>>(keys, is_hot, E, L, mark.p);
@@ -974,7 +975,7 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
         for (int b = 0; b <= 8; ++b) plan->compact_prefix[b] = (int64_t)at[b];
     }
     const int64_t cold_ids = plan->compact_prefix[8];             // == cold_sources without need lists
-    const int64_t chunks = (cold_ids + kPbChunk - 1) / kPbChunk;
+    const int64_t chunks = (cold_ids + chunk - 1) / chunk;
     if (chunks < 1 || chunks > kPbMaxChunks || f.n_out >= (1 << 28)) {
         (void)pooled_free(plan->cold_rank);
         plan->cold_rank = nullptr;
@@ -1243,7 +1244,8 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     p = PbFormat();
     PGH_CHECK(count == plan->slice_entries[slice], "propagation blocking: entry count does not match the plan");
     p.num_entries = count;
-    p.chunk = kPbChunk;
+    p.chunk = f.pb_chunk > 0 ? f.pb_chunk : kPbChunk;
+    p.f64 = f.pb64;
     p.hot = hot;
     p.k1_cold = plan->heavy_rows;
     p.bin_rows = plan->bin_rows;
@@ -1261,7 +1263,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
     L.rank = plan->cold_rank;
     L.blk = f.blk_size;
     L.hot = hot;
-    L.chunk = kPbChunk;
+    L.chunk = p.chunk;
     PbBuf<uint64_t> keys_a, keys_b;
     PbBuf<float> sorted_vals;
     PGH_TRY(keys_a.alloc(count));
@@ -1397,6 +1399,11 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         PGH_HIP(hipMemcpyAsync(p.first_task, first.data(), sizeof(int4) * first.size(), hipMemcpyHostToDevice, r.stream));
         PGH_HIP(hipStreamSynchronize(r.stream));
     }
+    if (p.f64) {
+        PGH_HIP(pooled_malloc(&p.tmp64, sizeof(double) * (size_t)(((padded / 8 + 63) / 64 + 1) * 512)));     // whole blocks of 64 groups (pb64_pair)
+        PGH_HIP(pooled_malloc(&p.amax64, sizeof(unsigned long long) * 2));
+        PGH_HIP(hipMemsetAsync(p.amax64, 0, sizeof(unsigned long long) * 2, r.stream));
+    } else
     PGH_HIP(pooled_malloc(&p.tmp, sizeof(float) * (size_t)(((padded / 8 + 63) / 64 + 1) * 512)));      // whole blocks of 64 groups (pb_tmp_quad)
     {
         // (chunk, bin) runs of a dozen groups or more: the two-plane layout of tmp; shorter runs: quads side by side
@@ -1580,7 +1587,7 @@ int pb_build(BsfFormat& f, PbPlan* plan, int slice, const uint64_t* cold_keys, c
         }
         PGH_HIP(hipStreamSynchronize(r.stream));           // the host vectors go out of scope
     }
-    p.device_bytes = padded * (4 + 2 + 2 + (cold_vals ? 4 : 0)) + padded / 2 + (int64_t)p.num_items * 32;
+    p.device_bytes = padded * ((p.f64 ? 8 : 4) + 2 + 2 + (cold_vals ? 4 : 0)) + padded / 2 + (int64_t)p.num_items * 32;
     p.enabled = true;
     return 0;
 }
@@ -1773,6 +1780,8 @@ void pb_destroy(PbFormat& p) {
     (void)pooled_free(p.task_range);
     (void)pooled_free(p.first_task);
     (void)pooled_free(p.tmp);
+    (void)pooled_free(p.tmp64);
+    (void)pooled_free(p.amax64);
     (void)pooled_free(p.dstg);
     (void)pooled_free(p.amax);
     (void)pooled_free(p.split);

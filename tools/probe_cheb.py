@@ -44,7 +44,8 @@ def main():
     ranker.rank(adj, sig)
     L.check(lib.pgh_profile_enable(0))
     parts = []
-    for kid, name in ((L.K_SPMV, "partial"), (L.K_FIXUP, "fixup"), (L.K_COMBINE, "combine"), (L.K_FINAL, "close")):
+    for kid, name in ((L.K_SPMV, "partial"), (L.K_FIXUP, "fixup"), (L.K_COMBINE, "combine"), (L.K_PB_GATHER, "pbA"),
+                      (L.K_PB_ACCUM, "pbB"), (L.K_FINAL, "close")):
         cnt, ms = C.c_int64(), C.c_double()
         L.check(lib.pgh_profile_read(kid, C.byref(cnt), C.byref(ms)))
         if cnt.value:
