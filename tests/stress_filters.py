@@ -201,6 +201,12 @@ def main():
                     sys.exit(1)
             done += 1
             continue
+        # Round 6: a third of the PageRank / AbsorbingWalks / taylor runs take the BACKEND-PRIMITIVE route (the whole-loop entry points
+        # switched off: lazy vectors, resident iterates, pgh_resident_step on whatever layout the switches gave) -- held to the same bounds
+        primitives = which in (0, 1, 2) and rng.random() < 0.33
+        if primitives:
+            ranker._fused_loop = lambda *a, **k: False
+            ranker._fused_rank = lambda *a, **k: None
         try:
             got = np.asarray(ranker.rank(adj, p.copy()).np)
         except Exception as exc:                                   # non-convergence must agree with the oracle too
@@ -249,6 +255,8 @@ def main():
         leg = {0: "PageRank", 1: "AbsorbingWalks", 2: "HeatKernel taylor", 3: "HeatKernel chebyshev"}[which]
         if which == 0 and kw["alpha"] >= 0.99:
             leg += " alpha=0.99"
+        if primitives:
+            leg += " (backend primitives)"
         if signed:
             leg += ", signed p"
         if which in (0, 1) and its > 100 and "0.99" not in leg:
