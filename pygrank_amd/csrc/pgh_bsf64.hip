@@ -332,13 +332,25 @@ __global__ void k_bsf64_fixlist(const int4* __restrict__ tile, const int32_t* __
 
 // segments that cross tiles: carries of the chain's tiles in ascending order + the head piece (fixed order); chains of 32+
 // tiles (hub rows) are summed by the whole wavefront
-__global__ __launch_bounds__(WG) void k_bsf64_fixup(const int32_t* __restrict__ fix_seg, const int4* __restrict__ tile,
-                                                     const double* __restrict__ tail, const double* __restrict__ head,
-                                                     double* __restrict__ psum, int num_tiles, const LoopState* __restrict__ state) {
-    if (state != nullptr && state->done) return;
+struct Fix64 {
+    const int32_t* fix_seg;
+    const int4*    tile;
+    const double*  tail;
+    const double*  head;
+    double*        psum;
+    int            num_tiles;
+};
+// (a device body: its own launch, or the first instructions of phase A of the cold image -- it touches nothing that kernel reads, and the
+// finishing pass is the first to read its results)
+__device__ __forceinline__ void bsf64_fixup_tiles(const Fix64& f, const int begin, const int stride) {
+    const int32_t* __restrict__ fix_seg = f.fix_seg;
+    const int4* __restrict__ tile = f.tile;
+    const double* __restrict__ tail = f.tail;
+    const double* __restrict__ head = f.head;
+    double* __restrict__ psum = f.psum;
+    const int num_tiles = f.num_tiles;
     const int lane = threadIdx.x & 63;
-    const int stride = gridDim.x * WG;
-    for (int t0 = blockIdx.x * WG; t0 < num_tiles; t0 += stride) {
+    for (int t0 = begin; t0 < num_tiles; t0 += stride) {
         const int t = t0 + (int)threadIdx.x;
         const int dst = t < num_tiles ? fix_seg[t] : -1;
         const int first = dst >= 0 ? tile[t].w : 0;
@@ -361,6 +373,10 @@ __global__ __launch_bounds__(WG) void k_bsf64_fixup(const int32_t* __restrict__ 
             if (lane == src) psum[dst] = total;
         }
     }
+}
+__global__ __launch_bounds__(WG) void k_bsf64_fixup(Fix64 f, const LoopState* __restrict__ state) {
+    if (state != nullptr && state->done) return;
+    bsf64_fixup_tiles(f, blockIdx.x * WG, gridDim.x * WG);
 }
 
 struct Epi64 {
@@ -550,6 +566,9 @@ constexpr int kChunk64 = 16384;
 #ifndef PGH_PB64_P
 #define PGH_PB64_P 4          // groups per lane and round of phase A on long pieces
 #endif
+#ifndef PGH_PB64_G
+#define PGH_PB64_G 1          // groups of 64 rows per wavefront in flight in the finishing pass's epilogue (2: 44 bytes of scratch, 181 against 172 us)
+#endif
 constexpr int kGather64Threads = 1024;
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -649,11 +668,14 @@ __device__ __forceinline__ void pb64_stream_piece(const double* __restrict__ s_x
 
 PGH_STAMP_DECL(g_times_gather64)
 template <bool HAS_VAL>
-__global__ __launch_bounds__(kGather64Threads) void k_pb64_gather(Pb64View f, const double* __restrict__ xg, const LoopState* __restrict__ state) {
+__global__ __launch_bounds__(kGather64Threads) void k_pb64_gather(Pb64View f, const double* __restrict__ xg, const LoopState* __restrict__ state,
+                                                                  Fix64 fix) {
     __shared__ __attribute__((aligned(16))) double s_x[kChunk64];
     __shared__ unsigned long long s_amax;
     if (state != nullptr && state->done) return;
     PGH_STAMP_BEGIN(g_times_gather64)
+    // the cross-tile fix-ups of the blocked stream ride along (one launch and one dependent boundary fewer per term)
+    bsf64_fixup_tiles(fix, blockIdx.x * kGather64Threads, gridDim.x * kGather64Threads);
     if (threadIdx.x == 0) s_amax = 0ULL;
     unsigned long long amax = 0ULL;
     const int piece_begin = f.task_range[blockIdx.x], piece_end = f.task_range[blockIdx.x + 1];
@@ -997,28 +1019,40 @@ __global__ __launch_bounds__(THREADS, 4) void k_pb64_finish(Pb64View f, Rows64 r
             // branch-free: lanes outside the item repeat a row of it, a row without a segment in a block reads the zero slot
             const int row_lo = epi.x, row_hi = epi.x + epi.y - 1;
             const int g_hi = row_hi >> 6;                       // (epi.y == 0: row_hi < row_lo, no group)
-            for (int g = (row_lo >> 6) + wave; g <= g_hi && epi.y > 0; g += WAVES) {
-                const int row = min(max((g << 6) + lane, row_lo), row_hi);
-                double v[NB];
+            constexpr int G = PGH_PB64_G;                       // groups per wavefront in flight
+            for (int g0 = (row_lo >> 6) + wave; g0 <= g_hi && epi.y > 0; g0 += WAVES * G) {
+                double v[G][NB];
+                Ops o[G];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const unsigned long long mask = s_mask[b * WORDS + (g - word0)];
-                    const unsigned int first = (unsigned int)s_base[b * WORDS + (g - word0)];
-                    const unsigned int lo = (unsigned int)mask, hi = (unsigned int)(mask >> 32);
-                    const unsigned int rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                    const bool has = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) != 0u;
-                    const unsigned int where = has ? first + rank : rs.zero_at;
-                    v[b] = rs.psum[where];
+                for (int u = 0; u < G; ++u) {
+                    const int g = min(g0 + u * WAVES, g_hi);    // wavefront-uniform; a group past the end repeats the last one (dropped below)
+                    const int row = min(max((g << 6) + lane, row_lo), row_hi);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const unsigned long long mask = s_mask[b * WORDS + (g - word0)];
+                        const unsigned int first = (unsigned int)s_base[b * WORDS + (g - word0)];
+                        const unsigned int lo = (unsigned int)mask, hi = (unsigned int)(mask >> 32);
+                        const unsigned int rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                        const bool has = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) != 0u;
+                        const unsigned int where = has ? first + rank : rs.zero_at;
+                        v[u][b] = rs.psum[where];
+                    }
+                    o[u] = load_ops(row);
                 }
-                const Ops o = load_ops(row);
-                const bool live = (g << 6) + lane >= row_lo && (g << 6) + lane <= row_hi;
-                const int i = live ? row - row_lo : 0;
-                const double c = finite ? (double)(long long)s_row[i < rows ? i : 0] * inv_S : __longlong_as_double(0x7ff8000000000000LL);
-                double sum = 0.0;
 #pragma unroll
-                for (int b = 0; b < NB; ++b) sum += v[b];
-                sum += i < rows ? c : 0.0;
-                apply(row, sum, o, live);
+                for (int u = 0; u < G; ++u) {
+                    const int g = g0 + u * WAVES;
+                    const int at_row = (g << 6) + lane;
+                    const bool live = g <= g_hi && at_row >= row_lo && at_row <= row_hi;
+                    const int row = live ? at_row : row_lo;
+                    const int i = row - row_lo;
+                    const double c = finite ? (double)(long long)s_row[i < rows ? i : 0] * inv_S : __longlong_as_double(0x7ff8000000000000LL);
+                    double sum = 0.0;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) sum += v[u][b];
+                    sum += i < rows ? c : 0.0;
+                    apply(row, sum, o[u], live);
+                }
             }
         }
         __syncthreads();                                   // s_row / s_hub are reused by the next item
@@ -1241,11 +1275,20 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
         else k_bsf64_partial<false, false><<<main_grid, kThreads, 0, r.stream>>>(v, xg, state, pc);
     }
     PGH_STAMP_DUMP(g_times_partial64, main_grid, "k_bsf64_partial")
-    {
+    Fix64 fix;
+    fix.fix_seg = f.fix_seg;
+    fix.tile = f.tile;
+    fix.tail = f.tail_carry;
+    fix.head = f.head_partial;
+    fix.psum = f.psum64;
+    fix.num_tiles = f.num_tiles;
+    static const bool fold_env = getenv("PGH_PB64_FOLD") == nullptr || atoi(getenv("PGH_PB64_FOLD")) != 0;
+    const bool fix_rides = fold_env && f.pb.enabled && f.pb.num_tasks > 0;       // inside phase A of the cold image
+    if (!fix_rides) {
         ProfScope prof(PGH_K_FIXUP);
         int fix_grid = (f.num_tiles + WG - 1) / WG;
         fix_grid = fix_grid < 1 ? 1 : (fix_grid > 1024 ? 1024 : fix_grid);
-        k_bsf64_fixup<<<fix_grid, WG, 0, r.stream>>>(f.fix_seg, f.tile, f.tail_carry, f.head_partial, f.psum64, f.num_tiles, state);
+        k_bsf64_fixup<<<fix_grid, WG, 0, r.stream>>>(fix, state);
     }
     Epi64 ep;
     ep.a = a;
@@ -1296,8 +1339,10 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
         {
             ProfScope prof(PGH_K_PB_GATHER);
             if (p.num_tasks > 0) {
-                if (p.val) k_pb64_gather<true><<<p.num_tasks, kGather64Threads, 0, r.stream>>>(pv, xg, state);
-                else k_pb64_gather<false><<<p.num_tasks, kGather64Threads, 0, r.stream>>>(pv, xg, state);
+                Fix64 ride = fix;
+                if (!fix_rides) ride.num_tiles = 0;
+                if (p.val) k_pb64_gather<true><<<p.num_tasks, kGather64Threads, 0, r.stream>>>(pv, xg, state, ride);
+                else k_pb64_gather<false><<<p.num_tasks, kGather64Threads, 0, r.stream>>>(pv, xg, state, ride);
             }
         }
         PGH_STAMP_DUMP(g_times_gather64, p.num_tasks, "k_pb64_gather")

@@ -8,6 +8,7 @@
 // The transposition is a device radix sort of (column << 32 | row) keys (rocPRIM via hipCUB -- a one-time
 // format conversion, not part of the per-iteration hot path), so the stored rows of M^T come out with their
 // column indices ascending and the result is deterministic.
+#include <cstring>
 #include "pgh_kernels.h"
 
 #include <hipcub/hipcub.hpp>
@@ -758,6 +759,16 @@ extern "C" int pgh_graph_format(pgh_graph_t g, char* buf, int buflen) {
                      f.pb_slices, (long long)f.pb.num_entries, f.pb.num_chunks, f.pb.num_bins, f.pb.k1_cold ? " (heavy rows stay in the stream)" : "");
     } else {
         snprintf(buf, buflen, "csr32+f32 row-major merge-path (8 B/edge), %d tiles of %d items", g->num_tiles, g->items_per_tile);
+    }
+    if (g->bsf64.enabled) {                                // the f64 image exists once an f64 route has run (pgh_bsf64.hip)
+        const BsfFormat& f = g->bsf64;
+        int used = (int)strlen(buf);
+        if (used < buflen - 1)
+            used += snprintf(buf + used, buflen - used, "; f64 image: %d column blocks, %lld entries (%d B/entry)", f.num_blocks, (long long)f.num_entries,
+                             (f.val ? 4 : 0) + (f.colf16 ? 2 : 4));
+        if (f.pb.enabled && used > 0 && used < buflen - 1)
+            snprintf(buf + used, buflen - used, ", cold tail: f64 propagation-blocking image of %lld entries in %d chunks x %d bins%s",
+                     (long long)f.pb.num_entries, f.pb.num_chunks, f.pb.num_bins, f.pb.k1_cold ? " (heavy rows stay in the stream)" : "");
     }
     return 0;
 }

@@ -431,6 +431,68 @@ def check_chebyshev_f64_route_on_blocked_stream(pg):
                 os.environ[k] = v
 
 
+def check_f64_cold_image(pg):
+    """The cold tail of the f64 image in its own propagation-blocking image (pgh_bsf64.hip, round 6: k_pb64_gather / k_pb64_finish,
+    hot-only 2-byte stream) -- forced on a graph of 1 M nodes (large graphs get it by default): the "chebyshev" recurrence
+    (abstract_filters.py:216-224), PageRank and AbsorbingWalks with f64 iterates (tol = 1e-9: adhoc.py:34-36, 166-169) against the
+    oracle with equal iteration counts, under every layout switch -- the image alone, hub bins + rows left in the stream, 4-byte stream
+    words, the cold gathers left in the stream (round 5's route) -- value-free and valued, and the routes against each other."""
+    import os
+    from pygrank_amd import _lib as L
+    if not L.runtime_name().startswith("hip:"):
+        return
+    from oracle import ref_loops as orc
+    rng = np.random.default_rng(5)
+    A = rmat_np.rmat_csr(20, 16, seed=2)                       # 1 M nodes, half of them live: 8 blocks of ~65 K referenced sources, 20 224 of each in the hot cache
+    W = sp.csr_array(A)
+    W.data = rng.uniform(0.5, 2.0, W.nnz)
+    p = np.zeros(A.shape[0])
+    p[rmat_np.seed_nodes(A, 60, seed=3)] = rng.uniform(0.5, 1.5, 60)
+    keys = ("PGH_PB", "PGH_PB_FORCE", "PGH_PB_HEAVY", "PGH_PB_HUBMAX", "PGH_PB64", "PGH_STREAM16")
+    saved = {k: os.environ.get(k) for k in keys}
+    layouts = (("cold image", dict(PGH_PB="1", PGH_PB_FORCE="1"), "f64 propagation-blocking", "(2 B/entry)"),
+               ("hub bins, heavy rows in the stream", dict(PGH_PB="1", PGH_PB_FORCE="1", PGH_PB_HEAVY="512", PGH_PB_HUBMAX="300"),
+                "heavy rows stay in the stream", None),
+               ("4-byte stream words", dict(PGH_PB="1", PGH_PB_FORCE="1", PGH_STREAM16="0"), "f64 propagation-blocking", "(4 B/entry)"),
+               ("cold gathers in the stream", dict(PGH_PB64="0"), None, None))
+    try:
+        for label, graph in (("value-free", A), ("valued", W)):
+            M = orc.normalize(graph, "col", True)
+            want = {"cheb": orc.heat_kernel(M, p, t=5, coefficient_type="chebyshev", tol=1e-9, max_iters=40, error_type="l1"),
+                    "ppr": orc.pagerank(M, p, alpha=0.85, error_type="l1", tol=1e-9, max_iters=200),
+                    "absorb": orc.absorbing_walks(M, p, alpha=0.85, error_type="l1", tol=1e-9, max_iters=200)}
+            got = {}
+            for name, env, must_have, stream in layouts:
+                for k in keys:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                adj = pg.preprocessor(normalization="col", assume_immutability=True)(pg.AdjacencyWrapper(graph, directed=True))
+                rankers = {"cheb": pg.HeatKernel(5, coefficient_type="chebyshev", error_type=pg.L1, tol=1e-9, max_iters=40),
+                           "ppr": pg.PageRank(0.85, error_type=pg.L1, tol=1e-9, max_iters=200),
+                           "absorb": pg.AbsorbingWalks(0.85, error_type=pg.L1, tol=1e-9, max_iters=200)}
+                for which, ranker in rankers.items():
+                    res = np.asarray(ranker.rank(adj, p.copy()).np, dtype=np.float64)
+                    assert ranker.convergence.iteration == want[which][1], (label, name, which, ranker.convergence.iteration, want[which][1])
+                    assert np.max(np.abs(res - want[which][0])) / np.max(np.abs(want[which][0])) <= 1e-6, (label, name, which)
+                    got[(name, which)] = res
+                fmt = adj.array.format()
+                assert "f64 image" in fmt, fmt
+                if label == "value-free":
+                    assert (must_have is None) == ("f64 propagation-blocking" not in fmt), (name, fmt)
+                    assert must_have is None or must_have in fmt, (name, fmt)
+                    assert stream is None or stream in fmt.split("f64 image")[1], (name, fmt)
+            for which in ("cheb", "ppr", "absorb"):                # the four layouts agree far below the f32 result's resolution
+                ref = got[("cold gathers in the stream", which)]
+                for name, _, _, _ in layouts[:3]:
+                    assert np.max(np.abs(got[(name, which)] - ref)) <= 2e-7 * np.max(np.abs(ref)), (label, name, which)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def check_loop_is_deterministic(pg):
     A = rmat_np.rmat_csr(14, 8, seed=2)
     p = np.zeros(A.shape[0])
