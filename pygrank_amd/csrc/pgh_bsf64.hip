@@ -52,6 +52,7 @@ struct View64 {
     double*         psum;        // [num_segs + pad] compact block partial sums
     int             num_blocks;
     int             blk;
+    int             hot;         // sources of every block in the LDS hot cache: kHot64 (PGH_HOT64: fewer, so that small test graphs have a cold tail)
     int             tile_begin[kMaxBlocks + 1];
 };
 
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void k_bsf64_partial(View64 f, const doub
         stride = ((gridDim.x >> 3) / q) * kWaves;
     }
     const uint32_t base = (uint32_t)b * (uint32_t)f.blk;
-    const uint32_t hot = (uint32_t)min(kHot64, f.blk);
+    const uint32_t hot = (uint32_t)min(f.hot, f.blk);
     {
         // the hot cache: all of a thread's loads in flight at once (round 5: one 8-byte load, one wait, one LDS store per stride of 1024 was
         // twenty round trips one after the other at the head of every launch), and the loop-state test + the previous term's close (PendingClose)
@@ -1125,7 +1126,10 @@ int bsf64_ensure(pgh_graph_s* g) {
     // workgroups share out its blocks) put more sources into some CU's LDS, but every block is another lookup per row in
     // the combine: measured at scale 23, 8 / 16 / 32 / 64 blocks: combine 116 / 192 / 344 / 682 us for 40 / 70 / 100 us less
     // in the partial sums.
-    int B = g->n_rows > (int64_t)kHot64 ? 8 : 1;
+    // (PGH_HOT64=<sources>: a smaller hot cache -- tests: graphs of a few thousand nodes then have cold entries, hub bins, heavy rows)
+    int hot64 = kHot64;
+    if (const char* h = getenv("PGH_HOT64")) hot64 = std::max(32, std::min(kHot64, atoi(h) / 32 * 32));
+    int B = g->n_rows > (int64_t)hot64 ? 8 : 1;
     const char* forced = getenv("PGH_BLOCKS64");
     if (forced != nullptr) {
         const int fb = atoi(forced);
@@ -1137,10 +1141,11 @@ int bsf64_ensure(pgh_graph_s* g) {
     {
         const char* pb64 = getenv("PGH_PB64");
         f.pb64 = B <= 8 && (pb64 == nullptr || atoi(pb64) != 0);
-        f.pb_hot = kHot64;
+        f.pb_hot = hot64;
         f.pb_chunk = kChunk64;
     }
     PGH_TRY(bsf_build(g, valfree ? nullptr : g->val, g->keep_mult, g->keep_src, g->keep_dst, true, B, &f));
+    f.pb_hot = hot64;                                      // (kept with the image: View64::hot)
     if (f.pb.enabled) {
         for (int b = 0; b < 8; ++b) f.xg_base[b] = f.xg_base_cold[b] = (int64_t)b * f.blk_size;
         f.device_bytes += f.pb.device_bytes;
@@ -1149,9 +1154,10 @@ int bsf64_ensure(pgh_graph_s* g) {
             View64 v{};
             v.num_blocks = f.num_blocks;
             v.blk = f.blk_size;
+            v.hot = hot64;
             for (int i = 0; i <= kMaxBlocks; ++i) v.tile_begin[i] = f.tile_begin[i];
             PGH_HIP(pooled_malloc(&f.colf16, sizeof(uint16_t) * (size_t)f.num_tiles * kT + 64));
-            k_bsf64_narrow<<<grid_for(f.num_entries, 16), WG, 0, r.stream>>>(f.colf, f.num_entries, v, (uint32_t)std::min(kHot64, f.blk_size), f.colf16);
+            k_bsf64_narrow<<<grid_for(f.num_entries, 16), WG, 0, r.stream>>>(f.colf, f.num_entries, v, (uint32_t)std::min(hot64, f.blk_size), f.colf16);
             PGH_HIP(hipGetLastError());
             PGH_HIP(hipStreamSynchronize(r.stream));
             (void)pooled_free(f.colf);
@@ -1257,6 +1263,7 @@ int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term,
     v.psum = f.psum64;
     v.num_blocks = f.num_blocks;
     v.blk = f.blk_size;
+    v.hot = f.pb_hot > 0 ? f.pb_hot : kHot64;
     for (int i = 0; i <= kMaxBlocks; ++i) v.tile_begin[i] = f.tile_begin[i];
     const int unit = f.num_blocks > 8 ? f.num_blocks : 8;                // whole XCD rounds, and whole rounds of an XCD's blocks
     const int main_grid = r.num_cus >= unit ? r.num_cus / unit * unit : unit;

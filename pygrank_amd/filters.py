@@ -84,6 +84,9 @@ class GraphFilter(NodeRanking):
         norm = raw.abssum() if isinstance(raw, DeviceVector) else backend.sum(backend.abs(raw))
         if norm == 0:
             return signal                       # nothing to spread: the reference hands the (all-zero) signal back
+        # (the f64 routes of the walks normalise the personalization themselves, in f64: an f32 quotient p / |p| sums to 1 only within
+        # 6e-8, which a run at tol = 1e-9 sees -- it would start beside the fixed point the reference starts ON)
+        self._raw_input = (raw, float(norm)) if warm_start is None and isinstance(raw, DeviceVector) else None
         signal = to_signal(signal, signal.np / norm)
         # the reference never writes into the caller's warm_start (every step builds a fresh array); the device loops update
         # their iterate in place, so the start vector is always a copy
@@ -134,6 +137,16 @@ class GraphFilter(NodeRanking):
         tol = self.convergence.tol
         cfg.tol = 0.0 if tol is None else max(float(tol), float(np.finfo(np.float64).eps))
         return cfg
+
+    def _f64_operands(self, cfg, p):
+        """(cfg, personalization) of an f64 recursive route: the UN-normalised personalization with its norm beside it whenever rank()
+        kept them (no warm start) -- the engine then forms p / |p| and the start vector in f64 (pgh_loop_cfg.in_norm, start_from_p)"""
+        cfg = self._f64_cfg(cfg)
+        raw = getattr(self, "_raw_input", None)
+        if raw is not None and len(raw[0]) == len(p) and raw[1] > 0:
+            cfg.in_norm, cfg.start_from_p = raw[1], 1
+            return cfg, raw[0]
+        return cfg, p
 
     def _loop_cfg(self, alpha=0.0, use_quotient=False, out_scale=1.0):
         cm = self.convergence
@@ -414,7 +427,8 @@ class AbsorbingWalks(RecursiveGraphFilter):
         lam = (to_signal(personalization.graph, absorption) * ((1 - self.alpha) / self.alpha)).np
         g = _device_graph(M)
         if cfg is not None and self._f64_wanted() and _f64_image_usable(g):
-            return self._run_recursive(L.lib().pgh_absorb_run_f64, g, self._f64_cfg(cfg), ranks, p, lam)
+            cfg, p = self._f64_operands(cfg, p)
+            return self._run_recursive(L.lib().pgh_absorb_run_f64, g, cfg, ranks, p, lam)
         return self._run_recursive(L.lib().pgh_absorb_run, g, cfg, ranks, p, lam)
 
 
@@ -453,7 +467,8 @@ class SymmetricAbsorbingRandomWalks(RecursiveGraphFilter):
         if not isinstance(p, DeviceVector) or g is None or "row-major" in g.format():     # PGH_FORMAT=csr: generic route
             return False
         if cfg is not None and self._f64_wanted() and _f64_image_usable(g):
-            return self._run_recursive(L.lib().pgh_sarw_run_f64, g, self._f64_cfg(cfg), ranks, p)
+            cfg, p = self._f64_operands(cfg, p)
+            return self._run_recursive(L.lib().pgh_sarw_run_f64, g, cfg, ranks, p)
         return self._run_recursive(L.lib().pgh_sarw_run, g, cfg, ranks, p)
 
 
