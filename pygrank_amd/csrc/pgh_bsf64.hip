@@ -1178,9 +1178,10 @@ int bsf64_ensure(pgh_graph_s* g) {
 
 int64_t bsf64_length(const pgh_graph_s* g) { return g->bsf64.n_out; }
 
-int bsf64_bring(pgh_graph_s* g, const float* p, double c1, double* term, double* res, double* xg) {
+int bsf64_bring(pgh_graph_s* g, const float* p, double c1, double* term, double* res, double* xg, bool keep_flag) {
     const BsfFormat& f = g->bsf64;
-    if (f.iso_flag != nullptr) PGH_HIP(hipMemsetAsync(f.iso_flag, 0, sizeof(int), rt().stream));
+    // (keep_flag: a second operand of the same run -- the warm start -- adds its non-zeros on isolated rows to the first one's)
+    if (f.iso_flag != nullptr && !keep_flag) PGH_HIP(hipMemsetAsync(f.iso_flag, 0, sizeof(int), rt().stream));
     k_bsf64_bring<<<grid_for(f.n_out, 16), WG, 0, rt().stream>>>(p, f.perm, f.src_scale, f.n_out, g->n_cols, c1, term, res, xg, f.iso_flag,
                                                                   f.blk_size, iso_from_of(f));
     PGH_HIP(hipGetLastError());

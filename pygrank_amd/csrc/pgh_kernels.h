@@ -783,7 +783,7 @@ void bsf_destroy(BsfFormat& f);
 bool bsf64_usable(const pgh_graph_s* g);
 int bsf64_ensure(pgh_graph_s* g);
 int64_t bsf64_length(const pgh_graph_s* g);      // length of the loop's internal-space vectors (the gather vector: + 1)
-int bsf64_bring(pgh_graph_s* g, const float* p, double c1, double* term, double* res, double* xg);
+int bsf64_bring(pgh_graph_s* g, const float* p, double c1, double* term, double* res, double* xg, bool keep_flag = false);
 int bsf64_take(pgh_graph_s* g, const double* res, double factor, float* out);
 int bsf64_take_col(pgh_graph_s* g, const double* vec, float* mat, int ld, int col);
 int bsf64_step(pgh_graph_s* g, double a, double b, double c, const double* term, double* term_out, double* result, double* xg,

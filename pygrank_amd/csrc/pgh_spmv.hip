@@ -2492,6 +2492,9 @@ int recursive_run_f64(pgh_graph_t g, int mode, pgh_vec_t p, pgh_vec_t lam, pgh_v
     const int rgrid = residual_grid(nv);
     PGH_TRY(parts.alloc(rgrid > kMaxPartials ? rgrid : kMaxPartials));
     PGH_HIP(hipMemsetAsync(dummy.p, 0, sizeof(double) * (size_t)nv, r.stream));
+    // (isolated rows -- no entry, referenced by nobody -- on which every operand of the run is zero stay zero in both iterates and are
+    // passed over by the step: the second iterate starts as zeros, the first one is written in full by bsf64_bring)
+    PGH_HIP(hipMemsetAsync(y1.p, 0, sizeof(double) * (size_t)nv, r.stream));
     // term = p (raw), res = p / |p| (the epilogue's TERM), gather = p * source scale.  The iterate is kept UN-normalised with its quotient
     // beside it (x_k = y_k * scale_k): x_0 = p / |p| is y_0 = p with scale_0 = 1 / |p|
     PGH_TRY(bsf64_bring(g, p->data, 1.0 / norm, praw.p, pn.p, xg64.p));
@@ -2499,7 +2502,7 @@ int recursive_run_f64(pgh_graph_t g, int mode, pgh_vec_t p, pgh_vec_t lam, pgh_v
     double scale = 1.0 / norm;
     if (!cfg->start_from_p) {                              // warm_start: the iterate starts as `ranks` (abstract_filters.py:56), its quotient is 1
         PGH_TRY(y0.alloc(nv));
-        PGH_TRY(bsf64_bring(g, ranks->data, 0.0, y0.p, spare.p, xg64.p));
+        PGH_TRY(bsf64_bring(g, ranks->data, 0.0, y0.p, spare.p, xg64.p, true));
         y[0] = y0.p;
         scale = 1.0;
     }
@@ -2538,7 +2541,7 @@ int recursive_run_f64(pgh_graph_t g, int mode, pgh_vec_t p, pgh_vec_t lam, pgh_v
         const int nxt = 1 - cur;
         int count = 0;
         const double a_step = mode == 0 ? cfg->alpha * scale : scale, b_step = mode == 0 ? 1.0 - cfg->alpha : 1.0;
-        PGH_TRY(bsf64_step(g, a_step, b_step, 0.0, pn.p, y[nxt], dummy.p, xg64.p, 0, nullptr, psum, pdel, &count, true, row_w_p, src_w_p));
+        PGH_TRY(bsf64_step(g, a_step, b_step, 0.0, pn.p, y[nxt], dummy.p, xg64.p, 0, nullptr, psum, pdel, &count, false, row_w_p, src_w_p));
         // (the epilogue's `term` slot holds p / |p| here, so its b * term is PageRank's (1 - alpha) * p; the gathered vector is the previous
         // iterate's y * source scale, its quotient rides in a)
         double S = 0.0;
