@@ -2448,9 +2448,21 @@ int poly_run_f64(pgh_graph_t g, pgh_vec_t p, const double* coeffs, int32_t num_c
 // those runs exact: the golden er10k/pagerank_tol1e-9 stops after the reference's 18 iterations.  An exactness mode, not a fast one: the
 // f64 image's step (k_bsf64_partial + fix-up + combine: ~500 us at RMAT scale 23) with its epilogue's operands set to PageRank's --
 // term_out = a * (M^T x) + b * TERM with TERM = p / |p|, a = alpha * quotient, b = 1 - alpha -- one residual pass, and a host look per step.
-__global__ __launch_bounds__(WG) void k_residual64(const double* __restrict__ a, double sa, const double* __restrict__ b, double sb, int64_t n, int linf,
-                                                    double* __restrict__ partials) {
+// (round 6) the step's scalars without a copy + synchronisation each: one single-workgroup launch folds the step's partial sums of sum(y)
+// in their order -> out[0]; the residual reads the new quotient FROM that word (quot_at); a second fold -> out[1]; ONE mailbox look per
+// step brings both (scalars_to_host)
+__global__ __launch_bounds__(WG) void k_fold64(const double* __restrict__ parts, int count, int linf, double* __restrict__ out) {
     __shared__ double s_red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += WG) acc = linf ? fmax(acc, parts[i]) : acc + parts[i];
+    const double t = linf ? block_reduce_256<1>(acc, s_red) : block_reduce_256<0>(acc, s_red);
+    if (threadIdx.x == 0) out[0] = t;
+}
+__global__ __launch_bounds__(WG) void k_residual64_dev(const double* __restrict__ a, const double* __restrict__ sum_at, int use_quotient,
+                                                        const double* __restrict__ b, double sb, int64_t n, int linf, double* __restrict__ partials) {
+    __shared__ double s_red[4];
+    const double S = *sum_at;
+    const double sa = use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
     double acc = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) {
         const double d = fabs(a[i] * sa - b[i] * sb);
@@ -2522,15 +2534,6 @@ int recursive_run_f64(pgh_graph_t g, int mode, pgh_vec_t p, pgh_vec_t lam, pgh_v
             PGH_TRY(bsf64_scale_by(g, xg64.p, src_w.p));    // the first product gathers x_0 / a as well
         }
     }
-    std::vector<double> host((size_t)(rgrid > kMaxPartials ? rgrid : kMaxPartials));
-    auto fold = [&](const double* dev, int count, int linf, double* out) -> int {
-        PGH_HIP(hipMemcpyAsync(host.data(), dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, r.stream));
-        PGH_HIP(hipStreamSynchronize(r.stream));
-        double t = 0.0;
-        for (int i = 0; i < count; ++i) t = linf ? fmax(t, host[i]) : t + host[i];
-        *out = t;
-        return 0;
-    };
     const int max_iters = cfg->max_iters, linf = cfg->err_kind == PGH_ERR_LINF;
     int it = 1, spmv = 0, cur = 0;
     bool converged = false;
@@ -2544,17 +2547,22 @@ int recursive_run_f64(pgh_graph_t g, int mode, pgh_vec_t p, pgh_vec_t lam, pgh_v
         PGH_TRY(bsf64_step(g, a_step, b_step, 0.0, pn.p, y[nxt], dummy.p, xg64.p, 0, nullptr, psum, pdel, &count, false, row_w_p, src_w_p));
         // (the epilogue's `term` slot holds p / |p| here, so its b * term is PageRank's (1 - alpha) * p; the gathered vector is the previous
         // iterate's y * source scale, its quotient rides in a)
-        double S = 0.0;
-        PGH_TRY(fold(psum, count, 0, &S));
-        const double scale_new = cfg->use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
         ++spmv;
         ++it;
         const bool check = cfg->err_kind != PGH_ERR_ITERS && it < max_iters && it % cfg->end_modulo == 0;
+        constexpr int kAt = 8;                             // words of rt().d_scalars this loop uses: [kAt] = sum(y), [kAt + 1] = residual
+        k_fold64<<<1, WG, 0, r.stream>>>(psum, count, 0, r.d_scalars + kAt);
         if (check) {
             ProfScope prof(PGH_K_RESIDUAL);
-            k_residual64<<<rgrid, WG, 0, r.stream>>>(y[nxt], scale_new, y[cur], scale, nv, linf, parts.p);
-            PGH_HIP(hipGetLastError());
-            PGH_TRY(fold(parts.p, rgrid, linf, &err));
+            k_residual64_dev<<<rgrid, WG, 0, r.stream>>>(y[nxt], r.d_scalars + kAt, cfg->use_quotient, y[cur], scale, nv, linf, parts.p);
+            k_fold64<<<1, WG, 0, r.stream>>>(parts.p, rgrid, linf, r.d_scalars + kAt + 1);
+        }
+        PGH_HIP(hipGetLastError());
+        PGH_TRY(scalars_to_host(kAt, check ? 2 : 1));
+        const double S = r.h_scalars[kAt];
+        const double scale_new = cfg->use_quotient ? (S != 0.0 ? 1.0 / S : 0.0) : 1.0;
+        if (check) {
+            err = r.h_scalars[kAt + 1];
             if (cfg->err_kind == PGH_ERR_MABS) err /= (double)n;
         }
         cur = nxt;
