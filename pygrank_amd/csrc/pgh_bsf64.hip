@@ -567,6 +567,9 @@ constexpr int kChunk64 = 16384;
 #ifndef PGH_PB64_P
 #define PGH_PB64_P 4          // groups per lane and round of phase A on long pieces
 #endif
+#ifndef PGH_PB64_FP
+#define PGH_PB64_FP 1         // groups per thread and stream round of the finishing pass
+#endif
 #ifndef PGH_PB64_G
 #define PGH_PB64_G 1          // groups of 64 rows per wavefront in flight in the finishing pass's epilogue (2: 44 bytes of scratch, 181 against 172 us)
 #endif
@@ -816,21 +819,26 @@ __global__ __launch_bounds__(THREADS, 4) void k_pb64_finish(Pb64View f, Rows64 r
         }
         return s;
     };
+    constexpr int FP = PGH_PB64_FP;
     struct Round {
-        u16x8 r8;
-        f64x2 v[4];
+        u16x8 r8[FP];
+        f64x2 v[FP][4];
     };
-    // group tid + round * THREADS of the bin (pad rows 0xffff beyond the bin's range)
+    // groups tid + (round * FP + q) * THREADS of the bin (pad rows 0xffff beyond the bin's range)
     auto fetch = [&](const int4& bin, int round, Round& R) __attribute__((always_inline)) {
         const bool hub = ((bin.y >> 21) & 1) != 0;
         const int groups = finite || hub ? bin.w : 0;
-        const int g = tid + round * THREADS;
-        const bool ok = g < groups;
-        const uint32_t grp = (uint32_t)(bin.z + g);
-        R.r8 = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(f.drow + (int64_t)grp * 8)) : u16x8{0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            R.v[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(f.tmp + pb64_pair(grp, j))) : f64x2{0.0, 0.0};
+        for (int q = 0; q < FP; ++q) {
+            const int g = tid + (round * FP + q) * THREADS;
+            const bool ok = g < groups;
+            const uint32_t grp = (uint32_t)(bin.z + g);
+            R.r8[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(f.drow + (int64_t)grp * 8))
+                         : u16x8{0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                R.v[q][j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(f.tmp + pb64_pair(grp, j))) : f64x2{0.0, 0.0};
+        }
         asm volatile("; stream round issued");
     };
     auto flush = [&](int where) __attribute__((always_inline)) {
@@ -929,24 +937,28 @@ __global__ __launch_bounds__(THREADS, 4) void k_pb64_finish(Pb64View f, Rows64 r
             for (int i = tid; i < rows; i += THREADS) s_row[i] = 0ULL;
         __syncthreads();
         const int groups = finite || hub ? bin.w : 0;
-        const int nrounds = (groups + THREADS - 1) / THREADS;
+        const int nrounds = (groups + THREADS * FP - 1) / (THREADS * FP);
         if (hub) {
             for (int round = 0; round < nrounds; ++round) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (R.r8[k] == 0) hub_sum += R.v[k >> 1][k & 1];
+                for (int q = 0; q < FP; ++q)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (R.r8[q][k] == 0) hub_sum += R.v[q][k >> 1][k & 1];
                 if (round + 1 < nrounds) fetch(bin, round + 1, R);
             }
         } else {
             for (int round = 0; round < nrounds; ++round) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int r = (int)R.r8[k];
-                    if (r < rows) {
-                        const long long fixed = __double_as_longlong(__builtin_fma(R.v[k >> 1][k & 1], S, kMagic)) - __double_as_longlong(kMagic);
-                        atomicAdd(&s_row[r], (unsigned long long)fixed);
+                for (int q = 0; q < FP; ++q)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = (int)R.r8[q][k];
+                        if (r < rows) {
+                            const long long fixed = __double_as_longlong(__builtin_fma(R.v[q][k >> 1][k & 1], S, kMagic)) - __double_as_longlong(kMagic);
+                            atomicAdd(&s_row[r], (unsigned long long)fixed);
+                        }
                     }
-                }
                 if (round + 1 < nrounds) fetch(bin, round + 1, R);
             }
         }
