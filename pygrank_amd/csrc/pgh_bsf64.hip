@@ -9,15 +9,17 @@
 // layout decisions of the f32 stream (pgh_bsf.hip), with 8-byte operands:
 //   * a second blocked image of the graph (pgh_graph_s::bsf64, built on first use like the multi-seed image): sources
 //     relabelled by descending reference count, dealt to 8 XCD-affine column blocks, entries sorted by (block, row, col), a
-//     flag bit opens every row segment, blocks padded to whole 512-entry wavefront tiles; cold entries STAY in the stream
-//     (an f64 propagation-blocking image would double the cold bytes);
+//     flag bit opens every row segment, blocks padded to whole 512-entry wavefront tiles; rounds 3-5 left the cold entries in
+//     the stream (an 8-byte gather through the XCD's L2 each); round 6 moves them into a propagation-blocking image of their
+//     own (second half of this file), the stream is then hot-only with 2-byte words;
 //   * k_bsf64_partial: one 1024-thread workgroup per CU; the first 20 224 doubles of the block's hot-first slice of the
 //     gather vector fill the LDS (158 KB), the rest of the slice is gathered through the XCD's own L2 (a block's referenced
 //     prefix is ~3.9 MB at scale 23: L2 hit rate 0.88); f64 segmented sums (DPP scans on register pairs), closed segments
 //     leave as 8-byte stores into the compact partial-sum array, pieces that cross tiles as carries;
 //   * k_bsf64_fixup closes the cross-tile segments in a fixed order; k_bsf64_combine folds a row's <= 8 block segments
-//     (SegMeta, as in the f32 layout), applies the recurrence's epilogue in f64 and writes the next gather vector.
-// Deterministic and atomic-free like the f32 path.
+//     (SegMeta, as in the f32 layout), applies the recurrence's epilogue in f64 and writes the next gather vector -- for
+//     images without a cold tail; with one, the fix-ups ride in k_pb64_gather and k_pb64_finish runs the epilogue.
+// Deterministic like the f32 path (the cold image's row sums are integer atomics: order-independent).
 #include "pgh_kernels.h"
 
 #include <cstdlib>
