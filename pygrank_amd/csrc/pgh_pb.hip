@@ -1116,6 +1116,10 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     // Valued graphs stream 4 more bytes per cold entry in phase A: 13 M cold entries measure -3 % (scale 21 upload).
     const int64_t least = (f.val != nullptr ? 16 : 10) * (1LL << 20);
     if (!forced && (in_image < least || in_image * 20 < E || run < 10.0)) return no_image();
+    // the f64 image hands DOUBLES from A to B: its (chunk, bin) runs must be longer to pay -- measured against the cold gathers left in
+    // the stream (profiles/r06/cheb_f64_cold_image.log): scale 22 (132 entries per run) 215 -> 179 us per term, scale 23 (111) 470 -> 381,
+    // scale 24 (133) 1037 -> 939, scale 25 (73) 2314 -> 2373
+    if (!forced && f.pb64 && run < 90.0) return no_image();
     // rows that keep their cold entries in the blocked stream read the DENSE cold slots from there: such a slice cannot number its cold
     // sources compactly (its exchange stays the all-gather); the plan is laid out again for the dense numbering
     if (plan->cold_rank != nullptr && heavy_rows) {
