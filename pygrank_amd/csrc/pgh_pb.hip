@@ -415,8 +415,13 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 4 : PGH_FIN_WPE) void k_pb
             const bool ok = g < groups && !(PGH_PROBE_PB & 8);
             R.r8[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(drow + (int64_t)g * 8))
                          : u16x8{0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff};
+#if PGH_PB_TMP_PLAINLOAD
+            R.lo[q] = ok ? *reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 0, f.tmp_planes)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.hi[q] = ok ? *reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 1, f.tmp_planes)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#else
             R.lo[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 0, f.tmp_planes))) : f32x4{0.f, 0.f, 0.f, 0.f};
             R.hi[q] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp + pb_tmp_quad((uint32_t)(bin.z + g), 1, f.tmp_planes))) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
         }
         // (the per-lane `ok` branches must meet again HERE, in a block of their own: when their join is also the join of the
         // workgroup-uniform branches around the call, every value merged there -- the item descriptors -- counts as divergent and

@@ -11,6 +11,13 @@
 #ifndef PGH_PROBE_PB
 #define PGH_PROBE_PB 0
 #endif
+// cache policy of the values handed from phase A to phase B (diagnostic builds): streaming stores / plain loads
+#ifndef PGH_PB_TMP_NTSTORE
+#define PGH_PB_TMP_NTSTORE 0
+#endif
+#ifndef PGH_PB_TMP_PLAINLOAD
+#define PGH_PB_TMP_PLAINLOAD 0
+#endif
 
 namespace pgh {
 
@@ -112,8 +119,13 @@ __device__ __forceinline__ void pb_stream_piece(const float* __restrict__ s_x, c
                 uint32_t group = r.to[q];
                 if (PGH_PROBE_PB & 64)                       // diagnostic: sequential stores
                     group = (uint32_t)((body_begin + min(rb + (int)threadIdx.x * 8 + q * (kPbThreads * 8), last)) >> 3);
+#if PGH_PB_TMP_NTSTORE
+                __builtin_nontemporal_store(lo, reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 0, f.tmp_planes)));
+                __builtin_nontemporal_store(hi, reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 1, f.tmp_planes)));
+#else
                 *reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 0, f.tmp_planes)) = lo;
                 *reinterpret_cast<f32x4*>(f.tmp + pb_tmp_quad(group, 1, f.tmp_planes)) = hi;
+#endif
             }
         };
         // (Round 5: the compiler joins the two exits of this loop with a full wait at its head -- every second round waits for the previous
