@@ -93,7 +93,11 @@ class GraphFilter(NodeRanking):
         ranks = to_signal(signal, backend.copy(signal.np if warm_start is None else to_signal(signal, warm_start).np))
         M = self.preprocessor(self._prepare_graph(signal.graph, signal, *args, **kwargs))
         self.convergence.start()
-        if graph_dropout == 0 and self._fused_loop(M, signal, ranks, norm if self.preserve_norm else 1.0, *args, **kwargs):
+        try:
+            fused = graph_dropout == 0 and self._fused_loop(M, signal, ranks, norm if self.preserve_norm else 1.0, *args, **kwargs)
+        finally:
+            self._raw_input = None             # (only the f64 routes of _fused_loop look at it; nothing keeps the caller's vector alive)
+        if fused:
             return ranks
         self._host_driven_loop(M, signal, ranks, graph_dropout, args, kwargs)
         if self.preserve_norm:
