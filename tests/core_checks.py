@@ -581,6 +581,22 @@ def check_f64_iterates_for_every_filter(pg):
             assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), (type(ranker).__name__, dtype)
     with pytest.raises(Exception):
         pg.HeatKernel(3, dtype="float16")
+    # a start ON the fixed point (a self-loop and an isolated node: p / |p| solves the walk's equation): the reference's fp64 loop sees
+    # a zero residual at its first check and stops; the f64 walks form p / |p| in f64 themselves (an f32 quotient sums to 1 within 6e-8
+    # only, and a run at 1e-9 started from it needs eight steps to come back)
+    import scipy.sparse as sp
+    loop = pg.AdjacencyWrapper(sp.csr_array(([2.0], ([0], [0])), shape=(2, 2)), directed=True)
+    q = np.array([0.6, 1.3])
+    Ml = orc.normalize(sp.csr_array(([2.0], ([0], [0])), shape=(2, 2)), "col", True)
+    for make, ref in ((lambda: pg.AbsorbingWalks(0.85, error_type=pg.L1, tol=1e-9, max_iters=100, preprocessor=pg.preprocessor(normalization="col")),
+                       lambda: orc.absorbing_walks(Ml, q, alpha=0.85, error_type="l1", tol=1e-9, max_iters=100)),
+                      (lambda: pg.SymmetricAbsorbingRandomWalks(error_type=pg.L1, tol=1e-9, max_iters=100, preprocessor=pg.preprocessor(normalization="col")),
+                       lambda: orc.symmetric_absorbing_walks(Ml, q, error_type="l1", tol=1e-9, max_iters=100))):
+        ranker = make()
+        got = np.asarray(ranker.rank(loop, q.copy()).np, dtype=np.float64)
+        want, want_iters = ref()
+        assert ranker.convergence.iteration == want_iters, (type(ranker).__name__, ranker.convergence.iteration, want_iters)
+        assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), type(ranker).__name__
 
 
 def check_differentiable_propagate(pg):
