@@ -285,6 +285,28 @@ def test_absorbing_walks_and_other_stopping_rules_scale23_vs_oracle(big):
     assert _rel(got, want) <= 1e-6
 
 
+def test_f64_iterates_scale23_vs_oracle(big):
+    """A tolerance below fp32 eps at the full size: the filters choose f64 iterates on the f64 image (round 6: its cold tail in a
+    propagation-blocking image of its own, hot-only 2-byte stream) -- PageRank and AbsorbingWalks at tol = 1e-9 with the iteration counts
+    of the oracle's fp64 loop (the reference's engine: pygrank/core/backend/numpy.py:84-86, convergence.py:101) and 1e-6 of the largest
+    rank; the image is the one the format string names."""
+    from oracle import ref_loops as orc
+    pg = big["pg"]
+    p = big["seeds"](5)
+    pr = pg.PageRank(0.85, error_type=pg.L1, tol=1e-9, max_iters=1000)
+    got = np.asarray(pr.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, want_iters = orc.pagerank(big["M"], p, alpha=0.85, error_type="l1", tol=1e-9, max_iters=1000)
+    assert pr.convergence.iteration == want_iters, (pr.convergence.iteration, want_iters)
+    assert _rel(got, want) <= 1e-6
+    aw = pg.AbsorbingWalks(0.85, error_type=pg.L1, tol=1e-9, max_iters=1000)
+    got = np.asarray(aw.rank(big["adj"], p.copy()).np, dtype=np.float64)
+    want, want_iters = orc.absorbing_walks(big["M"], p, alpha=0.85, error_type="l1", tol=1e-9, max_iters=1000)
+    assert aw.convergence.iteration == want_iters, (aw.convergence.iteration, want_iters)
+    assert _rel(got, want) <= 1e-6
+    fmt = big["g"].format()
+    assert "f64 image" in fmt and "f64 propagation-blocking image" in fmt and "(2 B/entry)" in fmt.split("f64 image")[1], fmt
+
+
 @pytest.mark.parametrize("which", ["pagerank_l1", "pagerank_default_rule", "heat_kernel_taylor", "absorbing_walks_l1", "pagerank_eager_primitives"])
 def test_backend_primitive_route_scale23_vs_oracle(big, which):
     """VERDICT r5 item 2 -- the route north_star names: the filters UNCHANGED, reaching the engine one backend primitive at a time
