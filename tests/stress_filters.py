@@ -180,17 +180,24 @@ def main():
             for j in range(b):
                 feats[rng.integers(0, n, 3), j] = 1.0 + j
             ranker = pg.PageRank(0.85, error_type=pg.L1, tol=1e-6, max_iters=300)
-            oracle_runs, oracle_fails = [], False
+            oracle_runs, oracle_fails, late = [], False, False
             for j in range(b):
                 try:
                     oracle_runs.append(orc.pagerank(M, feats[:, j], alpha=0.85, error_type="l1", tol=1e-6, max_iters=300, eps=EPS32))
                 except Exception:
-                    oracle_fails = True
-                    oracle_runs.append(None)
+                    # a column that crosses the tolerance within f32 rounding of it around the limit (seed 9084 #4277: the engine stops inside
+                    # the 300 steps, the oracle just outside): the oracle gets the slack the comparison below allows anyway, as in the
+                    # single-vector legs; a column that does not converge THERE must raise in the engine too
+                    try:
+                        oracle_runs.append(orc.pagerank(M, feats[:, j], alpha=0.85, error_type="l1", tol=1e-6, max_iters=300 + 300 // 25, eps=EPS32))
+                        late = True
+                    except Exception:
+                        oracle_fails = True
+                        oracle_runs.append(None)
             try:
                 out = np.asarray(ranker.propagate(adj, pg.to_primitive(feats)))
             except Exception as exc:
-                if oracle_fails:                                   # a column that does not converge raises in both
+                if oracle_fails or late:                           # a column that does not converge (or only just outside the limit) raises
                     done += 1
                     continue
                 print("EXCEPTION propagate", desc, exc, flush=True)
