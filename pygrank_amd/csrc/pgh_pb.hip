@@ -1125,8 +1125,9 @@ int pb_plan(BsfFormat& f, const uint64_t* keys, int64_t E, const int* live, int 
     if (!forced && (in_image < least || in_image * 20 < E || run < 10.0)) return no_image();
     // the f64 image hands DOUBLES from A to B: its (chunk, bin) runs must be longer to pay -- measured against the cold gathers left in
     // the stream (profiles/r06/cheb_f64_cold_image.log): scale 22 (132 entries per run) 215 -> 179 us per term, scale 23 (111) 470 -> 381,
-    // scale 24 (133) 1037 -> 939, scale 25 (73) 2314 -> 2373
-    if (!forced && f.pb64 && run < 90.0) return no_image();
+    // scale 24 (133) 1037 -> 939, scale 25 (73 with 8192-row bins) 2314 -> 2373, (134 with 16 384-row bins) -> 1961-2243, scale 26 (81 with
+    // 16 384-row bins) 5346 -> 4850
+    if (!forced && f.pb64 && run < 60.0) return no_image();
     // rows that keep their cold entries in the blocked stream read the DENSE cold slots from there: such a slice cannot number its cold
     // sources compactly (its exchange stays the all-gather); the plan is laid out again for the dense numbering
     if (plan->cold_rank != nullptr && heavy_rows) {
