@@ -240,12 +240,33 @@ __global__ void k_bsf_narrow(const uint32_t* __restrict__ colf, int num_tiles, u
 }
 
 // 1 + highest referenced slot of every block, over all entries of the sorted stream (sentinels point at slot 0)
+// (round 6: the keys are sorted by block, so a thread keeps the running maximum of the block it is in and a wavefront whose lanes end in
+// one block reports ONE value -- the per-entry test against live[b] plus its atomics took 5.9 ms for a 1-GB read at scale 23)
 __global__ void k_bsf_live(const uint64_t* __restrict__ keys, int64_t E, int blk, int32_t* __restrict__ live) {
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    int cur_b = -1, cur = 0;
+    // (a wavefront owns a CONTIGUOUS stretch of the sorted keys: it meets a block boundary only when its stretch holds one -- with a
+    // grid-stride loop every thread crosses every boundary and flushes there: 83 ms)
+    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6), wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t len = ((E + waves - 1) / waves + 63) & ~(int64_t)63;
+    const int64_t e_end = min(E, (wave + 1) * len);
+    for (int64_t e = wave * len + (threadIdx.x & 63); e < e_end; e += 64) {
         const uint64_t key = keys[e];
         const int b = (int)(key >> 58);
         const int loc = (int)((int64_t)(key & kLow29) - (int64_t)b * blk);
-        if (loc + 1 > live[b]) atomicMax(&live[b], loc + 1);
+        if (b != cur_b) {
+            if (cur_b >= 0) atomicMax(&live[cur_b], cur);
+            cur_b = b;
+            cur = 0;
+        }
+        cur = max(cur, loc + 1);
+    }
+    const int first_b = __shfl(cur_b, 0, 64);
+    if (__all(cur_b == first_b)) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cur = max(cur, __shfl_xor(cur, d, 64));
+        if ((threadIdx.x & 63) == 0 && cur_b >= 0) atomicMax(&live[cur_b], cur);
+    } else if (cur_b >= 0) {
+        atomicMax(&live[cur_b], cur);
     }
 }
 

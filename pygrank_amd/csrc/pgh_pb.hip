@@ -253,11 +253,23 @@ __global__ void k_pb_keys(const uint64_t* __restrict__ keys, int64_t count, PbLa
 }
 
 // entries per cell, [chunk][bin]
+// (the keys are sorted by (chunk, bin): a wavefront adds every run of one cell it holds with ONE atomic from the run's first lane)
 __global__ void k_pb_cell_counts(const uint64_t* __restrict__ keys, int64_t count, int num_bins, uint32_t* __restrict__ counts) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = keys[i];
-        const uint64_t c = key >> 45, w = (key >> 30) & 0x7fffu;
-        atomicAdd(&counts[c * (uint64_t)num_bins + w], 1u);
+    const int lane = threadIdx.x & 63;
+    for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x; i0 < count; i0 += (int64_t)gridDim.x * blockDim.x) {     // (uniform per workgroup)
+        const int64_t i = i0 + threadIdx.x;
+        const bool in = i < count;
+        const uint64_t cell = in ? keys[i] >> 30 : ~0ULL;                                   // chunk << 15 | bin
+        const uint64_t prev = (uint64_t)__shfl_up((long long)cell, 1, 64);
+        const bool head = lane == 0 || cell != prev;
+        const unsigned long long heads = __ballot(head), valid = __ballot(in);
+        if (head && in) {
+            const unsigned long long above = lane == 63 ? 0ULL : heads & ~((2ULL << lane) - 1ULL);
+            const int next = above != 0ULL ? __builtin_ctzll(above) : 64;
+            const unsigned long long upto = next == 64 ? ~0ULL : (1ULL << next) - 1ULL;
+            const unsigned int n = (unsigned int)__popcll(valid & upto & ~((1ULL << lane) - 1ULL));
+            atomicAdd(&counts[(cell >> 15) * (uint64_t)num_bins + (cell & 0x7fffu)], n);
+        }
     }
 }
 
