@@ -725,6 +725,19 @@ def lazy_residual(kind, a, b):
     return value / len(a) if kind == L.ERR_MABS else value
 
 
+def _all_ones(data):
+    """Are all weights 1 (the graph then travels as structure only)?  Chunk by chunk with an early exit -- a weighted graph is found out
+    in its first 4 M entries -- and as min / max: `np.all(data == 1.0)` materialises a boolean per entry (6x the time on 131 M weights)."""
+    if len(data) == 0:
+        return False
+    step = 1 << 22
+    for lo in range(0, len(data), step):
+        part = data[lo:lo + step]
+        if part.min() != 1.0 or part.max() != 1.0:
+            return False
+    return True
+
+
 class DeviceMatrix:
     """Row-major f32 [n, b] slab in HBM: the multi-seed batch layout (a gathered row is b*4 contiguous bytes)."""
 
@@ -912,7 +925,7 @@ class DeviceGraph:
         indptr = np.ascontiguousarray(W.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(W.indices, dtype=np.int32)
         data = np.ascontiguousarray(W.data, dtype=np.float64)
-        unit = len(data) > 0 and bool(np.all(data == 1.0))
+        unit = _all_ones(data)
         h = L.c_graph()
         if renormalize == 0 and kind != L.NORM_LAPLACIAN:
             L.check(L.lib().pgh_graph_from_adjacency(W.shape[0], W.shape[1], len(data), _ptr(indptr), _ptr(indices),
